@@ -1,0 +1,850 @@
+/*
+ * rnde_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).  See rnde_oracle.h.
+ *
+ * PARITY UNPINNED versus the Julia reference (no Julia, no golden vectors; see header).
+ *
+ * What each block follows:
+ *   dynamics f            reference experiments/mnist_node.jl:41-54, src/models/basic.jl:16-23,
+ *                         experiments/latent_ode.jl:113-124, src/models/neural_ode.jl:55 (dudt_)
+ *   parameter layout      Flux.destructure, reference src/models/neural_ode.jl:12
+ *   initial dt            OrdinaryDiffEq 5.50.0 src/initdt.jl (out-of-place), SURVEY.md B.1
+ *   Tsit5 step + EEst     OrdinaryDiffEq 5.50.0 src/perform_step/low_order_rk_perform_step.jl,
+ *                         DiffEqBase 6.53.4 src/calculate_residuals.jl, SURVEY.md A.1-A.2, B.2-B.3
+ *   PI controller / loop  OrdinaryDiffEq 5.50.0 src/integrators/integrator_utils.jl, SURVEY.md B.4
+ *   saving callback       DiffEqCallbacks 2.16.0 src/saving.jl via reference neural_ode.jl:126-127, SURVEY.md B.5
+ *   saveat dense output   OrdinaryDiffEq src/dense/low_order_rk_interpolants.jl, SURVEY.md A.3, B.6
+ *   reverse pass          what Tracker.gradient (reference experiments/mnist_node.jl:229) computes for
+ *                         sensealg=SensitivityADPassThrough (neural_ode.jl:134): the exact derivative of
+ *                         the discrete program, SURVEY.md B.8.
+ */
+#include "rnde_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+
+#ifdef RNDE_F64
+#define R(x) x
+#define rsqrt_ sqrt
+#define rtanh tanh
+#define rfabs fabs
+#define rpow pow
+#define rlog10 log10
+#else
+#define R(x) x##f
+#define rsqrt_ sqrtf
+#define rtanh tanhf
+#define rfabs fabsf
+#define rpow powf
+#define rlog10 log10f
+#endif
+
+/* ---------------- Tsit5 tableau ---------------- */
+static const double TS_C[7] = {0.0, 0.161, 0.327, 0.9, 0.9800255409045097, 1.0, 1.0};
+static const double TS_A[7][7] = {
+    {0},
+    {0.161},
+    {-0.008480655492356989, 0.335480655492357},
+    {2.8971530571054935, -6.359448489975075, 4.3622954328695815},
+    {5.325864828439257, -11.748883564062828, 7.4955393428898365, -0.09249506636175525},
+    {5.86145544294642, -12.92096931784711, 8.159367898576159, -0.071584973281401, -0.028269050394068383},
+    {0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081, 2.324710524099774, 0.0}};
+static const double TS_BT[7] = {-0.00178001105222577714, -0.0008164344596567469, 0.007880878010261995,
+                                -0.1447110071732629,     0.5823571654525552,     -0.45808210592918697,
+                                0.015151515151515152};
+/* controller constants, order 5 */
+#define BETA1 ((real)(7.0 / 50.0))
+#define BETA2 ((real)(2.0 / 25.0))
+#define GAMMA ((real)0.9)
+#define QMIN ((real)0.2)
+#define QMAX ((real)10.0)
+#define QOLDINIT ((real)1e-4)
+/* alg_stability_size(Tsit5()) recalled as 3.5068 (reference mnist_node.jl:73) */
+#define STAB_SIZE ((real)3.5068)
+
+void orc_tableau(double* a, double* c, double* bt) {
+    for (int s = 0; s < 7; ++s) {
+        c[s] = TS_C[s];
+        bt[s] = TS_BT[s];
+        for (int j = 0; j < 7; ++j) a[s * 7 + j] = TS_A[s][j];
+    }
+}
+/* dense output weights b_i(theta), SURVEY.md A.3 */
+void orc_dense_weights(double th, double* b) {
+    double t2 = th * th;
+    b[0] = -1.0530884977290216 * th * (th - 1.3299890189751412) * (t2 - 1.4364028541716351 * th + 0.7139816917074209);
+    b[1] = 0.1017 * t2 * (t2 - 2.1966568338249754 * th + 1.2949852507374631);
+    b[2] = 2.490627285651252793 * t2 * (t2 - 2.38535645472061657 * th + 1.57803468208092486);
+    b[3] = -16.54810288924490272 * (th - 1.21712927295533244) * (th - 0.61620406037800089) * t2;
+    b[4] = 47.37952196281928122 * (th - 1.203071208372362603) * (th - 0.658047292653547382) * t2;
+    b[5] = -34.87065786149660974 * (th - 1.2) * (th - 0.666666666666666667) * t2;
+    b[6] = 2.5 * (th - 1.0) * (th - 0.6) * t2;
+}
+/* d b_i / d theta by central difference of the polynomial in double (exact to ~1e-10; used only for the
+ * theta cotangent of saveat points, a second-order effect) */
+static void dense_weights_deriv(double th, double* db) {
+    double e = 1e-6, bp[7], bm[7];
+    orc_dense_weights(th + e, bp);
+    orc_dense_weights(th - e, bm);
+    for (int i = 0; i < 7; ++i) db[i] = (bp[i] - bm[i]) / (2 * e);
+}
+
+/* ---------------- dynamics ---------------- */
+int orc_param_count(const orc_arch* a) {
+    int n = 0;
+    for (int l = 0; l < a->n_layers; ++l) n += (a->dims[l] + (a->time_dep ? 1 : 0)) * a->dims[l + 1] + a->dims[l + 1];
+    return n;
+}
+static int act_rows_total(const orc_arch* a) { /* rows of stored activations per f eval: pre_act out + every layer out */
+    int n = a->pre_act ? a->dims[0] : 0;
+    for (int l = 0; l < a->n_layers; ++l) n += a->dims[l + 1];
+    return n;
+}
+
+/* forward f. acts (optional) receives [pre_act output (if any); y_1; ...; y_L], each (rows x B) col-major
+ * stacked as separate blocks: block offset = rows_before * B. out = y_L. */
+static void f_forward(const orc_arch* a, const real* p, const real* u, int B, real t, real* out, real* acts) {
+    int maxd = 0;
+    for (int l = 0; l <= a->n_layers; ++l)
+        if (a->dims[l] > maxd) maxd = a->dims[l];
+#pragma omp parallel
+    {
+        real* xa = (real*)malloc(sizeof(real) * maxd);
+        real* xb = (real*)malloc(sizeof(real) * maxd);
+#pragma omp for schedule(static)
+        for (int c = 0; c < B; ++c) {
+            const real* x = u + (size_t)c * a->dims[0];
+            int off_rows = 0;
+            if (a->pre_act) {
+                for (int i = 0; i < a->dims[0]; ++i) xa[i] = rtanh(x[i]);
+                if (acts) memcpy(acts + (size_t)off_rows * B + (size_t)c * a->dims[0], xa, sizeof(real) * a->dims[0]);
+                off_rows += a->dims[0];
+                x = xa;
+            }
+            const real* pl = p;
+            real* cur = xb;
+            for (int l = 0; l < a->n_layers; ++l) {
+                int in = a->dims[l], o = a->dims[l + 1], ine = in + (a->time_dep ? 1 : 0);
+                const real* W = pl;
+                const real* b = pl + (size_t)ine * o;
+                /* k-ordered chain: 0 + sum_i W[:,i] x_i (+ W[:,in] t) + b  -- same association order as the
+                 * f32 MFMA chain of the HIP kernel (bias and time folded in as trailing K columns). */
+                for (int r = 0; r < o; ++r) cur[r] = 0;
+                for (int i = 0; i < in; ++i) {
+                    real xi = x[i];
+                    const real* Wi = W + (size_t)i * o;
+                    for (int r = 0; r < o; ++r) cur[r] += Wi[r] * xi;
+                }
+                if (a->time_dep) {
+                    const real* Wt = W + (size_t)in * o;
+                    for (int r = 0; r < o; ++r) cur[r] += Wt[r] * t;
+                }
+                for (int r = 0; r < o; ++r) cur[r] += b[r];
+                if (a->act[l] == 1)
+                    for (int r = 0; r < o; ++r) cur[r] = rtanh(cur[r]);
+                if (acts) memcpy(acts + (size_t)off_rows * B + (size_t)c * o, cur, sizeof(real) * o);
+                off_rows += o;
+                pl += (size_t)ine * o + o;
+                x = cur;
+                cur = (cur == xb) ? xa : xb;
+            }
+            memcpy(out + (size_t)c * a->dims[a->n_layers], x, sizeof(real) * a->dims[a->n_layers]);
+        }
+        free(xa);
+        free(xb);
+    }
+}
+void orc_f_eval(const orc_arch* a, const real* p, const real* u, int B, real t, real* out) {
+    f_forward(a, p, u, B, t, out, NULL);
+}
+
+/* reverse of f at input u (stored), activations acts (stored):
+ * given kbar (D x B): ubar_out (D x B, overwritten), pbar += , returns tbar contribution. */
+static real f_backward(const orc_arch* a, const real* p, const real* u, const real* acts, int B, real t,
+                       const real* kbar, real* ubar_out, real* pbar) {
+    int L = a->n_layers;
+    int maxd = 0;
+    for (int l = 0; l <= L; ++l)
+        if (a->dims[l] > maxd) maxd = a->dims[l];
+    /* per-layer offsets */
+    size_t poff[ORC_MAX_LAYERS];
+    int aoff[ORC_MAX_LAYERS + 1]; /* row offsets into acts: aoff[l] = offset of y_l (l=1..L); input x_0 separately */
+    {
+        size_t po = 0;
+        int ro = a->pre_act ? a->dims[0] : 0;
+        for (int l = 0; l < L; ++l) {
+            poff[l] = po;
+            po += (size_t)(a->dims[l] + (a->time_dep ? 1 : 0)) * a->dims[l + 1] + a->dims[l + 1];
+            aoff[l + 1] = ro;
+            ro += a->dims[l + 1];
+        }
+    }
+    /* zbar per layer for all columns: compute column by column, keep zbar_l (o x B) for the weight gradient */
+    real* zb_all[ORC_MAX_LAYERS];
+    for (int l = 0; l < L; ++l) zb_all[l] = (real*)malloc(sizeof(real) * (size_t)a->dims[l + 1] * B);
+    double tbar_acc = 0;
+#pragma omp parallel
+    {
+        real* ga = (real*)malloc(sizeof(real) * maxd);
+        real* gb = (real*)malloc(sizeof(real) * maxd);
+        double tloc = 0;
+#pragma omp for schedule(static)
+        for (int c = 0; c < B; ++c) {
+            const real* g = kbar + (size_t)c * a->dims[L];
+            real* nxt = ga;
+            for (int l = L - 1; l >= 0; --l) {
+                int in = a->dims[l], o = a->dims[l + 1], ine = in + (a->time_dep ? 1 : 0);
+                const real* W = p + poff[l];
+                const real* y = acts + (size_t)aoff[l + 1] * B + (size_t)c * o;
+                real* zb = zb_all[l] + (size_t)c * o;
+                for (int r = 0; r < o; ++r) zb[r] = a->act[l] == 1 ? g[r] * (1 - y[r] * y[r]) : g[r];
+                for (int i = 0; i < in; ++i) {
+                    const real* Wi = W + (size_t)i * o;
+                    real s = 0;
+                    for (int r = 0; r < o; ++r) s += Wi[r] * zb[r];
+                    nxt[i] = s;
+                }
+                if (a->time_dep) {
+                    const real* Wt = W + (size_t)in * o;
+                    real s = 0;
+                    for (int r = 0; r < o; ++r) s += Wt[r] * zb[r];
+                    tloc += (double)s;
+                }
+                (void)ine;
+                g = nxt;
+                nxt = (nxt == ga) ? gb : ga;
+            }
+            real* uo = ubar_out + (size_t)c * a->dims[0];
+            if (a->pre_act) {
+                const real* x0 = acts + (size_t)c * a->dims[0];
+                for (int i = 0; i < a->dims[0]; ++i) uo[i] = g[i] * (1 - x0[i] * x0[i]);
+            } else {
+                for (int i = 0; i < a->dims[0]; ++i) uo[i] = g[i];
+            }
+        }
+#pragma omp atomic
+        tbar_acc += tloc;
+        free(ga);
+        free(gb);
+    }
+    /* weight gradients: Wbar[:,i] += sum_c zbar[:,c] * x_l[i,c] ; bbar += rowsum(zbar) */
+    for (int l = 0; l < L; ++l) {
+        int in = a->dims[l], o = a->dims[l + 1], ine = in + (a->time_dep ? 1 : 0);
+        real* Wb = pbar + poff[l];
+        real* bb = Wb + (size_t)ine * o;
+        const real* zb = zb_all[l];
+        const real* xin; /* input of layer l: (in x B) */
+        if (l == 0)
+            xin = a->pre_act ? acts : u;
+        else
+            xin = acts + (size_t)aoff[l] * B;
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < ine + 1; ++i) {
+            if (i < in) {
+                real* Wbi = Wb + (size_t)i * o;
+                for (int c = 0; c < B; ++c) {
+                    real xi = xin[(size_t)c * in + i];
+                    const real* z = zb + (size_t)c * o;
+                    for (int r = 0; r < o; ++r) Wbi[r] += z[r] * xi;
+                }
+            } else if (i == in && a->time_dep) {
+                real* Wbi = Wb + (size_t)in * o;
+                for (int c = 0; c < B; ++c) {
+                    const real* z = zb + (size_t)c * o;
+                    for (int r = 0; r < o; ++r) Wbi[r] += z[r] * t;
+                }
+            } else if (i == ine) {
+                for (int c = 0; c < B; ++c) {
+                    const real* z = zb + (size_t)c * o;
+                    for (int r = 0; r < o; ++r) bb[r] += z[r];
+                }
+            }
+        }
+    }
+    for (int l = 0; l < L; ++l) free(zb_all[l]);
+    return (real)tbar_acc;
+}
+
+/* ---------------- helpers ---------------- */
+static real rms_ratio(const real* a, const real* sk, size_t n) { /* sqrt(mean((a/sk)^2)) */
+    double s = 0;
+#ifdef RNDE_F64
+    for (size_t i = 0; i < n; ++i) { double v = a[i] / sk[i]; s += v * v; }
+    return sqrt(s / (double)n);
+#else
+    /* fp32 values, but the sum itself is carried in double so the oracle's norm does not depend on
+     * summation order (the HIP kernel uses a fixed-order tree of fp32 partials + a double final sum). */
+    for (size_t i = 0; i < n; ++i) { float v = a[i] / sk[i]; s += (double)(v * v); }
+    return (float)sqrt(s / (double)n);
+#endif
+}
+
+/* ---------------- tape ---------------- */
+typedef struct {
+    real t, dt, dtp_in;      /* dt actually used, dt proposed on entry */
+    int clamped;             /* dt = t1 - t */
+    real eest, q11, q, qold_in;
+    int accepted, q_clamped, eest_zero, dtmax_clamped;
+    real rej_m;              /* reject: m = min(1/qmin, q11/gamma) */
+    int rej_m_is_q11;
+    real eigen_est;
+    int sv_index;            /* index in saveval of this step's callback value, -1 if none */
+    real* uprev;             /* pointer (borrowed): u0 or previous accepted unew */
+    real* k[7];              /* k[0] borrowed (k1), k[1..6] owned */
+    real* unew;              /* owned */
+    real* acts[7];           /* activations of stages 2..7 (index 1..6), owned */
+    /* saveat points filled from this step */
+    int nsv_pts;
+    int sv_first;            /* first saveat index filled */
+} attempt_rec;
+
+typedef struct {
+    orc_config cfg;
+    int D, P, B, arows;
+    /* tape */
+    int n_att;
+    attempt_rec* att;
+    real *u0, *f0, *acts0; /* f(u0,t0) and its activations */
+    real *u1, *f1, *acts1; /* initdt second eval */
+    real t0, t1, dt0_small_or_clamped_flag;
+    /* initdt record */
+    real id_d0, id_d1, id_d2, id_dt0, id_dt1, id_dt;
+    int id_dt0_const, id_dt0_clamped, id_sel; /* sel: 0 -> 100 dt0, 1 -> dt1, 2 -> dtmax */
+    int id_dt1_const, id_max_is_d2;
+    real* p;
+    int nsave;
+    real* saveat;
+    int save_t0; /* saveat[0]==t0 saved from u0 */
+    int n_saveval;
+    int have_tape;
+} orc_handle;
+
+void* orc_create(const orc_config* cfg) {
+    orc_handle* h = (orc_handle*)calloc(1, sizeof(orc_handle));
+    h->cfg = *cfg;
+    h->D = cfg->arch.dims[0];
+    h->P = orc_param_count(&cfg->arch);
+    h->arows = act_rows_total(&cfg->arch);
+    h->att = (attempt_rec*)calloc((size_t)cfg->max_attempts + 1, sizeof(attempt_rec));
+    return h;
+}
+static void free_tape(orc_handle* h) {
+    for (int n = 0; n < h->n_att; ++n) {
+        attempt_rec* a = &h->att[n];
+        for (int s = 1; s < 7; ++s) { free(a->k[s]); free(a->acts[s]); a->k[s] = a->acts[s] = NULL; }
+        free(a->unew);
+        a->unew = NULL;
+    }
+    h->n_att = 0;
+    free(h->u0); free(h->f0); free(h->acts0); free(h->u1); free(h->f1); free(h->acts1); free(h->p); free(h->saveat);
+    h->u0 = h->f0 = h->acts0 = h->u1 = h->f1 = h->acts1 = h->p = h->saveat = NULL;
+    h->have_tape = 0;
+}
+void orc_destroy(void* hh) {
+    orc_handle* h = (orc_handle*)hh;
+    free_tape(h);
+    free(h->att);
+    free(h);
+}
+static real* ralloc(size_t n) { return (real*)malloc(sizeof(real) * n); }
+
+/* ---------------- one attempt (shared by forward and the kernel-parity entry) ---------------- */
+static void attempt_stages(const orc_config* cfg, const real* p, const real* uprev, real* const k[7], real* unew,
+                           real* const acts[7], int B, real t, real dt, real* eest_out, real* eigen_out) {
+    const orc_arch* a = &cfg->arch;
+    int D = a->dims[0];
+    size_t N = (size_t)D * B;
+    real* g = ralloc(N);
+    real* g6 = ralloc(N);
+    for (int s = 1; s < 7; ++s) { /* stage index s (0-based): computes k[s] = f(g_{s+1}) */
+        real as[6];
+        for (int j = 0; j < s; ++j) as[j] = (real)TS_A[s][j];
+#pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < N; ++i) {
+            real acc = 0;
+            for (int j = 0; j < s; ++j) acc += as[j] * k[j][i];
+            g[i] = uprev[i] + dt * acc;
+        }
+        if (s == 5) memcpy(g6, g, sizeof(real) * N);
+        if (s == 6) memcpy(unew, g, sizeof(real) * N);
+        f_forward(a, p, g, B, t + (real)TS_C[s] * dt, k[s], acts ? acts[s] : NULL);
+    }
+    /* error estimate */
+    real bt[7];
+    for (int j = 0; j < 7; ++j) bt[j] = (real)TS_BT[j];
+    double ssum = 0;
+#pragma omp parallel for schedule(static) reduction(+ : ssum)
+    for (size_t i = 0; i < N; ++i) {
+        real acc = 0;
+        for (int j = 0; j < 7; ++j) acc += bt[j] * k[j][i];
+        real ut = dt * acc;
+        real au = rfabs(uprev[i]), an = rfabs(unew[i]);
+        real sk = cfg->abstol + (au > an ? au : an) * cfg->reltol;
+        real r = ut / sk;
+        ssum += (double)(r * r);
+    }
+    *eest_out = (real)sqrt(ssum / (double)N);
+    if (eigen_out) { /* eigen_est = ||k7-k6|| / ||u - g6||   */
+        double n1 = 0, n2 = 0;
+        for (size_t i = 0; i < N; ++i) {
+            double d1 = (double)k[6][i] - (double)k[5][i], d2 = (double)unew[i] - (double)g6[i];
+            n1 += d1 * d1;
+            n2 += d2 * d2;
+        }
+        *eigen_out = (real)(sqrt(n1) / sqrt(n2));
+    }
+    free(g);
+    free(g6);
+}
+
+void orc_tsit5_attempt(const orc_config* cfg, const real* p, const real* uprev, const real* k1, int B, real t,
+                       real dt, real* kout, real* unew, real* eest, real* eigen_est) {
+    size_t N = (size_t)cfg->arch.dims[0] * B;
+    real* k[7];
+    k[0] = (real*)k1;
+    for (int s = 1; s < 7; ++s) k[s] = kout + (size_t)(s - 1) * N;
+    attempt_stages(cfg, p, uprev, k, unew, NULL, B, t, dt, eest, eigen_est);
+}
+
+/* ---------------- initial dt ---------------- */
+static real initdt_impl(orc_handle* h, const orc_config* cfg, const real* p, const real* u0, int B, real t0, real t1,
+                        real* f0, real* acts0, real* u1, real* f1, real* acts1) {
+    const orc_arch* a = &cfg->arch;
+    size_t N = (size_t)a->dims[0] * B;
+    real dtmax = t1 - t0;
+    real* sk = ralloc(N);
+    for (size_t i = 0; i < N; ++i) sk[i] = cfg->abstol + rfabs(u0[i]) * cfg->reltol;
+    real d0 = rms_ratio(u0, sk, N);
+    f_forward(a, p, u0, B, t0, f0, acts0);
+    real d1 = rms_ratio(f0, sk, N);
+    real dt0;
+    int c0 = 0, cl = 0;
+    if (d0 < R(1e-5) || d1 < R(1e-5)) { dt0 = R(1e-6); c0 = 1; }
+    else dt0 = (d0 / d1) / R(100.0);
+    if (dtmax < dt0) { dt0 = dtmax; cl = 1; }
+    for (size_t i = 0; i < N; ++i) u1[i] = u0[i] + dt0 * f0[i];
+    f_forward(a, p, u1, B, t0 + dt0, f1, acts1);
+    real* df = ralloc(N);
+    for (size_t i = 0; i < N; ++i) df[i] = f1[i] - f0[i];
+    real d2 = rms_ratio(df, sk, N) / dt0;
+    free(df);
+    free(sk);
+    real m = d1 > d2 ? d1 : d2;
+    real dt1;
+    int c1 = 0;
+    if (m <= R(1e-15)) { real a1 = R(1e-6), a2 = dt0 * R(1e-3); dt1 = a1 > a2 ? a1 : a2; c1 = 1; }
+    else dt1 = (real)pow(10.0, (double)(-(R(2.0) + rlog10(m)) / R(5.0))); /* Julia: 10.0^(...) is Float64, then convert */
+    real dt = R(100.0) * dt0;
+    int sel = 0;
+    if (dt1 < dt) { dt = dt1; sel = 1; }
+    if (dtmax < dt) { dt = dtmax; sel = 2; }
+    if (h) {
+        h->id_d0 = d0; h->id_d1 = d1; h->id_d2 = d2; h->id_dt0 = dt0; h->id_dt1 = dt1; h->id_dt = dt;
+        h->id_dt0_const = c0; h->id_dt0_clamped = cl; h->id_sel = sel; h->id_dt1_const = c1; h->id_max_is_d2 = (d2 >= d1);
+    }
+    return dt;
+}
+real orc_initdt(const orc_config* cfg, const real* p, const real* u0, int B, real t0, real t1, real* f0_out) {
+    size_t N = (size_t)cfg->arch.dims[0] * B;
+    real *f0 = ralloc(N), *u1 = ralloc(N), *f1 = ralloc(N);
+    real dt = initdt_impl(NULL, cfg, p, u0, B, t0, t1, f0, NULL, u1, f1, NULL);
+    if (f0_out) memcpy(f0_out, f0, sizeof(real) * N);
+    free(f0); free(u1); free(f1);
+    return dt;
+}
+
+/* callback value (reference mnist_node.jl:67, :74-79, :88-97) */
+static real cb_value(const orc_config* cfg, real eest, real dt, real eigen) {
+    switch (cfg->reg_kind) {
+        case 1: return eest * dt;
+        case 2: { real s = rfabs(eigen); return (s == 0 || isnan(s)) ? 0 : s / STAB_SIZE; }
+        case 3: {
+            real e = eest * dt;
+            real v = (e == 0 || isnan(e)) ? 0 : e;
+            real s = eigen;
+            v += R(0.1) * ((s == 0 || isnan(s)) ? 0 : s / STAB_SIZE);
+            return v;
+        }
+        default: return 0;
+    }
+}
+
+/* ---------------- forward solve ---------------- */
+int orc_forward(void* hh, const real* x, const real* p, int B, real t0, real t1, const real* saveat, int nsave,
+                real* u_out, long* nfe, real* saveval, int* nsaveval, real* steps_log, int* nattempts) {
+    orc_handle* h = (orc_handle*)hh;
+    const orc_config* cfg = &h->cfg;
+    const orc_arch* a = &cfg->arch;
+    free_tape(h);
+    int D = h->D;
+    size_t N = (size_t)D * B;
+    h->B = B; h->t0 = t0; h->t1 = t1;
+    h->p = ralloc(h->P); memcpy(h->p, p, sizeof(real) * h->P);
+    h->u0 = ralloc(N); memcpy(h->u0, x, sizeof(real) * N);
+    h->f0 = ralloc(N); h->u1 = ralloc(N); h->f1 = ralloc(N);
+    h->acts0 = ralloc((size_t)h->arows * B); h->acts1 = ralloc((size_t)h->arows * B);
+    h->nsave = nsave;
+    if (nsave) { h->saveat = ralloc(nsave); memcpy(h->saveat, saveat, sizeof(real) * nsave); }
+    long nf = 0;
+    real dtp = initdt_impl(h, cfg, p, h->u0, B, t0, t1, h->f0, h->acts0, h->u1, h->f1, h->acts1);
+    nf += 2;
+    /* fsalfirst = f(u0,t0): numerically identical to f0, counted as one more evaluation */
+    nf += 1;
+    real t = t0, qold = QOLDINIT, dtmax = t1 - t0;
+    int nsv = 0, ret = 0, n = 0, next_save = 0;
+    real dtmin = (real)(sizeof(real) == 4 ? 1.1920929e-7 : 2.220446049250313e-16);
+    if (cfg->reg_kind && cfg->cb_save_start) {
+        /* callback initialisation fires before the initial dt is chosen: EEst = 1, dt = 0 -> func = 0 for the
+         * error estimate; eigen_est initial value 1 for the stiffness variant. */
+        saveval[nsv++] = cb_value(cfg, 1, 0, 1);
+    }
+    h->save_t0 = 0;
+    if (nsave && saveat[0] == t0) { /* save_start */
+        for (int c = 0; c < B; ++c) memcpy(u_out + ((size_t)c * nsave + 0) * D, x + (size_t)c * D, sizeof(real) * D);
+        next_save = 1;
+        h->save_t0 = 1;
+    }
+    real* uprev = h->u0;
+    real* k1 = h->f0;
+    while (t < t1) {
+        if (n >= cfg->max_attempts) { ret = 1; break; }
+        attempt_rec* r = &h->att[n];
+        memset(r, 0, sizeof(*r));
+        r->sv_index = -1;
+        r->t = t; r->dtp_in = dtp; r->qold_in = qold;
+        real dt = dtp;
+        if (t1 - t < dt) { dt = t1 - t; r->clamped = 1; }
+        r->dt = dt;
+        if (!(dt > dtmin) || isnan(dt)) { ret = isnan(dt) ? 3 : 2; break; }
+        r->uprev = uprev;
+        r->k[0] = k1;
+        for (int s = 1; s < 7; ++s) { r->k[s] = ralloc(N); r->acts[s] = ralloc((size_t)h->arows * B); }
+        r->unew = ralloc(N);
+        real eest, eig = 0;
+        attempt_stages(cfg, p, uprev, r->k, r->unew, r->acts, B, t, dt, &eest, cfg->reg_kind >= 2 ? &eig : NULL);
+        nf += 6;
+        h->n_att = ++n;
+        r->eest = eest; r->eigen_est = eig;
+        if (!(eest == eest) || isinf(eest)) { ret = 3; break; }
+        /* PI controller */
+        real q, q11 = 0;
+        if (eest == 0) { q = 1 / QMAX; r->eest_zero = 1; r->q_clamped = 1; }
+        else {
+            q11 = rpow(eest, BETA1);
+            q = q11 / rpow(qold, BETA2);
+            real qg = q / GAMMA;
+            real lo = 1 / QMAX, hi = 1 / QMIN;
+            if (qg < lo) { q = lo; r->q_clamped = 1; }
+            else if (qg > hi) { q = hi; r->q_clamped = 1; }
+            else q = qg;
+        }
+        r->q11 = q11; r->q = q;
+        r->accepted = (eest <= 1);
+        if (steps_log) { steps_log[4 * (n - 1) + 0] = t; steps_log[4 * (n - 1) + 1] = dt; steps_log[4 * (n - 1) + 2] = eest; steps_log[4 * (n - 1) + 3] = (real)r->accepted; }
+        if (r->accepted) {
+            qold = eest > QOLDINIT ? eest : QOLDINIT;
+            real dtnew = dt / q;
+            if (dtmax < dtnew) { dtnew = dtmax; r->dtmax_clamped = 1; }
+            real tnew = t + dt;
+            /* saveat points in (t, tnew] from the dense output */
+            r->sv_first = next_save; r->nsv_pts = 0;
+            while (next_save < nsave && saveat[next_save] <= tnew) {
+                real ts = saveat[next_save];
+                if (ts == tnew) {
+                    for (int c = 0; c < B; ++c) memcpy(u_out + ((size_t)c * nsave + next_save) * D, r->unew + (size_t)c * D, sizeof(real) * D);
+                } else {
+                    double bth[7];
+                    orc_dense_weights((double)((ts - t) / dt), bth);
+                    for (int c = 0; c < B; ++c)
+                        for (int i = 0; i < D; ++i) {
+                            size_t e = (size_t)c * D + i;
+                            real acc = 0;
+                            for (int j = 0; j < 7; ++j) acc += (real)bth[j] * r->k[j][e];
+                            u_out[((size_t)c * nsave + next_save) * D + i] = uprev[e] + dt * acc;
+                        }
+                }
+                ++next_save; ++r->nsv_pts;
+            }
+            if (cfg->reg_kind) { r->sv_index = nsv; saveval[nsv++] = cb_value(cfg, eest, dt, eig); }
+            t = tnew; dtp = dtnew; uprev = r->unew; k1 = r->k[6];
+        } else {
+            real m = 1 / QMIN, m2 = q11 / GAMMA;
+            r->rej_m_is_q11 = 0;
+            if (m2 < m) { m = m2; r->rej_m_is_q11 = 1; }
+            r->rej_m = m;
+            dtp = dt / m;
+            if (dtmax < dtp) dtp = dtmax;
+        }
+    }
+    if (!nsave) memcpy(u_out, uprev, sizeof(real) * N);
+    *nfe = nf;
+    *nsaveval = nsv;
+    h->n_saveval = nsv;
+    *nattempts = n;
+    h->have_tape = (ret == 0);
+    (void)a;
+    return ret;
+}
+
+/* ---------------- reverse pass ---------------- */
+static double dotp(const real* a, const real* b, size_t n) {
+    double s = 0;
+#pragma omp parallel for schedule(static) reduction(+ : s)
+    for (size_t i = 0; i < n; ++i) s += (double)a[i] * (double)b[i];
+    return s;
+}
+
+int orc_backward(void* hh, const real* ubar, const real* svbar, real* xbar, real* pbar, real* tspanbar) {
+    orc_handle* h = (orc_handle*)hh;
+    if (!h->have_tape) return -1;
+    const orc_config* cfg = &h->cfg;
+    const orc_arch* a = &cfg->arch;
+    int D = h->D, B = h->B, nsave = h->nsave;
+    size_t N = (size_t)D * B;
+    const real* p = h->p;
+    memset(pbar, 0, sizeof(real) * h->P);
+    real* U = (real*)calloc(N, sizeof(real));   /* cotangent of current uprev' */
+    real* K1 = (real*)calloc(N, sizeof(real));  /* cotangent of current k1' */
+    real* kb[7];
+    for (int j = 0; j < 7; ++j) kb[j] = ralloc(N);
+    real* unb = ralloc(N);
+    real* upb = ralloc(N);
+    real* gb = ralloc(N);
+    real* utb = ralloc(N);
+    real* gtmp = ralloc(N);
+    double tb = 0, dtpb = 0, qoldb = 0, t1b = 0, t0b = 0; /* scalar cotangents carried backwards */
+    if (!nsave) memcpy(U, ubar, sizeof(real) * N);
+    for (int n = h->n_att - 1; n >= 0; --n) {
+        attempt_rec* r = &h->att[n];
+        real dt = r->dt, t = r->t;
+        double eb = 0, dtb = 0, q11b = 0, qb = 0, qoldb_in = 0, tb_in = tb;
+        /* ----- outputs of the attempt ----- */
+        if (r->accepted) {
+            /* saveat points */
+            memcpy(unb, U, sizeof(real) * N);
+            memset(upb, 0, sizeof(real) * N);
+            for (int j = 0; j < 7; ++j) memset(kb[j], 0, sizeof(real) * N);
+            memcpy(kb[6], K1, sizeof(real) * N); /* FSAL: k1' = k7 */
+            for (int sidx = r->sv_first; sidx < r->sv_first + r->nsv_pts; ++sidx) {
+                real ts = h->saveat[sidx];
+                real tnew = t + dt;
+                if (ts == tnew) {
+                    for (int c = 0; c < B; ++c)
+                        for (int i = 0; i < D; ++i) unb[(size_t)c * D + i] += ubar[((size_t)c * nsave + sidx) * D + i];
+                } else {
+                    double th = (double)((ts - t) / dt), bth[7], dbth[7];
+                    orc_dense_weights(th, bth);
+                    dense_weights_deriv(th, dbth);
+                    double d_dt = 0, d_th = 0;
+                    for (int c = 0; c < B; ++c)
+                        for (int i = 0; i < D; ++i) {
+                            size_t e = (size_t)c * D + i;
+                            real ub = ubar[((size_t)c * nsave + sidx) * D + i];
+                            upb[e] += ub;
+                            double acc = 0, dacc = 0;
+                            for (int j = 0; j < 7; ++j) {
+                                kb[j][e] += dt * (real)bth[j] * ub;
+                                acc += bth[j] * (double)r->k[j][e];
+                                dacc += dbth[j] * (double)r->k[j][e];
+                            }
+                            d_dt += (double)ub * acc;
+                            d_th += (double)ub * (double)dt * dacc;
+                        }
+                    dtb += d_dt;
+                    /* theta = (ts - t)/dt */
+                    tb_in += -d_th / (double)dt;
+                    dtb += -d_th * th / (double)dt;
+                }
+            }
+            if (r->sv_index >= 0 && svbar) {
+                double sb = (double)svbar[r->sv_index];
+                switch (cfg->reg_kind) {
+                    case 1: eb += sb * (double)dt; dtb += sb * (double)r->eest; break;
+                    case 3: { real e = r->eest * dt; if (!(e == 0 || isnan(e))) { eb += sb * (double)dt; dtb += sb * (double)r->eest; } } break;
+                    default: break; /* stiffness term: gradient not implemented in the oracle */
+                }
+            }
+            /* t' = t + dt */
+            dtb += tb;
+            /* dtp' = min(dt/q, dtmax) */
+            if (r->dtmax_clamped) { t1b += dtpb; t0b -= dtpb; }
+            else if (cfg->track_ctrl) { dtb += dtpb / (double)r->q; qb += -dtpb * (double)dt / ((double)r->q * (double)r->q); }
+            /* qold' = max(EEst, qoldinit) */
+            if (r->eest > QOLDINIT) eb += qoldb;
+            qoldb_in = 0;
+        } else {
+            memset(unb, 0, sizeof(real) * N);
+            memset(upb, 0, sizeof(real) * N);
+            for (int j = 0; j < 7; ++j) memset(kb[j], 0, sizeof(real) * N);
+            /* dtp' = dt / m (dtmax clamp after a reject cannot trigger: dt shrinks) */
+            dtb += dtpb / (double)r->rej_m;
+            if (r->rej_m_is_q11) q11b += -dtpb * (double)dt / ((double)r->rej_m * (double)r->rej_m) / (double)GAMMA;
+            qoldb_in = qoldb;
+        }
+        /* q = clamp(q11 / qold^beta2 / gamma) */
+        if (!r->q_clamped && !r->eest_zero) {
+            double qo = pow((double)r->qold_in, (double)BETA2);
+            q11b += qb / (qo * (double)GAMMA);
+            qoldb_in += -(double)BETA2 * qb * (double)r->q / (double)r->qold_in;
+        }
+        /* q11 = EEst^beta1 */
+        if (!r->eest_zero && r->eest > 0) eb += q11b * (double)BETA1 * (double)r->q11 / (double)r->eest;
+        /* EEst = sqrt(sum r^2 / N); r = utilde/sk */
+        {
+            real bt[7];
+            for (int j = 0; j < 7; ++j) bt[j] = (real)TS_BT[j];
+            double coef = (r->eest > 0) ? eb / ((double)N * (double)r->eest) : 0.0;
+            double d_dt = 0;
+#pragma omp parallel for schedule(static) reduction(+ : d_dt)
+            for (size_t i = 0; i < N; ++i) {
+                real acc = 0;
+                for (int j = 0; j < 7; ++j) acc += bt[j] * r->k[j][i];
+                real ut = dt * acc;
+                real au = rfabs(r->uprev[i]), an = rfabs(r->unew[i]);
+                int use_new = !(au > an);
+                real sk = cfg->abstol + (use_new ? an : au) * cfg->reltol;
+                real rr = ut / sk;
+                real rb = (real)(coef * (double)rr);
+                real utbv = rb / sk;
+                real skb = -rb * rr / sk;
+                utb[i] = utbv;
+                if (use_new) unb[i] += skb * cfg->reltol * (r->unew[i] > 0 ? 1 : (r->unew[i] < 0 ? -1 : 0));
+                else upb[i] += skb * cfg->reltol * (r->uprev[i] > 0 ? 1 : (r->uprev[i] < 0 ? -1 : 0));
+                for (int j = 0; j < 7; ++j) kb[j][i] += dt * bt[j] * utbv;
+                d_dt += (double)utbv * (double)acc;
+            }
+            dtb += d_dt;
+        }
+        /* stages 7..2 */
+        for (int s = 6; s >= 1; --s) {
+            /* stage input g_s+1 */
+            real as[6];
+            for (int j = 0; j < s; ++j) as[j] = (real)TS_A[s][j];
+#pragma omp parallel for schedule(static)
+            for (size_t i = 0; i < N; ++i) {
+                real acc = 0;
+                for (int j = 0; j < s; ++j) acc += as[j] * r->k[j][i];
+                gtmp[i] = r->uprev[i] + dt * acc;
+            }
+            const real* gin = (s == 6) ? r->unew : gtmp;
+            real tst = t + (real)TS_C[s] * dt;
+            real taub = f_backward(a, p, gin, r->acts[s], B, tst, kb[s], gb, pbar);
+            tb_in += (double)taub;
+            dtb += TS_C[s] * (double)taub;
+            if (s == 6) {
+                /* k7 = f(unew): gbar adds to unew-bar, then unew = uprev + dt sum a7j kj */
+#pragma omp parallel for schedule(static)
+                for (size_t i = 0; i < N; ++i) unb[i] += gb[i];
+                double d_dt = 0;
+#pragma omp parallel for schedule(static) reduction(+ : d_dt)
+                for (size_t i = 0; i < N; ++i) {
+                    real acc = 0;
+                    for (int j = 0; j < 6; ++j) { kb[j][i] += dt * as[j] * unb[i]; acc += as[j] * r->k[j][i]; }
+                    upb[i] += unb[i];
+                    d_dt += (double)unb[i] * (double)acc;
+                }
+                dtb += d_dt;
+            } else {
+                double d_dt = 0;
+#pragma omp parallel for schedule(static) reduction(+ : d_dt)
+                for (size_t i = 0; i < N; ++i) {
+                    real acc = 0;
+                    for (int j = 0; j < s; ++j) { kb[j][i] += dt * as[j] * gb[i]; acc += as[j] * r->k[j][i]; }
+                    upb[i] += gb[i];
+                    d_dt += (double)gb[i] * (double)acc;
+                }
+                dtb += d_dt;
+            }
+        }
+        /* state cotangents out */
+        if (r->accepted) {
+            memcpy(U, upb, sizeof(real) * N);
+            memcpy(K1, kb[0], sizeof(real) * N);
+        } else {
+            for (size_t i = 0; i < N; ++i) { U[i] += upb[i]; K1[i] += kb[0][i]; }
+        }
+        /* dt = min(dtp, t1 - t) */
+        if (r->clamped) { t1b += dtb; tb_in -= dtb; dtpb = 0; }
+        else dtpb = dtb;
+        tb = tb_in;
+        qoldb = qoldb_in;
+    }
+    /* k1 = f(u0, t0) (fsalfirst) */
+    real* f0b = (real*)calloc(N, sizeof(real));
+    memcpy(f0b, K1, sizeof(real) * N);
+    real* u0b = ralloc(N);
+    memcpy(u0b, U, sizeof(real) * N);
+    if (nsave && h->save_t0)
+        for (int c = 0; c < B; ++c)
+            for (int i = 0; i < D; ++i) u0b[(size_t)c * D + i] += ubar[((size_t)c * nsave + 0) * D + i];
+    /* initial dt */
+    if (cfg->track_initdt && dtpb != 0) {
+        double dtb = dtpb, dt0b = 0, d0b = 0, d1b = 0, d2b = 0;
+        real dt0 = h->id_dt0;
+        if (h->id_sel == 2) { t1b += dtb; t0b -= dtb; }
+        else if (h->id_sel == 0) dt0b += 100.0 * dtb;
+        else if (!h->id_dt1_const) {
+            double m = h->id_max_is_d2 ? h->id_d2 : h->id_d1;
+            double mb = dtb * (-0.2) * (double)h->id_dt1 / m;
+            if (h->id_max_is_d2) d2b += mb; else d1b += mb;
+        } else {
+            /* dt1 = max(1e-6, 1e-3 dt0) */
+            if (dt0 * R(1e-3) > R(1e-6)) dt0b += 1e-3 * dtb;
+        }
+        real* sk = ralloc(N);
+        real* skb = (real*)calloc(N, sizeof(real));
+        for (size_t i = 0; i < N; ++i) sk[i] = cfg->abstol + rfabs(h->u0[i]) * cfg->reltol;
+        /* d2 = rms((f1-f0)/sk)/dt0 */
+        real* f1b = (real*)calloc(N, sizeof(real));
+        if (d2b != 0) {
+            double n2 = (double)h->id_d2 * (double)dt0;
+            double n2b = d2b / (double)dt0;
+            dt0b += -d2b * (double)h->id_d2 / (double)dt0;
+            for (size_t i = 0; i < N; ++i) {
+                real w = (h->f1[i] - h->f0[i]) / sk[i];
+                real wb = (real)(n2 > 0 ? n2b * (double)w / ((double)N * n2) : 0.0);
+                f1b[i] += wb / sk[i];
+                f0b[i] -= wb / sk[i];
+                skb[i] += -wb * w / sk[i];
+            }
+            real taub = f_backward(a, p, h->u1, h->acts1, B, h->t0 + dt0, f1b, gb, pbar);
+            t0b += (double)taub;
+            dt0b += (double)taub;
+            for (size_t i = 0; i < N; ++i) { u0b[i] += gb[i]; f0b[i] += dt0 * gb[i]; }
+            dt0b += dotp(gb, h->f0, N);
+        }
+        if (h->id_dt0_clamped) { t1b += dt0b; t0b -= dt0b; }
+        else if (!h->id_dt0_const) {
+            d0b += dt0b / (100.0 * (double)h->id_d1);
+            d1b += -dt0b * (double)dt0 / (double)h->id_d1;
+        }
+        for (size_t i = 0; i < N; ++i) {
+            if (d1b != 0) {
+                real v = h->f0[i] / sk[i];
+                real vb = (real)(d1b * (double)v / ((double)N * (double)h->id_d1));
+                f0b[i] += vb / sk[i];
+                skb[i] += -vb * v / sk[i];
+            }
+            if (d0b != 0) {
+                real z = h->u0[i] / sk[i];
+                real zb = (real)(d0b * (double)z / ((double)N * (double)h->id_d0));
+                u0b[i] += zb / sk[i];
+                skb[i] += -zb * z / sk[i];
+            }
+            u0b[i] += skb[i] * cfg->reltol * (h->u0[i] > 0 ? 1 : (h->u0[i] < 0 ? -1 : 0));
+        }
+        free(sk); free(skb); free(f1b);
+    }
+    {
+        real taub = f_backward(a, p, h->u0, h->acts0, B, h->t0, f0b, gb, pbar);
+        t0b += (double)taub;
+        for (size_t i = 0; i < N; ++i) u0b[i] += gb[i];
+    }
+    t0b += tb;
+    memcpy(xbar, u0b, sizeof(real) * N);
+    if (tspanbar) { tspanbar[0] = (real)t0b; tspanbar[1] = (real)t1b; }
+    free(f0b); free(u0b); free(U); free(K1);
+    for (int j = 0; j < 7; ++j) free(kb[j]);
+    free(unb); free(upb); free(gb); free(utb); free(gtmp);
+    return 0;
+}

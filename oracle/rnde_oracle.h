@@ -1,0 +1,102 @@
+/*
+ * rnde_oracle.h -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+ *
+ * A from-scratch CPU restatement of the adaptive Tsit5 integration that sits
+ * behind RegNeuralDE.jl's TrackedNeuralODE call operator
+ * (reference: src/models/neural_ode.jl:48-180, `solve(prob, Tsit5(); ...)`).
+ *
+ * PARITY UNPINNED: the solver arithmetic of the reference lives in un-vendored
+ * Julia packages (OrdinaryDiffEq 5.50.0, DiffEqBase 6.53.4 fork,
+ * DiffEqCallbacks 2.16.0, Tracker 0.2.14 fork; reference Manifest.toml:242-278,
+ * :964-968, :1326-1332).  None of them, and no Julia runtime, exist in the
+ * build container, and the reference's own tests hold no golden vectors
+ * (test/test_node.jl has no @test).  This file restates the *published*
+ * algorithm (Tsitouras 2011 tableau; Hairer initial-step rule; PI controller)
+ * as recalled in SURVEY.md Appendix A/B, and is pinned only by its own
+ * self-tests (order conditions, convergence order, fp64 finite differences).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.  The product path (librnde.so) never links or calls it.
+ *
+ * Built twice from one source: real = float (librnde_oracle_f32.so) and
+ * real = double (-DRNDE_F64, librnde_oracle_f64.so).
+ */
+#ifndef RNDE_ORACLE_H
+#define RNDE_ORACLE_H
+
+#ifdef RNDE_F64
+typedef double real;
+#else
+typedef float real;
+#endif
+
+#define ORC_MAX_LAYERS 8
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Dynamics f(u,p,t): a Dense chain.
+ *  time_dep=1: TDChain semantics (reference src/models/basic.jl:16-23 and
+ *  experiments/mnist_node.jl:51-54): a row filled with t is vcat'ed onto the
+ *  input of EVERY layer, so layer l has weight out_l x (in_l+1).
+ *  pre_act=1: tanh applied to u before the first layer
+ *  (experiments/latent_ode.jl:113-124).
+ *  Parameter vector layout = Flux.destructure order: for each layer
+ *  [vec(W) column-major (out x in_ext); b(out)]. */
+typedef struct {
+    int n_layers;
+    int dims[ORC_MAX_LAYERS + 1]; /* dims[0] = D (state rows), dims[n_layers] = D */
+    int act[ORC_MAX_LAYERS];      /* 0 identity, 1 tanh */
+    int time_dep;
+    int pre_act;
+} orc_arch;
+
+typedef struct {
+    orc_arch arch;
+    real reltol, abstol;
+    int reg_kind;      /* 0 none (func ignored, neural_ode.jl:48-77); 1 EEst*dt (neural_ode.jl:116);
+                          2 stiffness estimate (mnist_node.jl:74-79); 3 err + 0.1*stiff (mnist_node.jl:88-97) */
+    int cb_save_start; /* 1: SavingCallback fires once at init with EEst=1, dt=0 -> pushes 0 */
+    int track_ctrl;    /* 1: differentiate dt_next = dt/q through the controller on accepted steps */
+    int track_initdt;  /* 1: differentiate the Hairer initial-step computation */
+    int max_attempts;
+} orc_config;
+
+int   orc_param_count(const orc_arch* a);
+void* orc_create(const orc_config* cfg);
+void  orc_destroy(void* h);
+
+/* f evaluation, no tape: out[D x B] = f(u[D x B], p, t). column-major. */
+void orc_f_eval(const orc_arch* a, const real* p, const real* u, int B, real t, real* out);
+
+/* One Tsit5 attempt without controller (kernel-level parity):
+ * given uprev, k1, t, dt -> k2..k7 (kout: 6 arrays D*B), unew, EEst. */
+void orc_tsit5_attempt(const orc_config* cfg, const real* p, const real* uprev, const real* k1,
+                       int B, real t, real dt, real* kout, real* unew, real* eest, real* eigen_est);
+
+/* Hairer initial step. returns dt; f0 (D*B) optional out. */
+real orc_initdt(const orc_config* cfg, const real* p, const real* u0, int B, real t0, real t1, real* f0_out);
+
+/* Full solve, records a tape inside the handle.
+ *  saveat/nsave: optional save times (return_multiple path, neural_ode.jl:79-108);
+ *  u_out: D*B (nsave==0) or D*nsave*B laid out (D, T, B) column-major (utils.jl:17-19).
+ *  saveval: caller buffer of max_attempts+1 reals; steps_log: 4 reals per attempt (t, dt, EEst, accepted).
+ *  returns 0 ok, 1 max attempts exceeded, 2 dt underflow, 3 non-finite. */
+int orc_forward(void* h, const real* x, const real* p, int B, real t0, real t1,
+                const real* saveat, int nsave, real* u_out, long* nfe,
+                real* saveval, int* nsaveval, real* steps_log, int* nattempts);
+
+/* Reverse pass of the recorded solve (discretise-then-optimise).
+ *  ubar: cotangent of u_out (same shape); svbar: cotangent per saveval element.
+ *  xbar[D*B], pbar[P], tspanbar[2]. */
+int orc_backward(void* h, const real* ubar, const real* svbar, real* xbar, real* pbar, real* tspanbar);
+
+/* Tableau access for unit tests. a: 7x7 row-major (a[s][j]), c[7], btilde[7]. */
+void orc_tableau(double* a, double* c, double* btilde);
+void orc_dense_weights(double theta, double* b7);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,129 @@
+/*
+ * rnde.h -- C ABI of librnde.so: the MI355X (gfx950) drop-in for the adaptive
+ * Runge-Kutta integration behind RegNeuralDE.jl's TrackedNeuralODE call operator.
+ *
+ * What each entry point replaces in the reference (paths relative to the reference root):
+ *   rnde_node_create    TrackedNeuralODE(model, tspan, time_dep, regularize, solver; kw...)
+ *                       src/models/neural_ode.jl:10-33 (constructor; Flux.destructure at :12)
+ *   rnde_node_forward   (n::TrackedNeuralODE{R,Z})(x, p; func, tspan, saveat)
+ *                       src/models/neural_ode.jl:48-77 ({false,false}), :110-144 ({true,false}):
+ *                       everything between ODEProblem construction (:128-129) and the unpacking
+ *                       of sol.u[end] / sol.destats.nf / sv (:138-143), i.e. the `solve` call
+ *                       (:131-137) that lives in OrdinaryDiffEq/DiffEqBase/DiffEqCallbacks.
+ *   rnde_node_backward  the reverse sweep Tracker.gradient performs over that solve
+ *                       (experiments/mnist_node.jl:229-232) because
+ *                       sensealg = SensitivityADPassThrough() (neural_ode.jl:134).
+ *   rnde_node_release_tape / rnde_node_destroy   Julia GC of the Tracker tape / the layer.
+ *
+ * All arrays are fp32, column-major, exactly as Julia holds them: x and u are D x B
+ * (element (r,c) at c*D + r); p is the Flux.destructure vector
+ * [vec(W1) (out x in_ext, column-major); b1; vec(W2); b2; ...] (neural_ode.jl:12).
+ * Pointers named *_dev are DEVICE (HBM) pointers owned by the caller; the library keeps no
+ * caller pointer after a call returns.  `stream` is a hipStream_t (0 = default stream); calls
+ * are asynchronous on that stream except where they return host scalars (they synchronise
+ * the stream before returning those).  One in-flight call per handle; handles are independent.
+ * No exceptions cross this boundary: every function returns an rnde_status.
+ */
+#ifndef RNDE_H
+#define RNDE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RNDE_MAX_LAYERS 8
+
+typedef enum {
+    RNDE_OK = 0,
+    RNDE_ERR_BAD_ARG = 1,       /* shape / config not supported                               */
+    RNDE_ERR_MAX_ATTEMPTS = 2,  /* solver hit max_attempts (reference: maxiters, never checked) */
+    RNDE_ERR_DT_UNDERFLOW = 3,  /* dt <= dtmin                                                 */
+    RNDE_ERR_NONFINITE = 4,     /* NaN/Inf in EEst or dt                                       */
+    RNDE_ERR_HIP = 5,           /* HIP runtime error, see rnde_last_error                      */
+    RNDE_ERR_NO_TAPE = 6,       /* backward without a recorded forward                         */
+    RNDE_ERR_NO_DEVICE = 7      /* no gfx950 device visible                                    */
+} rnde_status;
+
+typedef enum { RNDE_ACT_IDENTITY = 0, RNDE_ACT_TANH = 1 } rnde_act;
+typedef enum { RNDE_SOLVER_TSIT5 = 0 } rnde_solver;
+/* func passed to the layer call (neural_ode.jl:116; experiments/mnist_node.jl:67,:74-79,:88-97) */
+typedef enum { RNDE_REG_NONE = 0, RNDE_REG_ERR = 1, RNDE_REG_STIFF = 2, RNDE_REG_ERR_STIFF = 3 } rnde_reg;
+
+typedef struct {
+    /* dynamics: Dense chain; time_dep = TDChain semantics (src/models/basic.jl:16-23,
+     * experiments/mnist_node.jl:51-54): a row of t is appended to every layer input */
+    int32_t n_layers;
+    int32_t dims[RNDE_MAX_LAYERS + 1]; /* dims[0] = dims[n_layers] = D */
+    int32_t act[RNDE_MAX_LAYERS];
+    int32_t time_dep;
+    int32_t pre_act;       /* leading tanh (experiments/latent_ode.jl:114) */
+    int32_t max_batch;     /* largest B any call will pass */
+    int32_t solver;        /* rnde_solver */
+    float   reltol, abstol;
+    int32_t regularize;    /* rnde_reg: which value the saving callback records per accepted step */
+    int32_t cb_save_start; /* 1: callback also fires at init (value 0 for RNDE_REG_ERR) -- SURVEY.md B.5 */
+    int32_t track_ctrl;    /* 1: reverse pass differentiates dt_next = dt/q through the PI controller */
+    int32_t track_initdt;  /* 1: reverse pass differentiates the initial-step heuristic */
+    int32_t max_attempts;  /* tape capacity in attempted steps */
+    int32_t device;        /* HIP device ordinal */
+    int32_t col_tile;      /* 0 = auto; 4, 8 or 16 batch columns per workgroup */
+} rnde_node_config;
+
+typedef struct rnde_node rnde_node;
+
+const char* rnde_version(void);
+const char* rnde_last_error(const rnde_node* h); /* h may be NULL: last create error */
+int32_t     rnde_param_count(const rnde_node_config* cfg);
+
+rnde_status rnde_node_create(const rnde_node_config* cfg, rnde_node** out);
+void        rnde_node_destroy(rnde_node* h);
+
+/* Forward solve on [t0,t1].  u_out_dev: D x B.  saveval_host (may be NULL when regularize==0):
+ * room for max_attempts+1 floats.  keep_tape != 0 records what rnde_node_backward needs.
+ * nfe_out = sol.destats.nf (neural_ode.jl:72,:142).  Synchronises `stream` before returning. */
+rnde_status rnde_node_forward(rnde_node* h, const float* x_dev, const float* p_dev, int32_t B,
+                              float t0, float t1, float* u_out_dev, int64_t* nfe_out,
+                              float* saveval_host, int32_t* n_saveval_out, int32_t keep_tape,
+                              void* stream);
+
+/* Reverse pass of the last recorded forward.  u_bar_dev: D x B cotangent of u_out;
+ * saveval_bar_host: one cotangent per saveval element (NULL = zeros).
+ * Outputs: x_bar_dev (D x B), p_bar_dev (P, overwritten), tspan_bar_host[2] (may be NULL).
+ * Synchronises `stream` before returning. */
+rnde_status rnde_node_backward(rnde_node* h, const float* u_bar_dev, const float* saveval_bar_host,
+                               float* x_bar_dev, float* p_bar_dev, float* tspan_bar_host,
+                               void* stream);
+
+rnde_status rnde_node_release_tape(rnde_node* h);
+
+/* Host-pointer convenience variants (H2D/D2H copies inside; PCIe-inclusive). */
+rnde_status rnde_node_forward_host(rnde_node* h, const float* x, const float* p, int32_t B, float t0,
+                                   float t1, float* u_out, int64_t* nfe_out, float* saveval,
+                                   int32_t* n_saveval_out, int32_t keep_tape);
+rnde_status rnde_node_backward_host(rnde_node* h, const float* u_bar, const float* saveval_bar,
+                                    float* x_bar, float* p_bar, float* tspan_bar);
+
+/* Per-attempt log of the last forward: 4 floats per attempt (t, dt, EEst, accepted). */
+rnde_status rnde_node_steps(rnde_node* h, float* steps_host, int32_t capacity, int32_t* n_attempts_out);
+
+/* Kernel-level entry points used by the parity tests and by bench.py's roofline leg.
+ * rnde_debug_attempt: ONE Tsit5 attempt (6 f evaluations + error estimate) from a given
+ * (uprev, k1, t, dt); k_out_dev receives k2..k7 (6 x D x B), unew_out_dev D x B.
+ * rnde_debug_feval: out = f(u, p, t).
+ * rnde_bench_attempt: runs `iters` back-to-back launches of the step kernel on the handle's
+ * workspace and returns the mean kernel time in microseconds measured with HIP events on
+ * `stream` (the same kernel rocprofv3 reports as rnde_step_kernel). */
+rnde_status rnde_debug_feval(rnde_node* h, const float* u_dev, const float* p_dev, int32_t B, float t,
+                             float* out_dev, void* stream);
+rnde_status rnde_debug_attempt(rnde_node* h, const float* uprev_dev, const float* k1_dev,
+                               const float* p_dev, int32_t B, float t, float dt, float* k_out_dev,
+                               float* unew_out_dev, float* eest_out, void* stream);
+rnde_status rnde_bench_attempt(rnde_node* h, const float* x_dev, const float* p_dev, int32_t B,
+                               int32_t iters, float* mean_us_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

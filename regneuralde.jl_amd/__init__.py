@@ -1,0 +1,8 @@
+"""regneuralde.jl_amd -- MI355X-native drop-in for RegNeuralDE.jl's adaptive Runge-Kutta hot path.
+
+Only the hot path lives here: csrc/ (HIP kernels + C ABI, built into lib/librnde.so) and the
+host-side mirror of the reference's layer interface.  See DESIGN.md and INTEGRATION.md.
+"""
+from . import _lib, build  # noqa: F401
+from .layers import Chain, Dense, MLPDynamics, TDChain, destructure  # noqa: F401
+from .node import SavedValues, TrackedNeuralODE  # noqa: F401

@@ -1,0 +1,69 @@
+"""ctypes binding of include/rnde.h.  Fails loudly when librnde.so is missing: there is no CPU path."""
+import ctypes as C
+import os
+
+from . import build as _build
+
+MAX_LAYERS = 8
+OK, BAD_ARG, MAX_ATTEMPTS, DT_UNDERFLOW, NONFINITE, HIP_ERR, NO_TAPE, NO_DEVICE = range(8)
+REG = {"none": 0, False: 0, None: 0, "error_est": 1, True: 1, "stiff_est": 2, "error_stiff_est": 3}
+
+
+class NodeConfig(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("dims", C.c_int32 * (MAX_LAYERS + 1)), ("act", C.c_int32 * MAX_LAYERS),
+                ("time_dep", C.c_int32), ("pre_act", C.c_int32), ("max_batch", C.c_int32), ("solver", C.c_int32),
+                ("reltol", C.c_float), ("abstol", C.c_float), ("regularize", C.c_int32),
+                ("cb_save_start", C.c_int32), ("track_ctrl", C.c_int32), ("track_initdt", C.c_int32),
+                ("max_attempts", C.c_int32), ("device", C.c_int32), ("col_tile", C.c_int32)]
+
+
+class RndeError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"rnde status {status}: {msg}")
+        self.status = status
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950). There is no CPU fallback for the integration path.")
+    L = C.CDLL(path)
+    vp, f, i32, i64p, fp, i32p = C.c_void_p, C.c_float, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_float), C.POINTER(C.c_int32)
+    L.rnde_version.restype = C.c_char_p
+    L.rnde_last_error.restype = C.c_char_p
+    L.rnde_last_error.argtypes = [vp]
+    L.rnde_param_count.restype = i32
+    L.rnde_param_count.argtypes = [C.POINTER(NodeConfig)]
+    L.rnde_node_create.argtypes = [C.POINTER(NodeConfig), C.POINTER(vp)]
+    L.rnde_node_destroy.argtypes = [vp]
+    L.rnde_node_destroy.restype = None
+    L.rnde_node_forward.argtypes = [vp, vp, vp, i32, f, f, vp, i64p, fp, i32p, i32, vp]
+    L.rnde_node_backward.argtypes = [vp, vp, fp, vp, vp, fp, vp]
+    L.rnde_node_release_tape.argtypes = [vp]
+    L.rnde_node_forward_host.argtypes = [vp, fp, fp, i32, f, f, fp, i64p, fp, i32p, i32]
+    L.rnde_node_backward_host.argtypes = [vp, fp, fp, fp, fp, fp]
+    L.rnde_node_steps.argtypes = [vp, fp, i32, i32p]
+    L.rnde_debug_feval.argtypes = [vp, vp, vp, i32, f, vp, vp]
+    L.rnde_debug_attempt.argtypes = [vp, vp, vp, vp, i32, f, f, vp, vp, fp, vp]
+    L.rnde_bench_attempt.argtypes = [vp, vp, vp, i32, i32, fp, vp]
+    _lib = L
+    return L
+
+
+EXPORTS = ["rnde_version", "rnde_last_error", "rnde_param_count", "rnde_node_create", "rnde_node_destroy",
+           "rnde_node_forward", "rnde_node_backward", "rnde_node_release_tape", "rnde_node_forward_host",
+           "rnde_node_backward_host", "rnde_node_steps", "rnde_debug_feval", "rnde_debug_attempt",
+           "rnde_bench_attempt"]
+
+
+def check(h, status):
+    if status != OK:
+        msg = lib().rnde_last_error(h).decode() if h else lib().rnde_last_error(None).decode()
+        raise RndeError(status, msg)

@@ -1,0 +1,391 @@
+// rnde.hip -- C ABI (include/rnde.h) over the gfx950 kernels.  No torch, no oracle, no CPU fallback:
+// every entry point either runs the HIP kernels or returns an error status.
+#include "../../include/rnde.h"
+#include "rnde_fwd.h"
+#include "rnde_bwd.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace rnde;
+
+struct rnde_node {
+    rnde_node_config cfg{};
+    int D = 0, H = 0, P = 0, NG = 2, BT = 8, act2 = 1;
+    int K4_1 = 0, KS1 = 0, MT1 = 0, K4_2 = 0, KS2 = 0, MT2 = 0;  // forward GEMM geometry
+    int K4_1t = 0, MT1t = 0, K4_2t = 0, MT2t = 0;                // reverse GEMM geometry
+    int Bpad_max = 0, nwg_max = 0;
+    size_t lds_bytes = 0;
+    // device
+    float *f0 = nullptr, *h0 = nullptr, *u1 = nullptr, *f1 = nullptr, *h1 = nullptr, *arena = nullptr;
+    float* xcopy = nullptr;  // private copy of x (the tape must not alias caller memory)
+    long long arena_recs = 0, rec_stride = 0;
+    f32x4 *pw1 = nullptr, *pw2 = nullptr, *pw1t = nullptr, *pw2t = nullptr;
+    float* pcopy = nullptr;
+    StepState *ctl = nullptr, *ctl_final = nullptr;
+    StepMeta* meta = nullptr;
+    InitRec* initrec = nullptr;
+    float *errpart = nullptr, *initpart = nullptr;
+    BwdBuffers bw{};
+    // pinned host
+    StepState* h_ctl = nullptr;
+    StepMeta* h_meta = nullptr;
+    InitRec* h_init = nullptr;
+    float* h_scal = nullptr;
+    // last forward
+    int B = 0, Bpad = 0, nwg = 0, n_att = 0, predicted = 0;
+    float t0 = 0, t1 = 0;
+    bool have_tape = false;
+    std::vector<int> sv_index;  // per attempt: index into saveval or -1
+    int n_saveval = 0;
+    std::string err;
+};
+
+static std::string g_create_err;
+
+#define HIPCHK(h, call)                                                                              \
+    do {                                                                                             \
+        hipError_t e__ = (call);                                                                     \
+        if (e__ != hipSuccess) {                                                                     \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e__);                           \
+            return RNDE_ERR_HIP;                                                                     \
+        }                                                                                            \
+    } while (0)
+
+extern "C" const char* rnde_version(void) { return "rnde 0.1.0 (gfx950)"; }
+extern "C" const char* rnde_last_error(const rnde_node* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int32_t rnde_param_count(const rnde_node_config* c) {
+    int n = 0;
+    for (int l = 0; l < c->n_layers; ++l) n += (c->dims[l] + (c->time_dep ? 1 : 0)) * c->dims[l + 1] + c->dims[l + 1];
+    return n;
+}
+
+static StepParams make_params(rnde_node* h, const float* x, int B, float t0, float t1, int tape) {
+    StepParams P{};
+    P.x = x;
+    P.f0 = h->f0; P.h0 = h->h0; P.u1 = h->u1; P.f1 = h->f1; P.h1 = h->h1;
+    P.arena = h->arena; P.rec_stride = h->rec_stride;
+    P.pw1 = h->pw1; P.pw2 = h->pw2;
+    P.ctl = h->ctl; P.ctl_final = h->ctl_final; P.meta = h->meta; P.initrec = h->initrec;
+    P.errpart = h->errpart; P.initpart = h->initpart; P.dbg_out = nullptr;
+    P.D = h->D; P.H = h->H; P.B = B;
+    P.Bpad = ((B + h->BT - 1) / h->BT) * h->BT;
+    P.nwg = P.Bpad / h->BT;
+    P.K4_1 = h->K4_1; P.KS1 = h->KS1; P.MT1 = h->MT1; P.K4_2 = h->K4_2; P.KS2 = h->KS2; P.MT2 = h->MT2;
+    P.reltol = h->cfg.reltol; P.abstol = h->cfg.abstol; P.t0 = t0; P.t1 = t1;
+    P.tape = tape; P.max_attempts = h->cfg.max_attempts;
+    P.forced = 0; P.forced_t = 0; P.forced_dt = 0;
+    P.xvec = ((h->D & 3) == 0 && ((uintptr_t)x & 15) == 0) ? 1 : 0;
+    return P;
+}
+
+template <int NG, int ACT2, int MODE>
+static hipError_t launch_step_t(rnde_node* h, const StepParams& P, int n, hipStream_t s) {
+    auto kern = rnde_step_kernel<NG, ACT2, MODE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(P.nwg), dim3(kThreads), h->lds_bytes, s, P, n);
+    return hipGetLastError();
+}
+template <int MODE>
+static hipError_t launch_step(rnde_node* h, const StepParams& P, int n, hipStream_t s) {
+    if (h->NG == 1) return h->act2 ? launch_step_t<1, 1, MODE>(h, P, n, s) : launch_step_t<1, 0, MODE>(h, P, n, s);
+    return h->act2 ? launch_step_t<2, 1, MODE>(h, P, n, s) : launch_step_t<2, 0, MODE>(h, P, n, s);
+}
+static hipError_t launch_finish(rnde_node* h, const StepParams& P, int n, float* u_out, hipStream_t s) {
+    if (h->NG == 1) hipLaunchKernelGGL(rnde_finish_kernel<1>, dim3(P.nwg), dim3(256), 0, s, P, n, u_out);
+    else hipLaunchKernelGGL(rnde_finish_kernel<2>, dim3(P.nwg), dim3(256), 0, s, P, n, u_out);
+    return hipGetLastError();
+}
+static hipError_t launch_pack(rnde_node* h, const float* p, f32x4* dst, int which, int MT, int K4, hipStream_t s) {
+    const int TR = 64 / h->NG;
+    const long long total = (long long)MT * K4 * TR;
+    const int grid = (int)std::min<long long>((total + 255) / 256, 1024);
+    if (h->NG == 1) hipLaunchKernelGGL(rnde_pack_kernel<1>, dim3(grid), dim3(256), 0, s, p, dst, which, h->D, h->H, MT, K4);
+    else hipLaunchKernelGGL(rnde_pack_kernel<2>, dim3(grid), dim3(256), 0, s, p, dst, which, h->D, h->H, MT, K4);
+    return hipGetLastError();
+}
+
+extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** out) {
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= c->device) { g_create_err = "no HIP device"; return RNDE_ERR_NO_DEVICE; }
+    if (c->n_layers != 2 || !c->time_dep || c->pre_act || c->act[0] != RNDE_ACT_TANH || c->dims[0] != c->dims[2] ||
+        c->solver != RNDE_SOLVER_TSIT5) {
+        g_create_err = "unsupported dynamics: the gfx950 kernels cover the 2-layer time-dependent Dense chain "
+                       "(experiments/mnist_node.jl:41-54, test/test_node.jl:4) with Tsit5";
+        return RNDE_ERR_BAD_ARG;
+    }
+    if (c->regularize != RNDE_REG_NONE && c->regularize != RNDE_REG_ERR) {
+        g_create_err = "regularize: only NONE and ERR (EEst*dt) are implemented on the device path";
+        return RNDE_ERR_BAD_ARG;
+    }
+    rnde_node* h = new rnde_node();
+    h->cfg = *c;
+    h->D = c->dims[0]; h->H = c->dims[1]; h->P = rnde_param_count(c); h->act2 = c->act[1];
+    h->BT = c->col_tile ? c->col_tile : 8;
+    if (h->BT != 4 && h->BT != 8) { g_create_err = "col_tile must be 0, 4 or 8"; delete h; return RNDE_ERR_BAD_ARG; }
+    h->NG = h->BT / 4;
+    const int TR = 64 / h->NG, TPW = (h->NG == 1) ? 2 : 4;
+    if (h->H + 2 > 128 || h->D + 2 > kWaves * TPW * TR || h->D < 1 || h->H < 1 || c->max_batch < 1 || c->max_attempts < 1) {
+        g_create_err = "shape outside the kernel limits (H <= 126, D <= 1022 at col_tile 8)"; delete h; return RNDE_ERR_BAD_ARG;
+    }
+    auto up4 = [](int k) { return (k + 3) / 4; };
+    h->K4_1 = up4(h->D + 2); h->KS1 = 4 * (h->K4_1 | 1); h->MT1 = (h->H + TR - 1) / TR;
+    h->K4_2 = up4(h->H + 2); h->KS2 = 4 * (h->K4_2 | 1); h->MT2 = (h->D + TR - 1) / TR;
+    h->K4_2t = up4(h->D); h->MT2t = (h->H + 1 + TR - 1) / TR;   // pw2t: M = H+1, K = D   (B operand image uses KS1)
+    h->K4_1t = up4(h->H); h->MT1t = (h->D + 1 + TR - 1) / TR;   // pw1t: M = D+1, K = H   (B operand image uses KS2)
+    h->Bpad_max = ((c->max_batch + h->BT - 1) / h->BT) * h->BT;
+    h->nwg_max = h->Bpad_max / h->BT;
+    const int MTS = 128 / TR;
+    h->lds_bytes = sizeof(float) * ((size_t)h->BT * h->KS1 + (size_t)h->BT * h->KS2 + (size_t)kWaves * MTS * 256 + 64);
+    if (hipSetDevice(c->device) != hipSuccess) { g_create_err = "hipSetDevice failed"; delete h; return RNDE_ERR_HIP; }
+    const size_t A = (size_t)h->D * h->Bpad_max, HB = (size_t)h->H * h->Bpad_max;
+    RecLayout L{(long long)A, (long long)HB};
+    h->rec_stride = L.total();
+    auto dm = [&](void** p, size_t bytes) { return hipMalloc(p, bytes) == hipSuccess; };
+    bool ok = true;
+    ok &= dm((void**)&h->f0, A * 4) && dm((void**)&h->u1, A * 4) && dm((void**)&h->f1, A * 4) && dm((void**)&h->xcopy, A * 4);
+    ok &= dm((void**)&h->h0, HB * 4) && dm((void**)&h->h1, HB * 4);
+    ok &= dm((void**)&h->pw1, (size_t)h->MT1 * h->K4_1 * TR * 16) && dm((void**)&h->pw2, (size_t)h->MT2 * h->K4_2 * TR * 16);
+    ok &= dm((void**)&h->pw1t, (size_t)h->MT1t * h->K4_1t * TR * 16) && dm((void**)&h->pw2t, (size_t)h->MT2t * h->K4_2t * TR * 16);
+    ok &= dm((void**)&h->pcopy, (size_t)h->P * 4);
+    ok &= dm((void**)&h->ctl, 2 * sizeof(StepState)) && dm((void**)&h->ctl_final, sizeof(StepState));
+    ok &= dm((void**)&h->meta, (size_t)(c->max_attempts + 1) * sizeof(StepMeta)) && dm((void**)&h->initrec, sizeof(InitRec));
+    ok &= dm((void**)&h->errpart, (size_t)2 * h->nwg_max * 4) && dm((void**)&h->initpart, (size_t)3 * h->nwg_max * 4);
+    // scratch records: 2 (no-tape ring); grown to max_attempts on the first taped forward
+    h->arena_recs = 2;
+    ok &= dm((void**)&h->arena, (size_t)h->arena_recs * h->rec_stride * 4);
+    ok &= hipHostMalloc((void**)&h->h_ctl, sizeof(StepState)) == hipSuccess;
+    ok &= hipHostMalloc((void**)&h->h_meta, (size_t)(c->max_attempts + 1) * sizeof(StepMeta)) == hipSuccess;
+    ok &= hipHostMalloc((void**)&h->h_init, sizeof(InitRec)) == hipSuccess;
+    ok &= hipHostMalloc((void**)&h->h_scal, 64 * sizeof(float)) == hipSuccess;
+    if (!ok) { g_create_err = "device allocation failed"; rnde_node_destroy(h); return RNDE_ERR_HIP; }
+    hipMemset(h->initrec, 0, sizeof(InitRec));
+    h->predicted = 12;
+    *out = h;
+    return RNDE_OK;
+}
+
+extern "C" void rnde_node_destroy(rnde_node* h) {
+    if (!h) return;
+    void* d[] = {h->f0, h->h0, h->u1, h->f1, h->h1, h->arena, h->xcopy, h->pw1, h->pw2, h->pw1t, h->pw2t, h->pcopy,
+                 h->ctl, h->ctl_final, h->meta, h->initrec, h->errpart, h->initpart};
+    for (void* p : d) if (p) hipFree(p);
+    bwd_free(h->bw);
+    if (h->h_ctl) hipHostFree(h->h_ctl);
+    if (h->h_meta) hipHostFree(h->h_meta);
+    if (h->h_init) hipHostFree(h->h_init);
+    if (h->h_scal) hipHostFree(h->h_scal);
+    delete h;
+}
+
+static rnde_status ensure_arena(rnde_node* h, long long recs) {
+    if (h->arena_recs >= recs) return RNDE_OK;
+    if (h->arena) hipFree(h->arena);
+    h->arena = nullptr; h->arena_recs = 0;
+    HIPCHK(h, hipMalloc((void**)&h->arena, (size_t)recs * h->rec_stride * 4));
+    h->arena_recs = recs;
+    return RNDE_OK;
+}
+
+static rnde_status pack_weights(rnde_node* h, const float* p_dev, bool reverse, hipStream_t s) {
+    HIPCHK(h, launch_pack(h, p_dev, h->pw1, 0, h->MT1, h->K4_1, s));
+    HIPCHK(h, launch_pack(h, p_dev, h->pw2, 1, h->MT2, h->K4_2, s));
+    if (reverse) {
+        HIPCHK(h, launch_pack(h, p_dev, h->pw2t, 2, h->MT2t, h->K4_2t, s));
+        HIPCHK(h, launch_pack(h, p_dev, h->pw1t, 3, h->MT1t, h->K4_1t, s));
+    }
+    return RNDE_OK;
+}
+
+extern "C" rnde_status rnde_node_forward(rnde_node* h, const float* x_dev, const float* p_dev, int32_t B, float t0,
+                                         float t1, float* u_out_dev, int64_t* nfe_out, float* saveval_host,
+                                         int32_t* n_saveval_out, int32_t keep_tape, void* stream) {
+    if (!h) return RNDE_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (B < 1 || B > h->cfg.max_batch || !(t1 > t0)) { h->err = "bad B or tspan"; return RNDE_ERR_BAD_ARG; }
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    h->have_tape = false;
+    if (keep_tape) {
+        rnde_status st = ensure_arena(h, h->cfg.max_attempts);
+        if (st != RNDE_OK) return st;
+        // the tape owns copies of x and p (the caller may free or overwrite its buffers before backward)
+        HIPCHK(h, hipMemcpyAsync(h->xcopy, x_dev, (size_t)h->D * B * 4, hipMemcpyDeviceToDevice, s));
+        HIPCHK(h, hipMemcpyAsync(h->pcopy, p_dev, (size_t)h->P * 4, hipMemcpyDeviceToDevice, s));
+        x_dev = h->xcopy;
+    }
+    StepParams P = make_params(h, x_dev, B, t0, t1, keep_tape ? 1 : 0);
+    h->B = B; h->Bpad = P.Bpad; h->nwg = P.nwg; h->t0 = t0; h->t1 = t1;
+    rnde_status st = pack_weights(h, p_dev, keep_tape != 0, s);
+    if (st != RNDE_OK) return st;
+    HIPCHK(h, launch_step<MODE_INIT_A>(h, P, 0, s));
+    HIPCHK(h, launch_step<MODE_INIT_B>(h, P, 0, s));
+    int launched = 0;
+    int chunk = std::max(4, h->predicted);
+    const int cap = h->cfg.max_attempts;
+    while (true) {
+        for (int i = 0; i < chunk && launched < cap; ++i) { HIPCHK(h, launch_step<MODE_STEP>(h, P, launched, s)); ++launched; }
+        HIPCHK(h, launch_finish(h, P, launched, u_out_dev, s));
+        HIPCHK(h, hipMemcpyAsync(h->h_ctl, h->ctl_final, sizeof(StepState), hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipStreamSynchronize(s));
+        if (h->h_ctl->done) break;
+        if (launched >= cap) { h->err = "max_attempts reached"; h->n_att = h->h_ctl->n_att; return RNDE_ERR_MAX_ATTEMPTS; }
+        chunk = 4;
+    }
+    h->n_att = h->h_ctl->n_att;
+    h->predicted = h->n_att + 1;
+    if (h->n_att > 0) HIPCHK(h, hipMemcpyAsync(h->h_meta, h->meta, (size_t)h->n_att * sizeof(StepMeta), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(h->h_init, h->initrec, sizeof(InitRec), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    if (nfe_out) *nfe_out = 3 + 6 * (int64_t)h->n_att;  // 2 (initial dt) + 1 (fsalfirst) + 6 per attempt, SURVEY.md B.1-B.2
+    // saving callback values (reference neural_ode.jl:116,:126-127): EEst*dt per accepted step
+    int nsv = 0;
+    h->sv_index.assign(h->n_att, -1);
+    if (h->cfg.regularize == RNDE_REG_ERR) {
+        if (h->cfg.cb_save_start) { if (saveval_host) saveval_host[nsv] = 0.f; ++nsv; }
+        for (int i = 0; i < h->n_att; ++i)
+            if (h->h_meta[i].flags & F_ACCEPT) {
+                if (saveval_host) saveval_host[nsv] = h->h_meta[i].eest * h->h_meta[i].dt;
+                h->sv_index[i] = nsv++;
+            }
+    }
+    h->n_saveval = nsv;
+    if (n_saveval_out) *n_saveval_out = nsv;
+    switch (h->h_ctl->status) {
+        case 0: break;
+        case 2: h->err = "max_attempts reached"; return RNDE_ERR_MAX_ATTEMPTS;
+        case 3: h->err = "dt underflow"; return RNDE_ERR_DT_UNDERFLOW;
+        default: h->err = "non-finite error estimate or dt"; return RNDE_ERR_NONFINITE;
+    }
+    h->have_tape = keep_tape != 0;
+    return RNDE_OK;
+}
+
+extern "C" rnde_status rnde_node_steps(rnde_node* h, float* steps_host, int32_t capacity, int32_t* n_out) {
+    if (!h) return RNDE_ERR_BAD_ARG;
+    const int n = std::min(capacity, h->n_att);
+    for (int i = 0; i < n; ++i) {
+        steps_host[4 * i + 0] = h->h_meta[i].t; steps_host[4 * i + 1] = h->h_meta[i].dt;
+        steps_host[4 * i + 2] = h->h_meta[i].eest; steps_host[4 * i + 3] = (h->h_meta[i].flags & F_ACCEPT) ? 1.f : 0.f;
+    }
+    if (n_out) *n_out = h->n_att;
+    return RNDE_OK;
+}
+
+extern "C" rnde_status rnde_node_release_tape(rnde_node* h) {
+    if (!h) return RNDE_ERR_BAD_ARG;
+    h->have_tape = false;
+    return RNDE_OK;
+}
+
+extern "C" rnde_status rnde_node_backward(rnde_node* h, const float* u_bar_dev, const float* saveval_bar_host,
+                                          float* x_bar_dev, float* p_bar_dev, float* tspan_bar_host, void* stream) {
+    if (!h) return RNDE_ERR_BAD_ARG;
+    if (!h->have_tape) { h->err = "no recorded forward"; return RNDE_ERR_NO_TAPE; }
+    return bwd_run(h, u_bar_dev, saveval_bar_host, x_bar_dev, p_bar_dev, tspan_bar_host, (hipStream_t)stream);
+}
+
+// ---- host-pointer variants ------------------------------------------------------------------
+extern "C" rnde_status rnde_node_forward_host(rnde_node* h, const float* x, const float* p, int32_t B, float t0, float t1,
+                                              float* u_out, int64_t* nfe_out, float* saveval, int32_t* n_saveval_out,
+                                              int32_t keep_tape) {
+    if (!h) return RNDE_ERR_BAD_ARG;
+    float *xd = nullptr, *pd = nullptr, *ud = nullptr;
+    const size_t nb = (size_t)h->D * B * 4;
+    HIPCHK(h, hipMalloc((void**)&xd, nb)); HIPCHK(h, hipMalloc((void**)&ud, nb)); HIPCHK(h, hipMalloc((void**)&pd, (size_t)h->P * 4));
+    HIPCHK(h, hipMemcpy(xd, x, nb, hipMemcpyHostToDevice)); HIPCHK(h, hipMemcpy(pd, p, (size_t)h->P * 4, hipMemcpyHostToDevice));
+    rnde_status st = rnde_node_forward(h, xd, pd, B, t0, t1, ud, nfe_out, saveval, n_saveval_out, keep_tape, nullptr);
+    if (st == RNDE_OK || st == RNDE_ERR_MAX_ATTEMPTS) hipMemcpy(u_out, ud, nb, hipMemcpyDeviceToHost);
+    hipFree(xd); hipFree(pd); hipFree(ud);
+    return st;
+}
+extern "C" rnde_status rnde_node_backward_host(rnde_node* h, const float* u_bar, const float* saveval_bar, float* x_bar,
+                                               float* p_bar, float* tspan_bar) {
+    if (!h) return RNDE_ERR_BAD_ARG;
+    float *ub = nullptr, *xb = nullptr, *pb = nullptr;
+    const size_t nb = (size_t)h->D * h->B * 4;
+    HIPCHK(h, hipMalloc((void**)&ub, nb)); HIPCHK(h, hipMalloc((void**)&xb, nb)); HIPCHK(h, hipMalloc((void**)&pb, (size_t)h->P * 4));
+    HIPCHK(h, hipMemcpy(ub, u_bar, nb, hipMemcpyHostToDevice));
+    rnde_status st = rnde_node_backward(h, ub, saveval_bar, xb, pb, tspan_bar, nullptr);
+    if (st == RNDE_OK) { hipMemcpy(x_bar, xb, nb, hipMemcpyDeviceToHost); hipMemcpy(p_bar, pb, (size_t)h->P * 4, hipMemcpyDeviceToHost); }
+    hipFree(ub); hipFree(xb); hipFree(pb);
+    return st;
+}
+
+// ---- kernel-level entry points ----------------------------------------------------------------
+extern "C" rnde_status rnde_debug_feval(rnde_node* h, const float* u_dev, const float* p_dev, int32_t B, float t,
+                                        float* out_dev, void* stream) {
+    if (!h || B < 1 || B > h->cfg.max_batch) return RNDE_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    StepParams P = make_params(h, u_dev, B, 0.f, 1.f, 0);
+    P.forced = 1; P.forced_t = t; P.dbg_out = out_dev;
+    rnde_status st = pack_weights(h, p_dev, false, s);
+    if (st != RNDE_OK) return st;
+    HIPCHK(h, launch_step<MODE_FEVAL>(h, P, 0, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    return RNDE_OK;
+}
+
+extern "C" rnde_status rnde_debug_attempt(rnde_node* h, const float* uprev_dev, const float* k1_dev, const float* p_dev,
+                                          int32_t B, float t, float dt, float* k_out_dev, float* unew_out_dev,
+                                          float* eest_out, void* stream) {
+    if (!h || B < 1 || B > h->cfg.max_batch) return RNDE_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    h->have_tape = false;
+    StepParams P = make_params(h, uprev_dev, B, 0.f, 1.f, 0);
+    P.forced = 1; P.forced_t = t; P.forced_dt = dt;
+    rnde_status st = pack_weights(h, p_dev, false, s);
+    if (st != RNDE_OK) return st;
+    // k1 goes to the f0 buffer (column stride D in both layouts)
+    HIPCHK(h, hipMemsetAsync(h->f0, 0, (size_t)h->D * P.Bpad * 4, s));
+    HIPCHK(h, hipMemcpyAsync(h->f0, k1_dev, (size_t)h->D * B * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(h, launch_step<MODE_STEP>(h, P, 0, s));
+    HIPCHK(h, launch_finish(h, P, 1, nullptr, s));
+    HIPCHK(h, hipMemcpyAsync(h->h_ctl, h->ctl_final, sizeof(StepState), hipMemcpyDeviceToHost, s));
+    RecLayout L{(long long)h->D * P.Bpad, (long long)h->H * P.Bpad};
+    const float* R = h->arena;  // record 0 (no-tape: live == -1 -> rec 0)
+    for (int sidx = 2; sidx <= 7; ++sidx)
+        HIPCHK(h, hipMemcpyAsync(k_out_dev + (size_t)(sidx - 2) * h->D * B, R + L.k(sidx), (size_t)h->D * B * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(unew_out_dev, R + L.unew(), (size_t)h->D * B * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    if (eest_out) *eest_out = h->h_ctl->last_eest;
+    return RNDE_OK;
+}
+
+extern "C" rnde_status rnde_bench_attempt(rnde_node* h, const float* x_dev, const float* p_dev, int32_t B, int32_t iters,
+                                          float* mean_us_out, void* stream) {
+    if (!h || B < 1 || B > h->cfg.max_batch || iters < 1) return RNDE_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    h->have_tape = false;
+    StepParams P = make_params(h, x_dev, B, 0.f, 1.f, 0);
+    P.forced = 1; P.forced_t = 0.f; P.forced_dt = 0.05f;
+    rnde_status st = pack_weights(h, p_dev, false, s);
+    if (st != RNDE_OK) return st;
+    HIPCHK(h, launch_step<MODE_INIT_A>(h, P, 0, s));  // k1 = f(x, 0) into f0
+    for (int i = 0; i < 3; ++i) HIPCHK(h, launch_step<MODE_STEP>(h, P, 0, s));
+    hipEvent_t e0, e1;
+    HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
+    HIPCHK(h, hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) HIPCHK(h, launch_step<MODE_STEP>(h, P, 0, s));
+    HIPCHK(h, hipEventRecord(e1, s));
+    HIPCHK(h, hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    if (mean_us_out) *mean_us_out = ms * 1000.f / iters;
+    return RNDE_OK;
+}
+
+static rnde_status bwd_run(rnde_node* h, const float*, const float*, float*, float*, float*, hipStream_t) {
+    h->err = "reverse pass not built";
+    return RNDE_ERR_BAD_ARG;
+}

@@ -1,0 +1,164 @@
+"""TrackedNeuralODE: the reference's DE layer (src/models/neural_ode.jl), same constructor and
+call contract, with the `solve` call replaced by librnde.so (hand-written gfx950 kernels).
+
+    node = TrackedNeuralODE(model, [0.0, 1.0], True, regularize, "Tsit5",
+                            save_everystep=False, reltol=1.4e-8, abstol=1.4e-8, save_start=False)
+    u, nfe, sv = node(x, p)            # x: (B, D) cuda tensor == Julia D x B;  sv.saveval: tensor or None
+
+Differences from the Julia layer that are inherent to the host language: `func` is one of the
+reference's three callbacks selected by name (mnist_node.jl:67,:74-79,:88-97), not a closure.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .layers import destructure
+
+_ACT = {"identity": 0, "tanh": 1}
+_FUNCS = {None: 1, "error_est": 1, "stiff_est": 2, "error_stiff_est": 3}
+
+
+class SavedValues:
+    """DiffEqCallbacks.SavedValues as returned by the regularised call (neural_ode.jl:126,:143)."""
+
+    def __init__(self, saveval):
+        self.saveval = saveval
+
+
+class _Handle:
+    def __init__(self, cfg):
+        self.ptr = C.c_void_p()
+        st = _lib.lib().rnde_node_create(C.byref(cfg), C.byref(self.ptr))
+        _lib.check(None, st)
+        self.busy = False
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                _lib.lib().rnde_node_destroy(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+class _Solve(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, layer, t0, t1, keep_tape):
+        h = layer._acquire(x, keep_tape)
+        L = _lib.lib()
+        B, D = x.shape
+        u = torch.empty_like(x)
+        nfe = C.c_int64(0)
+        nsv = C.c_int32(0)
+        sv_host = (C.c_float * (layer.max_attempts + 1))()
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        st = L.rnde_node_forward(h.ptr, x.data_ptr(), p.data_ptr(), B, t0, t1, u.data_ptr(), C.byref(nfe), sv_host,
+                                 C.byref(nsv), 1 if keep_tape else 0, C.c_void_p(stream))
+        _lib.check(h.ptr, st)
+        layer.last_nfe = int(nfe.value)
+        saveval = torch.tensor(list(sv_host[:nsv.value]), dtype=torch.float32, device=x.device)
+        ctx.layer, ctx.h, ctx.nsv = layer, h, nsv.value
+        if keep_tape:
+            h.busy = True
+        ctx.mark_non_differentiable()
+        return u, saveval
+
+    @staticmethod
+    def backward(ctx, u_bar, sv_bar):
+        layer, h = ctx.layer, ctx.h
+        L = _lib.lib()
+        u_bar = u_bar.contiguous().to(torch.float32)
+        x_bar = torch.empty_like(u_bar)
+        p_bar = torch.empty(layer.P, dtype=torch.float32, device=u_bar.device)
+        svb = None
+        if ctx.nsv and sv_bar is not None:
+            svb = (C.c_float * ctx.nsv)(*sv_bar.detach().to("cpu", torch.float32).tolist())
+        tsb = (C.c_float * 2)()
+        stream = torch.cuda.current_stream(u_bar.device).cuda_stream
+        st = L.rnde_node_backward(h.ptr, u_bar.data_ptr(), svb, x_bar.data_ptr(), p_bar.data_ptr(), tsb, C.c_void_p(stream))
+        h.busy = False
+        _lib.check(h.ptr, st)
+        layer.last_tspan_bar = (tsb[0], tsb[1])
+        return x_bar, p_bar, None, None, None, None
+
+
+class TrackedNeuralODE:
+    """Mirror of reference src/models/neural_ode.jl:1-33 (struct + constructor) and :48-180 (call methods)."""
+
+    def __init__(self, model, tspan, time_dep, regularize, solver="Tsit5", *, max_batch=512, max_attempts=128,
+                 cb_save_start=True, track_ctrl=True, track_initdt=True, col_tile=0, **kwargs):
+        if solver not in ("Tsit5", "AutoTsit5"):
+            raise ValueError("solver: the reference's call sites use Tsit5() / AutoTsit5(Tsit5()) only")
+        self.model = model
+        self.p = destructure(model)                      # Flux.destructure (neural_ode.jl:12)
+        self.tspan = [float(tspan[0]), float(tspan[1])]
+        self.time_dep = bool(time_dep)
+        self.regularize = bool(regularize)
+        self.kwargs = dict(kwargs)                       # reltol, abstol, save_everystep, save_start, saveat
+        self.return_multiple = bool(kwargs.get("save_everystep", False)) or ("saveat" in kwargs)  # neural_ode.jl:11
+        if self.return_multiple:
+            raise NotImplementedError("saveat / save_everystep ({R,true} methods, neural_ode.jl:79-108,:146-180): next row")
+        if bool(time_dep) != bool(model.time_dep):
+            raise ValueError("time_dep must match the model (TDChain => True)")
+        self.max_batch, self.max_attempts = int(max_batch), int(max_attempts)
+        self.cb_save_start, self.track_ctrl, self.track_initdt, self.col_tile = cb_save_start, track_ctrl, track_initdt, col_tile
+        self.P = self.p.numel()
+        self._handles = {}
+        self.last_nfe = None
+        self.last_tspan_bar = None
+
+    # -- C-ABI config -------------------------------------------------------------------------
+    def _config(self, device_index, func):
+        cfg = _lib.NodeConfig()
+        dims = self.model.dims()
+        cfg.n_layers = len(self.model.layers)
+        for i, d in enumerate(dims):
+            cfg.dims[i] = d
+        for i, l in enumerate(self.model.layers):
+            cfg.act[i] = _ACT[l.act]
+        cfg.time_dep = int(self.time_dep)
+        cfg.pre_act = int(getattr(self.model, "pre_act", False))
+        cfg.max_batch = self.max_batch
+        cfg.solver = 0
+        cfg.reltol = float(self.kwargs.get("reltol", 1e-3))   # OrdinaryDiffEq defaults when not given
+        cfg.abstol = float(self.kwargs.get("abstol", 1e-6))
+        cfg.regularize = _FUNCS[func] if self.regularize else 0
+        cfg.cb_save_start = int(self.cb_save_start)
+        cfg.track_ctrl = int(self.track_ctrl)
+        cfg.track_initdt = int(self.track_initdt)
+        cfg.max_attempts = self.max_attempts
+        cfg.device = device_index
+        cfg.col_tile = self.col_tile
+        return cfg
+
+    def _acquire(self, x, keep_tape, func=None):
+        key = (x.device.index or 0, bool(keep_tape), self._func)
+        hs = self._handles.setdefault(key, [])
+        for h in hs:
+            if not h.busy:
+                return h
+        h = _Handle(self._config(x.device.index or 0, self._func))
+        hs.append(h)
+        return h
+
+    # -- call operator ------------------------------------------------------------------------
+    def __call__(self, x, p=None, func=None, tspan=None, saveat=None):
+        """(x, p = n.p; func, tspan, saveat) -> (res, nfe, sv)   [neural_ode.jl:48-54,:76,:110-119,:143]"""
+        if saveat is not None:
+            raise NotImplementedError("saveat override (neural_ode.jl:35-46): next row")
+        if not x.is_cuda:
+            raise RuntimeError("TrackedNeuralODE runs on the MI355X only: x must be a cuda tensor (no CPU fallback)")
+        p = self.p if p is None else p
+        if p.device != x.device:
+            if p is self.p:
+                self.p = p = self.p.to(x.device)
+            else:
+                raise RuntimeError("p and x must live on the same device")
+        x2 = x.reshape(x.shape[0], -1).to(torch.float32).contiguous()
+        ts = self.tspan if tspan is None else [float(tspan[0]), float(tspan[1])]   # _convert_tspan, utils.jl:21-23
+        self._func = func if self.regularize else None
+        keep = torch.is_grad_enabled() and (x2.requires_grad or p.requires_grad)
+        u, saveval = _Solve.apply(x2, p.contiguous(), self, ts[0], ts[1], keep)
+        sv = SavedValues(saveval) if self.regularize else None
+        return u, self.last_nfe, sv

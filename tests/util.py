@@ -1,0 +1,106 @@
+"""Shared helpers for the parity tests: device-side wrappers that go through the C ABI only."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+import regneuralde_jl_amd as rn
+from regneuralde_jl_amd import _lib
+from oracle.oracle import Oracle, arch_mnist, arch_test_node, glorot_params, make_arch  # test infrastructure
+
+
+def make_cfg(dims, acts, max_batch, reltol=1.4e-8, abstol=1.4e-8, regularize=1, max_attempts=128, col_tile=0,
+             cb_save_start=1, track_ctrl=1, track_initdt=1):
+    cfg = _lib.NodeConfig()
+    cfg.n_layers = len(acts)
+    for i, d in enumerate(dims):
+        cfg.dims[i] = d
+    for i, a in enumerate(acts):
+        cfg.act[i] = {"identity": 0, "tanh": 1}[a]
+    cfg.time_dep = 1
+    cfg.pre_act = 0
+    cfg.max_batch = max_batch
+    cfg.solver = 0
+    cfg.reltol, cfg.abstol = reltol, abstol
+    cfg.regularize = regularize
+    cfg.cb_save_start, cfg.track_ctrl, cfg.track_initdt = cb_save_start, track_ctrl, track_initdt
+    cfg.max_attempts = max_attempts
+    cfg.device = 0
+    cfg.col_tile = col_tile
+    return cfg
+
+
+class Node:
+    """Thin RAII wrapper over the C ABI handle (device pointers in, device pointers out)."""
+
+    def __init__(self, cfg):
+        self.L = _lib.lib()
+        self.h = C.c_void_p()
+        _lib.check(None, self.L.rnde_node_create(C.byref(cfg), C.byref(self.h)))
+        self.cfg = cfg
+        self.D = cfg.dims[0]
+
+    def close(self):
+        if self.h:
+            self.L.rnde_node_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+    def feval(self, u, p, t):
+        ud, pd = self.dev(u), self.dev(p)
+        out = torch.empty_like(ud)
+        _lib.check(self.h, self.L.rnde_debug_feval(self.h, ud.data_ptr(), pd.data_ptr(), u.shape[0], t, out.data_ptr(), None))
+        return out.cpu().numpy()
+
+    def attempt(self, uprev, k1, p, t, dt):
+        B = uprev.shape[0]
+        ud, kd, pd = self.dev(uprev), self.dev(k1), self.dev(p)
+        kout = torch.empty((6, B, self.D), dtype=torch.float32, device="cuda")
+        unew = torch.empty_like(ud)
+        eest = C.c_float(0)
+        _lib.check(self.h, self.L.rnde_debug_attempt(self.h, ud.data_ptr(), kd.data_ptr(), pd.data_ptr(), B, t, dt,
+                                                     kout.data_ptr(), unew.data_ptr(), C.byref(eest), None))
+        return kout.cpu().numpy(), unew.cpu().numpy(), eest.value
+
+    def forward(self, x, p, t0=0.0, t1=1.0, keep_tape=False):
+        B = x.shape[0]
+        xd, pd = self.dev(x), self.dev(p)
+        u = torch.empty_like(xd)
+        nfe = C.c_int64(0)
+        nsv = C.c_int32(0)
+        sv = (C.c_float * (self.cfg.max_attempts + 1))()
+        st = self.L.rnde_node_forward(self.h, xd.data_ptr(), pd.data_ptr(), B, t0, t1, u.data_ptr(), C.byref(nfe), sv,
+                                      C.byref(nsv), int(keep_tape), None)
+        _lib.check(self.h, st)
+        steps = (C.c_float * (4 * self.cfg.max_attempts))()
+        natt = C.c_int32(0)
+        self.L.rnde_node_steps(self.h, steps, self.cfg.max_attempts, C.byref(natt))
+        return dict(u=u.cpu().numpy(), nfe=nfe.value, saveval=np.array(sv[:nsv.value], dtype=np.float32),
+                    steps=np.array(steps[:4 * natt.value], dtype=np.float32).reshape(-1, 4), nattempts=natt.value)
+
+    def backward(self, ubar, svbar=None):
+        B = ubar.shape[0]
+        ub = self.dev(ubar)
+        xb = torch.empty_like(ub)
+        P = self.L.rnde_param_count(C.byref(self.cfg))
+        pb = torch.empty(P, dtype=torch.float32, device="cuda")
+        tsb = (C.c_float * 2)()
+        svb = None if svbar is None else (C.c_float * len(svbar))(*[float(v) for v in svbar])
+        st = self.L.rnde_node_backward(self.h, ub.data_ptr(), svb, xb.data_ptr(), pb.data_ptr(), tsb, None)
+        _lib.check(self.h, st)
+        return xb.cpu().numpy(), pb.cpu().numpy(), np.array([tsb[0], tsb[1]], dtype=np.float32)
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)

@@ -1,0 +1,184 @@
+#!/usr/bin/env python
+"""bench.py -- training-step throughput of the MNIST Neural ODE (BASELINE.json metric).
+
+One "step" = the reference's timed window (experiments/mnist_node.jl:228-234): loss forward (adaptive Tsit5
+solve, reltol = abstol = 1.4e-8, error-estimate regulariser), reverse pass through the solver, optimiser
+update -- on one batch of 512 synthetic MNIST-shaped images per GPU, already resident in HBM.
+N > 1: one process per GPU (torchrun), batch sharded 512 per rank (weak scaling, config "batch 4096 sharded
+8xMI355X"), one RCCL all-reduce of the flat gradient (166,418 fp32) per step.
+
+Prints ONE JSON line on rank 0.  Extra objects:
+  roofline      the dominant kernel (rnde_step_kernel = one attempted Tsit5 step) timed live with HIP events
+  cpu_baseline  the CPU restatement (oracle/, OpenMP) timed on a bounded sample of the same workload
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+D, H, NCLS = 784, 100, 10
+P_DYN = (D + 1) * H + H + (H + 1) * D + D          # 158,568
+ALG_BYTES = lambda B: 34 * 4 * D * B + 6 * 4 * P_DYN   # 34 A + 24 P per attempted step
+ALG_FLOPS = lambda B: 6 * 2 * B * ((D + 1) * H + (H + 1) * D)
+HBM_PEAK_GBS = 8000.0                              # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3
+
+
+def build_model(rn, device, batch, seed=1999):
+    g = torch.Generator().manual_seed(seed)
+    dyn = rn.MLPDynamics(D, H, generator=g)
+    node = rn.TrackedNeuralODE(dyn, [0.0, 1.0], True, True, "Tsit5", save_everystep=False, reltol=1.4e-8,
+                               abstol=1.4e-8, save_start=False, max_batch=batch, max_attempts=160)
+    post = rn.Dense(D, NCLS, "identity", generator=g)
+    model = rn.ClassifierNODE(node, post, device=device)
+    return model
+
+
+def cpu_baseline(batch=48, steps=1):
+    """CPU restatement of the same training step (oracle fp32 + numpy head) on a bounded sample."""
+    import numpy as np
+    from oracle.oracle import Oracle, arch_mnist, glorot_params
+    rng = np.random.default_rng(1999)
+    arch = arch_mnist(D, H)
+    orc = Oracle(arch, np.float32, reltol=1.4e-8, abstol=1.4e-8, reg_kind=1, max_attempts=400)
+    p = glorot_params(arch, rng)
+    W3 = rng.uniform(-0.0869, 0.0869, (D, NCLS)).astype(np.float32)
+    x = rng.uniform(0, 1, (batch, D)).astype(np.float32)
+    y = np.eye(NCLS, dtype=np.float32)[rng.integers(0, NCLS, batch)]
+
+    def step():
+        r = orc.forward(x, p)
+        logits = r["u"] @ W3
+        z = logits - logits.max(1, keepdims=True)
+        sm = np.exp(z) / np.exp(z).sum(1, keepdims=True)
+        ubar = ((sm - y) / batch) @ W3.T
+        svbar = np.full(len(r["saveval"]), 100.0 / len(r["saveval"]), dtype=np.float32)
+        orc.backward(ubar.astype(np.float32), svbar)
+        return r["nfe"]
+
+    step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        nfe = step()
+    dt = (time.perf_counter() - t0) / steps
+    cores = len(os.sched_getaffinity(0))
+    return {"value": batch / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} training step(s), batch {batch} of the same MNIST-NODE workload (fp32 CPU restatement, "
+                      f"OpenMP over {cores} threads; NOT the Julia reference, which cannot run here)", "nfe": int(nfe)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=512, help="per-GPU batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--col-tile", type=int, default=0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the integration path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import regneuralde_jl_amd as rn
+    B = args.batch
+    model = build_model(rn, device, B)
+    model.node.col_tile = args.col_tile
+    opt = rn.FluxOptimiser(model.trainable())
+    g = torch.Generator().manual_seed(1999 + rank)
+    x = torch.rand(B, 1, 28, 28, generator=g).to(device)                  # uniform [0,1) images, mnist_node.jl:206
+    y = torch.eye(NCLS)[torch.randint(0, NCLS, (B,), generator=g)].to(device)
+    flat = torch.zeros(model.p2.numel() + model.p3.numel(), device=device)
+    nfes = []
+
+    def train_step():
+        loss, ce, reg, nfe = rn.loss_function(x, y, model, lam=1.0e2)
+        loss.backward()
+        if world > 1:
+            n2 = model.p2.numel()
+            flat[:n2].copy_(model.p2.grad)
+            flat[n2:].copy_(model.p3.grad)
+            dist.all_reduce(flat)                                         # RCCL sum over xGMI
+            model.p2.grad.copy_(flat[:n2] / world)
+            model.p3.grad.copy_(flat[n2:] / world)
+        opt.step()
+        nfes.append(nfe)
+        return float(loss)
+
+    for _ in range(args.warmup):
+        train_step()
+    nfes.clear()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last_loss = train_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        nf = torch.tensor([sum(nfes) / len(nfes)], device=device, dtype=torch.float64)
+        dist.all_reduce(nf)
+        mean_nfe = float(nf.item()) / world
+    else:
+        mean_nfe = sum(nfes) / len(nfes)
+
+    out = None
+    if rank == 0:
+        # --- roofline leg: the step kernel alone, HIP events on the launch stream ---
+        from regneuralde_jl_amd import _lib
+        L = _lib.lib()
+        h = model.node._acquire(x.reshape(B, -1), False)
+        us = C.c_float(0)
+        xs = x.reshape(B, -1).contiguous()
+        stream = torch.cuda.current_stream(device).cuda_stream
+        _lib.check(h.ptr, L.rnde_bench_attempt(h.ptr, xs.data_ptr(), model.p2.data_ptr(), B, 200, C.byref(us), C.c_void_p(stream)))
+        t_att = us.value * 1e-6
+        roof = {"bound": "hbm", "achieved": ALG_BYTES(B) / t_att / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ALG_BYTES(B) / t_att / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "rnde_step_kernel", "us_per_launch": us.value,
+                "alg_bytes_per_launch": ALG_BYTES(B), "mfma_f32_tflops": ALG_FLOPS(B) / t_att / 1e12,
+                "mfma_frac": ALG_FLOPS(B) / t_att / 1e12 / MFMA_F32_PEAK_TF}
+        out = {"metric": "training-step samples/sec + mean NFE, MNIST Neural ODE bs=512",
+               "value": world * B * args.steps / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "mean_nfe": mean_nfe, "final_loss": last_loss,
+               "config": {"workload": "MNIST NODE regularized (error_est), Tsit5 reltol=abstol=1.4e-8, batch 512 per GPU, "
+                                      "1xMI355X per rank; step = loss fwd + reverse pass through the solver + "
+                                      "InvDecay/Momentum update", "global_batch": world * B,
+                          "parallelism": f"dp{world}" if world > 1 else "single"},
+               "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

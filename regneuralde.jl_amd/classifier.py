@@ -1,0 +1,95 @@
+"""Callers of the hot path, mirrored so the reference's training step runs end to end:
+
+ClassifierNODE        reference src/models/supervised_classification.jl:2-46
+loss_function         reference experiments/mnist_node.jl:132-152
+Optimiser(InvDecay(1e-5), Momentum(0.1, 0.9)) + update_parameters!
+                      reference experiments/mnist_node.jl:130, src/utils.jl:149-156
+
+The pre/post layers, the loss and the optimiser are a few tiny PyTorch ops around the solve; the
+integration itself (forward and reverse) is librnde.so.
+"""
+import math
+
+import torch
+
+from .layers import Dense
+from .node import TrackedNeuralODE
+
+
+class ClassifierNODE:
+    """preode (reshape to 784 x B) -> TrackedNeuralODE -> postode Dense(784, 10).  Parameters are the flat
+    vectors (p1, p2, p3) exactly as Flux.destructure produces them (supervised_classification.jl:9-13)."""
+
+    def __init__(self, node: TrackedNeuralODE, post: Dense, device="cuda"):
+        self.node = node
+        self.post_shape = (post.n_in, post.n_out)
+        self.p1 = torch.zeros(0, device=device)                                     # reshape has no parameters
+        self.p2 = node.p.to(device).clone().requires_grad_(True)
+        self.p3 = torch.cat([post.W.reshape(-1), post.b]).to(device).clone().requires_grad_(True)
+
+    def trainable(self):
+        return (self.p1, self.p2, self.p3)
+
+    def __call__(self, x, p1=None, p2=None, p3=None, **node_kwargs):
+        p2 = self.p2 if p2 is None else p2
+        p3 = self.p3 if p3 is None else p3
+        x = x.reshape(x.shape[0], -1)                                               # Chain(x -> reshape(x, 784, :))
+        u, nfe, sv = self.node(x, p2, **node_kwargs)
+        n_in, n_out = self.post_shape
+        W = p3[: n_in * n_out].view(n_in, n_out)                                    # (in, out) row-major == out x in col-major
+        b = p3[n_in * n_out:]
+        return u @ W + b, nfe, sv
+
+
+def logitcrossentropy(pred, y_onehot):
+    """Flux.Losses.logitcrossentropy: mean over the batch of -sum(y .* logsoftmax(pred))."""
+    return -(y_onehot * torch.log_softmax(pred, dim=1)).sum(dim=1).mean()
+
+
+def loss_function(x, y, model, p1=None, p2=None, p3=None, lam=1.0e2, regularize=True, agg=torch.mean, func="error_est",
+                  tspan=None):
+    """experiments/mnist_node.jl:132-137: cross entropy + lambda * agg(sv.saveval)."""
+    pred, nfe, sv = model(x, p1, p2, p3, func=func, tspan=tspan)
+    ce = logitcrossentropy(pred, y)
+    reg = lam * agg(sv.saveval) if regularize else torch.zeros((), device=pred.device)
+    return ce + reg, ce.detach(), reg.detach(), nfe
+
+
+class FluxOptimiser:
+    """Flux.Optimise.Optimiser(InvDecay(gamma), Momentum(eta, rho)) applied group by group
+    (reference src/utils.jl:149-156 skips empty groups)."""
+
+    def __init__(self, params, gamma=1.0e-5, eta=0.1, rho=0.9):
+        self.params = [p for p in params if p.numel() > 0]
+        self.gamma, self.eta, self.rho = gamma, eta, rho
+        self.n = [1 for _ in self.params]                 # InvDecay state starts at 1
+        self.v = [torch.zeros_like(p) for p in self.params]
+
+    @torch.no_grad()
+    def step(self, grads=None):
+        for i, p in enumerate(self.params):
+            g = p.grad if grads is None else grads[i]
+            if g is None:
+                continue
+            g = g / (1.0 + self.gamma * self.n[i])         # InvDecay
+            self.n[i] += 1
+            self.v[i].mul_(self.rho).sub_(g, alpha=self.eta)   # Momentum: v = rho v - eta g ; x -= -v
+            p.add_(self.v[i])
+            p.grad = None
+
+
+def lambda_schedule(epoch, epochs=75, lam0=1.0e2, lam1=1.0e1):
+    """experiments/mnist_node.jl:65-66,:106-108: exponential decay from lam0 to lam1 over the run."""
+    k = math.log(lam0 / lam1) / epochs
+    return lam0 * math.exp(-k * epoch)
+
+
+def accuracy(model, batches):
+    """reference src/metrics.jl:4-18 (argmax match), without the forced GC."""
+    correct = total = 0
+    with torch.no_grad():
+        for x, y in batches:
+            pred, _, _ = model(x)
+            correct += (pred.argmax(1) == y.argmax(1)).sum().item()
+            total += x.shape[0]
+    return correct / max(total, 1)

@@ -219,6 +219,7 @@ extern "C" rnde_status rnde_node_forward(rnde_node* h, const float* x_dev, const
         rnde_status st = ensure_arena(h, h->cfg.max_attempts);
         if (st != RNDE_OK) return st;
         // the tape owns copies of x and p (the caller may free or overwrite its buffers before backward)
+        if (B % h->BT) HIPCHK(h, hipMemsetAsync(h->xcopy, 0, (size_t)h->D * (((B + h->BT - 1) / h->BT) * h->BT) * 4, s));
         HIPCHK(h, hipMemcpyAsync(h->xcopy, x_dev, (size_t)h->D * B * 4, hipMemcpyDeviceToDevice, s));
         HIPCHK(h, hipMemcpyAsync(h->pcopy, p_dev, (size_t)h->P * 4, hipMemcpyDeviceToDevice, s));
         x_dev = h->xcopy;
@@ -385,7 +386,114 @@ extern "C" rnde_status rnde_bench_attempt(rnde_node* h, const float* x_dev, cons
     return RNDE_OK;
 }
 
-static rnde_status bwd_run(rnde_node* h, const float*, const float*, float*, float*, float*, hipStream_t) {
-    h->err = "reverse pass not built";
-    return RNDE_ERR_BAD_ARG;
+// ---- reverse pass driver ------------------------------------------------------------------------
+static size_t bwd_lds_bytes(const rnde_node* h) { return h->lds_bytes + sizeof(float) * 7 * 2 * h->BT; }
+
+static rnde_status bwd_prepare(rnde_node* h) {
+    BwdBuffers& b = h->bw;
+    if (b.ready) return RNDE_OK;
+    const size_t A = (size_t)h->D * h->Bpad_max, HB = (size_t)h->H * h->Bpad_max;
+    const int cap = h->cfg.max_attempts;
+    HIPCHK(h, hipMalloc((void**)&b.U, A * 4)); HIPCHK(h, hipMalloc((void**)&b.K1, A * 4)); HIPCHK(h, hipMalloc((void**)&b.UB1, A * 4));
+    HIPCHK(h, hipMalloc((void**)&b.zi2, 2 * A * 4)); HIPCHK(h, hipMalloc((void**)&b.zi1, 2 * HB * 4));
+    HIPCHK(h, hipMalloc((void**)&b.svb_att, (size_t)cap * 4));
+    HIPCHK(h, hipMalloc((void**)&b.bstate, 2 * sizeof(BState))); HIPCHK(h, hipMalloc((void**)&b.ibstate, 2 * sizeof(IBState)));
+    HIPCHK(h, hipMalloc((void**)&b.bpart, (size_t)2 * h->nwg_max * 4 * 4)); HIPCHK(h, hipMalloc((void**)&b.ipart, (size_t)2 * h->nwg_max * 4 * 4));
+    HIPCHK(h, hipMalloc((void**)&b.tspan_out, 2 * 4));
+    const size_t nev = (size_t)6 * cap + 2;
+    HIPCHK(h, hipMalloc((void**)&b.ev1, nev * sizeof(EvalDesc))); HIPCHK(h, hipMalloc((void**)&b.ev2, nev * sizeof(EvalDesc)));
+    HIPCHK(h, hipHostMalloc((void**)&b.h_ev1, nev * sizeof(EvalDesc))); HIPCHK(h, hipHostMalloc((void**)&b.h_ev2, nev * sizeof(EvalDesc)));
+    HIPCHK(h, hipHostMalloc((void**)&b.h_svb, (size_t)cap * 4));
+    const size_t seg = std::max((size_t)h->H * (h->D + 2), (size_t)h->D * (h->H + 2));
+    b.slab_floats = seg * 128;
+    HIPCHK(h, hipMalloc((void**)&b.slab, b.slab_floats * 4));
+    b.ready = true;
+    return RNDE_OK;
+}
+
+template <int NG, int ACT2>
+static hipError_t launch_bwd_t(rnde_node* h, const BwdParams& Q, int n_att, hipStream_t s) {
+    const size_t lds = bwd_lds_bytes(h);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)rnde_bstep_kernel<NG, ACT2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rnde_binit_kernel<NG, ACT2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rnde_binit_kernel<NG, ACT2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    for (int n = n_att - 1; n >= 0; --n) hipLaunchKernelGGL((rnde_bstep_kernel<NG, ACT2>), dim3(Q.F.nwg), dim3(kThreads), lds, s, Q, n);
+    hipLaunchKernelGGL((rnde_binit_kernel<NG, ACT2, 1>), dim3(Q.F.nwg), dim3(kThreads), lds, s, Q);
+    hipLaunchKernelGGL((rnde_binit_kernel<NG, ACT2, 2>), dim3(Q.F.nwg), dim3(kThreads), lds, s, Q);
+    hipLaunchKernelGGL(rnde_bfin_kernel, dim3(1), dim3(64), 0, s, Q);
+    return hipGetLastError();
+}
+
+static rnde_status launch_wgrad(rnde_node* h, const EvalDesc* ev, int n_evals, int M, int Nx, int Bpad, float* out, hipStream_t s) {
+    const int mtiles = (M + 31) / 32, ntiles = (Nx + 2 + 31) / 32;
+    const bool tall = M >= Nx;  // layer 2: M = D; layer 1: M = H
+    const int MB = tall ? 2 : 4, NB = tall ? 4 : 2;
+    const int blocks = ((mtiles + MB - 1) / MB) * ((ntiles + NB - 1) / NB);
+    const long long len = (long long)M * (Nx + 2);
+    int chunks = std::max(1, std::min(std::min(n_evals, 128), (1024 + blocks - 1) / blocks));
+    chunks = (int)std::min<long long>(chunks, (long long)(h->bw.slab_floats / (size_t)len));
+    const int per_chunk = (n_evals + chunks - 1) / chunks;
+    chunks = (n_evals + per_chunk - 1) / per_chunk;
+    if (tall) hipLaunchKernelGGL((rnde_wgrad_kernel<2, 4>), dim3(blocks, chunks), dim3(64), 0, s, ev, n_evals, per_chunk, M, Nx, Bpad, h->bw.slab);
+    else hipLaunchKernelGGL((rnde_wgrad_kernel<4, 2>), dim3(blocks, chunks), dim3(64), 0, s, ev, n_evals, per_chunk, M, Nx, Bpad, h->bw.slab);
+    HIPCHK(h, hipGetLastError());
+    const int grid = (int)std::min<long long>((len + 255) / 256, 2048);
+    hipLaunchKernelGGL(rnde_wgrad_reduce, dim3(grid), dim3(256), 0, s, h->bw.slab, chunks, len, out);
+    HIPCHK(h, hipGetLastError());
+    return RNDE_OK;
+}
+
+static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* saveval_bar_host, float* x_bar_dev,
+                           float* p_bar_dev, float* tspan_bar_host, hipStream_t s) {
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    rnde_status st = bwd_prepare(h);
+    if (st != RNDE_OK) return st;
+    BwdBuffers& b = h->bw;
+    const int n_att = h->n_att;
+    for (int i = 0; i < n_att; ++i)
+        b.h_svb[i] = (saveval_bar_host && h->sv_index[i] >= 0) ? saveval_bar_host[h->sv_index[i]] : 0.f;
+    HIPCHK(h, hipMemcpyAsync(b.svb_att, b.h_svb, (size_t)n_att * 4, hipMemcpyHostToDevice, s));
+    BwdParams Q{};
+    Q.F = make_params(h, h->xcopy, h->B, h->t0, h->t1, 1);
+    Q.pw2t = h->pw2t; Q.pw1t = h->pw1t; Q.K4_2t = h->K4_2t; Q.MT2t = h->MT2t; Q.K4_1t = h->K4_1t; Q.MT1t = h->MT1t;
+    Q.U = b.U; Q.K1 = b.K1; Q.UB1 = b.UB1; Q.zi2 = b.zi2; Q.zi1 = b.zi1; Q.svb_att = b.svb_att;
+    Q.bstate = b.bstate; Q.ibstate = b.ibstate; Q.bpart = b.bpart; Q.ipart = b.ipart;
+    Q.ubar = u_bar_dev; Q.xbar = x_bar_dev; Q.tspan_out = b.tspan_out;
+    Q.n_att = n_att; Q.track_ctrl = h->cfg.track_ctrl; Q.track_initdt = h->cfg.track_initdt; Q.reg_kind = h->cfg.regularize;
+    hipError_t e;
+    if (h->NG == 1) e = h->act2 ? launch_bwd_t<1, 1>(h, Q, n_att, s) : launch_bwd_t<1, 0>(h, Q, n_att, s);
+    else e = h->act2 ? launch_bwd_t<2, 1>(h, Q, n_att, s) : launch_bwd_t<2, 0>(h, Q, n_att, s);
+    HIPCHK(h, e);
+    // parameter gradient: evaluation descriptors for the two batched GEMMs
+    const long long A = (long long)h->D * Q.F.Bpad, HB = (long long)h->H * Q.F.Bpad;
+    RecLayout L{A, HB};
+    int ne = 0;
+    for (int n = 0; n < n_att; ++n) {
+        const StepMeta& m = h->h_meta[n];
+        const float* R = h->arena + (long long)m.rec * h->rec_stride;
+        for (int sidx = 2; sidx <= 7; ++sidx) {
+            const float ts = m.t + tsC(sidx - 1) * m.dt;
+            b.h_ev2[ne] = EvalDesc{R + L.k(sidx), R + L.h(sidx), ts, 0};
+            b.h_ev1[ne] = EvalDesc{R + L.z1(sidx), sidx < 7 ? R + L.g(sidx) : R + L.unew(), ts, 0};
+            ++ne;
+        }
+    }
+    b.h_ev2[ne] = EvalDesc{b.zi2, h->h0, h->t0, 0};           b.h_ev1[ne] = EvalDesc{b.zi1, h->xcopy, h->t0, 0}; ++ne;
+    b.h_ev2[ne] = EvalDesc{b.zi2 + A, h->h1, h->t0 + h->h_init->dt0, 0}; b.h_ev1[ne] = EvalDesc{b.zi1 + HB, h->u1, h->t0 + h->h_init->dt0, 0}; ++ne;
+    HIPCHK(h, hipMemcpyAsync(b.ev1, b.h_ev1, (size_t)ne * sizeof(EvalDesc), hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(b.ev2, b.h_ev2, (size_t)ne * sizeof(EvalDesc), hipMemcpyHostToDevice, s));
+    st = launch_wgrad(h, b.ev1, ne, h->H, h->D, Q.F.Bpad, p_bar_dev, s);                                   // [W1; b1]
+    if (st != RNDE_OK) return st;
+    st = launch_wgrad(h, b.ev2, ne, h->D, h->H, Q.F.Bpad, p_bar_dev + (size_t)h->H * (h->D + 2), s);       // [W2; b2]
+    if (st != RNDE_OK) return st;
+    HIPCHK(h, hipMemcpyAsync(h->h_scal, b.tspan_out, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    if (tspan_bar_host) { tspan_bar_host[0] = h->h_scal[0]; tspan_bar_host[1] = h->h_scal[1]; }
+    h->have_tape = false;  // z2bar overwrote k_s in place: the tape is consumed
+    return RNDE_OK;
 }

@@ -1,9 +1,533 @@
-// rnde_bwd.h -- reverse pass (placeholder until the kernels land; returns an error, never a CPU fallback)
+// rnde_bwd.h -- reverse pass kernels (discretise-then-optimise).
+//
+// Replaces what Tracker.gradient (reference experiments/mnist_node.jl:229-232) does over the taped
+// `solve` when sensealg = SensitivityADPassThrough() (reference src/models/neural_ode.jl:134): the exact
+// derivative of the discrete Tsit5 program, including t, dt, EEst and the PI controller.
+//
+// Structure (mirror image of the forward):
+//   rnde_bstep_kernel   one attempted step, reverse: the workgroup owns the same BT batch columns,
+//                       the cotangents of k1..k6 and uprev live in registers for the whole attempt,
+//                       J_f^T products run on the same two GEMM routines with transposed packed weights.
+//   rnde_binit_kernel   reverse of k1 = f(u0,t0) and of the initial-step heuristic (2 phases).
+//   rnde_wgrad_kernel   parameter gradient as two large batched GEMMs over ALL f evaluations of the
+//                       solve (K = evaluations x batch), off the latency-critical sweep; deterministic
+//                       (fixed-order slab reduction, no float atomics).
 #pragma once
-#include "rnde_device.h"
-struct rnde_node;
+#include "rnde_fwd.h"
+
 namespace rnde {
-struct BwdBuffers { int dummy; };
-inline void bwd_free(BwdBuffers&) {}
+
+struct BState {  // per attempt scalar cotangents produced by that attempt's prologue
+    double tb_pre, dtb_pre, qoldb, t1b, t0b, pad[3];
+};
+struct IBState {
+    double tb, t1b, t0b, dt0b, d1b, d2b, coef_w, pad;
+};
+struct EvalDesc {  // one f evaluation for the parameter-gradient GEMMs
+    const float* Z;  // cotangent of the layer pre-activation, M x Bpad
+    const float* X;  // layer input, Nx x Bpad
+    float t;
+    int pad;
+};
+
+struct BwdParams {
+    StepParams F;
+    const f32x4* pw2t; const f32x4* pw1t;
+    int K4_2t, MT2t, K4_1t, MT1t;
+    float* U; float* K1; float* UB1;   // running cotangents of (uprev, k1); u1bar of the initial-step heuristic
+    float* zi2; float* zi1;            // [2][A], [2][HB]: z2bar/z1bar of the evaluations at (u0,t0) and (u1,t0+dt0)
+    const float* svb_att;              // saveval cotangent per attempt (0 where the callback did not fire)
+    BState* bstate;                    // [2]
+    IBState* ibstate;                  // [2]
+    float* bpart;                      // [2][nwg][4]
+    float* ipart;                      // [2][nwg][4]
+    const float* ubar;                 // caller layout
+    float* xbar;                       // caller layout
+    float* tspan_out;                  // [2]
+    int n_att, track_ctrl, track_initdt, reg_kind;
+};
+
+struct BwdBuffers {
+    float *U = nullptr, *K1 = nullptr, *UB1 = nullptr, *zi2 = nullptr, *zi1 = nullptr, *svb_att = nullptr;
+    BState* bstate = nullptr;
+    IBState* ibstate = nullptr;
+    float *bpart = nullptr, *ipart = nullptr, *tspan_out = nullptr;
+    EvalDesc *ev1 = nullptr, *ev2 = nullptr;
+    float *slab = nullptr;
+    size_t slab_floats = 0;
+    EvalDesc *h_ev1 = nullptr, *h_ev2 = nullptr;  // pinned
+    float* h_svb = nullptr;
+    bool ready = false;
+};
+inline void bwd_free(BwdBuffers& b) {
+    void* d[] = {b.U, b.K1, b.UB1, b.zi2, b.zi1, b.svb_att, b.bstate, b.ibstate, b.bpart, b.ipart, b.tspan_out, b.ev1, b.ev2, b.slab};
+    for (void* p : d) if (p) (void)hipFree(p);
+    if (b.h_ev1) (void)hipHostFree(b.h_ev1);
+    if (b.h_ev2) (void)hipHostFree(b.h_ev2);
+    if (b.h_svb) (void)hipHostFree(b.h_svb);
+    b = BwdBuffers{};
 }
-static rnde_status bwd_run(rnde_node* h, const float*, const float*, float*, float*, float*, hipStream_t);
+
+__device__ __forceinline__ float sgnf(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+
+// ------------------------------------------------------------------------------------------
+// J_f^T product for the workgroup's columns.  zb2 = cotangent of the layer-2 pre-activation in the
+// ownership layout.  Stores z2bar (to z2dst) and z1bar (to z1dst) for the parameter-gradient GEMMs,
+// returns gbar (cotangent of the f input) in the ownership layout, and leaves the two time
+// cotangents per column in TAU[0..BT) (layer 2) and TAU[BT..2BT) (layer 1).
+// ------------------------------------------------------------------------------------------
+template <int NG>
+__device__ __forceinline__ void f_bwd(const BwdParams& Q, float* GL, float* HL, float* PART, float* TAU,
+                                      const f32x4 (&zb2)[Geo<NG>::TPW], const float* __restrict__ hsrc,
+                                      float* __restrict__ z2dst, float* __restrict__ z1dst, int col0, int gcol,
+                                      const Own<NG>& own, f32x4 (&gb)[Geo<NG>::TPW], int tid) {
+    using G = Geo<NG>;
+    const StepParams& P = Q.F;
+    const int lane = tid & 63, wave = tid >> 6;
+    const bool vec = (P.D & 3) == 0;
+#pragma unroll
+    for (int j = 0; j < G::TPW; ++j) {
+        put_g<NG>(P, GL, own, j, zb2[j]);
+        st_tile(z2dst + (size_t)gcol * P.D, own.row0[j], P.D, true, vec, zb2[j]);
+    }
+    __syncthreads();
+    {
+        f32x4 acc[G::MTS];
+        gemm_ksplit<NG>(Q.pw2t, Q.MT2t, Q.K4_2t, GL, P.KS1, acc, wave, lane);
+#pragma unroll
+        for (int T = 0; T < G::MTS; ++T)
+            if (T < Q.MT2t) *(f32x4*)(PART + ((wave * G::MTS + T) * 64 + lane) * 4) = acc[T];
+    }
+    __syncthreads();
+    const int H1 = P.H + 1;
+    for (int o = tid; o < H1 * G::BT; o += kThreads) {
+        const int c = o / H1, r = o - c * H1;
+        const int idx = part_index<NG>(r, c);
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) v += PART[w * G::MTS * 256 + idx];
+        if (r < P.H) {
+            const float hv = hsrc[(size_t)(col0 + c) * P.H + r];
+            const float z = v * (1.f - hv * hv);
+            HL[c * P.KS2 + r] = z;
+            z1dst[(size_t)(col0 + c) * P.H + r] = z;
+        } else {
+            TAU[c] = v;
+        }
+    }
+    __syncthreads();
+    gemm_rows<NG>(Q.pw1t, Q.MT1t, Q.K4_1t, HL, P.KS2, gb, wave, lane);
+#pragma unroll
+    for (int j = 0; j < G::TPW; ++j) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = own.row0[j] + i;
+            if (r == P.D) TAU[G::BT + own.col] = gb[j][i];
+            if (r >= P.D) gb[j][i] = 0.f;
+        }
+    }
+}
+
+// finish the scalar chain of attempt m (its vector part ran in the previous launch) -> cotangents of the
+// state before attempt m.  part = that launch's per-workgroup partials {S, tau, ctau, -}.
+__device__ __forceinline__ void finish_attempt_scalars(const BwdParams& Q, int m, int lane, double& tb, double& dtpb,
+                                                       double& qoldb, double& t1b, double& t0b) {
+    const BState b = Q.bstate[m & 1];
+    const StepMeta mm = Q.F.meta[m];
+    const float* part = Q.bpart + (size_t)(m & 1) * Q.F.nwg * 4;
+    double S = 0, tau = 0, ctau = 0;
+    for (int i = lane; i < Q.F.nwg; i += 64) { S += (double)part[4 * i]; tau += (double)part[4 * i + 1]; ctau += (double)part[4 * i + 2]; }
+    S = wave_sum_d(S); tau = wave_sum_d(tau); ctau = wave_sum_d(ctau);
+    const double dtb = b.dtb_pre + S / (double)mm.dt + ctau;
+    double tbx = b.tb_pre + tau;
+    t1b = b.t1b; t0b = b.t0b;
+    if (mm.flags & F_CLAMP) { t1b += dtb; tbx -= dtb; dtpb = 0; } else dtpb = dtb;
+    tb = tbx; qoldb = b.qoldb;
+}
+
+template <int NG, int ACT2>
+__global__ __launch_bounds__(kThreads) void rnde_bstep_kernel(const BwdParams Q, const int n) {
+    using G = Geo<NG>;
+    const StepParams& P = Q.F;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* GL = smem;
+    float* HL = GL + G::BT * P.KS1;
+    float* PART = HL + G::BT * P.KS2;
+    float* RED = PART + kWaves * G::MTS * 256;
+    float* TAU = RED + 64;  // [7][2*BT]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wg = blockIdx.x, col0 = wg * G::BT;
+    const Own<NG> own(wave, lane);
+    const int gcol = col0 + own.col;
+    const bool colok = gcol < P.B;
+    const bool vec = (P.D & 3) == 0;
+    const bool writer = (wg == 0 && tid == 0);
+    const bool first = (n == Q.n_att - 1);
+    const RecLayout L{(long long)P.D * P.Bpad, (long long)P.H * P.Bpad};
+
+    for (int i = tid; i < G::BT * P.KS1; i += kThreads)
+        if (i % P.KS1 >= P.D) GL[i] = 0.f;
+    for (int i = tid; i < G::BT * P.KS2; i += kThreads)
+        if (i % P.KS2 >= P.H) HL[i] = 0.f;
+    for (int i = tid; i < 7 * 2 * G::BT; i += kThreads) TAU[i] = 0.f;
+
+    // ---- scalar chain, identical in every wave ----
+    double tb = 0, dtpb = 0, qoldb = 0, t1b = 0, t0b = 0;
+    if (!first) finish_attempt_scalars(Q, n + 1, lane, tb, dtpb, qoldb, t1b, t0b);
+    const StepMeta m = P.meta[n];
+    const bool accepted = (m.flags & F_ACCEPT) != 0;
+    const float dt = m.dt, t = m.t;
+    float coef;
+    {
+        const double N = (double)P.D * (double)P.B;
+        double eb = 0, dtb_pre = 0, q11b = 0, qb = 0, qoldb_in = 0;
+        if (accepted) {
+            if (Q.reg_kind == 1) { const double sb = (double)Q.svb_att[n]; eb += sb * (double)dt; dtb_pre += sb * (double)m.eest; }
+            dtb_pre += tb;
+            if (m.flags & F_DTMAXCLAMP) { t1b += dtpb; t0b -= dtpb; }
+            else if (Q.track_ctrl) { dtb_pre += dtpb / (double)m.q; qb += -dtpb * (double)dt / ((double)m.q * (double)m.q); }
+            if (m.eest > kQoldInit) eb += qoldb;
+        } else {
+            dtb_pre += dtpb / (double)m.rej_m;
+            if (m.flags & F_REJQ11) q11b += -dtpb * (double)dt / ((double)m.rej_m * (double)m.rej_m) / (double)kGamma;
+            qoldb_in = qoldb;
+        }
+        if (!(m.flags & F_QCLAMP) && !(m.flags & F_EZERO)) {
+            const double qo = pow((double)m.qold_in, (double)kBeta2);
+            q11b += qb / (qo * (double)kGamma);
+            qoldb_in += -(double)kBeta2 * qb * (double)m.q / (double)m.qold_in;
+        }
+        if (!(m.flags & F_EZERO) && m.eest > 0.f) eb += q11b * (double)kBeta1 * (double)m.q11 / (double)m.eest;
+        coef = m.eest > 0.f ? (float)(eb / (N * (double)m.eest)) : 0.f;
+        if (writer) { BState b; b.tb_pre = tb; b.dtb_pre = dtb_pre; b.qoldb = qoldb_in; b.t1b = t1b; b.t0b = t0b; b.pad[0] = b.pad[1] = b.pad[2] = 0; Q.bstate[n & 1] = b; }
+    }
+
+    float* R = P.arena + (long long)m.rec * P.rec_stride;
+    const float* up; const float* k1p; bool upok, upvec;
+    if (m.src < 0) { up = P.x; k1p = P.f0; upok = colok; upvec = P.xvec != 0; }
+    else { const float* Rl = P.arena + (long long)m.src * P.rec_stride; up = Rl + L.unew(); k1p = Rl + L.k(7); upok = true; upvec = vec; }
+
+    // ---- A: reverse of the error estimate; seeds of unew-bar / uprev-bar ----
+    f32x4 utb[G::TPW], unb[G::TPW], upb[G::TPW];
+#pragma unroll
+    for (int j = 0; j < G::TPW; ++j) {
+        const int r0 = own.row0[j];
+        const f32x4 upv = ld_tile(up + (size_t)gcol * P.D, r0, P.D, upok, upvec);
+        const f32x4 unv = ld_tile(R + L.unew() + (size_t)gcol * P.D, r0, P.D, true, vec);
+        f32x4 acc = tsBt(0) * ld_tile(k1p + (size_t)gcol * P.D, r0, P.D, true, vec);
+#pragma unroll
+        for (int s = 2; s <= 7; ++s) acc += tsBt(s - 1) * ld_tile(R + L.k(s) + (size_t)gcol * P.D, r0, P.D, true, vec);
+        f32x4 uin = {0.f, 0.f, 0.f, 0.f};
+        if (accepted) uin = first ? ld_tile(Q.ubar + (size_t)gcol * P.D, r0, P.D, colok, false) : ld_tile(Q.U + (size_t)gcol * P.D, r0, P.D, true, vec);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float ut = dt * acc[i];
+            const float au = fabsf(upv[i]), an = fabsf(unv[i]);
+            const bool use_new = !(au > an);
+            const float sk = P.abstol + (use_new ? an : au) * P.reltol;
+            const float r = ut / sk;
+            const float rb = colok ? coef * r : 0.f;
+            const float skb = -rb * r / sk;
+            utb[j][i] = rb / sk;
+            unb[j][i] = uin[i] + (use_new ? skb * P.reltol * sgnf(unv[i]) : 0.f);
+            upb[j][i] = use_new ? 0.f : skb * P.reltol * sgnf(upv[i]);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // one tile's 10 loads at a time: keeps the live set under 256 VGPRs
+    }
+    float S = 0.f;  // sum_j <k_j, kbar_j (dt-scaled part)>  -> dt-bar = S / dt
+    f32x4 kb[6][G::TPW], gb[G::TPW];
+    // ---- B: stage 7 (k7 = f(unew, t + dt)) ----
+    {
+        f32x4 zb2[G::TPW];
+#pragma unroll
+        for (int j = 0; j < G::TPW; ++j) {
+            const int r0 = own.row0[j];
+            const f32x4 k7 = ld_tile(R + L.k(7) + (size_t)gcol * P.D, r0, P.D, true, vec);
+            f32x4 kb7 = (dt * tsBt(6)) * utb[j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) S += k7[i] * kb7[i];
+            if (accepted && !first) kb7 += ld_tile(Q.K1 + (size_t)gcol * P.D, r0, P.D, true, vec);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) zb2[j][i] = ACT2 ? kb7[i] * (1.f - k7[i] * k7[i]) : kb7[i];
+        }
+        f_bwd<NG>(Q, GL, HL, PART, TAU + 6 * 2 * G::BT, zb2, R + L.h(7), R + L.k(7), R + L.z1(7), col0, gcol, own, gb, tid);
+#pragma unroll
+        for (int j = 0; j < G::TPW; ++j) {
+            unb[j] += gb[j];
+#pragma unroll
+            for (int jj = 0; jj < 6; ++jj) kb[jj][j] = dt * (tsA(6, jj) * unb[j] + tsBt(jj) * utb[j]);
+            upb[j] += unb[j];
+        }
+    }
+    // ---- C: stages 6..2 ----
+#pragma unroll
+    for (int s = 5; s >= 1; --s) {  // zero-based: k_{s+1} = f(g_{s+1}, t + c_s dt)
+        f32x4 zb2[G::TPW];
+#pragma unroll
+        for (int j = 0; j < G::TPW; ++j) {
+            const f32x4 ks = ld_tile(R + L.k(s + 1) + (size_t)gcol * P.D, own.row0[j], P.D, true, vec);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                S += ks[i] * kb[s][j][i];
+                zb2[j][i] = ACT2 ? kb[s][j][i] * (1.f - ks[i] * ks[i]) : kb[s][j][i];
+            }
+        }
+        f_bwd<NG>(Q, GL, HL, PART, TAU + s * 2 * G::BT, zb2, R + L.h(s + 1), R + L.k(s + 1), R + L.z1(s + 1), col0, gcol, own, gb, tid);
+#pragma unroll
+        for (int j = 0; j < G::TPW; ++j) {
+#pragma unroll
+            for (int jj = 0; jj < s; ++jj) kb[jj][j] += (dt * tsA(s, jj)) * gb[j];
+            upb[j] += gb[j];
+        }
+    }
+    // ---- D: k1 and outputs ----
+#pragma unroll
+    for (int j = 0; j < G::TPW; ++j) {
+        const int r0 = own.row0[j];
+        const f32x4 k1v = ld_tile(k1p + (size_t)gcol * P.D, r0, P.D, true, vec);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) S += k1v[i] * kb[0][j][i];
+        f32x4 uo = upb[j], ko = kb[0][j];
+        if (!accepted) {
+            uo += first ? ld_tile(Q.ubar + (size_t)gcol * P.D, r0, P.D, colok, false) : ld_tile(Q.U + (size_t)gcol * P.D, r0, P.D, true, vec);
+            if (!first) ko += ld_tile(Q.K1 + (size_t)gcol * P.D, r0, P.D, true, vec);
+        }
+        st_tile(Q.U + (size_t)gcol * P.D, r0, P.D, true, vec, uo);
+        st_tile(Q.K1 + (size_t)gcol * P.D, r0, P.D, true, vec, ko);
+    }
+    S = wave_sum_f(S);
+    if (lane == 0) RED[wave] = S;
+    __syncthreads();
+    if (tid == 0) {
+        float s = 0.f;
+        for (int w = 0; w < kWaves; ++w) s += RED[w];
+        float tau = 0.f, ctau = 0.f;
+        for (int st = 1; st <= 6; ++st) {
+            float ts = 0.f;
+            for (int c = 0; c < 2 * G::BT; ++c) ts += TAU[st * 2 * G::BT + c];
+            tau += ts;
+            ctau += tsC(st) * ts;
+        }
+        float* o = Q.bpart + ((size_t)(n & 1) * P.nwg + wg) * 4;
+        o[0] = s; o[1] = tau; o[2] = ctau; o[3] = 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Reverse of the initialisation: PHASE 1 = f1 = f(u1, t0 + dt0) of the initial-step heuristic,
+// PHASE 2 = f0 = f(u0, t0) (both fsalfirst and the heuristic's first evaluation) and x-bar.
+// ------------------------------------------------------------------------------------------
+template <int NG, int ACT2, int PHASE>
+__global__ __launch_bounds__(kThreads) void rnde_binit_kernel(const BwdParams Q) {
+    using G = Geo<NG>;
+    const StepParams& P = Q.F;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* GL = smem;
+    float* HL = GL + G::BT * P.KS1;
+    float* PART = HL + G::BT * P.KS2;
+    float* RED = PART + kWaves * G::MTS * 256;
+    float* TAU = RED + 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wg = blockIdx.x, col0 = wg * G::BT;
+    const Own<NG> own(wave, lane);
+    const int gcol = col0 + own.col;
+    const bool colok = gcol < P.B;
+    const bool vec = (P.D & 3) == 0;
+    const bool writer = (wg == 0 && tid == 0);
+    const long long A = (long long)P.D * P.Bpad, HB = (long long)P.H * P.Bpad;
+    const double N = (double)P.D * (double)P.B;
+    for (int i = tid; i < G::BT * P.KS1; i += kThreads)
+        if (i % P.KS1 >= P.D) GL[i] = 0.f;
+    for (int i = tid; i < G::BT * P.KS2; i += kThreads)
+        if (i % P.KS2 >= P.H) HL[i] = 0.f;
+    for (int i = tid; i < 2 * G::BT; i += kThreads) TAU[i] = 0.f;
+    const InitRec ir = *P.initrec;
+    const float dt0 = ir.dt0;
+
+    if constexpr (PHASE == 1) {
+        double tb, dtpb, qoldb, t1b, t0b;
+        finish_attempt_scalars(Q, 0, lane, tb, dtpb, qoldb, t1b, t0b);
+        const double dtb = Q.track_initdt ? dtpb : 0.0;
+        double dt0b = 0, d1b = 0, d2b = 0;
+        if (ir.sel == 2) { t1b += dtb; t0b -= dtb; }
+        else if (ir.sel == 0) dt0b += 100.0 * dtb;
+        else if (!ir.dt1_const) {
+            const double mm = ir.max_is_d2 ? (double)ir.d2 : (double)ir.d1;
+            const double mb = dtb * (-0.2) * (double)ir.dt1 / mm;
+            if (ir.max_is_d2) d2b += mb; else d1b += mb;
+        } else if (dt0 * 1e-3f > 1e-6f) dt0b += 1e-3 * dtb;
+        const double n2 = (double)ir.d2 * (double)dt0, n2b = d2b / (double)dt0;
+        dt0b += -d2b * (double)ir.d2 / (double)dt0;
+        const double coef_w = n2 > 0 ? n2b / (N * n2) : 0.0;
+        if (writer) { IBState b; b.tb = tb; b.t1b = t1b; b.t0b = t0b; b.dt0b = dt0b; b.d1b = d1b; b.d2b = d2b; b.coef_w = coef_w; b.pad = 0; Q.ibstate[0] = b; }
+        const float cw = (float)coef_w;
+        f32x4 zb2[G::TPW], f0v[G::TPW], gb[G::TPW];
+#pragma unroll
+        for (int j = 0; j < G::TPW; ++j) {
+            const int r0 = own.row0[j];
+            const f32x4 xv = ld_tile(P.x + (size_t)gcol * P.D, r0, P.D, colok, P.xvec != 0);
+            f0v[j] = ld_tile(P.f0 + (size_t)gcol * P.D, r0, P.D, true, vec);
+            const f32x4 f1v = ld_tile(P.f1 + (size_t)gcol * P.D, r0, P.D, true, vec);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float sk = P.abstol + fabsf(xv[i]) * P.reltol;
+                const float w = (f1v[i] - f0v[j][i]) / sk;
+                const float f1b = (colok ? cw * w : 0.f) / sk;
+                zb2[j][i] = ACT2 ? f1b * (1.f - f1v[i] * f1v[i]) : f1b;
+            }
+        }
+        f_bwd<NG>(Q, GL, HL, PART, TAU, zb2, P.h1, Q.zi2 + A, Q.zi1 + HB, col0, gcol, own, gb, tid);
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < G::TPW; ++j) {
+            st_tile(Q.UB1 + (size_t)gcol * P.D, own.row0[j], P.D, true, vec, gb[j]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dot += gb[j][i] * f0v[j][i];
+        }
+        dot = wave_sum_f(dot);
+        if (lane == 0) RED[wave] = dot;
+        __syncthreads();
+        if (tid == 0) {
+            float s = 0.f, tau = 0.f;
+            for (int w = 0; w < kWaves; ++w) s += RED[w];
+            for (int c = 0; c < 2 * G::BT; ++c) tau += TAU[c];
+            float* o = Q.ipart + (size_t)wg * 4;
+            o[0] = s; o[1] = tau; o[2] = 0.f; o[3] = 0.f;
+        }
+    } else {
+        const IBState ib = Q.ibstate[0];
+        double dot1 = 0, tau1 = 0;
+        for (int i = lane; i < P.nwg; i += 64) { dot1 += (double)Q.ipart[4 * i]; tau1 += (double)Q.ipart[4 * i + 1]; }
+        dot1 = wave_sum_d(dot1); tau1 = wave_sum_d(tau1);
+        double dt0b = ib.dt0b + tau1 + dot1, t0b = ib.t0b + tau1, t1b = ib.t1b, d1b = ib.d1b, d0b = 0;
+        if (ir.dt0_clamped) { t1b += dt0b; t0b -= dt0b; }
+        else if (!ir.dt0_const) { d0b = dt0b / (100.0 * (double)ir.d1); d1b += -dt0b * (double)dt0 / (double)ir.d1; }
+        const float cv = ir.d1 > 0.f ? (float)(d1b / (N * (double)ir.d1)) : 0.f;
+        const float cz = ir.d0 > 0.f ? (float)(d0b / (N * (double)ir.d0)) : 0.f;
+        const float cw = (float)ib.coef_w;
+        if (writer) { IBState b = ib; b.t1b = t1b; b.t0b = t0b; Q.ibstate[1] = b; }
+        f32x4 zb2[G::TPW], u0b[G::TPW], gb[G::TPW];
+#pragma unroll
+        for (int j = 0; j < G::TPW; ++j) {
+            const int r0 = own.row0[j];
+            const f32x4 xv = ld_tile(P.x + (size_t)gcol * P.D, r0, P.D, colok, P.xvec != 0);
+            const f32x4 f0v = ld_tile(P.f0 + (size_t)gcol * P.D, r0, P.D, true, vec);
+            const f32x4 f1v = ld_tile(P.f1 + (size_t)gcol * P.D, r0, P.D, true, vec);
+            const f32x4 ub1 = ld_tile(Q.UB1 + (size_t)gcol * P.D, r0, P.D, true, vec);
+            const f32x4 Uv = ld_tile(Q.U + (size_t)gcol * P.D, r0, P.D, true, vec);
+            const f32x4 K1v = ld_tile(Q.K1 + (size_t)gcol * P.D, r0, P.D, true, vec);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float sk = P.abstol + fabsf(xv[i]) * P.reltol;
+                const float w = (f1v[i] - f0v[i]) / sk, v = f0v[i] / sk, z = xv[i] / sk;
+                const float wb = colok ? cw * w : 0.f, vb = colok ? cv * v : 0.f, zb = colok ? cz * z : 0.f;
+                const float skb = -(wb * w + vb * v + zb * z) / sk;
+                const float f0b = K1v[i] + dt0 * ub1[i] + (vb - wb) / sk;
+                u0b[j][i] = Uv[i] + ub1[i] + zb / sk + skb * P.reltol * sgnf(xv[i]);
+                zb2[j][i] = ACT2 ? f0b * (1.f - f0v[i] * f0v[i]) : f0b;
+            }
+        }
+        f_bwd<NG>(Q, GL, HL, PART, TAU, zb2, P.h0, Q.zi2, Q.zi1, col0, gcol, own, gb, tid);
+#pragma unroll
+        for (int j = 0; j < G::TPW; ++j)
+            st_tile(Q.xbar + (size_t)gcol * P.D, own.row0[j], P.D, colok, false, u0b[j] + gb[j]);
+        __syncthreads();
+        if (tid == 0) {
+            float tau = 0.f;
+            for (int c = 0; c < 2 * G::BT; ++c) tau += TAU[c];
+            float* o = Q.ipart + ((size_t)P.nwg + wg) * 4;
+            o[0] = tau; o[1] = 0.f; o[2] = 0.f; o[3] = 0.f;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void rnde_bfin_kernel(const BwdParams Q) {
+    const int lane = threadIdx.x;
+    const IBState ib = Q.ibstate[1];
+    double tau0 = 0;
+    for (int i = lane; i < Q.F.nwg; i += 64) tau0 += (double)Q.ipart[((size_t)Q.F.nwg + i) * 4];
+    tau0 = wave_sum_d(tau0);
+    if (lane == 0) {
+        Q.tspan_out[0] = (float)(ib.t0b + tau0 + ib.tb);
+        Q.tspan_out[1] = (float)ib.t1b;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Parameter gradient of one Dense layer over ALL f evaluations of the solve:
+//   Wext_bar[M][Nx+2] = sum_e  Z_e[M x Bpad] * [X_e ; t_e ; 1]^T            (bias = last column)
+// which is exactly the Flux.destructure segment [vec(W) (M x (Nx+1)); b (M)] in column-major order.
+// One wave computes MB x NB tiles of 32x32 with v_mfma_f32_32x32x2_f32 over a chunk of evaluations and
+// writes its partial to a slab; rnde_wgrad_reduce sums the slabs in fixed order.
+// ------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int MB, int NB>
+__global__ __launch_bounds__(64) void rnde_wgrad_kernel(const EvalDesc* __restrict__ evals, int n_evals, int per_chunk,
+                                                        int M, int Nx, int Bpad, float* __restrict__ slab) {
+    const int lane = threadIdx.x, l31 = lane & 31, kk = lane >> 5;
+    const int mtiles = (M + 31) / 32, ntiles = (Nx + 2 + 31) / 32;
+    const int mblocks = (mtiles + MB - 1) / MB;
+    const int mb = blockIdx.x % mblocks, nb = blockIdx.x / mblocks;
+    const int chunk = blockIdx.y;
+    const int e0 = chunk * per_chunk, e1 = min(n_evals, e0 + per_chunk);
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int a = 0; a < MB; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    int mrow[MB], nrow[NB];
+#pragma unroll
+    for (int a = 0; a < MB; ++a) mrow[a] = (mb * MB + a) * 32 + l31;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) nrow[b] = (nb * NB + b) * 32 + l31;
+    for (int e = e0; e < e1; ++e) {
+        const float* __restrict__ Z = evals[e].Z;
+        const float* __restrict__ X = evals[e].X;
+        const float te = evals[e].t;
+        float bconst[NB];  // value for the synthetic rows (time, bias), else NaN marker unused
+#pragma unroll
+        for (int b = 0; b < NB; ++b) bconst[b] = nrow[b] == Nx ? te : (nrow[b] == Nx + 1 ? 1.f : 0.f);
+#pragma unroll 2
+        for (int c = 0; c < Bpad; c += 2) {
+            const int cc = c + kk;
+            float av[MB], bv[NB];
+#pragma unroll
+            for (int a = 0; a < MB; ++a) av[a] = mrow[a] < M ? Z[(size_t)cc * M + mrow[a]] : 0.f;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) bv[b] = nrow[b] < Nx ? X[(size_t)cc * Nx + nrow[b]] : bconst[b];
+#pragma unroll
+            for (int a = 0; a < MB; ++a)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+        }
+    }
+    float* out = slab + (size_t)chunk * M * (Nx + 2);
+#pragma unroll
+    for (int a = 0; a < MB; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int ncol = (nb * NB + b) * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mr = (mb * MB + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                if (mr < M && ncol < Nx + 2) out[(size_t)ncol * M + mr] = acc[a][b][r];
+            }
+        }
+}
+
+__global__ void rnde_wgrad_reduce(const float* __restrict__ slab, int n_chunks, long long len, float* __restrict__ out) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < len; i += (long long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int c = 0; c < n_chunks; ++c) s += slab[(size_t)c * len + i];
+        out[i] = s;
+    }
+}
+
+}  // namespace rnde
+
+struct rnde_node;
+static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* saveval_bar_host, float* x_bar_dev,
+                           float* p_bar_dev, float* tspan_bar_host, hipStream_t s);

@@ -104,14 +104,17 @@ struct StepParams {
     int xvec;                                // x is 16-byte aligned and D % 4 == 0
 };
 
-// record layout inside the arena (floats): k2..k7 | g2..g6 | unew | h2..h7
+// record layout inside the arena (floats): k2..k7 | g2..g6 | unew | h2..h7 | z1bar2..z1bar7
+// (the reverse pass overwrites k_s in place with the layer-2 pre-activation cotangent z2bar_s once
+//  k_s is dead, and stores the layer-1 one in z1)
 struct RecLayout {
     long long A, HB;
     __host__ __device__ long long k(int s) const { return (long long)(s - 2) * A; }       // s = 2..7
     __host__ __device__ long long g(int s) const { return (long long)(6 + s - 2) * A; }   // s = 2..6
     __host__ __device__ long long unew() const { return 11LL * A; }
     __host__ __device__ long long h(int s) const { return 12LL * A + (long long)(s - 2) * HB; }
-    __host__ __device__ long long total() const { return 12LL * A + 6LL * HB; }
+    __host__ __device__ long long z1(int s) const { return 12LL * A + 6LL * HB + (long long)(s - 2) * HB; }
+    __host__ __device__ long long total() const { return 12LL * A + 12LL * HB; }
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {

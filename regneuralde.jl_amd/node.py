@@ -61,7 +61,6 @@ class _Solve(torch.autograd.Function):
         ctx.layer, ctx.h, ctx.nsv = layer, h, nsv.value
         if keep_tape:
             h.busy = True
-        ctx.mark_non_differentiable()
         return u, saveval
 
     @staticmethod

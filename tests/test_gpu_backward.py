@@ -1,0 +1,60 @@
+"""GPU parity: reverse pass (x-bar, p-bar, tspan-bar) of the HIP path against the CPU oracle.
+
+Only truncation-dominated regimes are compared element-wise (identical accept/reject sequences, see
+test_gpu_forward.py); tolerance: 2e-3 of the largest gradient entry (fp32 accumulation over
+~10^2 evaluations x batch in a different association order), fp64 oracle as arbiter."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("test_node", 7, 1e-3, 3.0, 1.0, 3, 8), ("small", 20, 1e-3, 4.0, 1.0, 3, 8), ("mnist", 32, 1e-3, 3.0, 1.0, 3, 8),
+         ("test_node", 3, 1e-2, 5.0, 2.0, 18, 8), ("mnist", 19, 1e-2, 6.0, 2.0, 5, 8),
+         ("test_node", 3, 3e-2, 5.0, 2.0, 27, 4),   # <- the two test_node cases here contain a rejected step
+         ("small", 9, 1e-3, 4.0, 1.0, 4, 4), ("mnist", 12, 1e-3, 3.0, 1.0, 6, 4)]
+
+
+@pytest.mark.parametrize("kind,B,tol,scale,t1,seed,col_tile", CASES)
+@pytest.mark.parametrize("wu,ws", [(1.0, 0.0), (1.0, 50.0)])
+def test_backward_matches_oracle(kind, B, tol, scale, t1, seed, col_tile, wu, ws):
+    from tests.test_gpu_forward import _cfg, _setup
+    from tests.util import Node, Oracle, rel_err
+    arch, p, x = _setup(kind, B, seed, scale)
+    rng = np.random.default_rng(100 + seed)
+    node = Node(_cfg(arch, B, reltol=tol, abstol=tol, col_tile=col_tile))
+    got = node.forward(x, p, 0.0, t1, keep_tape=True)
+    o32 = Oracle(arch, np.float32, reltol=tol, abstol=tol, reg_kind=1)
+    o64 = Oracle(arch, np.float64, reltol=tol, abstol=tol, reg_kind=1)
+    r32 = o32.forward(x, p, 0.0, t1)
+    r64 = o64.forward(x, p, 0.0, t1)
+    assert (got["steps"][:, 3] == r32["steps"][:, 3]).all() and got["nattempts"] == r32["nattempts"]
+    ubar = (wu * rng.standard_normal(x.shape)).astype(np.float32)
+    svbar = np.full(len(got["saveval"]), ws, dtype=np.float32)
+    xb, pb, tsb = node.backward(ubar, svbar)
+    xb32, pb32, tsb32 = o32.backward(ubar, svbar)
+    same64 = r64["nattempts"] == r32["nattempts"] and (r64["steps"][:, 3] == r32["steps"][:, 3]).all()
+    print(f"{kind} B={B} natt={got['nattempts']} nrej={int((got['steps'][:,3]==0).sum())} "
+          f"x-bar err {rel_err(xb, xb32):.2e}  p-bar err {rel_err(pb, pb32):.2e}  tspan {tsb} vs {tsb32}")
+    # conditioning of the case itself: how far the fp32 oracle is from the fp64 oracle (rejected steps only
+    # occur in rough regimes where gradients are sensitive; those cases are judged relative to that spread)
+    cx = cp = 0.0
+    if same64:
+        xb64, pb64, tsb64 = o64.backward(ubar.astype(np.float64), svbar.astype(np.float64))
+        cx, cp = rel_err(xb32, xb64), rel_err(pb32, pb64)
+        print(f"   oracle f32 vs f64 spread: x {cx:.2e} p {cp:.2e}; device vs f64: x {rel_err(xb, xb64):.2e} p {rel_err(pb, pb64):.2e}")
+        assert rel_err(xb, xb64) <= 2e-3 + 3 * cx
+        assert rel_err(pb, pb64) <= 2e-3 + 3 * cp
+    assert rel_err(xb, xb32) <= 2e-3 + 4 * cx
+    assert rel_err(pb, pb32) <= 2e-3 + 4 * cp
+    assert np.abs(tsb - tsb32).max() <= (2e-3 + 4 * max(cx, cp)) * max(1.0, np.abs(tsb32).max())
+
+
+def test_backward_requires_tape():
+    from tests.test_gpu_forward import _cfg, _setup
+    from tests.util import Node
+    from regneuralde_jl_amd._lib import RndeError
+    arch, p, x = _setup("small", 4, 0, 1.0)
+    node = Node(_cfg(arch, 4, reltol=1e-3, abstol=1e-3))
+    node.forward(x, p, keep_tape=False)
+    with pytest.raises(RndeError):
+        node.backward(np.ones_like(x))

@@ -138,7 +138,8 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
     if (h->H + 2 > 128 || h->D + 2 > kWaves * TPW * TR || h->D < 1 || h->H < 1 || c->max_batch < 1 || c->max_attempts < 1) {
         g_create_err = "shape outside the kernel limits (H <= 126, D <= 1022 at col_tile 8)"; delete h; return RNDE_ERR_BAD_ARG;
     }
-    auto up4 = [](int k) { return (k + 3) / 4; };
+    const int KU = h->NG;  // k4 groups per weight-ring unit (rnde_device.h): K4 counts are padded to it
+    auto up4 = [KU](int k) { return ((k + 3) / 4 + KU - 1) / KU * KU; };
     h->K4_1 = up4(h->D + 2); h->KS1 = 4 * (h->K4_1 | 1); h->MT1 = (h->H + TR - 1) / TR;
     h->K4_2 = up4(h->H + 2); h->KS2 = 4 * (h->K4_2 | 1); h->MT2 = (h->D + TR - 1) / TR;
     h->K4_2t = up4(h->D); h->MT2t = (h->H + 1 + TR - 1) / TR;   // pw2t: M = H+1, K = D   (B operand image uses KS1)
@@ -146,7 +147,7 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
     h->Bpad_max = ((c->max_batch + h->BT - 1) / h->BT) * h->BT;
     h->nwg_max = h->Bpad_max / h->BT;
     const int MTS = 128 / TR;
-    h->lds_bytes = sizeof(float) * ((size_t)h->BT * h->KS1 + (size_t)h->BT * h->KS2 + (size_t)kWaves * MTS * 256 + 64);
+    h->lds_bytes = sizeof(float) * ((size_t)h->BT * h->KS1 + (size_t)h->BT * h->KS2 + (size_t)kWaves * MTS * 256 + 192 + (size_t)kWaves * kRing * 256);
     if (hipSetDevice(c->device) != hipSuccess) { g_create_err = "hipSetDevice failed"; delete h; return RNDE_ERR_HIP; }
     const size_t A = (size_t)h->D * h->Bpad_max, HB = (size_t)h->H * h->Bpad_max;
     RecLayout L{(long long)A, (long long)HB};
@@ -383,11 +384,22 @@ extern "C" rnde_status rnde_bench_attempt(rnde_node* h, const float* x_dev, cons
     HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
     hipEventDestroy(e0); hipEventDestroy(e1);
     if (mean_us_out) *mean_us_out = ms * 1000.f / iters;
+#ifdef RNDE_DIAG
+    {   // phase stamps of the LAST f evaluation of one launch (workgroup 0), in shader cycles relative to stamp 0 of wave 0
+        unsigned long long* d = nullptr; unsigned long long hst[64];
+        hipMalloc((void**)&d, sizeof(hst)); hipMemset(d, 0, sizeof(hst));
+        P.dbg_out = (float*)d;
+        launch_step<MODE_STEP>(h, P, 0, s); hipStreamSynchronize(s);
+        hipMemcpy(hst, d, sizeof(hst), hipMemcpyDeviceToHost); hipFree(d);
+        fprintf(stderr, "stamps (cycles since wave0 stamp0): start sync1 gemm1 sync2 reduce sync3 gemm2 tanh\n");
+        for (int w = 0; w < 8; ++w) { fprintf(stderr, "wave %d:", w); for (int i = 0; i < 8; ++i) fprintf(stderr, " %7lld", (long long)(hst[w * 8 + i] - hst[0])); fprintf(stderr, "\n"); }
+    }
+#endif
     return RNDE_OK;
 }
 
 // ---- reverse pass driver ------------------------------------------------------------------------
-static size_t bwd_lds_bytes(const rnde_node* h) { return h->lds_bytes + sizeof(float) * 7 * 2 * h->BT; }
+static size_t bwd_lds_bytes(const rnde_node* h) { return h->lds_bytes; }
 
 static rnde_status bwd_prepare(rnde_node* h) {
     BwdBuffers& b = h->bw;

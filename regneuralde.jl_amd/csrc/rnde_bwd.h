@@ -77,13 +77,14 @@ __device__ __forceinline__ float sgnf(float v) { return v > 0.f ? 1.f : (v < 0.f
 // cotangents per column in TAU[0..BT) (layer 2) and TAU[BT..2BT) (layer 1).
 // ------------------------------------------------------------------------------------------
 template <int NG>
-__device__ __forceinline__ void f_bwd(const BwdParams& Q, float* GL, float* HL, float* PART, float* TAU,
+__device__ __forceinline__ void f_bwd(const BwdParams& Q, float* GL, float* HL, float* PART, float* RING, float* TAU,
                                       const f32x4 (&zb2)[Geo<NG>::TPW], const float* __restrict__ hsrc,
                                       float* __restrict__ z2dst, float* __restrict__ z1dst, int col0, int gcol,
                                       const Own<NG>& own, f32x4 (&gb)[Geo<NG>::TPW], int tid) {
     using G = Geo<NG>;
     const StepParams& P = Q.F;
     const int lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const bool vec = (P.D & 3) == 0;
 #pragma unroll
     for (int j = 0; j < G::TPW; ++j) {
@@ -93,7 +94,7 @@ __device__ __forceinline__ void f_bwd(const BwdParams& Q, float* GL, float* HL, 
     __syncthreads();
     {
         f32x4 acc[G::MTS];
-        gemm_ksplit<NG>(Q.pw2t, Q.MT2t, Q.K4_2t, GL, P.KS1, acc, wave, lane);
+        gemm_ksplit<NG>(Q.pw2t, Q.MT2t, Q.K4_2t, GL, P.KS1, RING, acc, wave_u, lane);
 #pragma unroll
         for (int T = 0; T < G::MTS; ++T)
             if (T < Q.MT2t) *(f32x4*)(PART + ((wave * G::MTS + T) * 64 + lane) * 4) = acc[T];
@@ -116,7 +117,7 @@ __device__ __forceinline__ void f_bwd(const BwdParams& Q, float* GL, float* HL, 
         }
     }
     __syncthreads();
-    gemm_rows<NG>(Q.pw1t, Q.MT1t, Q.K4_1t, HL, P.KS2, gb, wave, lane);
+    gemm_rows<NG>(Q.pw1t, Q.MT1t, Q.K4_1t, HL, P.KS2, RING, gb, wave_u, lane);
 #pragma unroll
     for (int j = 0; j < G::TPW; ++j) {
 #pragma unroll
@@ -156,6 +157,7 @@ __global__ __launch_bounds__(kThreads) void rnde_bstep_kernel(const BwdParams Q,
     float* RED = PART + kWaves * G::MTS * 256;
     float* TAU = RED + 64;  // [7][2*BT]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* RING = RED + 192 + __builtin_amdgcn_readfirstlane(wave) * (kRing * 256);
     const int wg = blockIdx.x, col0 = wg * G::BT;
     const Own<NG> own(wave, lane);
     const int gcol = col0 + own.col;
@@ -235,7 +237,10 @@ __global__ __launch_bounds__(kThreads) void rnde_bstep_kernel(const BwdParams Q,
         __builtin_amdgcn_sched_barrier(0);  // one tile's 10 loads at a time: keeps the live set under 256 VGPRs
     }
     float S = 0.f;  // sum_j <k_j, kbar_j (dt-scaled part)>  -> dt-bar = S / dt
-    f32x4 kb[6][G::TPW], gb[G::TPW];
+    // Rb[i] = cotangent of k_{s-i} (zero-based k index) where s is the next stage to be reversed: Rb[0] is
+    // consumed by that stage, the others receive dt * a_{s, .} * gbar_s and the array shifts down (rolled loop,
+    // coefficients from kBwdShift).
+    f32x4 Rb[6][G::TPW], gb[G::TPW];
     // ---- B: stage 7 (k7 = f(unew, t + dt)) ----
     {
         f32x4 zb2[G::TPW];
@@ -250,44 +255,47 @@ __global__ __launch_bounds__(kThreads) void rnde_bstep_kernel(const BwdParams Q,
 #pragma unroll
             for (int i = 0; i < 4; ++i) zb2[j][i] = ACT2 ? kb7[i] * (1.f - k7[i] * k7[i]) : kb7[i];
         }
-        f_bwd<NG>(Q, GL, HL, PART, TAU + 6 * 2 * G::BT, zb2, R + L.h(7), R + L.k(7), R + L.z1(7), col0, gcol, own, gb, tid);
+        f_bwd<NG>(Q, GL, HL, PART, RING, TAU + 6 * 2 * G::BT, zb2, R + L.h(7), R + L.k(7), R + L.z1(7), col0, gcol, own, gb, tid);
 #pragma unroll
         for (int j = 0; j < G::TPW; ++j) {
             unb[j] += gb[j];
 #pragma unroll
-            for (int jj = 0; jj < 6; ++jj) kb[jj][j] = dt * (tsA(6, jj) * unb[j] + tsBt(jj) * utb[j]);
+            for (int i = 0; i < 6; ++i) Rb[i][j] = dt * (tsA(6, 5 - i) * unb[j] + tsBt(5 - i) * utb[j]);  // kbar_{5-i}
             upb[j] += unb[j];
         }
     }
     // ---- C: stages 6..2 ----
-#pragma unroll
-    for (int s = 5; s >= 1; --s) {  // zero-based: k_{s+1} = f(g_{s+1}, t + c_s dt)
+#pragma unroll 1
+    for (int s = 5; s >= 1; --s) {  // zero-based: k_s = f(g_s, t + c_s dt), stored as k(s+1)
         f32x4 zb2[G::TPW];
 #pragma unroll
         for (int j = 0; j < G::TPW; ++j) {
             const f32x4 ks = ld_tile(R + L.k(s + 1) + (size_t)gcol * P.D, own.row0[j], P.D, true, vec);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                S += ks[i] * kb[s][j][i];
-                zb2[j][i] = ACT2 ? kb[s][j][i] * (1.f - ks[i] * ks[i]) : kb[s][j][i];
+                S += ks[i] * Rb[0][j][i];
+                zb2[j][i] = ACT2 ? Rb[0][j][i] * (1.f - ks[i] * ks[i]) : Rb[0][j][i];
             }
         }
-        f_bwd<NG>(Q, GL, HL, PART, TAU + s * 2 * G::BT, zb2, R + L.h(s + 1), R + L.k(s + 1), R + L.z1(s + 1), col0, gcol, own, gb, tid);
+        f_bwd<NG>(Q, GL, HL, PART, RING, TAU + s * 2 * G::BT, zb2, R + L.h(s + 1), R + L.k(s + 1), R + L.z1(s + 1), col0, gcol, own, gb, tid);
+        float cb[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) cb[i] = dt * kBwdShift[s][i];
 #pragma unroll
         for (int j = 0; j < G::TPW; ++j) {
 #pragma unroll
-            for (int jj = 0; jj < s; ++jj) kb[jj][j] += (dt * tsA(s, jj)) * gb[j];
+            for (int i = 0; i < 5; ++i) Rb[i][j] = Rb[i + 1][j] + cb[i] * gb[j];
             upb[j] += gb[j];
         }
     }
-    // ---- D: k1 and outputs ----
+    // ---- D: k1 and outputs (Rb[0] is now the cotangent of k1) ----
 #pragma unroll
     for (int j = 0; j < G::TPW; ++j) {
         const int r0 = own.row0[j];
         const f32x4 k1v = ld_tile(k1p + (size_t)gcol * P.D, r0, P.D, true, vec);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) S += k1v[i] * kb[0][j][i];
-        f32x4 uo = upb[j], ko = kb[0][j];
+        for (int i = 0; i < 4; ++i) S += k1v[i] * Rb[0][j][i];
+        f32x4 uo = upb[j], ko = Rb[0][j];
         if (!accepted) {
             uo += first ? ld_tile(Q.ubar + (size_t)gcol * P.D, r0, P.D, colok, false) : ld_tile(Q.U + (size_t)gcol * P.D, r0, P.D, true, vec);
             if (!first) ko += ld_tile(Q.K1 + (size_t)gcol * P.D, r0, P.D, true, vec);
@@ -328,6 +336,7 @@ __global__ __launch_bounds__(kThreads) void rnde_binit_kernel(const BwdParams Q)
     float* RED = PART + kWaves * G::MTS * 256;
     float* TAU = RED + 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* RING = RED + 192 + __builtin_amdgcn_readfirstlane(wave) * (kRing * 256);
     const int wg = blockIdx.x, col0 = wg * G::BT;
     const Own<NG> own(wave, lane);
     const int gcol = col0 + own.col;
@@ -376,7 +385,7 @@ __global__ __launch_bounds__(kThreads) void rnde_binit_kernel(const BwdParams Q)
                 zb2[j][i] = ACT2 ? f1b * (1.f - f1v[i] * f1v[i]) : f1b;
             }
         }
-        f_bwd<NG>(Q, GL, HL, PART, TAU, zb2, P.h1, Q.zi2 + A, Q.zi1 + HB, col0, gcol, own, gb, tid);
+        f_bwd<NG>(Q, GL, HL, PART, RING, TAU, zb2, P.h1, Q.zi2 + A, Q.zi1 + HB, col0, gcol, own, gb, tid);
         float dot = 0.f;
 #pragma unroll
         for (int j = 0; j < G::TPW; ++j) {
@@ -427,7 +436,7 @@ __global__ __launch_bounds__(kThreads) void rnde_binit_kernel(const BwdParams Q)
                 zb2[j][i] = ACT2 ? f0b * (1.f - f0v[i] * f0v[i]) : f0b;
             }
         }
-        f_bwd<NG>(Q, GL, HL, PART, TAU, zb2, P.h0, Q.zi2, Q.zi1, col0, gcol, own, gb, tid);
+        f_bwd<NG>(Q, GL, HL, PART, RING, TAU, zb2, P.h0, Q.zi2, Q.zi1, col0, gcol, own, gb, tid);
 #pragma unroll
         for (int j = 0; j < G::TPW; ++j)
             st_tile(Q.xbar + (size_t)gcol * P.D, own.row0[j], P.D, colok, false, u0b[j] + gb[j]);

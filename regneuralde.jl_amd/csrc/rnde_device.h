@@ -46,6 +46,30 @@ __host__ __device__ constexpr float tsBt(int j) {
                               0.015151515151515152};
     return (float)BT[j];
 }
+// Run-time indexed copies for the rolled stage loops (double literals rounded to fp32 by the compiler,
+// identical to (float)A[s][j] above).
+// kFwdShift[s][i] = A[s+1+i][s] (0 beyond the tableau): coefficient of k_s in the input of stage s+1+i
+__constant__ float kFwdShift[7][6] = {
+    {0.161f, -0.008480655492356989f, 2.8971530571054935f, 5.325864828439257f, 5.86145544294642f, 0.09646076681806523f},
+    {0.335480655492357f, -6.359448489975075f, -11.748883564062828f, -12.92096931784711f, 0.01f, 0.f},
+    {4.3622954328695815f, 7.4955393428898365f, 8.159367898576159f, 0.4798896504144996f, 0.f, 0.f},
+    {-0.09249506636175525f, -0.071584973281401f, 1.379008574103742f, 0.f, 0.f, 0.f},
+    {-0.028269050394068383f, -3.290069515436081f, 0.f, 0.f, 0.f, 0.f},
+    {2.324710524099774f, 0.f, 0.f, 0.f, 0.f, 0.f},
+    {0.f, 0.f, 0.f, 0.f, 0.f, 0.f},
+};
+// kBwdShift[s][i] = A[s][s-1-i] (0 below the tableau): weight of gbar_s in the cotangent of k_{s-1-i}
+__constant__ float kBwdShift[7][6] = {
+    {0.f, 0.f, 0.f, 0.f, 0.f, 0.f},
+    {0.161f, 0.f, 0.f, 0.f, 0.f, 0.f},
+    {0.335480655492357f, -0.008480655492356989f, 0.f, 0.f, 0.f, 0.f},
+    {4.3622954328695815f, -6.359448489975075f, 2.8971530571054935f, 0.f, 0.f, 0.f},
+    {-0.09249506636175525f, 7.4955393428898365f, -11.748883564062828f, 5.325864828439257f, 0.f, 0.f},
+    {-0.028269050394068383f, -0.071584973281401f, 8.159367898576159f, -12.92096931784711f, 5.86145544294642f, 0.f},
+    {2.324710524099774f, -3.290069515436081f, 1.379008574103742f, 0.4798896504144996f, 0.01f, 0.09646076681806523f},
+};
+__constant__ float kTsC[8] = {0.f, 0.161f, 0.327f, 0.9f, 0.9800255409045097f, 1.0f, 1.0f, 0.f};
+__constant__ float kTsBt[8] = {-0.001780011052225777f, -0.0008164344596567469f, 0.007880878010261995f, -0.1447110071732629f, 0.5823571654525552f, -0.45808210592918697f, 0.015151515151515152f, 0.f};
 // PI controller constants
 constexpr float kBeta1 = (float)(7.0 / 50.0);
 constexpr float kBeta2 = (float)(2.0 / 25.0);
@@ -118,7 +142,12 @@ struct RecLayout {
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+#ifdef RNDE_EXP_NOMFMA   // (ablation builds only) keep the operands live, skip the matrix pipe
+    asm volatile("" ::"v"(a), "v"(b));
+    return c;
+#else
     return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+#endif
 }
 
 __device__ __forceinline__ double wave_sum_d(double s) {
@@ -138,74 +167,127 @@ __device__ __forceinline__ double sum_partials(const float* __restrict__ part, i
     return wave_sum_d(s);
 }
 
-// ---- small-M GEMM: out[M<=128][BT] = PW[M][K] * XL[K][BT]; K split over the 8 waves --------------
-// pw: packed [tile][k4][TR] float4 (4 consecutive k per lane).  XL: LDS, column c at XL + c*KS.
-template <int NG>
-__device__ __forceinline__ void gemm_ksplit(const f32x4* __restrict__ pw, int MT, int K4, const float* XL, int KS,
-                                            f32x4 (&acc)[Geo<NG>::MTS], int wave, int lane) {
+// ---- weight streaming: per-wave LDS-DMA ring ------------------------------------------------------
+// The Dense-layer GEMMs of one workgroup re-stream all packed weights (~0.7 MB) from L2 for every f
+// evaluation, and each weight is used for only BT columns, so the loop is bound by bytes in flight, not
+// by MFMA issue: with register prefetch a wave can keep ~2 KB in flight (measured 27 GB/s per CU).
+// Instead every wave owns kRing 1-KiB slots of LDS and keeps kRing `global_load_lds_dwordx4`
+// (1 KiB each, no VGPR destination) in flight: 8 waves x 12 KiB = 96 KiB per CU.  The ring is private to
+// the wave, so no workgroup barrier is involved: a counted s_waitcnt vmcnt orders DMA -> ds_read, and
+// s_waitcnt lgkmcnt(0) orders ds_read -> slot reuse.
+// One ring unit = 64 lanes x 16 B = (one tile, KU = 64/TR consecutive k4 groups) of the packed weights.
+constexpr int kRing = 12;
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+__device__ __forceinline__ void dma_unit(const f32x4* __restrict__ gsrc_lane, float* lds_slot_uniform) {
+#ifndef RNDE_EXP_NODMA   // (ablation builds only: tools/ablate.sh)
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)gsrc_lane, (lds_void_t*)lds_slot_uniform, 16, 0, 0);
+#endif
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// acc[j] = PW[tile (tile0 + j*tstride)][k range] * XL[k range][BT] for j < N over k4 groups [kb, ke)
+// (multiples of KU).  pw: packed [tile][K4e][TR] float4.  All scalar arguments must be wave-uniform
+// (callers pass readfirstlane'd wave ids) so the control flow stays on the scalar unit; N is a template
+// parameter so the MFMA block is branch-free.
+// Per K step the wave waits for its N oldest ring units, reads their A fragments, refills the slots and
+// issues the MFMAs interleaved across the tiles' independent accumulators (the 4x4x1 MFMA has a 40-cycle
+// dependent latency, tools/probe_mfma.hip).
+template <int NG, int N>
+__device__ __forceinline__ void gemm_stream(const f32x4* __restrict__ pw, int K4e, int tile0, int tstride, int kb, int ke,
+                                            const float* xcol, float* ring, f32x4 (&acc)[N], int lane) {
     using G = Geo<NG>;
-    const int chunk = (K4 + kWaves - 1) / kWaves;
-    const int kb = wave * chunk;
-    const int ke = min(K4, kb + chunk);
-    const int ar = lane & (G::TR - 1);
-    const float* xcol = XL + (4 * (lane / G::TR) + (lane & 3)) * KS;
+    constexpr int KU = 64 / G::TR;  // k4 groups per ring unit
+    static_assert(N <= kRing / 2, "ring too small for the tile group");
 #pragma unroll
-    for (int T = 0; T < G::MTS; ++T) acc[T] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 an[G::MTS];
-    if (kb < ke) {
+    for (int j = 0; j < N; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int total = ((ke - kb) / KU) * N;
+    if (total <= 0) return;
+    int issued = 0, ik = kb, ij = 0, islot = 0;
+    const f32x4* __restrict__ src = pw + lane;
+    auto issue = [&]() {
+        dma_unit(src + (size_t)((tile0 + ij * tstride) * K4e + ik) * G::TR, ring + islot * 256);
+        ++issued;
+        if (++ij == N) { ij = 0; ik += KU; }
+        if (++islot == kRing) islot = 0;
+    };
+    const int pre = total < kRing ? total : kRing;
+    for (int i = 0; i < pre; ++i) issue();
+    int slot = 0;
+    bool drained = false;
+    const float* rd = ring + (lane & (G::TR - 1)) * 4;
+    for (int k4 = kb; k4 < ke; k4 += KU) {
+        // outstanding DMAs = kRing while units remain to be issued: <= kRing - N left => the N oldest landed
+        if (issued < total) wait_vm<kRing - N>();
+        else if (!drained) { wait_vm<0>(); drained = true; }
 #pragma unroll
-        for (int T = 0; T < G::MTS; ++T)
-            if (T < MT) an[T] = pw[(size_t)(T * K4 + kb) * G::TR + ar];
-    }
-    for (int k4 = kb; k4 < ke; ++k4) {
-        f32x4 a[G::MTS];
+        for (int q = 0; q < KU; ++q) {
+            const f32x4 b = *(const f32x4*)(xcol + 4 * (k4 + q));
+            f32x4 a[N];
 #pragma unroll
-        for (int T = 0; T < G::MTS; ++T) a[T] = an[T];
-        if (k4 + 1 < ke) {
+            for (int j = 0; j < N; ++j) {
+                int sj = slot + j;
+                if (sj >= kRing) sj -= kRing;
+                a[j] = *(const f32x4*)(rd + sj * 256 + q * G::TR * 4);
+            }
+            wait_lgkm0();
+            if (q == KU - 1) {  // every fragment of these units is in registers: refill their slots
 #pragma unroll
-            for (int T = 0; T < G::MTS; ++T)
-                if (T < MT) an[T] = pw[(size_t)(T * K4 + k4 + 1) * G::TR + ar];
-        }
-        const f32x4 b = *(const f32x4*)(xcol + 4 * k4);
+                for (int j = 0; j < N; ++j)
+                    if (issued < total) issue();
+                slot += N;
+                if (slot >= kRing) slot -= kRing;
+            }
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+            for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-            for (int T = 0; T < G::MTS; ++T)
-                if (T < MT) acc[T] = mfma4(a[T][kk], b[kk], acc[T]);
+                for (int j = 0; j < N; ++j) acc[j] = mfma4(a[j][kk], b[kk], acc[j]);
         }
     }
 }
 
+template <int NG, int NMAX, int N>
+__device__ __forceinline__ void gemm_dispatch(int nt, const f32x4* __restrict__ pw, int K4e, int tile0, int tstride, int kb, int ke,
+                                              const float* xcol, float* ring, f32x4 (&acc)[NMAX], int lane) {
+    if (nt == N) {
+        f32x4 t[N];
+        gemm_stream<NG, N>(pw, K4e, tile0, tstride, kb, ke, xcol, ring, t, lane);
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j) acc[j] = j < N ? t[j < N ? j : 0] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    } else if constexpr (N > 1) {
+        gemm_dispatch<NG, NMAX, N - 1>(nt, pw, K4e, tile0, tstride, kb, ke, xcol, ring, acc, lane);
+    } else {
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+// ---- small-M GEMM: out[M<=128][BT] = PW[M][K] * XL[K][BT]; K split over the 8 waves --------------
+// (wave must be wave-uniform: __builtin_amdgcn_readfirstlane)
+template <int NG>
+__device__ __forceinline__ void gemm_ksplit(const f32x4* __restrict__ pw, int MT, int K4e, const float* XL, int KS, float* ring,
+                                            f32x4 (&acc)[Geo<NG>::MTS], int wave, int lane) {
+    using G = Geo<NG>;
+    constexpr int KU = 64 / G::TR;
+    const int nku = K4e / KU;
+    const int chunk = (nku + kWaves - 1) / kWaves;
+    const int kb = min(nku, wave * chunk) * KU, ke = min(nku, (wave + 1) * chunk) * KU;
+    const float* xcol = XL + (4 * (lane / G::TR) + (lane & 3)) * KS;
+    gemm_dispatch<NG, G::MTS, G::MTS>(MT, pw, K4e, 0, 1, kb, ke, xcol, ring, acc, lane);
+}
+
 // ---- big-M GEMM: out[M][BT] = PW[M][K] * XL[K][BT]; tiles T = wave + 8*j owned by this wave ------
 template <int NG>
-__device__ __forceinline__ void gemm_rows(const f32x4* __restrict__ pw, int MT, int K4, const float* XL, int KS,
+__device__ __forceinline__ void gemm_rows(const f32x4* __restrict__ pw, int MT, int K4e, const float* XL, int KS, float* ring,
                                           f32x4 (&acc)[Geo<NG>::TPW], int wave, int lane) {
     using G = Geo<NG>;
-    const int ar = lane & (G::TR - 1);
+    const int nt = wave < MT ? min(G::TPW, (MT - wave + kWaves - 1) / kWaves) : 0;
     const float* xcol = XL + (4 * (lane / G::TR) + (lane & 3)) * KS;
-#pragma unroll
-    for (int j = 0; j < G::TPW; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 an[G::TPW];
-#pragma unroll
-    for (int j = 0; j < G::TPW; ++j)
-        if (wave + kWaves * j < MT) an[j] = pw[(size_t)((wave + kWaves * j) * K4) * G::TR + ar];
-    for (int k4 = 0; k4 < K4; ++k4) {
-        f32x4 a[G::TPW];
-#pragma unroll
-        for (int j = 0; j < G::TPW; ++j) a[j] = an[j];
-        if (k4 + 1 < K4) {
-#pragma unroll
-            for (int j = 0; j < G::TPW; ++j)
-                if (wave + kWaves * j < MT) an[j] = pw[(size_t)((wave + kWaves * j) * K4 + k4 + 1) * G::TR + ar];
-        }
-        const f32x4 b = *(const f32x4*)(xcol + 4 * k4);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-            for (int j = 0; j < G::TPW; ++j)
-                if (wave + kWaves * j < MT) acc[j] = mfma4(a[j][kk], b[kk], acc[j]);
-        }
-    }
+    gemm_dispatch<NG, G::TPW, G::TPW>(nt, pw, K4e, wave, kWaves, 0, K4e, xcol, ring, acc, lane);
 }
 
 // position of output (r, c) of a small-M GEMM inside the PART scratch (float index, wave 0)

@@ -95,23 +95,33 @@ __device__ __forceinline__ void st_tile(float* __restrict__ colbase, int row0, i
 // Returns k in the ownership layout.  Three workgroup barriers.
 // ------------------------------------------------------------------------------------------
 template <int NG, int ACT2>
-__device__ __forceinline__ void eval_f(const StepParams& P, float* GL, float* HL, float* PART, float ts,
+__device__ __forceinline__ void eval_f(const StepParams& P, float* GL, float* HL, float* PART, float* RING, float ts,
                                        float* __restrict__ hdst, int col0, f32x4 (&kout)[Geo<NG>::TPW], int tid) {
     using G = Geo<NG>;
     const int lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+#ifdef RNDE_DIAG   // diagnostic build only (tools/diag.sh): s_memtime stamps of workgroup 0, never in the product build
+#define RNDE_STAMP(i) do { if (P.dbg_out && blockIdx.x == 0 && lane == 0) ((unsigned long long*)P.dbg_out)[(wave_u * 8 + (i))] = clock64(); } while (0)
+#else
+#define RNDE_STAMP(i) do { } while (0)
+#endif
+    RNDE_STAMP(0);
     if (tid < G::BT) {
         GL[tid * P.KS1 + P.D] = ts;
         GL[tid * P.KS1 + P.D + 1] = 1.f;
     }
     __syncthreads();
+    RNDE_STAMP(1);
     {
         f32x4 acc[G::MTS];
-        gemm_ksplit<NG>(P.pw1, P.MT1, P.K4_1, GL, P.KS1, acc, wave, lane);
+        gemm_ksplit<NG>(P.pw1, P.MT1, P.K4_1, GL, P.KS1, RING, acc, wave_u, lane);
 #pragma unroll
         for (int T = 0; T < G::MTS; ++T)
             if (T < P.MT1) *(f32x4*)(PART + ((wave * G::MTS + T) * 64 + lane) * 4) = acc[T];
     }
+    RNDE_STAMP(2);
     __syncthreads();
+    RNDE_STAMP(3);
     // (HL's time/bias rows are written here, not earlier: slower waves may still be reading HL in the
     //  previous evaluation's gemm_rows until they pass the barrier above)
     if (tid < G::BT) {
@@ -128,13 +138,17 @@ __device__ __forceinline__ void eval_f(const StepParams& P, float* GL, float* HL
         HL[c * P.KS2 + r] = v;
         if (hdst) hdst[(size_t)(col0 + c) * P.H + r] = v;
     }
+    RNDE_STAMP(4);
     __syncthreads();
-    gemm_rows<NG>(P.pw2, P.MT2, P.K4_2, HL, P.KS2, kout, wave, lane);
+    RNDE_STAMP(5);
+    gemm_rows<NG>(P.pw2, P.MT2, P.K4_2, HL, P.KS2, RING, kout, wave_u, lane);
+    RNDE_STAMP(6);
 #pragma unroll
     for (int j = 0; j < G::TPW; ++j) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) kout[j][i] = act_apply(ACT2, kout[j][i]);
     }
+    RNDE_STAMP(7);
 }
 
 // write a stage input into GL (rows < D only; rows D, D+1 belong to eval_f)
@@ -257,6 +271,7 @@ __global__ __launch_bounds__(kThreads) void rnde_step_kernel(const StepParams P,
     float* PART = HL + G::BT * P.KS2;
     float* RED = PART + kWaves * G::MTS * 256;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* RING = RED + 192 + __builtin_amdgcn_readfirstlane(wave) * (kRing * 256);  // this wave's weight ring
     const int wg = blockIdx.x, col0 = wg * G::BT;
     const Own<NG> own(wave, lane);
     const int gcol = col0 + own.col;
@@ -276,7 +291,7 @@ __global__ __launch_bounds__(kThreads) void rnde_step_kernel(const StepParams P,
 #pragma unroll
         for (int j = 0; j < G::TPW; ++j)
             put_g<NG>(P, GL, own, j, ld_tile(P.x + (size_t)gcol * P.D, own.row0[j], P.D, colok, P.xvec != 0));
-        eval_f<NG, ACT2>(P, GL, HL, PART, P.forced_t, nullptr, col0, kv, tid);
+        eval_f<NG, ACT2>(P, GL, HL, PART, RING, P.forced_t, nullptr, col0, kv, tid);
 #pragma unroll
         for (int j = 0; j < G::TPW; ++j) st_tile(P.dbg_out + (size_t)gcol * P.D, own.row0[j], P.D, colok, false, kv[j]);
         return;
@@ -308,7 +323,7 @@ __global__ __launch_bounds__(kThreads) void rnde_step_kernel(const StepParams P,
             }
         }
         const float ts = (MODE == MODE_INIT_B) ? P.t0 + dt0 : P.t0;
-        eval_f<NG, ACT2>(P, GL, HL, PART, ts, (MODE == MODE_INIT_B) ? P.h1 : P.h0, col0, kv, tid);
+        eval_f<NG, ACT2>(P, GL, HL, PART, RING, ts, (MODE == MODE_INIT_B) ? P.h1 : P.h0, col0, kv, tid);
         float pa = 0.f, pb = 0.f;
 #pragma unroll
         for (int j = 0; j < G::TPW; ++j) {
@@ -347,50 +362,56 @@ __global__ __launch_bounds__(kThreads) void rnde_step_kernel(const StepParams P,
         const float dt = (!P.forced && (P.t1 - S.t < S.dtp)) ? (P.t1 - S.t) : S.dtp;
         const int rec = P.tape ? n : (S.live == 0 ? 1 : 0);
         float* R = P.arena + (long long)rec * P.rec_stride;
-        const float* up; const float* k1p; bool upok, upvec;
-        if (S.live < 0) { up = P.x; k1p = P.f0; upok = colok; upvec = P.xvec != 0; }
-        else { const float* Rl = P.arena + (long long)S.live * P.rec_stride; up = Rl + L.unew(); k1p = Rl + L.k(7); upok = true; upvec = vec; }
+        const float* upsrc; const float* k1p; bool upok, upvec;
+        if (S.live < 0) { upsrc = P.x; k1p = P.f0; upok = colok; upvec = P.xvec != 0; }
+        else { const float* Rl = P.arena + (long long)S.live * P.rec_stride; upsrc = Rl + L.unew(); k1p = Rl + L.k(7); upok = true; upvec = vec; }
 
-        f32x4 st[7][G::TPW];  // uprev, k1..k6
+        // Rolled stage loop.  Sa[i] = sum_j a_{s+1+i, j} k_j is the running combination for the i-th stage still
+        // to come (same ascending-j association as the reference formula g = uprev + dt * sum_j a_sj k_j);
+        // after each stage the array shifts down by one.  E = sum_j btilde_j k_j.
+        f32x4 up[G::TPW], Sa[6][G::TPW], E[G::TPW], un[G::TPW];
 #pragma unroll
         for (int j = 0; j < G::TPW; ++j) {
-            st[0][j] = ld_tile(up + (size_t)gcol * P.D, own.row0[j], P.D, upok, upvec);
-            st[1][j] = ld_tile(k1p + (size_t)gcol * P.D, own.row0[j], P.D, true, vec);
-        }
-        f32x4 un[G::TPW], k7[G::TPW];
+            up[j] = ld_tile(upsrc + (size_t)gcol * P.D, own.row0[j], P.D, upok, upvec);
+            const f32x4 k1 = ld_tile(k1p + (size_t)gcol * P.D, own.row0[j], P.D, true, vec);
 #pragma unroll
-        for (int s = 1; s < 7; ++s) {  // zero-based stage: computes k_{s+1}
+            for (int i = 0; i < 6; ++i) Sa[i][j] = kFwdShift[0][i] * k1;
+            E[j] = kTsBt[0] * k1;
+            un[j] = up[j];
+        }
+#pragma unroll 1
+        for (int s = 1; s < 7; ++s) {  // zero-based stage: computes k_{s+1} = f(g_{s+1}, t + c_s dt)
+            const bool last = (s == 6);
 #pragma unroll
             for (int j = 0; j < G::TPW; ++j) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int jj = 0; jj < s; ++jj) acc += tsA(s, jj) * st[jj + 1][j];
-                const f32x4 g = st[0][j] + dt * acc;
+                const f32x4 g = up[j] + dt * Sa[0][j];
                 put_g<NG>(P, GL, own, j, g);
-                if (s == 6) { un[j] = g; st_tile(R + L.unew() + (size_t)gcol * P.D, own.row0[j], P.D, true, vec, g); }
+                if (last) { un[j] = g; st_tile(R + L.unew() + (size_t)gcol * P.D, own.row0[j], P.D, true, vec, g); }
                 else if (P.tape) st_tile(R + L.g(s + 1) + (size_t)gcol * P.D, own.row0[j], P.D, true, vec, g);
             }
             f32x4 kv[G::TPW];
-            eval_f<NG, ACT2>(P, GL, HL, PART, t + tsC(s) * dt, R + L.h(s + 1), col0, kv, tid);
+            eval_f<NG, ACT2>(P, GL, HL, PART, RING, t + kTsC[s] * dt, R + L.h(s + 1), col0, kv, tid);
+            const float bts = kTsBt[s];
+            float cs[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) cs[i] = kFwdShift[s][i];
 #pragma unroll
             for (int j = 0; j < G::TPW; ++j) {
                 st_tile(R + L.k(s + 1) + (size_t)gcol * P.D, own.row0[j], P.D, true, vec, kv[j]);
-                if (s < 6) st[s + 1][j] = kv[j]; else k7[j] = kv[j];
+                E[j] += bts * kv[j];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) Sa[i][j] = Sa[i + 1][j] + cs[i] * kv[j];
             }
         }
         // ---- embedded error estimate, SURVEY.md B.3: partial sum of (utilde / sk)^2 ----
         float part = 0.f;
 #pragma unroll
         for (int j = 0; j < G::TPW; ++j) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int jj = 0; jj < 6; ++jj) acc += tsBt(jj) * st[jj + 1][j];
-            acc += tsBt(6) * k7[j];
             if (colok) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float ut = dt * acc[i];
-                    const float sk = P.abstol + fmaxf(fabsf(st[0][j][i]), fabsf(un[j][i])) * P.reltol;
+                    const float ut = dt * E[j][i];
+                    const float sk = P.abstol + fmaxf(fabsf(up[j][i]), fabsf(un[j][i])) * P.reltol;
                     const float r = ut / sk;
                     part += r * r;
                 }

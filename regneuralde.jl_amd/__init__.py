@@ -7,3 +7,4 @@ from . import _lib, build  # noqa: F401
 from .layers import Chain, Dense, MLPDynamics, TDChain, destructure  # noqa: F401
 from .node import SavedValues, TrackedNeuralODE  # noqa: F401
 from .classifier import ClassifierNODE, FluxOptimiser, accuracy, lambda_schedule, logitcrossentropy, loss_function  # noqa: F401
+from .dataparallel import GradientAllReducer, shard_columns  # noqa: F401

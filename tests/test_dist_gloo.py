@@ -1,0 +1,51 @@
+"""world_size = 2 on CPU (gloo): the N > 1 path of the training step -- flat gradient all-reduce and
+identical optimiser updates on every rank."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import regneuralde_jl_amd as rn
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    p1 = torch.zeros(0)
+    p2 = torch.randn(1000, requires_grad=True)
+    p3 = torch.randn(37, requires_grad=True)
+    g = torch.Generator().manual_seed(100 + rank)
+    p2.grad = torch.randn(1000, generator=g)
+    p3.grad = torch.randn(37, generator=g)
+    local = torch.cat([p2.grad, p3.grad]).clone()
+    red = rn.GradientAllReducer([p1, p2, p3])
+    red.allreduce_()
+    opt = rn.FluxOptimiser([p1, p2, p3])
+    avg = torch.cat([p2.grad, p3.grad]).clone()
+    opt.step()
+    q.put((rank, local, avg, torch.cat([p2.detach(), p3.detach()])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_and_update_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, l0, a0, w0), (_, l1, a1, w1) = res
+    assert torch.allclose(a0, (l0 + l1) / 2, atol=1e-6) and torch.equal(a0, a1)   # mean of the rank gradients
+    assert torch.equal(w0, w1)                                                     # replicas stay identical

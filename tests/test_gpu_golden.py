@@ -1,0 +1,37 @@
+"""GPU: the HIP path against the committed golden fixtures (tests/golden/*.npz, made by make_golden.py) --
+the check that runs on the GPU box, where neither /root/reference nor Julia exists.
+Tolerances: fp32; u within 2e-5 absolute, gradients within 3e-3 (+ twice the fixture's own fp32-vs-fp64 spread) of the
+largest entry, with the fp64 fixture as arbiter."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.golden.make_golden import inputs
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("name", ["test_node_B1", "test_node_B5", "mnist_small_B4", "mnist_B3"])
+def test_device_reproduces_golden(name):
+    from tests.test_gpu_forward import _cfg
+    from tests.util import Node, rel_err
+    arch, p, x, wu, tol, t1 = inputs(name)
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    node = Node(_cfg(arch, x.shape[0], reltol=tol, abstol=tol))
+    got = node.forward(x.astype(np.float32), p.astype(np.float32), 0.0, t1, keep_tape=True)
+    assert got["nfe"] == int(g["nfe_f32"]) == int(g["nfe_f64"])
+    assert (got["steps"][:, 3] == g["steps_f64"][:, 3]).all()
+    assert np.abs(got["u"] - g["u_f64"]).max() <= 2e-5
+    np.testing.assert_allclose(got["saveval"], g["saveval_f64"], rtol=3e-2, atol=3e-6)   # atol: fp32 noise floor of EEst*dt at tol 1e-3
+    xb, pb, tsb = node.backward(wu.astype(np.float32), np.full(len(got["saveval"]), 25.0, dtype=np.float32))
+    st = int(g["pbar_stride_f64"])
+    print(name, "x-bar", rel_err(xb, g["xbar_f64"]), "(oracle f32:", rel_err(g["xbar_f32"], g["xbar_f64"]), ") p-bar", rel_err(pb[::st], g["pbar_f64"]),
+          "(oracle f32:", rel_err(g["pbar_f32"], g["pbar_f64"]), ")")
+    # gradients of EEst at tol 1e-3 carry fp32 noise: the fixture's own fp32-vs-fp64 spread sets the scale
+    sx, sp = rel_err(g["xbar_f32"], g["xbar_f64"]), rel_err(g["pbar_f32"], g["pbar_f64"])
+    assert rel_err(xb, g["xbar_f64"]) <= 3e-3 + 2 * sx
+    assert rel_err(pb[::st], g["pbar_f64"]) <= 3e-3 + 2 * sp
+    assert abs(np.linalg.norm(pb.astype(np.float64)) - float(g["pbar_norm_f64"])) <= 3e-3 * float(g["pbar_norm_f64"])
+    assert np.abs(tsb - g["tspanbar_f64"]).max() <= 3e-3 * max(1.0, np.abs(g["tspanbar_f64"]).max())

@@ -1,0 +1,77 @@
+"""GPU: the host-side mirror (TrackedNeuralODE / ClassifierNODE) end to end through torch.autograd."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(rn, D=36, Hd=10, B=12, tol=1e-3, regularize=True, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    dyn = rn.MLPDynamics(D, Hd, generator=g)
+    for l in dyn.layers:
+        l.W.mul_(3.0)
+    node = rn.TrackedNeuralODE(dyn, [0.0, 1.0], True, regularize, "Tsit5", save_everystep=False, reltol=tol, abstol=tol,
+                               save_start=False, max_batch=B, max_attempts=64)
+    return node, g
+
+
+def test_layer_call_contract_and_autograd_vs_oracle(rnde):
+    from oracle.oracle import Oracle, arch_mnist
+    rn = rnde
+    D, Hd, B = 36, 10, 12
+    node, g = _model(rn, D, Hd, B)
+    x = torch.rand(B, D, generator=g).cuda().requires_grad_(True)
+    p = node.p.cuda().clone().requires_grad_(True)
+    u, nfe, sv = node(x, p)                                     # (res, nfe, sv), neural_ode.jl:143
+    assert u.shape == (B, D) and isinstance(nfe, int) and nfe % 6 == 3 and sv.saveval.ndim == 1
+    w = torch.randn(B, D, generator=g).cuda()
+    loss = (u * w).sum() + 40.0 * sv.saveval.sum()              # test/test_node.jl:47-57 style objective
+    loss.backward()
+    orc = Oracle(arch_mnist(D, Hd), np.float64, reltol=1e-3, abstol=1e-3, reg_kind=1)
+    r = orc.forward(x.detach().cpu().numpy().astype(np.float64), p.detach().cpu().numpy().astype(np.float64))
+    assert r["nfe"] == nfe
+    xb, pb, _ = orc.backward(w.cpu().numpy().astype(np.float64), np.full(len(r["saveval"]), 40.0))
+    assert np.abs(u.detach().cpu().numpy() - r["u"]).max() < 2e-5
+    assert np.abs(x.grad.cpu().numpy() - xb).max() <= 3e-3 * np.abs(xb).max()
+    assert np.abs(p.grad.cpu().numpy() - pb).max() <= 3e-3 * np.abs(pb).max()
+
+
+def test_unregularised_layer_returns_nothing_for_sv(rnde):
+    node, g = _model(rnde, regularize=False)
+    x = torch.rand(5, 36, generator=g).cuda()
+    with torch.no_grad():
+        u, nfe, sv = node(x)                                     # {false,false} method, neural_ode.jl:48-77
+    assert sv is None and nfe % 6 == 3 and torch.isfinite(u).all()
+
+
+def test_nfe_probe_between_forward_and_backward_keeps_the_tape(rnde):
+    """experiments/mnist_node.jl:245 probes NFE with a plain call; it must not clobber a pending backward."""
+    node, g = _model(rnde)
+    x = torch.rand(8, 36, generator=g).cuda()
+    p = node.p.cuda().clone().requires_grad_(True)
+    u, nfe, sv = node(x, p)
+    with torch.no_grad():
+        node(torch.rand(8, 36, generator=g).cuda(), p)
+    (u.sum() + sv.saveval.mean()).backward()
+    assert torch.isfinite(p.grad).all() and p.grad.abs().max() > 0
+
+
+def test_classifier_training_reduces_loss(rnde):
+    rn = rnde
+    g = torch.Generator().manual_seed(3)
+    dyn = rn.MLPDynamics(784, 100, generator=g)
+    node = rn.TrackedNeuralODE(dyn, [0.0, 1.0], True, True, "Tsit5", save_everystep=False, reltol=1e-3, abstol=1e-3,
+                               save_start=False, max_batch=32, max_attempts=64)
+    model = rn.ClassifierNODE(node, rn.Dense(784, 10, generator=g))
+    opt = rn.FluxOptimiser(model.trainable())
+    x = torch.rand(32, 1, 28, 28, generator=g).cuda()
+    y = torch.eye(10)[torch.randint(0, 10, (32,), generator=g)].cuda()
+    losses = []
+    for _ in range(12):
+        loss, ce, reg, nfe = rn.loss_function(x, y, model, lam=10.0)
+        loss.backward()
+        opt.step()
+        losses.append(float(ce))
+    assert losses[-1] < 0.7 * losses[0], losses
+    assert rn.accuracy(model, [(x, y)]) > 0.3

@@ -1,0 +1,242 @@
+"""CPU tests of the oracle itself (no GPU): what pins it in the absence of a Julia runtime.
+
+1. Tsit5 tableau: row sums, order conditions through order 5 (b), order 4 for the embedded weights,
+   dense-output consistency.
+2. Convergence order on a linear ODE with a known solution.
+3. fp64 finite-difference check of the reverse pass (with saveat, with the controller chain, with a
+   rejected step).
+4. NFE accounting: nfe = 3 + 6 * attempts.
+5. Cross-check of the adaptive solve against scipy's RK45 at tolerance level.
+6. Golden fixtures (tests/golden/*.npz) reproduce.
+"""
+import itertools
+import os
+
+import numpy as np
+import pytest
+import scipy.linalg
+from scipy.integrate import solve_ivp
+
+from oracle.oracle import Oracle, arch_latent, arch_mnist, arch_test_node, glorot_params, make_arch
+from tests.golden.make_golden import CASES, inputs
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+# ---------------------------------------------------------------- 1. tableau
+def _tableau():
+    o = Oracle(arch_test_node(), np.float64)
+    a, c, bt = o.tableau()
+    b = a[6].copy()
+    return o, a, c, b, bt
+
+
+def test_tableau_row_sums_and_fsal():
+    _, a, c, b, bt = _tableau()
+    np.testing.assert_allclose(a.sum(1), c, atol=2e-15)
+    assert b[6] == 0.0 and c[6] == 1.0 and c[5] == 1.0
+    assert abs(bt.sum()) < 1e-15
+
+
+def _order_conditions(a, b, c, order):
+    """Rooted-tree order conditions up to `order` (<= 5): returns max |residual|."""
+    A = a
+    Ac = A @ c
+    res = [b.sum() - 1]
+    if order >= 2:
+        res += [b @ c - 1 / 2]
+    if order >= 3:
+        res += [b @ c**2 - 1 / 3, b @ Ac - 1 / 6]
+    if order >= 4:
+        res += [b @ c**3 - 1 / 4, b @ (c * Ac) - 1 / 8, b @ (A @ c**2) - 1 / 12, b @ (A @ Ac) - 1 / 24]
+    if order >= 5:
+        res += [b @ c**4 - 1 / 5, b @ (c**2 * Ac) - 1 / 10, b @ (Ac * Ac) - 1 / 20, b @ (c * (A @ c**2)) - 1 / 15,
+                b @ (A @ c**3) - 1 / 20, b @ (c * (A @ Ac)) - 1 / 30, b @ (A @ (c * Ac)) - 1 / 40,
+                b @ (A @ (A @ c**2)) - 1 / 60, b @ (A @ (A @ Ac)) - 1 / 120]
+    return max(abs(r) for r in res)
+
+
+def test_tableau_order_conditions():
+    _, a, c, b, bt = _tableau()
+    assert _order_conditions(a, b, c, 5) < 5e-15          # 5th-order solution weights (17 conditions)
+    for sign in (+1, -1):                                 # embedded weights: order 4, not 5 (either sign convention)
+        bh = b + sign * bt
+        assert _order_conditions(a, bh, c, 4) < 5e-15
+        assert _order_conditions(a, bh, c, 5) > 1e-4
+
+
+def test_dense_output_weights():
+    o, a, c, b, bt = _tableau()
+    np.testing.assert_allclose(o.dense_weights(1.0), b, atol=5e-15)
+    np.testing.assert_allclose(o.dense_weights(0.0), 0, atol=1e-300)
+    for th in (0.25, 0.5, 0.8):                           # theta-scaled conditions through order 4
+        bth = o.dense_weights(th)
+        assert abs(bth.sum() - th) < 2e-15
+        assert abs(bth @ c - th**2 / 2) < 2e-15
+        assert abs(bth @ c**2 - th**3 / 3) < 2e-15
+        assert abs(bth @ (a @ c) - th**3 / 6) < 2e-15
+        assert abs(bth @ c**3 - th**4 / 4) < 2e-15
+
+
+# ---------------------------------------------------------------- 2. convergence order
+def test_fixed_step_convergence_order_linear_ode():
+    D = 3
+    arch = make_arch([D, D], ["identity"], False)
+    rng = np.random.default_rng(0)
+    Wm = rng.standard_normal((D, D)) * 0.7
+    bvec = rng.standard_normal(D) * 0.3
+    p = np.concatenate([Wm.T.reshape(-1), bvec])          # column-major (out x in) == row-major (in, out)
+    u0 = rng.standard_normal((1, D))
+    o = Oracle(arch, np.float64)
+    # exact: u' = W u + b
+    M = np.zeros((D + 1, D + 1)); M[:D, :D] = Wm; M[:D, D] = bvec
+    exact = (scipy.linalg.expm(M) @ np.append(u0[0], 1.0))[:D]
+    errs = []
+    for n in (4, 8, 16, 32):
+        u = u0.copy(); dt = 1.0 / n
+        for i in range(n):
+            k1 = o.f_eval(p, u, i * dt)
+            _, u, _, _ = o.attempt(p, u, k1, i * dt, dt)
+        errs.append(np.abs(u[0] - exact).max())
+    rates = np.log2(np.array(errs[:-1]) / np.array(errs[1:]))
+    assert (rates > 4.7).all() and (rates < 5.6).all(), rates
+
+
+# ---------------------------------------------------------------- 3. finite differences (fp64)
+def _fd_check(arch, B, tol, scale, seed, t1=1.0, saveat=None, ws=10.0, eps=1e-6, **kw):
+    rng = np.random.default_rng(seed)
+    p = glorot_params(arch, rng, np.float64); p = (p + 0.1 * rng.standard_normal(p.shape)) * scale
+    x = rng.uniform(0, 1, (B, arch.dims[0]))
+    o = Oracle(arch, np.float64, reltol=tol, abstol=tol, reg_kind=1, **kw)
+    r0 = o.forward(x, p, 0.0, t1, saveat=saveat)
+    wgt = np.random.default_rng(5).standard_normal(r0["u"].shape)
+
+    def loss(x_, p_, t1_=t1):
+        r = o.forward(x_, p_, 0.0, t1_, saveat=saveat)
+        return (r["u"] * wgt).sum() + ws * r["saveval"].sum(), r
+
+    L0, r0 = loss(x, p)
+    xb, pb, tsb = o.backward(wgt, np.full(len(r0["saveval"]), ws))
+    pat = r0["steps"][:, 3].copy()
+    gfd = np.zeros_like(p)
+    for i in range(len(p)):
+        vals = []
+        for s in (1, -1):
+            pp = p.copy(); pp[i] += s * eps
+            v, r = loss(x, pp)
+            assert len(r["steps"]) == len(pat) and (r["steps"][:, 3] == pat).all(), "FD step crossed an accept/reject boundary"
+            vals.append(v)
+        gfd[i] = (vals[0] - vals[1]) / (2 * eps)
+    xfd = np.zeros(x.size)
+    for i in range(x.size):
+        xp = x.copy().reshape(-1); xp[i] += eps
+        xm = x.copy().reshape(-1); xm[i] -= eps
+        xfd[i] = (loss(xp.reshape(x.shape), p)[0] - loss(xm.reshape(x.shape), p)[0]) / (2 * eps)
+    t1fd = (loss(x, p, t1 + eps)[0] - loss(x, p, t1 - eps)[0]) / (2 * eps)
+    ep = np.abs(gfd - pb).max() / np.abs(gfd).max()
+    ex = np.abs(xfd - xb.reshape(-1)).max() / np.abs(xfd).max()
+    return ep, ex, abs(t1fd - tsb[1]) / max(1.0, abs(t1fd)), int((pat == 0).sum())
+
+
+def test_reverse_pass_fd_test_node_shape():
+    ep, ex, et, _ = _fd_check(arch_test_node(), 3, 1e-3, 3.0, 0)
+    assert ep < 1e-5 and ex < 1e-5 and et < 1e-5
+
+
+def test_reverse_pass_fd_mnist_like_shape():
+    ep, ex, et, _ = _fd_check(arch_mnist(12, 5), 4, 1e-2, 5.0, 1)
+    assert ep < 1e-5 and ex < 1e-5 and et < 1e-5
+
+
+def test_reverse_pass_fd_latent_chain_with_saveat():
+    ep, ex, et, _ = _fd_check(arch_latent(), 2, 1e-3, 2.0, 4, saveat=np.array([0.0, 0.13, 0.5, 0.77, 1.0]))
+    assert ep < 1e-5 and ex < 1e-5
+
+
+def test_reverse_pass_fd_with_rejected_step():
+    # one rejected step (seed found by search; the regime is rough, hence the looser bound)
+    ep, ex, et, nrej = _fd_check(arch_test_node(), 3, 1e-2, 15.0, 9, t1=3.0, eps=1e-6)
+    assert nrej >= 1
+    assert ep < 2e-4 and ex < 2e-4
+
+
+def test_track_ctrl_off_cuts_only_the_controller_chain():
+    """With track_ctrl=0 the dt_next = dt/q path is not differentiated; for a loss that does not depend on the
+    step sizes beyond discretisation error (ws = 0) the gradient is essentially unchanged."""
+    arch = arch_test_node(); rng = np.random.default_rng(3)
+    p = glorot_params(arch, rng, np.float64); p = (p + 0.1 * rng.standard_normal(p.shape)) * 3.0
+    x = rng.uniform(0, 1, (3, 2))
+    g = []
+    for tc in (1, 0):
+        o = Oracle(arch, np.float64, reltol=1e-6, abstol=1e-6, reg_kind=1, track_ctrl=tc)
+        r = o.forward(x, p)
+        g.append(o.backward(np.ones_like(x), np.zeros(len(r["saveval"])))[1])
+    assert np.abs(g[0] - g[1]).max() < 1e-4 * np.abs(g[0]).max()
+
+
+# ---------------------------------------------------------------- 4. NFE accounting
+@pytest.mark.parametrize("tol", [1e-2, 1e-4, 1e-6])
+def test_nfe_is_3_plus_6_per_attempt(tol):
+    arch = arch_test_node(); rng = np.random.default_rng(2)
+    p = glorot_params(arch, rng, np.float32, 4.0); x = rng.uniform(0, 1, (5, 2)).astype(np.float32)
+    r = Oracle(arch, np.float32, reltol=tol, abstol=tol).forward(x, p)
+    assert r["nfe"] == 3 + 6 * r["nattempts"] and r["nfe"] % 6 == 3
+    assert len(r["saveval"]) == int(r["steps"][:, 3].sum()) + 1 and r["saveval"][0] == 0.0   # callback start value
+    acc = r["steps"][r["steps"][:, 3] == 1]
+    np.testing.assert_allclose(r["saveval"][1:], acc[:, 2] * acc[:, 1], rtol=1e-6)            # EEst * dt
+    assert abs(acc[:, 1].sum() - 1.0) < 1e-5                                                  # accepted steps tile [0,1]
+
+
+# ---------------------------------------------------------------- 5. scipy cross-check
+def test_against_scipy_rk45():
+    arch = arch_test_node(); rng = np.random.default_rng(7)
+    p = glorot_params(arch, rng, np.float64, 3.0); x = rng.uniform(0, 1, (4, 2))
+    o = Oracle(arch, np.float64, reltol=1e-9, abstol=1e-9)
+    r = o.forward(x, p)
+    sol = solve_ivp(lambda t, u: o.f_eval(p, u.reshape(4, 2), t).reshape(-1), (0, 1), x.reshape(-1), method="RK45",
+                    rtol=1e-10, atol=1e-12)
+    assert np.abs(sol.y[:, -1] - r["u"].reshape(-1)).max() < 1e-7
+
+
+def test_f32_and_f64_builds_agree():
+    arch = arch_mnist(36, 10); rng = np.random.default_rng(8)
+    p = glorot_params(arch, rng, np.float32, 3.0); x = rng.uniform(0, 1, (6, 36)).astype(np.float32)
+    a = Oracle(arch, np.float32, reltol=1e-3, abstol=1e-3).forward(x, p)
+    b = Oracle(arch, np.float64, reltol=1e-3, abstol=1e-3).forward(x, p)
+    assert a["nfe"] == b["nfe"]
+    assert np.abs(a["u"] - b["u"]).max() < 1e-5
+
+
+def test_parameter_layout_is_flux_destructure():
+    """Hand-built case: p = [vec(W1) (out x in+1, column-major); b1; vec(W2); b2] (neural_ode.jl:12)."""
+    arch = arch_test_node()
+    W1 = np.arange(30, dtype=np.float64).reshape(3, 10).T * 0.01     # (out=10, in+1=3)
+    b1 = np.linspace(-0.1, 0.1, 10)
+    W2 = np.arange(22, dtype=np.float64).reshape(11, 2).T * 0.02 - 0.2
+    b2 = np.array([0.3, -0.4])
+    p = np.concatenate([W1.T.reshape(-1), b1, W2.T.reshape(-1), b2])   # column-major vec(W) == W.T row-major flatten
+    u = np.array([[0.2, -0.7]]); t = 0.4
+    h = np.tanh(W1 @ np.array([0.2, -0.7, t]) + b1)
+    ref = W2 @ np.append(h, t) + b2
+    got = Oracle(arch, np.float64).f_eval(p, u, t)
+    np.testing.assert_allclose(got[0], ref, atol=1e-14)
+
+
+# ---------------------------------------------------------------- 6. golden fixtures
+@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("tag,dt", [("f32", np.float32), ("f64", np.float64)])
+def test_oracle_reproduces_golden(name, tag, dt):
+    arch, p, x, wu, tol, t1 = inputs(name)
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    o = Oracle(arch, dt, reltol=tol, abstol=tol, reg_kind=1)
+    r = o.forward(x, p, 0.0, t1)
+    assert r["nfe"] == int(g[f"nfe_{tag}"])
+    rt = 1e-12 if dt == np.float64 else 2e-5   # fp32 build: OpenMP/FMA contraction may differ between hosts
+    np.testing.assert_allclose(r["u"], g[f"u_{tag}"], rtol=rt, atol=rt)
+    np.testing.assert_allclose(r["steps"][:, 3], g[f"steps_{tag}"][:, 3])
+    xb, pb, tsb = o.backward(wu, np.full(len(r["saveval"]), 25.0))
+    gt = 1e-9 if dt == np.float64 else 2e-3
+    np.testing.assert_allclose(xb, g[f"xbar_{tag}"], rtol=gt, atol=gt * np.abs(g[f"xbar_{tag}"]).max())
+    st = int(g[f"pbar_stride_{tag}"])
+    np.testing.assert_allclose(pb[::st], g[f"pbar_{tag}"], rtol=gt, atol=gt * np.abs(g[f"pbar_{tag}"]).max())
+    assert abs(np.linalg.norm(pb.astype(np.float64)) - float(g[f"pbar_norm_{tag}"])) <= gt * float(g[f"pbar_norm_{tag}"])

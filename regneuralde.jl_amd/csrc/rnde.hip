@@ -3,6 +3,7 @@
 #include "../../include/rnde.h"
 #include "rnde_fwd.h"
 #include "rnde_bwd.h"
+#include "rnde_stage.h"
 
 #include <cmath>
 #include <cstdio>
@@ -19,6 +20,12 @@ struct rnde_node {
     int K4_1t = 0, MT1t = 0, K4_2t = 0, MT2t = 0;                // reverse GEMM geometry
     int Bpad_max = 0, nwg_max = 0;
     size_t lds_bytes = 0;
+    // stage engine (rnde_stage.h)
+    int engine = 1;                       // 1 column-owner, 2 stage kernels
+    int sMT = 0, sWT = 0, sR = 0, sHT = 0, sK2b = 0, sKHb = 0;
+    f32x4 *spwB = nullptr, *spwD = nullptr, *spwBt = nullptr, *spwDt = nullptr;
+    float* slab2 = nullptr;
+    size_t stage_lds = 0;
     // device
     float *f0 = nullptr, *h0 = nullptr, *u1 = nullptr, *f1 = nullptr, *h1 = nullptr, *arena = nullptr;
     float* xcopy = nullptr;  // private copy of x (the tape must not alias caller memory)
@@ -73,8 +80,8 @@ static StepParams make_params(rnde_node* h, const float* x, int B, float t0, flo
     P.ctl = h->ctl; P.ctl_final = h->ctl_final; P.meta = h->meta; P.initrec = h->initrec;
     P.errpart = h->errpart; P.initpart = h->initpart; P.dbg_out = nullptr;
     P.D = h->D; P.H = h->H; P.B = B;
-    P.Bpad = ((B + h->BT - 1) / h->BT) * h->BT;
-    P.nwg = P.Bpad / h->BT;
+    P.Bpad = ((B + 15) / 16) * 16;   // both engines pad the batch to 16 columns (one tape format)
+    P.nwg = h->engine == 2 ? h->sR * (P.Bpad / 16) : P.Bpad / h->BT;
     P.K4_1 = h->K4_1; P.KS1 = h->KS1; P.MT1 = h->MT1; P.K4_2 = h->K4_2; P.KS2 = h->KS2; P.MT2 = h->MT2;
     P.reltol = h->cfg.reltol; P.abstol = h->cfg.abstol; P.t0 = t0; P.t1 = t1;
     P.tape = tape; P.max_attempts = h->cfg.max_attempts;
@@ -131,8 +138,8 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
     rnde_node* h = new rnde_node();
     h->cfg = *c;
     h->D = c->dims[0]; h->H = c->dims[1]; h->P = rnde_param_count(c); h->act2 = c->act[1];
-    h->BT = c->col_tile ? c->col_tile : 8;
-    if (h->BT != 4 && h->BT != 8) { g_create_err = "col_tile must be 0, 4 or 8"; delete h; return RNDE_ERR_BAD_ARG; }
+    h->BT = (c->col_tile == 4) ? 4 : 8;   // column-owner tile (also used by the reverse sweep of the stage engine for now)
+    if (c->col_tile != 0 && c->col_tile != 4 && c->col_tile != 8 && c->col_tile != 16) { g_create_err = "col_tile must be 0 (auto), 4, 8 (column-owner engine) or 16 (stage engine)"; delete h; return RNDE_ERR_BAD_ARG; }
     h->NG = h->BT / 4;
     const int TR = 64 / h->NG, TPW = (h->NG == 1) ? 2 : 4;
     if (h->H + 2 > 128 || h->D + 2 > kWaves * TPW * TR || h->D < 1 || h->H < 1 || c->max_batch < 1 || c->max_attempts < 1) {
@@ -144,8 +151,15 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
     h->K4_2 = up4(h->H + 2); h->KS2 = 4 * (h->K4_2 | 1); h->MT2 = (h->D + TR - 1) / TR;
     h->K4_2t = up4(h->D); h->MT2t = (h->H + 1 + TR - 1) / TR;   // pw2t: M = H+1, K = D   (B operand image uses KS1)
     h->K4_1t = up4(h->H); h->MT1t = (h->D + 1 + TR - 1) / TR;   // pw1t: M = D+1, K = H   (B operand image uses KS2)
-    h->Bpad_max = ((c->max_batch + h->BT - 1) / h->BT) * h->BT;
-    h->nwg_max = h->Bpad_max / h->BT;
+    h->Bpad_max = ((c->max_batch + 15) / 16) * 16;
+    // stage engine geometry: WT row tiles (waves) per block chosen to minimise padding, preferring more waves
+    h->sMT = (h->D + 15) / 16; h->sHT = (h->H + 1 + 15) / 16; h->sK2b = (h->H + 2 + 15) / 16; h->sKHb = (h->H + 15) / 16;
+    { int best = 1, bw = 1 << 30;
+      for (int wt = std::min(8, h->sMT); wt >= std::max(1, std::min(4, h->sMT)); --wt) { int R = (h->sMT + wt - 1) / wt; int waste = R * wt - h->sMT; if (waste < bw) { bw = waste; best = wt; } }
+      h->sWT = best; h->sR = (h->sMT + best - 1) / best; }
+    h->engine = (c->col_tile == 16 || c->col_tile == 0) ? 2 : 1;
+    h->nwg_max = std::max(h->Bpad_max / h->BT, h->sR * (h->Bpad_max / 16));
+    h->stage_lds = sizeof(float) * ((size_t)16 * (16 * std::max(h->sK2b, h->sHT) + 4) + (size_t)16 * (16 * std::max(h->sWT, h->sKHb) + 4) + 64);
     const int MTS = 128 / TR;
     h->lds_bytes = sizeof(float) * ((size_t)h->BT * h->KS1 + (size_t)h->BT * h->KS2 + (size_t)kWaves * MTS * 256 + 192 + (size_t)kWaves * kRing * 256);
     if (hipSetDevice(c->device) != hipSuccess) { g_create_err = "hipSetDevice failed"; delete h; return RNDE_ERR_HIP; }
@@ -159,6 +173,9 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
     ok &= dm((void**)&h->pw1, (size_t)h->MT1 * h->K4_1 * TR * 16) && dm((void**)&h->pw2, (size_t)h->MT2 * h->K4_2 * TR * 16);
     ok &= dm((void**)&h->pw1t, (size_t)h->MT1t * h->K4_1t * TR * 16) && dm((void**)&h->pw2t, (size_t)h->MT2t * h->K4_2t * TR * 16);
     ok &= dm((void**)&h->pcopy, (size_t)h->P * 4);
+    ok &= dm((void**)&h->spwB, (size_t)h->sMT * h->sK2b * 64 * 16) && dm((void**)&h->spwD, (size_t)h->sHT * h->sMT * 64 * 16);
+    ok &= dm((void**)&h->spwBt, (size_t)h->sMT * h->sKHb * 64 * 16) && dm((void**)&h->spwDt, (size_t)h->sHT * h->sMT * 64 * 16);
+    ok &= dm((void**)&h->slab2, (size_t)2 * (h->Bpad_max / 16) * h->sR * h->sHT * 64 * 16);
     ok &= dm((void**)&h->ctl, 2 * sizeof(StepState)) && dm((void**)&h->ctl_final, sizeof(StepState));
     ok &= dm((void**)&h->meta, (size_t)(c->max_attempts + 1) * sizeof(StepMeta)) && dm((void**)&h->initrec, sizeof(InitRec));
     ok &= dm((void**)&h->errpart, (size_t)2 * h->nwg_max * 4) && dm((void**)&h->initpart, (size_t)3 * h->nwg_max * 4);
@@ -178,7 +195,7 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
 
 extern "C" void rnde_node_destroy(rnde_node* h) {
     if (!h) return;
-    void* d[] = {h->f0, h->h0, h->u1, h->f1, h->h1, h->arena, h->xcopy, h->pw1, h->pw2, h->pw1t, h->pw2t, h->pcopy,
+    void* d[] = {h->f0, h->h0, h->u1, h->f1, h->h1, h->arena, h->xcopy, h->pw1, h->pw2, h->pw1t, h->pw2t, h->pcopy, h->spwB, h->spwD, h->spwBt, h->spwDt, h->slab2,
                  h->ctl, h->ctl_final, h->meta, h->initrec, h->errpart, h->initpart};
     for (void* p : d) if (p) hipFree(p);
     bwd_free(h->bw);
@@ -208,6 +225,40 @@ static rnde_status pack_weights(rnde_node* h, const float* p_dev, bool reverse, 
     return RNDE_OK;
 }
 
+// ---- stage engine host side ----------------------------------------------------------------------
+static StageParams make_stage_params(rnde_node* h, const StepParams& P, const float* p_dev) {
+    StageParams Q{};
+    Q.F = P; Q.p = p_dev; Q.pwB = h->spwB; Q.pwD = h->spwD; Q.slab = h->slab2;
+    Q.MT = h->sMT; Q.WT = h->sWT; Q.R = h->sR; Q.C = P.Bpad / 16; Q.HT = h->sHT; Q.K2b = h->sK2b; Q.Bpad16 = P.Bpad;
+    return Q;
+}
+template <int ACT2, int MODE>
+static hipError_t launch_stage_t(rnde_node* h, const StageParams& Q, int n, int s, hipStream_t st) {
+    hipLaunchKernelGGL((rnde_stage_kernel<ACT2, MODE>), dim3(Q.R * Q.C), dim3(64 * Q.WT), h->stage_lds, st, Q, n, s);
+    return hipGetLastError();
+}
+template <int MODE>
+static hipError_t launch_stage(rnde_node* h, const StageParams& Q, int n, int s, hipStream_t st) {
+    return h->act2 ? launch_stage_t<1, MODE>(h, Q, n, s, st) : launch_stage_t<0, MODE>(h, Q, n, s, st);
+}
+static hipError_t stage_pack(rnde_node* h, const float* p, f32x4* dst, int which, int MTrows, int Kb, hipStream_t st) {
+    const long long total = (long long)MTrows * Kb * 64;
+    const int grid = (int)std::min<long long>((total + 255) / 256, 1024);
+    hipLaunchKernelGGL(rnde_stage_pack_kernel, dim3(grid), dim3(256), 0, st, p, dst, which, h->D, h->H, MTrows, Kb);
+    return hipGetLastError();
+}
+static rnde_status stage_pack_weights(rnde_node* h, const float* p_dev, hipStream_t s) {
+    HIPCHK(h, stage_pack(h, p_dev, h->spwB, 0, h->sMT, h->sK2b, s));
+    HIPCHK(h, stage_pack(h, p_dev, h->spwD, 1, h->sHT, h->sMT, s));
+    return RNDE_OK;
+}
+static hipError_t stage_attempt(rnde_node* h, const StageParams& Q, int n, hipStream_t s) {
+    hipError_t e = launch_stage<SM_START>(h, Q, n, 0, s);
+    for (int st = 1; st <= 5 && e == hipSuccess; ++st) e = launch_stage<SM_STAGE>(h, Q, n, st, s);
+    if (e == hipSuccess) e = launch_stage<SM_LAST>(h, Q, n, 6, s);
+    return e;
+}
+
 extern "C" rnde_status rnde_node_forward(rnde_node* h, const float* x_dev, const float* p_dev, int32_t B, float t0,
                                          float t1, float* u_out_dev, int64_t* nfe_out, float* saveval_host,
                                          int32_t* n_saveval_out, int32_t keep_tape, void* stream) {
@@ -227,16 +278,32 @@ extern "C" rnde_status rnde_node_forward(rnde_node* h, const float* x_dev, const
     }
     StepParams P = make_params(h, x_dev, B, t0, t1, keep_tape ? 1 : 0);
     h->B = B; h->Bpad = P.Bpad; h->nwg = P.nwg; h->t0 = t0; h->t1 = t1;
-    rnde_status st = pack_weights(h, p_dev, keep_tape != 0, s);
+    rnde_status st = pack_weights(h, p_dev, keep_tape != 0, s);   // (column-owner packs: also used by the reverse sweep)
     if (st != RNDE_OK) return st;
-    HIPCHK(h, launch_step<MODE_INIT_A>(h, P, 0, s));
-    HIPCHK(h, launch_step<MODE_INIT_B>(h, P, 0, s));
+    StageParams SQ{};
+    if (h->engine == 2) {
+        st = stage_pack_weights(h, keep_tape ? h->pcopy : p_dev, s);
+        if (st != RNDE_OK) return st;
+        SQ = make_stage_params(h, P, keep_tape ? h->pcopy : p_dev);
+        HIPCHK(h, launch_stage<SM_I1>(h, SQ, 0, 0, s));
+        HIPCHK(h, launch_stage<SM_I2>(h, SQ, 0, 0, s));
+        HIPCHK(h, launch_stage<SM_I3>(h, SQ, 0, 0, s));
+        HIPCHK(h, launch_stage<SM_I4>(h, SQ, 0, 0, s));
+    } else {
+        HIPCHK(h, launch_step<MODE_INIT_A>(h, P, 0, s));
+        HIPCHK(h, launch_step<MODE_INIT_B>(h, P, 0, s));
+    }
     int launched = 0;
     int chunk = std::max(4, h->predicted);
     const int cap = h->cfg.max_attempts;
     while (true) {
-        for (int i = 0; i < chunk && launched < cap; ++i) { HIPCHK(h, launch_step<MODE_STEP>(h, P, launched, s)); ++launched; }
-        HIPCHK(h, launch_finish(h, P, launched, u_out_dev, s));
+        for (int i = 0; i < chunk && launched < cap; ++i) {
+            if (h->engine == 2) HIPCHK(h, stage_attempt(h, SQ, launched, s));
+            else HIPCHK(h, launch_step<MODE_STEP>(h, P, launched, s));
+            ++launched;
+        }
+        if (h->engine == 2) { hipLaunchKernelGGL(rnde_stage_finish_kernel, dim3(64), dim3(256), 0, s, SQ, launched, u_out_dev); HIPCHK(h, hipGetLastError()); }
+        else HIPCHK(h, launch_finish(h, P, launched, u_out_dev, s));
         HIPCHK(h, hipMemcpyAsync(h->h_ctl, h->ctl_final, sizeof(StepState), hipMemcpyDeviceToHost, s));
         HIPCHK(h, hipStreamSynchronize(s));
         if (h->h_ctl->done) break;
@@ -330,6 +397,15 @@ extern "C" rnde_status rnde_debug_feval(rnde_node* h, const float* u_dev, const 
     hipStream_t s = (hipStream_t)stream;
     StepParams P = make_params(h, u_dev, B, 0.f, 1.f, 0);
     P.forced = 1; P.forced_t = t; P.dbg_out = out_dev;
+    if (h->engine == 2) {
+        rnde_status st2 = stage_pack_weights(h, p_dev, s);
+        if (st2 != RNDE_OK) return st2;
+        StageParams SQ = make_stage_params(h, P, p_dev);
+        HIPCHK(h, launch_stage<SM_FEVAL1>(h, SQ, 0, 0, s));
+        HIPCHK(h, launch_stage<SM_FEVAL2>(h, SQ, 0, 0, s));
+        HIPCHK(h, hipStreamSynchronize(s));
+        return RNDE_OK;
+    }
     rnde_status st = pack_weights(h, p_dev, false, s);
     if (st != RNDE_OK) return st;
     HIPCHK(h, launch_step<MODE_FEVAL>(h, P, 0, s));
@@ -350,8 +426,17 @@ extern "C" rnde_status rnde_debug_attempt(rnde_node* h, const float* uprev_dev, 
     // k1 goes to the f0 buffer (column stride D in both layouts)
     HIPCHK(h, hipMemsetAsync(h->f0, 0, (size_t)h->D * P.Bpad * 4, s));
     HIPCHK(h, hipMemcpyAsync(h->f0, k1_dev, (size_t)h->D * B * 4, hipMemcpyDeviceToDevice, s));
-    HIPCHK(h, launch_step<MODE_STEP>(h, P, 0, s));
-    HIPCHK(h, launch_finish(h, P, 1, nullptr, s));
+    if (h->engine == 2) {
+        rnde_status st2 = stage_pack_weights(h, p_dev, s);
+        if (st2 != RNDE_OK) return st2;
+        StageParams SQ = make_stage_params(h, P, p_dev);
+        HIPCHK(h, stage_attempt(h, SQ, 0, s));
+        hipLaunchKernelGGL(rnde_stage_finish_kernel, dim3(64), dim3(256), 0, s, SQ, 1, (float*)nullptr);
+        HIPCHK(h, hipGetLastError());
+    } else {
+        HIPCHK(h, launch_step<MODE_STEP>(h, P, 0, s));
+        HIPCHK(h, launch_finish(h, P, 1, nullptr, s));
+    }
     HIPCHK(h, hipMemcpyAsync(h->h_ctl, h->ctl_final, sizeof(StepState), hipMemcpyDeviceToHost, s));
     RecLayout L{(long long)h->D * P.Bpad, (long long)h->H * P.Bpad};
     const float* R = h->arena;  // record 0 (no-tape: live == -1 -> rec 0)
@@ -372,12 +457,25 @@ extern "C" rnde_status rnde_bench_attempt(rnde_node* h, const float* x_dev, cons
     P.forced = 1; P.forced_t = 0.f; P.forced_dt = 0.05f;
     rnde_status st = pack_weights(h, p_dev, false, s);
     if (st != RNDE_OK) return st;
-    HIPCHK(h, launch_step<MODE_INIT_A>(h, P, 0, s));  // k1 = f(x, 0) into f0
-    for (int i = 0; i < 3; ++i) HIPCHK(h, launch_step<MODE_STEP>(h, P, 0, s));
+    StageParams SQ{};
+    if (h->engine == 2) {
+        st = stage_pack_weights(h, p_dev, s);
+        if (st != RNDE_OK) return st;
+        SQ = make_stage_params(h, P, p_dev);
+        HIPCHK(h, launch_stage<SM_I1>(h, SQ, 0, 0, s));
+        HIPCHK(h, launch_stage<SM_I2>(h, SQ, 0, 0, s));   // k1 = f(x, 0) into f0
+        for (int i = 0; i < 3; ++i) HIPCHK(h, stage_attempt(h, SQ, 0, s));
+    } else {
+        HIPCHK(h, launch_step<MODE_INIT_A>(h, P, 0, s));  // k1 = f(x, 0) into f0
+        for (int i = 0; i < 3; ++i) HIPCHK(h, launch_step<MODE_STEP>(h, P, 0, s));
+    }
     hipEvent_t e0, e1;
     HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
     HIPCHK(h, hipEventRecord(e0, s));
-    for (int i = 0; i < iters; ++i) HIPCHK(h, launch_step<MODE_STEP>(h, P, 0, s));
+    for (int i = 0; i < iters; ++i) {
+        if (h->engine == 2) HIPCHK(h, stage_attempt(h, SQ, 0, s));
+        else HIPCHK(h, launch_step<MODE_STEP>(h, P, 0, s));
+    }
     HIPCHK(h, hipEventRecord(e1, s));
     HIPCHK(h, hipEventSynchronize(e1));
     float ms = 0.f;
@@ -389,9 +487,10 @@ extern "C" rnde_status rnde_bench_attempt(rnde_node* h, const float* x_dev, cons
         unsigned long long* d = nullptr; unsigned long long hst[64];
         hipMalloc((void**)&d, sizeof(hst)); hipMemset(d, 0, sizeof(hst));
         P.dbg_out = (float*)d;
-        launch_step<MODE_STEP>(h, P, 0, s); hipStreamSynchronize(s);
+        if (h->engine == 2) { SQ.F.dbg_out = (float*)d; stage_attempt(h, SQ, 0, s); } else launch_step<MODE_STEP>(h, P, 0, s);
+        hipStreamSynchronize(s);
         hipMemcpy(hst, d, sizeof(hst), hipMemcpyDeviceToHost); hipFree(d);
-        fprintf(stderr, "stamps (cycles since wave0 stamp0): start sync1 gemm1 sync2 reduce sync3 gemm2 tanh\n");
+        fprintf(stderr, "stamps (cycles since wave0 stamp0); column-owner: start sync1 gemm1 sync2 reduce sync3 gemm2 tanh | stage: start scalars A sync B C sync D\n");
         for (int w = 0; w < 8; ++w) { fprintf(stderr, "wave %d:", w); for (int i = 0; i < 8; ++i) fprintf(stderr, " %7lld", (long long)(hst[w * 8 + i] - hst[0])); fprintf(stderr, "\n"); }
     }
 #endif

@@ -68,6 +68,16 @@ __constant__ float kBwdShift[7][6] = {
     {-0.028269050394068383f, -0.071584973281401f, 8.159367898576159f, -12.92096931784711f, 5.86145544294642f, 0.f},
     {2.324710524099774f, -3.290069515436081f, 1.379008574103742f, 0.4798896504144996f, 0.01f, 0.09646076681806523f},
 };
+// kTsA[s][j] = a_{s+1,j+1}: run-time indexed copy of tsA (stage engine)
+__constant__ float kTsA[7][8] = {
+    {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f},
+    {0.161f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f},
+    {-0.008480655492356989f, 0.335480655492357f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f},
+    {2.8971530571054935f, -6.359448489975075f, 4.3622954328695815f, 0.f, 0.f, 0.f, 0.f, 0.f},
+    {5.325864828439257f, -11.748883564062828f, 7.4955393428898365f, -0.09249506636175525f, 0.f, 0.f, 0.f, 0.f},
+    {5.86145544294642f, -12.92096931784711f, 8.159367898576159f, -0.071584973281401f, -0.028269050394068383f, 0.f, 0.f, 0.f},
+    {0.09646076681806523f, 0.01f, 0.4798896504144996f, 1.379008574103742f, -3.290069515436081f, 2.324710524099774f, 0.f, 0.f}};
+__device__ __forceinline__ float tsA_rt(int s, int j) { return kTsA[s][j]; }
 __constant__ float kTsC[8] = {0.f, 0.161f, 0.327f, 0.9f, 0.9800255409045097f, 1.0f, 1.0f, 0.f};
 __constant__ float kTsBt[8] = {-0.001780011052225777f, -0.0008164344596567469f, 0.007880878010261995f, -0.1447110071732629f, 0.5823571654525552f, -0.45808210592918697f, 0.015151515151515152f, 0.f};
 // PI controller constants

@@ -32,7 +32,8 @@ def _cfg(arch, B, **kw):
 
 
 @pytest.mark.parametrize("kind,B,col_tile", [("mnist", 16, 8), ("mnist", 13, 8), ("mnist", 8, 4), ("test_node", 1, 8),
-                                             ("test_node", 5, 4), ("small", 9, 8)])
+                                             ("test_node", 5, 4), ("small", 9, 8), ("mnist", 16, 16), ("mnist", 37, 16),
+                                             ("test_node", 3, 16), ("small", 9, 16)])
 def test_feval_matches_oracle(kind, B, col_tile):
     from tests.util import Node, Oracle
     arch, p, x = _setup(kind, B, 1)
@@ -44,7 +45,8 @@ def test_feval_matches_oracle(kind, B, col_tile):
     assert np.abs(got - ref32).max() <= 2e-5
 
 
-@pytest.mark.parametrize("kind,B,col_tile", [("mnist", 16, 8), ("mnist", 11, 8), ("mnist", 12, 4), ("test_node", 3, 8), ("small", 9, 8)])
+@pytest.mark.parametrize("kind,B,col_tile", [("mnist", 16, 8), ("mnist", 11, 8), ("mnist", 12, 4), ("test_node", 3, 8), ("small", 9, 8),
+                                             ("mnist", 16, 16), ("mnist", 21, 16), ("test_node", 3, 16), ("small", 9, 16)])
 def test_attempt_matches_oracle(kind, B, col_tile):
     from tests.util import Node, Oracle
     arch, p, x = _setup(kind, B, 2)
@@ -70,14 +72,15 @@ def test_attempt_matches_oracle(kind, B, col_tile):
                                                        ("mnist", 32, 1e-3, 3.0, 1.0, 3), ("test_node", 3, 1e-2, 10.0, 3.0, 0),
                                                        ("test_node", 3, 1e-2, 8.0, 3.0, 8), ("mnist", 19, 1e-2, 6.0, 2.0, 5),
                                                        ("small", 6, 1e-2, 15.0, 2.0, 12)])
-def test_forward_solve_exact_sequence(kind, B, tol, scale, t1, seed):
+@pytest.mark.parametrize("col_tile", [16, 8])
+def test_forward_solve_exact_sequence(kind, B, tol, scale, t1, seed, col_tile):
     """Truncation-dominated regime (EEst >> fp32 noise floor eps*dt*|k|/tol): accept/reject sequence, NFE and
     the dt sequence must match the oracle; includes cases with rejected steps."""
     from tests.util import Node, Oracle
     arch, p, x = _setup(kind, B, seed, scale)
     orc = Oracle(arch, np.float32, reltol=tol, abstol=tol, reg_kind=1)
     ref = orc.forward(x, p, 0.0, t1)
-    node = Node(_cfg(arch, B, reltol=tol, abstol=tol))
+    node = Node(_cfg(arch, B, reltol=tol, abstol=tol, col_tile=col_tile))
     got = node.forward(x, p, 0.0, t1)
     print(kind, "attempts", got["nattempts"], "rejected", int((ref["steps"][:, 3] == 0).sum()))
     assert got["nattempts"] == ref["nattempts"]
@@ -94,8 +97,9 @@ def test_forward_solve_exact_sequence(kind, B, tol, scale, t1, seed):
     assert len(got["saveval"]) == len(ref["saveval"])
 
 
+@pytest.mark.parametrize("col_tile", [16, 8])
 @pytest.mark.parametrize("kind,B", [("test_node", 1), ("mnist", 64)])
-def test_forward_solve_reference_tolerance(kind, B):
+def test_forward_solve_reference_tolerance(kind, B, col_tile):
     """reltol = abstol = 1.4e-8 in fp32 (the reference's setting, experiments/mnist_node.jl:122-123) sits on the
     fp32 rounding-noise floor of the error estimate (see test_attempt_matches_oracle): step sizes are set by
     noise, so attempt counts agree statistically, not exactly.  u_end must still agree to 1e-5 absolute
@@ -104,7 +108,7 @@ def test_forward_solve_reference_tolerance(kind, B):
     arch, p, x = _setup(kind, B, 3)
     ref = Oracle(arch, np.float32, reltol=1.4e-8, abstol=1.4e-8, reg_kind=1).forward(x, p)
     ref64 = Oracle(arch, np.float64, reltol=1.4e-8, abstol=1.4e-8, reg_kind=1).forward(x, p)
-    got = Node(_cfg(arch, B)).forward(x, p)
+    got = Node(_cfg(arch, B, col_tile=col_tile)).forward(x, p)
     print(f"attempts: device {got['nattempts']}, oracle f32 {ref['nattempts']}, oracle f64 {ref64['nattempts']}")
     assert got["nfe"] == 3 + 6 * got["nattempts"]
     assert abs(got["nattempts"] - ref["nattempts"]) <= 0.25 * ref["nattempts"] + 1

@@ -4,6 +4,7 @@
 #include "rnde_fwd.h"
 #include "rnde_bwd.h"
 #include "rnde_stage.h"
+#include "rnde_bstage.h"
 
 #include <cmath>
 #include <cstdio>
@@ -518,6 +519,10 @@ static rnde_status bwd_prepare(rnde_node* h) {
     const size_t seg = std::max((size_t)h->H * (h->D + 2), (size_t)h->D * (h->H + 2));
     b.slab_floats = seg * 128;
     HIPCHK(h, hipMalloc((void**)&b.slab, b.slab_floats * 4));
+    if (h->engine == 2) {
+        HIPCHK(h, hipMalloc((void**)&b.UTB, A * 4)); HIPCHK(h, hipMalloc((void**)&b.UNB, A * 4)); HIPCHK(h, hipMalloc((void**)&b.UPB0, A * 4));
+        HIPCHK(h, hipMalloc((void**)&b.GB, 6 * A * 4));
+    }
     b.ready = true;
     return RNDE_OK;
 }
@@ -565,7 +570,7 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
     rnde_status st = bwd_prepare(h);
     if (st != RNDE_OK) return st;
     BwdBuffers& b = h->bw;
-    const int n_att = h->n_att;
+    int n_att = h->n_att;
     for (int i = 0; i < n_att; ++i)
         b.h_svb[i] = (saveval_bar_host && h->sv_index[i] >= 0) ? saveval_bar_host[h->sv_index[i]] : 0.f;
     HIPCHK(h, hipMemcpyAsync(b.svb_att, b.h_svb, (size_t)n_att * 4, hipMemcpyHostToDevice, s));
@@ -576,10 +581,33 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
     Q.bstate = b.bstate; Q.ibstate = b.ibstate; Q.bpart = b.bpart; Q.ipart = b.ipart;
     Q.ubar = u_bar_dev; Q.xbar = x_bar_dev; Q.tspan_out = b.tspan_out;
     Q.n_att = n_att; Q.track_ctrl = h->cfg.track_ctrl; Q.track_initdt = h->cfg.track_initdt; Q.reg_kind = h->cfg.regularize;
+    Q.bpart_n = Q.F.nwg;
     hipError_t e;
+    if (h->engine == 2) {
+        // stage engine sweep: 7 launches per attempt; then the (column-owner) kernels for the initialisation part
+        HIPCHK(h, stage_pack(h, h->pcopy, h->spwBt, 2, h->sMT, h->sKHb, s));
+        HIPCHK(h, stage_pack(h, h->pcopy, h->spwDt, 3, h->sHT, h->sMT, s));
+        BStageParams BQ{};
+        BQ.B = Q; BQ.p = h->pcopy; BQ.pwBt = h->spwBt; BQ.pwDt = h->spwDt; BQ.slab = h->slab2;
+        BQ.UTB = b.UTB; BQ.UNB = b.UNB; BQ.UPB0 = b.UPB0; BQ.GB = b.GB;
+        BQ.MT = h->sMT; BQ.WT = h->sWT; BQ.R = h->sR; BQ.C = Q.F.Bpad / 16; BQ.HT = h->sHT; BQ.KHb = h->sKHb;
+        const dim3 grid(BQ.R * BQ.C), blk(64 * BQ.WT);
+        for (int n = n_att - 1; n >= 0; --n) {
+            if (h->act2) hipLaunchKernelGGL((rnde_bstage_kernel<1, BM_START>), grid, blk, h->stage_lds, s, BQ, n, 0);
+            else hipLaunchKernelGGL((rnde_bstage_kernel<0, BM_START>), grid, blk, h->stage_lds, s, BQ, n, 0);
+            for (int j = 6; j >= 1; --j) {
+                if (h->act2) hipLaunchKernelGGL((rnde_bstage_kernel<1, BM_STAGE>), grid, blk, h->stage_lds, s, BQ, n, j);
+                else hipLaunchKernelGGL((rnde_bstage_kernel<0, BM_STAGE>), grid, blk, h->stage_lds, s, BQ, n, j);
+            }
+        }
+        HIPCHK(h, hipGetLastError());
+        Q.F.nwg = Q.F.Bpad / h->BT;     // the initialisation kernels below are column-owner kernels
+        n_att = 0;                       // (their attempt loop is skipped)
+    }
     if (h->NG == 1) e = h->act2 ? launch_bwd_t<1, 1>(h, Q, n_att, s) : launch_bwd_t<1, 0>(h, Q, n_att, s);
     else e = h->act2 ? launch_bwd_t<2, 1>(h, Q, n_att, s) : launch_bwd_t<2, 0>(h, Q, n_att, s);
     HIPCHK(h, e);
+    n_att = h->n_att;
     // parameter gradient: evaluation descriptors for the two batched GEMMs
     const long long A = (long long)h->D * Q.F.Bpad, HB = (long long)h->H * Q.F.Bpad;
     RecLayout L{A, HB};

@@ -45,6 +45,7 @@ struct BwdParams {
     float* xbar;                       // caller layout
     float* tspan_out;                  // [2]
     int n_att, track_ctrl, track_initdt, reg_kind;
+    int bpart_n;                       // number of per-workgroup partials the sweep wrote (differs from F.nwg when the stage engine ran it)
 };
 
 struct BwdBuffers {
@@ -55,12 +56,13 @@ struct BwdBuffers {
     EvalDesc *ev1 = nullptr, *ev2 = nullptr;
     float *slab = nullptr;
     size_t slab_floats = 0;
+    float *UTB = nullptr, *UNB = nullptr, *UPB0 = nullptr, *GB = nullptr;   // stage engine scratch
     EvalDesc *h_ev1 = nullptr, *h_ev2 = nullptr;  // pinned
     float* h_svb = nullptr;
     bool ready = false;
 };
 inline void bwd_free(BwdBuffers& b) {
-    void* d[] = {b.U, b.K1, b.UB1, b.zi2, b.zi1, b.svb_att, b.bstate, b.ibstate, b.bpart, b.ipart, b.tspan_out, b.ev1, b.ev2, b.slab};
+    void* d[] = {b.U, b.K1, b.UB1, b.zi2, b.zi1, b.svb_att, b.bstate, b.ibstate, b.bpart, b.ipart, b.tspan_out, b.ev1, b.ev2, b.slab, b.UTB, b.UNB, b.UPB0, b.GB};
     for (void* p : d) if (p) (void)hipFree(p);
     if (b.h_ev1) (void)hipHostFree(b.h_ev1);
     if (b.h_ev2) (void)hipHostFree(b.h_ev2);
@@ -135,9 +137,9 @@ __device__ __forceinline__ void finish_attempt_scalars(const BwdParams& Q, int m
                                                        double& qoldb, double& t1b, double& t0b) {
     const BState b = Q.bstate[m & 1];
     const StepMeta mm = Q.F.meta[m];
-    const float* part = Q.bpart + (size_t)(m & 1) * Q.F.nwg * 4;
+    const float* part = Q.bpart + (size_t)(m & 1) * Q.bpart_n * 4;
     double S = 0, tau = 0, ctau = 0;
-    for (int i = lane; i < Q.F.nwg; i += 64) { S += (double)part[4 * i]; tau += (double)part[4 * i + 1]; ctau += (double)part[4 * i + 2]; }
+    for (int i = lane; i < Q.bpart_n; i += 64) { S += (double)part[4 * i]; tau += (double)part[4 * i + 1]; ctau += (double)part[4 * i + 2]; }
     S = wave_sum_d(S); tau = wave_sum_d(tau); ctau = wave_sum_d(ctau);
     const double dtb = b.dtb_pre + S / (double)mm.dt + ctau;
     double tbx = b.tb_pre + tau;
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(kThreads) void rnde_bstep_kernel(const BwdParams Q,
             tau += ts;
             ctau += tsC(st) * ts;
         }
-        float* o = Q.bpart + ((size_t)(n & 1) * P.nwg + wg) * 4;
+        float* o = Q.bpart + ((size_t)(n & 1) * Q.bpart_n + wg) * 4;
         o[0] = s; o[1] = tau; o[2] = ctau; o[3] = 0.f;
     }
 }

@@ -27,6 +27,8 @@ struct rnde_node {
     f32x4 *spwB = nullptr, *spwD = nullptr, *spwBt = nullptr, *spwDt = nullptr;
     float* slab2 = nullptr;
     size_t stage_lds = 0;
+    hipStream_t wstream = nullptr;        // weight-gradient GEMMs run here, underneath the latency-bound sweep
+    std::vector<hipEvent_t> wevents;
     // device
     float *f0 = nullptr, *h0 = nullptr, *u1 = nullptr, *f1 = nullptr, *h1 = nullptr, *arena = nullptr;
     float* xcopy = nullptr;  // private copy of x (the tape must not alias caller memory)
@@ -200,6 +202,8 @@ extern "C" void rnde_node_destroy(rnde_node* h) {
                  h->ctl, h->ctl_final, h->meta, h->initrec, h->errpart, h->initpart};
     for (void* p : d) if (p) hipFree(p);
     bwd_free(h->bw);
+    for (hipEvent_t e : h->wevents) hipEventDestroy(e);
+    if (h->wstream) hipStreamDestroy(h->wstream);
     if (h->h_ctl) hipHostFree(h->h_ctl);
     if (h->h_meta) hipHostFree(h->h_meta);
     if (h->h_init) hipHostFree(h->h_init);
@@ -517,8 +521,16 @@ static rnde_status bwd_prepare(rnde_node* h) {
     HIPCHK(h, hipHostMalloc((void**)&b.h_ev1, nev * sizeof(EvalDesc))); HIPCHK(h, hipHostMalloc((void**)&b.h_ev2, nev * sizeof(EvalDesc)));
     HIPCHK(h, hipHostMalloc((void**)&b.h_svb, (size_t)cap * 4));
     const size_t seg = std::max((size_t)h->H * (h->D + 2), (size_t)h->D * (h->H + 2));
-    b.slab_floats = seg * 128;
-    HIPCHK(h, hipMalloc((void**)&b.slab, b.slab_floats * 4));
+    b.slab_floats = seg * 256;              // per layer; two layers back to back
+    HIPCHK(h, hipMalloc((void**)&b.slab, 2 * b.slab_floats * 4));
+    HIPCHK(h, hipMalloc((void**)&b.slab_r, 16 * seg * 4));
+    if (!h->wstream) {
+        int prio_least = 0, prio_greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+        HIPCHK(h, hipStreamCreateWithPriority(&h->wstream, hipStreamNonBlocking, prio_least));   // never ahead of the sweep
+        h->wevents.resize(66);
+        for (auto& e : h->wevents) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
     if (h->engine == 2) {
         HIPCHK(h, hipMalloc((void**)&b.UTB, A * 4)); HIPCHK(h, hipMalloc((void**)&b.UNB, A * 4)); HIPCHK(h, hipMalloc((void**)&b.UPB0, A * 4));
         HIPCHK(h, hipMalloc((void**)&b.GB, 6 * A * 4));
@@ -545,21 +557,34 @@ static hipError_t launch_bwd_t(rnde_node* h, const BwdParams& Q, int n_att, hipS
     return hipGetLastError();
 }
 
-static rnde_status launch_wgrad(rnde_node* h, const EvalDesc* ev, int n_evals, int M, int Nx, int Bpad, float* out, hipStream_t s) {
+// one group of evaluations -> `*chunk_cursor` .. slabs of region `slab`; returns the number of chunks written
+static rnde_status launch_wgrad_part(rnde_node* h, const EvalDesc* ev, int n_evals, int per_chunk, int M, int Nx, int Bpad,
+                                     float* slab, int* chunk_cursor, hipStream_t s) {
+    if (n_evals <= 0) return RNDE_OK;
     const int mtiles = (M + 31) / 32, ntiles = (Nx + 2 + 31) / 32;
     const bool tall = M >= Nx;  // layer 2: M = D; layer 1: M = H
     const int MB = tall ? 2 : 4, NB = tall ? 4 : 2;
     const int blocks = ((mtiles + MB - 1) / MB) * ((ntiles + NB - 1) / NB);
     const long long len = (long long)M * (Nx + 2);
-    int chunks = std::max(1, std::min(std::min(n_evals, 128), (1024 + blocks - 1) / blocks));
-    chunks = (int)std::min<long long>(chunks, (long long)(h->bw.slab_floats / (size_t)len));
-    const int per_chunk = (n_evals + chunks - 1) / chunks;
-    chunks = (n_evals + per_chunk - 1) / per_chunk;
-    if (tall) hipLaunchKernelGGL((rnde_wgrad_kernel<2, 4>), dim3(blocks, chunks), dim3(64), 0, s, ev, n_evals, per_chunk, M, Nx, Bpad, h->bw.slab);
-    else hipLaunchKernelGGL((rnde_wgrad_kernel<4, 2>), dim3(blocks, chunks), dim3(64), 0, s, ev, n_evals, per_chunk, M, Nx, Bpad, h->bw.slab);
+    const int chunks = (n_evals + per_chunk - 1) / per_chunk;
+    if ((size_t)(*chunk_cursor + chunks) * (size_t)len > h->bw.slab_floats) { h->err = "weight-gradient slab overflow"; return RNDE_ERR_BAD_ARG; }
+    float* dst = slab + (size_t)(*chunk_cursor) * len;
+    if (tall) hipLaunchKernelGGL((rnde_wgrad_kernel<2, 4>), dim3(blocks, chunks), dim3(64), 0, s, ev, n_evals, per_chunk, M, Nx, Bpad, dst);
+    else hipLaunchKernelGGL((rnde_wgrad_kernel<4, 2>), dim3(blocks, chunks), dim3(64), 0, s, ev, n_evals, per_chunk, M, Nx, Bpad, dst);
     HIPCHK(h, hipGetLastError());
+    *chunk_cursor += chunks;
+    return RNDE_OK;
+}
+static rnde_status launch_wgrad_reduce(rnde_node* h, const float* slab, int chunks, int M, int Nx, float* out, hipStream_t s) {
+    const long long len = (long long)M * (Nx + 2);
     const int grid = (int)std::min<long long>((len + 255) / 256, 2048);
-    hipLaunchKernelGGL(rnde_wgrad_reduce, dim3(grid), dim3(256), 0, s, h->bw.slab, chunks, len, out);
+    if (chunks <= 16) {
+        hipLaunchKernelGGL(rnde_wgrad_reduce, dim3(grid, 1), dim3(256), 0, s, slab, chunks, chunks, len, out);
+    } else {   // two passes: 16 chunk groups in parallel, then their 16 partial sums (fixed order => deterministic)
+        const int per_group = (chunks + 15) / 16, groups = (chunks + per_group - 1) / per_group;
+        hipLaunchKernelGGL(rnde_wgrad_reduce, dim3(grid, groups), dim3(256), 0, s, slab, chunks, per_group, len, h->bw.slab_r);
+        hipLaunchKernelGGL(rnde_wgrad_reduce, dim3(grid, 1), dim3(256), 0, s, (const float*)h->bw.slab_r, groups, groups, len, out);
+    }
     HIPCHK(h, hipGetLastError());
     return RNDE_OK;
 }
@@ -582,33 +607,7 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
     Q.ubar = u_bar_dev; Q.xbar = x_bar_dev; Q.tspan_out = b.tspan_out;
     Q.n_att = n_att; Q.track_ctrl = h->cfg.track_ctrl; Q.track_initdt = h->cfg.track_initdt; Q.reg_kind = h->cfg.regularize;
     Q.bpart_n = Q.F.nwg;
-    hipError_t e;
-    if (h->engine == 2) {
-        // stage engine sweep: 7 launches per attempt; then the (column-owner) kernels for the initialisation part
-        HIPCHK(h, stage_pack(h, h->pcopy, h->spwBt, 2, h->sMT, h->sKHb, s));
-        HIPCHK(h, stage_pack(h, h->pcopy, h->spwDt, 3, h->sHT, h->sMT, s));
-        BStageParams BQ{};
-        BQ.B = Q; BQ.p = h->pcopy; BQ.pwBt = h->spwBt; BQ.pwDt = h->spwDt; BQ.slab = h->slab2;
-        BQ.UTB = b.UTB; BQ.UNB = b.UNB; BQ.UPB0 = b.UPB0; BQ.GB = b.GB;
-        BQ.MT = h->sMT; BQ.WT = h->sWT; BQ.R = h->sR; BQ.C = Q.F.Bpad / 16; BQ.HT = h->sHT; BQ.KHb = h->sKHb;
-        const dim3 grid(BQ.R * BQ.C), blk(64 * BQ.WT);
-        for (int n = n_att - 1; n >= 0; --n) {
-            if (h->act2) hipLaunchKernelGGL((rnde_bstage_kernel<1, BM_START>), grid, blk, h->stage_lds, s, BQ, n, 0);
-            else hipLaunchKernelGGL((rnde_bstage_kernel<0, BM_START>), grid, blk, h->stage_lds, s, BQ, n, 0);
-            for (int j = 6; j >= 1; --j) {
-                if (h->act2) hipLaunchKernelGGL((rnde_bstage_kernel<1, BM_STAGE>), grid, blk, h->stage_lds, s, BQ, n, j);
-                else hipLaunchKernelGGL((rnde_bstage_kernel<0, BM_STAGE>), grid, blk, h->stage_lds, s, BQ, n, j);
-            }
-        }
-        HIPCHK(h, hipGetLastError());
-        Q.F.nwg = Q.F.Bpad / h->BT;     // the initialisation kernels below are column-owner kernels
-        n_att = 0;                       // (their attempt loop is skipped)
-    }
-    if (h->NG == 1) e = h->act2 ? launch_bwd_t<1, 1>(h, Q, n_att, s) : launch_bwd_t<1, 0>(h, Q, n_att, s);
-    else e = h->act2 ? launch_bwd_t<2, 1>(h, Q, n_att, s) : launch_bwd_t<2, 0>(h, Q, n_att, s);
-    HIPCHK(h, e);
-    n_att = h->n_att;
-    // parameter gradient: evaluation descriptors for the two batched GEMMs
+    // ---- evaluation descriptors for the parameter-gradient GEMMs (all pointers are known before the sweep) ----
     const long long A = (long long)h->D * Q.F.Bpad, HB = (long long)h->H * Q.F.Bpad;
     RecLayout L{A, HB};
     int ne = 0;
@@ -626,9 +625,76 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
     b.h_ev2[ne] = EvalDesc{b.zi2 + A, h->h1, h->t0 + h->h_init->dt0, 0}; b.h_ev1[ne] = EvalDesc{b.zi1 + HB, h->u1, h->t0 + h->h_init->dt0, 0}; ++ne;
     HIPCHK(h, hipMemcpyAsync(b.ev1, b.h_ev1, (size_t)ne * sizeof(EvalDesc), hipMemcpyHostToDevice, s));
     HIPCHK(h, hipMemcpyAsync(b.ev2, b.h_ev2, (size_t)ne * sizeof(EvalDesc), hipMemcpyHostToDevice, s));
-    st = launch_wgrad(h, b.ev1, ne, h->H, h->D, Q.F.Bpad, p_bar_dev, s);                                   // [W1; b1]
+    float* slab1 = b.slab;
+    float* slab2w = b.slab + b.slab_floats;
+    int cur1 = 0, cur2 = 0, evi = 0;
+    // Footprint control: a GEMM wave runs for ~100 us and holds 147 VGPRs, so at most ~one per CU may be in
+    // flight or the sweep's workgroups cannot be placed: <= 12 chunks x 13 tile blocks per launch.
+    const int per_chunk = std::max(1, (ne + 239) / 240);          // one evaluation per wave when possible: >= 2 waves per SIMD
+    const int group = 4;                                          // attempts per weight-gradient launch
+    const int per_chunk_grp = std::max(per_chunk, (6 * group + 11) / 12);
+    // launches the two GEMMs for evaluations [lo, hi) on the side stream once the main stream reaches this point
+    // Measured (round 1): running these GEMMs on a second, low-priority stream underneath the sweep is a net
+    // LOSS (6.4 -> 8.4..9.8 ms per step): their ~100 us waves hold VGPRs the latency-critical sweep workgroups
+    // need.  So `overlap` stays off and the GEMMs run after the sweep on the caller's stream.
+    const bool overlap = false;
+    auto wgrad_group = [&](int lo, int hi) -> rnde_status {
+        if (hi <= lo) return RNDE_OK;
+        hipStream_t ws = s;
+        int pc = per_chunk;
+        if (overlap) {
+            hipEvent_t ev = h->wevents[evi++ % 64];
+            HIPCHK(h, hipEventRecord(ev, s));
+            HIPCHK(h, hipStreamWaitEvent(h->wstream, ev, 0));
+            ws = h->wstream; pc = per_chunk_grp;
+        }
+        rnde_status r = launch_wgrad_part(h, b.ev1 + lo, hi - lo, pc, h->H, h->D, Q.F.Bpad, slab1, &cur1, ws);
+        if (r != RNDE_OK) return r;
+        return launch_wgrad_part(h, b.ev2 + lo, hi - lo, pc, h->D, h->H, Q.F.Bpad, slab2w, &cur2, ws);
+    };
+    hipError_t e;
+    if (h->engine == 2) {
+        // stage engine sweep: 7 launches per attempt; then the (column-owner) kernels for the initialisation part
+        HIPCHK(h, stage_pack(h, h->pcopy, h->spwBt, 2, h->sMT, h->sKHb, s));
+        HIPCHK(h, stage_pack(h, h->pcopy, h->spwDt, 3, h->sHT, h->sMT, s));
+        BStageParams BQ{};
+        BQ.B = Q; BQ.p = h->pcopy; BQ.pwBt = h->spwBt; BQ.pwDt = h->spwDt; BQ.slab = h->slab2;
+        BQ.UTB = b.UTB; BQ.UNB = b.UNB; BQ.UPB0 = b.UPB0; BQ.GB = b.GB;
+        BQ.MT = h->sMT; BQ.WT = h->sWT; BQ.R = h->sR; BQ.C = Q.F.Bpad / 16; BQ.HT = h->sHT; BQ.KHb = h->sKHb;
+        const dim3 grid(BQ.R * BQ.C), blk(64 * BQ.WT);
+        int hi_att = n_att;
+        for (int n = n_att - 1; n >= 0; --n) {
+            if (h->act2) hipLaunchKernelGGL((rnde_bstage_kernel<1, BM_START>), grid, blk, h->stage_lds, s, BQ, n, 0, h->h_meta[n]);
+            else hipLaunchKernelGGL((rnde_bstage_kernel<0, BM_START>), grid, blk, h->stage_lds, s, BQ, n, 0, h->h_meta[n]);
+            for (int j = 6; j >= 1; --j) {
+                if (h->act2) hipLaunchKernelGGL((rnde_bstage_kernel<1, BM_STAGE>), grid, blk, h->stage_lds, s, BQ, n, j, h->h_meta[n]);
+                else hipLaunchKernelGGL((rnde_bstage_kernel<0, BM_STAGE>), grid, blk, h->stage_lds, s, BQ, n, j, h->h_meta[n]);
+            }
+            if (overlap && (hi_att - n >= group || n == 0)) {       // attempts [n, hi_att) are final: their GEMM slice can start now
+                st = wgrad_group(6 * n, 6 * hi_att);
+                if (st != RNDE_OK) return st;
+                hi_att = n;
+            }
+        }
+        HIPCHK(h, hipGetLastError());
+        Q.F.nwg = Q.F.Bpad / h->BT;     // the initialisation kernels below are column-owner kernels
+        n_att = 0;                       // (their attempt loop is skipped)
+    }
+    if (h->NG == 1) e = h->act2 ? launch_bwd_t<1, 1>(h, Q, n_att, s) : launch_bwd_t<1, 0>(h, Q, n_att, s);
+    else e = h->act2 ? launch_bwd_t<2, 1>(h, Q, n_att, s) : launch_bwd_t<2, 0>(h, Q, n_att, s);
+    HIPCHK(h, e);
+    n_att = h->n_att;
+    // remaining evaluations (column-owner engine: everything; stage engine: the two initialisation evaluations)
+    st = wgrad_group((overlap && h->engine == 2) ? 6 * n_att : 0, ne);
     if (st != RNDE_OK) return st;
-    st = launch_wgrad(h, b.ev2, ne, h->D, h->H, Q.F.Bpad, p_bar_dev + (size_t)h->H * (h->D + 2), s);       // [W2; b2]
+    if (overlap) {
+        hipEvent_t ev = h->wevents[64];
+        HIPCHK(h, hipEventRecord(ev, h->wstream));
+        HIPCHK(h, hipStreamWaitEvent(s, ev, 0));
+    }
+    st = launch_wgrad_reduce(h, slab1, cur1, h->H, h->D, p_bar_dev, s);                                    // [W1; b1]
+    if (st != RNDE_OK) return st;
+    st = launch_wgrad_reduce(h, slab2w, cur2, h->D, h->H, p_bar_dev + (size_t)h->H * (h->D + 2), s);      // [W2; b2]
     if (st != RNDE_OK) return st;
     HIPCHK(h, hipMemcpyAsync(h->h_scal, b.tspan_out, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));

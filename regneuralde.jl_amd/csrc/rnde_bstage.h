@@ -30,7 +30,7 @@ struct BStageParams {
 enum { BM_START = 0, BM_STAGE = 1 };
 
 template <int ACT2, int MODE>
-__global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_kernel(const BStageParams Q, const int n, const int j) {
+__global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_kernel(const BStageParams Q, const int n, const int j, const StepMeta m) {
     const BwdParams& Bq = Q.B;
     const StepParams& P = Bq.F;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -53,7 +53,8 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_kernel(const BStagePa
     const bool first = (n == Bq.n_att - 1);
     const size_t co = (size_t)gcol * P.D;
 
-    // ---- weights first ----
+    // The attempt's record (which tape slot, dt, flags) is known to the host after the forward pass, so it arrives as
+    // a kernel argument: every address below is known at launch and all loads of the launch are issued up front.
     f32x4 wB[kSMaxHT], wD[kSMaxW];
     if constexpr (MODE == BM_STAGE) {
 #pragma unroll
@@ -68,19 +69,15 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_kernel(const BStagePa
     }
     // hbar slabs of the previous launch + the hidden activations they are combined with
     f32x4 zs = {0.f, 0.f, 0.f, 0.f};
-    const StepMeta m = P.meta[n];
+    f32x4 zr[kSMaxW];
     float* R = P.arena + (long long)m.rec * P.rec_stride;
     float w1t_own[4] = {0.f, 0.f, 0.f, 0.f}, h_own[4] = {0.f, 0.f, 0.f, 0.f};
     if constexpr (MODE == BM_STAGE) {
         const int par0 = j & 1;
         const f32x4* sl0 = (const f32x4*)Q.slab + (((size_t)par0 * Q.C + ct) * Q.R) * Q.HT * 64;
         if (w < Q.HT) {
-            f32x4 zr[kSMaxW];
 #pragma unroll
             for (int r = 0; r < kSMaxW; ++r) if (r < Q.R) zr[r] = sl0[((size_t)r * Q.HT + w) * 64 + lane];
-#pragma unroll
-            for (int r = 0; r < kSMaxW; ++r) if (r < Q.R) zs += zr[r];
-            for (int r = kSMaxW; r < Q.R; ++r) zs += sl0[((size_t)r * Q.HT + w) * 64 + lane];
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -89,6 +86,17 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_kernel(const BStagePa
         }
     }
 
+    // phase-C operands of BM_STAGE (unew-bar, utilde-bar, stored gbar_s, k_{j-1}): issue now
+    f32x4 c_unb = {0.f, 0.f, 0.f, 0.f}, c_utb = {0.f, 0.f, 0.f, 0.f}, c_ks = {0.f, 0.f, 0.f, 0.f}, c_gs[5];
+    if constexpr (MODE == BM_STAGE) {
+        if (tile_ok) {
+            c_unb = ld4(Q.UNB + co, r0, P.D, true, vec);
+            c_utb = ld4(Q.UTB + co, r0, P.D, true, vec);
+            if (j >= 2) c_ks = ld4(R + L.k(j) + co, r0, P.D, true, vec);          // k_{j-1} is stored as k(j)
+#pragma unroll
+            for (int s = 1; s <= 5; ++s) if (s > j || j == 1) c_gs[s - 1] = ld4(Q.GB + (size_t)(s - 1) * A + co, r0, P.D, true, vec);
+        }
+    }
     const bool accepted = (m.flags & F_ACCEPT) != 0;
     const float dt = m.dt;
     const float* upsrc = P.x; const float* k1p = P.f0; bool upok = colok, upvec = P.xvec != 0;
@@ -165,6 +173,12 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_kernel(const BStagePa
         }
     } else {
         // ---- phase A: hbar from the slabs; z1bar; time cotangents ----
+        if (w < Q.HT) {
+            const f32x4* sl0 = (const f32x4*)Q.slab + (((size_t)(j & 1) * Q.C + ct) * Q.R) * Q.HT * 64;
+#pragma unroll
+            for (int r = 0; r < kSMaxW; ++r) if (r < Q.R) zs += zr[r];
+            for (int r = kSMaxW; r < Q.R; ++r) zs += sl0[((size_t)r * Q.HT + w) * 64 + lane];
+        }
         const float* W1t = Q.p + (size_t)P.H * P.D;
         const f32x4* sl = (const f32x4*)Q.slab + (((size_t)(j & 1) * Q.C + ct) * Q.R) * Q.HT * 64;
         const float* hsrc = R + L.h(j + 1);
@@ -221,18 +235,18 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_kernel(const BStagePa
         // ---- phase C ----
         if (tile_ok) {
             st4(Q.GB + (size_t)(j - 1) * A + co, r0, P.D, true, vec, gb);
-            f32x4 unb = ld4(Q.UNB + co, r0, P.D, true, vec);
+            f32x4 unb = c_unb;
             if (j == 6) { unb += gb; st4(Q.UNB + co, r0, P.D, true, vec, unb); }
-            const f32x4 utb = ld4(Q.UTB + co, r0, P.D, true, vec);
+            const f32x4 utb = c_utb;
             const int jn = j - 1;                                   // zero-based index of the k whose cotangent is now complete
             f32x4 kbar = tsA_rt(6, jn) * unb + kTsBt[jn] * utb;
-            for (int s = jn + 1; s <= 5; ++s) {
-                const f32x4 gs = (s == j) ? gb : ld4(Q.GB + (size_t)(s - 1) * A + co, r0, P.D, true, vec);
-                kbar += tsA_rt(s, jn) * gs;
+#pragma unroll
+            for (int s = 1; s <= 5; ++s) {
+                if (s > jn) kbar += tsA_rt(s, jn) * ((s == j) ? gb : c_gs[s - 1]);
             }
             kbar = dt * kbar;
             if (jn >= 1) {
-                const f32x4 ks = ld4(R + L.k(jn + 1) + co, r0, P.D, true, vec);
+                const f32x4 ks = c_ks;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     S += ks[i] * kbar[i];
@@ -245,7 +259,8 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_kernel(const BStagePa
 #pragma unroll
                 for (int i = 0; i < 4; ++i) S += k1v[i] * kbar[i];
                 f32x4 uo = ld4(Q.UPB0 + co, r0, P.D, true, vec) + unb;
-                for (int s = 1; s <= 5; ++s) uo += (s == j) ? gb : ld4(Q.GB + (size_t)(s - 1) * A + co, r0, P.D, true, vec);
+#pragma unroll
+                for (int s = 1; s <= 5; ++s) uo += (s == j) ? gb : c_gs[s - 1];
                 f32x4 ko = kbar;
                 if (!accepted) {
                     uo += first ? ld4(Bq.ubar + co, r0, P.D, colok, false) : ld4(Bq.U + co, r0, P.D, true, vec);

@@ -54,7 +54,7 @@ struct BwdBuffers {
     IBState* ibstate = nullptr;
     float *bpart = nullptr, *ipart = nullptr, *tspan_out = nullptr;
     EvalDesc *ev1 = nullptr, *ev2 = nullptr;
-    float *slab = nullptr;
+    float *slab = nullptr, *slab_r = nullptr;   // per-chunk partials; second-level partials of the two-pass reduction
     size_t slab_floats = 0;
     float *UTB = nullptr, *UNB = nullptr, *UPB0 = nullptr, *GB = nullptr;   // stage engine scratch
     EvalDesc *h_ev1 = nullptr, *h_ev2 = nullptr;  // pinned
@@ -62,7 +62,7 @@ struct BwdBuffers {
     bool ready = false;
 };
 inline void bwd_free(BwdBuffers& b) {
-    void* d[] = {b.U, b.K1, b.UB1, b.zi2, b.zi1, b.svb_att, b.bstate, b.ibstate, b.bpart, b.ipart, b.tspan_out, b.ev1, b.ev2, b.slab, b.UTB, b.UNB, b.UPB0, b.GB};
+    void* d[] = {b.U, b.K1, b.UB1, b.zi2, b.zi1, b.svb_att, b.bstate, b.ibstate, b.bpart, b.ipart, b.tspan_out, b.ev1, b.ev2, b.slab, b.slab_r, b.UTB, b.UNB, b.UPB0, b.GB};
     for (void* p : d) if (p) (void)hipFree(p);
     if (b.h_ev1) (void)hipHostFree(b.h_ev1);
     if (b.h_ev2) (void)hipHostFree(b.h_ev2);
@@ -501,18 +501,26 @@ __global__ __launch_bounds__(64) void rnde_wgrad_kernel(const EvalDesc* __restri
         float bconst[NB];  // value for the synthetic rows (time, bias), else NaN marker unused
 #pragma unroll
         for (int b = 0; b < NB; ++b) bconst[b] = nrow[b] == Nx ? te : (nrow[b] == Nx + 1 ? 1.f : 0.f);
-#pragma unroll 2
-        for (int c = 0; c < Bpad; c += 2) {
-            const int cc = c + kk;
-            float av[MB], bv[NB];
+        // batches of KB column pairs: all operand loads of a batch are issued before its MFMAs so that ~50 loads are
+        // in flight per wave (the loop was load-latency bound with 2 pairs in flight: 28 TF)
+        constexpr int KB = 8;
+        for (int c = 0; c < Bpad; c += 2 * KB) {
+            float av[KB][MB], bv[KB][NB];
 #pragma unroll
-            for (int a = 0; a < MB; ++a) av[a] = mrow[a] < M ? Z[(size_t)cc * M + mrow[a]] : 0.f;
+            for (int u = 0; u < KB; ++u) {
+                const int cc = c + 2 * u + kk;
+                const bool cok = cc < Bpad;
 #pragma unroll
-            for (int b = 0; b < NB; ++b) bv[b] = nrow[b] < Nx ? X[(size_t)cc * Nx + nrow[b]] : bconst[b];
+                for (int a = 0; a < MB; ++a) av[u][a] = (cok && mrow[a] < M) ? Z[(size_t)cc * M + mrow[a]] : 0.f;
 #pragma unroll
-            for (int a = 0; a < MB; ++a)
+                for (int bb = 0; bb < NB; ++bb) bv[u][bb] = cok ? (nrow[bb] < Nx ? X[(size_t)cc * Nx + nrow[bb]] : bconst[bb]) : 0.f;
+            }
 #pragma unroll
-                for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+            for (int u = 0; u < KB; ++u)
+#pragma unroll
+                for (int a = 0; a < MB; ++a)
+#pragma unroll
+                    for (int bb = 0; bb < NB; ++bb) acc[a][bb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][a], bv[u][bb], acc[a][bb], 0, 0, 0);
         }
     }
     float* out = slab + (size_t)chunk * M * (Nx + 2);
@@ -529,11 +537,14 @@ __global__ __launch_bounds__(64) void rnde_wgrad_kernel(const EvalDesc* __restri
         }
 }
 
-__global__ void rnde_wgrad_reduce(const float* __restrict__ slab, int n_chunks, long long len, float* __restrict__ out) {
+// fixed-order sum of chunks [c0, c1) of the slab -> out (blockIdx.y selects the chunk group in pass 1)
+__global__ void rnde_wgrad_reduce(const float* __restrict__ slab, int n_chunks, int per_group, long long len, float* __restrict__ out) {
+    const int c0 = blockIdx.y * per_group, c1 = min(n_chunks, c0 + per_group);
+    float* o = out + (size_t)blockIdx.y * len;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < len; i += (long long)gridDim.x * blockDim.x) {
         float s = 0.f;
-        for (int c = 0; c < n_chunks; ++c) s += slab[(size_t)c * len + i];
-        out[i] = s;
+        for (int c = c0; c < c1; ++c) s += slab[(size_t)c * len + i];
+        o[i] = s;
     }
 }
 

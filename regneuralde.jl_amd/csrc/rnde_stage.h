@@ -107,7 +107,26 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_kernel(const StagePara
 #define SSTAMP(i) do { } while (0)
 #endif
     SSTAMP(0);
-    // ---- weights first: they are this workgroup's only long-latency loads; issue before anything else ----
+    // After a kernel boundary every read is served from Infinity Cache / HBM (the per-XCD L2s are written back
+    // and invalidated), ~2 us per DEPENDENT round trip: issue every independent load of the launch up front --
+    // controller state, weights, slabs -- and the state-array operands as soon as the controller state is in.
+    StepState S0;
+    if constexpr (MODE == SM_STAGE || MODE == SM_LAST) S0 = P.ctl[n & 1];
+    f32x4 c_up = {0.f, 0.f, 0.f, 0.f}, c_un = {0.f, 0.f, 0.f, 0.f}, c_k[6];
+    bool c_early = false;
+    if constexpr (MODE == SM_STAGE || MODE == SM_LAST) {
+        if (P.tape && tile_ok) {   // taped forward: this attempt's record is record n, (uprev, k1) were copied into it by SM_START
+            const float* Rn = P.arena + (long long)n * P.rec_stride;
+            const size_t co = (size_t)gcol * P.D;
+            c_up = ld4(Rn + L.upc() + co, r0, P.D, true, vec);
+            c_k[0] = ld4(Rn + L.k1c() + co, r0, P.D, true, vec);
+#pragma unroll
+            for (int j = 1; j < 6; ++j) if (j < s) c_k[j] = ld4(Rn + L.k(j + 1) + co, r0, P.D, true, vec);
+            if constexpr (MODE == SM_LAST) c_un = ld4(Rn + L.unew() + co, r0, P.D, true, vec);
+            c_early = true;
+        }
+    }
+    // ---- weights: this workgroup's 1/R slice, ~90 KB ----
     f32x4 wB[kSMaxHT];   // phase B A-operands: row tile T, all K2b blocks   (K2b <= 8)
     f32x4 wD[kSMaxW];    // phase D A-operands: hidden tile(s) of this wave, the block's WT k16 blocks (first hidden tile)
     if constexpr (kHasA) {
@@ -123,6 +142,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_kernel(const StagePara
 
     // z1 slabs of the previous launch (independent of the controller state: issue now)
     f32x4 zs = {0.f, 0.f, 0.f, 0.f};
+    f32x4 zr[kSMaxW];
     float w1t_own[4] = {0.f, 0.f, 0.f, 0.f}, b1_own[4] = {0.f, 0.f, 0.f, 0.f};
     if constexpr (kHasA) {
 #pragma unroll
@@ -133,12 +153,8 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_kernel(const StagePara
         const int par0 = (MODE == SM_STAGE || MODE == SM_LAST) ? (s & 1) : 0;
         const f32x4* sl0 = (const f32x4*)Q.slab + (((size_t)par0 * Q.C + ct) * Q.R) * Q.HT * 64;
         if (w < Q.HT) {
-            f32x4 zr[kSMaxW];
 #pragma unroll
             for (int r = 0; r < kSMaxW; ++r) if (r < Q.R) zr[r] = sl0[((size_t)r * Q.HT + w) * 64 + lane];
-#pragma unroll
-            for (int r = 0; r < kSMaxW; ++r) if (r < Q.R) zs += zr[r];   // fixed order: deterministic
-            for (int r = kSMaxW; r < Q.R; ++r) zs += sl0[((size_t)r * Q.HT + w) * 64 + lane];
         }
     }
 
@@ -150,7 +166,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_kernel(const StagePara
         if (S.done) return;
         t = S.t; dt = (!P.forced && (P.t1 - S.t < S.dtp)) ? (P.t1 - S.t) : S.dtp; live = S.live;
     } else if constexpr (MODE == SM_STAGE || MODE == SM_LAST) {
-        const StepState S = P.ctl[n & 1];
+        const StepState S = S0;
         if (S.done) return;
         t = S.t; dt = (!P.forced && (P.t1 - S.t < S.dtp)) ? (P.t1 - S.t) : S.dtp; live = S.live;
     }
@@ -159,10 +175,21 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_kernel(const StagePara
     const float* upsrc = P.x; const float* k1p = P.f0; bool upok = colok, upvec = P.xvec != 0;
     if (live >= 0) { const float* Rl = P.arena + (long long)live * P.rec_stride; upsrc = Rl + L.unew(); k1p = Rl + L.k(7); upok = true; upvec = vec; }
 
-    // phase-C operands (L2-resident state arrays): issue now so they land under phases A and B
-    f32x4 c_up = {0.f, 0.f, 0.f, 0.f}, c_un = {0.f, 0.f, 0.f, 0.f}, c_k[6];
+    // slab sum first (these loads were issued together with the controller state, so they have landed); only then
+    // issue the state-array loads -- a wait placed after them would have to cover them too (conditional loads
+    // make the compiler fall back to vmcnt(0))
+    if constexpr (kHasA) {
+        if (w < Q.HT) {
+            const int par0 = (MODE == SM_STAGE || MODE == SM_LAST) ? (s & 1) : 0;
+            const f32x4* sl0 = (const f32x4*)Q.slab + (((size_t)par0 * Q.C + ct) * Q.R) * Q.HT * 64;
+#pragma unroll
+            for (int r = 0; r < kSMaxW; ++r) if (r < Q.R) zs += zr[r];   // fixed order: deterministic
+            for (int r = kSMaxW; r < Q.R; ++r) zs += sl0[((size_t)r * Q.HT + w) * 64 + lane];
+        }
+    }
+    // phase-C operands (state arrays): issue now so they land under phases A and B
     if constexpr (MODE == SM_START || MODE == SM_STAGE || MODE == SM_LAST) {
-        if (tile_ok) {
+        if (tile_ok && !c_early) {
             c_up = ld4(upsrc + (size_t)gcol * P.D, r0, P.D, upok, upvec);
             c_k[0] = ld4(k1p + (size_t)gcol * P.D, r0, P.D, true, vec);
             if constexpr (MODE != SM_START) {
@@ -196,6 +223,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_kernel(const StagePara
     f32x4 kv = {0.f, 0.f, 0.f, 0.f};
     SSTAMP(1);
     if constexpr (kHasA) {
+
         // ---- phase A: hidden activations of this column tile from the z1 slabs of the previous launch ----
         const float* W1t = Q.p + (size_t)P.H * P.D;           // time column of W1 (H x (D+1), column-major)
         const float* b1 = Q.p + (size_t)P.H * (P.D + 1);
@@ -213,7 +241,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_kernel(const StagePara
                 const int hr = h0 + i;
                 float v = 0.f;
                 if (hr < P.H) {
-                    v = tanhf(z[i] + ((ht == w) ? w1t_own[i] : W1t[hr]) * ts + ((ht == w) ? b1_own[i] : b1[hr]));
+                    v = tanh_fast(z[i] + ((ht == w) ? w1t_own[i] : W1t[hr]) * ts + ((ht == w) ? b1_own[i] : b1[hr]));
                     if (rb == 0 && hdst) hdst[(size_t)gcol * P.H + hr] = v;
                 } else if (hr == P.H) v = ts;
                 else if (hr == P.H + 1) v = 1.f;
@@ -248,7 +276,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_kernel(const StagePara
             }
             kv = acc0 + acc1;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) kv[i] = (r0 + i < P.D) ? act_apply(ACT2, kv[i]) : 0.f;
+            for (int i = 0; i < 4; ++i) kv[i] = (r0 + i < P.D) ? act_apply_fast(ACT2, kv[i]) : 0.f;
         }
     }
 
@@ -259,7 +287,11 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_kernel(const StagePara
     if (tile_ok) {
         if constexpr (MODE == SM_START) {
             v = c_up + dt * (kFwdShift[0][0] * c_k[0]);
-            if (P.tape) st4(R + L.g(2) + (size_t)gcol * P.D, r0, P.D, true, vec, v);
+            if (P.tape) {
+                st4(R + L.g(2) + (size_t)gcol * P.D, r0, P.D, true, vec, v);
+                st4(R + L.upc() + (size_t)gcol * P.D, r0, P.D, true, vec, c_up);
+                st4(R + L.k1c() + (size_t)gcol * P.D, r0, P.D, true, vec, c_k[0]);
+            }
         } else if constexpr (MODE == SM_STAGE) {
             st4(kdst + (size_t)gcol * P.D, r0, P.D, true, vec, kv);
             f32x4 acc = tsA_rt(s + 1, 0) * c_k[0];

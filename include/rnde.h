@@ -123,6 +123,15 @@ rnde_status rnde_debug_attempt(rnde_node* h, const float* uprev_dev, const float
 rnde_status rnde_bench_attempt(rnde_node* h, const float* x_dev, const float* p_dev, int32_t B,
                                int32_t iters, float* mean_us_out, void* stream);
 
+/* Fused caller of the hot path: postode Dense(D, C) + Flux.Losses.logitcrossentropy and their
+ * reverse in one call -- replaces reference src/models/supervised_classification.jl:44-45 + experiments/mnist_node.jl:135
+ * and the Tracker reverse of both.  p3 = Flux.destructure(Dense(D, C)) = [vec(W) (C x D col-major); b (C)];
+ * y: one-hot C x B.  Outputs: logits (C x B, may be NULL), u_bar = d ce / d u (D x B), p3_bar (C*D + C),
+ * ce (device scalar: mean cross entropy).  Asynchronous on `stream`. */
+rnde_status rnde_classifier_head(rnde_node* h, const float* u_dev, const float* p3_dev, const float* y_dev,
+                                 int32_t B, int32_t n_classes, float* logits_out_dev, float* u_bar_dev,
+                                 float* p3_bar_dev, float* ce_out_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,7 +6,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "lib", "librnde.so")
 SOURCES = ["rnde.hip"]
-HEADERS = ["rnde_device.h", "rnde_fwd.h", "rnde_bwd.h", os.path.join("..", "..", "include", "rnde.h")]
+HEADERS = ["rnde_device.h", "rnde_fwd.h", "rnde_bwd.h", "rnde_stage.h", "rnde_bstage.h", "rnde_head.h", os.path.join("..", "..", "include", "rnde.h")]
 
 
 def needs_build():

@@ -41,6 +41,48 @@ class ClassifierNODE:
         return u @ W + b, nfe, sv
 
 
+def fused_loss_and_grad(model, x, y, lam=1.0e2, regularize=True, tspan=None):
+    """One training-step gradient without a tape library in the loop:
+    [solve, taped] -> [fused Dense(784,10) + logitcrossentropy + their reverse] -> [reverse solve], all through the C ABI.
+    Same loss surface as `loss_function` (experiments/mnist_node.jl:132-137, agg = mean): sets .grad on p2 and p3 and
+    returns (total_loss, cross_entropy, reg, nfe) as Python floats / int (the call already synchronises)."""
+    import ctypes as C
+    from . import _lib
+    node = model.node
+    L = _lib.lib()
+    x2 = x.reshape(x.shape[0], -1).to(torch.float32).contiguous()
+    B, D = x2.shape
+    node._func = "error_est" if node.regularize else None
+    h = node._acquire(x2, True)
+    ts = node.tspan if tspan is None else [float(tspan[0]), float(tspan[1])]
+    stream = C.c_void_p(torch.cuda.current_stream(x2.device).cuda_stream)
+    u = torch.empty_like(x2)
+    nfe, nsv = C.c_int64(0), C.c_int32(0)
+    sv = (C.c_float * (node.max_attempts + 1))()
+    p2, p3 = model.p2.detach(), model.p3.detach()
+    _lib.check(h.ptr, L.rnde_node_forward(h.ptr, x2.data_ptr(), p2.data_ptr(), B, ts[0], ts[1], u.data_ptr(), C.byref(nfe), sv,
+                                          C.byref(nsv), 1, stream))
+    n_cls = model.post_shape[1]
+    ubar = torch.empty_like(x2)
+    p3bar = torch.empty_like(p3)
+    ce = torch.empty(1, dtype=torch.float32, device=x2.device)
+    _lib.check(h.ptr, L.rnde_classifier_head(h.ptr, u.data_ptr(), p3.data_ptr(), y.contiguous().data_ptr(), B, n_cls, None,
+                                             ubar.data_ptr(), p3bar.data_ptr(), ce.data_ptr(), stream))
+    n = nsv.value
+    reg = 0.0
+    svb = None
+    if regularize and n > 0:
+        reg = lam * sum(sv[:n]) / n                       # lambda * mean(sv.saveval)
+        svb = (C.c_float * n)(*([lam / n] * n))
+    xbar = torch.empty_like(x2)
+    p2bar = torch.empty_like(p2)
+    _lib.check(h.ptr, L.rnde_node_backward(h.ptr, ubar.data_ptr(), svb, xbar.data_ptr(), p2bar.data_ptr(), None, stream))
+    model.p2.grad, model.p3.grad = p2bar, p3bar
+    node.last_nfe = int(nfe.value)
+    ce_f = float(ce.item())
+    return ce_f + reg, ce_f, reg, int(nfe.value)
+
+
 def logitcrossentropy(pred, y_onehot):
     """Flux.Losses.logitcrossentropy: mean over the batch of -sum(y .* logsoftmax(pred))."""
     return -(y_onehot * torch.log_softmax(pred, dim=1)).sum(dim=1).mean()

@@ -5,8 +5,11 @@
 #include "rnde_bwd.h"
 #include "rnde_stage.h"
 #include "rnde_bstage.h"
+#include "rnde_head.h"
 
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -27,7 +30,8 @@ struct rnde_node {
     f32x4 *spwB = nullptr, *spwD = nullptr, *spwBt = nullptr, *spwDt = nullptr;
     float* slab2 = nullptr;
     size_t stage_lds = 0;
-    hipStream_t wstream = nullptr;        // weight-gradient GEMMs run here, underneath the latency-bound sweep
+    float* head_ws = nullptr; size_t head_ws_floats = 0;   // fused classifier head scratch
+    hipStream_t wstream = nullptr;        // (experimental overlap path of the weight-gradient GEMMs)
     std::vector<hipEvent_t> wevents;
     // device
     float *f0 = nullptr, *h0 = nullptr, *u1 = nullptr, *f1 = nullptr, *h1 = nullptr, *arena = nullptr;
@@ -202,6 +206,7 @@ extern "C" void rnde_node_destroy(rnde_node* h) {
                  h->ctl, h->ctl_final, h->meta, h->initrec, h->errpart, h->initpart};
     for (void* p : d) if (p) hipFree(p);
     bwd_free(h->bw);
+    if (h->head_ws) hipFree(h->head_ws);
     for (hipEvent_t e : h->wevents) hipEventDestroy(e);
     if (h->wstream) hipStreamDestroy(h->wstream);
     if (h->h_ctl) hipHostFree(h->h_ctl);
@@ -477,10 +482,13 @@ extern "C" rnde_status rnde_bench_attempt(rnde_node* h, const float* x_dev, cons
     hipEvent_t e0, e1;
     HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
     HIPCHK(h, hipEventRecord(e0, s));
+    const auto host_t0 = std::chrono::steady_clock::now();
     for (int i = 0; i < iters; ++i) {
         if (h->engine == 2) HIPCHK(h, stage_attempt(h, SQ, 0, s));
         else HIPCHK(h, launch_step<MODE_STEP>(h, P, 0, s));
     }
+    const double host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - host_t0).count();
+    if (getenv("RNDE_TRACE_HOST")) fprintf(stderr, "[rnde] host enqueue: %.2f us per attempt (%d launches each)\n", host_us / iters, h->engine == 2 ? 7 : 1);
     HIPCHK(h, hipEventRecord(e1, s));
     HIPCHK(h, hipEventSynchronize(e1));
     float ms = 0.f;
@@ -700,5 +708,31 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
     HIPCHK(h, hipStreamSynchronize(s));
     if (tspan_bar_host) { tspan_bar_host[0] = h->h_scal[0]; tspan_bar_host[1] = h->h_scal[1]; }
     h->have_tape = false;  // z2bar overwrote k_s in place: the tape is consumed
+    return RNDE_OK;
+}
+
+// ---- fused classifier head ------------------------------------------------------
+extern "C" rnde_status rnde_classifier_head(rnde_node* h, const float* u_dev, const float* p3_dev, const float* y_dev,
+                                            int32_t B, int32_t n_classes, float* logits_out_dev, float* u_bar_dev,
+                                            float* p3_bar_dev, float* ce_out_dev, void* stream) {
+    if (!h || B < 1 || n_classes < 1 || n_classes > kHeadMaxC) return RNDE_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t need = (size_t)B * n_classes + B + (size_t)kHeadChunks * n_classes * h->D;
+    if (h->head_ws_floats < need) {
+        if (h->head_ws) hipFree(h->head_ws);
+        h->head_ws = nullptr; h->head_ws_floats = 0;
+        HIPCHK(h, hipMalloc((void**)&h->head_ws, need * 4));
+        h->head_ws_floats = need;
+    }
+    float* delta = h->head_ws;
+    float* ce_col = h->head_ws + (size_t)B * n_classes;
+    hipLaunchKernelGGL(rnde_head_col_kernel, dim3((B + 3) / 4), dim3(256), 0, s, u_dev, p3_dev, y_dev, h->D, n_classes, B,
+                       logits_out_dev, u_bar_dev, delta, ce_col);
+    float* partial = ce_col + B;
+    hipLaunchKernelGGL(rnde_head_wgrad_kernel, dim3((h->D + 255) / 256, kHeadChunks), dim3(256), 0, s, u_dev, (const float*)delta,
+                       h->D, n_classes, B, partial);
+    hipLaunchKernelGGL(rnde_head_reduce_kernel, dim3((n_classes * h->D + 255) / 256), dim3(256), 0, s, (const float*)partial,
+                       (const float*)delta, (const float*)ce_col, h->D, n_classes, B, p3_bar_dev, ce_out_dev);
+    HIPCHK(h, hipGetLastError());
     return RNDE_OK;
 }

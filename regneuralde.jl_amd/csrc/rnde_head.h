@@ -1,0 +1,110 @@
+// rnde_head.h -- the caller of the hot path, fused: postode Dense(D, C) + logitcrossentropy
+// and their reverse in two small launches, so a training step is [solve] -> [head] -> [reverse solve] without a
+// tape library in between.
+// Replaces, for the classifier: reference src/models/supervised_classification.jl:44-45 (postode),
+// experiments/mnist_node.jl:135 (Flux.Losses.logitcrossentropy) and the Tracker reverse of both.
+//   p3 = Flux.destructure(Dense(D, C)) = [vec(W) (C x D, column-major); b (C)]
+//   logits = W u + b;  ce = mean_c( -sum_i y_ic * logsoftmax(logits)_ic );  delta = (softmax - y) / B
+//   u-bar = W^T delta;  W-bar = delta u^T;  b-bar = rowsum(delta)
+#pragma once
+#include "rnde_device.h"
+
+namespace rnde {
+
+constexpr int kHeadMaxC = 16;
+
+// one wave per batch column
+__global__ __launch_bounds__(256) void rnde_head_col_kernel(const float* __restrict__ u, const float* __restrict__ p3,
+                                                            const float* __restrict__ y, int D, int C, int B,
+                                                            float* __restrict__ logits_out, float* __restrict__ ubar,
+                                                            float* __restrict__ delta, float* __restrict__ ce_col) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= B) return;
+    const float* W = p3;
+    const float* b = p3 + (size_t)C * D;
+    const float* uc = u + (size_t)c * D;
+    float acc[kHeadMaxC];
+#pragma unroll
+    for (int i = 0; i < kHeadMaxC; ++i) acc[i] = 0.f;
+    for (int d = lane; d < D; d += 64) {
+        const float uv = uc[d];
+#pragma unroll
+        for (int i = 0; i < kHeadMaxC; ++i) if (i < C) acc[i] = fmaf(W[(size_t)d * C + i], uv, acc[i]);
+    }
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < kHeadMaxC; ++i) if (i < C) { acc[i] = wave_sum_f(acc[i]) + b[i]; mx = fmaxf(mx, acc[i]); }
+    float se = 0.f;
+#pragma unroll
+    for (int i = 0; i < kHeadMaxC; ++i) if (i < C) se += expf(acc[i] - mx);
+    const float lse = mx + logf(se);
+    float ce = 0.f, dl[kHeadMaxC];
+    const float invB = 1.f / (float)B;
+#pragma unroll
+    for (int i = 0; i < kHeadMaxC; ++i) {
+        dl[i] = 0.f;
+        if (i < C) {
+            const float yv = y[(size_t)c * C + i];
+            ce -= yv * (acc[i] - lse);
+            dl[i] = (expf(acc[i] - lse) - yv) * invB;
+        }
+    }
+    if (lane == 0) {
+        ce_col[c] = ce;
+        for (int i = 0; i < C; ++i) { delta[(size_t)c * C + i] = dl[i]; if (logits_out) logits_out[(size_t)c * C + i] = acc[i]; }
+    }
+    for (int d = lane; d < D; d += 64) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < kHeadMaxC; ++i) if (i < C) s = fmaf(W[(size_t)d * C + i], dl[i], s);
+        ubar[(size_t)c * D + d] = s;
+    }
+}
+
+// W-bar[i][d] = sum_c delta[i][c] u[d][c]: pass 1 -- one thread per (d, column chunk), partial[chunk][d*C + i]
+constexpr int kHeadChunks = 32;
+__global__ __launch_bounds__(256) void rnde_head_wgrad_kernel(const float* __restrict__ u, const float* __restrict__ delta,
+                                                              int D, int C, int B, float* __restrict__ partial) {
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    const int ch = blockIdx.y;
+    const int per = (B + kHeadChunks - 1) / kHeadChunks;
+    const int c0 = ch * per, c1 = min(B, c0 + per);
+    if (d >= D) return;
+    float acc[kHeadMaxC];
+#pragma unroll
+    for (int i = 0; i < kHeadMaxC; ++i) acc[i] = 0.f;
+    for (int c = c0; c < c1; ++c) {
+        const float uv = u[(size_t)c * D + d];
+#pragma unroll
+        for (int i = 0; i < kHeadMaxC; ++i) if (i < C) acc[i] = fmaf(delta[(size_t)c * C + i], uv, acc[i]);
+    }
+    float* o = partial + (size_t)ch * C * D;
+    for (int i = 0; i < C; ++i) o[(size_t)d * C + i] = acc[i];
+}
+// pass 2 -- fixed-order sum of the chunk partials; bias gradient and mean cross entropy by one extra wave
+__global__ __launch_bounds__(256) void rnde_head_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ delta,
+                                                               const float* __restrict__ ce_col, int D, int C, int B,
+                                                               float* __restrict__ p3bar, float* __restrict__ ce_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < C * D) {
+        float s = 0.f;
+        for (int ch = 0; ch < kHeadChunks; ++ch) s += partial[(size_t)ch * C * D + i];
+        p3bar[i] = s;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        for (int k = 0; k < C; ++k) {
+            float s = 0.f;
+            for (int c = lane; c < B; c += 64) s += delta[(size_t)c * C + k];
+            s = wave_sum_f(s);
+            if (lane == 0) p3bar[(size_t)C * D + k] = s;
+        }
+        float s = 0.f;
+        for (int c = lane; c < B; c += 64) s += ce_col[c];
+        s = wave_sum_f(s);
+        if (lane == 0) *ce_out = s / (float)B;
+    }
+}
+
+}  // namespace rnde

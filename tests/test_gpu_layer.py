@@ -75,3 +75,28 @@ def test_classifier_training_reduces_loss(rnde):
         losses.append(float(ce))
     assert losses[-1] < 0.7 * losses[0], losses
     assert rn.accuracy(model, [(x, y)]) > 0.3
+
+
+def test_fused_head_step_matches_autograd(rnde):
+    """rnde_classifier_head + fused_loss_and_grad against the torch.autograd path on the same inputs."""
+    rn = rnde
+    def make():
+        g = torch.Generator().manual_seed(5)
+        dyn = rn.MLPDynamics(784, 100, generator=g)
+        node = rn.TrackedNeuralODE(dyn, [0.0, 1.0], True, True, "Tsit5", save_everystep=False, reltol=1e-3, abstol=1e-3,
+                                   save_start=False, max_batch=24, max_attempts=64)
+        post = rn.Dense(784, 10, generator=g)
+        post.b.uniform_(-0.1, 0.1, generator=g)
+        model = rn.ClassifierNODE(node, post)
+        x = torch.rand(24, 1, 28, 28, generator=g).cuda()
+        y = torch.eye(10)[torch.randint(0, 10, (24,), generator=g)].cuda()
+        return model, x, y
+    m1, x, y = make()
+    loss1, ce1, reg1, nfe1 = rn.loss_function(x, y, m1, lam=50.0)
+    loss1.backward()
+    m2, _, _ = make()
+    loss2, ce2, reg2, nfe2 = rn.fused_loss_and_grad(m2, x, y, lam=50.0)
+    assert nfe1 == nfe2
+    assert abs(float(loss1) - loss2) <= 1e-5 * max(1.0, abs(loss2))
+    for a, b in ((m1.p2.grad, m2.p2.grad), (m1.p3.grad, m2.p3.grad)):
+        assert (a - b).abs().max() <= 5e-4 * b.abs().max()   # different fp32 association in the head GEMM

@@ -656,12 +656,45 @@ int orc_backward(void* hh, const real* ubar, const real* svbar, real* xbar, real
                     dtb += -d_th * th / (double)dt;
                 }
             }
+            double eigb = 0; /* cotangent of eigen_est (reference mnist_node.jl:74-79, :88-97) */
             if (r->sv_index >= 0 && svbar) {
                 double sb = (double)svbar[r->sv_index];
+                real eg = r->eigen_est;
+                int eg_ok = !(eg == 0 || isnan(eg));
                 switch (cfg->reg_kind) {
                     case 1: eb += sb * (double)dt; dtb += sb * (double)r->eest; break;
-                    case 3: { real e = r->eest * dt; if (!(e == 0 || isnan(e))) { eb += sb * (double)dt; dtb += sb * (double)r->eest; } } break;
-                    default: break; /* stiffness term: gradient not implemented in the oracle */
+                    case 2: if (eg_ok) eigb += sb * (eg > 0 ? 1.0 : -1.0) / (double)STAB_SIZE; break;   /* stab * |eigen_est| */
+                    case 3: { real e = r->eest * dt; if (!(e == 0 || isnan(e))) { eb += sb * (double)dt; dtb += sb * (double)r->eest; }
+                              if (eg_ok) eigb += 0.1 * sb / (double)STAB_SIZE; } break;
+                    default: break;
+                }
+            }
+            if (eigb != 0) {
+                /* eigen_est = N1/N2, N1 = ||k7-k6||, N2 = ||unew-g6||, g6 = uprev + dt sum_j a6j kj   */
+                double n1 = 0, n2 = 0;
+                for (size_t i = 0; i < N; ++i) {
+                    real acc = 0;
+                    for (int j = 0; j < 5; ++j) acc += (real)TS_A[5][j] * r->k[j][i];
+                    gtmp[i] = r->uprev[i] + dt * acc;
+                    double d1 = (double)r->k[6][i] - (double)r->k[5][i], d2 = (double)r->unew[i] - (double)gtmp[i];
+                    n1 += d1 * d1; n2 += d2 * d2;
+                }
+                n1 = sqrt(n1); n2 = sqrt(n2);
+                if (n1 > 0 && n2 > 0) {
+                    const double c1 = eigb / (n2 * n1), c2 = -eigb * (n1 / n2) / (n2 * n2);
+                    double d_dt = 0;
+                    for (size_t i = 0; i < N; ++i) {
+                        const real d1 = r->k[6][i] - r->k[5][i], d2 = r->unew[i] - gtmp[i];
+                        kb[6][i] += (real)(c1 * (double)d1);
+                        kb[5][i] -= (real)(c1 * (double)d1);
+                        unb[i] += (real)(c2 * (double)d2);
+                        const real g6b = -(real)(c2 * (double)d2);
+                        upb[i] += g6b;
+                        real acc = 0;
+                        for (int j = 0; j < 5; ++j) { kb[j][i] += dt * (real)TS_A[5][j] * g6b; acc += (real)TS_A[5][j] * r->k[j][i]; }
+                        d_dt += (double)g6b * (double)acc;
+                    }
+                    dtb += d_dt;
                 }
             }
             /* t' = t + dt */

@@ -120,6 +120,20 @@ class FluxOptimiser:
             p.grad = None
 
 
+def sample_tspan_ubound(b=0.5, generator=None):
+    """STEER (experiments/mnist_node.jl:104-105,:133): integrate to t1 ~ U(1 - b, 1 + b) instead of 1."""
+    r = float(torch.rand((), generator=generator))
+    return [0.0, 1.0 - (2.0 * r - 1.0) * b]
+
+
+# (lambda0, lambda1, callback, aggregation, solver) per regulariser type, experiments/mnist_node.jl:62-103
+REGULARISERS = {
+    "error_est": (1.0e2, 1.0e1, "error_est", torch.mean, "Tsit5"),
+    "stiff_est": (0.1, 0.1, "stiff_est", torch.max, "AutoTsit5"),
+    "error_stiff_est": (1.0e1, 1.0e1, "error_stiff_est", torch.mean, "AutoTsit5"),
+}
+
+
 def lambda_schedule(epoch, epochs=75, lam0=1.0e2, lam1=1.0e1):
     """experiments/mnist_node.jl:65-66,:106-108: exponential decay from lam0 to lam1 over the run."""
     k = math.log(lam0 / lam1) / epochs

@@ -94,6 +94,7 @@ static StepParams make_params(rnde_node* h, const float* x, int B, float t0, flo
     P.tape = tape; P.max_attempts = h->cfg.max_attempts;
     P.forced = 0; P.forced_t = 0; P.forced_dt = 0;
     P.xvec = ((h->D & 3) == 0 && ((uintptr_t)x & 15) == 0) ? 1 : 0;
+    P.reg_kind = h->cfg.regularize;
     return P;
 }
 
@@ -138,8 +139,9 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
                        "(experiments/mnist_node.jl:41-54, test/test_node.jl:4) with Tsit5";
         return RNDE_ERR_BAD_ARG;
     }
-    if (c->regularize != RNDE_REG_NONE && c->regularize != RNDE_REG_ERR) {
-        g_create_err = "regularize: only NONE and ERR (EEst*dt) are implemented on the device path";
+    if (c->regularize < RNDE_REG_NONE || c->regularize > RNDE_REG_ERR_STIFF) { g_create_err = "regularize: unknown value"; return RNDE_ERR_BAD_ARG; }
+    if (c->regularize >= RNDE_REG_STIFF && (c->col_tile == 4 || c->col_tile == 8)) {
+        g_create_err = "the stiffness-estimate regularisers run on the stage engine only (col_tile 0 or 16)";
         return RNDE_ERR_BAD_ARG;
     }
     rnde_node* h = new rnde_node();
@@ -185,7 +187,7 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
     ok &= dm((void**)&h->slab2, (size_t)2 * (h->Bpad_max / 16) * h->sR * h->sHT * 64 * 16);
     ok &= dm((void**)&h->ctl, 2 * sizeof(StepState)) && dm((void**)&h->ctl_final, sizeof(StepState));
     ok &= dm((void**)&h->meta, (size_t)(c->max_attempts + 1) * sizeof(StepMeta)) && dm((void**)&h->initrec, sizeof(InitRec));
-    ok &= dm((void**)&h->errpart, (size_t)2 * h->nwg_max * 4) && dm((void**)&h->initpart, (size_t)3 * h->nwg_max * 4);
+    ok &= dm((void**)&h->errpart, (size_t)6 * h->nwg_max * 4) && dm((void**)&h->initpart, (size_t)3 * h->nwg_max * 4);
     // scratch records: 2 (no-tape ring); grown to max_attempts on the first taped forward
     h->arena_recs = 2;
     ok &= dm((void**)&h->arena, (size_t)h->arena_recs * h->rec_stride * 4);
@@ -329,11 +331,22 @@ extern "C" rnde_status rnde_node_forward(rnde_node* h, const float* x_dev, const
     // saving callback values (reference neural_ode.jl:116,:126-127): EEst*dt per accepted step
     int nsv = 0;
     h->sv_index.assign(h->n_att, -1);
-    if (h->cfg.regularize == RNDE_REG_ERR) {
-        if (h->cfg.cb_save_start) { if (saveval_host) saveval_host[nsv] = 0.f; ++nsv; }
+    // func(u, t, integrator) of the reference: EEst*dt (mnist_node.jl:67), stab*|eigen_est| (:74-79), their blend (:88-97)
+    const float stab = 1.0f / 3.5068f;   // 1 / alg_stability_size(Tsit5()), as recalled in SURVEY.md 8a row a9
+    auto cbval = [&](float eest, float dt, float eig) -> float {
+        const bool eg_ok = !(eig == 0.f || eig != eig);
+        switch (h->cfg.regularize) {
+            case RNDE_REG_ERR: return eest * dt;
+            case RNDE_REG_STIFF: return eg_ok ? stab * fabsf(eig) : 0.f;
+            case RNDE_REG_ERR_STIFF: { const float e = eest * dt; return ((e == 0.f || e != e) ? 0.f : e) + 0.1f * (eg_ok ? stab * eig : 0.f); }
+            default: return 0.f;
+        }
+    };
+    if (h->cfg.regularize != RNDE_REG_NONE) {
+        if (h->cfg.cb_save_start) { if (saveval_host) saveval_host[nsv] = cbval(1.f, 0.f, 1.f); ++nsv; }   // EEst = 1, dt = 0, eigen_est = 1 at init
         for (int i = 0; i < h->n_att; ++i)
             if (h->h_meta[i].flags & F_ACCEPT) {
-                if (saveval_host) saveval_host[nsv] = h->h_meta[i].eest * h->h_meta[i].dt;
+                if (saveval_host) saveval_host[nsv] = cbval(h->h_meta[i].eest, h->h_meta[i].dt, h->h_meta[i].eigen);
                 h->sv_index[i] = nsv++;
             }
     }
@@ -541,7 +554,7 @@ static rnde_status bwd_prepare(rnde_node* h) {
     }
     if (h->engine == 2) {
         HIPCHK(h, hipMalloc((void**)&b.UTB, A * 4)); HIPCHK(h, hipMalloc((void**)&b.UNB, A * 4)); HIPCHK(h, hipMalloc((void**)&b.UPB0, A * 4));
-        HIPCHK(h, hipMalloc((void**)&b.GB, 6 * A * 4));
+        HIPCHK(h, hipMalloc((void**)&b.GB, 8 * A * 4));   // gbar_1..6, then EXK, EXG (stiffness extras)
     }
     b.ready = true;
     return RNDE_OK;
@@ -668,15 +681,29 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
         BStageParams BQ{};
         BQ.B = Q; BQ.p = h->pcopy; BQ.pwBt = h->spwBt; BQ.pwDt = h->spwDt; BQ.slab = h->slab2;
         BQ.UTB = b.UTB; BQ.UNB = b.UNB; BQ.UPB0 = b.UPB0; BQ.GB = b.GB;
+        BQ.EXK = b.GB + 6 * A; BQ.EXG = b.GB + 7 * A;
         BQ.MT = h->sMT; BQ.WT = h->sWT; BQ.R = h->sR; BQ.C = Q.F.Bpad / 16; BQ.HT = h->sHT; BQ.KHb = h->sKHb;
         const dim3 grid(BQ.R * BQ.C), blk(64 * BQ.WT);
         int hi_att = n_att;
         for (int n = n_att - 1; n >= 0; --n) {
-            if (h->act2) hipLaunchKernelGGL((rnde_bstage_kernel<1, BM_START>), grid, blk, h->stage_lds, s, BQ, n, 0, h->h_meta[n]);
-            else hipLaunchKernelGGL((rnde_bstage_kernel<0, BM_START>), grid, blk, h->stage_lds, s, BQ, n, 0, h->h_meta[n]);
+            // cotangent of eigen_est for this attempt (host-known: saveval cotangent, callback form, recorded norms)
+            float c1 = 0.f, c2 = 0.f;
+            {
+                const StepMeta& mm = h->h_meta[n];
+                const bool eg_ok = !(mm.eigen == 0.f || mm.eigen != mm.eigen);
+                double eigb = 0.0;
+                if (h->cfg.regularize == RNDE_REG_STIFF && eg_ok) eigb = (double)b.h_svb[n] * (mm.eigen > 0 ? 1.0 : -1.0) / 3.5068;
+                if (h->cfg.regularize == RNDE_REG_ERR_STIFF && eg_ok) eigb = 0.1 * (double)b.h_svb[n] / 3.5068;
+                if (eigb != 0.0 && mm.n1 > 0.f && mm.n2 > 0.f) {
+                    c1 = (float)(eigb / ((double)mm.n2 * (double)mm.n1));
+                    c2 = (float)(-eigb * ((double)mm.n1 / (double)mm.n2) / ((double)mm.n2 * (double)mm.n2));
+                }
+            }
+            if (h->act2) hipLaunchKernelGGL((rnde_bstage_kernel<1, BM_START>), grid, blk, h->stage_lds, s, BQ, n, 0, h->h_meta[n], c1, c2);
+            else hipLaunchKernelGGL((rnde_bstage_kernel<0, BM_START>), grid, blk, h->stage_lds, s, BQ, n, 0, h->h_meta[n], c1, c2);
             for (int j = 6; j >= 1; --j) {
-                if (h->act2) hipLaunchKernelGGL((rnde_bstage_kernel<1, BM_STAGE>), grid, blk, h->stage_lds, s, BQ, n, j, h->h_meta[n]);
-                else hipLaunchKernelGGL((rnde_bstage_kernel<0, BM_STAGE>), grid, blk, h->stage_lds, s, BQ, n, j, h->h_meta[n]);
+                if (h->act2) hipLaunchKernelGGL((rnde_bstage_kernel<1, BM_STAGE>), grid, blk, h->stage_lds, s, BQ, n, j, h->h_meta[n], c1, c2);
+                else hipLaunchKernelGGL((rnde_bstage_kernel<0, BM_STAGE>), grid, blk, h->stage_lds, s, BQ, n, j, h->h_meta[n], c1, c2);
             }
             if (overlap && (hi_att - n >= group || n == 0)) {       // attempts [n, hi_att) are final: their GEMM slice can start now
                 st = wgrad_group(6 * n, 6 * hi_att);

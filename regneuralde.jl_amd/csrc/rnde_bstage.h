@@ -24,13 +24,15 @@ struct BStageParams {
     const f32x4* pwDt;        // [HT][MT][64]   [W2x^T; w2t^T]  (phase D, K = state rows)
     float* slab;              // [2][C][R][HT][64][4]
     float* UTB; float* UNB; float* UPB0; float* GB;   // utilde-bar, unew-bar, uprev-bar seed, gbar_s (s = 1..6 -> GB + (s-1)*A)
+    float* EXK; float* EXG;   // stiffness-estimate extras: direct cotangent of k6, of g6 (regularize >= 2)
     int MT, WT, R, C, HT, KHb;
 };
 
 enum { BM_START = 0, BM_STAGE = 1 };
 
 template <int ACT2, int MODE>
-__global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_kernel(const BStageParams Q, const int n, const int j, const StepMeta m) {
+__global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_kernel(const BStageParams Q, const int n, const int j, const StepMeta m,
+                                                                   const float eig_c1, const float eig_c2) {
     const BwdParams& Bq = Q.B;
     const StepParams& P = Bq.F;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -114,7 +116,8 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_kernel(const BStagePa
             const double N = (double)P.D * (double)P.B;
             double eb = 0, dtb_pre = 0, q11b = 0, qb = 0, qoldb_in = 0;
             if (accepted) {
-                if (Bq.reg_kind == 1) { const double sb = (double)Bq.svb_att[n]; eb += sb * (double)dt; dtb_pre += sb * (double)m.eest; }
+                const bool err_term = Bq.reg_kind == 1 || (Bq.reg_kind == 3 && !(m.eest * dt == 0.f));
+                if (err_term) { const double sb = (double)Bq.svb_att[n]; eb += sb * (double)dt; dtb_pre += sb * (double)m.eest; }
                 dtb_pre += tb;
                 if (m.flags & F_DTMAXCLAMP) { t1b += dtpb; t0b -= dtpb; }
                 else if (Bq.track_ctrl) { dtb_pre += dtpb / (double)m.q; qb += -dtpb * (double)dt / ((double)m.q * (double)m.q); }
@@ -136,9 +139,14 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_kernel(const BStagePa
         if (tile_ok) {
             const f32x4 upv = ld4(upsrc + co, r0, P.D, upok, upvec);
             const f32x4 unv = ld4(R + L.unew() + co, r0, P.D, true, vec);
-            f32x4 acc = tsBt(0) * ld4(k1p + co, r0, P.D, true, vec);
+            const f32x4 k1v = ld4(k1p + co, r0, P.D, true, vec);
+            f32x4 acc = tsBt(0) * k1v, g6 = tsA(5, 0) * k1v, k6 = k1v;
 #pragma unroll
-            for (int s = 2; s <= 6; ++s) acc += tsBt(s - 1) * ld4(R + L.k(s) + co, r0, P.D, true, vec);
+            for (int s = 2; s <= 6; ++s) {
+                const f32x4 ks = ld4(R + L.k(s) + co, r0, P.D, true, vec);
+                acc += tsBt(s - 1) * ks;
+                if (s <= 5) g6 += tsA(5, s - 1) * ks; else k6 = ks;
+            }
             const f32x4 k7 = ld4(R + L.k(7) + co, r0, P.D, true, vec);
             acc += tsBt(6) * k7;
             f32x4 uin = {0.f, 0.f, 0.f, 0.f}, k1in = {0.f, 0.f, 0.f, 0.f};
@@ -167,6 +175,22 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_kernel(const BStagePa
 #pragma unroll
             for (int i = 0; i < 4; ++i) S += k7[i] * kb7[i];
             kb7 += k1in;
+            if (eig_c1 != 0.f || eig_c2 != 0.f) {
+                // reverse of eigen_est = ||k7-k6|| / ||unew-g6|| (direct terms; not part of S: they do not scale with dt)
+                f32x4 exk, exg;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool ok = colok && (r0 + i < P.D);
+                    const float d1 = k7[i] - k6[i], d2 = unv[i] - (upv[i] + dt * g6[i]);
+                    kb7[i] += ok ? eig_c1 * d1 : 0.f;
+                    exk[i] = ok ? -eig_c1 * d1 : 0.f;
+                    unb[i] += ok ? eig_c2 * d2 : 0.f;
+                    exg[i] = ok ? -eig_c2 * d2 : 0.f;
+                }
+                st4(Q.UNB + co, r0, P.D, true, vec, unb);
+                st4(Q.EXK + co, r0, P.D, true, vec, exk);
+                st4(Q.EXG + co, r0, P.D, true, vec, exg);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = (r0 + i < P.D) ? (ACT2 ? kb7[i] * (1.f - k7[i] * k7[i]) : kb7[i]) : 0.f;
             st4(R + L.k(7) + co, r0, P.D, true, vec, v);   // z2bar_7 replaces k7 (dead from here on)
@@ -234,6 +258,8 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_kernel(const BStagePa
         }
         // ---- phase C ----
         if (tile_ok) {
+            const bool has_eig = (eig_c1 != 0.f || eig_c2 != 0.f);
+            if (has_eig && j == 5) gb += ld4(Q.EXG + co, r0, P.D, true, vec);        // direct cotangent of g6 joins gbar of stage 6
             st4(Q.GB + (size_t)(j - 1) * A + co, r0, P.D, true, vec, gb);
             f32x4 unb = c_unb;
             if (j == 6) { unb += gb; st4(Q.UNB + co, r0, P.D, true, vec, unb); }
@@ -248,10 +274,10 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_kernel(const BStagePa
             if (jn >= 1) {
                 const f32x4 ks = c_ks;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    S += ks[i] * kbar[i];
-                    v[i] = (r0 + i < P.D) ? (ACT2 ? kbar[i] * (1.f - ks[i] * ks[i]) : kbar[i]) : 0.f;
-                }
+                for (int i = 0; i < 4; ++i) S += ks[i] * kbar[i];
+                if (has_eig && j == 6) kbar += ld4(Q.EXK + co, r0, P.D, true, vec);   // direct cotangent of k6 (after S: not dt-scaled)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = (r0 + i < P.D) ? (ACT2 ? kbar[i] * (1.f - ks[i] * ks[i]) : kbar[i]) : 0.f;
                 st4(R + L.k(jn + 1) + co, r0, P.D, true, vec, v);  // z2bar replaces k (dead)
             } else {
                 // j == 1: kbar is the cotangent of k1; assemble the attempt's outputs

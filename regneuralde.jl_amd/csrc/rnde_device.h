@@ -111,7 +111,9 @@ struct StepState {  // state BEFORE an attempt (double-buffered in HBM, one writ
 };
 struct StepMeta {  // one per attempted step; consumed by the reverse pass and by the host
     float t, dt, dtp_in, eest, q11, q, qold_in, rej_m;
-    int flags, src, rec, pad;
+    int flags, src, rec;
+    float eigen, n1, n2;   // stiffness estimate ||k7-k6|| / ||unew-g6|| and its two norms (regularize >= 2 only)
+    int pad[2];
 };
 struct InitRec {  // initial-step heuristic record
     float d0, d1, d2, dt0, dt1, dt;
@@ -136,6 +138,7 @@ struct StepParams {
     int tape, max_attempts;
     int forced; float forced_t, forced_dt;  // debug/bench: run one attempt from a given (t, dt)
     int xvec;                                // x is 16-byte aligned and D % 4 == 0
+    int reg_kind;                            // rnde_reg: 2, 3 also need the stiffness estimate
 };
 
 // record layout inside the arena (floats): k2..k7 | g2..g6 | unew | h2..h7 | z1bar2..z1bar7

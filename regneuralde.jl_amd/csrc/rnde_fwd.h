@@ -211,8 +211,15 @@ __device__ __forceinline__ StepState advance_state(const StepParams& P, int n, i
     S = p;
     const bool clamped = !P.forced && (P.t1 - p.t < p.dtp);
     const float dt = clamped ? (P.t1 - p.t) : p.dtp;
-    const double ss = sum_partials(P.errpart + ((n - 1) & 1) * P.nwg, P.nwg, lane);
+    const float* ep = P.errpart + (size_t)((n - 1) & 1) * 3 * P.nwg;   // [parity][{r^2, (k7-k6)^2, (unew-g6)^2}][workgroup]
+    const double ss = sum_partials(ep, P.nwg, lane);
     const float eest = (float)sqrt(ss / N);
+    float eig = 0.f, en1 = 0.f, en2 = 0.f;
+    if (P.reg_kind >= 2) {   // stiffness estimate of the composite algorithm AutoTsit5(Tsit5())
+        en1 = (float)sqrt(sum_partials(ep + P.nwg, P.nwg, lane));
+        en2 = (float)sqrt(sum_partials(ep + 2 * P.nwg, P.nwg, lane));
+        eig = en1 / en2;
+    }
     const int rec = P.tape ? (n - 1) : (p.live == 0 ? 1 : 0);
     int flags = clamped ? F_CLAMP : 0;
     float q, q11 = 0.f, rej_m = 0.f;
@@ -250,7 +257,7 @@ __device__ __forceinline__ StepState advance_state(const StepParams& P, int n, i
         *out = S;
         StepMeta M;
         M.t = p.t; M.dt = dt; M.dtp_in = p.dtp; M.eest = eest; M.q11 = q11; M.q = q; M.qold_in = p.qold; M.rej_m = rej_m;
-        M.flags = flags; M.src = p.live; M.rec = rec; M.pad = 0;
+        M.flags = flags; M.src = p.live; M.rec = rec; M.eigen = eig; M.n1 = en1; M.n2 = en2; M.pad[0] = M.pad[1] = 0;
         P.meta[n - 1] = M;
     }
     return S;
@@ -423,7 +430,7 @@ __global__ __launch_bounds__(kThreads) void rnde_step_kernel(const StepParams P,
         if (tid == 0) {
             float s = 0.f;
             for (int w = 0; w < kWaves; ++w) s += RED[w];
-            P.errpart[(n & 1) * P.nwg + wg] = s;
+            P.errpart[(size_t)(n & 1) * 3 * P.nwg + wg] = s;
         }
     }
 }

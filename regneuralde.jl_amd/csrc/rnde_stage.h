@@ -283,7 +283,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_kernel(const StagePara
     SSTAMP(4);
     // ---- phase C: element-wise work on this wave's 16 rows x 16 columns ----
     f32x4 v = {0.f, 0.f, 0.f, 0.f};   // this wave's rows of the next layer-1 input
-    float part0 = 0.f, part1 = 0.f;
+    float part0 = 0.f, part1 = 0.f, part2 = 0.f;
     if (tile_ok) {
         if constexpr (MODE == SM_START) {
             v = c_up + dt * (kFwdShift[0][0] * c_k[0]);
@@ -315,6 +315,19 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_kernel(const StagePara
                     const float sk = P.abstol + fmaxf(fabsf(up[i]), fabsf(un[i])) * P.reltol;
                     const float r = ut / sk;
                     part0 += r * r;
+                }
+                if (P.reg_kind >= 2) {   // stiffness estimate partials: ||k7 - k6||^2, ||unew - g6||^2
+                    f32x4 g6 = tsA_rt(5, 0) * c_k[0];
+#pragma unroll
+                    for (int j = 1; j < 5; ++j) g6 += tsA_rt(5, j) * c_k[j];
+                    g6 = up + dt * g6;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (r0 + i < P.D) {
+                            const float d1 = kv[i] - c_k[5][i], d2 = un[i] - g6[i];
+                            part1 += d1 * d1; part2 += d2 * d2;
+                        }
+                    }
                 }
             }
         } else if constexpr (MODE == SM_I1 || MODE == SM_FEVAL1) {
@@ -400,13 +413,16 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_kernel(const StagePara
     }
 
     if constexpr (MODE == SM_LAST || MODE == SM_I2 || MODE == SM_I4) {
-        part0 = wave_sum_f(part0); part1 = wave_sum_f(part1);
-        if (lane == 0) { RED[w] = part0; RED[8 + w] = part1; }
+        part0 = wave_sum_f(part0); part1 = wave_sum_f(part1); part2 = wave_sum_f(part2);
+        if (lane == 0) { RED[w] = part0; RED[8 + w] = part1; RED[16 + w] = part2; }
         __syncthreads();
         if (tid == 0) {
-            float sa = 0.f, sb = 0.f;
-            for (int i = 0; i < Q.WT; ++i) { sa += RED[i]; sb += RED[8 + i]; }
-            if constexpr (MODE == SM_LAST) P.errpart[(n & 1) * P.nwg + blockIdx.x] = sa;
+            float sa = 0.f, sb = 0.f, sc = 0.f;
+            for (int i = 0; i < Q.WT; ++i) { sa += RED[i]; sb += RED[8 + i]; sc += RED[16 + i]; }
+            if constexpr (MODE == SM_LAST) {
+                float* ep = P.errpart + (size_t)(n & 1) * 3 * P.nwg;
+                ep[blockIdx.x] = sa; ep[P.nwg + blockIdx.x] = sb; ep[2 * P.nwg + blockIdx.x] = sc;
+            }
             else if constexpr (MODE == SM_I2) { P.initpart[blockIdx.x] = sa; P.initpart[P.nwg + blockIdx.x] = sb; }
             else P.initpart[2 * P.nwg + blockIdx.x] = sa;
         }

@@ -156,6 +156,9 @@ class TrackedNeuralODE:
                 raise RuntimeError("p and x must live on the same device")
         x2 = x.reshape(x.shape[0], -1).to(torch.float32).contiguous()
         ts = self.tspan if tspan is None else [float(tspan[0]), float(tspan[1])]   # _convert_tspan, utils.jl:21-23
+        if func not in _FUNCS:
+            raise ValueError("func must be one of None/'error_est', 'stiff_est', 'error_stiff_est' "
+                             "(the three callbacks of experiments/mnist_node.jl:62-103)")
         self._func = func if self.regularize else None
         keep = torch.is_grad_enabled() and (x2.requires_grad or p.requires_grad)
         u, saveval = _Solve.apply(x2, p.contiguous(), self, ts[0], ts[1], keep)

@@ -63,3 +63,44 @@ def test_backward_requires_tape():
     node.forward(x, p, keep_tape=False)
     with pytest.raises(RndeError):
         node.backward(np.ones_like(x))
+
+
+@pytest.mark.parametrize("kind,B,tol,scale,seed", [("test_node", 5, 1e-3, 3.0, 3), ("small", 12, 1e-3, 4.0, 4), ("mnist", 17, 1e-3, 3.0, 5)])
+@pytest.mark.parametrize("reg,agg", [(2, "max"), (2, "mean"), (3, "mean")])
+def test_stiffness_regulariser_matches_oracle(kind, B, tol, scale, seed, reg, agg):
+    """regularize = stiff_est / error_stiff_est (experiments/mnist_node.jl:70-99, AutoTsit5(Tsit5()) semantics):
+    callback values and the reverse pass of eigen_est = ||k7-k6|| / ||u-g6|| against the oracle."""
+    from tests.test_gpu_forward import _cfg, _setup
+    from tests.util import Node, Oracle, rel_err
+    arch, p, x = _setup(kind, B, seed, scale)
+    node = Node(_cfg(arch, B, reltol=tol, abstol=tol, regularize=reg, col_tile=16))
+    got = node.forward(x, p, 0.0, 1.0, keep_tape=True)
+    o32 = Oracle(arch, np.float32, reltol=tol, abstol=tol, reg_kind=reg)
+    o64 = Oracle(arch, np.float64, reltol=tol, abstol=tol, reg_kind=reg)
+    r32, r64 = o32.forward(x, p), o64.forward(x, p)
+    assert got["nattempts"] == r32["nattempts"] and (got["steps"][:, 3] == r32["steps"][:, 3]).all()
+    np.testing.assert_allclose(got["saveval"], r64["saveval"], rtol=2e-2, atol=1e-5)
+    rng = np.random.default_rng(7)
+    ubar = rng.standard_normal(x.shape).astype(np.float32)
+    sv = got["saveval"]
+    svbar = np.zeros(len(sv), dtype=np.float32)
+    if agg == "max":
+        svbar[int(np.argmax(r64["saveval"]))] = 2.0
+    else:
+        svbar[:] = 2.0 / len(sv)
+    xb, pb, tsb = node.backward(ubar, svbar)
+    xb64, pb64, _ = o64.backward(ubar.astype(np.float64), svbar.astype(np.float64))
+    xb32, pb32, _ = o32.backward(ubar, svbar)
+    cx, cp = rel_err(xb32, xb64), rel_err(pb32, pb64)
+    print(f"reg {reg}/{agg} {kind}: x-bar {rel_err(xb, xb64):.2e} (oracle f32 {cx:.2e})  p-bar {rel_err(pb, pb64):.2e} (oracle f32 {cp:.2e})")
+    assert rel_err(xb, xb64) <= 3e-3 + 3 * cx
+    assert rel_err(pb, pb64) <= 3e-3 + 3 * cp
+
+
+def test_stiffness_regulariser_needs_stage_engine():
+    from tests.test_gpu_forward import _cfg, _setup
+    from tests.util import Node
+    from regneuralde_jl_amd._lib import RndeError
+    arch, p, x = _setup("small", 4, 0, 1.0)
+    with pytest.raises(RndeError):
+        Node(_cfg(arch, 4, regularize=2, col_tile=8))

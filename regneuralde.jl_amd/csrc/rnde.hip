@@ -590,7 +590,13 @@ static rnde_status launch_wgrad_part(rnde_node* h, const EvalDesc* ev, int n_eva
     const int chunks = (n_evals + per_chunk - 1) / per_chunk;
     if ((size_t)(*chunk_cursor + chunks) * (size_t)len > h->bw.slab_floats) { h->err = "weight-gradient slab overflow"; return RNDE_ERR_BAD_ARG; }
     float* dst = slab + (size_t)(*chunk_cursor) * len;
-    if (tall) hipLaunchKernelGGL((rnde_wgrad_kernel<2, 4>), dim3(blocks, chunks), dim3(64), 0, s, ev, n_evals, per_chunk, M, Nx, Bpad, dst);
+    static const bool legacy = getenv("RNDE_WGRAD_LEGACY") != nullptr;   // direct-from-global variant, kept for A/B runs
+    const bool fits = tall ? (Nx + 2 <= 128) : (M <= 128);                // the staged kernel covers 128 on the un-split side
+    if (!legacy && fits) {
+        const int pblocks = tall ? (M + 127) / 128 : (Nx + 2 + 127) / 128;
+        if (tall) hipLaunchKernelGGL((rnde_wgrad2_kernel<true>), dim3(pblocks, chunks), dim3(256), 0, s, ev, n_evals, per_chunk, M, Nx, Bpad, dst);
+        else hipLaunchKernelGGL((rnde_wgrad2_kernel<false>), dim3(pblocks, chunks), dim3(256), 0, s, ev, n_evals, per_chunk, M, Nx, Bpad, dst);
+    } else if (tall) hipLaunchKernelGGL((rnde_wgrad_kernel<2, 4>), dim3(blocks, chunks), dim3(64), 0, s, ev, n_evals, per_chunk, M, Nx, Bpad, dst);
     else hipLaunchKernelGGL((rnde_wgrad_kernel<4, 2>), dim3(blocks, chunks), dim3(64), 0, s, ev, n_evals, per_chunk, M, Nx, Bpad, dst);
     HIPCHK(h, hipGetLastError());
     *chunk_cursor += chunks;

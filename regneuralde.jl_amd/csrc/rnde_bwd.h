@@ -537,6 +537,100 @@ __global__ __launch_bounds__(64) void rnde_wgrad_kernel(const EvalDesc* __restri
         }
 }
 
+// ---- LDS-staged variant (used by default) -----------------------------------------------------------------
+// A workgroup of 4 waves computes a 128 x 128 block of Wext_bar for its chunk of evaluations: 32 batch columns of Z
+// (128 rows) and of [X; t; 1] (128 rows) are staged per step with 16-byte coalesced loads, then every wave runs
+// 16 K-pairs x 4 tiles of v_mfma_f32_32x32x2_f32 from LDS.  SPLIT_M: the workgroups tile the M side (layer 2,
+// M = D) and each wave owns one 32-row M tile against all 4 N tiles; otherwise they tile the N side (layer 1,
+// N = D + 2) and each wave owns one N tile against all 4 M tiles.  Output: same slab format as rnde_wgrad_kernel.
+template <bool SPLIT_M>
+__global__ __launch_bounds__(256) void rnde_wgrad2_kernel(const EvalDesc* __restrict__ evals, int n_evals, int per_chunk,
+                                                          int M, int Nx, int Bpad, float* __restrict__ slab) {
+    constexpr int KC = 32;
+    __shared__ __attribute__((aligned(16))) float Zl[KC][128];
+    __shared__ __attribute__((aligned(16))) float Xl[KC][128];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, kk = lane >> 5;
+    const int blk = blockIdx.x, chunk = blockIdx.y;
+    const int m0 = SPLIT_M ? blk * 128 : 0, n0 = SPLIT_M ? 0 : blk * 128;
+    const int e0 = chunk * per_chunk, e1 = min(n_evals, e0 + per_chunk);
+    f32x16 acc[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+    const bool mvec = (M & 3) == 0, nvec = (Nx & 3) == 0;
+    // software pipeline over (evaluation, 32-column step): the next step's 8 float4 are fetched into registers while
+    // the current step's 64 MFMAs per wave run, and written to LDS after the barrier that retires the current step
+    const int steps_per_eval = (Bpad + KC - 1) / KC;
+    const int total_steps = (e1 - e0) * steps_per_eval;
+    f32x4 zreg[4], xreg[4];
+    auto fetch = [&](int step) {
+        const int e = e0 + step / steps_per_eval, c0 = (step % steps_per_eval) * KC;
+        const float* __restrict__ Z = evals[e].Z;
+        const float* __restrict__ X = evals[e].X;
+        const float te = evals[e].t;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = tid + 256 * q, col = idx >> 5, r4 = (idx & 31) * 4;
+            const int cc = c0 + col;
+            f32x4 zv = {0.f, 0.f, 0.f, 0.f}, xv = {0.f, 0.f, 0.f, 0.f};
+            if (cc < Bpad) {
+                const int mr = m0 + r4, nr = n0 + r4;
+                if (mvec && mr + 3 < M) zv = *(const f32x4*)(Z + (size_t)cc * M + mr);
+                else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if (mr + i < M) zv[i] = Z[(size_t)cc * M + mr + i];
+                }
+                if (nvec && nr + 3 < Nx) xv = *(const f32x4*)(X + (size_t)cc * Nx + nr);
+                else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int n = nr + i;
+                        xv[i] = n < Nx ? X[(size_t)cc * Nx + n] : (n == Nx ? te : (n == Nx + 1 ? 1.f : 0.f));
+                    }
+                }
+            }
+            zreg[q] = zv; xreg[q] = xv;
+        }
+    };
+    if (total_steps > 0) fetch(0);
+    for (int step = 0; step < total_steps; ++step) {
+        __syncthreads();                       // every wave is done reading the previous step's LDS image
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = tid + 256 * q, col = idx >> 5, r4 = (idx & 31) * 4;
+            *(f32x4*)&Zl[col][r4] = zreg[q];
+            *(f32x4*)&Xl[col][r4] = xreg[q];
+        }
+        __syncthreads();
+        if (step + 1 < total_steps) fetch(step + 1);   // in flight under the MFMAs below
+#pragma unroll
+        for (int kp = 0; kp < KC / 2; ++kp) {
+            const int col = 2 * kp + kk;
+            if (SPLIT_M) {
+                const float a = Zl[col][32 * w + l31];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Xl[col][32 * t + l31], acc[t], 0, 0, 0);
+            } else {
+                const float bq = Xl[col][32 * w + l31];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(Zl[col][32 * t + l31], bq, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    float* out = slab + (size_t)chunk * M * (Nx + 2);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int mt = SPLIT_M ? w : t, nt = SPLIT_M ? t : w;
+        const int ncol = n0 + 32 * nt + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mr = m0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * kk;
+            if (mr < M && ncol < Nx + 2) out[(size_t)ncol * M + mr] = acc[t][r];
+        }
+    }
+}
+
 // fixed-order sum of chunks [c0, c1) of the slab -> out (blockIdx.y selects the chunk group in pass 1)
 __global__ void rnde_wgrad_reduce(const float* __restrict__ slab, int n_chunks, int per_group, long long len, float* __restrict__ out) {
     const int c0 = blockIdx.y * per_group, c1 = min(n_chunks, c0 + per_group);

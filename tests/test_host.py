@@ -75,3 +75,16 @@ def test_shard_columns(rnde):
     x = torch.arange(20).reshape(10, 2)
     a, b = rnde.shard_columns(x, 0, 2), rnde.shard_columns(x, 1, 2)
     assert torch.equal(torch.cat([a, b]), x) and a.shape[0] == 5
+
+
+def test_regulariser_table_and_steer(rnde):
+    lam0, lam1, func, agg, solver = rnde.REGULARISERS["stiff_est"]
+    assert (lam0, lam1, func, solver) == (0.1, 0.1, "stiff_est", "AutoTsit5") and agg is torch.max      # mnist_node.jl:70-83
+    assert rnde.REGULARISERS["error_est"][:2] == (1.0e2, 1.0e1) and rnde.REGULARISERS["error_stiff_est"][:2] == (1.0e1, 1.0e1)
+    g = torch.Generator().manual_seed(0)
+    ts = [rnde.sample_tspan_ubound(generator=g) for _ in range(200)]
+    assert all(t0 == 0.0 and 0.5 <= t1 <= 1.5 for t0, t1 in ts)                                          # mnist_node.jl:104-105
+    assert max(t1 for _, t1 in ts) > 1.3 and min(t1 for _, t1 in ts) < 0.7
+    dyn = rnde.MLPDynamics(8, 4)
+    node = rnde.TrackedNeuralODE(dyn, [0.0, 1.0], True, True, "AutoTsit5", reltol=1e-3, abstol=1e-3)     # test_node.jl:60-72
+    assert node.regularize

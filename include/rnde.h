@@ -88,6 +88,15 @@ rnde_status rnde_node_forward(rnde_node* h, const float* x_dev, const float* p_d
                               float* saveval_host, int32_t* n_saveval_out, int32_t keep_tape,
                               void* stream);
 
+/* The {R,true} call methods (reference src/models/neural_ode.jl:79-108, :146-180 and update_saveat! :35-46): same
+ * solve, returning the state at every time of `saveat` (increasing, inside [t0,t1]) from the Tsit5 dense output.
+ * u_saved_dev: D x n_saveat x B, column-major, exactly what diffeqsol_to_3dtrackedarray builds (src/utils.jl:17-19).
+ * With a taped saveat forward, rnde_node_backward takes u_bar_dev of that same D x n_saveat x B shape. */
+rnde_status rnde_node_forward_saveat(rnde_node* h, const float* x_dev, const float* p_dev, int32_t B,
+                                     float t0, float t1, const float* saveat_host, int32_t n_saveat,
+                                     float* u_saved_dev, int64_t* nfe_out, float* saveval_host,
+                                     int32_t* n_saveval_out, int32_t keep_tape, void* stream);
+
 /* Reverse pass of the last recorded forward.  u_bar_dev: D x B cotangent of u_out;
  * saveval_bar_host: one cotangent per saveval element (NULL = zeros).
  * Outputs: x_bar_dev (D x B), p_bar_dev (P, overwritten), tspan_bar_host[2] (may be NULL).

@@ -31,6 +31,7 @@ struct rnde_node {
     float* slab2 = nullptr;
     size_t stage_lds = 0;
     float* head_ws = nullptr; size_t head_ws_floats = 0;   // fused classifier head scratch
+    float* sv_t_dev = nullptr; size_t sv_cap = 0; std::vector<float> saveat;   // saveat times of the last forward
     hipStream_t wstream = nullptr;        // (experimental overlap path of the weight-gradient GEMMs)
     std::vector<hipEvent_t> wevents;
     // device
@@ -209,6 +210,7 @@ extern "C" void rnde_node_destroy(rnde_node* h) {
     for (void* p : d) if (p) hipFree(p);
     bwd_free(h->bw);
     if (h->head_ws) hipFree(h->head_ws);
+    if (h->sv_t_dev) hipFree(h->sv_t_dev);
     for (hipEvent_t e : h->wevents) hipEventDestroy(e);
     if (h->wstream) hipStreamDestroy(h->wstream);
     if (h->h_ctl) hipHostFree(h->h_ctl);
@@ -271,11 +273,44 @@ static hipError_t stage_attempt(rnde_node* h, const StageParams& Q, int n, hipSt
     return e;
 }
 
+static rnde_status forward_impl(rnde_node* h, const float* x_dev, const float* p_dev, int32_t B, float t0, float t1,
+                                float* u_out_dev, const float* saveat_host, int32_t n_saveat, float* sv_out_dev,
+                                int64_t* nfe_out, float* saveval_host, int32_t* n_saveval_out, int32_t keep_tape, void* stream);
+
 extern "C" rnde_status rnde_node_forward(rnde_node* h, const float* x_dev, const float* p_dev, int32_t B, float t0,
                                          float t1, float* u_out_dev, int64_t* nfe_out, float* saveval_host,
                                          int32_t* n_saveval_out, int32_t keep_tape, void* stream) {
+    return forward_impl(h, x_dev, p_dev, B, t0, t1, u_out_dev, nullptr, 0, nullptr, nfe_out, saveval_host, n_saveval_out, keep_tape, stream);
+}
+
+extern "C" rnde_status rnde_node_forward_saveat(rnde_node* h, const float* x_dev, const float* p_dev, int32_t B, float t0,
+                                                float t1, const float* saveat_host, int32_t n_saveat, float* u_saved_dev,
+                                                int64_t* nfe_out, float* saveval_host, int32_t* n_saveval_out,
+                                                int32_t keep_tape, void* stream) {
+    if (!h || !saveat_host || n_saveat < 1 || !u_saved_dev) return RNDE_ERR_BAD_ARG;
+    return forward_impl(h, x_dev, p_dev, B, t0, t1, nullptr, saveat_host, n_saveat, u_saved_dev, nfe_out, saveval_host, n_saveval_out, keep_tape, stream);
+}
+
+static rnde_status forward_impl(rnde_node* h, const float* x_dev, const float* p_dev, int32_t B, float t0, float t1,
+                                float* u_out_dev, const float* saveat_host, int32_t n_saveat, float* sv_out_dev,
+                                int64_t* nfe_out, float* saveval_host, int32_t* n_saveval_out, int32_t keep_tape, void* stream) {
     if (!h) return RNDE_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
+    if (n_saveat > 0) {
+        if (h->engine != 2) { h->err = "saveat runs on the stage engine only (col_tile 0 or 16)"; return RNDE_ERR_BAD_ARG; }
+        for (int i = 0; i < n_saveat; ++i)
+            if (!(saveat_host[i] >= t0 && saveat_host[i] <= t1) || (i > 0 && !(saveat_host[i] > saveat_host[i - 1]))) {
+                h->err = "saveat must be increasing and inside [t0, t1]"; return RNDE_ERR_BAD_ARG;
+            }
+        if ((size_t)n_saveat > h->sv_cap) {
+            if (h->sv_t_dev) hipFree(h->sv_t_dev);
+            h->sv_t_dev = nullptr; h->sv_cap = 0;
+            HIPCHK(h, hipMalloc((void**)&h->sv_t_dev, (size_t)n_saveat * 4));
+            h->sv_cap = n_saveat;
+        }
+        h->saveat.assign(saveat_host, saveat_host + n_saveat);
+        HIPCHK(h, hipMemcpyAsync(h->sv_t_dev, h->saveat.data(), (size_t)n_saveat * 4, hipMemcpyHostToDevice, s));
+    } else h->saveat.clear();
     if (B < 1 || B > h->cfg.max_batch || !(t1 > t0)) { h->err = "bad B or tspan"; return RNDE_ERR_BAD_ARG; }
     HIPCHK(h, hipSetDevice(h->cfg.device));
     h->have_tape = false;
@@ -289,6 +324,7 @@ extern "C" rnde_status rnde_node_forward(rnde_node* h, const float* x_dev, const
         x_dev = h->xcopy;
     }
     StepParams P = make_params(h, x_dev, B, t0, t1, keep_tape ? 1 : 0);
+    P.sv_t = n_saveat > 0 ? h->sv_t_dev : nullptr; P.nsave = n_saveat; P.sv_out = sv_out_dev;
     h->B = B; h->Bpad = P.Bpad; h->nwg = P.nwg; h->t0 = t0; h->t1 = t1;
     rnde_status st = pack_weights(h, p_dev, keep_tape != 0, s);   // (column-owner packs: also used by the reverse sweep)
     if (st != RNDE_OK) return st;
@@ -554,7 +590,7 @@ static rnde_status bwd_prepare(rnde_node* h) {
     }
     if (h->engine == 2) {
         HIPCHK(h, hipMalloc((void**)&b.UTB, A * 4)); HIPCHK(h, hipMalloc((void**)&b.UNB, A * 4)); HIPCHK(h, hipMalloc((void**)&b.UPB0, A * 4));
-        HIPCHK(h, hipMalloc((void**)&b.GB, 8 * A * 4));   // gbar_1..6, then EXK, EXG (stiffness extras)
+        HIPCHK(h, hipMalloc((void**)&b.GB, 15 * A * 4));   // gbar_1..6, EXK, EXG (stiffness extras), W_1..7 (saveat)
     }
     b.ready = true;
     return RNDE_OK;
@@ -634,6 +670,9 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
     Q.ubar = u_bar_dev; Q.xbar = x_bar_dev; Q.tspan_out = b.tspan_out;
     Q.n_att = n_att; Q.track_ctrl = h->cfg.track_ctrl; Q.track_initdt = h->cfg.track_initdt; Q.reg_kind = h->cfg.regularize;
     Q.bpart_n = Q.F.nwg;
+    Q.sv_T = (int)h->saveat.size();
+    Q.sv_ubar0 = (!h->saveat.empty() && h->saveat[0] == h->t0) ? u_bar_dev : nullptr;
+    if (!h->saveat.empty() && h->engine != 2) { h->err = "saveat reverse pass runs on the stage engine only"; return RNDE_ERR_BAD_ARG; }
     // ---- evaluation descriptors for the parameter-gradient GEMMs (all pointers are known before the sweep) ----
     const long long A = (long long)h->D * Q.F.Bpad, HB = (long long)h->H * Q.F.Bpad;
     RecLayout L{A, HB};
@@ -687,10 +726,24 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
         BStageParams BQ{};
         BQ.B = Q; BQ.p = h->pcopy; BQ.pwBt = h->spwBt; BQ.pwDt = h->spwDt; BQ.slab = h->slab2;
         BQ.UTB = b.UTB; BQ.UNB = b.UNB; BQ.UPB0 = b.UPB0; BQ.GB = b.GB;
-        BQ.EXK = b.GB + 6 * A; BQ.EXG = b.GB + 7 * A;
+        BQ.EXK = b.GB + 6 * A; BQ.EXG = b.GB + 7 * A; BQ.SVW = b.GB + 8 * A;
+        BQ.sv_t = h->saveat.empty() ? nullptr : h->sv_t_dev; BQ.sv_ubar = u_bar_dev; BQ.nsave = (int)h->saveat.size();
         BQ.MT = h->sMT; BQ.WT = h->sWT; BQ.R = h->sR; BQ.C = Q.F.Bpad / 16; BQ.HT = h->sHT; BQ.KHb = h->sKHb;
         const dim3 grid(BQ.R * BQ.C), blk(64 * BQ.WT);
         int hi_att = n_att;
+        // saveat: which save indices each accepted attempt covers (same float comparisons as the forward controller)
+        std::vector<int> sv_lo(n_att, 0), sv_hi(n_att, 0);
+        if (!h->saveat.empty()) {
+            int ns = (h->saveat[0] == h->t0) ? 1 : 0;
+            for (int n = 0; n < n_att; ++n) {
+                sv_lo[n] = ns;
+                if (h->h_meta[n].flags & F_ACCEPT) {
+                    const float tnew = h->h_meta[n].t + h->h_meta[n].dt;
+                    while (ns < (int)h->saveat.size() && h->saveat[ns] <= tnew) ++ns;
+                }
+                sv_hi[n] = ns;
+            }
+        }
         for (int n = n_att - 1; n >= 0; --n) {
             // cotangent of eigen_est for this attempt (host-known: saveval cotangent, callback form, recorded norms)
             float c1 = 0.f, c2 = 0.f;
@@ -705,11 +758,11 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
                     c2 = (float)(-eigb * ((double)mm.n1 / (double)mm.n2) / ((double)mm.n2 * (double)mm.n2));
                 }
             }
-            if (h->act2) hipLaunchKernelGGL((rnde_bstage_kernel<1, BM_START>), grid, blk, h->stage_lds, s, BQ, n, 0, h->h_meta[n], c1, c2);
-            else hipLaunchKernelGGL((rnde_bstage_kernel<0, BM_START>), grid, blk, h->stage_lds, s, BQ, n, 0, h->h_meta[n], c1, c2);
+            if (h->act2) hipLaunchKernelGGL((rnde_bstage_kernel<1, BM_START>), grid, blk, h->stage_lds, s, BQ, n, 0, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n]);
+            else hipLaunchKernelGGL((rnde_bstage_kernel<0, BM_START>), grid, blk, h->stage_lds, s, BQ, n, 0, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n]);
             for (int j = 6; j >= 1; --j) {
-                if (h->act2) hipLaunchKernelGGL((rnde_bstage_kernel<1, BM_STAGE>), grid, blk, h->stage_lds, s, BQ, n, j, h->h_meta[n], c1, c2);
-                else hipLaunchKernelGGL((rnde_bstage_kernel<0, BM_STAGE>), grid, blk, h->stage_lds, s, BQ, n, j, h->h_meta[n], c1, c2);
+                if (h->act2) hipLaunchKernelGGL((rnde_bstage_kernel<1, BM_STAGE>), grid, blk, h->stage_lds, s, BQ, n, j, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n]);
+                else hipLaunchKernelGGL((rnde_bstage_kernel<0, BM_STAGE>), grid, blk, h->stage_lds, s, BQ, n, j, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n]);
             }
             if (overlap && (hi_att - n >= group || n == 0)) {       // attempts [n, hi_att) are final: their GEMM slice can start now
                 st = wgrad_group(6 * n, 6 * hi_att);
@@ -753,6 +806,7 @@ extern "C" rnde_status rnde_classifier_head(rnde_node* h, const float* u_dev, co
     const size_t need = (size_t)B * n_classes + B + (size_t)kHeadChunks * n_classes * h->D;
     if (h->head_ws_floats < need) {
         if (h->head_ws) hipFree(h->head_ws);
+    if (h->sv_t_dev) hipFree(h->sv_t_dev);
         h->head_ws = nullptr; h->head_ws_floats = 0;
         HIPCHK(h, hipMalloc((void**)&h->head_ws, need * 4));
         h->head_ws_floats = need;

@@ -25,6 +25,7 @@ struct BStageParams {
     float* slab;              // [2][C][R][HT][64][4]
     float* UTB; float* UNB; float* UPB0; float* GB;   // utilde-bar, unew-bar, uprev-bar seed, gbar_s (s = 1..6 -> GB + (s-1)*A)
     float* EXK; float* EXG;   // stiffness-estimate extras: direct cotangent of k6, of g6 (regularize >= 2)
+    const float* sv_t; const float* sv_ubar; int nsave; float* SVW;   // saveat: times, D x T x B cotangent, W_i = sum_p b_i(theta_p) ubar_p (7 arrays)
     int MT, WT, R, C, HT, KHb;
 };
 
@@ -32,7 +33,7 @@ enum { BM_START = 0, BM_STAGE = 1 };
 
 template <int ACT2, int MODE>
 __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_kernel(const BStageParams Q, const int n, const int j, const StepMeta m,
-                                                                   const float eig_c1, const float eig_c2) {
+                                                                   const float eig_c1, const float eig_c2, const int sv_lo, const int sv_hi) {
     const BwdParams& Bq = Q.B;
     const StepParams& P = Bq.F;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_kernel(const BStagePa
     const float* upsrc = P.x; const float* k1p = P.f0; bool upok = colok, upvec = P.xvec != 0;
     if (m.src >= 0) { const float* Rl = P.arena + (long long)m.src * P.rec_stride; upsrc = Rl + L.unew(); k1p = Rl + L.k(7); upok = true; upvec = vec; }
 
-    float S = 0.f, tau = 0.f;   // dot partial sum_j <k_j, kbar_j>, time-cotangent partial of this launch
+    float S = 0.f, tau = 0.f, exdt = 0.f;   // dot partial sum_j <k_j, kbar_j>; time-cotangent partial; extra dt-bar (saveat theta terms)
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
 
     if constexpr (MODE == BM_START) {
@@ -139,20 +140,19 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_kernel(const BStagePa
         if (tile_ok) {
             const f32x4 upv = ld4(upsrc + co, r0, P.D, upok, upvec);
             const f32x4 unv = ld4(R + L.unew() + co, r0, P.D, true, vec);
-            const f32x4 k1v = ld4(k1p + co, r0, P.D, true, vec);
-            f32x4 acc = tsBt(0) * k1v, g6 = tsA(5, 0) * k1v, k6 = k1v;
+            f32x4 kq[7];
+            kq[0] = ld4(k1p + co, r0, P.D, true, vec);
 #pragma unroll
-            for (int s = 2; s <= 6; ++s) {
-                const f32x4 ks = ld4(R + L.k(s) + co, r0, P.D, true, vec);
-                acc += tsBt(s - 1) * ks;
-                if (s <= 5) g6 += tsA(5, s - 1) * ks; else k6 = ks;
-            }
-            const f32x4 k7 = ld4(R + L.k(7) + co, r0, P.D, true, vec);
-            acc += tsBt(6) * k7;
+            for (int s = 2; s <= 7; ++s) kq[s - 1] = ld4(R + L.k(s) + co, r0, P.D, true, vec);
+            f32x4 acc = tsBt(0) * kq[0], g6 = tsA(5, 0) * kq[0];
+#pragma unroll
+            for (int s = 1; s < 7; ++s) { acc += tsBt(s) * kq[s]; if (s < 5) g6 += tsA(5, s) * kq[s]; }
+            const f32x4 k6 = kq[5], k7 = kq[6];
             f32x4 uin = {0.f, 0.f, 0.f, 0.f}, k1in = {0.f, 0.f, 0.f, 0.f};
+            const bool sv_mode = Q.nsave > 0;          // saveat: the only outputs are the saved points, no u_end cotangent
             if (accepted) {
-                uin = first ? ld4(Bq.ubar + co, r0, P.D, colok, false) : ld4(Bq.U + co, r0, P.D, true, vec);
-                if (!first) k1in = ld4(Bq.K1 + co, r0, P.D, true, vec);
+                if (!first) { uin = ld4(Bq.U + co, r0, P.D, true, vec); k1in = ld4(Bq.K1 + co, r0, P.D, true, vec); }
+                else if (!sv_mode) uin = ld4(Bq.ubar + co, r0, P.D, colok, false);
             }
             f32x4 utb, unb, upb;
 #pragma unroll
@@ -168,10 +168,39 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_kernel(const BStagePa
                 unb[i] = uin[i] + (use_new ? skb * P.reltol * sgnf(unv[i]) : 0.f);
                 upb[i] = use_new ? 0.f : skb * P.reltol * sgnf(upv[i]);
             }
+            f32x4 w7 = {0.f, 0.f, 0.f, 0.f};
+            if (sv_hi > sv_lo) {
+                // reverse of the dense output u(ts) = uprev + dt sum_i b_i(theta) k_i, theta = (ts - t)/dt  
+                f32x4 Wv[7];
+#pragma unroll
+                for (int i = 0; i < 7; ++i) Wv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const float tnew = m.t + dt;
+                for (int idx = sv_lo; idx < sv_hi; ++idx) {
+                    const float ts = Q.sv_t[idx];
+                    const f32x4 ub = ld4(Q.sv_ubar + ((size_t)gcol * Q.nsave + idx) * P.D, r0, P.D, colok, vec);
+                    if (ts == tnew) { unb += ub; continue; }
+                    const float th = (ts - m.t) / dt;
+                    float bw[7], dbw[7];
+                    dense_weights(th, bw);
+                    dense_weights_deriv(th, dbw);
+                    upb += ub;
+                    f32x4 dacc = dbw[0] * kq[0];
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) { Wv[i] += bw[i] * ub; if (i) dacc += dbw[i] * kq[i]; }
+                    float dth = 0.f;                 // <ubar_p, dt * sum_i b_i'(theta) k_i>
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dth += ub[i] * dt * dacc[i];
+                    tau += -dth / dt;                // t-bar    (theta = (ts - t)/dt)
+                    exdt += -dth * th / dt;          // dt-bar, beyond the dt-scaled part that S carries
+                }
+#pragma unroll
+                for (int i = 0; i < 7; ++i) st4(Q.SVW + (size_t)i * A + co, r0, P.D, true, vec, Wv[i]);
+                w7 = Wv[6];
+            }
             st4(Q.UTB + co, r0, P.D, true, vec, utb);
             st4(Q.UNB + co, r0, P.D, true, vec, unb);
             st4(Q.UPB0 + co, r0, P.D, true, vec, upb);
-            f32x4 kb7 = (dt * tsBt(6)) * utb;
+            f32x4 kb7 = dt * (tsBt(6) * utb + w7);
 #pragma unroll
             for (int i = 0; i < 4; ++i) S += k7[i] * kb7[i];
             kb7 += k1in;
@@ -270,6 +299,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_kernel(const BStagePa
             for (int s = 1; s <= 5; ++s) {
                 if (s > jn) kbar += tsA_rt(s, jn) * ((s == j) ? gb : c_gs[s - 1]);
             }
+            if (sv_hi > sv_lo) kbar += ld4(Q.SVW + (size_t)jn * A + co, r0, P.D, true, vec);   // saveat: dense-output weights on k_jn
             kbar = dt * kbar;
             if (jn >= 1) {
                 const f32x4 ks = c_ks;
@@ -339,16 +369,16 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_kernel(const BStagePa
     }
 
     // ---- per-workgroup partials {S, tau, c_j * tau} accumulated over the 7 launches of the attempt ----
-    if (!colok) tau = 0.f;
-    S = wave_sum_f(S); tau = wave_sum_f(tau);
+    if (!colok) { tau = 0.f; exdt = 0.f; }
+    S = wave_sum_f(S); tau = wave_sum_f(tau); exdt = wave_sum_f(exdt);
     __syncthreads();
-    if (lane == 0) { RED[w] = S; RED[8 + w] = tau; }
+    if (lane == 0) { RED[w] = S; RED[8 + w] = tau; RED[16 + w] = exdt; }
     __syncthreads();
     if (tid == 0) {
-        float sa = 0.f, ta = 0.f;
-        for (int i = 0; i < Q.WT; ++i) { sa += RED[i]; ta += RED[8 + i]; }
+        float sa = 0.f, ta = 0.f, xa = 0.f;
+        for (int i = 0; i < Q.WT; ++i) { sa += RED[i]; ta += RED[8 + i]; xa += RED[16 + i]; }
         float* o = Bq.bpart + ((size_t)(n & 1) * Bq.bpart_n + blockIdx.x) * 4;
-        if constexpr (MODE == BM_START) { o[0] = sa; o[1] = 0.f; o[2] = 0.f; o[3] = 0.f; }
+        if constexpr (MODE == BM_START) { o[0] = sa; o[1] = ta; o[2] = xa; o[3] = 0.f; }   // (saveat theta terms: t-bar, dt-bar)
         else { o[0] += sa; o[1] += ta; o[2] += kTsC[j] * ta; }
     }
 }

@@ -45,6 +45,7 @@ struct BwdParams {
     float* xbar;                       // caller layout
     float* tspan_out;                  // [2]
     int n_att, track_ctrl, track_initdt, reg_kind;
+    const float* sv_ubar0; int sv_T;   // saveat with t0 among the save times: cotangent slice of that point (else NULL)
     int bpart_n;                       // number of per-workgroup partials the sweep wrote (differs from F.nwg when the stage engine ran it)
 };
 
@@ -435,6 +436,7 @@ __global__ __launch_bounds__(kThreads) void rnde_binit_kernel(const BwdParams Q)
                 const float skb = -(wb * w + vb * v + zb * z) / sk;
                 const float f0b = K1v[i] + dt0 * ub1[i] + (vb - wb) / sk;
                 u0b[j][i] = Uv[i] + ub1[i] + zb / sk + skb * P.reltol * sgnf(xv[i]);
+                if (Q.sv_ubar0 && colok && r0 + i < P.D) u0b[j][i] += Q.sv_ubar0[((size_t)gcol * Q.sv_T) * P.D + r0 + i];
                 zb2[j][i] = ACT2 ? f0b * (1.f - f0v[i] * f0v[i]) : f0b;
             }
         }

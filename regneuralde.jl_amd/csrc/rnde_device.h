@@ -80,6 +80,40 @@ __constant__ float kTsA[7][8] = {
 __device__ __forceinline__ float tsA_rt(int s, int j) { return kTsA[s][j]; }
 __constant__ float kTsC[8] = {0.f, 0.161f, 0.327f, 0.9f, 0.9800255409045097f, 1.0f, 1.0f, 0.f};
 __constant__ float kTsBt[8] = {-0.001780011052225777f, -0.0008164344596567469f, 0.007880878010261995f, -0.1447110071732629f, 0.5823571654525552f, -0.45808210592918697f, 0.015151515151515152f, 0.f};
+// Tsit5 dense output u(t + theta*dt) = uprev + dt * sum_i b_i(theta) k_i  
+__host__ __device__ inline void dense_weights(float th, float (&b)[7]) {
+    const float t2 = th * th;
+    b[0] = -1.0530884977290216f * th * (th - 1.3299890189751412f) * (t2 - 1.4364028541716351f * th + 0.7139816917074209f);
+    b[1] = 0.1017f * t2 * (t2 - 2.1966568338249754f * th + 1.2949852507374631f);
+    b[2] = 2.490627285651252793f * t2 * (t2 - 2.38535645472061657f * th + 1.57803468208092486f);
+    b[3] = -16.54810288924490272f * (th - 1.21712927295533244f) * (th - 0.61620406037800089f) * t2;
+    b[4] = 47.37952196281928122f * (th - 1.203071208372362603f) * (th - 0.658047292653547382f) * t2;
+    b[5] = -34.87065786149660974f * (th - 1.2f) * (th - 0.666666666666666667f) * t2;
+    b[6] = 2.5f * (th - 1.0f) * (th - 0.6f) * t2;
+}
+// d b_i / d theta (analytic), for the theta-cotangent of saveat points in the reverse pass
+__host__ __device__ inline void dense_weights_deriv(float th, float (&db)[7]) {
+    const float t2 = th * th;
+    {   // b1 = c * f * g, f = th^2 - r th, g = th^2 - p th + q
+        const float c = -1.0530884977290216f, r = 1.3299890189751412f, p = 1.4364028541716351f, q = 0.7139816917074209f;
+        const float f = t2 - r * th, g = t2 - p * th + q;
+        db[0] = c * ((2.f * th - r) * g + f * (2.f * th - p));
+    }
+    {   // b = c * th^2 * (th^2 - p th + q)
+        const float c[2] = {0.1017f, 2.490627285651252793f};
+        const float p[2] = {2.1966568338249754f, 2.38535645472061657f}, q[2] = {1.2949852507374631f, 1.57803468208092486f};
+        for (int i = 0; i < 2; ++i) db[1 + i] = c[i] * (2.f * th * (t2 - p[i] * th + q[i]) + t2 * (2.f * th - p[i]));
+    }
+    {   // b = c * (th - r)(th - s) * th^2
+        const float c[4] = {-16.54810288924490272f, 47.37952196281928122f, -34.87065786149660974f, 2.5f};
+        const float r[4] = {1.21712927295533244f, 1.203071208372362603f, 1.2f, 1.0f};
+        const float s[4] = {0.61620406037800089f, 0.658047292653547382f, 0.666666666666666667f, 0.6f};
+        for (int i = 0; i < 4; ++i) {
+            const float f = (th - r[i]) * (th - s[i]);
+            db[3 + i] = c[i] * ((2.f * th - r[i] - s[i]) * t2 + f * 2.f * th);
+        }
+    }
+}
 // PI controller constants
 constexpr float kBeta1 = (float)(7.0 / 50.0);
 constexpr float kBeta2 = (float)(2.0 / 25.0);
@@ -107,7 +141,8 @@ struct StepState {  // state BEFORE an attempt (double-buffered in HBM, one writ
     int done;    // integration finished or aborted
     int status;  // rnde_status of the solve
     int n_att, n_acc;
-    int pad[3];
+    int next_save;   // saveat: index of the first save time not yet written
+    int pad[2];
 };
 struct StepMeta {  // one per attempted step; consumed by the reverse pass and by the host
     float t, dt, dtp_in, eest, q11, q, qold_in, rej_m;
@@ -139,6 +174,7 @@ struct StepParams {
     int forced; float forced_t, forced_dt;  // debug/bench: run one attempt from a given (t, dt)
     int xvec;                                // x is 16-byte aligned and D % 4 == 0
     int reg_kind;                            // rnde_reg: 2, 3 also need the stiffness estimate
+    const float* sv_t; int nsave; float* sv_out;   // saveat times (device), their count, output D x T x B
 };
 
 // record layout inside the arena (floats): k2..k7 | g2..g6 | unew | h2..h7 | z1bar2..z1bar7

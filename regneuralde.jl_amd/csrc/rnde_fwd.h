@@ -184,7 +184,8 @@ __device__ __forceinline__ StepState advance_state(const StepParams& P, int n, i
     const double N = (double)P.D * (double)P.B;
     if (n == 0) {
         S.last_eest = 1.f; S.live = -1; S.done = 0; S.status = 0; S.n_att = 0; S.n_acc = 0; S.qold = kQoldInit;
-        S.pad[0] = S.pad[1] = S.pad[2] = 0;
+        S.pad[0] = S.pad[1] = 0;
+        S.next_save = (P.nsave > 0 && P.sv_t[0] == P.t0) ? 1 : 0;   // save_start: t0 itself is a save time
         if (P.forced) {
             S.t = P.forced_t; S.dtp = P.forced_dt;
         } else {
@@ -243,6 +244,7 @@ __device__ __forceinline__ StepState advance_state(const StepParams& P, int n, i
             float dtnew = dt / q;
             if (!P.forced && dtmax < dtnew) { dtnew = dtmax; flags |= F_DTMAXCLAMP; }
             S.t = p.t + dt; S.dtp = dtnew; S.live = rec; S.n_acc = p.n_acc + 1;
+            while (S.next_save < P.nsave && P.sv_t[S.next_save] <= S.t) ++S.next_save;   // save times inside (t, t + dt]
         } else {
             rej_m = 1.f / kQmin;
             const float m2 = q11 / kGamma;

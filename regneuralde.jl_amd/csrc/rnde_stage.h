@@ -73,6 +73,31 @@ __global__ void rnde_stage_pack_kernel(const float* __restrict__ p, f32x4* __res
     }
 }
 
+// Dense output of the attempt that has just been accepted (record Rp: uprev/k1 copies, k2..k7, unew), for save indices
+// [lo, hi): 4 rows of one column per call.  A save time equal to the new t copies unew (as the reference does).
+__device__ __forceinline__ void dense_points(const StepParams& P, const RecLayout& L, const float* Rp, float tp, float dtp_, float tnew,
+                                             int lo, int hi, size_t co, int gcol, int r0, bool colok, bool vec) {
+    const f32x4 up = ld_tile(Rp + L.upc() + co, r0, P.D, true, vec);
+    f32x4 k[7];
+    k[0] = ld_tile(Rp + L.k1c() + co, r0, P.D, true, vec);
+#pragma unroll
+    for (int j = 1; j < 7; ++j) k[j] = ld_tile(Rp + L.k(j + 1) + co, r0, P.D, true, vec);
+    const f32x4 un = ld_tile(Rp + L.unew() + co, r0, P.D, true, vec);
+    for (int idx = lo; idx < hi; ++idx) {
+        const float ts = P.sv_t[idx];
+        f32x4 o = un;
+        if (ts != tnew) {
+            float b[7];
+            dense_weights((ts - tp) / dtp_, b);
+            f32x4 acc = b[0] * k[0];
+#pragma unroll
+            for (int j = 1; j < 7; ++j) acc += b[j] * k[j];
+            o = up + dtp_ * acc;
+        }
+        st_tile(P.sv_out + ((size_t)gcol * P.nsave + idx) * P.D, r0, P.D, colok, vec && ((P.D & 3) == 0), o);
+    }
+}
+
 enum { SM_START = 0, SM_STAGE = 1, SM_LAST = 2, SM_I1 = 3, SM_I2 = 4, SM_I3 = 5, SM_I4 = 6, SM_FEVAL1 = 7, SM_FEVAL2 = 8 };
 
 // 4 consecutive rows of one column (16x16 D-fragment ownership: col = lane & 15, rows 4*(lane>>4) + reg)
@@ -163,6 +188,21 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_kernel(const StagePara
     int live = -1, rec = 0;
     if constexpr (MODE == SM_START) {
         const StepState S = advance_state(P, n, lane, writer, &P.ctl[n & 1]);
+        if (P.nsave > 0) {
+            // saveat (reference neural_ode.jl:79-108: the {R,true} methods): points inside the step just accepted
+            const int lo = (n == 0) ? 0 : P.ctl[(n - 1) & 1].next_save, hi = S.next_save;
+            if (hi > lo && tile_ok) {
+                if (n == 0) {
+                    st_tile(P.sv_out + (size_t)gcol * P.nsave * P.D, r0, P.D, colok, vec,
+                            ld_tile(P.x + (size_t)gcol * P.D, r0, P.D, colok, P.xvec != 0));
+                } else {
+                    const StepState pv = P.ctl[(n - 1) & 1];
+                    const float dtp_ = (P.t1 - pv.t < pv.dtp) ? (P.t1 - pv.t) : pv.dtp;
+                    const float* Rp = P.arena + (long long)S.live * P.rec_stride;     // accepted => it is the live record
+                    dense_points(P, L, Rp, pv.t, dtp_, S.t, lo, hi, (size_t)gcol * P.D, gcol, r0, colok, vec);
+                }
+            }
+        }
         if (S.done) return;
         t = S.t; dt = (!P.forced && (P.t1 - S.t < S.dtp)) ? (P.t1 - S.t) : S.dtp; live = S.live;
     } else if constexpr (MODE == SM_STAGE || MODE == SM_LAST) {
@@ -287,8 +327,8 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_kernel(const StagePara
     if (tile_ok) {
         if constexpr (MODE == SM_START) {
             v = c_up + dt * (kFwdShift[0][0] * c_k[0]);
-            if (P.tape) {
-                st4(R + L.g(2) + (size_t)gcol * P.D, r0, P.D, true, vec, v);
+            if (P.tape) st4(R + L.g(2) + (size_t)gcol * P.D, r0, P.D, true, vec, v);
+            if (P.tape || P.nsave > 0) {
                 st4(R + L.upc() + (size_t)gcol * P.D, r0, P.D, true, vec, c_up);
                 st4(R + L.k1c() + (size_t)gcol * P.D, r0, P.D, true, vec, c_k[0]);
             }
@@ -435,8 +475,22 @@ __global__ __launch_bounds__(256) void rnde_stage_finish_kernel(const StageParam
     const int tid = threadIdx.x, lane = tid & 63;
     const bool writer = (blockIdx.x == 0 && tid == 0);
     const StepState S = advance_state(P, n, lane, writer, P.ctl_final);
-    if (!u_out) return;
     const RecLayout L{(long long)P.D * P.Bpad, (long long)P.H * P.Bpad};
+    if (P.nsave > 0 && n > 0) {
+        const StepState pv = P.ctl[(n - 1) & 1];
+        const int lo = pv.next_save, hi = S.next_save;
+        if (hi > lo && !pv.done) {     // the last launched attempt was accepted and covers save times
+            const float dtp_ = (P.t1 - pv.t < pv.dtp) ? (P.t1 - pv.t) : pv.dtp;
+            const float* Rp = P.arena + (long long)S.live * P.rec_stride;
+            const bool vec = (P.D & 3) == 0;
+            const int ntile = (P.D + 3) / 4;
+            for (long long i = blockIdx.x * 256LL + tid; i < (long long)ntile * P.B; i += (long long)gridDim.x * 256) {
+                const int gcol = (int)(i / ntile), r0 = 4 * (int)(i % ntile);
+                dense_points(P, L, Rp, pv.t, dtp_, S.t, lo, hi, (size_t)gcol * P.D, gcol, r0, true, vec);
+            }
+        }
+    }
+    if (!u_out) return;
     const float* src = S.live < 0 ? P.x : P.arena + (long long)S.live * P.rec_stride + L.unew();
     const long long total = (long long)P.D * P.B;
     for (long long i = blockIdx.x * 256LL + tid; i < total; i += (long long)gridDim.x * 256) u_out[i] = src[i];

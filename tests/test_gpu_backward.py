@@ -104,3 +104,29 @@ def test_stiffness_regulariser_needs_stage_engine():
     arch, p, x = _setup("small", 4, 0, 1.0)
     with pytest.raises(RndeError):
         Node(_cfg(arch, 4, regularize=2, col_tile=8))
+
+
+@pytest.mark.parametrize("kind,B,tol,scale,saveat,reg", [("test_node", 5, 1e-3, 3.0, np.linspace(0, 1, 7), 1), ("small", 12, 1e-3, 4.0, np.array([0.1, 0.5, 0.9]), 1),
+                                                          ("mnist", 19, 1e-3, 3.0, np.linspace(0, 1, 13), 1), ("small", 33, 1e-4, 4.0, np.array([0.0, 0.25, 1.0]), 0),
+                                                          ("small", 7, 1e-3, 4.0, np.array([0.31, 0.32, 0.33, 0.34]), 3)])
+def test_saveat_reverse_matches_oracle(kind, B, tol, scale, saveat, reg):
+    """Reverse pass of the {R,true} call methods (neural_ode.jl:79-108,:146-180): the cotangent is the D x T x B array
+    Tracker hands back for diffeqsol_to_3dtrackedarray (src/utils.jl:17-19); dense-output points carry their theta
+    dependence on t and dt."""
+    from tests.util import Node, Oracle, rel_err
+    from tests.test_gpu_forward import _setup, _cfg
+    arch, p, x = _setup(kind, B, 5, scale)
+    sa = saveat.astype(np.float32)
+    o = Oracle(arch, np.float64, reltol=tol, abstol=tol, reg_kind=reg, track_ctrl=1, track_initdt=1)
+    ref = o.forward(x, p, saveat=sa)
+    rng = np.random.default_rng(3)
+    ubar = rng.standard_normal(ref["u"].shape).astype(np.float32)
+    svbar = (rng.standard_normal(len(ref["saveval"])) * 10).astype(np.float32) if reg else None
+    rx, rp, rt = o.backward(ubar, svbar)
+    n = Node(_cfg(arch, B, reltol=tol, abstol=tol, col_tile=16, regularize=reg, track_ctrl=1, track_initdt=1))
+    got = n.forward_saveat(x, p, sa, keep_tape=True)
+    assert got["nfe"] == ref["nfe"] and len(got["saveval"]) == len(ref["saveval"])
+    gx, gp, gt = n.backward(ubar, svbar)
+    assert rel_err(gx, rx) < 2e-3
+    assert rel_err(gp, rp) < 2e-3
+    assert np.abs(gt - rt).max() <= 2e-3 * max(1.0, np.abs(rt).max())

@@ -117,3 +117,17 @@ def test_forward_solve_reference_tolerance(kind, B, col_tile):
     assert np.abs(got["u"] - ref64["u"]).max() <= 1e-5 * max(1.0, np.abs(ref64["u"]).max())
     assert np.abs(ref["u"] - ref64["u"]).max() <= 1e-5 * max(1.0, np.abs(ref64["u"]).max())
     assert len(got["saveval"]) == got["steps"][:, 3].sum() + 1
+
+
+@pytest.mark.parametrize("kind,B,tol,scale,saveat", [("test_node", 5, 1e-3, 3.0, np.linspace(0, 1, 7)), ("small", 12, 1e-3, 4.0, np.array([0.1, 0.5, 0.9])),
+                                                      ("mnist", 19, 1e-3, 3.0, np.linspace(0, 1, 49)), ("small", 33, 1e-4, 4.0, np.array([0.0, 0.25, 1.0]))])
+def test_saveat_dense_output_matches_oracle(kind, B, tol, scale, saveat):
+    """{R,true} call methods (neural_ode.jl:79-108,:146-180): D x T x B result from the Tsit5 dense output."""
+    from tests.util import Node, Oracle
+    arch, p, x = _setup(kind, B, 5, scale)
+    sa = saveat.astype(np.float32)
+    ref = Oracle(arch, np.float64, reltol=tol, abstol=tol, reg_kind=1).forward(x, p, saveat=sa)
+    got = Node(_cfg(arch, B, reltol=tol, abstol=tol, col_tile=16)).forward_saveat(x, p, sa)
+    assert got["nfe"] == ref["nfe"]
+    assert got["u"].shape == ref["u"].shape == (B, len(sa), arch.dims[0])
+    assert np.abs(got["u"] - ref["u"]).max() <= 3e-5 * max(1.0, np.abs(ref["u"]).max())

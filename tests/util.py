@@ -87,10 +87,24 @@ class Node:
         return dict(u=u.cpu().numpy(), nfe=nfe.value, saveval=np.array(sv[:nsv.value], dtype=np.float32),
                     steps=np.array(steps[:4 * natt.value], dtype=np.float32).reshape(-1, 4), nattempts=natt.value)
 
+    def forward_saveat(self, x, p, saveat, t0=0.0, t1=1.0, keep_tape=False):
+        B = x.shape[0]
+        xd, pd = self.dev(x), self.dev(p)
+        T = len(saveat)
+        u = torch.empty((B, T, self.D), dtype=torch.float32, device="cuda")
+        nfe = C.c_int64(0)
+        nsv = C.c_int32(0)
+        sv = (C.c_float * (self.cfg.max_attempts + 1))()
+        sa = (C.c_float * T)(*[float(v) for v in saveat])
+        st = self.L.rnde_node_forward_saveat(self.h, xd.data_ptr(), pd.data_ptr(), B, t0, t1, sa, T, u.data_ptr(), C.byref(nfe), sv,
+                                             C.byref(nsv), int(keep_tape), None)
+        _lib.check(self.h, st)
+        return dict(u=u.cpu().numpy(), nfe=nfe.value, saveval=np.array(sv[:nsv.value], dtype=np.float32))
+
     def backward(self, ubar, svbar=None):
         B = ubar.shape[0]
         ub = self.dev(ubar)
-        xb = torch.empty_like(ub)
+        xb = torch.empty((B, self.D), dtype=torch.float32, device="cuda")   # ubar is (B, T, D) after a saveat forward
         P = self.L.rnde_param_count(C.byref(self.cfg))
         pb = torch.empty(P, dtype=torch.float32, device="cuda")
         tsb = (C.c_float * 2)()

@@ -81,8 +81,33 @@ function solve_forward(h::Handle, x::CuArray{Float32,2}, p::CuArray{Float32,1}, 
     return u, Int(nfe[]), sv[1:nsv[]]
 end
 
-function solve_backward(h::Handle, ubar::CuArray{Float32,2}, svbar::Vector{Float32}, np::Int)
-    xbar = similar(ubar)
+"""
+    solve_forward_saveat(h, x, p, tspan, saveat; keep_tape) -> (u3, nfe, saveval)
+
+The {R,true} call methods (reference neural_ode.jl:79-108, :146-180): `u3` is the D x T x B array
+`diffeqsol_to_3dtrackedarray` builds (src/utils.jl:17-19), T = length(saveat).
+"""
+function solve_forward_saveat(h::Handle, x::CuArray{Float32,2}, p::CuArray{Float32,1}, tspan, saveat::Vector{Float32};
+                              keep_tape::Bool)
+    D, B = size(x)
+    u3 = CuArray{Float32}(undef, D, length(saveat), B)
+    nfe = Ref{Int64}(0)
+    nsv = Ref{Int32}(0)
+    sv = Vector{Float32}(undef, h.cfg.max_attempts + 1)
+    GC.@preserve x p u3 sv saveat begin
+        st = ccall((:rnde_node_forward_saveat, LIB), Cint,
+                   (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Int32, Float32, Float32, Ptr{Float32}, Int32, Ptr{Float32},
+                    Ref{Int64}, Ptr{Float32}, Ref{Int32}, Int32, Ptr{Cvoid}),
+                   h.ptr, pointer(x), pointer(p), B, Float32(tspan[1]), Float32(tspan[2]), saveat, length(saveat),
+                   pointer(u3), nfe, sv, nsv, keep_tape ? 1 : 0, C_NULL)
+        check(h, st)
+    end
+    return u3, Int(nfe[]), sv[1:nsv[]]
+end
+
+# ubar: D x B after solve_forward, D x T x B after solve_forward_saveat; x-bar is D x B either way
+function solve_backward(h::Handle, ubar::CuArray{Float32}, svbar::Vector{Float32}, np::Int)
+    xbar = CuArray{Float32}(undef, size(ubar, 1), size(ubar, ndims(ubar)))
     pbar = CuArray{Float32}(undef, np)
     tsbar = zeros(Float32, 2)
     GC.@preserve ubar xbar pbar svbar tsbar begin

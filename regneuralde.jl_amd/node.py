@@ -5,8 +5,13 @@ call contract, with the `solve` call replaced by librnde.so (hand-written gfx950
                             save_everystep=False, reltol=1.4e-8, abstol=1.4e-8, save_start=False)
     u, nfe, sv = node(x, p)            # x: (B, D) cuda tensor == Julia D x B;  sv.saveval: tensor or None
 
+With `saveat=` (constructor keyword or per-call override, neural_ode.jl:35-46) the {R,true} methods run
+(neural_ode.jl:79-108,:146-180): `u` is then the (B, T, D) tensor whose memory is exactly the Julia
+D x T x B array of diffeqsol_to_3dtrackedarray (src/utils.jl:17-19).
+
 Differences from the Julia layer that are inherent to the host language: `func` is one of the
-reference's three callbacks selected by name (mnist_node.jl:67,:74-79,:88-97), not a closure.
+reference's three callbacks selected by name (mnist_node.jl:67,:74-79,:88-97), not a closure;
+`save_everystep=True` (a result whose length is data dependent; no reference call site uses it) is refused.
 """
 import ctypes as C
 
@@ -44,17 +49,24 @@ class _Handle:
 
 class _Solve(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, p, layer, t0, t1, keep_tape):
+    def forward(ctx, x, p, layer, t0, t1, keep_tape, saveat):
         h = layer._acquire(x, keep_tape)
         L = _lib.lib()
         B, D = x.shape
-        u = torch.empty_like(x)
         nfe = C.c_int64(0)
         nsv = C.c_int32(0)
         sv_host = (C.c_float * (layer.max_attempts + 1))()
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        st = L.rnde_node_forward(h.ptr, x.data_ptr(), p.data_ptr(), B, t0, t1, u.data_ptr(), C.byref(nfe), sv_host,
-                                 C.byref(nsv), 1 if keep_tape else 0, C.c_void_p(stream))
+        if saveat is None:
+            u = torch.empty_like(x)
+            st = L.rnde_node_forward(h.ptr, x.data_ptr(), p.data_ptr(), B, t0, t1, u.data_ptr(), C.byref(nfe), sv_host,
+                                     C.byref(nsv), 1 if keep_tape else 0, C.c_void_p(stream))
+        else:
+            T = len(saveat)
+            u = torch.empty((B, T, D), dtype=torch.float32, device=x.device)
+            sa = (C.c_float * T)(*saveat)
+            st = L.rnde_node_forward_saveat(h.ptr, x.data_ptr(), p.data_ptr(), B, t0, t1, sa, T, u.data_ptr(), C.byref(nfe),
+                                            sv_host, C.byref(nsv), 1 if keep_tape else 0, C.c_void_p(stream))
         _lib.check(h.ptr, st)
         layer.last_nfe = int(nfe.value)
         saveval = torch.tensor(list(sv_host[:nsv.value]), dtype=torch.float32, device=x.device)
@@ -68,7 +80,7 @@ class _Solve(torch.autograd.Function):
         layer, h = ctx.layer, ctx.h
         L = _lib.lib()
         u_bar = u_bar.contiguous().to(torch.float32)
-        x_bar = torch.empty_like(u_bar)
+        x_bar = torch.empty((u_bar.shape[0], u_bar.shape[-1]), dtype=torch.float32, device=u_bar.device)
         p_bar = torch.empty(layer.P, dtype=torch.float32, device=u_bar.device)
         svb = None
         if ctx.nsv and sv_bar is not None:
@@ -79,7 +91,7 @@ class _Solve(torch.autograd.Function):
         h.busy = False
         _lib.check(h.ptr, st)
         layer.last_tspan_bar = (tsb[0], tsb[1])
-        return x_bar, p_bar, None, None, None, None
+        return x_bar, p_bar, None, None, None, None, None
 
 
 class TrackedNeuralODE:
@@ -96,8 +108,9 @@ class TrackedNeuralODE:
         self.regularize = bool(regularize)
         self.kwargs = dict(kwargs)                       # reltol, abstol, save_everystep, save_start, saveat
         self.return_multiple = bool(kwargs.get("save_everystep", False)) or ("saveat" in kwargs)  # neural_ode.jl:11
-        if self.return_multiple:
-            raise NotImplementedError("saveat / save_everystep ({R,true} methods, neural_ode.jl:79-108,:146-180): next row")
+        if bool(kwargs.get("save_everystep", False)):
+            raise NotImplementedError("save_everystep=True: the result length is data dependent; pass saveat= instead "
+                                      "(every reference call site does: latent_ode.jl:144, mnist_node.jl:121)")
         if bool(time_dep) != bool(model.time_dep):
             raise ValueError("time_dep must match the model (TDChain => True)")
         self.max_batch, self.max_attempts = int(max_batch), int(max_attempts)
@@ -141,11 +154,32 @@ class TrackedNeuralODE:
         hs.append(h)
         return h
 
+    @staticmethod
+    def _saveat_times(saveat, ts):
+        """What OrdinaryDiffEq saves for `saveat`: a vector as given (must lie in [t0, t1], increasing); a number s is the
+        range t0:s:t1 plus t1 (save_start = save_end = true for a Number)."""
+        if isinstance(saveat, (int, float)):
+            s, out, k = float(saveat), [], 0
+            if s <= 0:
+                raise ValueError("saveat step must be positive")
+            while ts[0] + k * s < ts[1]:
+                out.append(ts[0] + k * s)
+                k += 1
+            out.append(ts[1])
+            return out
+        v = [float(t) for t in (saveat.detach().cpu().reshape(-1).tolist() if torch.is_tensor(saveat) else list(saveat))]
+        if not v:
+            raise ValueError("saveat is empty")
+        if any(b <= a for a, b in zip(v, v[1:])) or v[0] < ts[0] or v[-1] > ts[1]:
+            raise ValueError("saveat must be strictly increasing inside tspan")
+        return v
+
     # -- call operator ------------------------------------------------------------------------
     def __call__(self, x, p=None, func=None, tspan=None, saveat=None):
         """(x, p = n.p; func, tspan, saveat) -> (res, nfe, sv)   [neural_ode.jl:48-54,:76,:110-119,:143]"""
-        if saveat is not None:
-            raise NotImplementedError("saveat override (neural_ode.jl:35-46): next row")
+        if saveat is not None and not self.return_multiple:
+            raise ValueError("saveat override on a layer built without saveat: the reference dispatches on the constructor "
+                             "keyword (neural_ode.jl:11), build the layer with saveat=")
         if not x.is_cuda:
             raise RuntimeError("TrackedNeuralODE runs on the MI355X only: x must be a cuda tensor (no CPU fallback)")
         p = self.p if p is None else p
@@ -161,6 +195,9 @@ class TrackedNeuralODE:
                              "(the three callbacks of experiments/mnist_node.jl:62-103)")
         self._func = func if self.regularize else None
         keep = torch.is_grad_enabled() and (x2.requires_grad or p.requires_grad)
-        u, saveval = _Solve.apply(x2, p.contiguous(), self, ts[0], ts[1], keep)
+        times = None
+        if self.return_multiple:      # update_saveat! (neural_ode.jl:35-46): a per-call override, the stored one otherwise
+            times = self._saveat_times(self.kwargs["saveat"] if saveat is None else saveat, ts)
+        u, saveval = _Solve.apply(x2, p.contiguous(), self, ts[0], ts[1], keep, times)
         sv = SavedValues(saveval) if self.regularize else None
         return u, self.last_nfe, sv

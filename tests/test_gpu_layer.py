@@ -37,6 +37,37 @@ def test_layer_call_contract_and_autograd_vs_oracle(rnde):
     assert np.abs(p.grad.cpu().numpy() - pb).max() <= 3e-3 * np.abs(pb).max()
 
 
+def test_saveat_layer_returns_3d_array_and_differentiates(rnde):
+    """{true,true} method (neural_ode.jl:146-180) + per-call saveat override (update_saveat!, :35-46)."""
+    from oracle.oracle import Oracle, arch_mnist
+    rn = rnde
+    D, Hd, B = 36, 10, 12
+    g = torch.Generator().manual_seed(1)
+    dyn = rn.MLPDynamics(D, Hd, generator=g)
+    for l in dyn.layers:
+        l.W.mul_(3.0)
+    node = rn.TrackedNeuralODE(dyn, [0.0, 1.0], True, True, "Tsit5", reltol=1e-3, abstol=1e-3, saveat=[0.0, 0.5, 1.0],
+                               max_batch=B, max_attempts=64)
+    x = torch.rand(B, D, generator=g).cuda().requires_grad_(True)
+    p = node.p.cuda().clone().requires_grad_(True)
+    u0, _, _ = node(x, p)
+    assert u0.shape == (B, 3, D)
+    assert torch.equal(u0[:, 0], x.detach())                   # save point at t0 is the input itself
+    sa = [0.1, 0.35, 0.62, 0.97]
+    u, nfe, sv = node(x, p, saveat=sa)
+    assert u.shape == (B, 4, D) and node.kwargs["saveat"] == [0.0, 0.5, 1.0]   # restored (neural_ode.jl:41-44)
+    w = torch.randn(B, 4, D, generator=g).cuda()
+    ((u * w).sum() + 40.0 * sv.saveval.sum()).backward()
+    orc = Oracle(arch_mnist(D, Hd), np.float64, reltol=1e-3, abstol=1e-3, reg_kind=1)
+    r = orc.forward(x.detach().cpu().numpy().astype(np.float64), p.detach().cpu().numpy().astype(np.float64),
+                    saveat=np.array(sa, dtype=np.float32))
+    assert r["nfe"] == nfe
+    xb, pb, _ = orc.backward(w.cpu().numpy().astype(np.float64), np.full(len(r["saveval"]), 40.0))
+    assert np.abs(u.detach().cpu().numpy() - r["u"]).max() < 3e-5
+    assert np.abs(x.grad.cpu().numpy() - xb).max() <= 3e-3 * np.abs(xb).max()
+    assert np.abs(p.grad.cpu().numpy() - pb).max() <= 3e-3 * np.abs(pb).max()
+
+
 def test_unregularised_layer_returns_nothing_for_sv(rnde):
     node, g = _model(rnde, regularize=False)
     x = torch.rand(5, 36, generator=g).cuda()

@@ -56,8 +56,16 @@ def test_node_constructor_contract(rnde):
     node = rnde.TrackedNeuralODE(dyn, [0.0, 1.0], True, True, "Tsit5", save_everystep=False, reltol=1.4e-8, abstol=1.4e-8,
                                  save_start=False)
     assert node.P == 158568 and node.return_multiple is False and node.regularize
+    multi = rnde.TrackedNeuralODE(dyn, [0.0, 1.0], True, True, "Tsit5", saveat=[0.0, 0.5, 1.0])
+    assert multi.return_multiple is True                      # neural_ode.jl:11
     with pytest.raises(NotImplementedError):
-        rnde.TrackedNeuralODE(dyn, [0.0, 1.0], True, True, "Tsit5", saveat=[0.0, 0.5, 1.0])
+        rnde.TrackedNeuralODE(dyn, [0.0, 1.0], True, True, "Tsit5", save_everystep=True)
+    assert rnde.TrackedNeuralODE._saveat_times(0.25, [0.0, 1.0]) == [0.0, 0.25, 0.5, 0.75, 1.0]
+    assert rnde.TrackedNeuralODE._saveat_times(0.4, [0.0, 1.0]) == pytest.approx([0.0, 0.4, 0.8, 1.0])
+    with pytest.raises(ValueError):
+        rnde.TrackedNeuralODE._saveat_times([0.5, 0.2], [0.0, 1.0])
+    with pytest.raises(ValueError):
+        rnde.TrackedNeuralODE._saveat_times([0.5, 1.2], [0.0, 1.0])
     with pytest.raises(ValueError):
         rnde.TrackedNeuralODE(dyn, [0.0, 1.0], False, True, "Tsit5")
     with pytest.raises(ValueError):

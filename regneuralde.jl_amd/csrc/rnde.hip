@@ -6,6 +6,7 @@
 #include "rnde_stage.h"
 #include "rnde_bstage.h"
 #include "rnde_head.h"
+#include "rnde_chain.h"
 
 #include <chrono>
 #include <cmath>
@@ -25,7 +26,8 @@ struct rnde_node {
     int Bpad_max = 0, nwg_max = 0;
     size_t lds_bytes = 0;
     // stage engine (rnde_stage.h)
-    int engine = 1;                       // 1 column-owner, 2 stage kernels
+    int engine = 1;                       // 1 column-owner, 2 stage kernels, 3 chain engine (rnde_chain.h)
+    ChainGeo cg{}; float* cfrags = nullptr; int NKD = 0; size_t chain_lds_f = 0, chain_lds_b = 0;
     int sMT = 0, sWT = 0, sR = 0, sHT = 0, sK2b = 0, sKHb = 0;
     f32x4 *spwB = nullptr, *spwD = nullptr, *spwBt = nullptr, *spwDt = nullptr;
     float* slab2 = nullptr;
@@ -60,6 +62,8 @@ struct rnde_node {
 };
 
 static std::string g_create_err;
+static rnde_status chain_bwd_run(rnde_node* h, const float* u_bar_dev, const float* saveval_bar_host, float* x_bar_dev,
+                                 float* p_bar_dev, float* tspan_bar_host, hipStream_t s);
 
 #define HIPCHK(h, call)                                                                              \
     do {                                                                                             \
@@ -89,7 +93,7 @@ static StepParams make_params(rnde_node* h, const float* x, int B, float t0, flo
     P.errpart = h->errpart; P.initpart = h->initpart; P.dbg_out = nullptr;
     P.D = h->D; P.H = h->H; P.B = B;
     P.Bpad = ((B + 15) / 16) * 16;   // both engines pad the batch to 16 columns (one tape format)
-    P.nwg = h->engine == 2 ? h->sR * (P.Bpad / 16) : P.Bpad / h->BT;
+    P.nwg = h->engine == 2 ? h->sR * (P.Bpad / 16) : (h->engine == 3 ? (P.Bpad / 16 + kCW - 1) / kCW : P.Bpad / h->BT);
     P.K4_1 = h->K4_1; P.KS1 = h->KS1; P.MT1 = h->MT1; P.K4_2 = h->K4_2; P.KS2 = h->KS2; P.MT2 = h->MT2;
     P.reltol = h->cfg.reltol; P.abstol = h->cfg.abstol; P.t0 = t0; P.t1 = t1;
     P.tape = tape; P.max_attempts = h->cfg.max_attempts;
@@ -130,16 +134,110 @@ static hipError_t launch_pack(rnde_node* h, const float* p, f32x4* dst, int whic
     return hipGetLastError();
 }
 
+// ---- chain engine host side (rnde_chain.h) --------------------------------------------------------------
+static_assert(kCMaxL == RNDE_MAX_LAYERS, "chain engine layer limit");
+static bool chain_geo(const rnde_node_config* c, ChainGeo& G) {
+    G = ChainGeo{};
+    G.n_layers = c->n_layers; G.time_dep = c->time_dep ? 1 : 0; G.pre_act = c->pre_act ? 1 : 0;
+    int po = 0, fo = 0, bo = 0, to = 0;
+    for (int l = 0; l <= c->n_layers; ++l) {
+        if (c->dims[l] < 1 || c->dims[l] > 4 * kCMaxKs) return false;
+        G.width[l] = c->dims[l]; G.nks[l] = (c->dims[l] + 3) / 4;
+    }
+    for (int l = 0; l < c->n_layers; ++l) {
+        G.act[l] = c->act[l];
+        G.poff[l] = po; po += (G.width[l] + G.time_dep) * G.width[l + 1] + G.width[l + 1];
+        G.foff[l] = fo; fo += ((G.nks[l + 1] + 3) / 4) * G.nks[l];
+        G.boff[l] = bo; bo += G.nks[l + 1] * (1 + G.time_dep);
+        G.toff[l] = to; to += ((G.nks[l] + 3) / 4) * G.nks[l + 1];
+    }
+    G.nfrag_f = fo; G.nfrag_b = bo; G.nfrag_t = to; G.nksD = G.nks[0];
+    return true;
+}
+static rnde_status chain_create(const rnde_node_config* c, rnde_node** out) {
+    ChainGeo G;
+    if (!chain_geo(c, G)) { g_create_err = "unsupported dynamics: beyond the 2-layer time-dependent form the kernels cover Dense chains of width <= 64"; return RNDE_ERR_BAD_ARG; }
+    const size_t lds_f = ((size_t)(G.nfrag_f + G.nfrag_b) * 64 + 64) * 4, lds_b = ((size_t)(G.nfrag_f + G.nfrag_b + G.nfrag_t) * 64 + 64) * 4;
+    if (lds_b > 160 * 1024) { g_create_err = "chain too large: its weight fragments must fit the 160 KB LDS of a CU"; return RNDE_ERR_BAD_ARG; }
+    if (c->regularize < RNDE_REG_NONE || c->regularize > RNDE_REG_ERR) { g_create_err = "chain engine: regularize must be RNDE_REG_NONE or RNDE_REG_ERR"; return RNDE_ERR_BAD_ARG; }
+    if (c->col_tile != 0 && c->col_tile != 64) { g_create_err = "col_tile: this network runs on the chain engine (0 or 64)"; return RNDE_ERR_BAD_ARG; }
+    if (c->max_batch < 1 || c->max_attempts < 1) { g_create_err = "max_batch / max_attempts"; return RNDE_ERR_BAD_ARG; }
+    rnde_node* h = new rnde_node();
+    h->cfg = *c; h->engine = 3; h->cg = G;
+    h->D = c->dims[0]; h->H = 0; h->P = rnde_param_count(c); h->BT = 16; h->NG = 0;
+    h->NKD = G.nksD <= 4 ? 4 : (G.nksD <= 8 ? 8 : 16);
+    h->chain_lds_f = lds_f; h->chain_lds_b = lds_b;
+    h->Bpad_max = ((c->max_batch + 15) / 16) * 16;
+    const int ntiles = h->Bpad_max / 16;
+    h->nwg_max = (ntiles + kCW - 1) / kCW;
+    if (hipSetDevice(c->device) != hipSuccess) { g_create_err = "hipSetDevice failed"; delete h; return RNDE_ERR_HIP; }
+    const size_t Ac = (size_t)ntiles * G.nksD * 64;
+    h->rec_stride = ChainRec{(long long)Ac}.total();
+    auto dm = [&](void** p, size_t bytes) { return hipMalloc(p, bytes) == hipSuccess; };
+    bool ok = true;
+    ok &= dm((void**)&h->f0, Ac * 4) && dm((void**)&h->u1, Ac * 4) && dm((void**)&h->f1, Ac * 4) && dm((void**)&h->xcopy, (size_t)h->D * h->Bpad_max * 4);
+    ok &= dm((void**)&h->pcopy, (size_t)h->P * 4) && dm((void**)&h->cfrags, (size_t)(G.nfrag_f + G.nfrag_b + G.nfrag_t) * 256);
+    ok &= dm((void**)&h->ctl, 2 * sizeof(StepState)) && dm((void**)&h->ctl_final, sizeof(StepState));
+    ok &= dm((void**)&h->meta, (size_t)(c->max_attempts + 1) * sizeof(StepMeta)) && dm((void**)&h->initrec, sizeof(InitRec));
+    ok &= dm((void**)&h->errpart, (size_t)6 * h->nwg_max * 4) && dm((void**)&h->initpart, (size_t)3 * h->nwg_max * 4);
+    h->arena_recs = 2;
+    ok &= dm((void**)&h->arena, (size_t)h->arena_recs * h->rec_stride * 4);
+    ok &= hipHostMalloc((void**)&h->h_ctl, sizeof(StepState)) == hipSuccess;
+    ok &= hipHostMalloc((void**)&h->h_meta, (size_t)(c->max_attempts + 1) * sizeof(StepMeta)) == hipSuccess;
+    ok &= hipHostMalloc((void**)&h->h_init, sizeof(InitRec)) == hipSuccess;
+    ok &= hipHostMalloc((void**)&h->h_scal, 64 * sizeof(float)) == hipSuccess;
+    if (!ok) { g_create_err = "device allocation failed"; rnde_node_destroy(h); return RNDE_ERR_HIP; }
+    hipMemset(h->initrec, 0, sizeof(InitRec));
+    h->predicted = 12;
+    *out = h;
+    return RNDE_OK;
+}
+static ChainParams make_chain_params(rnde_node* h, const StepParams& P) {
+    ChainParams Q{};
+    Q.F = P; Q.G = h->cg; Q.frags = h->cfrags; Q.ntiles = P.Bpad / 16;
+    return Q;
+}
+template <int NKD, int MODE>
+static hipError_t launch_chain_t(rnde_node* h, const ChainParams& Q, int n, float* u_out, hipStream_t s) {
+    auto kern = rnde_chain_kernel<NKD, MODE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(Q.F.nwg), dim3(64 * kCW), MODE == CM_FINISH ? 0 : h->chain_lds_f, s, Q, n, u_out);
+    return hipGetLastError();
+}
+template <int MODE>
+static hipError_t launch_chain(rnde_node* h, const ChainParams& Q, int n, float* u_out, hipStream_t s) {
+    switch (h->NKD) {
+        case 4: return launch_chain_t<4, MODE>(h, Q, n, u_out, s);
+        case 8: return launch_chain_t<8, MODE>(h, Q, n, u_out, s);
+        default: return launch_chain_t<16, MODE>(h, Q, n, u_out, s);
+    }
+}
+static rnde_status chain_pack(rnde_node* h, const float* p_dev, hipStream_t s) {
+    const long long total = (long long)(h->cg.nfrag_f + h->cg.nfrag_b + h->cg.nfrag_t) * 64;
+    hipLaunchKernelGGL(rnde_chain_pack_kernel, dim3((int)std::min<long long>((total + 255) / 256, 512)), dim3(256), 0, s, p_dev, h->cfrags, h->cg);
+    HIPCHK(h, hipGetLastError());
+    return RNDE_OK;
+}
+static hipError_t chain_convert(const float* src, float* dst, int D, int B, int ntiles, int nksD, int to_caller, hipStream_t s) {
+    const long long total = (long long)ntiles * nksD * 64;
+    hipLaunchKernelGGL(rnde_chain_convert_kernel, dim3((int)std::min<long long>((total + 255) / 256, 512)), dim3(256), 0, s, src, dst, D, B, ntiles, nksD, to_caller);
+    return hipGetLastError();
+}
+
 extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** out) {
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= c->device) { g_create_err = "no HIP device"; return RNDE_ERR_NO_DEVICE; }
-    if (c->n_layers != 2 || !c->time_dep || c->pre_act || c->act[0] != RNDE_ACT_TANH || c->dims[0] != c->dims[2] ||
-        c->solver != RNDE_SOLVER_TSIT5) {
-        g_create_err = "unsupported dynamics: the gfx950 kernels cover the 2-layer time-dependent Dense chain "
-                       "(experiments/mnist_node.jl:41-54, test/test_node.jl:4) with Tsit5";
-        return RNDE_ERR_BAD_ARG;
+    if (c->solver != RNDE_SOLVER_TSIT5 || c->n_layers < 1 || c->n_layers > RNDE_MAX_LAYERS || c->dims[0] != c->dims[c->n_layers]) {
+        g_create_err = "unsupported configuration: Tsit5 over a Dense chain with dims[0] == dims[n_layers]"; return RNDE_ERR_BAD_ARG;
     }
+    const bool mnist_form = c->n_layers == 2 && c->time_dep && !c->pre_act && c->act[0] == RNDE_ACT_TANH;
+    if (c->col_tile == 64 || !mnist_form) return chain_create(c, out);   // small-width chains (latent_ode.jl:113-124): rnde_chain.h
     if (c->regularize < RNDE_REG_NONE || c->regularize > RNDE_REG_ERR_STIFF) { g_create_err = "regularize: unknown value"; return RNDE_ERR_BAD_ARG; }
     if (c->regularize >= RNDE_REG_STIFF && (c->col_tile == 4 || c->col_tile == 8)) {
         g_create_err = "the stiffness-estimate regularisers run on the stage engine only (col_tile 0 or 16)";
@@ -211,6 +309,7 @@ extern "C" void rnde_node_destroy(rnde_node* h) {
     bwd_free(h->bw);
     if (h->head_ws) hipFree(h->head_ws);
     if (h->sv_t_dev) hipFree(h->sv_t_dev);
+    if (h->cfrags) hipFree(h->cfrags);
     for (hipEvent_t e : h->wevents) hipEventDestroy(e);
     if (h->wstream) hipStreamDestroy(h->wstream);
     if (h->h_ctl) hipHostFree(h->h_ctl);
@@ -297,7 +396,7 @@ static rnde_status forward_impl(rnde_node* h, const float* x_dev, const float* p
     if (!h) return RNDE_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (n_saveat > 0) {
-        if (h->engine != 2) { h->err = "saveat runs on the stage engine only (col_tile 0 or 16)"; return RNDE_ERR_BAD_ARG; }
+        if (h->engine == 1) { h->err = "saveat is not available on the column-owner engine (col_tile 4/8)"; return RNDE_ERR_BAD_ARG; }
         for (int i = 0; i < n_saveat; ++i)
             if (!(saveat_host[i] >= t0 && saveat_host[i] <= t1) || (i > 0 && !(saveat_host[i] > saveat_host[i - 1]))) {
                 h->err = "saveat must be increasing and inside [t0, t1]"; return RNDE_ERR_BAD_ARG;
@@ -326,10 +425,16 @@ static rnde_status forward_impl(rnde_node* h, const float* x_dev, const float* p
     StepParams P = make_params(h, x_dev, B, t0, t1, keep_tape ? 1 : 0);
     P.sv_t = n_saveat > 0 ? h->sv_t_dev : nullptr; P.nsave = n_saveat; P.sv_out = sv_out_dev;
     h->B = B; h->Bpad = P.Bpad; h->nwg = P.nwg; h->t0 = t0; h->t1 = t1;
-    rnde_status st = pack_weights(h, p_dev, keep_tape != 0, s);   // (column-owner packs: also used by the reverse sweep)
+    rnde_status st = h->engine == 3 ? chain_pack(h, keep_tape ? h->pcopy : p_dev, s)
+                                    : pack_weights(h, p_dev, keep_tape != 0, s);   // (column-owner packs: also used by the reverse sweep)
     if (st != RNDE_OK) return st;
     StageParams SQ{};
-    if (h->engine == 2) {
+    ChainParams CQ{};
+    if (h->engine == 3) {
+        CQ = make_chain_params(h, P);
+        HIPCHK(h, launch_chain<CM_INIT_A>(h, CQ, 0, nullptr, s));
+        HIPCHK(h, launch_chain<CM_INIT_B>(h, CQ, 0, nullptr, s));
+    } else if (h->engine == 2) {
         st = stage_pack_weights(h, keep_tape ? h->pcopy : p_dev, s);
         if (st != RNDE_OK) return st;
         SQ = make_stage_params(h, P, keep_tape ? h->pcopy : p_dev);
@@ -346,11 +451,13 @@ static rnde_status forward_impl(rnde_node* h, const float* x_dev, const float* p
     const int cap = h->cfg.max_attempts;
     while (true) {
         for (int i = 0; i < chunk && launched < cap; ++i) {
-            if (h->engine == 2) HIPCHK(h, stage_attempt(h, SQ, launched, s));
+            if (h->engine == 3) HIPCHK(h, launch_chain<CM_STEP>(h, CQ, launched, nullptr, s));
+            else if (h->engine == 2) HIPCHK(h, stage_attempt(h, SQ, launched, s));
             else HIPCHK(h, launch_step<MODE_STEP>(h, P, launched, s));
             ++launched;
         }
-        if (h->engine == 2) { hipLaunchKernelGGL(rnde_stage_finish_kernel, dim3(64), dim3(256), 0, s, SQ, launched, u_out_dev); HIPCHK(h, hipGetLastError()); }
+        if (h->engine == 3) HIPCHK(h, launch_chain<CM_FINISH>(h, CQ, launched, u_out_dev, s));
+        else if (h->engine == 2) { hipLaunchKernelGGL(rnde_stage_finish_kernel, dim3(64), dim3(256), 0, s, SQ, launched, u_out_dev); HIPCHK(h, hipGetLastError()); }
         else HIPCHK(h, launch_finish(h, P, launched, u_out_dev, s));
         HIPCHK(h, hipMemcpyAsync(h->h_ctl, h->ctl_final, sizeof(StepState), hipMemcpyDeviceToHost, s));
         HIPCHK(h, hipStreamSynchronize(s));
@@ -419,6 +526,7 @@ extern "C" rnde_status rnde_node_backward(rnde_node* h, const float* u_bar_dev, 
                                           float* x_bar_dev, float* p_bar_dev, float* tspan_bar_host, void* stream) {
     if (!h) return RNDE_ERR_BAD_ARG;
     if (!h->have_tape) { h->err = "no recorded forward"; return RNDE_ERR_NO_TAPE; }
+    if (h->engine == 3) return chain_bwd_run(h, u_bar_dev, saveval_bar_host, x_bar_dev, p_bar_dev, tspan_bar_host, (hipStream_t)stream);
     return bwd_run(h, u_bar_dev, saveval_bar_host, x_bar_dev, p_bar_dev, tspan_bar_host, (hipStream_t)stream);
 }
 
@@ -456,6 +564,13 @@ extern "C" rnde_status rnde_debug_feval(rnde_node* h, const float* u_dev, const 
     hipStream_t s = (hipStream_t)stream;
     StepParams P = make_params(h, u_dev, B, 0.f, 1.f, 0);
     P.forced = 1; P.forced_t = t; P.dbg_out = out_dev;
+    if (h->engine == 3) {
+        rnde_status st3 = chain_pack(h, p_dev, s);
+        if (st3 != RNDE_OK) return st3;
+        HIPCHK(h, launch_chain<CM_FEVAL>(h, make_chain_params(h, P), 0, nullptr, s));
+        HIPCHK(h, hipStreamSynchronize(s));
+        return RNDE_OK;
+    }
     if (h->engine == 2) {
         rnde_status st2 = stage_pack_weights(h, p_dev, s);
         if (st2 != RNDE_OK) return st2;
@@ -480,6 +595,23 @@ extern "C" rnde_status rnde_debug_attempt(rnde_node* h, const float* uprev_dev, 
     h->have_tape = false;
     StepParams P = make_params(h, uprev_dev, B, 0.f, 1.f, 0);
     P.forced = 1; P.forced_t = t; P.forced_dt = dt;
+    if (h->engine == 3) {
+        rnde_status st3 = chain_pack(h, p_dev, s);
+        if (st3 != RNDE_OK) return st3;
+        const ChainParams CQ = make_chain_params(h, P);
+        const int nks = h->cg.nksD;
+        HIPCHK(h, chain_convert(k1_dev, h->f0, h->D, B, CQ.ntiles, nks, 0, s));
+        HIPCHK(h, launch_chain<CM_STEP>(h, CQ, 0, nullptr, s));
+        HIPCHK(h, launch_chain<CM_FINISH>(h, CQ, 1, nullptr, s));
+        HIPCHK(h, hipMemcpyAsync(h->h_ctl, h->ctl_final, sizeof(StepState), hipMemcpyDeviceToHost, s));
+        const ChainRec CL{(long long)CQ.ntiles * nks * 64};
+        for (int sidx = 2; sidx <= 7; ++sidx)
+            HIPCHK(h, chain_convert(h->arena + CL.k(sidx), k_out_dev + (size_t)(sidx - 2) * h->D * B, h->D, B, CQ.ntiles, nks, 1, s));
+        HIPCHK(h, chain_convert(h->arena + CL.unew(), unew_out_dev, h->D, B, CQ.ntiles, nks, 1, s));
+        HIPCHK(h, hipStreamSynchronize(s));
+        if (eest_out) *eest_out = h->h_ctl->last_eest;
+        return RNDE_OK;
+    }
     rnde_status st = pack_weights(h, p_dev, false, s);
     if (st != RNDE_OK) return st;
     // k1 goes to the f0 buffer (column stride D in both layouts)
@@ -514,10 +646,15 @@ extern "C" rnde_status rnde_bench_attempt(rnde_node* h, const float* x_dev, cons
     h->have_tape = false;
     StepParams P = make_params(h, x_dev, B, 0.f, 1.f, 0);
     P.forced = 1; P.forced_t = 0.f; P.forced_dt = 0.05f;
-    rnde_status st = pack_weights(h, p_dev, false, s);
+    rnde_status st = h->engine == 3 ? chain_pack(h, p_dev, s) : pack_weights(h, p_dev, false, s);
     if (st != RNDE_OK) return st;
     StageParams SQ{};
-    if (h->engine == 2) {
+    ChainParams CQ{};
+    if (h->engine == 3) {
+        CQ = make_chain_params(h, P);
+        HIPCHK(h, launch_chain<CM_INIT_A>(h, CQ, 0, nullptr, s));   // k1 = f(x, 0) into f0
+        for (int i = 0; i < 3; ++i) HIPCHK(h, launch_chain<CM_STEP>(h, CQ, 0, nullptr, s));
+    } else if (h->engine == 2) {
         st = stage_pack_weights(h, p_dev, s);
         if (st != RNDE_OK) return st;
         SQ = make_stage_params(h, P, p_dev);
@@ -533,7 +670,8 @@ extern "C" rnde_status rnde_bench_attempt(rnde_node* h, const float* x_dev, cons
     HIPCHK(h, hipEventRecord(e0, s));
     const auto host_t0 = std::chrono::steady_clock::now();
     for (int i = 0; i < iters; ++i) {
-        if (h->engine == 2) HIPCHK(h, stage_attempt(h, SQ, 0, s));
+        if (h->engine == 3) HIPCHK(h, launch_chain<CM_STEP>(h, CQ, 0, nullptr, s));
+        else if (h->engine == 2) HIPCHK(h, stage_attempt(h, SQ, 0, s));
         else HIPCHK(h, launch_step<MODE_STEP>(h, P, 0, s));
     }
     const double host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - host_t0).count();
@@ -822,4 +960,10 @@ extern "C" rnde_status rnde_classifier_head(rnde_node* h, const float* u_dev, co
                        (const float*)delta, (const float*)ce_col, h->D, n_classes, B, p3_bar_dev, ce_out_dev);
     HIPCHK(h, hipGetLastError());
     return RNDE_OK;
+}
+
+// ---- chain engine reverse pass ----------------------------------------------------------------------------
+static rnde_status chain_bwd_run(rnde_node* h, const float*, const float*, float*, float*, float*, hipStream_t) {
+    h->err = "chain engine: reverse pass not built yet";
+    return RNDE_ERR_BAD_ARG;
 }

@@ -28,7 +28,7 @@ def _cfg(arch, B, **kw):
     from tests.util import make_cfg
     dims = [arch.dims[i] for i in range(arch.n_layers + 1)]
     acts = ["tanh" if arch.act[i] else "identity" for i in range(arch.n_layers)]
-    return make_cfg(dims, acts, B, **kw)
+    return make_cfg(dims, acts, B, time_dep=arch.time_dep, pre_act=arch.pre_act, **kw)
 
 
 @pytest.mark.parametrize("kind,B,col_tile", [("mnist", 16, 8), ("mnist", 13, 8), ("mnist", 8, 4), ("test_node", 1, 8),

@@ -10,15 +10,15 @@ from oracle.oracle import Oracle, arch_mnist, arch_test_node, glorot_params, mak
 
 
 def make_cfg(dims, acts, max_batch, reltol=1.4e-8, abstol=1.4e-8, regularize=1, max_attempts=128, col_tile=0,
-             cb_save_start=1, track_ctrl=1, track_initdt=1):
+             cb_save_start=1, track_ctrl=1, track_initdt=1, time_dep=1, pre_act=0):
     cfg = _lib.NodeConfig()
     cfg.n_layers = len(acts)
     for i, d in enumerate(dims):
         cfg.dims[i] = d
     for i, a in enumerate(acts):
         cfg.act[i] = {"identity": 0, "tanh": 1}[a]
-    cfg.time_dep = 1
-    cfg.pre_act = 0
+    cfg.time_dep = int(time_dep)
+    cfg.pre_act = int(pre_act)
     cfg.max_batch = max_batch
     cfg.solver = 0
     cfg.reltol, cfg.abstol = reltol, abstol

@@ -7,6 +7,7 @@
 #include "rnde_bstage.h"
 #include "rnde_head.h"
 #include "rnde_chain.h"
+#include "rnde_bchain.h"
 
 #include <chrono>
 #include <cmath>
@@ -28,6 +29,7 @@ struct rnde_node {
     // stage engine (rnde_stage.h)
     int engine = 1;                       // 1 column-owner, 2 stage kernels, 3 chain engine (rnde_chain.h)
     ChainGeo cg{}; float* cfrags = nullptr; int NKD = 0; size_t chain_lds_f = 0, chain_lds_b = 0;
+    float* cslab = nullptr; size_t cslab_floats = 0; float* ev_t = nullptr; float* h_ev_t = nullptr;   // chain reverse: (H, Z) dump, evaluation times
     int sMT = 0, sWT = 0, sR = 0, sHT = 0, sK2b = 0, sKHb = 0;
     f32x4 *spwB = nullptr, *spwD = nullptr, *spwBt = nullptr, *spwDt = nullptr;
     float* slab2 = nullptr;
@@ -310,6 +312,9 @@ extern "C" void rnde_node_destroy(rnde_node* h) {
     if (h->head_ws) hipFree(h->head_ws);
     if (h->sv_t_dev) hipFree(h->sv_t_dev);
     if (h->cfrags) hipFree(h->cfrags);
+    if (h->cslab) hipFree(h->cslab);
+    if (h->ev_t) hipFree(h->ev_t);
+    if (h->h_ev_t) hipHostFree(h->h_ev_t);
     for (hipEvent_t e : h->wevents) hipEventDestroy(e);
     if (h->wstream) hipStreamDestroy(h->wstream);
     if (h->h_ctl) hipHostFree(h->h_ctl);
@@ -963,7 +968,113 @@ extern "C" rnde_status rnde_classifier_head(rnde_node* h, const float* u_dev, co
 }
 
 // ---- chain engine reverse pass ----------------------------------------------------------------------------
-static rnde_status chain_bwd_run(rnde_node* h, const float*, const float*, float*, float*, float*, hipStream_t) {
-    h->err = "chain engine: reverse pass not built yet";
-    return RNDE_ERR_BAD_ARG;
+template <int NKD>
+static hipError_t launch_bchain_t(rnde_node* h, const BChainParams& Q, const std::vector<int>& sv_lo, const std::vector<int>& sv_hi, hipStream_t s) {
+    const size_t lds = h->chain_lds_b;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)rnde_bchain_kernel<NKD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rnde_bchain_init_kernel<NKD, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rnde_bchain_init_kernel<NKD, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const dim3 grid(Q.B.F.nwg), blk(64 * kCW);
+    for (int n = Q.B.n_att - 1; n >= 0; --n) hipLaunchKernelGGL((rnde_bchain_kernel<NKD>), grid, blk, lds, s, Q, n, h->h_meta[n], sv_lo[n], sv_hi[n]);
+    hipLaunchKernelGGL((rnde_bchain_init_kernel<NKD, 1>), grid, blk, lds, s, Q);
+    hipLaunchKernelGGL((rnde_bchain_init_kernel<NKD, 2>), grid, blk, lds, s, Q);
+    hipLaunchKernelGGL(rnde_bfin_kernel, dim3(1), dim3(64), 0, s, Q.B);
+    return hipGetLastError();
+}
+
+static rnde_status chain_bwd_run(rnde_node* h, const float* u_bar_dev, const float* saveval_bar_host, float* x_bar_dev,
+                                 float* p_bar_dev, float* tspan_bar_host, hipStream_t s) {
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    BwdBuffers& b = h->bw;
+    const ChainGeo& G = h->cg;
+    const int cap = h->cfg.max_attempts, ntiles_max = h->Bpad_max / 16;
+    if (!b.ready) {
+        const size_t Ac = (size_t)ntiles_max * G.nksD * 64;
+        HIPCHK(h, hipMalloc((void**)&b.U, Ac * 4)); HIPCHK(h, hipMalloc((void**)&b.K1, Ac * 4)); HIPCHK(h, hipMalloc((void**)&b.UB1, Ac * 4));
+        HIPCHK(h, hipMalloc((void**)&b.svb_att, (size_t)cap * 4));
+        HIPCHK(h, hipMalloc((void**)&b.bstate, 2 * sizeof(BState))); HIPCHK(h, hipMalloc((void**)&b.ibstate, 2 * sizeof(IBState)));
+        HIPCHK(h, hipMalloc((void**)&b.bpart, (size_t)2 * h->nwg_max * 4 * 4)); HIPCHK(h, hipMalloc((void**)&b.ipart, (size_t)2 * h->nwg_max * 4 * 4));
+        HIPCHK(h, hipMalloc((void**)&b.tspan_out, 2 * 4));
+        HIPCHK(h, hipHostMalloc((void**)&b.h_svb, (size_t)cap * 4));
+        HIPCHK(h, hipMalloc((void**)&b.slab, (size_t)96 * h->P * 4)); HIPCHK(h, hipMalloc((void**)&b.slab_r, (size_t)16 * h->P * 4));
+        HIPCHK(h, hipMalloc((void**)&h->ev_t, ((size_t)6 * cap + 2) * 4)); HIPCHK(h, hipHostMalloc((void**)&h->h_ev_t, ((size_t)6 * cap + 2) * 4));
+        b.ready = true;
+    }
+    const int n_att = h->n_att, n_evals = 6 * n_att + 2;
+    for (int i = 0; i < n_att; ++i)
+        b.h_svb[i] = (saveval_bar_host && h->sv_index[i] >= 0) ? saveval_bar_host[h->sv_index[i]] : 0.f;
+    HIPCHK(h, hipMemcpyAsync(b.svb_att, b.h_svb, (size_t)std::max(1, n_att) * 4, hipMemcpyHostToDevice, s));
+    BChainParams Q{};
+    Q.B.F = make_params(h, h->xcopy, h->B, h->t0, h->t1, 1);
+    Q.B.U = b.U; Q.B.K1 = b.K1; Q.B.UB1 = b.UB1; Q.B.svb_att = b.svb_att;
+    Q.B.bstate = b.bstate; Q.B.ibstate = b.ibstate; Q.B.bpart = b.bpart; Q.B.ipart = b.ipart;
+    Q.B.ubar = u_bar_dev; Q.B.xbar = x_bar_dev; Q.B.tspan_out = b.tspan_out;
+    Q.B.n_att = n_att; Q.B.track_ctrl = h->cfg.track_ctrl; Q.B.track_initdt = h->cfg.track_initdt; Q.B.reg_kind = h->cfg.regularize;
+    Q.B.bpart_n = Q.B.F.nwg;
+    Q.B.sv_T = (int)h->saveat.size();
+    Q.B.sv_ubar0 = (!h->saveat.empty() && h->saveat[0] == h->t0) ? u_bar_dev : nullptr;
+    Q.G = G; Q.frags = h->cfrags; Q.ntiles = Q.B.F.Bpad / 16;
+    int row = 0;
+    for (int l = 0; l < G.n_layers; ++l) { Q.hrow[l] = row; row += G.nks[l]; Q.zrow[l] = row; row += G.nks[l + 1]; }
+    Q.RS = row; Q.ev_stride = (long long)Q.ntiles * row * 64;
+    Q.sv_t = h->saveat.empty() ? nullptr : h->sv_t_dev; Q.sv_ubar = u_bar_dev; Q.nsave = (int)h->saveat.size();
+    const size_t need = (size_t)n_evals * Q.ev_stride;
+    if (h->cslab_floats < need) {
+        if (h->cslab) hipFree(h->cslab);
+        h->cslab = nullptr; h->cslab_floats = 0;
+        HIPCHK(h, hipMalloc((void**)&h->cslab, need * 4));
+        h->cslab_floats = need;
+    }
+    Q.slab = h->cslab;
+    // evaluation times (time column of TDChain layers) and the save indices each accepted attempt covers
+    std::vector<int> sv_lo(std::max(1, n_att), 0), sv_hi(std::max(1, n_att), 0);
+    {
+        int ns = (!h->saveat.empty() && h->saveat[0] == h->t0) ? 1 : 0;
+        for (int n = 0; n < n_att; ++n) {
+            const StepMeta& m = h->h_meta[n];
+            for (int sidx = 2; sidx <= 7; ++sidx) h->h_ev_t[6 * n + sidx - 2] = m.t + tsC(sidx - 1) * m.dt;
+            sv_lo[n] = ns;
+            if (m.flags & F_ACCEPT) {
+                const float tnew = m.t + m.dt;
+                while (ns < (int)h->saveat.size() && h->saveat[ns] <= tnew) ++ns;
+            }
+            sv_hi[n] = ns;
+        }
+        h->h_ev_t[6 * n_att] = h->t0; h->h_ev_t[6 * n_att + 1] = h->t0 + h->h_init->dt0;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->ev_t, h->h_ev_t, (size_t)n_evals * 4, hipMemcpyHostToDevice, s));
+    hipError_t e;
+    switch (h->NKD) {
+        case 4: e = launch_bchain_t<4>(h, Q, sv_lo, sv_hi, s); break;
+        case 8: e = launch_bchain_t<8>(h, Q, sv_lo, sv_hi, s); break;
+        default: e = launch_bchain_t<16>(h, Q, sv_lo, sv_hi, s); break;
+    }
+    HIPCHK(h, e);
+    // parameter gradients of all layers over all evaluations
+    const int n_units = n_evals * Q.ntiles;
+    const int chunks = std::max(1, std::min(96, n_units / 8));
+    const int per_chunk = (n_units + chunks - 1) / chunks;
+    hipLaunchKernelGGL(rnde_chain_wgrad_kernel, dim3(G.n_layers, chunks), dim3(64 * kCW), 0, s, Q, (const float*)h->ev_t, n_units, per_chunk, b.slab, h->P);
+    HIPCHK(h, hipGetLastError());
+    {
+        const long long len = h->P;
+        const int grid = (int)std::min<long long>((len + 255) / 256, 2048);
+        if (chunks <= 16) hipLaunchKernelGGL(rnde_wgrad_reduce, dim3(grid, 1), dim3(256), 0, s, (const float*)b.slab, chunks, chunks, len, p_bar_dev);
+        else {
+            const int per_group = (chunks + 15) / 16, groups = (chunks + per_group - 1) / per_group;
+            hipLaunchKernelGGL(rnde_wgrad_reduce, dim3(grid, groups), dim3(256), 0, s, (const float*)b.slab, chunks, per_group, len, b.slab_r);
+            hipLaunchKernelGGL(rnde_wgrad_reduce, dim3(grid, 1), dim3(256), 0, s, (const float*)b.slab_r, groups, groups, len, p_bar_dev);
+        }
+        HIPCHK(h, hipGetLastError());
+    }
+    HIPCHK(h, hipMemcpyAsync(h->h_scal, b.tspan_out, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    if (tspan_bar_host) { tspan_bar_host[0] = h->h_scal[0]; tspan_bar_host[1] = h->h_scal[1]; }
+    h->have_tape = false;
+    return RNDE_OK;
 }

@@ -44,14 +44,17 @@ struct ChainParams {
     int ntiles;            // Bpad / 16
 };
 
-// record layout (fragment order arrays of ntiles * nksD * 64 floats): k2..k7 | unew | uprev copy | k1 copy
+// record layout (fragment order arrays of ntiles * nksD * 64 floats): k2..k7 | unew | uprev copy | k1 copy | g2..g6
+// (the stage inputs g_s are taped rather than recomputed so that the reverse pass linearises exactly the values the
+//  forward evaluated)
 struct ChainRec {
     long long A;
     __host__ __device__ long long k(int s) const { return (long long)(s - 2) * A; }   // s = 2..7
     __host__ __device__ long long unew() const { return 6 * A; }
     __host__ __device__ long long upc() const { return 7 * A; }
     __host__ __device__ long long k1c() const { return 8 * A; }
-    __host__ __device__ long long total() const { return 9 * A; }
+    __host__ __device__ long long g(int s) const { return (long long)(9 + s - 2) * A; }   // s = 2..6
+    __host__ __device__ long long total() const { return 14 * A; }
 };
 
 
@@ -347,6 +350,9 @@ __global__ __launch_bounds__(64 * kCW) void rnde_chain_kernel(const ChainParams 
                     if (s == 6) {
 #pragma unroll
                         for (int q = 0; q < NKD; ++q) { un[q] = gq[q]; if (q < nksD) R[L.unew() + fo + q * 64] = gq[q]; }
+                    } else if (P.tape) {
+#pragma unroll
+                        for (int q = 0; q < NKD; ++q) if (q < nksD) R[L.g(s + 1) + fo + q * 64] = gq[q];
                     }
                     chain_eval<NKD>(G, FR, BF, t + kTsC[s] * dt, gq, kv, lane);
                     const float bts = kTsBt[s];

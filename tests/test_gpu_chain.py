@@ -111,3 +111,73 @@ def test_chain_config4_statistics():
     print(f"attempts: device {n_dev}, oracle f32 {n32}, oracle f64 {n64}")
     assert abs(n_dev - n32) <= 0.25 * n32 + 1
     assert np.abs(got["u"] - ref64["u"]).max() <= 1e-5 * max(1.0, np.abs(ref64["u"]).max())
+
+
+@pytest.mark.parametrize("kind,B,tol,scale,ws", [("latent", 4, 1e-3, 1.5, 0.0), ("latent", 37, 1e-3, 1.5, 30.0), ("chain3", 19, 1e-3, 2.0, 30.0),
+                                                  ("wide", 16, 1e-3, 1.5, 30.0), ("one", 3, 1e-3, 3.0, 30.0), ("test_node", 5, 1e-3, 3.0, 30.0),
+                                                  ("small", 70, 1e-3, 4.0, 30.0)])
+def test_chain_reverse_matches_oracle(kind, B, tol, scale, ws):
+    """x-bar, p-bar, tspan-bar of the chain engine against the fp64 oracle (same accept/reject sequence); tolerance 2e-3 of the
+    largest entry plus the fp32-vs-fp64 oracle spread (conditioning of the case)."""
+    from tests.util import Node, Oracle, rel_err
+    arch, p, x = _setup(kind, B, 3, scale)
+    o64 = Oracle(arch, np.float64, reltol=tol, abstol=tol, reg_kind=1)
+    o32 = Oracle(arch, np.float32, reltol=tol, abstol=tol, reg_kind=1)
+    r64, r32 = o64.forward(x, p), o32.forward(x, p)
+    node = Node(_cfg(arch, B, reltol=tol, abstol=tol))
+    got = node.forward(x, p, keep_tape=True)
+    assert got["nfe"] == r64["nfe"] == r32["nfe"]
+    rng = np.random.default_rng(11)
+    ubar = rng.standard_normal(x.shape).astype(np.float32)
+    svbar = np.full(len(got["saveval"]), ws, dtype=np.float32)
+    gx, gp, gt = node.backward(ubar, svbar)
+    x64, p64, t64 = o64.backward(ubar.astype(np.float64), svbar.astype(np.float64))
+    x32, p32, t32 = o32.backward(ubar, svbar)
+    cx, cp = rel_err(x32, x64), rel_err(p32, p64)
+    print(f"{kind}: x-bar {rel_err(gx, x64):.2e} (oracle spread {cx:.2e})  p-bar {rel_err(gp, p64):.2e} ({cp:.2e})  tspan {gt} vs {t64}")
+    assert rel_err(gx, x64) <= 2e-3 + 4 * cx
+    assert rel_err(gp, p64) <= 2e-3 + 4 * cp
+    assert np.abs(gt - t64).max() <= (2e-3 + 4 * max(cx, cp)) * max(1.0, np.abs(t64).max())
+
+
+@pytest.mark.parametrize("kind,B,tol,scale,saveat", [("latent", 4, 1e-3, 1.5, np.linspace(0, 1, 49)), ("latent", 70, 1e-4, 1.5, np.array([0.1, 0.5, 0.9])),
+                                                      ("chain3", 19, 1e-3, 2.0, np.array([0.0, 0.25, 1.0]))])
+def test_chain_saveat_reverse_matches_oracle(kind, B, tol, scale, saveat):
+    from tests.util import Node, Oracle, rel_err
+    arch, p, x = _setup(kind, B, 5, scale)
+    sa = saveat.astype(np.float32)
+    o64 = Oracle(arch, np.float64, reltol=tol, abstol=tol, reg_kind=1)
+    o32 = Oracle(arch, np.float32, reltol=tol, abstol=tol, reg_kind=1)
+    r64, r32 = o64.forward(x, p, saveat=sa), o32.forward(x, p, saveat=sa)
+    node = Node(_cfg(arch, B, reltol=tol, abstol=tol))
+    got = node.forward_saveat(x, p, sa, keep_tape=True)
+    assert got["nfe"] == r64["nfe"] == r32["nfe"]
+    rng = np.random.default_rng(12)
+    ubar = rng.standard_normal(r64["u"].shape).astype(np.float32)
+    svbar = (10 * rng.standard_normal(len(got["saveval"]))).astype(np.float32)
+    gx, gp, gt = node.backward(ubar, svbar)
+    x64, p64, t64 = o64.backward(ubar.astype(np.float64), svbar.astype(np.float64))
+    x32, p32, t32 = o32.backward(ubar, svbar)
+    cx, cp = rel_err(x32, x64), rel_err(p32, p64)
+    print(f"{kind}: x-bar {rel_err(gx, x64):.2e} ({cx:.2e})  p-bar {rel_err(gp, p64):.2e} ({cp:.2e})  tspan {gt} vs {t64}")
+    assert rel_err(gx, x64) <= 2e-3 + 4 * cx
+    assert rel_err(gp, p64) <= 2e-3 + 4 * cp
+    assert np.abs(gt - t64).max() <= (2e-3 + 4 * max(cx, cp)) * max(1.0, np.abs(t64).max())
+
+
+def test_chain_config4_reverse():
+    """Config 4 at full size, tol 1.4e-8: both solves are converged to ~1e-7, so the cotangents of the saved states agree with
+    the fp64 oracle's even though the step sequences differ (fp32 noise floor); 1e-3 of the largest entry."""
+    from tests.util import Node, Oracle, rel_err
+    arch, p, x = _setup("latent", 512, 7, 1.0)
+    sa = np.linspace(0, 1, 49).astype(np.float32)
+    o64 = Oracle(arch, np.float64, reltol=1.4e-8, abstol=1.4e-8, reg_kind=1)
+    r64 = o64.forward(x, p, saveat=sa)
+    node = Node(_cfg(arch, 512, max_attempts=512))
+    got = node.forward_saveat(x, p, sa, keep_tape=True)
+    rng = np.random.default_rng(13)
+    ubar = rng.standard_normal(r64["u"].shape).astype(np.float32)
+    gx, gp, gt = node.backward(ubar, None)
+    x64, p64, t64 = o64.backward(ubar.astype(np.float64), None)
+    print(f"x-bar {rel_err(gx, x64):.2e}  p-bar {rel_err(gp, p64):.2e}  tspan {gt} vs {t64}")
+    assert rel_err(gx, x64) <= 1e-3 and rel_err(gp, p64) <= 1e-3

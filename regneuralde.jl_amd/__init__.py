@@ -4,7 +4,7 @@ Only the hot path lives here: csrc/ (HIP kernels + C ABI, built into lib/librnde
 host-side mirror of the reference's layer interface.  See DESIGN.md and INTEGRATION.md.
 """
 from . import _lib, build  # noqa: F401
-from .layers import Chain, Dense, MLPDynamics, TDChain, destructure  # noqa: F401
+from .layers import Chain, Dense, LatentGenDynamics, MLPDynamics, TDChain, destructure  # noqa: F401
 from .node import SavedValues, TrackedNeuralODE  # noqa: F401
 from .classifier import ClassifierNODE, FluxOptimiser, accuracy, fused_loss_and_grad, REGULARISERS, lambda_schedule, logitcrossentropy, loss_function, sample_tspan_ubound  # noqa: F401
 from .dataparallel import GradientAllReducer, shard_columns  # noqa: F401

@@ -28,7 +28,7 @@ struct rnde_node {
     size_t lds_bytes = 0;
     // stage engine (rnde_stage.h)
     int engine = 1;                       // 1 column-owner, 2 stage kernels, 3 chain engine (rnde_chain.h)
-    ChainGeo cg{}; float* cfrags = nullptr; int NKD = 0; size_t chain_lds_f = 0, chain_lds_b = 0;
+    ChainGeo cg{}; float* cfrags = nullptr; int NKD = 0, chain_alt = 0; size_t chain_lds_f = 0, chain_lds_b = 0;
     float* cslab = nullptr; size_t cslab_floats = 0; float* ev_t = nullptr; float* h_ev_t = nullptr;   // chain reverse: (H, Z) dump, evaluation times
     int sMT = 0, sWT = 0, sR = 0, sHT = 0, sK2b = 0, sKHb = 0;
     f32x4 *spwB = nullptr, *spwD = nullptr, *spwBt = nullptr, *spwDt = nullptr;
@@ -150,7 +150,7 @@ static bool chain_geo(const rnde_node_config* c, ChainGeo& G) {
         G.act[l] = c->act[l];
         G.poff[l] = po; po += (G.width[l] + G.time_dep) * G.width[l + 1] + G.width[l + 1];
         G.foff[l] = fo; fo += ((G.nks[l + 1] + 3) / 4) * G.nks[l];
-        G.boff[l] = bo; bo += G.nks[l + 1] * (1 + G.time_dep);
+        G.boff[l] = bo; bo += 4 * ((G.nks[l + 1] + 3) / 4) * (1 + G.time_dep);   // padded to whole tiles
         G.toff[l] = to; to += ((G.nks[l] + 3) / 4) * G.nks[l + 1];
     }
     G.nfrag_f = fo; G.nfrag_b = bo; G.nfrag_t = to; G.nksD = G.nks[0];
@@ -159,7 +159,8 @@ static bool chain_geo(const rnde_node_config* c, ChainGeo& G) {
 static rnde_status chain_create(const rnde_node_config* c, rnde_node** out) {
     ChainGeo G;
     if (!chain_geo(c, G)) { g_create_err = "unsupported dynamics: beyond the 2-layer time-dependent form the kernels cover Dense chains of width <= 64"; return RNDE_ERR_BAD_ARG; }
-    const size_t lds_f = ((size_t)(G.nfrag_f + G.nfrag_b) * 64 + 64) * 4, lds_b = ((size_t)(G.nfrag_f + G.nfrag_b + G.nfrag_t) * 64 + 64) * 4;
+    // LDS: fragment tables rounded up to whole 1 KiB DMA units, then 64 floats of reduction scratch
+    const size_t lds_f = ((size_t)((G.nfrag_f + G.nfrag_b + 3) / 4) * 256 + 64) * 4, lds_b = ((size_t)((G.nfrag_f + G.nfrag_b + G.nfrag_t + 3) / 4) * 256 + 64) * 4;
     if (lds_b > 160 * 1024) { g_create_err = "chain too large: its weight fragments must fit the 160 KB LDS of a CU"; return RNDE_ERR_BAD_ARG; }
     if (c->regularize < RNDE_REG_NONE || c->regularize > RNDE_REG_ERR) { g_create_err = "chain engine: regularize must be RNDE_REG_NONE or RNDE_REG_ERR"; return RNDE_ERR_BAD_ARG; }
     if (c->col_tile != 0 && c->col_tile != 64) { g_create_err = "col_tile: this network runs on the chain engine (0 or 64)"; return RNDE_ERR_BAD_ARG; }
@@ -168,17 +169,22 @@ static rnde_status chain_create(const rnde_node_config* c, rnde_node** out) {
     h->cfg = *c; h->engine = 3; h->cg = G;
     h->D = c->dims[0]; h->H = 0; h->P = rnde_param_count(c); h->BT = 16; h->NG = 0;
     h->NKD = G.nksD <= 4 ? 4 : (G.nksD <= 8 ? 8 : 16);
+    {   // compile-time shape specialisation for the reference's own latent-ODE widths (rnde_chain.h: ALT)
+        bool alt = G.nksD == kAltA && !getenv("RNDE_CHAIN_GENERIC");
+        for (int l = 0; l <= G.n_layers && alt; ++l) alt = G.nks[l] == ((l & 1) ? kAltB : kAltA);
+        h->chain_alt = alt ? 1 : 0;
+    }
     h->chain_lds_f = lds_f; h->chain_lds_b = lds_b;
     h->Bpad_max = ((c->max_batch + 15) / 16) * 16;
     const int ntiles = h->Bpad_max / 16;
     h->nwg_max = (ntiles + kCW - 1) / kCW;
     if (hipSetDevice(c->device) != hipSuccess) { g_create_err = "hipSetDevice failed"; delete h; return RNDE_ERR_HIP; }
-    const size_t Ac = (size_t)ntiles * G.nksD * 64;
+    const size_t Ac = (size_t)ntiles * h->NKD * 64;   // fragment-order arrays are padded to NKD k-steps
     h->rec_stride = ChainRec{(long long)Ac}.total();
     auto dm = [&](void** p, size_t bytes) { return hipMalloc(p, bytes) == hipSuccess; };
     bool ok = true;
     ok &= dm((void**)&h->f0, Ac * 4) && dm((void**)&h->u1, Ac * 4) && dm((void**)&h->f1, Ac * 4) && dm((void**)&h->xcopy, (size_t)h->D * h->Bpad_max * 4);
-    ok &= dm((void**)&h->pcopy, (size_t)h->P * 4) && dm((void**)&h->cfrags, (size_t)(G.nfrag_f + G.nfrag_b + G.nfrag_t) * 256);
+    ok &= dm((void**)&h->pcopy, (size_t)h->P * 4) && dm((void**)&h->cfrags, (size_t)(G.nfrag_f + G.nfrag_b + G.nfrag_t + 4) * 256);
     ok &= dm((void**)&h->ctl, 2 * sizeof(StepState)) && dm((void**)&h->ctl_final, sizeof(StepState));
     ok &= dm((void**)&h->meta, (size_t)(c->max_attempts + 1) * sizeof(StepMeta)) && dm((void**)&h->initrec, sizeof(InitRec));
     ok &= dm((void**)&h->errpart, (size_t)6 * h->nwg_max * 4) && dm((void**)&h->initpart, (size_t)3 * h->nwg_max * 4);
@@ -199,9 +205,9 @@ static ChainParams make_chain_params(rnde_node* h, const StepParams& P) {
     Q.F = P; Q.G = h->cg; Q.frags = h->cfrags; Q.ntiles = P.Bpad / 16;
     return Q;
 }
-template <int NKD, int MODE>
+template <int NKD, int MODE, int ALT = 0>
 static hipError_t launch_chain_t(rnde_node* h, const ChainParams& Q, int n, float* u_out, hipStream_t s) {
-    auto kern = rnde_chain_kernel<NKD, MODE>;
+    auto kern = rnde_chain_kernel<NKD, MODE, ALT>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -215,7 +221,7 @@ template <int MODE>
 static hipError_t launch_chain(rnde_node* h, const ChainParams& Q, int n, float* u_out, hipStream_t s) {
     switch (h->NKD) {
         case 4: return launch_chain_t<4, MODE>(h, Q, n, u_out, s);
-        case 8: return launch_chain_t<8, MODE>(h, Q, n, u_out, s);
+        case 8: return h->chain_alt ? launch_chain_t<8, MODE, 1>(h, Q, n, u_out, s) : launch_chain_t<8, MODE>(h, Q, n, u_out, s);
         default: return launch_chain_t<16, MODE>(h, Q, n, u_out, s);
     }
 }
@@ -604,7 +610,7 @@ extern "C" rnde_status rnde_debug_attempt(rnde_node* h, const float* uprev_dev, 
         rnde_status st3 = chain_pack(h, p_dev, s);
         if (st3 != RNDE_OK) return st3;
         const ChainParams CQ = make_chain_params(h, P);
-        const int nks = h->cg.nksD;
+        const int nks = h->NKD;
         HIPCHK(h, chain_convert(k1_dev, h->f0, h->D, B, CQ.ntiles, nks, 0, s));
         HIPCHK(h, launch_chain<CM_STEP>(h, CQ, 0, nullptr, s));
         HIPCHK(h, launch_chain<CM_FINISH>(h, CQ, 1, nullptr, s));
@@ -689,9 +695,15 @@ extern "C" rnde_status rnde_bench_attempt(rnde_node* h, const float* x_dev, cons
     if (mean_us_out) *mean_us_out = ms * 1000.f / iters;
 #ifdef RNDE_DIAG
     {   // phase stamps of the LAST f evaluation of one launch (workgroup 0), in shader cycles relative to stamp 0 of wave 0
-        unsigned long long* d = nullptr; unsigned long long hst[64];
+        unsigned long long* d = nullptr; unsigned long long hst[64] = {0};
         hipMalloc((void**)&d, sizeof(hst)); hipMemset(d, 0, sizeof(hst));
         P.dbg_out = (float*)d;
+        if (h->engine == 3) { CQ.F.dbg_out = (float*)d; launch_chain<CM_STEP>(h, CQ, 0, nullptr, s); hipStreamSynchronize(s); hipMemcpy(hst, d, sizeof(hst), hipMemcpyDeviceToHost);
+            fprintf(stderr, "chain stamps (cycles): fill %lld ctl %lld loads %lld |", (long long)(hst[1]-hst[0]), (long long)(hst[2]-hst[1]), (long long)(hst[3]-hst[2]));
+            for (int i = 4; i <= 9; ++i) fprintf(stderr, " st%d %lld", i - 3, (long long)(hst[i]-hst[i-1]));
+            fprintf(stderr, " | tail %lld total %lld\n", (long long)(hst[10]-hst[9]), (long long)(hst[10]-hst[0]));
+            for (int l = 0; l < h->cg.n_layers; ++l) fprintf(stderr, "  layer %d: bias %lld mm %lld act %lld (gap to next %lld)\n", l, (long long)(hst[17+4*l]-hst[16+4*l]), (long long)(hst[18+4*l]-hst[17+4*l]), (long long)(hst[19+4*l]-hst[18+4*l]), l + 1 < h->cg.n_layers ? (long long)(hst[20+4*l]-hst[19+4*l]) : 0LL);
+            hipFree(d); return RNDE_OK; }
         if (h->engine == 2) { SQ.F.dbg_out = (float*)d; stage_attempt(h, SQ, 0, s); } else launch_step<MODE_STEP>(h, P, 0, s);
         hipStreamSynchronize(s);
         hipMemcpy(hst, d, sizeof(hst), hipMemcpyDeviceToHost); hipFree(d);
@@ -968,21 +980,21 @@ extern "C" rnde_status rnde_classifier_head(rnde_node* h, const float* u_dev, co
 }
 
 // ---- chain engine reverse pass ----------------------------------------------------------------------------
-template <int NKD>
+template <int NKD, int ALT = 0>
 static hipError_t launch_bchain_t(rnde_node* h, const BChainParams& Q, const std::vector<int>& sv_lo, const std::vector<int>& sv_hi, hipStream_t s) {
     const size_t lds = h->chain_lds_b;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)rnde_bchain_kernel<NKD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rnde_bchain_init_kernel<NKD, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rnde_bchain_init_kernel<NKD, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)rnde_bchain_kernel<NKD, ALT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rnde_bchain_init_kernel<NKD, 1, ALT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rnde_bchain_init_kernel<NKD, 2, ALT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const dim3 grid(Q.B.F.nwg), blk(64 * kCW);
-    for (int n = Q.B.n_att - 1; n >= 0; --n) hipLaunchKernelGGL((rnde_bchain_kernel<NKD>), grid, blk, lds, s, Q, n, h->h_meta[n], sv_lo[n], sv_hi[n]);
-    hipLaunchKernelGGL((rnde_bchain_init_kernel<NKD, 1>), grid, blk, lds, s, Q);
-    hipLaunchKernelGGL((rnde_bchain_init_kernel<NKD, 2>), grid, blk, lds, s, Q);
+    for (int n = Q.B.n_att - 1; n >= 0; --n) hipLaunchKernelGGL((rnde_bchain_kernel<NKD, ALT>), grid, blk, lds, s, Q, n, h->h_meta[n], sv_lo[n], sv_hi[n]);
+    hipLaunchKernelGGL((rnde_bchain_init_kernel<NKD, 1, ALT>), grid, blk, lds, s, Q);
+    hipLaunchKernelGGL((rnde_bchain_init_kernel<NKD, 2, ALT>), grid, blk, lds, s, Q);
     hipLaunchKernelGGL(rnde_bfin_kernel, dim3(1), dim3(64), 0, s, Q.B);
     return hipGetLastError();
 }
@@ -994,7 +1006,7 @@ static rnde_status chain_bwd_run(rnde_node* h, const float* u_bar_dev, const flo
     const ChainGeo& G = h->cg;
     const int cap = h->cfg.max_attempts, ntiles_max = h->Bpad_max / 16;
     if (!b.ready) {
-        const size_t Ac = (size_t)ntiles_max * G.nksD * 64;
+        const size_t Ac = (size_t)ntiles_max * h->NKD * 64;
         HIPCHK(h, hipMalloc((void**)&b.U, Ac * 4)); HIPCHK(h, hipMalloc((void**)&b.K1, Ac * 4)); HIPCHK(h, hipMalloc((void**)&b.UB1, Ac * 4));
         HIPCHK(h, hipMalloc((void**)&b.svb_att, (size_t)cap * 4));
         HIPCHK(h, hipMalloc((void**)&b.bstate, 2 * sizeof(BState))); HIPCHK(h, hipMalloc((void**)&b.ibstate, 2 * sizeof(IBState)));
@@ -1020,7 +1032,9 @@ static rnde_status chain_bwd_run(rnde_node* h, const float* u_bar_dev, const flo
     Q.B.sv_ubar0 = (!h->saveat.empty() && h->saveat[0] == h->t0) ? u_bar_dev : nullptr;
     Q.G = G; Q.frags = h->cfrags; Q.ntiles = Q.B.F.Bpad / 16;
     int row = 0;
-    for (int l = 0; l < G.n_layers; ++l) { Q.hrow[l] = row; row += G.nks[l]; Q.zrow[l] = row; row += G.nks[l + 1]; }
+    auto pad4 = [](int k) { return 4 * ((k + 3) / 4); };
+    for (int l = 0; l < G.n_layers; ++l) { Q.hrow[l] = row; row += pad4(G.nks[l]); Q.zrow[l] = row; row += pad4(G.nks[l + 1]); }
+    Q.hrow[G.n_layers] = row; row += pad4(G.nks[G.n_layers]);
     Q.RS = row; Q.ev_stride = (long long)Q.ntiles * row * 64;
     Q.sv_t = h->saveat.empty() ? nullptr : h->sv_t_dev; Q.sv_ubar = u_bar_dev; Q.nsave = (int)h->saveat.size();
     const size_t need = (size_t)n_evals * Q.ev_stride;
@@ -1051,7 +1065,7 @@ static rnde_status chain_bwd_run(rnde_node* h, const float* u_bar_dev, const flo
     hipError_t e;
     switch (h->NKD) {
         case 4: e = launch_bchain_t<4>(h, Q, sv_lo, sv_hi, s); break;
-        case 8: e = launch_bchain_t<8>(h, Q, sv_lo, sv_hi, s); break;
+        case 8: e = h->chain_alt ? launch_bchain_t<8, 1>(h, Q, sv_lo, sv_hi, s) : launch_bchain_t<8>(h, Q, sv_lo, sv_hi, s); break;
         default: e = launch_bchain_t<16>(h, Q, sv_lo, sv_hi, s); break;
     }
     HIPCHK(h, e);

@@ -24,14 +24,49 @@ struct BChainParams {
     float* slab;            // [n_evals][ntiles][RS][64]: per layer its input (H) and its pre-activation cotangent (Z)
     long long ev_stride;    // ntiles * RS * 64
     int RS;                 // k-step rows per (evaluation, tile)
-    int hrow[kCMaxL], zrow[kCMaxL];
+    int hrow[kCMaxL + 1], zrow[kCMaxL];   // rows padded to whole tiles; hrow[n_layers] = the evaluation's output
     const float* sv_t; const float* sv_ubar; int nsave;   // saveat: times, D x T x B cotangent (caller layout)
 };
+
+template <int MT>
+__device__ __forceinline__ void chain_store_rows_t(float* p, const float (&a)[kCMaxKs]) {
+#pragma unroll
+    for (int ks = 0; ks < 4 * MT; ++ks) p[ks * 64] = a[ks];
+}
+__device__ __forceinline__ void chain_store_rows(float* p, int mt, const float (&a)[kCMaxKs]) {
+    switch (mt) {
+        case 1: chain_store_rows_t<1>(p, a); break;  case 2: chain_store_rows_t<2>(p, a); break;
+        case 3: chain_store_rows_t<3>(p, a); break;  default: chain_store_rows_t<4>(p, a); break;
+    }
+}
+// z = abar .* act'(out) for the MT output tiles of a layer; dumps z, accumulates the time-column cotangent
+template <int MT>
+__device__ __forceinline__ void chain_zstage_t(const float (&ab)[kCMaxKs], bool th, const float* op, float* zp, const float* wt, int td,
+                                               float (&z)[kCMaxKs], float& tl) {
+    float o[4 * MT];
+    if (th) {
+#pragma unroll
+        for (int ks = 0; ks < 4 * MT; ++ks) o[ks] = op[ks * 64];
+    }
+#pragma unroll
+    for (int ks = 0; ks < kCMaxKs; ++ks) {
+        float v = 0.f;
+        if (ks < 4 * MT) { v = ab[ks]; if (th) v *= (1.f - o[ks < 4 * MT ? ks : 0] * o[ks < 4 * MT ? ks : 0]); zp[ks * 64] = v; }
+        z[ks] = v;
+    }
+    if (td) {
+        float w[4 * MT];
+#pragma unroll
+        for (int ks = 0; ks < 4 * MT; ++ks) w[ks] = wt[ks * 64];
+#pragma unroll
+        for (int ks = 0; ks < 4 * MT; ++ks) tl = fmaf(z[ks], w[ks], tl);
+    }
+}
 
 // J_f^T product for the wave's 16 columns at the point (g, ts) whose value kout = f(g, ts) is on the tape.
 // Dumps every layer's input and pre-activation cotangent for the weight-gradient kernel; returns gbar and adds the
 // cotangent of the time input (TDChain layers) to tau.
-template <int NKD>
+template <int NKD, int ALT = 0>
 __device__ __forceinline__ void chain_fbwd(const BChainParams& Q, const float* FR, const float* BF, const float* TF, float ts,
                                            const float (&g)[NKD], const float (&kout)[NKD], const float (&kbar)[NKD], float (&gb)[NKD],
                                            float* __restrict__ sl, float& tau, int lane) {
@@ -39,44 +74,58 @@ __device__ __forceinline__ void chain_fbwd(const BChainParams& Q, const float* F
     float a[kCMaxKs];
 #pragma unroll
     for (int k = 0; k < kCMaxKs; ++k) a[k] = (k < NKD) ? (G.pre_act ? tanh_fast(g[k < NKD ? k : 0]) : g[k < NKD ? k : 0]) : 0.f;
-    // forward recompute: every layer's input goes to the slab (the last layer's output is kout)
+    // forward recompute: every layer's input goes to the slab; the last layer's output is kout (taped)
 #pragma unroll 1
     for (int l = 0; l < G.n_layers; ++l) {
-        const int nin = G.nks[l];
-        float* hp = sl + (size_t)Q.hrow[l] * 64;
-#pragma unroll
-        for (int ks = 0; ks < kCMaxKs; ++ks) if (ks < nin) hp[ks * 64] = a[ks];
-        if (l + 1 < G.n_layers) chain_layer(G, FR, BF, l, ts, a, lane);
+        if constexpr (ALT == 1) {
+            if ((l & 1) == 0) chain_store_rows_t<(kAltA + 3) / 4>(sl + (size_t)Q.hrow[l] * 64, a);
+            else chain_store_rows_t<(kAltB + 3) / 4>(sl + (size_t)Q.hrow[l] * 64, a);
+        } else chain_store_rows(sl + (size_t)Q.hrow[l] * 64, (G.nks[l] + 3) >> 2, a);
+        if (l + 1 < G.n_layers) chain_layer<ALT>(G, FR, BF, l, ts, a, lane);
     }
     float ab[kCMaxKs];
 #pragma unroll
-    for (int k = 0; k < kCMaxKs; ++k) ab[k] = (k < NKD) ? kbar[k < NKD ? k : 0] : 0.f;
+    for (int k = 0; k < kCMaxKs; ++k) { a[k] = (k < NKD) ? kout[k < NKD ? k : 0] : 0.f; ab[k] = (k < NKD) ? kbar[k < NKD ? k : 0] : 0.f; }
+    chain_store_rows(sl + (size_t)Q.hrow[G.n_layers] * 64, (G.nks[G.n_layers] + 3) >> 2, a);
     float tl = 0.f;
 #pragma unroll 1
     for (int l = G.n_layers - 1; l >= 0; --l) {
-        const int nin = G.nks[l], nout = G.nks[l + 1];
-        const bool th = G.act[l] != 0, lastl = (l + 1 == G.n_layers);
-        const float* op = sl + (size_t)Q.hrow[lastl ? l : l + 1] * 64;   // layer output = next layer's input
+        const int nout = G.nks[l + 1], mto = (nout + 3) >> 2, mti = (G.nks[l] + 3) >> 2;
+        const bool th = G.act[l] != 0;
+        const float* op = sl + (size_t)Q.hrow[l + 1] * 64;   // layer output = next layer's input (or kout)
         float* zp = sl + (size_t)Q.zrow[l] * 64;
-        const float* wt = BF + (size_t)(G.boff[l] + nout) * 64 + lane;
+        const float* wt = BF + (size_t)(G.boff[l] + 4 * mto) * 64 + lane;
         float z[kCMaxKs];
+        if constexpr (ALT == 1) {
+            constexpr int MA = (kAltA + 3) / 4, MB = (kAltB + 3) / 4;
+            f32x4 acc[4];
 #pragma unroll
-        for (int ks = 0; ks < kCMaxKs; ++ks) {
-            float v = 0.f;
-            if (ks < nout) {
-                v = ab[ks];
-                if (th) { const float o = lastl ? (ks < NKD ? kout[ks < NKD ? ks : 0] : 0.f) : op[ks * 64]; v *= (1.f - o * o); }
-                zp[ks * 64] = v;
-                if (G.time_dep) tl += v * wt[ks * 64];
+            for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if ((l & 1) == 0) {   // forward kAltA -> kAltB: z has kAltB k-steps, the product kAltA
+                chain_zstage_t<MB>(ab, th, op, zp, wt, G.time_dep, z, tl);
+                chain_mm_t<kAltB>(TF + (size_t)G.toff[l] * 64 + lane, MA, z, acc);
+                chain_act_t<MA>(acc, false, ab);
+            } else {
+                chain_zstage_t<MA>(ab, th, op, zp, wt, G.time_dep, z, tl);
+                chain_mm_t<kAltA>(TF + (size_t)G.toff[l] * 64 + lane, MB, z, acc);
+                chain_act_t<MB>(acc, false, ab);
             }
-            z[ks] = v;
+            continue;
+        }
+        switch (mto) {
+            case 1: chain_zstage_t<1>(ab, th, op, zp, wt, G.time_dep, z, tl); break;
+            case 2: chain_zstage_t<2>(ab, th, op, zp, wt, G.time_dep, z, tl); break;
+            case 3: chain_zstage_t<3>(ab, th, op, zp, wt, G.time_dep, z, tl); break;
+            default: chain_zstage_t<4>(ab, th, op, zp, wt, G.time_dep, z, tl); break;
         }
         f32x4 acc[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        chain_mm(TF + (size_t)G.toff[l] * 64 + lane, nout, (nin + 3) >> 2, z, acc);
-#pragma unroll
-        for (int ks = 0; ks < kCMaxKs; ++ks) ab[ks] = (ks < nin) ? acc[ks >> 2][ks & 3] : 0.f;
+        chain_mm(TF + (size_t)G.toff[l] * 64 + lane, nout, mti, z, acc);
+        switch (mti) {
+            case 1: chain_act_t<1>(acc, false, ab); break;  case 2: chain_act_t<2>(acc, false, ab); break;
+            case 3: chain_act_t<3>(acc, false, ab); break;  default: chain_act_t<4>(acc, false, ab); break;
+        }
     }
 #pragma unroll
     for (int k = 0; k < NKD; ++k) {
@@ -87,7 +136,7 @@ __device__ __forceinline__ void chain_fbwd(const BChainParams& Q, const float* F
     tau += tl;
 }
 
-template <int NKD>
+template <int NKD, int ALT = 0>
 __global__ __launch_bounds__(64 * kCW) void rnde_bchain_kernel(const BChainParams Q, const int n, const StepMeta m, const int sv_lo, const int sv_hi) {
     const BwdParams& Bq = Q.B;
     const StepParams& P = Bq.F;
@@ -96,7 +145,8 @@ __global__ __launch_bounds__(64 * kCW) void rnde_bchain_kernel(const BChainParam
     float* FR = smem;
     float* BF = FR + (size_t)G.nfrag_f * 64;
     float* TF = BF + (size_t)G.nfrag_b * 64;
-    float* RED = TF + (size_t)G.nfrag_t * 64;   // [3][kCW]
+    const int fill_units = (G.nfrag_f + G.nfrag_b + G.nfrag_t + 3) >> 2;
+    float* RED = smem + (size_t)fill_units * 256;   // [3][kCW]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = blockIdx.x * kCW + wave;
@@ -105,14 +155,10 @@ __global__ __launch_bounds__(64 * kCW) void rnde_bchain_kernel(const BChainParam
     const bool colok = tile_ok && gcol < P.B;
     const bool writer = (blockIdx.x == 0 && tid == 0);
     const bool first = (n == Bq.n_att - 1);
-    const int nksD = G.nksD;
-    const ChainRec L{(long long)Q.ntiles * nksD * 64};
-    const size_t fo = ((size_t)tile * nksD) * 64 + lane;
-    {
-        const int nf = (G.nfrag_f + G.nfrag_b + G.nfrag_t) * 64;
-        for (int i = tid; i < nf; i += 64 * kCW) smem[i] = Q.frags[i];
-        __syncthreads();
-    }
+    constexpr int nksD = NKD;   // arena arrays are padded to NKD k-steps
+    const ChainRec L{(long long)Q.ntiles * NKD * 64};
+    const size_t fo = ((size_t)tile * NKD) * 64 + lane;
+    chain_fill_lds(Q.frags, smem, fill_units, wave, lane);
     // ---- scalar chain, identical in every wave; same arithmetic as rnde_bstep_kernel ----
     double tb = 0, dtpb = 0, qoldb = 0, t1b = 0, t0b = 0;
     if (!first) finish_attempt_scalars(Bq, n + 1, lane, tb, dtpb, qoldb, t1b, t0b);
@@ -230,7 +276,7 @@ __global__ __launch_bounds__(64 * kCW) void rnde_bchain_kernel(const BChainParam
                 if (accepted && !first && in) kb7[q] += Bq.K1[fo + q * 64];
             }
             float t7 = 0.f;
-            chain_fbwd<NKD>(Q, FR, BF, TF, t + dt, unv, k7, kb7, gb, sl0 + 5 * Q.ev_stride, t7, lane);
+            chain_fbwd<NKD, ALT>(Q, FR, BF, TF, t + dt, unv, k7, kb7, gb, sl0 + 5 * Q.ev_stride, t7, lane);
             tau += t7; ctau += t7;
 #pragma unroll
             for (int q = 0; q < NKD; ++q) {
@@ -253,7 +299,7 @@ __global__ __launch_bounds__(64 * kCW) void rnde_bchain_kernel(const BChainParam
                 S += ks[q] * kb[q];
             }
             float ts_ = 0.f;
-            chain_fbwd<NKD>(Q, FR, BF, TF, t + kTsC[s] * dt, gs, ks, kb, gb, sl0 + (size_t)(s - 1) * Q.ev_stride, ts_, lane);
+            chain_fbwd<NKD, ALT>(Q, FR, BF, TF, t + kTsC[s] * dt, gs, ks, kb, gb, sl0 + (size_t)(s - 1) * Q.ev_stride, ts_, lane);
             tau += ts_; ctau += kTsC[s] * ts_;
             float cb[5];
 #pragma unroll
@@ -294,7 +340,7 @@ __global__ __launch_bounds__(64 * kCW) void rnde_bchain_kernel(const BChainParam
 
 // Reverse of the initialisation (mirror of rnde_binit_kernel): PHASE 1 = f1 = f(u1, t0 + dt0) of the initial-step
 // heuristic, PHASE 2 = f0 = f(u0, t0) (fsalfirst and the heuristic's first evaluation) and x-bar.
-template <int NKD, int PHASE>
+template <int NKD, int PHASE, int ALT = 0>
 __global__ __launch_bounds__(64 * kCW) void rnde_bchain_init_kernel(const BChainParams Q) {
     const BwdParams& Bq = Q.B;
     const StepParams& P = Bq.F;
@@ -303,7 +349,8 @@ __global__ __launch_bounds__(64 * kCW) void rnde_bchain_init_kernel(const BChain
     float* FR = smem;
     float* BF = FR + (size_t)G.nfrag_f * 64;
     float* TF = BF + (size_t)G.nfrag_b * 64;
-    float* RED = TF + (size_t)G.nfrag_t * 64;
+    const int fill_units = (G.nfrag_f + G.nfrag_b + G.nfrag_t + 3) >> 2;
+    float* RED = smem + (size_t)fill_units * 256;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = blockIdx.x * kCW + wave;
@@ -311,14 +358,10 @@ __global__ __launch_bounds__(64 * kCW) void rnde_bchain_init_kernel(const BChain
     const int col = lane & 15, g = lane >> 4, gcol = tile * 16 + col;
     const bool colok = tile_ok && gcol < P.B;
     const bool writer = (blockIdx.x == 0 && tid == 0);
-    const int nksD = G.nksD;
-    const size_t fo = ((size_t)tile * nksD) * 64 + lane;
+    constexpr int nksD = NKD;
+    const size_t fo = ((size_t)tile * NKD) * 64 + lane;
     const double N = (double)P.D * (double)P.B;
-    {
-        const int nf = (G.nfrag_f + G.nfrag_b + G.nfrag_t) * 64;
-        for (int i = tid; i < nf; i += 64 * kCW) smem[i] = Q.frags[i];
-        __syncthreads();
-    }
+    chain_fill_lds(Q.frags, smem, fill_units, wave, lane);
     const InitRec ir = *P.initrec;
     const float dt0 = ir.dt0;
     float* sl = Q.slab + (size_t)(6 * Bq.n_att + (PHASE == 1 ? 1 : 0)) * Q.ev_stride + ((size_t)tile * Q.RS) * 64 + lane;
@@ -350,7 +393,7 @@ __global__ __launch_bounds__(64 * kCW) void rnde_bchain_init_kernel(const BChain
                 f1b[q] = 0.f;
                 if (valid) { const float sk = P.abstol + fabsf(xv) * P.reltol; f1b[q] = cw * ((f1v[q] - f0v[q]) / sk) / sk; }
             }
-            chain_fbwd<NKD>(Q, FR, BF, TF, P.t0 + dt0, u1v, f1v, f1b, gb, sl, tau, lane);
+            chain_fbwd<NKD, ALT>(Q, FR, BF, TF, P.t0 + dt0, u1v, f1v, f1b, gb, sl, tau, lane);
 #pragma unroll
             for (int q = 0; q < NKD; ++q) { if (q < nksD) Bq.UB1[fo + q * 64] = gb[q]; dot += gb[q] * f0v[q]; }
             if (!colok) tau = 0.f;
@@ -396,7 +439,7 @@ __global__ __launch_bounds__(64 * kCW) void rnde_bchain_init_kernel(const BChain
                     if (Bq.sv_ubar0) u0b[q] += Bq.sv_ubar0[((size_t)gcol * Bq.sv_T) * P.D + 4 * q + g];
                 }
             }
-            chain_fbwd<NKD>(Q, FR, BF, TF, P.t0, xq, f0v, f0b, gb, sl, tau, lane);
+            chain_fbwd<NKD, ALT>(Q, FR, BF, TF, P.t0, xq, f0v, f0b, gb, sl, tau, lane);
 #pragma unroll
             for (int q = 0; q < NKD; ++q)
                 if (q < nksD && colok && 4 * q + g < P.D) Bq.xbar[(size_t)gcol * P.D + 4 * q + g] = u0b[q] + gb[q];
@@ -442,9 +485,9 @@ __global__ __launch_bounds__(64 * kCW) void rnde_chain_wgrad_kernel(const BChain
             const int cidx = 4 * s + kk;
             float a[4], b[5];
 #pragma unroll
-            for (int mo = 0; mo < 4; ++mo) a[mo] = (mo < ot && 16 * mo + rho < 4 * nout) ? Zp[(16 * mo + rho) * 16 + cidx] : 0.f;
+            for (int mo = 0; mo < 4; ++mo) a[mo] = mo < ot ? Zp[(16 * mo + rho) * 16 + cidx] : 0.f;
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) b[mi] = (mi < it && 16 * mi + rho < 4 * nin) ? Hp[(16 * mi + rho) * 16 + cidx] : 0.f;
+            for (int mi = 0; mi < 4; ++mi) b[mi] = mi < it ? Hp[(16 * mi + rho) * 16 + cidx] : 0.f;
             b[4] = rho == 0 ? (G.time_dep ? te : 0.f) : (rho == 1 ? 1.f : 0.f);
 #pragma unroll
             for (int mo = 0; mo < 4; ++mo) {

@@ -16,8 +16,12 @@
 //
 // Layout vocabulary: an activation vector of width n is nks = ceil(n/4) "k-steps"; k-step ks of a wave is one VGPR
 // whose lane (g = lane >> 4, col = lane & 15) holds feature 4*ks + g of batch column 16*tile + col (0 past n).
-// Arrays in the arena use the same order: [tile][ks][lane] ("fragment order", 256-byte coalesced rows); caller
-// arrays (x, u_out, the saveat output, cotangents) stay D x B column-major as the ABI says.
+// Arrays in the arena use the same order: [tile][ks][lane] ("fragment order", 256-byte coalesced rows), with the
+// k-step count padded to the kernel's compile-time NKD (zeros), and the bias tables / reverse-pass dumps padded to
+// whole 16-feature tiles: every per-element loop in the kernels is then compile-time, and the only data-dependent
+// control flow is one switch per layer on its tile counts (per-element uniform branches serialised each LDS read
+// behind its own s_waitcnt: 260 cycles per MFMA measured, against 46 for the dependent chain itself).
+// Caller arrays (x, u_out, the saveat output, cotangents) stay D x B column-major as the ABI says.
 #pragma once
 #include "rnde_fwd.h"
 #include "rnde_stage.h"   // mfma16
@@ -81,7 +85,7 @@ __global__ void rnde_chain_pack_kernel(const float* __restrict__ p, float* __res
             int l = 0;
             while (l + 1 < G.n_layers && fr >= G.boff[l + 1]) ++l;
             int r = fr - G.boff[l];
-            const int nout = G.nks[l + 1], in = G.width[l], out = G.width[l + 1];
+            const int nout = 4 * ((G.nks[l + 1] + 3) >> 2), in = G.width[l], out = G.width[l + 1];   // padded to whole tiles
             const bool tcol = r >= nout;
             if (tcol) r -= nout;
             const int f = 4 * r + kk;
@@ -99,18 +103,75 @@ __global__ void rnde_chain_pack_kernel(const float* __restrict__ p, float* __res
     }
 }
 
+// copy `units` KiB of fragment tables into LDS with the LDS-DMA path (no VGPR round trip, all loads in flight at once)
+__device__ __forceinline__ void chain_fill_lds(const float* __restrict__ frags, float* smem, int units, int wave, int lane) {
+    for (int u = wave; u < units; u += kCW) dma_unit((const f32x4*)(frags + (size_t)u * 256) + lane, smem + (size_t)u * 256);
+    wait_vm<0>();
+    __syncthreads();
+}
+
 // ---- acc[mo] += A(mo, .) * in   for the first `mt` output tiles; NKS = k-steps of the input --------------------------
+// C chains of MFMAs, interleaved: chain c accumulates A fragments frag(c, k) for k in [0, n_c) into acc_c
 template <int NKS>
 __device__ __forceinline__ void chain_mm_t(const float* fr, int mt, const float (&in)[kCMaxKs], f32x4 (&acc)[4]) {
+    // A dependent v_mfma_f32_16x16x4_f32 issues every 46 cycles, an independent one every 32 (tools/micro/mfma_chain):
+    // keep up to 4 independent accumulation chains in flight -- the layer's output tiles, and when there are only 1-2 of
+    // them the two halves of K (the half sums are added at the end; summation order differs from a serial dot product
+    // by fp32 rounding only).  All A fragments of the layer are read from LDS in one batch first; the sched_barriers
+    // keep the compiler from re-serialising every ds_read behind its own s_waitcnt.
+    constexpr int K0 = (NKS + 1) / 2, K1 = NKS - K0;
+    if (mt >= 3) {
+        float a[4][NKS];
 #pragma unroll
-    for (int mo = 0; mo < 4; ++mo) {
-        if (mo < mt) {
-            float a[NKS];
+        for (int mo = 0; mo < 4; ++mo)
+            if (mo < 3 || mt == 4) {
 #pragma unroll
-            for (int k = 0; k < NKS; ++k) a[k] = fr[(mo * NKS + k) * 64];
+                for (int k = 0; k < NKS; ++k) a[mo][k] = fr[(mo * NKS + k) * 64];
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        if (mt == 4) {
 #pragma unroll
-            for (int k = 0; k < NKS; ++k) acc[mo] = mfma16(a[k], in[k], acc[mo]);
+            for (int k = 0; k < NKS; ++k) {
+#pragma unroll
+                for (int mo = 0; mo < 4; ++mo) acc[mo] = mfma16(a[mo][k], in[k], acc[mo]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NKS; ++k) {
+#pragma unroll
+                for (int mo = 0; mo < 3; ++mo) acc[mo] = mfma16(a[mo][k], in[k], acc[mo]);
+            }
         }
+        __builtin_amdgcn_sched_barrier(0);
+    } else {
+        float a[2][NKS];
+#pragma unroll
+        for (int mo = 0; mo < 2; ++mo)
+            if (mo < mt) {
+#pragma unroll
+                for (int k = 0; k < NKS; ++k) a[mo][k] = fr[(mo * NKS + k) * 64];
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 hi[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        if (mt == 2) {
+#pragma unroll
+            for (int k = 0; k < K0; ++k) {
+#pragma unroll
+                for (int mo = 0; mo < 2; ++mo) {
+                    acc[mo] = mfma16(a[mo][k], in[k], acc[mo]);
+                    if (k < K1) hi[mo] = mfma16(a[mo][K0 + (k < K1 ? k : 0)], in[K0 + (k < K1 ? k : 0)], hi[mo]);
+                }
+            }
+            acc[0] += hi[0]; acc[1] += hi[1];
+        } else {
+#pragma unroll
+            for (int k = 0; k < K0; ++k) {
+                acc[0] = mfma16(a[0][k], in[k], acc[0]);
+                if (k < K1) hi[0] = mfma16(a[0][K0 + (k < K1 ? k : 0)], in[K0 + (k < K1 ? k : 0)], hi[0]);
+            }
+            acc[0] += hi[0];
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 __device__ __forceinline__ void chain_mm(const float* fr, int nks, int mt, const float (&in)[kCMaxKs], f32x4 (&acc)[4]) {
@@ -126,35 +187,128 @@ __device__ __forceinline__ void chain_mm(const float* fr, int nks, int mt, const
     }
 }
 
-// one Dense layer on the wave's 16 columns: a <- act(W a + b (+ t * w_t)); all widths in k-steps
-__device__ __forceinline__ void chain_layer(const ChainGeo& G, const float* FR, const float* BF, int l, float ts, float (&a)[kCMaxKs], int lane) {
-    const int nin = G.nks[l], nout = G.nks[l + 1];
-    const float* bf = BF + (size_t)G.boff[l] * 64 + lane;
-    f32x4 acc[4];
+// accumulator init = bias (+ t * time column) for the MT output tiles of a layer; bf -> this lane's entry of row 0
+template <int MT>
+__device__ __forceinline__ void chain_bias_t(const float* bf, float ts, int td, f32x4 (&acc)[4]) {
+    float b[4 * MT];
 #pragma unroll
-    for (int ks = 0; ks < kCMaxKs; ++ks) {
-        float v = 0.f;
-        if (ks < nout) { v = bf[ks * 64]; if (G.time_dep) v += ts * bf[(nout + ks) * 64]; }
-        acc[ks >> 2][ks & 3] = v;
+    for (int ks = 0; ks < 4 * MT; ++ks) b[ks] = bf[ks * 64];
+    if (td) {
+        float w[4 * MT];
+#pragma unroll
+        for (int ks = 0; ks < 4 * MT; ++ks) w[ks] = bf[(4 * MT + ks) * 64];
+#pragma unroll
+        for (int ks = 0; ks < 4 * MT; ++ks) b[ks] = fmaf(ts, w[ks], b[ks]);
     }
-    chain_mm(FR + (size_t)G.foff[l] * 64 + lane, nin, (nout + 3) >> 2, a, acc);
-    const bool th = G.act[l] != 0;
 #pragma unroll
-    for (int ks = 0; ks < kCMaxKs; ++ks) {
-        float v = 0.f;
-        if (ks < nout) { v = acc[ks >> 2][ks & 3]; if (th) v = tanh_fast(v); }
-        a[ks] = v;
+    for (int ks = 0; ks < 16; ++ks) acc[ks >> 2][ks & 3] = ks < 4 * MT ? b[ks < 4 * MT ? ks : 0] : 0.f;
+}
+template <int MT>
+__device__ __forceinline__ void chain_act_t(const f32x4 (&acc)[4], bool th, float (&a)[kCMaxKs]) {   // identity / generic
+    if (th) {
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) a[ks] = ks < 4 * MT ? tanh_fast(acc[ks >> 2][ks & 3]) : 0.f;
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) a[ks] = ks < 4 * MT ? acc[ks >> 2][ks & 3] : 0.f;
+    }
+}
+// tanh on exactly N k-steps, two per instruction (the rows past N are padding: zero)
+template <int N>
+__device__ __forceinline__ void chain_tanh_n(const f32x4 (&acc)[4], float (&a)[kCMaxKs]) {
+#pragma unroll
+    for (int ks = 0; ks < 16; ks += 2) {
+        if (ks + 1 < N) {
+            const f32x2 v = tanh_fast2((f32x2){acc[ks >> 2][ks & 3], acc[(ks + 1) >> 2][(ks + 1) & 3]});
+            a[ks] = v.x; a[ks + 1] = v.y;
+        } else if (ks < N) {
+            a[ks] = tanh_fast(acc[ks >> 2][ks & 3]); a[ks + 1] = 0.f;
+        } else { a[ks] = 0.f; a[ks + 1] = 0.f; }
+    }
+}
+__device__ __forceinline__ void chain_tanh(const f32x4 (&acc)[4], int n, float (&a)[kCMaxKs]) {
+    switch (n) {
+        case 1: chain_tanh_n<1>(acc, a); break;   case 2: chain_tanh_n<2>(acc, a); break;   case 3: chain_tanh_n<3>(acc, a); break;
+        case 4: chain_tanh_n<4>(acc, a); break;   case 5: chain_tanh_n<5>(acc, a); break;   case 6: chain_tanh_n<6>(acc, a); break;
+        case 7: chain_tanh_n<7>(acc, a); break;   case 8: chain_tanh_n<8>(acc, a); break;   case 9: chain_tanh_n<9>(acc, a); break;
+        case 10: chain_tanh_n<10>(acc, a); break; case 11: chain_tanh_n<11>(acc, a); break; case 12: chain_tanh_n<12>(acc, a); break;
+        case 13: chain_tanh_n<13>(acc, a); break; case 14: chain_tanh_n<14>(acc, a); break; case 15: chain_tanh_n<15>(acc, a); break;
+        default: chain_tanh_n<16>(acc, a); break;
     }
 }
 
+// one Dense layer on the wave's 16 columns: a <- act(W a + b (+ t * w_t)); all widths in k-steps.
+// ALT = 0: any chain, shapes dispatched at run time.  The dispatch is not free: the structurised switches merge the
+// 16-register accumulator / activation arrays after every case (measured: 32.5 k cycles per latent-ODE evaluation
+// against 17.3 k with compile-time shapes, tools/micro/chain_eval.hip).  ALT = 1 therefore fixes the k-step pattern
+// of the reference's own latent-ODE dynamics at compile time (experiments/latent_ode.jl:113-124: widths 20 <-> 50,
+// i.e. 5 <-> 13 k-steps, alternating; depth, activations and flags stay run-time).
+constexpr int kAltA = 5, kAltB = 13;
+template <int ALT = 0>
+__device__ __forceinline__ void chain_layer(const ChainGeo& G, const float* FR, const float* BF, int l, float ts, float (&a)[kCMaxKs], int lane, unsigned long long* dbg = nullptr) {
+    const int nin = G.nks[l], mt = (G.nks[l + 1] + 3) >> 2;
+    const float* bf = BF + (size_t)G.boff[l] * 64 + lane;
+    f32x4 acc[4];
+    if constexpr (ALT == 1) {
+        constexpr int MA = (kAltA + 3) / 4, MB = (kAltB + 3) / 4;
+        const bool th = G.act[l] != 0;
+        if ((l & 1) == 0) {
+            chain_bias_t<MB>(bf, ts, G.time_dep, acc);
+            chain_mm_t<kAltA>(FR + (size_t)G.foff[l] * 64 + lane, MB, a, acc);
+            if (th) chain_tanh_n<kAltB>(acc, a); else chain_act_t<MB>(acc, false, a);
+        } else {
+            chain_bias_t<MA>(bf, ts, G.time_dep, acc);
+            chain_mm_t<kAltB>(FR + (size_t)G.foff[l] * 64 + lane, MA, a, acc);
+            if (th) chain_tanh_n<kAltA>(acc, a); else chain_act_t<MA>(acc, false, a);
+        }
+        return;
+    }
+#ifdef RNDE_DIAG
+    if (dbg) dbg[16 + 4 * l] = clock64();
+#endif
+#ifdef CH_NO_BIAS
+    for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (false)
+#endif
+    switch (mt) {
+        case 1: chain_bias_t<1>(bf, ts, G.time_dep, acc); break;
+        case 2: chain_bias_t<2>(bf, ts, G.time_dep, acc); break;
+        case 3: chain_bias_t<3>(bf, ts, G.time_dep, acc); break;
+        default: chain_bias_t<4>(bf, ts, G.time_dep, acc); break;
+    }
+#ifdef RNDE_DIAG
+    if (dbg) dbg[17 + 4 * l] = clock64();
+#endif
+#ifndef CH_NO_MFMA
+    chain_mm(FR + (size_t)G.foff[l] * 64 + lane, nin, mt, a, acc);
+#endif
+#ifdef RNDE_DIAG
+    if (dbg) dbg[18 + 4 * l] = clock64();
+#endif
+#ifdef CH_NO_TANH   // (ablation builds only: tools/micro/chain_eval.hip)
+    if (false) {}
+#else
+    if (G.act[l] != 0) chain_tanh(acc, G.nks[l + 1], a);
+#endif
+    else switch (mt) {
+        case 1: chain_act_t<1>(acc, false, a); break;
+        case 2: chain_act_t<2>(acc, false, a); break;
+        case 3: chain_act_t<3>(acc, false, a); break;
+        default: chain_act_t<4>(acc, false, a); break;
+    }
+#ifdef RNDE_DIAG
+    if (dbg) dbg[19 + 4 * l] = clock64();
+#endif
+}
+
 // k = f(g, t) for the wave's columns (reference a6: dudt_, neural_ode.jl:55; latent_ode.jl:113-124)
-template <int NKD>
-__device__ __forceinline__ void chain_eval(const ChainGeo& G, const float* FR, const float* BF, float ts, const float (&g)[NKD], float (&out)[NKD], int lane) {
+template <int NKD, int ALT = 0>
+__device__ __forceinline__ void chain_eval(const ChainGeo& G, const float* FR, const float* BF, float ts, const float (&g)[NKD], float (&out)[NKD], int lane, unsigned long long* dbg = nullptr) {
     float a[kCMaxKs];
 #pragma unroll
     for (int k = 0; k < kCMaxKs; ++k) a[k] = (k < NKD) ? (G.pre_act ? tanh_fast(g[k < NKD ? k : 0]) : g[k < NKD ? k : 0]) : 0.f;
 #pragma unroll 1
-    for (int l = 0; l < G.n_layers; ++l) chain_layer(G, FR, BF, l, ts, a, lane);
+    for (int l = 0; l < G.n_layers; ++l) chain_layer<ALT>(G, FR, BF, l, ts, a, lane, dbg);
 #pragma unroll
     for (int k = 0; k < NKD; ++k) out[k] = a[k];
 }
@@ -200,14 +354,21 @@ __device__ __forceinline__ void chain_dense_points(const StepParams& P, const Ch
     }
 }
 
-template <int NKD, int MODE>
+#ifdef RNDE_DIAG
+#define CHAIN_STAMP(i) do { if (MODE == CM_STEP && P.dbg_out && blockIdx.x == 0 && tid == 0) ((unsigned long long*)P.dbg_out)[i] = clock64(); } while (0)
+#else
+#define CHAIN_STAMP(i) do { } while (0)
+#endif
+
+template <int NKD, int MODE, int ALT = 0>
 __global__ __launch_bounds__(64 * kCW) void rnde_chain_kernel(const ChainParams Q, const int n, float* __restrict__ u_out) {
     const StepParams& P = Q.F;
     const ChainGeo& G = Q.G;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* FR = smem;
     float* BF = FR + (size_t)G.nfrag_f * 64;
-    float* RED = BF + (size_t)G.nfrag_b * 64;   // [3][kCW]
+    const int fill_units = (G.nfrag_f + G.nfrag_b + 3) >> 2;
+    float* RED = smem + (size_t)fill_units * 256;   // [3][kCW]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = blockIdx.x * kCW + wave;
@@ -215,22 +376,20 @@ __global__ __launch_bounds__(64 * kCW) void rnde_chain_kernel(const ChainParams 
     const int col = lane & 15, g = lane >> 4, gcol = tile * 16 + col;
     const bool colok = tile_ok && gcol < P.B;
     const bool writer = (blockIdx.x == 0 && tid == 0);
-    const int nksD = G.nksD;
-    const ChainRec L{(long long)Q.ntiles * nksD * 64};
-    const size_t fo = ((size_t)tile * nksD) * 64 + lane;      // fragment-order offset of this lane's k-step 0
+    constexpr int nksD = NKD;                                  // arena arrays are padded to NKD k-steps
+    const ChainRec L{(long long)Q.ntiles * NKD * 64};
+    const size_t fo = ((size_t)tile * NKD) * 64 + lane;        // fragment-order offset of this lane's k-step 0
 
-    if constexpr (MODE != CM_FINISH) {
-        const int nf = (G.nfrag_f + G.nfrag_b) * 64;
-        for (int i = tid; i < nf; i += 64 * kCW) smem[i] = Q.frags[i];
-        __syncthreads();
-    }
+    CHAIN_STAMP(0);
+    if constexpr (MODE != CM_FINISH) chain_fill_lds(Q.frags, smem, fill_units, wave, lane);
+    CHAIN_STAMP(1);
 
     if constexpr (MODE == CM_FEVAL) {
         if (!tile_ok) return;
         float gv[NKD], kv[NKD];
 #pragma unroll
         for (int q = 0; q < NKD; ++q) gv[q] = ldc(P.x, P.D, gcol, 4 * q + g, colok && q < nksD);
-        chain_eval<NKD>(G, FR, BF, P.forced_t, gv, kv, lane);
+        chain_eval<NKD, ALT>(G, FR, BF, P.forced_t, gv, kv, lane);
 #pragma unroll
         for (int q = 0; q < NKD; ++q) if (q < nksD && colok && 4 * q + g < P.D) P.dbg_out[(size_t)gcol * P.D + 4 * q + g] = kv[q];
         return;
@@ -261,7 +420,7 @@ __global__ __launch_bounds__(64 * kCW) void rnde_chain_kernel(const ChainParams 
                     if (q < nksD) P.u1[fo + q * 64] = gv[q];
                 } else gv[q] = xv[q];
             }
-            chain_eval<NKD>(G, FR, BF, (MODE == CM_INIT_B) ? P.t0 + dt0 : P.t0, gv, kv, lane);
+            chain_eval<NKD, ALT>(G, FR, BF, (MODE == CM_INIT_B) ? P.t0 + dt0 : P.t0, gv, kv, lane);
 #pragma unroll
             for (int q = 0; q < NKD; ++q) {
                 if (q < nksD) {
@@ -287,6 +446,7 @@ __global__ __launch_bounds__(64 * kCW) void rnde_chain_kernel(const ChainParams 
     } else {
         // ---- controller, then (STEP) one attempted step / (FINISH) the copy-out ----
         const StepState S = advance_state(P, n, lane, writer, (MODE == CM_FINISH) ? P.ctl_final : &P.ctl[n & 1]);
+        CHAIN_STAMP(2);
         if (P.nsave > 0 && tile_ok) {
             // saveat ({R,true} methods, neural_ode.jl:79-108): the points inside the step accepted last
             if (n == 0) {
@@ -342,6 +502,7 @@ __global__ __launch_bounds__(64 * kCW) void rnde_chain_kernel(const ChainParams 
                     E[q] = kTsBt[0] * k1;
                     un[q] = up[q];
                 }
+                CHAIN_STAMP(3);
 #pragma unroll 1
                 for (int s = 1; s < 7; ++s) {   // zero-based stage: k_{s+1} = f(g_{s+1}, t + c_s dt)
                     float gq[NKD], kv[NKD];
@@ -354,7 +515,12 @@ __global__ __launch_bounds__(64 * kCW) void rnde_chain_kernel(const ChainParams 
 #pragma unroll
                         for (int q = 0; q < NKD; ++q) if (q < nksD) R[L.g(s + 1) + fo + q * 64] = gq[q];
                     }
-                    chain_eval<NKD>(G, FR, BF, t + kTsC[s] * dt, gq, kv, lane);
+#ifdef RNDE_DIAG
+                    chain_eval<NKD, ALT>(G, FR, BF, t + kTsC[s] * dt, gq, kv, lane, (s == 2 && P.dbg_out && blockIdx.x == 0 && tid == 0) ? (unsigned long long*)P.dbg_out : nullptr);
+#else
+                    chain_eval<NKD, ALT>(G, FR, BF, t + kTsC[s] * dt, gq, kv, lane);
+#endif
+                    CHAIN_STAMP(3 + s);
                     const float bts = kTsBt[s];
                     float cs[5];
 #pragma unroll
@@ -378,6 +544,7 @@ __global__ __launch_bounds__(64 * kCW) void rnde_chain_kernel(const ChainParams 
                     }
                 }
             }
+            CHAIN_STAMP(10);
             part = wave_sum_f(part);
             if (lane == 0) RED[wave] = part;
             __syncthreads();

@@ -381,6 +381,32 @@ __device__ __forceinline__ float tanh_fast(float x) {
     big = ax > 9.1f ? 1.0f : big;
     return ax < 0.55f ? small : copysignf(big, x);
 }
+// two values per instruction (v_pk_fma_f32 / v_pk_mul_f32): same operation sequence per component as tanh_fast, so
+// results are bit-identical to it
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 tanh_fast2(f32x2 x) {
+    const f32x2 ax = __builtin_elementwise_abs(x), x2 = x * x;
+    f32x2 p = fma2((f32x2)(-0.00671552f), x2, (f32x2)(0.02136713f));
+    p = fma2(p, x2, (f32x2)(-0.05391917f));
+    p = fma2(p, x2, (f32x2)(0.13333165f));
+    p = fma2(p, x2, (f32x2)(-0.33333332f));
+    const f32x2 sm = fma2(x, x2 * p, x);
+    constexpr float L = 2.8853900817779268f;
+    constexpr float Llo = (float)(2.8853900817779268 - (double)L);
+    const f32x2 yh = ax * L;
+    const f32x2 yl = fma2(ax, (f32x2)(L), -yh) + ax * Llo;
+    f32x2 e = {__builtin_amdgcn_exp2f(yh.x), __builtin_amdgcn_exp2f(yh.y)};
+    e = fma2(e, yl * 0.6931471805599453f, e);
+    const f32x2 dd = e + 1.0f;
+    f32x2 r = {__builtin_amdgcn_rcpf(dd.x), __builtin_amdgcn_rcpf(dd.y)};
+    r = fma2(fma2(-dd, r, (f32x2)(1.0f)), r, r);
+    const f32x2 big = fma2((f32x2)(-2.0f), r, (f32x2)(1.0f));
+    f32x2 o;
+    o.x = ax.x < 0.55f ? sm.x : copysignf(ax.x > 9.1f ? 1.0f : big.x, x.x);
+    o.y = ax.y < 0.55f ? sm.y : copysignf(ax.y > 9.1f ? 1.0f : big.y, x.y);
+    return o;
+}
 __device__ __forceinline__ float act_apply_fast(int act, float v) { return act ? tanh_fast(v) : v; }
 
 }  // namespace rnde

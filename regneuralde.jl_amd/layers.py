@@ -56,6 +56,13 @@ class Chain:
         return d
 
 
+def LatentGenDynamics(latent=20, hidden=50, depth=8, generator=None):
+    """reference experiments/latent_ode.jl:113-124 (gen_dynamics): x -> tanh.(x), then `depth` Dense layers alternating
+    latent -> hidden -> latent, all tanh, time independent."""
+    dims = [latent if i % 2 == 0 else hidden for i in range(depth + 1)]
+    return Chain(*[Dense(dims[i], dims[i + 1], "tanh", generator) for i in range(depth)], pre_act=True)
+
+
 def destructure(model):
     """Flux.destructure(model)[1]: flat fp32 parameter vector."""
     parts = []

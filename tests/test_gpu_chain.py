@@ -181,3 +181,28 @@ def test_chain_config4_reverse():
     x64, p64, t64 = o64.backward(ubar.astype(np.float64), None)
     print(f"x-bar {rel_err(gx, x64):.2e}  p-bar {rel_err(gp, p64):.2e}  tspan {gt} vs {t64}")
     assert rel_err(gx, x64) <= 1e-3 and rel_err(gp, p64) <= 1e-3
+
+
+def test_chain_generic_dispatch_path_on_latent_shape(monkeypatch):
+    """The latent-ODE widths normally take the compile-time-shape kernels (rnde_chain.h: ALT); RNDE_CHAIN_GENERIC=1 forces the
+    run-time-dispatch kernels on the same network: both must agree with the oracle (forward and reverse)."""
+    from tests.util import Node, Oracle, rel_err
+    monkeypatch.setenv("RNDE_CHAIN_GENERIC", "1")
+    arch, p, x = _setup("latent", 37, 3, 1.5)
+    sa = np.array([0.0, 0.3, 0.8, 1.0], dtype=np.float32)
+    o64 = Oracle(arch, np.float64, reltol=1e-3, abstol=1e-3, reg_kind=1)
+    o32 = Oracle(arch, np.float32, reltol=1e-3, abstol=1e-3, reg_kind=1)
+    r64, r32 = o64.forward(x, p, saveat=sa), o32.forward(x, p, saveat=sa)
+    node = Node(_cfg(arch, 37, reltol=1e-3, abstol=1e-3))
+    got = node.forward_saveat(x, p, sa, keep_tape=True)
+    assert got["nfe"] == r64["nfe"] == r32["nfe"]
+    spread = np.abs(r32["u"] - r64["u"]).max(axis=(1, 2))
+    assert (np.abs(got["u"] - r64["u"]).max(axis=(1, 2)) <= 3e-5 * max(1.0, np.abs(r64["u"]).max()) + 4 * spread).all()
+    rng = np.random.default_rng(14)
+    ubar = rng.standard_normal(r64["u"].shape).astype(np.float32)
+    svbar = np.full(len(got["saveval"]), 20.0, dtype=np.float32)
+    gx, gp, gt = node.backward(ubar, svbar)
+    x64, p64, _ = o64.backward(ubar.astype(np.float64), svbar.astype(np.float64))
+    x32, p32, _ = o32.backward(ubar, svbar)
+    assert rel_err(gx, x64) <= 2e-3 + 4 * rel_err(x32, x64)
+    assert rel_err(gp, p64) <= 2e-3 + 4 * rel_err(p32, p64)

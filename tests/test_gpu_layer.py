@@ -68,6 +68,45 @@ def test_saveat_layer_returns_3d_array_and_differentiates(rnde):
     assert np.abs(p.grad.cpu().numpy() - pb).max() <= 3e-3 * np.abs(pb).max()
 
 
+def test_latent_ode_layer_call(rnde):
+    """The node of experiments/latent_ode.jl:113-147: gen_dynamics (tanh + 8 Dense), time independent, saveat = the data's
+    time grid; per-call saveat override as in loss_function (latent_ode.jl:237-241).  Runs on the chain engine."""
+    from oracle.oracle import Oracle, arch_latent
+    rn = rnde
+    B = 24
+    g = torch.Generator().manual_seed(2)
+    dyn = rn.LatentGenDynamics(generator=g)
+    for l in dyn.layers:
+        l.W.mul_(1.5)            # truncation-dominated regime (with Glorot weights fp32 EEst sits on its rounding floor, DESIGN.md 3)
+    grid = np.linspace(0.0, 1.0, 49).astype(np.float32)
+    node = rn.TrackedNeuralODE(dyn, [0.0, 1.0], False, True, "Tsit5", saveat=grid.tolist(), reltol=1e-3, abstol=1e-3,
+                               max_batch=B, max_attempts=64)
+    assert node.P == 8280 and node.return_multiple                  # SURVEY.md 8a row a1
+    z0 = (torch.rand(B, 20, generator=g) * 2 - 1).cuda().requires_grad_(True)
+    p = node.p.cuda().clone().requires_grad_(True)
+    res, nfe, sv = node(z0, p)
+    assert res.shape == (B, 49, 20) and sv.saveval.ndim == 1
+    sub = grid[::6]
+    res2, nfe2, sv2 = node(z0, p, saveat=sub.tolist())
+    assert nfe2 == nfe and torch.allclose(res2, res[:, ::6], atol=1e-6)
+    w = torch.randn(B, 49, 20, generator=g).cuda()
+    ((res * w).sum() + 5.0 * sv.saveval.sum()).backward()
+    orc = Oracle(arch_latent(), np.float64, reltol=1e-3, abstol=1e-3, reg_kind=1)
+    r = orc.forward(z0.detach().cpu().numpy().astype(np.float64), p.detach().cpu().numpy().astype(np.float64), saveat=grid)
+    assert r["nfe"] == nfe
+    xb, pb, _ = orc.backward(w.cpu().numpy().astype(np.float64), np.full(len(r["saveval"]), 5.0))
+    # conditioning: spread between the fp32 and fp64 oracles on the same inputs (8 stacked tanh layers amplify rounding)
+    o32 = Oracle(arch_latent(), np.float32, reltol=1e-3, abstol=1e-3, reg_kind=1)
+    r32 = o32.forward(z0.detach().cpu().numpy(), p.detach().cpu().numpy(), saveat=grid)
+    assert r32["nfe"] == nfe
+    xb32, pb32, _ = o32.backward(w.cpu().numpy(), np.full(len(r["saveval"]), 5.0, dtype=np.float32))
+    su = np.abs(r32["u"] - r["u"]).max()
+    sx, sp = np.abs(xb32 - xb).max() / np.abs(xb).max(), np.abs(pb32 - pb).max() / np.abs(pb).max()
+    assert np.abs(res.detach().cpu().numpy() - r["u"]).max() < 3e-5 + 4 * su
+    assert np.abs(z0.grad.cpu().numpy() - xb).max() <= (3e-3 + 4 * sx) * np.abs(xb).max()
+    assert np.abs(p.grad.cpu().numpy() - pb).max() <= (3e-3 + 4 * sp) * np.abs(pb).max()
+
+
 def test_unregularised_layer_returns_nothing_for_sv(rnde):
     node, g = _model(rnde, regularize=False)
     x = torch.rand(5, 36, generator=g).cuda()

@@ -72,6 +72,12 @@ def test_node_constructor_contract(rnde):
         rnde.TrackedNeuralODE(dyn, [0.0, 1.0], True, True, "Vern7")
 
 
+def test_latent_gen_dynamics_shape(rnde):
+    dyn = rnde.LatentGenDynamics()
+    assert dyn.dims() == [20, 50, 20, 50, 20, 50, 20, 50, 20] and dyn.pre_act and not dyn.time_dep
+    assert rnde.destructure(dyn).numel() == 8280                   # latent ODE P = 8,280
+
+
 def test_node_refuses_cpu_tensors_loudly(rnde):
     dyn = rnde.MLPDynamics(8, 4)
     node = rnde.TrackedNeuralODE(dyn, [0.0, 1.0], True, False, "Tsit5", reltol=1e-3, abstol=1e-3)

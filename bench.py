@@ -157,13 +157,15 @@ def main():
         _lib.check(h.ptr, L.rnde_bench_attempt(h.ptr, xs.data_ptr(), model.p2.data_ptr(), B, 200, C.byref(us), C.c_void_p(stream)))
         t_att = us.value * 1e-6
         stage_engine = args.col_tile in (0, 16)
+        nl = int(L.rnde_node_launches_per_attempt(h.ptr))
         roof = {"bound": "hbm", "achieved": ALG_BYTES(B) / t_att / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ALG_BYTES(B) / t_att / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                "kernel": ("rnde_stage_kernel: one attempted Tsit5 step = 7 launches (START, 5 x STAGE, LAST)" if stage_engine
+                "kernel": (("rnde_stage_attempt_kernel: one attempted Tsit5 step = 1 launch (7 stages, in-kernel slab hand-off)" if nl == 1 else
+                            "rnde_stage_kernel: one attempted Tsit5 step = 7 launches (START, 5 x STAGE, LAST)") if stage_engine
                            else "rnde_step_kernel: one attempted Tsit5 step = 1 launch"),
-                "launches_per_unit": 7 if stage_engine else 1, "us_per_launch": us.value / (7 if stage_engine else 1),
+                "launches_per_unit": nl, "us_per_launch": us.value / nl,
                 "us_per_attempt": us.value,
-                "alg_bytes_per_attempt": ALG_BYTES(B), "alg_bytes_per_launch": ALG_BYTES(B) / (7 if stage_engine else 1),
+                "alg_bytes_per_attempt": ALG_BYTES(B), "alg_bytes_per_launch": ALG_BYTES(B) / nl,
                 "mfma_f32_tflops": ALG_FLOPS(B) / t_att / 1e12,
                 "mfma_frac": ALG_FLOPS(B) / t_att / 1e12 / MFMA_F32_PEAK_TF}
         out = {"metric": "training-step samples/sec + mean NFE, MNIST Neural ODE bs=512",

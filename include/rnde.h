@@ -131,6 +131,9 @@ rnde_status rnde_debug_attempt(rnde_node* h, const float* uprev_dev, const float
                                float* unew_out_dev, float* eest_out, void* stream);
 rnde_status rnde_bench_attempt(rnde_node* h, const float* x_dev, const float* p_dev, int32_t B,
                                int32_t iters, float* mean_us_out, void* stream);
+/* How the handle currently runs one attempted step: number of kernel launches (1: rnde_stage_attempt_kernel /
+ * rnde_step_kernel / rnde_chain_kernel; 7: rnde_stage_kernel START, 5 x STAGE, LAST) -- bench.py's roofline bookkeeping. */
+int32_t     rnde_node_launches_per_attempt(const rnde_node* h);
 
 /* Fused caller of the hot path: postode Dense(D, C) + Flux.Losses.logitcrossentropy and their
  * reverse in one call -- replaces reference src/models/supervised_classification.jl:44-45 + experiments/mnist_node.jl:135

@@ -5,6 +5,7 @@
 #include "rnde_bwd.h"
 #include "rnde_stage.h"
 #include "rnde_bstage.h"
+#include "rnde_stage_persist.h"
 #include "rnde_head.h"
 #include "rnde_chain.h"
 #include "rnde_bchain.h"
@@ -36,6 +37,8 @@ struct rnde_node {
     size_t stage_lds = 0;
     float* head_ws = nullptr; size_t head_ws_floats = 0;   // fused classifier head scratch
     float* sv_t_dev = nullptr; size_t sv_cap = 0; std::vector<float> saveat;   // saveat times of the last forward
+    // persistent attempt kernel (rnde_stage_persist.h): 1 = in use, 0 = off (RNDE_PERSIST=0), -1 = disabled after a failure
+    int persist = 0; unsigned persist_seq = 0; unsigned *pflags = nullptr, *pabort = nullptr, *pxcc = nullptr; unsigned* h_pchk = nullptr;
     hipStream_t wstream = nullptr;        // (experimental overlap path of the weight-gradient GEMMs)
     std::vector<hipEvent_t> wevents;
     // device
@@ -292,6 +295,8 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
     ok &= dm((void**)&h->spwB, (size_t)h->sMT * h->sK2b * 64 * 16) && dm((void**)&h->spwD, (size_t)h->sHT * h->sMT * 64 * 16);
     ok &= dm((void**)&h->spwBt, (size_t)h->sMT * h->sKHb * 64 * 16) && dm((void**)&h->spwDt, (size_t)h->sHT * h->sMT * 64 * 16);
     ok &= dm((void**)&h->slab2, (size_t)2 * (h->Bpad_max / 16) * h->sR * h->sHT * 64 * 16);
+    ok &= dm((void**)&h->pflags, (size_t)(h->Bpad_max / 16) * 8 * 4) && dm((void**)&h->pabort, 8) && dm((void**)&h->pxcc, (size_t)h->nwg_max * 4);
+    ok &= hipHostMalloc((void**)&h->h_pchk, ((size_t)h->nwg_max + 2) * 4) == hipSuccess;
     ok &= dm((void**)&h->ctl, 2 * sizeof(StepState)) && dm((void**)&h->ctl_final, sizeof(StepState));
     ok &= dm((void**)&h->meta, (size_t)(c->max_attempts + 1) * sizeof(StepMeta)) && dm((void**)&h->initrec, sizeof(InitRec));
     ok &= dm((void**)&h->errpart, (size_t)6 * h->nwg_max * 4) && dm((void**)&h->initpart, (size_t)3 * h->nwg_max * 4);
@@ -304,6 +309,8 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
     ok &= hipHostMalloc((void**)&h->h_scal, 64 * sizeof(float)) == hipSuccess;
     if (!ok) { g_create_err = "device allocation failed"; rnde_node_destroy(h); return RNDE_ERR_HIP; }
     hipMemset(h->initrec, 0, sizeof(InitRec));
+    hipMemset(h->pflags, 0, (size_t)(h->Bpad_max / 16) * 8 * 4); hipMemset(h->pabort, 0, 8); hipMemset(h->pxcc, 0, (size_t)h->nwg_max * 4);
+    { const char* e = getenv("RNDE_PERSIST"); h->persist = (h->engine == 2 && h->sR <= 8 && !(e && e[0] == '0')) ? 1 : 0; }
     h->predicted = 12;
     *out = h;
     return RNDE_OK;
@@ -318,6 +325,10 @@ extern "C" void rnde_node_destroy(rnde_node* h) {
     if (h->head_ws) hipFree(h->head_ws);
     if (h->sv_t_dev) hipFree(h->sv_t_dev);
     if (h->cfrags) hipFree(h->cfrags);
+    if (h->pflags) hipFree(h->pflags);
+    if (h->pabort) hipFree(h->pabort);
+    if (h->pxcc) hipFree(h->pxcc);
+    if (h->h_pchk) hipHostFree(h->h_pchk);
     if (h->cslab) hipFree(h->cslab);
     if (h->ev_t) hipFree(h->ev_t);
     if (h->h_ev_t) hipHostFree(h->h_ev_t);
@@ -377,15 +388,52 @@ static rnde_status stage_pack_weights(rnde_node* h, const float* p_dev, hipStrea
     return RNDE_OK;
 }
 static hipError_t stage_attempt(rnde_node* h, const StageParams& Q, int n, hipStream_t s) {
+    if (h->persist == 1) {   // one launch per attempt, slab hand-offs inside the kernel (rnde_stage_persist.h)
+        PersistSync Y{h->pflags, h->pabort, h->pxcc, h->persist_seq};
+        h->persist_seq += 8;
+        const dim3 grid(8 * Q.R * ((Q.C + 7) / 8));   // a column tile's row blocks share blockIdx % 8 (same XCD)
+        if (h->act2) hipLaunchKernelGGL((rnde_stage_attempt_kernel<1>), grid, dim3(64 * Q.WT), h->stage_lds, s, Q, n, Y);
+        else hipLaunchKernelGGL((rnde_stage_attempt_kernel<0>), grid, dim3(64 * Q.WT), h->stage_lds, s, Q, n, Y);
+        return hipGetLastError();
+    }
     hipError_t e = launch_stage<SM_START>(h, Q, n, 0, s);
     for (int st = 1; st <= 5 && e == hipSuccess; ++st) e = launch_stage<SM_STAGE>(h, Q, n, st, s);
     if (e == hipSuccess) e = launch_stage<SM_LAST>(h, Q, n, 6, s);
     return e;
 }
 
-static rnde_status forward_impl(rnde_node* h, const float* x_dev, const float* p_dev, int32_t B, float t0, float t1,
+static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p_dev, int32_t B, float t0, float t1,
                                 float* u_out_dev, const float* saveat_host, int32_t n_saveat, float* sv_out_dev,
                                 int64_t* nfe_out, float* saveval_host, int32_t* n_saveval_out, int32_t keep_tape, void* stream);
+static const rnde_status RNDE_INTERNAL_RETRY = static_cast<rnde_status>(100);
+
+// After a synchronisation point: did a persistent launch time out, or did a column tile's workgroups land on different
+// XCDs (then their slab hand-off through L2 would not be coherent)?  Either way the persistent kernels are disabled for
+// this handle and the caller redoes the solve with the multi-launch kernels.
+static bool persist_failed(rnde_node* h, int grid, int C, int R, hipStream_t s) {
+    if (h->persist != 1) return false;
+    if (hipMemcpyAsync(h->h_pchk, h->pabort, 8, hipMemcpyDeviceToHost, s) != hipSuccess) return true;
+    if (hipMemcpyAsync(h->h_pchk + 2, h->pxcc, (size_t)grid * 4, hipMemcpyDeviceToHost, s) != hipSuccess) return true;
+    if (hipStreamSynchronize(s) != hipSuccess) return true;
+    bool bad = h->h_pchk[0] != 0;
+    for (int ct = 0; ct < C && !bad; ++ct)
+        for (int rb = 1; rb < R; ++rb) if (h->h_pchk[2 + rb * C + ct] != h->h_pchk[2 + ct]) { bad = true; break; }
+    if (bad) {
+        fprintf(stderr, "[rnde] persistent attempt kernel disabled (%s); using the multi-launch kernels\n", h->h_pchk[0] ? "hand-off timed out" : "column tile spans XCDs");
+        h->persist = -1;
+        hipMemsetAsync(h->pabort, 0, 8, s);
+    }
+    return bad;
+}
+
+static rnde_status forward_impl(rnde_node* h, const float* x_dev, const float* p_dev, int32_t B, float t0, float t1,
+                                float* u_out_dev, const float* saveat_host, int32_t n_saveat, float* sv_out_dev,
+                                int64_t* nfe_out, float* saveval_host, int32_t* n_saveval_out, int32_t keep_tape, void* stream) {
+    rnde_status st = forward_core(h, x_dev, p_dev, B, t0, t1, u_out_dev, saveat_host, n_saveat, sv_out_dev, nfe_out, saveval_host, n_saveval_out, keep_tape, stream);
+    if (st == RNDE_INTERNAL_RETRY)
+        st = forward_core(h, x_dev, p_dev, B, t0, t1, u_out_dev, saveat_host, n_saveat, sv_out_dev, nfe_out, saveval_host, n_saveval_out, keep_tape, stream);
+    return st;
+}
 
 extern "C" rnde_status rnde_node_forward(rnde_node* h, const float* x_dev, const float* p_dev, int32_t B, float t0,
                                          float t1, float* u_out_dev, int64_t* nfe_out, float* saveval_host,
@@ -401,7 +449,7 @@ extern "C" rnde_status rnde_node_forward_saveat(rnde_node* h, const float* x_dev
     return forward_impl(h, x_dev, p_dev, B, t0, t1, nullptr, saveat_host, n_saveat, u_saved_dev, nfe_out, saveval_host, n_saveval_out, keep_tape, stream);
 }
 
-static rnde_status forward_impl(rnde_node* h, const float* x_dev, const float* p_dev, int32_t B, float t0, float t1,
+static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p_dev, int32_t B, float t0, float t1,
                                 float* u_out_dev, const float* saveat_host, int32_t n_saveat, float* sv_out_dev,
                                 int64_t* nfe_out, float* saveval_host, int32_t* n_saveval_out, int32_t keep_tape, void* stream) {
     if (!h) return RNDE_ERR_BAD_ARG;
@@ -472,6 +520,7 @@ static rnde_status forward_impl(rnde_node* h, const float* x_dev, const float* p
         else HIPCHK(h, launch_finish(h, P, launched, u_out_dev, s));
         HIPCHK(h, hipMemcpyAsync(h->h_ctl, h->ctl_final, sizeof(StepState), hipMemcpyDeviceToHost, s));
         HIPCHK(h, hipStreamSynchronize(s));
+        if (h->engine == 2 && persist_failed(h, SQ.R * SQ.C, SQ.C, SQ.R, s)) return RNDE_INTERNAL_RETRY;
         if (h->h_ctl->done) break;
         if (launched >= cap) { h->err = "max_attempts reached"; h->n_att = h->h_ctl->n_att; return RNDE_ERR_MAX_ATTEMPTS; }
         chunk = 4;
@@ -525,6 +574,11 @@ extern "C" rnde_status rnde_node_steps(rnde_node* h, float* steps_host, int32_t 
     }
     if (n_out) *n_out = h->n_att;
     return RNDE_OK;
+}
+
+extern "C" int32_t rnde_node_launches_per_attempt(const rnde_node* h) {
+    if (!h) return 0;
+    return (h->engine == 2 && h->persist != 1) ? 7 : 1;
 }
 
 extern "C" rnde_status rnde_node_release_tape(rnde_node* h) {

@@ -40,6 +40,9 @@ __device__ __forceinline__ int kperm(int k) { return (k & ~15) | ((k & 3) << 2) 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+// explicit fused multiply-adds for the stage combinations: rnde_stage_kernel and rnde_stage_attempt_kernel must round
+// identically (their outputs are compared bit for bit), so contraction is not left to the compiler
+__device__ __forceinline__ f32x4 fma4(float s, f32x4 a, f32x4 c) { return __builtin_elementwise_fma((f32x4){s, s, s, s}, a, c); }
 
 // packed A operands for the stage engine: element (tile T, block kb, lane l, q) = Wsel[16*T + (l&15)][16*kb + 4*q + (l>>4)]
 // which: 0 pwB fwd  = W2ext (rows D, k <= H: W2 incl. time col; k == H+1: b2)
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_kernel(const StagePara
     // stage time and tape slots
     float ts = t;
     float* hdst = nullptr; float* kdst = nullptr;
-    if constexpr (MODE == SM_STAGE || MODE == SM_LAST) { ts = t + kTsC[s] * dt; hdst = R + L.h(s + 1); kdst = R + L.k(s + 1); }
+    if constexpr (MODE == SM_STAGE || MODE == SM_LAST) { ts = fmaf(kTsC[s], dt, t); hdst = R + L.h(s + 1); kdst = R + L.k(s + 1); }
     if constexpr (MODE == SM_I2) { ts = P.t0; hdst = P.h0; kdst = P.f0; }
     if constexpr (MODE == SM_I4) { ts = P.t0 + dt0; hdst = P.h1; kdst = P.f1; }
     if constexpr (MODE == SM_FEVAL2) { ts = P.forced_t; }
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_kernel(const StagePara
                 const int hr = h0 + i;
                 float v = 0.f;
                 if (hr < P.H) {
-                    v = tanh_fast(z[i] + ((ht == w) ? w1t_own[i] : W1t[hr]) * ts + ((ht == w) ? b1_own[i] : b1[hr]));
+                    v = tanh_fast(fmaf((ht == w) ? w1t_own[i] : W1t[hr], ts, z[i]) + ((ht == w) ? b1_own[i] : b1[hr]));
                     if (rb == 0 && hdst) hdst[(size_t)gcol * P.H + hr] = v;
                 } else if (hr == P.H) v = ts;
                 else if (hr == P.H + 1) v = 1.f;
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_kernel(const StagePara
     float part0 = 0.f, part1 = 0.f, part2 = 0.f;
     if (tile_ok) {
         if constexpr (MODE == SM_START) {
-            v = c_up + dt * (kFwdShift[0][0] * c_k[0]);
+            v = fma4(dt, kFwdShift[0][0] * c_k[0], c_up);
             if (P.tape) st4(R + L.g(2) + (size_t)gcol * P.D, r0, P.D, true, vec, v);
             if (P.tape || P.nsave > 0) {
                 st4(R + L.upc() + (size_t)gcol * P.D, r0, P.D, true, vec, c_up);
@@ -336,9 +339,9 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_kernel(const StagePara
             st4(kdst + (size_t)gcol * P.D, r0, P.D, true, vec, kv);
             f32x4 acc = tsA_rt(s + 1, 0) * c_k[0];
 #pragma unroll
-            for (int j = 1; j < 6; ++j) if (j < s) acc += tsA_rt(s + 1, j) * c_k[j];
-            acc += tsA_rt(s + 1, s) * kv;
-            v = c_up + dt * acc;
+            for (int j = 1; j < 6; ++j) if (j < s) acc = fma4(tsA_rt(s + 1, j), c_k[j], acc);
+            acc = fma4(tsA_rt(s + 1, s), kv, acc);
+            v = fma4(dt, acc, c_up);
             if (s == 5) st4(R + L.unew() + (size_t)gcol * P.D, r0, P.D, true, vec, v);
             else if (P.tape) st4(R + L.g(s + 2) + (size_t)gcol * P.D, r0, P.D, true, vec, v);
         } else if constexpr (MODE == SM_LAST) {
@@ -346,8 +349,8 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_kernel(const StagePara
             const f32x4 up = c_up, un = c_un;
             f32x4 acc = kTsBt[0] * c_k[0];
 #pragma unroll
-            for (int j = 1; j < 6; ++j) acc += kTsBt[j] * c_k[j];
-            acc += kTsBt[6] * kv;
+            for (int j = 1; j < 6; ++j) acc = fma4(kTsBt[j], c_k[j], acc);
+            acc = fma4(kTsBt[6], kv, acc);
             if (colok) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -359,8 +362,8 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_kernel(const StagePara
                 if (P.reg_kind >= 2) {   // stiffness estimate partials: ||k7 - k6||^2, ||unew - g6||^2
                     f32x4 g6 = tsA_rt(5, 0) * c_k[0];
 #pragma unroll
-                    for (int j = 1; j < 5; ++j) g6 += tsA_rt(5, j) * c_k[j];
-                    g6 = up + dt * g6;
+                    for (int j = 1; j < 5; ++j) g6 = fma4(tsA_rt(5, j), c_k[j], g6);
+                    g6 = fma4(dt, g6, up);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         if (r0 + i < P.D) {

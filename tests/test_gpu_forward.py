@@ -131,3 +131,33 @@ def test_saveat_dense_output_matches_oracle(kind, B, tol, scale, saveat):
     assert got["nfe"] == ref["nfe"]
     assert got["u"].shape == ref["u"].shape == (B, len(sa), arch.dims[0])
     assert np.abs(got["u"] - ref["u"]).max() <= 3e-5 * max(1.0, np.abs(ref["u"]).max())
+
+
+@pytest.mark.parametrize("kind,B,tol,scale,saveat", [("mnist", 512, 1.4e-8, 1.0, None), ("mnist", 37, 1e-3, 3.0, np.linspace(0, 1, 9)),
+                                                      ("small", 33, 1e-3, 4.0, None), ("test_node", 3, 1e-2, 8.0, np.array([0.5, 1.0]))])
+def test_persistent_attempt_is_bit_identical(kind, B, tol, scale, saveat, monkeypatch):
+    """rnde_stage_attempt_kernel (one launch per attempt, in-kernel slab hand-off between the row blocks of a column tile)
+    performs exactly the arithmetic of the 7 rnde_stage_kernel launches: states, step log, saved values and the tape (checked
+    through the reverse pass) must be bit-identical."""
+    from tests.util import Node
+    arch, p, x = _setup(kind, B, 5, scale)
+    rng = np.random.default_rng(9)
+    outs = []
+    for persist in ("1", "0"):
+        monkeypatch.setenv("RNDE_PERSIST", persist)
+        node = Node(_cfg(arch, B, reltol=tol, abstol=tol, col_tile=16, max_attempts=256))
+        if saveat is None:
+            got = node.forward(x, p, keep_tape=True)
+        else:
+            got = node.forward_saveat(x, p, saveat.astype(np.float32), keep_tape=True)
+        ubar = np.random.default_rng(9).standard_normal(got["u"].shape).astype(np.float32)
+        svbar = np.full(len(got["saveval"]), 3.0, dtype=np.float32)
+        gx, gp, gt = node.backward(ubar, svbar)
+        outs.append((got, gx, gp, gt))
+    a, b = outs
+    assert a[0]["nfe"] == b[0]["nfe"]
+    assert np.array_equal(a[0]["u"], b[0]["u"])
+    assert np.array_equal(a[0]["saveval"], b[0]["saveval"])
+    if "steps" in a[0]:
+        assert np.array_equal(a[0]["steps"], b[0]["steps"])
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])

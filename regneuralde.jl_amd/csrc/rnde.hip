@@ -6,6 +6,7 @@
 #include "rnde_stage.h"
 #include "rnde_bstage.h"
 #include "rnde_stage_persist.h"
+#include "rnde_bstage_persist.h"
 #include "rnde_head.h"
 #include "rnde_chain.h"
 #include "rnde_bchain.h"
@@ -967,6 +968,14 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
                     c2 = (float)(-eigb * ((double)mm.n1 / (double)mm.n2) / ((double)mm.n2 * (double)mm.n2));
                 }
             }
+            if (h->persist == 1) {   // the attempt's 7 reverse launches as one (rnde_bstage_persist.h)
+                PersistSync Y{h->pflags, h->pabort, h->pxcc, h->persist_seq};
+                h->persist_seq += 8;
+                const dim3 pgrid(8 * BQ.R * ((BQ.C + 7) / 8));
+                if (h->act2) hipLaunchKernelGGL((rnde_bstage_attempt_kernel<1>), pgrid, blk, h->stage_lds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y);
+                else hipLaunchKernelGGL((rnde_bstage_attempt_kernel<0>), pgrid, blk, h->stage_lds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y);
+                continue;
+            }
             if (h->act2) hipLaunchKernelGGL((rnde_bstage_kernel<1, BM_START>), grid, blk, h->stage_lds, s, BQ, n, 0, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n]);
             else hipLaunchKernelGGL((rnde_bstage_kernel<0, BM_START>), grid, blk, h->stage_lds, s, BQ, n, 0, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n]);
             for (int j = 6; j >= 1; --j) {
@@ -1003,6 +1012,10 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
     HIPCHK(h, hipStreamSynchronize(s));
     if (tspan_bar_host) { tspan_bar_host[0] = h->h_scal[0]; tspan_bar_host[1] = h->h_scal[1]; }
     h->have_tape = false;  // z2bar overwrote k_s in place: the tape is consumed
+    if (h->engine == 2 && persist_failed(h, h->sR * (Q.F.Bpad / 16), Q.F.Bpad / 16, h->sR, s)) {
+        h->err = "persistent reverse kernel abandoned its hand-off (tape consumed): rerun forward + backward, the multi-launch kernels are now in use";
+        return RNDE_ERR_HIP;
+    }
     return RNDE_OK;
 }
 

@@ -34,6 +34,7 @@ enum { BM_START = 0, BM_STAGE = 1 };
 template <int ACT2, int MODE>
 __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_kernel(const BStageParams Q, const int n, const int j, const StepMeta m,
                                                                    const float eig_c1, const float eig_c2, const int sv_lo, const int sv_hi) {
+#pragma clang fp contract(off)   // rounds exactly like rnde_bstage_attempt_kernel (rnde_bstage_persist.h): outputs are compared bit for bit
     const BwdParams& Bq = Q.B;
     const StepParams& P = Bq.F;
     extern __shared__ __attribute__((aligned(16))) float smem[];

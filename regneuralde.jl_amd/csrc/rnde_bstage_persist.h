@@ -1,0 +1,379 @@
+// rnde_bstage_persist.h -- reverse pass of one attempted step of the stage engine as ONE launch (mirror of
+// rnde_stage_persist.h): BM_START and the six BM_STAGE launches of rnde_bstage_kernel fused, with the hbar slab handed
+// between the row blocks of a column tile through the XCD's L2 (persist_signal / persist_wait).
+//   * weights (W1x^T rows, [W2x^T; w2t^T] K-slices) are loaded once; utilde-bar, unew-bar, the uprev-bar seed, the six
+//     gbar_s, the dense-output weights W_i and the stiffness extras never leave registers (the multi-launch kernels
+//     round-trip them through HBM: UTB/UNB/UPB0/GB/SVW/EXK/EXG);
+//   * the tape operands of stage j (h_j, k_{j-1}) are requested before waiting for the hand-off of stage j;
+//   * what remains a kernel boundary is what the algorithm needs: dt-bar of attempt n+1 is a sum over ALL workgroups.
+// Same arithmetic in the same order as rnde_bstage_kernel (both are compiled with contraction off), so cotangents are
+// bit-identical (tests/test_gpu_forward.py::test_persistent_attempt_is_bit_identical).
+#pragma once
+#include "rnde_bstage.h"
+#include "rnde_stage_persist.h"
+
+namespace rnde {
+
+template <int ACT2>
+__global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const BStageParams Q, const int n, const StepMeta m, const float eig_c1,
+                                                                          const float eig_c2, const int sv_lo, const int sv_hi, const PersistSync Y) {
+#pragma clang fp contract(off)
+    const BwdParams& Bq = Q.B;
+    const StepParams& P = Bq.F;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int KZ = 16 * Q.KHb + 4, KG = 16 * Q.WT + 4;
+    float* ZL = smem;
+    float* GL = ZL + kSCB * KZ;
+    float* RED = GL + kSCB * KG;         // [32]; RED[31]: persist_wait
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rb = (blockIdx.x >> 3) % Q.R, ct = 8 * ((blockIdx.x >> 3) / Q.R) + (blockIdx.x & 7);   // see rnde_stage_persist.h
+    if (ct >= Q.C) return;
+    const int wg = rb * Q.C + ct;
+    const int col = lane & 15, gcol = ct * kSCB + col;
+    const bool colok = gcol < P.B;
+    const bool vec = (P.D & 3) == 0;
+    const bool writer = (wg == 0 && tid == 0);
+    const int T = rb * Q.WT + w;
+    const int r0 = 16 * T + 4 * (lane >> 4);
+    const bool tile_ok = T < Q.MT;
+    const long long A = (long long)P.D * P.Bpad;
+    const RecLayout L{A, (long long)P.H * P.Bpad};
+    const bool first = (n == Bq.n_att - 1);
+    const size_t co = (size_t)gcol * P.D;
+    if (tid == 0) Y.xcc[wg] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15;
+
+    f32x4 wB[kSMaxHT], wD[kSMaxW];
+#pragma unroll
+    for (int kb = 0; kb < kSMaxHT; ++kb)
+        if (kb < Q.KHb && tile_ok) wB[kb] = Q.pwBt[((size_t)T * Q.KHb + kb) * 64 + lane];
+#pragma unroll
+    for (int kb = 0; kb < kSMaxW; ++kb)
+        if (kb < Q.WT && w < Q.HT && rb * Q.WT + kb < Q.MT) wD[kb] = Q.pwDt[((size_t)w * Q.MT + rb * Q.WT + kb) * 64 + lane];
+    float* R = P.arena + (long long)m.rec * P.rec_stride;
+    float w1t_own[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int hr = 16 * w + 4 * (lane >> 4) + i;
+        if (hr < P.H) w1t_own[i] = Q.p[(size_t)P.H * P.D + hr];
+    }
+    const float* W1t = Q.p + (size_t)P.H * P.D;
+    const bool accepted = (m.flags & F_ACCEPT) != 0;
+    const float dt = m.dt;
+    const float* upsrc = P.x; const float* k1p = P.f0; bool upok = colok, upvec = P.xvec != 0;
+    if (m.src >= 0) { const float* Rl = P.arena + (long long)m.src * P.rec_stride; upsrc = Rl + L.unew(); k1p = Rl + L.k(7); upok = true; upvec = vec; }
+    const bool has_eig = (eig_c1 != 0.f || eig_c2 != 0.f);
+    const bool has_sv = sv_hi > sv_lo;
+
+    // per-stage partials {S, tau, exdt}: index 0 = START, 1..6 = stage j = 6..1 (reduced at the end in launch order)
+    float pS[7], pT[7], pX[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { pS[i] = 0.f; pT[i] = 0.f; pX[i] = 0.f; }
+
+    // values that the multi-launch kernels pass through HBM between the launches of an attempt
+    f32x4 utb = {0.f, 0.f, 0.f, 0.f}, unb = {0.f, 0.f, 0.f, 0.f}, upb0 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 exk = {0.f, 0.f, 0.f, 0.f}, exg = {0.f, 0.f, 0.f, 0.f}, Wv[7], gbs[6];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) Wv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) gbs[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto phase_d = [&](const f32x4& v, int par, unsigned ex) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) GL[col * KG + kperm(16 * w + 4 * (lane >> 4) + i)] = tile_ok ? v[i] : 0.f;
+        __syncthreads();
+        f32x4* sl = (f32x4*)Q.slab + ((((size_t)par * Q.C + ct) * Q.R + rb) * Q.HT) * 64;
+        const float* gbp = GL + col * KG + 4 * (lane >> 4);
+        f32x4 bg[kSMaxW];
+#pragma unroll
+        for (int kb = 0; kb < kSMaxW; ++kb) if (kb < Q.WT) bg[kb] = *(const f32x4*)(gbp + 16 * kb);
+        if (w < Q.HT) {
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < kSMaxW; ++kb) {
+                if (kb < Q.WT && rb * Q.WT + kb < Q.MT) {
+                    acc0 = mfma16(wD[kb][0], bg[kb][0], acc0);
+                    acc1 = mfma16(wD[kb][1], bg[kb][1], acc1);
+                    acc0 = mfma16(wD[kb][2], bg[kb][2], acc0);
+                    acc1 = mfma16(wD[kb][3], bg[kb][3], acc1);
+                }
+            }
+            sl[(size_t)w * 64 + lane] = acc0 + acc1;
+        }
+        for (int ht = w + Q.WT; ht < Q.HT; ht += Q.WT) {
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < kSMaxW; ++kb) {
+                if (kb < Q.WT && rb * Q.WT + kb < Q.MT) {
+                    const f32x4 a = Q.pwDt[((size_t)ht * Q.MT + rb * Q.WT + kb) * 64 + lane];
+                    acc0 = mfma16(a[0], bg[kb][0], acc0);
+                    acc1 = mfma16(a[1], bg[kb][1], acc1);
+                    acc0 = mfma16(a[2], bg[kb][2], acc0);
+                    acc1 = mfma16(a[3], bg[kb][3], acc1);
+                }
+            }
+            sl[(size_t)ht * 64 + lane] = acc0 + acc1;
+        }
+        persist_signal(Y, ct, rb, Y.seq_base + ex, tid);
+    };
+
+    // ================= BM_START =================
+    {
+#pragma clang fp contract(off)
+        double tb = 0, dtpb = 0, qoldb = 0, t1b = 0, t0b = 0;
+        if (!first) finish_attempt_scalars(Bq, n + 1, lane, tb, dtpb, qoldb, t1b, t0b);
+        float coef;
+        {
+            const double N = (double)P.D * (double)P.B;
+            double eb = 0, dtb_pre = 0, q11b = 0, qb = 0, qoldb_in = 0;
+            if (accepted) {
+                const bool err_term = Bq.reg_kind == 1 || (Bq.reg_kind == 3 && !(m.eest * dt == 0.f));
+                if (err_term) { const double sb = (double)Bq.svb_att[n]; eb += sb * (double)dt; dtb_pre += sb * (double)m.eest; }
+                dtb_pre += tb;
+                if (m.flags & F_DTMAXCLAMP) { t1b += dtpb; t0b -= dtpb; }
+                else if (Bq.track_ctrl) { dtb_pre += dtpb / (double)m.q; qb += -dtpb * (double)dt / ((double)m.q * (double)m.q); }
+                if (m.eest > kQoldInit) eb += qoldb;
+            } else {
+                dtb_pre += dtpb / (double)m.rej_m;
+                if (m.flags & F_REJQ11) q11b += -dtpb * (double)dt / ((double)m.rej_m * (double)m.rej_m) / (double)kGamma;
+                qoldb_in = qoldb;
+            }
+            if (!(m.flags & F_QCLAMP) && !(m.flags & F_EZERO)) {
+                const double qo = pow((double)m.qold_in, (double)kBeta2);
+                q11b += qb / (qo * (double)kGamma);
+                qoldb_in += -(double)kBeta2 * qb * (double)m.q / (double)m.qold_in;
+            }
+            if (!(m.flags & F_EZERO) && m.eest > 0.f) eb += q11b * (double)kBeta1 * (double)m.q11 / (double)m.eest;
+            coef = m.eest > 0.f ? (float)(eb / (N * (double)m.eest)) : 0.f;
+            if (writer) { BState b; b.tb_pre = tb; b.dtb_pre = dtb_pre; b.qoldb = qoldb_in; b.t1b = t1b; b.t0b = t0b; b.pad[0] = b.pad[1] = b.pad[2] = 0; Bq.bstate[n & 1] = b; }
+        }
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        float S = 0.f, tau = 0.f, exdt = 0.f;
+        if (tile_ok) {
+            const f32x4 upv = ld4(upsrc + co, r0, P.D, upok, upvec);
+            const f32x4 unv = ld4(R + L.unew() + co, r0, P.D, true, vec);
+            f32x4 kq[7];
+            kq[0] = ld4(k1p + co, r0, P.D, true, vec);
+#pragma unroll
+            for (int s = 2; s <= 7; ++s) kq[s - 1] = ld4(R + L.k(s) + co, r0, P.D, true, vec);
+            f32x4 acc = tsBt(0) * kq[0], g6 = tsA(5, 0) * kq[0];
+#pragma unroll
+            for (int s = 1; s < 7; ++s) { acc += tsBt(s) * kq[s]; if (s < 5) g6 += tsA(5, s) * kq[s]; }
+            const f32x4 k6 = kq[5], k7 = kq[6];
+            f32x4 uin = {0.f, 0.f, 0.f, 0.f}, k1in = {0.f, 0.f, 0.f, 0.f};
+            const bool sv_mode = Q.nsave > 0;
+            if (accepted) {
+                if (!first) { uin = ld4(Bq.U + co, r0, P.D, true, vec); k1in = ld4(Bq.K1 + co, r0, P.D, true, vec); }
+                else if (!sv_mode) uin = ld4(Bq.ubar + co, r0, P.D, colok, false);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float ut = dt * acc[i];
+                const float au = fabsf(upv[i]), an = fabsf(unv[i]);
+                const bool use_new = !(au > an);
+                const float sk = P.abstol + (use_new ? an : au) * P.reltol;
+                const float r = ut / sk;
+                const float rb_ = colok ? coef * r : 0.f;
+                const float skb = -rb_ * r / sk;
+                utb[i] = rb_ / sk;
+                unb[i] = uin[i] + (use_new ? skb * P.reltol * sgnf(unv[i]) : 0.f);
+                upb0[i] = use_new ? 0.f : skb * P.reltol * sgnf(upv[i]);
+            }
+            f32x4 w7 = {0.f, 0.f, 0.f, 0.f};
+            if (has_sv) {
+                const float tnew = m.t + dt;
+                for (int idx = sv_lo; idx < sv_hi; ++idx) {
+                    const float ts = Q.sv_t[idx];
+                    const f32x4 ub = ld4(Q.sv_ubar + ((size_t)gcol * Q.nsave + idx) * P.D, r0, P.D, colok, vec);
+                    if (ts == tnew) { unb += ub; continue; }
+                    const float th = (ts - m.t) / dt;
+                    float bw[7], dbw[7];
+                    dense_weights(th, bw);
+                    dense_weights_deriv(th, dbw);
+                    upb0 += ub;
+                    f32x4 dacc = dbw[0] * kq[0];
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) { Wv[i] += bw[i] * ub; if (i) dacc += dbw[i] * kq[i]; }
+                    float dth = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dth += ub[i] * dt * dacc[i];
+                    tau += -dth / dt;
+                    exdt += -dth * th / dt;
+                }
+                w7 = Wv[6];
+            }
+            f32x4 kb7 = dt * (tsBt(6) * utb + w7);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) S += k7[i] * kb7[i];
+            kb7 += k1in;
+            if (has_eig) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool ok = colok && (r0 + i < P.D);
+                    const float d1 = k7[i] - k6[i], d2 = unv[i] - (upv[i] + dt * g6[i]);
+                    kb7[i] += ok ? eig_c1 * d1 : 0.f;
+                    exk[i] = ok ? -eig_c1 * d1 : 0.f;
+                    unb[i] += ok ? eig_c2 * d2 : 0.f;
+                    exg[i] = ok ? -eig_c2 * d2 : 0.f;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = (r0 + i < P.D) ? (ACT2 ? kb7[i] * (1.f - k7[i] * k7[i]) : kb7[i]) : 0.f;
+            st4(R + L.k(7) + co, r0, P.D, true, vec, v);
+        }
+        if (!colok) { tau = 0.f; exdt = 0.f; }
+        pS[0] = S; pT[0] = tau; pX[0] = exdt;
+        phase_d(v, 0, 1u);
+    }
+
+    bool alive = true;
+    // ================= BM_STAGE j = 6..1 =================
+    auto stage = [&](auto jc) {
+#pragma clang fp contract(off)
+        constexpr int j = decltype(jc)::value;
+        if (!alive) return;
+        // tape operands of this stage: independent of the hand-off, so request them first
+        float h_own[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int hr = 16 * w + 4 * (lane >> 4) + i;
+            if (hr < P.H) h_own[i] = (R + L.h(j + 1))[(size_t)gcol * P.H + hr];
+        }
+        f32x4 c_ks = {0.f, 0.f, 0.f, 0.f};
+        if (tile_ok) c_ks = (j >= 2) ? ld4(R + L.k(j) + co, r0, P.D, true, vec) : ld4(k1p + co, r0, P.D, true, vec);
+        if (!persist_wait(Y, ct, Q.R, Y.seq_base + (unsigned)(7 - j), w, lane, RED)) { alive = false; return; }
+        float S = 0.f, tau = 0.f;
+        // ---- phase A ----
+        const f32x4* sl = (const f32x4*)Q.slab + (((size_t)(j & 1) * Q.C + ct) * Q.R) * Q.HT * 64;
+        f32x4 zs = {0.f, 0.f, 0.f, 0.f};
+        if (w < Q.HT) {
+            f32x4 zr[kSMaxW];
+#pragma unroll
+            for (int r = 0; r < kSMaxW; ++r) if (r < Q.R) zr[r] = sl[((size_t)r * Q.HT + w) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < kSMaxW; ++r) if (r < Q.R) zs += zr[r];
+            for (int r = kSMaxW; r < Q.R; ++r) zs += sl[((size_t)r * Q.HT + w) * 64 + lane];
+        }
+        const float* hsrc = R + L.h(j + 1);
+        float* z1dst = R + L.z1(j + 1);
+        for (int ht = w; ht < Q.HT; ht += Q.WT) {
+            f32x4 z = zs;
+            if (ht != w) {
+                z = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int r = 0; r < Q.R; ++r) z += sl[((size_t)r * Q.HT + ht) * 64 + lane];
+            }
+            const int h0 = 16 * ht + 4 * (lane >> 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int hr = h0 + i;
+                float zv = 0.f;
+                if (hr < P.H) {
+                    const float hv = (ht == w) ? h_own[i] : hsrc[(size_t)gcol * P.H + hr];
+                    zv = z[i] * (1.f - hv * hv);
+                    if (rb == 0) { z1dst[(size_t)gcol * P.H + hr] = zv; tau += ((ht == w) ? w1t_own[i] : W1t[hr]) * zv; }
+                } else if (hr == P.H) {
+                    if (rb == 0) tau += z[i];
+                }
+                if (hr < 16 * Q.KHb) ZL[col * KZ + kperm(hr)] = zv;
+            }
+        }
+        if (Q.KHb > Q.HT) {
+            for (int i = tid; i < kSCB * 16 * Q.KHb; i += blockDim.x) {
+                const int c = i / (16 * Q.KHb), k = i - c * 16 * Q.KHb;
+                if (k >= 16 * Q.HT) ZL[c * KZ + kperm(k)] = 0.f;
+            }
+        }
+        __syncthreads();
+        // ---- phase B ----
+        f32x4 gb = {0.f, 0.f, 0.f, 0.f};
+        if (tile_ok) {
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            const float* zb = ZL + col * KZ + 4 * (lane >> 4);
+            f32x4 bf[kSMaxHT];
+#pragma unroll
+            for (int kb = 0; kb < kSMaxHT; ++kb) if (kb < Q.KHb) bf[kb] = *(const f32x4*)(zb + 16 * kb);
+#pragma unroll
+            for (int kb = 0; kb < kSMaxHT; ++kb) {
+                if (kb < Q.KHb) {
+                    acc0 = mfma16(wB[kb][0], bf[kb][0], acc0);
+                    acc1 = mfma16(wB[kb][1], bf[kb][1], acc1);
+                    acc0 = mfma16(wB[kb][2], bf[kb][2], acc0);
+                    acc1 = mfma16(wB[kb][3], bf[kb][3], acc1);
+                }
+            }
+            gb = acc0 + acc1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (r0 + i >= P.D) gb[i] = 0.f;
+        }
+        // ---- phase C ----
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (tile_ok) {
+            if (has_eig && j == 5) gb += exg;
+            gbs[j - 1] = gb;
+            if (j == 6) unb += gb;
+            constexpr int jn = j - 1;
+            f32x4 kbar = tsA_rt(6, jn) * unb + kTsBt[jn] * utb;
+#pragma unroll
+            for (int s = 1; s <= 5; ++s) {
+                if (s > jn) kbar += tsA_rt(s, jn) * gbs[s - 1];
+            }
+            if (has_sv) kbar += Wv[jn];
+            kbar = dt * kbar;
+            if constexpr (jn >= 1) {
+                const f32x4 ks = c_ks;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) S += ks[i] * kbar[i];
+                if (has_eig && j == 6) kbar += exk;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = (r0 + i < P.D) ? (ACT2 ? kbar[i] * (1.f - ks[i] * ks[i]) : kbar[i]) : 0.f;
+                st4(R + L.k(jn + 1) + co, r0, P.D, true, vec, v);
+            } else {
+                const f32x4 k1v = c_ks;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) S += k1v[i] * kbar[i];
+                f32x4 uo = upb0 + unb;
+#pragma unroll
+                for (int s = 1; s <= 5; ++s) uo += gbs[s - 1];
+                f32x4 ko = kbar;
+                if (!accepted) {
+                    uo += first ? ld4(Bq.ubar + co, r0, P.D, colok, false) : ld4(Bq.U + co, r0, P.D, true, vec);
+                    if (!first) ko += ld4(Bq.K1 + co, r0, P.D, true, vec);
+                }
+                st4(Bq.U + co, r0, P.D, true, vec, uo);
+                st4(Bq.K1 + co, r0, P.D, true, vec, ko);
+            }
+        }
+        if (!colok) tau = 0.f;
+        pS[7 - j] = S; pT[7 - j] = tau;
+        if constexpr (j > 1) phase_d(v, (j - 1) & 1, (unsigned)(7 - j + 1));
+    };
+    stage(std::integral_constant<int, 6>{});
+    stage(std::integral_constant<int, 5>{});
+    stage(std::integral_constant<int, 4>{});
+    stage(std::integral_constant<int, 3>{});
+    stage(std::integral_constant<int, 2>{});
+    stage(std::integral_constant<int, 1>{});
+    if (!alive) return;
+
+    // ---- per-workgroup partials {S, tau, sum_j c_j tau_j (+ saveat dt-bar)}: same reduction order as the 7 launches ----
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const float a = wave_sum_f(pS[i]), b = wave_sum_f(pT[i]), c = wave_sum_f(pX[i]);
+        if (lane == 0) { GL[(i * 3 + 0) * 8 + w] = a; GL[(i * 3 + 1) * 8 + w] = b; GL[(i * 3 + 2) * 8 + w] = c; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+        for (int i = 0; i < 7; ++i) {
+            float sa = 0.f, ta = 0.f, xa = 0.f;
+            for (int q = 0; q < Q.WT; ++q) { sa += GL[(i * 3 + 0) * 8 + q]; ta += GL[(i * 3 + 1) * 8 + q]; xa += GL[(i * 3 + 2) * 8 + q]; }
+            if (i == 0) { o0 = sa; o1 = ta; o2 = xa; }
+            else { o0 += sa; o1 += ta; o2 += kTsC[7 - i] * ta; }
+        }
+        float* o = Bq.bpart + ((size_t)(n & 1) * Bq.bpart_n + wg) * 4;
+        o[0] = o0; o[1] = o1; o[2] = o2; o[3] = 0.f;
+    }
+}
+
+}  // namespace rnde

@@ -39,7 +39,7 @@ struct rnde_node {
     float* head_ws = nullptr; size_t head_ws_floats = 0;   // fused classifier head scratch
     float* sv_t_dev = nullptr; size_t sv_cap = 0; std::vector<float> saveat;   // saveat times of the last forward
     // persistent attempt kernel (rnde_stage_persist.h): 1 = in use, 0 = off (RNDE_PERSIST=0), -1 = disabled after a failure
-    int persist = 0; unsigned persist_seq = 0; unsigned *pflags = nullptr, *pabort = nullptr, *pxcc = nullptr; unsigned* h_pchk = nullptr;
+    int persist = 0; unsigned persist_seq = 0; float* tslab = nullptr; unsigned *pabort = nullptr, *pxcc = nullptr; unsigned* h_pchk = nullptr;
     hipStream_t wstream = nullptr;        // (experimental overlap path of the weight-gradient GEMMs)
     std::vector<hipEvent_t> wevents;
     // device
@@ -296,7 +296,8 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
     ok &= dm((void**)&h->spwB, (size_t)h->sMT * h->sK2b * 64 * 16) && dm((void**)&h->spwD, (size_t)h->sHT * h->sMT * 64 * 16);
     ok &= dm((void**)&h->spwBt, (size_t)h->sMT * h->sKHb * 64 * 16) && dm((void**)&h->spwDt, (size_t)h->sHT * h->sMT * 64 * 16);
     ok &= dm((void**)&h->slab2, (size_t)2 * (h->Bpad_max / 16) * h->sR * h->sHT * 64 * 16);
-    ok &= dm((void**)&h->pflags, (size_t)(h->Bpad_max / 16) * 8 * 4) && dm((void**)&h->pabort, 8) && dm((void**)&h->pxcc, (size_t)h->nwg_max * 4);
+    const size_t tslab_bytes = (size_t)2 * (h->Bpad_max / 16) * h->sR * h->sHT * 128 * 16;   // tagged slabs: two 16-byte entries per lane
+    ok &= dm((void**)&h->tslab, tslab_bytes) && dm((void**)&h->pabort, 8) && dm((void**)&h->pxcc, (size_t)h->nwg_max * 4);
     ok &= hipHostMalloc((void**)&h->h_pchk, ((size_t)h->nwg_max + 2) * 4) == hipSuccess;
     ok &= dm((void**)&h->ctl, 2 * sizeof(StepState)) && dm((void**)&h->ctl_final, sizeof(StepState));
     ok &= dm((void**)&h->meta, (size_t)(c->max_attempts + 1) * sizeof(StepMeta)) && dm((void**)&h->initrec, sizeof(InitRec));
@@ -310,7 +311,7 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
     ok &= hipHostMalloc((void**)&h->h_scal, 64 * sizeof(float)) == hipSuccess;
     if (!ok) { g_create_err = "device allocation failed"; rnde_node_destroy(h); return RNDE_ERR_HIP; }
     hipMemset(h->initrec, 0, sizeof(InitRec));
-    hipMemset(h->pflags, 0, (size_t)(h->Bpad_max / 16) * 8 * 4); hipMemset(h->pabort, 0, 8); hipMemset(h->pxcc, 0, (size_t)h->nwg_max * 4);
+    hipMemset(h->tslab, 0, tslab_bytes); hipMemset(h->pabort, 0, 8); hipMemset(h->pxcc, 0, (size_t)h->nwg_max * 4);
     { const char* e = getenv("RNDE_PERSIST"); h->persist = (h->engine == 2 && h->sR <= 8 && !(e && e[0] == '0')) ? 1 : 0; }
     h->predicted = 12;
     *out = h;
@@ -326,7 +327,7 @@ extern "C" void rnde_node_destroy(rnde_node* h) {
     if (h->head_ws) hipFree(h->head_ws);
     if (h->sv_t_dev) hipFree(h->sv_t_dev);
     if (h->cfrags) hipFree(h->cfrags);
-    if (h->pflags) hipFree(h->pflags);
+    if (h->tslab) hipFree(h->tslab);
     if (h->pabort) hipFree(h->pabort);
     if (h->pxcc) hipFree(h->pxcc);
     if (h->h_pchk) hipHostFree(h->h_pchk);
@@ -390,7 +391,7 @@ static rnde_status stage_pack_weights(rnde_node* h, const float* p_dev, hipStrea
 }
 static hipError_t stage_attempt(rnde_node* h, const StageParams& Q, int n, hipStream_t s) {
     if (h->persist == 1) {   // one launch per attempt, slab hand-offs inside the kernel (rnde_stage_persist.h)
-        PersistSync Y{h->pflags, h->pabort, h->pxcc, h->persist_seq};
+        PersistSync Y{h->tslab, h->pabort, h->pxcc, h->persist_seq};
         h->persist_seq += 8;
         const dim3 grid(8 * Q.R * ((Q.C + 7) / 8));   // a column tile's row blocks share blockIdx % 8 (same XCD)
         if (h->act2) hipLaunchKernelGGL((rnde_stage_attempt_kernel<1>), grid, dim3(64 * Q.WT), h->stage_lds, s, Q, n, Y);
@@ -701,6 +702,7 @@ extern "C" rnde_status rnde_debug_attempt(rnde_node* h, const float* uprev_dev, 
         HIPCHK(h, hipMemcpyAsync(k_out_dev + (size_t)(sidx - 2) * h->D * B, R + L.k(sidx), (size_t)h->D * B * 4, hipMemcpyDeviceToDevice, s));
     HIPCHK(h, hipMemcpyAsync(unew_out_dev, R + L.unew(), (size_t)h->D * B * 4, hipMemcpyDeviceToDevice, s));
     HIPCHK(h, hipStreamSynchronize(s));
+    if (h->engine == 2 && persist_failed(h, h->sR * (P.Bpad / 16), P.Bpad / 16, h->sR, s)) { h->err = "persistent attempt kernel abandoned its hand-off; call again (multi-launch kernels now in use)"; return RNDE_ERR_HIP; }
     if (eest_out) *eest_out = h->h_ctl->last_eest;
     return RNDE_OK;
 }
@@ -759,6 +761,15 @@ extern "C" rnde_status rnde_bench_attempt(rnde_node* h, const float* x_dev, cons
             fprintf(stderr, " | tail %lld total %lld\n", (long long)(hst[10]-hst[9]), (long long)(hst[10]-hst[0]));
             for (int l = 0; l < h->cg.n_layers; ++l) fprintf(stderr, "  layer %d: bias %lld mm %lld act %lld (gap to next %lld)\n", l, (long long)(hst[17+4*l]-hst[16+4*l]), (long long)(hst[18+4*l]-hst[17+4*l]), (long long)(hst[19+4*l]-hst[18+4*l]), l + 1 < h->cg.n_layers ? (long long)(hst[20+4*l]-hst[19+4*l]) : 0LL);
             hipFree(d); return RNDE_OK; }
+        if (h->engine == 2 && h->persist == 1) {
+            SQ.F.dbg_out = (float*)d; stage_attempt(h, SQ, 0, s); hipStreamSynchronize(s);
+            hipMemcpy(hst, d, sizeof(hst), hipMemcpyDeviceToHost); hipFree(d);
+            fprintf(stderr, "persistent attempt (workgroup 0 thread 0, cycles): prologue(weights) %lld ctl %lld startC %lld startD %lld\n", 0LL, (long long)(hst[1]-hst[0]), (long long)(hst[2]-hst[1]), (long long)(hst[3]-hst[2]));
+            for (int st = 1; st <= 6; ++st) { const unsigned long long* q = hst + 4 + 5 * (st - 1); const unsigned long long prev = st == 1 ? hst[3] : hst[8 + 5 * (st - 2)];
+                if (st < 6) fprintf(stderr, "  stage %d: poll %lld A %lld B %lld C %lld D+put %lld\n", st, (long long)(q[0]-prev), (long long)(q[1]-q[0]), (long long)(q[2]-q[1]), (long long)(q[3]-q[2]), (long long)(q[4]-q[3]));
+                else fprintf(stderr, "  stage %d: poll %lld A %lld B %lld C+err %lld | total %lld cycles\n", st, (long long)(q[0]-prev), (long long)(q[1]-q[0]), (long long)(q[2]-q[1]), (long long)(hst[34]-q[2]), (long long)(hst[34]-hst[0])); }
+            return RNDE_OK;
+        }
         if (h->engine == 2) { SQ.F.dbg_out = (float*)d; stage_attempt(h, SQ, 0, s); } else launch_step<MODE_STEP>(h, P, 0, s);
         hipStreamSynchronize(s);
         hipMemcpy(hst, d, sizeof(hst), hipMemcpyDeviceToHost); hipFree(d);
@@ -969,7 +980,7 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
                 }
             }
             if (h->persist == 1) {   // the attempt's 7 reverse launches as one (rnde_bstage_persist.h)
-                PersistSync Y{h->pflags, h->pabort, h->pxcc, h->persist_seq};
+                PersistSync Y{h->tslab, h->pabort, h->pxcc, h->persist_seq};
                 h->persist_seq += 8;
                 const dim3 pgrid(8 * BQ.R * ((BQ.C + 7) / 8));
                 if (h->act2) hipLaunchKernelGGL((rnde_bstage_attempt_kernel<1>), pgrid, blk, h->stage_lds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y);

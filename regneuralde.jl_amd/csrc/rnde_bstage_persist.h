@@ -1,6 +1,6 @@
 // rnde_bstage_persist.h -- reverse pass of one attempted step of the stage engine as ONE launch (mirror of
 // rnde_stage_persist.h): BM_START and the six BM_STAGE launches of rnde_bstage_kernel fused, with the hbar slab handed
-// between the row blocks of a column tile through the XCD's L2 (persist_signal / persist_wait).
+// between the row blocks of a column tile through the XCD's L2 (slab_put / slab_poll_sum).
 //   * weights (W1x^T rows, [W2x^T; w2t^T] K-slices) are loaded once; utilde-bar, unew-bar, the uprev-bar seed, the six
 //     gbar_s, the dense-output weights W_i and the stiffness extras never leave registers (the multi-launch kernels
 //     round-trip them through HBM: UTB/UNB/UPB0/GB/SVW/EXK/EXG);
@@ -24,7 +24,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
     const int KZ = 16 * Q.KHb + 4, KG = 16 * Q.WT + 4;
     float* ZL = smem;
     float* GL = ZL + kSCB * KZ;
-    float* RED = GL + kSCB * KG;         // [32]; RED[31]: persist_wait
+    float* RED = GL + kSCB * KG;         // [32]; RED[24..31]: per-wave "gave up" flags of the hand-off
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rb = (blockIdx.x >> 3) % Q.R, ct = 8 * ((blockIdx.x >> 3) / Q.R) + (blockIdx.x & 7);   // see rnde_stage_persist.h
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
 #pragma unroll
         for (int i = 0; i < 4; ++i) GL[col * KG + kperm(16 * w + 4 * (lane >> 4) + i)] = tile_ok ? v[i] : 0.f;
         __syncthreads();
-        f32x4* sl = (f32x4*)Q.slab + ((((size_t)par * Q.C + ct) * Q.R + rb) * Q.HT) * 64;
+        const size_t tile0 = (((size_t)par * Q.C + ct) * Q.R + rb) * Q.HT;
         const float* gbp = GL + col * KG + 4 * (lane >> 4);
         f32x4 bg[kSMaxW];
 #pragma unroll
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
                     acc1 = mfma16(wD[kb][3], bg[kb][3], acc1);
                 }
             }
-            sl[(size_t)w * 64 + lane] = acc0 + acc1;
+            slab_put(Y.tslab, tile0 + w, lane, acc0 + acc1, Y.seq_base + ex);
         }
         for (int ht = w + Q.WT; ht < Q.HT; ht += Q.WT) {
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -112,9 +112,8 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
                     acc1 = mfma16(a[3], bg[kb][3], acc1);
                 }
             }
-            sl[(size_t)ht * 64 + lane] = acc0 + acc1;
+            slab_put(Y.tslab, tile0 + ht, lane, acc0 + acc1, Y.seq_base + ex);
         }
-        persist_signal(Y, ct, rb, Y.seq_base + ex, tid);
     };
 
     // ================= BM_START =================
@@ -241,27 +240,17 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
         }
         f32x4 c_ks = {0.f, 0.f, 0.f, 0.f};
         if (tile_ok) c_ks = (j >= 2) ? ld4(R + L.k(j) + co, r0, P.D, true, vec) : ld4(k1p + co, r0, P.D, true, vec);
-        if (!persist_wait(Y, ct, Q.R, Y.seq_base + (unsigned)(7 - j), w, lane, RED)) { alive = false; return; }
         float S = 0.f, tau = 0.f;
-        // ---- phase A ----
-        const f32x4* sl = (const f32x4*)Q.slab + (((size_t)(j & 1) * Q.C + ct) * Q.R) * Q.HT * 64;
+        // ---- phase A: poll this wave's hidden tile of the R row blocks (the polling load is the data load) ----
+        const unsigned tag = Y.seq_base + (unsigned)(7 - j);
+        bool dead = false;
         f32x4 zs = {0.f, 0.f, 0.f, 0.f};
-        if (w < Q.HT) {
-            f32x4 zr[kSMaxW];
-#pragma unroll
-            for (int r = 0; r < kSMaxW; ++r) if (r < Q.R) zr[r] = sl[((size_t)r * Q.HT + w) * 64 + lane];
-#pragma unroll
-            for (int r = 0; r < kSMaxW; ++r) if (r < Q.R) zs += zr[r];
-            for (int r = kSMaxW; r < Q.R; ++r) zs += sl[((size_t)r * Q.HT + w) * 64 + lane];
-        }
+        if (w < Q.HT) dead = !slab_poll_sum(Y, j & 1, Q.C, Q.R, Q.HT, ct, w, lane, tag, zs);
         const float* hsrc = R + L.h(j + 1);
         float* z1dst = R + L.z1(j + 1);
         for (int ht = w; ht < Q.HT; ht += Q.WT) {
             f32x4 z = zs;
-            if (ht != w) {
-                z = (f32x4){0.f, 0.f, 0.f, 0.f};
-                for (int r = 0; r < Q.R; ++r) z += sl[((size_t)r * Q.HT + ht) * 64 + lane];
-            }
+            if (ht != w && !dead) dead = !slab_poll_sum(Y, j & 1, Q.C, Q.R, Q.HT, ct, ht, lane, tag, z);
             const int h0 = 16 * ht + 4 * (lane >> 4);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -283,7 +272,13 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
                 if (k >= 16 * Q.HT) ZL[c * KZ + kperm(k)] = 0.f;
             }
         }
+        if (lane == 0) RED[24 + w] = dead ? 1.f : 0.f;
         __syncthreads();
+        {
+            float any = 0.f;
+            for (int q = 0; q < Q.WT; ++q) any += RED[24 + q];
+            if (any != 0.f) { alive = false; return; }
+        }
         // ---- phase B ----
         f32x4 gb = {0.f, 0.f, 0.f, 0.f};
         if (tile_ok) {

@@ -7,10 +7,10 @@
 //   * weights (this block's 1/R slice, 64 VGPRs per lane) and the attempt's own k_1..k_6 / uprev rows stay in registers;
 //   * the slab hand-off happens inside the kernel between the R workgroups of a column tile.  They have the same
 //     blockIdx % 8, hence sit on the same XCD (round-robin dispatch; verified at run time from HW_REG_XCC_ID) and share its
-//     L2: producer = slab stores, workgroup-scope release (s_waitcnt vmcnt(0): the write-through stores are in L2),
-//     barrier, relaxed agent-scope flag store; consumer = one wave polls the R flags with L1-bypassing loads, agent-scope
-//     acquire (buffer_inv sc1), barrier, plain loads.  Measured 3.1 us per hand-off (tools/micro/cluster_sync.hip).
-//     No L2 write-back is involved, which is what would make an agent-scope release slow on a multi-XCD part;
+//     L2.  A flag-based protocol (stores, release, barrier, flag; poll, acquire, barrier, loads) costs 3.1 us per
+//     hand-off (tools/micro/cluster_sync.hip: four dependent L2 round trips); the tagged entries below carry validity in
+//     the data itself and need about half of that.  No L2 write-back is involved in either, which is what makes an
+//     agent-scope release slow on a multi-XCD part;
 //   * the kernel boundary that remains (one per attempt) is the one the algorithm needs: the global error norm.
 // Arithmetic, association order and tape layout are exactly those of rnde_stage_kernel, so results are bit-identical
 // (tests/test_gpu_forward.py::test_persistent_attempt_is_bit_identical).
@@ -24,41 +24,77 @@
 namespace rnde {
 
 struct PersistSync {
-    unsigned* flags;        // [C][8] sequence numbers, monotonic across launches
-    unsigned* abort_flag;   // [0] abort, [1] placement error (cluster spans XCDs)
-    unsigned* xcc;          // [grid] XCC id of each workgroup (written every launch)
-    unsigned seq_base;
+    float* tslab;           // tagged slabs [2][C][R][HT][2][64] f32x4 (see slab_put / slab_poll)
+    unsigned* abort_flag;   // [0] a hand-off timed out
+    unsigned* xcc;          // [grid] XCC id of each workgroup (written every launch, checked by the host)
+    unsigned seq_base;      // exchange tags are seq_base + 1..6; the host adds 8 per launch
 };
 
-constexpr int kPersistMaxSpins = 200000;
+constexpr int kPersistMaxSpins = 100000;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void persist_signal(const PersistSync& Y, int ct, int rb, unsigned seq, int tid) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's slab stores have reached L2
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(Y.flags + ct * 8 + rb, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// ---- tagged slab hand-off -------------------------------------------------------------------------------------------
+// A slab tile (one f32x4 of layer-1 partials per lane) travels as two 16-byte entries {v0, v1, tag, tag}, {v2, v3, tag, tag}:
+// data and validity arrive in the SAME store, so there is no separate flag, no release wait for the store's
+// acknowledgement and no second load after the flag has been seen -- the consumer's polling load is the data load
+// (3.1 us -> ~1.5 us per hand-off).  A 16-byte aligned store of one lane lands in one cache line of the XCD's L2 in one
+// write, and the consumer reads it with agent-scope (sc1: L1-bypassing) loads, so a matching tag implies matching data.
+// Tags are unique per exchange over the life of the handle; buffers alternate by parity, and a producer can only be two
+// exchanges ahead of the slowest consumer of its column tile (it needs that consumer's previous tile to get there).
+__device__ __forceinline__ void slab_put(float* tslab, size_t tile_index, int lane, const f32x4& v, unsigned tag) {
+    const float tf = __builtin_bit_cast(float, tag);
+    f32x4* d = (f32x4*)tslab + tile_index * 128;
+    d[lane] = (f32x4){v[0], v[1], tf, tf};
+    d[64 + lane] = (f32x4){v[2], v[3], tf, tf};
 }
-// returns false when the launch must be abandoned (uniform over the workgroup)
-__device__ __forceinline__ bool persist_wait(const PersistSync& Y, int ct, int R, unsigned seq, int w, int lane, float* RED) {
-    if (w == 0) {
-        unsigned v = seq;
-        int spins = 0;
-        bool dead = false;
-        while (true) {
-            if (lane < R) v = __hip_atomic_load(Y.flags + ct * 8 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const bool ok = (lane >= R) || ((int)(v - seq) >= 0);
-            if (__all(ok)) break;
-            if (++spins > kPersistMaxSpins || __hip_atomic_load(Y.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                __hip_atomic_store(Y.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                dead = true;
-                break;
+// Sum over the R row blocks (fixed order r = 0..R-1, as the multi-launch kernels) of tile `ht` of column tile `ct`;
+// polls until all R entries carry `tag`.  Returns false on time-out / abort (per wave; the caller agrees over the
+// workgroup at its next barrier).
+__device__ __forceinline__ bool slab_poll_sum(const PersistSync& Y, int par, int C, int R, int HT, int ct, int ht, int lane, unsigned tag, f32x4& zs) {
+    const float* base = Y.tslab + ((((size_t)par * C + ct) * R) * HT) * 512;     // R * HT tiles of 128 f32x4 = 512 floats
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+    int spins = 0;
+    while (true) {
+        u32x4 e0[kSMaxW], e1[kSMaxW];
+#pragma unroll
+        for (int r = 0; r < kSMaxW; ++r) {
+            if (r < R) {
+                const int off = ((r * HT + ht) * 128 + lane) * 16;
+                e0[r] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);            // aux 16 = sc1: agent scope, misses L1
+                e1[r] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 1024, 0, 16);
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // drop this CU's L1 lines: the slab addresses are reused every other stage
-        if (lane == 0) RED[31] = dead ? 1.f : 0.f;
+        bool ok = true;
+#pragma unroll
+        for (int r = 0; r < kSMaxW; ++r) if (r < R) ok = ok && e0[r][2] == tag && e0[r][3] == tag && e1[r][2] == tag && e1[r][3] == tag;
+        if (__all(ok)) {
+            // (scalar adds on purpose: the vector form `zs += {bitcast(e0.x), bitcast(e0.y), bitcast(e1.x), bitcast(e1.y)}` is
+            //  miscompiled by this toolchain into v_pk_add_f32 with op_sel_hi:[0,0] -- two of the four sums come out wrong;
+            //  tools/micro/cluster_tagged2.hip checks this helper against a direct sum)
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+            for (int r = 0; r < kSMaxW; ++r) {
+                if (r < R) {
+                    const f32x4 f0 = __builtin_bit_cast(f32x4, e0[r]), f1 = __builtin_bit_cast(f32x4, e1[r]);
+                    s0 += f0[0]; s1 += f0[1]; s2 += f1[0]; s3 += f1[1];
+                }
+            }
+            zs = (f32x4){s0, s1, s2, s3};
+            return true;
+        }
+        if (++spins > kPersistMaxSpins || ((spins & 63) == 0 && __hip_atomic_load(Y.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            __hip_atomic_store(Y.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            zs = (f32x4){0.f, 0.f, 0.f, 0.f};
+            return false;
+        }
     }
-    __syncthreads();
-    return RED[31] == 0.f;
 }
+
+#ifdef RNDE_DIAG
+#define PSTAMP(i) do { if (P.dbg_out && wg == 0 && tid == 0) ((unsigned long long*)P.dbg_out)[i] = clock64(); } while (0)
+#else
+#define PSTAMP(i) do { } while (0)
+#endif
 
 template <int ACT2>
 __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const StageParams Q, const int n, const PersistSync Y) {
@@ -67,7 +103,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
     const int KH = 16 * Q.K2b + 4, KG = 16 * Q.WT + 4;
     float* HL = smem;
     float* GL = HL + kSCB * KH;
-    float* RED = GL + kSCB * KG;         // [32]; RED[31] = abandon flag of persist_wait
+    float* RED = GL + kSCB * KG;         // [32]; RED[24..31] = per-wave "gave up" flags of the hand-off
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     // Workgroup -> (row block, column tile): the R row blocks of a column tile must sit on ONE XCD (they talk through its
@@ -86,6 +122,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
     const RecLayout L{(long long)P.D * P.Bpad, (long long)P.H * P.Bpad};
     if (tid == 0) Y.xcc[wg] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15;   // HW_REG_XCC_ID
 
+    PSTAMP(0);
     // ---- this block's weight slice and the layer-1 bias / time column of this wave's hidden tile: loaded once ----
     f32x4 wB[kSMaxHT], wD[kSMaxW];
 #pragma unroll
@@ -118,6 +155,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
             }
         }
     }
+    PSTAMP(1);
     if (S.done) return;
     const float t = S.t, dt = (!P.forced && (P.t1 - S.t < S.dtp)) ? (P.t1 - S.t) : S.dtp;
     const int live = S.live;
@@ -136,7 +174,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
 #pragma unroll
         for (int i = 0; i < 4; ++i) GL[col * KG + kperm(16 * w + 4 * (lane >> 4) + i)] = (tile_ok && r0 + i < P.D) ? v[i] : 0.f;
         __syncthreads();
-        f32x4* sl = (f32x4*)Q.slab + ((((size_t)par * Q.C + ct) * Q.R + rb) * Q.HT) * 64;
+        const size_t tile0 = (((size_t)par * Q.C + ct) * Q.R + rb) * Q.HT;
         const float* gbp = GL + col * KG + 4 * (lane >> 4);
         f32x4 bg[kSMaxW];
 #pragma unroll
@@ -152,7 +190,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
                     acc1 = mfma16(wD[kb][3], bg[kb][3], acc1);
                 }
             }
-            sl[(size_t)w * 64 + lane] = acc0 + acc1;
+            slab_put(Y.tslab, tile0 + w, lane, acc0 + acc1, Y.seq_base + ex);
         }
         for (int ht = w + Q.WT; ht < Q.HT; ht += Q.WT) {
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -166,9 +204,8 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
                     acc1 = mfma16(a[3], bg[kb][3], acc1);
                 }
             }
-            sl[(size_t)ht * 64 + lane] = acc0 + acc1;
+            slab_put(Y.tslab, tile0 + ht, lane, acc0 + acc1, Y.seq_base + ex);
         }
-        persist_signal(Y, ct, rb, Y.seq_base + ex, tid);
     };
 
     // ---- SM_START's phase C / D ----
@@ -179,7 +216,9 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
             if (P.tape) st4(R + L.g(2) + co, r0, P.D, true, vec, v);
             if (P.tape || P.nsave > 0) { st4(R + L.upc() + co, r0, P.D, true, vec, c_up); st4(R + L.k1c() + co, r0, P.D, true, vec, c_k[0]); }
         }
+        PSTAMP(2);
         phase_d(v, 1, 1u);
+        PSTAMP(3);
     }
 
     float part0 = 0.f, part1 = 0.f, part2 = 0.f;
@@ -188,28 +227,19 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
     auto stage = [&](auto sc) {
         constexpr int s = decltype(sc)::value;
         if (!alive) return;
-        if (!persist_wait(Y, ct, Q.R, Y.seq_base + (unsigned)s, w, lane, RED)) { alive = false; return; }
         const float ts = fmaf(kTsC[s], dt, t);
         float* hdst = R + L.h(s + 1);
         float* kdst = R + L.k(s + 1);
         const int par = s & 1;
-        const f32x4* sl = (const f32x4*)Q.slab + (((size_t)par * Q.C + ct) * Q.R) * Q.HT * 64;
-        // ---- phase A ----
+        const unsigned tag = Y.seq_base + (unsigned)s;
+        // ---- phase A: poll this wave's hidden tile of the R row blocks (the polling load is the data load) ----
+        bool dead = false;
         f32x4 zs = {0.f, 0.f, 0.f, 0.f};
-        if (w < Q.HT) {
-            f32x4 zr[kSMaxW];
-#pragma unroll
-            for (int r = 0; r < kSMaxW; ++r) if (r < Q.R) zr[r] = sl[((size_t)r * Q.HT + w) * 64 + lane];
-#pragma unroll
-            for (int r = 0; r < kSMaxW; ++r) if (r < Q.R) zs += zr[r];
-            for (int r = kSMaxW; r < Q.R; ++r) zs += sl[((size_t)r * Q.HT + w) * 64 + lane];
-        }
+        if (w < Q.HT) dead = !slab_poll_sum(Y, par, Q.C, Q.R, Q.HT, ct, w, lane, tag, zs);
+        PSTAMP(4 + 5 * (s - 1));
         for (int ht = w; ht < Q.HT; ht += Q.WT) {
             f32x4 z = zs;
-            if (ht != w) {
-                z = (f32x4){0.f, 0.f, 0.f, 0.f};
-                for (int r = 0; r < Q.R; ++r) z += sl[((size_t)r * Q.HT + ht) * 64 + lane];
-            }
+            if (ht != w && !dead) dead = !slab_poll_sum(Y, par, Q.C, Q.R, Q.HT, ct, ht, lane, tag, z);
             const int h0 = 16 * ht + 4 * (lane >> 4);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -229,7 +259,14 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
                 if (k >= 16 * Q.HT) HL[c * KH + kperm(k)] = (k == P.H) ? ts : (k == P.H + 1 ? 1.f : 0.f);
             }
         }
+        if (lane == 0) RED[24 + w] = dead ? 1.f : 0.f;
         __syncthreads();
+        {   // a wave that gave up takes the whole workgroup with it (uniform decision after the barrier)
+            float any = 0.f;
+            for (int q = 0; q < Q.WT; ++q) any += RED[24 + q];
+            if (any != 0.f) { alive = false; return; }
+        }
+        PSTAMP(5 + 5 * (s - 1));
         // ---- phase B ----
         f32x4 kv = {0.f, 0.f, 0.f, 0.f};
         if (tile_ok) {
@@ -251,6 +288,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
 #pragma unroll
             for (int i = 0; i < 4; ++i) kv[i] = (r0 + i < P.D) ? act_apply_fast(ACT2, kv[i]) : 0.f;
         }
+        PSTAMP(6 + 5 * (s - 1));
         // ---- phase C ----
         if constexpr (s < 6) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -265,7 +303,9 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
                 else if (P.tape) st4(R + L.g(s + 2) + co, r0, P.D, true, vec, v);
                 c_k[s] = kv;
             }
+            PSTAMP(7 + 5 * (s - 1));
             phase_d(v, (s + 1) & 1, (unsigned)(s + 1));
+            PSTAMP(8 + 5 * (s - 1));
         } else {
             if (tile_ok) {
                 st4(kdst + co, r0, P.D, true, vec, kv);
@@ -306,6 +346,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
     stage(std::integral_constant<int, 5>{});
     stage(std::integral_constant<int, 6>{});
     if (!alive) return;
+    PSTAMP(34);
 
     part0 = wave_sum_f(part0); part1 = wave_sum_f(part1); part2 = wave_sum_f(part2);
     if (lane == 0) { RED[w] = part0; RED[8 + w] = part1; RED[16 + w] = part2; }

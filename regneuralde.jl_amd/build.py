@@ -4,9 +4,11 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB = os.path.join(_HERE, "lib", "librnde.so")
+# RNDE_LIB: load another build of the same library (A/B runs of kernel variants on one GPU box; tools/ab_bench.sh)
+LIB = os.environ.get("RNDE_LIB") or os.path.join(_HERE, "lib", "librnde.so")
 SOURCES = ["rnde.hip"]
-HEADERS = ["rnde_device.h", "rnde_fwd.h", "rnde_bwd.h", "rnde_stage.h", "rnde_bstage.h", "rnde_head.h", os.path.join("..", "..", "include", "rnde.h")]
+HEADERS = ["rnde_device.h", "rnde_fwd.h", "rnde_bwd.h", "rnde_stage.h", "rnde_bstage.h", "rnde_stage_persist.h", "rnde_bstage_persist.h",
+           "rnde_chain.h", "rnde_bchain.h", "rnde_head.h", os.path.join("..", "..", "include", "rnde.h")]
 
 
 def needs_build():

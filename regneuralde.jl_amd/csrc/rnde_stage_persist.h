@@ -241,12 +241,21 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
             f32x4 z = zs;
             if (ht != w && !dead) dead = !slab_poll_sum(Y, par, Q.C, Q.R, Q.HT, ct, ht, lane, tag, z);
             const int h0 = 16 * ht + 4 * (lane >> 4);
+            // two tanh per instruction (v_pk_fma_f32): the 4 rows of this lane as two pairs
+            float pre[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int hr = h0 + i;
+                pre[i] = (hr < P.H) ? fmaf((ht == w) ? w1t_own[i] : W1t[hr], ts, z[i]) + ((ht == w) ? b1_own[i] : b1[hr]) : 0.f;
+            }
+            const f32x2 t01 = tanh_fast2((f32x2){pre[0], pre[1]}), t23 = tanh_fast2((f32x2){pre[2], pre[3]});
+            const float th4[4] = {t01.x, t01.y, t23.x, t23.y};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int hr = h0 + i;
                 float v = 0.f;
                 if (hr < P.H) {
-                    v = tanh_fast(fmaf((ht == w) ? w1t_own[i] : W1t[hr], ts, z[i]) + ((ht == w) ? b1_own[i] : b1[hr]));
+                    v = th4[i];
                     if (rb == 0) hdst[(size_t)gcol * P.H + hr] = v;
                 } else if (hr == P.H) v = ts;
                 else if (hr == P.H + 1) v = 1.f;
@@ -285,8 +294,12 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
                 }
             }
             kv = acc0 + acc1;
+            if (ACT2) {
+                const f32x2 a01 = tanh_fast2((f32x2){kv[0], kv[1]}), a23 = tanh_fast2((f32x2){kv[2], kv[3]});
+                kv = (f32x4){a01.x, a01.y, a23.x, a23.y};
+            }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) kv[i] = (r0 + i < P.D) ? act_apply_fast(ACT2, kv[i]) : 0.f;
+            for (int i = 0; i < 4; ++i) kv[i] = (r0 + i < P.D) ? kv[i] : 0.f;
         }
         PSTAMP(6 + 5 * (s - 1));
         // ---- phase C ----

@@ -168,6 +168,20 @@ def main():
                 "alg_bytes_per_attempt": ALG_BYTES(B), "alg_bytes_per_launch": ALG_BYTES(B) / nl,
                 "mfma_f32_tflops": ALG_FLOPS(B) / t_att / 1e12,
                 "mfma_frac": ALG_FLOPS(B) / t_att / 1e12 / MFMA_F32_PEAK_TF}
+        # HBM traffic per launch of that kernel: PMC counters cannot be collected from inside the bench; the committed separate
+        # passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same command, corrected as MI355X_MICROARCH.md prescribes) are
+        # reported when present, with their source
+        try:
+            import csv
+            pf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic.csv")
+            want = "rnde_stage_attempt_kernel" if (stage_engine and nl == 1) else ("rnde_stage_kernel<1, 1>" if stage_engine else "rnde_step_kernel")
+            for row in csv.reader(l for l in open(pf) if not l.startswith("#")):
+                if row and want in row[0]:
+                    roof["traffic"] = float(row[4]) * (7 if (stage_engine and nl == 7) else 1)
+                    roof["traffic_source"] = "profiles/r01_pmc_hbm_traffic.csv (separate --pmc passes; bytes per attempted step)"
+                    break
+        except Exception:
+            pass
         out = {"metric": "training-step samples/sec + mean NFE, MNIST Neural ODE bs=512",
                "value": world * B * args.steps / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,

@@ -39,6 +39,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // acknowledgement and no second load after the flag has been seen -- the consumer's polling load is the data load
 // (3.1 us -> ~1.5 us per hand-off).  A 16-byte aligned store of one lane lands in one cache line of the XCD's L2 in one
 // write, and the consumer reads it with agent-scope (sc1: L1-bypassing) loads, so a matching tag implies matching data.
+// (A back-off between polls, s_sleep 4 / 16, was measured and makes the attempt 1-3 % slower: polling traffic is not the limit.)
 // Tags are unique per exchange over the life of the handle; buffers alternate by parity, and a producer can only be two
 // exchanges ahead of the slowest consumer of its column tile (it needs that consumer's previous tile to get there).
 __device__ __forceinline__ void slab_put(float* tslab, size_t tile_index, int lane, const f32x4& v, unsigned tag) {

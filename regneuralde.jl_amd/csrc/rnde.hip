@@ -39,7 +39,7 @@ struct rnde_node {
     float* head_ws = nullptr; size_t head_ws_floats = 0;   // fused classifier head scratch
     float* sv_t_dev = nullptr; size_t sv_cap = 0; std::vector<float> saveat;   // saveat times of the last forward
     // persistent attempt kernel (rnde_stage_persist.h): 1 = in use, 0 = off (RNDE_PERSIST=0), -1 = disabled after a failure
-    int persist = 0; unsigned persist_seq = 0; float* tslab = nullptr; unsigned *pabort = nullptr, *pxcc = nullptr; unsigned* h_pchk = nullptr;
+    int persist = 0, persist_spins = kPersistMaxSpins; unsigned persist_seq = 0; float* tslab = nullptr; unsigned *pabort = nullptr, *pxcc = nullptr; unsigned* h_pchk = nullptr;
     hipStream_t wstream = nullptr;        // (experimental overlap path of the weight-gradient GEMMs)
     std::vector<hipEvent_t> wevents;
     // device
@@ -313,6 +313,7 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
     hipMemset(h->initrec, 0, sizeof(InitRec));
     hipMemset(h->tslab, 0, tslab_bytes); hipMemset(h->pabort, 0, 8); hipMemset(h->pxcc, 0, (size_t)h->nwg_max * 4);
     { const char* e = getenv("RNDE_PERSIST"); h->persist = (h->engine == 2 && h->sR <= 8 && !(e && e[0] == '0')) ? 1 : 0; }
+    if (const char* e = getenv("RNDE_PERSIST_SPINS")) h->persist_spins = atoi(e);
     h->predicted = 12;
     *out = h;
     return RNDE_OK;
@@ -391,7 +392,7 @@ static rnde_status stage_pack_weights(rnde_node* h, const float* p_dev, hipStrea
 }
 static hipError_t stage_attempt(rnde_node* h, const StageParams& Q, int n, hipStream_t s) {
     if (h->persist == 1) {   // one launch per attempt, slab hand-offs inside the kernel (rnde_stage_persist.h)
-        PersistSync Y{h->tslab, h->pabort, h->pxcc, h->persist_seq};
+        PersistSync Y{h->tslab, h->pabort, h->pxcc, h->persist_seq, h->persist_spins};
         h->persist_seq += 8;
         const dim3 grid(8 * Q.R * ((Q.C + 7) / 8));   // a column tile's row blocks share blockIdx % 8 (same XCD)
         if (h->act2) hipLaunchKernelGGL((rnde_stage_attempt_kernel<1>), grid, dim3(64 * Q.WT), h->stage_lds, s, Q, n, Y);
@@ -980,7 +981,7 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
                 }
             }
             if (h->persist == 1) {   // the attempt's 7 reverse launches as one (rnde_bstage_persist.h)
-                PersistSync Y{h->tslab, h->pabort, h->pxcc, h->persist_seq};
+                PersistSync Y{h->tslab, h->pabort, h->pxcc, h->persist_seq, h->persist_spins};
                 h->persist_seq += 8;
                 const dim3 pgrid(8 * BQ.R * ((BQ.C + 7) / 8));
                 if (h->act2) hipLaunchKernelGGL((rnde_bstage_attempt_kernel<1>), pgrid, blk, h->stage_lds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y);

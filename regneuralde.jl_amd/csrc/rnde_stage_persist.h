@@ -28,6 +28,7 @@ struct PersistSync {
     unsigned* abort_flag;   // [0] a hand-off timed out
     unsigned* xcc;          // [grid] XCC id of each workgroup (written every launch, checked by the host)
     unsigned seq_base;      // exchange tags are seq_base + 1..6; the host adds 8 per launch
+    int max_spins;          // bound of every polling loop (kPersistMaxSpins; RNDE_PERSIST_SPINS overrides it: the fallback test uses 0)
 };
 
 constexpr int kPersistMaxSpins = 100000;
@@ -83,7 +84,7 @@ __device__ __forceinline__ bool slab_poll_sum(const PersistSync& Y, int par, int
             zs = (f32x4){s0, s1, s2, s3};
             return true;
         }
-        if (++spins > kPersistMaxSpins || ((spins & 63) == 0 && __hip_atomic_load(Y.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        if (++spins > Y.max_spins || ((spins & 63) == 0 && __hip_atomic_load(Y.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
             __hip_atomic_store(Y.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             zs = (f32x4){0.f, 0.f, 0.f, 0.f};
             return false;

@@ -1,0 +1,131 @@
+"""GPU: edge cases and error behaviour of the C ABI (status codes of include/rnde.h), plus a full-size replication
+property (size-independent properties at BASELINE.json's sizes)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+OK, BAD_ARG, MAX_ATT, DT_UNDER, NONFINITE, HIP, NO_TAPE = 0, 1, 2, 3, 4, 5, 6
+
+
+def _mk(kind="small", B=9, **kw):
+    from tests.test_gpu_forward import _cfg, _setup
+    from tests.util import Node
+    arch, p, x = _setup(kind, B, 3, kw.pop("scale", 3.0))
+    return Node(_cfg(arch, kw.pop("max_batch", B), **kw)), p, x
+
+
+def test_max_attempts_is_reported_not_hidden():
+    """The reference never checks retcode (SURVEY 8b 'Errors'); the ABI returns RNDE_ERR_MAX_ATTEMPTS."""
+    from regneuralde_jl_amd._lib import RndeError
+    node, p, x = _mk("small", 9, reltol=1e-6, abstol=1e-6, max_attempts=3, col_tile=16)
+    with pytest.raises(RndeError) as e:
+        node.forward(x, p)
+    assert e.value.status == MAX_ATT
+    node2, p, x = _mk("small", 9, reltol=1e-6, abstol=1e-6, max_attempts=3, col_tile=64)     # chain engine
+    with pytest.raises(RndeError) as e:
+        node2.forward(x, p)
+    assert e.value.status == MAX_ATT
+
+
+@pytest.mark.parametrize("col_tile", [16, 64, 8])
+def test_nonfinite_input_is_reported(col_tile):
+    from regneuralde_jl_amd._lib import RndeError
+    node, p, x = _mk("small", 9, reltol=1e-3, abstol=1e-3, col_tile=col_tile)
+    x = x.copy(); x[4, 7] = np.nan
+    with pytest.raises(RndeError) as e:
+        node.forward(x, p)
+    assert e.value.status == NONFINITE
+
+
+def test_bad_arguments():
+    from regneuralde_jl_amd._lib import RndeError
+    from tests.util import Node, make_arch
+    from tests.test_gpu_forward import _cfg
+    node, p, x = _mk("small", 9, reltol=1e-3, abstol=1e-3, col_tile=16, max_batch=9)
+    with pytest.raises(RndeError) as e:                      # batch larger than the handle was created for
+        node.forward(np.concatenate([x, x]), p)
+    assert e.value.status == BAD_ARG
+    with pytest.raises(RndeError) as e:                      # tspan reversed
+        node.forward(x, p, 1.0, 0.0)
+    assert e.value.status == BAD_ARG
+    for bad in ([0.5, 0.2], [0.5, 1.5], [-0.1, 0.3]):        # saveat not increasing / outside tspan
+        with pytest.raises(RndeError) as e:
+            node.forward_saveat(x, p, np.array(bad, dtype=np.float32))
+        assert e.value.status == BAD_ARG
+    with pytest.raises(RndeError) as e:                      # reverse pass without a recorded forward
+        node.backward(np.zeros_like(x), None)
+    assert e.value.status == NO_TAPE
+    wide = make_arch([8, 100, 100, 8], ["tanh", "tanh", "identity"], False)   # not the MNIST form and wider than the chain engine
+    with pytest.raises(RndeError) as e:
+        Node(_cfg(wide, 4))
+    assert e.value.status == BAD_ARG
+
+
+def test_saveat_is_refused_on_the_column_owner_engine():
+    from regneuralde_jl_amd._lib import RndeError
+    node, p, x = _mk("small", 9, reltol=1e-3, abstol=1e-3, col_tile=8)
+    with pytest.raises(RndeError) as e:
+        node.forward_saveat(x, p, np.array([0.5], dtype=np.float32))
+    assert e.value.status == BAD_ARG
+
+
+@pytest.mark.parametrize("B", [1, 15, 17])
+def test_ragged_batches_match_the_padded_run(B):
+    """Columns are independent given the step sequence: a batch that is not a multiple of the 16-column tile gives the same
+    states as the same columns inside a larger batch whose extra columns are copies (same global error norm up to the mean)."""
+    from tests.test_gpu_forward import _cfg, _setup
+    from tests.util import Node
+    arch, p, x = _setup("small", B, 4, 3.0)
+    a = Node(_cfg(arch, B, reltol=1e-3, abstol=1e-3, col_tile=16)).forward(x, p)
+    reps = 16 // B + 2
+    xb = np.tile(x, (reps, 1))                               # every column replicated: identical RMS norms
+    b = Node(_cfg(arch, B * reps, reltol=1e-3, abstol=1e-3, col_tile=16)).forward(xb, p)
+    assert a["nfe"] == b["nfe"]
+    np.testing.assert_allclose(b["u"][:B], a["u"], rtol=2e-5, atol=2e-6)
+    for r in range(1, reps):
+        assert np.array_equal(b["u"][r * B:(r + 1) * B], b["u"][:B])      # replicas are bit-identical
+
+
+def test_full_size_replication_property():
+    """B = 4096 on one GPU (the global batch of SURVEY 8d config 3): 8 copies of 512 distinct MNIST-sized columns.  Each copy
+    must come out bit-identical (same arithmetic per column wherever it sits: 256 column tiles, 1792 workgroups), NFE = 3 mod 6,
+    and the result must agree with the B = 512 solve of the same columns (same RMS error norm up to summation order)."""
+    from tests.test_gpu_forward import _cfg, _setup
+    from tests.util import Node
+    arch, p, x = _setup("mnist", 512, 6, 2.0)
+    a = Node(_cfg(arch, 512, reltol=1e-4, abstol=1e-4, col_tile=16)).forward(x, p)
+    xb = np.tile(x, (8, 1))
+    node = Node(_cfg(arch, 4096, reltol=1e-4, abstol=1e-4, col_tile=16))
+    b = node.forward(xb, p, keep_tape=True)
+    assert b["nfe"] % 6 == 3 and b["nfe"] == a["nfe"]
+    for r in range(1, 8):
+        assert np.array_equal(b["u"][r * 512:(r + 1) * 512], b["u"][:512])
+    np.testing.assert_allclose(b["u"][:512], a["u"], rtol=1e-4, atol=1e-5)
+    ubar = np.tile(np.random.default_rng(0).standard_normal((512, 784)).astype(np.float32), (8, 1))
+    gx, gp, gt = node.backward(ubar, np.full(len(b["saveval"]), 2.0, dtype=np.float32))
+    for r in range(1, 8):
+        assert np.array_equal(gx[r * 512:(r + 1) * 512], gx[:512])
+    assert np.isfinite(gp).all() and np.isfinite(gt).all()
+
+
+def test_persistent_kernel_failure_falls_back_to_the_multi_launch_kernels(monkeypatch):
+    """Safety net of rnde_stage_persist.h: when a hand-off gives up (here: a polling bound of zero, so the first poll that is not
+    satisfied at once abandons the launch) the handle must notice, switch to the 7-launch kernels for good and redo the solve --
+    the caller sees correct results, not an error and not garbage."""
+    import ctypes as C
+    from tests.test_gpu_forward import _cfg, _setup
+    from tests.util import Node
+    arch, p, x = _setup("mnist", 64, 5, 3.0)
+    monkeypatch.setenv("RNDE_PERSIST", "0")
+    ref = Node(_cfg(arch, 64, reltol=1e-3, abstol=1e-3, col_tile=16)).forward(x, p)
+    monkeypatch.setenv("RNDE_PERSIST", "1")
+    monkeypatch.setenv("RNDE_PERSIST_SPINS", "0")
+    node = Node(_cfg(arch, 64, reltol=1e-3, abstol=1e-3, col_tile=16))
+    node.L.rnde_node_launches_per_attempt.restype = C.c_int32
+    assert node.L.rnde_node_launches_per_attempt(node.h) == 1
+    got = node.forward(x, p)
+    assert node.L.rnde_node_launches_per_attempt(node.h) == 7          # disabled after the failure
+    assert got["nfe"] == ref["nfe"] and np.array_equal(got["u"], ref["u"]) and np.array_equal(got["saveval"], ref["saveval"])
+    again = node.forward(x, p)
+    assert np.array_equal(again["u"], ref["u"])

@@ -216,7 +216,9 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
         if (tile_ok) {
             v = fma4(dt, kFwdShift[0][0] * c_k[0], c_up);
             if (P.tape) st4(R + L.g(2) + co, r0, P.D, true, vec, v);
-            if (P.tape || P.nsave > 0) { st4(R + L.upc() + co, r0, P.D, true, vec, c_up); st4(R + L.k1c() + co, r0, P.D, true, vec, c_k[0]); }
+            // (uprev, k1) copies: only the dense output of saveat reads them here (the multi-launch STAGE kernels also do; streaming
+            //  tape stores with `nt` were measured: no difference)
+            if (P.nsave > 0) { st4(R + L.upc() + co, r0, P.D, true, vec, c_up); st4(R + L.k1c() + co, r0, P.D, true, vec, c_k[0]); }
         }
         PSTAMP(2);
         phase_d(v, 1, 1u);

@@ -413,11 +413,15 @@ static const rnde_status RNDE_INTERNAL_RETRY = static_cast<rnde_status>(100);
 // After a synchronisation point: did a persistent launch time out, or did a column tile's workgroups land on different
 // XCDs (then their slab hand-off through L2 would not be coherent)?  Either way the persistent kernels are disabled for
 // this handle and the caller redoes the solve with the multi-launch kernels.
-static bool persist_failed(rnde_node* h, int grid, int C, int R, hipStream_t s) {
+// (two halves so that the two small copies ride on a synchronisation the caller performs anyway)
+static void persist_check_enqueue(rnde_node* h, int grid, hipStream_t s) {
+    if (h->persist != 1) return;
+    h->h_pchk[0] = 1;   // stays 1 ("failed") if a copy cannot even be enqueued
+    if (hipMemcpyAsync(h->h_pchk, h->pabort, 8, hipMemcpyDeviceToHost, s) != hipSuccess) return;
+    (void)hipMemcpyAsync(h->h_pchk + 2, h->pxcc, (size_t)grid * 4, hipMemcpyDeviceToHost, s);
+}
+static bool persist_check_result(rnde_node* h, int C, int R, hipStream_t s) {   // call after the stream has been synchronised
     if (h->persist != 1) return false;
-    if (hipMemcpyAsync(h->h_pchk, h->pabort, 8, hipMemcpyDeviceToHost, s) != hipSuccess) return true;
-    if (hipMemcpyAsync(h->h_pchk + 2, h->pxcc, (size_t)grid * 4, hipMemcpyDeviceToHost, s) != hipSuccess) return true;
-    if (hipStreamSynchronize(s) != hipSuccess) return true;
     bool bad = h->h_pchk[0] != 0;
     for (int ct = 0; ct < C && !bad; ++ct)
         for (int rb = 1; rb < R; ++rb) if (h->h_pchk[2 + rb * C + ct] != h->h_pchk[2 + ct]) { bad = true; break; }
@@ -427,6 +431,12 @@ static bool persist_failed(rnde_node* h, int grid, int C, int R, hipStream_t s) 
         hipMemsetAsync(h->pabort, 0, 8, s);
     }
     return bad;
+}
+static bool persist_failed(rnde_node* h, int grid, int C, int R, hipStream_t s) {
+    if (h->persist != 1) return false;
+    persist_check_enqueue(h, grid, s);
+    if (hipStreamSynchronize(s) != hipSuccess) return true;
+    return persist_check_result(h, C, R, s);
 }
 
 static rnde_status forward_impl(rnde_node* h, const float* x_dev, const float* p_dev, int32_t B, float t0, float t1,
@@ -521,18 +531,20 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
         if (h->engine == 3) HIPCHK(h, launch_chain<CM_FINISH>(h, CQ, launched, u_out_dev, s));
         else if (h->engine == 2) { hipLaunchKernelGGL(rnde_stage_finish_kernel, dim3(64), dim3(256), 0, s, SQ, launched, u_out_dev); HIPCHK(h, hipGetLastError()); }
         else HIPCHK(h, launch_finish(h, P, launched, u_out_dev, s));
+        // one synchronisation per chunk: controller state, the persistent kernels' health words, and (speculatively: the solve
+        // usually ends in the first chunk) the step metadata and the initial-step record the epilogue needs
         HIPCHK(h, hipMemcpyAsync(h->h_ctl, h->ctl_final, sizeof(StepState), hipMemcpyDeviceToHost, s));
+        if (h->engine == 2) persist_check_enqueue(h, SQ.R * SQ.C, s);
+        HIPCHK(h, hipMemcpyAsync(h->h_meta, h->meta, (size_t)launched * sizeof(StepMeta), hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipMemcpyAsync(h->h_init, h->initrec, sizeof(InitRec), hipMemcpyDeviceToHost, s));
         HIPCHK(h, hipStreamSynchronize(s));
-        if (h->engine == 2 && persist_failed(h, SQ.R * SQ.C, SQ.C, SQ.R, s)) return RNDE_INTERNAL_RETRY;
+        if (h->engine == 2 && persist_check_result(h, SQ.C, SQ.R, s)) return RNDE_INTERNAL_RETRY;
         if (h->h_ctl->done) break;
         if (launched >= cap) { h->err = "max_attempts reached"; h->n_att = h->h_ctl->n_att; return RNDE_ERR_MAX_ATTEMPTS; }
         chunk = 4;
     }
     h->n_att = h->h_ctl->n_att;
     h->predicted = h->n_att + 1;
-    if (h->n_att > 0) HIPCHK(h, hipMemcpyAsync(h->h_meta, h->meta, (size_t)h->n_att * sizeof(StepMeta), hipMemcpyDeviceToHost, s));
-    HIPCHK(h, hipMemcpyAsync(h->h_init, h->initrec, sizeof(InitRec), hipMemcpyDeviceToHost, s));
-    HIPCHK(h, hipStreamSynchronize(s));
     if (nfe_out) *nfe_out = 3 + 6 * (int64_t)h->n_att;  // 2 (initial dt) + 1 (fsalfirst) + 6 per attempt, SURVEY.md B.1-B.2
     // saving callback values (reference neural_ode.jl:116,:126-127): EEst*dt per accepted step
     int nsv = 0;
@@ -1021,10 +1033,11 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
     st = launch_wgrad_reduce(h, slab2w, cur2, h->D, h->H, p_bar_dev + (size_t)h->H * (h->D + 2), s);      // [W2; b2]
     if (st != RNDE_OK) return st;
     HIPCHK(h, hipMemcpyAsync(h->h_scal, b.tspan_out, 8, hipMemcpyDeviceToHost, s));
+    if (h->engine == 2) persist_check_enqueue(h, h->sR * (Q.F.Bpad / 16), s);
     HIPCHK(h, hipStreamSynchronize(s));
     if (tspan_bar_host) { tspan_bar_host[0] = h->h_scal[0]; tspan_bar_host[1] = h->h_scal[1]; }
     h->have_tape = false;  // z2bar overwrote k_s in place: the tape is consumed
-    if (h->engine == 2 && persist_failed(h, h->sR * (Q.F.Bpad / 16), Q.F.Bpad / 16, h->sR, s)) {
+    if (h->engine == 2 && persist_check_result(h, Q.F.Bpad / 16, h->sR, s)) {
         h->err = "persistent reverse kernel abandoned its hand-off (tape consumed): rerun forward + backward, the multi-launch kernels are now in use";
         return RNDE_ERR_HIP;
     }

@@ -166,7 +166,7 @@ static rnde_status chain_create(const rnde_node_config* c, rnde_node** out) {
     // LDS: fragment tables rounded up to whole 1 KiB DMA units, then 64 floats of reduction scratch
     const size_t lds_f = ((size_t)((G.nfrag_f + G.nfrag_b + 3) / 4) * 256 + 64) * 4, lds_b = ((size_t)((G.nfrag_f + G.nfrag_b + G.nfrag_t + 3) / 4) * 256 + 64) * 4;
     if (lds_b > 160 * 1024) { g_create_err = "chain too large: its weight fragments must fit the 160 KB LDS of a CU"; return RNDE_ERR_BAD_ARG; }
-    if (c->regularize < RNDE_REG_NONE || c->regularize > RNDE_REG_ERR) { g_create_err = "chain engine: regularize must be RNDE_REG_NONE or RNDE_REG_ERR"; return RNDE_ERR_BAD_ARG; }
+    if (c->regularize < RNDE_REG_NONE || c->regularize > RNDE_REG_ERR_STIFF) { g_create_err = "regularize: unknown value"; return RNDE_ERR_BAD_ARG; }
     if (c->col_tile != 0 && c->col_tile != 64) { g_create_err = "col_tile: this network runs on the chain engine (0 or 64)"; return RNDE_ERR_BAD_ARG; }
     if (c->max_batch < 1 || c->max_attempts < 1) { g_create_err = "max_batch / max_attempts"; return RNDE_ERR_BAD_ARG; }
     rnde_node* h = new rnde_node();
@@ -1074,6 +1074,7 @@ extern "C" rnde_status rnde_classifier_head(rnde_node* h, const float* u_dev, co
 // ---- chain engine reverse pass ----------------------------------------------------------------------------
 template <int NKD, int ALT = 0>
 static hipError_t launch_bchain_t(rnde_node* h, const BChainParams& Q, const std::vector<int>& sv_lo, const std::vector<int>& sv_hi, hipStream_t s) {
+    const BwdBuffers& b = h->bw;
     const size_t lds = h->chain_lds_b;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1084,7 +1085,19 @@ static hipError_t launch_bchain_t(rnde_node* h, const BChainParams& Q, const std
         attr_set = true;
     }
     const dim3 grid(Q.B.F.nwg), blk(64 * kCW);
-    for (int n = Q.B.n_att - 1; n >= 0; --n) hipLaunchKernelGGL((rnde_bchain_kernel<NKD, ALT>), grid, blk, lds, s, Q, n, h->h_meta[n], sv_lo[n], sv_hi[n]);
+    for (int n = Q.B.n_att - 1; n >= 0; --n) {
+        float c1 = 0.f, c2 = 0.f;   // cotangent of eigen_est for this attempt (as in bwd_run)
+        const StepMeta& mm = h->h_meta[n];
+        const bool eg_ok = !(mm.eigen == 0.f || mm.eigen != mm.eigen);
+        double eigb = 0.0;
+        if (h->cfg.regularize == RNDE_REG_STIFF && eg_ok) eigb = (double)b.h_svb[n] * (mm.eigen > 0 ? 1.0 : -1.0) / 3.5068;
+        if (h->cfg.regularize == RNDE_REG_ERR_STIFF && eg_ok) eigb = 0.1 * (double)b.h_svb[n] / 3.5068;
+        if (eigb != 0.0 && mm.n1 > 0.f && mm.n2 > 0.f) {
+            c1 = (float)(eigb / ((double)mm.n2 * (double)mm.n1));
+            c2 = (float)(-eigb * ((double)mm.n1 / (double)mm.n2) / ((double)mm.n2 * (double)mm.n2));
+        }
+        hipLaunchKernelGGL((rnde_bchain_kernel<NKD, ALT>), grid, blk, lds, s, Q, n, mm, sv_lo[n], sv_hi[n], c1, c2);
+    }
     hipLaunchKernelGGL((rnde_bchain_init_kernel<NKD, 1, ALT>), grid, blk, lds, s, Q);
     hipLaunchKernelGGL((rnde_bchain_init_kernel<NKD, 2, ALT>), grid, blk, lds, s, Q);
     hipLaunchKernelGGL(rnde_bfin_kernel, dim3(1), dim3(64), 0, s, Q.B);

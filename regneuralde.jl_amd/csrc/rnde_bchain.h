@@ -137,7 +137,7 @@ __device__ __forceinline__ void chain_fbwd(const BChainParams& Q, const float* F
 }
 
 template <int NKD, int ALT = 0>
-__global__ __launch_bounds__(64 * kCW) void rnde_bchain_kernel(const BChainParams Q, const int n, const StepMeta m, const int sv_lo, const int sv_hi) {
+__global__ __launch_bounds__(64 * kCW) void rnde_bchain_kernel(const BChainParams Q, const int n, const StepMeta m, const int sv_lo, const int sv_hi, const float eig_c1, const float eig_c2) {
     const BwdParams& Bq = Q.B;
     const StepParams& P = Bq.F;
     const ChainGeo& G = Q.G;
@@ -169,7 +169,8 @@ __global__ __launch_bounds__(64 * kCW) void rnde_bchain_kernel(const BChainParam
         const double N = (double)P.D * (double)P.B;
         double eb = 0, dtb_pre = 0, q11b = 0, qb = 0, qoldb_in = 0;
         if (accepted) {
-            if (Bq.reg_kind == 1) { const double sb = (double)Bq.svb_att[n]; eb += sb * (double)dt; dtb_pre += sb * (double)m.eest; }
+            const bool err_term = Bq.reg_kind == 1 || (Bq.reg_kind == 3 && !(m.eest * dt == 0.f));
+            if (err_term) { const double sb = (double)Bq.svb_att[n]; eb += sb * (double)dt; dtb_pre += sb * (double)m.eest; }
             dtb_pre += tb;
             if (m.flags & F_DTMAXCLAMP) { t1b += dtpb; t0b -= dtpb; }
             else if (Bq.track_ctrl) { dtb_pre += dtpb / (double)m.q; qb += -dtpb * (double)dt / ((double)m.q * (double)m.q); }
@@ -262,7 +263,8 @@ __global__ __launch_bounds__(64 * kCW) void rnde_bchain_kernel(const BChainParam
             }
         }
         // Rb[i] = cotangent of k_{s-i} (zero-based) where s is the next stage to be reversed (rolled loop, kBwdShift)
-        float Rb[6][NKD], gb[NKD];
+        float Rb[6][NKD], gb[NKD], exk[NKD], exg[NKD];
+        const bool has_eig = (eig_c1 != 0.f || eig_c2 != 0.f);
         // ---- B: stage 7 (k7 = f(unew, t + dt)) ----
         {
             float k7[NKD], unv[NKD], kb7[NKD];
@@ -274,6 +276,13 @@ __global__ __launch_bounds__(64 * kCW) void rnde_bchain_kernel(const BChainParam
                 kb7[q] = dt * (tsBt(6) * utb[q] + Wv[6][q]);
                 S += k7[q] * kb7[q];
                 if (accepted && !first && in) kb7[q] += Bq.K1[fo + q * 64];
+                exk[q] = 0.f; exg[q] = 0.f;
+                if (has_eig) {   // reverse of eigen_est = ||k7-k6|| / ||unew-g6|| (direct terms: they do not scale with dt, so not in S)
+                    const bool ok = colok && 4 * q + g < P.D;
+                    const float d1 = ok ? k7[q] - R[L.k(6) + fo + q * 64] : 0.f, d2 = ok ? unv[q] - R[L.g(6) + fo + q * 64] : 0.f;
+                    kb7[q] += eig_c1 * d1; exk[q] = -eig_c1 * d1;
+                    unb[q] += eig_c2 * d2; exg[q] = -eig_c2 * d2;
+                }
             }
             float t7 = 0.f;
             chain_fbwd<NKD, ALT>(Q, FR, BF, TF, t + dt, unv, k7, kb7, gb, sl0 + 5 * Q.ev_stride, t7, lane);
@@ -297,10 +306,15 @@ __global__ __launch_bounds__(64 * kCW) void rnde_bchain_kernel(const BChainParam
                 gs[q] = in ? R[L.g(s + 1) + fo + q * 64] : 0.f;
                 kb[q] = Rb[0][q];
                 S += ks[q] * kb[q];
+                if (has_eig && s == 5) kb[q] += exk[q];          // direct cotangent of k6
             }
             float ts_ = 0.f;
             chain_fbwd<NKD, ALT>(Q, FR, BF, TF, t + kTsC[s] * dt, gs, ks, kb, gb, sl0 + (size_t)(s - 1) * Q.ev_stride, ts_, lane);
             tau += ts_; ctau += kTsC[s] * ts_;
+            if (has_eig && s == 5) {
+#pragma unroll
+                for (int q = 0; q < NKD; ++q) gb[q] += exg[q];   // direct cotangent of g6
+            }
             float cb[5];
 #pragma unroll
             for (int i = 0; i < 5; ++i) cb[i] = dt * kBwdShift[s][i];

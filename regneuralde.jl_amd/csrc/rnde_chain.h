@@ -482,11 +482,11 @@ __global__ __launch_bounds__(64 * kCW) void rnde_chain_kernel(const ChainParams 
             const float dt = (!P.forced && (P.t1 - S.t < S.dtp)) ? (P.t1 - S.t) : S.dtp;
             const int rec = P.tape ? n : (S.live == 0 ? 1 : 0);
             float* R = P.arena + (long long)rec * P.rec_stride;
-            float part = 0.f;
+            float part = 0.f, part1 = 0.f, part2 = 0.f;
             if (tile_ok) {
                 // Rolled stage loop with shifting partial sums, exactly as rnde_step_kernel (rnde_fwd.h): Sa[i] is the
                 // running combination sum_j a_{s+1+i,j} k_j of the i-th stage still to come; E = sum_j btilde_j k_j.
-                float up[NKD], Sa[6][NKD], E[NKD], un[NKD];
+                float up[NKD], Sa[6][NKD], E[NKD], un[NKD], g6[NKD], k6[NKD];   // g6, k6: stiffness estimate only (reg_kind >= 2)
                 const float* Rl = P.arena + (long long)(S.live < 0 ? 0 : S.live) * P.rec_stride;
 #pragma unroll
                 for (int q = 0; q < NKD; ++q) {
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(64 * kCW) void rnde_chain_kernel(const ChainParams 
 #pragma unroll
                     for (int i = 0; i < 6; ++i) Sa[i][q] = kFwdShift[0][i] * k1;
                     E[q] = kTsBt[0] * k1;
-                    un[q] = up[q];
+                    un[q] = up[q]; g6[q] = 0.f; k6[q] = 0.f;
                 }
                 CHAIN_STAMP(3);
 #pragma unroll 1
@@ -521,6 +521,16 @@ __global__ __launch_bounds__(64 * kCW) void rnde_chain_kernel(const ChainParams 
                     chain_eval<NKD, ALT>(G, FR, BF, t + kTsC[s] * dt, gq, kv, lane);
 #endif
                     CHAIN_STAMP(3 + s);
+                    if (s == 5 && P.reg_kind >= 2) {
+#pragma unroll
+                        for (int q = 0; q < NKD; ++q) { g6[q] = gq[q]; k6[q] = kv[q]; }
+                    }
+                    if (s == 6 && P.reg_kind >= 2) {   // ||k7 - k6||^2, ||unew - g6||^2 (eigen_est of the composite algorithm)
+#pragma unroll
+                        for (int q = 0; q < NKD; ++q) {
+                            if (colok && 4 * q + g < P.D) { const float d1 = kv[q] - k6[q], d2 = un[q] - g6[q]; part1 += d1 * d1; part2 += d2 * d2; }
+                        }
+                    }
                     const float bts = kTsBt[s];
                     float cs[5];
 #pragma unroll
@@ -545,13 +555,14 @@ __global__ __launch_bounds__(64 * kCW) void rnde_chain_kernel(const ChainParams 
                 }
             }
             CHAIN_STAMP(10);
-            part = wave_sum_f(part);
-            if (lane == 0) RED[wave] = part;
+            part = wave_sum_f(part); part1 = wave_sum_f(part1); part2 = wave_sum_f(part2);
+            if (lane == 0) { RED[wave] = part; RED[kCW + wave] = part1; RED[2 * kCW + wave] = part2; }
             __syncthreads();
             if (tid == 0) {
-                float s = 0.f;
-                for (int w = 0; w < kCW; ++w) s += RED[w];
-                P.errpart[(size_t)(n & 1) * 3 * P.nwg + blockIdx.x] = s;
+                float s = 0.f, s1 = 0.f, s2 = 0.f;
+                for (int w = 0; w < kCW; ++w) { s += RED[w]; s1 += RED[kCW + w]; s2 += RED[2 * kCW + w]; }
+                float* ep = P.errpart + (size_t)(n & 1) * 3 * P.nwg;
+                ep[blockIdx.x] = s; ep[P.nwg + blockIdx.x] = s1; ep[2 * P.nwg + blockIdx.x] = s2;
             }
         }
     }

@@ -206,3 +206,33 @@ def test_chain_generic_dispatch_path_on_latent_shape(monkeypatch):
     x32, p32, _ = o32.backward(ubar, svbar)
     assert rel_err(gx, x64) <= 2e-3 + 4 * rel_err(x32, x64)
     assert rel_err(gp, p64) <= 2e-3 + 4 * rel_err(p32, p64)
+
+
+@pytest.mark.parametrize("kind,B,tol,scale", [("latent", 21, 1e-3, 1.5), ("chain3", 19, 1e-3, 2.0), ("small", 12, 1e-3, 4.0)])
+@pytest.mark.parametrize("reg,agg", [(2, "max"), (2, "mean"), (3, "mean")])
+def test_chain_stiffness_regulariser_matches_oracle(kind, B, tol, scale, reg, agg):
+    """regularize = stiff_est / error_stiff_est on the chain engine (latent_ode.jl:127-136 selects AutoTsit5(Tsit5()) for them):
+    callback values and the reverse pass of eigen_est = ||k7-k6|| / ||u-g6|| against the oracle."""
+    from tests.util import Node, Oracle, rel_err
+    arch, p, x = _setup(kind, B, 4, scale)
+    node = Node(_cfg(arch, B, reltol=tol, abstol=tol, regularize=reg))
+    got = node.forward(x, p, keep_tape=True)
+    o32 = Oracle(arch, np.float32, reltol=tol, abstol=tol, reg_kind=reg)
+    o64 = Oracle(arch, np.float64, reltol=tol, abstol=tol, reg_kind=reg)
+    r32, r64 = o32.forward(x, p), o64.forward(x, p)
+    assert got["nfe"] == r32["nfe"] == r64["nfe"]
+    np.testing.assert_allclose(got["saveval"], r64["saveval"], rtol=5e-2, atol=1e-5)
+    rng = np.random.default_rng(7)
+    ubar = rng.standard_normal(x.shape).astype(np.float32)
+    svbar = np.zeros(len(got["saveval"]), dtype=np.float32)
+    if agg == "max":
+        svbar[int(np.argmax(r64["saveval"]))] = 2.0
+    else:
+        svbar[:] = 2.0 / len(svbar)
+    xb, pb, tsb = node.backward(ubar, svbar)
+    xb64, pb64, _ = o64.backward(ubar.astype(np.float64), svbar.astype(np.float64))
+    xb32, pb32, _ = o32.backward(ubar, svbar)
+    cx, cp = rel_err(xb32, xb64), rel_err(pb32, pb64)
+    print(f"reg {reg}/{agg} {kind}: x-bar {rel_err(xb, xb64):.2e} (oracle f32 {cx:.2e})  p-bar {rel_err(pb, pb64):.2e} (oracle f32 {cp:.2e})")
+    assert rel_err(xb, xb64) <= 3e-3 + 4 * cx
+    assert rel_err(pb, pb64) <= 3e-3 + 4 * cp

@@ -47,7 +47,7 @@ CASES = {
     "test_node_B5": (arch_test_node, 5, 1e-3, 3.0, 1.0, 12),
     "mnist_small_B4": (lambda: arch_mnist(36, 10), 4, 1e-3, 4.0, 1.0, 13),
     "mnist_B3": (arch_mnist, 3, 1e-3, 3.0, 1.0, 14),
-    "latent_B4": (arch_latent, 4, 1e-3, 2.0, 1.0, 15),             # oracle only (device kernels: next row)
+    "latent_B4": (arch_latent, 4, 1e-3, 2.0, 1.0, 15),             # chain engine (tests/test_gpu_golden.py)
 }
 
 

@@ -35,3 +35,27 @@ def test_device_reproduces_golden(name):
     assert rel_err(pb[::st], g["pbar_f64"]) <= 3e-3 + 2 * sp
     assert abs(np.linalg.norm(pb.astype(np.float64)) - float(g["pbar_norm_f64"])) <= 3e-3 * float(g["pbar_norm_f64"])
     assert np.abs(tsb - g["tspanbar_f64"]).max() <= 3e-3 * max(1.0, np.abs(g["tspanbar_f64"]).max())
+
+
+def test_chain_engine_reproduces_latent_golden():
+    """The latent-ODE dynamics fixture (tanh + 8 Dense layers, experiments/latent_ode.jl:113-124) on the chain engine.  One of the
+    4 columns is ill conditioned at this weight scale (fp32 and fp64 oracle differ by 1.3e-3 there): the fixture's own
+    fp32-vs-fp64 spread sets the tolerance per column."""
+    from tests.test_gpu_forward import _cfg
+    from tests.util import Node, rel_err
+    name = "latent_B4"
+    arch, p, x, wu, tol, t1 = inputs(name)
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    node = Node(_cfg(arch, x.shape[0], reltol=tol, abstol=tol))
+    got = node.forward(x.astype(np.float32), p.astype(np.float32), 0.0, t1, keep_tape=True)
+    assert got["nfe"] == int(g["nfe_f32"]) == int(g["nfe_f64"])
+    assert (got["steps"][:, 3] == g["steps_f64"][:, 3]).all()
+    spread = np.abs(g["u_f32"] - g["u_f64"]).max(axis=1)
+    assert (np.abs(got["u"] - g["u_f64"]).max(axis=1) <= 2e-5 + 4 * spread).all()
+    np.testing.assert_allclose(got["saveval"], g["saveval_f64"], rtol=0.15, atol=3e-6)
+    xb, pb, tsb = node.backward(wu.astype(np.float32), np.full(len(got["saveval"]), 25.0, dtype=np.float32))
+    sx, sp = rel_err(g["xbar_f32"], g["xbar_f64"]), rel_err(g["pbar_f32"], g["pbar_f64"])
+    print("latent x-bar", rel_err(xb, g["xbar_f64"]), "(oracle f32:", sx, ") p-bar", rel_err(pb, g["pbar_f64"]), "(oracle f32:", sp, ")")
+    assert rel_err(xb, g["xbar_f64"]) <= 3e-3 + 4 * sx
+    assert rel_err(pb, g["pbar_f64"]) <= 3e-3 + 4 * sp
+    assert np.abs(tsb - g["tspanbar_f64"]).max() <= (3e-3 + 4 * max(sx, sp)) * max(1.0, np.abs(g["tspanbar_f64"]).max())

@@ -863,9 +863,20 @@ static rnde_status launch_wgrad_part(rnde_node* h, const EvalDesc* ev, int n_eva
     static const bool legacy = getenv("RNDE_WGRAD_LEGACY") != nullptr;   // direct-from-global variant, kept for A/B runs
     const bool fits = tall ? (Nx + 2 <= 128) : (M <= 128);                // the staged kernel covers 128 on the un-split side
     if (!legacy && fits) {
+        // staged kernel: chunks are ranges of 32-column steps; pick the count that fills the chip in whole rounds
+        // (3 workgroups per CU -> 768 resident: one round; measured 768 / 1100 / 1536 / 1792 -> 4.44 / 4.57 / 4.51 / 4.54 ms per step)
         const int pblocks = tall ? (M + 127) / 128 : (Nx + 2 + 127) / 128;
-        if (tall) hipLaunchKernelGGL((rnde_wgrad2_kernel<true>), dim3(pblocks, chunks), dim3(256), 0, s, ev, n_evals, per_chunk, M, Nx, Bpad, dst);
-        else hipLaunchKernelGGL((rnde_wgrad2_kernel<false>), dim3(pblocks, chunks), dim3(256), 0, s, ev, n_evals, per_chunk, M, Nx, Bpad, dst);
+        const int total_steps = n_evals * ((Bpad + 31) / 32);
+        static const int target_wgs = getenv("RNDE_WGRAD_WGS") ? atoi(getenv("RNDE_WGRAD_WGS")) : 768;
+        int sc = std::max(1, std::min({target_wgs / pblocks, total_steps, 256}));
+        const int steps_per_chunk = (total_steps + sc - 1) / sc;
+        sc = (total_steps + steps_per_chunk - 1) / steps_per_chunk;
+        if ((size_t)(*chunk_cursor + sc) * (size_t)len > h->bw.slab_floats) { h->err = "weight-gradient slab overflow"; return RNDE_ERR_BAD_ARG; }
+        if (tall) hipLaunchKernelGGL((rnde_wgrad2_kernel<true>), dim3(pblocks, sc), dim3(256), 0, s, ev, n_evals, steps_per_chunk, M, Nx, Bpad, dst);
+        else hipLaunchKernelGGL((rnde_wgrad2_kernel<false>), dim3(pblocks, sc), dim3(256), 0, s, ev, n_evals, steps_per_chunk, M, Nx, Bpad, dst);
+        HIPCHK(h, hipGetLastError());
+        *chunk_cursor += sc;
+        return RNDE_OK;
     } else if (tall) hipLaunchKernelGGL((rnde_wgrad_kernel<2, 4>), dim3(blocks, chunks), dim3(64), 0, s, ev, n_evals, per_chunk, M, Nx, Bpad, dst);
     else hipLaunchKernelGGL((rnde_wgrad_kernel<4, 2>), dim3(blocks, chunks), dim3(64), 0, s, ev, n_evals, per_chunk, M, Nx, Bpad, dst);
     HIPCHK(h, hipGetLastError());

@@ -554,7 +554,10 @@ __global__ __launch_bounds__(256) void rnde_wgrad2_kernel(const EvalDesc* __rest
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, kk = lane >> 5;
     const int blk = blockIdx.x, chunk = blockIdx.y;
     const int m0 = SPLIT_M ? blk * 128 : 0, n0 = SPLIT_M ? 0 : blk * 128;
-    const int e0 = chunk * per_chunk, e1 = min(n_evals, e0 + per_chunk);
+    // chunk = a contiguous range of 32-column steps of the (evaluation, column) axis -- not whole evaluations -- so that the
+    // host can pick the workgroup count that fills the chip in whole rounds (per_chunk = steps per chunk)
+    const int steps_per_eval = (Bpad + 32 - 1) / 32;
+    const int s_lo = chunk * per_chunk, s_hi = min(n_evals * steps_per_eval, s_lo + per_chunk);
     f32x16 acc[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -563,11 +566,10 @@ __global__ __launch_bounds__(256) void rnde_wgrad2_kernel(const EvalDesc* __rest
     const bool mvec = (M & 3) == 0, nvec = (Nx & 3) == 0;
     // software pipeline over (evaluation, 32-column step): the next step's 8 float4 are fetched into registers while
     // the current step's 64 MFMAs per wave run, and written to LDS after the barrier that retires the current step
-    const int steps_per_eval = (Bpad + KC - 1) / KC;
-    const int total_steps = (e1 - e0) * steps_per_eval;
+    const int total_steps = max(0, s_hi - s_lo);
     f32x4 zreg[4], xreg[4];
     auto fetch = [&](int step) {
-        const int e = e0 + step / steps_per_eval, c0 = (step % steps_per_eval) * KC;
+        const int e = (s_lo + step) / steps_per_eval, c0 = ((s_lo + step) % steps_per_eval) * KC;
         const float* __restrict__ Z = evals[e].Z;
         const float* __restrict__ X = evals[e].X;
         const float te = evals[e].t;

@@ -74,6 +74,51 @@ def cpu_baseline(batch=256, steps=1):
                       f"OpenMP over {cores} threads; NOT the Julia reference, which cannot run here)", "nfe": int(nfe)}
 
 
+def bench_latent(args):
+    """SURVEY.md 8d config 4 ("latent ODE dynamics only, for the kernel benchmark"): gen_dynamics of experiments/latent_ode.jl:113-124
+    (tanh + 8 x Dense(20<->50, tanh), P = 8,280), B = 512, 49 saveat points on [0, 1], Tsit5 at 1.4e-8; forward + reverse of the layer
+    call.  Not the headline metric: printed only with --workload latent."""
+    import ctypes as C
+    import regneuralde_jl_amd as rn
+    from regneuralde_jl_amd import _lib
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    B, T = args.batch, 49
+    g = torch.Generator().manual_seed(1999)
+    dyn = rn.LatentGenDynamics(generator=g)
+    grid = [i / (T - 1) for i in range(T)]
+    node = rn.TrackedNeuralODE(dyn, [0.0, 1.0], False, True, "Tsit5", saveat=grid, reltol=1.4e-8, abstol=1.4e-8, max_batch=B, max_attempts=256)
+    z0 = torch.randn(B, 20, generator=g).to(device).requires_grad_(True)
+    p = node.p.to(device).clone().requires_grad_(True)
+    w = torch.randn(B, T, 20, generator=g).to(device)
+
+    def step():
+        z0.grad = None; p.grad = None
+        res, nfe, sv = node(z0, p)
+        ((res * w).sum() / B + 10.0 * sv.saveval.mean()).backward()
+        return nfe
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nfes = [step() for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    L = _lib.lib()
+    h = node._acquire(z0.detach(), False)
+    us = C.c_float(0)
+    _lib.check(h.ptr, L.rnde_bench_attempt(h.ptr, z0.detach().contiguous().data_ptr(), p.detach().data_ptr(), B, 200, C.byref(us), None))
+    flops = 6 * 2 * B * 8280
+    print(json.dumps({"metric": "forward+reverse samples/sec, latent-ODE dynamics (config 4)", "value": B * args.steps / el, "unit": "samples/s",
+                      "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
+                      "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "mean_nfe": sum(nfes) / len(nfes),
+                      "config": {"workload": "latent ODE gen_dynamics D=20, 8 Dense layers 20<->50 tanh, B=512, 49 saveat points, Tsit5 1.4e-8 (chain engine)"},
+                      "roofline": {"bound": "mfma", "achieved": flops / (us.value * 1e-6) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                                   "frac": flops / (us.value * 1e-6) / 1e12 / MFMA_F32_PEAK_TF, "traffic": None,
+                                   "kernel": "rnde_chain_kernel: one attempted Tsit5 step = 1 launch; latency bound (32 waves on the chip)",
+                                   "us_per_attempt": us.value}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,7 +128,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--col-tile", type=int, default=0)
     ap.add_argument("--autograd", action="store_true", help="head + loss through torch.autograd instead of the fused C-ABI head")
+    ap.add_argument("--workload", default="mnist", choices=["mnist", "latent"], help="mnist = BASELINE.json's metric (default); latent = SURVEY 8d config 4")
     args = ap.parse_args()
+    if args.workload == "latent":
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the integration path has no CPU fallback")
+        return bench_latent(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -68,7 +68,8 @@ typedef struct {
     int32_t track_initdt;  /* 1: reverse pass differentiates the initial-step heuristic */
     int32_t max_attempts;  /* tape capacity in attempted steps */
     int32_t device;        /* HIP device ordinal */
-    int32_t col_tile;      /* 0 = auto; 4, 8 or 16 batch columns per workgroup */
+    int32_t col_tile;      /* 0 = auto; MNIST form: 16 (stage engine, default), 4 / 8 (column-owner engine); small-width chains:
+                            * 64 (chain engine, 16 columns per wave, default), 32 (4 columns per wave: experimental, forward only) */
 } rnde_node_config;
 
 typedef struct rnde_node rnde_node;

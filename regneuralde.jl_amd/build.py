@@ -8,7 +8,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB = os.environ.get("RNDE_LIB") or os.path.join(_HERE, "lib", "librnde.so")
 SOURCES = ["rnde.hip"]
 HEADERS = ["rnde_device.h", "rnde_fwd.h", "rnde_bwd.h", "rnde_stage.h", "rnde_bstage.h", "rnde_stage_persist.h", "rnde_bstage_persist.h",
-           "rnde_chain.h", "rnde_bchain.h", "rnde_head.h", os.path.join("..", "..", "include", "rnde.h")]
+           "rnde_chain.h", "rnde_quad.h", "rnde_bchain.h", "rnde_head.h", os.path.join("..", "..", "include", "rnde.h")]
 
 
 def needs_build():

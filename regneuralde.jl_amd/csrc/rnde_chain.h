@@ -25,6 +25,7 @@
 #pragma once
 #include "rnde_fwd.h"
 #include "rnde_stage.h"   // mfma16
+#include "rnde_quad.h"    // layout 1: four batch columns per wave
 
 namespace rnde {
 
@@ -45,7 +46,9 @@ struct ChainParams {
     StepParams F;          // shared controller / tape parameters (H and the packed-weight fields are unused)
     ChainGeo G;
     const float* frags;    // [nfrag_f + nfrag_b + nfrag_t][64]
-    int ntiles;            // Bpad / 16
+    int ntiles;            // wave tiles: Bpad / 16 (layout 0) or Bpad / 4 (layout 1)
+    QuadGeo Q2;            // layout 1 (rnde_quad.h)
+    const f32x4* qtab;     // its tables
 };
 
 // record layout (fragment order arrays of ntiles * nksD * 64 floats): k2..k7 | unew | uprev copy | k1 copy | g2..g6
@@ -322,7 +325,7 @@ enum { CM_STEP = 0, CM_INIT_A = 1, CM_INIT_B = 2, CM_FEVAL = 3, CM_FINISH = 4 };
 // Dense output of the attempt accepted last (record Rp) at save indices [lo, hi), wave-tile local
 template <int NKD>
 __device__ __forceinline__ void chain_dense_points(const StepParams& P, const ChainRec& L, const float* Rp, size_t fo, int nksD, float tp, float dtp_,
-                                                   float tnew, int lo, int hi, int gcol, int g, bool colok) {
+                                                   float tnew, int lo, int hi, int gcol, int fb, int fs, bool colok) {
     float up[NKD], un[NKD], k[7][NKD];
 #pragma unroll
     for (int q = 0; q < NKD; ++q) {
@@ -347,7 +350,7 @@ __device__ __forceinline__ void chain_dense_points(const StepParams& P, const Ch
                     for (int j = 1; j < 7; ++j) acc += b[j] * k[j][q];
                     o = up[q] + dtp_ * acc;
                 }
-                const int f = 4 * q + g;
+                const int f = fb + fs * q;
                 if (colok && f < P.D) P.sv_out[((size_t)gcol * P.nsave + idx) * P.D + f] = o;
             }
         }
@@ -360,20 +363,29 @@ __device__ __forceinline__ void chain_dense_points(const StepParams& P, const Ch
 #define CHAIN_STAMP(i) do { } while (0)
 #endif
 
-template <int NKD, int MODE, int ALT = 0>
+template <int NKD, int MODE, int ALT = 0, int LAY = 0>
 __global__ __launch_bounds__(64 * kCW) void rnde_chain_kernel(const ChainParams Q, const int n, float* __restrict__ u_out) {
     const StepParams& P = Q.F;
     const ChainGeo& G = Q.G;
+    static_assert(LAY == 0 || NKD == 4, "layout 1 keeps 4 registers per state array");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* FR = smem;
     float* BF = FR + (size_t)G.nfrag_f * 64;
-    const int fill_units = (G.nfrag_f + G.nfrag_b + 3) >> 2;
-    float* RED = smem + (size_t)fill_units * 256;   // [3][kCW]
+    const int fill_units = LAY ? (Q.Q2.units_f + Q.Q2.units_b) : ((G.nfrag_f + G.nfrag_b + 3) >> 2);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // layout 1: wave-private activation images and K-split partial buffers behind the tables (rnde_quad.h)
+    constexpr int kQPriv = 5 * 4 * kQRS + 16;
+    float* QP = smem + (size_t)fill_units * 256 + (size_t)wave * kQPriv;
+    float* RED = smem + (size_t)fill_units * 256 + (LAY ? kCW * kQPriv : 0);   // [3][kCW]
+    const f32x4* TAB = (const f32x4*)smem;
+    i32x4* PLAN = (i32x4*)(RED + 64);                                            // layout 1: per-layer plan (rnde_quad.h)
     const int tile = blockIdx.x * kCW + wave;
     const bool tile_ok = tile < Q.ntiles;
-    const int col = lane & 15, g = lane >> 4, gcol = tile * 16 + col;
+    // feature of register q of this lane = fb + fs * q; its batch column = gcol
+    const int g = lane >> 4;
+    const int fb = LAY ? 4 * (lane >> 2) : g, fs = LAY ? 1 : 4;
+    const int gcol = LAY ? tile * 4 + (lane & 3) : tile * 16 + (lane & 15);
     const bool colok = tile_ok && gcol < P.B;
     const bool writer = (blockIdx.x == 0 && tid == 0);
     constexpr int nksD = NKD;                                  // arena arrays are padded to NKD k-steps
@@ -381,17 +393,30 @@ __global__ __launch_bounds__(64 * kCW) void rnde_chain_kernel(const ChainParams 
     const size_t fo = ((size_t)tile * NKD) * 64 + lane;        // fragment-order offset of this lane's k-step 0
 
     CHAIN_STAMP(0);
-    if constexpr (MODE != CM_FINISH) chain_fill_lds(Q.frags, smem, fill_units, wave, lane);
+    if constexpr (MODE != CM_FINISH) {
+        if constexpr (LAY == 1) {
+            for (int i = lane; i < kQPriv; i += 64) QP[i] = 0.f;     // no NaN bit patterns under the zero-weight padding
+            quad_build_plan(Q.Q2, PLAN, false, tid, 64 * kCW);
+            chain_fill_lds((const float*)Q.qtab, smem, fill_units, wave, lane);
+        } else chain_fill_lds(Q.frags, smem, fill_units, wave, lane);
+    }
+    auto EVAL = [&](float ts_, const float (&gin)[NKD], float (&kout)[NKD]) {
+        if constexpr (LAY == 1) {
+            f32x4 gi = {gin[0], gin[1], gin[2], gin[3]}, ko;
+            quad_eval(Q.Q2, PLAN, TAB, QP, QP + 4 * kQRS, QP + 8 * kQRS, ts_, gi, ko, lane);
+            kout[0] = ko[0]; kout[1] = ko[1]; kout[2] = ko[2]; kout[3] = ko[3];
+        } else chain_eval<NKD, ALT>(G, FR, BF, ts_, gin, kout, lane);
+    };
     CHAIN_STAMP(1);
 
     if constexpr (MODE == CM_FEVAL) {
         if (!tile_ok) return;
         float gv[NKD], kv[NKD];
 #pragma unroll
-        for (int q = 0; q < NKD; ++q) gv[q] = ldc(P.x, P.D, gcol, 4 * q + g, colok && q < nksD);
-        chain_eval<NKD, ALT>(G, FR, BF, P.forced_t, gv, kv, lane);
+        for (int q = 0; q < NKD; ++q) gv[q] = ldc(P.x, P.D, gcol, fb + fs * q, colok && q < nksD);
+        EVAL(P.forced_t, gv, kv);
 #pragma unroll
-        for (int q = 0; q < NKD; ++q) if (q < nksD && colok && 4 * q + g < P.D) P.dbg_out[(size_t)gcol * P.D + 4 * q + g] = kv[q];
+        for (int q = 0; q < NKD; ++q) if (q < nksD && colok && fb + fs * q < P.D) P.dbg_out[(size_t)gcol * P.D + fb + fs * q] = kv[q];
         return;
     } else if constexpr (MODE == CM_INIT_A || MODE == CM_INIT_B) {
         // ---- initial-step heuristic, SURVEY.md B.1 (same arithmetic as rnde_step_kernel) ----
@@ -412,7 +437,7 @@ __global__ __launch_bounds__(64 * kCW) void rnde_chain_kernel(const ChainParams 
             float xv[NKD], fv[NKD], gv[NKD], kv[NKD];
 #pragma unroll
             for (int q = 0; q < NKD; ++q) {
-                xv[q] = ldc(P.x, P.D, gcol, 4 * q + g, colok && q < nksD);
+                xv[q] = ldc(P.x, P.D, gcol, fb + fs * q, colok && q < nksD);
                 fv[q] = 0.f;
                 if constexpr (MODE == CM_INIT_B) {
                     if (q < nksD) fv[q] = P.f0[fo + q * 64];
@@ -420,12 +445,12 @@ __global__ __launch_bounds__(64 * kCW) void rnde_chain_kernel(const ChainParams 
                     if (q < nksD) P.u1[fo + q * 64] = gv[q];
                 } else gv[q] = xv[q];
             }
-            chain_eval<NKD, ALT>(G, FR, BF, (MODE == CM_INIT_B) ? P.t0 + dt0 : P.t0, gv, kv, lane);
+            EVAL((MODE == CM_INIT_B) ? P.t0 + dt0 : P.t0, gv, kv);
 #pragma unroll
             for (int q = 0; q < NKD; ++q) {
                 if (q < nksD) {
                     ((MODE == CM_INIT_B) ? P.f1 : P.f0)[fo + q * 64] = kv[q];
-                    if (colok && 4 * q + g < P.D) {
+                    if (colok && fb + fs * q < P.D) {
                         const float sk = P.abstol + fabsf(xv[q]) * P.reltol;
                         if constexpr (MODE == CM_INIT_A) { const float a = xv[q] / sk, b = kv[q] / sk; pa += a * a; pb += b * b; }
                         else { const float a = (kv[q] - fv[q]) / sk; pa += a * a; }
@@ -453,7 +478,7 @@ __global__ __launch_bounds__(64 * kCW) void rnde_chain_kernel(const ChainParams 
                 if (S.next_save > 0) {
 #pragma unroll
                     for (int q = 0; q < NKD; ++q) {
-                        const int f = 4 * q + g;
+                        const int f = fb + fs * q;
                         if (q < nksD && colok && f < P.D) P.sv_out[((size_t)gcol * P.nsave) * P.D + f] = P.x[(size_t)gcol * P.D + f];
                     }
                 }
@@ -463,7 +488,7 @@ __global__ __launch_bounds__(64 * kCW) void rnde_chain_kernel(const ChainParams 
                 if (hi > lo && !pv.done) {
                     const float dtp_ = (P.t1 - pv.t < pv.dtp) ? (P.t1 - pv.t) : pv.dtp;
                     const float* Rp = P.arena + (long long)S.live * P.rec_stride;     // accepted => it is the live record
-                    chain_dense_points<NKD>(P, L, Rp, fo, nksD, pv.t, dtp_, S.t, lo, hi, gcol, g, colok);
+                    chain_dense_points<NKD>(P, L, Rp, fo, nksD, pv.t, dtp_, S.t, lo, hi, gcol, fb, fs, colok);
                 }
             }
         }
@@ -471,7 +496,7 @@ __global__ __launch_bounds__(64 * kCW) void rnde_chain_kernel(const ChainParams 
             if (!u_out || !tile_ok) return;
 #pragma unroll
             for (int q = 0; q < NKD; ++q) {
-                const int f = 4 * q + g;
+                const int f = fb + fs * q;
                 if (q < nksD && colok && f < P.D)
                     u_out[(size_t)gcol * P.D + f] = S.live < 0 ? P.x[(size_t)gcol * P.D + f] : P.arena[(long long)S.live * P.rec_stride + L.unew() + fo + q * 64];
             }
@@ -493,7 +518,7 @@ __global__ __launch_bounds__(64 * kCW) void rnde_chain_kernel(const ChainParams 
                     float k1 = 0.f;
                     up[q] = 0.f;
                     if (q < nksD) {
-                        if (S.live < 0) { up[q] = ldc(P.x, P.D, gcol, 4 * q + g, colok); k1 = P.f0[fo + q * 64]; }
+                        if (S.live < 0) { up[q] = ldc(P.x, P.D, gcol, fb + fs * q, colok); k1 = P.f0[fo + q * 64]; }
                         else { up[q] = Rl[L.unew() + fo + q * 64]; k1 = Rl[L.k(7) + fo + q * 64]; }
                         if (P.tape || P.nsave > 0) { R[L.upc() + fo + q * 64] = up[q]; R[L.k1c() + fo + q * 64] = k1; }
                     }
@@ -515,11 +540,7 @@ __global__ __launch_bounds__(64 * kCW) void rnde_chain_kernel(const ChainParams 
 #pragma unroll
                         for (int q = 0; q < NKD; ++q) if (q < nksD) R[L.g(s + 1) + fo + q * 64] = gq[q];
                     }
-#ifdef RNDE_DIAG
-                    chain_eval<NKD, ALT>(G, FR, BF, t + kTsC[s] * dt, gq, kv, lane, (s == 2 && P.dbg_out && blockIdx.x == 0 && tid == 0) ? (unsigned long long*)P.dbg_out : nullptr);
-#else
-                    chain_eval<NKD, ALT>(G, FR, BF, t + kTsC[s] * dt, gq, kv, lane);
-#endif
+                    EVAL(t + kTsC[s] * dt, gq, kv);
                     CHAIN_STAMP(3 + s);
                     if (s == 5 && P.reg_kind >= 2) {
 #pragma unroll
@@ -528,7 +549,7 @@ __global__ __launch_bounds__(64 * kCW) void rnde_chain_kernel(const ChainParams 
                     if (s == 6 && P.reg_kind >= 2) {   // ||k7 - k6||^2, ||unew - g6||^2 (eigen_est of the composite algorithm)
 #pragma unroll
                         for (int q = 0; q < NKD; ++q) {
-                            if (colok && 4 * q + g < P.D) { const float d1 = kv[q] - k6[q], d2 = un[q] - g6[q]; part1 += d1 * d1; part2 += d2 * d2; }
+                            if (colok && fb + fs * q < P.D) { const float d1 = kv[q] - k6[q], d2 = un[q] - g6[q]; part1 += d1 * d1; part2 += d2 * d2; }
                         }
                     }
                     const float bts = kTsBt[s];
@@ -546,7 +567,7 @@ __global__ __launch_bounds__(64 * kCW) void rnde_chain_kernel(const ChainParams 
                 // embedded error estimate, SURVEY.md B.3
 #pragma unroll
                 for (int q = 0; q < NKD; ++q) {
-                    if (q < nksD && colok && 4 * q + g < P.D) {
+                    if (q < nksD && colok && fb + fs * q < P.D) {
                         const float ut = dt * E[q];
                         const float sk = P.abstol + fmaxf(fabsf(up[q]), fabsf(un[q])) * P.reltol;
                         const float r = ut / sk;
@@ -569,11 +590,11 @@ __global__ __launch_bounds__(64 * kCW) void rnde_chain_kernel(const ChainParams 
 }
 
 // fragment order <-> caller layout (debug entry points, and k1 hand-over of rnde_debug_attempt)
-__global__ void rnde_chain_convert_kernel(const float* __restrict__ src, float* __restrict__ dst, int D, int B, int ntiles, int nksD, int to_caller) {
+__global__ void rnde_chain_convert_kernel(const float* __restrict__ src, float* __restrict__ dst, int D, int B, int ntiles, int nksD, int to_caller, int lay) {
     const long long total = (long long)ntiles * nksD * 64;
     for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
         const int lane = (int)(e & 63), q = (int)((e >> 6) % nksD), tile = (int)((e >> 6) / nksD);
-        const int f = 4 * q + (lane >> 4), gcol = tile * 16 + (lane & 15);
+        const int f = lay ? 4 * (lane >> 2) + q : 4 * q + (lane >> 4), gcol = lay ? tile * 4 + (lane & 3) : tile * 16 + (lane & 15);
         const bool ok = f < D && gcol < B;
         if (to_caller) { if (ok) dst[(size_t)gcol * D + f] = src[e]; }
         else dst[e] = ok ? src[(size_t)gcol * D + f] : 0.f;

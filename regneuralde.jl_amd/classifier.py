@@ -41,11 +41,13 @@ class ClassifierNODE:
         return u @ W + b, nfe, sv
 
 
-def fused_loss_and_grad(model, x, y, lam=1.0e2, regularize=True, tspan=None):
+def fused_loss_and_grad(model, x, y, lam=1.0e2, regularize=True, tspan=None, sync=True):
     """One training-step gradient without a tape library in the loop:
     [solve, taped] -> [fused Dense(784,10) + logitcrossentropy + their reverse] -> [reverse solve], all through the C ABI.
     Same loss surface as `loss_function` (experiments/mnist_node.jl:132-137, agg = mean): sets .grad on p2 and p3 and
-    returns (total_loss, cross_entropy, reg, nfe) as Python floats / int (the call already synchronises)."""
+    returns (total_loss, cross_entropy, reg, nfe) as Python floats / int (the call already synchronises).
+    sync=False: the reverse pass is only enqueued (rnde_node_backward_async) and the losses come back as device tensors, so a
+    training loop can queue the optimiser update and the next step underneath it; nothing is read on the host."""
     import ctypes as C
     from . import _lib
     node = model.node
@@ -76,6 +78,12 @@ def fused_loss_and_grad(model, x, y, lam=1.0e2, regularize=True, tspan=None):
         svb = (C.c_float * n)(*([lam / n] * n))
     xbar = torch.empty_like(x2)
     p2bar = torch.empty_like(p2)
+    if not sync:
+        _lib.check(h.ptr, L.rnde_node_backward_async(h.ptr, ubar.data_ptr(), svb, xbar.data_ptr(), p2bar.data_ptr(), None, stream))
+        model.p2.grad, model.p3.grad = p2bar, p3bar
+        node.last_nfe = int(nfe.value)
+        model._keep = (ubar, xbar, u)            # buffers the enqueued kernels still use
+        return ce + reg, ce, reg, int(nfe.value)
     _lib.check(h.ptr, L.rnde_node_backward(h.ptr, ubar.data_ptr(), svb, xbar.data_ptr(), p2bar.data_ptr(), None, stream))
     model.p2.grad, model.p3.grad = p2bar, p3bar
     node.last_nfe = int(nfe.value)

@@ -64,6 +64,7 @@ struct rnde_node {
     int B = 0, Bpad = 0, nwg = 0, n_att = 0, predicted = 0;
     float t0 = 0, t1 = 0;
     bool have_tape = false;
+    bool pending_bwd = false;   // an asynchronous reverse pass whose health words have not been looked at yet
     std::vector<int> sv_index;  // per attempt: index into saveval or -1
     int n_saveval = 0;
     std::string err;
@@ -71,7 +72,7 @@ struct rnde_node {
 
 static std::string g_create_err;
 static rnde_status chain_bwd_run(rnde_node* h, const float* u_bar_dev, const float* saveval_bar_host, float* x_bar_dev,
-                                 float* p_bar_dev, float* tspan_bar_host, hipStream_t s);
+                                 float* p_bar_dev, float* tspan_bar_host, hipStream_t s, bool sync = true, float* tspan_bar_dev = nullptr);
 
 #define HIPCHK(h, call)                                                                              \
     do {                                                                                             \
@@ -574,7 +575,15 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
         HIPCHK(h, hipMemcpyAsync(h->h_meta, h->meta, (size_t)launched * sizeof(StepMeta), hipMemcpyDeviceToHost, s));
         HIPCHK(h, hipMemcpyAsync(h->h_init, h->initrec, sizeof(InitRec), hipMemcpyDeviceToHost, s));
         HIPCHK(h, hipStreamSynchronize(s));
-        if (h->engine == 2 && persist_check_result(h, SQ.C, SQ.R, s)) return RNDE_INTERNAL_RETRY;
+        if (h->engine == 2 && persist_check_result(h, SQ.C, SQ.R, s)) {
+            if (h->pending_bwd) {   // the failure may belong to the asynchronous reverse pass before this forward: its outputs cannot be trusted
+                h->pending_bwd = false;
+                h->err = "a persistent kernel abandoned its hand-off during or after the previous asynchronous reverse pass: the gradients of that step are invalid (multi-launch kernels now in use)";
+                return RNDE_ERR_HIP;
+            }
+            return RNDE_INTERNAL_RETRY;
+        }
+        h->pending_bwd = false;
         if (h->h_ctl->done) break;
         if (launched >= cap) { h->err = "max_attempts reached"; h->n_att = h->h_ctl->n_att; return RNDE_ERR_MAX_ATTEMPTS; }
         chunk = 4;
@@ -636,6 +645,14 @@ extern "C" rnde_status rnde_node_release_tape(rnde_node* h) {
     if (!h) return RNDE_ERR_BAD_ARG;
     h->have_tape = false;
     return RNDE_OK;
+}
+
+extern "C" rnde_status rnde_node_backward_async(rnde_node* h, const float* u_bar_dev, const float* saveval_bar_host, float* x_bar_dev,
+                                                float* p_bar_dev, float* tspan_bar_dev, void* stream) {
+    if (!h) return RNDE_ERR_BAD_ARG;
+    if (!h->have_tape) { h->err = "no recorded forward"; return RNDE_ERR_NO_TAPE; }
+    if (h->engine == 3) return chain_bwd_run(h, u_bar_dev, saveval_bar_host, x_bar_dev, p_bar_dev, nullptr, (hipStream_t)stream, false, tspan_bar_dev);
+    return bwd_run(h, u_bar_dev, saveval_bar_host, x_bar_dev, p_bar_dev, nullptr, (hipStream_t)stream, false, tspan_bar_dev);
 }
 
 extern "C" rnde_status rnde_node_backward(rnde_node* h, const float* u_bar_dev, const float* saveval_bar_host,
@@ -934,7 +951,7 @@ static rnde_status launch_wgrad_reduce(rnde_node* h, const float* slab, int chun
 }
 
 static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* saveval_bar_host, float* x_bar_dev,
-                           float* p_bar_dev, float* tspan_bar_host, hipStream_t s) {
+                           float* p_bar_dev, float* tspan_bar_host, hipStream_t s, bool sync, float* tspan_bar_dev) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
     rnde_status st = bwd_prepare(h);
     if (st != RNDE_OK) return st;
@@ -1079,6 +1096,12 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
     if (st != RNDE_OK) return st;
     st = launch_wgrad_reduce(h, slab2w, cur2, h->D, h->H, p_bar_dev + (size_t)h->H * (h->D + 2), s);      // [W2; b2]
     if (st != RNDE_OK) return st;
+    if (!sync) {   // rnde_node_backward_async: no host round trip; the health words are looked at by the next synchronising call
+        if (tspan_bar_dev) HIPCHK(h, hipMemcpyAsync(tspan_bar_dev, b.tspan_out, 8, hipMemcpyDeviceToDevice, s));
+        h->have_tape = false;
+        h->pending_bwd = (h->engine == 2 && h->persist == 1);
+        return RNDE_OK;
+    }
     HIPCHK(h, hipMemcpyAsync(h->h_scal, b.tspan_out, 8, hipMemcpyDeviceToHost, s));
     if (h->engine == 2) persist_check_enqueue(h, h->sR * (Q.F.Bpad / 16), s);
     HIPCHK(h, hipStreamSynchronize(s));
@@ -1151,7 +1174,7 @@ static hipError_t launch_bchain_t(rnde_node* h, const BChainParams& Q, const std
 }
 
 static rnde_status chain_bwd_run(rnde_node* h, const float* u_bar_dev, const float* saveval_bar_host, float* x_bar_dev,
-                                 float* p_bar_dev, float* tspan_bar_host, hipStream_t s) {
+                                 float* p_bar_dev, float* tspan_bar_host, hipStream_t s, bool sync, float* tspan_bar_dev) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
     if (h->chain_lay) { h->err = "chain engine layout 1 (col_tile 32): reverse pass not built yet"; return RNDE_ERR_BAD_ARG; }
     BwdBuffers& b = h->bw;
@@ -1238,9 +1261,13 @@ static rnde_status chain_bwd_run(rnde_node* h, const float* u_bar_dev, const flo
         }
         HIPCHK(h, hipGetLastError());
     }
+    h->have_tape = false;
+    if (!sync) {
+        if (tspan_bar_dev) HIPCHK(h, hipMemcpyAsync(tspan_bar_dev, b.tspan_out, 8, hipMemcpyDeviceToDevice, s));
+        return RNDE_OK;
+    }
     HIPCHK(h, hipMemcpyAsync(h->h_scal, b.tspan_out, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
     if (tspan_bar_host) { tspan_bar_host[0] = h->h_scal[0]; tspan_bar_host[1] = h->h_scal[1]; }
-    h->have_tape = false;
     return RNDE_OK;
 }

@@ -650,4 +650,4 @@ __global__ void rnde_wgrad_reduce(const float* __restrict__ slab, int n_chunks, 
 
 struct rnde_node;
 static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* saveval_bar_host, float* x_bar_dev,
-                           float* p_bar_dev, float* tspan_bar_host, hipStream_t s);
+                           float* p_bar_dev, float* tspan_bar_host, hipStream_t s, bool sync = true, float* tspan_bar_dev = nullptr);

@@ -170,3 +170,22 @@ def test_fused_head_step_matches_autograd(rnde):
     assert abs(float(loss1) - loss2) <= 1e-5 * max(1.0, abs(loss2))
     for a, b in ((m1.p2.grad, m2.p2.grad), (m1.p3.grad, m2.p3.grad)):
         assert (a - b).abs().max() <= 5e-4 * b.abs().max()   # different fp32 association in the head GEMM
+
+
+def test_async_backward_matches_the_synchronous_one(rnde):
+    """rnde_node_backward_async (fused step with sync=False): same gradients as the synchronising call, valid in stream order."""
+    rn = rnde
+    g = torch.Generator().manual_seed(5)
+    dyn = rn.MLPDynamics(36, 10, generator=g)
+    node = rn.TrackedNeuralODE(dyn, [0.0, 1.0], True, True, "Tsit5", save_everystep=False, reltol=1e-3, abstol=1e-3, save_start=False,
+                               max_batch=16, max_attempts=64)
+    model = rn.ClassifierNODE(node, rn.Dense(36, 10, "identity", generator=g), device=torch.device("cuda", 0))
+    x = torch.rand(16, 36, generator=g).cuda()
+    y = torch.eye(10)[torch.randint(0, 10, (16,), generator=g)].cuda()
+    l1, ce1, reg1, nfe1 = rn.fused_loss_and_grad(model, x, y, lam=50.0)
+    g2, g3 = model.p2.grad.clone(), model.p3.grad.clone()
+    l2, ce2, reg2, nfe2 = rn.fused_loss_and_grad(model, x, y, lam=50.0, sync=False)
+    assert torch.is_tensor(l2) and nfe1 == nfe2
+    torch.cuda.synchronize()
+    assert torch.equal(model.p2.grad, g2) and torch.equal(model.p3.grad, g3)
+    assert abs(float(l2) - l1) <= 1e-6 * max(1.0, abs(l1))

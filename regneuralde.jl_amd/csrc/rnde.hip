@@ -64,7 +64,8 @@ struct rnde_node {
     int B = 0, Bpad = 0, nwg = 0, n_att = 0, predicted = 0;
     float t0 = 0, t1 = 0;
     bool have_tape = false;
-    bool pending_bwd = false;   // an asynchronous reverse pass whose health words have not been looked at yet
+    bool pending_bwd = false;
+    float* diag_buf = nullptr;   // (RNDE_DIAG builds) cycle stamps   // an asynchronous reverse pass whose health words have not been looked at yet
     std::vector<int> sv_index;  // per attempt: index into saveval or -1
     int n_saveval = 0;
     std::string err;
@@ -968,6 +969,9 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
     Q.ubar = u_bar_dev; Q.xbar = x_bar_dev; Q.tspan_out = b.tspan_out;
     Q.n_att = n_att; Q.track_ctrl = h->cfg.track_ctrl; Q.track_initdt = h->cfg.track_initdt; Q.reg_kind = h->cfg.regularize;
     Q.bpart_n = Q.F.nwg;
+#ifdef RNDE_DIAG
+    if (getenv("RNDE_DIAG_BWD")) { if (!h->diag_buf) hipMalloc((void**)&h->diag_buf, 512); hipMemset(h->diag_buf, 0, 512); Q.F.dbg_out = h->diag_buf; }
+#endif
     Q.sv_T = (int)h->saveat.size();
     Q.sv_ubar0 = (!h->saveat.empty() && h->saveat[0] == h->t0) ? u_bar_dev : nullptr;
     if (!h->saveat.empty() && h->engine != 2) { h->err = "saveat reverse pass runs on the stage engine only"; return RNDE_ERR_BAD_ARG; }
@@ -1056,19 +1060,20 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
                     c2 = (float)(-eigb * ((double)mm.n1 / (double)mm.n2) / ((double)mm.n2 * (double)mm.n2));
                 }
             }
+            const double qo = pow((double)h->h_meta[n].qold_in, (double)kBeta2);   // for the scalar adjoint chain of the attempt
             if (h->persist == 1) {   // the attempt's 7 reverse launches as one (rnde_bstage_persist.h)
                 PersistSync Y{h->tslab, h->pabort, h->pxcc, h->persist_seq, h->persist_spins};
                 h->persist_seq += 8;
                 const dim3 pgrid(8 * BQ.R * ((BQ.C + 7) / 8));
-                if (h->act2) hipLaunchKernelGGL((rnde_bstage_attempt_kernel<1>), pgrid, blk, h->stage_lds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y);
-                else hipLaunchKernelGGL((rnde_bstage_attempt_kernel<0>), pgrid, blk, h->stage_lds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y);
+                if (h->act2) hipLaunchKernelGGL((rnde_bstage_attempt_kernel<1>), pgrid, blk, h->stage_lds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo);
+                else hipLaunchKernelGGL((rnde_bstage_attempt_kernel<0>), pgrid, blk, h->stage_lds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo);
                 continue;
             }
-            if (h->act2) hipLaunchKernelGGL((rnde_bstage_kernel<1, BM_START>), grid, blk, h->stage_lds, s, BQ, n, 0, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n]);
-            else hipLaunchKernelGGL((rnde_bstage_kernel<0, BM_START>), grid, blk, h->stage_lds, s, BQ, n, 0, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n]);
+            if (h->act2) hipLaunchKernelGGL((rnde_bstage_kernel<1, BM_START>), grid, blk, h->stage_lds, s, BQ, n, 0, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], qo);
+            else hipLaunchKernelGGL((rnde_bstage_kernel<0, BM_START>), grid, blk, h->stage_lds, s, BQ, n, 0, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], qo);
             for (int j = 6; j >= 1; --j) {
-                if (h->act2) hipLaunchKernelGGL((rnde_bstage_kernel<1, BM_STAGE>), grid, blk, h->stage_lds, s, BQ, n, j, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n]);
-                else hipLaunchKernelGGL((rnde_bstage_kernel<0, BM_STAGE>), grid, blk, h->stage_lds, s, BQ, n, j, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n]);
+                if (h->act2) hipLaunchKernelGGL((rnde_bstage_kernel<1, BM_STAGE>), grid, blk, h->stage_lds, s, BQ, n, j, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], qo);
+                else hipLaunchKernelGGL((rnde_bstage_kernel<0, BM_STAGE>), grid, blk, h->stage_lds, s, BQ, n, j, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], qo);
             }
             if (overlap && (hi_att - n >= group || n == 0)) {       // attempts [n, hi_att) are final: their GEMM slice can start now
                 st = wgrad_group(6 * n, 6 * hi_att);
@@ -1096,6 +1101,17 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
     if (st != RNDE_OK) return st;
     st = launch_wgrad_reduce(h, slab2w, cur2, h->D, h->H, p_bar_dev + (size_t)h->H * (h->D + 2), s);      // [W2; b2]
     if (st != RNDE_OK) return st;
+#ifdef RNDE_DIAG
+    if (h->engine == 2 && h->persist == 1 && getenv("RNDE_DIAG_BWD")) {
+        unsigned long long hst[64] = {0};
+        hipStreamSynchronize(s);
+        hipMemcpy(hst, h->diag_buf, sizeof(hst), hipMemcpyDeviceToHost);
+        fprintf(stderr, "persistent reverse attempt (workgroup 0 thread 0, cycles): START %lld (entry->weights issued %lld, ->w1t %lld, ->array loads issued %lld, finish_attempt_scalars %lld, scalar chain %lld, vector part %lld), its phase D + put %lld\n", (long long)(hst[1]-hst[0]), (long long)(hst[43]-hst[0]), (long long)(hst[44]-hst[43]), (long long)(hst[40]-hst[44]), (long long)(hst[41]-hst[40]), (long long)(hst[42]-hst[41]), (long long)(hst[1]-hst[42]), (long long)(hst[2]-hst[1]));
+        for (int st = 0; st < 6; ++st) { const unsigned long long* q = hst + 3 + 5 * st; const unsigned long long prev = st == 0 ? hst[2] : hst[7 + 5 * (st - 1)];
+            fprintf(stderr, "  stage j=%d: poll %lld A %lld B %lld C %lld D+put %lld\n", 6 - st, (long long)(q[0]-prev), (long long)(q[1]-q[0]), (long long)(q[2]-q[1]), (long long)(q[3]-q[2]), st < 5 ? (long long)(q[4]-q[3]) : 0LL); }
+        fprintf(stderr, "  total %lld cycles\n", (long long)(hst[34]-hst[0]));
+    }
+#endif
     if (!sync) {   // rnde_node_backward_async: no host round trip; the health words are looked at by the next synchronising call
         if (tspan_bar_dev) HIPCHK(h, hipMemcpyAsync(tspan_bar_dev, b.tspan_out, 8, hipMemcpyDeviceToDevice, s));
         h->have_tape = false;

@@ -33,7 +33,7 @@ enum { BM_START = 0, BM_STAGE = 1 };
 
 template <int ACT2, int MODE>
 __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_kernel(const BStageParams Q, const int n, const int j, const StepMeta m,
-                                                                   const float eig_c1, const float eig_c2, const int sv_lo, const int sv_hi) {
+                                                                   const float eig_c1, const float eig_c2, const int sv_lo, const int sv_hi, const double qo_host) {
 #pragma clang fp contract(off)   // rounds exactly like rnde_bstage_attempt_kernel (rnde_bstage_persist.h): outputs are compared bit for bit
     const BwdParams& Bq = Q.B;
     const StepParams& P = Bq.F;
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_kernel(const BStagePa
                 qoldb_in = qoldb;
             }
             if (!(m.flags & F_QCLAMP) && !(m.flags & F_EZERO)) {
-                const double qo = pow((double)m.qold_in, (double)kBeta2);
+                const double qo = qo_host;   // = pow(qold_in, beta2), evaluated once on the host (a double pow per wave cost ~1 us of every launch)
                 q11b += qb / (qo * (double)kGamma);
                 qoldb_in += -(double)kBeta2 * qb * (double)m.q / (double)m.qold_in;
             }

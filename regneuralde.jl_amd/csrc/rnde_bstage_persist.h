@@ -14,9 +14,15 @@
 
 namespace rnde {
 
+#ifdef RNDE_DIAG
+#define BSTAMP(i) do { if (Q.B.F.dbg_out && wg == 0 && tid == 0) ((unsigned long long*)Q.B.F.dbg_out)[i] = clock64(); } while (0)
+#else
+#define BSTAMP(i) do { } while (0)
+#endif
+
 template <int ACT2>
 __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const BStageParams Q, const int n, const StepMeta m, const float eig_c1,
-                                                                          const float eig_c2, const int sv_lo, const int sv_hi, const PersistSync Y) {
+                                                                          const float eig_c2, const int sv_lo, const int sv_hi, const PersistSync Y, const double qo_host) {
 #pragma clang fp contract(off)
     const BwdParams& Bq = Q.B;
     const StepParams& P = Bq.F;
@@ -43,6 +49,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
     const size_t co = (size_t)gcol * P.D;
     if (tid == 0) Y.xcc[wg] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15;
 
+    BSTAMP(0);
     f32x4 wB[kSMaxHT], wD[kSMaxW];
 #pragma unroll
     for (int kb = 0; kb < kSMaxHT; ++kb)
@@ -50,6 +57,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
 #pragma unroll
     for (int kb = 0; kb < kSMaxW; ++kb)
         if (kb < Q.WT && w < Q.HT && rb * Q.WT + kb < Q.MT) wD[kb] = Q.pwDt[((size_t)w * Q.MT + rb * Q.WT + kb) * 64 + lane];
+    BSTAMP(43);
     float* R = P.arena + (long long)m.rec * P.rec_stride;
     float w1t_own[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -57,6 +65,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
         const int hr = 16 * w + 4 * (lane >> 4) + i;
         if (hr < P.H) w1t_own[i] = Q.p[(size_t)P.H * P.D + hr];
     }
+    BSTAMP(44);
     const float* W1t = Q.p + (size_t)P.H * P.D;
     const bool accepted = (m.flags & F_ACCEPT) != 0;
     const float dt = m.dt;
@@ -119,8 +128,23 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
     // ================= BM_START =================
     {
 #pragma clang fp contract(off)
+        // the attempt's arrays are requested first: they do not depend on the scalar chain below, whose own loads (partials of
+        // attempt n+1, BState) and double-precision arithmetic would otherwise sit in front of them (START: 21 k cycles)
+        f32x4 upv = {0.f, 0.f, 0.f, 0.f}, unv = upv, kq[7];
+#pragma unroll
+        for (int s = 0; s < 7; ++s) kq[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (tile_ok) {
+            upv = ld4(upsrc + co, r0, P.D, upok, upvec);
+            unv = ld4(R + L.unew() + co, r0, P.D, true, vec);
+            kq[0] = ld4(k1p + co, r0, P.D, true, vec);
+#pragma unroll
+            for (int s = 2; s <= 7; ++s) kq[s - 1] = ld4(R + L.k(s) + co, r0, P.D, true, vec);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep these requests in front of the scalar chain (the scheduler sinks them to their uses otherwise)
+        BSTAMP(40);
         double tb = 0, dtpb = 0, qoldb = 0, t1b = 0, t0b = 0;
         if (!first) finish_attempt_scalars(Bq, n + 1, lane, tb, dtpb, qoldb, t1b, t0b);
+        BSTAMP(41);
         float coef;
         {
             const double N = (double)P.D * (double)P.B;
@@ -138,7 +162,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
                 qoldb_in = qoldb;
             }
             if (!(m.flags & F_QCLAMP) && !(m.flags & F_EZERO)) {
-                const double qo = pow((double)m.qold_in, (double)kBeta2);
+                const double qo = qo_host;   // = pow(qold_in, beta2), evaluated once on the host (a double pow per wave cost ~1 us of every launch)
                 q11b += qb / (qo * (double)kGamma);
                 qoldb_in += -(double)kBeta2 * qb * (double)m.q / (double)m.qold_in;
             }
@@ -146,15 +170,10 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
             coef = m.eest > 0.f ? (float)(eb / (N * (double)m.eest)) : 0.f;
             if (writer) { BState b; b.tb_pre = tb; b.dtb_pre = dtb_pre; b.qoldb = qoldb_in; b.t1b = t1b; b.t0b = t0b; b.pad[0] = b.pad[1] = b.pad[2] = 0; Bq.bstate[n & 1] = b; }
         }
+        BSTAMP(42);
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         float S = 0.f, tau = 0.f, exdt = 0.f;
         if (tile_ok) {
-            const f32x4 upv = ld4(upsrc + co, r0, P.D, upok, upvec);
-            const f32x4 unv = ld4(R + L.unew() + co, r0, P.D, true, vec);
-            f32x4 kq[7];
-            kq[0] = ld4(k1p + co, r0, P.D, true, vec);
-#pragma unroll
-            for (int s = 2; s <= 7; ++s) kq[s - 1] = ld4(R + L.k(s) + co, r0, P.D, true, vec);
             f32x4 acc = tsBt(0) * kq[0], g6 = tsA(5, 0) * kq[0];
 #pragma unroll
             for (int s = 1; s < 7; ++s) { acc += tsBt(s) * kq[s]; if (s < 5) g6 += tsA(5, s) * kq[s]; }
@@ -222,7 +241,9 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
         }
         if (!colok) { tau = 0.f; exdt = 0.f; }
         pS[0] = S; pT[0] = tau; pX[0] = exdt;
+        BSTAMP(1);
         phase_d(v, 0, 1u);
+        BSTAMP(2);
     }
 
     bool alive = true;
@@ -246,6 +267,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
         bool dead = false;
         f32x4 zs = {0.f, 0.f, 0.f, 0.f};
         if (w < Q.HT) dead = !slab_poll_sum(Y, j & 1, Q.C, Q.R, Q.HT, ct, w, lane, tag, zs);
+        BSTAMP(3 + 5 * (6 - j));
         const float* hsrc = R + L.h(j + 1);
         float* z1dst = R + L.z1(j + 1);
         for (int ht = w; ht < Q.HT; ht += Q.WT) {
@@ -279,6 +301,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
             for (int q = 0; q < Q.WT; ++q) any += RED[24 + q];
             if (any != 0.f) { alive = false; return; }
         }
+        BSTAMP(4 + 5 * (6 - j));
         // ---- phase B ----
         f32x4 gb = {0.f, 0.f, 0.f, 0.f};
         if (tile_ok) {
@@ -300,6 +323,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
 #pragma unroll
             for (int i = 0; i < 4; ++i) if (r0 + i >= P.D) gb[i] = 0.f;
         }
+        BSTAMP(5 + 5 * (6 - j));
         // ---- phase C ----
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (tile_ok) {
@@ -340,7 +364,9 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
         }
         if (!colok) tau = 0.f;
         pS[7 - j] = S; pT[7 - j] = tau;
+        BSTAMP(6 + 5 * (6 - j));
         if constexpr (j > 1) phase_d(v, (j - 1) & 1, (unsigned)(7 - j + 1));
+        BSTAMP(7 + 5 * (6 - j));
     };
     stage(std::integral_constant<int, 6>{});
     stage(std::integral_constant<int, 5>{});
@@ -349,6 +375,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
     stage(std::integral_constant<int, 2>{});
     stage(std::integral_constant<int, 1>{});
     if (!alive) return;
+    BSTAMP(34);
 
     // ---- per-workgroup partials {S, tau, sum_j c_j tau_j (+ saveat dt-bar)}: same reduction order as the 7 launches ----
     __syncthreads();

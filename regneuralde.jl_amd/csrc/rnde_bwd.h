@@ -140,7 +140,13 @@ __device__ __forceinline__ void finish_attempt_scalars(const BwdParams& Q, int m
     const StepMeta mm = Q.F.meta[m];
     const float* part = Q.bpart + (size_t)(m & 1) * Q.bpart_n * 4;
     double S = 0, tau = 0, ctau = 0;
-    for (int i = lane; i < Q.bpart_n; i += 64) { S += (double)part[4 * i]; tau += (double)part[4 * i + 1]; ctau += (double)part[4 * i + 2]; }
+    for (int base = 0; base < Q.bpart_n; base += 256) {   // four entries per lane in flight (see sum_partials)
+        f32x4 e[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int i = base + lane + 64 * q; e[q] = i < Q.bpart_n ? *(const f32x4*)(part + 4 * (size_t)i) : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (base + lane + 64 * q < Q.bpart_n) { S += (double)e[q][0]; tau += (double)e[q][1]; ctau += (double)e[q][2]; }
+    }
     S = wave_sum_d(S); tau = wave_sum_d(tau); ctau = wave_sum_d(ctau);
     const double dtb = b.dtb_pre + S / (double)mm.dt + ctau;
     double tbx = b.tb_pre + tau;

@@ -214,9 +214,18 @@ __device__ __forceinline__ float wave_sum_f(float s) {
     return s;
 }
 // fixed-order sum of n fp32 partials, carried in double; identical result on every lane / workgroup
+// (four loads per lane are requested before the first add: the plain loop `for (i = lane; i < n; i += 64) s += part[i]` waits
+//  for each cold load in turn -- 8 k cycles in front of every launch for n = 224; same additions in the same order)
 __device__ __forceinline__ double sum_partials(const float* __restrict__ part, int n, int lane) {
     double s = 0;
-    for (int i = lane; i < n; i += 64) s += (double)part[i];
+    for (int base = 0; base < n; base += 256) {
+        const int i0 = base + lane, i1 = i0 + 64, i2 = i0 + 128, i3 = i0 + 192;
+        const float v0 = i0 < n ? part[i0] : 0.f, v1 = i1 < n ? part[i1] : 0.f, v2 = i2 < n ? part[i2] : 0.f, v3 = i3 < n ? part[i3] : 0.f;
+        if (i0 < n) s += (double)v0;
+        if (i1 < n) s += (double)v1;
+        if (i2 < n) s += (double)v2;
+        if (i3 < n) s += (double)v3;
+    }
     return wave_sum_d(s);
 }
 

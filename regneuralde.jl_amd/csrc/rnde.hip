@@ -916,6 +916,28 @@ static rnde_status launch_wgrad_part(rnde_node* h, const EvalDesc* ev, int n_eva
     float* dst = slab + (size_t)(*chunk_cursor) * len;
     static const bool legacy = getenv("RNDE_WGRAD_LEGACY") != nullptr;   // direct-from-global variant, kept for A/B runs
     const bool fits = tall ? (Nx + 2 <= 128) : (M <= 128);                // the staged kernel covers 128 on the un-split side
+    const bool no_v3 = getenv("RNDE_WGRAD_V2") != nullptr;                // A/B switch (read per call): keep the 32x32x2 staged kernel
+    const int wide = tall ? M : Nx + 2, narrow = tall ? Nx + 2 : M;
+    if (!legacy && !no_v3 && M % 4 == 0 && Nx % 4 == 0 && wide > 656 && wide <= 800 && narrow <= 112) {
+        // 16x16x4 kernel: two workgroups (the halves of the wide side) per chunk of 32-column steps
+        const int total_steps = n_evals * ((Bpad + 31) / 32);
+        static const int target_chunks = getenv("RNDE_WGRAD3_CHUNKS") ? atoi(getenv("RNDE_WGRAD3_CHUNKS")) : 128;
+        int sc = std::max(1, std::min({target_chunks, total_steps, 256}));
+        const int steps_per_chunk = (total_steps + sc - 1) / sc;
+        sc = (total_steps + steps_per_chunk - 1) / steps_per_chunk;
+        if ((size_t)(*chunk_cursor + sc) * (size_t)len > h->bw.slab_floats) { h->err = "weight-gradient slab overflow"; return RNDE_ERR_BAD_ARG; }
+        const size_t lds = (size_t)2 * 32 * (464 + 144) * sizeof(float);   // two buffers
+        static const hipError_t attr = [&] {
+            hipError_t e = hipFuncSetAttribute((const void*)rnde_wgrad3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            return e == hipSuccess ? hipFuncSetAttribute((const void*)rnde_wgrad3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) : e;
+        }();
+        HIPCHK(h, attr);
+        if (tall) hipLaunchKernelGGL((rnde_wgrad3_kernel<true>), dim3(2, sc), dim3(448), lds, s, ev, n_evals, steps_per_chunk, M, Nx, Bpad, dst);
+        else hipLaunchKernelGGL((rnde_wgrad3_kernel<false>), dim3(2, sc), dim3(448), lds, s, ev, n_evals, steps_per_chunk, M, Nx, Bpad, dst);
+        HIPCHK(h, hipGetLastError());
+        *chunk_cursor += sc;
+        return RNDE_OK;
+    }
     if (!legacy && fits) {
         // staged kernel: chunks are ranges of 32-column steps; pick the count that fills the chip in whole rounds
         // (3 workgroups per CU -> 768 resident: one round; measured 768 / 1100 / 1536 / 1792 -> 4.44 / 4.57 / 4.51 / 4.54 ms per step)

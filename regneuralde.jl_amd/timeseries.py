@@ -1,0 +1,211 @@
+"""The caller of the hot path in the latent-ODE experiment, mirrored so that configuration 4 runs end
+to end around the device solve:
+
+LatentGRU, single_run            reference experiments/latent_ode.jl:39-99
+LatentTimeSeriesModel            reference src/models/time_series.jl:1-70
+log_likelihood, kl_divergence,
+loss_function, sample_tbounds    reference experiments/latent_ode.jl:188-269
+Optimiser(InvDecay, AdaMax)      reference experiments/latent_ode.jl:108
+
+Only the node (gen_dynamics integrated by Tsit5 with `saveat`, latent_ode.jl:137-147) is the hot path: it runs in librnde.so
+(chain engine) forward and reverse.  The recognition GRU, the two small Dense stacks and the likelihood are a few dozen tiny
+PyTorch ops per step around it -- the same split as ClassifierNODE (classifier.py).
+
+Layouts: a Julia `F x T x B` array is a torch tensor of shape (B, T, F); flat parameter vectors are what Flux.destructure
+returns for the corresponding struct (fields in declaration order, each Dense as [vec(W) column-major (out x in); b]).
+"""
+import math
+
+import torch
+
+from .layers import Chain, Dense, destructure
+from .node import TrackedNeuralODE
+
+_ACTS = {"identity": lambda v: v, "tanh": torch.tanh, "sigmoid": torch.sigmoid}
+
+
+def _apply_chain(chain, p, x):
+    """re(p)(x) for a Chain of Dense layers; x is (B, n_in)."""
+    o = 0
+    if getattr(chain, "pre_act", False):
+        x = torch.tanh(x)
+    for l in chain.layers:
+        W = p[o:o + l.n_in * l.n_out].view(l.n_in, l.n_out)        # (in, out) row-major == out x in column-major
+        o += l.n_in * l.n_out
+        b = p[o:o + l.n_out]
+        o += l.n_out
+        x = _ACTS[l.act](x @ W + b)
+    return x
+
+
+def _chain_len(chain):
+    return sum(l.n_in * l.n_out + l.n_out for l in chain.layers)
+
+
+class LatentGRU:
+    """latent_ode.jl:39-63: three two-layer stacks over vcat(y_mean, y_std, x); in_dim counts the DATA rows (37), the input
+    carries data, mask and one time-difference row, i.e. 2 in_dim + 1 rows."""
+
+    def __init__(self, in_dim, h_dim, latent_dim, generator=None):
+        n_in = latent_dim * 2 + in_dim * 2 + 1
+        self.update_gate = Chain(Dense(n_in, h_dim, "tanh", generator), Dense(h_dim, latent_dim, "sigmoid", generator))
+        self.reset_gate = Chain(Dense(n_in, h_dim, "tanh", generator), Dense(h_dim, latent_dim, "sigmoid", generator))
+        self.new_state = Chain(Dense(n_in, h_dim, "tanh", generator), Dense(h_dim, latent_dim * 2, "identity", generator))
+        self.in_dim, self.latent_dim = in_dim, latent_dim
+
+    def chains(self):
+        return (self.update_gate, self.reset_gate, self.new_state)          # @functor field order
+
+    def single_run(self, p, y_mean, y_std, x):
+        """latent_ode.jl:67-97.  y_*: (B, latent); x: (B, 2 in_dim + 1)."""
+        n0, n1 = _chain_len(self.update_gate), _chain_len(self.reset_gate)
+        pu, pr, pn = p[:n0], p[n0:n0 + n1], p[n0 + n1:]
+        y_concat = torch.cat([y_mean, y_std, x], dim=1)
+        update_gate = _apply_chain(self.update_gate, pu, y_concat)
+        reset_gate = _apply_chain(self.reset_gate, pr, y_concat)
+        concat = torch.cat([y_mean * reset_gate, y_std * reset_gate, x], dim=1)
+        new_state = _apply_chain(self.new_state, pn, concat)
+        new_state_mean, new_state_std = new_state[:, :self.latent_dim], new_state[:, self.latent_dim:]
+        new_y_mean = (1 - update_gate) * new_state_mean + update_gate * y_mean
+        new_y_std = (1 - update_gate) * new_state_std + update_gate * y_std
+        # rows (size(x,1) / 2 + 1):end of the Julia input: integer division of 2 in_dim + 1 -> the mask rows and the time row
+        half = x.shape[1] // 2
+        mask = (x[:, half:].sum(dim=1, keepdim=True) > 0).to(x.dtype)
+        return mask * new_y_mean + (1 - mask) * y_mean, mask * new_y_std + (1 - mask) * y_std
+
+    def __call__(self, p, x):
+        """latent_ode.jl:99-106: runs over the time axis BACKWARDS from zeros; returns vcat(y_mean, y_std) as (B, 2 latent)."""
+        B, T = x.shape[0], x.shape[1]
+        y_mean = y_std = torch.zeros(B, self.latent_dim, dtype=x.dtype, device=x.device)
+        for t in range(T - 1, -1, -1):
+            y_mean, y_std = self.single_run(p, y_mean, y_std, x[:, t, :])
+        return torch.cat([y_mean, y_std], dim=1)
+
+
+def destructure_gru(gru):
+    return torch.cat([destructure(c) for c in gru.chains()])
+
+
+class LatentTimeSeriesModel:
+    """time_series.jl:1-70: rnn -> enc -> (mu0, log sigma^2) -> z0 = eps * exp(log sigma^2 / 2) + mu0 -> node (saveat) -> dec.
+    Parameters are the four flat vectors (p1, p2, p3, p4) of Flux.trainable (time_series.jl:38)."""
+
+    def __init__(self, rnn: LatentGRU, enc: Chain, node: TrackedNeuralODE, dec: Dense, device="cuda"):
+        self.rnn, self.enc, self.node, self.dec = rnn, enc, node, Chain(dec)
+        self.p1 = destructure_gru(rnn).to(device).requires_grad_(True)
+        self.p2 = destructure(enc).to(device).requires_grad_(True)
+        self.p3 = node.p.to(device).clone().requires_grad_(True)
+        self.p4 = destructure(self.dec).to(device).requires_grad_(True)
+
+    def trainable(self):
+        return (self.p1, self.p2, self.p3, self.p4)
+
+    def __call__(self, x, p1=None, p2=None, p3=None, p4=None, generator=None, **node_kwargs):
+        """x: (B, T, 2 in_dim + 1) = vcat(data, mask, dt).  Returns (result (B, T, in_dim), mu0, log sigma^2, nfe, sv)."""
+        p1 = self.p1 if p1 is None else p1
+        p2 = self.p2 if p2 is None else p2
+        p3 = self.p3 if p3 is None else p3
+        p4 = self.p4 if p4 is None else p4
+        out = _apply_chain(self.enc, p2, self.rnn(p1, x))
+        latent_dim = out.shape[1] // 2
+        mu0, logvar = out[:, :latent_dim], out[:, latent_dim:]
+        sample = torch.randn(mu0.shape, dtype=mu0.dtype, device=mu0.device, generator=generator)   # CUDA.randn, time_series.jl:58
+        z0 = sample * torch.exp(logvar / 2) + mu0
+        res, nfe, sv = self.node(z0, p3, **node_kwargs)                 # (B, T, latent): the device solve
+        B, T, _ = res.shape
+        result = _apply_chain(self.dec, p4, res.reshape(B * T, -1)).reshape(B, T, -1)
+        return result, mu0, logvar, nfe, sv
+
+
+def log_likelihood(dpred, mask, sigma=0.01):
+    """latent_ode.jl:192-200: Gaussian log density of the masked residual, summed over (feature, time), divided by the number of
+    observed entries; one value per sample.  (As in the reference the constant terms are counted at unobserved entries too.)"""
+    ll = -dpred.pow(2) / (2 * sigma ** 2) - math.log(sigma) - math.log(2 * math.pi) / 2
+    return ll.sum(dim=(1, 2)) / mask.sum(dim=(1, 2))
+
+
+def kl_divergence(mu, logvar):
+    """latent_ode.jl:203-204 (standard normal prior): mean over the latent rows of (exp(lv) + mu^2 - 1 - lv) / 2."""
+    return (torch.exp(logvar) + mu.pow(2) - 1 - logvar).mean(dim=1) / 2
+
+
+def latent_loss_function(data, mask, t_row, model, p1=None, p2=None, p3=None, p4=None, lam_r=1.0e2, lam_k=1.0, regularize=True,
+                         agg=torch.mean, func="error_est", saveat=None, generator=None):
+    """latent_ode.jl:206-262: -mean(log likelihood - lam_k KL) + lam_r agg(sv.saveval).
+    data, mask: (B, T, in_dim); t_row: (B, T, 1) (the constant `_t` row).  Returns (total, nll, kl, reg, nfe)."""
+    x_ = torch.cat([data, mask, t_row], dim=2)
+    result, mu0, logvar, nfe, sv = model(x_, p1, p2, p3, p4, generator=generator, func=func, saveat=saveat)
+    dpred = result * mask - data * mask
+    ll = log_likelihood(dpred, mask)
+    kl = lam_k * kl_divergence(mu0, logvar)
+    reg = lam_r * agg(sv.saveval) if regularize and sv is not None else torch.zeros((), device=data.device)
+    total = -(ll - kl).mean() + reg
+    return total, (-ll.mean()).detach(), kl.mean().detach(), reg.detach(), nfe
+
+
+def lambda_k(epoch):
+    """latent_ode.jl:178: KL weight warm-up max(0, 1 - 0.99^(epoch - 10))."""
+    return max(0.0, 1.0 - 0.99 ** (epoch - 10))
+
+
+def sample_tbounds(t, dt=None, generator=None):
+    """STEER on the save grid, latent_ode.jl:180-189: every time but the first moves uniformly within half its gap to the
+    previous one, clamped to [0, 1].  t: 1-D tensor.  Returns (sampled, gaps)."""
+    if dt is None:
+        dt = t[1:] - t[:-1] + torch.finfo(torch.float32).eps
+    r = torch.rand(dt.shape, dtype=dt.dtype, device=dt.device, generator=generator)
+    return torch.cat([t[:1], t[1:] + (2 * r - 1) * dt / 2]).clamp_(0.0, 1.0), dt
+
+
+def get_t_saveat(t, saveat, steer=False, gaps=None, generator=None):
+    """latent_ode.jl:323-333.  t: (B, T, 1) observation times of the batch; saveat: 1-D grid of the layer.  Returns
+    (t, save grid for this call, the time-difference row `_t` of shape (B, T, 1) with a trailing zero)."""
+    if steer:
+        tt, _ = sample_tbounds(saveat, gaps, generator)
+        t = tt.reshape(1, -1, 1).repeat(t.shape[0], 1, 1)
+    else:
+        t, tt = t.to(torch.float32), saveat
+    dt_row = torch.cat([t[:, 1:] - t[:, :-1], torch.zeros_like(t[:, :1])], dim=1)
+    return t, tt, dt_row
+
+
+class FluxAdaMax:
+    """Flux.Optimise.Optimiser(InvDecay(gamma), AdaMax(eta, (0.9, 0.999))) group by group (latent_ode.jl:108; utils.jl:149-156)."""
+
+    def __init__(self, params, gamma=1.0e-5, eta=0.01, beta=(0.9, 0.999), eps=1.0e-8):
+        self.params = [p for p in params if p.numel() > 0]
+        self.gamma, self.eta, self.beta, self.eps = gamma, eta, beta, eps
+        self.n = [1 for _ in self.params]
+        self.m = [torch.zeros_like(p) for p in self.params]
+        self.u = [torch.zeros_like(p) for p in self.params]
+        self.bp = [beta[0] for _ in self.params]
+
+    @torch.no_grad()
+    def step(self, grads=None):
+        b1, b2 = self.beta
+        for i, p in enumerate(self.params):
+            g = p.grad if grads is None else grads[i]
+            if g is None:
+                continue
+            g = g / (1.0 + self.gamma * self.n[i])                       # InvDecay
+            self.n[i] += 1
+            self.m[i].mul_(b1).add_(g, alpha=1 - b1)
+            torch.maximum(self.u[i] * b2, g.abs(), out=self.u[i])
+            p.sub_((self.eta / (1 - self.bp[i])) * self.m[i] / (self.u[i] + self.eps))
+            self.bp[i] *= b1
+            p.grad = None
+
+
+def build_latent_ode(in_dim=37, h_dim=40, rec_dim=50, latent=20, hidden=50, depth=8, saveat=None, regularize=True,
+                     generator=None, device="cuda", **solver_kwargs):
+    """The model of latent_ode.jl:111-147 at the reference's sizes: LatentGRU(37, 40, 50), rec_to_gen
+    Dense(100, 50, tanh) -> Dense(50, 40), gen_dynamics (tanh + 8 Dense 20 <-> 50), gen_to_data Dense(20, 37)."""
+    from .layers import LatentGenDynamics
+    rnn = LatentGRU(in_dim, h_dim, rec_dim, generator)
+    enc = Chain(Dense(2 * rec_dim, rec_dim, "tanh", generator), Dense(rec_dim, 2 * latent, "identity", generator))
+    dyn = LatentGenDynamics(latent, hidden, depth, generator)
+    kw = dict(reltol=1.4e-8, abstol=1.4e-8)
+    kw.update(solver_kwargs)
+    node = TrackedNeuralODE(dyn, [0.0, 1.0], False, regularize, "Tsit5", saveat=saveat, **kw)
+    dec = Dense(latent, in_dim, "identity", generator)
+    return LatentTimeSeriesModel(rnn, enc, node, dec, device=device)

@@ -189,3 +189,81 @@ def test_async_backward_matches_the_synchronous_one(rnde):
     torch.cuda.synchronize()
     assert torch.equal(model.p2.grad, g2) and torch.equal(model.p3.grad, g3)
     assert abs(float(l2) - l1) <= 1e-6 * max(1.0, abs(l1))
+
+
+def _latent_batch(g, B, T=49, in_dim=37):
+    data = torch.randn(B, T, in_dim, generator=g)
+    mask = (torch.rand(B, T, in_dim, generator=g) > 0.7).float()
+    mask[:, 0, 0] = 1
+    grid = torch.linspace(0, 1, T)
+    t = grid.reshape(1, T, 1).repeat(B, 1, 1)
+    return data.cuda(), mask.cuda(), t.cuda(), grid
+
+
+def test_latent_time_series_model_end_to_end(rnde):
+    """LatentTimeSeriesModel (time_series.jl:40-70) at the reference's sizes around the device solve: shapes of the five results,
+    and the node's part of the total-loss gradient (z0-bar and p3-bar given the cotangents the decoder/likelihood/regulariser hand
+    it) against the fp64 oracle run on the same z0 -- i.e. the hot path checked inside its real caller."""
+    from oracle.oracle import Oracle, arch_latent
+    rn = rnde
+    g = torch.Generator().manual_seed(12)
+    B = 16
+    data, mask, t, grid = _latent_batch(g, B)
+    model = rn.build_latent_ode(saveat=grid.tolist(), generator=g, reltol=1e-3, abstol=1e-3, max_batch=B, max_attempts=64)
+    with torch.no_grad():
+        model.p3.mul_(1.5)                          # truncation-dominated regime, as in test_latent_ode_layer_call
+    assert [p.numel() for p in model.trainable()] == [3 * (175 * 40 + 40) + 2 * (40 * 50 + 50) + 40 * 100 + 100, 100 * 50 + 50 + 50 * 40 + 40,
+                                                       8280, 20 * 37 + 37]
+    _, tt, trow = rn.get_t_saveat(t, grid)
+    seen = {}
+    inner = model.node
+    class Spy:                                       # records what the model hands to / gets from the node
+        def __call__(self, z0, p3, **kw):
+            z0.retain_grad()
+            res, nfe, sv = inner(z0, p3, **kw)
+            res.retain_grad(); sv.saveval.retain_grad()
+            seen.update(z0=z0, res=res, sv=sv.saveval, nfe=nfe)
+            return res, nfe, sv
+    model.node = Spy()
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    total, nll, kl, reg, nfe = rn.latent_loss_function(data, mask, trow, model, lam_r=1.0e2, lam_k=0.5, saveat=tt, generator=gen)
+    assert torch.isfinite(total) and nfe % 6 == 3 and seen["res"].shape == (B, 49, 20)
+    total.backward()
+    for p in model.trainable():
+        assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().max() > 0
+    z0 = seen["z0"].detach().cpu().numpy().astype(np.float64)
+    p3 = model.p3.detach().cpu().numpy().astype(np.float64)
+    orc = Oracle(arch_latent(), np.float64, reltol=1e-3, abstol=1e-3, reg_kind=1)
+    r = orc.forward(z0, p3, saveat=grid.numpy())
+    assert r["nfe"] == nfe
+    xb, pb, _ = orc.backward(seen["res"].grad.cpu().numpy().astype(np.float64), seen["sv"].grad.cpu().numpy().astype(np.float64))
+    o32 = Oracle(arch_latent(), np.float32, reltol=1e-3, abstol=1e-3, reg_kind=1)
+    r32 = o32.forward(z0.astype(np.float32), p3.astype(np.float32), saveat=grid.numpy())
+    assert r32["nfe"] == nfe
+    xb32, pb32, _ = o32.backward(seen["res"].grad.cpu().numpy(), seen["sv"].grad.cpu().numpy())
+    sx, sp = np.abs(xb32 - xb).max() / np.abs(xb).max(), np.abs(pb32 - pb).max() / np.abs(pb).max()
+    assert np.abs(seen["res"].detach().cpu().numpy() - r["u"]).max() < 3e-5 + 4 * np.abs(r32["u"] - r["u"]).max()
+    assert np.abs(seen["z0"].grad.cpu().numpy() - xb).max() <= (3e-3 + 4 * sx) * np.abs(xb).max()
+    assert np.abs(model.p3.grad.cpu().numpy() - pb).max() <= (3e-3 + 4 * sp) * np.abs(pb).max()
+
+
+def test_latent_ode_training_reduces_loss(rnde):
+    """A few AdaMax steps of experiments/latent_ode.jl's training loop (loss_function + Optimiser(InvDecay, AdaMax)) on one
+    synthetic batch: the negative log likelihood must fall."""
+    rn = rnde
+    g = torch.Generator().manual_seed(13)
+    B = 16
+    data, mask, t, grid = _latent_batch(g, B)
+    data = 0.1 * data
+    model = rn.build_latent_ode(saveat=grid.tolist(), generator=g, reltol=1e-3, abstol=1e-3, max_batch=B, max_attempts=96)
+    opt = rn.FluxAdaMax(model.trainable())
+    _, tt, trow = rn.get_t_saveat(t, grid)
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    nlls = []
+    for it in range(10):
+        total, nll, kl, reg, nfe = rn.latent_loss_function(data, mask, trow, model, lam_r=1.0e2, lam_k=rn.lambda_k(it), saveat=tt,
+                                                           generator=gen)
+        total.backward()
+        opt.step()
+        nlls.append(float(nll))
+    assert nlls[-1] < 0.8 * nlls[0], nlls

@@ -102,3 +102,100 @@ def test_regulariser_table_and_steer(rnde):
     dyn = rnde.MLPDynamics(8, 4)
     node = rnde.TrackedNeuralODE(dyn, [0.0, 1.0], True, True, "AutoTsit5", reltol=1e-3, abstol=1e-3)     # test_node.jl:60-72
     assert node.regularize
+
+
+# ---- latent time-series caller (experiments/latent_ode.jl, src/models/time_series.jl) ---------------------------------------
+
+def _dense_cm(p, o, n_in, n_out):
+    """One Dense out of a Flux.destructure vector, read the JULIA way: W = reshape(p[o+1 : o+out*in], out, in) column-major."""
+    W = p[o:o + n_in * n_out].reshape(n_out, n_in, order="F")
+    b = p[o + n_in * n_out:o + n_in * n_out + n_out]
+    return W, b, o + n_in * n_out + n_out
+
+
+def test_latent_gru_matches_a_column_major_restatement(rnde):
+    """LatentGRU against a loop written in the reference's own orientation (features x batch, W out x in taken column-major from
+    the flat vector): pins the parameter layout of p1 and the backwards time loop / mask rule of latent_ode.jl:67-106."""
+    g = torch.Generator().manual_seed(4)
+    in_dim, h_dim, lat, B, T = 5, 7, 6, 4, 9
+    gru = rnde.LatentGRU(in_dim, h_dim, lat, generator=g)
+    for c in gru.chains():
+        for l in c.layers:
+            l.b.uniform_(-0.2, 0.2, generator=g)
+    from regneuralde_jl_amd.timeseries import destructure_gru
+    p = destructure_gru(gru)
+    n_in = 2 * lat + 2 * in_dim + 1
+    assert p.numel() == 2 * (n_in * h_dim + h_dim + h_dim * lat + lat) + n_in * h_dim + h_dim + h_dim * 2 * lat + 2 * lat
+    data = torch.randn(B, T, in_dim, generator=g)
+    mask = (torch.rand(B, T, in_dim, generator=g) > 0.6).float()
+    mask[:, 3] = 0                                   # a time with nothing observed anywhere ...
+    dt = torch.rand(B, T, 1, generator=g); dt[:, 3] = 0   # ... and a zero time row: the state must pass through unchanged
+    x = torch.cat([data, mask, dt], 2)
+    got = gru(p, x).numpy()
+
+    pn = p.numpy().astype(np.float64); o = 0
+    Ws = []
+    for n_out2 in (lat, lat, 2 * lat):                           # update_gate, reset_gate, new_state
+        W1, b1, o = _dense_cm(pn, o, n_in, h_dim)
+        W2, b2, o = _dense_cm(pn, o, h_dim, n_out2)
+        Ws.append((W1, b1, W2, b2))
+    sig = lambda v: 1 / (1 + np.exp(-v))
+    ym = ys = np.zeros((lat, B))
+    xj = x.numpy().astype(np.float64).transpose(2, 1, 0)          # F x T x B
+    for t in range(T - 1, -1, -1):
+        xt = xj[:, t, :]
+        yc = np.vstack([ym, ys, xt])
+        ug = sig(Ws[0][2] @ np.tanh(Ws[0][0] @ yc + Ws[0][1][:, None]) + Ws[0][3][:, None])
+        rg = sig(Ws[1][2] @ np.tanh(Ws[1][0] @ yc + Ws[1][1][:, None]) + Ws[1][3][:, None])
+        cc = np.vstack([ym * rg, ys * rg, xt])
+        ns = Ws[2][2] @ np.tanh(Ws[2][0] @ cc + Ws[2][1][:, None]) + Ws[2][3][:, None]
+        nm, nsd = (1 - ug) * ns[:lat] + ug * ym, (1 - ug) * ns[lat:] + ug * ys
+        m = (xt[xt.shape[0] // 2:].sum(0, keepdims=True) > 0).astype(np.float64)   # Julia rows (75 / 2 + 1):end, 0-based 37:
+        ym, ys = m * nm + (1 - m) * ym, m * nsd + (1 - m) * ys
+    np.testing.assert_allclose(got, np.vstack([ym, ys]).T, atol=2e-6)
+
+
+def test_latent_likelihood_and_kl_formulas(rnde):
+    g = torch.Generator().manual_seed(6)
+    d = torch.randn(3, 5, 4, generator=g) * 0.02
+    m = (torch.rand(3, 5, 4, generator=g) > 0.5).float(); m[0, 0, 0] = 1
+    ll = rnde.log_likelihood(d * m, m).numpy()
+    ref = [(-(d[i] * m[i]).numpy() ** 2 / (2 * 0.01 ** 2) - math.log(0.01) - math.log(2 * math.pi) / 2).sum() / m[i].sum().item()
+           for i in range(3)]
+    np.testing.assert_allclose(ll, ref, rtol=1e-5)
+    mu, lv = torch.randn(3, 6, generator=g), torch.randn(3, 6, generator=g)
+    kl = rnde.kl_divergence(mu, lv).numpy()
+    np.testing.assert_allclose(kl, ((np.exp(lv.numpy()) + mu.numpy() ** 2 - 1 - lv.numpy()).mean(1)) / 2, rtol=1e-5)
+    assert (rnde.kl_divergence(torch.zeros(2, 6), torch.zeros(2, 6)) == 0).all()
+    assert rnde.lambda_k(10) == 0.0 and rnde.lambda_k(5) == 0.0 and abs(rnde.lambda_k(11) - 0.01) < 1e-12
+
+
+def test_flux_adamax_recurrence(rnde):
+    p = torch.tensor([1.0, -2.0, 0.5], requires_grad=True)
+    opt = rnde.FluxAdaMax([torch.zeros(0), p], gamma=1e-5, eta=0.01)
+    ref, m, u, bp = p.detach().clone().double(), torch.zeros(3).double(), torch.zeros(3).double(), 0.9
+    for k in range(4):
+        grad = torch.tensor([0.3, -0.1 * (k + 1), 0.0])
+        p.grad = grad.clone()
+        opt.step()
+        gg = grad.double() / (1 + 1e-5 * (k + 1))
+        m = 0.9 * m + 0.1 * gg
+        u = torch.maximum(0.999 * u, gg.abs())
+        ref = ref - (0.01 / (1 - bp)) * m / (u + 1e-8)
+        bp *= 0.9
+    np.testing.assert_allclose(p.detach().numpy(), ref.numpy(), rtol=1e-6)
+
+
+def test_sample_tbounds_and_time_row(rnde):
+    g = torch.Generator().manual_seed(8)
+    grid = torch.linspace(0, 1, 49)
+    tt, gaps = rnde.sample_tbounds(grid, generator=g)
+    assert tt[0] == 0 and tt.min() >= 0 and tt.max() <= 1 and gaps.shape == (48,)
+    assert ((tt[1:] - grid[1:]).abs() <= gaps / 2 + 1e-7).all()
+    assert (tt[1:] > tt[:-1]).all()                       # half-gap jitter cannot reorder the grid
+    t = grid.reshape(1, -1, 1).repeat(3, 1, 1)
+    t2, tt2, row = rnde.get_t_saveat(t, grid)
+    assert tt2 is grid and row.shape == (3, 49, 1) and row[:, -1].abs().max() == 0
+    np.testing.assert_allclose(row[0, :-1, 0].numpy(), (grid[1:] - grid[:-1]).numpy(), atol=1e-7)
+    t3, tt3, row3 = rnde.get_t_saveat(t, grid, steer=True, gaps=gaps, generator=g)
+    assert t3.shape == (3, 49, 1) and torch.equal(t3[0, :, 0], tt3)

@@ -903,8 +903,17 @@ static hipError_t launch_bwd_t(rnde_node* h, const BwdParams& Q, int n_att, hipS
 }
 
 // one group of evaluations -> `*chunk_cursor` .. slabs of region `slab`; returns the number of chunks written
+// shapes the 16x16x4 kernel (rnde_wgrad3_kernel) covers: both widths multiples of 4, the wide side in 42..50 tiles, the narrow one <= 112
+static bool wgrad3_ok(int M, int Nx) {
+    const bool tall = M >= Nx;
+    const int wide = tall ? M : Nx + 2, narrow = tall ? Nx + 2 : M;
+    return getenv("RNDE_WGRAD_LEGACY") == nullptr && getenv("RNDE_WGRAD_V2") == nullptr && M % 4 == 0 && Nx % 4 == 0 && wide > 656 &&
+           wide <= 800 && narrow <= 112;
+}
+// `max_chunks` > 0 caps the number of chunks (two workgroups each) of the 16x16x4 kernel: 16 for the launches that run
+// underneath the sweep on the CUs it leaves idle, see bwd_run
 static rnde_status launch_wgrad_part(rnde_node* h, const EvalDesc* ev, int n_evals, int per_chunk, int M, int Nx, int Bpad,
-                                     float* slab, int* chunk_cursor, hipStream_t s) {
+                                     float* slab, int* chunk_cursor, hipStream_t s, int max_chunks = 0) {
     if (n_evals <= 0) return RNDE_OK;
     const int mtiles = (M + 31) / 32, ntiles = (Nx + 2 + 31) / 32;
     const bool tall = M >= Nx;  // layer 2: M = D; layer 1: M = H
@@ -916,13 +925,11 @@ static rnde_status launch_wgrad_part(rnde_node* h, const EvalDesc* ev, int n_eva
     float* dst = slab + (size_t)(*chunk_cursor) * len;
     static const bool legacy = getenv("RNDE_WGRAD_LEGACY") != nullptr;   // direct-from-global variant, kept for A/B runs
     const bool fits = tall ? (Nx + 2 <= 128) : (M <= 128);                // the staged kernel covers 128 on the un-split side
-    const bool no_v3 = getenv("RNDE_WGRAD_V2") != nullptr;                // A/B switch (read per call): keep the 32x32x2 staged kernel
-    const int wide = tall ? M : Nx + 2, narrow = tall ? Nx + 2 : M;
-    if (!legacy && !no_v3 && M % 4 == 0 && Nx % 4 == 0 && wide > 656 && wide <= 800 && narrow <= 112) {
+    if (wgrad3_ok(M, Nx)) {                                               // (RNDE_WGRAD_V2, read per call, keeps the 32x32x2 staged kernel: A/B)
         // 16x16x4 kernel: two workgroups (the halves of the wide side) per chunk of 32-column steps
         const int total_steps = n_evals * ((Bpad + 31) / 32);
         static const int target_chunks = getenv("RNDE_WGRAD3_CHUNKS") ? atoi(getenv("RNDE_WGRAD3_CHUNKS")) : 128;
-        int sc = std::max(1, std::min({target_chunks, total_steps, 256}));
+        int sc = std::max(1, std::min({max_chunks > 0 ? max_chunks : target_chunks, total_steps, 256}));
         const int steps_per_chunk = (total_steps + sc - 1) / sc;
         sc = (total_steps + steps_per_chunk - 1) / steps_per_chunk;
         if ((size_t)(*chunk_cursor + sc) * (size_t)len > h->bw.slab_floats) { h->err = "weight-gradient slab overflow"; return RNDE_ERR_BAD_ARG; }
@@ -1000,7 +1007,11 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
     // ---- evaluation descriptors for the parameter-gradient GEMMs (all pointers are known before the sweep) ----
     const long long A = (long long)h->D * Q.F.Bpad, HB = (long long)h->H * Q.F.Bpad;
     RecLayout L{A, HB};
-    int ne = 0;
+    // order: the two evaluations of the initial-step heuristic, then 6 per attempt -- so that "everything up to attempt n" is
+    // one contiguous range for the launch that runs after the sweep
+    int ne = 2;
+    b.h_ev2[0] = EvalDesc{b.zi2, h->h0, h->t0, 0};           b.h_ev1[0] = EvalDesc{b.zi1, h->xcopy, h->t0, 0};
+    b.h_ev2[1] = EvalDesc{b.zi2 + A, h->h1, h->t0 + h->h_init->dt0, 0}; b.h_ev1[1] = EvalDesc{b.zi1 + HB, h->u1, h->t0 + h->h_init->dt0, 0};
     for (int n = 0; n < n_att; ++n) {
         const StepMeta& m = h->h_meta[n];
         const float* R = h->arena + (long long)m.rec * h->rec_stride;
@@ -1011,37 +1022,41 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
             ++ne;
         }
     }
-    b.h_ev2[ne] = EvalDesc{b.zi2, h->h0, h->t0, 0};           b.h_ev1[ne] = EvalDesc{b.zi1, h->xcopy, h->t0, 0}; ++ne;
-    b.h_ev2[ne] = EvalDesc{b.zi2 + A, h->h1, h->t0 + h->h_init->dt0, 0}; b.h_ev1[ne] = EvalDesc{b.zi1 + HB, h->u1, h->t0 + h->h_init->dt0, 0}; ++ne;
     HIPCHK(h, hipMemcpyAsync(b.ev1, b.h_ev1, (size_t)ne * sizeof(EvalDesc), hipMemcpyHostToDevice, s));
     HIPCHK(h, hipMemcpyAsync(b.ev2, b.h_ev2, (size_t)ne * sizeof(EvalDesc), hipMemcpyHostToDevice, s));
     float* slab1 = b.slab;
     float* slab2w = b.slab + b.slab_floats;
     int cur1 = 0, cur2 = 0, evi = 0;
-    // Footprint control: a GEMM wave runs for ~100 us and holds 147 VGPRs, so at most ~one per CU may be in
-    // flight or the sweep's workgroups cannot be placed: <= 12 chunks x 13 tile blocks per launch.
-    const int per_chunk = std::max(1, (ne + 239) / 240);          // one evaluation per wave when possible: >= 2 waves per SIMD
-    const int group = 4;                                          // attempts per weight-gradient launch
-    const int per_chunk_grp = std::max(per_chunk, (6 * group + 11) / 12);
-    // launches the two GEMMs for evaluations [lo, hi) on the side stream once the main stream reaches this point
-    // Measured (round 1): running these GEMMs on a second, low-priority stream underneath the sweep is a net
-    // LOSS (6.4 -> 8.4..9.8 ms per step): their ~100 us waves hold VGPRs the latency-critical sweep workgroups
-    // need.  So `overlap` stays off and the GEMMs run after the sweep on the caller's stream.
-    const bool overlap = false;
-    auto wgrad_group = [&](int lo, int hi) -> rnde_status {
+    const int per_chunk = std::max(1, (ne + 239) / 240);          // (chunking of the 32x32x2 kernels; the 16x16x4 kernel chunks by steps)
+    // ---- weight-gradient GEMMs underneath the sweep ----
+    // The persistent reverse kernel occupies 8 * R * ceil(C / 8) CUs (224 of 256 at B = 512: one workgroup per CU, 28 per XCD)
+    // and is latency bound; the 32 CUs it cannot use sit idle for the whole sweep (~1.7 ms).  A launch of 16 chunks x 2
+    // workgroups of rnde_wgrad3_kernel lands 4 per XCD (round-robin dispatch) and, at 155 KB of LDS and 238 VGPRs per workgroup,
+    // exactly one per CU -- it takes those idle CUs and nothing else.  So the evaluations of the attempts reversed first
+    // (`side_frac` of them, in groups) go to a second stream as such 32-workgroup launches, each waiting on an event recorded
+    // after its last reverse launch; the rest runs on all CUs after the sweep as before.  An earlier form of this overlap with
+    // unrestricted grids was a net loss (the GEMM waves took CUs the sweep's workgroups needed: 6.4 -> 8.4..9.8 ms per step).
+    const int side_pct = getenv("RNDE_WGRAD_SIDE") ? atoi(getenv("RNDE_WGRAD_SIDE")) : 50;
+    const int sweep_cus = 8 * h->sR * ((Q.F.Bpad / 16 + 7) / 8);
+    const bool side = h->engine == 2 && h->persist == 1 && side_pct > 0 && n_att >= 8 && sweep_cus <= 224 &&
+                      wgrad3_ok(h->H, h->D) && wgrad3_ok(h->D, h->H);
+    const int side_att = side ? std::min(n_att, n_att * side_pct / 100) : 0;      // attempts [n_att - side_att, n_att)
+    const int group = std::max(4, (side_att + 5) / 6);                             // <= 6 side launches per layer (slab space: 16 chunks each)
+    bool used_side = false;
+    auto wgrad_group = [&](int lo, int hi, bool on_side) -> rnde_status {
         if (hi <= lo) return RNDE_OK;
         hipStream_t ws = s;
-        int pc = per_chunk;
-        if (overlap) {
+        if (on_side) {
             hipEvent_t ev = h->wevents[evi++ % 64];
             HIPCHK(h, hipEventRecord(ev, s));
             HIPCHK(h, hipStreamWaitEvent(h->wstream, ev, 0));
-            ws = h->wstream; pc = per_chunk_grp;
+            ws = h->wstream; used_side = true;
         }
-        rnde_status r = launch_wgrad_part(h, b.ev1 + lo, hi - lo, pc, h->H, h->D, Q.F.Bpad, slab1, &cur1, ws);
+        rnde_status r = launch_wgrad_part(h, b.ev1 + lo, hi - lo, per_chunk, h->H, h->D, Q.F.Bpad, slab1, &cur1, ws, on_side ? 16 : 0);
         if (r != RNDE_OK) return r;
-        return launch_wgrad_part(h, b.ev2 + lo, hi - lo, pc, h->D, h->H, Q.F.Bpad, slab2w, &cur2, ws);
+        return launch_wgrad_part(h, b.ev2 + lo, hi - lo, per_chunk, h->D, h->H, Q.F.Bpad, slab2w, &cur2, ws, on_side ? 16 : 0);
     };
+    int hi_att = n_att;                                           // evaluations of attempts >= hi_att are already launched
     hipError_t e;
     if (h->engine == 2) {
         // stage engine sweep: one persistent launch per reversed attempt (fallback: 7 launches); then the (column-owner) kernels for the initialisation part
@@ -1054,7 +1069,6 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
         BQ.sv_t = h->saveat.empty() ? nullptr : h->sv_t_dev; BQ.sv_ubar = u_bar_dev; BQ.nsave = (int)h->saveat.size();
         BQ.MT = h->sMT; BQ.WT = h->sWT; BQ.R = h->sR; BQ.C = Q.F.Bpad / 16; BQ.HT = h->sHT; BQ.KHb = h->sKHb;
         const dim3 grid(BQ.R * BQ.C), blk(64 * BQ.WT);
-        int hi_att = n_att;
         // saveat: which save indices each accepted attempt covers (same float comparisons as the forward controller)
         std::vector<int> sv_lo(n_att, 0), sv_hi(n_att, 0);
         if (!h->saveat.empty()) {
@@ -1089,6 +1103,11 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
                 const dim3 pgrid(8 * BQ.R * ((BQ.C + 7) / 8));
                 if (h->act2) hipLaunchKernelGGL((rnde_bstage_attempt_kernel<1>), pgrid, blk, h->stage_lds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo);
                 else hipLaunchKernelGGL((rnde_bstage_attempt_kernel<0>), pgrid, blk, h->stage_lds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo);
+                if (n >= n_att - side_att && (hi_att - n >= group || n == n_att - side_att)) {   // attempts [n, hi_att) are final
+                    st = wgrad_group(2 + 6 * n, 2 + 6 * hi_att, true);
+                    if (st != RNDE_OK) return st;
+                    hi_att = n;
+                }
                 continue;
             }
             if (h->act2) hipLaunchKernelGGL((rnde_bstage_kernel<1, BM_START>), grid, blk, h->stage_lds, s, BQ, n, 0, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], qo);
@@ -1096,11 +1115,6 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
             for (int j = 6; j >= 1; --j) {
                 if (h->act2) hipLaunchKernelGGL((rnde_bstage_kernel<1, BM_STAGE>), grid, blk, h->stage_lds, s, BQ, n, j, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], qo);
                 else hipLaunchKernelGGL((rnde_bstage_kernel<0, BM_STAGE>), grid, blk, h->stage_lds, s, BQ, n, j, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], qo);
-            }
-            if (overlap && (hi_att - n >= group || n == 0)) {       // attempts [n, hi_att) are final: their GEMM slice can start now
-                st = wgrad_group(6 * n, 6 * hi_att);
-                if (st != RNDE_OK) return st;
-                hi_att = n;
             }
         }
         HIPCHK(h, hipGetLastError());
@@ -1111,10 +1125,10 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
     else e = h->act2 ? launch_bwd_t<2, 1>(h, Q, n_att, s) : launch_bwd_t<2, 0>(h, Q, n_att, s);
     HIPCHK(h, e);
     n_att = h->n_att;
-    // remaining evaluations (column-owner engine: everything; stage engine: the two initialisation evaluations)
-    st = wgrad_group((overlap && h->engine == 2) ? 6 * n_att : 0, ne);
+    // remaining evaluations on all CUs (everything that did not go to the side stream, incl. the two initialisation evaluations)
+    st = wgrad_group(0, 2 + 6 * hi_att, false);
     if (st != RNDE_OK) return st;
-    if (overlap) {
+    if (used_side) {
         hipEvent_t ev = h->wevents[64];
         HIPCHK(h, hipEventRecord(ev, h->wstream));
         HIPCHK(h, hipStreamWaitEvent(s, ev, 0));

@@ -704,7 +704,8 @@ __global__ __launch_bounds__(448) void rnde_wgrad3_kernel(const EvalDesc* __rest
         for (int q = 0; q < 8; ++q) {
             const int cc = c0_f + tcol[q];
             const bool real = tcol[q] >= 0 && cc < Bpad && trow[q] < TRp;
-            treg[q] = *(const f32x4*)(Tp + (real ? (size_t)cc * TRp + trow[q] : 0));
+            // (non-temporal: each wide-operand element is read once; keeps the streams out of the way of the sweep running beside it)
+            treg[q] = __builtin_nontemporal_load((const f32x4*)(Tp + (real ? (size_t)cc * TRp + trow[q] : 0)));
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {

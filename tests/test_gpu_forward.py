@@ -143,6 +143,10 @@ def test_persistent_attempt_is_bit_identical(kind, B, tol, scale, saveat, monkey
     arch, p, x = _setup(kind, B, 5, scale)
     rng = np.random.default_rng(9)
     outs = []
+    # (the weight-gradient launches underneath the persistent sweep partition the GEMM differently from the launch after a
+    #  multi-launch sweep -- a different summation order, covered by test_weight_gradient_kernels_agree; here the partition is
+    #  held fixed so that p-bar checks the tape bit for bit)
+    monkeypatch.setenv("RNDE_WGRAD_SIDE", "0")
     for persist in ("1", "0"):
         monkeypatch.setenv("RNDE_PERSIST", persist)
         node = Node(_cfg(arch, B, reltol=tol, abstol=tol, col_tile=16, max_attempts=256))

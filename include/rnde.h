@@ -153,6 +153,14 @@ rnde_status rnde_classifier_head(rnde_node* h, const float* u_dev, const float* 
                                  int32_t B, int32_t n_classes, float* logits_out_dev, float* u_bar_dev,
                                  float* p3_bar_dev, float* ce_out_dev, void* stream);
 
+/* Optimiser update of the reference's training step, one launch per parameter group:
+ * Flux.Optimise.Optimiser(InvDecay(gamma), Momentum(eta, rho)) applied by update_parameters! -- replaces reference
+ * experiments/mnist_node.jl:130 + src/utils.jl:149-156 for one flat group:
+ *     g' = g / (1 + gamma * n);   v = rho * v - eta * g';   p = p + v          (n = the group's InvDecay counter, >= 1)
+ * p, g, v: device vectors of `len` floats; in place on p and v.  No handle: pure function of its arguments, asynchronous. */
+rnde_status rnde_momentum_step(float* p_dev, const float* g_dev, float* v_dev, int64_t len, int64_t n, float gamma,
+                               float eta, float rho, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

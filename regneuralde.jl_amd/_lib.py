@@ -59,6 +59,7 @@ def lib():
     L.rnde_node_launches_per_attempt.restype = C.c_int32
     L.rnde_node_launches_per_attempt.argtypes = [vp]
     L.rnde_classifier_head.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]
+    L.rnde_momentum_step.argtypes = [vp, vp, vp, C.c_int64, C.c_int64, f, f, f, vp]
     _lib = L
     return L
 
@@ -66,7 +67,7 @@ def lib():
 EXPORTS = ["rnde_version", "rnde_last_error", "rnde_param_count", "rnde_node_create", "rnde_node_destroy",
            "rnde_node_forward", "rnde_node_forward_saveat", "rnde_node_backward", "rnde_node_backward_async", "rnde_node_release_tape", "rnde_node_forward_host",
            "rnde_node_backward_host", "rnde_node_steps", "rnde_debug_feval", "rnde_debug_attempt",
-           "rnde_bench_attempt", "rnde_node_launches_per_attempt", "rnde_classifier_head"]
+           "rnde_bench_attempt", "rnde_node_launches_per_attempt", "rnde_classifier_head", "rnde_momentum_step"]
 
 
 def check(h, status):

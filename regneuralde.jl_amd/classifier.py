@@ -121,7 +121,18 @@ class FluxOptimiser:
             g = p.grad if grads is None else grads[i]
             if g is None:
                 continue
-            g = g / (1.0 + self.gamma * self.n[i])         # InvDecay
+            if p.is_cuda:                                   # one launch per group through the C ABI (rnde_momentum_step)
+                import ctypes as C
+                from . import _lib
+                g = g.contiguous()
+                st = _lib.lib().rnde_momentum_step(p.data_ptr(), g.data_ptr(), self.v[i].data_ptr(), p.numel(), self.n[i],
+                                                   self.gamma, self.eta, self.rho,
+                                                   C.c_void_p(torch.cuda.current_stream(p.device).cuda_stream))
+                _lib.check(None, st)
+                self.n[i] += 1
+                p.grad = None
+                continue
+            g = g / (1.0 + self.gamma * self.n[i])         # InvDecay (host tensors: the same recurrence in torch ops)
             self.n[i] += 1
             self.v[i].mul_(self.rho).sub_(g, alpha=self.eta)   # Momentum: v = rho v - eta g ; x -= -v
             p.add_(self.v[i])

@@ -1181,7 +1181,8 @@ extern "C" rnde_status rnde_classifier_head(rnde_node* h, const float* u_dev, co
     }
     float* delta = h->head_ws;
     float* ce_col = h->head_ws + (size_t)B * n_classes;
-    hipLaunchKernelGGL(rnde_head_col_kernel, dim3((B + 3) / 4), dim3(256), 0, s, u_dev, p3_dev, y_dev, h->D, n_classes, B,
+    if (h->D > 256 * kHeadRowsPerThread) { h->err = "classifier head: D <= 1024"; return RNDE_ERR_BAD_ARG; }
+    hipLaunchKernelGGL(rnde_head_col_kernel, dim3(B), dim3(256), 0, s, u_dev, p3_dev, y_dev, h->D, n_classes, B,
                        logits_out_dev, u_bar_dev, delta, ce_col);
     float* partial = ce_col + B;
     hipLaunchKernelGGL(rnde_head_wgrad_kernel, dim3((h->D + 255) / 256, kHeadChunks), dim3(256), 0, s, u_dev, (const float*)delta,
@@ -1322,4 +1323,14 @@ static rnde_status chain_bwd_run(rnde_node* h, const float* u_bar_dev, const flo
     HIPCHK(h, hipStreamSynchronize(s));
     if (tspan_bar_host) { tspan_bar_host[0] = h->h_scal[0]; tspan_bar_host[1] = h->h_scal[1]; }
     return RNDE_OK;
+}
+
+extern "C" rnde_status rnde_momentum_step(float* p_dev, const float* g_dev, float* v_dev, int64_t len, int64_t n, float gamma,
+                                          float eta, float rho, void* stream) {
+    if (!p_dev || !g_dev || !v_dev || len < 0 || n < 1) return RNDE_ERR_BAD_ARG;
+    if (len == 0) return RNDE_OK;
+    const float inv_decay = 1.0f / (1.0f + gamma * (float)n);
+    hipLaunchKernelGGL(rnde::rnde_momentum_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p_dev, g_dev,
+                       v_dev, (long long)len, inv_decay, eta, rho);
+    return hipGetLastError() == hipSuccess ? RNDE_OK : RNDE_ERR_HIP;
 }

@@ -13,28 +13,41 @@ namespace rnde {
 
 constexpr int kHeadMaxC = 16;
 
-// one wave per batch column
+// one workgroup (4 waves) per batch column: every thread owns rows d = tid + 256 k, k < 4, and keeps its rows of W in registers
+// for both products (logits = W u, u-bar = W^T delta); all loads of the first product are issued up front (the one-wave-per-column form it
+// replaces walked 13 dependent iterations twice: 34 -> 25 us at B = 512; staging W through LDS was measured: no faster)
+constexpr int kHeadRowsPerThread = 4;       // D <= 1024
 __global__ __launch_bounds__(256) void rnde_head_col_kernel(const float* __restrict__ u, const float* __restrict__ p3,
                                                             const float* __restrict__ y, int D, int C, int B,
                                                             float* __restrict__ logits_out, float* __restrict__ ubar,
                                                             float* __restrict__ delta, float* __restrict__ ce_col) {
-    const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= B) return;
+    __shared__ float red[4][kHeadMaxC];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int c = blockIdx.x;
     const float* W = p3;
     const float* b = p3 + (size_t)C * D;
     const float* uc = u + (size_t)c * D;
+    float wv[kHeadRowsPerThread][kHeadMaxC], uv[kHeadRowsPerThread];
+#pragma unroll
+    for (int k = 0; k < kHeadRowsPerThread; ++k) {
+        const int d = tid + 256 * k;
+        uv[k] = d < D ? uc[d] : 0.f;
+#pragma unroll
+        for (int i = 0; i < kHeadMaxC; ++i) wv[k][i] = (i < C && d < D) ? W[(size_t)d * C + i] : 0.f;
+    }
     float acc[kHeadMaxC];
 #pragma unroll
-    for (int i = 0; i < kHeadMaxC; ++i) acc[i] = 0.f;
-    for (int d = lane; d < D; d += 64) {
-        const float uv = uc[d];
+    for (int i = 0; i < kHeadMaxC; ++i) {
+        acc[i] = 0.f;
 #pragma unroll
-        for (int i = 0; i < kHeadMaxC; ++i) if (i < C) acc[i] = fmaf(W[(size_t)d * C + i], uv, acc[i]);
+        for (int k = 0; k < kHeadRowsPerThread; ++k) acc[i] = fmaf(wv[k][i], uv[k], acc[i]);
     }
+#pragma unroll
+    for (int i = 0; i < kHeadMaxC; ++i) if (i < C) { const float s = wave_sum_f(acc[i]); if (lane == 0) red[w][i] = s; }
+    __syncthreads();
     float mx = -3.0e38f;
 #pragma unroll
-    for (int i = 0; i < kHeadMaxC; ++i) if (i < C) { acc[i] = wave_sum_f(acc[i]) + b[i]; mx = fmaxf(mx, acc[i]); }
+    for (int i = 0; i < kHeadMaxC; ++i) if (i < C) { acc[i] = ((red[0][i] + red[1][i]) + (red[2][i] + red[3][i])) + b[i]; mx = fmaxf(mx, acc[i]); }
     float se = 0.f;
 #pragma unroll
     for (int i = 0; i < kHeadMaxC; ++i) if (i < C) se += expf(acc[i] - mx);
@@ -50,15 +63,17 @@ __global__ __launch_bounds__(256) void rnde_head_col_kernel(const float* __restr
             dl[i] = (expf(acc[i] - lse) - yv) * invB;
         }
     }
-    if (lane == 0) {
+    if (tid == 0) {
         ce_col[c] = ce;
         for (int i = 0; i < C; ++i) { delta[(size_t)c * C + i] = dl[i]; if (logits_out) logits_out[(size_t)c * C + i] = acc[i]; }
     }
-    for (int d = lane; d < D; d += 64) {
+#pragma unroll
+    for (int k = 0; k < kHeadRowsPerThread; ++k) {
+        const int d = tid + 256 * k;
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < kHeadMaxC; ++i) if (i < C) s = fmaf(W[(size_t)d * C + i], dl[i], s);
-        ubar[(size_t)c * D + d] = s;
+        for (int i = 0; i < kHeadMaxC; ++i) if (i < C) s = fmaf(wv[k][i], dl[i], s);
+        if (d < D) ubar[(size_t)c * D + d] = s;
     }
 }
 
@@ -105,6 +120,17 @@ __global__ __launch_bounds__(256) void rnde_head_reduce_kernel(const float* __re
         s = wave_sum_f(s);
         if (lane == 0) *ce_out = s / (float)B;
     }
+}
+
+// Optimiser(InvDecay(gamma), Momentum(eta, rho)) on one flat parameter group (include/rnde.h: rnde_momentum_step)
+__global__ __launch_bounds__(256) void rnde_momentum_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ v,
+                                                            long long len, float inv_decay, float eta, float rho) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= len) return;
+    const float gs = g[i] * inv_decay;
+    const float vn = rho * v[i] - eta * gs;
+    v[i] = vn;
+    p[i] = p[i] + vn;
 }
 
 }  // namespace rnde

@@ -267,3 +267,20 @@ def test_latent_ode_training_reduces_loss(rnde):
         opt.step()
         nlls.append(float(nll))
     assert nlls[-1] < 0.8 * nlls[0], nlls
+
+
+def test_momentum_step_matches_the_torch_recurrence(rnde):
+    """rnde_momentum_step (one launch per parameter group) against the host form of Optimiser(InvDecay, Momentum),
+    reference src/utils.jl:149-156 + experiments/mnist_node.jl:130."""
+    rn = rnde
+    g = torch.Generator().manual_seed(21)
+    p0 = torch.randn(166_418 - 7850, generator=g)
+    pc, pg = p0.clone().requires_grad_(True), p0.clone().cuda().requires_grad_(True)
+    oc, og = rn.FluxOptimiser([torch.zeros(0), pc]), rn.FluxOptimiser([torch.zeros(0, device="cuda"), pg])
+    for k in range(5):
+        grad = torch.randn(p0.shape, generator=g)
+        pc.grad, pg.grad = grad.clone(), grad.clone().cuda()
+        oc.step(); og.step()
+        assert pg.grad is None and og.n == oc.n
+    assert (pg.detach().cpu() - pc.detach()).abs().max() <= 1e-6 * pc.detach().abs().max()
+    assert (og.v[0].cpu() - oc.v[0]).abs().max() <= 1e-6 * oc.v[0].abs().max()

@@ -146,4 +146,17 @@ const LAST_NFE = Ref(0)
 # and the constructor (:10-33) creates `rnde_handle = RNDE.Handle(RNDE.config_for(...))` from the Dense sizes
 # of `model`, kwargs[:reltol], kwargs[:abstol] and `regularize`.
 
+# Optimiser(InvDecay(gamma), Momentum(eta, rho)) on one flat group, in place (src/utils.jl:149-156, mnist_node.jl:130);
+# `n` is the group's InvDecay counter (starts at 1, the caller increments it).
+function momentum_step!(p::CuArray{Float32,1}, g::CuArray{Float32,1}, v::CuArray{Float32,1}, n::Integer;
+                        gamma = 1f-5, eta = 0.1f0, rho = 0.9f0)
+    GC.@preserve p g v begin
+        st = ccall((:rnde_momentum_step, LIB), Cint,
+                   (CuPtr{Cfloat}, CuPtr{Cfloat}, CuPtr{Cfloat}, Int64, Int64, Cfloat, Cfloat, Cfloat, Ptr{Cvoid}),
+                   p, g, v, length(p), n, gamma, eta, rho, C_NULL)
+    end
+    st == 0 || error("rnde_momentum_step: status $st")
+    return p
+end
+
 end # module

@@ -51,6 +51,7 @@ struct rnde_node {
     f32x4 *pw1 = nullptr, *pw2 = nullptr, *pw1t = nullptr, *pw2t = nullptr;
     float* pcopy = nullptr;
     StepState *ctl = nullptr, *ctl_final = nullptr;
+    unsigned char *mbox = nullptr, *h_mbox = nullptr; size_t mbox_meta_off = 0;   // stage engine: everything the host reads per chunk, contiguous (one copy)
     StepMeta* meta = nullptr;
     InitRec* initrec = nullptr;
     float *errpart = nullptr, *initpart = nullptr;
@@ -334,20 +335,27 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
     ok &= dm((void**)&h->spwBt, (size_t)h->sMT * h->sKHb * 64 * 16) && dm((void**)&h->spwDt, (size_t)h->sHT * h->sMT * 64 * 16);
     ok &= dm((void**)&h->slab2, (size_t)2 * (h->Bpad_max / 16) * h->sR * h->sHT * 64 * 16);
     const size_t tslab_bytes = (size_t)2 * (h->Bpad_max / 16) * h->sR * h->sHT * 128 * 16;   // tagged slabs: two 16-byte entries per lane
-    ok &= dm((void**)&h->tslab, tslab_bytes) && dm((void**)&h->pabort, 8) && dm((void**)&h->pxcc, (size_t)h->nwg_max * 4);
-    ok &= hipHostMalloc((void**)&h->h_pchk, ((size_t)h->nwg_max + 2) * 4) == hipSuccess;
-    ok &= dm((void**)&h->ctl, 2 * sizeof(StepState)) && dm((void**)&h->ctl_final, sizeof(StepState));
-    ok &= dm((void**)&h->meta, (size_t)(c->max_attempts + 1) * sizeof(StepMeta)) && dm((void**)&h->initrec, sizeof(InitRec));
+    ok &= dm((void**)&h->tslab, tslab_bytes);
+    // mailbox: [0) final controller state | [512) initial-step record | [1016) abort word of the persistent kernels, [1024) their
+    // XCC ids | [meta_off) step metadata -- read by the host with ONE copy per chunk (was five)
+    static_assert(sizeof(StepState) <= 512 && sizeof(InitRec) <= 504, "mailbox layout");
+    h->mbox_meta_off = (1024 + (size_t)h->nwg_max * 4 + 255) / 256 * 256;
+    const size_t mbox_bytes = h->mbox_meta_off + (size_t)(c->max_attempts + 1) * sizeof(StepMeta);
+    ok &= dm((void**)&h->mbox, mbox_bytes) && hipHostMalloc((void**)&h->h_mbox, mbox_bytes) == hipSuccess;
+    if (ok) {
+        hipMemset(h->mbox, 0, mbox_bytes);
+        h->ctl_final = (StepState*)h->mbox; h->initrec = (InitRec*)(h->mbox + 512);
+        h->pabort = (unsigned*)(h->mbox + 1016); h->pxcc = (unsigned*)(h->mbox + 1024); h->meta = (StepMeta*)(h->mbox + h->mbox_meta_off);
+        h->h_ctl = (StepState*)h->h_mbox; h->h_init = (InitRec*)(h->h_mbox + 512);
+        h->h_pchk = (unsigned*)(h->h_mbox + 1016); h->h_meta = (StepMeta*)(h->h_mbox + h->mbox_meta_off);
+    }
+    ok &= dm((void**)&h->ctl, 2 * sizeof(StepState));
     ok &= dm((void**)&h->errpart, (size_t)6 * h->nwg_max * 4) && dm((void**)&h->initpart, (size_t)3 * h->nwg_max * 4);
     // scratch records: 2 (no-tape ring); grown to max_attempts on the first taped forward
     h->arena_recs = 2;
     ok &= dm((void**)&h->arena, (size_t)h->arena_recs * h->rec_stride * 4);
-    ok &= hipHostMalloc((void**)&h->h_ctl, sizeof(StepState)) == hipSuccess;
-    ok &= hipHostMalloc((void**)&h->h_meta, (size_t)(c->max_attempts + 1) * sizeof(StepMeta)) == hipSuccess;
-    ok &= hipHostMalloc((void**)&h->h_init, sizeof(InitRec)) == hipSuccess;
     ok &= hipHostMalloc((void**)&h->h_scal, 64 * sizeof(float)) == hipSuccess;
     if (!ok) { g_create_err = "device allocation failed"; rnde_node_destroy(h); return RNDE_ERR_HIP; }
-    hipMemset(h->initrec, 0, sizeof(InitRec));
     hipMemset(h->tslab, 0, tslab_bytes); hipMemset(h->pabort, 0, 8); hipMemset(h->pxcc, 0, (size_t)h->nwg_max * 4);
     { const char* e = getenv("RNDE_PERSIST"); h->persist = (h->engine == 2 && h->sR <= 8 && !(e && e[0] == '0')) ? 1 : 0; }
     if (const char* e = getenv("RNDE_PERSIST_SPINS")) h->persist_spins = atoi(e);
@@ -360,6 +368,12 @@ extern "C" void rnde_node_destroy(rnde_node* h) {
     if (!h) return;
     void* d[] = {h->f0, h->h0, h->u1, h->f1, h->h1, h->arena, h->xcopy, h->pw1, h->pw2, h->pw1t, h->pw2t, h->pcopy, h->spwB, h->spwD, h->spwBt, h->spwDt, h->slab2,
                  h->ctl, h->ctl_final, h->meta, h->initrec, h->errpart, h->initpart};
+    if (h->mbox || h->h_mbox) {   // these alias the mailbox
+        for (void*& p : d) if (p == h->ctl_final || p == h->meta || p == h->initrec) p = nullptr;
+        h->pabort = h->pxcc = nullptr; h->h_pchk = nullptr; h->h_ctl = nullptr; h->h_meta = nullptr; h->h_init = nullptr;
+        if (h->mbox) hipFree(h->mbox);
+        if (h->h_mbox) hipHostFree(h->h_mbox);
+    }
     for (void* p : d) if (p) hipFree(p);
     bwd_free(h->bw);
     if (h->head_ws) hipFree(h->head_ws);
@@ -571,10 +585,13 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
         else HIPCHK(h, launch_finish(h, P, launched, u_out_dev, s));
         // one synchronisation per chunk: controller state, the persistent kernels' health words, and (speculatively: the solve
         // usually ends in the first chunk) the step metadata and the initial-step record the epilogue needs
-        HIPCHK(h, hipMemcpyAsync(h->h_ctl, h->ctl_final, sizeof(StepState), hipMemcpyDeviceToHost, s));
-        if (h->engine == 2) persist_check_enqueue(h, SQ.R * SQ.C, s);
-        HIPCHK(h, hipMemcpyAsync(h->h_meta, h->meta, (size_t)launched * sizeof(StepMeta), hipMemcpyDeviceToHost, s));
-        HIPCHK(h, hipMemcpyAsync(h->h_init, h->initrec, sizeof(InitRec), hipMemcpyDeviceToHost, s));
+        if (h->mbox) {
+            HIPCHK(h, hipMemcpyAsync(h->h_mbox, h->mbox, h->mbox_meta_off + (size_t)launched * sizeof(StepMeta), hipMemcpyDeviceToHost, s));
+        } else {
+            HIPCHK(h, hipMemcpyAsync(h->h_ctl, h->ctl_final, sizeof(StepState), hipMemcpyDeviceToHost, s));
+            HIPCHK(h, hipMemcpyAsync(h->h_meta, h->meta, (size_t)launched * sizeof(StepMeta), hipMemcpyDeviceToHost, s));
+            HIPCHK(h, hipMemcpyAsync(h->h_init, h->initrec, sizeof(InitRec), hipMemcpyDeviceToHost, s));
+        }
         HIPCHK(h, hipStreamSynchronize(s));
         if (h->engine == 2 && persist_check_result(h, SQ.C, SQ.R, s)) {
             if (h->pending_bwd) {   // the failure may belong to the asynchronous reverse pass before this forward: its outputs cannot be trusted

@@ -405,9 +405,11 @@ static rnde_status ensure_arena(rnde_node* h, long long recs) {
     return RNDE_OK;
 }
 
-static rnde_status pack_weights(rnde_node* h, const float* p_dev, bool reverse, hipStream_t s) {
-    HIPCHK(h, launch_pack(h, p_dev, h->pw1, 0, h->MT1, h->K4_1, s));
-    HIPCHK(h, launch_pack(h, p_dev, h->pw2, 1, h->MT2, h->K4_2, s));
+static rnde_status pack_weights(rnde_node* h, const float* p_dev, bool reverse, hipStream_t s, bool forward = true) {
+    if (forward) {   // (the stage engine's forward pass has its own packs; it only needs the transposed ones below, for rnde_binit_kernel)
+        HIPCHK(h, launch_pack(h, p_dev, h->pw1, 0, h->MT1, h->K4_1, s));
+        HIPCHK(h, launch_pack(h, p_dev, h->pw2, 1, h->MT2, h->K4_2, s));
+    }
     if (reverse) {
         HIPCHK(h, launch_pack(h, p_dev, h->pw2t, 2, h->MT2t, h->K4_2t, s));
         HIPCHK(h, launch_pack(h, p_dev, h->pw1t, 3, h->MT1t, h->K4_1t, s));
@@ -550,7 +552,7 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
     P.sv_t = n_saveat > 0 ? h->sv_t_dev : nullptr; P.nsave = n_saveat; P.sv_out = sv_out_dev;
     h->B = B; h->Bpad = P.Bpad; h->nwg = P.nwg; h->t0 = t0; h->t1 = t1;
     rnde_status st = h->engine == 3 ? chain_pack(h, keep_tape ? h->pcopy : p_dev, s)
-                                    : pack_weights(h, p_dev, keep_tape != 0, s);   // (column-owner packs: also used by the reverse sweep)
+                                    : pack_weights(h, p_dev, keep_tape != 0, s, h->engine != 2);   // (column-owner packs: also used by the reverse sweep)
     if (st != RNDE_OK) return st;
     StageParams SQ{};
     ChainParams CQ{};

@@ -128,6 +128,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--col-tile", type=int, default=0)
     ap.add_argument("--autograd", action="store_true", help="head + loss through torch.autograd instead of the fused C-ABI head")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) and run the gradient all-reduce even at world size 1: exercises the N > 1 code path on a 1-GPU box")
     ap.add_argument("--workload", default="mnist", choices=["mnist", "latent"], help="mnist = BASELINE.json's metric (default); latent = SURVEY 8d config 4")
     args = ap.parse_args()
     if args.workload == "latent":
@@ -143,9 +144,11 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import regneuralde_jl_amd as rn
@@ -156,7 +159,7 @@ def main():
     g = torch.Generator().manual_seed(1999 + rank)
     x = torch.rand(B, 1, 28, 28, generator=g).to(device)                  # uniform [0,1) images, mnist_node.jl:206
     y = torch.eye(NCLS)[torch.randint(0, NCLS, (B,), generator=g)].to(device)
-    reducer = rn.GradientAllReducer(model.trainable()) if world > 1 else None
+    reducer = rn.GradientAllReducer(model.trainable()) if use_dist else None
     nfes = []
 
     def train_step():
@@ -166,7 +169,7 @@ def main():
             loss = float(loss.detach())
         else:
             loss, ce, reg, nfe = rn.fused_loss_and_grad(model, x, y, lam=1.0e2, sync=False)   # loss stays on the device
-        if world > 1:
+        if use_dist:
             reducer.allreduce_()                                          # one RCCL sum over xGMI, 166,418 fp32
         opt.step()
         nfes.append(nfe)
@@ -175,18 +178,18 @@ def main():
     for _ in range(args.warmup):
         train_step()
     nfes.clear()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last_loss = train_step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     last_loss = float(last_loss)          # (a device tensor on the fused path: read after the timed region, as the reference's loop does)
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -245,11 +248,12 @@ def main():
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+        C.CDLL(None).fflush(None)          # RCCL's version banner sits in the C stdio buffer: push it out BEFORE the JSON line
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -583,7 +583,7 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
             ++launched;
         }
         if (h->engine == 3) HIPCHK(h, launch_chain<CM_FINISH>(h, CQ, launched, u_out_dev, s));
-        else if (h->engine == 2) { hipLaunchKernelGGL(rnde_stage_finish_kernel, dim3(64), dim3(256), 0, s, SQ, launched, u_out_dev); HIPCHK(h, hipGetLastError()); }
+        else if (h->engine == 2) { hipLaunchKernelGGL(rnde_stage_finish_kernel, dim3(256), dim3(256), 0, s, SQ, launched, u_out_dev); HIPCHK(h, hipGetLastError()); }
         else HIPCHK(h, launch_finish(h, P, launched, u_out_dev, s));
         // one synchronisation per chunk: controller state, the persistent kernels' health words, and (speculatively: the solve
         // usually ends in the first chunk) the step metadata and the initial-step record the epilogue needs
@@ -775,7 +775,7 @@ extern "C" rnde_status rnde_debug_attempt(rnde_node* h, const float* uprev_dev, 
         if (st2 != RNDE_OK) return st2;
         StageParams SQ = make_stage_params(h, P, p_dev);
         HIPCHK(h, stage_attempt(h, SQ, 0, s));
-        hipLaunchKernelGGL(rnde_stage_finish_kernel, dim3(64), dim3(256), 0, s, SQ, 1, (float*)nullptr);
+        hipLaunchKernelGGL(rnde_stage_finish_kernel, dim3(256), dim3(256), 0, s, SQ, 1, (float*)nullptr);
         HIPCHK(h, hipGetLastError());
     } else {
         HIPCHK(h, launch_step<MODE_STEP>(h, P, 0, s));

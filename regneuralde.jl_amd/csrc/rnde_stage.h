@@ -509,7 +509,11 @@ __global__ __launch_bounds__(256) void rnde_stage_finish_kernel(const StageParam
     if (!u_out) return;
     const float* src = S.live < 0 ? P.x : P.arena + (long long)S.live * P.rec_stride + L.unew();
     const long long total = (long long)P.D * P.B;
-    for (long long i = blockIdx.x * 256LL + tid; i < total; i += (long long)gridDim.x * 256) u_out[i] = src[i];
+    if (((total & 3) == 0) && (((reinterpret_cast<size_t>(u_out) | reinterpret_cast<size_t>(src)) & 15) == 0)) {
+        for (long long i = blockIdx.x * 256LL + tid; i < total / 4; i += (long long)gridDim.x * 256) ((f32x4*)u_out)[i] = ((const f32x4*)src)[i];
+    } else {
+        for (long long i = blockIdx.x * 256LL + tid; i < total; i += (long long)gridDim.x * 256) u_out[i] = src[i];
+    }
 }
 
 }  // namespace rnde

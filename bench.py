@@ -41,7 +41,7 @@ def build_model(rn, device, batch, seed=1999):
     return model
 
 
-def cpu_baseline(batch=256, steps=1):
+def cpu_baseline(batch=512, steps=2):
     """CPU restatement of the same training step (oracle fp32 + numpy head) on a bounded sample."""
     import numpy as np
     from oracle.oracle import Oracle, arch_mnist, glorot_params

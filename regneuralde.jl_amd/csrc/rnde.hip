@@ -41,7 +41,7 @@ struct rnde_node {
     float* head_ws = nullptr; size_t head_ws_floats = 0;   // fused classifier head scratch
     float* sv_t_dev = nullptr; size_t sv_cap = 0; std::vector<float> saveat;   // saveat times of the last forward
     // persistent attempt kernel (rnde_stage_persist.h): 1 = in use, 0 = off (RNDE_PERSIST=0), -1 = disabled after a failure
-    int persist = 0, persist_spins = kPersistMaxSpins; unsigned persist_seq = 0; float* tslab = nullptr; unsigned *pabort = nullptr, *pxcc = nullptr; unsigned* h_pchk = nullptr;
+    int persist = 0, persist_spins = kPersistMaxSpins; int tslab_Bpad = -1; size_t tslab_bytes = 0; float* tslab = nullptr; unsigned *pabort = nullptr, *pxcc = nullptr; unsigned* h_pchk = nullptr;
     hipStream_t wstream = nullptr;        // (experimental overlap path of the weight-gradient GEMMs)
     std::vector<hipEvent_t> wevents;
     // device
@@ -334,7 +334,8 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
     ok &= dm((void**)&h->spwB, (size_t)h->sMT * h->sK2b * 64 * 16) && dm((void**)&h->spwD, (size_t)h->sHT * h->sMT * 64 * 16);
     ok &= dm((void**)&h->spwBt, (size_t)h->sMT * h->sKHb * 64 * 16) && dm((void**)&h->spwDt, (size_t)h->sHT * h->sMT * 64 * 16);
     ok &= dm((void**)&h->slab2, (size_t)2 * (h->Bpad_max / 16) * h->sR * h->sHT * 64 * 16);
-    const size_t tslab_bytes = (size_t)2 * (h->Bpad_max / 16) * h->sR * h->sHT * 128 * 16;   // tagged slabs: two 16-byte entries per lane
+    const size_t tslab_bytes = (size_t)3 * (h->Bpad_max / 16) * h->sR * h->sHT * 64 * 16;    // three buffers of one 16-byte entry per lane and tile
+    h->tslab_bytes = tslab_bytes;
     ok &= dm((void**)&h->tslab, tslab_bytes);
     // mailbox: [0) final controller state | [512) initial-step record | [1016) abort word of the persistent kernels, [1024) their
     // XCC ids | [meta_off) step metadata -- read by the host with ONE copy per chunk (was five)
@@ -356,7 +357,7 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
     ok &= dm((void**)&h->arena, (size_t)h->arena_recs * h->rec_stride * 4);
     ok &= hipHostMalloc((void**)&h->h_scal, 64 * sizeof(float)) == hipSuccess;
     if (!ok) { g_create_err = "device allocation failed"; rnde_node_destroy(h); return RNDE_ERR_HIP; }
-    hipMemset(h->tslab, 0, tslab_bytes); hipMemset(h->pabort, 0, 8); hipMemset(h->pxcc, 0, (size_t)h->nwg_max * 4);
+    hipMemset(h->tslab, 0xFF, tslab_bytes); hipMemset(h->pabort, 0, 8); hipMemset(h->pxcc, 0, (size_t)h->nwg_max * 4);
     { const char* e = getenv("RNDE_PERSIST"); h->persist = (h->engine == 2 && h->sR <= 8 && !(e && e[0] == '0')) ? 1 : 0; }
     if (const char* e = getenv("RNDE_PERSIST_SPINS")) h->persist_spins = atoi(e);
     h->predicted = 12;
@@ -444,10 +445,17 @@ static rnde_status stage_pack_weights(rnde_node* h, const float* p_dev, hipStrea
     HIPCHK(h, stage_pack(h, p_dev, h->spwD, 1, h->sHT, h->sMT, s));
     return RNDE_OK;
 }
+// The hand-off slabs must read "empty" wherever the persistent kernels have not written in the current tile indexing: at
+// creation, and whenever the padded batch width (= number of column tiles) differs from the last persistent launch's.
+static hipError_t slab_prepare(rnde_node* h, int Bpad, hipStream_t s) {
+    if (h->tslab_Bpad == Bpad) return hipSuccess;
+    h->tslab_Bpad = Bpad;
+    return hipMemsetAsync(h->tslab, 0xFF, h->tslab_bytes, s);
+}
 static hipError_t stage_attempt(rnde_node* h, const StageParams& Q, int n, hipStream_t s) {
     if (h->persist == 1) {   // one launch per attempt, slab hand-offs inside the kernel (rnde_stage_persist.h)
-        PersistSync Y{h->tslab, h->pabort, h->pxcc, h->persist_seq, h->persist_spins};
-        h->persist_seq += 8;
+        PersistSync Y{h->tslab, h->pabort, h->pxcc, h->persist_spins};
+        if (hipError_t e = slab_prepare(h, Q.Bpad16, s); e != hipSuccess) return e;
         const dim3 grid(8 * Q.R * ((Q.C + 7) / 8));   // a column tile's row blocks share blockIdx % 8 (same XCD)
         if (h->act2) hipLaunchKernelGGL((rnde_stage_attempt_kernel<1>), grid, dim3(64 * Q.WT), h->stage_lds, s, Q, n, Y);
         else hipLaunchKernelGGL((rnde_stage_attempt_kernel<0>), grid, dim3(64 * Q.WT), h->stage_lds, s, Q, n, Y);
@@ -1117,8 +1125,8 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
             }
             const double qo = pow((double)h->h_meta[n].qold_in, (double)kBeta2);   // for the scalar adjoint chain of the attempt
             if (h->persist == 1) {   // the attempt's 7 reverse launches as one (rnde_bstage_persist.h)
-                PersistSync Y{h->tslab, h->pabort, h->pxcc, h->persist_seq, h->persist_spins};
-                h->persist_seq += 8;
+                PersistSync Y{h->tslab, h->pabort, h->pxcc, h->persist_spins};
+                HIPCHK(h, slab_prepare(h, Q.F.Bpad, s));
                 const dim3 pgrid(8 * BQ.R * ((BQ.C + 7) / 8));
                 if (h->act2) hipLaunchKernelGGL((rnde_bstage_attempt_kernel<1>), pgrid, blk, h->stage_lds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo);
                 else hipLaunchKernelGGL((rnde_bstage_attempt_kernel<0>), pgrid, blk, h->stage_lds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo);

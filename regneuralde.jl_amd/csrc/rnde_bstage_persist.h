@@ -87,11 +87,11 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
 #pragma unroll
     for (int i = 0; i < 6; ++i) gbs[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    auto phase_d = [&](const f32x4& v, int par, unsigned ex) {
+    auto phase_d = [&](const f32x4& v, unsigned ex) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) GL[col * KG + kperm(16 * w + 4 * (lane >> 4) + i)] = tile_ok ? v[i] : 0.f;
         __syncthreads();
-        const size_t tile0 = (((size_t)par * Q.C + ct) * Q.R + rb) * Q.HT;
+        const size_t tile0 = (((size_t)slab_buf(ex) * Q.C + ct) * Q.R + rb) * Q.HT;
         const float* gbp = GL + col * KG + 4 * (lane >> 4);
         f32x4 bg[kSMaxW];
 #pragma unroll
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
                     acc1 = mfma16(wD[kb][3], bg[kb][3], acc1);
                 }
             }
-            slab_put(Y.tslab, tile0 + w, lane, acc0 + acc1, Y.seq_base + ex);
+            slab_put(Y.tslab, tile0 + w, lane, acc0 + acc1);
         }
         for (int ht = w + Q.WT; ht < Q.HT; ht += Q.WT) {
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
                     acc1 = mfma16(a[3], bg[kb][3], acc1);
                 }
             }
-            slab_put(Y.tslab, tile0 + ht, lane, acc0 + acc1, Y.seq_base + ex);
+            slab_put(Y.tslab, tile0 + ht, lane, acc0 + acc1);
         }
     };
 
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
         if (!colok) { tau = 0.f; exdt = 0.f; }
         pS[0] = S; pT[0] = tau; pX[0] = exdt;
         BSTAMP(1);
-        phase_d(v, 0, 1u);
+        phase_d(v, 1u);
         BSTAMP(2);
     }
 
@@ -263,16 +263,20 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
         if (tile_ok) c_ks = (j >= 2) ? ld4(R + L.k(j) + co, r0, P.D, true, vec) : ld4(k1p + co, r0, P.D, true, vec);
         float S = 0.f, tau = 0.f;
         // ---- phase A: poll this wave's hidden tile of the R row blocks (the polling load is the data load) ----
-        const unsigned tag = Y.seq_base + (unsigned)(7 - j);
+        constexpr unsigned ex = (unsigned)(7 - j);          // the exchange this stage consumes (1 = START's put)
+        const int buf = slab_buf(ex);
         bool dead = false;
         f32x4 zs = {0.f, 0.f, 0.f, 0.f};
-        if (w < Q.HT) dead = !slab_poll_sum(Y, j & 1, Q.C, Q.R, Q.HT, ct, w, lane, tag, zs);
+        if (w < Q.HT) dead = !slab_poll_sum(Y, buf, Q.C, Q.R, Q.HT, ct, w, lane, zs);
         BSTAMP(3 + 5 * (6 - j));
         const float* hsrc = R + L.h(j + 1);
         float* z1dst = R + L.z1(j + 1);
+        // every row block has produced exchange ex, hence consumed ex - 1: this wave's entries of that buffer can be emptied
+        const size_t tprev0 = (((size_t)slab_buf(ex + 2u) * Q.C + ct) * Q.R + rb) * Q.HT;     // (ex - 1) % 3 == (ex + 2) % 3
         for (int ht = w; ht < Q.HT; ht += Q.WT) {
             f32x4 z = zs;
-            if (ht != w && !dead) dead = !slab_poll_sum(Y, j & 1, Q.C, Q.R, Q.HT, ct, ht, lane, tag, z);
+            if (ht != w && !dead) dead = !slab_poll_sum(Y, buf, Q.C, Q.R, Q.HT, ct, ht, lane, z);
+            if (!dead) slab_clear(Y.tslab, tprev0 + ht, lane);
             const int h0 = 16 * ht + 4 * (lane >> 4);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -325,6 +329,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
         }
         BSTAMP(5 + 5 * (6 - j));
         // ---- phase C ----
+        if constexpr (j > 1) slab_clears_done();      // before this stage's put (see slab_put; the clears were issued two phases ago)
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (tile_ok) {
             if (has_eig && j == 5) gb += exg;
@@ -365,7 +370,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
         if (!colok) tau = 0.f;
         pS[7 - j] = S; pT[7 - j] = tau;
         BSTAMP(6 + 5 * (6 - j));
-        if constexpr (j > 1) phase_d(v, (j - 1) & 1, (unsigned)(7 - j + 1));
+        if constexpr (j > 1) phase_d(v, ex + 1u);
         BSTAMP(7 + 5 * (6 - j));
     };
     stage(std::integral_constant<int, 6>{});

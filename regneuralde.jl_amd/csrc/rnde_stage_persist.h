@@ -24,61 +24,72 @@
 namespace rnde {
 
 struct PersistSync {
-    float* tslab;           // tagged slabs [2][C][R][HT][2][64] f32x4 (see slab_put / slab_poll)
+    float* tslab;           // hand-off slabs [3][C][R][HT][64] f32x4 (see slab_put / slab_poll_sum)
     unsigned* abort_flag;   // [0] a hand-off timed out
     unsigned* xcc;          // [grid] XCC id of each workgroup (written every launch, checked by the host)
-    unsigned seq_base;      // exchange tags are seq_base + 1..6; the host adds 8 per launch
     int max_spins;          // bound of every polling loop (kPersistMaxSpins; RNDE_PERSIST_SPINS overrides it: the fallback test uses 0)
 };
 
 constexpr int kPersistMaxSpins = 100000;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// ---- tagged slab hand-off -------------------------------------------------------------------------------------------
-// A slab tile (one f32x4 of layer-1 partials per lane) travels as two 16-byte entries {v0, v1, tag, tag}, {v2, v3, tag, tag}:
-// data and validity arrive in the SAME store, so there is no separate flag, no release wait for the store's
-// acknowledgement and no second load after the flag has been seen -- the consumer's polling load is the data load
-// (3.1 us -> ~1.5 us per hand-off).  A 16-byte aligned store of one lane lands in one cache line of the XCD's L2 in one
-// write, and the consumer reads it with agent-scope (sc1: L1-bypassing) loads, so a matching tag implies matching data.
-// (A back-off between polls, s_sleep 4 / 16, was measured and makes the attempt 1-3 % slower: polling traffic is not the limit.)
-// Tags are unique per exchange over the life of the handle; buffers alternate by parity, and a producer can only be two
-// exchanges ahead of the slowest consumer of its column tile (it needs that consumer's previous tile to get there).
-__device__ __forceinline__ void slab_put(float* tslab, size_t tile_index, int lane, const f32x4& v, unsigned tag) {
-    const float tf = __builtin_bit_cast(float, tag);
-    f32x4* d = (f32x4*)tslab + tile_index * 128;
-    d[lane] = (f32x4){v[0], v[1], tf, tf};
-    d[64 + lane] = (f32x4){v[2], v[3], tf, tf};
+// ---- slab hand-off: the data is its own validity ---------------------------------------------------------------------------
+// A slab tile (one f32x4 of layer-1 partials per lane) travels as ONE 16-byte entry per lane.  An entry that has not been
+// written yet holds the bit pattern kSlabEmpty in all four words (a NaN no arithmetic here produces); the consumer's polling
+// load is the data load, and the data is valid when none of the four words is kSlabEmpty -- no flag, no tag words, no release
+// wait, no second load.  Polling volume is what a hand-off costs (tools/micro/cluster_poll_size.hip: 1.69 us per exchange with
+// two tagged entries per lane, the previous form of this protocol, 0.99 us with one), so the entry carries payload only.
+//
+// Who empties an entry again: its producer, and it can tell when that is safe.  Every launch that exchanges at all performs
+// exactly 6 exchanges (ex = 1..6, forward and reverse kernels alike), exchange ex uses buffer ex % 3.  When a workgroup's poll of
+// exchange ex succeeds, every row block of its column tile has produced ex, hence consumed ex - 1: the workgroup empties ITS
+// entries of buffer (ex - 1) % 3 (for ex = 1 that is buffer 0 = exchange 6 of the previous launch, which the kernel boundary has
+// long completed).  It waits for those stores to be acknowledged (s_waitcnt vmcnt(0), placed a whole phase later, where it is free)
+// before its next put, so whoever sees that put -- and only such a workgroup can get to polling exchange ex + 2 in the buffer just
+// emptied -- also sees the emptied entries, never the stale ones.  6 = 0 (mod 3), so every launch starts in the same state
+// (buffers 1, 2 empty, buffer 0 holding the last exchange), and launches that exit at once (a finished solve) change nothing.
+// The host fills the slabs with kSlabEmpty at creation and whenever the batch width (the tile indexing) changes.
+// (A back-off between polls, s_sleep 4 / 16, was measured and makes the attempt 1-3 % slower.)
+constexpr unsigned kSlabEmpty = 0xFFFFFFFFu;
+__device__ __forceinline__ int slab_buf(unsigned ex) { return (int)(ex % 3u); }
+__device__ __forceinline__ void slab_put(float* tslab, size_t tile_index, int lane, const f32x4& v) {
+    ((f32x4*)tslab + tile_index * 64)[lane] = v;
 }
-// Sum over the R row blocks (fixed order r = 0..R-1, as the multi-launch kernels) of tile `ht` of column tile `ct`;
-// polls until all R entries carry `tag`.  Returns false on time-out / abort (per wave; the caller agrees over the
+__device__ __forceinline__ void slab_clear(float* tslab, size_t tile_index, int lane) {
+    const float e = __builtin_bit_cast(float, kSlabEmpty);
+    ((f32x4*)tslab + tile_index * 64)[lane] = (f32x4){e, e, e, e};
+}
+// all earlier vector-memory operations of this wave (the slab_clear stores) acknowledged; gfx9 encoding of vmcnt(0) alone
+__device__ __forceinline__ void slab_clears_done() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+// Sum over the R row blocks (fixed order r = 0..R-1, as the multi-launch kernels) of tile `ht` of column tile `ct` in buffer
+// `buf`; polls until all R entries are written.  Returns false on time-out / abort (per wave; the caller agrees over the
 // workgroup at its next barrier).
-__device__ __forceinline__ bool slab_poll_sum(const PersistSync& Y, int par, int C, int R, int HT, int ct, int ht, int lane, unsigned tag, f32x4& zs) {
-    const float* base = Y.tslab + ((((size_t)par * C + ct) * R) * HT) * 512;     // R * HT tiles of 128 f32x4 = 512 floats
+__device__ __forceinline__ bool slab_poll_sum(const PersistSync& Y, int buf, int C, int R, int HT, int ct, int ht, int lane, f32x4& zs) {
+    const float* base = Y.tslab + ((((size_t)buf * C + ct) * R) * HT) * 256;     // R * HT tiles of 64 f32x4 = 256 floats
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
     int spins = 0;
     while (true) {
-        u32x4 e0[kSMaxW], e1[kSMaxW];
+        // compiler barrier: the buffer loads below are plain (non-volatile) reads to the optimiser, which would otherwise be free
+        // to hoist them out of the spin loop (tools/micro/cluster_poll_size.hip showed exactly that happening to a loop without
+        // the atomic abort-flag load further down)
+        __asm__ volatile("" ::: "memory");
+        u32x4 e[kSMaxW];
 #pragma unroll
-        for (int r = 0; r < kSMaxW; ++r) {
-            if (r < R) {
-                const int off = ((r * HT + ht) * 128 + lane) * 16;
-                e0[r] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);            // aux 16 = sc1: agent scope, misses L1
-                e1[r] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 1024, 0, 16);
-            }
-        }
+        for (int r = 0; r < kSMaxW; ++r)
+            if (r < R) e[r] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((r * HT + ht) * 64 + lane) * 16, 0, 16);   // aux 16 = sc1: agent scope, misses L1
         bool ok = true;
 #pragma unroll
-        for (int r = 0; r < kSMaxW; ++r) if (r < R) ok = ok && e0[r][2] == tag && e0[r][3] == tag && e1[r][2] == tag && e1[r][3] == tag;
+        for (int r = 0; r < kSMaxW; ++r)
+            if (r < R) ok = ok && e[r][0] != kSlabEmpty && e[r][1] != kSlabEmpty && e[r][2] != kSlabEmpty && e[r][3] != kSlabEmpty;
         if (__all(ok)) {
-            // (scalar adds on purpose: the vector form `zs += {bitcast(e0.x), bitcast(e0.y), bitcast(e1.x), bitcast(e1.y)}` is
-            //  miscompiled by this toolchain into v_pk_add_f32 with op_sel_hi:[0,0] -- two of the four sums come out wrong;
-            //  tools/micro/cluster_tagged2.hip checks this helper against a direct sum)
+            // (scalar adds on purpose: the vector form `zs += bitcast(e[r])` over buffer-load results was miscompiled by this
+            //  toolchain into v_pk_add_f32 with op_sel_hi:[0,0] in the tagged form of this helper -- two of four sums wrong)
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
             for (int r = 0; r < kSMaxW; ++r) {
                 if (r < R) {
-                    const f32x4 f0 = __builtin_bit_cast(f32x4, e0[r]), f1 = __builtin_bit_cast(f32x4, e1[r]);
-                    s0 += f0[0]; s1 += f0[1]; s2 += f1[0]; s3 += f1[1];
+                    const f32x4 f = __builtin_bit_cast(f32x4, e[r]);
+                    s0 += f[0]; s1 += f[1]; s2 += f[2]; s3 += f[3];
                 }
             }
             zs = (f32x4){s0, s1, s2, s3};
@@ -172,11 +183,11 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
     if (tile_ok) { c_up = ld4(upsrc + co, r0, P.D, upok, upvec); c_k[0] = ld4(k1p + co, r0, P.D, true, vec); }
 
     // phase D: this row block's layer-1 partial of the stage input v -> slab[par], then publish exchange number `ex`
-    auto phase_d = [&](const f32x4& v, int par, unsigned ex) {
+    auto phase_d = [&](const f32x4& v, unsigned ex) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) GL[col * KG + kperm(16 * w + 4 * (lane >> 4) + i)] = (tile_ok && r0 + i < P.D) ? v[i] : 0.f;
         __syncthreads();
-        const size_t tile0 = (((size_t)par * Q.C + ct) * Q.R + rb) * Q.HT;
+        const size_t tile0 = (((size_t)slab_buf(ex) * Q.C + ct) * Q.R + rb) * Q.HT;
         const float* gbp = GL + col * KG + 4 * (lane >> 4);
         f32x4 bg[kSMaxW];
 #pragma unroll
@@ -192,7 +203,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
                     acc1 = mfma16(wD[kb][3], bg[kb][3], acc1);
                 }
             }
-            slab_put(Y.tslab, tile0 + w, lane, acc0 + acc1, Y.seq_base + ex);
+            slab_put(Y.tslab, tile0 + w, lane, acc0 + acc1);
         }
         for (int ht = w + Q.WT; ht < Q.HT; ht += Q.WT) {
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -206,7 +217,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
                     acc1 = mfma16(a[3], bg[kb][3], acc1);
                 }
             }
-            slab_put(Y.tslab, tile0 + ht, lane, acc0 + acc1, Y.seq_base + ex);
+            slab_put(Y.tslab, tile0 + ht, lane, acc0 + acc1);
         }
     };
 
@@ -221,7 +232,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
             if (P.nsave > 0) { st4(R + L.upc() + co, r0, P.D, true, vec, c_up); st4(R + L.k1c() + co, r0, P.D, true, vec, c_k[0]); }
         }
         PSTAMP(2);
-        phase_d(v, 1, 1u);
+        phase_d(v, 1u);
         PSTAMP(3);
     }
 
@@ -234,16 +245,18 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
         const float ts = fmaf(kTsC[s], dt, t);
         float* hdst = R + L.h(s + 1);
         float* kdst = R + L.k(s + 1);
-        const int par = s & 1;
-        const unsigned tag = Y.seq_base + (unsigned)s;
+        const int buf = slab_buf((unsigned)s);              // exchange s: put by the previous stage (START for s = 1)
         // ---- phase A: poll this wave's hidden tile of the R row blocks (the polling load is the data load) ----
         bool dead = false;
         f32x4 zs = {0.f, 0.f, 0.f, 0.f};
-        if (w < Q.HT) dead = !slab_poll_sum(Y, par, Q.C, Q.R, Q.HT, ct, w, lane, tag, zs);
+        if (w < Q.HT) dead = !slab_poll_sum(Y, buf, Q.C, Q.R, Q.HT, ct, w, lane, zs);
         PSTAMP(4 + 5 * (s - 1));
+        // every row block has produced exchange s, hence consumed s - 1: this wave's entries of that buffer can be emptied
+        const size_t tprev0 = (((size_t)slab_buf((unsigned)(s + 2)) * Q.C + ct) * Q.R + rb) * Q.HT;     // (s - 1) % 3 == (s + 2) % 3
         for (int ht = w; ht < Q.HT; ht += Q.WT) {
             f32x4 z = zs;
-            if (ht != w && !dead) dead = !slab_poll_sum(Y, par, Q.C, Q.R, Q.HT, ct, ht, lane, tag, z);
+            if (ht != w && !dead) dead = !slab_poll_sum(Y, buf, Q.C, Q.R, Q.HT, ct, ht, lane, z);
+            if (!dead) slab_clear(Y.tslab, tprev0 + ht, lane);
             const int h0 = 16 * ht + 4 * (lane >> 4);
             // two tanh per instruction (v_pk_fma_f32): the 4 rows of this lane as two pairs
             float pre[4];
@@ -308,6 +321,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
         PSTAMP(6 + 5 * (s - 1));
         // ---- phase C ----
         if constexpr (s < 6) {
+            slab_clears_done();      // (issued two phases ago: nothing to wait for in practice) before this stage's put, see slab_put
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (tile_ok) {
                 st4(kdst + co, r0, P.D, true, vec, kv);
@@ -321,7 +335,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
                 c_k[s] = kv;
             }
             PSTAMP(7 + 5 * (s - 1));
-            phase_d(v, (s + 1) & 1, (unsigned)(s + 1));
+            phase_d(v, (unsigned)(s + 1));
             PSTAMP(8 + 5 * (s - 1));
         } else {
             if (tile_ok) {

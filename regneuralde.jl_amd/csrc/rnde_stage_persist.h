@@ -30,7 +30,7 @@ struct PersistSync {
     int max_spins;          // bound of every polling loop (kPersistMaxSpins; RNDE_PERSIST_SPINS overrides it: the fallback test uses 0)
 };
 
-constexpr int kPersistMaxSpins = 100000;
+constexpr int kPersistMaxSpins = 2000000;   // ~1 s: a hand-off only gives up when its partners are truly not running (another tenant keeping CUs busy merely delays them)
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // ---- slab hand-off: the data is its own validity ---------------------------------------------------------------------------

@@ -182,10 +182,23 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
     for (int j = 0; j < 7; ++j) c_k[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (tile_ok) { c_up = ld4(upsrc + co, r0, P.D, upok, upvec); c_k[0] = ld4(k1p + co, r0, P.D, true, vec); }
 
+    // Loop-invariant addressing of this lane's four rows of its own hidden tile (phase A) and row tile (phase D): the stages are
+    // instruction bound between the hand-offs (7 waves share 4 SIMDs), so nothing that does not change is recomputed per stage.
+    int own_hl[4], own_kind[4], own_gl[4];        // LDS offsets (-1: no slot); kind 0 = hidden unit, 1 = the t row, 2 = the 1 row, 3 = padding
+    size_t own_hd[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int hr = 16 * w + 4 * (lane >> 4) + i;
+        own_kind[i] = hr < P.H ? 0 : (hr == P.H ? 1 : (hr == P.H + 1 ? 2 : 3));
+        own_hl[i] = hr < 16 * Q.K2b ? col * KH + kperm(hr) : -1;
+        own_hd[i] = (size_t)gcol * P.H + hr;
+        own_gl[i] = col * KG + kperm(hr);
+    }
+    if (tid == 0) RED[24] = 0.f;                  // "a wave of this workgroup gave up" (written by any such wave; read after the phase-A barrier)
     // phase D: this row block's layer-1 partial of the stage input v -> slab[par], then publish exchange number `ex`
     auto phase_d = [&](const f32x4& v, unsigned ex) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) GL[col * KG + kperm(16 * w + 4 * (lane >> 4) + i)] = (tile_ok && r0 + i < P.D) ? v[i] : 0.f;
+        for (int i = 0; i < 4; ++i) GL[own_gl[i]] = (tile_ok && r0 + i < P.D) ? v[i] : 0.f;
         __syncthreads();
         const size_t tile0 = (((size_t)slab_buf(ex) * Q.C + ct) * Q.R + rb) * Q.HT;
         const float* gbp = GL + col * KG + 4 * (lane >> 4);
@@ -253,17 +266,31 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
         PSTAMP(4 + 5 * (s - 1));
         // every row block has produced exchange s, hence consumed s - 1: this wave's entries of that buffer can be emptied
         const size_t tprev0 = (((size_t)slab_buf((unsigned)(s + 2)) * Q.C + ct) * Q.R + rb) * Q.HT;     // (s - 1) % 3 == (s + 2) % 3
-        for (int ht = w; ht < Q.HT; ht += Q.WT) {
-            f32x4 z = zs;
-            if (ht != w && !dead) dead = !slab_poll_sum(Y, buf, Q.C, Q.R, Q.HT, ct, ht, lane, z);
+        if (w < Q.HT) {      // this wave's own hidden tile: addressing precomputed (own_*)
+            if (!dead) slab_clear(Y.tslab, tprev0 + w, lane);
+            float pre[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pre[i] = own_kind[i] == 0 ? fmaf(w1t_own[i], ts, zs[i]) + b1_own[i] : 0.f;
+            // two tanh per instruction (v_pk_fma_f32): the 4 rows of this lane as two pairs
+            const f32x2 t01 = tanh_fast2((f32x2){pre[0], pre[1]}), t23 = tanh_fast2((f32x2){pre[2], pre[3]});
+            const float th4[4] = {t01.x, t01.y, t23.x, t23.y};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v = own_kind[i] == 0 ? th4[i] : (own_kind[i] == 1 ? ts : (own_kind[i] == 2 ? 1.f : 0.f));
+                if (rb == 0 && own_kind[i] == 0) hdst[own_hd[i]] = v;
+                if (own_hl[i] >= 0) HL[own_hl[i]] = v;
+            }
+        }
+        for (int ht = w + Q.WT; ht < Q.HT; ht += Q.WT) {      // further hidden tiles (more tiles than waves): the general form
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            if (!dead) dead = !slab_poll_sum(Y, buf, Q.C, Q.R, Q.HT, ct, ht, lane, z);
             if (!dead) slab_clear(Y.tslab, tprev0 + ht, lane);
             const int h0 = 16 * ht + 4 * (lane >> 4);
-            // two tanh per instruction (v_pk_fma_f32): the 4 rows of this lane as two pairs
             float pre[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int hr = h0 + i;
-                pre[i] = (hr < P.H) ? fmaf((ht == w) ? w1t_own[i] : W1t[hr], ts, z[i]) + ((ht == w) ? b1_own[i] : b1[hr]) : 0.f;
+                pre[i] = (hr < P.H) ? fmaf(W1t[hr], ts, z[i]) + b1[hr] : 0.f;
             }
             const f32x2 t01 = tanh_fast2((f32x2){pre[0], pre[1]}), t23 = tanh_fast2((f32x2){pre[2], pre[3]});
             const float th4[4] = {t01.x, t01.y, t23.x, t23.y};
@@ -285,13 +312,9 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
                 if (k >= 16 * Q.HT) HL[c * KH + kperm(k)] = (k == P.H) ? ts : (k == P.H + 1 ? 1.f : 0.f);
             }
         }
-        if (lane == 0) RED[24 + w] = dead ? 1.f : 0.f;
+        if (dead && lane == 0) RED[24] = 1.f;
         __syncthreads();
-        {   // a wave that gave up takes the whole workgroup with it (uniform decision after the barrier)
-            float any = 0.f;
-            for (int q = 0; q < Q.WT; ++q) any += RED[24 + q];
-            if (any != 0.f) { alive = false; return; }
-        }
+        if (RED[24] != 0.f) { alive = false; return; }      // a wave that gave up takes the whole workgroup with it (uniform after the barrier)
         PSTAMP(5 + 5 * (s - 1));
         // ---- phase B ----
         f32x4 kv = {0.f, 0.f, 0.f, 0.f};

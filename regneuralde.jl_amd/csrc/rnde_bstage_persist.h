@@ -87,9 +87,16 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
 #pragma unroll
     for (int i = 0; i < 6; ++i) gbs[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // loop-invariant addressing of this lane's four rows of its own hidden tile / row tile (kperm(16 w + 4 g + i) = 16 w + g + 4 i):
+    // the stages are instruction bound between the hand-offs, nothing that does not change is recomputed per stage
+    const int own_h0 = 16 * w + 4 * (lane >> 4);                       // first of the four hidden rows
+    const int own_zl0 = col * KZ + 16 * w + (lane >> 4);               // ZL slot of row own_h0 (+ 4 i)
+    const int own_gl0 = col * KG + 16 * w + (lane >> 4);               // GL slot of row 16 w + 4 g (+ 4 i)
+    const size_t own_zd0 = (size_t)gcol * P.H + own_h0;                // tape offset of (column, own_h0) in the H x B arrays
+    if (tid == 0) RED[24] = 0.f;                                       // "a wave of this workgroup gave up"
     auto phase_d = [&](const f32x4& v, unsigned ex) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) GL[col * KG + kperm(16 * w + 4 * (lane >> 4) + i)] = tile_ok ? v[i] : 0.f;
+        for (int i = 0; i < 4; ++i) GL[own_gl0 + 4 * i] = tile_ok ? v[i] : 0.f;
         __syncthreads();
         const size_t tile0 = (((size_t)slab_buf(ex) * Q.C + ct) * Q.R + rb) * Q.HT;
         const float* gbp = GL + col * KG + 4 * (lane >> 4);
@@ -256,8 +263,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
         float h_own[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int hr = 16 * w + 4 * (lane >> 4) + i;
-            if (hr < P.H) h_own[i] = (R + L.h(j + 1))[(size_t)gcol * P.H + hr];
+            if (own_h0 + i < P.H) h_own[i] = (R + L.h(j + 1))[own_zd0 + i];
         }
         f32x4 c_ks = {0.f, 0.f, 0.f, 0.f};
         if (tile_ok) c_ks = (j >= 2) ? ld4(R + L.k(j) + co, r0, P.D, true, vec) : ld4(k1p + co, r0, P.D, true, vec);
@@ -273,9 +279,25 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
         float* z1dst = R + L.z1(j + 1);
         // every row block has produced exchange ex, hence consumed ex - 1: this wave's entries of that buffer can be emptied
         const size_t tprev0 = (((size_t)slab_buf(ex + 2u) * Q.C + ct) * Q.R + rb) * Q.HT;     // (ex - 1) % 3 == (ex + 2) % 3
-        for (int ht = w; ht < Q.HT; ht += Q.WT) {
-            f32x4 z = zs;
-            if (ht != w && !dead) dead = !slab_poll_sum(Y, buf, Q.C, Q.R, Q.HT, ct, ht, lane, z);
+        if (w < Q.HT) {      // this wave's own hidden tile (addressing precomputed)
+            if (!dead) slab_clear(Y.tslab, tprev0 + w, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int hr = own_h0 + i;
+                float zv = 0.f;
+                if (hr < P.H) {
+                    const float hv = h_own[i];
+                    zv = zs[i] * (1.f - hv * hv);
+                    if (rb == 0) { z1dst[own_zd0 + i] = zv; tau += w1t_own[i] * zv; }
+                } else if (hr == P.H) {
+                    if (rb == 0) tau += zs[i];
+                }
+                if (hr < 16 * Q.KHb) ZL[own_zl0 + 4 * i] = zv;
+            }
+        }
+        for (int ht = w + Q.WT; ht < Q.HT; ht += Q.WT) {      // further hidden tiles (more tiles than waves): the general form
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            if (!dead) dead = !slab_poll_sum(Y, buf, Q.C, Q.R, Q.HT, ct, ht, lane, z);
             if (!dead) slab_clear(Y.tslab, tprev0 + ht, lane);
             const int h0 = 16 * ht + 4 * (lane >> 4);
 #pragma unroll
@@ -283,9 +305,9 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
                 const int hr = h0 + i;
                 float zv = 0.f;
                 if (hr < P.H) {
-                    const float hv = (ht == w) ? h_own[i] : hsrc[(size_t)gcol * P.H + hr];
+                    const float hv = hsrc[(size_t)gcol * P.H + hr];
                     zv = z[i] * (1.f - hv * hv);
-                    if (rb == 0) { z1dst[(size_t)gcol * P.H + hr] = zv; tau += ((ht == w) ? w1t_own[i] : W1t[hr]) * zv; }
+                    if (rb == 0) { z1dst[(size_t)gcol * P.H + hr] = zv; tau += W1t[hr] * zv; }
                 } else if (hr == P.H) {
                     if (rb == 0) tau += z[i];
                 }
@@ -298,13 +320,9 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
                 if (k >= 16 * Q.HT) ZL[c * KZ + kperm(k)] = 0.f;
             }
         }
-        if (lane == 0) RED[24 + w] = dead ? 1.f : 0.f;
+        if (dead && lane == 0) RED[24] = 1.f;
         __syncthreads();
-        {
-            float any = 0.f;
-            for (int q = 0; q < Q.WT; ++q) any += RED[24 + q];
-            if (any != 0.f) { alive = false; return; }
-        }
+        if (RED[24] != 0.f) { alive = false; return; }      // a wave that gave up takes the whole workgroup with it
         BSTAMP(4 + 5 * (6 - j));
         // ---- phase B ----
         f32x4 gb = {0.f, 0.f, 0.f, 0.f};

@@ -457,8 +457,12 @@ static hipError_t stage_attempt(rnde_node* h, const StageParams& Q, int n, hipSt
         PersistSync Y{h->tslab, h->pabort, h->pxcc, h->persist_spins};
         if (hipError_t e = slab_prepare(h, Q.Bpad16, s); e != hipSuccess) return e;
         const dim3 grid(8 * Q.R * ((Q.C + 7) / 8));   // a column tile's row blocks share blockIdx % 8 (same XCD)
-        if (h->act2) hipLaunchKernelGGL((rnde_stage_attempt_kernel<1>), grid, dim3(64 * Q.WT), h->stage_lds, s, Q, n, Y);
-        else hipLaunchKernelGGL((rnde_stage_attempt_kernel<0>), grid, dim3(64 * Q.WT), h->stage_lds, s, Q, n, Y);
+        const bool fix = Q.WT == 7 && Q.HT == 7 && Q.K2b == 7 && Q.MT == 49 && Q.R == 7 && h->D == 784 && h->H == 100 && getenv("RNDE_STAGE_GENERIC") == nullptr;
+        if (fix) {
+            if (h->act2) hipLaunchKernelGGL((rnde_stage_attempt_kernel<1, 1>), grid, dim3(64 * Q.WT), h->stage_lds, s, Q, n, Y);
+            else hipLaunchKernelGGL((rnde_stage_attempt_kernel<0, 1>), grid, dim3(64 * Q.WT), h->stage_lds, s, Q, n, Y);
+        } else if (h->act2) hipLaunchKernelGGL((rnde_stage_attempt_kernel<1, 0>), grid, dim3(64 * Q.WT), h->stage_lds, s, Q, n, Y);
+        else hipLaunchKernelGGL((rnde_stage_attempt_kernel<0, 0>), grid, dim3(64 * Q.WT), h->stage_lds, s, Q, n, Y);
         return hipGetLastError();
     }
     hipError_t e = launch_stage<SM_START>(h, Q, n, 0, s);

@@ -109,30 +109,35 @@ __device__ __forceinline__ bool slab_poll_sum(const PersistSync& Y, int buf, int
 #define PSTAMP(i) do { } while (0)
 #endif
 
-template <int ACT2>
+// FIX = 1: the geometry of the headline configuration (D = 784 = 49 row tiles, H = 100 -> 7 hidden tiles, 7 waves, 7 row blocks) as
+// compile-time constants: the stages are instruction bound and full of wave-uniform conditions on these numbers.  FIX = 0: any geometry.
+template <int ACT2, int FIX>
 __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const StageParams Q, const int n, const PersistSync Y) {
     const StepParams& P = Q.F;
+    const int gWT = FIX ? 7 : Q.WT, gHT = FIX ? 7 : Q.HT, gK2b = FIX ? 7 : Q.K2b, gMT = FIX ? 49 : Q.MT, gR = FIX ? 7 : Q.R;
+    const int gD = FIX ? 784 : P.D, gH = FIX ? 100 : P.H;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int KH = 16 * Q.K2b + 4, KG = 16 * Q.WT + 4;
+    const int KH = 16 * gK2b + 4, KG = 16 * gWT + 4;
     float* HL = smem;
     float* GL = HL + kSCB * KH;
     float* RED = GL + kSCB * KG;         // [32]; RED[24..31] = per-wave "gave up" flags of the hand-off
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (FIX) __builtin_assume(w >= 0 && w < 7);
     // Workgroup -> (row block, column tile): the R row blocks of a column tile must sit on ONE XCD (they talk through its
     // L2).  Dispatch is round-robin, XCD = blockIdx % 8, so a tile's members are given block indices that agree mod 8;
     // the grid is 8 * R * ceil(C / 8) and the surplus workgroups (ct >= C) leave at once.
-    const int rb = (blockIdx.x >> 3) % Q.R, ct = 8 * ((blockIdx.x >> 3) / Q.R) + (blockIdx.x & 7);
+    const int rb = (blockIdx.x >> 3) % gR, ct = 8 * ((blockIdx.x >> 3) / gR) + (blockIdx.x & 7);
     if (ct >= Q.C) return;
     const int wg = rb * Q.C + ct;        // logical workgroup id (index of the per-workgroup partials, as in rnde_stage_kernel)
     const int col = lane & 15, gcol = ct * kSCB + col;
     const bool colok = gcol < P.B;
-    const bool vec = (P.D & 3) == 0;
+    const bool vec = (gD & 3) == 0;
     const bool writer = (wg == 0 && tid == 0);
-    const int T = rb * Q.WT + w;
+    const int T = rb * gWT + w;
     const int r0 = 16 * T + 4 * (lane >> 4);
-    const bool tile_ok = T < Q.MT;
-    const RecLayout L{(long long)P.D * P.Bpad, (long long)P.H * P.Bpad};
+    const bool tile_ok = T < gMT;
+    const RecLayout L{(long long)gD * P.Bpad, (long long)gH * P.Bpad};
     if (tid == 0) Y.xcc[wg] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15;   // HW_REG_XCC_ID
 
     PSTAMP(0);
@@ -140,18 +145,18 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
     f32x4 wB[kSMaxHT], wD[kSMaxW];
 #pragma unroll
     for (int kb = 0; kb < kSMaxHT; ++kb)
-        if (kb < Q.K2b && tile_ok) wB[kb] = Q.pwB[((size_t)T * Q.K2b + kb) * 64 + lane];
+        if (kb < gK2b && tile_ok) wB[kb] = Q.pwB[((size_t)T * gK2b + kb) * 64 + lane];
 #pragma unroll
     for (int kb = 0; kb < kSMaxW; ++kb)
-        if (kb < Q.WT && w < Q.HT && rb * Q.WT + kb < Q.MT) wD[kb] = Q.pwD[((size_t)w * Q.MT + rb * Q.WT + kb) * 64 + lane];
+        if (kb < gWT && w < gHT && rb * gWT + kb < gMT) wD[kb] = Q.pwD[((size_t)w * gMT + rb * gWT + kb) * 64 + lane];
     float w1t_own[4] = {0.f, 0.f, 0.f, 0.f}, b1_own[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int hr = 16 * w + 4 * (lane >> 4) + i;
-        if (hr < P.H) { w1t_own[i] = Q.p[(size_t)P.H * P.D + hr]; b1_own[i] = Q.p[(size_t)P.H * (P.D + 1) + hr]; }
+        if (hr < gH) { w1t_own[i] = Q.p[(size_t)gH * gD + hr]; b1_own[i] = Q.p[(size_t)gH * (gD + 1) + hr]; }
     }
-    const float* W1t = Q.p + (size_t)P.H * P.D;
-    const float* b1 = Q.p + (size_t)P.H * (P.D + 1);
+    const float* W1t = Q.p + (size_t)gH * gD;
+    const float* b1 = Q.p + (size_t)gH * (gD + 1);
 
     // ---- controller (identical to SM_START) ----
     const StepState S = advance_state(P, n, lane, writer, &P.ctl[n & 1]);
@@ -159,12 +164,12 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
         const int lo = (n == 0) ? 0 : P.ctl[(n - 1) & 1].next_save, hi = S.next_save;
         if (hi > lo && tile_ok) {
             if (n == 0) {
-                st_tile(P.sv_out + (size_t)gcol * P.nsave * P.D, r0, P.D, colok, vec, ld_tile(P.x + (size_t)gcol * P.D, r0, P.D, colok, P.xvec != 0));
+                st_tile(P.sv_out + (size_t)gcol * P.nsave * gD, r0, gD, colok, vec, ld_tile(P.x + (size_t)gcol * gD, r0, gD, colok, P.xvec != 0));
             } else {
                 const StepState pv = P.ctl[(n - 1) & 1];
                 const float dtp_ = (P.t1 - pv.t < pv.dtp) ? (P.t1 - pv.t) : pv.dtp;
                 const float* Rp = P.arena + (long long)S.live * P.rec_stride;
-                dense_points(P, L, Rp, pv.t, dtp_, S.t, lo, hi, (size_t)gcol * P.D, gcol, r0, colok, vec);
+                dense_points(P, L, Rp, pv.t, dtp_, S.t, lo, hi, (size_t)gcol * gD, gcol, r0, colok, vec);
             }
         }
     }
@@ -176,11 +181,11 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
     float* R = P.arena + (long long)rec * P.rec_stride;
     const float* upsrc = P.x; const float* k1p = P.f0; bool upok = colok, upvec = P.xvec != 0;
     if (live >= 0) { const float* Rl = P.arena + (long long)live * P.rec_stride; upsrc = Rl + L.unew(); k1p = Rl + L.k(7); upok = true; upvec = vec; }
-    const size_t co = (size_t)gcol * P.D;
+    const size_t co = (size_t)gcol * gD;
     f32x4 c_up = {0.f, 0.f, 0.f, 0.f}, c_un = {0.f, 0.f, 0.f, 0.f}, c_k[7];
 #pragma unroll
     for (int j = 0; j < 7; ++j) c_k[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (tile_ok) { c_up = ld4(upsrc + co, r0, P.D, upok, upvec); c_k[0] = ld4(k1p + co, r0, P.D, true, vec); }
+    if (tile_ok) { c_up = ld4(upsrc + co, r0, gD, upok, upvec); c_k[0] = ld4(k1p + co, r0, gD, true, vec); }
 
     // Loop-invariant addressing of this lane's four rows of its own hidden tile (phase A) and row tile (phase D): the stages are
     // instruction bound between the hand-offs (7 waves share 4 SIMDs), so nothing that does not change is recomputed per stage.
@@ -189,27 +194,27 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int hr = 16 * w + 4 * (lane >> 4) + i;
-        own_kind[i] = hr < P.H ? 0 : (hr == P.H ? 1 : (hr == P.H + 1 ? 2 : 3));
-        own_hl[i] = hr < 16 * Q.K2b ? col * KH + kperm(hr) : -1;
-        own_hd[i] = (size_t)gcol * P.H + hr;
+        own_kind[i] = hr < gH ? 0 : (hr == gH ? 1 : (hr == gH + 1 ? 2 : 3));
+        own_hl[i] = hr < 16 * gK2b ? col * KH + kperm(hr) : -1;
+        own_hd[i] = (size_t)gcol * gH + hr;
         own_gl[i] = col * KG + kperm(hr);
     }
     if (tid == 0) RED[24] = 0.f;                  // "a wave of this workgroup gave up" (written by any such wave; read after the phase-A barrier)
     // phase D: this row block's layer-1 partial of the stage input v -> slab[par], then publish exchange number `ex`
     auto phase_d = [&](const f32x4& v, unsigned ex) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) GL[own_gl[i]] = (tile_ok && r0 + i < P.D) ? v[i] : 0.f;
+        for (int i = 0; i < 4; ++i) GL[own_gl[i]] = (tile_ok && r0 + i < gD) ? v[i] : 0.f;
         __syncthreads();
-        const size_t tile0 = (((size_t)slab_buf(ex) * Q.C + ct) * Q.R + rb) * Q.HT;
+        const size_t tile0 = (((size_t)slab_buf(ex) * Q.C + ct) * gR + rb) * gHT;
         const float* gbp = GL + col * KG + 4 * (lane >> 4);
         f32x4 bg[kSMaxW];
 #pragma unroll
-        for (int kb = 0; kb < kSMaxW; ++kb) if (kb < Q.WT) bg[kb] = *(const f32x4*)(gbp + 16 * kb);
-        if (w < Q.HT) {
+        for (int kb = 0; kb < kSMaxW; ++kb) if (kb < gWT) bg[kb] = *(const f32x4*)(gbp + 16 * kb);
+        if (w < gHT) {
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kb = 0; kb < kSMaxW; ++kb) {
-                if (kb < Q.WT && rb * Q.WT + kb < Q.MT) {
+                if (kb < gWT && rb * gWT + kb < gMT) {
                     acc0 = mfma16(wD[kb][0], bg[kb][0], acc0);
                     acc1 = mfma16(wD[kb][1], bg[kb][1], acc1);
                     acc0 = mfma16(wD[kb][2], bg[kb][2], acc0);
@@ -218,12 +223,12 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
             }
             slab_put(Y.tslab, tile0 + w, lane, acc0 + acc1);
         }
-        for (int ht = w + Q.WT; ht < Q.HT; ht += Q.WT) {
+        for (int ht = w + gWT; ht < gHT; ht += gWT) {
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kb = 0; kb < kSMaxW; ++kb) {
-                if (kb < Q.WT && rb * Q.WT + kb < Q.MT) {
-                    const f32x4 a = Q.pwD[((size_t)ht * Q.MT + rb * Q.WT + kb) * 64 + lane];
+                if (kb < gWT && rb * gWT + kb < gMT) {
+                    const f32x4 a = Q.pwD[((size_t)ht * gMT + rb * gWT + kb) * 64 + lane];
                     acc0 = mfma16(a[0], bg[kb][0], acc0);
                     acc1 = mfma16(a[1], bg[kb][1], acc1);
                     acc0 = mfma16(a[2], bg[kb][2], acc0);
@@ -239,10 +244,10 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (tile_ok) {
             v = fma4(dt, kFwdShift[0][0] * c_k[0], c_up);
-            if (P.tape) st4(R + L.g(2) + co, r0, P.D, true, vec, v);
+            if (P.tape) st4(R + L.g(2) + co, r0, gD, true, vec, v);
             // (uprev, k1) copies: only the dense output of saveat reads them here (the multi-launch STAGE kernels also do; streaming
             //  tape stores with `nt` were measured: no difference)
-            if (P.nsave > 0) { st4(R + L.upc() + co, r0, P.D, true, vec, c_up); st4(R + L.k1c() + co, r0, P.D, true, vec, c_k[0]); }
+            if (P.nsave > 0) { st4(R + L.upc() + co, r0, gD, true, vec, c_up); st4(R + L.k1c() + co, r0, gD, true, vec, c_k[0]); }
         }
         PSTAMP(2);
         phase_d(v, 1u);
@@ -262,11 +267,11 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
         // ---- phase A: poll this wave's hidden tile of the R row blocks (the polling load is the data load) ----
         bool dead = false;
         f32x4 zs = {0.f, 0.f, 0.f, 0.f};
-        if (w < Q.HT) dead = !slab_poll_sum(Y, buf, Q.C, Q.R, Q.HT, ct, w, lane, zs);
+        if (w < gHT) dead = !slab_poll_sum(Y, buf, Q.C, gR, gHT, ct, w, lane, zs);
         PSTAMP(4 + 5 * (s - 1));
         // every row block has produced exchange s, hence consumed s - 1: this wave's entries of that buffer can be emptied
-        const size_t tprev0 = (((size_t)slab_buf((unsigned)(s + 2)) * Q.C + ct) * Q.R + rb) * Q.HT;     // (s - 1) % 3 == (s + 2) % 3
-        if (w < Q.HT) {      // this wave's own hidden tile: addressing precomputed (own_*)
+        const size_t tprev0 = (((size_t)slab_buf((unsigned)(s + 2)) * Q.C + ct) * gR + rb) * gHT;     // (s - 1) % 3 == (s + 2) % 3
+        if (w < gHT) {      // this wave's own hidden tile: addressing precomputed (own_*)
             if (!dead) slab_clear(Y.tslab, tprev0 + w, lane);
             float pre[4];
 #pragma unroll
@@ -281,16 +286,16 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
                 if (own_hl[i] >= 0) HL[own_hl[i]] = v;
             }
         }
-        for (int ht = w + Q.WT; ht < Q.HT; ht += Q.WT) {      // further hidden tiles (more tiles than waves): the general form
+        for (int ht = w + gWT; ht < gHT; ht += gWT) {      // further hidden tiles (more tiles than waves): the general form
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            if (!dead) dead = !slab_poll_sum(Y, buf, Q.C, Q.R, Q.HT, ct, ht, lane, z);
+            if (!dead) dead = !slab_poll_sum(Y, buf, Q.C, gR, gHT, ct, ht, lane, z);
             if (!dead) slab_clear(Y.tslab, tprev0 + ht, lane);
             const int h0 = 16 * ht + 4 * (lane >> 4);
             float pre[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int hr = h0 + i;
-                pre[i] = (hr < P.H) ? fmaf(W1t[hr], ts, z[i]) + b1[hr] : 0.f;
+                pre[i] = (hr < gH) ? fmaf(W1t[hr], ts, z[i]) + b1[hr] : 0.f;
             }
             const f32x2 t01 = tanh_fast2((f32x2){pre[0], pre[1]}), t23 = tanh_fast2((f32x2){pre[2], pre[3]});
             const float th4[4] = {t01.x, t01.y, t23.x, t23.y};
@@ -298,18 +303,18 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
             for (int i = 0; i < 4; ++i) {
                 const int hr = h0 + i;
                 float v = 0.f;
-                if (hr < P.H) {
+                if (hr < gH) {
                     v = th4[i];
-                    if (rb == 0) hdst[(size_t)gcol * P.H + hr] = v;
-                } else if (hr == P.H) v = ts;
-                else if (hr == P.H + 1) v = 1.f;
-                if (hr < 16 * Q.K2b) HL[col * KH + kperm(hr)] = v;
+                    if (rb == 0) hdst[(size_t)gcol * gH + hr] = v;
+                } else if (hr == gH) v = ts;
+                else if (hr == gH + 1) v = 1.f;
+                if (hr < 16 * gK2b) HL[col * KH + kperm(hr)] = v;
             }
         }
-        if (Q.K2b > Q.HT) {
-            for (int i = tid; i < kSCB * 16 * Q.K2b; i += blockDim.x) {
-                const int c = i / (16 * Q.K2b), k = i - c * 16 * Q.K2b;
-                if (k >= 16 * Q.HT) HL[c * KH + kperm(k)] = (k == P.H) ? ts : (k == P.H + 1 ? 1.f : 0.f);
+        if (gK2b > gHT) {
+            for (int i = tid; i < kSCB * 16 * gK2b; i += blockDim.x) {
+                const int c = i / (16 * gK2b), k = i - c * 16 * gK2b;
+                if (k >= 16 * gHT) HL[c * KH + kperm(k)] = (k == gH) ? ts : (k == gH + 1 ? 1.f : 0.f);
             }
         }
         if (dead && lane == 0) RED[24] = 1.f;
@@ -323,10 +328,10 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
             const float* hb = HL + col * KH + 4 * (lane >> 4);
             f32x4 bf[kSMaxHT];
 #pragma unroll
-            for (int kb = 0; kb < kSMaxHT; ++kb) if (kb < Q.K2b) bf[kb] = *(const f32x4*)(hb + 16 * kb);
+            for (int kb = 0; kb < kSMaxHT; ++kb) if (kb < gK2b) bf[kb] = *(const f32x4*)(hb + 16 * kb);
 #pragma unroll
             for (int kb = 0; kb < kSMaxHT; ++kb) {
-                if (kb < Q.K2b) {
+                if (kb < gK2b) {
                     acc0 = mfma16(wB[kb][0], bf[kb][0], acc0);
                     acc1 = mfma16(wB[kb][1], bf[kb][1], acc1);
                     acc0 = mfma16(wB[kb][2], bf[kb][2], acc0);
@@ -339,7 +344,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
                 kv = (f32x4){a01.x, a01.y, a23.x, a23.y};
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) kv[i] = (r0 + i < P.D) ? kv[i] : 0.f;
+            for (int i = 0; i < 4; ++i) kv[i] = (r0 + i < gD) ? kv[i] : 0.f;
         }
         PSTAMP(6 + 5 * (s - 1));
         // ---- phase C ----
@@ -347,14 +352,14 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
             slab_clears_done();      // (issued two phases ago: nothing to wait for in practice) before this stage's put, see slab_put
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (tile_ok) {
-                st4(kdst + co, r0, P.D, true, vec, kv);
+                st4(kdst + co, r0, gD, true, vec, kv);
                 f32x4 acc = tsA_rt(s + 1, 0) * c_k[0];
 #pragma unroll
                 for (int j = 1; j < 6; ++j) if (j < s) acc = fma4(tsA_rt(s + 1, j), c_k[j], acc);
                 acc = fma4(tsA_rt(s + 1, s), kv, acc);
                 v = fma4(dt, acc, c_up);
-                if (s == 5) { st4(R + L.unew() + co, r0, P.D, true, vec, v); c_un = v; }
-                else if (P.tape) st4(R + L.g(s + 2) + co, r0, P.D, true, vec, v);
+                if (s == 5) { st4(R + L.unew() + co, r0, gD, true, vec, v); c_un = v; }
+                else if (P.tape) st4(R + L.g(s + 2) + co, r0, gD, true, vec, v);
                 c_k[s] = kv;
             }
             PSTAMP(7 + 5 * (s - 1));
@@ -362,7 +367,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
             PSTAMP(8 + 5 * (s - 1));
         } else {
             if (tile_ok) {
-                st4(kdst + co, r0, P.D, true, vec, kv);
+                st4(kdst + co, r0, gD, true, vec, kv);
                 const f32x4 up = c_up, un = c_un;
                 f32x4 acc = kTsBt[0] * c_k[0];
 #pragma unroll
@@ -383,7 +388,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
                         g6 = fma4(dt, g6, up);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            if (r0 + i < P.D) {
+                            if (r0 + i < gD) {
                                 const float d1 = kv[i] - c_k[5][i], d2 = un[i] - g6[i];
                                 part1 += d1 * d1; part2 += d2 * d2;
                             }
@@ -407,7 +412,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
     __syncthreads();
     if (tid == 0) {
         float sa = 0.f, sb = 0.f, sc = 0.f;
-        for (int i = 0; i < Q.WT; ++i) { sa += RED[i]; sb += RED[8 + i]; sc += RED[16 + i]; }
+        for (int i = 0; i < gWT; ++i) { sa += RED[i]; sb += RED[8 + i]; sc += RED[16 + i]; }
         float* ep = P.errpart + (size_t)(n & 1) * 3 * P.nwg;
         ep[wg] = sa; ep[P.nwg + wg] = sb; ep[2 * P.nwg + wg] = sc;
     }

@@ -20,53 +20,57 @@ namespace rnde {
 #define BSTAMP(i) do { } while (0)
 #endif
 
-template <int ACT2>
+// FIX = 1: the headline geometry (D = 784, H = 100, 7 waves, 7 row blocks) as compile-time constants, see rnde_stage_attempt_kernel
+template <int ACT2, int FIX>
 __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const BStageParams Q, const int n, const StepMeta m, const float eig_c1,
                                                                           const float eig_c2, const int sv_lo, const int sv_hi, const PersistSync Y, const double qo_host) {
 #pragma clang fp contract(off)
     const BwdParams& Bq = Q.B;
     const StepParams& P = Bq.F;
+    const int gWT = FIX ? 7 : Q.WT, gHT = FIX ? 7 : Q.HT, gKHb = FIX ? 7 : Q.KHb, gMT = FIX ? 49 : Q.MT, gR = FIX ? 7 : Q.R;
+    const int gD = FIX ? 784 : P.D, gH = FIX ? 100 : P.H;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int KZ = 16 * Q.KHb + 4, KG = 16 * Q.WT + 4;
+    const int KZ = 16 * gKHb + 4, KG = 16 * gWT + 4;
     float* ZL = smem;
     float* GL = ZL + kSCB * KZ;
     float* RED = GL + kSCB * KG;         // [32]; RED[24..31]: per-wave "gave up" flags of the hand-off
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rb = (blockIdx.x >> 3) % Q.R, ct = 8 * ((blockIdx.x >> 3) / Q.R) + (blockIdx.x & 7);   // see rnde_stage_persist.h
+    if (FIX) __builtin_assume(w >= 0 && w < 7);
+    const int rb = (blockIdx.x >> 3) % gR, ct = 8 * ((blockIdx.x >> 3) / gR) + (blockIdx.x & 7);   // see rnde_stage_persist.h
     if (ct >= Q.C) return;
     const int wg = rb * Q.C + ct;
     const int col = lane & 15, gcol = ct * kSCB + col;
     const bool colok = gcol < P.B;
-    const bool vec = (P.D & 3) == 0;
+    const bool vec = (gD & 3) == 0;
     const bool writer = (wg == 0 && tid == 0);
-    const int T = rb * Q.WT + w;
+    const int T = rb * gWT + w;
     const int r0 = 16 * T + 4 * (lane >> 4);
-    const bool tile_ok = T < Q.MT;
-    const long long A = (long long)P.D * P.Bpad;
-    const RecLayout L{A, (long long)P.H * P.Bpad};
+    const bool tile_ok = T < gMT;
+    const long long A = (long long)gD * P.Bpad;
+    const RecLayout L{A, (long long)gH * P.Bpad};
     const bool first = (n == Bq.n_att - 1);
-    const size_t co = (size_t)gcol * P.D;
+    const size_t co = (size_t)gcol * gD;
     if (tid == 0) Y.xcc[wg] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15;
 
     BSTAMP(0);
     f32x4 wB[kSMaxHT], wD[kSMaxW];
 #pragma unroll
     for (int kb = 0; kb < kSMaxHT; ++kb)
-        if (kb < Q.KHb && tile_ok) wB[kb] = Q.pwBt[((size_t)T * Q.KHb + kb) * 64 + lane];
+        if (kb < gKHb && tile_ok) wB[kb] = Q.pwBt[((size_t)T * gKHb + kb) * 64 + lane];
 #pragma unroll
     for (int kb = 0; kb < kSMaxW; ++kb)
-        if (kb < Q.WT && w < Q.HT && rb * Q.WT + kb < Q.MT) wD[kb] = Q.pwDt[((size_t)w * Q.MT + rb * Q.WT + kb) * 64 + lane];
+        if (kb < gWT && w < gHT && rb * gWT + kb < gMT) wD[kb] = Q.pwDt[((size_t)w * gMT + rb * gWT + kb) * 64 + lane];
     BSTAMP(43);
     float* R = P.arena + (long long)m.rec * P.rec_stride;
     float w1t_own[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int hr = 16 * w + 4 * (lane >> 4) + i;
-        if (hr < P.H) w1t_own[i] = Q.p[(size_t)P.H * P.D + hr];
+        if (hr < gH) w1t_own[i] = Q.p[(size_t)gH * gD + hr];
     }
     BSTAMP(44);
-    const float* W1t = Q.p + (size_t)P.H * P.D;
+    const float* W1t = Q.p + (size_t)gH * gD;
     const bool accepted = (m.flags & F_ACCEPT) != 0;
     const float dt = m.dt;
     const float* upsrc = P.x; const float* k1p = P.f0; bool upok = colok, upvec = P.xvec != 0;
@@ -92,22 +96,22 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
     const int own_h0 = 16 * w + 4 * (lane >> 4);                       // first of the four hidden rows
     const int own_zl0 = col * KZ + 16 * w + (lane >> 4);               // ZL slot of row own_h0 (+ 4 i)
     const int own_gl0 = col * KG + 16 * w + (lane >> 4);               // GL slot of row 16 w + 4 g (+ 4 i)
-    const size_t own_zd0 = (size_t)gcol * P.H + own_h0;                // tape offset of (column, own_h0) in the H x B arrays
+    const size_t own_zd0 = (size_t)gcol * gH + own_h0;                // tape offset of (column, own_h0) in the H x B arrays
     if (tid == 0) RED[24] = 0.f;                                       // "a wave of this workgroup gave up"
     auto phase_d = [&](const f32x4& v, unsigned ex) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) GL[own_gl0 + 4 * i] = tile_ok ? v[i] : 0.f;
         __syncthreads();
-        const size_t tile0 = (((size_t)slab_buf(ex) * Q.C + ct) * Q.R + rb) * Q.HT;
+        const size_t tile0 = (((size_t)slab_buf(ex) * Q.C + ct) * gR + rb) * gHT;
         const float* gbp = GL + col * KG + 4 * (lane >> 4);
         f32x4 bg[kSMaxW];
 #pragma unroll
-        for (int kb = 0; kb < kSMaxW; ++kb) if (kb < Q.WT) bg[kb] = *(const f32x4*)(gbp + 16 * kb);
-        if (w < Q.HT) {
+        for (int kb = 0; kb < kSMaxW; ++kb) if (kb < gWT) bg[kb] = *(const f32x4*)(gbp + 16 * kb);
+        if (w < gHT) {
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kb = 0; kb < kSMaxW; ++kb) {
-                if (kb < Q.WT && rb * Q.WT + kb < Q.MT) {
+                if (kb < gWT && rb * gWT + kb < gMT) {
                     acc0 = mfma16(wD[kb][0], bg[kb][0], acc0);
                     acc1 = mfma16(wD[kb][1], bg[kb][1], acc1);
                     acc0 = mfma16(wD[kb][2], bg[kb][2], acc0);
@@ -116,12 +120,12 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
             }
             slab_put(Y.tslab, tile0 + w, lane, acc0 + acc1);
         }
-        for (int ht = w + Q.WT; ht < Q.HT; ht += Q.WT) {
+        for (int ht = w + gWT; ht < gHT; ht += gWT) {
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kb = 0; kb < kSMaxW; ++kb) {
-                if (kb < Q.WT && rb * Q.WT + kb < Q.MT) {
-                    const f32x4 a = Q.pwDt[((size_t)ht * Q.MT + rb * Q.WT + kb) * 64 + lane];
+                if (kb < gWT && rb * gWT + kb < gMT) {
+                    const f32x4 a = Q.pwDt[((size_t)ht * gMT + rb * gWT + kb) * 64 + lane];
                     acc0 = mfma16(a[0], bg[kb][0], acc0);
                     acc1 = mfma16(a[1], bg[kb][1], acc1);
                     acc0 = mfma16(a[2], bg[kb][2], acc0);
@@ -141,11 +145,11 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
 #pragma unroll
         for (int s = 0; s < 7; ++s) kq[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (tile_ok) {
-            upv = ld4(upsrc + co, r0, P.D, upok, upvec);
-            unv = ld4(R + L.unew() + co, r0, P.D, true, vec);
-            kq[0] = ld4(k1p + co, r0, P.D, true, vec);
+            upv = ld4(upsrc + co, r0, gD, upok, upvec);
+            unv = ld4(R + L.unew() + co, r0, gD, true, vec);
+            kq[0] = ld4(k1p + co, r0, gD, true, vec);
 #pragma unroll
-            for (int s = 2; s <= 7; ++s) kq[s - 1] = ld4(R + L.k(s) + co, r0, P.D, true, vec);
+            for (int s = 2; s <= 7; ++s) kq[s - 1] = ld4(R + L.k(s) + co, r0, gD, true, vec);
         }
         __builtin_amdgcn_sched_barrier(0);   // keep these requests in front of the scalar chain (the scheduler sinks them to their uses otherwise)
         BSTAMP(40);
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
         BSTAMP(41);
         float coef;
         {
-            const double N = (double)P.D * (double)P.B;
+            const double N = (double)gD * (double)P.B;
             double eb = 0, dtb_pre = 0, q11b = 0, qb = 0, qoldb_in = 0;
             if (accepted) {
                 const bool err_term = Bq.reg_kind == 1 || (Bq.reg_kind == 3 && !(m.eest * dt == 0.f));
@@ -188,8 +192,8 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
             f32x4 uin = {0.f, 0.f, 0.f, 0.f}, k1in = {0.f, 0.f, 0.f, 0.f};
             const bool sv_mode = Q.nsave > 0;
             if (accepted) {
-                if (!first) { uin = ld4(Bq.U + co, r0, P.D, true, vec); k1in = ld4(Bq.K1 + co, r0, P.D, true, vec); }
-                else if (!sv_mode) uin = ld4(Bq.ubar + co, r0, P.D, colok, false);
+                if (!first) { uin = ld4(Bq.U + co, r0, gD, true, vec); k1in = ld4(Bq.K1 + co, r0, gD, true, vec); }
+                else if (!sv_mode) uin = ld4(Bq.ubar + co, r0, gD, colok, false);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
                 const float tnew = m.t + dt;
                 for (int idx = sv_lo; idx < sv_hi; ++idx) {
                     const float ts = Q.sv_t[idx];
-                    const f32x4 ub = ld4(Q.sv_ubar + ((size_t)gcol * Q.nsave + idx) * P.D, r0, P.D, colok, vec);
+                    const f32x4 ub = ld4(Q.sv_ubar + ((size_t)gcol * Q.nsave + idx) * gD, r0, gD, colok, vec);
                     if (ts == tnew) { unb += ub; continue; }
                     const float th = (ts - m.t) / dt;
                     float bw[7], dbw[7];
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
             if (has_eig) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const bool ok = colok && (r0 + i < P.D);
+                    const bool ok = colok && (r0 + i < gD);
                     const float d1 = k7[i] - k6[i], d2 = unv[i] - (upv[i] + dt * g6[i]);
                     kb7[i] += ok ? eig_c1 * d1 : 0.f;
                     exk[i] = ok ? -eig_c1 * d1 : 0.f;
@@ -243,8 +247,8 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = (r0 + i < P.D) ? (ACT2 ? kb7[i] * (1.f - k7[i] * k7[i]) : kb7[i]) : 0.f;
-            st4(R + L.k(7) + co, r0, P.D, true, vec, v);
+            for (int i = 0; i < 4; ++i) v[i] = (r0 + i < gD) ? (ACT2 ? kb7[i] * (1.f - k7[i] * k7[i]) : kb7[i]) : 0.f;
+            st4(R + L.k(7) + co, r0, gD, true, vec, v);
         }
         if (!colok) { tau = 0.f; exdt = 0.f; }
         pS[0] = S; pT[0] = tau; pX[0] = exdt;
@@ -263,61 +267,61 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
         float h_own[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (own_h0 + i < P.H) h_own[i] = (R + L.h(j + 1))[own_zd0 + i];
+            if (own_h0 + i < gH) h_own[i] = (R + L.h(j + 1))[own_zd0 + i];
         }
         f32x4 c_ks = {0.f, 0.f, 0.f, 0.f};
-        if (tile_ok) c_ks = (j >= 2) ? ld4(R + L.k(j) + co, r0, P.D, true, vec) : ld4(k1p + co, r0, P.D, true, vec);
+        if (tile_ok) c_ks = (j >= 2) ? ld4(R + L.k(j) + co, r0, gD, true, vec) : ld4(k1p + co, r0, gD, true, vec);
         float S = 0.f, tau = 0.f;
         // ---- phase A: poll this wave's hidden tile of the R row blocks (the polling load is the data load) ----
         constexpr unsigned ex = (unsigned)(7 - j);          // the exchange this stage consumes (1 = START's put)
         const int buf = slab_buf(ex);
         bool dead = false;
         f32x4 zs = {0.f, 0.f, 0.f, 0.f};
-        if (w < Q.HT) dead = !slab_poll_sum(Y, buf, Q.C, Q.R, Q.HT, ct, w, lane, zs);
+        if (w < gHT) dead = !slab_poll_sum(Y, buf, Q.C, gR, gHT, ct, w, lane, zs);
         BSTAMP(3 + 5 * (6 - j));
         const float* hsrc = R + L.h(j + 1);
         float* z1dst = R + L.z1(j + 1);
         // every row block has produced exchange ex, hence consumed ex - 1: this wave's entries of that buffer can be emptied
-        const size_t tprev0 = (((size_t)slab_buf(ex + 2u) * Q.C + ct) * Q.R + rb) * Q.HT;     // (ex - 1) % 3 == (ex + 2) % 3
-        if (w < Q.HT) {      // this wave's own hidden tile (addressing precomputed)
+        const size_t tprev0 = (((size_t)slab_buf(ex + 2u) * Q.C + ct) * gR + rb) * gHT;     // (ex - 1) % 3 == (ex + 2) % 3
+        if (w < gHT) {      // this wave's own hidden tile (addressing precomputed)
             if (!dead) slab_clear(Y.tslab, tprev0 + w, lane);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int hr = own_h0 + i;
                 float zv = 0.f;
-                if (hr < P.H) {
+                if (hr < gH) {
                     const float hv = h_own[i];
                     zv = zs[i] * (1.f - hv * hv);
                     if (rb == 0) { z1dst[own_zd0 + i] = zv; tau += w1t_own[i] * zv; }
-                } else if (hr == P.H) {
+                } else if (hr == gH) {
                     if (rb == 0) tau += zs[i];
                 }
-                if (hr < 16 * Q.KHb) ZL[own_zl0 + 4 * i] = zv;
+                if (hr < 16 * gKHb) ZL[own_zl0 + 4 * i] = zv;
             }
         }
-        for (int ht = w + Q.WT; ht < Q.HT; ht += Q.WT) {      // further hidden tiles (more tiles than waves): the general form
+        for (int ht = w + gWT; ht < gHT; ht += gWT) {      // further hidden tiles (more tiles than waves): the general form
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            if (!dead) dead = !slab_poll_sum(Y, buf, Q.C, Q.R, Q.HT, ct, ht, lane, z);
+            if (!dead) dead = !slab_poll_sum(Y, buf, Q.C, gR, gHT, ct, ht, lane, z);
             if (!dead) slab_clear(Y.tslab, tprev0 + ht, lane);
             const int h0 = 16 * ht + 4 * (lane >> 4);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int hr = h0 + i;
                 float zv = 0.f;
-                if (hr < P.H) {
-                    const float hv = hsrc[(size_t)gcol * P.H + hr];
+                if (hr < gH) {
+                    const float hv = hsrc[(size_t)gcol * gH + hr];
                     zv = z[i] * (1.f - hv * hv);
-                    if (rb == 0) { z1dst[(size_t)gcol * P.H + hr] = zv; tau += W1t[hr] * zv; }
-                } else if (hr == P.H) {
+                    if (rb == 0) { z1dst[(size_t)gcol * gH + hr] = zv; tau += W1t[hr] * zv; }
+                } else if (hr == gH) {
                     if (rb == 0) tau += z[i];
                 }
-                if (hr < 16 * Q.KHb) ZL[col * KZ + kperm(hr)] = zv;
+                if (hr < 16 * gKHb) ZL[col * KZ + kperm(hr)] = zv;
             }
         }
-        if (Q.KHb > Q.HT) {
-            for (int i = tid; i < kSCB * 16 * Q.KHb; i += blockDim.x) {
-                const int c = i / (16 * Q.KHb), k = i - c * 16 * Q.KHb;
-                if (k >= 16 * Q.HT) ZL[c * KZ + kperm(k)] = 0.f;
+        if (gKHb > gHT) {
+            for (int i = tid; i < kSCB * 16 * gKHb; i += blockDim.x) {
+                const int c = i / (16 * gKHb), k = i - c * 16 * gKHb;
+                if (k >= 16 * gHT) ZL[c * KZ + kperm(k)] = 0.f;
             }
         }
         if (dead && lane == 0) RED[24] = 1.f;
@@ -331,10 +335,10 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
             const float* zb = ZL + col * KZ + 4 * (lane >> 4);
             f32x4 bf[kSMaxHT];
 #pragma unroll
-            for (int kb = 0; kb < kSMaxHT; ++kb) if (kb < Q.KHb) bf[kb] = *(const f32x4*)(zb + 16 * kb);
+            for (int kb = 0; kb < kSMaxHT; ++kb) if (kb < gKHb) bf[kb] = *(const f32x4*)(zb + 16 * kb);
 #pragma unroll
             for (int kb = 0; kb < kSMaxHT; ++kb) {
-                if (kb < Q.KHb) {
+                if (kb < gKHb) {
                     acc0 = mfma16(wB[kb][0], bf[kb][0], acc0);
                     acc1 = mfma16(wB[kb][1], bf[kb][1], acc1);
                     acc0 = mfma16(wB[kb][2], bf[kb][2], acc0);
@@ -343,7 +347,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
             }
             gb = acc0 + acc1;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) if (r0 + i >= P.D) gb[i] = 0.f;
+            for (int i = 0; i < 4; ++i) if (r0 + i >= gD) gb[i] = 0.f;
         }
         BSTAMP(5 + 5 * (6 - j));
         // ---- phase C ----
@@ -367,8 +371,8 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
                 for (int i = 0; i < 4; ++i) S += ks[i] * kbar[i];
                 if (has_eig && j == 6) kbar += exk;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = (r0 + i < P.D) ? (ACT2 ? kbar[i] * (1.f - ks[i] * ks[i]) : kbar[i]) : 0.f;
-                st4(R + L.k(jn + 1) + co, r0, P.D, true, vec, v);
+                for (int i = 0; i < 4; ++i) v[i] = (r0 + i < gD) ? (ACT2 ? kbar[i] * (1.f - ks[i] * ks[i]) : kbar[i]) : 0.f;
+                st4(R + L.k(jn + 1) + co, r0, gD, true, vec, v);
             } else {
                 const f32x4 k1v = c_ks;
 #pragma unroll
@@ -378,11 +382,11 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
                 for (int s = 1; s <= 5; ++s) uo += gbs[s - 1];
                 f32x4 ko = kbar;
                 if (!accepted) {
-                    uo += first ? ld4(Bq.ubar + co, r0, P.D, colok, false) : ld4(Bq.U + co, r0, P.D, true, vec);
-                    if (!first) ko += ld4(Bq.K1 + co, r0, P.D, true, vec);
+                    uo += first ? ld4(Bq.ubar + co, r0, gD, colok, false) : ld4(Bq.U + co, r0, gD, true, vec);
+                    if (!first) ko += ld4(Bq.K1 + co, r0, gD, true, vec);
                 }
-                st4(Bq.U + co, r0, P.D, true, vec, uo);
-                st4(Bq.K1 + co, r0, P.D, true, vec, ko);
+                st4(Bq.U + co, r0, gD, true, vec, uo);
+                st4(Bq.K1 + co, r0, gD, true, vec, ko);
             }
         }
         if (!colok) tau = 0.f;
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
         float o0 = 0.f, o1 = 0.f, o2 = 0.f;
         for (int i = 0; i < 7; ++i) {
             float sa = 0.f, ta = 0.f, xa = 0.f;
-            for (int q = 0; q < Q.WT; ++q) { sa += GL[(i * 3 + 0) * 8 + q]; ta += GL[(i * 3 + 1) * 8 + q]; xa += GL[(i * 3 + 2) * 8 + q]; }
+            for (int q = 0; q < gWT; ++q) { sa += GL[(i * 3 + 0) * 8 + q]; ta += GL[(i * 3 + 1) * 8 + q]; xa += GL[(i * 3 + 2) * 8 + q]; }
             if (i == 0) { o0 = sa; o1 = ta; o2 = xa; }
             else { o0 += sa; o1 += ta; o2 += kTsC[7 - i] * ta; }
         }

@@ -1067,7 +1067,7 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
     // (`side_frac` of them, in groups) go to a second stream as such 32-workgroup launches, each waiting on an event recorded
     // after its last reverse launch; the rest runs on all CUs after the sweep as before.  An earlier form of this overlap with
     // unrestricted grids was a net loss (the GEMM waves took CUs the sweep's workgroups needed: 6.4 -> 8.4..9.8 ms per step).
-    const int side_pct = getenv("RNDE_WGRAD_SIDE") ? atoi(getenv("RNDE_WGRAD_SIDE")) : 42;
+    const int side_pct = getenv("RNDE_WGRAD_SIDE") ? atoi(getenv("RNDE_WGRAD_SIDE")) : 35;
     const int sweep_cus = 8 * h->sR * ((Q.F.Bpad / 16 + 7) / 8);
     const bool side = h->engine == 2 && h->persist == 1 && side_pct > 0 && n_att >= 8 && sweep_cus <= 224 &&
                       wgrad3_ok(h->H, h->D) && wgrad3_ok(h->D, h->H);

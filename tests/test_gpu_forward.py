@@ -135,7 +135,8 @@ def test_saveat_dense_output_matches_oracle(kind, B, tol, scale, saveat):
 
 @pytest.mark.parametrize("kind,B,tol,scale,saveat", [("mnist", 512, 1.4e-8, 1.0, None), ("mnist", 37, 1e-3, 3.0, np.linspace(0, 1, 9)),
                                                       ("small", 33, 1e-3, 4.0, None), ("test_node", 3, 1e-2, 8.0, np.array([0.5, 1.0]))])
-def test_persistent_attempt_is_bit_identical(kind, B, tol, scale, saveat, monkeypatch):
+@pytest.mark.parametrize("generic", [False, True])
+def test_persistent_attempt_is_bit_identical(kind, B, tol, scale, saveat, generic, monkeypatch):
     """rnde_stage_attempt_kernel (one launch per attempt, in-kernel slab hand-off between the row blocks of a column tile)
     performs exactly the arithmetic of the 7 rnde_stage_kernel launches: states, step log, saved values and the tape (checked
     through the reverse pass) must be bit-identical."""
@@ -147,6 +148,14 @@ def test_persistent_attempt_is_bit_identical(kind, B, tol, scale, saveat, monkey
     #  multi-launch sweep -- a different summation order, covered by test_weight_gradient_kernels_agree; here the partition is
     #  held fixed so that p-bar checks the tape bit for bit)
     monkeypatch.setenv("RNDE_WGRAD_SIDE", "0")
+    # the MNIST geometry (D = 784, H = 100) runs kernels with that geometry fixed at compile time; RNDE_STAGE_GENERIC=1 sends
+    # it through the run-time-geometry kernels every other shape uses: both must reproduce the multi-launch kernels bit for bit
+    if generic:
+        if kind != "mnist":
+            pytest.skip("only the MNIST geometry has a specialised kernel")
+        monkeypatch.setenv("RNDE_STAGE_GENERIC", "1")
+    else:
+        monkeypatch.delenv("RNDE_STAGE_GENERIC", raising=False)
     for persist in ("1", "0"):
         monkeypatch.setenv("RNDE_PERSIST", persist)
         node = Node(_cfg(arch, B, reltol=tol, abstol=tol, col_tile=16, max_attempts=256))

@@ -338,11 +338,11 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
             for (int kb = 0; kb < kSMaxHT; ++kb) if (kb < gKHb) bf[kb] = *(const f32x4*)(zb + 16 * kb);
 #pragma unroll
             for (int kb = 0; kb < kSMaxHT; ++kb) {
-                if (kb < gKHb) {
+                if (kb < gKHb) {      // (FIX: the k-steps past row H - 1 multiply zeros and are left out -- 25 MFMAs instead of 28)
                     acc0 = mfma16(wB[kb][0], bf[kb][0], acc0);
-                    acc1 = mfma16(wB[kb][1], bf[kb][1], acc1);
-                    acc0 = mfma16(wB[kb][2], bf[kb][2], acc0);
-                    acc1 = mfma16(wB[kb][3], bf[kb][3], acc1);
+                    if (!FIX || 16 * kb + 4 < gH) acc1 = mfma16(wB[kb][1], bf[kb][1], acc1);
+                    if (!FIX || 16 * kb + 8 < gH) acc0 = mfma16(wB[kb][2], bf[kb][2], acc0);
+                    if (!FIX || 16 * kb + 12 < gH) acc1 = mfma16(wB[kb][3], bf[kb][3], acc1);
                 }
             }
             gb = acc0 + acc1;

@@ -331,11 +331,11 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
             for (int kb = 0; kb < kSMaxHT; ++kb) if (kb < gK2b) bf[kb] = *(const f32x4*)(hb + 16 * kb);
 #pragma unroll
             for (int kb = 0; kb < kSMaxHT; ++kb) {
-                if (kb < gK2b) {
+                if (kb < gK2b) {      // (FIX: the k-steps past row H + 1 multiply zeros and are left out -- 26 MFMAs instead of 28)
                     acc0 = mfma16(wB[kb][0], bf[kb][0], acc0);
-                    acc1 = mfma16(wB[kb][1], bf[kb][1], acc1);
-                    acc0 = mfma16(wB[kb][2], bf[kb][2], acc0);
-                    acc1 = mfma16(wB[kb][3], bf[kb][3], acc1);
+                    if (!FIX || 16 * kb + 4 < gH + 2) acc1 = mfma16(wB[kb][1], bf[kb][1], acc1);
+                    if (!FIX || 16 * kb + 8 < gH + 2) acc0 = mfma16(wB[kb][2], bf[kb][2], acc0);
+                    if (!FIX || 16 * kb + 12 < gH + 2) acc1 = mfma16(wB[kb][3], bf[kb][3], acc1);
                 }
             }
             kv = acc0 + acc1;

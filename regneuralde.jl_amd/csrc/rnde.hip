@@ -1217,7 +1217,9 @@ extern "C" rnde_status rnde_classifier_head(rnde_node* h, const float* u_dev, co
     float* delta = h->head_ws;
     float* ce_col = h->head_ws + (size_t)B * n_classes;
     if (h->D > 256 * kHeadRowsPerThread) { h->err = "classifier head: D <= 1024"; return RNDE_ERR_BAD_ARG; }
-    hipLaunchKernelGGL(rnde_head_col_kernel, dim3(B), dim3(256), 0, s, u_dev, p3_dev, y_dev, h->D, n_classes, B,
+    if (n_classes == 10) hipLaunchKernelGGL((rnde_head_col_kernel<10>), dim3(B), dim3(256), 0, s, u_dev, p3_dev, y_dev, h->D, n_classes, B,
+                       logits_out_dev, u_bar_dev, delta, ce_col);
+    else hipLaunchKernelGGL((rnde_head_col_kernel<0>), dim3(B), dim3(256), 0, s, u_dev, p3_dev, y_dev, h->D, n_classes, B,
                        logits_out_dev, u_bar_dev, delta, ce_col);
     float* partial = ce_col + B;
     hipLaunchKernelGGL(rnde_head_wgrad_kernel, dim3((h->D + 255) / 256, kHeadChunks), dim3(256), 0, s, u_dev, (const float*)delta,

@@ -17,45 +17,49 @@ constexpr int kHeadMaxC = 16;
 // for both products (logits = W u, u-bar = W^T delta); all loads of the first product are issued up front (the one-wave-per-column form it
 // replaces walked 13 dependent iterations twice: 34 -> 25 us at B = 512; staging W through LDS was measured: no faster)
 constexpr int kHeadRowsPerThread = 4;       // D <= 1024
+// CC > 0: the number of classes as a compile-time constant (10 for the reference's classifier), CC = 0: any C <= kHeadMaxC
+template <int CC>
 __global__ __launch_bounds__(256) void rnde_head_col_kernel(const float* __restrict__ u, const float* __restrict__ p3,
                                                             const float* __restrict__ y, int D, int C, int B,
                                                             float* __restrict__ logits_out, float* __restrict__ ubar,
                                                             float* __restrict__ delta, float* __restrict__ ce_col) {
+    constexpr int NC = CC ? CC : kHeadMaxC;
+    if (CC) C = CC;
     __shared__ float red[4][kHeadMaxC];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int c = blockIdx.x;
     const float* W = p3;
     const float* b = p3 + (size_t)C * D;
     const float* uc = u + (size_t)c * D;
-    float wv[kHeadRowsPerThread][kHeadMaxC], uv[kHeadRowsPerThread];
+    float wv[kHeadRowsPerThread][NC], uv[kHeadRowsPerThread];
 #pragma unroll
     for (int k = 0; k < kHeadRowsPerThread; ++k) {
         const int d = tid + 256 * k;
         uv[k] = d < D ? uc[d] : 0.f;
 #pragma unroll
-        for (int i = 0; i < kHeadMaxC; ++i) wv[k][i] = (i < C && d < D) ? W[(size_t)d * C + i] : 0.f;
+        for (int i = 0; i < NC; ++i) wv[k][i] = (i < C && d < D) ? W[(size_t)d * C + i] : 0.f;
     }
-    float acc[kHeadMaxC];
+    float acc[NC];
 #pragma unroll
-    for (int i = 0; i < kHeadMaxC; ++i) {
+    for (int i = 0; i < NC; ++i) {
         acc[i] = 0.f;
 #pragma unroll
         for (int k = 0; k < kHeadRowsPerThread; ++k) acc[i] = fmaf(wv[k][i], uv[k], acc[i]);
     }
 #pragma unroll
-    for (int i = 0; i < kHeadMaxC; ++i) if (i < C) { const float s = wave_sum_f(acc[i]); if (lane == 0) red[w][i] = s; }
+    for (int i = 0; i < NC; ++i) if (i < C) { const float s = wave_sum_f(acc[i]); if (lane == 0) red[w][i] = s; }
     __syncthreads();
     float mx = -3.0e38f;
 #pragma unroll
-    for (int i = 0; i < kHeadMaxC; ++i) if (i < C) { acc[i] = ((red[0][i] + red[1][i]) + (red[2][i] + red[3][i])) + b[i]; mx = fmaxf(mx, acc[i]); }
+    for (int i = 0; i < NC; ++i) if (i < C) { acc[i] = ((red[0][i] + red[1][i]) + (red[2][i] + red[3][i])) + b[i]; mx = fmaxf(mx, acc[i]); }
     float se = 0.f;
 #pragma unroll
-    for (int i = 0; i < kHeadMaxC; ++i) if (i < C) se += expf(acc[i] - mx);
+    for (int i = 0; i < NC; ++i) if (i < C) se += expf(acc[i] - mx);
     const float lse = mx + logf(se);
-    float ce = 0.f, dl[kHeadMaxC];
+    float ce = 0.f, dl[NC];
     const float invB = 1.f / (float)B;
 #pragma unroll
-    for (int i = 0; i < kHeadMaxC; ++i) {
+    for (int i = 0; i < NC; ++i) {
         dl[i] = 0.f;
         if (i < C) {
             const float yv = y[(size_t)c * C + i];
@@ -72,7 +76,7 @@ __global__ __launch_bounds__(256) void rnde_head_col_kernel(const float* __restr
         const int d = tid + 256 * k;
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < kHeadMaxC; ++i) if (i < C) s = fmaf(wv[k][i], dl[i], s);
+        for (int i = 0; i < NC; ++i) if (i < C) s = fmaf(wv[k][i], dl[i], s);
         if (d < D) ubar[(size_t)c * D + d] = s;
     }
 }

@@ -19,6 +19,17 @@
 #include <string>
 #include <vector>
 
+// Every device allocation of the library goes through here.  RNDE_POISON=1 fills fresh memory with 0xFF bytes (NaN as float): a
+// read of something that was never written then shows up as NaN in the results instead of depending on what the allocator hands
+// back (a debugging aid; tests/test_gpu_edge.py runs a solve under it).
+static hipError_t rnde_malloc(void** p, size_t bytes) {
+    const hipError_t e = (hipMalloc)(p, bytes);
+    const bool poison = getenv("RNDE_POISON") != nullptr;       // (read per allocation: allocations are rare)
+    if (e == hipSuccess && poison && bytes) (void)hipMemset(*p, 0xFF, bytes);
+    return e;
+}
+#define hipMalloc(p, n) rnde_malloc((void**)(p), (n))
+
 using namespace rnde;
 
 struct rnde_node {
@@ -1083,9 +1094,9 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
             HIPCHK(h, hipStreamWaitEvent(h->wstream, ev, 0));
             ws = h->wstream; used_side = true;
         }
-        rnde_status r = launch_wgrad_part(h, b.ev1 + lo, hi - lo, per_chunk, h->H, h->D, Q.F.Bpad, slab1, &cur1, ws, on_side ? 16 : 0);
+        rnde_status r = launch_wgrad_part(h, b.ev1 + lo, hi - lo, per_chunk, h->H, h->D, h->B, slab1, &cur1, ws, on_side ? 16 : 0);
         if (r != RNDE_OK) return r;
-        return launch_wgrad_part(h, b.ev2 + lo, hi - lo, per_chunk, h->D, h->H, Q.F.Bpad, slab2w, &cur2, ws, on_side ? 16 : 0);
+        return launch_wgrad_part(h, b.ev2 + lo, hi - lo, per_chunk, h->D, h->H, h->B, slab2w, &cur2, ws, on_side ? 16 : 0);
     };
     int hi_att = n_att;                                           // evaluations of attempts >= hi_att are already launched
     hipError_t e;

@@ -161,3 +161,27 @@ def test_stage_engine_geometry_corners(D, H, B, persist, monkeypatch):
     x32, p32, _ = o32.backward(ubar, svbar)
     assert rel_err(gx, x64) <= 2e-3 + 4 * rel_err(x32, x64)
     assert rel_err(gp, p64) <= 2e-3 + 4 * rel_err(p32, p64)
+
+
+@pytest.mark.parametrize("kind,B,col_tile", [("mnist", 19, 16), ("small", 33, 16), ("test_node", 7, 8), ("mnist", 12, 4)])
+def test_results_do_not_depend_on_uninitialised_memory(kind, B, col_tile, monkeypatch):
+    """Ragged batches leave padded columns in every tape array.  With RNDE_POISON=1 the library fills each fresh allocation with
+    0xFF bytes (NaN): forward and reverse results must be the same, bit for bit, as without it.  (This caught the parameter-gradient
+    GEMMs summing over the padded columns -- 0 x whatever the allocator had left there -- which showed up as a NaN gradient in
+    the first test run on a fresh GPU box only.)"""
+    from tests.test_gpu_forward import _cfg, _setup
+    from tests.util import Node
+    arch, p, x = _setup(kind, B, 3, 3.0)
+    rng = np.random.default_rng(17)
+    ubar = rng.standard_normal(x.shape).astype(np.float32)
+    out = []
+    for poison in (False, True):
+        if poison: monkeypatch.setenv("RNDE_POISON", "1")
+        else: monkeypatch.delenv("RNDE_POISON", raising=False)
+        node = Node(_cfg(arch, B, reltol=1e-3, abstol=1e-3, col_tile=col_tile))
+        got = node.forward(x, p, 0.0, 1.0, keep_tape=True)
+        gx, gp, gt = node.backward(ubar, np.full(len(got["saveval"]), 5.0, dtype=np.float32))
+        assert np.isfinite(got["u"]).all() and np.isfinite(gx).all() and np.isfinite(gp).all() and np.isfinite(gt).all()
+        out.append((got["u"], got["saveval"], gx, gp, gt))
+    for a, b2 in zip(out[0], out[1]):
+        assert np.array_equal(a, b2)

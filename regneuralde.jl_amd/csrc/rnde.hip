@@ -1145,10 +1145,10 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
                 const dim3 pgrid(8 * BQ.R * ((BQ.C + 7) / 8));
                 const bool fix = BQ.WT == 7 && BQ.HT == 7 && BQ.KHb == 7 && BQ.MT == 49 && BQ.R == 7 && h->D == 784 && h->H == 100 && getenv("RNDE_STAGE_GENERIC") == nullptr;
                 if (fix) {
-                    if (h->act2) hipLaunchKernelGGL((rnde_bstage_attempt_kernel<1, 1>), pgrid, blk, h->stage_lds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo);
-                    else hipLaunchKernelGGL((rnde_bstage_attempt_kernel<0, 1>), pgrid, blk, h->stage_lds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo);
-                } else if (h->act2) hipLaunchKernelGGL((rnde_bstage_attempt_kernel<1, 0>), pgrid, blk, h->stage_lds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo);
-                else hipLaunchKernelGGL((rnde_bstage_attempt_kernel<0, 0>), pgrid, blk, h->stage_lds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo);
+                    if (h->act2) hipLaunchKernelGGL((rnde_bstage_attempt_kernel<1, 1>), pgrid, blk, h->stage_lds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
+                    else hipLaunchKernelGGL((rnde_bstage_attempt_kernel<0, 1>), pgrid, blk, h->stage_lds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
+                } else if (h->act2) hipLaunchKernelGGL((rnde_bstage_attempt_kernel<1, 0>), pgrid, blk, h->stage_lds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
+                else hipLaunchKernelGGL((rnde_bstage_attempt_kernel<0, 0>), pgrid, blk, h->stage_lds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
                 if (n >= n_att - side_att && (hi_att - n >= group || n == n_att - side_att)) {   // attempts [n, hi_att) are final
                     st = wgrad_group(2 + 6 * n, 2 + 6 * hi_att, true);
                     if (st != RNDE_OK) return st;

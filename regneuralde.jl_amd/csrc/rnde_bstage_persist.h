@@ -23,7 +23,8 @@ namespace rnde {
 // FIX = 1: the headline geometry (D = 784, H = 100, 7 waves, 7 row blocks) as compile-time constants, see rnde_stage_attempt_kernel
 template <int ACT2, int FIX>
 __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const BStageParams Q, const int n, const StepMeta m, const float eig_c1,
-                                                                          const float eig_c2, const int sv_lo, const int sv_hi, const PersistSync Y, const double qo_host) {
+                                                                          const float eig_c2, const int sv_lo, const int sv_hi, const PersistSync Y, const double qo_host,
+                                                                          const float svb_n /* = svb_att[n], known to the host: saves a dependent load in the scalar chain */) {
 #pragma clang fp contract(off)
     const BwdParams& Bq = Q.B;
     const StepParams& P = Bq.F;
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
             double eb = 0, dtb_pre = 0, q11b = 0, qb = 0, qoldb_in = 0;
             if (accepted) {
                 const bool err_term = Bq.reg_kind == 1 || (Bq.reg_kind == 3 && !(m.eest * dt == 0.f));
-                if (err_term) { const double sb = (double)Bq.svb_att[n]; eb += sb * (double)dt; dtb_pre += sb * (double)m.eest; }
+                if (err_term) { const double sb = (double)svb_n; eb += sb * (double)dt; dtb_pre += sb * (double)m.eest; }
                 dtb_pre += tb;
                 if (m.flags & F_DTMAXCLAMP) { t1b += dtpb; t0b -= dtpb; }
                 else if (Bq.track_ctrl) { dtb_pre += dtpb / (double)m.q; qb += -dtpb * (double)dt / ((double)m.q * (double)m.q); }

@@ -70,6 +70,11 @@ typedef struct {
     int32_t device;        /* HIP device ordinal */
     int32_t col_tile;      /* 0 = auto; MNIST form: 16 (stage engine, default), 4 / 8 (column-owner engine); small-width chains:
                             * 64 (chain engine, 16 columns per wave, default), 32 (4 columns per wave: experimental, forward only) */
+    /* tuning (0 = default everywhere, so a zero-initialised tail keeps the defaults) */
+    int32_t persist;        /* stage engine: 0 = one launch per attempted step where the shape allows, -1 = always the 7-launch kernels */
+    int32_t wgrad_side_pct; /* share (per cent of the attempts) of the parameter-gradient GEMMs run beside the reverse sweep on the CUs
+                             * it leaves idle: 0 = default (35), -1 = none */
+    int32_t stage_generic;  /* 1 = never use the instantiations with the MNIST geometry (D = 784, H = 100) as compile-time constants */
 } rnde_node_config;
 
 typedef struct rnde_node rnde_node;
@@ -96,6 +101,19 @@ rnde_status rnde_node_forward(rnde_node* h, const float* x_dev, const float* p_d
 rnde_status rnde_node_forward_saveat(rnde_node* h, const float* x_dev, const float* p_dev, int32_t B,
                                      float t0, float t1, const float* saveat_host, int32_t n_saveat,
                                      float* u_saved_dev, int64_t* nfe_out, float* saveval_host,
+                                     int32_t* n_saveval_out, int32_t keep_tape, void* stream);
+
+/* Parity instrument: the same solve along a GIVEN sequence of attempts.  steps_host holds n_steps pairs
+ * (dt_proposed, accepted != 0): attempt n runs with min(dt_proposed[n], t1 - t) and is accepted or rejected as told, and
+ * the solve ends after n_steps attempts; the error estimate, q11 and q of every attempt are still computed and logged
+ * (rnde_node_steps), the saving callback still fires per accepted step, the tape is recorded and rnde_node_backward
+ * differentiates the recorded program as if the controller had produced the sequence.  At the reference tolerance
+ * (reltol = abstol = 1.4e-8, experiments/mnist_node.jl:121-124) the fp32 error estimate sits on its rounding floor, so
+ * two fp32 implementations choose different step sequences; replaying ONE sequence (e.g. the fp32 CPU solver's) is how
+ * trajectories and gradients are compared element-wise there (tests/test_gpu_replay.py).  Not a reference entry point. */
+rnde_status rnde_node_forward_replay(rnde_node* h, const float* x_dev, const float* p_dev, int32_t B,
+                                     float t0, float t1, const float* steps_host, int32_t n_steps,
+                                     float* u_out_dev, int64_t* nfe_out, float* saveval_host,
                                      int32_t* n_saveval_out, int32_t keep_tape, void* stream);
 
 /* Reverse pass of the last recorded forward.  u_bar_dev: D x B cotangent of u_out;

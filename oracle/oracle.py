@@ -140,6 +140,22 @@ class Oracle:
         return dict(rc=rc, u=u_out, nfe=nfe.value, saveval=saveval[:nsv.value].copy(),
                     steps=log[:natt.value].copy(), nattempts=natt.value)
 
+    def set_replay(self, dtp=None, acc=None):
+        """Following forwards take attempt n with proposed size dtp[n] and accept decision acc[n] (None: back to the controller)."""
+        if dtp is None:
+            self.lib.orc_set_replay(self.h, None, None, C.c_int(0))
+            return
+        d = self._arr(dtp); a = np.ascontiguousarray(acc, dtype=np.int32)
+        assert d.shape == a.shape and d.ndim == 1
+        self.lib.orc_set_replay(self.h, self._p(d), a.ctypes.data_as(C.c_void_p), C.c_int(len(d)))
+
+    def steps_ext(self):
+        """(n, 6) array of the last forward: t, dt, dtp_in, EEst, accepted, q."""
+        out = np.zeros((self.max_attempts, 6), dtype=self.dtype)
+        self.lib.orc_steps_ext.restype = C.c_int
+        n = self.lib.orc_steps_ext(self.h, self._p(out), C.c_int(self.max_attempts))
+        return out[:n].copy()
+
     def backward(self, ubar, svbar=None):
         ubar = self._arr(ubar)
         B = ubar.shape[0]

@@ -317,6 +317,11 @@ typedef struct {
     int save_t0; /* saveat[0]==t0 saved from u0 */
     int n_saveval;
     int have_tape;
+    /* replay (orc_set_replay): the next orc_forward follows a given sequence of proposed step sizes and accept
+     * decisions instead of its own controller's -- parity tests run fp32 / fp64 / device along ONE sequence */
+    int n_replay;
+    real* replay_dtp;
+    int* replay_acc;
 } orc_handle;
 
 void* orc_create(const orc_config* cfg) {
@@ -340,9 +345,21 @@ static void free_tape(orc_handle* h) {
     h->u0 = h->f0 = h->acts0 = h->u1 = h->f1 = h->acts1 = h->p = h->saveat = NULL;
     h->have_tape = 0;
 }
+void orc_set_replay(void* hh, const real* dtp, const int* acc, int n) {
+    orc_handle* h = (orc_handle*)hh;
+    free(h->replay_dtp); free(h->replay_acc);
+    h->replay_dtp = NULL; h->replay_acc = NULL; h->n_replay = 0;
+    if (n <= 0) return;
+    h->replay_dtp = (real*)malloc(sizeof(real) * n);
+    h->replay_acc = (int*)malloc(sizeof(int) * n);
+    memcpy(h->replay_dtp, dtp, sizeof(real) * n);
+    memcpy(h->replay_acc, acc, sizeof(int) * n);
+    h->n_replay = n;
+}
 void orc_destroy(void* hh) {
     orc_handle* h = (orc_handle*)hh;
     free_tape(h);
+    free(h->replay_dtp); free(h->replay_acc);
     free(h->att);
     free(h);
 }
@@ -490,6 +507,8 @@ int orc_forward(void* hh, const real* x, const real* p, int B, real t0, real t1,
     nf += 2;
     /* fsalfirst = f(u0,t0): numerically identical to f0, counted as one more evaluation */
     nf += 1;
+    const int replay = h->n_replay;
+    if (replay) dtp = h->replay_dtp[0];
     real t = t0, qold = QOLDINIT, dtmax = t1 - t0;
     int nsv = 0, ret = 0, n = 0, next_save = 0;
     real dtmin = (real)(sizeof(real) == 4 ? 1.1920929e-7 : 2.220446049250313e-16);
@@ -506,7 +525,7 @@ int orc_forward(void* hh, const real* x, const real* p, int B, real t0, real t1,
     }
     real* uprev = h->u0;
     real* k1 = h->f0;
-    while (t < t1) {
+    while (replay ? n < replay : t < t1) {
         if (n >= cfg->max_attempts) { ret = 1; break; }
         attempt_rec* r = &h->att[n];
         memset(r, 0, sizeof(*r));
@@ -539,7 +558,7 @@ int orc_forward(void* hh, const real* x, const real* p, int B, real t0, real t1,
             else q = qg;
         }
         r->q11 = q11; r->q = q;
-        r->accepted = (eest <= 1);
+        r->accepted = replay ? h->replay_acc[n - 1] : (eest <= 1);
         if (steps_log) { steps_log[4 * (n - 1) + 0] = t; steps_log[4 * (n - 1) + 1] = dt; steps_log[4 * (n - 1) + 2] = eest; steps_log[4 * (n - 1) + 3] = (real)r->accepted; }
         if (r->accepted) {
             qold = eest > QOLDINIT ? eest : QOLDINIT;
@@ -567,6 +586,7 @@ int orc_forward(void* hh, const real* x, const real* p, int B, real t0, real t1,
             }
             if (cfg->reg_kind) { r->sv_index = nsv; saveval[nsv++] = cb_value(cfg, eest, dt, eig); }
             t = tnew; dtp = dtnew; uprev = r->unew; k1 = r->k[6];
+            if (replay && n < replay) dtp = h->replay_dtp[n];
         } else {
             real m = 1 / QMIN, m2 = q11 / GAMMA;
             r->rej_m_is_q11 = 0;
@@ -574,6 +594,7 @@ int orc_forward(void* hh, const real* x, const real* p, int B, real t0, real t1,
             r->rej_m = m;
             dtp = dt / m;
             if (dtmax < dtp) dtp = dtmax;
+            if (replay && n < replay) dtp = h->replay_dtp[n];
         }
     }
     if (!nsave) memcpy(u_out, uprev, sizeof(real) * N);
@@ -584,6 +605,18 @@ int orc_forward(void* hh, const real* x, const real* p, int B, real t0, real t1,
     h->have_tape = (ret == 0);
     (void)a;
     return ret;
+}
+
+/* per attempt of the last forward: t, dt, dtp_in (proposed size on entry, before the clamp to t1 - t), EEst, accepted, q */
+int orc_steps_ext(void* hh, real* out6, int cap) {
+    orc_handle* h = (orc_handle*)hh;
+    int n = h->n_att < cap ? h->n_att : cap;
+    for (int i = 0; i < n; ++i) {
+        const attempt_rec* r = &h->att[i];
+        out6[6 * i + 0] = r->t; out6[6 * i + 1] = r->dt; out6[6 * i + 2] = r->dtp_in;
+        out6[6 * i + 3] = r->eest; out6[6 * i + 4] = (real)r->accepted; out6[6 * i + 5] = r->q;
+    }
+    return h->n_att;
 }
 
 /* ---------------- reverse pass ---------------- */

@@ -87,6 +87,15 @@ int orc_forward(void* h, const real* x, const real* p, int B, real t0, real t1,
                 const real* saveat, int nsave, real* u_out, long* nfe,
                 real* saveval, int* nsaveval, real* steps_log, int* nattempts);
 
+/* Replay: the NEXT orc_forward on this handle (and every one after it until orc_set_replay(h, 0, 0, 0)) takes attempt n with
+ * the proposed step size dtp[n] (still clamped to t1 - t) and the accept decision acc[n], and stops after n attempts, instead
+ * of following its own PI controller.  EEst, q11, q are still computed and recorded, and orc_backward differentiates the
+ * recorded program as if the controller had produced the sequence.  Used to run the fp32 oracle, the fp64 oracle and the
+ * device along ONE (t, dt) sequence at the reference tolerance, where each one's own sequence is set by rounding noise. */
+void orc_set_replay(void* h, const real* dtp, const int* acc, int n);
+/* 6 reals per attempt of the last forward: t, dt, dtp_in, EEst, accepted, q.  Returns the number of attempts. */
+int  orc_steps_ext(void* h, real* out6, int cap);
+
 /* Reverse pass of the recorded solve (discretise-then-optimise).
  *  ubar: cotangent of u_out (same shape); svbar: cotangent per saveval element.
  *  xbar[D*B], pbar[P], tspanbar[2]. */

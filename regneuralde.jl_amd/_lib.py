@@ -14,7 +14,8 @@ class NodeConfig(C.Structure):
                 ("time_dep", C.c_int32), ("pre_act", C.c_int32), ("max_batch", C.c_int32), ("solver", C.c_int32),
                 ("reltol", C.c_float), ("abstol", C.c_float), ("regularize", C.c_int32),
                 ("cb_save_start", C.c_int32), ("track_ctrl", C.c_int32), ("track_initdt", C.c_int32),
-                ("max_attempts", C.c_int32), ("device", C.c_int32), ("col_tile", C.c_int32)]
+                ("max_attempts", C.c_int32), ("device", C.c_int32), ("col_tile", C.c_int32),
+                ("persist", C.c_int32), ("wgrad_side_pct", C.c_int32), ("stage_generic", C.c_int32)]
 
 
 class RndeError(RuntimeError):
@@ -46,6 +47,7 @@ def lib():
     L.rnde_node_destroy.restype = None
     L.rnde_node_forward.argtypes = [vp, vp, vp, i32, f, f, vp, i64p, fp, i32p, i32, vp]
     L.rnde_node_forward_saveat.argtypes = [vp, vp, vp, i32, f, f, fp, i32, vp, i64p, fp, i32p, i32, vp]
+    L.rnde_node_forward_replay.argtypes = [vp, vp, vp, i32, f, f, fp, i32, vp, i64p, fp, i32p, i32, vp]
     L.rnde_node_backward.argtypes = [vp, vp, fp, vp, vp, fp, vp]
     L.rnde_node_backward_async.restype = C.c_int32
     L.rnde_node_backward_async.argtypes = [vp, vp, fp, vp, vp, vp, vp]
@@ -65,7 +67,7 @@ def lib():
 
 
 EXPORTS = ["rnde_version", "rnde_last_error", "rnde_param_count", "rnde_node_create", "rnde_node_destroy",
-           "rnde_node_forward", "rnde_node_forward_saveat", "rnde_node_backward", "rnde_node_backward_async", "rnde_node_release_tape", "rnde_node_forward_host",
+           "rnde_node_forward", "rnde_node_forward_saveat", "rnde_node_forward_replay", "rnde_node_backward", "rnde_node_backward_async", "rnde_node_release_tape", "rnde_node_forward_host",
            "rnde_node_backward_host", "rnde_node_steps", "rnde_debug_feval", "rnde_debug_attempt",
            "rnde_bench_attempt", "rnde_node_launches_per_attempt", "rnde_classifier_head", "rnde_momentum_step"]
 

@@ -51,7 +51,9 @@ struct rnde_node {
     size_t stage_lds = 0;
     float* head_ws = nullptr; size_t head_ws_floats = 0;   // fused classifier head scratch
     float* sv_t_dev = nullptr; size_t sv_cap = 0; std::vector<float> saveat;   // saveat times of the last forward
+    float* replay_dev = nullptr; size_t replay_cap = 0; const float* replay_host = nullptr; int n_replay = 0;   // rnde_node_forward_replay (set for one forward)
     // persistent attempt kernel (rnde_stage_persist.h): 1 = in use, 0 = off (RNDE_PERSIST=0), -1 = disabled after a failure
+    int wgrad_side_pct = 35, stage_generic = 0, persist_clean = 0;   // fixed at creation (config fields; RNDE_* environment overrides are read once, there)
     int persist = 0, persist_spins = kPersistMaxSpins; int tslab_Bpad = -1; size_t tslab_bytes = 0; float* tslab = nullptr; unsigned *pabort = nullptr, *pxcc = nullptr; unsigned* h_pchk = nullptr;
     hipStream_t wstream = nullptr;        // (experimental overlap path of the weight-gradient GEMMs)
     std::vector<hipEvent_t> wevents;
@@ -122,6 +124,7 @@ static StepParams make_params(rnde_node* h, const float* x, int B, float t0, flo
     P.forced = 0; P.forced_t = 0; P.forced_dt = 0;
     P.xvec = ((h->D & 3) == 0 && ((uintptr_t)x & 15) == 0) ? 1 : 0;
     P.reg_kind = h->cfg.regularize;
+    P.replay = nullptr; P.n_replay = 0;
     return P;
 }
 
@@ -369,8 +372,15 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
     ok &= hipHostMalloc((void**)&h->h_scal, 64 * sizeof(float)) == hipSuccess;
     if (!ok) { g_create_err = "device allocation failed"; rnde_node_destroy(h); return RNDE_ERR_HIP; }
     hipMemset(h->tslab, 0xFF, tslab_bytes); hipMemset(h->pabort, 0, 8); hipMemset(h->pxcc, 0, (size_t)h->nwg_max * 4);
-    { const char* e = getenv("RNDE_PERSIST"); h->persist = (h->engine == 2 && h->sR <= 8 && !(e && e[0] == '0')) ? 1 : 0; }
-    if (const char* e = getenv("RNDE_PERSIST_SPINS")) h->persist_spins = atoi(e);
+    {   // tuning knobs: config fields, each with a create-time environment override for A/B tooling (never read per solve)
+        const char* e = getenv("RNDE_PERSIST");
+        const bool off = c->persist < 0 || (e && e[0] == '0');
+        h->persist = (h->engine == 2 && h->sR <= 8 && !off) ? 1 : 0;
+        if (const char* e2 = getenv("RNDE_PERSIST_SPINS")) h->persist_spins = atoi(e2);
+        h->wgrad_side_pct = c->wgrad_side_pct < 0 ? 0 : (c->wgrad_side_pct == 0 ? 35 : std::min(100, c->wgrad_side_pct));
+        if (const char* e3 = getenv("RNDE_WGRAD_SIDE")) h->wgrad_side_pct = atoi(e3);
+        h->stage_generic = (c->stage_generic != 0 || getenv("RNDE_STAGE_GENERIC") != nullptr) ? 1 : 0;
+    }
     h->predicted = 12;
     *out = h;
     return RNDE_OK;
@@ -390,6 +400,7 @@ extern "C" void rnde_node_destroy(rnde_node* h) {
     bwd_free(h->bw);
     if (h->head_ws) hipFree(h->head_ws);
     if (h->sv_t_dev) hipFree(h->sv_t_dev);
+    if (h->replay_dev) hipFree(h->replay_dev);
     if (h->cfrags) hipFree(h->cfrags);
     if (h->qtab) hipFree(h->qtab);
     if (h->tslab) hipFree(h->tslab);
@@ -468,7 +479,7 @@ static hipError_t stage_attempt(rnde_node* h, const StageParams& Q, int n, hipSt
         PersistSync Y{h->tslab, h->pabort, h->pxcc, h->persist_spins};
         if (hipError_t e = slab_prepare(h, Q.Bpad16, s); e != hipSuccess) return e;
         const dim3 grid(8 * Q.R * ((Q.C + 7) / 8));   // a column tile's row blocks share blockIdx % 8 (same XCD)
-        const bool fix = Q.WT == 7 && Q.HT == 7 && Q.K2b == 7 && Q.MT == 49 && Q.R == 7 && h->D == 784 && h->H == 100 && getenv("RNDE_STAGE_GENERIC") == nullptr;
+        const bool fix = Q.WT == 7 && Q.HT == 7 && Q.K2b == 7 && Q.MT == 49 && Q.R == 7 && h->D == 784 && h->H == 100 && !h->stage_generic;
         if (fix) {
             if (h->act2) hipLaunchKernelGGL((rnde_stage_attempt_kernel<1, 1>), grid, dim3(64 * Q.WT), h->stage_lds, s, Q, n, Y);
             else hipLaunchKernelGGL((rnde_stage_attempt_kernel<0, 1>), grid, dim3(64 * Q.WT), h->stage_lds, s, Q, n, Y);
@@ -531,6 +542,18 @@ extern "C" rnde_status rnde_node_forward(rnde_node* h, const float* x_dev, const
     return forward_impl(h, x_dev, p_dev, B, t0, t1, u_out_dev, nullptr, 0, nullptr, nfe_out, saveval_host, n_saveval_out, keep_tape, stream);
 }
 
+extern "C" rnde_status rnde_node_forward_replay(rnde_node* h, const float* x_dev, const float* p_dev, int32_t B, float t0,
+                                                float t1, const float* steps_host, int32_t n_steps, float* u_out_dev,
+                                                int64_t* nfe_out, float* saveval_host, int32_t* n_saveval_out,
+                                                int32_t keep_tape, void* stream) {
+    if (!h || !steps_host || n_steps < 1) return RNDE_ERR_BAD_ARG;
+    if (n_steps > h->cfg.max_attempts) { h->err = "replay: more steps than max_attempts"; return RNDE_ERR_BAD_ARG; }
+    h->replay_host = steps_host; h->n_replay = n_steps;
+    const rnde_status st = forward_impl(h, x_dev, p_dev, B, t0, t1, u_out_dev, nullptr, 0, nullptr, nfe_out, saveval_host, n_saveval_out, keep_tape, stream);
+    h->replay_host = nullptr; h->n_replay = 0;
+    return st;
+}
+
 extern "C" rnde_status rnde_node_forward_saveat(rnde_node* h, const float* x_dev, const float* p_dev, int32_t B, float t0,
                                                 float t1, const float* saveat_host, int32_t n_saveat, float* u_saved_dev,
                                                 int64_t* nfe_out, float* saveval_host, int32_t* n_saveval_out,
@@ -573,6 +596,16 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
     }
     StepParams P = make_params(h, x_dev, B, t0, t1, keep_tape ? 1 : 0);
     P.sv_t = n_saveat > 0 ? h->sv_t_dev : nullptr; P.nsave = n_saveat; P.sv_out = sv_out_dev;
+    if (h->n_replay > 0) {
+        if ((size_t)h->n_replay > h->replay_cap) {
+            if (h->replay_dev) hipFree(h->replay_dev);
+            h->replay_dev = nullptr; h->replay_cap = 0;
+            HIPCHK(h, hipMalloc((void**)&h->replay_dev, (size_t)h->n_replay * 8));
+            h->replay_cap = h->n_replay;
+        }
+        HIPCHK(h, hipMemcpyAsync(h->replay_dev, h->replay_host, (size_t)h->n_replay * 8, hipMemcpyHostToDevice, s));
+        P.replay = h->replay_dev; P.n_replay = h->n_replay;
+    }
     h->B = B; h->Bpad = P.Bpad; h->nwg = P.nwg; h->t0 = t0; h->t1 = t1;
     rnde_status st = h->engine == 3 ? chain_pack(h, keep_tape ? h->pcopy : p_dev, s)
                                     : pack_weights(h, p_dev, keep_tape != 0, s, h->engine != 2);   // (column-owner packs: also used by the reverse sweep)
@@ -1078,7 +1111,7 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
     // (`side_frac` of them, in groups) go to a second stream as such 32-workgroup launches, each waiting on an event recorded
     // after its last reverse launch; the rest runs on all CUs after the sweep as before.  An earlier form of this overlap with
     // unrestricted grids was a net loss (the GEMM waves took CUs the sweep's workgroups needed: 6.4 -> 8.4..9.8 ms per step).
-    const int side_pct = getenv("RNDE_WGRAD_SIDE") ? atoi(getenv("RNDE_WGRAD_SIDE")) : 35;
+    const int side_pct = h->wgrad_side_pct;
     const int sweep_cus = 8 * h->sR * ((Q.F.Bpad / 16 + 7) / 8);
     const bool side = h->engine == 2 && h->persist == 1 && side_pct > 0 && n_att >= 8 && sweep_cus <= 224 &&
                       wgrad3_ok(h->H, h->D) && wgrad3_ok(h->D, h->H);
@@ -1143,7 +1176,7 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
                 PersistSync Y{h->tslab, h->pabort, h->pxcc, h->persist_spins};
                 HIPCHK(h, slab_prepare(h, Q.F.Bpad, s));
                 const dim3 pgrid(8 * BQ.R * ((BQ.C + 7) / 8));
-                const bool fix = BQ.WT == 7 && BQ.HT == 7 && BQ.KHb == 7 && BQ.MT == 49 && BQ.R == 7 && h->D == 784 && h->H == 100 && getenv("RNDE_STAGE_GENERIC") == nullptr;
+                const bool fix = BQ.WT == 7 && BQ.HT == 7 && BQ.KHb == 7 && BQ.MT == 49 && BQ.R == 7 && h->D == 784 && h->H == 100 && !h->stage_generic;
                 if (fix) {
                     if (h->act2) hipLaunchKernelGGL((rnde_bstage_attempt_kernel<1, 1>), pgrid, blk, h->stage_lds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
                     else hipLaunchKernelGGL((rnde_bstage_attempt_kernel<0, 1>), pgrid, blk, h->stage_lds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);

@@ -175,6 +175,9 @@ struct StepParams {
     int xvec;                                // x is 16-byte aligned and D % 4 == 0
     int reg_kind;                            // rnde_reg: 2, 3 also need the stiffness estimate
     const float* sv_t; int nsave; float* sv_out;   // saveat times (device), their count, output D x T x B
+    // replay (rnde_node_forward_replay): attempt n takes the proposed size replay[2n] and the accept decision replay[2n+1] != 0
+    // instead of the controller's; the solve ends after n_replay attempts.  EEst, q11, q are still computed and recorded.
+    const float* replay; int n_replay;
 };
 
 // record layout inside the arena (floats): k2..k7 | g2..g6 | unew | h2..h7 | z1bar2..z1bar7

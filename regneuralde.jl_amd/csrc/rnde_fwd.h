@@ -201,7 +201,7 @@ __device__ __forceinline__ StepState advance_state(const StepParams& P, int n, i
             if (dtmax < dt) { dt = dtmax; sel = 2; }
             if (writer) { P.initrec->d2 = d2; P.initrec->dt1 = dt1; P.initrec->dt = dt; P.initrec->sel = sel;
                           P.initrec->dt1_const = c1; P.initrec->max_is_d2 = (d2 >= d1); }
-            S.t = P.t0; S.dtp = dt;
+            S.t = P.t0; S.dtp = P.replay ? P.replay[0] : dt;
             finalize_state(P, S);
         }
         if (writer) *out = S;
@@ -238,7 +238,7 @@ __device__ __forceinline__ StepState advance_state(const StepParams& P, int n, i
             else q = qg;
         }
         const float dtmax = P.t1 - P.t0;
-        if (eest <= 1.f) {
+        if (P.replay ? (P.replay[2 * (n - 1) + 1] != 0.f) : (eest <= 1.f)) {
             flags |= F_ACCEPT;
             S.qold = eest > kQoldInit ? eest : kQoldInit;
             float dtnew = dt / q;
@@ -252,6 +252,9 @@ __device__ __forceinline__ StepState advance_state(const StepParams& P, int n, i
             float dtp = dt / rej_m;
             if (!P.forced && dtmax < dtp) dtp = dtmax;
             S.dtp = dtp;
+        }
+        if (P.replay) {   // the given sequence decides what comes next and where the solve ends
+            if (n < P.n_replay) S.dtp = P.replay[2 * n]; else S.done = 1;
         }
         if (P.forced) S.done = 1; else finalize_state(P, S);
     }

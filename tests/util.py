@@ -10,7 +10,7 @@ from oracle.oracle import Oracle, arch_mnist, arch_test_node, glorot_params, mak
 
 
 def make_cfg(dims, acts, max_batch, reltol=1.4e-8, abstol=1.4e-8, regularize=1, max_attempts=128, col_tile=0,
-             cb_save_start=1, track_ctrl=1, track_initdt=1, time_dep=1, pre_act=0):
+             cb_save_start=1, track_ctrl=1, track_initdt=1, time_dep=1, pre_act=0, persist=0, wgrad_side_pct=0, stage_generic=0):
     cfg = _lib.NodeConfig()
     cfg.n_layers = len(acts)
     for i, d in enumerate(dims):
@@ -27,6 +27,7 @@ def make_cfg(dims, acts, max_batch, reltol=1.4e-8, abstol=1.4e-8, regularize=1, 
     cfg.max_attempts = max_attempts
     cfg.device = 0
     cfg.col_tile = col_tile
+    cfg.persist, cfg.wgrad_side_pct, cfg.stage_generic = persist, wgrad_side_pct, stage_generic
     return cfg
 
 
@@ -80,6 +81,27 @@ class Node:
         sv = (C.c_float * (self.cfg.max_attempts + 1))()
         st = self.L.rnde_node_forward(self.h, xd.data_ptr(), pd.data_ptr(), B, t0, t1, u.data_ptr(), C.byref(nfe), sv,
                                       C.byref(nsv), int(keep_tape), None)
+        _lib.check(self.h, st)
+        steps = (C.c_float * (4 * self.cfg.max_attempts))()
+        natt = C.c_int32(0)
+        self.L.rnde_node_steps(self.h, steps, self.cfg.max_attempts, C.byref(natt))
+        return dict(u=u.cpu().numpy(), nfe=nfe.value, saveval=np.array(sv[:nsv.value], dtype=np.float32),
+                    steps=np.array(steps[:4 * natt.value], dtype=np.float32).reshape(-1, 4), nattempts=natt.value)
+
+    def forward_replay(self, x, p, dtp, acc, t0=0.0, t1=1.0, keep_tape=False):
+        """The solve along a given sequence of (proposed step size, accept decision) pairs: rnde_node_forward_replay."""
+        B = x.shape[0]
+        xd, pd = self.dev(x), self.dev(p)
+        u = torch.empty_like(xd)
+        nfe = C.c_int64(0)
+        nsv = C.c_int32(0)
+        sv = (C.c_float * (self.cfg.max_attempts + 1))()
+        n = len(dtp)
+        pairs = (C.c_float * (2 * n))()
+        for i in range(n):
+            pairs[2 * i], pairs[2 * i + 1] = float(dtp[i]), float(acc[i] != 0)
+        st = self.L.rnde_node_forward_replay(self.h, xd.data_ptr(), pd.data_ptr(), B, t0, t1, pairs, n, u.data_ptr(), C.byref(nfe), sv,
+                                             C.byref(nsv), int(keep_tape), None)
         _lib.check(self.h, st)
         steps = (C.c_float * (4 * self.cfg.max_attempts))()
         natt = C.c_int32(0)

@@ -17,7 +17,7 @@ MAX_LAYERS = 8
 def build(force=False):
     out = os.path.join(_HERE, "_build")
     libs = [os.path.join(out, f"librnde_oracle_{s}.so") for s in ("f32", "f64")]
-    src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("rnde_oracle.c", "rnde_oracle.h"))
+    src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("rnde_oracle.c", "rnde_oracle.h", "rnde_sde_oracle.c", "rnde_sde_oracle.h"))
     if force or not all(os.path.exists(l) and os.path.getmtime(l) >= src_m for l in libs):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
     return libs

@@ -95,7 +95,7 @@ int orc_param_count(const orc_arch* a) {
     for (int l = 0; l < a->n_layers; ++l) n += (a->dims[l] + (a->time_dep ? 1 : 0)) * a->dims[l + 1] + a->dims[l + 1];
     return n;
 }
-static int act_rows_total(const orc_arch* a) { /* rows of stored activations per f eval: pre_act out + every layer out */
+int orc_act_rows_total(const orc_arch* a) { /* rows of stored activations per f eval: pre_act out + every layer out */
     int n = a->pre_act ? a->dims[0] : 0;
     for (int l = 0; l < a->n_layers; ++l) n += a->dims[l + 1];
     return n;
@@ -103,7 +103,7 @@ static int act_rows_total(const orc_arch* a) { /* rows of stored activations per
 
 /* forward f. acts (optional) receives [pre_act output (if any); y_1; ...; y_L], each (rows x B) col-major
  * stacked as separate blocks: block offset = rows_before * B. out = y_L. */
-static void f_forward(const orc_arch* a, const real* p, const real* u, int B, real t, real* out, real* acts) {
+void orc_f_forward(const orc_arch* a, const real* p, const real* u, int B, real t, real* out, real* acts) {
     int maxd = 0;
     for (int l = 0; l <= a->n_layers; ++l)
         if (a->dims[l] > maxd) maxd = a->dims[l];
@@ -155,12 +155,12 @@ static void f_forward(const orc_arch* a, const real* p, const real* u, int B, re
     }
 }
 void orc_f_eval(const orc_arch* a, const real* p, const real* u, int B, real t, real* out) {
-    f_forward(a, p, u, B, t, out, NULL);
+    orc_f_forward(a, p, u, B, t, out, NULL);
 }
 
 /* reverse of f at input u (stored), activations acts (stored):
  * given kbar (D x B): ubar_out (D x B, overwritten), pbar += , returns tbar contribution. */
-static real f_backward(const orc_arch* a, const real* p, const real* u, const real* acts, int B, real t,
+real orc_f_backward(const orc_arch* a, const real* p, const real* u, const real* acts, int B, real t,
                        const real* kbar, real* ubar_out, real* pbar) {
     int L = a->n_layers;
     int maxd = 0;
@@ -329,7 +329,7 @@ void* orc_create(const orc_config* cfg) {
     h->cfg = *cfg;
     h->D = cfg->arch.dims[0];
     h->P = orc_param_count(&cfg->arch);
-    h->arows = act_rows_total(&cfg->arch);
+    h->arows = orc_act_rows_total(&cfg->arch);
     h->att = (attempt_rec*)calloc((size_t)cfg->max_attempts + 1, sizeof(attempt_rec));
     return h;
 }
@@ -384,7 +384,7 @@ static void attempt_stages(const orc_config* cfg, const real* p, const real* upr
         }
         if (s == 5) memcpy(g6, g, sizeof(real) * N);
         if (s == 6) memcpy(unew, g, sizeof(real) * N);
-        f_forward(a, p, g, B, t + (real)TS_C[s] * dt, k[s], acts ? acts[s] : NULL);
+        orc_f_forward(a, p, g, B, t + (real)TS_C[s] * dt, k[s], acts ? acts[s] : NULL);
     }
     /* error estimate */
     real bt[7];
@@ -432,7 +432,7 @@ static real initdt_impl(orc_handle* h, const orc_config* cfg, const real* p, con
     real* sk = ralloc(N);
     for (size_t i = 0; i < N; ++i) sk[i] = cfg->abstol + rfabs(u0[i]) * cfg->reltol;
     real d0 = rms_ratio(u0, sk, N);
-    f_forward(a, p, u0, B, t0, f0, acts0);
+    orc_f_forward(a, p, u0, B, t0, f0, acts0);
     real d1 = rms_ratio(f0, sk, N);
     real dt0;
     int c0 = 0, cl = 0;
@@ -440,7 +440,7 @@ static real initdt_impl(orc_handle* h, const orc_config* cfg, const real* p, con
     else dt0 = (d0 / d1) / R(100.0);
     if (dtmax < dt0) { dt0 = dtmax; cl = 1; }
     for (size_t i = 0; i < N; ++i) u1[i] = u0[i] + dt0 * f0[i];
-    f_forward(a, p, u1, B, t0 + dt0, f1, acts1);
+    orc_f_forward(a, p, u1, B, t0 + dt0, f1, acts1);
     real* df = ralloc(N);
     for (size_t i = 0; i < N; ++i) df[i] = f1[i] - f0[i];
     real d2 = rms_ratio(df, sk, N) / dt0;
@@ -794,7 +794,7 @@ int orc_backward(void* hh, const real* ubar, const real* svbar, real* xbar, real
             }
             const real* gin = (s == 6) ? r->unew : gtmp;
             real tst = t + (real)TS_C[s] * dt;
-            real taub = f_backward(a, p, gin, r->acts[s], B, tst, kb[s], gb, pbar);
+            real taub = orc_f_backward(a, p, gin, r->acts[s], B, tst, kb[s], gb, pbar);
             tb_in += (double)taub;
             dtb += TS_C[s] * (double)taub;
             if (s == 6) {
@@ -873,7 +873,7 @@ int orc_backward(void* hh, const real* ubar, const real* svbar, real* xbar, real
                 f0b[i] -= wb / sk[i];
                 skb[i] += -wb * w / sk[i];
             }
-            real taub = f_backward(a, p, h->u1, h->acts1, B, h->t0 + dt0, f1b, gb, pbar);
+            real taub = orc_f_backward(a, p, h->u1, h->acts1, B, h->t0 + dt0, f1b, gb, pbar);
             t0b += (double)taub;
             dt0b += (double)taub;
             for (size_t i = 0; i < N; ++i) { u0b[i] += gb[i]; f0b[i] += dt0 * gb[i]; }
@@ -902,7 +902,7 @@ int orc_backward(void* hh, const real* ubar, const real* svbar, real* xbar, real
         free(sk); free(skb); free(f1b);
     }
     {
-        real taub = f_backward(a, p, h->u0, h->acts0, B, h->t0, f0b, gb, pbar);
+        real taub = orc_f_backward(a, p, h->u0, h->acts0, B, h->t0, f0b, gb, pbar);
         t0b += (double)taub;
         for (size_t i = 0; i < N; ++i) u0b[i] += gb[i];
     }

@@ -179,6 +179,76 @@ rnde_status rnde_classifier_head(rnde_node* h, const float* u_dev, const float* 
 rnde_status rnde_momentum_step(float* p_dev, const float* g_dev, float* v_dev, int64_t len, int64_t n, float gamma,
                                float eta, float rho, void* stream);
 
+/* ======================================================================================================================
+ * TrackedNeuralDSDE: the stochastic layer (reference src/models/neural_sde.jl:1-146; caller ClassifierNSDE,
+ * src/models/supervised_classification.jl:82-103; experiment experiments/mnist_nsde.jl:70-100).
+ *   rnde_nsde_create    TrackedNeuralDSDE(model1, model2, tspan, regularize, solver; kw...)   neural_sde.jl:13-41
+ *   rnde_nsde_forward   (n::TrackedNeuralDSDE{R,false})(x, p; func): the `solve(SDEProblem{false}(...), SOSRI(); callback, ...)`
+ *                       between :98 and :108 (and :54-56 for the unregularised method), returning what :109-113 unpack:
+ *                       u (D x B), nfe1, nfe2 (the closures' counters, :46,:50) and the saved EEst*dt values
+ *   rnde_nsde_backward  the reverse sweep Tracker performs over that solve (sensealg = SensitivityADPassThrough, :104)
+ * p = vcat(destructure(model1), destructure(model2)) (:15-17): the drift chain's parameters, then the diffusion chain's.
+ * Diagonal noise: the diffusion chain maps D -> D and multiplies the increments element-wise (:49-52).
+ * Noise: a pool of standard normals, n_pool draws of 2*D*B floats each (xi_W block then xi_Z block, both D x B column-major),
+ * consumed in order -- draw 0 makes the first increments, every later accepted step that needs fresh or bridged noise and
+ * every rejected step takes the next one (at most 1 + attempts draws).  noise_dev = NULL: the library fills its own pool
+ * from `seed` (Philox4x32-10 + Box-Muller); a caller that wants its own random stream (Julia: randn!) passes the pool.
+ * ====================================================================================================================== */
+typedef enum { RNDE_SDE_SOSRI = 0, RNDE_SDE_SRIW1 = 1, RNDE_SDE_SOSRI2 = 2 } rnde_sde_solver;
+
+typedef struct {
+    int32_t drift_layers;                       /* Dense chain of the drift, time independent (neural_sde.jl:45-47) */
+    int32_t drift_dims[RNDE_MAX_LAYERS + 1];    /* drift_dims[0] = drift_dims[drift_layers] = D; every width <= 64 */
+    int32_t drift_act[RNDE_MAX_LAYERS];         /* rnde_act per layer */
+    int32_t diff_layers;                        /* Dense chain of the diffusion (neural_sde.jl:49-52) */
+    int32_t diff_dims[RNDE_MAX_LAYERS + 1];
+    int32_t diff_act[RNDE_MAX_LAYERS];
+    int32_t max_batch;                          /* largest B (= batch x trajectories) any call will pass */
+    int32_t solver;                             /* rnde_sde_solver: the tableau */
+    float   reltol, abstol;                     /* experiments/mnist_nsde.jl:79-80 */
+    int32_t regularize;                         /* RNDE_REG_NONE or RNDE_REG_ERR (func = EEst*dt, neural_sde.jl:87) */
+    int32_t cb_save_start;                      /* 1: the saving callback also fires at initialisation (pushes 0) */
+    int32_t max_attempts;
+    int32_t device;
+    /* controller constants, 0 = the StochasticDiffEq defaults as recalled: beta2 = 2/(5 order),
+     * beta1 = 7/(10 order), order = 3/2, gamma = 0.9, qmin = 0.2, qmax = 1.125, qoldinit = 1e-4, delta = 1 (SRIW1: 1/6) */
+    float   beta1, beta2, gamma, qmin, qmax, qoldinit, delta;
+} rnde_nsde_config;
+
+typedef struct rnde_nsde rnde_nsde;
+
+int32_t     rnde_nsde_param_count(const rnde_nsde_config* cfg, int32_t* len_drift_out);
+rnde_status rnde_nsde_create(const rnde_nsde_config* cfg, rnde_nsde** out);
+void        rnde_nsde_destroy(rnde_nsde* h);
+const char* rnde_nsde_last_error(const rnde_nsde* h);   /* h may be NULL: last create error of this thread */
+
+/* Forward solve on [t0, t1].  x_dev, u_out_dev: D x B.  saveval_host: room for max_attempts + 1 floats (may be NULL when
+ * regularize == 0).  nfe1_out = drift evaluations, nfe2_out = diffusion evaluations (2 + 4 per attempted step each).
+ * keep_tape != 0 records what rnde_nsde_backward needs.  Synchronises `stream` before returning. */
+rnde_status rnde_nsde_forward(rnde_nsde* h, const float* x_dev, const float* p_dev, int32_t B, float t0, float t1,
+                              const float* noise_dev, int32_t n_pool, uint64_t seed, float* u_out_dev,
+                              int64_t* nfe1_out, int64_t* nfe2_out, float* saveval_host, int32_t* n_saveval_out,
+                              int32_t keep_tape, void* stream);
+/* Parity instrument (as rnde_node_forward_replay): the solve along n_steps given (dt, accepted != 0) pairs. */
+rnde_status rnde_nsde_forward_replay(rnde_nsde* h, const float* x_dev, const float* p_dev, int32_t B, float t0, float t1,
+                                     const float* noise_dev, int32_t n_pool, const float* steps_host, int32_t n_steps,
+                                     float* u_out_dev, int64_t* nfe1_out, int64_t* nfe2_out, float* saveval_host,
+                                     int32_t* n_saveval_out, int32_t keep_tape, void* stream);
+/* Reverse pass of the last recorded forward: u_bar_dev (D x B), saveval_bar_host (one per saveval element, NULL = zeros)
+ * -> x_bar_dev (D x B), p_bar_dev (P, overwritten).  Step sizes and noise increments are constants of the reverse pass
+ * (the SDE step-size controller strips tracking: DESIGN.md 3.2).  Synchronises `stream` before returning. */
+rnde_status rnde_nsde_backward(rnde_nsde* h, const float* u_bar_dev, const float* saveval_bar_host, float* x_bar_dev,
+                               float* p_bar_dev, void* stream);
+/* Per-attempt log of the last forward: 4 floats per attempt (t, dt, EEst, accepted); draws_out = noise draws consumed. */
+rnde_status rnde_nsde_steps(rnde_nsde* h, float* steps_host, int32_t capacity, int32_t* n_attempts_out, int32_t* draws_out);
+/* Kernel-level parity entry: ONE attempted step from (uprev, dt, dW, dZ), all D x B device arrays: kg_out_dev receives
+ * k1..k4, g1..g4 (8 x D x B), unew_out_dev the proposed state, eest_out the error estimate. */
+rnde_status rnde_nsde_debug_attempt(rnde_nsde* h, const float* uprev_dev, const float* p_dev, int32_t B, float dt,
+                                    const float* dW_dev, const float* dZ_dev, float* kg_out_dev, float* unew_out_dev,
+                                    float* eest_out, void* stream);
+/* Fill `n` floats with standard normals from (seed, stream_id): the library's own generator, exposed for its statistical test. */
+rnde_status rnde_normal_fill(float* out_dev, int64_t n, uint64_t seed, uint64_t stream_id, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,6 +18,18 @@ class NodeConfig(C.Structure):
                 ("persist", C.c_int32), ("wgrad_side_pct", C.c_int32), ("stage_generic", C.c_int32)]
 
 
+class NsdeConfig(C.Structure):
+    _fields_ = [("drift_layers", C.c_int32), ("drift_dims", C.c_int32 * (MAX_LAYERS + 1)), ("drift_act", C.c_int32 * MAX_LAYERS),
+                ("diff_layers", C.c_int32), ("diff_dims", C.c_int32 * (MAX_LAYERS + 1)), ("diff_act", C.c_int32 * MAX_LAYERS),
+                ("max_batch", C.c_int32), ("solver", C.c_int32), ("reltol", C.c_float), ("abstol", C.c_float),
+                ("regularize", C.c_int32), ("cb_save_start", C.c_int32), ("max_attempts", C.c_int32), ("device", C.c_int32),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("gamma", C.c_float), ("qmin", C.c_float), ("qmax", C.c_float),
+                ("qoldinit", C.c_float), ("delta", C.c_float)]
+
+
+SDE_SOLVER = {"SOSRI": 0, "SRIW1": 1, "SOSRI2": 2}
+
+
 class RndeError(RuntimeError):
     def __init__(self, status, msg):
         super().__init__(f"rnde status {status}: {msg}")
@@ -62,6 +74,20 @@ def lib():
     L.rnde_node_launches_per_attempt.argtypes = [vp]
     L.rnde_classifier_head.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]
     L.rnde_momentum_step.argtypes = [vp, vp, vp, C.c_int64, C.c_int64, f, f, f, vp]
+    u64 = C.c_uint64
+    L.rnde_nsde_param_count.restype = i32
+    L.rnde_nsde_param_count.argtypes = [C.POINTER(NsdeConfig), i32p]
+    L.rnde_nsde_create.argtypes = [C.POINTER(NsdeConfig), C.POINTER(vp)]
+    L.rnde_nsde_destroy.argtypes = [vp]
+    L.rnde_nsde_destroy.restype = None
+    L.rnde_nsde_last_error.restype = C.c_char_p
+    L.rnde_nsde_last_error.argtypes = [vp]
+    L.rnde_nsde_forward.argtypes = [vp, vp, vp, i32, f, f, vp, i32, u64, vp, i64p, i64p, fp, i32p, i32, vp]
+    L.rnde_nsde_forward_replay.argtypes = [vp, vp, vp, i32, f, f, vp, i32, fp, i32, vp, i64p, i64p, fp, i32p, i32, vp]
+    L.rnde_nsde_backward.argtypes = [vp, vp, fp, vp, vp, vp]
+    L.rnde_nsde_steps.argtypes = [vp, fp, i32, i32p, i32p]
+    L.rnde_nsde_debug_attempt.argtypes = [vp, vp, vp, i32, f, vp, vp, vp, vp, fp, vp]
+    L.rnde_normal_fill.argtypes = [vp, C.c_int64, u64, u64, vp]
     _lib = L
     return L
 
@@ -69,10 +95,17 @@ def lib():
 EXPORTS = ["rnde_version", "rnde_last_error", "rnde_param_count", "rnde_node_create", "rnde_node_destroy",
            "rnde_node_forward", "rnde_node_forward_saveat", "rnde_node_forward_replay", "rnde_node_backward", "rnde_node_backward_async", "rnde_node_release_tape", "rnde_node_forward_host",
            "rnde_node_backward_host", "rnde_node_steps", "rnde_debug_feval", "rnde_debug_attempt",
-           "rnde_bench_attempt", "rnde_node_launches_per_attempt", "rnde_classifier_head", "rnde_momentum_step"]
+           "rnde_bench_attempt", "rnde_node_launches_per_attempt", "rnde_classifier_head", "rnde_momentum_step",
+           "rnde_nsde_param_count", "rnde_nsde_create", "rnde_nsde_destroy", "rnde_nsde_last_error", "rnde_nsde_forward",
+           "rnde_nsde_forward_replay", "rnde_nsde_backward", "rnde_nsde_steps", "rnde_nsde_debug_attempt", "rnde_normal_fill"]
 
 
 def check(h, status):
     if status != OK:
         msg = lib().rnde_last_error(h).decode() if h else lib().rnde_last_error(None).decode()
         raise RndeError(status, msg)
+
+
+def check_nsde(h, status):
+    if status != OK:
+        raise RndeError(status, lib().rnde_nsde_last_error(h if h else None).decode())

@@ -1,30 +1,51 @@
-"""Build librnde.so (the C-ABI HIP library) in-tree with hipcc for gfx950."""
+"""Build librnde.so (the C-ABI HIP library) in-tree with hipcc for gfx950: one object per translation unit (in parallel), then link."""
+import glob
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 # RNDE_LIB: load another build of the same library (A/B runs of kernel variants on one GPU box; tools/ab_bench.sh)
 LIB = os.environ.get("RNDE_LIB") or os.path.join(_HERE, "lib", "librnde.so")
-SOURCES = ["rnde.hip"]
-HEADERS = ["rnde_device.h", "rnde_fwd.h", "rnde_bwd.h", "rnde_stage.h", "rnde_bstage.h", "rnde_stage_persist.h", "rnde_bstage_persist.h",
-           "rnde_chain.h", "rnde_quad.h", "rnde_bchain.h", "rnde_head.h", os.path.join("..", "..", "include", "rnde.h")]
+SOURCES = ["rnde.hip", "rnde_sde.hip"]
+
+
+def _headers():
+    return sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(_HERE, "..", "include", "rnde.h")]
 
 
 def needs_build():
     if not os.path.exists(LIB):
         return True
     m = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > m for f in SOURCES + HEADERS)
+    return any(os.path.getmtime(f) > m for f in [os.path.join(CSRC, s) for s in SOURCES] + _headers())
 
 
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    objdir = os.path.join(os.path.dirname(LIB), "obj")
+    os.makedirs(objdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-undefined-internal"]
+    hdr_m = max(os.path.getmtime(f) for f in _headers())
+
+    def compile_one(src):
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        srcp = os.path.join(CSRC, src)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(srcp), hdr_m):
+            return obj
+        cmd = [hipcc] + flags + ["-c", srcp, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -1,0 +1,752 @@
+// rnde_sde.h -- the stochastic half of the hot path: TrackedNeuralDSDE (reference src/models/neural_sde.jl:1-146),
+// i.e. `solve(SDEProblem{false}(drift, diffusion, x, tspan, p), SOSRI(); callback = svcb, reltol, abstol, ...)` with
+// diagonal noise, and its reverse sweep, for small-width Dense chains (reference experiments/mnist_nsde.jl:72-84:
+// D = 32, drift 32 -> 64 -> 32, diffusion 32 -> 32, reltol = abstol = 0.14).
+//
+// The state of 16 batch columns is 8 VGPRs per array, a whole solve is ~60 attempted steps of 8 tiny network
+// evaluations each, and the only thing that couples the columns is the error norm: everything about this problem is
+// latency.  So the WHOLE SOLVE is one kernel launch:
+//   * one wave owns 16 batch columns from x to u(t1); uprev, the four drift / four diffusion stage values, the Wiener
+//     increments dW, dZ never leave its registers inside an attempt (MFMA chains as in rnde_chain.h: a Dense layer's
+//     B operand is the previous layer's D registers, weight fragments resident in LDS);
+//   * the adaptive controller (SURVEY.md B.7 / StochasticDiffEq loopfooter!), the saving callback and the
+//     rejection-sampling-with-memory stacks of the noise process (RSwM3) run INSIDE the kernel, replicated per workgroup:
+//     thread 0 turns (EEst, stack metadata in LDS) into a decision block and a short list of array operations, the waves
+//     execute it on their own columns.  The stack arrays live in a slot pool in HBM, one fragment-order array per slot;
+//   * workgroups meet once per attempt, to sum the squared residuals: each publishes its partial as ONE 8-byte
+//     agent-scope atomic store {value, sequence tag} and polls the others' with agent-scope atomic loads
+//     (/opt/skills/guides/cdna_hip_programming.md section 6 Guideline 16, the 8-byte-atomics form: placement independent,
+//     no fence, no L2 write-back).  Every entry is written once per solve (index = exchange number), the tag carries the
+//     solve's epoch, every spin is bounded;
+//   * noise enters as a POOL of standard normals in the caller's layout (draw k = xi_W, xi_Z, both D x B), consumed in
+//     order: the caller may fill it from its own generator (a Julia caller: randn!) or let the library fill it
+//     (rnde_normal_fill_kernel, Philox4x32-10 + Box-Muller).
+// The reverse pass needs no meeting at all (the SDE controller strips tracking, so step sizes and increments are
+// constants of the reverse pass and rejected attempts carry no gradient): one launch, each wave walks its columns'
+// accepted steps backwards; (layer input, pre-activation cotangent) pairs go to a slab and rnde_chain_wgrad_kernel
+// contracts them over columns x evaluations afterwards, as for the chain engine.
+#pragma once
+#include "rnde_bchain.h"
+
+namespace rnde {
+
+constexpr int kSdeMaxOps = 64;       // array operations one accept / reject can ask for (whole pops + a bridge + fresh)
+constexpr int kSdeSpinMax = 4000000; // bound of every poll (~1 s)
+
+struct SriTableau {   // lower-triangular 4x4 stage matrices (row = stage) and weights, fp32 (tableau as data)
+    float A0[16], A1[16], B0[16], B1[16], alpha[4], beta1[4], beta2[4], beta3[4], beta4[4];
+};
+
+struct SdeMeta {   // one per attempted step
+    float t, dt, eest, q;
+    int accepted, rec, pad0, pad1;
+};
+struct SdeFinal {  // written once, by workgroup 0, when the solve ends
+    int n_att, n_acc, status, n_draws;
+    float t, dt0, pad0, pad1;
+};
+
+struct SdeParams {
+    ChainGeo Gf, Gg;                 // drift / diffusion chains (time independent)
+    const float* frags_f;            // drift fragment tables [fwd | bias | transposed][64]
+    const float* frags_g;
+    SriTableau T;
+    const float* x;                  // D x B, caller layout
+    const float* noise;              // pool: [n_pool][2][B][D] standard normals (caller layout)
+    float* slots;                    // [n_slots][2][ntiles][NKD][64]
+    float* tape;                     // [max_acc][12][ntiles][NKD][64]: uprev dW dZ k1..4 g1..4 unew
+    SdeMeta* meta;
+    SdeFinal* fin;
+    unsigned long long* xch;         // [n_exchanges][2][nwg] {float value, uint tag}
+    unsigned* abort_word;
+    float* u_out;                    // D x B, caller layout (may be NULL)
+    const float* replay;             // optional: [n_replay][2] (dt, accepted)
+    int n_replay;
+    int D, B, ntiles, nwg, n_pool, n_slots, max_attempts, keep_tape, reg_kind;
+    unsigned epoch;
+    float t0, t1, reltol, abstol;
+    float beta1, beta2, gamma, qmin, qmax, qoldinit, delta, order;
+};
+
+__device__ __forceinline__ unsigned long long sde_pack(float v, unsigned tag) { return ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v); }
+
+// ---- LDS layout of the solve kernel ------------------------------------------------------------------------------------
+struct SdeOp { int type, a, b, c; float f0, f1; int draw, flags; };   // see sde_apply_ops
+enum { OP_ADD = 1, OP_BRIDGE = 2, OP_FRESH = 3, OP_SUB = 4, OP_RBRIDGE = 5 };
+struct SdeDecision {
+    float eest, dt, sqdt, t, q;
+    int accepted, done, status, nops, n_att, n_acc, n_draws, rec;
+    double xsum[2];
+};
+
+// one network evaluation on the wave's 16 columns (chain_eval of rnde_chain.h with this net's tables)
+template <int NKD>
+__device__ __forceinline__ void sde_net(const ChainGeo& G, const float* FR, const float (&in)[NKD], float (&out)[NKD], int lane) {
+    chain_eval<NKD, 0>(G, FR, FR + (size_t)G.nfrag_f * 64, 0.f, in, out, lane);
+}
+
+// ---- one attempted SRI step for the wave's columns (StochasticDiffEq FourStageSRIConstantCache) ------------
+// returns this lane's share of sum r^2, r = (delta E1 + E2) / (abstol + max(|uprev|, |u|) reltol)
+template <int NKD>
+__device__ __forceinline__ float sde_attempt(const SdeParams& Q, const float* FRf, const float* FRg, const float (&up)[NKD], float dt,
+                                             float sqdt, const float (&dW)[NKD], const float (&dZ)[NKD], float (&k)[4][NKD],
+                                             float (&g)[4][NKD], float (&un)[NKD], bool colok, int gq, int lane) {
+    const SriTableau& T = Q.T;
+    float chi2[NKD];
+    const float sqrt3 = 1.7320508075688772f;
+#pragma unroll
+    for (int q = 0; q < NKD; ++q) chi2[q] = (dW[q] + dZ[q] / sqrt3) / 2.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        float h0[NKD], h1[NKD];
+#pragma unroll
+        for (int q = 0; q < NKD; ++q) {
+            float a0 = 0.f, b0 = 0.f, a1 = 0.f, b1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < s) {
+                    a0 += T.A0[4 * s + j] * k[j][q]; b0 += T.B0[4 * s + j] * g[j][q];
+                    a1 += T.A1[4 * s + j] * k[j][q]; b1 += T.B1[4 * s + j] * g[j][q];
+                }
+            h0[q] = s ? up[q] + dt * a0 + chi2[q] * b0 : up[q];
+            h1[q] = s ? up[q] + dt * a1 + sqdt * b1 : up[q];
+        }
+        sde_net<NKD>(Q.Gf, FRf, h0, k[s], lane);
+        sde_net<NKD>(Q.Gg, FRg, h1, g[s], lane);
+    }
+    float part = 0.f;
+#pragma unroll
+    for (int q = 0; q < NKD; ++q) {
+        const float w = dW[q];
+        const float chi1 = (w * w - fabsf(dt)) / (2.f * sqdt);
+        const float chi3 = (w * w * w - 3.f * w * dt) / (6.f * dt);
+        float sa = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, sk_ = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sa += T.alpha[j] * k[j][q]; sk_ += k[j][q];
+            s1 += T.beta1[j] * g[j][q]; s2 += T.beta2[j] * g[j][q];
+            s3 += T.beta3[j] * g[j][q]; s4 += T.beta4[j] * g[j][q];
+        }
+        const float E2 = chi2[q] * s3 + chi3 * s4;
+        const float u = up[q] + dt * sa + E2 + w * s1 + chi1 * s2;
+        un[q] = u;
+        if (colok && 4 * q + gq < Q.D) {
+            const float E1 = dt * sk_;
+            const float sc = Q.abstol + fmaxf(fabsf(up[q]), fabsf(u)) * Q.reltol;
+            const float r = (Q.delta * E1 + E2) / sc;
+            part += r * r;
+        }
+    }
+    return part;
+}
+
+// ---- cross-workgroup sum of NV per-workgroup values: publish, poll, fixed-order double sum --------------------------------
+// called by wave 0 only; `mine` valid in lane 0.  Returns false on time-out / abort.
+template <int NV>
+__device__ __forceinline__ bool sde_exchange(const SdeParams& Q, int seq, const float (&mine)[NV], double (&out)[NV], int wg, int lane) {
+    const unsigned tag = Q.epoch * 8192u + (unsigned)seq + 1u;
+    unsigned long long* base = Q.xch + (size_t)seq * 2 * Q.nwg;
+    if (lane == 0) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            float m = mine[v];
+            if (m != m) m = __uint_as_float(0x7FC00000u);
+            __hip_atomic_store(base + (size_t)v * Q.nwg + wg, sde_pack(m, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        double s = 0.0;
+        for (int b0 = 0; b0 < Q.nwg; b0 += 64) {
+            const int i = b0 + lane;
+            unsigned long long e = 0;
+            bool ok = i >= Q.nwg;
+            int spins = 0;
+            while (true) {
+                if (!ok) { e = __hip_atomic_load(base + (size_t)v * Q.nwg + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = (unsigned)(e >> 32) == tag; }
+                if (__all(ok)) break;
+                if (++spins > kSdeSpinMax || ((spins & 1023) == 0 && __hip_atomic_load(Q.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                    if (lane == 0) __hip_atomic_store(Q.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return false;
+                }
+            }
+            if (i < Q.nwg) s += (double)__uint_as_float((unsigned)(e & 0xFFFFFFFFull));
+        }
+        out[v] = wave_sum_d(s);
+    }
+    return true;
+}
+
+// array element access: fragment-order slot / tape arrays of this wave's tile
+__device__ __forceinline__ size_t sde_slot_off(const SdeParams& Q, int slot, int wz, int tile, int NKD) { return (((size_t)slot * 2 + wz) * Q.ntiles + tile) * NKD * 64; }
+
+// ---- noise process bookkeeping (thread 0 of each workgroup, replicated; DiffEqNoiseProcess RSwM3) -------------------------
+struct SdeStacks {   // in LDS
+    int n1, n2, nfree, next_slot, next_draw, pad;
+    float Wdt, pad1;
+};
+__device__ __forceinline__ int sde_alloc(SdeStacks& S, int* freel, int n_slots, int& status) {
+    if (S.nfree > 0) return freel[--S.nfree];
+    if (S.next_slot < n_slots) return S.next_slot++;
+    status = 4;
+    return 0;
+}
+
+template <int NKD>
+__global__ __launch_bounds__(64 * kCW) void rnde_sde_solve_kernel(const SdeParams Q) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg = blockIdx.x;
+    const int units_f = (Q.Gf.nfrag_f + Q.Gf.nfrag_b + 3) >> 2, units_g = (Q.Gg.nfrag_f + Q.Gg.nfrag_b + 3) >> 2;
+    float* FRf = smem;
+    float* FRg = smem + (size_t)units_f * 256;
+    float* scratch = FRg + (size_t)units_g * 256;
+    float* RED = scratch;                                   // [2][kCW]
+    SdeDecision* DEC = (SdeDecision*)(scratch + 16);       // 16-byte aligned
+    SdeStacks* STK = (SdeStacks*)(scratch + 16 + 32);
+    SdeOp* OPS = (SdeOp*)(scratch + 16 + 32 + 8);
+    const int cap = 2 * Q.max_attempts + 8;
+    float* S1L = (float*)(OPS + kSdeMaxOps);
+    int* S1s = (int*)(S1L + cap);
+    float* S2L = (float*)(S1s + cap);
+    int* S2s = (int*)(S2L + cap);
+    int* FREEL = (int*)(S2s + cap);
+    // fragment tables -> LDS
+    for (int u = wave; u < units_f; u += kCW) dma_unit((const f32x4*)(Q.frags_f + (size_t)u * 256) + lane, FRf + (size_t)u * 256);
+    for (int u = wave; u < units_g; u += kCW) dma_unit((const f32x4*)(Q.frags_g + (size_t)u * 256) + lane, FRg + (size_t)u * 256);
+    wait_vm<0>();
+    if (tid == 0) { SdeStacks s{}; *STK = s; }
+    __syncthreads();
+
+    const int tile = wg * kCW + wave;
+    const bool tile_ok = tile < Q.ntiles;
+    const int gq = lane >> 4, gcol = tile * 16 + (lane & 15);
+    const bool colok = tile_ok && gcol < Q.B;
+    const size_t fo = (size_t)lane;
+    const double N = (double)Q.D * (double)Q.B;
+    const float dtmax = Q.t1 - Q.t0;
+    const float dtmin = 1.1920929e-7f;
+
+    float up[NKD], dW[NKD], dZ[NKD];
+#pragma unroll
+    for (int q = 0; q < NKD; ++q) { up[q] = ldc(Q.x, Q.D, gcol, 4 * q + gq, colok); dW[q] = 0.f; dZ[q] = 0.f; }
+
+    // draw `d` of the pool for this lane's elements
+    auto xi = [&](int d, int wz, int q) -> float {
+        const int f = 4 * q + gq;
+        return (colok && f < Q.D) ? Q.noise[(((size_t)d * 2 + wz) * Q.B + gcol) * Q.D + f] : 0.f;
+    };
+
+    // ---- initial step size: sde_determine_initdt (StochasticDiffEq src/initdt.jl) ----
+    float dt;
+    int seq = 0;
+    {
+        float f0[NKD], g0[NKD];
+        sde_net<NKD>(Q.Gf, FRf, up, f0, lane);
+        sde_net<NKD>(Q.Gg, FRg, up, g0, lane);
+        float pa = 0.f, pb = 0.f;
+#pragma unroll
+        for (int q = 0; q < NKD; ++q) {
+            g0[q] *= 3.f;
+            if (colok && 4 * q + gq < Q.D) {
+                const float sk = Q.abstol + fabsf(up[q]) * Q.reltol;
+                const float a = up[q] / sk, b = fmaxf(fabsf(f0[q] + g0[q]), fabsf(f0[q] - g0[q])) / sk;
+                pa += a * a; pb += b * b;
+            }
+        }
+        pa = wave_sum_f(pa); pb = wave_sum_f(pb);
+        if (lane == 0) { RED[wave] = pa; RED[kCW + wave] = pb; }
+        __syncthreads();
+        if (wave == 0) {
+            float mine[2] = {0.f, 0.f};
+            for (int w = 0; w < kCW; ++w) { mine[0] += RED[w]; mine[1] += RED[kCW + w]; }
+            double o[2];
+            const bool ok = sde_exchange<2>(Q, seq, mine, o, wg, lane);
+            if (lane == 0) { DEC->xsum[0] = o[0]; DEC->xsum[1] = o[1]; DEC->status = ok ? 0 : 5; }
+        }
+        __syncthreads();
+        ++seq;
+        if (DEC->status) { if (wg == 0 && tid == 0) { SdeFinal F{}; F.status = 5; *Q.fin = F; } return; }
+        const float d0 = (float)sqrt(DEC->xsum[0] / N), d1 = (float)sqrt(DEC->xsum[1] / N);
+        float dt0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6f : (d0 / d1) / 100.f;
+        if (dtmax < dt0) dt0 = dtmax;
+        float u1[NKD], f1[NKD], g1[NKD];
+#pragma unroll
+        for (int q = 0; q < NKD; ++q) u1[q] = up[q] + dt0 * f0[q];
+        sde_net<NKD>(Q.Gf, FRf, u1, f1, lane);
+        sde_net<NKD>(Q.Gg, FRg, u1, g1, lane);
+        float pc = 0.f;
+#pragma unroll
+        for (int q = 0; q < NKD; ++q) {
+            g1[q] *= 3.f;
+            if (colok && 4 * q + gq < Q.D) {
+                const float sk = Q.abstol + fabsf(up[q]) * Q.reltol;
+                const float dg = fmaxf(fabsf(g0[q] - g1[q]), fabsf(g0[q] + g1[q]));
+                const float c = fmaxf(fabsf(f1[q] - f0[q] + dg), fabsf(f1[q] - f0[q] - dg)) / sk;
+                pc += c * c;
+            }
+        }
+        __syncthreads();   // RED reuse
+        pc = wave_sum_f(pc);
+        if (lane == 0) RED[wave] = pc;
+        __syncthreads();
+        if (wave == 0) {
+            float mine[1] = {0.f};
+            for (int w = 0; w < kCW; ++w) mine[0] += RED[w];
+            double o[1];
+            const bool ok = sde_exchange<1>(Q, seq, mine, o, wg, lane);
+            if (lane == 0) { DEC->xsum[0] = o[0]; DEC->status = ok ? 0 : 5; }
+        }
+        __syncthreads();
+        ++seq;
+        if (DEC->status) { if (wg == 0 && tid == 0) { SdeFinal F{}; F.status = 5; *Q.fin = F; } return; }
+        const float d2 = (float)sqrt(DEC->xsum[0] / N) / dt0;
+        const float m = d1 > d2 ? d1 : d2;
+        float dt1;
+        if (m <= 1e-15f) dt1 = fmaxf(1e-6f, dt0 * 1e-3f);
+        else dt1 = (float)pow(10.0, (double)(-(2.f + log10f(m)) / (Q.order + 0.5f)));
+        dt = 100.f * dt0;
+        if (dt1 < dt) dt = dt1;
+        if (dtmax < dt) dt = dtmax;
+        if (Q.replay) dt = Q.replay[0];
+    }
+    float t = Q.t0, qold = Q.qoldinit;
+    if (Q.t1 - t < dt) dt = Q.t1 - t;
+    // first increments: draw 0, one piece of the current step
+    int my_status = 0;
+    if (Q.n_pool < 1) my_status = 4;
+    {
+        const float s = sqrtf(fabsf(dt));
+#pragma unroll
+        for (int q = 0; q < NKD; ++q) { dW[q] = s * xi(0, 0, q); dZ[q] = s * xi(0, 1, q); }
+        if (tile_ok) {
+            float* w0 = Q.slots + sde_slot_off(Q, 0, 0, tile, NKD) + fo;
+            float* z0 = Q.slots + sde_slot_off(Q, 0, 1, tile, NKD) + fo;
+#pragma unroll
+            for (int q = 0; q < NKD; ++q) { w0[q * 64] = dW[q]; z0[q * 64] = dZ[q]; }
+        }
+        if (tid == 0) { STK->next_slot = 1; STK->next_draw = 1; STK->n2 = 1; S2L[0] = dt; S2s[0] = 0; STK->Wdt = dt; }
+    }
+    int n = 0, n_acc = 0;
+    __syncthreads();
+
+    // ---- the solve ----
+    while (true) {
+        // loop-top checks (identical in every thread of every workgroup)
+        int status = my_status;
+        bool stop = false;
+        if (status == 0) {
+            if (!(t < Q.t1) || (Q.replay && n >= Q.n_replay)) stop = true;
+            else if (n >= Q.max_attempts) { status = 1; stop = true; }
+            else if (dt != dt) { status = 3; stop = true; }
+            else if (!(dt > dtmin)) { status = 2; stop = true; }
+        } else stop = true;
+        if (stop) { my_status = status; break; }
+
+        const float sqdt = sqrtf(fabsf(dt));
+        float k[4][NKD], g[4][NKD], un[NKD];
+        float part = sde_attempt<NKD>(Q, FRf, FRg, up, dt, sqdt, dW, dZ, k, g, un, colok, gq, lane);
+        part = wave_sum_f(part);
+        if (lane == 0) RED[wave] = part;
+        __syncthreads();
+        if (wave == 0) {
+            float mine[1] = {0.f};
+            for (int w = 0; w < kCW; ++w) mine[0] += RED[w];
+            double o[1];
+            const bool ok = sde_exchange<1>(Q, seq, mine, o, wg, lane);
+            if (lane == 0) {
+                // ---- controller + noise bookkeeping: one thread per workgroup, identical everywhere ----
+                SdeDecision d{};
+                d.status = ok ? 0 : 5;
+                const float eest = (float)sqrt(o[0] / N);
+                d.eest = eest;
+                int nops = 0;
+                if (d.status == 0 && (!(eest == eest) || isinf(eest))) d.status = 3;
+                if (d.status == 0) {
+                    const float q11 = powf(eest, Q.beta1);
+                    float q = q11 / powf(qold, Q.beta2);
+                    { const float qg = q / Q.gamma, lo = 1.f / Q.qmax, hi = 1.f / Q.qmin; q = qg < lo ? lo : (qg > hi ? hi : qg); }
+                    d.q = q;
+                    const bool acc = Q.replay ? (Q.replay[2 * n + 1] != 0.f) : (eest <= 1.f);
+                    d.accepted = acc ? 1 : 0;
+                    SdeStacks S = *STK;
+                    const float discard = 1e-15f;
+                    if (acc) {
+                        const float tn = t + dt;
+                        float dtn = dt / q;
+                        if (dtmax < dtn) dtn = dtmax;
+                        if (dtn < dtmin) dtn = dtmin;
+                        if (Q.replay && n + 1 < Q.n_replay) dtn = Q.replay[2 * (n + 1)];
+                        const bool last = !(tn < Q.t1) || (Q.replay && n + 1 >= Q.n_replay);
+                        d.t = tn; d.rec = n_acc;
+                        if (!last) {
+                            if (Q.t1 - tn < dtn) dtn = Q.t1 - tn;
+                            // accept_step!: the pieces of the finished step are forgotten, the next step is assembled from the future stack
+                            for (int i = 0; i < S.n2; ++i) FREEL[S.nfree++] = S2s[i];
+                            S.n2 = 0;
+                            float dttmp = 0.f;
+                            bool bridged = false;
+                            while (S.n1 > 0 && nops < kSdeMaxOps - 2) {
+                                const float L = S1L[S.n1 - 1]; const int sl = S1s[S.n1 - 1];
+                                --S.n1;
+                                const float qtmp = (dtn - dttmp) / L;
+                                if (qtmp > 1.f) {
+                                    dttmp += L;
+                                    OPS[nops++] = SdeOp{OP_ADD, sl, 0, 0, 0.f, 0.f, 0, 0};
+                                    S2L[S.n2] = L; S2s[S.n2] = sl; ++S.n2;
+                                } else {
+                                    if (S.next_draw >= Q.n_pool) { d.status = 4; break; }
+                                    const float rest = (1.f - qtmp) * L, piece = qtmp * L;
+                                    const int keepP = rest > discard, keepN = piece > discard;
+                                    const int ns = keepN ? sde_alloc(S, FREEL, Q.n_slots, d.status) : 0;
+                                    OPS[nops++] = SdeOp{OP_BRIDGE, sl, ns, 0, qtmp, sqrtf((1.f - qtmp) * qtmp * L), S.next_draw++, keepP | (keepN << 1)};
+                                    if (keepP) { S1L[S.n1] = rest; S1s[S.n1] = sl; ++S.n1; } else FREEL[S.nfree++] = sl;
+                                    if (keepN) { S2L[S.n2] = piece; S2s[S.n2] = ns; ++S.n2; }
+                                    bridged = true;
+                                    break;
+                                }
+                            }
+                            if (!bridged && d.status == 0) {
+                                const float dtleft = dtn - dttmp;
+                                if (dtleft > 0.f) {
+                                    if (S.next_draw >= Q.n_pool) d.status = 4;
+                                    else {
+                                        const int ns = sde_alloc(S, FREEL, Q.n_slots, d.status);
+                                        OPS[nops++] = SdeOp{OP_FRESH, ns, 0, 0, sqrtf(dtleft), 0.f, S.next_draw++, 0};
+                                        S2L[S.n2] = dtleft; S2s[S.n2] = ns; ++S.n2;
+                                    }
+                                }
+                            }
+                            S.Wdt = dtn;
+                        }
+                        d.dt = dtn;
+                        d.done = last ? 1 : 0;
+                    } else {
+                        float mrej = 1.f / Q.qmin;
+                        const float m2 = q11 / Q.gamma;
+                        if (m2 < mrej) mrej = m2;
+                        float dtn = dt / mrej;
+                        if (dtmax < dtn) dtn = dtmax;
+                        if (Q.replay && n + 1 < Q.n_replay) dtn = Q.replay[2 * (n + 1)];
+                        const bool last = Q.replay && n + 1 >= Q.n_replay;
+                        if (Q.t1 - t < dtn) dtn = Q.t1 - t;
+                        d.t = t; d.dt = dtn; d.done = last ? 1 : 0;
+                        if (!last) {
+                            // reject_step!: whole pieces of the tail go back to the future stack, the rest is bridged
+                            float dttmp = 0.f;
+                            while (S.n2 > 0 && nops < kSdeMaxOps - 2) {
+                                const float L = S2L[S.n2 - 1]; const int sl = S2s[S.n2 - 1];
+                                if (S.Wdt - dttmp - L < dtn) break;
+                                --S.n2;
+                                dttmp += L;
+                                OPS[nops++] = SdeOp{OP_SUB, sl, 0, 0, 0.f, 0.f, 0, 0};
+                                S1L[S.n1] = L; S1s[S.n1] = sl; ++S.n1;
+                            }
+                            if (S.next_draw >= Q.n_pool) d.status = 4;
+                            else {
+                                const float dtK = S.Wdt - dttmp, qK = dtn / dtK, cut = (1.f - qK) * dtK;
+                                const int keepR = cut > discard;
+                                for (int i = 0; i < S.n2; ++i) FREEL[S.nfree++] = S2s[i];     // the finer structure of [0, dtK] is forgotten
+                                S.n2 = 0;
+                                const int rs = keepR ? sde_alloc(S, FREEL, Q.n_slots, d.status) : 0;
+                                const int cs = sde_alloc(S, FREEL, Q.n_slots, d.status);
+                                OPS[nops++] = SdeOp{OP_RBRIDGE, rs, cs, 0, qK, sqrtf((1.f - qK) * qK * dtK), S.next_draw++, keepR};
+                                if (keepR) { S1L[S.n1] = cut; S1s[S.n1] = rs; ++S.n1; }
+                                S2L[0] = dtn; S2s[0] = cs; S.n2 = 1;
+                                S.Wdt = dtn;
+                            }
+                        }
+                    }
+                    if (S.n1 >= cap - 2 || S.n2 >= cap - 2 || S.nfree >= cap - 2 || nops >= kSdeMaxOps - 1) d.status = d.status ? d.status : 4;
+                    *STK = S;
+                }
+                d.nops = nops; d.n_att = n + 1; d.n_draws = STK->next_draw;
+                d.n_acc = n_acc + (d.accepted ? 1 : 0);
+                d.sqdt = 0.f;
+                *DEC = d;
+                if (wg == 0) { SdeMeta M{t, dt, eest, d.q, d.accepted, d.accepted ? n_acc : -1, 0, 0}; Q.meta[n] = M; }
+            }
+        }
+        __syncthreads();
+        ++seq;
+        const SdeDecision d = *DEC;
+        if (d.status) { my_status = d.status; ++n; break; }
+        if (d.accepted) {
+            if (Q.keep_tape && tile_ok) {
+                float* R = Q.tape + ((size_t)n_acc * 12 * Q.ntiles + tile) * NKD * 64 + fo;
+                const size_t as = (size_t)Q.ntiles * NKD * 64;
+#pragma unroll
+                for (int q = 0; q < NKD; ++q) {
+                    R[q * 64] = up[q]; R[as + q * 64] = dW[q]; R[2 * as + q * 64] = dZ[q];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { R[(3 + j) * as + q * 64] = k[j][q]; R[(7 + j) * as + q * 64] = g[j][q]; }
+                    R[11 * as + q * 64] = un[q];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NKD; ++q) up[q] = un[q];
+            ++n_acc;
+            // array operations of accept_step!
+            float aw[NKD], az[NKD];
+#pragma unroll
+            for (int q = 0; q < NKD; ++q) { aw[q] = 0.f; az[q] = 0.f; }
+            for (int i = 0; i < d.nops; ++i) {
+                const SdeOp op = OPS[i];
+                float* pw = Q.slots + sde_slot_off(Q, op.a, 0, tile_ok ? tile : 0, NKD) + fo;
+                float* pz = Q.slots + sde_slot_off(Q, op.a, 1, tile_ok ? tile : 0, NKD) + fo;
+                if (op.type == OP_ADD) {
+#pragma unroll
+                    for (int q = 0; q < NKD; ++q) if (tile_ok) { aw[q] += pw[q * 64]; az[q] += pz[q * 64]; }
+                } else if (op.type == OP_BRIDGE) {
+                    float* nw = Q.slots + sde_slot_off(Q, op.b, 0, tile_ok ? tile : 0, NKD) + fo;
+                    float* nz = Q.slots + sde_slot_off(Q, op.b, 1, tile_ok ? tile : 0, NKD) + fo;
+#pragma unroll
+                    for (int q = 0; q < NKD; ++q) if (tile_ok) {
+                        const float lw = pw[q * 64], lz = pz[q * 64];
+                        const float bw = op.f0 * lw + op.f1 * xi(op.draw, 0, q), bz = op.f0 * lz + op.f1 * xi(op.draw, 1, q);
+                        aw[q] += bw; az[q] += bz;
+                        if (op.flags & 1) { pw[q * 64] = lw - bw; pz[q * 64] = lz - bz; }
+                        if (op.flags & 2) { nw[q * 64] = bw; nz[q * 64] = bz; }
+                    }
+                } else if (op.type == OP_FRESH) {
+#pragma unroll
+                    for (int q = 0; q < NKD; ++q) if (tile_ok) {
+                        const float fw = op.f0 * xi(op.draw, 0, q), fz = op.f0 * xi(op.draw, 1, q);
+                        aw[q] += fw; az[q] += fz;
+                        pw[q * 64] = fw; pz[q * 64] = fz;
+                    }
+                }
+            }
+            if (!d.done) {
+#pragma unroll
+                for (int q = 0; q < NKD; ++q) { dW[q] = aw[q]; dZ[q] = az[q]; }
+            }
+            qold = d.eest > Q.qoldinit ? d.eest : Q.qoldinit;
+        } else if (!d.done) {
+            float tw[NKD], tz[NKD];
+#pragma unroll
+            for (int q = 0; q < NKD; ++q) { tw[q] = 0.f; tz[q] = 0.f; }
+            for (int i = 0; i < d.nops; ++i) {
+                const SdeOp op = OPS[i];
+                float* pw = Q.slots + sde_slot_off(Q, op.a, 0, tile_ok ? tile : 0, NKD) + fo;
+                float* pz = Q.slots + sde_slot_off(Q, op.a, 1, tile_ok ? tile : 0, NKD) + fo;
+                if (op.type == OP_SUB) {
+#pragma unroll
+                    for (int q = 0; q < NKD; ++q) if (tile_ok) { tw[q] += pw[q * 64]; tz[q] += pz[q * 64]; }
+                } else if (op.type == OP_RBRIDGE) {
+                    float* cw = Q.slots + sde_slot_off(Q, op.b, 0, tile_ok ? tile : 0, NKD) + fo;
+                    float* cz = Q.slots + sde_slot_off(Q, op.b, 1, tile_ok ? tile : 0, NKD) + fo;
+#pragma unroll
+                    for (int q = 0; q < NKD; ++q) {
+                        const float K2 = dW[q] - tw[q], K3 = dZ[q] - tz[q];
+                        const float bw = op.f0 * K2 + op.f1 * xi(op.draw, 0, q), bz = op.f0 * K3 + op.f1 * xi(op.draw, 1, q);
+                        if (tile_ok) {
+                            if (op.flags & 1) { pw[q * 64] = K2 - bw; pz[q * 64] = K3 - bz; }
+                            cw[q * 64] = bw; cz[q * 64] = bz;
+                        }
+                        dW[q] = bw; dZ[q] = bz;
+                    }
+                }
+            }
+        }
+        t = d.t; dt = d.dt;
+        ++n;
+        __syncthreads();   // DEC / OPS / RED are rewritten by the next attempt
+        if (d.done) break;
+    }
+    if (Q.u_out) {
+#pragma unroll
+        for (int q = 0; q < NKD; ++q) if (colok && 4 * q + gq < Q.D) Q.u_out[(size_t)gcol * Q.D + 4 * q + gq] = up[q];
+    }
+    if (wg == 0 && tid == 0) { SdeFinal F{n, n_acc, my_status, STK->next_draw, t, 0.f, 0.f, 0.f}; *Q.fin = F; }
+}
+
+// ---- kernel-level parity entry: ONE attempt from (uprev, dt, dW, dZ) given in caller layout ----------------------------------
+template <int NKD>
+__global__ __launch_bounds__(64 * kCW) void rnde_sde_attempt_kernel(const SdeParams Q, const float* __restrict__ uprev, const float* __restrict__ dWc,
+                                                                    const float* __restrict__ dZc, float dt, float* __restrict__ kg_out,
+                                                                    float* __restrict__ unew_out, float* __restrict__ part_out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int units_f = (Q.Gf.nfrag_f + Q.Gf.nfrag_b + 3) >> 2, units_g = (Q.Gg.nfrag_f + Q.Gg.nfrag_b + 3) >> 2;
+    float* FRf = smem;
+    float* FRg = smem + (size_t)units_f * 256;
+    float* RED = FRg + (size_t)units_g * 256;
+    for (int u = wave; u < units_f; u += kCW) dma_unit((const f32x4*)(Q.frags_f + (size_t)u * 256) + lane, FRf + (size_t)u * 256);
+    for (int u = wave; u < units_g; u += kCW) dma_unit((const f32x4*)(Q.frags_g + (size_t)u * 256) + lane, FRg + (size_t)u * 256);
+    wait_vm<0>();
+    __syncthreads();
+    const int tile = blockIdx.x * kCW + wave;
+    const bool tile_ok = tile < Q.ntiles;
+    const int gq = lane >> 4, gcol = tile * 16 + (lane & 15);
+    const bool colok = tile_ok && gcol < Q.B;
+    float up[NKD], dW[NKD], dZ[NKD], k[4][NKD], g[4][NKD], un[NKD];
+#pragma unroll
+    for (int q = 0; q < NKD; ++q) { up[q] = ldc(uprev, Q.D, gcol, 4 * q + gq, colok); dW[q] = ldc(dWc, Q.D, gcol, 4 * q + gq, colok); dZ[q] = ldc(dZc, Q.D, gcol, 4 * q + gq, colok); }
+    float part = sde_attempt<NKD>(Q, FRf, FRg, up, dt, sqrtf(fabsf(dt)), dW, dZ, k, g, un, colok, gq, lane);
+    const size_t A = (size_t)Q.D * Q.B;
+#pragma unroll
+    for (int q = 0; q < NKD; ++q) if (colok && 4 * q + gq < Q.D) {
+        const size_t e = (size_t)gcol * Q.D + 4 * q + gq;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { kg_out[j * A + e] = k[j][q]; kg_out[(4 + j) * A + e] = g[j][q]; }
+        unew_out[e] = un[q];
+    }
+    part = wave_sum_f(part);
+    if (lane == 0) RED[wave] = part;
+    __syncthreads();
+    if (tid == 0) { float s = 0.f; for (int w = 0; w < kCW; ++w) s += RED[w]; part_out[blockIdx.x] = s; }
+}
+
+// ---- reverse sweep: every accepted step backwards, one launch, no meeting between workgroups ----------------------------------
+struct SdeBwdParams {
+    SdeParams F;
+    const float* ubar;       // D x B caller layout
+    float* xbar;             // D x B caller layout
+    const float* svb_acc;    // saveval cotangent per ACCEPTED step (device)
+    const SdeMeta* acc_meta; // meta of the accepted steps, in order (device)
+    int n_acc;
+    BChainParams Cf, Cg;     // per net: G, slab [4 n_acc][ntiles][RS][64], ev_stride, RS, hrow, zrow, ntiles
+};
+static_assert(sizeof(SdeBwdParams) <= 4096, "kernel argument segment");
+
+template <int NKD>
+__global__ __launch_bounds__(64 * kCW) void rnde_sde_bwd_kernel(const SdeBwdParams Bq) {
+    const SdeParams& Q = Bq.F;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int units_f = (Q.Gf.nfrag_f + Q.Gf.nfrag_b + Q.Gf.nfrag_t + 3) >> 2, units_g = (Q.Gg.nfrag_f + Q.Gg.nfrag_b + Q.Gg.nfrag_t + 3) >> 2;
+    float* Ff = smem;
+    float* Fg = smem + (size_t)units_f * 256;
+    for (int u = wave; u < units_f; u += kCW) dma_unit((const f32x4*)(Q.frags_f + (size_t)u * 256) + lane, Ff + (size_t)u * 256);
+    for (int u = wave; u < units_g; u += kCW) dma_unit((const f32x4*)(Q.frags_g + (size_t)u * 256) + lane, Fg + (size_t)u * 256);
+    wait_vm<0>();
+    __syncthreads();
+    const int tile = blockIdx.x * kCW + wave;
+    if (tile >= Q.ntiles) return;
+    const int gq = lane >> 4, gcol = tile * 16 + (lane & 15);
+    const bool colok = gcol < Q.B;
+    const SriTableau& T = Q.T;
+    const BChainParams& Cf = Bq.Cf;   // the two nets as chain_fbwd wants them (kernel-argument memory: their tables stay scalar loads)
+    const BChainParams& Cg = Bq.Cg;
+    const float* FRf = Ff; const float* BFf = Ff + (size_t)Q.Gf.nfrag_f * 64; const float* TFf = BFf + (size_t)Q.Gf.nfrag_b * 64;
+    const float* FRg = Fg; const float* BFg = Fg + (size_t)Q.Gg.nfrag_f * 64; const float* TFg = BFg + (size_t)Q.Gg.nfrag_b * 64;
+    const double N = (double)Q.D * (double)Q.B;
+    const float sqrt3 = 1.7320508075688772f;
+    const size_t as = (size_t)Q.ntiles * NKD * 64;
+    float U[NKD];
+#pragma unroll
+    for (int q = 0; q < NKD; ++q) U[q] = ldc(Bq.ubar, Q.D, gcol, 4 * q + gq, colok);
+    for (int a = Bq.n_acc - 1; a >= 0; --a) {
+        const SdeMeta m = Bq.acc_meta[a];
+        const float dt = m.dt, sqdt = sqrtf(fabsf(dt));
+        const float* R = Q.tape + ((size_t)a * 12 * Q.ntiles + tile) * NKD * 64 + lane;
+        float up[NKD], dW[NKD], dZ[NKD], k[4][NKD], g[4][NKD], kb[4][NKD], gb[4][NKD], upb[NKD], chi2[NKD];
+        const double eb = (Q.reg_kind == 1) ? (double)Bq.svb_acc[a] * (double)dt : 0.0;   // saveval = EEst * dt, dt constant
+        const float coef = m.eest > 0.f ? (float)(eb / (N * (double)m.eest)) : 0.f;
+#pragma unroll
+        for (int q = 0; q < NKD; ++q) {
+            up[q] = R[q * 64]; dW[q] = R[as + q * 64]; dZ[q] = R[2 * as + q * 64];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { k[j][q] = R[(3 + j) * as + q * 64]; g[j][q] = R[(7 + j) * as + q * 64]; }
+            const float un = R[11 * as + q * 64];
+            const float w = dW[q];
+            const float chi1 = (w * w - fabsf(dt)) / (2.f * sqdt);
+            chi2[q] = (w + dZ[q] / sqrt3) / 2.f;
+            const float chi3 = (w * w * w - 3.f * w * dt) / (6.f * dt);
+            float sk_ = 0.f, s3 = 0.f, s4 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { sk_ += k[j][q]; s3 += T.beta3[j] * g[j][q]; s4 += T.beta4[j] * g[j][q]; }
+            float unb = U[q], upv = 0.f, numb = 0.f;
+            if (colok && 4 * q + gq < Q.D) {
+                const float E2 = chi2[q] * s3 + chi3 * s4, E1 = dt * sk_;
+                const float au = fabsf(up[q]), an = fabsf(un);
+                const bool use_new = !(au > an);
+                const float sc = Q.abstol + (use_new ? an : au) * Q.reltol;
+                const float res = (Q.delta * E1 + E2) / sc;
+                const float rb = coef * res;
+                numb = rb / sc;
+                const float scb = -rb * res / sc;
+                if (use_new) unb += scb * Q.reltol * sgnf(un); else upv += scb * Q.reltol * sgnf(up[q]);
+            }
+            upv += unb;
+            const float e2b = unb + numb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                kb[j][q] = dt * T.alpha[j] * unb + dt * Q.delta * numb;
+                gb[j][q] = (w * T.beta1[j] + chi1 * T.beta2[j]) * unb + (chi2[q] * T.beta3[j] + chi3 * T.beta4[j]) * e2b;
+            }
+            upb[q] = upv;
+        }
+#pragma unroll
+        for (int s = 3; s >= 0; --s) {
+            float h0[NKD], h1[NKD], hb[NKD];
+#pragma unroll
+            for (int q = 0; q < NKD; ++q) {
+                float a0 = 0.f, b0 = 0.f, a1 = 0.f, b1 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < s) {
+                        a0 += T.A0[4 * s + j] * k[j][q]; b0 += T.B0[4 * s + j] * g[j][q];
+                        a1 += T.A1[4 * s + j] * k[j][q]; b1 += T.B1[4 * s + j] * g[j][q];
+                    }
+                h0[q] = s ? up[q] + dt * a0 + chi2[q] * b0 : up[q];
+                h1[q] = s ? up[q] + dt * a1 + sqdt * b1 : up[q];
+            }
+            float tau = 0.f;
+            float* slf = Cf.slab + (size_t)(4 * a + s) * Cf.ev_stride + ((size_t)tile * Cf.RS) * 64 + lane;
+            chain_fbwd<NKD, 0>(Cf, FRf, BFf, TFf, 0.f, h0, k[s], kb[s], hb, slf, tau, lane);
+#pragma unroll
+            for (int q = 0; q < NKD; ++q) {
+                upb[q] += hb[q];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (j < s) { kb[j][q] += dt * T.A0[4 * s + j] * hb[q]; gb[j][q] += chi2[q] * T.B0[4 * s + j] * hb[q]; }
+            }
+            float* slg = Cg.slab + (size_t)(4 * a + s) * Cg.ev_stride + ((size_t)tile * Cg.RS) * 64 + lane;
+            chain_fbwd<NKD, 0>(Cg, FRg, BFg, TFg, 0.f, h1, g[s], gb[s], hb, slg, tau, lane);
+#pragma unroll
+            for (int q = 0; q < NKD; ++q) {
+                upb[q] += hb[q];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (j < s) { kb[j][q] += dt * T.A1[4 * s + j] * hb[q]; gb[j][q] += sqdt * T.B1[4 * s + j] * hb[q]; }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NKD; ++q) U[q] = upb[q];
+    }
+#pragma unroll
+    for (int q = 0; q < NKD; ++q) if (colok && 4 * q + gq < Q.D) Bq.xbar[(size_t)gcol * Q.D + 4 * q + gq] = U[q];
+}
+
+// ---- library noise: Philox4x32-10 counter-based generator + Box-Muller, fills a pool in the caller's layout ------------------
+__device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned k0, unsigned k1) {
+    const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+    const unsigned h0 = (unsigned)(p0 >> 32), l0 = (unsigned)p0, h1 = (unsigned)(p1 >> 32), l1 = (unsigned)p1;
+    c[0] = h1 ^ c[1] ^ k0; c[1] = l1; c[2] = h0 ^ c[3] ^ k1; c[3] = l0;
+}
+__global__ void rnde_normal_fill_kernel(float* __restrict__ out, long long n, unsigned long long seed, unsigned long long stream_id) {
+    const long long quads = (n + 3) / 4;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < quads; i += (long long)gridDim.x * 256) {
+        unsigned c[4] = {(unsigned)i, (unsigned)(i >> 32), (unsigned)stream_id, (unsigned)(stream_id >> 32)};
+        unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+        float z[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float u1 = ((float)c[2 * h] + 0.5f) * 2.3283064365386963e-10f;      // (0, 1)
+            const float u2 = ((float)c[2 * h + 1] + 0.5f) * 2.3283064365386963e-10f;
+            const float r = sqrtf(-2.f * logf(u1));
+            float sn, cs;
+            sincosf(6.283185307179586f * u2, &sn, &cs);
+            z[2 * h] = r * cs; z[2 * h + 1] = r * sn;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (4 * i + j < n) out[4 * i + j] = z[j];
+    }
+}
+
+}  // namespace rnde

@@ -1,0 +1,225 @@
+"""GPU parity tests of the stochastic layer (rnde_nsde_*, reference src/models/neural_sde.jl) against the CPU oracle
+(oracle/rnde_sde_oracle.c) on identical inputs AND identical noise (the pool of standard normals both consume in order).
+
+fp32 tolerances, stated per test.  At the reference tolerance (reltol = abstol = 0.14, experiments/mnist_nsde.jl:79-80) the
+error estimate is truncation dominated by orders of magnitude, so -- unlike the ODE at 1.4e-8 -- the accept/reject sequence,
+the number of attempts and the number of noise draws must match the oracle EXACTLY, and dt to 1e-5 relative (powf differs
+by an ulp between the device and libm).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+AGGR = dict(qmax=10.0, gamma=1.0, beta2=1e-9)   # a controller that rejects often (the recalled defaults hardly ever do)
+
+
+def _nets(kind):
+    from oracle.oracle import make_arch
+    from oracle.oracle_sde import arch_nsde_diffusion, arch_nsde_drift
+    if kind == "nsde":          # experiments/mnist_nsde.jl:73-74
+        return arch_nsde_drift(), arch_nsde_diffusion()
+    if kind == "small":
+        return make_arch([3, 5, 3], ["tanh", "identity"], False), make_arch([3, 3], ["identity"], False)
+    if kind == "deep":          # three-layer drift, two-layer tanh diffusion, D = 20 (another k-step count)
+        return make_arch([20, 33, 17, 20], ["tanh", "tanh", "identity"], False), make_arch([20, 9, 20], ["tanh", "identity"], False)
+    if kind == "wide":          # D = 40 -> 16 k-step registers per array
+        return make_arch([40, 64, 40], ["tanh", "identity"], False), make_arch([40, 40], ["tanh"], False)
+    raise KeyError(kind)
+
+
+def _setup(kind, B, seed, n_pool, scale=2.0, dscale=0.5):
+    from oracle.oracle_sde import nsde_params
+    drift, diff = _nets(kind)
+    rng = np.random.default_rng(seed)
+    p = nsde_params(drift, diff, rng, np.float32, scale, dscale)
+    p = (p + 0.05 * rng.standard_normal(len(p))).astype(np.float32)
+    D = drift.dims[0]
+    x = rng.standard_normal((B, D)).astype(np.float32)
+    noise = rng.standard_normal((n_pool, 2, B, D)).astype(np.float32)
+    return drift, diff, p, x, noise
+
+
+def _cfg(drift, diff, B, **kw):
+    from tests.util import make_nsde_cfg
+    dd = [drift.dims[i] for i in range(drift.n_layers + 1)]
+    da = ["tanh" if drift.act[i] else "identity" for i in range(drift.n_layers)]
+    gd = [diff.dims[i] for i in range(diff.n_layers + 1)]
+    ga = ["tanh" if diff.act[i] else "identity" for i in range(diff.n_layers)]
+    return make_nsde_cfg(dd, da, gd, ga, B, **kw)
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.mark.parametrize("kind,B,solver", [("nsde", 16, "SOSRI"), ("nsde", 37, "SOSRI"), ("small", 5, "SOSRI"), ("small", 1, "SRIW1"),
+                                           ("deep", 21, "SOSRI2"), ("wide", 19, "SOSRI")])
+def test_attempt_matches_oracle(kind, B, solver):
+    """One attempted step from a given (uprev, dt, dW, dZ): the eight stage values, the proposed state and the error estimate.
+    Differences: association order of the fp32 dot products (MFMA chains vs sequential) and 1-ulp tanh -> 2e-5 abs on O(1) values."""
+    from oracle.oracle_sde import SdeOracle
+    from tests.util import NsdeNode
+    drift, diff, p, x, noise = _setup(kind, B, 3, 1)
+    dt = 0.07
+    dW, dZ = np.sqrt(dt) * noise[0, 0], np.sqrt(dt) * noise[0, 1]
+    o32 = SdeOracle(drift, diff, np.float32, tableau=solver)
+    o64 = SdeOracle(drift, diff, np.float64, tableau=solver)
+    kg_ref, un_ref, e_ref = o32.attempt(p, x, dt, dW, dZ)
+    _, un64, e64 = o64.attempt(p, x, dt, dW, dZ)
+    node = NsdeNode(_cfg(drift, diff, B, solver=solver))
+    kg, un, e = node.attempt(x, p, dt, dW, dZ)
+    assert np.abs(kg - kg_ref).max() <= 2e-5 * max(1.0, np.abs(kg_ref).max())
+    assert np.abs(un - un64).max() <= 2e-5 * max(1.0, np.abs(un64).max())
+    assert abs(e - e64) <= 2e-5 * e64 + 1e-6 and abs(e_ref - e64) <= 2e-5 * e64 + 1e-6
+    node.close()
+
+
+@pytest.mark.parametrize("kind,B,tol,ctrl,solver", [("nsde", 64, 0.14, {}, "SOSRI"), ("nsde", 37, 0.14, AGGR, "SOSRI"), ("small", 7, 0.05, AGGR, "SOSRI"),
+                                                    ("deep", 21, 0.1, AGGR, "SOSRI2"), ("small", 3, 0.05, AGGR, "SRIW1"), ("wide", 33, 0.14, AGGR, "SOSRI")])
+def test_solve_matches_oracle_on_the_same_noise(kind, B, tol, ctrl, solver):
+    """Whole solve: same accept/reject sequence, same number of attempts and of noise draws, NFE counters, saved values and
+    u(t1) (2e-4 relative: the trajectory amplifies stage-level rounding over ~60 steps)."""
+    from oracle.oracle_sde import SdeOracle
+    from tests.util import NsdeNode
+    drift, diff, p, x, noise = _setup(kind, B, 5, 400)
+    o = SdeOracle(drift, diff, np.float32, tol, tol, tableau=solver, max_attempts=399, **ctrl)
+    ref = o.forward(x, p, noise)
+    assert ref["rc"] == 0
+    node = NsdeNode(_cfg(drift, diff, B, reltol=tol, abstol=tol, solver=solver, max_attempts=399, **ctrl))
+    got = node.forward(x, p, noise)
+    if ctrl:
+        assert (ref["steps"][:, 3] == 0).sum() >= 3, "this case is meant to exercise rejections"
+    assert got["nattempts"] == ref["nattempts"] and np.array_equal(got["steps"][:, 3], ref["steps"][:, 3])
+    assert got["ndraws"] == ref["ndraws"]
+    assert got["nfe1"] == ref["nfe1"] == 2 + 4 * ref["nattempts"] and got["nfe2"] == ref["nfe2"]
+    assert np.allclose(got["steps"][:, 1], ref["steps"][:, 1], rtol=2e-5, atol=0) and np.allclose(got["steps"][:, 0], ref["steps"][:, 0], rtol=2e-5, atol=1e-7)
+    assert np.allclose(got["steps"][:, 2], ref["steps"][:, 2], rtol=5e-4, atol=1e-6)
+    assert len(got["saveval"]) == len(ref["saveval"]) and np.allclose(got["saveval"], ref["saveval"], rtol=5e-4, atol=1e-7)
+    assert _rel(got["u"], ref["u"]) <= 2e-4
+    node.close()
+
+
+@pytest.mark.parametrize("kind,B,tol,ctrl", [("nsde", 48, 0.14, {}), ("nsde", 21, 0.14, AGGR), ("small", 6, 0.05, AGGR), ("deep", 17, 0.1, AGGR)])
+def test_reverse_pass_matches_oracle(kind, B, tol, ctrl):
+    """x_bar, p_bar for cotangents on u(t1) and on every saved EEst*dt, against the fp32 and fp64 oracle along the same
+    (replayed) sequence.  Bound: 2e-3 of the largest entry plus the case's own fp32-vs-fp64 spread."""
+    from oracle.oracle_sde import SdeOracle
+    from tests.util import NsdeNode
+    drift, diff, p, x, noise = _setup(kind, B, 9, 400)
+    rng = np.random.default_rng(1)
+    o32 = SdeOracle(drift, diff, np.float32, tol, tol, max_attempts=399, **ctrl)
+    r32 = o32.forward(x, p, noise)
+    ubar = rng.standard_normal(x.shape).astype(np.float32) / B
+    svbar = (rng.standard_normal(len(r32["saveval"])) * 0.3).astype(np.float32)
+    g32 = o32.backward(ubar, svbar)
+    o64 = SdeOracle(drift, diff, np.float64, tol, tol, max_attempts=399, **ctrl)
+    o64.set_replay(r32["steps"][:, 1], r32["steps"][:, 3].astype(np.int32))
+    r64 = o64.forward(x, p, noise)
+    assert r64["nattempts"] == r32["nattempts"]
+    g64 = o64.backward(ubar, svbar)
+    node = NsdeNode(_cfg(drift, diff, B, reltol=tol, abstol=tol, max_attempts=399, **ctrl))
+    got = node.forward(x, p, noise, keep_tape=True)
+    assert np.array_equal(got["steps"][:, 3], r32["steps"][:, 3])
+    xb, pb = node.backward(ubar, svbar)
+    for name, a, b32, b64 in (("x_bar", xb, g32[0], g64[0]), ("p_bar", pb, g32[1], g64[1])):
+        scale = np.abs(b64).max()
+        spread = np.abs(np.asarray(b32, np.float64) - b64).max()
+        err = np.abs(np.asarray(a, np.float64) - b64).max()
+        print(f"{kind} B={B} {name}: device-fp64 {err / scale:.2e}, fp32 oracle-fp64 {spread / scale:.2e}")
+        assert err <= 2e-3 * scale + 3 * spread, (name, err, scale, spread)
+    # drift and diffusion gradients both populated
+    assert np.abs(pb[:node.len]).max() > 0 and np.abs(pb[node.len:]).max() > 0
+    node.close()
+
+
+def test_config5_full_size_vs_fp64_oracle():
+    """BASELINE config 5: D = 32, drift 32 -> 64 -> 32, diffusion 32 -> 32, B = 512, trajectories = 1, tol 0.14 (reference
+    experiments/mnist_nsde.jl:70-84,:96), forward + reverse with lambda = 10 on mean(saveval) (:47-48, :99)."""
+    from oracle.oracle_sde import SdeOracle
+    from tests.util import NsdeNode
+    B = 512
+    drift, diff, p, x, noise = _setup("nsde", B, 21, 257, scale=1.0, dscale=1.0)
+    o64 = SdeOracle(drift, diff, np.float64, max_attempts=256)
+    r64 = o64.forward(x, p, noise)
+    assert r64["rc"] == 0
+    node = NsdeNode(_cfg(drift, diff, B, max_attempts=256))
+    got = node.forward(x, p, noise, keep_tape=True)
+    print(f"config 5: attempts {got['nattempts']} (fp64 oracle {r64['nattempts']}), nfe1 = nfe2 = {got['nfe1']}, draws {got['ndraws']}")
+    assert got["nattempts"] == r64["nattempts"] and np.array_equal(got["steps"][:, 3], r64["steps"][:, 3])
+    assert got["nfe1"] == r64["nfe1"] and got["nfe2"] == r64["nfe2"] and got["ndraws"] == r64["ndraws"]
+    assert _rel(got["u"], r64["u"]) <= 2e-4
+    assert np.allclose(got["saveval"], r64["saveval"], rtol=5e-4, atol=1e-7)
+    rng = np.random.default_rng(2)
+    ubar = (rng.standard_normal(x.shape) / B).astype(np.float32)
+    svbar = np.full(len(got["saveval"]), 10.0 / len(got["saveval"]), np.float32)
+    xb, pb = node.backward(ubar, svbar)
+    g64 = o64.backward(ubar, svbar)
+    ex, ep = _rel(xb, g64[0]), _rel(pb, g64[1])
+    print(f"config 5 reverse vs fp64 oracle: x_bar {ex:.2e}, p_bar {ep:.2e}")
+    assert ex <= 1e-3 and ep <= 1e-3
+    node.close()
+
+
+def test_replay_and_fixed_step_mode():
+    """rnde_nsde_forward_replay: a fixed-step run (all accepted, equal dt) and a replayed adaptive sequence reproduce the oracle."""
+    from oracle.oracle_sde import SdeOracle
+    from tests.util import NsdeNode
+    drift, diff, p, x, noise = _setup("nsde", 32, 13, 80)
+    n = 20
+    o = SdeOracle(drift, diff, np.float32, max_attempts=79)
+    o.set_replay(np.full(n, 1.0 / n, np.float32), np.ones(n, np.int32))
+    ref = o.forward(x, p, noise)
+    node = NsdeNode(_cfg(drift, diff, 32, max_attempts=79))
+    got = node.forward(x, p, noise, replay=np.stack([np.full(n, 1.0 / n), np.ones(n)], 1))
+    assert got["nattempts"] == n == ref["nattempts"] and got["ndraws"] == ref["ndraws"] == n
+    assert _rel(got["u"], ref["u"]) <= 1e-4
+    node.close()
+
+
+def test_library_noise_stream_is_standard_normal_and_reproducible():
+    """noise_dev = NULL: the library's Philox4x32-10 + Box-Muller stream.  Moments of 4M samples within 5 sigma, no
+    correlation between neighbours, the same seed gives the same solve and another seed another one."""
+    import ctypes as C
+    import torch
+    from regneuralde_jl_amd import _lib
+    from tests.util import NsdeNode
+    L = _lib.lib()
+    n = 1 << 22
+    buf = torch.empty(n, dtype=torch.float32, device="cuda")
+    assert L.rnde_normal_fill(buf.data_ptr(), n, 1234, 7, None) == 0
+    torch.cuda.synchronize()
+    z = buf.cpu().numpy().astype(np.float64)
+    s = 5.0 / np.sqrt(n)
+    assert abs(z.mean()) < s and abs(z.var() - 1) < s * np.sqrt(2) and abs((z ** 3).mean()) < s * np.sqrt(15) and abs((z ** 4).mean() - 3) < s * np.sqrt(96)
+    assert abs(np.mean(z[:-1] * z[1:])) < s and abs(np.mean(z[:-4:4] * z[2::4][:len(z[:-4:4])])) < 2 * s
+    assert np.abs(z).max() < 6.5 and (np.abs(z) > 4).mean() < 2e-4
+    buf2 = torch.empty(n, dtype=torch.float32, device="cuda")
+    L.rnde_normal_fill(buf2.data_ptr(), n, 1234, 8, None)
+    torch.cuda.synchronize()
+    assert abs(np.mean(z * buf2.cpu().numpy())) < s      # streams are independent
+    drift, diff, p, x, _ = _setup("nsde", 64, 2, 1)
+    node = NsdeNode(_cfg(drift, diff, 64))
+    a = node.forward(x, p, None, seed=99)
+    b = node.forward(x, p, None, seed=99)
+    c = node.forward(x, p, None, seed=100)
+    assert np.array_equal(a["u"], b["u"]) and a["nattempts"] == b["nattempts"]
+    assert not np.array_equal(a["u"], c["u"])
+    assert a["nfe1"] == 2 + 4 * a["nattempts"] == a["nfe2"]
+    node.close()
+
+
+def test_error_paths():
+    from regneuralde_jl_amd import _lib
+    from tests.util import NsdeNode
+    drift, diff, p, x, noise = _setup("nsde", 16, 1, 4)
+    node = NsdeNode(_cfg(drift, diff, 16, max_attempts=100))
+    r = node.forward(x, p, noise, check=False)                 # 4 draws cannot cover ~60 attempts
+    assert r["rc"] == _lib.BAD_ARG and b"noise pool" in node.L.rnde_nsde_last_error(node.h)
+    with pytest.raises(_lib.RndeError):
+        node.backward(np.zeros_like(x))                        # no tape
+    node2 = NsdeNode(_cfg(drift, diff, 16, max_attempts=5))
+    r = node2.forward(x, p, np.random.default_rng(0).standard_normal((8, 2, 16, 32)).astype(np.float32), check=False)
+    assert r["rc"] == _lib.MAX_ATTEMPTS
+    node.close(); node2.close()

@@ -140,3 +140,100 @@ def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+# ---- stochastic layer (rnde_nsde_*) ------------------------------------------------------------------------------------
+def make_nsde_cfg(drift_dims, drift_acts, diff_dims, diff_acts, max_batch, reltol=0.14, abstol=0.14, solver="SOSRI", regularize=1,
+                  cb_save_start=1, max_attempts=256, **ctrl):
+    cfg = _lib.NsdeConfig()
+    cfg.drift_layers = len(drift_acts)
+    for i, d in enumerate(drift_dims):
+        cfg.drift_dims[i] = d
+    for i, a in enumerate(drift_acts):
+        cfg.drift_act[i] = {"identity": 0, "tanh": 1}[a]
+    cfg.diff_layers = len(diff_acts)
+    for i, d in enumerate(diff_dims):
+        cfg.diff_dims[i] = d
+    for i, a in enumerate(diff_acts):
+        cfg.diff_act[i] = {"identity": 0, "tanh": 1}[a]
+    cfg.max_batch = max_batch
+    cfg.solver = _lib.SDE_SOLVER[solver]
+    cfg.reltol, cfg.abstol = reltol, abstol
+    cfg.regularize, cfg.cb_save_start, cfg.max_attempts, cfg.device = regularize, cb_save_start, max_attempts, 0
+    for k in ("beta1", "beta2", "gamma", "qmin", "qmax", "qoldinit", "delta"):
+        setattr(cfg, k, ctrl.get(k, 0.0))
+    return cfg
+
+
+class NsdeNode:
+    """Thin wrapper over the C ABI handle of the stochastic layer (device pointers in, device pointers out)."""
+
+    def __init__(self, cfg):
+        self.L = _lib.lib()
+        self.h = C.c_void_p()
+        _lib.check_nsde(None, self.L.rnde_nsde_create(C.byref(cfg), C.byref(self.h)))
+        self.cfg = cfg
+        self.D = cfg.drift_dims[0]
+        ld = C.c_int32(0)
+        self.P = self.L.rnde_nsde_param_count(C.byref(cfg), C.byref(ld))
+        self.len = ld.value
+
+    def close(self):
+        if self.h:
+            self.L.rnde_nsde_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    dev = staticmethod(Node.dev)
+
+    def attempt(self, uprev, p, dt, dW, dZ):
+        B = uprev.shape[0]
+        ud, pd, wd, zd = self.dev(uprev), self.dev(p), self.dev(dW), self.dev(dZ)
+        kg = torch.empty((8, B, self.D), dtype=torch.float32, device="cuda")
+        un = torch.empty_like(ud)
+        e = C.c_float(0)
+        _lib.check_nsde(self.h, self.L.rnde_nsde_debug_attempt(self.h, ud.data_ptr(), pd.data_ptr(), B, dt, wd.data_ptr(), zd.data_ptr(),
+                                                               kg.data_ptr(), un.data_ptr(), C.byref(e), None))
+        return kg.cpu().numpy(), un.cpu().numpy(), e.value
+
+    def _log(self):
+        steps = (C.c_float * (4 * self.cfg.max_attempts))()
+        natt, ndr = C.c_int32(0), C.c_int32(0)
+        self.L.rnde_nsde_steps(self.h, steps, self.cfg.max_attempts, C.byref(natt), C.byref(ndr))
+        return np.array(steps[:4 * natt.value], dtype=np.float32).reshape(-1, 4), natt.value, ndr.value
+
+    def forward(self, x, p, noise=None, seed=0, t0=0.0, t1=1.0, keep_tape=False, replay=None, check=True):
+        """noise: (n_pool, 2, B, D) standard normals or None (library stream from `seed`); replay: (n, 2) array of (dt, accepted)."""
+        B = x.shape[0]
+        xd, pd = self.dev(x), self.dev(p)
+        nd = None if noise is None else self.dev(noise)
+        u = torch.empty_like(xd)
+        n1, n2, nsv = C.c_int64(0), C.c_int64(0), C.c_int32(0)
+        sv = (C.c_float * (self.cfg.max_attempts + 1))()
+        npool = 0 if noise is None else noise.shape[0]
+        if replay is None:
+            st = self.L.rnde_nsde_forward(self.h, xd.data_ptr(), pd.data_ptr(), B, t0, t1, nd.data_ptr() if nd is not None else None, npool,
+                                          seed, u.data_ptr(), C.byref(n1), C.byref(n2), sv, C.byref(nsv), int(keep_tape), None)
+        else:
+            rp = np.ascontiguousarray(replay, dtype=np.float32)
+            st = self.L.rnde_nsde_forward_replay(self.h, xd.data_ptr(), pd.data_ptr(), B, t0, t1, nd.data_ptr(), npool,
+                                                 rp.ctypes.data_as(C.POINTER(C.c_float)), rp.shape[0], u.data_ptr(), C.byref(n1), C.byref(n2), sv,
+                                                 C.byref(nsv), int(keep_tape), None)
+        if check:
+            _lib.check_nsde(self.h, st)
+        steps, natt, ndr = self._log()
+        return dict(rc=st, u=u.cpu().numpy(), nfe1=n1.value, nfe2=n2.value, saveval=np.array(sv[:nsv.value], dtype=np.float32), steps=steps,
+                    nattempts=natt, ndraws=ndr)
+
+    def backward(self, ubar, svbar=None):
+        ub = self.dev(ubar)
+        xb = torch.empty_like(ub)
+        pb = torch.empty(self.P, dtype=torch.float32, device="cuda")
+        svb = None if svbar is None else (C.c_float * len(svbar))(*[float(v) for v in svbar])
+        _lib.check_nsde(self.h, self.L.rnde_nsde_backward(self.h, ub.data_ptr(), svb, xb.data_ptr(), pb.data_ptr(), None))
+        return xb.cpu().numpy(), pb.cpu().numpy()

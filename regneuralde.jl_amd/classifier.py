@@ -52,7 +52,10 @@ def fused_loss_and_grad(model, x, y, lam=1.0e2, regularize=True, tspan=None, syn
     from . import _lib
     node = model.node
     L = _lib.lib()
-    x2 = x.reshape(x.shape[0], -1).to(torch.float32).contiguous()
+    from .node import _check_f32
+    for name, t in (("x", x), ("y", y), ("p2", model.p2), ("p3", model.p3)):
+        _check_f32(name, t)
+    x2 = x.reshape(x.shape[0], -1).contiguous()
     B, D = x2.shape
     node._func = "error_est" if node.regularize else None
     h = node._acquire(x2, True)

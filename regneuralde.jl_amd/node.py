@@ -47,6 +47,40 @@ class _Handle:
             pass
 
 
+class _TapeToken:
+    """Lifetime of one taped forward.  It lives in the autograd node's ctx: when the graph is dropped WITHOUT a backward pass
+    (the reference's per-epoch `_, nfe, _ = node(dummy)` with tracking on, experiments/mnist_node.jl:236) the token dies with
+    it, releases the tape and hands the handle back to the pool -- otherwise every such call would pin a handle and its
+    max_attempts arena (~4 GB at B = 512) for good."""
+
+    def __init__(self, h, release):
+        self.h, self.release, self.done = h, release, False
+
+    def finish(self):
+        if not self.done:
+            self.done = True
+            self.h.busy = False
+
+    def __del__(self):
+        try:
+            if not self.done:
+                self.done = True
+                if self.h.ptr:
+                    self.release(self.h.ptr)
+                self.h.busy = False
+        except Exception:
+            pass
+
+
+MAX_HANDLES_PER_KEY = 4   # simultaneously pending (taped, not yet back-propagated) forwards per layer, device and callback
+
+
+def _check_f32(name, t):
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32 (got {t.dtype}): the C ABI reads raw fp32 memory; convert explicitly, "
+                        "as the reference does with eltype(p)")
+
+
 class _Solve(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, p, layer, t0, t1, keep_tape, saveat):
@@ -73,6 +107,7 @@ class _Solve(torch.autograd.Function):
         ctx.layer, ctx.h, ctx.nsv = layer, h, nsv.value
         if keep_tape:
             h.busy = True
+            ctx.token = _TapeToken(h, L.rnde_node_release_tape)
         return u, saveval
 
     @staticmethod
@@ -88,7 +123,7 @@ class _Solve(torch.autograd.Function):
         tsb = (C.c_float * 2)()
         stream = torch.cuda.current_stream(u_bar.device).cuda_stream
         st = L.rnde_node_backward(h.ptr, u_bar.data_ptr(), svb, x_bar.data_ptr(), p_bar.data_ptr(), tsb, C.c_void_p(stream))
-        h.busy = False
+        ctx.token.finish()
         _lib.check(h.ptr, st)
         layer.last_tspan_bar = (tsb[0], tsb[1])
         return x_bar, p_bar, None, None, None, None, None
@@ -150,6 +185,9 @@ class TrackedNeuralODE:
         for h in hs:
             if not h.busy:
                 return h
+        if len(hs) >= MAX_HANDLES_PER_KEY:
+            raise RuntimeError(f"{len(hs)} taped forwards of this layer are pending without a backward pass; each owns a tape of "
+                               "max_attempts records.  Run them under torch.no_grad() (NFE probes), call backward, or drop the graphs")
         h = _Handle(self._config(x.device.index or 0, self._func))
         hs.append(h)
         return h
@@ -188,7 +226,9 @@ class TrackedNeuralODE:
                 self.p = p = self.p.to(x.device)
             else:
                 raise RuntimeError("p and x must live on the same device")
-        x2 = x.reshape(x.shape[0], -1).to(torch.float32).contiguous()
+        _check_f32("p", p)
+        _check_f32("x", x)
+        x2 = x.reshape(x.shape[0], -1).contiguous()
         ts = self.tspan if tspan is None else [float(tspan[0]), float(tspan[1])]   # _convert_tspan, utils.jl:21-23
         if func not in _FUNCS:
             raise ValueError("func must be one of None/'error_est', 'stiff_est', 'error_stiff_est' "

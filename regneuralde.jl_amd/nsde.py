@@ -1,0 +1,206 @@
+"""TrackedNeuralDSDE and ClassifierNSDE: the reference's stochastic layer (src/models/neural_sde.jl) and its caller
+(src/models/supervised_classification.jl:50-103), same constructors and call contracts, with the `solve` call replaced by
+librnde.so (rnde_nsde_*: the whole adaptive SOSRI solve is one kernel launch).
+
+    nsde = TrackedNeuralDSDE(Chain(Dense(32, 64, "tanh"), Dense(64, 32)), Chain(Dense(32, 32)), [0.0, 1.0], regularize, "SOSRI",
+                             save_everystep=False, reltol=1.4e-1, abstol=1.4e-1, save_start=False)     # experiments/mnist_nsde.jl:72-84
+    u, nfe1, nfe2, sv = nsde(x, p)          # x: (B, D) cuda tensor == Julia D x B
+
+Differences inherent to the host language / the device: `func` is the reference's EEst*dt callback (neural_sde.jl:87) or none;
+the {R,true} methods (save_everystep / saveat, :44-61,:84-113; used only by experiments/sde_toy_problem.jl) are not built;
+the noise comes from the library's Philox stream (seed = nsde.seed, advanced every call) unless `noise=` passes a pool of
+standard normals of shape (n_pool, 2, B, D) -- a Julia caller would fill that from its own RNG.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .layers import Chain, Dense, destructure
+from .node import MAX_HANDLES_PER_KEY, SavedValues, _check_f32, _TapeToken
+
+_ACT = {"identity": 0, "tanh": 1}
+
+
+class _NsdeHandle:
+    def __init__(self, cfg):
+        self.ptr = C.c_void_p()
+        _lib.check_nsde(None, _lib.lib().rnde_nsde_create(C.byref(cfg), C.byref(self.ptr)))
+        self.busy = False
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                _lib.lib().rnde_nsde_destroy(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+class _SdeSolve(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, layer, keep_tape, noise, seed):
+        h = layer._acquire(x)
+        L = _lib.lib()
+        B, D = x.shape
+        n1, n2, nsv = C.c_int64(0), C.c_int64(0), C.c_int32(0)
+        sv_host = (C.c_float * (layer.max_attempts + 1))()
+        stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        u = torch.empty_like(x)
+        st = L.rnde_nsde_forward(h.ptr, x.data_ptr(), p.data_ptr(), B, layer.tspan[0], layer.tspan[1],
+                                 noise.data_ptr() if noise is not None else None, 0 if noise is None else noise.shape[0], seed,
+                                 u.data_ptr(), C.byref(n1), C.byref(n2), sv_host, C.byref(nsv), 1 if keep_tape else 0, stream)
+        _lib.check_nsde(h.ptr, st)
+        layer.last_nfe = (int(n1.value), int(n2.value))
+        saveval = torch.tensor(list(sv_host[:nsv.value]), dtype=torch.float32, device=x.device)
+        ctx.layer, ctx.h, ctx.nsv = layer, h, nsv.value
+        if keep_tape:
+            h.busy = True
+            ctx.token = _TapeToken(h, lambda ptr: None)     # the SDE tape needs no release call: freeing the handle for reuse is enough
+        return u, saveval
+
+    @staticmethod
+    def backward(ctx, u_bar, sv_bar):
+        layer, h = ctx.layer, ctx.h
+        u_bar = u_bar.contiguous().to(torch.float32)
+        x_bar = torch.empty_like(u_bar)
+        p_bar = torch.empty(layer.P, dtype=torch.float32, device=u_bar.device)
+        svb = None
+        if ctx.nsv and sv_bar is not None:
+            svb = (C.c_float * ctx.nsv)(*sv_bar.detach().to("cpu", torch.float32).tolist())
+        stream = C.c_void_p(torch.cuda.current_stream(u_bar.device).cuda_stream)
+        st = _lib.lib().rnde_nsde_backward(h.ptr, u_bar.data_ptr(), svb, x_bar.data_ptr(), p_bar.data_ptr(), stream)
+        ctx.token.finish()
+        _lib.check_nsde(h.ptr, st)
+        return x_bar, p_bar, None, None, None, None
+
+
+class TrackedNeuralDSDE:
+    """Mirror of reference src/models/neural_sde.jl:1-41 (struct + constructor) and :64-82,:116-146 (the {R,false} call methods)."""
+
+    def __init__(self, model1, model2, tspan, regularize, solver="SOSRI", *, max_batch=512, max_attempts=256, cb_save_start=True,
+                 seed=0, **kwargs):
+        if solver not in _lib.SDE_SOLVER:
+            raise ValueError("solver: SOSRI (experiments/mnist_nsde.jl:49,:63), SOSRI2 or SRIW1")
+        if isinstance(model2, Dense):
+            model2 = Chain(model2)
+        if kwargs.get("save_everystep", False) or "saveat" in kwargs:
+            raise NotImplementedError("the {R,true} methods (save_everystep / saveat, neural_sde.jl:44-61,:84-113) are not built: "
+                                      "the MNIST experiment uses save_everystep=false (mnist_nsde.jl:78)")
+        if model1.time_dep or model2.time_dep:
+            raise ValueError("drift and diffusion are time independent (neural_sde.jl:45-52 call re(p)(u))")
+        self.model1, self.model2 = model1, model2
+        p1, p2 = destructure(model1), destructure(model2)
+        self.p = torch.cat([p1, p2])                       # neural_sde.jl:17
+        self.len = p1.numel()                              # neural_sde.jl:38
+        self.P = self.p.numel()
+        self.tspan = [float(tspan[0]), float(tspan[1])]
+        self.regularize = bool(regularize)
+        self.solver, self.kwargs = solver, dict(kwargs)
+        self.max_batch, self.max_attempts, self.cb_save_start = int(max_batch), int(max_attempts), bool(cb_save_start)
+        self.seed = int(seed)
+        self._handles = {}
+        self.last_nfe = None
+
+    def _config(self, device_index):
+        cfg = _lib.NsdeConfig()
+        for name, model in (("drift", self.model1), ("diff", self.model2)):
+            dims = model.dims()
+            setattr(cfg, f"{name}_layers", len(model.layers))
+            for i, d in enumerate(dims):
+                getattr(cfg, f"{name}_dims")[i] = d
+            for i, l in enumerate(model.layers):
+                getattr(cfg, f"{name}_act")[i] = _ACT[l.act]
+        cfg.max_batch = self.max_batch
+        cfg.solver = _lib.SDE_SOLVER[self.solver]
+        cfg.reltol = float(self.kwargs.get("reltol", 1e-2))   # StochasticDiffEq defaults when not given
+        cfg.abstol = float(self.kwargs.get("abstol", 1e-2))
+        cfg.regularize = 1 if self.regularize else 0
+        cfg.cb_save_start = int(self.cb_save_start)
+        cfg.max_attempts = self.max_attempts
+        cfg.device = device_index
+        return cfg
+
+    def _acquire(self, x):
+        key = x.device.index or 0
+        hs = self._handles.setdefault(key, [])
+        for h in hs:
+            if not h.busy:
+                return h
+        if len(hs) >= MAX_HANDLES_PER_KEY:
+            raise RuntimeError(f"{len(hs)} taped forwards of this layer are pending without a backward pass")
+        h = _NsdeHandle(self._config(key))
+        hs.append(h)
+        return h
+
+    def __call__(self, x, p=None, func=None, noise=None):
+        """(x, p = n.p; func) -> (arr, nfe1, nfe2, sv)   [neural_sde.jl:64-82, :116-146]"""
+        if not x.is_cuda:
+            raise RuntimeError("TrackedNeuralDSDE runs on the MI355X only: x must be a cuda tensor (no CPU fallback)")
+        if func not in (None, "error_est"):
+            raise ValueError("func: the reference's SDE callback is EEst*dt ('error_est', neural_sde.jl:87) or none")
+        p = self.p if p is None else p
+        if p.device != x.device:
+            if p is self.p:
+                self.p = p = self.p.to(x.device)
+            else:
+                raise RuntimeError("p and x must live on the same device")
+        _check_f32("p", p)
+        _check_f32("x", x)
+        if noise is not None:
+            _check_f32("noise", noise)
+            if tuple(noise.shape[1:]) != (2, x.shape[0], x.shape[1]) or not noise.is_cuda:
+                raise ValueError("noise: cuda tensor of shape (n_pool, 2, B, D)")
+            noise = noise.contiguous()
+        keep = torch.is_grad_enabled() and (x.requires_grad or p.requires_grad)
+        self.seed += 1
+        u, saveval = _SdeSolve.apply(x.contiguous(), p.contiguous(), self, keep, noise, self.seed)
+        nfe1, nfe2 = self.last_nfe                         # n.nfes, reset after the solve (neural_sde.jl:78-79,:142-143)
+        return u, nfe1, nfe2, (SavedValues(saveval) if self.regularize else None)
+
+
+def _expand(x, d):
+    """supervised_classification.jl:102-103: repeat along the batch dimension (Julia's last dimension = torch's first)."""
+    return x.repeat(d, *([1] * (x.dim() - 1)))
+
+
+class ClassifierNSDE:
+    """Mirror of reference src/models/supervised_classification.jl:50-100: presde -> nsde -> postsde, `trajectories` sample
+    paths per input, logits averaged over them."""
+
+    def __init__(self, presde, nsde, postsde, device=None):
+        self.nsde = nsde
+        self.pre_shape, self.post_shape = (presde.n_in, presde.n_out), (postsde.n_in, postsde.n_out)
+        dev = device if device is not None else torch.device("cuda", 0)
+        self.p1 = destructure(Chain(presde)).to(dev).requires_grad_(True)
+        self.p2 = nsde.p.to(dev).requires_grad_(True)
+        self.p3 = destructure(Chain(postsde)).to(dev).requires_grad_(True)
+
+    def trainable(self):                                   # Flux.trainable(m::ClassifierNSDE) = (m.p1, m.p2, m.p3)
+        return (self.p1, self.p2, self.p3)
+
+    @staticmethod
+    def _dense(x, p, shape):
+        n_in, n_out = shape
+        return x @ p[: n_in * n_out].view(n_in, n_out) + p[n_in * n_out:]
+
+    def __call__(self, x, p1=None, p2=None, p3=None, trajectories=10, **nsde_kwargs):
+        p1 = self.p1 if p1 is None else p1
+        p2 = self.p2 if p2 is None else p2
+        p3 = self.p3 if p3 is None else p3
+        bsize = x.shape[0]
+        x = _expand(x.reshape(bsize, -1), trajectories)                           # :92 (batch order: trajectory-major, as repeat gives)
+        h = self._dense(x, p1, self.pre_shape)                                   # :93-94
+        u, nfe1, nfe2, sv = self.nsde(h.contiguous(), p2, **nsde_kwargs)         # :95
+        z = self._dense(u, p3, self.post_shape)                                  # :96-97
+        z = z.reshape(trajectories, bsize, -1).mean(dim=0)                       # :98
+        return z, nfe1, nfe2, sv
+
+
+def nsde_loss_function(x, y, model, p1=None, p2=None, p3=None, trajectories=1, lam=1.0e2, regularize=True, agg=torch.mean):
+    """experiments/mnist_nsde.jl:88-118 (without the logger): logitcrossentropy(pred, y) + lambda * agg(sv.saveval)."""
+    from .classifier import logitcrossentropy
+    pred, nfe1, nfe2, sv = model(x, p1, p2, p3, trajectories=trajectories, func="error_est" if regularize else None)
+    ce = logitcrossentropy(pred, y)
+    reg = lam * agg(sv.saveval) if (regularize and sv is not None) else torch.zeros((), device=pred.device)
+    return ce + reg, ce, reg, nfe1, nfe2

@@ -7,18 +7,21 @@ update -- on one batch of 512 synthetic MNIST-shaped images per GPU, already res
 N > 1: one process per GPU (torchrun), batch sharded 512 per rank (weak scaling, config "batch 4096 sharded
 8xMI355X"), one RCCL all-reduce of the flat gradient (166,418 fp32) per step.
 
-Prints ONE JSON line on rank 0.  Extra objects:
-  roofline      the dominant kernel (rnde_step_kernel = one attempted Tsit5 step) timed live with HIP events
+Prints ONE JSON line on rank 0.  Besides the contract's keys:
+  value_fixed_weights   the same K steps with the weights restored after every update (the optimiser still runs): NFE does not
+                        drift with the number of steps, so this number is comparable across --steps/--warmup choices
+  attempts_per_step, us_per_attempt_fwd / _rev, rev_rest_ms, persist_fallback   NFE-independent companions (HIP events)
+  roofline      the dominant kernel (the TAPED attempted-step kernel, as a training step runs it) timed live with HIP events
   cpu_baseline  the CPU restatement (oracle/, OpenMP) timed on a bounded sample of the same workload
+  other_workloads   N = 1 only: config 4 (latent-ODE dynamics, chain engine) and config 5 (MNIST neural SDE) records
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -29,9 +32,11 @@ ALG_BYTES = lambda B: 34 * 4 * D * B + 6 * 4 * P_DYN   # 34 A + 
 ALG_FLOPS = lambda B: 6 * 2 * B * ((D + 1) * H + (H + 1) * D)
 HBM_PEAK_GBS = 8000.0                              # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3
+PROFILE_ROUND = "r02"
 
 
 def build_model(rn, device, batch, seed=1999):
+    import torch
     g = torch.Generator().manual_seed(seed)
     dyn = rn.MLPDynamics(D, H, generator=g)
     node = rn.TrackedNeuralODE(dyn, [0.0, 1.0], True, True, "Tsit5", save_everystep=False, reltol=1.4e-8,
@@ -76,14 +81,13 @@ def cpu_baseline(batch=512, steps=2):
 
 def bench_latent(args):
     """SURVEY.md 8d config 4 ("latent ODE dynamics only, for the kernel benchmark"): gen_dynamics of experiments/latent_ode.jl:113-124
-    (tanh + 8 x Dense(20<->50, tanh), P = 8,280), B = 512, 49 saveat points on [0, 1], Tsit5 at 1.4e-8; forward + reverse of the layer
-    call.  Not the headline metric: printed only with --workload latent."""
-    import ctypes as C
+    (tanh + 8 x Dense(20<->50, tanh), P = 8,280), B = 512, 49 saveat points on [0, 1], Tsit5 at 1.4e-8; forward + reverse of the layer call."""
+    import torch
     import regneuralde_jl_amd as rn
     from regneuralde_jl_amd import _lib
     device = torch.device("cuda", 0)
     torch.cuda.set_device(0)
-    B, T = args.batch, 49
+    B, T = 512, 49
     g = torch.Generator().manual_seed(1999)
     dyn = rn.LatentGenDynamics(generator=g)
     grid = [i / (T - 1) for i in range(T)]
@@ -109,38 +113,110 @@ def bench_latent(args):
     us = C.c_float(0)
     _lib.check(h.ptr, L.rnde_bench_attempt(h.ptr, z0.detach().contiguous().data_ptr(), p.detach().data_ptr(), B, 200, C.byref(us), None))
     flops = 6 * 2 * B * 8280
-    print(json.dumps({"metric": "forward+reverse samples/sec, latent-ODE dynamics (config 4)", "value": B * args.steps / el, "unit": "samples/s",
-                      "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
-                      "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "mean_nfe": sum(nfes) / len(nfes),
-                      "config": {"workload": "latent ODE gen_dynamics D=20, 8 Dense layers 20<->50 tanh, B=512, 49 saveat points, Tsit5 1.4e-8 (chain engine)"},
-                      "roofline": {"bound": "mfma", "achieved": flops / (us.value * 1e-6) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                                   "frac": flops / (us.value * 1e-6) / 1e12 / MFMA_F32_PEAK_TF, "traffic": None,
-                                   "kernel": "rnde_chain_kernel: one attempted Tsit5 step = 1 launch; latency bound (32 waves on the chip)",
-                                   "us_per_attempt": us.value}}))
+    return {"metric": "forward+reverse samples/sec, latent-ODE dynamics (config 4)", "value": B * args.steps / el, "unit": "samples/s",
+            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "mean_nfe": sum(nfes) / len(nfes),
+            "config": {"workload": "latent ODE gen_dynamics D=20, 8 Dense layers 20<->50 tanh, B=512, 49 saveat points, Tsit5 1.4e-8 (chain engine)"},
+            "roofline": {"bound": "mfma", "achieved": flops / (us.value * 1e-6) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": flops / (us.value * 1e-6) / 1e12 / MFMA_F32_PEAK_TF, "traffic": None,
+                         "kernel": "rnde_chain_kernel: one attempted Tsit5 step = 1 launch; latency bound (32 waves on the chip)",
+                         "us_per_attempt": us.value}}
+
+
+def bench_nsde(args):
+    """BASELINE config 5: MNIST neural SDE (experiments/mnist_nsde.jl:70-100), D = 32, drift 32 -> 64 -> 32, diffusion 32 -> 32, SOSRI at
+    reltol = abstol = 0.14, B = 512, trajectories = 1 (training); step = ClassifierNSDE loss forward (Dense(784,32) -> one-launch adaptive
+    solve -> Dense(32,10), logitcrossentropy + 10 * mean(EEst*dt)) + reverse + ADAM(0.01) update."""
+    import torch
+    import regneuralde_jl_amd as rn
+    from regneuralde_jl_amd import _lib
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    B = 512
+    g = torch.Generator().manual_seed(1999)
+    nsde = rn.TrackedNeuralDSDE(rn.Chain(rn.Dense(32, 64, "tanh", g), rn.Dense(64, 32, "identity", g)), rn.Dense(32, 32, "identity", g), [0.0, 1.0], True,
+                                "SOSRI", save_everystep=False, reltol=0.14, abstol=0.14, save_start=False, max_batch=B, max_attempts=256, seed=1999)
+    model = rn.ClassifierNSDE(rn.Dense(784, 32, "identity", g), nsde, rn.Dense(32, 10, "identity", g), device=device)
+    opt = torch.optim.Adam(model.trainable(), lr=0.01)
+    x = torch.rand(B, 784, generator=g).to(device)
+    y = torch.eye(NCLS)[torch.randint(0, NCLS, (B,), generator=g)].to(device)
+    L = _lib.lib()
+    stats = {"att": [], "acc": [], "solve_ms": [], "rev_ms": []}
+
+    def step(record):
+        opt.zero_grad(set_to_none=True)
+        loss, ce, reg, nfe1, nfe2 = rn.nsde_loss_function(x, y, model, trajectories=1, lam=10.0)
+        loss.backward()
+        opt.step()
+        if record:
+            h = nsde._handles[0][0]
+            a, b, na, nc = C.c_float(0), C.c_float(0), C.c_int32(0), C.c_int32(0)
+            L.rnde_nsde_timing(h.ptr, C.byref(a), C.byref(b), C.byref(na), C.byref(nc))
+            stats["att"].append(na.value); stats["acc"].append(nc.value); stats["solve_ms"].append(a.value); stats["rev_ms"].append(b.value)
+        return nfe1, nfe2
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nf = [step(False) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    for _ in range(3):
+        step(True)
+    att = sum(stats["att"]) / len(stats["att"])
+    acc = sum(stats["acc"]) / len(stats["acc"])
+    us_att = 1e3 * sum(stats["solve_ms"]) / sum(stats["att"])
+    flops = 8 * B * (32 * 64 + 64 + 64 * 32 + 32 + 32 * 32 + 32)      # 4 drift + 4 diffusion evaluations per attempted step
+    return {"metric": "training-step samples/sec + NFE, MNIST Neural SDE bs=512 (config 5)", "value": B * args.steps / el, "unit": "samples/s",
+            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic (library Philox noise)",
+            "mean_nfe1": sum(a for a, _ in nf) / len(nf), "mean_nfe2": sum(b for _, b in nf) / len(nf),
+            "attempts_per_step": att, "accepted_per_step": acc, "solve_ms": sum(stats["solve_ms"]) / 3, "rev_sweep_ms": sum(stats["rev_ms"]) / 3,
+            "config": {"workload": "MNIST NSDE regularized (error_est, lambda 10), SOSRI reltol=abstol=0.14, B=512, trajectories=1, diagonal noise; "
+                                   "step = ClassifierNSDE loss fwd + reverse + ADAM"},
+            "roofline": {"bound": "mfma", "achieved": flops / (us_att * 1e-6) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": flops / (us_att * 1e-6) / 1e12 / MFMA_F32_PEAK_TF, "traffic": None,
+                         "kernel": "rnde_sde_solve_kernel: the WHOLE adaptive solve = 1 launch; unit = one attempted SRI step inside it "
+                                   "(8 small network evaluations + the cross-workgroup norm); latency bound (32 waves on the chip)",
+                         "us_per_attempt": us_att}}
+
+
+def spawn_multi_gpu(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a fresh torchrun child (nothing here has touched the GPU
+    yet, and the child is a child process, not an exec) and pass its JSON line through."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29500 + os.getpid() % 1000), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=512, help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the fixed-weights leg and the config 4 / config 5 records")
     ap.add_argument("--col-tile", type=int, default=0)
     ap.add_argument("--autograd", action="store_true", help="head + loss through torch.autograd instead of the fused C-ABI head")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) and run the gradient all-reduce even at world size 1: exercises the N > 1 code path on a 1-GPU box")
-    ap.add_argument("--workload", default="mnist", choices=["mnist", "latent"], help="mnist = BASELINE.json's metric (default); latent = SURVEY 8d config 4")
+    ap.add_argument("--workload", default="mnist", choices=["mnist", "latent", "nsde"], help="mnist = BASELINE.json's metric (default); latent = config 4; nsde = config 5")
     args = ap.parse_args()
-    if args.workload == "latent":
-        if not torch.cuda.is_available():
-            raise SystemExit("bench.py needs an MI355X: the integration path has no CPU fallback")
-        return bench_latent(args)
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_multi_gpu(args))
+    if args.gpus != world and not (args.gpus == 1 and world == 1):
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun --nproc-per-node {args.gpus} (or run `python bench.py --gpus N` directly)")
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the integration path has no CPU fallback")
+    if args.workload == "latent":
+        return print(json.dumps(bench_latent(args)), flush=True)
+    if args.workload == "nsde":
+        return print(json.dumps(bench_nsde(args)), flush=True)
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -152,6 +228,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import regneuralde_jl_amd as rn
+    from regneuralde_jl_amd import _lib
+    L = _lib.lib()
     B = args.batch
     model = build_model(rn, device, B)
     model.node.col_tile = args.col_tile
@@ -161,8 +239,9 @@ def main():
     y = torch.eye(NCLS)[torch.randint(0, NCLS, (B,), generator=g)].to(device)
     reducer = rn.GradientAllReducer(model.trainable()) if use_dist else None
     nfes = []
+    saved = [p.detach().clone() for p in model.trainable()]
 
-    def train_step():
+    def train_step(restore=False):
         if args.autograd:
             loss, ce, reg, nfe = rn.loss_function(x, y, model, lam=1.0e2)
             loss.backward()
@@ -172,53 +251,76 @@ def main():
         if use_dist:
             reducer.allreduce_()                                          # one RCCL sum over xGMI, 166,418 fp32
         opt.step()
+        if restore:                                                       # fixed-weights leg: the update ran, its effect is undone
+            with torch.no_grad():
+                for p, s0 in zip(model.trainable(), saved):
+                    p.copy_(s0)
         nfes.append(nfe)
         return loss
 
+    def timed(restore):
+        nfes.clear()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            last = train_step(restore)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if use_dist:
+            tt = torch.tensor([el], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+            nf = torch.tensor([sum(nfes) / len(nfes)], device=device, dtype=torch.float64)
+            dist.all_reduce(nf)
+            mean_nfe = float(nf.item()) / world
+        else:
+            mean_nfe = sum(nfes) / len(nfes)
+        return el, mean_nfe, float(last)
+
+    # fixed-weights leg FIRST (from the initial weights: stationary by construction), then the real training leg
+    fixed = None
+    if not args.no_extras:
+        for _ in range(args.warmup):
+            train_step(True)
+        el_f, nfe_f, _ = timed(True)
+        fixed = {"value": world * B * args.steps / el_f, "ms_per_step": 1e3 * el_f / args.steps, "mean_nfe": nfe_f}
+        opt = rn.FluxOptimiser(model.trainable())                         # fresh optimiser state for the training leg
     for _ in range(args.warmup):
         train_step()
-    nfes.clear()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        last_loss = train_step()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    last_loss = float(last_loss)          # (a device tensor on the fused path: read after the timed region, as the reference's loop does)
-    if use_dist:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        nf = torch.tensor([sum(nfes) / len(nfes)], device=device, dtype=torch.float64)
-        dist.all_reduce(nf)
-        mean_nfe = float(nf.item()) / world
-    else:
-        mean_nfe = sum(nfes) / len(nfes)
+    elapsed, mean_nfe, last_loss = timed(False)
 
     out = None
     if rank == 0:
-        # --- roofline leg: the step kernel alone, HIP events on the launch stream ---
-        from regneuralde_jl_amd import _lib
-        L = _lib.lib()
-        h = model.node._acquire(x.reshape(B, -1), False)
-        us = C.c_float(0)
+        h = model.node._acquire(x.reshape(B, -1), True)
+        # --- NFE-independent companions: HIP events around the attempted steps of the forward and the reverse sweep, 3 steps ---
+        L.rnde_node_set_timing(h.ptr, 1)
+        fa, rs, rr, atts = [], [], [], []
+        for _ in range(3):
+            rn.fused_loss_and_grad(model, x, y, lam=1.0e2, sync=True)
+            a, b, c = C.c_float(0), C.c_float(0), C.c_float(0)
+            L.rnde_node_timing(h.ptr, C.byref(a), C.byref(b), C.byref(c))
+            fa.append(a.value); rs.append(b.value); rr.append(c.value); atts.append(int(L.rnde_node_last_attempts(h.ptr)))
+        L.rnde_node_set_timing(h.ptr, 0)
+        # --- roofline leg: the TAPED attempted-step kernel alone (what a training step runs), HIP events on the launch stream ---
+        us, us_untaped = C.c_float(0), C.c_float(0)
         xs = x.reshape(B, -1).contiguous()
-        stream = torch.cuda.current_stream(device).cuda_stream
-        _lib.check(h.ptr, L.rnde_bench_attempt(h.ptr, xs.data_ptr(), model.p2.data_ptr(), B, 200, C.byref(us), C.c_void_p(stream)))
+        stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        _lib.check(h.ptr, L.rnde_bench_attempt_taped(h.ptr, xs.data_ptr(), model.p2.data_ptr(), B, 200, C.byref(us), stream))
+        _lib.check(h.ptr, L.rnde_bench_attempt(h.ptr, xs.data_ptr(), model.p2.data_ptr(), B, 200, C.byref(us_untaped), stream))
         t_att = us.value * 1e-6
         stage_engine = args.col_tile in (0, 16)
         nl = int(L.rnde_node_launches_per_attempt(h.ptr))
         roof = {"bound": "hbm", "achieved": ALG_BYTES(B) / t_att / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ALG_BYTES(B) / t_att / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                "kernel": (("rnde_stage_attempt_kernel: one attempted Tsit5 step = 1 launch (7 stages, in-kernel slab hand-off)" if nl == 1 else
-                            "rnde_stage_kernel: one attempted Tsit5 step = 7 launches (START, 5 x STAGE, LAST)") if stage_engine
+                "kernel": (("rnde_stage_attempt_kernel (taped): one attempted Tsit5 step = 1 launch (7 stages, in-kernel slab hand-off)" if nl == 1 else
+                            "rnde_stage_kernel (taped): one attempted Tsit5 step = 7 launches (START, 5 x STAGE, LAST)") if stage_engine
                            else "rnde_step_kernel: one attempted Tsit5 step = 1 launch"),
                 "launches_per_unit": nl, "us_per_launch": us.value / nl,
-                "us_per_attempt": us.value,
+                "us_per_attempt": us.value, "us_per_attempt_untaped": us_untaped.value,
                 "alg_bytes_per_attempt": ALG_BYTES(B), "alg_bytes_per_launch": ALG_BYTES(B) / nl,
                 "mfma_f32_tflops": ALG_FLOPS(B) / t_att / 1e12,
                 "mfma_frac": ALG_FLOPS(B) / t_att / 1e12 / MFMA_F32_PEAK_TF}
@@ -227,12 +329,17 @@ def main():
         # reported when present, with their source
         try:
             import csv
-            pf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic.csv")
-            want = "rnde_stage_attempt_kernel" if (stage_engine and nl == 1) else ("rnde_stage_kernel<1, 1>" if stage_engine else "rnde_step_kernel")
-            for row in csv.reader(l for l in open(pf) if not l.startswith("#")):
-                if row and want in row[0]:
-                    roof["traffic"] = float(row[4]) * (7 if (stage_engine and nl == 7) else 1)
-                    roof["traffic_source"] = "profiles/r01_pmc_hbm_traffic.csv (separate --pmc passes; bytes per attempted step)"
+            for rnd in (PROFILE_ROUND, "r01"):
+                pf = os.path.join(ROOT, "profiles", f"{rnd}_pmc_hbm_traffic.csv")
+                if not os.path.exists(pf):
+                    continue
+                want = "rnde_stage_attempt_kernel" if (stage_engine and nl == 1) else ("rnde_stage_kernel<1, 1>" if stage_engine else "rnde_step_kernel")
+                for row in csv.reader(l for l in open(pf) if not l.startswith("#")):
+                    if row and want in row[0]:
+                        roof["traffic"] = float(row[4]) * (7 if (stage_engine and nl == 7) else 1)
+                        roof["traffic_source"] = f"profiles/{rnd}_pmc_hbm_traffic.csv (separate --pmc passes; bytes per attempted step)"
+                        break
+                if roof["traffic"] is not None:
                     break
         except Exception:
             pass
@@ -241,13 +348,30 @@ def main():
                "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "mean_nfe": mean_nfe, "final_loss": last_loss,
+               "value_fixed_weights": None if fixed is None else fixed["value"],
+               "fixed_weights": fixed,
+               "attempts_per_step": sum(atts) / len(atts),
+               "us_per_attempt_fwd": 1e3 * sum(fa) / max(1, sum(atts)),
+               "us_per_attempt_rev": 1e3 * sum(rs) / max(1, sum(atts)),
+               "rev_rest_ms": sum(rr) / len(rr),
+               "persist_fallback": bool(stage_engine and nl != 1),
                "config": {"workload": "MNIST NODE regularized (error_est), Tsit5 reltol=abstol=1.4e-8, batch 512 per GPU, "
                                       "1xMI355X per rank; step = loss fwd + reverse pass through the solver + "
-                                      "InvDecay/Momentum update", "global_batch": world * B,
+                                      "InvDecay/Momentum update; the weights train during the timed steps (mean_nfe drifts with "
+                                      "--steps: value_fixed_weights is the stationary companion)", "global_batch": world * B,
                           "parallelism": f"dp{world}" if world > 1 else "single"},
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+        if world == 1 and not args.no_extras and not use_dist:
+            sub = argparse.Namespace(steps=max(3, args.steps // 2), warmup=2)
+            others = {}
+            for name, fn in (("latent_config4", bench_latent), ("nsde_config5", bench_nsde)):
+                try:
+                    others[name] = fn(sub)
+                except Exception as e:      # a secondary record must never cost the headline line
+                    others[name] = {"error": repr(e)}
+            out["other_workloads"] = others
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -158,6 +158,16 @@ rnde_status rnde_debug_attempt(rnde_node* h, const float* uprev_dev, const float
                                float* unew_out_dev, float* eest_out, void* stream);
 rnde_status rnde_bench_attempt(rnde_node* h, const float* x_dev, const float* p_dev, int32_t B,
                                int32_t iters, float* mean_us_out, void* stream);
+/* The same with the tape stores a training step's forward performs (keep_tape != 0): the kernel variant that dominates a
+ * training step, which is what bench.py's roofline object is computed from. */
+rnde_status rnde_bench_attempt_taped(rnde_node* h, const float* x_dev, const float* p_dev, int32_t B,
+                                     int32_t iters, float* mean_us_out, void* stream);
+/* Measurement aid: with timing on, every forward / reverse records HIP events on the caller's stream around (a) the attempted
+ * steps of the forward solve, (b) the reverse sweep, (c) the rest of the reverse pass (parameter-gradient GEMMs after the
+ * sweep + reductions); rnde_node_timing waits for them and returns the three durations in ms (-1 = not recorded). */
+rnde_status rnde_node_set_timing(rnde_node* h, int32_t on);
+rnde_status rnde_node_timing(rnde_node* h, float* fwd_attempts_ms, float* rev_sweep_ms, float* rev_rest_ms);
+int32_t     rnde_node_last_attempts(const rnde_node* h);   /* attempted steps of the last forward */
 /* How the handle currently runs one attempted step: number of kernel launches (1: rnde_stage_attempt_kernel /
  * rnde_step_kernel / rnde_chain_kernel; 7: rnde_stage_kernel START, 5 x STAGE, LAST) -- bench.py's roofline bookkeeping. */
 int32_t     rnde_node_launches_per_attempt(const rnde_node* h);
@@ -246,6 +256,9 @@ rnde_status rnde_nsde_steps(rnde_nsde* h, float* steps_host, int32_t capacity, i
 rnde_status rnde_nsde_debug_attempt(rnde_nsde* h, const float* uprev_dev, const float* p_dev, int32_t B, float dt,
                                     const float* dW_dev, const float* dZ_dev, float* kg_out_dev, float* unew_out_dev,
                                     float* eest_out, void* stream);
+/* Measurement aid: HIP-event durations (ms, on the caller's stream) of the last forward's solve kernel (ONE launch = the
+ * whole adaptive solve) and of the last reverse sweep kernel, with the attempt counts of that forward; -1 = not recorded. */
+rnde_status rnde_nsde_timing(rnde_nsde* h, float* solve_ms, float* rev_sweep_ms, int32_t* attempts, int32_t* accepted);
 /* Fill `n` floats with standard normals from (seed, stream_id): the library's own generator, exposed for its statistical test. */
 rnde_status rnde_normal_fill(float* out_dev, int64_t n, uint64_t seed, uint64_t stream_id, void* stream);
 

@@ -70,6 +70,11 @@ def lib():
     L.rnde_debug_feval.argtypes = [vp, vp, vp, i32, f, vp, vp]
     L.rnde_debug_attempt.argtypes = [vp, vp, vp, vp, i32, f, f, vp, vp, fp, vp]
     L.rnde_bench_attempt.argtypes = [vp, vp, vp, i32, i32, fp, vp]
+    L.rnde_bench_attempt_taped.argtypes = [vp, vp, vp, i32, i32, fp, vp]
+    L.rnde_node_set_timing.argtypes = [vp, i32]
+    L.rnde_node_timing.argtypes = [vp, fp, fp, fp]
+    L.rnde_node_last_attempts.restype = C.c_int32
+    L.rnde_node_last_attempts.argtypes = [vp]
     L.rnde_node_launches_per_attempt.restype = C.c_int32
     L.rnde_node_launches_per_attempt.argtypes = [vp]
     L.rnde_classifier_head.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]
@@ -87,6 +92,7 @@ def lib():
     L.rnde_nsde_backward.argtypes = [vp, vp, fp, vp, vp, vp]
     L.rnde_nsde_steps.argtypes = [vp, fp, i32, i32p, i32p]
     L.rnde_nsde_debug_attempt.argtypes = [vp, vp, vp, i32, f, vp, vp, vp, vp, fp, vp]
+    L.rnde_nsde_timing.argtypes = [vp, fp, fp, i32p, i32p]
     L.rnde_normal_fill.argtypes = [vp, C.c_int64, u64, u64, vp]
     _lib = L
     return L
@@ -95,9 +101,10 @@ def lib():
 EXPORTS = ["rnde_version", "rnde_last_error", "rnde_param_count", "rnde_node_create", "rnde_node_destroy",
            "rnde_node_forward", "rnde_node_forward_saveat", "rnde_node_forward_replay", "rnde_node_backward", "rnde_node_backward_async", "rnde_node_release_tape", "rnde_node_forward_host",
            "rnde_node_backward_host", "rnde_node_steps", "rnde_debug_feval", "rnde_debug_attempt",
-           "rnde_bench_attempt", "rnde_node_launches_per_attempt", "rnde_classifier_head", "rnde_momentum_step",
+           "rnde_bench_attempt", "rnde_bench_attempt_taped", "rnde_node_set_timing", "rnde_node_timing", "rnde_node_last_attempts",
+           "rnde_node_launches_per_attempt", "rnde_classifier_head", "rnde_momentum_step",
            "rnde_nsde_param_count", "rnde_nsde_create", "rnde_nsde_destroy", "rnde_nsde_last_error", "rnde_nsde_forward",
-           "rnde_nsde_forward_replay", "rnde_nsde_backward", "rnde_nsde_steps", "rnde_nsde_debug_attempt", "rnde_normal_fill"]
+           "rnde_nsde_forward_replay", "rnde_nsde_backward", "rnde_nsde_steps", "rnde_nsde_debug_attempt", "rnde_nsde_timing", "rnde_normal_fill"]
 
 
 def check(h, status):

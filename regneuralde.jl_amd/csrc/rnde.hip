@@ -82,10 +82,12 @@ struct rnde_node {
     float* diag_buf = nullptr;   // (RNDE_DIAG builds) cycle stamps   // an asynchronous reverse pass whose health words have not been looked at yet
     std::vector<int> sv_index;  // per attempt: index into saveval or -1
     int n_saveval = 0;
+    // rnde_node_set_timing: HIP events around the attempt loop of the forward, the reverse sweep and the rest of the reverse pass
+    int timing = 0; hipEvent_t tev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; bool tev_fwd = false, tev_bwd = false;
     std::string err;
 };
 
-static std::string g_create_err;
+static thread_local std::string g_create_err;   // last create error of the calling thread (rnde_last_error(NULL)); no process-wide mutable state
 static rnde_status chain_bwd_run(rnde_node* h, const float* u_bar_dev, const float* saveval_bar_host, float* x_bar_dev,
                                  float* p_bar_dev, float* tspan_bar_host, hipStream_t s, bool sync = true, float* tspan_bar_dev = nullptr);
 
@@ -411,6 +413,7 @@ extern "C" void rnde_node_destroy(rnde_node* h) {
     if (h->ev_t) hipFree(h->ev_t);
     if (h->h_ev_t) hipHostFree(h->h_ev_t);
     for (hipEvent_t e : h->wevents) hipEventDestroy(e);
+    for (hipEvent_t e : h->tev) if (e) hipEventDestroy(e);
     if (h->wstream) hipStreamDestroy(h->wstream);
     if (h->h_ctl) hipHostFree(h->h_ctl);
     if (h->h_meta) hipHostFree(h->h_meta);
@@ -631,6 +634,8 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
     int launched = 0;
     int chunk = std::max(4, h->predicted);
     const int cap = h->cfg.max_attempts;
+    h->tev_fwd = false;
+    if (h->timing) HIPCHK(h, hipEventRecord(h->tev[0], s));
     while (true) {
         for (int i = 0; i < chunk && launched < cap; ++i) {
             if (h->engine == 3) HIPCHK(h, launch_chain<CM_STEP>(h, CQ, launched, nullptr, s));
@@ -638,6 +643,7 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
             else HIPCHK(h, launch_step<MODE_STEP>(h, P, launched, s));
             ++launched;
         }
+        if (h->timing && !h->tev_fwd) { HIPCHK(h, hipEventRecord(h->tev[1], s)); h->tev_fwd = true; }   // (first chunk: normally the whole solve)
         if (h->engine == 3) HIPCHK(h, launch_chain<CM_FINISH>(h, CQ, launched, u_out_dev, s));
         else if (h->engine == 2) { hipLaunchKernelGGL(rnde_stage_finish_kernel, dim3(256), dim3(256), 0, s, SQ, launched, u_out_dev); HIPCHK(h, hipGetLastError()); }
         else HIPCHK(h, launch_finish(h, P, launched, u_out_dev, s));
@@ -711,6 +717,27 @@ extern "C" rnde_status rnde_node_steps(rnde_node* h, float* steps_host, int32_t 
     if (n_out) *n_out = h->n_att;
     return RNDE_OK;
 }
+
+extern "C" rnde_status rnde_node_set_timing(rnde_node* h, int32_t on) {
+    if (!h) return RNDE_ERR_BAD_ARG;
+    if (on && !h->tev[0]) for (auto& e : h->tev) HIPCHK(h, hipEventCreate(&e));
+    h->timing = on ? 1 : 0; h->tev_fwd = h->tev_bwd = false;
+    return RNDE_OK;
+}
+extern "C" rnde_status rnde_node_timing(rnde_node* h, float* fwd_attempts_ms, float* rev_sweep_ms, float* rev_rest_ms) {
+    if (!h || !h->timing) return RNDE_ERR_BAD_ARG;
+    float a = -1.f, b = -1.f, c = -1.f;
+    if (h->tev_fwd) { HIPCHK(h, hipEventSynchronize(h->tev[1])); HIPCHK(h, hipEventElapsedTime(&a, h->tev[0], h->tev[1])); }
+    if (h->tev_bwd) {
+        HIPCHK(h, hipEventSynchronize(h->tev[4]));
+        HIPCHK(h, hipEventElapsedTime(&b, h->tev[2], h->tev[3])); HIPCHK(h, hipEventElapsedTime(&c, h->tev[3], h->tev[4]));
+    }
+    if (fwd_attempts_ms) *fwd_attempts_ms = a;
+    if (rev_sweep_ms) *rev_sweep_ms = b;
+    if (rev_rest_ms) *rev_rest_ms = c;
+    return RNDE_OK;
+}
+extern "C" int32_t rnde_node_last_attempts(const rnde_node* h) { return h ? h->n_att : 0; }
 
 extern "C" int32_t rnde_node_launches_per_attempt(const rnde_node* h) {
     if (!h) return 0;
@@ -849,12 +876,22 @@ extern "C" rnde_status rnde_debug_attempt(rnde_node* h, const float* uprev_dev, 
     return RNDE_OK;
 }
 
+static rnde_status bench_attempt_impl(rnde_node* h, const float* x_dev, const float* p_dev, int32_t B, int32_t iters, int32_t taped,
+                                      float* mean_us_out, void* stream);
 extern "C" rnde_status rnde_bench_attempt(rnde_node* h, const float* x_dev, const float* p_dev, int32_t B, int32_t iters,
                                           float* mean_us_out, void* stream) {
+    return bench_attempt_impl(h, x_dev, p_dev, B, iters, 0, mean_us_out, stream);
+}
+extern "C" rnde_status rnde_bench_attempt_taped(rnde_node* h, const float* x_dev, const float* p_dev, int32_t B, int32_t iters,
+                                                float* mean_us_out, void* stream) {
+    return bench_attempt_impl(h, x_dev, p_dev, B, iters, 1, mean_us_out, stream);
+}
+static rnde_status bench_attempt_impl(rnde_node* h, const float* x_dev, const float* p_dev, int32_t B, int32_t iters, int32_t taped,
+                                      float* mean_us_out, void* stream) {
     if (!h || B < 1 || B > h->cfg.max_batch || iters < 1) return RNDE_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     h->have_tape = false;
-    StepParams P = make_params(h, x_dev, B, 0.f, 1.f, 0);
+    StepParams P = make_params(h, x_dev, B, 0.f, 1.f, taped ? 1 : 0);   // taped: the variant a training step runs (record 0 of the arena)
     P.forced = 1; P.forced_t = 0.f; P.forced_dt = 0.05f;
     rnde_status st = h->engine == 3 ? chain_pack(h, p_dev, s) : pack_weights(h, p_dev, false, s);
     if (st != RNDE_OK) return st;
@@ -1133,6 +1170,8 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
     };
     int hi_att = n_att;                                           // evaluations of attempts >= hi_att are already launched
     hipError_t e;
+    h->tev_bwd = false;
+    if (h->timing) HIPCHK(h, hipEventRecord(h->tev[2], s));
     if (h->engine == 2) {
         // stage engine sweep: one persistent launch per reversed attempt (fallback: 7 launches); then the (column-owner) kernels for the initialisation part
         HIPCHK(h, stage_pack(h, h->pcopy, h->spwBt, 2, h->sMT, h->sKHb, s));
@@ -1204,6 +1243,7 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
     else e = h->act2 ? launch_bwd_t<2, 1>(h, Q, n_att, s) : launch_bwd_t<2, 0>(h, Q, n_att, s);
     HIPCHK(h, e);
     n_att = h->n_att;
+    if (h->timing) HIPCHK(h, hipEventRecord(h->tev[3], s));
     // remaining evaluations on all CUs (everything that did not go to the side stream, incl. the two initialisation evaluations)
     st = wgrad_group(0, 2 + 6 * hi_att, false);
     if (st != RNDE_OK) return st;
@@ -1216,6 +1256,7 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
     if (st != RNDE_OK) return st;
     st = launch_wgrad_reduce(h, slab2w, cur2, h->D, h->H, p_bar_dev + (size_t)h->H * (h->D + 2), s);      // [W2; b2]
     if (st != RNDE_OK) return st;
+    if (h->timing) { HIPCHK(h, hipEventRecord(h->tev[4], s)); h->tev_bwd = true; }
 #ifdef RNDE_DIAG
     if (h->engine == 2 && h->persist == 1 && getenv("RNDE_DIAG_BWD")) {
         unsigned long long hst[64] = {0};

@@ -37,6 +37,7 @@ struct rnde_nsde {
     // last forward
     int B = 0, ntiles = 0, nwg = 0, n_att = 0, n_acc = 0, n_draws = 0, n_saveval = 0;
     bool have_tape = false;
+    hipEvent_t tev[4] = {nullptr, nullptr, nullptr, nullptr}; bool tev_f = false, tev_b = false;   // around the solve kernel / the reverse sweep kernel
     std::vector<int> sv_index;   // per accepted step: index into saveval
     std::string err;
 };
@@ -180,6 +181,7 @@ extern "C" rnde_status rnde_nsde_create(const rnde_nsde_config* c, rnde_nsde** o
     ok &= hipHostMalloc((void**)&h->h_svb, (size_t)(c->max_attempts + 1) * 4) == hipSuccess;
     ok &= hipHostMalloc((void**)&h->h_part, (size_t)h->nwg_max * 4) == hipSuccess;
     if (!ok) { g_nsde_create_err = "device allocation failed"; rnde_nsde_destroy(h); return RNDE_ERR_HIP; }
+    for (auto& e : h->tev) if (hipEventCreate(&e) != hipSuccess) { g_nsde_create_err = "hipEventCreate failed"; rnde_nsde_destroy(h); return RNDE_ERR_HIP; }
     hipMemset(h->abort_word, 0, 16);
     hipMemset(h->xch, 0, (size_t)(c->max_attempts + 4) * 2 * h->nwg_max * 8);
     hipMemset(h->frags_f, 0, (size_t)(Gf.nfrag_f + Gf.nfrag_b + Gf.nfrag_t + 4) * 256);
@@ -195,6 +197,7 @@ extern "C" void rnde_nsde_destroy(rnde_nsde* h) {
     for (void* p : d) if (p) (void)hipFree(p);
     void* hd[] = {h->h_meta, h->h_acc_meta, h->h_fin, h->h_svb, h->h_part};
     for (void* p : hd) if (p) (void)hipHostFree(p);
+    for (hipEvent_t e : h->tev) if (e) (void)hipEventDestroy(e);
     delete h;
 }
 
@@ -300,8 +303,12 @@ static rnde_status nsde_forward_impl(rnde_nsde* h, const float* x_dev, const flo
         SCHK(h, hipMemcpyAsync(h->replay, steps_host, (size_t)n_steps * 8, hipMemcpyHostToDevice, s));
         Q.replay = h->replay; Q.n_replay = n_steps;
     }
+    h->tev_f = false;
+    SCHK(h, hipEventRecord(h->tev[0], s));
     hipError_t e = h->NKD == 4 ? launch_solve<4>(h, Q, s) : (h->NKD == 8 ? launch_solve<8>(h, Q, s) : launch_solve<16>(h, Q, s));
     SCHK(h, e);
+    SCHK(h, hipEventRecord(h->tev[1], s));
+    h->tev_f = true;
     SCHK(h, hipMemcpyAsync(h->h_fin, h->fin, sizeof(SdeFinal), hipMemcpyDeviceToHost, s));
     SCHK(h, hipMemcpyAsync(h->h_meta, h->meta, (size_t)h->cfg.max_attempts * sizeof(SdeMeta), hipMemcpyDeviceToHost, s));
     SCHK(h, hipStreamSynchronize(s));
@@ -435,8 +442,12 @@ extern "C" rnde_status rnde_nsde_backward(rnde_nsde* h, const float* u_bar_dev, 
         h->have_tape = false;
         return RNDE_OK;
     }
+    h->tev_b = false;
+    SCHK(h, hipEventRecord(h->tev[2], s));
     hipError_t e = h->NKD == 4 ? launch_bwd<4>(h, Bq, s) : (h->NKD == 8 ? launch_bwd<8>(h, Bq, s) : launch_bwd<16>(h, Bq, s));
     SCHK(h, e);
+    SCHK(h, hipEventRecord(h->tev[3], s));
+    h->tev_b = true;
     // parameter gradients of both chains over all evaluations (rnde_bchain.h), per-chunk partials in Flux.destructure order
     const int n_units = 4 * n_acc * ntiles;
     const int chunks = std::max(1, std::min(96, n_units / 8));
@@ -457,6 +468,18 @@ extern "C" rnde_status rnde_nsde_backward(rnde_nsde* h, const float* u_bar_dev, 
     }
     SCHK(h, hipStreamSynchronize(s));
     h->have_tape = false;
+    return RNDE_OK;
+}
+
+extern "C" rnde_status rnde_nsde_timing(rnde_nsde* h, float* solve_ms, float* rev_sweep_ms, int32_t* attempts, int32_t* accepted) {
+    if (!h) return RNDE_ERR_BAD_ARG;
+    float a = -1.f, b = -1.f;
+    if (h->tev_f) { SCHK(h, hipEventSynchronize(h->tev[1])); SCHK(h, hipEventElapsedTime(&a, h->tev[0], h->tev[1])); }
+    if (h->tev_b) { SCHK(h, hipEventSynchronize(h->tev[3])); SCHK(h, hipEventElapsedTime(&b, h->tev[2], h->tev[3])); }
+    if (solve_ms) *solve_ms = a;
+    if (rev_sweep_ms) *rev_sweep_ms = b;
+    if (attempts) *attempts = h->n_att;
+    if (accepted) *accepted = h->n_acc;
     return RNDE_OK;
 }
 

@@ -223,6 +223,8 @@ typedef struct {
     /* controller constants, 0 = the StochasticDiffEq defaults as recalled: beta2 = 2/(5 order),
      * beta1 = 7/(10 order), order = 3/2, gamma = 0.9, qmin = 0.2, qmax = 1.125, qoldinit = 1e-4, delta = 1 (SRIW1: 1/6) */
     float   beta1, beta2, gamma, qmin, qmax, qoldinit, delta;
+    int32_t generic;                            /* 1 = never use the instantiations with the reference's shape (32 -> 64 -> 32, 32 -> 32)
+                                                 * as compile-time constants (A/B runs, parity tests of the generic kernels) */
 } rnde_nsde_config;
 
 typedef struct rnde_nsde rnde_nsde;

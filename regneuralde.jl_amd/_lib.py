@@ -24,7 +24,7 @@ class NsdeConfig(C.Structure):
                 ("max_batch", C.c_int32), ("solver", C.c_int32), ("reltol", C.c_float), ("abstol", C.c_float),
                 ("regularize", C.c_int32), ("cb_save_start", C.c_int32), ("max_attempts", C.c_int32), ("device", C.c_int32),
                 ("beta1", C.c_float), ("beta2", C.c_float), ("gamma", C.c_float), ("qmin", C.c_float), ("qmax", C.c_float),
-                ("qoldinit", C.c_float), ("delta", C.c_float)]
+                ("qoldinit", C.c_float), ("delta", C.c_float), ("generic", C.c_int32)]
 
 
 SDE_SOLVER = {"SOSRI": 0, "SRIW1": 1, "SOSRI2": 2}

@@ -85,9 +85,47 @@ __device__ __forceinline__ void sde_net(const ChainGeo& G, const float* FR, cons
     chain_eval<NKD, 0>(G, FR, FR + (size_t)G.nfrag_f * 64, 0.f, in, out, lane);
 }
 
+// ---- compile-time shapes for the reference's own NSDE form (experiments/mnist_nsde.jl:73-74): drift = Dense(D, Hd, act0) -> Dense(Hd, D, act1),
+// diffusion = Dense(D, D, act).  Run-time shape dispatch costs a factor ~2 per layer (rnde_chain.h: the structurised switches merge
+// the 16-register accumulator / activation arrays after every case), and the whole solve is a chain of ~700 such layers.
+// FIXH = k-steps of the hidden width (0 = generic chains through chain_eval).
+template <int NI, int NO>
+__device__ __forceinline__ void sde_layer_fixed(const ChainGeo& G, const float* FR, int l, const float (&in)[kCMaxKs], float (&out)[kCMaxKs], int lane) {
+    constexpr int MT = (NO + 3) / 4;
+    f32x4 acc[4];
+    chain_bias_t<MT>(FR + (size_t)(G.nfrag_f + G.boff[l]) * 64 + lane, 0.f, 0, acc);
+    chain_mm_t<NI>(FR + (size_t)G.foff[l] * 64 + lane, MT, in, acc);
+    if (G.act[l] != 0) chain_tanh_n<NO>(acc, out); else chain_act_t<MT>(acc, false, out);
+}
+template <int NKD, int FIXH>
+__device__ __forceinline__ void sde_drift(const ChainGeo& G, const float* FR, const float (&in)[NKD], float (&out)[NKD], int lane) {
+    if constexpr (FIXH == 0) chain_eval<NKD, 0>(G, FR, FR + (size_t)G.nfrag_f * 64, 0.f, in, out, lane);
+    else {
+        float a[kCMaxKs], b[kCMaxKs];
+#pragma unroll
+        for (int k = 0; k < kCMaxKs; ++k) a[k] = k < NKD ? in[k < NKD ? k : 0] : 0.f;
+        sde_layer_fixed<NKD, FIXH>(G, FR, 0, a, b, lane);
+        sde_layer_fixed<FIXH, NKD>(G, FR, 1, b, a, lane);
+#pragma unroll
+        for (int k = 0; k < NKD; ++k) out[k] = a[k];
+    }
+}
+template <int NKD, int FIXH>
+__device__ __forceinline__ void sde_diff(const ChainGeo& G, const float* FR, const float (&in)[NKD], float (&out)[NKD], int lane) {
+    if constexpr (FIXH == 0) chain_eval<NKD, 0>(G, FR, FR + (size_t)G.nfrag_f * 64, 0.f, in, out, lane);
+    else {
+        float a[kCMaxKs], b[kCMaxKs];
+#pragma unroll
+        for (int k = 0; k < kCMaxKs; ++k) a[k] = k < NKD ? in[k < NKD ? k : 0] : 0.f;
+        sde_layer_fixed<NKD, NKD>(G, FR, 0, a, b, lane);
+#pragma unroll
+        for (int k = 0; k < NKD; ++k) out[k] = b[k];
+    }
+}
+
 // ---- one attempted SRI step for the wave's columns (StochasticDiffEq FourStageSRIConstantCache) ------------
 // returns this lane's share of sum r^2, r = (delta E1 + E2) / (abstol + max(|uprev|, |u|) reltol)
-template <int NKD>
+template <int NKD, int FIXH = 0>
 __device__ __forceinline__ float sde_attempt(const SdeParams& Q, const float* FRf, const float* FRg, const float (&up)[NKD], float dt,
                                              float sqdt, const float (&dW)[NKD], const float (&dZ)[NKD], float (&k)[4][NKD],
                                              float (&g)[4][NKD], float (&un)[NKD], bool colok, int gq, int lane) {
@@ -111,8 +149,8 @@ __device__ __forceinline__ float sde_attempt(const SdeParams& Q, const float* FR
             h0[q] = s ? up[q] + dt * a0 + chi2[q] * b0 : up[q];
             h1[q] = s ? up[q] + dt * a1 + sqdt * b1 : up[q];
         }
-        sde_net<NKD>(Q.Gf, FRf, h0, k[s], lane);
-        sde_net<NKD>(Q.Gg, FRg, h1, g[s], lane);
+        sde_drift<NKD, FIXH>(Q.Gf, FRf, h0, k[s], lane);
+        sde_diff<NKD, FIXH>(Q.Gg, FRg, h1, g[s], lane);
     }
     float part = 0.f;
 #pragma unroll
@@ -192,7 +230,7 @@ __device__ __forceinline__ int sde_alloc(SdeStacks& S, int* freel, int n_slots, 
     return 0;
 }
 
-template <int NKD>
+template <int NKD, int FIXH = 0>
 __global__ __launch_bounds__(64 * kCW) void rnde_sde_solve_kernel(const SdeParams Q) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -243,8 +281,8 @@ __global__ __launch_bounds__(64 * kCW) void rnde_sde_solve_kernel(const SdeParam
     int seq = 0;
     {
         float f0[NKD], g0[NKD];
-        sde_net<NKD>(Q.Gf, FRf, up, f0, lane);
-        sde_net<NKD>(Q.Gg, FRg, up, g0, lane);
+        sde_drift<NKD, FIXH>(Q.Gf, FRf, up, f0, lane);
+        sde_diff<NKD, FIXH>(Q.Gg, FRg, up, g0, lane);
         float pa = 0.f, pb = 0.f;
 #pragma unroll
         for (int q = 0; q < NKD; ++q) {
@@ -274,8 +312,8 @@ __global__ __launch_bounds__(64 * kCW) void rnde_sde_solve_kernel(const SdeParam
         float u1[NKD], f1[NKD], g1[NKD];
 #pragma unroll
         for (int q = 0; q < NKD; ++q) u1[q] = up[q] + dt0 * f0[q];
-        sde_net<NKD>(Q.Gf, FRf, u1, f1, lane);
-        sde_net<NKD>(Q.Gg, FRg, u1, g1, lane);
+        sde_drift<NKD, FIXH>(Q.Gf, FRf, u1, f1, lane);
+        sde_diff<NKD, FIXH>(Q.Gg, FRg, u1, g1, lane);
         float pc = 0.f;
 #pragma unroll
         for (int q = 0; q < NKD; ++q) {
@@ -346,7 +384,7 @@ __global__ __launch_bounds__(64 * kCW) void rnde_sde_solve_kernel(const SdeParam
 
         const float sqdt = sqrtf(fabsf(dt));
         float k[4][NKD], g[4][NKD], un[NKD];
-        float part = sde_attempt<NKD>(Q, FRf, FRg, up, dt, sqdt, dW, dZ, k, g, un, colok, gq, lane);
+        float part = sde_attempt<NKD, FIXH>(Q, FRf, FRg, up, dt, sqdt, dW, dZ, k, g, un, colok, gq, lane);
         part = wave_sum_f(part);
         if (lane == 0) RED[wave] = part;
         __syncthreads();
@@ -600,6 +638,72 @@ __global__ __launch_bounds__(64 * kCW) void rnde_sde_attempt_kernel(const SdePar
     if (tid == 0) { float s = 0.f; for (int w = 0; w < kCW; ++w) s += RED[w]; part_out[blockIdx.x] = s; }
 }
 
+// ---- J^T products with compile-time shapes (the fixed form above): layer outputs stay in registers (chain_fbwd re-reads them from
+// the slab it has just written), every loop bound is a constant.  Dumps the same (layer input, pre-activation cotangent) rows.
+template <int NO>
+__device__ __forceinline__ void sde_zstage_fixed(const float (&ab)[kCMaxKs], bool th, const float (&o)[kCMaxKs], float* zp, float (&z)[kCMaxKs]) {
+    constexpr int MT = (NO + 3) / 4;
+#pragma unroll
+    for (int ks = 0; ks < kCMaxKs; ++ks) {
+        float v = 0.f;
+        if (ks < 4 * MT) { v = ab[ks]; if (th) v *= (1.f - o[ks] * o[ks]); zp[ks * 64] = v; }
+        z[ks] = v;
+    }
+}
+template <int NI, int NO>
+__device__ __forceinline__ void sde_layer_bwd_fixed(const ChainGeo& G, const float* TF, int l, const float (&z)[kCMaxKs], float (&ab)[kCMaxKs], int lane) {
+    constexpr int MTI = (NI + 3) / 4;
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    chain_mm_t<NO>(TF + (size_t)G.toff[l] * 64 + lane, MTI, z, acc);
+    chain_act_t<MTI>(acc, false, ab);
+}
+template <int NKD, int FIXH>
+__device__ __forceinline__ void sde_drift_bwd(const BChainParams& C, const float* FR, const float (&hin)[NKD], const float (&kout)[NKD], const float (&kbar)[NKD],
+                                              float (&gb)[NKD], float* __restrict__ sl, int lane) {
+    const ChainGeo& G = C.G;
+    if constexpr (FIXH == 0) {
+        float tau = 0.f;
+        chain_fbwd<NKD, 0>(C, FR, FR + (size_t)G.nfrag_f * 64, FR + (size_t)(G.nfrag_f + G.nfrag_b) * 64, 0.f, hin, kout, kbar, gb, sl, tau, lane);
+    } else {
+        const float* TF = FR + (size_t)(G.nfrag_f + G.nfrag_b) * 64;
+        float a[kCMaxKs], hmid[kCMaxKs], o[kCMaxKs], ab[kCMaxKs], z[kCMaxKs];
+#pragma unroll
+        for (int k = 0; k < kCMaxKs; ++k) { a[k] = k < NKD ? hin[k < NKD ? k : 0] : 0.f; o[k] = k < NKD ? kout[k < NKD ? k : 0] : 0.f; ab[k] = k < NKD ? kbar[k < NKD ? k : 0] : 0.f; }
+        chain_store_rows_t<(NKD + 3) / 4>(sl + (size_t)C.hrow[0] * 64, a);
+        sde_layer_fixed<NKD, FIXH>(G, FR, 0, a, hmid, lane);
+        chain_store_rows_t<(FIXH + 3) / 4>(sl + (size_t)C.hrow[1] * 64, hmid);
+        chain_store_rows_t<(NKD + 3) / 4>(sl + (size_t)C.hrow[2] * 64, o);
+        sde_zstage_fixed<NKD>(ab, G.act[1] != 0, o, sl + (size_t)C.zrow[1] * 64, z);
+        sde_layer_bwd_fixed<FIXH, NKD>(G, TF, 1, z, ab, lane);
+        sde_zstage_fixed<FIXH>(ab, G.act[0] != 0, hmid, sl + (size_t)C.zrow[0] * 64, z);
+        sde_layer_bwd_fixed<NKD, FIXH>(G, TF, 0, z, ab, lane);
+#pragma unroll
+        for (int k = 0; k < NKD; ++k) gb[k] = ab[k];
+    }
+}
+template <int NKD, int FIXH>
+__device__ __forceinline__ void sde_diff_bwd(const BChainParams& C, const float* FR, const float (&hin)[NKD], const float (&gout)[NKD], const float (&gbar)[NKD],
+                                             float (&hb)[NKD], float* __restrict__ sl, int lane) {
+    const ChainGeo& G = C.G;
+    if constexpr (FIXH == 0) {
+        float tau = 0.f;
+        chain_fbwd<NKD, 0>(C, FR, FR + (size_t)G.nfrag_f * 64, FR + (size_t)(G.nfrag_f + G.nfrag_b) * 64, 0.f, hin, gout, gbar, hb, sl, tau, lane);
+    } else {
+        const float* TF = FR + (size_t)(G.nfrag_f + G.nfrag_b) * 64;
+        float a[kCMaxKs], o[kCMaxKs], ab[kCMaxKs], z[kCMaxKs];
+#pragma unroll
+        for (int k = 0; k < kCMaxKs; ++k) { a[k] = k < NKD ? hin[k < NKD ? k : 0] : 0.f; o[k] = k < NKD ? gout[k < NKD ? k : 0] : 0.f; ab[k] = k < NKD ? gbar[k < NKD ? k : 0] : 0.f; }
+        chain_store_rows_t<(NKD + 3) / 4>(sl + (size_t)C.hrow[0] * 64, a);
+        chain_store_rows_t<(NKD + 3) / 4>(sl + (size_t)C.hrow[1] * 64, o);
+        sde_zstage_fixed<NKD>(ab, G.act[0] != 0, o, sl + (size_t)C.zrow[0] * 64, z);
+        sde_layer_bwd_fixed<NKD, NKD>(G, TF, 0, z, ab, lane);
+#pragma unroll
+        for (int k = 0; k < NKD; ++k) hb[k] = ab[k];
+    }
+}
+
 // ---- reverse sweep: every accepted step backwards, one launch, no meeting between workgroups ----------------------------------
 struct SdeBwdParams {
     SdeParams F;
@@ -612,7 +716,7 @@ struct SdeBwdParams {
 };
 static_assert(sizeof(SdeBwdParams) <= 4096, "kernel argument segment");
 
-template <int NKD>
+template <int NKD, int FIXH = 0>
 __global__ __launch_bounds__(64 * kCW) void rnde_sde_bwd_kernel(const SdeBwdParams Bq) {
     const SdeParams& Q = Bq.F;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -632,8 +736,8 @@ __global__ __launch_bounds__(64 * kCW) void rnde_sde_bwd_kernel(const SdeBwdPara
     const SriTableau& T = Q.T;
     const BChainParams& Cf = Bq.Cf;   // the two nets as chain_fbwd wants them (kernel-argument memory: their tables stay scalar loads)
     const BChainParams& Cg = Bq.Cg;
-    const float* FRf = Ff; const float* BFf = Ff + (size_t)Q.Gf.nfrag_f * 64; const float* TFf = BFf + (size_t)Q.Gf.nfrag_b * 64;
-    const float* FRg = Fg; const float* BFg = Fg + (size_t)Q.Gg.nfrag_f * 64; const float* TFg = BFg + (size_t)Q.Gg.nfrag_b * 64;
+    const float* FRf = Ff;
+    const float* FRg = Fg;
     const double N = (double)Q.D * (double)Q.B;
     const float sqrt3 = 1.7320508075688772f;
     const size_t as = (size_t)Q.ntiles * NKD * 64;
@@ -696,9 +800,8 @@ __global__ __launch_bounds__(64 * kCW) void rnde_sde_bwd_kernel(const SdeBwdPara
                 h0[q] = s ? up[q] + dt * a0 + chi2[q] * b0 : up[q];
                 h1[q] = s ? up[q] + dt * a1 + sqdt * b1 : up[q];
             }
-            float tau = 0.f;
             float* slf = Cf.slab + (size_t)(4 * a + s) * Cf.ev_stride + ((size_t)tile * Cf.RS) * 64 + lane;
-            chain_fbwd<NKD, 0>(Cf, FRf, BFf, TFf, 0.f, h0, k[s], kb[s], hb, slf, tau, lane);
+            sde_drift_bwd<NKD, FIXH>(Cf, FRf, h0, k[s], kb[s], hb, slf, lane);
 #pragma unroll
             for (int q = 0; q < NKD; ++q) {
                 upb[q] += hb[q];
@@ -706,7 +809,7 @@ __global__ __launch_bounds__(64 * kCW) void rnde_sde_bwd_kernel(const SdeBwdPara
                 for (int j = 0; j < 4; ++j) if (j < s) { kb[j][q] += dt * T.A0[4 * s + j] * hb[q]; gb[j][q] += chi2[q] * T.B0[4 * s + j] * hb[q]; }
             }
             float* slg = Cg.slab + (size_t)(4 * a + s) * Cg.ev_stride + ((size_t)tile * Cg.RS) * 64 + lane;
-            chain_fbwd<NKD, 0>(Cg, FRg, BFg, TFg, 0.f, h1, g[s], gb[s], hb, slg, tau, lane);
+            sde_diff_bwd<NKD, FIXH>(Cg, FRg, h1, g[s], gb[s], hb, slg, lane);
 #pragma unroll
             for (int q = 0; q < NKD; ++q) {
                 upb[q] += hb[q];

@@ -19,6 +19,7 @@ using namespace rnde;
 struct rnde_nsde {
     rnde_nsde_config cfg{};
     int D = 0, Pf = 0, Pg = 0, P = 0, NKD = 8, Bpad_max = 0, ntiles_max = 0, nwg_max = 0;
+    int fix = 0;   // 1: the reference's own shape (drift 8 -> 16 -> 8 k-steps, one-layer diffusion): kernels with compile-time shapes
     ChainGeo Gf{}, Gg{};
     SriTableau T{};
     float order = 1.5f, beta1 = 0, beta2 = 0, gamma = 0, qmin = 0, qmax = 0, qoldinit = 0, delta = 0;
@@ -142,6 +143,7 @@ extern "C" rnde_status rnde_nsde_create(const rnde_nsde_config* c, rnde_nsde** o
     h->cfg = *c; h->D = D; h->Gf = Gf; h->Gg = Gg;
     h->Pf = chain_params(c->drift_layers, c->drift_dims); h->Pg = chain_params(c->diff_layers, c->diff_dims); h->P = h->Pf + h->Pg;
     h->NKD = D <= 16 ? 4 : (D <= 32 ? 8 : 16);
+    h->fix = (c->drift_layers == 2 && c->diff_layers == 1 && Gf.nks[0] == 8 && Gf.nks[1] == 16 && c->generic == 0) ? 1 : 0;
     float ddef = 1.f;
     sde_tableau(c->solver, h->T, ddef);
     h->order = 1.5f;
@@ -222,15 +224,15 @@ static rnde_status sde_pack(rnde_nsde* h, const float* p_dev, hipStream_t s) {
     return RNDE_OK;
 }
 
-template <int NKD>
+template <int NKD, int FIXH = 0>
 static hipError_t launch_solve(rnde_nsde* h, const SdeParams& Q, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)rnde_sde_solve_kernel<NKD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)rnde_sde_solve_kernel<NKD, FIXH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr = true;
     }
-    hipLaunchKernelGGL(rnde_sde_solve_kernel<NKD>, dim3(Q.nwg), dim3(64 * kCW), h->lds_fwd, s, Q);
+    hipLaunchKernelGGL((rnde_sde_solve_kernel<NKD, FIXH>), dim3(Q.nwg), dim3(64 * kCW), h->lds_fwd, s, Q);
     return hipGetLastError();
 }
 template <int NKD>
@@ -244,15 +246,15 @@ static hipError_t launch_attempt(rnde_nsde* h, const SdeParams& Q, const float* 
     hipLaunchKernelGGL(rnde_sde_attempt_kernel<NKD>, dim3(Q.nwg), dim3(64 * kCW), h->lds_fwd, s, Q, up, dW, dZ, dt, kg, un, h->part);
     return hipGetLastError();
 }
-template <int NKD>
+template <int NKD, int FIXH = 0>
 static hipError_t launch_bwd(rnde_nsde* h, const SdeBwdParams& Bq, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)rnde_sde_bwd_kernel<NKD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)rnde_sde_bwd_kernel<NKD, FIXH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr = true;
     }
-    hipLaunchKernelGGL(rnde_sde_bwd_kernel<NKD>, dim3(Bq.F.nwg), dim3(64 * kCW), h->lds_bwd, s, Bq);
+    hipLaunchKernelGGL((rnde_sde_bwd_kernel<NKD, FIXH>), dim3(Bq.F.nwg), dim3(64 * kCW), h->lds_bwd, s, Bq);
     return hipGetLastError();
 }
 
@@ -305,7 +307,8 @@ static rnde_status nsde_forward_impl(rnde_nsde* h, const float* x_dev, const flo
     }
     h->tev_f = false;
     SCHK(h, hipEventRecord(h->tev[0], s));
-    hipError_t e = h->NKD == 4 ? launch_solve<4>(h, Q, s) : (h->NKD == 8 ? launch_solve<8>(h, Q, s) : launch_solve<16>(h, Q, s));
+    hipError_t e = h->fix ? launch_solve<8, 16>(h, Q, s)
+                 : (h->NKD == 4 ? launch_solve<4>(h, Q, s) : (h->NKD == 8 ? launch_solve<8>(h, Q, s) : launch_solve<16>(h, Q, s)));
     SCHK(h, e);
     SCHK(h, hipEventRecord(h->tev[1], s));
     h->tev_f = true;
@@ -444,7 +447,8 @@ extern "C" rnde_status rnde_nsde_backward(rnde_nsde* h, const float* u_bar_dev, 
     }
     h->tev_b = false;
     SCHK(h, hipEventRecord(h->tev[2], s));
-    hipError_t e = h->NKD == 4 ? launch_bwd<4>(h, Bq, s) : (h->NKD == 8 ? launch_bwd<8>(h, Bq, s) : launch_bwd<16>(h, Bq, s));
+    hipError_t e = h->fix ? launch_bwd<8, 16>(h, Bq, s)
+                 : (h->NKD == 4 ? launch_bwd<4>(h, Bq, s) : (h->NKD == 8 ? launch_bwd<8>(h, Bq, s) : launch_bwd<16>(h, Bq, s)));
     SCHK(h, e);
     SCHK(h, hipEventRecord(h->tev[3], s));
     h->tev_b = true;

@@ -325,3 +325,22 @@ def test_dropped_graph_returns_the_handle():
     # and a float64 parameter vector is refused instead of being reinterpreted
     with pytest.raises(TypeError):
         node(x, p.detach().double())
+
+
+def test_fixed_shape_kernels_agree_with_the_generic_ones():
+    """The reference's own shape (32 -> 64 -> 32, 32 -> 32) runs on kernels with the shapes as compile-time constants; cfg.generic = 1
+    keeps the run-time-shape kernels.  Same arithmetic in the same order: same step sequence, states and gradients to rounding."""
+    from tests.util import NsdeNode
+    drift, diff, p, x, noise = _setup("nsde", 50, 17, 257)
+    rng = np.random.default_rng(3)
+    ubar = (rng.standard_normal(x.shape) / 50).astype(np.float32)
+    outs = []
+    for generic in (0, 1):
+        node = NsdeNode(_cfg(drift, diff, 50, generic=generic))
+        r = node.forward(x, p, noise, keep_tape=True)
+        xb, pb = node.backward(ubar, np.full(len(r["saveval"]), 0.2, np.float32))
+        outs.append((r, xb, pb))
+        node.close()
+    (a, xa, pa), (b, xb, pb) = outs
+    assert a["nattempts"] == b["nattempts"] and np.array_equal(a["steps"][:, 3], b["steps"][:, 3])
+    assert _rel(a["u"], b["u"]) <= 1e-6 and _rel(xa, xb) <= 1e-5 and _rel(pa, pb) <= 1e-5

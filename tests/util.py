@@ -144,7 +144,7 @@ def rel_err(a, b):
 
 # ---- stochastic layer (rnde_nsde_*) ------------------------------------------------------------------------------------
 def make_nsde_cfg(drift_dims, drift_acts, diff_dims, diff_acts, max_batch, reltol=0.14, abstol=0.14, solver="SOSRI", regularize=1,
-                  cb_save_start=1, max_attempts=256, **ctrl):
+                  cb_save_start=1, max_attempts=256, generic=0, **ctrl):
     cfg = _lib.NsdeConfig()
     cfg.drift_layers = len(drift_acts)
     for i, d in enumerate(drift_dims):
@@ -162,6 +162,7 @@ def make_nsde_cfg(drift_dims, drift_acts, diff_dims, diff_acts, max_batch, relto
     cfg.regularize, cfg.cb_save_start, cfg.max_attempts, cfg.device = regularize, cb_save_start, max_attempts, 0
     for k in ("beta1", "beta2", "gamma", "qmin", "qmax", "qoldinit", "delta"):
         setattr(cfg, k, ctrl.get(k, 0.0))
+    cfg.generic = generic
     return cfg
 
 

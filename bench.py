@@ -237,7 +237,8 @@ def main():
     g = torch.Generator().manual_seed(1999 + rank)
     x = torch.rand(B, 1, 28, 28, generator=g).to(device)                  # uniform [0,1) images, mnist_node.jl:206
     y = torch.eye(NCLS)[torch.randint(0, NCLS, (B,), generator=g)].to(device)
-    reducer = rn.GradientAllReducer(model.trainable()) if use_dist else None
+    fg = rn.FlatGrads(model.trainable()) if use_dist else None
+    reducer = rn.GradientAllReducer(model.trainable(), flat=fg) if use_dist else None   # the library's RCCL communicator (rnde_comm_*)
     nfes = []
     saved = [p.detach().clone() for p in model.trainable()]
 
@@ -246,11 +247,11 @@ def main():
             loss, ce, reg, nfe = rn.loss_function(x, y, model, lam=1.0e2)
             loss.backward()
             loss = float(loss.detach())
-        else:
-            loss, ce, reg, nfe = rn.fused_loss_and_grad(model, x, y, lam=1.0e2, sync=False)   # loss stays on the device
-        if use_dist:
-            reducer.allreduce_()                                          # one RCCL sum over xGMI, 166,418 fp32
-        opt.step()
+            if use_dist:
+                reducer.allreduce_(mean=False)
+        else:   # loss stays on the device; with a reducer the two gradient all-reduces (RCCL over xGMI, 166,418 fp32 in all) are queued inside
+            loss, ce, reg, nfe = rn.fused_loss_and_grad(model, x, y, lam=1.0e2, sync=False, flat=fg, reducer=reducer)
+        opt.step(grad_scale=reducer.grad_scale if use_dist else 1.0)
         if restore:                                                       # fixed-weights leg: the update ran, its effect is undone
             with torch.no_grad():
                 for p, s0 in zip(model.trainable(), saved):
@@ -354,7 +355,9 @@ def main():
                "us_per_attempt_fwd": 1e3 * sum(fa) / max(1, sum(atts)),
                "us_per_attempt_rev": 1e3 * sum(rs) / max(1, sum(atts)),
                "rev_rest_ms": sum(rr) / len(rr),
-               "persist_fallback": bool(stage_engine and nl != 1),
+               "persist_fallback": bool(stage_engine and nl != 1), "persist_fallback_count": int(L.rnde_node_fallback_count(h.ptr)),
+               "collective": (None if not use_dist else "rnde_comm_allreduce (RCCL via librnde.so): head gradient queued before the reverse sweep, "
+                              "solve gradient behind it; 1/world folded into the optimiser launch"),
                "config": {"workload": "MNIST NODE regularized (error_est), Tsit5 reltol=abstol=1.4e-8, batch 512 per GPU, "
                                       "1xMI355X per rank; step = loss fwd + reverse pass through the solver + "
                                       "InvDecay/Momentum update; the weights train during the timed steps (mean_nfe drifts with "

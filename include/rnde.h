@@ -168,6 +168,9 @@ rnde_status rnde_bench_attempt_taped(rnde_node* h, const float* x_dev, const flo
 rnde_status rnde_node_set_timing(rnde_node* h, int32_t on);
 rnde_status rnde_node_timing(rnde_node* h, float* fwd_attempts_ms, float* rev_sweep_ms, float* rev_rest_ms);
 int32_t     rnde_node_last_attempts(const rnde_node* h);   /* attempted steps of the last forward */
+/* How often the one-launch attempt kernels gave up a hand-off (co-tenant on the CUs for > 1 s) and the handle went to the
+ * 7-launch kernels; it returns to the one-launch kernels after 8, 16, 32, ... clean solves (not sticky). */
+int32_t     rnde_node_fallback_count(const rnde_node* h);
 /* How the handle currently runs one attempted step: number of kernel launches (1: rnde_stage_attempt_kernel /
  * rnde_step_kernel / rnde_chain_kernel; 7: rnde_stage_kernel START, 5 x STAGE, LAST) -- bench.py's roofline bookkeeping. */
 int32_t     rnde_node_launches_per_attempt(const rnde_node* h);
@@ -188,6 +191,33 @@ rnde_status rnde_classifier_head(rnde_node* h, const float* u_dev, const float* 
  * p, g, v: device vectors of `len` floats; in place on p and v.  No handle: pure function of its arguments, asynchronous. */
 rnde_status rnde_momentum_step(float* p_dev, const float* g_dev, float* v_dev, int64_t len, int64_t n, float gamma,
                                float eta, float rho, void* stream);
+
+/* The same update with the gradient scaled first: g' = gscale * g / (1 + gamma * n).  gscale = 1 / world folds the averaging of a
+ * sum-all-reduced gradient (rnde_comm_allreduce with mean = 0) into the optimiser launch. */
+rnde_status rnde_momentum_step_scaled(float* p_dev, const float* g_dev, float* v_dev, int64_t len, int64_t n, float gamma,
+                                      float eta, float rho, float gscale, void* stream);
+
+/* ======================================================================================================================
+ * Data parallelism: the one collective of a training step.  The reference is single-process; with the
+ * minibatch sharded by columns over the GPUs of a node (one process per GPU, each integrating its shard with its own
+ * controller), the only exchange is a sum of the flat gradient between Tracker.gradient and update_parameters!
+ * (reference experiments/mnist_node.jl:229-233, src/utils.jl:149-156).  rnde_comm_* gives a non-Python caller that
+ * collective from this library: RCCL over xGMI on the caller's stream.  RCCL is bound at run time (dlopen): no link-time
+ * dependency, never loaded by single-GPU users.
+ *   rank 0: rnde_comm_unique_id(id) -> ship the 128 bytes to the other ranks by any means (Julia: Distributed / MPI; Python:
+ *   the torch.distributed store) -> every rank: rnde_comm_create(id, rank, world, device, &c) (collective: blocks until all
+ *   ranks arrive) -> per step: rnde_comm_allreduce(c, grad_dev, n, mean, stream) -> rnde_comm_destroy(c).
+ * ====================================================================================================================== */
+#define RNDE_COMM_ID_BYTES 128
+typedef struct rnde_comm rnde_comm;
+rnde_status rnde_comm_unique_id(uint8_t id_out[RNDE_COMM_ID_BYTES]);
+rnde_status rnde_comm_create(const uint8_t id[RNDE_COMM_ID_BYTES], int32_t rank, int32_t world, int32_t device, rnde_comm** out);
+void        rnde_comm_destroy(rnde_comm* c);
+int32_t     rnde_comm_world(const rnde_comm* c);
+const char* rnde_comm_last_error(const rnde_comm* c);   /* c may be NULL: last create / id error of this thread */
+/* In-place sum of n floats over the ranks (mean != 0: followed by a scale by 1 / world), asynchronous on `stream`.
+ * MNIST-NODE payload: 166,418 floats = 665,672 B in ONE call (latency bound: one contiguous buffer). */
+rnde_status rnde_comm_allreduce(rnde_comm* c, float* buf_dev, int64_t n, int32_t mean, void* stream);
 
 /* ======================================================================================================================
  * TrackedNeuralDSDE: the stochastic layer (reference src/models/neural_sde.jl:1-146; caller ClassifierNSDE,

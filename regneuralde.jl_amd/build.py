@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 # RNDE_LIB: load another build of the same library (A/B runs of kernel variants on one GPU box; tools/ab_bench.sh)
 LIB = os.environ.get("RNDE_LIB") or os.path.join(_HERE, "lib", "librnde.so")
-SOURCES = ["rnde.hip", "rnde_sde.hip"]
+SOURCES = ["rnde.hip", "rnde_sde.hip", "rnde_comm.hip"]
 
 
 def _headers():
@@ -45,7 +45,7 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

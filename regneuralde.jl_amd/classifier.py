@@ -41,13 +41,17 @@ class ClassifierNODE:
         return u @ W + b, nfe, sv
 
 
-def fused_loss_and_grad(model, x, y, lam=1.0e2, regularize=True, tspan=None, sync=True):
+def fused_loss_and_grad(model, x, y, lam=1.0e2, regularize=True, tspan=None, sync=True, flat=None, reducer=None):
     """One training-step gradient without a tape library in the loop:
     [solve, taped] -> [fused Dense(784,10) + logitcrossentropy + their reverse] -> [reverse solve], all through the C ABI.
     Same loss surface as `loss_function` (experiments/mnist_node.jl:132-137, agg = mean): sets .grad on p2 and p3 and
     returns (total_loss, cross_entropy, reg, nfe) as Python floats / int (the call already synchronises).
     sync=False: the reverse pass is only enqueued (rnde_node_backward_async) and the losses come back as device tensors, so a
-    training loop can queue the optimiser update and the next step underneath it; nothing is read on the host."""
+    training loop can queue the optimiser update and the next step underneath it; nothing is read on the host.
+    flat (dataparallel.FlatGrads over model.trainable()): the reverse pass writes both gradients straight into that one
+    contiguous buffer; reducer (dataparallel.GradientAllReducer on the same buffer): the head's gradient is sum-all-reduced as
+    soon as the head kernel is queued -- it travels while the reverse sweep of the solve runs -- and the solve's gradient right
+    behind the sweep; averaging is left to the optimiser (reducer.grad_scale)."""
     import ctypes as C
     from . import _lib
     node = model.node
@@ -69,7 +73,10 @@ def fused_loss_and_grad(model, x, y, lam=1.0e2, regularize=True, tspan=None, syn
                                           C.byref(nsv), 1, stream))
     n_cls = model.post_shape[1]
     ubar = torch.empty_like(x2)
-    p3bar = torch.empty_like(p3)
+    if flat is not None:                                  # trainable() = (p1 (empty), p2, p3) -> groups [p2, p3]
+        p2bar, p3bar = flat.views[0], flat.views[1]
+    else:
+        p2bar, p3bar = torch.empty_like(p2), torch.empty_like(p3)
     ce = torch.empty(1, dtype=torch.float32, device=x2.device)
     _lib.check(h.ptr, L.rnde_classifier_head(h.ptr, u.data_ptr(), p3.data_ptr(), y.contiguous().data_ptr(), B, n_cls, None,
                                              ubar.data_ptr(), p3bar.data_ptr(), ce.data_ptr(), stream))
@@ -80,14 +87,20 @@ def fused_loss_and_grad(model, x, y, lam=1.0e2, regularize=True, tspan=None, syn
         reg = lam * sum(sv[:n]) / n                       # lambda * mean(sv.saveval)
         svb = (C.c_float * n)(*([lam / n] * n))
     xbar = torch.empty_like(x2)
-    p2bar = torch.empty_like(p2)
+    n2 = p2bar.numel()
+    if reducer is not None:
+        reducer.allreduce_range_(n2, n2 + p3bar.numel())     # the head's gradient: on its way before the reverse sweep starts
     if not sync:
         _lib.check(h.ptr, L.rnde_node_backward_async(h.ptr, ubar.data_ptr(), svb, xbar.data_ptr(), p2bar.data_ptr(), None, stream))
+        if reducer is not None:
+            reducer.allreduce_range_(0, n2)
         model.p2.grad, model.p3.grad = p2bar, p3bar
         node.last_nfe = int(nfe.value)
         model._keep = (ubar, xbar, u)            # buffers the enqueued kernels still use
         return ce + reg, ce, reg, int(nfe.value)
     _lib.check(h.ptr, L.rnde_node_backward(h.ptr, ubar.data_ptr(), svb, xbar.data_ptr(), p2bar.data_ptr(), None, stream))
+    if reducer is not None:
+        reducer.allreduce_range_(0, n2)
     model.p2.grad, model.p3.grad = p2bar, p3bar
     node.last_nfe = int(nfe.value)
     ce_f = float(ce.item())
@@ -119,7 +132,8 @@ class FluxOptimiser:
         self.v = [torch.zeros_like(p) for p in self.params]
 
     @torch.no_grad()
-    def step(self, grads=None):
+    def step(self, grads=None, grad_scale=1.0):
+        """grad_scale: factor applied to the gradients first (1 / world after a sum-all-reduce: the averaging rides in this launch)."""
         for i, p in enumerate(self.params):
             g = p.grad if grads is None else grads[i]
             if g is None:
@@ -128,14 +142,14 @@ class FluxOptimiser:
                 import ctypes as C
                 from . import _lib
                 g = g.contiguous()
-                st = _lib.lib().rnde_momentum_step(p.data_ptr(), g.data_ptr(), self.v[i].data_ptr(), p.numel(), self.n[i],
-                                                   self.gamma, self.eta, self.rho,
-                                                   C.c_void_p(torch.cuda.current_stream(p.device).cuda_stream))
+                st = _lib.lib().rnde_momentum_step_scaled(p.data_ptr(), g.data_ptr(), self.v[i].data_ptr(), p.numel(), self.n[i],
+                                                          self.gamma, self.eta, self.rho, float(grad_scale),
+                                                          C.c_void_p(torch.cuda.current_stream(p.device).cuda_stream))
                 _lib.check(None, st)
                 self.n[i] += 1
                 p.grad = None
                 continue
-            g = g / (1.0 + self.gamma * self.n[i])         # InvDecay (host tensors: the same recurrence in torch ops)
+            g = g * (grad_scale / (1.0 + self.gamma * self.n[i]))   # InvDecay (host tensors: the same recurrence in torch ops)
             self.n[i] += 1
             self.v[i].mul_(self.rho).sub_(g, alpha=self.eta)   # Momentum: v = rho v - eta g ; x -= -v
             p.add_(self.v[i])

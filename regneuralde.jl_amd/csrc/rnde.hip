@@ -53,7 +53,8 @@ struct rnde_node {
     float* sv_t_dev = nullptr; size_t sv_cap = 0; std::vector<float> saveat;   // saveat times of the last forward
     float* replay_dev = nullptr; size_t replay_cap = 0; const float* replay_host = nullptr; int n_replay = 0;   // rnde_node_forward_replay (set for one forward)
     // persistent attempt kernel (rnde_stage_persist.h): 1 = in use, 0 = off (RNDE_PERSIST=0), -1 = disabled after a failure
-    int wgrad_side_pct = 35, stage_generic = 0, persist_clean = 0;   // fixed at creation (config fields; RNDE_* environment overrides are read once, there)
+    int wgrad_side_pct = 35, stage_generic = 0;
+    int persist_clean = 0, persist_retry_after = 8, persist_fallbacks = 0;   // non-sticky fallback: clean multi-launch solves since the last failure, when to try again   // fixed at creation (config fields; RNDE_* environment overrides are read once, there)
     int persist = 0, persist_spins = kPersistMaxSpins; int tslab_Bpad = -1; size_t tslab_bytes = 0; float* tslab = nullptr; unsigned *pabort = nullptr, *pxcc = nullptr; unsigned* h_pchk = nullptr;
     hipStream_t wstream = nullptr;        // (experimental overlap path of the weight-gradient GEMMs)
     std::vector<hipEvent_t> wevents;
@@ -517,8 +518,9 @@ static bool persist_check_result(rnde_node* h, int C, int R, hipStream_t s) {   
     for (int ct = 0; ct < C && !bad; ++ct)
         for (int rb = 1; rb < R; ++rb) if (h->h_pchk[2 + rb * C + ct] != h->h_pchk[2 + ct]) { bad = true; break; }
     if (bad) {
-        fprintf(stderr, "[rnde] persistent attempt kernel disabled (%s); using the multi-launch kernels\n", h->h_pchk[0] ? "hand-off timed out" : "column tile spans XCDs");
-        h->persist = -1;
+        fprintf(stderr, "[rnde] persistent attempt kernel suspended (%s); using the multi-launch kernels for the next %d solves\n",
+                h->h_pchk[0] ? "hand-off timed out" : "column tile spans XCDs", h->persist_retry_after);
+        h->persist = -1; h->persist_clean = 0; ++h->persist_fallbacks;
         hipMemsetAsync(h->pabort, 0, 8, s);
     }
     return bad;
@@ -672,6 +674,12 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
     }
     h->n_att = h->h_ctl->n_att;
     h->predicted = h->n_att + 1;
+    // a hand-off time-out (a co-tenant held CUs for a second, e.g. another process's kernels) must not halve the speed for good:
+    // after `persist_retry_after` clean multi-launch solves the one-launch kernels get another chance; each new failure doubles the wait
+    if (h->persist == -1 && h->engine == 2 && h->cfg.persist >= 0 && ++h->persist_clean >= h->persist_retry_after) {
+        h->persist = 1; h->persist_retry_after = std::min(1024, 2 * h->persist_retry_after);
+        h->tslab_Bpad = -1;                          // slabs are refilled with the empty pattern before the next persistent launch
+    }
     if (nfe_out) *nfe_out = 3 + 6 * (int64_t)h->n_att;  // 2 (initial dt) + 1 (fsalfirst) + 6 per attempt, SURVEY.md B.1-B.2
     // saving callback values (reference neural_ode.jl:116,:126-127): EEst*dt per accepted step
     int nsv = 0;
@@ -738,6 +746,7 @@ extern "C" rnde_status rnde_node_timing(rnde_node* h, float* fwd_attempts_ms, fl
     return RNDE_OK;
 }
 extern "C" int32_t rnde_node_last_attempts(const rnde_node* h) { return h ? h->n_att : 0; }
+extern "C" int32_t rnde_node_fallback_count(const rnde_node* h) { return h ? h->persist_fallbacks : 0; }
 
 extern "C" int32_t rnde_node_launches_per_attempt(const rnde_node* h) {
     if (!h) return 0;
@@ -1447,11 +1456,17 @@ static rnde_status chain_bwd_run(rnde_node* h, const float* u_bar_dev, const flo
     return RNDE_OK;
 }
 
+extern "C" rnde_status rnde_momentum_step_scaled(float* p_dev, const float* g_dev, float* v_dev, int64_t len, int64_t n, float gamma,
+                                                 float eta, float rho, float gscale, void* stream);
 extern "C" rnde_status rnde_momentum_step(float* p_dev, const float* g_dev, float* v_dev, int64_t len, int64_t n, float gamma,
                                           float eta, float rho, void* stream) {
+    return rnde_momentum_step_scaled(p_dev, g_dev, v_dev, len, n, gamma, eta, rho, 1.0f, stream);
+}
+extern "C" rnde_status rnde_momentum_step_scaled(float* p_dev, const float* g_dev, float* v_dev, int64_t len, int64_t n, float gamma,
+                                                 float eta, float rho, float gscale, void* stream) {
     if (!p_dev || !g_dev || !v_dev || len < 0 || n < 1) return RNDE_ERR_BAD_ARG;
     if (len == 0) return RNDE_OK;
-    const float inv_decay = 1.0f / (1.0f + gamma * (float)n);
+    const float inv_decay = gscale / (1.0f + gamma * (float)n);
     hipLaunchKernelGGL(rnde::rnde_momentum_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p_dev, g_dev,
                        v_dev, (long long)len, inv_decay, eta, rho);
     return hipGetLastError() == hipSuccess ? RNDE_OK : RNDE_ERR_HIP;

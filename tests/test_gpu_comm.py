@@ -1,0 +1,66 @@
+"""The gradient collective behind the C ABI (rnde_comm_*, RCCL bound at run time) on the one GPU of the test box: world = 1
+exercises id creation, communicator set-up, the all-reduce launch on the caller's stream and the folded averaging; the
+world-2 arithmetic of the same classes is covered on CPU by tests/test_dist_gloo.py."""
+import ctypes as C
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_comm_world1_through_the_abi():
+    import torch
+    from regneuralde_jl_amd import _lib
+    L = _lib.lib()
+    buf = C.create_string_buffer(128)
+    assert L.rnde_comm_unique_id(buf) == 0, L.rnde_comm_last_error(None)
+    comm = C.c_void_p()
+    assert L.rnde_comm_create(bytes(buf.raw), 0, 1, 0, C.byref(comm)) == 0, L.rnde_comm_last_error(None)
+    assert L.rnde_comm_world(comm) == 1
+    g = torch.arange(166418, dtype=torch.float32, device="cuda") / 1000.0
+    ref = g.clone()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        assert L.rnde_comm_allreduce(comm, g.data_ptr(), g.numel(), 1, C.c_void_p(s.cuda_stream)) == 0
+    s.synchronize()
+    assert torch.equal(g, ref)
+    assert L.rnde_comm_create(bytes(buf.raw), 3, 2, 0, C.byref(C.c_void_p())) == _lib.BAD_ARG     # rank >= world
+    L.rnde_comm_destroy(comm)
+
+
+def test_training_step_with_flat_gradients_and_early_allreduce():
+    """fused_loss_and_grad(flat=, reducer=): the reverse pass writes into ONE buffer, the head's gradient is all-reduced before the
+    sweep, the solve's behind it, 1/world rides in the optimiser launch -- same update as the single-process step."""
+    import torch
+    import torch.distributed as dist
+    import regneuralde_jl_amd as rn
+    store = tempfile.NamedTemporaryFile(delete=False)
+    dist.init_process_group("gloo", init_method=f"file://{store.name}", rank=0, world_size=1)
+    try:
+        def make():
+            g = torch.Generator().manual_seed(4)
+            dyn = rn.MLPDynamics(784, 100, generator=g)
+            node = rn.TrackedNeuralODE(dyn, [0.0, 1.0], True, True, "Tsit5", reltol=1e-3, abstol=1e-3, max_batch=32, max_attempts=64)
+            return rn.ClassifierNODE(node, rn.Dense(784, 10, generator=g), device=torch.device("cuda", 0)), g
+        m1, g1 = make()
+        m2, _ = make()
+        x = torch.rand(32, 1, 28, 28, generator=g1).cuda()
+        y = torch.eye(10)[torch.randint(0, 10, (32,), generator=g1)].cuda()
+        fg = rn.FlatGrads(m2.trainable())
+        red = rn.GradientAllReducer(m2.trainable(), flat=fg)
+        assert red.comm is not None and fg.flat.numel() == 158568 + 7850
+        o1, o2 = rn.FluxOptimiser(m1.trainable()), rn.FluxOptimiser(m2.trainable())
+        for _ in range(3):
+            rn.fused_loss_and_grad(m1, x, y, sync=True)
+            o1.step()
+            rn.fused_loss_and_grad(m2, x, y, sync=False, flat=fg, reducer=red)
+            assert m2.p2.grad.data_ptr() == fg.flat.data_ptr()
+            o2.step(grad_scale=red.grad_scale)
+        torch.cuda.synchronize()
+        assert torch.equal(m1.p2, m2.p2) and torch.equal(m1.p3, m2.p3)
+    finally:
+        dist.destroy_process_group()
+        os.unlink(store.name)

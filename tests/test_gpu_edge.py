@@ -111,7 +111,7 @@ def test_full_size_replication_property():
 
 def test_persistent_kernel_failure_falls_back_to_the_multi_launch_kernels(monkeypatch):
     """Safety net of rnde_stage_persist.h: when a hand-off gives up (here: a polling bound of zero, so the first poll that is not
-    satisfied at once abandons the launch) the handle must notice, switch to the 7-launch kernels for good and redo the solve --
+    satisfied at once abandons the launch) the handle must notice, switch to the 7-launch kernels and redo the solve --
     the caller sees correct results, not an error and not garbage."""
     import ctypes as C
     from tests.test_gpu_forward import _cfg, _setup
@@ -129,6 +129,15 @@ def test_persistent_kernel_failure_falls_back_to_the_multi_launch_kernels(monkey
     assert got["nfe"] == ref["nfe"] and np.array_equal(got["u"], ref["u"]) and np.array_equal(got["saveval"], ref["saveval"])
     again = node.forward(x, p)
     assert np.array_equal(again["u"], ref["u"])
+    # not sticky: after 8 clean multi-launch solves the one-launch kernels get another chance (here they fail again at once,
+    # because the polling bound is still zero -- the caller still sees correct results, and the wait doubles)
+    node.L.rnde_node_fallback_count.restype = C.c_int32
+    assert node.L.rnde_node_fallback_count(node.h) == 1
+    for _ in range(6):
+        assert np.array_equal(node.forward(x, p)["u"], ref["u"])
+    assert node.L.rnde_node_launches_per_attempt(node.h) == 1          # armed again
+    assert np.array_equal(node.forward(x, p)["u"], ref["u"])
+    assert node.L.rnde_node_fallback_count(node.h) == 2 and node.L.rnde_node_launches_per_attempt(node.h) == 7
 
 
 @pytest.mark.parametrize("D,H,B", [(8, 50, 21), (20, 15, 9), (40, 31, 33), (130, 47, 18)])

@@ -1,18 +1,24 @@
-# RNDE.jl -- Julia binding of librnde.so (include/rnde.h) for RegNeuralDE.jl.
+# RNDE.jl -- Julia binding of librnde.so (include/rnde.h) for RegNeuralDE.jl on MI355X.
 #
-# SOURCE ONLY: no Julia toolchain exists in the build image, so this file has never been executed.
-# It shows exactly what a maintainer adds to the reference: the body of the TrackedNeuralODE call methods
-# between ODEProblem construction and result unpacking (reference src/models/neural_ode.jl:126-142) becomes
-# one `ccall`, and the reverse sweep is registered with `Tracker.@grad` so that
+# SOURCE ONLY: no Julia toolchain exists in the build image, so this file has never been executed (INTEGRATION.md says what
+# was checked instead: every prototype below is the one regneuralde.jl_amd/_lib.py binds with ctypes and the GPU tests call).
+# It shows exactly what a maintainer adds to the reference: the body of the TrackedNeuralODE call methods between ODEProblem
+# construction and result unpacking (reference src/models/neural_ode.jl:126-142) becomes one `ccall`, the same for
+# TrackedNeuralDSDE (src/models/neural_sde.jl:98-113), and the reverse sweeps are registered with `Tracker.@grad` so that
 # `Tracker.gradient(...)` (reference experiments/mnist_node.jl:229-232) keeps working unchanged.
+#
+# Device arrays are AMDGPU.jl `ROCArray`s (the reference's `|> gpu` becomes `|> roc`).  A device pointer crosses the ABI as a
+# plain `Ptr{Cvoid}`: `devptr(a)` below reinterprets AMDGPU's typed device pointer, nothing else about the array is touched.
 module RNDE
 
-using CUDA: CuArray           # the reference's array type; on MI355X use AMDGPU.ROCArray (same pointer semantics)
+using AMDGPU: ROCArray, ROCVector, ROCMatrix
 using Tracker
 using Tracker: TrackedArray, data, track, @grad
 
 const LIB = joinpath(@__DIR__, "..", "..", "regneuralde.jl_amd", "lib", "librnde.so")
 const MAX_LAYERS = 8
+
+devptr(a::ROCArray) = reinterpret(Ptr{Cvoid}, pointer(a))
 
 # mirrors rnde_node_config (include/rnde.h); field order and widths must match
 struct NodeConfig
@@ -32,16 +38,20 @@ struct NodeConfig
     max_attempts::Int32
     device::Int32
     col_tile::Int32
+    persist::Int32
+    wgrad_side_pct::Int32
+    stage_generic::Int32
 end
 
 mutable struct Handle
     ptr::Ptr{Cvoid}
     cfg::NodeConfig
+    last_nfe::Int
     function Handle(cfg::NodeConfig)
         out = Ref{Ptr{Cvoid}}(C_NULL)
         st = ccall((:rnde_node_create, LIB), Cint, (Ref{NodeConfig}, Ref{Ptr{Cvoid}}), cfg, out)
         st == 0 || error("rnde_node_create: ", unsafe_string(ccall((:rnde_last_error, LIB), Cstring, (Ptr{Cvoid},), C_NULL)))
-        h = new(out[], cfg)
+        h = new(out[], cfg, 0)
         finalizer(h -> ccall((:rnde_node_destroy, LIB), Cvoid, (Ptr{Cvoid},), h.ptr), h)
         return h
     end
@@ -52,10 +62,10 @@ check(h::Handle, st) = st == 0 ||
 
 # Flux.Dense chain (MLPDynamics / TDChain) -> config.  `p` from Flux.destructure is accepted as is.
 function config_for(dims::Vector{Int}, acts::Vector{Int}; time_dep, max_batch, reltol, abstol, regularize,
-                    max_attempts = 160, device = 0)
+                    max_attempts = 160, device = 0, pre_act = false)
     d = ntuple(i -> Int32(i <= length(dims) ? dims[i] : 0), 9)
     a = ntuple(i -> Int32(i <= length(acts) ? acts[i] : 0), 8)
-    NodeConfig(length(acts), d, a, time_dep, 0, max_batch, 0, reltol, abstol, regularize, 1, 1, 1, max_attempts, device, 0)
+    NodeConfig(length(acts), d, a, time_dep, pre_act, max_batch, 0, reltol, abstol, regularize, 1, 1, 1, max_attempts, device, 0, 0, 0, 0)
 end
 
 """
@@ -64,7 +74,7 @@ end
 Replaces `solve(prob, Tsit5(); sensealg, callback, kwargs...)` + `diffeqsol_to_trackedarray` + `sol.destats.nf`
 (reference neural_ode.jl:131-142).  x, p: device arrays (Float32, column-major D x B / flat).
 """
-function solve_forward(h::Handle, x::CuArray{Float32,2}, p::CuArray{Float32,1}, tspan; keep_tape::Bool)
+function solve_forward(h::Handle, x::ROCMatrix{Float32}, p::ROCVector{Float32}, tspan; keep_tape::Bool)
     D, B = size(x)
     u = similar(x)
     nfe = Ref{Int64}(0)
@@ -72,9 +82,9 @@ function solve_forward(h::Handle, x::CuArray{Float32,2}, p::CuArray{Float32,1}, 
     sv = Vector{Float32}(undef, h.cfg.max_attempts + 1)
     GC.@preserve x p u sv begin
         st = ccall((:rnde_node_forward, LIB), Cint,
-                   (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Int32, Float32, Float32, Ptr{Float32}, Ref{Int64},
+                   (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Float32, Float32, Ptr{Cvoid}, Ref{Int64},
                     Ptr{Float32}, Ref{Int32}, Int32, Ptr{Cvoid}),
-                   h.ptr, pointer(x), pointer(p), B, Float32(tspan[1]), Float32(tspan[2]), pointer(u), nfe,
+                   h.ptr, devptr(x), devptr(p), B, Float32(tspan[1]), Float32(tspan[2]), devptr(u), nfe,
                    sv, nsv, keep_tape ? 1 : 0, C_NULL)
         check(h, st)
     end
@@ -87,52 +97,51 @@ end
 The {R,true} call methods (reference neural_ode.jl:79-108, :146-180): `u3` is the D x T x B array
 `diffeqsol_to_3dtrackedarray` builds (src/utils.jl:17-19), T = length(saveat).
 """
-function solve_forward_saveat(h::Handle, x::CuArray{Float32,2}, p::CuArray{Float32,1}, tspan, saveat::Vector{Float32};
+function solve_forward_saveat(h::Handle, x::ROCMatrix{Float32}, p::ROCVector{Float32}, tspan, saveat::Vector{Float32};
                               keep_tape::Bool)
     D, B = size(x)
-    u3 = CuArray{Float32}(undef, D, length(saveat), B)
+    u3 = ROCArray{Float32}(undef, D, length(saveat), B)
     nfe = Ref{Int64}(0)
     nsv = Ref{Int32}(0)
     sv = Vector{Float32}(undef, h.cfg.max_attempts + 1)
     GC.@preserve x p u3 sv saveat begin
         st = ccall((:rnde_node_forward_saveat, LIB), Cint,
-                   (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Int32, Float32, Float32, Ptr{Float32}, Int32, Ptr{Float32},
+                   (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Float32, Float32, Ptr{Float32}, Int32, Ptr{Cvoid},
                     Ref{Int64}, Ptr{Float32}, Ref{Int32}, Int32, Ptr{Cvoid}),
-                   h.ptr, pointer(x), pointer(p), B, Float32(tspan[1]), Float32(tspan[2]), saveat, length(saveat),
-                   pointer(u3), nfe, sv, nsv, keep_tape ? 1 : 0, C_NULL)
+                   h.ptr, devptr(x), devptr(p), B, Float32(tspan[1]), Float32(tspan[2]), saveat, length(saveat),
+                   devptr(u3), nfe, sv, nsv, keep_tape ? 1 : 0, C_NULL)
         check(h, st)
     end
     return u3, Int(nfe[]), sv[1:nsv[]]
 end
 
 # ubar: D x B after solve_forward, D x T x B after solve_forward_saveat; x-bar is D x B either way
-function solve_backward(h::Handle, ubar::CuArray{Float32}, svbar::Vector{Float32}, np::Int)
-    xbar = CuArray{Float32}(undef, size(ubar, 1), size(ubar, ndims(ubar)))
-    pbar = CuArray{Float32}(undef, np)
+function solve_backward(h::Handle, ubar::ROCArray{Float32}, svbar::Vector{Float32}, np::Int)
+    xbar = ROCArray{Float32}(undef, size(ubar, 1), size(ubar, ndims(ubar)))
+    pbar = ROCArray{Float32}(undef, np)
     tsbar = zeros(Float32, 2)
     GC.@preserve ubar xbar pbar svbar tsbar begin
         st = ccall((:rnde_node_backward, LIB), Cint,
-                   (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Cvoid}),
-                   h.ptr, pointer(ubar), svbar, pointer(xbar), pointer(pbar), tsbar, C_NULL)
+                   (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float32}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float32}, Ptr{Cvoid}),
+                   h.ptr, devptr(ubar), svbar, devptr(xbar), devptr(pbar), tsbar, C_NULL)
         check(h, st)
     end
     return xbar, pbar, tsbar
 end
 
 # ---- Tracker glue: one tape node for the whole solve ------------------------------------------------
-# rnde_solve(h, x, p, tspan) returns (u, saveval); nfe is stashed on the handle side (non-differentiable).
+# rnde_solve(h, x, p, tspan) returns (u, saveval); nfe is kept on the handle (non-differentiable).
 rnde_solve(h::Handle, x::TrackedArray, p::TrackedArray, tspan) = track(rnde_solve, h, x, p, tspan)
 
 @grad function rnde_solve(h::Handle, x, p, tspan)
     u, nfe, sv = solve_forward(h, data(x), data(p), data.(tspan); keep_tape = true)
-    LAST_NFE[] = nfe
+    h.last_nfe = nfe
     return (u, sv), function (Δ)
         ubar, svbar = Δ
-        xbar, pbar, tsbar = solve_backward(h, CuArray{Float32,2}(ubar), Vector{Float32}(svbar), length(p))
+        xbar, pbar, tsbar = solve_backward(h, ROCArray{Float32}(ubar), Vector{Float32}(svbar), length(p))
         return (nothing, xbar, pbar, tsbar)
     end
 end
-const LAST_NFE = Ref(0)
 
 # ---- what changes in src/models/neural_ode.jl (reference :110-144) -----------------------------------
 #
@@ -140,23 +149,107 @@ const LAST_NFE = Ref(0)
 #       tspan = _convert_tspan(isnothing(tspan) ? n.tspan : tspan, p)
 #       res, saveval = RNDE.rnde_solve(n.rnde_handle, x, p, tspan)        # <- replaces :126-138
 #       sv = SavedValues(eltype(tspan), eltype(p)); append!(sv.saveval, saveval)
-#       return res, RNDE.LAST_NFE[], sv
+#       return res, n.rnde_handle.last_nfe, sv
 #   end
 #
 # and the constructor (:10-33) creates `rnde_handle = RNDE.Handle(RNDE.config_for(...))` from the Dense sizes
 # of `model`, kwargs[:reltol], kwargs[:abstol] and `regularize`.
 
-# Optimiser(InvDecay(gamma), Momentum(eta, rho)) on one flat group, in place (src/utils.jl:149-156, mnist_node.jl:130);
-# `n` is the group's InvDecay counter (starts at 1, the caller increments it).
-function momentum_step!(p::CuArray{Float32,1}, g::CuArray{Float32,1}, v::CuArray{Float32,1}, n::Integer;
-                        gamma = 1f-5, eta = 0.1f0, rho = 0.9f0)
-    GC.@preserve p g v begin
-        st = ccall((:rnde_momentum_step, LIB), Cint,
-                   (CuPtr{Cfloat}, CuPtr{Cfloat}, CuPtr{Cfloat}, Int64, Int64, Cfloat, Cfloat, Cfloat, Ptr{Cvoid}),
-                   p, g, v, length(p), n, gamma, eta, rho, C_NULL)
+# ---- TrackedNeuralDSDE (reference src/models/neural_sde.jl) -----------------------------------------
+struct NsdeConfig   # mirrors rnde_nsde_config
+    drift_layers::Int32
+    drift_dims::NTuple{9,Int32}
+    drift_act::NTuple{8,Int32}
+    diff_layers::Int32
+    diff_dims::NTuple{9,Int32}
+    diff_act::NTuple{8,Int32}
+    max_batch::Int32
+    solver::Int32          # 0 SOSRI, 1 SRIW1, 2 SOSRI2
+    reltol::Float32
+    abstol::Float32
+    regularize::Int32
+    cb_save_start::Int32
+    max_attempts::Int32
+    device::Int32
+    beta1::Float32; beta2::Float32; gamma::Float32; qmin::Float32; qmax::Float32; qoldinit::Float32; delta::Float32
+    generic::Int32
+end
+
+mutable struct NsdeHandle
+    ptr::Ptr{Cvoid}
+    cfg::NsdeConfig
+    function NsdeHandle(cfg::NsdeConfig)
+        out = Ref{Ptr{Cvoid}}(C_NULL)
+        st = ccall((:rnde_nsde_create, LIB), Cint, (Ref{NsdeConfig}, Ref{Ptr{Cvoid}}), cfg, out)
+        st == 0 || error("rnde_nsde_create: ", unsafe_string(ccall((:rnde_nsde_last_error, LIB), Cstring, (Ptr{Cvoid},), C_NULL)))
+        h = new(out[], cfg)
+        finalizer(h -> ccall((:rnde_nsde_destroy, LIB), Cvoid, (Ptr{Cvoid},), h.ptr), h)
+        return h
     end
-    st == 0 || error("rnde_momentum_step: status $st")
+end
+
+"""
+    nsde_forward(h, x, p, tspan; noise = nothing, seed = 0, keep_tape) -> (u, nfe1, nfe2, saveval)
+
+Replaces `solve(prob, SOSRI(); sensealg, callback, kwargs...)` and the unpacking at neural_sde.jl:98-113.
+`noise`: a `ROCArray{Float32,4}` of size (D, B, 2, n_pool) filled by `randn!` (the caller's own random stream: memory order
+D fastest, then B, then W/Z, then the draw -- exactly the pool layout of include/rnde.h), or `nothing` for the library's
+Philox stream named by `seed`.
+"""
+function nsde_forward(h::NsdeHandle, x::ROCMatrix{Float32}, p::ROCVector{Float32}, tspan; noise = nothing, seed::Integer = 0, keep_tape::Bool)
+    D, B = size(x)
+    u = similar(x)
+    nfe1 = Ref{Int64}(0); nfe2 = Ref{Int64}(0); nsv = Ref{Int32}(0)
+    sv = Vector{Float32}(undef, h.cfg.max_attempts + 1)
+    npool = noise === nothing ? 0 : size(noise, 4)
+    GC.@preserve x p u sv noise begin
+        st = ccall((:rnde_nsde_forward, LIB), Cint,
+                   (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Float32, Float32, Ptr{Cvoid}, Int32, UInt64, Ptr{Cvoid},
+                    Ref{Int64}, Ref{Int64}, Ptr{Float32}, Ref{Int32}, Int32, Ptr{Cvoid}),
+                   h.ptr, devptr(x), devptr(p), B, Float32(tspan[1]), Float32(tspan[2]),
+                   noise === nothing ? C_NULL : devptr(noise), npool, UInt64(seed), devptr(u), nfe1, nfe2, sv, nsv, keep_tape ? 1 : 0, C_NULL)
+        st == 0 || error("rnde_nsde_forward status $st: ", unsafe_string(ccall((:rnde_nsde_last_error, LIB), Cstring, (Ptr{Cvoid},), h.ptr)))
+    end
+    return u, Int(nfe1[]), Int(nfe2[]), sv[1:nsv[]]
+end
+
+function nsde_backward(h::NsdeHandle, ubar::ROCMatrix{Float32}, svbar::Vector{Float32}, np::Int)
+    xbar = similar(ubar)
+    pbar = ROCArray{Float32}(undef, np)
+    GC.@preserve ubar xbar pbar svbar begin
+        st = ccall((:rnde_nsde_backward, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float32}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                   h.ptr, devptr(ubar), svbar, devptr(xbar), devptr(pbar), C_NULL)
+        st == 0 || error("rnde_nsde_backward status $st")
+    end
+    return xbar, pbar
+end
+
+# ---- optimiser step and the data-parallel collective -------------------------------------------------
+# Optimiser(InvDecay(gamma), Momentum(eta, rho)) on one flat group, in place (src/utils.jl:149-156, mnist_node.jl:130);
+# `n` is the group's InvDecay counter (starts at 1, the caller increments it); gscale = 1 / nworkers after a summed all-reduce.
+function momentum_step!(p::ROCVector{Float32}, g::ROCVector{Float32}, v::ROCVector{Float32}, n::Integer;
+                        gamma = 1f-5, eta = 0.1f0, rho = 0.9f0, gscale = 1f0)
+    GC.@preserve p g v begin
+        st = ccall((:rnde_momentum_step_scaled, LIB), Cint,
+                   (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Cfloat, Cfloat, Cfloat, Cfloat, Ptr{Cvoid}),
+                   devptr(p), devptr(g), devptr(v), length(p), n, gamma, eta, rho, gscale, C_NULL)
+    end
+    st == 0 || error("rnde_momentum_step_scaled: status $st")
     return p
+end
+
+# one process per GPU (Distributed / MPI.jl carry the 128-byte id from rank 0 to the others)
+comm_unique_id() = (id = zeros(UInt8, 128); ccall((:rnde_comm_unique_id, LIB), Cint, (Ptr{UInt8},), id) == 0 || error("rnde_comm_unique_id"); id)
+function comm_create(id::Vector{UInt8}, rank::Integer, world::Integer, device::Integer)
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    ccall((:rnde_comm_create, LIB), Cint, (Ptr{UInt8}, Int32, Int32, Int32, Ref{Ptr{Cvoid}}), id, rank, world, device, out) == 0 ||
+        error("rnde_comm_create: ", unsafe_string(ccall((:rnde_comm_last_error, LIB), Cstring, (Ptr{Cvoid},), C_NULL)))
+    return out[]
+end
+allreduce_sum!(comm::Ptr{Cvoid}, g::ROCVector{Float32}) = GC.@preserve g begin
+    ccall((:rnde_comm_allreduce, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int32, Ptr{Cvoid}), comm, devptr(g), length(g), 0, C_NULL) == 0 ||
+        error("rnde_comm_allreduce")
+    g
 end
 
 end # module

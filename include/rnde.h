@@ -69,7 +69,7 @@ typedef struct {
     int32_t max_attempts;  /* tape capacity in attempted steps */
     int32_t device;        /* HIP device ordinal */
     int32_t col_tile;      /* 0 = auto; MNIST form: 16 (stage engine, default), 4 / 8 (column-owner engine); small-width chains:
-                            * 64 (chain engine, 16 columns per wave, default), 32 (4 columns per wave: experimental, forward only) */
+                            * 64 (chain engine: 16 columns per wave) */
     /* tuning (0 = default everywhere, so a zero-initialised tail keeps the defaults) */
     int32_t persist;        /* stage engine: 0 = one launch per attempted step where the shape allows, -1 = always the 7-launch kernels */
     int32_t wgrad_side_pct; /* share (per cent of the attempts) of the parameter-gradient GEMMs run beside the reverse sweep on the CUs

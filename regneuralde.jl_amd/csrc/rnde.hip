@@ -43,7 +43,6 @@ struct rnde_node {
     int engine = 1;                       // 1 column-owner, 2 stage kernels, 3 chain engine (rnde_chain.h)
     ChainGeo cg{}; float* cfrags = nullptr; int NKD = 0, chain_alt = 0;
     size_t chain_lds_f = 0, chain_lds_b = 0;
-    int chain_lay = 0; QuadGeo qg{}; f32x4* qtab = nullptr;   // layout 1 of the chain engine (rnde_quad.h): 4 batch columns per wave
     float* cslab = nullptr; size_t cslab_floats = 0; float* ev_t = nullptr; float* h_ev_t = nullptr;   // chain reverse: (H, Z) dump, evaluation times
     int sMT = 0, sWT = 0, sR = 0, sHT = 0, sK2b = 0, sKHb = 0;
     f32x4 *spwB = nullptr, *spwD = nullptr, *spwBt = nullptr, *spwDt = nullptr;
@@ -120,7 +119,7 @@ static StepParams make_params(rnde_node* h, const float* x, int B, float t0, flo
     P.errpart = h->errpart; P.initpart = h->initpart; P.dbg_out = nullptr;
     P.D = h->D; P.H = h->H; P.B = B;
     P.Bpad = ((B + 15) / 16) * 16;   // both engines pad the batch to 16 columns (one tape format)
-    P.nwg = h->engine == 2 ? h->sR * (P.Bpad / 16) : (h->engine == 3 ? (P.Bpad / (h->chain_lay ? 4 : 16) + kCW - 1) / kCW : P.Bpad / h->BT);
+    P.nwg = h->engine == 2 ? h->sR * (P.Bpad / 16) : (h->engine == 3 ? (P.Bpad / 16 + kCW - 1) / kCW : P.Bpad / h->BT);
     P.K4_1 = h->K4_1; P.KS1 = h->KS1; P.MT1 = h->MT1; P.K4_2 = h->K4_2; P.KS2 = h->KS2; P.MT2 = h->MT2;
     P.reltol = h->cfg.reltol; P.abstol = h->cfg.abstol; P.t0 = t0; P.t1 = t1;
     P.tape = tape; P.max_attempts = h->cfg.max_attempts;
@@ -187,45 +186,22 @@ static rnde_status chain_create(const rnde_node_config* c, rnde_node** out) {
     if (!chain_geo(c, G)) { g_create_err = "unsupported dynamics: beyond the 2-layer time-dependent form the kernels cover Dense chains of width <= 64"; return RNDE_ERR_BAD_ARG; }
     // LDS: fragment tables rounded up to whole 1 KiB DMA units, then 64 floats of reduction scratch
     size_t lds_f = ((size_t)((G.nfrag_f + G.nfrag_b + 3) / 4) * 256 + 64) * 4, lds_b = ((size_t)((G.nfrag_f + G.nfrag_b + G.nfrag_t + 3) / 4) * 256 + 64) * 4;
-    if (c->col_tile != 32 && lds_b > 160 * 1024) { g_create_err = "chain too large: its weight fragments must fit the 160 KB LDS of a CU"; return RNDE_ERR_BAD_ARG; }
+    if (lds_b > 160 * 1024) { g_create_err = "chain too large: its weight fragments must fit the 160 KB LDS of a CU"; return RNDE_ERR_BAD_ARG; }
     if (c->regularize < RNDE_REG_NONE || c->regularize > RNDE_REG_ERR_STIFF) { g_create_err = "regularize: unknown value"; return RNDE_ERR_BAD_ARG; }
-    if (c->col_tile != 0 && c->col_tile != 64 && c->col_tile != 32) { g_create_err = "col_tile: this network runs on the chain engine (0 = auto, 64 = 16 columns per wave, 32 = 4 columns per wave)"; return RNDE_ERR_BAD_ARG; }
+    if (c->col_tile != 0 && c->col_tile != 64) { g_create_err = "col_tile: this network runs on the chain engine (0 = auto, 64 = chain engine)"; return RNDE_ERR_BAD_ARG; }
     if (c->max_batch < 1 || c->max_attempts < 1) { g_create_err = "max_batch / max_attempts"; return RNDE_ERR_BAD_ARG; }
     rnde_node* h = new rnde_node();
     h->cfg = *c; h->engine = 3; h->cg = G;
     h->D = c->dims[0]; h->H = 0; h->P = rnde_param_count(c); h->BT = 16; h->NG = 0;
     h->NKD = G.nksD <= 4 ? 4 : (G.nksD <= 8 ? 8 : 16);
-    h->chain_lay = (c->col_tile == 32) ? 1 : 0;
-    if (h->chain_lay) {   // layout 1 (rnde_quad.h): 4 registers per state array, tables per layer with K splits over idle row blocks
-        QuadGeo& Q2 = h->qg;
-        Q2 = QuadGeo{};
-        Q2.n_layers = G.n_layers; Q2.time_dep = G.time_dep; Q2.pre_act = G.pre_act; Q2.D = c->dims[0];
-        int ao = 0, bo = 0, to = 0;
-        for (int l = 0; l < G.n_layers; ++l) {
-            Q2.in[l] = G.width[l]; Q2.out[l] = G.width[l + 1]; Q2.act[l] = G.act[l]; Q2.poff[l] = G.poff[l];
-            quad_split(Q2.out[l], Q2.in[l], Q2.nb[l], Q2.ks[l], Q2.kper[l]);
-            quad_split(Q2.in[l], Q2.out[l], Q2.nbT[l], Q2.ksT[l], Q2.kperT[l]);
-            Q2.aoff[l] = ao; ao += Q2.kper[l] / 4;
-            Q2.boff[l] = bo; bo += 1 + G.time_dep;
-            Q2.toff[l] = to; to += Q2.kperT[l] / 4;
-        }
-        Q2.units_f = ao; Q2.units_b = bo; Q2.units_t = to;
-        h->NKD = 4;
-    }
     {   // compile-time shape specialisation for the reference's own latent-ODE widths (rnde_chain.h: ALT)
         bool alt = G.nksD == kAltA && !getenv("RNDE_CHAIN_GENERIC");
         for (int l = 0; l <= G.n_layers && alt; ++l) alt = G.nks[l] == ((l & 1) ? kAltB : kAltA);
         h->chain_alt = alt ? 1 : 0;
     }
     h->Bpad_max = ((c->max_batch + 15) / 16) * 16;
-    const int ntiles = h->Bpad_max / (h->chain_lay ? 4 : 16);
+    const int ntiles = h->Bpad_max / 16;
     h->nwg_max = (ntiles + kCW - 1) / kCW;
-    if (h->chain_lay) {
-        const size_t priv = (size_t)kCW * (5 * 4 * kQRS + 16) + 64 + (size_t)kQMaxL * kQPlanStride * 4;
-        lds_f = ((size_t)(h->qg.units_f + h->qg.units_b) * 256 + priv) * 4;
-        lds_b = ((size_t)(h->qg.units_f + h->qg.units_b + h->qg.units_t) * 256 + (size_t)kCW * (5 * 4 * kQRS + 16 + (kQMaxL + 1) * 4 * kQRS) + 64 + (size_t)2 * kQMaxL * kQPlanStride * 4) * 4;
-        if (lds_f > 160 * 1024) { g_create_err = "chain too large: its weight tables must fit the 160 KB LDS of a CU"; delete h; return RNDE_ERR_BAD_ARG; }
-    }
     h->chain_lds_f = lds_f; h->chain_lds_b = lds_b;
     if (hipSetDevice(c->device) != hipSuccess) { g_create_err = "hipSetDevice failed"; delete h; return RNDE_ERR_HIP; }
     const size_t Ac = (size_t)ntiles * h->NKD * 64;   // fragment-order arrays are padded to NKD k-steps
@@ -234,7 +210,6 @@ static rnde_status chain_create(const rnde_node_config* c, rnde_node** out) {
     bool ok = true;
     ok &= dm((void**)&h->f0, Ac * 4) && dm((void**)&h->u1, Ac * 4) && dm((void**)&h->f1, Ac * 4) && dm((void**)&h->xcopy, (size_t)h->D * h->Bpad_max * 4);
     ok &= dm((void**)&h->pcopy, (size_t)h->P * 4) && dm((void**)&h->cfrags, (size_t)(G.nfrag_f + G.nfrag_b + G.nfrag_t + 4) * 256);
-    if (h->chain_lay) ok &= dm((void**)&h->qtab, (size_t)(h->qg.units_f + h->qg.units_b + h->qg.units_t + 1) * 1024);
     ok &= dm((void**)&h->ctl, 2 * sizeof(StepState)) && dm((void**)&h->ctl_final, sizeof(StepState));
     ok &= dm((void**)&h->meta, (size_t)(c->max_attempts + 1) * sizeof(StepMeta)) && dm((void**)&h->initrec, sizeof(InitRec));
     ok &= dm((void**)&h->errpart, (size_t)6 * h->nwg_max * 4) && dm((void**)&h->initpart, (size_t)3 * h->nwg_max * 4);
@@ -252,13 +227,12 @@ static rnde_status chain_create(const rnde_node_config* c, rnde_node** out) {
 }
 static ChainParams make_chain_params(rnde_node* h, const StepParams& P) {
     ChainParams Q{};
-    Q.F = P; Q.G = h->cg; Q.frags = h->cfrags; Q.ntiles = P.Bpad / (h->chain_lay ? 4 : 16);
-    Q.Q2 = h->qg; Q.qtab = h->qtab;
+    Q.F = P; Q.G = h->cg; Q.frags = h->cfrags; Q.ntiles = P.Bpad / 16;
     return Q;
 }
-template <int NKD, int MODE, int ALT = 0, int LAY = 0>
+template <int NKD, int MODE, int ALT = 0>
 static hipError_t launch_chain_t(rnde_node* h, const ChainParams& Q, int n, float* u_out, hipStream_t s) {
-    auto kern = rnde_chain_kernel<NKD, MODE, ALT, LAY>;
+    auto kern = rnde_chain_kernel<NKD, MODE, ALT>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -270,7 +244,6 @@ static hipError_t launch_chain_t(rnde_node* h, const ChainParams& Q, int n, floa
 }
 template <int MODE>
 static hipError_t launch_chain(rnde_node* h, const ChainParams& Q, int n, float* u_out, hipStream_t s) {
-    if (h->chain_lay) return launch_chain_t<4, MODE, 0, 1>(h, Q, n, u_out, s);
     switch (h->NKD) {
         case 4: return launch_chain_t<4, MODE>(h, Q, n, u_out, s);
         case 8: return h->chain_alt ? launch_chain_t<8, MODE, 1>(h, Q, n, u_out, s) : launch_chain_t<8, MODE>(h, Q, n, u_out, s);
@@ -278,20 +251,14 @@ static hipError_t launch_chain(rnde_node* h, const ChainParams& Q, int n, float*
     }
 }
 static rnde_status chain_pack(rnde_node* h, const float* p_dev, hipStream_t s) {
-    if (h->chain_lay) {
-        const long long tq = (long long)(h->qg.units_f + h->qg.units_b + h->qg.units_t) * 64;
-        hipLaunchKernelGGL(rnde_quad_pack_kernel, dim3((int)std::min<long long>((tq + 255) / 256, 512)), dim3(256), 0, s, p_dev, h->qtab, h->qg);
-        HIPCHK(h, hipGetLastError());
-        return RNDE_OK;
-    }
     const long long total = (long long)(h->cg.nfrag_f + h->cg.nfrag_b + h->cg.nfrag_t) * 64;
     hipLaunchKernelGGL(rnde_chain_pack_kernel, dim3((int)std::min<long long>((total + 255) / 256, 512)), dim3(256), 0, s, p_dev, h->cfrags, h->cg);
     HIPCHK(h, hipGetLastError());
     return RNDE_OK;
 }
-static hipError_t chain_convert(const float* src, float* dst, int D, int B, int ntiles, int nksD, int to_caller, int lay, hipStream_t s) {
+static hipError_t chain_convert(const float* src, float* dst, int D, int B, int ntiles, int nksD, int to_caller, hipStream_t s) {
     const long long total = (long long)ntiles * nksD * 64;
-    hipLaunchKernelGGL(rnde_chain_convert_kernel, dim3((int)std::min<long long>((total + 255) / 256, 512)), dim3(256), 0, s, src, dst, D, B, ntiles, nksD, to_caller, lay);
+    hipLaunchKernelGGL(rnde_chain_convert_kernel, dim3((int)std::min<long long>((total + 255) / 256, 512)), dim3(256), 0, s, src, dst, D, B, ntiles, nksD, to_caller);
     return hipGetLastError();
 }
 
@@ -303,7 +270,7 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
         g_create_err = "unsupported configuration: Tsit5 over a Dense chain with dims[0] == dims[n_layers]"; return RNDE_ERR_BAD_ARG;
     }
     const bool mnist_form = c->n_layers == 2 && c->time_dep && !c->pre_act && c->act[0] == RNDE_ACT_TANH;
-    if (c->col_tile == 64 || c->col_tile == 32 || !mnist_form) return chain_create(c, out);   // small-width chains (latent_ode.jl:113-124): rnde_chain.h
+    if (c->col_tile == 64 || !mnist_form) return chain_create(c, out);   // small-width chains (latent_ode.jl:113-124): rnde_chain.h
     if (c->regularize < RNDE_REG_NONE || c->regularize > RNDE_REG_ERR_STIFF) { g_create_err = "regularize: unknown value"; return RNDE_ERR_BAD_ARG; }
     if (c->regularize >= RNDE_REG_STIFF && (c->col_tile == 4 || c->col_tile == 8)) {
         g_create_err = "the stiffness-estimate regularisers run on the stage engine only (col_tile 0 or 16)";
@@ -405,7 +372,6 @@ extern "C" void rnde_node_destroy(rnde_node* h) {
     if (h->sv_t_dev) hipFree(h->sv_t_dev);
     if (h->replay_dev) hipFree(h->replay_dev);
     if (h->cfrags) hipFree(h->cfrags);
-    if (h->qtab) hipFree(h->qtab);
     if (h->tslab) hipFree(h->tslab);
     if (h->pabort) hipFree(h->pabort);
     if (h->pxcc) hipFree(h->pxcc);
@@ -845,14 +811,14 @@ extern "C" rnde_status rnde_debug_attempt(rnde_node* h, const float* uprev_dev, 
         if (st3 != RNDE_OK) return st3;
         const ChainParams CQ = make_chain_params(h, P);
         const int nks = h->NKD;
-        HIPCHK(h, chain_convert(k1_dev, h->f0, h->D, B, CQ.ntiles, nks, 0, h->chain_lay, s));
+        HIPCHK(h, chain_convert(k1_dev, h->f0, h->D, B, CQ.ntiles, nks, 0, s));
         HIPCHK(h, launch_chain<CM_STEP>(h, CQ, 0, nullptr, s));
         HIPCHK(h, launch_chain<CM_FINISH>(h, CQ, 1, nullptr, s));
         HIPCHK(h, hipMemcpyAsync(h->h_ctl, h->ctl_final, sizeof(StepState), hipMemcpyDeviceToHost, s));
         const ChainRec CL{(long long)CQ.ntiles * nks * 64};
         for (int sidx = 2; sidx <= 7; ++sidx)
-            HIPCHK(h, chain_convert(h->arena + CL.k(sidx), k_out_dev + (size_t)(sidx - 2) * h->D * B, h->D, B, CQ.ntiles, nks, 1, h->chain_lay, s));
-        HIPCHK(h, chain_convert(h->arena + CL.unew(), unew_out_dev, h->D, B, CQ.ntiles, nks, 1, h->chain_lay, s));
+            HIPCHK(h, chain_convert(h->arena + CL.k(sidx), k_out_dev + (size_t)(sidx - 2) * h->D * B, h->D, B, CQ.ntiles, nks, 1, s));
+        HIPCHK(h, chain_convert(h->arena + CL.unew(), unew_out_dev, h->D, B, CQ.ntiles, nks, 1, s));
         HIPCHK(h, hipStreamSynchronize(s));
         if (eest_out) *eest_out = h->h_ctl->last_eest;
         return RNDE_OK;
@@ -1360,7 +1326,6 @@ static hipError_t launch_bchain_t(rnde_node* h, const BChainParams& Q, const std
 static rnde_status chain_bwd_run(rnde_node* h, const float* u_bar_dev, const float* saveval_bar_host, float* x_bar_dev,
                                  float* p_bar_dev, float* tspan_bar_host, hipStream_t s, bool sync, float* tspan_bar_dev) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    if (h->chain_lay) { h->err = "chain engine layout 1 (col_tile 32): reverse pass not built yet"; return RNDE_ERR_BAD_ARG; }
     BwdBuffers& b = h->bw;
     const ChainGeo& G = h->cg;
     const int cap = h->cfg.max_attempts, ntiles_max = h->Bpad_max / 16;

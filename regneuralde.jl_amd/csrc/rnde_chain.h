@@ -25,7 +25,6 @@
 #pragma once
 #include "rnde_fwd.h"
 #include "rnde_stage.h"   // mfma16
-#include "rnde_quad.h"    // layout 1: four batch columns per wave
 
 namespace rnde {
 
@@ -46,9 +45,7 @@ struct ChainParams {
     StepParams F;          // shared controller / tape parameters (H and the packed-weight fields are unused)
     ChainGeo G;
     const float* frags;    // [nfrag_f + nfrag_b + nfrag_t][64]
-    int ntiles;            // wave tiles: Bpad / 16 (layout 0) or Bpad / 4 (layout 1)
-    QuadGeo Q2;            // layout 1 (rnde_quad.h)
-    const f32x4* qtab;     // its tables
+    int ntiles;            // wave tiles: Bpad / 16
 };
 
 // record layout (fragment order arrays of ntiles * nksD * 64 floats): k2..k7 | unew | uprev copy | k1 copy | g2..g6
@@ -363,29 +360,23 @@ __device__ __forceinline__ void chain_dense_points(const StepParams& P, const Ch
 #define CHAIN_STAMP(i) do { } while (0)
 #endif
 
-template <int NKD, int MODE, int ALT = 0, int LAY = 0>
+template <int NKD, int MODE, int ALT = 0>
 __global__ __launch_bounds__(64 * kCW) void rnde_chain_kernel(const ChainParams Q, const int n, float* __restrict__ u_out) {
     const StepParams& P = Q.F;
     const ChainGeo& G = Q.G;
-    static_assert(LAY == 0 || NKD == 4, "layout 1 keeps 4 registers per state array");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* FR = smem;
     float* BF = FR + (size_t)G.nfrag_f * 64;
-    const int fill_units = LAY ? (Q.Q2.units_f + Q.Q2.units_b) : ((G.nfrag_f + G.nfrag_b + 3) >> 2);
+    const int fill_units = (G.nfrag_f + G.nfrag_b + 3) >> 2;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // layout 1: wave-private activation images and K-split partial buffers behind the tables (rnde_quad.h)
-    constexpr int kQPriv = 5 * 4 * kQRS + 16;
-    float* QP = smem + (size_t)fill_units * 256 + (size_t)wave * kQPriv;
-    float* RED = smem + (size_t)fill_units * 256 + (LAY ? kCW * kQPriv : 0);   // [3][kCW]
-    const f32x4* TAB = (const f32x4*)smem;
-    i32x4* PLAN = (i32x4*)(RED + 64);                                            // layout 1: per-layer plan (rnde_quad.h)
+    float* RED = smem + (size_t)fill_units * 256;   // [3][kCW]
     const int tile = blockIdx.x * kCW + wave;
     const bool tile_ok = tile < Q.ntiles;
     // feature of register q of this lane = fb + fs * q; its batch column = gcol
     const int g = lane >> 4;
-    const int fb = LAY ? 4 * (lane >> 2) : g, fs = LAY ? 1 : 4;
-    const int gcol = LAY ? tile * 4 + (lane & 3) : tile * 16 + (lane & 15);
+    const int fb = g, fs = 4;
+    const int gcol = tile * 16 + (lane & 15);
     const bool colok = tile_ok && gcol < P.B;
     const bool writer = (blockIdx.x == 0 && tid == 0);
     constexpr int nksD = NKD;                                  // arena arrays are padded to NKD k-steps
@@ -393,20 +384,8 @@ __global__ __launch_bounds__(64 * kCW) void rnde_chain_kernel(const ChainParams 
     const size_t fo = ((size_t)tile * NKD) * 64 + lane;        // fragment-order offset of this lane's k-step 0
 
     CHAIN_STAMP(0);
-    if constexpr (MODE != CM_FINISH) {
-        if constexpr (LAY == 1) {
-            for (int i = lane; i < kQPriv; i += 64) QP[i] = 0.f;     // no NaN bit patterns under the zero-weight padding
-            quad_build_plan(Q.Q2, PLAN, false, tid, 64 * kCW);
-            chain_fill_lds((const float*)Q.qtab, smem, fill_units, wave, lane);
-        } else chain_fill_lds(Q.frags, smem, fill_units, wave, lane);
-    }
-    auto EVAL = [&](float ts_, const float (&gin)[NKD], float (&kout)[NKD]) {
-        if constexpr (LAY == 1) {
-            f32x4 gi = {gin[0], gin[1], gin[2], gin[3]}, ko;
-            quad_eval(Q.Q2, PLAN, TAB, QP, QP + 4 * kQRS, QP + 8 * kQRS, ts_, gi, ko, lane);
-            kout[0] = ko[0]; kout[1] = ko[1]; kout[2] = ko[2]; kout[3] = ko[3];
-        } else chain_eval<NKD, ALT>(G, FR, BF, ts_, gin, kout, lane);
-    };
+    if constexpr (MODE != CM_FINISH) chain_fill_lds(Q.frags, smem, fill_units, wave, lane);
+    auto EVAL = [&](float ts_, const float (&gin)[NKD], float (&kout)[NKD]) { chain_eval<NKD, ALT>(G, FR, BF, ts_, gin, kout, lane); };
     CHAIN_STAMP(1);
 
     if constexpr (MODE == CM_FEVAL) {
@@ -590,11 +569,11 @@ __global__ __launch_bounds__(64 * kCW) void rnde_chain_kernel(const ChainParams 
 }
 
 // fragment order <-> caller layout (debug entry points, and k1 hand-over of rnde_debug_attempt)
-__global__ void rnde_chain_convert_kernel(const float* __restrict__ src, float* __restrict__ dst, int D, int B, int ntiles, int nksD, int to_caller, int lay) {
+__global__ void rnde_chain_convert_kernel(const float* __restrict__ src, float* __restrict__ dst, int D, int B, int ntiles, int nksD, int to_caller) {
     const long long total = (long long)ntiles * nksD * 64;
     for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
         const int lane = (int)(e & 63), q = (int)((e >> 6) % nksD), tile = (int)((e >> 6) / nksD);
-        const int f = lay ? 4 * (lane >> 2) + q : 4 * q + (lane >> 4), gcol = lay ? tile * 4 + (lane & 3) : tile * 16 + (lane & 15);
+        const int f = 4 * q + (lane >> 4), gcol = tile * 16 + (lane & 15);
         const bool ok = f < D && gcol < B;
         if (to_caller) { if (ok) dst[(size_t)gcol * D + f] = src[e]; }
         else dst[e] = ok ? src[(size_t)gcol * D + f] : 0.f;

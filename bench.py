@@ -330,7 +330,7 @@ def main():
         # reported when present, with their source
         try:
             import csv
-            for rnd in (PROFILE_ROUND, "r01"):
+            for rnd in ((PROFILE_ROUND, "r01") if B == 512 else ()):      # the committed passes are of the B = 512 bench
                 pf = os.path.join(ROOT, "profiles", f"{rnd}_pmc_hbm_traffic.csv")
                 if not os.path.exists(pf):
                     continue

@@ -10,6 +10,8 @@
 #include "rnde_head.h"
 #include "rnde_chain.h"
 #include "rnde_bchain.h"
+#include "rnde_chainmw.h"
+#include "rnde_bchainmw.h"
 
 #include <chrono>
 #include <cmath>
@@ -43,6 +45,8 @@ struct rnde_node {
     int engine = 1;                       // 1 column-owner, 2 stage kernels, 3 chain engine (rnde_chain.h)
     ChainGeo cg{}; float* cfrags = nullptr; int NKD = 0, chain_alt = 0;
     size_t chain_lds_f = 0, chain_lds_b = 0;
+    // multi-wave kernels of the chain engine (rnde_chainmw.h): 4 waves per 16 columns, activations taped in the slab by the forward
+    int mw = 0; MwGeo mg{}; float* mw_tab = nullptr; float* mw_slab = nullptr; long long mw_slab_evals = 0; size_t mw_lds_f = 0, mw_lds_b = 0;
     float* cslab = nullptr; size_t cslab_floats = 0; float* ev_t = nullptr; float* h_ev_t = nullptr;   // chain reverse: (H, Z) dump, evaluation times
     int sMT = 0, sWT = 0, sR = 0, sHT = 0, sK2b = 0, sKHb = 0;
     f32x4 *spwB = nullptr, *spwD = nullptr, *spwBt = nullptr, *spwDt = nullptr;
@@ -119,7 +123,7 @@ static StepParams make_params(rnde_node* h, const float* x, int B, float t0, flo
     P.errpart = h->errpart; P.initpart = h->initpart; P.dbg_out = nullptr;
     P.D = h->D; P.H = h->H; P.B = B;
     P.Bpad = ((B + 15) / 16) * 16;   // both engines pad the batch to 16 columns (one tape format)
-    P.nwg = h->engine == 2 ? h->sR * (P.Bpad / 16) : (h->engine == 3 ? (P.Bpad / 16 + kCW - 1) / kCW : P.Bpad / h->BT);
+    P.nwg = h->engine == 2 ? h->sR * (P.Bpad / 16) : (h->engine == 3 ? (h->mw ? P.Bpad / 16 : (P.Bpad / 16 + kCW - 1) / kCW) : P.Bpad / h->BT);
     P.K4_1 = h->K4_1; P.KS1 = h->KS1; P.MT1 = h->MT1; P.K4_2 = h->K4_2; P.KS2 = h->KS2; P.MT2 = h->MT2;
     P.reltol = h->cfg.reltol; P.abstol = h->cfg.abstol; P.t0 = t0; P.t1 = t1;
     P.tape = tape; P.max_attempts = h->cfg.max_attempts;
@@ -188,7 +192,7 @@ static rnde_status chain_create(const rnde_node_config* c, rnde_node** out) {
     size_t lds_f = ((size_t)((G.nfrag_f + G.nfrag_b + 3) / 4) * 256 + 64) * 4, lds_b = ((size_t)((G.nfrag_f + G.nfrag_b + G.nfrag_t + 3) / 4) * 256 + 64) * 4;
     if (lds_b > 160 * 1024) { g_create_err = "chain too large: its weight fragments must fit the 160 KB LDS of a CU"; return RNDE_ERR_BAD_ARG; }
     if (c->regularize < RNDE_REG_NONE || c->regularize > RNDE_REG_ERR_STIFF) { g_create_err = "regularize: unknown value"; return RNDE_ERR_BAD_ARG; }
-    if (c->col_tile != 0 && c->col_tile != 64) { g_create_err = "col_tile: this network runs on the chain engine (0 = auto, 64 = chain engine)"; return RNDE_ERR_BAD_ARG; }
+    if (c->col_tile != 0 && c->col_tile != 64 && c->col_tile != 65) { g_create_err = "col_tile: this network runs on the chain engine (0 = auto, 64 = one wave per column tile, 65 = four waves per column tile)"; return RNDE_ERR_BAD_ARG; }
     if (c->max_batch < 1 || c->max_attempts < 1) { g_create_err = "max_batch / max_attempts"; return RNDE_ERR_BAD_ARG; }
     rnde_node* h = new rnde_node();
     h->cfg = *c; h->engine = 3; h->cg = G;
@@ -202,6 +206,28 @@ static rnde_status chain_create(const rnde_node_config* c, rnde_node** out) {
     h->Bpad_max = ((c->max_batch + 15) / 16) * 16;
     const int ntiles = h->Bpad_max / 16;
     h->nwg_max = (ntiles + kCW - 1) / kCW;
+    {   // multi-wave kernels: geometry, LDS budget, who runs (col_tile 0 = auto -> multi-wave, 64 = one wave per tile, 65 = multi-wave)
+        MwGeo& M = h->mg;
+        M = MwGeo{};
+        M.n_layers = G.n_layers; M.time_dep = G.time_dep; M.pre_act = G.pre_act; M.D = c->dims[0];
+        int fo = 0, to = 0, row = 0;
+        for (int l = 0; l <= G.n_layers; ++l) { M.width[l] = G.width[l]; M.mt[l] = (G.width[l] + 15) / 16; }
+        for (int l = 0; l < G.n_layers; ++l) {
+            M.act[l] = G.act[l]; M.poff[l] = G.poff[l];
+            M.foff[l] = fo; fo += M.mt[l] * M.mt[l + 1] * 4;
+            M.toff[l] = to; to += M.mt[l] * M.mt[l + 1] * 4;
+            M.hrow[l] = row; row += 4 * M.mt[l]; M.zrow[l] = row; row += 4 * M.mt[l + 1];
+        }
+        M.hrow[G.n_layers] = row; row += 4 * M.mt[G.n_layers];
+        M.RS = row; M.nfrag_f = (fo + 3) / 4 * 4; M.nfrag_t = (to + 3) / 4 * 4;
+        h->mw_lds_f = ((size_t)M.nfrag_f * 64 + 1024 + 2048 + 64) * 4;
+        h->mw_lds_b = ((size_t)M.nfrag_t * 64 + 1024 + 2048 + 64) * 4;
+        const bool fits = h->mw_lds_f <= 160 * 1024 && h->mw_lds_b <= 160 * 1024;
+        const char* e = getenv("RNDE_CHAIN_MW");
+        h->mw = (fits && c->col_tile != 64 && !(e && e[0] == '0')) ? 1 : 0;
+        if (c->col_tile == 65 && !fits) { g_create_err = "col_tile 65: the multi-wave kernels need the padded weight fragments in 160 KB of LDS"; delete h; return RNDE_ERR_BAD_ARG; }
+        if (h->mw) h->nwg_max = ntiles;
+    }
     h->chain_lds_f = lds_f; h->chain_lds_b = lds_b;
     if (hipSetDevice(c->device) != hipSuccess) { g_create_err = "hipSetDevice failed"; delete h; return RNDE_ERR_HIP; }
     const size_t Ac = (size_t)ntiles * h->NKD * 64;   // fragment-order arrays are padded to NKD k-steps
@@ -210,6 +236,7 @@ static rnde_status chain_create(const rnde_node_config* c, rnde_node** out) {
     bool ok = true;
     ok &= dm((void**)&h->f0, Ac * 4) && dm((void**)&h->u1, Ac * 4) && dm((void**)&h->f1, Ac * 4) && dm((void**)&h->xcopy, (size_t)h->D * h->Bpad_max * 4);
     ok &= dm((void**)&h->pcopy, (size_t)h->P * 4) && dm((void**)&h->cfrags, (size_t)(G.nfrag_f + G.nfrag_b + G.nfrag_t + 4) * 256);
+    if (h->mw) ok &= dm((void**)&h->mw_tab, mw_tab_floats(h->mg) * 4);
     ok &= dm((void**)&h->ctl, 2 * sizeof(StepState)) && dm((void**)&h->ctl_final, sizeof(StepState));
     ok &= dm((void**)&h->meta, (size_t)(c->max_attempts + 1) * sizeof(StepMeta)) && dm((void**)&h->initrec, sizeof(InitRec));
     ok &= dm((void**)&h->errpart, (size_t)6 * h->nwg_max * 4) && dm((void**)&h->initpart, (size_t)3 * h->nwg_max * 4);
@@ -250,7 +277,56 @@ static hipError_t launch_chain(rnde_node* h, const ChainParams& Q, int n, float*
         default: return launch_chain_t<16, MODE>(h, Q, n, u_out, s);
     }
 }
+static MwParams make_mw_params(rnde_node* h, const StepParams& P) {
+    MwParams Q{};
+    Q.F = P; Q.G = h->mg; Q.tab = h->mw_tab; Q.ntiles = P.Bpad / 16;
+    Q.ev_stride = (long long)Q.ntiles * h->mg.RS * 64;
+    Q.slab = P.tape ? h->mw_slab : nullptr;
+    return Q;
+}
+template <int NR, int MODE>
+static hipError_t launch_mw_t(rnde_node* h, const MwParams& Q, int n, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)rnde_chainmw_kernel<NR, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((rnde_chainmw_kernel<NR, MODE>), dim3(Q.ntiles), dim3(kMwThreads), h->mw_lds_f, s, Q, n);
+    return hipGetLastError();
+}
+template <int MODE>
+static hipError_t launch_mw(rnde_node* h, const MwParams& Q, int n, hipStream_t s) {
+    switch (h->NKD) {
+        case 4: return launch_mw_t<1, MODE>(h, Q, n, s);
+        case 8: return launch_mw_t<2, MODE>(h, Q, n, s);
+        default: return launch_mw_t<4, MODE>(h, Q, n, s);
+    }
+}
+// the forward tapes every layer input of every evaluation into the slab: make room for `evals` evaluations (growing keeps what is there)
+static rnde_status ensure_mw_slab(rnde_node* h, long long evals, int Bpad, hipStream_t s) {
+    const long long per_eval = (long long)(h->Bpad_max / 16) * h->mg.RS * 64;   // sized for max_batch so that ev_stride changes never outgrow it
+    (void)Bpad;
+    if (h->mw_slab_evals >= evals) return RNDE_OK;
+    const long long want = std::max(evals, 2 * h->mw_slab_evals);
+    float* nb = nullptr;
+    HIPCHK(h, hipStreamSynchronize(s));
+    HIPCHK(h, hipMalloc((void**)&nb, (size_t)want * per_eval * 4));
+    if (h->mw_slab) {
+        HIPCHK(h, hipMemcpy(nb, h->mw_slab, (size_t)h->mw_slab_evals * per_eval * 4, hipMemcpyDeviceToDevice));
+        hipFree(h->mw_slab);
+    }
+    h->mw_slab = nb; h->mw_slab_evals = want;
+    return RNDE_OK;
+}
+
 static rnde_status chain_pack(rnde_node* h, const float* p_dev, hipStream_t s) {
+    if (h->mw) {
+        const long long tm = (long long)mw_tab_floats(h->mg);
+        hipLaunchKernelGGL(rnde_chainmw_pack_kernel, dim3((int)std::min<long long>((tm + 255) / 256, 512)), dim3(256), 0, s, p_dev, h->mw_tab, h->mg);
+        HIPCHK(h, hipGetLastError());
+        return RNDE_OK;
+    }
     const long long total = (long long)(h->cg.nfrag_f + h->cg.nfrag_b + h->cg.nfrag_t) * 64;
     hipLaunchKernelGGL(rnde_chain_pack_kernel, dim3((int)std::min<long long>((total + 255) / 256, 512)), dim3(256), 0, s, p_dev, h->cfrags, h->cg);
     HIPCHK(h, hipGetLastError());
@@ -270,7 +346,7 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
         g_create_err = "unsupported configuration: Tsit5 over a Dense chain with dims[0] == dims[n_layers]"; return RNDE_ERR_BAD_ARG;
     }
     const bool mnist_form = c->n_layers == 2 && c->time_dep && !c->pre_act && c->act[0] == RNDE_ACT_TANH;
-    if (c->col_tile == 64 || !mnist_form) return chain_create(c, out);   // small-width chains (latent_ode.jl:113-124): rnde_chain.h
+    if (c->col_tile == 64 || c->col_tile == 65 || !mnist_form) return chain_create(c, out);   // small-width chains (latent_ode.jl:113-124): rnde_chain.h
     if (c->regularize < RNDE_REG_NONE || c->regularize > RNDE_REG_ERR_STIFF) { g_create_err = "regularize: unknown value"; return RNDE_ERR_BAD_ARG; }
     if (c->regularize >= RNDE_REG_STIFF && (c->col_tile == 4 || c->col_tile == 8)) {
         g_create_err = "the stiffness-estimate regularisers run on the stage engine only (col_tile 0 or 16)";
@@ -372,6 +448,8 @@ extern "C" void rnde_node_destroy(rnde_node* h) {
     if (h->sv_t_dev) hipFree(h->sv_t_dev);
     if (h->replay_dev) hipFree(h->replay_dev);
     if (h->cfrags) hipFree(h->cfrags);
+    if (h->mw_tab) hipFree(h->mw_tab);
+    if (h->mw_slab) hipFree(h->mw_slab);
     if (h->tslab) hipFree(h->tslab);
     if (h->pabort) hipFree(h->pabort);
     if (h->pxcc) hipFree(h->pxcc);
@@ -583,10 +661,18 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
     if (st != RNDE_OK) return st;
     StageParams SQ{};
     ChainParams CQ{};
+    MwParams MQ{};
     if (h->engine == 3) {
         CQ = make_chain_params(h, P);
-        HIPCHK(h, launch_chain<CM_INIT_A>(h, CQ, 0, nullptr, s));
-        HIPCHK(h, launch_chain<CM_INIT_B>(h, CQ, 0, nullptr, s));
+        if (h->mw) {
+            if (keep_tape) { st = ensure_mw_slab(h, 2 + 6LL * std::max(4, h->predicted), P.Bpad, s); if (st != RNDE_OK) return st; }
+            MQ = make_mw_params(h, P);
+            HIPCHK(h, launch_mw<MW_INIT_A>(h, MQ, 0, s));
+            HIPCHK(h, launch_mw<MW_INIT_B>(h, MQ, 0, s));
+        } else {
+            HIPCHK(h, launch_chain<CM_INIT_A>(h, CQ, 0, nullptr, s));
+            HIPCHK(h, launch_chain<CM_INIT_B>(h, CQ, 0, nullptr, s));
+        }
     } else if (h->engine == 2) {
         st = stage_pack_weights(h, keep_tape ? h->pcopy : p_dev, s);
         if (st != RNDE_OK) return st;
@@ -605,8 +691,14 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
     h->tev_fwd = false;
     if (h->timing) HIPCHK(h, hipEventRecord(h->tev[0], s));
     while (true) {
+        if (h->engine == 3 && h->mw && keep_tape) {   // room in the activation slab for this chunk's evaluations (a regrowth keeps the taped ones)
+            st = ensure_mw_slab(h, 2 + 6LL * std::min(cap, launched + chunk), P.Bpad, s);
+            if (st != RNDE_OK) return st;
+            MQ.slab = h->mw_slab;
+        }
         for (int i = 0; i < chunk && launched < cap; ++i) {
-            if (h->engine == 3) HIPCHK(h, launch_chain<CM_STEP>(h, CQ, launched, nullptr, s));
+            if (h->engine == 3 && h->mw) HIPCHK(h, launch_mw<MW_STEP>(h, MQ, launched, s));
+            else if (h->engine == 3) HIPCHK(h, launch_chain<CM_STEP>(h, CQ, launched, nullptr, s));
             else if (h->engine == 2) HIPCHK(h, stage_attempt(h, SQ, launched, s));
             else HIPCHK(h, launch_step<MODE_STEP>(h, P, launched, s));
             ++launched;
@@ -778,7 +870,8 @@ extern "C" rnde_status rnde_debug_feval(rnde_node* h, const float* u_dev, const 
     if (h->engine == 3) {
         rnde_status st3 = chain_pack(h, p_dev, s);
         if (st3 != RNDE_OK) return st3;
-        HIPCHK(h, launch_chain<CM_FEVAL>(h, make_chain_params(h, P), 0, nullptr, s));
+        if (h->mw) HIPCHK(h, launch_mw<MW_FEVAL>(h, make_mw_params(h, P), 0, s));
+        else HIPCHK(h, launch_chain<CM_FEVAL>(h, make_chain_params(h, P), 0, nullptr, s));
         HIPCHK(h, hipStreamSynchronize(s));
         return RNDE_OK;
     }
@@ -812,7 +905,8 @@ extern "C" rnde_status rnde_debug_attempt(rnde_node* h, const float* uprev_dev, 
         const ChainParams CQ = make_chain_params(h, P);
         const int nks = h->NKD;
         HIPCHK(h, chain_convert(k1_dev, h->f0, h->D, B, CQ.ntiles, nks, 0, s));
-        HIPCHK(h, launch_chain<CM_STEP>(h, CQ, 0, nullptr, s));
+        if (h->mw) HIPCHK(h, launch_mw<MW_STEP>(h, make_mw_params(h, P), 0, s));
+        else HIPCHK(h, launch_chain<CM_STEP>(h, CQ, 0, nullptr, s));
         HIPCHK(h, launch_chain<CM_FINISH>(h, CQ, 1, nullptr, s));
         HIPCHK(h, hipMemcpyAsync(h->h_ctl, h->ctl_final, sizeof(StepState), hipMemcpyDeviceToHost, s));
         const ChainRec CL{(long long)CQ.ntiles * nks * 64};
@@ -872,7 +966,13 @@ static rnde_status bench_attempt_impl(rnde_node* h, const float* x_dev, const fl
     if (st != RNDE_OK) return st;
     StageParams SQ{};
     ChainParams CQ{};
-    if (h->engine == 3) {
+    MwParams MQ{};
+    if (h->engine == 3 && h->mw) {
+        if (taped) { st = ensure_mw_slab(h, 8, P.Bpad, s); if (st != RNDE_OK) return st; }
+        MQ = make_mw_params(h, P);
+        HIPCHK(h, launch_mw<MW_INIT_A>(h, MQ, 0, s));   // k1 = f(x, 0) into f0
+        for (int i = 0; i < 3; ++i) HIPCHK(h, launch_mw<MW_STEP>(h, MQ, 0, s));
+    } else if (h->engine == 3) {
         CQ = make_chain_params(h, P);
         HIPCHK(h, launch_chain<CM_INIT_A>(h, CQ, 0, nullptr, s));   // k1 = f(x, 0) into f0
         for (int i = 0; i < 3; ++i) HIPCHK(h, launch_chain<CM_STEP>(h, CQ, 0, nullptr, s));
@@ -892,7 +992,8 @@ static rnde_status bench_attempt_impl(rnde_node* h, const float* x_dev, const fl
     HIPCHK(h, hipEventRecord(e0, s));
     const auto host_t0 = std::chrono::steady_clock::now();
     for (int i = 0; i < iters; ++i) {
-        if (h->engine == 3) HIPCHK(h, launch_chain<CM_STEP>(h, CQ, 0, nullptr, s));
+        if (h->engine == 3 && h->mw) HIPCHK(h, launch_mw<MW_STEP>(h, MQ, 0, s));
+        else if (h->engine == 3) HIPCHK(h, launch_chain<CM_STEP>(h, CQ, 0, nullptr, s));
         else if (h->engine == 2) HIPCHK(h, stage_attempt(h, SQ, 0, s));
         else HIPCHK(h, launch_step<MODE_STEP>(h, P, 0, s));
     }
@@ -1323,8 +1424,127 @@ static hipError_t launch_bchain_t(rnde_node* h, const BChainParams& Q, const std
     return hipGetLastError();
 }
 
+
+// ---- chain engine, multi-wave kernels: reverse pass (rnde_bchainmw.h) ------------------------------------------------------
+template <int NR>
+static hipError_t launch_bmw_t(rnde_node* h, const BMwParams& Q, const std::vector<int>& sv_lo, const std::vector<int>& sv_hi, hipStream_t s) {
+    const BwdBuffers& b = h->bw;
+    const size_t lds = h->mw_lds_b;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)rnde_bchainmw_kernel<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rnde_bchainmw_init_kernel<NR, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rnde_bchainmw_init_kernel<NR, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const dim3 grid(Q.ntiles), blk(kMwThreads);
+    for (int n = Q.B.n_att - 1; n >= 0; --n) {
+        float c1 = 0.f, c2 = 0.f;   // cotangent of eigen_est for this attempt (as in bwd_run)
+        const StepMeta& mm = h->h_meta[n];
+        const bool eg_ok = !(mm.eigen == 0.f || mm.eigen != mm.eigen);
+        double eigb = 0.0;
+        if (h->cfg.regularize == RNDE_REG_STIFF && eg_ok) eigb = (double)b.h_svb[n] * (mm.eigen > 0 ? 1.0 : -1.0) / 3.5068;
+        if (h->cfg.regularize == RNDE_REG_ERR_STIFF && eg_ok) eigb = 0.1 * (double)b.h_svb[n] / 3.5068;
+        if (eigb != 0.0 && mm.n1 > 0.f && mm.n2 > 0.f) {
+            c1 = (float)(eigb / ((double)mm.n2 * (double)mm.n1));
+            c2 = (float)(-eigb * ((double)mm.n1 / (double)mm.n2) / ((double)mm.n2 * (double)mm.n2));
+        }
+        hipLaunchKernelGGL((rnde_bchainmw_kernel<NR>), grid, blk, lds, s, Q, n, mm, sv_lo[n], sv_hi[n], c1, c2);
+    }
+    hipLaunchKernelGGL((rnde_bchainmw_init_kernel<NR, 1>), grid, blk, lds, s, Q);
+    hipLaunchKernelGGL((rnde_bchainmw_init_kernel<NR, 2>), grid, blk, lds, s, Q);
+    hipLaunchKernelGGL(rnde_bfin_kernel, dim3(1), dim3(64), 0, s, Q.B);
+    return hipGetLastError();
+}
+
+static rnde_status chain_mw_bwd_run(rnde_node* h, const float* u_bar_dev, const float* saveval_bar_host, float* x_bar_dev,
+                                    float* p_bar_dev, float* tspan_bar_host, hipStream_t s, bool sync, float* tspan_bar_dev) {
+    BwdBuffers& b = h->bw;
+    const ChainGeo& G = h->cg;
+    const int cap = h->cfg.max_attempts, ntiles_max = h->Bpad_max / 16;
+    if (!b.ready) {
+        const size_t Ac = (size_t)ntiles_max * h->NKD * 64;
+        HIPCHK(h, hipMalloc((void**)&b.U, Ac * 4)); HIPCHK(h, hipMalloc((void**)&b.K1, Ac * 4)); HIPCHK(h, hipMalloc((void**)&b.UB1, Ac * 4));
+        HIPCHK(h, hipMalloc((void**)&b.svb_att, (size_t)cap * 4));
+        HIPCHK(h, hipMalloc((void**)&b.bstate, 2 * sizeof(BState))); HIPCHK(h, hipMalloc((void**)&b.ibstate, 2 * sizeof(IBState)));
+        HIPCHK(h, hipMalloc((void**)&b.bpart, (size_t)2 * h->nwg_max * 4 * 4)); HIPCHK(h, hipMalloc((void**)&b.ipart, (size_t)2 * h->nwg_max * 4 * 4));
+        HIPCHK(h, hipMalloc((void**)&b.tspan_out, 2 * 4));
+        HIPCHK(h, hipHostMalloc((void**)&b.h_svb, (size_t)cap * 4));
+        HIPCHK(h, hipMalloc((void**)&b.slab, (size_t)96 * h->P * 4)); HIPCHK(h, hipMalloc((void**)&b.slab_r, (size_t)16 * h->P * 4));
+        HIPCHK(h, hipMalloc((void**)&h->ev_t, ((size_t)6 * cap + 2) * 4)); HIPCHK(h, hipHostMalloc((void**)&h->h_ev_t, ((size_t)6 * cap + 2) * 4));
+        b.ready = true;
+    }
+    const int n_att = h->n_att, n_evals = 6 * n_att + 2;
+    if (!h->mw_slab || h->mw_slab_evals < n_evals) { h->err = "activation slab missing: the forward was not taped on the multi-wave kernels"; return RNDE_ERR_NO_TAPE; }
+    for (int i = 0; i < n_att; ++i)
+        b.h_svb[i] = (saveval_bar_host && h->sv_index[i] >= 0) ? saveval_bar_host[h->sv_index[i]] : 0.f;
+    HIPCHK(h, hipMemcpyAsync(b.svb_att, b.h_svb, (size_t)std::max(1, n_att) * 4, hipMemcpyHostToDevice, s));
+    BMwParams Q{};
+    Q.B.F = make_params(h, h->xcopy, h->B, h->t0, h->t1, 1);
+    Q.B.U = b.U; Q.B.K1 = b.K1; Q.B.UB1 = b.UB1; Q.B.svb_att = b.svb_att;
+    Q.B.bstate = b.bstate; Q.B.ibstate = b.ibstate; Q.B.bpart = b.bpart; Q.B.ipart = b.ipart;
+    Q.B.ubar = u_bar_dev; Q.B.xbar = x_bar_dev; Q.B.tspan_out = b.tspan_out;
+    Q.B.n_att = n_att; Q.B.track_ctrl = h->cfg.track_ctrl; Q.B.track_initdt = h->cfg.track_initdt; Q.B.reg_kind = h->cfg.regularize;
+    Q.B.bpart_n = Q.B.F.nwg;
+    Q.B.sv_T = (int)h->saveat.size();
+    Q.B.sv_ubar0 = (!h->saveat.empty() && h->saveat[0] == h->t0) ? u_bar_dev : nullptr;
+    Q.G = h->mg; Q.tab = h->mw_tab; Q.ntiles = Q.B.F.Bpad / 16;
+    Q.slab = h->mw_slab; Q.ev_stride = (long long)Q.ntiles * h->mg.RS * 64;
+    Q.sv_t = h->saveat.empty() ? nullptr : h->sv_t_dev; Q.sv_ubar = u_bar_dev; Q.nsave = (int)h->saveat.size();
+    // evaluation times in slab order (0: f(u0,t0), 1: f(u1,t0+dt0), 2 + 6n + (s-1): stage s of attempt n), save indices per accepted attempt
+    std::vector<int> sv_lo(std::max(1, n_att), 0), sv_hi(std::max(1, n_att), 0);
+    {
+        int ns = (!h->saveat.empty() && h->saveat[0] == h->t0) ? 1 : 0;
+        h->h_ev_t[0] = h->t0; h->h_ev_t[1] = h->t0 + h->h_init->dt0;
+        for (int n = 0; n < n_att; ++n) {
+            const StepMeta& m = h->h_meta[n];
+            for (int sidx = 2; sidx <= 7; ++sidx) h->h_ev_t[2 + 6 * n + sidx - 2] = m.t + tsC(sidx - 1) * m.dt;
+            sv_lo[n] = ns;
+            if (m.flags & F_ACCEPT) {
+                const float tnew = m.t + m.dt;
+                while (ns < (int)h->saveat.size() && h->saveat[ns] <= tnew) ++ns;
+            }
+            sv_hi[n] = ns;
+        }
+    }
+    HIPCHK(h, hipMemcpyAsync(h->ev_t, h->h_ev_t, (size_t)n_evals * 4, hipMemcpyHostToDevice, s));
+    hipError_t e = h->NKD == 4 ? launch_bmw_t<1>(h, Q, sv_lo, sv_hi, s) : (h->NKD == 8 ? launch_bmw_t<2>(h, Q, sv_lo, sv_hi, s) : launch_bmw_t<4>(h, Q, sv_lo, sv_hi, s));
+    HIPCHK(h, e);
+    // parameter gradients of all layers over all evaluations: the one-wave engine's kernel on the same slab format
+    BChainParams W{};
+    W.G = G; W.ntiles = Q.ntiles; W.slab = h->mw_slab; W.ev_stride = Q.ev_stride; W.RS = h->mg.RS;
+    for (int l = 0; l <= G.n_layers; ++l) { W.hrow[l] = h->mg.hrow[l]; if (l < G.n_layers) W.zrow[l] = h->mg.zrow[l]; }
+    const int n_units = n_evals * Q.ntiles;
+    const int chunks = std::max(1, std::min(96, n_units / 8));
+    const int per_chunk = (n_units + chunks - 1) / chunks;
+    hipLaunchKernelGGL(rnde_chain_wgrad_kernel, dim3(G.n_layers, chunks), dim3(64 * kCW), 0, s, W, (const float*)h->ev_t, n_units, per_chunk, b.slab, h->P);
+    HIPCHK(h, hipGetLastError());
+    {
+        const long long len = h->P;
+        const int grid = (int)std::min<long long>((len + 255) / 256, 2048);
+        if (chunks <= 16) hipLaunchKernelGGL(rnde_wgrad_reduce, dim3(grid, 1), dim3(256), 0, s, (const float*)b.slab, chunks, chunks, len, p_bar_dev);
+        else {
+            const int per_group = (chunks + 15) / 16, groups = (chunks + per_group - 1) / per_group;
+            hipLaunchKernelGGL(rnde_wgrad_reduce, dim3(grid, groups), dim3(256), 0, s, (const float*)b.slab, chunks, per_group, len, b.slab_r);
+            hipLaunchKernelGGL(rnde_wgrad_reduce, dim3(grid, 1), dim3(256), 0, s, (const float*)b.slab_r, groups, groups, len, p_bar_dev);
+        }
+        HIPCHK(h, hipGetLastError());
+    }
+    h->have_tape = false;
+    if (!sync) {
+        if (tspan_bar_dev) HIPCHK(h, hipMemcpyAsync(tspan_bar_dev, b.tspan_out, 8, hipMemcpyDeviceToDevice, s));
+        return RNDE_OK;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->h_scal, b.tspan_out, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    if (tspan_bar_host) { tspan_bar_host[0] = h->h_scal[0]; tspan_bar_host[1] = h->h_scal[1]; }
+    return RNDE_OK;
+}
+
 static rnde_status chain_bwd_run(rnde_node* h, const float* u_bar_dev, const float* saveval_bar_host, float* x_bar_dev,
                                  float* p_bar_dev, float* tspan_bar_host, hipStream_t s, bool sync, float* tspan_bar_dev) {
+    if (h->mw) { HIPCHK(h, hipSetDevice(h->cfg.device)); return chain_mw_bwd_run(h, u_bar_dev, saveval_bar_host, x_bar_dev, p_bar_dev, tspan_bar_host, s, sync, tspan_bar_dev); }
     HIPCHK(h, hipSetDevice(h->cfg.device));
     BwdBuffers& b = h->bw;
     const ChainGeo& G = h->cg;

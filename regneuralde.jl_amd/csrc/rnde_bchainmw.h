@@ -1,0 +1,435 @@
+// rnde_bchainmw.h -- reverse pass of the multi-wave chain kernels (rnde_chainmw.h): discretise-then-optimise through the taped
+// Tsit5 attempts, same scalar chain (t, dt, EEst, PI controller, initial-step heuristic) as rnde_bchain.h / rnde_bwd.h.
+//
+// One workgroup of four waves per 16 batch columns, as in the forward.  A J_f^T product is a chain of transposed Dense layers:
+// wave w owns INPUT-feature tile w of each layer; the pre-activation cotangent z_l sits in LDS as [feature][16 columns]
+// (B operand), the product comes out in the MFMA's D layout and is multiplied there by the activation derivative of the
+// layer below -- whose output the FORWARD pass taped in the slab, so nothing is recomputed (the one-wave kernels run the
+// chain forward again: 16 layer products per evaluation; here 8) and every taped value is requested before the chain starts.
+// z_l goes to LDS (next layer's operand) and to the slab (parameter-gradient kernel, rnde_chain_wgrad_kernel) in one step.
+#pragma once
+#include "rnde_chainmw.h"
+#include "rnde_bchain.h"
+
+namespace rnde {
+
+struct BMwParams {
+    BwdParams B;            // B.U / B.K1 / B.UB1 are fragment-order arrays
+    MwGeo G;
+    const float* tab;
+    float* slab;            // activations from the forward (H rows), pre-activation cotangents written here (Z rows)
+    long long ev_stride;
+    int ntiles;
+    const float* sv_t; const float* sv_ubar; int nsave;
+};
+
+// J_f^T product at a taped evaluation.  kout = f's value (element-wise), kbar its cotangent; returns gbar (element-wise) and adds
+// this lane's share of the time cotangent to tau.  ZA, ZB: 64 x 16 LDS buffers.  sl: slab base of this (evaluation, tile).
+template <int NR>
+__device__ __forceinline__ void mw_fbwd(const MwGeo& G, const float* FRt, const float* TV, float* ZA, float* ZB, float* __restrict__ sl,
+                                        const float (&gin)[NR], const float (&kout)[NR], const float (&kbar)[NR], float (&gb)[NR], float& tau,
+                                        int tid, int wave, int lane) {
+    const int Lr = G.n_layers, g = lane >> 4, col = lane & 15;
+    // taped outputs of layers 0 .. L-2 (= inputs of layers 1 .. L-1) in this wave's D layout: all requested now
+    f32x4 oo[kCMaxL];
+#pragma unroll
+    for (int l = 1; l < kCMaxL; ++l) {
+        oo[l] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (l < Lr && wave < G.mt[l] && G.act[l - 1] != 0) {
+            const float* hp = sl + (size_t)G.hrow[l] * 64 + (16 * wave + 4 * g) * 16 + col;
+            oo[l] = (f32x4){hp[0], hp[16], hp[32], hp[48]};
+        }
+    }
+    float tl = 0.f;
+    // z of the last layer, element-wise
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int e = tid + 256 * r;
+        float v = kbar[r];
+        if (G.act[Lr - 1] != 0) v *= (1.f - kout[r] * kout[r]);
+        if (e < 16 * 16 * G.mt[Lr]) { ZA[e] = v; sl[(size_t)G.zrow[Lr - 1] * 64 + e] = v; }
+        if (G.time_dep) tl = fmaf(v, TV[(Lr - 1) * 64 + (e >> 4)], tl);
+    }
+    __syncthreads();
+    float* Zc = ZA; float* Zn = ZB;
+#pragma unroll
+    for (int l = kCMaxL - 1; l >= 0; --l) {
+        if (l < Lr) {
+            const int mtin = G.mt[l], mtout = G.mt[l + 1];
+            if (wave < mtin) {
+                const int mi = wave;
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                const float* fr = FRt + ((size_t)G.toff[l] + (size_t)mi * mtout * 4) * 64 + lane;
+                const float* zb = Zc + lane;
+                float a[4], b[4], a2[4], b2[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { a[j] = fr[j * 64]; b[j] = zb[j * 64]; }
+#pragma unroll
+                for (int mo = 0; mo < 4; ++mo) {
+                    if (mo < mtout) {
+                        if (mo + 1 < mtout) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { a2[j] = fr[((mo + 1) * 4 + j) * 64]; b2[j] = zb[((mo + 1) * 4 + j) * 64]; }
+                        }
+                        acc0 = mfma16(a[0], b[0], acc0); acc1 = mfma16(a[1], b[1], acc1);
+                        acc0 = mfma16(a[2], b[2], acc0); acc1 = mfma16(a[3], b[3], acc1);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { a[j] = a2[j]; b[j] = b2[j]; }
+                    }
+                }
+                f32x4 o = acc0 + acc1;
+                float* zp = Zn + (16 * mi + 4 * g) * 16 + col;
+                if (l > 0) {     // z_{l-1} = (W_l^T z_l) .* act'_{l-1}(out_{l-1})
+                    if (G.act[l - 1] != 0) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) o[i] *= (1.f - oo[l][i] * oo[l][i]);
+                    }
+                    float* sp = sl + (size_t)G.zrow[l - 1] * 64 + (16 * mi + 4 * g) * 16 + col;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { zp[i * 16] = o[i]; sp[i * 16] = o[i]; }
+                    if (G.time_dep) {
+                        const f32x4 wt = *(const f32x4*)(TV + (l - 1) * 64 + 16 * mi + 4 * g);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) tl = fmaf(o[i], wt[i], tl);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) zp[i * 16] = o[i];
+                }
+            }
+            __syncthreads();
+            float* t_ = Zc; Zc = Zn; Zn = t_;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        float v = ((tid + 256 * r) >> 4) < 16 * G.mt[0] ? Zc[tid + 256 * r] : 0.f;   // (rows past the last tile were never written)
+        if (G.pre_act) { const float a0 = tanh_fast(gin[r]); v *= (1.f - a0 * a0); }
+        gb[r] = v;
+    }
+    __syncthreads();
+    tau += tl;
+}
+
+template <int NR>
+__global__ __launch_bounds__(kMwThreads) void rnde_bchainmw_kernel(const BMwParams Q, const int n, const StepMeta m, const int sv_lo, const int sv_hi,
+                                                                   const float eig_c1, const float eig_c2) {
+    const BwdParams& Bq = Q.B;
+    const StepParams& P = Bq.F;
+    const MwGeo& G = Q.G;
+    constexpr int NKD = 4 * NR;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* TV = smem + 512;                       // [BV | TV | FRt] as laid out in the table
+    float* FRt = smem + 1024;
+    float* ZA = FRt + (size_t)G.nfrag_t * 64;
+    float* ZB = ZA + 1024;
+    float* RED = ZB + 1024;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x;
+    const int gcol = tile * 16 + (tid & 15);
+    const bool colok = gcol < P.B;
+    const bool writer = (tile == 0 && tid == 0);
+    const bool first = (n == Bq.n_att - 1);
+    const ChainRec L{(long long)Q.ntiles * NKD * 64};
+    const size_t fo = (size_t)tile * NKD * 64 + tid;
+    auto feat = [&](int r) { return (tid + 256 * r) >> 4; };
+    auto valid = [&](int r) { return colok && feat(r) < P.D; };
+    mw_fill_lds(Q.tab + (size_t)G.nfrag_f * 64, smem, (G.nfrag_t >> 2) + 4, wave, lane);
+    // ---- scalar chain, identical in every wave; same arithmetic as rnde_bchain_kernel ----
+    double tb = 0, dtpb = 0, qoldb = 0, t1b = 0, t0b = 0;
+    if (!first) finish_attempt_scalars(Bq, n + 1, lane, tb, dtpb, qoldb, t1b, t0b);
+    const bool accepted = (m.flags & F_ACCEPT) != 0;
+    const float dt = m.dt, t = m.t;
+    float coef;
+    {
+        const double N = (double)P.D * (double)P.B;
+        double eb = 0, dtb_pre = 0, q11b = 0, qb = 0, qoldb_in = 0;
+        if (accepted) {
+            const bool err_term = Bq.reg_kind == 1 || (Bq.reg_kind == 3 && !(m.eest * dt == 0.f));
+            if (err_term) { const double sb = (double)Bq.svb_att[n]; eb += sb * (double)dt; dtb_pre += sb * (double)m.eest; }
+            dtb_pre += tb;
+            if (m.flags & F_DTMAXCLAMP) { t1b += dtpb; t0b -= dtpb; }
+            else if (Bq.track_ctrl) { dtb_pre += dtpb / (double)m.q; qb += -dtpb * (double)dt / ((double)m.q * (double)m.q); }
+            if (m.eest > kQoldInit) eb += qoldb;
+        } else {
+            dtb_pre += dtpb / (double)m.rej_m;
+            if (m.flags & F_REJQ11) q11b += -dtpb * (double)dt / ((double)m.rej_m * (double)m.rej_m) / (double)kGamma;
+            qoldb_in = qoldb;
+        }
+        if (!(m.flags & F_QCLAMP) && !(m.flags & F_EZERO)) {
+            const double qo = pow((double)m.qold_in, (double)kBeta2);
+            q11b += qb / (qo * (double)kGamma);
+            qoldb_in += -(double)kBeta2 * qb * (double)m.q / (double)m.qold_in;
+        }
+        if (!(m.flags & F_EZERO) && m.eest > 0.f) eb += q11b * (double)kBeta1 * (double)m.q11 / (double)m.eest;
+        coef = m.eest > 0.f ? (float)(eb / (N * (double)m.eest)) : 0.f;
+        if (writer) { BState b; b.tb_pre = tb; b.dtb_pre = dtb_pre; b.qoldb = qoldb_in; b.t1b = t1b; b.t0b = t0b; b.pad[0] = b.pad[1] = b.pad[2] = 0; Bq.bstate[n & 1] = b; }
+    }
+
+    float S = 0.f, tau = 0.f, ctau = 0.f;   // sum_j <k_j, kbar_j>; sum of time cotangents; c_s-weighted (+ extra dt-bar)
+    const float* R = P.arena + (long long)m.rec * P.rec_stride;
+    float* sl0 = Q.slab + (size_t)(2 + 6 * n) * Q.ev_stride + ((size_t)tile * G.RS) * 64;
+    const bool sv_mode = Q.nsave > 0;
+    float utb[NR], unb[NR], upb[NR], k1v[NR], Wv[7][NR];
+    // ---- A: reverse of the error estimate; seeds of unew-bar / uprev-bar ----
+    {
+        float kq[7][NR], upv[NR], unv[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            upv[r] = R[L.upc() + fo + 256 * r];
+            unv[r] = R[L.unew() + fo + 256 * r];
+            kq[0][r] = R[L.k1c() + fo + 256 * r];
+#pragma unroll
+            for (int j = 1; j < 7; ++j) kq[j][r] = R[L.k(j + 1) + fo + 256 * r];
+            k1v[r] = kq[0][r];
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            float acc = tsBt(0) * kq[0][r];
+#pragma unroll
+            for (int j = 1; j < 7; ++j) acc += tsBt(j) * kq[j][r];
+            float uin = 0.f;
+            if (accepted) {
+                if (!first) uin = Bq.U[fo + 256 * r];
+                else if (!sv_mode) uin = valid(r) ? Bq.ubar[(size_t)gcol * P.D + feat(r)] : 0.f;
+            }
+            utb[r] = 0.f; unb[r] = uin; upb[r] = 0.f;
+            if (valid(r)) {
+                const float ut = dt * acc;
+                const float au = fabsf(upv[r]), an = fabsf(unv[r]);
+                const bool use_new = !(au > an);
+                const float sk = P.abstol + (use_new ? an : au) * P.reltol;
+                const float rr = ut / sk;
+                const float rb = coef * rr;
+                const float skb = -rb * rr / sk;
+                utb[r] = rb / sk;
+                if (use_new) unb[r] += skb * P.reltol * sgnf(unv[r]); else upb[r] = skb * P.reltol * sgnf(upv[r]);
+            }
+#pragma unroll
+            for (int i = 0; i < 7; ++i) Wv[i][r] = 0.f;
+        }
+        if (sv_hi > sv_lo) {
+            // reverse of the dense output u(ts) = uprev + dt sum_i b_i(theta) k_i, theta = (ts - t)/dt  
+            const float tnew = m.t + dt;
+            for (int idx = sv_lo; idx < sv_hi; ++idx) {
+                const float ts = Q.sv_t[idx];
+                const bool at_end = (ts == tnew);
+                const float th = (ts - m.t) / dt;
+                float bw[7], dbw[7];
+                dense_weights(th, bw);
+                dense_weights_deriv(th, dbw);
+                float dth = 0.f;
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const float ub = valid(r) ? Q.sv_ubar[((size_t)gcol * Q.nsave + idx) * P.D + feat(r)] : 0.f;
+                    if (at_end) unb[r] += ub;
+                    else {
+                        upb[r] += ub;
+                        float dacc = dbw[0] * kq[0][r];
+#pragma unroll
+                        for (int i = 0; i < 7; ++i) { Wv[i][r] += bw[i] * ub; if (i) dacc += dbw[i] * kq[i][r]; }
+                        dth += ub * dt * dacc;
+                    }
+                }
+                if (!at_end) { tau += -dth / dt; ctau += -dth * th / dt; }
+            }
+        }
+    }
+    // Rb[i] = cotangent of k_{s-i} (zero-based) where s is the next stage to be reversed (rolled loop, kBwdShift)
+    float Rb[6][NR], gb[NR], exk[NR], exg[NR];
+    const bool has_eig = (eig_c1 != 0.f || eig_c2 != 0.f);
+    // ---- B: stage 7 (k7 = f(unew, t + dt)) ----
+    {
+        float k7[NR], unv[NR], kb7[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            k7[r] = R[L.k(7) + fo + 256 * r];
+            unv[r] = R[L.unew() + fo + 256 * r];
+            kb7[r] = dt * (tsBt(6) * utb[r] + Wv[6][r]);
+            S += k7[r] * kb7[r];
+            if (accepted && !first) kb7[r] += Bq.K1[fo + 256 * r];
+            exk[r] = 0.f; exg[r] = 0.f;
+            if (has_eig) {   // reverse of eigen_est = ||k7-k6|| / ||unew-g6|| (direct terms: they do not scale with dt, so not in S)
+                const bool ok = valid(r);
+                const float d1 = ok ? k7[r] - R[L.k(6) + fo + 256 * r] : 0.f, d2 = ok ? unv[r] - R[L.g(6) + fo + 256 * r] : 0.f;
+                kb7[r] += eig_c1 * d1; exk[r] = -eig_c1 * d1;
+                unb[r] += eig_c2 * d2; exg[r] = -eig_c2 * d2;
+            }
+        }
+        float t7 = 0.f;
+        mw_fbwd<NR>(G, FRt, TV, ZA, ZB, sl0 + 5 * Q.ev_stride, unv, k7, kb7, gb, t7, tid, wave, lane);
+        tau += t7; ctau += t7;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            unb[r] += gb[r];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) Rb[i][r] = dt * (tsA(6, 5 - i) * unb[r] + tsBt(5 - i) * utb[r] + Wv[5 - i][r]);   // kbar_{5-i}
+            upb[r] += unb[r];
+        }
+    }
+    // ---- C: stages 6..2 ----
+#pragma unroll 1
+    for (int s = 5; s >= 1; --s) {   // zero-based: k_s = f(g_s, t + c_s dt), taped as k(s+1), g(s+1)
+        float ks[NR], gs[NR], kb[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            ks[r] = R[L.k(s + 1) + fo + 256 * r];
+            gs[r] = R[L.g(s + 1) + fo + 256 * r];
+            kb[r] = Rb[0][r];
+            S += ks[r] * kb[r];
+            if (has_eig && s == 5) kb[r] += exk[r];          // direct cotangent of k6
+        }
+        float ts_ = 0.f;
+        mw_fbwd<NR>(G, FRt, TV, ZA, ZB, sl0 + (size_t)(s - 1) * Q.ev_stride, gs, ks, kb, gb, ts_, tid, wave, lane);
+        tau += ts_; ctau += kTsC[s] * ts_;
+        if (has_eig && s == 5) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) gb[r] += exg[r];   // direct cotangent of g6
+        }
+        float cb[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) cb[i] = dt * kBwdShift[s][i];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) Rb[i][r] = Rb[i + 1][r] + cb[i] * gb[r];
+            upb[r] += gb[r];
+        }
+    }
+    // ---- D: k1 and outputs (Rb[0] is now the cotangent of k1) ----
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        S += k1v[r] * Rb[0][r];
+        float uo = upb[r], ko = Rb[0][r];
+        if (!accepted) {
+            if (!first) { uo += Bq.U[fo + 256 * r]; ko += Bq.K1[fo + 256 * r]; }
+            else if (!sv_mode) uo += valid(r) ? Bq.ubar[(size_t)gcol * P.D + feat(r)] : 0.f;
+        }
+        Bq.U[fo + 256 * r] = uo;
+        Bq.K1[fo + 256 * r] = ko;
+    }
+    // (time cotangents: every lane's share counts -- rows / columns past D, B carry exact zeros in z)
+    S = wave_sum_f(S); tau = wave_sum_f(tau); ctau = wave_sum_f(ctau);
+    if (lane == 0) { RED[wave] = S; RED[4 + wave] = tau; RED[8 + wave] = ctau; }
+    __syncthreads();
+    if (tid == 0) {
+        float s = 0.f, ta = 0.f, ca = 0.f;
+        for (int w = 0; w < kMwWaves; ++w) { s += RED[w]; ta += RED[4 + w]; ca += RED[8 + w]; }
+        float* o = Bq.bpart + ((size_t)(n & 1) * Bq.bpart_n + tile) * 4;
+        o[0] = s; o[1] = ta; o[2] = ca; o[3] = 0.f;
+    }
+}
+
+// Reverse of the initialisation (mirror of rnde_bchain_init_kernel): PHASE 1 = f1 = f(u1, t0 + dt0) of the initial-step
+// heuristic (slab evaluation 1), PHASE 2 = f0 = f(u0, t0) (evaluation 0) and x-bar.
+template <int NR, int PHASE>
+__global__ __launch_bounds__(kMwThreads) void rnde_bchainmw_init_kernel(const BMwParams Q) {
+    const BwdParams& Bq = Q.B;
+    const StepParams& P = Bq.F;
+    const MwGeo& G = Q.G;
+    constexpr int NKD = 4 * NR;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* TV = smem + 512;
+    float* FRt = smem + 1024;
+    float* ZA = FRt + (size_t)G.nfrag_t * 64;
+    float* ZB = ZA + 1024;
+    float* RED = ZB + 1024;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x;
+    const int gcol = tile * 16 + (tid & 15);
+    const bool colok = gcol < P.B;
+    const bool writer = (tile == 0 && tid == 0);
+    const size_t fo = (size_t)tile * NKD * 64 + tid;
+    const double N = (double)P.D * (double)P.B;
+    auto feat = [&](int r) { return (tid + 256 * r) >> 4; };
+    auto valid = [&](int r) { return colok && feat(r) < P.D; };
+    mw_fill_lds(Q.tab + (size_t)G.nfrag_f * 64, smem, (G.nfrag_t >> 2) + 4, wave, lane);
+    const InitRec ir = *P.initrec;
+    const float dt0 = ir.dt0;
+    float* sl = Q.slab + (size_t)(PHASE == 1 ? 1 : 0) * Q.ev_stride + ((size_t)tile * G.RS) * 64;
+    float dot = 0.f, tau = 0.f;
+    if constexpr (PHASE == 1) {
+        double tb, dtpb, qoldb, t1b, t0b;
+        finish_attempt_scalars(Bq, 0, lane, tb, dtpb, qoldb, t1b, t0b);
+        const double dtb = Bq.track_initdt ? dtpb : 0.0;
+        double dt0b = 0, d1b = 0, d2b = 0;
+        if (ir.sel == 2) { t1b += dtb; t0b -= dtb; }
+        else if (ir.sel == 0) dt0b += 100.0 * dtb;
+        else if (!ir.dt1_const) {
+            const double mm = ir.max_is_d2 ? (double)ir.d2 : (double)ir.d1;
+            const double mb = dtb * (-0.2) * (double)ir.dt1 / mm;
+            if (ir.max_is_d2) d2b += mb; else d1b += mb;
+        } else if (dt0 * 1e-3f > 1e-6f) dt0b += 1e-3 * dtb;
+        const double n2 = (double)ir.d2 * (double)dt0, n2b = d2b / (double)dt0;
+        dt0b += -d2b * (double)ir.d2 / (double)dt0;
+        const double coef_w = n2 > 0 ? n2b / (N * n2) : 0.0;
+        if (writer) { IBState b; b.tb = tb; b.t1b = t1b; b.t0b = t0b; b.dt0b = dt0b; b.d1b = d1b; b.d2b = d2b; b.coef_w = coef_w; b.pad = 0; Bq.ibstate[0] = b; }
+        const float cw = (float)coef_w;
+        float f0v[NR], f1v[NR], u1v[NR], f1b[NR], gb[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const float xv = valid(r) ? P.x[(size_t)gcol * P.D + feat(r)] : 0.f;
+            f0v[r] = P.f0[fo + 256 * r]; f1v[r] = P.f1[fo + 256 * r]; u1v[r] = P.u1[fo + 256 * r];
+            f1b[r] = 0.f;
+            if (valid(r)) { const float sk = P.abstol + fabsf(xv) * P.reltol; f1b[r] = cw * ((f1v[r] - f0v[r]) / sk) / sk; }
+        }
+        mw_fbwd<NR>(G, FRt, TV, ZA, ZB, sl, u1v, f1v, f1b, gb, tau, tid, wave, lane);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) { Bq.UB1[fo + 256 * r] = gb[r]; dot += gb[r] * f0v[r]; }
+        dot = wave_sum_f(dot); tau = wave_sum_f(tau);
+        if (lane == 0) { RED[wave] = dot; RED[4 + wave] = tau; }
+        __syncthreads();
+        if (tid == 0) {
+            float s = 0.f, ta = 0.f;
+            for (int w = 0; w < kMwWaves; ++w) { s += RED[w]; ta += RED[4 + w]; }
+            float* o = Bq.ipart + (size_t)tile * 4;
+            o[0] = s; o[1] = ta; o[2] = 0.f; o[3] = 0.f;
+        }
+    } else {
+        const IBState ib = Bq.ibstate[0];
+        double dot1 = 0, tau1 = 0;
+        for (int i = lane; i < P.nwg; i += 64) { dot1 += (double)Bq.ipart[4 * i]; tau1 += (double)Bq.ipart[4 * i + 1]; }
+        dot1 = wave_sum_d(dot1); tau1 = wave_sum_d(tau1);
+        double dt0b = ib.dt0b + tau1 + dot1, t0b = ib.t0b + tau1, t1b = ib.t1b, d1b = ib.d1b, d0b = 0;
+        if (ir.dt0_clamped) { t1b += dt0b; t0b -= dt0b; }
+        else if (!ir.dt0_const) { d0b = dt0b / (100.0 * (double)ir.d1); d1b += -dt0b * (double)dt0 / (double)ir.d1; }
+        const float cv = ir.d1 > 0.f ? (float)(d1b / (N * (double)ir.d1)) : 0.f;
+        const float cz = ir.d0 > 0.f ? (float)(d0b / (N * (double)ir.d0)) : 0.f;
+        const float cw = (float)ib.coef_w;
+        if (writer) { IBState b = ib; b.t1b = t1b; b.t0b = t0b; Bq.ibstate[1] = b; }
+        float xq[NR], f0v[NR], f0b[NR], u0b[NR], gb[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            xq[r] = valid(r) ? P.x[(size_t)gcol * P.D + feat(r)] : 0.f;
+            f0v[r] = P.f0[fo + 256 * r];
+            const float f1v = P.f1[fo + 256 * r], ub1 = Bq.UB1[fo + 256 * r];
+            const float Uv = Bq.U[fo + 256 * r], K1v = Bq.K1[fo + 256 * r];
+            f0b[r] = K1v + dt0 * ub1; u0b[r] = Uv + ub1;
+            if (valid(r)) {
+                const float sk = P.abstol + fabsf(xq[r]) * P.reltol;
+                const float w = (f1v - f0v[r]) / sk, v = f0v[r] / sk, z = xq[r] / sk;
+                const float wb = cw * w, vb = cv * v, zb = cz * z;
+                const float skb = -(wb * w + vb * v + zb * z) / sk;
+                f0b[r] += (vb - wb) / sk;
+                u0b[r] += zb / sk + skb * P.reltol * sgnf(xq[r]);
+                if (Bq.sv_ubar0) u0b[r] += Bq.sv_ubar0[((size_t)gcol * Bq.sv_T) * P.D + feat(r)];
+            }
+        }
+        mw_fbwd<NR>(G, FRt, TV, ZA, ZB, sl, xq, f0v, f0b, gb, tau, tid, wave, lane);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) if (valid(r)) Bq.xbar[(size_t)gcol * P.D + feat(r)] = u0b[r] + gb[r];
+        tau = wave_sum_f(tau);
+        if (lane == 0) RED[wave] = tau;
+        __syncthreads();
+        if (tid == 0) {
+            float ta = 0.f;
+            for (int w = 0; w < kMwWaves; ++w) ta += RED[w];
+            float* o = Bq.ipart + ((size_t)P.nwg + tile) * 4;
+            o[0] = ta; o[1] = 0.f; o[2] = 0.f; o[3] = 0.f;
+        }
+    }
+}
+
+}  // namespace rnde

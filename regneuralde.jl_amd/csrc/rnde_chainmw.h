@@ -1,0 +1,357 @@
+// rnde_chainmw.h -- "multi-wave" kernels of the chain engine: the adaptive Tsit5 attempt for small-width Dense chains
+// (every width <= 64; the latent-ODE dynamics of reference experiments/latent_ode.jl:113-124) with
+// ONE WORKGROUP OF FOUR WAVES PER 16 BATCH COLUMNS instead of one wave (rnde_chain.h).
+//
+// Why: with one wave per tile a Dense layer is a chain of 20-26 dependent-ish MFMAs plus 13 tanh registers on a single SIMD:
+// ~2.2 k cycles per layer, 48 layers per attempted step, 32 waves on a 1,024-SIMD chip (the kernel furthest
+// below its roof).  Here a layer's output tiles are dealt to the four SIMDs of a CU:
+//   * activations live in LDS as [feature][16 columns] (two ping-pong buffers); an MFMA's B operand for k-step
+//     (input tile mi, j) is one conflict-free ds_read_b32 at X + (16 mi + 4 j) * 16 + lane;
+//   * wave w owns output tile w of every layer: <= 16 MFMAs (k-steps padded to whole input tiles, zero weights), its 4 D
+//     registers get bias / tanh and go back to LDS at Y[(16 mo + 4 g + i) * 16 + col]; one workgroup barrier per layer;
+//   * weight fragments stay resident in LDS (natural row order: no K permutation is needed when operands come from LDS);
+//   * the Runge-Kutta state (uprev, running stage sums, error accumulator) is element-wise work: 256 lanes x NKD/4 registers
+//     per array, element e = tid + 256 r <-> (feature e >> 4, column e & 15) -- the arena's fragment order IS [feature][16],
+//     so tape records, initialisation buffers and the host loop are those of rnde_chain.h, unchanged.
+// The forward pass tapes every layer's input (the slab rows the parameter-gradient kernel reads anyway), so the reverse pass
+// (rnde_bchainmw.h) recomputes nothing: 8 layer products per evaluation instead of 16.
+#pragma once
+#include "rnde_chain.h"
+
+namespace rnde {
+
+constexpr int kMwWaves = 4;
+constexpr int kMwThreads = 64 * kMwWaves;
+
+struct MwGeo {
+    int n_layers, time_dep, pre_act, D;
+    int width[kCMaxL + 1], mt[kCMaxL + 1];   // mt = 16-feature tiles of each width (k-steps are padded to 4 mt)
+    int act[kCMaxL], poff[kCMaxL];
+    int foff[kCMaxL], toff[kCMaxL];          // fragment offsets (units of 64 floats) inside the forward / transposed tables
+    int nfrag_f, nfrag_t;                    // padded to multiples of 4 (1 KiB DMA units)
+    int hrow[kCMaxL + 1], zrow[kCMaxL], RS;  // slab rows (k-step units) of layer inputs / pre-activation cotangents, as BChainParams
+};
+// global table: [forward fragments | bias vectors 8 x 64 | time columns 8 x 64 | transposed fragments]
+__host__ __device__ inline size_t mw_tab_floats(const MwGeo& G) { return (size_t)(G.nfrag_f + G.nfrag_t) * 64 + 1024; }
+
+struct MwParams {
+    StepParams F;
+    MwGeo G;
+    const float* tab;
+    float* slab;             // [n_evals][ntiles][RS][64] (NULL when not taping): evaluation 0 = f(u0), 1 = f(u1), 2 + 6 n + (s - 1) = stage s of attempt n
+    long long ev_stride;
+    int ntiles;
+};
+
+// forward fragment (l, mo, mi, j): lane (kk = lane >> 4, rho = lane & 15) = W_l[16 mo + rho][16 mi + 4 j + kk]
+// transposed      (l, mi, mo, j): lane (kk, rho)                         = W_l[16 mo + 4 j + kk][16 mi + rho]
+// bias vector l: b_l[f] for f < 64; time column l: W_l[f][in] (TDChain layers)
+__global__ void rnde_chainmw_pack_kernel(const float* __restrict__ p, float* __restrict__ tab, const MwGeo G) {
+    const long long nf = (long long)G.nfrag_f * 64, nt = (long long)G.nfrag_t * 64, total = nf + 1024 + nt;
+    for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        float v = 0.f;
+        if (e < nf || e >= nf + 1024) {
+            const bool tr = e >= nf;
+            const long long ee = tr ? e - nf - 1024 : e;
+            int fr = (int)(ee >> 6);
+            const int lane = (int)(ee & 63), rho = lane & 15, kk = lane >> 4;
+            const int* off = tr ? G.toff : G.foff;
+            int l = 0;
+            while (l + 1 < G.n_layers && fr >= off[l + 1]) ++l;
+            fr -= off[l];
+            const int in = G.width[l], out = G.width[l + 1];
+            const int j = fr & 3, t = fr >> 2;
+            int fo, fi;
+            if (!tr) { const int mo = t / G.mt[l], mi = t - mo * G.mt[l]; fo = 16 * mo + rho; fi = 16 * mi + 4 * j + kk; }
+            else { const int mi = t / G.mt[l + 1], mo = t - mi * G.mt[l + 1]; fo = 16 * mo + 4 * j + kk; fi = 16 * mi + rho; }
+            if (t < G.mt[l] * G.mt[l + 1] && fo < out && fi < in) v = p[G.poff[l] + (size_t)fi * out + fo];
+        } else {
+            const int r = (int)(e - nf), tcol = r >= 512, rr = r & 511, l = rr >> 6, f = rr & 63;
+            if (l < G.n_layers && f < G.width[l + 1]) {
+                const int in = G.width[l], out = G.width[l + 1];
+                v = tcol ? (G.time_dep ? p[G.poff[l] + (size_t)in * out + f] : 0.f) : p[G.poff[l] + (size_t)(in + G.time_dep) * out + f];
+            }
+        }
+        tab[e] = v;
+    }
+}
+
+__device__ __forceinline__ void mw_fill_lds(const float* __restrict__ src, float* dst, int units, int wave, int lane) {
+    for (int u = wave; u < units; u += kMwWaves) dma_unit((const f32x4*)(src + (size_t)u * 256) + lane, dst + (size_t)u * 256);
+    wait_vm<0>();
+    __syncthreads();
+}
+
+// One Dense layer: X (LDS, [feature][16], rows < 16 mt[l] finite) -> Y.  Wave w computes output tile w.  Ends with a barrier.
+// hs != NULL: the layer's OUTPUT is also written to the slab rows hs (the next layer's input / the evaluation's value).
+__device__ __forceinline__ void mw_layer(const MwGeo& G, const float* FRm, const float* BV, const float* TV, int l, float ts, const float* X, float* Y,
+                                         float* __restrict__ hs, int wave, int lane) {
+    const int mtin = G.mt[l], mtout = G.mt[l + 1];
+    if (wave < mtout) {
+        const int mo = wave, g = lane >> 4, col = lane & 15;
+        f32x4 acc0 = *(const f32x4*)(BV + l * 64 + 16 * mo + 4 * g), acc1 = {0.f, 0.f, 0.f, 0.f};
+        if (G.time_dep) { const f32x4 wt = *(const f32x4*)(TV + l * 64 + 16 * mo + 4 * g); acc0 = __builtin_elementwise_fma((f32x4){ts, ts, ts, ts}, wt, acc0); }
+        const float* fr = FRm + ((size_t)G.foff[l] + (size_t)mo * mtin * 4) * 64 + lane;
+        const float* xb = X + lane;
+        float a[4], b[4], a2[4], b2[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[j] = fr[j * 64]; b[j] = xb[j * 64]; }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            if (mi < mtin) {
+                if (mi + 1 < mtin) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { a2[j] = fr[((mi + 1) * 4 + j) * 64]; b2[j] = xb[((mi + 1) * 4 + j) * 64]; }
+                }
+                acc0 = mfma16(a[0], b[0], acc0); acc1 = mfma16(a[1], b[1], acc1);
+                acc0 = mfma16(a[2], b[2], acc0); acc1 = mfma16(a[3], b[3], acc1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { a[j] = a2[j]; b[j] = b2[j]; }
+            }
+        }
+        f32x4 o = acc0 + acc1;
+        if (G.act[l] != 0) {
+            const f32x2 t01 = tanh_fast2((f32x2){o[0], o[1]}), t23 = tanh_fast2((f32x2){o[2], o[3]});
+            o = (f32x4){t01.x, t01.y, t23.x, t23.y};
+        }
+        float* yp = Y + (16 * mo + 4 * g) * 16 + col;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) yp[i * 16] = o[i];
+        if (hs) {
+            float* sp = hs + (16 * mo + 4 * g) * 16 + col;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sp[i * 16] = o[i];
+        }
+    }
+    __syncthreads();
+}
+
+// k = f(g, ts) for the workgroup's 16 columns.  gv / kv: element-wise registers (e = tid + 256 r).  XB, YB: 64 x 16 floats each.
+// sl: slab base of this (evaluation, tile) or NULL.
+template <int NR>
+__device__ __forceinline__ void mw_eval(const MwGeo& G, const float* FRm, const float* BV, const float* TV, float* XB, float* YB, float ts,
+                                        const float (&gv)[NR], float (&kv)[NR], float* __restrict__ sl, int tid, int wave, int lane) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const float a = G.pre_act ? tanh_fast(gv[r]) : gv[r];
+        XB[tid + 256 * r] = a;
+        if (sl) sl[(size_t)G.hrow[0] * 64 + tid + 256 * r] = a;
+    }
+    // (a layer reads exactly the 16 mt[l] rows its predecessor wrote; the input covers 4 NKD >= 16 mt[0] rows: nothing stale is ever read)
+    __syncthreads();
+    float* X = XB; float* Y = YB;
+#pragma unroll 1
+    for (int l = 0; l < G.n_layers; ++l) {
+        mw_layer(G, FRm, BV, TV, l, ts, X, Y, sl ? sl + (size_t)G.hrow[l + 1] * 64 : nullptr, wave, lane);
+        float* t_ = X; X = Y; Y = t_;
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) kv[r] = ((tid + 256 * r) >> 4) < 16 * G.mt[G.n_layers] ? X[tid + 256 * r] : 0.f;   // (rows past the last tile were never written)
+    __syncthreads();   // X is rewritten by the next evaluation's input
+}
+
+enum { MW_STEP = 0, MW_INIT_A = 1, MW_INIT_B = 2, MW_FEVAL = 3 };
+
+// NR = NKD / 4 registers per state array and lane (NKD = 4, 8, 16 k-steps of D as in rnde_chain.h: arena arrays are NKD * 64 floats per tile)
+template <int NR, int MODE>
+__global__ __launch_bounds__(kMwThreads) void rnde_chainmw_kernel(const MwParams Q, const int n) {
+    const StepParams& P = Q.F;
+    const MwGeo& G = Q.G;
+    constexpr int NKD = 4 * NR;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* FRm = smem;
+    float* BV = FRm + (size_t)G.nfrag_f * 64;
+    float* TV = BV + 512;
+    float* XB = TV + 512;
+    float* YB = XB + 1024;
+    float* RED = YB + 1024;    // [3][4]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x;
+    const bool writer = (tile == 0 && tid == 0);
+    const ChainRec L{(long long)Q.ntiles * NKD * 64};
+    const size_t fo = (size_t)tile * NKD * 64 + tid;         // element r of this lane: fo + 256 r
+    mw_fill_lds(Q.tab, smem, (G.nfrag_f >> 2) + 4, wave, lane);
+    // element (r): feature f = (tid + 256 r) >> 4, column gcol
+    const int gcol = tile * 16 + (tid & 15);
+    const bool colok = gcol < P.B;
+    auto feat = [&](int r) { return (tid + 256 * r) >> 4; };
+    auto valid = [&](int r) { return colok && feat(r) < P.D; };
+    auto ldx = [&](const float* base, int r) { return valid(r) ? base[(size_t)gcol * P.D + feat(r)] : 0.f; };
+    float* slab_tile = Q.slab ? Q.slab + ((size_t)tile * G.RS) * 64 : nullptr;
+
+    if constexpr (MODE == MW_FEVAL) {
+        float gv[NR], kv[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) gv[r] = ldx(P.x, r);
+        mw_eval<NR>(G, FRm, BV, TV, XB, YB, P.forced_t, gv, kv, nullptr, tid, wave, lane);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) if (valid(r)) P.dbg_out[(size_t)gcol * P.D + feat(r)] = kv[r];
+        return;
+    } else if constexpr (MODE == MW_INIT_A || MODE == MW_INIT_B) {
+        // ---- initial-step heuristic, SURVEY.md B.1 (same arithmetic as rnde_chain_kernel) ----
+        float dt0 = 0.f;
+        if constexpr (MODE == MW_INIT_B) {
+            const double N = (double)P.D * (double)P.B;
+            const double s0 = sum_partials(P.initpart, P.nwg, lane);
+            const double s1 = sum_partials(P.initpart + P.nwg, P.nwg, lane);
+            const float d0 = (float)sqrt(s0 / N), d1 = (float)sqrt(s1 / N), dtmax = P.t1 - P.t0;
+            int c0 = 0, cl = 0;
+            if (d0 < 1e-5f || d1 < 1e-5f) { dt0 = 1e-6f; c0 = 1; }
+            else dt0 = (d0 / d1) / 100.f;
+            if (dtmax < dt0) { dt0 = dtmax; cl = 1; }
+            if (writer) { P.initrec->d0 = d0; P.initrec->d1 = d1; P.initrec->dt0 = dt0; P.initrec->dt0_const = c0; P.initrec->dt0_clamped = cl; }
+        }
+        float xv[NR], fv[NR], gv[NR], kv[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            xv[r] = ldx(P.x, r);
+            fv[r] = 0.f;
+            if constexpr (MODE == MW_INIT_B) {
+                fv[r] = P.f0[fo + 256 * r];
+                gv[r] = xv[r] + dt0 * fv[r];
+                P.u1[fo + 256 * r] = gv[r];
+            } else gv[r] = xv[r];
+        }
+        float* sl = (slab_tile && P.tape) ? slab_tile + (size_t)(MODE == MW_INIT_B ? 1 : 0) * Q.ev_stride : nullptr;
+        mw_eval<NR>(G, FRm, BV, TV, XB, YB, (MODE == MW_INIT_B) ? P.t0 + dt0 : P.t0, gv, kv, sl, tid, wave, lane);
+        float pa = 0.f, pb = 0.f;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            ((MODE == MW_INIT_B) ? P.f1 : P.f0)[fo + 256 * r] = kv[r];
+            if (valid(r)) {
+                const float sk = P.abstol + fabsf(xv[r]) * P.reltol;
+                if constexpr (MODE == MW_INIT_A) { const float a = xv[r] / sk, b = kv[r] / sk; pa += a * a; pb += b * b; }
+                else { const float a = (kv[r] - fv[r]) / sk; pa += a * a; }
+            }
+        }
+        pa = wave_sum_f(pa); pb = wave_sum_f(pb);
+        if (lane == 0) { RED[wave] = pa; RED[4 + wave] = pb; }
+        __syncthreads();
+        if (tid == 0) {
+            float sa = 0.f, sb = 0.f;
+            for (int w = 0; w < kMwWaves; ++w) { sa += RED[w]; sb += RED[4 + w]; }
+            if constexpr (MODE == MW_INIT_A) { P.initpart[tile] = sa; P.initpart[P.nwg + tile] = sb; }
+            else P.initpart[2 * P.nwg + tile] = sa;
+        }
+        return;
+    } else {
+        // ---- controller, then one attempted step ----
+        const StepState S = advance_state(P, n, lane, writer, &P.ctl[n & 1]);
+        if (P.nsave > 0) {
+            // saveat ({R,true} methods, neural_ode.jl:79-108): the points inside the step accepted last
+            if (n == 0) {
+                if (S.next_save > 0) {
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) if (valid(r)) P.sv_out[((size_t)gcol * P.nsave) * P.D + feat(r)] = P.x[(size_t)gcol * P.D + feat(r)];
+                }
+            } else {
+                const StepState pv = P.ctl[(n - 1) & 1];
+                const int lo = pv.next_save, hi = S.next_save;
+                if (hi > lo && !pv.done) {
+                    const float dtp_ = (P.t1 - pv.t < pv.dtp) ? (P.t1 - pv.t) : pv.dtp;
+                    const float* Rp = P.arena + (long long)S.live * P.rec_stride;
+                    float up[NR], un[NR], k[7][NR];
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        up[r] = Rp[L.upc() + fo + 256 * r]; un[r] = Rp[L.unew() + fo + 256 * r]; k[0][r] = Rp[L.k1c() + fo + 256 * r];
+#pragma unroll
+                        for (int j = 1; j < 7; ++j) k[j][r] = Rp[L.k(j + 1) + fo + 256 * r];
+                    }
+                    for (int idx = lo; idx < hi; ++idx) {
+                        const float tsv = P.sv_t[idx];
+                        float b[7];
+                        const bool at_end = (tsv == S.t);
+                        dense_weights((tsv - pv.t) / dtp_, b);
+#pragma unroll
+                        for (int r = 0; r < NR; ++r) {
+                            float o = un[r];
+                            if (!at_end) {
+                                float acc = b[0] * k[0][r];
+#pragma unroll
+                                for (int j = 1; j < 7; ++j) acc += b[j] * k[j][r];
+                                o = up[r] + dtp_ * acc;
+                            }
+                            if (valid(r)) P.sv_out[((size_t)gcol * P.nsave + idx) * P.D + feat(r)] = o;
+                        }
+                    }
+                }
+            }
+        }
+        if (S.done) return;
+        const float t = S.t;
+        const float dt = (!P.forced && (P.t1 - S.t < S.dtp)) ? (P.t1 - S.t) : S.dtp;
+        const int rec = P.tape ? n : (S.live == 0 ? 1 : 0);
+        float* R = P.arena + (long long)rec * P.rec_stride;
+        float part = 0.f, part1 = 0.f, part2 = 0.f;
+        // Rolled stage loop with shifting partial sums, exactly as rnde_chain_kernel: Sa[i] = running combination of the i-th stage still to come
+        float up[NR], Sa[6][NR], E[NR], un[NR], g6[NR], k6[NR];
+        const float* Rl = P.arena + (long long)(S.live < 0 ? 0 : S.live) * P.rec_stride;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            float k1;
+            if (S.live < 0) { up[r] = ldx(P.x, r); k1 = P.f0[fo + 256 * r]; }
+            else { up[r] = Rl[L.unew() + fo + 256 * r]; k1 = Rl[L.k(7) + fo + 256 * r]; }
+            if (P.tape || P.nsave > 0) { R[L.upc() + fo + 256 * r] = up[r]; R[L.k1c() + fo + 256 * r] = k1; }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) Sa[i][r] = kFwdShift[0][i] * k1;
+            E[r] = kTsBt[0] * k1;
+            un[r] = up[r]; g6[r] = 0.f; k6[r] = 0.f;
+        }
+#pragma unroll 1
+        for (int s = 1; s < 7; ++s) {   // zero-based stage: k_{s+1} = f(g_{s+1}, t + c_s dt)
+            float gq[NR], kv[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) gq[r] = up[r] + dt * Sa[0][r];
+            if (s == 6) {
+#pragma unroll
+                for (int r = 0; r < NR; ++r) { un[r] = gq[r]; R[L.unew() + fo + 256 * r] = gq[r]; }
+            } else if (P.tape) {
+#pragma unroll
+                for (int r = 0; r < NR; ++r) R[L.g(s + 1) + fo + 256 * r] = gq[r];
+            }
+            float* sl = (slab_tile && P.tape) ? slab_tile + (size_t)(2 + 6 * n + (s - 1)) * Q.ev_stride : nullptr;
+            mw_eval<NR>(G, FRm, BV, TV, XB, YB, t + kTsC[s] * dt, gq, kv, sl, tid, wave, lane);
+            if (s == 5 && P.reg_kind >= 2) {
+#pragma unroll
+                for (int r = 0; r < NR; ++r) { g6[r] = gq[r]; k6[r] = kv[r]; }
+            }
+            if (s == 6 && P.reg_kind >= 2) {   // ||k7 - k6||^2, ||unew - g6||^2
+#pragma unroll
+                for (int r = 0; r < NR; ++r) if (valid(r)) { const float d1 = kv[r] - k6[r], d2 = un[r] - g6[r]; part1 += d1 * d1; part2 += d2 * d2; }
+            }
+            const float bts = kTsBt[s];
+            float cs[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) cs[i] = kFwdShift[s][i];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                R[L.k(s + 1) + fo + 256 * r] = kv[r];
+                E[r] += bts * kv[r];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) Sa[i][r] = Sa[i + 1][r] + cs[i] * kv[r];
+            }
+        }
+        // embedded error estimate, SURVEY.md B.3
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if (valid(r)) {
+                const float ut = dt * E[r];
+                const float sk = P.abstol + fmaxf(fabsf(up[r]), fabsf(un[r])) * P.reltol;
+                const float rr = ut / sk;
+                part += rr * rr;
+            }
+        }
+        part = wave_sum_f(part); part1 = wave_sum_f(part1); part2 = wave_sum_f(part2);
+        if (lane == 0) { RED[wave] = part; RED[4 + wave] = part1; RED[8 + wave] = part2; }
+        __syncthreads();
+        if (tid == 0) {
+            float s = 0.f, s1 = 0.f, s2 = 0.f;
+            for (int w = 0; w < kMwWaves; ++w) { s += RED[w]; s1 += RED[4 + w]; s2 += RED[8 + w]; }
+            float* ep = P.errpart + (size_t)(n & 1) * 3 * P.nwg;
+            ep[tile] = s; ep[P.nwg + tile] = s1; ep[2 * P.nwg + tile] = s2;
+        }
+    }
+}
+
+}  // namespace rnde

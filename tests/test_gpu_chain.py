@@ -32,12 +32,21 @@ def _setup(kind, B, seed, scale=1.0):
 
 def _cfg(arch, B, **kw):
     from tests.test_gpu_forward import _cfg as base
-    kw.setdefault("col_tile", 64)
+    kw.setdefault("col_tile", _DEFAULT_TILE[0])
     return base(arch, B, **kw)
 
 
 KINDS = [("latent", 4), ("latent", 37), ("latent", 512), ("chain3", 19), ("wide", 16), ("one", 3), ("test_node", 5), ("small", 70)]
-LAYOUTS = [64]         # col_tile: 16 batch columns per wave (rnde_chain.h)
+LAYOUTS = [64, 65]     # col_tile: one wave per 16 batch columns (rnde_chain.h) / four waves per 16 columns (rnde_chainmw.h)
+_DEFAULT_TILE = [64]
+
+
+@pytest.fixture(autouse=True, params=[64, 65], ids=["one-wave", "multi-wave"])
+def _engine(request):
+    """Every test of this file that does not pick a layout itself runs on both kernel families of the chain engine."""
+    _DEFAULT_TILE[0] = request.param
+    yield
+    _DEFAULT_TILE[0] = 64
 
 
 @pytest.mark.parametrize("lay", LAYOUTS)

@@ -1010,6 +1010,14 @@ static rnde_status bench_attempt_impl(rnde_node* h, const float* x_dev, const fl
         unsigned long long* d = nullptr; unsigned long long hst[64] = {0};
         hipMalloc((void**)&d, sizeof(hst)); hipMemset(d, 0, sizeof(hst));
         P.dbg_out = (float*)d;
+        if (h->engine == 3 && h->mw) {
+            MQ.F.dbg_out = (float*)d; launch_mw<MW_STEP>(h, MQ, 0, s); hipStreamSynchronize(s); hipMemcpy(hst, d, sizeof(hst), hipMemcpyDeviceToHost);
+            fprintf(stderr, "mw chain stamps (cycles): LDS fill %lld, controller %lld, state load %lld |", (long long)(hst[1]-hst[0]), (long long)(hst[2]-hst[1]), (long long)(hst[3]-hst[2]));
+            for (int i = 4; i <= 9; ++i) fprintf(stderr, " eval%d %lld", i - 3, (long long)(hst[i]-hst[i-1]));
+            fprintf(stderr, " | tail %lld total %lld\n  first eval: input->L0 %lld", (long long)(hst[10]-hst[9]), (long long)(hst[10]-hst[0]), (long long)(hst[16]-hst[3]));
+            for (int l = 0; l < h->mg.n_layers; ++l) fprintf(stderr, " L%d %lld", l, (long long)(hst[17+l]-hst[16+l]));
+            fprintf(stderr, "\n");
+            hipFree(d); return RNDE_OK; }
         if (h->engine == 3) { CQ.F.dbg_out = (float*)d; launch_chain<CM_STEP>(h, CQ, 0, nullptr, s); hipStreamSynchronize(s); hipMemcpy(hst, d, sizeof(hst), hipMemcpyDeviceToHost);
             fprintf(stderr, "chain stamps (cycles): fill %lld ctl %lld loads %lld |", (long long)(hst[1]-hst[0]), (long long)(hst[2]-hst[1]), (long long)(hst[3]-hst[2]));
             for (int i = 4; i <= 9; ++i) fprintf(stderr, " st%d %lld", i - 3, (long long)(hst[i]-hst[i-1]));

@@ -126,11 +126,18 @@ __device__ __forceinline__ void mw_layer(const MwGeo& G, const float* FRm, const
     __syncthreads();
 }
 
+#ifdef RNDE_DIAG
+#define MW_STAMP(i) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[i] = clock64(); } while (0)
+#else
+#define MW_STAMP(i) do { } while (0)
+#endif
+
 // k = f(g, ts) for the workgroup's 16 columns.  gv / kv: element-wise registers (e = tid + 256 r).  XB, YB: 64 x 16 floats each.
 // sl: slab base of this (evaluation, tile) or NULL.
 template <int NR>
 __device__ __forceinline__ void mw_eval(const MwGeo& G, const float* FRm, const float* BV, const float* TV, float* XB, float* YB, float ts,
-                                        const float (&gv)[NR], float (&kv)[NR], float* __restrict__ sl, int tid, int wave, int lane) {
+                                        const float (&gv)[NR], float (&kv)[NR], float* __restrict__ sl, int tid, int wave, int lane,
+                                        unsigned long long* dbg = nullptr) {
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const float a = G.pre_act ? tanh_fast(gv[r]) : gv[r];
@@ -139,12 +146,15 @@ __device__ __forceinline__ void mw_eval(const MwGeo& G, const float* FRm, const 
     }
     // (a layer reads exactly the 16 mt[l] rows its predecessor wrote; the input covers 4 NKD >= 16 mt[0] rows: nothing stale is ever read)
     __syncthreads();
+    // (rolled on purpose: eight unrolled copies of the layer body measured 41.5 us per attempt against 38.6 us)
     float* X = XB; float* Y = YB;
 #pragma unroll 1
     for (int l = 0; l < G.n_layers; ++l) {
+        MW_STAMP(16 + l);
         mw_layer(G, FRm, BV, TV, l, ts, X, Y, sl ? sl + (size_t)G.hrow[l + 1] * 64 : nullptr, wave, lane);
         float* t_ = X; X = Y; Y = t_;
     }
+    MW_STAMP(16 + G.n_layers);
 #pragma unroll
     for (int r = 0; r < NR; ++r) kv[r] = ((tid + 256 * r) >> 4) < 16 * G.mt[G.n_layers] ? X[tid + 256 * r] : 0.f;   // (rows past the last tile were never written)
     __syncthreads();   // X is rewritten by the next evaluation's input
@@ -171,7 +181,13 @@ __global__ __launch_bounds__(kMwThreads) void rnde_chainmw_kernel(const MwParams
     const bool writer = (tile == 0 && tid == 0);
     const ChainRec L{(long long)Q.ntiles * NKD * 64};
     const size_t fo = (size_t)tile * NKD * 64 + tid;         // element r of this lane: fo + 256 r
+    unsigned long long* dbg = nullptr;
+#ifdef RNDE_DIAG
+    if (MODE == MW_STEP) dbg = (unsigned long long*)P.dbg_out;
+#endif
+    MW_STAMP(0);
     mw_fill_lds(Q.tab, smem, (G.nfrag_f >> 2) + 4, wave, lane);
+    MW_STAMP(1);
     // element (r): feature f = (tid + 256 r) >> 4, column gcol
     const int gcol = tile * 16 + (tid & 15);
     const bool colok = gcol < P.B;
@@ -238,6 +254,7 @@ __global__ __launch_bounds__(kMwThreads) void rnde_chainmw_kernel(const MwParams
     } else {
         // ---- controller, then one attempted step ----
         const StepState S = advance_state(P, n, lane, writer, &P.ctl[n & 1]);
+        MW_STAMP(2);
         if (P.nsave > 0) {
             // saveat ({R,true} methods, neural_ode.jl:79-108): the points inside the step accepted last
             if (n == 0) {
@@ -311,7 +328,8 @@ __global__ __launch_bounds__(kMwThreads) void rnde_chainmw_kernel(const MwParams
                 for (int r = 0; r < NR; ++r) R[L.g(s + 1) + fo + 256 * r] = gq[r];
             }
             float* sl = (slab_tile && P.tape) ? slab_tile + (size_t)(2 + 6 * n + (s - 1)) * Q.ev_stride : nullptr;
-            mw_eval<NR>(G, FRm, BV, TV, XB, YB, t + kTsC[s] * dt, gq, kv, sl, tid, wave, lane);
+            MW_STAMP(2 + s);
+            mw_eval<NR>(G, FRm, BV, TV, XB, YB, t + kTsC[s] * dt, gq, kv, sl, tid, wave, lane, s == 1 ? dbg : nullptr);
             if (s == 5 && P.reg_kind >= 2) {
 #pragma unroll
                 for (int r = 0; r < NR; ++r) { g6[r] = gq[r]; k6[r] = kv[r]; }
@@ -342,9 +360,11 @@ __global__ __launch_bounds__(kMwThreads) void rnde_chainmw_kernel(const MwParams
                 part += rr * rr;
             }
         }
+        MW_STAMP(9);
         part = wave_sum_f(part); part1 = wave_sum_f(part1); part2 = wave_sum_f(part2);
         if (lane == 0) { RED[wave] = part; RED[4 + wave] = part1; RED[8 + wave] = part2; }
         __syncthreads();
+        MW_STAMP(10);
         if (tid == 0) {
             float s = 0.f, s1 = 0.f, s2 = 0.f;
             for (int w = 0; w < kMwWaves; ++w) { s += RED[w]; s1 += RED[4 + w]; s2 += RED[8 + w]; }

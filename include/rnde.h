@@ -223,7 +223,7 @@ rnde_status rnde_comm_allreduce(rnde_comm* c, float* buf_dev, int64_t n, int32_t
  * TrackedNeuralDSDE: the stochastic layer (reference src/models/neural_sde.jl:1-146; caller ClassifierNSDE,
  * src/models/supervised_classification.jl:82-103; experiment experiments/mnist_nsde.jl:70-100).
  *   rnde_nsde_create    TrackedNeuralDSDE(model1, model2, tspan, regularize, solver; kw...)   neural_sde.jl:13-41
- *   rnde_nsde_forward   (n::TrackedNeuralDSDE{R,false})(x, p; func): the `solve(SDEProblem{false}(...), SOSRI(); callback, ...)`
+ *   rnde_nsde_forward / rnde_nsde_forward_saveat   (n::TrackedNeuralDSDE{R,false / true})(x, p; func): the `solve(SDEProblem{false}(...), SOSRI(); callback, ...)`
  *                       between :98 and :108 (and :54-56 for the unregularised method), returning what :109-113 unpack:
  *                       u (D x B), nfe1, nfe2 (the closures' counters, :46,:50) and the saved EEst*dt values
  *   rnde_nsde_backward  the reverse sweep Tracker performs over that solve (sensealg = SensitivityADPassThrough, :104)
@@ -271,6 +271,14 @@ rnde_status rnde_nsde_forward(rnde_nsde* h, const float* x_dev, const float* p_d
                               const float* noise_dev, int32_t n_pool, uint64_t seed, float* u_out_dev,
                               int64_t* nfe1_out, int64_t* nfe2_out, float* saveval_host, int32_t* n_saveval_out,
                               int32_t keep_tape, void* stream);
+/* The {R,true} call methods (neural_sde.jl:44-61, :84-113; experiments/sde_toy_problem.jl:50-60): the same solve, returning the
+ * state at every time of `saveat` (increasing, inside [t0, t1]) as the D x n_saveat x B array diffeqsol_to_3dtrackedarray builds
+ * (src/utils.jl:17-19).  Points inside a step come from the SDE solution's linear interpolant (StochasticDiffEq has no
+ * higher-order dense output), a save time equal to t0 is x.  rnde_nsde_backward then takes u_bar_dev of that D x n_saveat x B shape. */
+rnde_status rnde_nsde_forward_saveat(rnde_nsde* h, const float* x_dev, const float* p_dev, int32_t B, float t0, float t1,
+                                     const float* noise_dev, int32_t n_pool, uint64_t seed, const float* saveat_host,
+                                     int32_t n_saveat, float* u_saved_dev, int64_t* nfe1_out, int64_t* nfe2_out,
+                                     float* saveval_host, int32_t* n_saveval_out, int32_t keep_tape, void* stream);
 /* Parity instrument (as rnde_node_forward_replay): the solve along n_steps given (dt, accepted != 0) pairs. */
 rnde_status rnde_nsde_forward_replay(rnde_nsde* h, const float* x_dev, const float* p_dev, int32_t B, float t0, float t1,
                                      const float* noise_dev, int32_t n_pool, const float* steps_host, int32_t n_steps,

@@ -98,12 +98,22 @@ class SdeOracle:
         d = self._arr(dt); a = np.ascontiguousarray(acc, dtype=np.int32)
         self.lib.orc_sde_set_replay(self.h, self._p(d), a.ctypes.data_as(C.c_void_p), C.c_int(len(d)))
 
+    def set_saveat(self, saveat=None):
+        if saveat is None:
+            self.lib.orc_sde_set_saveat(self.h, None, C.c_int(0))
+            self.nsave = 0
+            return
+        sa = self._arr(saveat)
+        self.lib.orc_sde_set_saveat(self.h, self._p(sa), C.c_int(len(sa)))
+        self.nsave = len(sa)
+
     def forward(self, x, p, noise, t0=0.0, t1=1.0):
-        """x: (B, D); noise: (n_pool, 2, B, D) standard normals."""
+        """x: (B, D); noise: (n_pool, 2, B, D) standard normals.  After set_saveat: u is (B, T, D)."""
         x, p, noise = self._arr(x), self._arr(p), self._arr(noise)
         B = x.shape[0]
         assert noise.shape[1:] == (2, B, self.D)
-        u = np.empty_like(x)
+        ns = getattr(self, "nsave", 0)
+        u = np.empty((B, ns, self.D), dtype=self.dtype) if ns else np.empty_like(x)
         n1, n2 = C.c_long(0), C.c_long(0)
         sv = np.zeros(self.max_attempts + 1, dtype=self.dtype)
         nsv, natt, ndr = C.c_int(0), C.c_int(0), C.c_int(0)
@@ -121,7 +131,7 @@ class SdeOracle:
 
     def backward(self, ubar, svbar=None):
         ubar = self._arr(ubar)
-        xbar = np.empty_like(ubar)
+        xbar = np.empty((ubar.shape[0], self.D), dtype=self.dtype)
         pbar = np.empty(self.P, dtype=self.dtype)
         sv = self._arr(svbar) if svbar is not None else None
         rc = self.lib.orc_sde_backward(self.h, self._p(ubar), self._p(sv) if sv is not None else None, self._p(xbar), self._p(pbar))

@@ -105,6 +105,7 @@ typedef struct { stack_item* it; int n, cap; } nstack;
 typedef struct {
     real t, dt, eest;
     int sv_index;
+    int sv_first, nsv_pts;    /* saveat points filled from this step (linear interpolation between uprev and u) */
     real *uprev, *u;          /* uprev borrowed (u0 or the previous record's u), u owned */
     real *dW, *dZ;            /* owned copies of the increments the attempt used */
     real *k[4], *g[4];        /* owned */
@@ -124,6 +125,7 @@ typedef struct {
     real *wtot, *ztot;
     int have_tape, n_saveval;
     int n_replay; real* replay_dt; int* replay_acc;   /* orc_sde_set_replay */
+    int nsave; real* saveat; int save_t0;             /* orc_sde_set_saveat: the {R,true} call methods (neural_sde.jl:44-61,:84-113) */
 } sde_handle;
 
 static real* ralloc(size_t n) { return (real*)malloc(sizeof(real) * n); }
@@ -165,6 +167,17 @@ static void free_tape(sde_handle* h) {
     h->u0 = h->p = h->wtot = h->ztot = NULL;
     h->have_tape = 0;
 }
+/* saveat (the {R,true} methods): following forwards return the state at every time of `saveat` (increasing, inside [t0, t1]) as a
+ * (D, T, B) column-major array; points inside a step come from the SDE solution's LINEAR interpolant (StochasticDiffEq has no
+ * higher-order dense output), a point equal to t0 is u0 (save_start).  n = 0 switches back to the end state. */
+void orc_sde_set_saveat(void* hh, const real* saveat, int n) {
+    sde_handle* h = (sde_handle*)hh;
+    free(h->saveat);
+    h->saveat = NULL; h->nsave = 0;
+    if (n <= 0) return;
+    h->saveat = rdup(saveat, n);
+    h->nsave = n;
+}
 void orc_sde_set_replay(void* hh, const real* dt, const int* acc, int n) {
     sde_handle* h = (sde_handle*)hh;
     free(h->replay_dt); free(h->replay_acc);
@@ -179,7 +192,7 @@ void orc_sde_destroy(void* hh) {
     sde_handle* h = (sde_handle*)hh;
     if (!h) return;
     free_tape(h);
-    free(h->replay_dt); free(h->replay_acc);
+    free(h->replay_dt); free(h->replay_acc); free(h->saveat);
     free(h->rec);
     free(h);
 }
@@ -423,6 +436,13 @@ int orc_sde_forward(void* hh, const real* x, const real* p, int B, real t0, real
     if (t1 - t < dt) dt = t1 - t;
     ret = noise_init(&W, dt);
     const real* uprev = h->u0;
+    const int nsave = h->nsave, Dd = h->D;
+    int next_save = 0;
+    h->save_t0 = 0;
+    if (nsave && h->saveat[0] == t0) {
+        for (int c = 0; c < B; ++c) memcpy(u_out + ((size_t)c * nsave) * Dd, x + (size_t)c * Dd, sizeof(real) * Dd);
+        next_save = 1; h->save_t0 = 1;
+    }
     while (ret == 0 && t < t1 && (!replay || n < replay)) {
         if (n >= cfg->max_attempts) { ret = 1; break; }
         if (!(dt > dtmin) || isnan(dt)) { ret = isnan(dt) ? 3 : 2; break; }
@@ -449,6 +469,19 @@ int orc_sde_forward(void* hh, const real* x, const real* p, int B, real t0, real
             r.dW = rdup(W.dW, N); r.dZ = rdup(W.dZ, N);
             for (size_t i = 0; i < N; ++i) { h->wtot[i] += W.dW[i]; h->ztot[i] += W.dZ[i]; }
             if (cfg->reg_kind) { r.sv_index = nsv; saveval[nsv++] = eest * dt; }
+            r.sv_first = next_save; r.nsv_pts = 0;
+            {
+                const real tnew = t + dt;
+                while (next_save < nsave && h->saveat[next_save] <= tnew) {
+                    const real th = (h->saveat[next_save] == tnew) ? (real)1 : (h->saveat[next_save] - t) / dt;
+                    for (int c = 0; c < B; ++c)
+                        for (int i = 0; i < Dd; ++i) {
+                            const size_t e = (size_t)c * Dd + i;
+                            u_out[((size_t)c * nsave + next_save) * Dd + i] = th == 1 ? r.u[e] : (1 - th) * uprev[e] + th * r.u[e];
+                        }
+                    ++next_save; ++r.nsv_pts;
+                }
+            }
             h->rec[h->n_acc++] = r;
             uprev = r.u;
             t = t + dt;
@@ -475,7 +508,7 @@ int orc_sde_forward(void* hh, const real* x, const real* p, int B, real t0, real
             dt = dtn;
         }
     }
-    memcpy(u_out, uprev, sizeof(real) * N);
+    if (!nsave) memcpy(u_out, uprev, sizeof(real) * N);
     *nfe1 = nf1; *nfe2 = nf2; *nsaveval = nsv; *nattempts = n;
     if (ndraws_out) *ndraws_out = W.next;
     h->n_saveval = nsv;
@@ -501,7 +534,8 @@ int orc_sde_backward(void* hh, const real* ubar, const real* svbar, real* xbar, 
     const real* pf = h->p;
     const real* pg = h->p + h->Pf;
     memset(pbar, 0, sizeof(real) * h->P);
-    real* U = rdup(ubar, N);   /* cotangent of the state after the step being reversed */
+    const int nsave = h->nsave, Dd = h->D;
+    real* U = nsave ? (real*)calloc(N, sizeof(real)) : rdup(ubar, N);   /* cotangent of the state after the step being reversed */
     real *kb[4], *gb[4];
     for (int j = 0; j < 4; ++j) { kb[j] = ralloc(N); gb[j] = ralloc(N); }
     real* upb = ralloc(N);
@@ -510,6 +544,22 @@ int orc_sde_backward(void* hh, const real* ubar, const real* svbar, real* xbar, 
     for (int n = h->n_acc - 1; n >= 0; --n) {
         const sde_rec* r = &h->rec[n];
         const real dt = r->dt, sqdt = rsqrt_(rfabs(dt));
+        /* saveat points of this step: u(ts) = (1 - th) uprev + th u, th a constant of the reverse pass */
+        real* svup = NULL;
+        if (r->nsv_pts) {
+            svup = (real*)calloc(N, sizeof(real));
+            for (int idx = r->sv_first; idx < r->sv_first + r->nsv_pts; ++idx) {
+                const real tnew = r->t + dt;
+                const real th = (h->saveat[idx] == tnew) ? (real)1 : (h->saveat[idx] - r->t) / dt;
+                for (int c = 0; c < B; ++c)
+                    for (int i = 0; i < Dd; ++i) {
+                        const size_t e = (size_t)c * Dd + i;
+                        const real ub = ubar[((size_t)c * nsave + idx) * Dd + i];
+                        U[e] += th * ub;
+                        svup[e] += (1 - th) * ub;
+                    }
+            }
+        }
         double eb = 0;   /* cotangent of EEst: saveval = EEst * dt, dt a constant here */
         if (r->sv_index >= 0 && svbar && h->cfg.reg_kind == 1) eb = (double)svbar[r->sv_index] * (double)dt;
         const double coef = (r->eest > 0) ? eb / ((double)N * (double)r->eest) : 0.0;
@@ -539,8 +589,9 @@ int orc_sde_backward(void* hh, const real* ubar, const real* svbar, real* xbar, 
                 kb[j][i] = dt * (real)T->alpha[j] * unb + dt * h->delta * numb;
                 gb[j][i] = (w * (real)T->beta1[j] + chi1 * (real)T->beta2[j]) * unb + (chi2 * (real)T->beta3[j] + chi3 * (real)T->beta4[j]) * e2b;
             }
-            upb[i] = up;
+            upb[i] = up + (svup ? svup[i] : 0);
         }
+        free(svup);
         for (int s = 3; s >= 0; --s) {
             const real* h0 = s ? r->H0[s] : r->uprev;
             const real* h1 = s ? r->H1[s] : r->uprev;
@@ -562,6 +613,9 @@ int orc_sde_backward(void* hh, const real* ubar, const real* svbar, real* xbar, 
         }
         memcpy(U, upb, sizeof(real) * N);
     }
+    if (nsave && h->save_t0)
+        for (int c = 0; c < B; ++c)
+            for (int i = 0; i < Dd; ++i) U[(size_t)c * Dd + i] += ubar[((size_t)c * nsave) * Dd + i];
     memcpy(xbar, U, sizeof(real) * N);
     free(U); free(upb); free(hb);
     for (int j = 0; j < 4; ++j) { free(kb[j]); free(gb[j]); }

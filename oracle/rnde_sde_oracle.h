@@ -68,6 +68,10 @@ void orc_sde_attempt(void* h, const real* p, const real* uprev, int B, real dt, 
 int orc_sde_forward(void* h, const real* x, const real* p, int B, real t0, real t1, const real* noise, int n_pool,
                     real* u_out, long* nfe1, long* nfe2, real* saveval, int* nsaveval, real* steps_log, int* nattempts,
                     int* ndraws_out);
+/* saveat: following forwards return u at every time of `saveat` (increasing, inside [t0, t1]) as a (D, T, B) column-major array
+ * in u_out (the {R,true} call methods, neural_sde.jl:44-61,:84-113; diffeqsol_to_3dtrackedarray): linear interpolation inside a
+ * step, u0 for a point equal to t0; orc_sde_backward then takes ubar of that shape.  n = 0: back to the end state. */
+void orc_sde_set_saveat(void* h, const real* saveat, int n);
 /* Replay (as orc_set_replay of the ODE oracle): following forwards take attempt n with step size dt[n] (still clamped to
  * t1 - t) and the accept decision acc[n], and stop after n attempts; the noise bookkeeping follows those decisions.
  * All-accepted equal steps = the fixed-step method (convergence tests); also freezes the sequence for finite differences. */

@@ -39,7 +39,7 @@ struct SriTableau {   // lower-triangular 4x4 stage matrices (row = stage) and w
 
 struct SdeMeta {   // one per attempted step
     float t, dt, eest, q;
-    int accepted, rec, pad0, pad1;
+    int accepted, rec, sv_lo, sv_hi;   // saveat indices [sv_lo, sv_hi) this (accepted) step covers
 };
 struct SdeFinal {  // written once, by workgroup 0, when the solve ends
     int n_att, n_acc, status, n_draws;
@@ -62,6 +62,7 @@ struct SdeParams {
     float* u_out;                    // D x B, caller layout (may be NULL)
     const float* replay;             // optional: [n_replay][2] (dt, accepted)
     int n_replay;
+    const float* sv_t; int nsave; float* sv_out;   // saveat ({R,true} methods, neural_sde.jl:44-61,:84-113): times (device), count, output D x T x B
     int D, B, ntiles, nwg, n_pool, n_slots, max_attempts, keep_tape, reg_kind;
     unsigned epoch;
     float t0, t1, reltol, abstol;
@@ -75,7 +76,7 @@ struct SdeOp { int type, a, b, c; float f0, f1; int draw, flags; };   // see sde
 enum { OP_ADD = 1, OP_BRIDGE = 2, OP_FRESH = 3, OP_SUB = 4, OP_RBRIDGE = 5 };
 struct SdeDecision {
     float eest, dt, sqdt, t, q;
-    int accepted, done, status, nops, n_att, n_acc, n_draws, rec;
+    int accepted, done, status, nops, n_att, n_acc, n_draws, rec, sv_lo, sv_hi, pad0, pad1;
     double xsum[2];
 };
 
@@ -366,7 +367,12 @@ __global__ __launch_bounds__(64 * kCW) void rnde_sde_solve_kernel(const SdeParam
         }
         if (tid == 0) { STK->next_slot = 1; STK->next_draw = 1; STK->n2 = 1; S2L[0] = dt; S2s[0] = 0; STK->Wdt = dt; }
     }
-    int n = 0, n_acc = 0;
+    int n = 0, n_acc = 0, next_save = 0;
+    if (Q.nsave > 0 && Q.sv_t[0] == Q.t0) {      // save_start: t0 itself is a save time
+#pragma unroll
+        for (int q = 0; q < NKD; ++q) if (colok && 4 * q + gq < Q.D) Q.sv_out[((size_t)gcol * Q.nsave) * Q.D + 4 * q + gq] = up[q];
+        next_save = 1;
+    }
     __syncthreads();
 
     // ---- the solve ----
@@ -418,6 +424,8 @@ __global__ __launch_bounds__(64 * kCW) void rnde_sde_solve_kernel(const SdeParam
                         if (Q.replay && n + 1 < Q.n_replay) dtn = Q.replay[2 * (n + 1)];
                         const bool last = !(tn < Q.t1) || (Q.replay && n + 1 >= Q.n_replay);
                         d.t = tn; d.rec = n_acc;
+                        d.sv_lo = next_save; d.sv_hi = next_save;
+                        while (d.sv_hi < Q.nsave && Q.sv_t[d.sv_hi] <= tn) ++d.sv_hi;
                         if (!last) {
                             if (Q.t1 - tn < dtn) dtn = Q.t1 - tn;
                             // accept_step!: the pieces of the finished step are forgotten, the next step is assembled from the future stack
@@ -503,7 +511,7 @@ __global__ __launch_bounds__(64 * kCW) void rnde_sde_solve_kernel(const SdeParam
                 d.n_acc = n_acc + (d.accepted ? 1 : 0);
                 d.sqdt = 0.f;
                 *DEC = d;
-                if (wg == 0) { SdeMeta M{t, dt, eest, d.q, d.accepted, d.accepted ? n_acc : -1, 0, 0}; Q.meta[n] = M; }
+                if (wg == 0) { SdeMeta M{t, dt, eest, d.q, d.accepted, d.accepted ? n_acc : -1, d.sv_lo, d.sv_hi}; Q.meta[n] = M; }
             }
         }
         __syncthreads();
@@ -522,6 +530,15 @@ __global__ __launch_bounds__(64 * kCW) void rnde_sde_solve_kernel(const SdeParam
                     R[11 * as + q * 64] = un[q];
                 }
             }
+            for (int idx = d.sv_lo; idx < d.sv_hi; ++idx) {      // saveat: linear interpolant of the SDE solution inside the step
+                const float tsv = Q.sv_t[idx];
+                const bool at_end = (tsv == d.t);
+                const float th = (tsv - t) / dt;
+#pragma unroll
+                for (int q = 0; q < NKD; ++q)
+                    if (colok && 4 * q + gq < Q.D) Q.sv_out[((size_t)gcol * Q.nsave + idx) * Q.D + 4 * q + gq] = at_end ? un[q] : (1.f - th) * up[q] + th * un[q];
+            }
+            next_save = d.sv_hi;
 #pragma unroll
             for (int q = 0; q < NKD; ++q) up[q] = un[q];
             ++n_acc;
@@ -712,6 +729,7 @@ struct SdeBwdParams {
     const float* svb_acc;    // saveval cotangent per ACCEPTED step (device)
     const SdeMeta* acc_meta; // meta of the accepted steps, in order (device)
     int n_acc;
+    const float* sv_t; int nsave; int save_t0;   // saveat: ubar is then D x T x B
     BChainParams Cf, Cg;     // per net: G, slab [4 n_acc][ntiles][RS][64], ev_stride, RS, hrow, zrow, ntiles
 };
 static_assert(sizeof(SdeBwdParams) <= 4096, "kernel argument segment");
@@ -743,12 +761,25 @@ __global__ __launch_bounds__(64 * kCW) void rnde_sde_bwd_kernel(const SdeBwdPara
     const size_t as = (size_t)Q.ntiles * NKD * 64;
     float U[NKD];
 #pragma unroll
-    for (int q = 0; q < NKD; ++q) U[q] = ldc(Bq.ubar, Q.D, gcol, 4 * q + gq, colok);
+    for (int q = 0; q < NKD; ++q) U[q] = Bq.nsave > 0 ? 0.f : ldc(Bq.ubar, Q.D, gcol, 4 * q + gq, colok);
     for (int a = Bq.n_acc - 1; a >= 0; --a) {
         const SdeMeta m = Bq.acc_meta[a];
         const float dt = m.dt, sqdt = sqrtf(fabsf(dt));
         const float* R = Q.tape + ((size_t)a * 12 * Q.ntiles + tile) * NKD * 64 + lane;
         float up[NKD], dW[NKD], dZ[NKD], k[4][NKD], g[4][NKD], kb[4][NKD], gb[4][NKD], upb[NKD], chi2[NKD];
+        float svup[NKD];
+#pragma unroll
+        for (int q = 0; q < NKD; ++q) svup[q] = 0.f;
+        for (int idx = m.sv_lo; idx < m.sv_hi && Bq.nsave > 0; ++idx) {      // saveat points of this step: u(ts) = (1 - th) uprev + th u
+            const float tsv = Bq.sv_t[idx];
+            const bool at_end = (tsv == m.t + dt);
+            const float th = at_end ? 1.f : (tsv - m.t) / dt;
+#pragma unroll
+            for (int q = 0; q < NKD; ++q) {
+                const float ub = (colok && 4 * q + gq < Q.D) ? Bq.ubar[((size_t)gcol * Bq.nsave + idx) * Q.D + 4 * q + gq] : 0.f;
+                U[q] += th * ub; svup[q] += (1.f - th) * ub;
+            }
+        }
         const double eb = (Q.reg_kind == 1) ? (double)Bq.svb_acc[a] * (double)dt : 0.0;   // saveval = EEst * dt, dt constant
         const float coef = m.eest > 0.f ? (float)(eb / (N * (double)m.eest)) : 0.f;
 #pragma unroll
@@ -783,7 +814,7 @@ __global__ __launch_bounds__(64 * kCW) void rnde_sde_bwd_kernel(const SdeBwdPara
                 kb[j][q] = dt * T.alpha[j] * unb + dt * Q.delta * numb;
                 gb[j][q] = (w * T.beta1[j] + chi1 * T.beta2[j]) * unb + (chi2[q] * T.beta3[j] + chi3 * T.beta4[j]) * e2b;
             }
-            upb[q] = upv;
+            upb[q] = upv + svup[q];
         }
 #pragma unroll
         for (int s = 3; s >= 0; --s) {
@@ -821,7 +852,12 @@ __global__ __launch_bounds__(64 * kCW) void rnde_sde_bwd_kernel(const SdeBwdPara
         for (int q = 0; q < NKD; ++q) U[q] = upb[q];
     }
 #pragma unroll
-    for (int q = 0; q < NKD; ++q) if (colok && 4 * q + gq < Q.D) Bq.xbar[(size_t)gcol * Q.D + 4 * q + gq] = U[q];
+    for (int q = 0; q < NKD; ++q)
+        if (colok && 4 * q + gq < Q.D) {
+            float v = U[q];
+            if (Bq.nsave > 0 && Bq.save_t0) v += Bq.ubar[((size_t)gcol * Bq.nsave) * Q.D + 4 * q + gq];
+            Bq.xbar[(size_t)gcol * Q.D + 4 * q + gq] = v;
+        }
 }
 
 // ---- library noise: Philox4x32-10 counter-based generator + Box-Muller, fills a pool in the caller's layout ------------------

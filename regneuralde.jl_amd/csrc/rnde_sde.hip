@@ -33,10 +33,12 @@ struct rnde_nsde {
     float *svb = nullptr, *h_svb = nullptr, *slab_f = nullptr, *slab_g = nullptr, *wslab = nullptr, *wslab_r = nullptr, *ev_t = nullptr;
     size_t slab_f_floats = 0, slab_g_floats = 0, ev_t_n = 0;
     float *part = nullptr, *h_part = nullptr;
+    float* sv_t_dev = nullptr; size_t sv_cap = 0; std::vector<float> saveat;   // saveat times of the last forward ({R,true} methods)
     unsigned epoch = 0;
     size_t lds_fwd = 0, lds_bwd = 0;
     // last forward
     int B = 0, ntiles = 0, nwg = 0, n_att = 0, n_acc = 0, n_draws = 0, n_saveval = 0;
+    float t0 = 0.f;
     bool have_tape = false;
     hipEvent_t tev[4] = {nullptr, nullptr, nullptr, nullptr}; bool tev_f = false, tev_b = false;   // around the solve kernel / the reverse sweep kernel
     std::vector<int> sv_index;   // per accepted step: index into saveval
@@ -195,7 +197,7 @@ extern "C" rnde_status rnde_nsde_create(const rnde_nsde_config* c, rnde_nsde** o
 extern "C" void rnde_nsde_destroy(rnde_nsde* h) {
     if (!h) return;
     void* d[] = {h->frags_f, h->frags_g, h->slots, h->tape, h->noise, h->replay, h->meta, h->acc_meta, h->fin, h->xch, h->abort_word, h->svb,
-                 h->slab_f, h->slab_g, h->wslab, h->wslab_r, h->ev_t, h->part};
+                 h->slab_f, h->slab_g, h->wslab, h->wslab_r, h->ev_t, h->part, h->sv_t_dev};
     for (void* p : d) if (p) (void)hipFree(p);
     void* hd[] = {h->h_meta, h->h_acc_meta, h->h_fin, h->h_svb, h->h_part};
     for (void* p : hd) if (p) (void)hipHostFree(p);
@@ -260,9 +262,24 @@ static hipError_t launch_bwd(rnde_nsde* h, const SdeBwdParams& Bq, hipStream_t s
 
 static rnde_status nsde_forward_impl(rnde_nsde* h, const float* x_dev, const float* p_dev, int32_t B, float t0, float t1, const float* noise_dev,
                                      int32_t n_pool, uint64_t seed, const float* steps_host, int32_t n_steps, float* u_out_dev, int64_t* nfe1_out,
-                                     int64_t* nfe2_out, float* saveval_host, int32_t* n_saveval_out, int32_t keep_tape, void* stream) {
+                                     int64_t* nfe2_out, float* saveval_host, int32_t* n_saveval_out, int32_t keep_tape, void* stream,
+                                     const float* saveat_host = nullptr, int32_t n_saveat = 0, float* sv_out_dev = nullptr) {
     if (!h) return RNDE_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
+    if (n_saveat > 0) {
+        for (int i = 0; i < n_saveat; ++i)
+            if (!(saveat_host[i] >= t0 && saveat_host[i] <= t1) || (i > 0 && !(saveat_host[i] > saveat_host[i - 1]))) {
+                h->err = "saveat must be increasing and inside [t0, t1]"; return RNDE_ERR_BAD_ARG;
+            }
+        if ((size_t)n_saveat > h->sv_cap) {
+            if (h->sv_t_dev) (void)hipFree(h->sv_t_dev);
+            h->sv_t_dev = nullptr; h->sv_cap = 0;
+            SCHK(h, hipMalloc((void**)&h->sv_t_dev, (size_t)n_saveat * 4));
+            h->sv_cap = n_saveat;
+        }
+        h->saveat.assign(saveat_host, saveat_host + n_saveat);
+        SCHK(h, hipMemcpyAsync(h->sv_t_dev, h->saveat.data(), (size_t)n_saveat * 4, hipMemcpyHostToDevice, s));
+    } else h->saveat.clear();
     if (B < 1 || B > h->cfg.max_batch || !(t1 > t0) || !x_dev || !p_dev) { h->err = "bad B, tspan or pointers"; return RNDE_ERR_BAD_ARG; }
     if (noise_dev && n_pool < 1) { h->err = "noise pool: n_pool >= 1"; return RNDE_ERR_BAD_ARG; }
     if (n_steps > h->cfg.max_attempts) { h->err = "replay: more steps than max_attempts"; return RNDE_ERR_BAD_ARG; }
@@ -301,6 +318,7 @@ static rnde_status nsde_forward_impl(rnde_nsde* h, const float* x_dev, const flo
     }
     SdeParams Q = sde_params(h, x_dev, noise_dev, n_pool, B, t0, t1, keep_tape ? 1 : 0);
     Q.u_out = u_out_dev;
+    Q.sv_t = n_saveat > 0 ? h->sv_t_dev : nullptr; Q.nsave = n_saveat; Q.sv_out = sv_out_dev;
     if (n_steps > 0) {
         SCHK(h, hipMemcpyAsync(h->replay, steps_host, (size_t)n_steps * 8, hipMemcpyHostToDevice, s));
         Q.replay = h->replay; Q.n_replay = n_steps;
@@ -316,7 +334,7 @@ static rnde_status nsde_forward_impl(rnde_nsde* h, const float* x_dev, const flo
     SCHK(h, hipMemcpyAsync(h->h_meta, h->meta, (size_t)h->cfg.max_attempts * sizeof(SdeMeta), hipMemcpyDeviceToHost, s));
     SCHK(h, hipStreamSynchronize(s));
     const SdeFinal F = *h->h_fin;
-    h->B = B; h->ntiles = ntiles; h->nwg = Q.nwg; h->n_att = F.n_att; h->n_acc = F.n_acc; h->n_draws = F.n_draws;
+    h->B = B; h->ntiles = ntiles; h->nwg = Q.nwg; h->n_att = F.n_att; h->n_acc = F.n_acc; h->n_draws = F.n_draws; h->t0 = t0;
     if (nfe1_out) *nfe1_out = 2 + 4 * (int64_t)F.n_att;   // the closures' counters (neural_sde.jl:46,:50): 2 probes of the initial-step rule + 4 per attempt
     if (nfe2_out) *nfe2_out = 2 + 4 * (int64_t)F.n_att;
     int nsv = 0;
@@ -347,6 +365,14 @@ extern "C" rnde_status rnde_nsde_forward(rnde_nsde* h, const float* x_dev, const
                                          int32_t n_pool, uint64_t seed, float* u_out_dev, int64_t* nfe1_out, int64_t* nfe2_out, float* saveval_host,
                                          int32_t* n_saveval_out, int32_t keep_tape, void* stream) {
     return nsde_forward_impl(h, x_dev, p_dev, B, t0, t1, noise_dev, n_pool, seed, nullptr, 0, u_out_dev, nfe1_out, nfe2_out, saveval_host, n_saveval_out, keep_tape, stream);
+}
+extern "C" rnde_status rnde_nsde_forward_saveat(rnde_nsde* h, const float* x_dev, const float* p_dev, int32_t B, float t0, float t1, const float* noise_dev,
+                                                int32_t n_pool, uint64_t seed, const float* saveat_host, int32_t n_saveat, float* u_saved_dev,
+                                                int64_t* nfe1_out, int64_t* nfe2_out, float* saveval_host, int32_t* n_saveval_out, int32_t keep_tape,
+                                                void* stream) {
+    if (!h || !saveat_host || n_saveat < 1 || !u_saved_dev) return RNDE_ERR_BAD_ARG;
+    return nsde_forward_impl(h, x_dev, p_dev, B, t0, t1, noise_dev, n_pool, seed, nullptr, 0, nullptr, nfe1_out, nfe2_out, saveval_host, n_saveval_out, keep_tape,
+                             stream, saveat_host, n_saveat, u_saved_dev);
 }
 extern "C" rnde_status rnde_nsde_forward_replay(rnde_nsde* h, const float* x_dev, const float* p_dev, int32_t B, float t0, float t1, const float* noise_dev,
                                                 int32_t n_pool, const float* steps_host, int32_t n_steps, float* u_out_dev, int64_t* nfe1_out,
@@ -408,6 +434,7 @@ extern "C" rnde_status rnde_nsde_backward(rnde_nsde* h, const float* u_bar_dev, 
     SdeBwdParams Bq{};
     Bq.F = sde_params(h, nullptr, nullptr, 0, h->B, 0.f, 1.f, 1);
     Bq.ubar = u_bar_dev; Bq.xbar = x_bar_dev; Bq.svb_acc = h->svb; Bq.acc_meta = h->acc_meta; Bq.n_acc = n_acc;
+    Bq.nsave = (int)h->saveat.size(); Bq.sv_t = Bq.nsave ? h->sv_t_dev : nullptr; Bq.save_t0 = (Bq.nsave && h->saveat[0] == h->t0) ? 1 : 0;
     auto pad4 = [](int k) { return 4 * ((k + 3) / 4); };
     auto dump = [&](const ChainGeo& G, BChainParams& C) {
         C.G = G; C.ntiles = ntiles;
@@ -438,7 +465,8 @@ extern "C" rnde_status rnde_nsde_backward(rnde_nsde* h, const float* u_bar_dev, 
     }
     if (!h->wslab) { SCHK(h, hipMalloc((void**)&h->wslab, (size_t)96 * h->P * 4)); SCHK(h, hipMalloc((void**)&h->wslab_r, (size_t)16 * h->P * 4)); }
     Bq.Cf.slab = h->slab_f; Bq.Cg.slab = h->slab_g;
-    if (n_acc == 0) {   // nothing was integrated: identity
+    if (n_acc == 0) {   // nothing was integrated: identity (never with saveat: t1 > t0 guarantees a step)
+        if (Bq.nsave) { h->err = "reverse pass of a saveat solve without accepted steps"; return RNDE_ERR_NO_TAPE; }
         SCHK(h, hipMemcpyAsync(x_bar_dev, u_bar_dev, (size_t)h->D * h->B * 4, hipMemcpyDeviceToDevice, s));
         SCHK(h, hipMemsetAsync(p_bar_dev, 0, (size_t)h->P * 4, s));
         SCHK(h, hipStreamSynchronize(s));

@@ -6,8 +6,11 @@ librnde.so (rnde_nsde_*: the whole adaptive SOSRI solve is one kernel launch).
                              save_everystep=False, reltol=1.4e-1, abstol=1.4e-1, save_start=False)     # experiments/mnist_nsde.jl:72-84
     u, nfe1, nfe2, sv = nsde(x, p)          # x: (B, D) cuda tensor == Julia D x B
 
+With `saveat=` the {R,true} methods run (neural_sde.jl:44-61,:84-113; experiments/sde_toy_problem.jl:50-60): `u` is then the
+(B, T, D) tensor whose memory is exactly the Julia D x T x B array of diffeqsol_to_3dtrackedarray (src/utils.jl:17-19).
+
 Differences inherent to the host language / the device: `func` is the reference's EEst*dt callback (neural_sde.jl:87) or none;
-the {R,true} methods (save_everystep / saveat, :44-61,:84-113; used only by experiments/sde_toy_problem.jl) are not built;
+`save_everystep=True` (a result whose length is data dependent) is refused;
 the noise comes from the library's Philox stream (seed = nsde.seed, advanced every call) unless `noise=` passes a pool of
 standard normals of shape (n_pool, 2, B, D) -- a Julia caller would fill that from its own RNG.
 """
@@ -39,17 +42,24 @@ class _NsdeHandle:
 
 class _SdeSolve(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, p, layer, keep_tape, noise, seed):
+    def forward(ctx, x, p, layer, keep_tape, noise, seed, saveat):
         h = layer._acquire(x)
         L = _lib.lib()
         B, D = x.shape
         n1, n2, nsv = C.c_int64(0), C.c_int64(0), C.c_int32(0)
         sv_host = (C.c_float * (layer.max_attempts + 1))()
         stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-        u = torch.empty_like(x)
-        st = L.rnde_nsde_forward(h.ptr, x.data_ptr(), p.data_ptr(), B, layer.tspan[0], layer.tspan[1],
-                                 noise.data_ptr() if noise is not None else None, 0 if noise is None else noise.shape[0], seed,
-                                 u.data_ptr(), C.byref(n1), C.byref(n2), sv_host, C.byref(nsv), 1 if keep_tape else 0, stream)
+        nptr, npool = (noise.data_ptr() if noise is not None else None), (0 if noise is None else noise.shape[0])
+        if saveat is None:
+            u = torch.empty_like(x)
+            st = L.rnde_nsde_forward(h.ptr, x.data_ptr(), p.data_ptr(), B, layer.tspan[0], layer.tspan[1], nptr, npool, seed,
+                                     u.data_ptr(), C.byref(n1), C.byref(n2), sv_host, C.byref(nsv), 1 if keep_tape else 0, stream)
+        else:
+            T = len(saveat)
+            u = torch.empty((B, T, D), dtype=torch.float32, device=x.device)
+            sa = (C.c_float * T)(*saveat)
+            st = L.rnde_nsde_forward_saveat(h.ptr, x.data_ptr(), p.data_ptr(), B, layer.tspan[0], layer.tspan[1], nptr, npool, seed, sa, T,
+                                            u.data_ptr(), C.byref(n1), C.byref(n2), sv_host, C.byref(nsv), 1 if keep_tape else 0, stream)
         _lib.check_nsde(h.ptr, st)
         layer.last_nfe = (int(n1.value), int(n2.value))
         saveval = torch.tensor(list(sv_host[:nsv.value]), dtype=torch.float32, device=x.device)
@@ -63,7 +73,7 @@ class _SdeSolve(torch.autograd.Function):
     def backward(ctx, u_bar, sv_bar):
         layer, h = ctx.layer, ctx.h
         u_bar = u_bar.contiguous().to(torch.float32)
-        x_bar = torch.empty_like(u_bar)
+        x_bar = torch.empty((u_bar.shape[0], u_bar.shape[-1]), dtype=torch.float32, device=u_bar.device)
         p_bar = torch.empty(layer.P, dtype=torch.float32, device=u_bar.device)
         svb = None
         if ctx.nsv and sv_bar is not None:
@@ -72,7 +82,7 @@ class _SdeSolve(torch.autograd.Function):
         st = _lib.lib().rnde_nsde_backward(h.ptr, u_bar.data_ptr(), svb, x_bar.data_ptr(), p_bar.data_ptr(), stream)
         ctx.token.finish()
         _lib.check_nsde(h.ptr, st)
-        return x_bar, p_bar, None, None, None, None
+        return x_bar, p_bar, None, None, None, None, None
 
 
 class TrackedNeuralDSDE:
@@ -84,9 +94,10 @@ class TrackedNeuralDSDE:
             raise ValueError("solver: SOSRI (experiments/mnist_nsde.jl:49,:63), SOSRI2 or SRIW1")
         if isinstance(model2, Dense):
             model2 = Chain(model2)
-        if kwargs.get("save_everystep", False) or "saveat" in kwargs:
-            raise NotImplementedError("the {R,true} methods (save_everystep / saveat, neural_sde.jl:44-61,:84-113) are not built: "
-                                      "the MNIST experiment uses save_everystep=false (mnist_nsde.jl:78)")
+        if kwargs.get("save_everystep", False):
+            raise NotImplementedError("save_everystep=True: the result length is data dependent; pass saveat= instead "
+                                      "(experiments/sde_toy_problem.jl:57 does)")
+        self.return_multiple = "saveat" in kwargs          # neural_sde.jl:14
         if model1.time_dep or model2.time_dep:
             raise ValueError("drift and diffusion are time independent (neural_sde.jl:45-52 call re(p)(u))")
         self.model1, self.model2 = model1, model2
@@ -154,7 +165,11 @@ class TrackedNeuralDSDE:
             noise = noise.contiguous()
         keep = torch.is_grad_enabled() and (x.requires_grad or p.requires_grad)
         self.seed += 1
-        u, saveval = _SdeSolve.apply(x.contiguous(), p.contiguous(), self, keep, noise, self.seed)
+        times = None
+        if self.return_multiple:
+            from .node import TrackedNeuralODE
+            times = TrackedNeuralODE._saveat_times(self.kwargs["saveat"], self.tspan)
+        u, saveval = _SdeSolve.apply(x.contiguous(), p.contiguous(), self, keep, noise, self.seed, times)
         nfe1, nfe2 = self.last_nfe                         # n.nfes, reset after the solve (neural_sde.jl:78-79,:142-143)
         return u, nfe1, nfe2, (SavedValues(saveval) if self.regularize else None)
 

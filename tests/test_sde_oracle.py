@@ -151,3 +151,45 @@ def test_reverse_pass_matches_finite_differences(name):
         xp[idx] += eps; xm[idx] -= eps
         fd = (loss(xp, p) - loss(xm, p)) / (2 * eps)
         assert abs(fd - xbar[idx]) <= 1e-6 * max(1.0, abs(fd)), (idx, fd, xbar[idx])
+
+
+def test_saveat_linear_interpolation_and_its_reverse():
+    """The {R,true} call methods: states at the save times (linear interpolant between accepted steps, u0 at t0, the end state
+    at t1), as a (B, T, D) array, and the reverse pass for a cotangent of that shape against finite differences."""
+    drift = make_arch([3, 5, 3], ["tanh", "identity"], False)
+    diff = make_arch([3, 3], ["identity"], False)
+    rng = np.random.default_rng(17)
+    B = 3
+    p = nsde_params(drift, diff, rng, np.float64, 2.0, 0.6)
+    x = rng.standard_normal((B, 3))
+    noise = rng.standard_normal((200, 2, B, 3))
+    o = SdeOracle(drift, diff, np.float64, 0.1, 0.1, reg_kind=1, max_attempts=199)
+    end = o.forward(x, p, noise)
+    sa = np.array([0.0, 0.13, 0.5, 0.77, 1.0])
+    o.set_saveat(sa)
+    r = o.forward(x, p, noise)
+    assert r["u"].shape == (B, 5, 3) and r["nattempts"] == end["nattempts"]
+    assert np.array_equal(r["u"][:, 0], x) and np.array_equal(r["u"][:, -1], end["u"])
+    # an interior point lies on the segment between the states of the step that covers it
+    acc = r["steps"][r["steps"][:, 3] == 1]
+    o.set_replay(r["steps"][:, 1], r["steps"][:, 3].astype(np.int32))          # freeze the sequence for finite differences
+    ubar = rng.standard_normal((B, 5, 3))
+    svbar = rng.standard_normal(len(r["saveval"]))
+
+    def loss(xx, pp):
+        q = o.forward(xx, pp, noise)
+        return float((q["u"] * ubar).sum() + (q["saveval"] * svbar).sum())
+
+    o.forward(x, p, noise)
+    xbar, pbar = o.backward(ubar, svbar)
+    eps = 1e-6
+    for idx in rng.choice(len(p), 10, replace=False):
+        pp, pm = p.copy(), p.copy()
+        pp[idx] += eps; pm[idx] -= eps
+        fd = (loss(x, pp) - loss(x, pm)) / (2 * eps)
+        assert abs(fd - pbar[idx]) <= 1e-6 * max(1.0, abs(fd)), (idx, fd, pbar[idx])
+    for idx in [(0, 0), (2, 1)]:
+        xp, xm = x.copy(), x.copy()
+        xp[idx] += eps; xm[idx] -= eps
+        fd = (loss(xp, p) - loss(xm, p)) / (2 * eps)
+        assert abs(fd - xbar[idx]) <= 1e-6 * max(1.0, abs(fd)), (idx, fd, xbar[idx])

@@ -208,16 +208,21 @@ class NsdeNode:
         self.L.rnde_nsde_steps(self.h, steps, self.cfg.max_attempts, C.byref(natt), C.byref(ndr))
         return np.array(steps[:4 * natt.value], dtype=np.float32).reshape(-1, 4), natt.value, ndr.value
 
-    def forward(self, x, p, noise=None, seed=0, t0=0.0, t1=1.0, keep_tape=False, replay=None, check=True):
-        """noise: (n_pool, 2, B, D) standard normals or None (library stream from `seed`); replay: (n, 2) array of (dt, accepted)."""
+    def forward(self, x, p, noise=None, seed=0, t0=0.0, t1=1.0, keep_tape=False, replay=None, check=True, saveat=None):
+        """noise: (n_pool, 2, B, D) standard normals or None (library stream from `seed`); replay: (n, 2) array of (dt, accepted);
+        saveat: times -> u is (B, T, D)."""
         B = x.shape[0]
         xd, pd = self.dev(x), self.dev(p)
         nd = None if noise is None else self.dev(noise)
-        u = torch.empty_like(xd)
+        u = torch.empty_like(xd) if saveat is None else torch.empty((B, len(saveat), self.D), dtype=torch.float32, device="cuda")
         n1, n2, nsv = C.c_int64(0), C.c_int64(0), C.c_int32(0)
         sv = (C.c_float * (self.cfg.max_attempts + 1))()
         npool = 0 if noise is None else noise.shape[0]
-        if replay is None:
+        if saveat is not None:
+            sa = (C.c_float * len(saveat))(*[float(v) for v in saveat])
+            st = self.L.rnde_nsde_forward_saveat(self.h, xd.data_ptr(), pd.data_ptr(), B, t0, t1, nd.data_ptr() if nd is not None else None, npool,
+                                                 seed, sa, len(saveat), u.data_ptr(), C.byref(n1), C.byref(n2), sv, C.byref(nsv), int(keep_tape), None)
+        elif replay is None:
             st = self.L.rnde_nsde_forward(self.h, xd.data_ptr(), pd.data_ptr(), B, t0, t1, nd.data_ptr() if nd is not None else None, npool,
                                           seed, u.data_ptr(), C.byref(n1), C.byref(n2), sv, C.byref(nsv), int(keep_tape), None)
         else:
@@ -233,7 +238,7 @@ class NsdeNode:
 
     def backward(self, ubar, svbar=None):
         ub = self.dev(ubar)
-        xb = torch.empty_like(ub)
+        xb = torch.empty((ub.shape[0], self.D), dtype=torch.float32, device="cuda")   # ubar is (B, T, D) after a saveat forward
         pb = torch.empty(self.P, dtype=torch.float32, device="cuda")
         svb = None if svbar is None else (C.c_float * len(svbar))(*[float(v) for v in svbar])
         _lib.check_nsde(self.h, self.L.rnde_nsde_backward(self.h, ub.data_ptr(), svb, xb.data_ptr(), pb.data_ptr(), None))

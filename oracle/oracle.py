@@ -58,7 +58,7 @@ def arch_latent():
 
 class Oracle:
     def __init__(self, arch, dtype=np.float32, reltol=1.4e-8, abstol=1.4e-8, reg_kind=1, cb_save_start=1,
-                 track_ctrl=1, track_initdt=1, max_attempts=4096):
+                 track_ctrl=1, track_initdt=1, max_attempts=4096, solver="Tsit5"):
         libs = build()
         self.dtype = np.dtype(dtype)
         f64 = self.dtype == np.float64
@@ -68,10 +68,11 @@ class Oracle:
         class Config(C.Structure):
             _fields_ = [("arch", Arch), ("reltol", self.real), ("abstol", self.real), ("reg_kind", C.c_int),
                         ("cb_save_start", C.c_int), ("track_ctrl", C.c_int), ("track_initdt", C.c_int),
-                        ("max_attempts", C.c_int)]
+                        ("max_attempts", C.c_int), ("solver", C.c_int)]
 
         self.Config = Config
-        self.cfg = Config(arch, reltol, abstol, reg_kind, cb_save_start, track_ctrl, track_initdt, max_attempts)
+        self.solver = {"Tsit5": 0, "DP5": 1}[solver]
+        self.cfg = Config(arch, reltol, abstol, reg_kind, cb_save_start, track_ctrl, track_initdt, max_attempts, self.solver)
         self.arch = arch
         L = self.lib
         L.orc_param_count.restype = C.c_int
@@ -170,12 +171,12 @@ class Oracle:
 
     def tableau(self):
         a = np.zeros((7, 7)); c = np.zeros(7); bt = np.zeros(7)
-        self.lib.orc_tableau(self._p(a), self._p(c), self._p(bt))
+        self.lib.orc_tableau_of(C.c_int(self.solver), self._p(a), self._p(c), self._p(bt))
         return a, c, bt
 
     def dense_weights(self, theta):
         b = np.zeros(7)
-        self.lib.orc_dense_weights(C.c_double(theta), self._p(b))
+        self.lib.orc_dense_weights_of(C.c_int(self.solver), C.c_double(theta), self._p(b))
         return b
 
 

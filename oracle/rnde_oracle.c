@@ -52,6 +52,32 @@ static const double TS_A[7][7] = {
 static const double TS_BT[7] = {-0.00178001105222577714, -0.0008164344596567469, 0.007880878010261995,
                                 -0.1447110071732629,     0.5823571654525552,     -0.45808210592918697,
                                 0.015151515151515152};
+/* ---------------- Dormand-Prince 5(4) (DP5; Dormand & Prince 1980; dense output: Shampine 1986 as used by scipy's RK45) ----------------
+ * A second 7-stage FSAL pair of order 5 behind the same step / controller / reverse code: the tableau is DATA (cfg->solver), which is
+ * what lets tests/test_oracle.py pin the generic explicit-Runge-Kutta path against scipy.integrate's RK45 step for step. */
+static const double DP_C[7] = {0.0, 0.2, 0.3, 0.8, 8.0 / 9.0, 1.0, 1.0};
+static const double DP_A[7][7] = {
+    {0},
+    {1.0 / 5.0},
+    {3.0 / 40.0, 9.0 / 40.0},
+    {44.0 / 45.0, -56.0 / 15.0, 32.0 / 9.0},
+    {19372.0 / 6561.0, -25360.0 / 2187.0, 64448.0 / 6561.0, -212.0 / 729.0},
+    {9017.0 / 3168.0, -355.0 / 33.0, 46732.0 / 5247.0, 49.0 / 176.0, -5103.0 / 18656.0},
+    {35.0 / 384.0, 0.0, 500.0 / 1113.0, 125.0 / 192.0, -2187.0 / 6784.0, 11.0 / 84.0, 0.0}};
+static const double DP_BT[7] = {-71.0 / 57600.0, 0.0, 71.0 / 16695.0, -71.0 / 1920.0, 17253.0 / 339200.0, -22.0 / 525.0, 1.0 / 40.0};
+/* dense output u(t + theta dt) = uprev + dt sum_i k_i sum_j P[i][j] theta^(j+1) */
+static const double DP_P[7][4] = {
+    {1.0, -8048581381.0 / 2820520608.0, 8663915743.0 / 2820520608.0, -12715105075.0 / 11282082432.0},
+    {0.0, 0.0, 0.0, 0.0},
+    {0.0, 131558114200.0 / 32700410799.0, -68118460800.0 / 10900136933.0, 87487479700.0 / 32700410799.0},
+    {0.0, -1754552775.0 / 470086768.0, 14199869525.0 / 1410260304.0, -10690763975.0 / 1880347072.0},
+    {0.0, 127303824393.0 / 49829197408.0, -318862633887.0 / 49829197408.0, 701980252875.0 / 199316789632.0},
+    {0.0, -282668133.0 / 205662961.0, 2019193451.0 / 616988883.0, -1453857185.0 / 822651844.0},
+    {0.0, 40617522.0 / 29380423.0, -110615467.0 / 29380423.0, 69997945.0 / 29380423.0}};
+static const double (*tabA(int solver))[7] { return solver == 1 ? DP_A : TS_A; }
+static const double* tabC(int solver) { return solver == 1 ? DP_C : TS_C; }
+static const double* tabBT(int solver) { return solver == 1 ? DP_BT : TS_BT; }
+
 /* controller constants, order 5 */
 #define BETA1 ((real)(7.0 / 50.0))
 #define BETA2 ((real)(2.0 / 25.0))
@@ -62,13 +88,14 @@ static const double TS_BT[7] = {-0.00178001105222577714, -0.0008164344596567469,
 /* alg_stability_size(Tsit5()) recalled as 3.5068 (reference mnist_node.jl:73) */
 #define STAB_SIZE ((real)3.5068)
 
-void orc_tableau(double* a, double* c, double* bt) {
+void orc_tableau_of(int solver, double* a, double* c, double* bt) {
     for (int s = 0; s < 7; ++s) {
-        c[s] = TS_C[s];
-        bt[s] = TS_BT[s];
-        for (int j = 0; j < 7; ++j) a[s * 7 + j] = TS_A[s][j];
+        c[s] = tabC(solver)[s];
+        bt[s] = tabBT(solver)[s];
+        for (int j = 0; j < 7; ++j) a[s * 7 + j] = tabA(solver)[s][j];
     }
 }
+void orc_tableau(double* a, double* c, double* bt) { orc_tableau_of(0, a, c, bt); }
 /* dense output weights b_i(theta), SURVEY.md A.3 */
 void orc_dense_weights(double th, double* b) {
     double t2 = th * th;
@@ -82,10 +109,18 @@ void orc_dense_weights(double th, double* b) {
 }
 /* d b_i / d theta by central difference of the polynomial in double (exact to ~1e-10; used only for the
  * theta cotangent of saveat points, a second-order effect) */
-static void dense_weights_deriv(double th, double* db) {
+void orc_dense_weights_of(int solver, double th, double* b) {
+    if (solver != 1) { orc_dense_weights(th, b); return; }
+    for (int i = 0; i < 7; ++i) {
+        double acc = 0, tp = th;
+        for (int j = 0; j < 4; ++j) { acc += DP_P[i][j] * tp; tp *= th; }
+        b[i] = acc;
+    }
+}
+static void dense_weights_deriv(int solver, double th, double* db) {
     double e = 1e-6, bp[7], bm[7];
-    orc_dense_weights(th + e, bp);
-    orc_dense_weights(th - e, bm);
+    orc_dense_weights_of(solver, th + e, bp);
+    orc_dense_weights_of(solver, th - e, bm);
     for (int i = 0; i < 7; ++i) db[i] = (bp[i] - bm[i]) / (2 * e);
 }
 
@@ -375,7 +410,7 @@ static void attempt_stages(const orc_config* cfg, const real* p, const real* upr
     real* g6 = ralloc(N);
     for (int s = 1; s < 7; ++s) { /* stage index s (0-based): computes k[s] = f(g_{s+1}) */
         real as[6];
-        for (int j = 0; j < s; ++j) as[j] = (real)TS_A[s][j];
+        for (int j = 0; j < s; ++j) as[j] = (real)tabA(cfg->solver)[s][j];
 #pragma omp parallel for schedule(static)
         for (size_t i = 0; i < N; ++i) {
             real acc = 0;
@@ -384,11 +419,11 @@ static void attempt_stages(const orc_config* cfg, const real* p, const real* upr
         }
         if (s == 5) memcpy(g6, g, sizeof(real) * N);
         if (s == 6) memcpy(unew, g, sizeof(real) * N);
-        orc_f_forward(a, p, g, B, t + (real)TS_C[s] * dt, k[s], acts ? acts[s] : NULL);
+        orc_f_forward(a, p, g, B, t + (real)tabC(cfg->solver)[s] * dt, k[s], acts ? acts[s] : NULL);
     }
     /* error estimate */
     real bt[7];
-    for (int j = 0; j < 7; ++j) bt[j] = (real)TS_BT[j];
+    for (int j = 0; j < 7; ++j) bt[j] = (real)tabBT(cfg->solver)[j];
     double ssum = 0;
 #pragma omp parallel for schedule(static) reduction(+ : ssum)
     for (size_t i = 0; i < N; ++i) {
@@ -573,7 +608,7 @@ int orc_forward(void* hh, const real* x, const real* p, int B, real t0, real t1,
                     for (int c = 0; c < B; ++c) memcpy(u_out + ((size_t)c * nsave + next_save) * D, r->unew + (size_t)c * D, sizeof(real) * D);
                 } else {
                     double bth[7];
-                    orc_dense_weights((double)((ts - t) / dt), bth);
+                    orc_dense_weights_of(cfg->solver, (double)((ts - t) / dt), bth);
                     for (int c = 0; c < B; ++c)
                         for (int i = 0; i < D; ++i) {
                             size_t e = (size_t)c * D + i;
@@ -666,8 +701,8 @@ int orc_backward(void* hh, const real* ubar, const real* svbar, real* xbar, real
                         for (int i = 0; i < D; ++i) unb[(size_t)c * D + i] += ubar[((size_t)c * nsave + sidx) * D + i];
                 } else {
                     double th = (double)((ts - t) / dt), bth[7], dbth[7];
-                    orc_dense_weights(th, bth);
-                    dense_weights_deriv(th, dbth);
+                    orc_dense_weights_of(cfg->solver, th, bth);
+                    dense_weights_deriv(cfg->solver, th, dbth);
                     double d_dt = 0, d_th = 0;
                     for (int c = 0; c < B; ++c)
                         for (int i = 0; i < D; ++i) {
@@ -707,7 +742,7 @@ int orc_backward(void* hh, const real* ubar, const real* svbar, real* xbar, real
                 double n1 = 0, n2 = 0;
                 for (size_t i = 0; i < N; ++i) {
                     real acc = 0;
-                    for (int j = 0; j < 5; ++j) acc += (real)TS_A[5][j] * r->k[j][i];
+                    for (int j = 0; j < 5; ++j) acc += (real)tabA(cfg->solver)[5][j] * r->k[j][i];
                     gtmp[i] = r->uprev[i] + dt * acc;
                     double d1 = (double)r->k[6][i] - (double)r->k[5][i], d2 = (double)r->unew[i] - (double)gtmp[i];
                     n1 += d1 * d1; n2 += d2 * d2;
@@ -724,7 +759,7 @@ int orc_backward(void* hh, const real* ubar, const real* svbar, real* xbar, real
                         const real g6b = -(real)(c2 * (double)d2);
                         upb[i] += g6b;
                         real acc = 0;
-                        for (int j = 0; j < 5; ++j) { kb[j][i] += dt * (real)TS_A[5][j] * g6b; acc += (real)TS_A[5][j] * r->k[j][i]; }
+                        for (int j = 0; j < 5; ++j) { kb[j][i] += dt * (real)tabA(cfg->solver)[5][j] * g6b; acc += (real)tabA(cfg->solver)[5][j] * r->k[j][i]; }
                         d_dt += (double)g6b * (double)acc;
                     }
                     dtb += d_dt;
@@ -758,7 +793,7 @@ int orc_backward(void* hh, const real* ubar, const real* svbar, real* xbar, real
         /* EEst = sqrt(sum r^2 / N); r = utilde/sk */
         {
             real bt[7];
-            for (int j = 0; j < 7; ++j) bt[j] = (real)TS_BT[j];
+            for (int j = 0; j < 7; ++j) bt[j] = (real)tabBT(cfg->solver)[j];
             double coef = (r->eest > 0) ? eb / ((double)N * (double)r->eest) : 0.0;
             double d_dt = 0;
 #pragma omp parallel for schedule(static) reduction(+ : d_dt)
@@ -785,7 +820,7 @@ int orc_backward(void* hh, const real* ubar, const real* svbar, real* xbar, real
         for (int s = 6; s >= 1; --s) {
             /* stage input g_s+1 */
             real as[6];
-            for (int j = 0; j < s; ++j) as[j] = (real)TS_A[s][j];
+            for (int j = 0; j < s; ++j) as[j] = (real)tabA(cfg->solver)[s][j];
 #pragma omp parallel for schedule(static)
             for (size_t i = 0; i < N; ++i) {
                 real acc = 0;
@@ -793,10 +828,10 @@ int orc_backward(void* hh, const real* ubar, const real* svbar, real* xbar, real
                 gtmp[i] = r->uprev[i] + dt * acc;
             }
             const real* gin = (s == 6) ? r->unew : gtmp;
-            real tst = t + (real)TS_C[s] * dt;
+            real tst = t + (real)tabC(cfg->solver)[s] * dt;
             real taub = orc_f_backward(a, p, gin, r->acts[s], B, tst, kb[s], gb, pbar);
             tb_in += (double)taub;
-            dtb += TS_C[s] * (double)taub;
+            dtb += tabC(cfg->solver)[s] * (double)taub;
             if (s == 6) {
                 /* k7 = f(unew): gbar adds to unew-bar, then unew = uprev + dt sum a7j kj */
 #pragma omp parallel for schedule(static)

@@ -61,6 +61,8 @@ typedef struct {
     int track_ctrl;    /* 1: differentiate dt_next = dt/q through the controller on accepted steps */
     int track_initdt;  /* 1: differentiate the Hairer initial-step computation */
     int max_attempts;
+    int solver;        /* 0 Tsit5 (every reference call site), 1 DP5: Dormand-Prince 5(4), the second 7-stage FSAL pair of the
+                          tableau-as-data path (validated against scipy's RK45) */
 } orc_config;
 
 int   orc_param_count(const orc_arch* a);
@@ -104,6 +106,8 @@ int orc_backward(void* h, const real* ubar, const real* svbar, real* xbar, real*
 /* Tableau access for unit tests. a: 7x7 row-major (a[s][j]), c[7], btilde[7]. */
 void orc_tableau(double* a, double* c, double* btilde);
 void orc_dense_weights(double theta, double* b7);
+void orc_tableau_of(int solver, double* a, double* c, double* btilde);
+void orc_dense_weights_of(int solver, double theta, double* b7);
 
 #ifdef __cplusplus
 }

@@ -46,6 +46,7 @@ struct rnde_node {
     ChainGeo cg{}; float* cfrags = nullptr; int NKD = 0, chain_alt = 0;
     size_t chain_lds_f = 0, chain_lds_b = 0;
     // multi-wave kernels of the chain engine (rnde_chainmw.h): 4 waves per 16 columns, activations taped in the slab by the forward
+    int rk_tab = 0; RkTab rk{};   // explicit RK pair as data (DP5, or Tsit5 through the same path when RNDE_CHAIN_TAB=1)
     int mw = 0; MwGeo mg{}; float* mw_tab = nullptr; float* mw_slab = nullptr; long long mw_slab_evals = 0; size_t mw_lds_f = 0, mw_lds_b = 0;
     float* cslab = nullptr; size_t cslab_floats = 0; float* ev_t = nullptr; float* h_ev_t = nullptr;   // chain reverse: (H, Z) dump, evaluation times
     int sMT = 0, sWT = 0, sR = 0, sHT = 0, sK2b = 0, sKHb = 0;
@@ -227,6 +228,45 @@ static rnde_status chain_create(const rnde_node_config* c, rnde_node** out) {
         h->mw = (fits && c->col_tile != 64 && !(e && e[0] == '0')) ? 1 : 0;
         if (c->col_tile == 65 && !fits) { g_create_err = "col_tile 65: the multi-wave kernels need the padded weight fragments in 160 KB of LDS"; delete h; return RNDE_ERR_BAD_ARG; }
         if (h->mw) h->nwg_max = ntiles;
+        if (c->solver == RNDE_SOLVER_DP5 && !h->mw) { g_create_err = "DP5 needs the multi-wave kernels (weights must fit LDS)"; delete h; return RNDE_ERR_BAD_ARG; }
+        h->rk_tab = (h->mw && (c->solver == RNDE_SOLVER_DP5 || getenv("RNDE_CHAIN_TAB") != nullptr)) ? 1 : 0;
+        if (h->rk_tab) {
+            double A[7][7] = {{0}}, Cn[7], BT[7], Dn[7][4];
+            if (c->solver == RNDE_SOLVER_DP5) {   // Dormand & Prince 1980; dense output: Shampine 1986 (the matrix scipy's RK45 uses)
+                const double a[7][7] = {{0}, {1.0 / 5}, {3.0 / 40, 9.0 / 40}, {44.0 / 45, -56.0 / 15, 32.0 / 9}, {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729},
+                                        {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656}, {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84, 0}};
+                const double cc[7] = {0, 0.2, 0.3, 0.8, 8.0 / 9, 1, 1};
+                const double bt[7] = {-71.0 / 57600, 0, 71.0 / 16695, -71.0 / 1920, 17253.0 / 339200, -22.0 / 525, 1.0 / 40};
+                const double dn[7][4] = {{1.0, -8048581381.0 / 2820520608.0, 8663915743.0 / 2820520608.0, -12715105075.0 / 11282082432.0}, {0, 0, 0, 0},
+                                         {0, 131558114200.0 / 32700410799.0, -68118460800.0 / 10900136933.0, 87487479700.0 / 32700410799.0},
+                                         {0, -1754552775.0 / 470086768.0, 14199869525.0 / 1410260304.0, -10690763975.0 / 1880347072.0},
+                                         {0, 127303824393.0 / 49829197408.0, -318862633887.0 / 49829197408.0, 701980252875.0 / 199316789632.0},
+                                         {0, -282668133.0 / 205662961.0, 2019193451.0 / 616988883.0, -1453857185.0 / 822651844.0},
+                                         {0, 40617522.0 / 29380423.0, -110615467.0 / 29380423.0, 69997945.0 / 29380423.0}};
+                memcpy(A, a, sizeof(A)); memcpy(Cn, cc, sizeof(Cn)); memcpy(BT, bt, sizeof(BT)); memcpy(Dn, dn, sizeof(Dn));
+            } else {   // Tsit5 through the data path (cross-check of the path itself): tableau of rnde_device.h, dense output expanded to monomials
+                for (int sI = 0; sI < 7; ++sI) { Cn[sI] = tsC(sI); BT[sI] = tsBt(sI); for (int j = 0; j < 7; ++j) A[sI][j] = tsA(sI, j); }
+                auto mul = [](const double* a, int na, const double* b, int nb, double* o) { for (int i = 0; i < na + nb - 1; ++i) o[i] = 0; for (int i = 0; i < na; ++i) for (int j = 0; j < nb; ++j) o[i + j] += a[i] * b[j]; };
+                auto put = [&](int i, double cf, const double* poly5) { for (int j = 0; j < 4; ++j) Dn[i][j] = cf * poly5[j + 1]; };   // poly5[k] = coefficient of theta^k, k = 0..4
+                {   // b1 = c th (th - r)(th^2 - p th + q)
+                    const double f1[2] = {-1.3299890189751412, 1.0}, f2[3] = {0.7139816917074209, -1.4364028541716351, 1.0}; double t3[4], t5[5], th[2] = {0.0, 1.0};
+                    mul(f1, 2, f2, 3, t3); mul(th, 2, t3, 4, t5); put(0, -1.0530884977290216, t5);
+                }
+                const double cq[2] = {0.1017, 2.490627285651252793}, pq[2] = {2.1966568338249754, 2.38535645472061657}, qq[2] = {1.2949852507374631, 1.57803468208092486};
+                for (int i = 0; i < 2; ++i) { const double t5[5] = {0, 0, qq[i], -pq[i], 1.0}; put(1 + i, cq[i], t5); }   // c th^2 (th^2 - p th + q)
+                const double c4[4] = {-16.54810288924490272, 47.37952196281928122, -34.87065786149660974, 2.5}, r4[4] = {1.21712927295533244, 1.203071208372362603, 1.2, 1.0},
+                             s4[4] = {0.61620406037800089, 0.658047292653547382, 0.666666666666666667, 0.6};
+                for (int i = 0; i < 4; ++i) { const double t5[5] = {0, 0, r4[i] * s4[i], -(r4[i] + s4[i]), 1.0}; put(3 + i, c4[i], t5); }   // c (th - r)(th - s) th^2
+            }
+            RkTab& T = h->rk;
+            T = RkTab{};
+            for (int sI = 0; sI < 7; ++sI) {
+                T.c[sI] = (float)Cn[sI]; T.bt[sI] = (float)BT[sI];
+                for (int i = 0; i < 6; ++i) { T.fwd[sI][i] = (sI + 1 + i < 7) ? (float)A[sI + 1 + i][sI] : 0.f; T.bwd[sI][i] = (sI - 1 - i >= 0) ? (float)A[sI][sI - 1 - i] : 0.f; }
+                for (int j = 0; j < 4; ++j) T.dense[sI][j] = (float)Dn[sI][j];
+            }
+            for (int j = 0; j < 7; ++j) T.a7[j] = (float)A[6][j];
+        }
     }
     h->chain_lds_f = lds_f; h->chain_lds_b = lds_b;
     if (hipSetDevice(c->device) != hipSuccess) { g_create_err = "hipSetDevice failed"; delete h; return RNDE_ERR_HIP; }
@@ -279,28 +319,35 @@ static hipError_t launch_chain(rnde_node* h, const ChainParams& Q, int n, float*
 }
 static MwParams make_mw_params(rnde_node* h, const StepParams& P) {
     MwParams Q{};
-    Q.F = P; Q.G = h->mg; Q.tab = h->mw_tab; Q.ntiles = P.Bpad / 16;
+    Q.F = P; Q.G = h->mg; Q.rk = h->rk; Q.tab = h->mw_tab; Q.ntiles = P.Bpad / 16; Q.u_out = nullptr;
     Q.ev_stride = (long long)Q.ntiles * h->mg.RS * 64;
     Q.slab = P.tape ? h->mw_slab : nullptr;
     return Q;
 }
-template <int NR, int MODE>
+template <int NR, int MODE, int TAB>
 static hipError_t launch_mw_t(rnde_node* h, const MwParams& Q, int n, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)rnde_chainmw_kernel<NR, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)rnde_chainmw_kernel<NR, MODE, TAB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((rnde_chainmw_kernel<NR, MODE>), dim3(Q.ntiles), dim3(kMwThreads), h->mw_lds_f, s, Q, n);
+    hipLaunchKernelGGL((rnde_chainmw_kernel<NR, MODE, TAB>), dim3(Q.ntiles), dim3(kMwThreads), MODE == MW_FINISH ? 0 : h->mw_lds_f, s, Q, n);
     return hipGetLastError();
 }
 template <int MODE>
 static hipError_t launch_mw(rnde_node* h, const MwParams& Q, int n, hipStream_t s) {
+    if (h->rk_tab) {
+        switch (h->NKD) {
+            case 4: return launch_mw_t<1, MODE, 1>(h, Q, n, s);
+            case 8: return launch_mw_t<2, MODE, 1>(h, Q, n, s);
+            default: return launch_mw_t<4, MODE, 1>(h, Q, n, s);
+        }
+    }
     switch (h->NKD) {
-        case 4: return launch_mw_t<1, MODE>(h, Q, n, s);
-        case 8: return launch_mw_t<2, MODE>(h, Q, n, s);
-        default: return launch_mw_t<4, MODE>(h, Q, n, s);
+        case 4: return launch_mw_t<1, MODE, 0>(h, Q, n, s);
+        case 8: return launch_mw_t<2, MODE, 0>(h, Q, n, s);
+        default: return launch_mw_t<4, MODE, 0>(h, Q, n, s);
     }
 }
 // the forward tapes every layer input of every evaluation into the slab: make room for `evals` evaluations (growing keeps what is there)
@@ -342,10 +389,14 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= c->device) { g_create_err = "no HIP device"; return RNDE_ERR_NO_DEVICE; }
-    if (c->solver != RNDE_SOLVER_TSIT5 || c->n_layers < 1 || c->n_layers > RNDE_MAX_LAYERS || c->dims[0] != c->dims[c->n_layers]) {
-        g_create_err = "unsupported configuration: Tsit5 over a Dense chain with dims[0] == dims[n_layers]"; return RNDE_ERR_BAD_ARG;
+    if ((c->solver != RNDE_SOLVER_TSIT5 && c->solver != RNDE_SOLVER_DP5) || c->n_layers < 1 || c->n_layers > RNDE_MAX_LAYERS || c->dims[0] != c->dims[c->n_layers]) {
+        g_create_err = "unsupported configuration: Tsit5 (or DP5) over a Dense chain with dims[0] == dims[n_layers]"; return RNDE_ERR_BAD_ARG;
     }
     const bool mnist_form = c->n_layers == 2 && c->time_dep && !c->pre_act && c->act[0] == RNDE_ACT_TANH;
+    if (c->solver == RNDE_SOLVER_DP5 && ((mnist_form && c->col_tile != 65) || c->col_tile == 64 || c->regularize >= RNDE_REG_STIFF)) {
+        g_create_err = "DP5 runs on the tableau-as-data kernels of the chain engine (col_tile 0 for Dense chains of width <= 64, or 65), callbacks none / EEst*dt";
+        return RNDE_ERR_BAD_ARG;
+    }
     if (c->col_tile == 64 || c->col_tile == 65 || !mnist_form) return chain_create(c, out);   // small-width chains (latent_ode.jl:113-124): rnde_chain.h
     if (c->regularize < RNDE_REG_NONE || c->regularize > RNDE_REG_ERR_STIFF) { g_create_err = "regularize: unknown value"; return RNDE_ERR_BAD_ARG; }
     if (c->regularize >= RNDE_REG_STIFF && (c->col_tile == 4 || c->col_tile == 8)) {
@@ -704,7 +755,8 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
             ++launched;
         }
         if (h->timing && !h->tev_fwd) { HIPCHK(h, hipEventRecord(h->tev[1], s)); h->tev_fwd = true; }   // (first chunk: normally the whole solve)
-        if (h->engine == 3) HIPCHK(h, launch_chain<CM_FINISH>(h, CQ, launched, u_out_dev, s));
+        if (h->engine == 3 && h->mw) { MQ.u_out = u_out_dev; HIPCHK(h, launch_mw<MW_FINISH>(h, MQ, launched, s)); }
+        else if (h->engine == 3) HIPCHK(h, launch_chain<CM_FINISH>(h, CQ, launched, u_out_dev, s));
         else if (h->engine == 2) { hipLaunchKernelGGL(rnde_stage_finish_kernel, dim3(256), dim3(256), 0, s, SQ, launched, u_out_dev); HIPCHK(h, hipGetLastError()); }
         else HIPCHK(h, launch_finish(h, P, launched, u_out_dev, s));
         // one synchronisation per chunk: controller state, the persistent kernels' health words, and (speculatively: the solve
@@ -905,9 +957,8 @@ extern "C" rnde_status rnde_debug_attempt(rnde_node* h, const float* uprev_dev, 
         const ChainParams CQ = make_chain_params(h, P);
         const int nks = h->NKD;
         HIPCHK(h, chain_convert(k1_dev, h->f0, h->D, B, CQ.ntiles, nks, 0, s));
-        if (h->mw) HIPCHK(h, launch_mw<MW_STEP>(h, make_mw_params(h, P), 0, s));
-        else HIPCHK(h, launch_chain<CM_STEP>(h, CQ, 0, nullptr, s));
-        HIPCHK(h, launch_chain<CM_FINISH>(h, CQ, 1, nullptr, s));
+        if (h->mw) { HIPCHK(h, launch_mw<MW_STEP>(h, make_mw_params(h, P), 0, s)); HIPCHK(h, launch_mw<MW_FINISH>(h, make_mw_params(h, P), 1, s)); }
+        else { HIPCHK(h, launch_chain<CM_STEP>(h, CQ, 0, nullptr, s)); HIPCHK(h, launch_chain<CM_FINISH>(h, CQ, 1, nullptr, s)); }
         HIPCHK(h, hipMemcpyAsync(h->h_ctl, h->ctl_final, sizeof(StepState), hipMemcpyDeviceToHost, s));
         const ChainRec CL{(long long)CQ.ntiles * nks * 64};
         for (int sidx = 2; sidx <= 7; ++sidx)
@@ -1434,13 +1485,13 @@ static hipError_t launch_bchain_t(rnde_node* h, const BChainParams& Q, const std
 
 
 // ---- chain engine, multi-wave kernels: reverse pass (rnde_bchainmw.h) ------------------------------------------------------
-template <int NR>
+template <int NR, int TAB>
 static hipError_t launch_bmw_t(rnde_node* h, const BMwParams& Q, const std::vector<int>& sv_lo, const std::vector<int>& sv_hi, hipStream_t s) {
     const BwdBuffers& b = h->bw;
     const size_t lds = h->mw_lds_b;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)rnde_bchainmw_kernel<NR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)rnde_bchainmw_kernel<NR, TAB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rnde_bchainmw_init_kernel<NR, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rnde_bchainmw_init_kernel<NR, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -1458,7 +1509,7 @@ static hipError_t launch_bmw_t(rnde_node* h, const BMwParams& Q, const std::vect
             c1 = (float)(eigb / ((double)mm.n2 * (double)mm.n1));
             c2 = (float)(-eigb * ((double)mm.n1 / (double)mm.n2) / ((double)mm.n2 * (double)mm.n2));
         }
-        hipLaunchKernelGGL((rnde_bchainmw_kernel<NR>), grid, blk, lds, s, Q, n, mm, sv_lo[n], sv_hi[n], c1, c2);
+        hipLaunchKernelGGL((rnde_bchainmw_kernel<NR, TAB>), grid, blk, lds, s, Q, n, mm, sv_lo[n], sv_hi[n], c1, c2);
     }
     hipLaunchKernelGGL((rnde_bchainmw_init_kernel<NR, 1>), grid, blk, lds, s, Q);
     hipLaunchKernelGGL((rnde_bchainmw_init_kernel<NR, 2>), grid, blk, lds, s, Q);
@@ -1497,7 +1548,7 @@ static rnde_status chain_mw_bwd_run(rnde_node* h, const float* u_bar_dev, const 
     Q.B.bpart_n = Q.B.F.nwg;
     Q.B.sv_T = (int)h->saveat.size();
     Q.B.sv_ubar0 = (!h->saveat.empty() && h->saveat[0] == h->t0) ? u_bar_dev : nullptr;
-    Q.G = h->mg; Q.tab = h->mw_tab; Q.ntiles = Q.B.F.Bpad / 16;
+    Q.G = h->mg; Q.rk = h->rk; Q.tab = h->mw_tab; Q.ntiles = Q.B.F.Bpad / 16;
     Q.slab = h->mw_slab; Q.ev_stride = (long long)Q.ntiles * h->mg.RS * 64;
     Q.sv_t = h->saveat.empty() ? nullptr : h->sv_t_dev; Q.sv_ubar = u_bar_dev; Q.nsave = (int)h->saveat.size();
     // evaluation times in slab order (0: f(u0,t0), 1: f(u1,t0+dt0), 2 + 6n + (s-1): stage s of attempt n), save indices per accepted attempt
@@ -1507,7 +1558,7 @@ static rnde_status chain_mw_bwd_run(rnde_node* h, const float* u_bar_dev, const 
         h->h_ev_t[0] = h->t0; h->h_ev_t[1] = h->t0 + h->h_init->dt0;
         for (int n = 0; n < n_att; ++n) {
             const StepMeta& m = h->h_meta[n];
-            for (int sidx = 2; sidx <= 7; ++sidx) h->h_ev_t[2 + 6 * n + sidx - 2] = m.t + tsC(sidx - 1) * m.dt;
+            for (int sidx = 2; sidx <= 7; ++sidx) h->h_ev_t[2 + 6 * n + sidx - 2] = m.t + (h->rk_tab ? h->rk.c[sidx - 1] : tsC(sidx - 1)) * m.dt;
             sv_lo[n] = ns;
             if (m.flags & F_ACCEPT) {
                 const float tnew = m.t + m.dt;
@@ -1517,7 +1568,9 @@ static rnde_status chain_mw_bwd_run(rnde_node* h, const float* u_bar_dev, const 
         }
     }
     HIPCHK(h, hipMemcpyAsync(h->ev_t, h->h_ev_t, (size_t)n_evals * 4, hipMemcpyHostToDevice, s));
-    hipError_t e = h->NKD == 4 ? launch_bmw_t<1>(h, Q, sv_lo, sv_hi, s) : (h->NKD == 8 ? launch_bmw_t<2>(h, Q, sv_lo, sv_hi, s) : launch_bmw_t<4>(h, Q, sv_lo, sv_hi, s));
+    hipError_t e;
+    if (h->rk_tab) e = h->NKD == 4 ? launch_bmw_t<1, 1>(h, Q, sv_lo, sv_hi, s) : (h->NKD == 8 ? launch_bmw_t<2, 1>(h, Q, sv_lo, sv_hi, s) : launch_bmw_t<4, 1>(h, Q, sv_lo, sv_hi, s));
+    else e = h->NKD == 4 ? launch_bmw_t<1, 0>(h, Q, sv_lo, sv_hi, s) : (h->NKD == 8 ? launch_bmw_t<2, 0>(h, Q, sv_lo, sv_hi, s) : launch_bmw_t<4, 0>(h, Q, sv_lo, sv_hi, s));
     HIPCHK(h, e);
     // parameter gradients of all layers over all evaluations: the one-wave engine's kernel on the same slab format
     BChainParams W{};

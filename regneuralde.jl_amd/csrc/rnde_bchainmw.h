@@ -16,6 +16,7 @@ namespace rnde {
 struct BMwParams {
     BwdParams B;            // B.U / B.K1 / B.UB1 are fragment-order arrays
     MwGeo G;
+    RkTab rk;
     const float* tab;
     float* slab;            // activations from the forward (H rows), pre-activation cotangents written here (Z rows)
     long long ev_stride;
@@ -111,7 +112,7 @@ __device__ __forceinline__ void mw_fbwd(const MwGeo& G, const float* FRt, const 
     tau += tl;
 }
 
-template <int NR>
+template <int NR, int TAB = 0>
 __global__ __launch_bounds__(kMwThreads) void rnde_bchainmw_kernel(const BMwParams Q, const int n, const StepMeta m, const int sv_lo, const int sv_hi,
                                                                    const float eig_c1, const float eig_c2) {
     const BwdParams& Bq = Q.B;
@@ -186,9 +187,9 @@ __global__ __launch_bounds__(kMwThreads) void rnde_bchainmw_kernel(const BMwPara
         }
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            float acc = tsBt(0) * kq[0][r];
+            float acc = rk_bt<TAB>(Q.rk, 0) * kq[0][r];
 #pragma unroll
-            for (int j = 1; j < 7; ++j) acc += tsBt(j) * kq[j][r];
+            for (int j = 1; j < 7; ++j) acc += rk_bt<TAB>(Q.rk, j) * kq[j][r];
             float uin = 0.f;
             if (accepted) {
                 if (!first) uin = Bq.U[fo + 256 * r];
@@ -217,8 +218,8 @@ __global__ __launch_bounds__(kMwThreads) void rnde_bchainmw_kernel(const BMwPara
                 const bool at_end = (ts == tnew);
                 const float th = (ts - m.t) / dt;
                 float bw[7], dbw[7];
-                dense_weights(th, bw);
-                dense_weights_deriv(th, dbw);
+                rk_dense<TAB>(Q.rk, th, bw);
+                rk_dense_deriv<TAB>(Q.rk, th, dbw);
                 float dth = 0.f;
 #pragma unroll
                 for (int r = 0; r < NR; ++r) {
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(kMwThreads) void rnde_bchainmw_kernel(const BMwPara
         for (int r = 0; r < NR; ++r) {
             k7[r] = R[L.k(7) + fo + 256 * r];
             unv[r] = R[L.unew() + fo + 256 * r];
-            kb7[r] = dt * (tsBt(6) * utb[r] + Wv[6][r]);
+            kb7[r] = dt * (rk_bt<TAB>(Q.rk, 6) * utb[r] + Wv[6][r]);
             S += k7[r] * kb7[r];
             if (accepted && !first) kb7[r] += Bq.K1[fo + 256 * r];
             exk[r] = 0.f; exg[r] = 0.f;
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(kMwThreads) void rnde_bchainmw_kernel(const BMwPara
         for (int r = 0; r < NR; ++r) {
             unb[r] += gb[r];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) Rb[i][r] = dt * (tsA(6, 5 - i) * unb[r] + tsBt(5 - i) * utb[r] + Wv[5 - i][r]);   // kbar_{5-i}
+            for (int i = 0; i < 6; ++i) Rb[i][r] = dt * (rk_a7<TAB>(Q.rk, 5 - i) * unb[r] + rk_bt<TAB>(Q.rk, 5 - i) * utb[r] + Wv[5 - i][r]);   // kbar_{5-i}
             upb[r] += unb[r];
         }
     }
@@ -282,14 +283,14 @@ __global__ __launch_bounds__(kMwThreads) void rnde_bchainmw_kernel(const BMwPara
         }
         float ts_ = 0.f;
         mw_fbwd<NR>(G, FRt, TV, ZA, ZB, sl0 + (size_t)(s - 1) * Q.ev_stride, gs, ks, kb, gb, ts_, tid, wave, lane);
-        tau += ts_; ctau += kTsC[s] * ts_;
+        tau += ts_; ctau += rk_c<TAB>(Q.rk, s) * ts_;
         if (has_eig && s == 5) {
 #pragma unroll
             for (int r = 0; r < NR; ++r) gb[r] += exg[r];   // direct cotangent of g6
         }
         float cb[5];
 #pragma unroll
-        for (int i = 0; i < 5; ++i) cb[i] = dt * kBwdShift[s][i];
+        for (int i = 0; i < 5; ++i) cb[i] = dt * rk_bwd<TAB>(Q.rk, s, i);
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
 #pragma unroll

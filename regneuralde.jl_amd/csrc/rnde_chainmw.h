@@ -34,10 +34,40 @@ struct MwGeo {
 // global table: [forward fragments | bias vectors 8 x 64 | time columns 8 x 64 | transposed fragments]
 __host__ __device__ inline size_t mw_tab_floats(const MwGeo& G) { return (size_t)(G.nfrag_f + G.nfrag_t) * 64 + 1024; }
 
+// An explicit Runge-Kutta pair as DATA (7 stages, first-same-as-last, embedded error weights, dense output as a polynomial in
+// theta): kernels instantiated with TAB = 1 take every coefficient from here instead of the Tsit5 constants of rnde_device.h, so
+// another pair of that shape is a table, not a kernel (RNDE_SOLVER_DP5: Dormand-Prince 5(4), validated against scipy's RK45).
+struct RkTab {
+    float fwd[7][6];     // fwd[s][i] = a_{s+1+i, s}   (as kFwdShift)
+    float bwd[7][6];     // bwd[s][i] = a_{s, s-1-i}   (as kBwdShift)
+    float a7[8];         // a_{7, j}: the weights of u_new
+    float bt[8], c[8];   // embedded error weights, nodes
+    float dense[7][4];   // b_i(theta) = sum_j dense[i][j] theta^(j+1)
+};
+template <int TAB> __device__ __forceinline__ float rk_fwd(const RkTab& T, int s, int i) { return TAB ? T.fwd[s][i] : kFwdShift[s][i]; }
+template <int TAB> __device__ __forceinline__ float rk_bwd(const RkTab& T, int s, int i) { return TAB ? T.bwd[s][i] : kBwdShift[s][i]; }
+template <int TAB> __device__ __forceinline__ float rk_bt(const RkTab& T, int j) { return TAB ? T.bt[j] : kTsBt[j]; }
+template <int TAB> __device__ __forceinline__ float rk_c(const RkTab& T, int s) { return TAB ? T.c[s] : kTsC[s]; }
+template <int TAB> __device__ __forceinline__ float rk_a7(const RkTab& T, int j) { return TAB ? T.a7[j] : kTsA[6][j]; }
+template <int TAB> __device__ __forceinline__ void rk_dense(const RkTab& T, float th, float (&b)[7]) {
+    if (TAB) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) b[i] = th * (T.dense[i][0] + th * (T.dense[i][1] + th * (T.dense[i][2] + th * T.dense[i][3])));
+    } else dense_weights(th, b);
+}
+template <int TAB> __device__ __forceinline__ void rk_dense_deriv(const RkTab& T, float th, float (&db)[7]) {
+    if (TAB) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) db[i] = T.dense[i][0] + th * (2.f * T.dense[i][1] + th * (3.f * T.dense[i][2] + th * 4.f * T.dense[i][3]));
+    } else dense_weights_deriv(th, db);
+}
+
 struct MwParams {
     StepParams F;
     MwGeo G;
+    RkTab rk;
     const float* tab;
+    float* u_out;            // MW_FINISH: end state, D x B caller layout (may be NULL)
     float* slab;             // [n_evals][ntiles][RS][64] (NULL when not taping): evaluation 0 = f(u0), 1 = f(u1), 2 + 6 n + (s - 1) = stage s of attempt n
     long long ev_stride;
     int ntiles;
@@ -160,10 +190,10 @@ __device__ __forceinline__ void mw_eval(const MwGeo& G, const float* FRm, const 
     __syncthreads();   // X is rewritten by the next evaluation's input
 }
 
-enum { MW_STEP = 0, MW_INIT_A = 1, MW_INIT_B = 2, MW_FEVAL = 3 };
+enum { MW_STEP = 0, MW_INIT_A = 1, MW_INIT_B = 2, MW_FEVAL = 3, MW_FINISH = 4 };
 
 // NR = NKD / 4 registers per state array and lane (NKD = 4, 8, 16 k-steps of D as in rnde_chain.h: arena arrays are NKD * 64 floats per tile)
-template <int NR, int MODE>
+template <int NR, int MODE, int TAB = 0>
 __global__ __launch_bounds__(kMwThreads) void rnde_chainmw_kernel(const MwParams Q, const int n) {
     const StepParams& P = Q.F;
     const MwGeo& G = Q.G;
@@ -186,7 +216,7 @@ __global__ __launch_bounds__(kMwThreads) void rnde_chainmw_kernel(const MwParams
     if (MODE == MW_STEP) dbg = (unsigned long long*)P.dbg_out;
 #endif
     MW_STAMP(0);
-    mw_fill_lds(Q.tab, smem, (G.nfrag_f >> 2) + 4, wave, lane);
+    if constexpr (MODE != MW_FINISH) mw_fill_lds(Q.tab, smem, (G.nfrag_f >> 2) + 4, wave, lane);
     MW_STAMP(1);
     // element (r): feature f = (tid + 256 r) >> 4, column gcol
     const int gcol = tile * 16 + (tid & 15);
@@ -252,8 +282,8 @@ __global__ __launch_bounds__(kMwThreads) void rnde_chainmw_kernel(const MwParams
         }
         return;
     } else {
-        // ---- controller, then one attempted step ----
-        const StepState S = advance_state(P, n, lane, writer, &P.ctl[n & 1]);
+        // ---- controller, then (STEP) one attempted step / (FINISH) the last step's save points and the copy-out ----
+        const StepState S = advance_state(P, n, lane, writer, (MODE == MW_FINISH) ? P.ctl_final : &P.ctl[n & 1]);
         MW_STAMP(2);
         if (P.nsave > 0) {
             // saveat ({R,true} methods, neural_ode.jl:79-108): the points inside the step accepted last
@@ -279,7 +309,7 @@ __global__ __launch_bounds__(kMwThreads) void rnde_chainmw_kernel(const MwParams
                         const float tsv = P.sv_t[idx];
                         float b[7];
                         const bool at_end = (tsv == S.t);
-                        dense_weights((tsv - pv.t) / dtp_, b);
+                        rk_dense<TAB>(Q.rk, (tsv - pv.t) / dtp_, b);
 #pragma unroll
                         for (int r = 0; r < NR; ++r) {
                             float o = un[r];
@@ -294,6 +324,13 @@ __global__ __launch_bounds__(kMwThreads) void rnde_chainmw_kernel(const MwParams
                     }
                 }
             }
+        }
+        if constexpr (MODE == MW_FINISH) {
+            if (!Q.u_out) return;
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+                if (valid(r)) Q.u_out[(size_t)gcol * P.D + feat(r)] = S.live < 0 ? P.x[(size_t)gcol * P.D + feat(r)] : P.arena[(long long)S.live * P.rec_stride + L.unew() + fo + 256 * r];
+            return;
         }
         if (S.done) return;
         const float t = S.t;
@@ -311,8 +348,8 @@ __global__ __launch_bounds__(kMwThreads) void rnde_chainmw_kernel(const MwParams
             else { up[r] = Rl[L.unew() + fo + 256 * r]; k1 = Rl[L.k(7) + fo + 256 * r]; }
             if (P.tape || P.nsave > 0) { R[L.upc() + fo + 256 * r] = up[r]; R[L.k1c() + fo + 256 * r] = k1; }
 #pragma unroll
-            for (int i = 0; i < 6; ++i) Sa[i][r] = kFwdShift[0][i] * k1;
-            E[r] = kTsBt[0] * k1;
+            for (int i = 0; i < 6; ++i) Sa[i][r] = rk_fwd<TAB>(Q.rk, 0, i) * k1;
+            E[r] = rk_bt<TAB>(Q.rk, 0) * k1;
             un[r] = up[r]; g6[r] = 0.f; k6[r] = 0.f;
         }
 #pragma unroll 1
@@ -329,7 +366,7 @@ __global__ __launch_bounds__(kMwThreads) void rnde_chainmw_kernel(const MwParams
             }
             float* sl = (slab_tile && P.tape) ? slab_tile + (size_t)(2 + 6 * n + (s - 1)) * Q.ev_stride : nullptr;
             MW_STAMP(2 + s);
-            mw_eval<NR>(G, FRm, BV, TV, XB, YB, t + kTsC[s] * dt, gq, kv, sl, tid, wave, lane, s == 1 ? dbg : nullptr);
+            mw_eval<NR>(G, FRm, BV, TV, XB, YB, t + rk_c<TAB>(Q.rk, s) * dt, gq, kv, sl, tid, wave, lane, s == 1 ? dbg : nullptr);
             if (s == 5 && P.reg_kind >= 2) {
 #pragma unroll
                 for (int r = 0; r < NR; ++r) { g6[r] = gq[r]; k6[r] = kv[r]; }
@@ -338,10 +375,10 @@ __global__ __launch_bounds__(kMwThreads) void rnde_chainmw_kernel(const MwParams
 #pragma unroll
                 for (int r = 0; r < NR; ++r) if (valid(r)) { const float d1 = kv[r] - k6[r], d2 = un[r] - g6[r]; part1 += d1 * d1; part2 += d2 * d2; }
             }
-            const float bts = kTsBt[s];
+            const float bts = rk_bt<TAB>(Q.rk, s);
             float cs[5];
 #pragma unroll
-            for (int i = 0; i < 5; ++i) cs[i] = kFwdShift[s][i];
+            for (int i = 0; i < 5; ++i) cs[i] = rk_fwd<TAB>(Q.rk, s, i);
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
                 R[L.k(s + 1) + fo + 256 * r] = kv[r];

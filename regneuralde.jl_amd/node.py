@@ -134,8 +134,10 @@ class TrackedNeuralODE:
 
     def __init__(self, model, tspan, time_dep, regularize, solver="Tsit5", *, max_batch=512, max_attempts=128,
                  cb_save_start=True, track_ctrl=True, track_initdt=True, col_tile=0, **kwargs):
-        if solver not in ("Tsit5", "AutoTsit5"):
-            raise ValueError("solver: the reference's call sites use Tsit5() / AutoTsit5(Tsit5()) only")
+        if solver not in ("Tsit5", "AutoTsit5", "DP5"):
+            raise ValueError("solver: the reference's call sites use Tsit5() / AutoTsit5(Tsit5()) only; DP5 is the second "
+                             "pair of the tableau-as-data kernels (Dense chains of width <= 64)")
+        self.solver = solver
         self.model = model
         self.p = destructure(model)                      # Flux.destructure (neural_ode.jl:12)
         self.tspan = [float(tspan[0]), float(tspan[1])]
@@ -167,7 +169,7 @@ class TrackedNeuralODE:
         cfg.time_dep = int(self.time_dep)
         cfg.pre_act = int(getattr(self.model, "pre_act", False))
         cfg.max_batch = self.max_batch
-        cfg.solver = 0
+        cfg.solver = _lib.ODE_SOLVER[self.solver]
         cfg.reltol = float(self.kwargs.get("reltol", 1e-3))   # OrdinaryDiffEq defaults when not given
         cfg.abstol = float(self.kwargs.get("abstol", 1e-6))
         cfg.regularize = _FUNCS[func] if self.regularize else 0

@@ -250,3 +250,122 @@ def test_chain_stiffness_regulariser_matches_oracle(kind, B, tol, scale, reg, ag
     print(f"reg {reg}/{agg} {kind}: x-bar {rel_err(xb, xb64):.2e} (oracle f32 {cx:.2e})  p-bar {rel_err(pb, pb64):.2e} (oracle f32 {cp:.2e})")
     assert rel_err(xb, xb64) <= 3e-3 + 4 * cx
     assert rel_err(pb, pb64) <= 3e-3 + 4 * cp
+
+
+# ---- explicit RK pair as data (rnde_chainmw.h RkTab): Dormand-Prince 5(4) on the device against the DP5 oracle (itself pinned
+# ---- step for step on scipy's RK45, tests/test_oracle.py), and Tsit5 through the same data path against the constant-folded kernels
+DP5_CASES = [("latent", 4, 1e-3, 2.0), ("latent", 100, 1e-4, 2.0), ("chain3", 19, 1e-3, 2.0), ("wide", 16, 1e-3, 1.5), ("one", 3, 1e-3, 3.0),
+             ("test_node", 5, 1e-3, 3.0), ("small", 70, 1e-3, 4.0)]
+
+
+@pytest.fixture
+def _mw_only():
+    if _DEFAULT_TILE[0] != 65:
+        pytest.skip("tableau-as-data runs on the multi-wave kernels only")
+
+
+@pytest.mark.parametrize("kind,B", [("latent", 37), ("chain3", 19), ("small", 70)])
+def test_dp5_attempt_matches_oracle(kind, B, _mw_only):
+    from tests.util import Node, Oracle
+    arch, p, x = _setup(kind, B, 2)
+    o64 = Oracle(arch, np.float64, reltol=1e-6, abstol=1e-6, solver="DP5")
+    k1 = o64.f_eval(p, x, 0.1).astype(np.float32)
+    t, dt = 0.1, 0.05
+    kref, unew_ref, eest_ref, _ = o64.attempt(p, x, k1, t, dt)
+    kout, unew, eest = Node(_cfg(arch, B, reltol=1e-6, abstol=1e-6, solver="DP5")).attempt(x, k1, p, t, dt)
+    assert np.abs(kout - kref).max() <= 2e-5
+    assert np.abs(unew - unew_ref).max() <= 2e-5
+    floor = 3 * 6e-8 * dt * np.abs(kref).max() / 1e-6
+    assert abs(eest - eest_ref) <= 5e-3 * eest_ref + floor
+    # and it is a different method from Tsit5 (guards against the table being ignored)
+    _, unew_ts, eest_ts, _ = Oracle(arch, np.float64, reltol=1e-6, abstol=1e-6).attempt(p, x, k1, t, dt)
+    assert abs(eest_ts - eest_ref) > 0.05 * eest_ref
+
+
+@pytest.mark.parametrize("kind,B,tol,scale", DP5_CASES)
+def test_dp5_solve_and_reverse_match_oracle(kind, B, tol, scale, _mw_only):
+    from tests.util import Node, Oracle, rel_err
+    arch, p, x = _setup(kind, B, 3, scale)
+    o64 = Oracle(arch, np.float64, reltol=tol, abstol=tol, reg_kind=1, solver="DP5")
+    o32 = Oracle(arch, np.float32, reltol=tol, abstol=tol, reg_kind=1, solver="DP5")
+    r64, r32 = o64.forward(x, p), o32.forward(x, p)
+    node = Node(_cfg(arch, B, reltol=tol, abstol=tol, solver="DP5"))
+    got = node.forward(x, p, keep_tape=True)
+    assert got["nfe"] == r64["nfe"] == r32["nfe"] and (got["steps"][:, 3] == r64["steps"][:, 3]).all()
+    spread = np.abs(r32["u"] - r64["u"]).max(axis=1)
+    assert (np.abs(got["u"] - r64["u"]).max(axis=1) <= 3e-5 * max(1.0, np.abs(r64["u"]).max()) + 4 * spread).all()
+    np.testing.assert_allclose(got["saveval"], r64["saveval"], rtol=5e-2, atol=1e-6)
+    rng = np.random.default_rng(11)
+    ubar = rng.standard_normal(x.shape).astype(np.float32)
+    svbar = np.full(len(got["saveval"]), 30.0, dtype=np.float32)
+    gx, gp, gt = node.backward(ubar, svbar)
+    x64, p64, t64 = o64.backward(ubar.astype(np.float64), svbar.astype(np.float64))
+    x32, p32, _ = o32.backward(ubar, svbar)
+    cx, cp = rel_err(x32, x64), rel_err(p32, p64)
+    print(f"DP5 {kind}: x-bar {rel_err(gx, x64):.2e} ({cx:.2e})  p-bar {rel_err(gp, p64):.2e} ({cp:.2e})  tspan {gt} vs {t64}")
+    assert rel_err(gx, x64) <= 2e-3 + 4 * cx
+    assert rel_err(gp, p64) <= 2e-3 + 4 * cp
+    assert np.abs(gt - t64).max() <= (2e-3 + 4 * max(cx, cp)) * max(1.0, np.abs(t64).max())
+
+
+@pytest.mark.parametrize("kind,B,tol,scale,saveat", [("latent", 4, 1e-3, 1.5, np.linspace(0, 1, 49)), ("latent", 70, 1e-4, 1.5, np.array([0.1, 0.5, 0.9])),
+                                                      ("chain3", 19, 1e-3, 2.0, np.array([0.0, 0.25, 1.0]))])
+def test_dp5_saveat_and_reverse_match_oracle(kind, B, tol, scale, saveat, _mw_only):
+    """Dense output of the pair (Shampine's quartic for DP5) forward and through the reverse pass."""
+    from tests.util import Node, Oracle, rel_err
+    arch, p, x = _setup(kind, B, 5, scale)
+    sa = saveat.astype(np.float32)
+    o64 = Oracle(arch, np.float64, reltol=tol, abstol=tol, reg_kind=1, solver="DP5")
+    o32 = Oracle(arch, np.float32, reltol=tol, abstol=tol, reg_kind=1, solver="DP5")
+    r64, r32 = o64.forward(x, p, saveat=sa), o32.forward(x, p, saveat=sa)
+    node = Node(_cfg(arch, B, reltol=tol, abstol=tol, solver="DP5"))
+    got = node.forward_saveat(x, p, sa, keep_tape=True)
+    assert got["nfe"] == r64["nfe"] == r32["nfe"]
+    spread = np.abs(r32["u"] - r64["u"]).max(axis=(1, 2))
+    assert (np.abs(got["u"] - r64["u"]).max(axis=(1, 2)) <= 3e-5 * max(1.0, np.abs(r64["u"]).max()) + 8 * spread).all()
+    rng = np.random.default_rng(12)
+    ubar = rng.standard_normal(r64["u"].shape).astype(np.float32)
+    svbar = (10 * rng.standard_normal(len(got["saveval"]))).astype(np.float32)
+    gx, gp, gt = node.backward(ubar, svbar)
+    x64, p64, t64 = o64.backward(ubar.astype(np.float64), svbar.astype(np.float64))
+    x32, p32, _ = o32.backward(ubar, svbar)
+    cx, cp = rel_err(x32, x64), rel_err(p32, p64)
+    print(f"DP5 saveat {kind}: x-bar {rel_err(gx, x64):.2e} ({cx:.2e})  p-bar {rel_err(gp, p64):.2e} ({cp:.2e})")
+    assert rel_err(gx, x64) <= 2e-3 + 4 * cx
+    assert rel_err(gp, p64) <= 2e-3 + 4 * cp
+    assert np.abs(gt - t64).max() <= (2e-3 + 4 * max(cx, cp)) * max(1.0, np.abs(t64).max())
+
+
+def test_tsit5_through_the_table_equals_the_constant_folded_kernels(monkeypatch, _mw_only):
+    """RNDE_CHAIN_TAB=1 feeds the Tsit5 coefficients to the data path (dense output expanded to monomials): same accept/reject
+    sequence, states and cotangents as the kernels with the pair folded into the code."""
+    from tests.util import Node
+    arch, p, x = _setup("latent", 70, 5, 1.5)
+    sa = np.linspace(0, 1, 9).astype(np.float32)
+    rng = np.random.default_rng(15)
+
+    def run():
+        node = Node(_cfg(arch, 70, reltol=1e-4, abstol=1e-4))
+        got = node.forward_saveat(x, p, sa, keep_tape=True)
+        ubar = np.random.default_rng(16).standard_normal(got["u"].shape).astype(np.float32)
+        svbar = np.full(len(got["saveval"]), 5.0, dtype=np.float32)
+        return got, node.backward(ubar, svbar)
+
+    a, ga = run()
+    monkeypatch.setenv("RNDE_CHAIN_TAB", "1")
+    b, gb = run()
+    assert a["nfe"] == b["nfe"]
+    np.testing.assert_allclose(a["saveval"], b["saveval"], rtol=1e-3, atol=1e-7)
+    assert np.abs(a["u"] - b["u"]).max() <= 2e-6 * max(1.0, np.abs(a["u"]).max())
+    for u, v in zip(ga, gb):
+        assert np.abs(u - v).max() <= 2e-5 * max(1.0, np.abs(u).max())
+
+
+def test_dp5_is_refused_where_the_table_kernels_do_not_run():
+    from tests.util import Node, arch_mnist
+    with pytest.raises(Exception):
+        Node(_cfg(_arch("latent"), 8, col_tile=64, solver="DP5"))          # one-wave kernels fold Tsit5 into the code
+    with pytest.raises(Exception):
+        Node(_cfg(_arch("latent"), 8, regularize=2, solver="DP5"))         # stiffness callbacks are wired for Tsit5 only
+    with pytest.raises(Exception):
+        Node(_cfg(arch_mnist(), 8, col_tile=16, solver="DP5"))             # stage engine

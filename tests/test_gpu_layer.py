@@ -284,3 +284,28 @@ def test_momentum_step_matches_the_torch_recurrence(rnde):
         assert pg.grad is None and og.n == oc.n
     assert (pg.detach().cpu() - pc.detach()).abs().max() <= 1e-6 * pc.detach().abs().max()
     assert (og.v[0].cpu() - oc.v[0]).abs().max() <= 1e-6 * oc.v[0].abs().max()
+
+
+def test_layer_with_the_dp5_pair(rnde):
+    """solver="DP5" on the host mirror: the small MNIST-form network routed to the tableau-as-data kernels (col_tile 65)."""
+    from oracle.oracle import Oracle, arch_mnist
+    rn = rnde
+    D, Hd, B = 36, 10, 12
+    g = torch.Generator().manual_seed(3)
+    dyn = rn.MLPDynamics(D, Hd, generator=g)
+    for l in dyn.layers:
+        l.W.mul_(3.0)
+    node = rn.TrackedNeuralODE(dyn, [0.0, 1.0], True, True, "DP5", save_everystep=False, reltol=1e-3, abstol=1e-3, save_start=False,
+                               max_batch=B, max_attempts=64, col_tile=65)
+    x = torch.rand(B, D, generator=g).cuda().requires_grad_(True)
+    p = node.p.cuda().clone().requires_grad_(True)
+    u, nfe, sv = node(x, p)
+    w = torch.randn(B, D, generator=g).cuda()
+    ((u * w).sum() + 40.0 * sv.saveval.sum()).backward()
+    orc = Oracle(arch_mnist(D, Hd), np.float64, reltol=1e-3, abstol=1e-3, reg_kind=1, solver="DP5")
+    r = orc.forward(x.detach().cpu().numpy().astype(np.float64), p.detach().cpu().numpy().astype(np.float64))
+    assert r["nfe"] == nfe
+    xb, pb, _ = orc.backward(w.cpu().numpy().astype(np.float64), np.full(len(r["saveval"]), 40.0))
+    assert np.abs(u.detach().cpu().numpy() - r["u"]).max() < 2e-5
+    assert np.abs(x.grad.cpu().numpy() - xb).max() <= 3e-3 * np.abs(xb).max()
+    assert np.abs(p.grad.cpu().numpy() - pb).max() <= 3e-3 * np.abs(pb).max()

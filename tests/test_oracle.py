@@ -282,3 +282,56 @@ def test_julia_golden_if_present():
         xb, pb, _ = o.backward(wu, np.full(len(r["saveval"]), 25.0))
         assert np.abs(xb.reshape(-1) - ref["xbar"]).max() <= 5e-3 * np.abs(ref["xbar"]).max(), name
         assert np.abs(pb - ref["pbar"]).max() <= 5e-3 * np.abs(ref["pbar"]).max(), name
+
+
+def test_dp5_tableau_path_matches_scipy_rk45_step_for_step():
+    """The tableau-as-data path (cfg.solver = DP5, the second 7-stage FSAL pair) against scipy.integrate's RK45 internals on the
+    same dynamics: one step from (t, y, f(t, y)) with a given h -- stage values, y_new, the error norm -- and the dense output;
+    then the order conditions / FSAL row and a converged solve.  (The Tsit5 path is the same code with the other table.)"""
+    from scipy.integrate._ivp.rk import RK45, rk_step
+    from oracle.oracle import Oracle, arch_test_node, glorot_params
+    arch = arch_test_node()                       # TDChain(Dense(3, 10, tanh), Dense(11, 2)): time dependent
+    rng = np.random.default_rng(5)
+    p = (glorot_params(arch, rng, np.float64, 3.0) + 0.1 * rng.standard_normal(64)).astype(np.float64)
+    o = Oracle(arch, np.float64, 1e-6, 1e-6, solver="DP5")
+    a, c, bt = o.tableau()
+    assert np.allclose(a[1:7, :5][:5], RK45.A[1:], atol=1e-15) and np.allclose(a[6, :6], RK45.B, atol=1e-15)      # FSAL: row 7 = b
+    assert np.allclose(c[:6], RK45.C, atol=1e-15) and np.allclose(np.abs(bt), np.abs(RK45.E), atol=1e-15)
+    assert np.allclose(o.dense_weights(1.0), np.append(RK45.B, 0.0), atol=1e-14)
+    for th in (0.2, 0.55, 0.9):
+        assert np.allclose(o.dense_weights(th), RK45.P @ np.array([th, th ** 2, th ** 3, th ** 4]), atol=1e-14)
+    y = rng.standard_normal((1, 2))
+    t, h = 0.3, 0.07
+
+    def fun(tt, yy):
+        return o.f_eval(p, yy.reshape(1, 2), tt).reshape(-1)
+
+    f0 = fun(t, y.reshape(-1))
+    K = np.empty((7, 2))
+    y_new, f_new = rk_step(fun, t, y.reshape(-1), f0, h, RK45.A, RK45.B, RK45.C, K)
+    kout, unew, eest, _ = o.attempt(p, y, f0.reshape(1, 2), t, h)
+    assert np.allclose(unew.reshape(-1), y_new, rtol=0, atol=1e-14)
+    assert np.allclose(kout[:, 0, :], K[1:], rtol=0, atol=1e-13)
+    scale = 1e-6 + np.maximum(np.abs(y.reshape(-1)), np.abs(y_new)) * 1e-6
+    err_norm = np.linalg.norm(K.T @ RK45.E * h / scale) / np.sqrt(2)
+    assert abs(eest - err_norm) <= 1e-9 * err_norm
+    # converged solve + dense output at the save points vs scipy's own adaptive RK45 at a much tighter tolerance
+    from scipy.integrate import solve_ivp
+    sa = np.array([0.0, 0.2, 0.5, 0.83, 1.0])
+    r = o.forward(y, p, saveat=sa)
+    assert r["rc"] == 0 and r["nfe"] == 3 + 6 * r["nattempts"]
+    ref = solve_ivp(fun, (0.0, 1.0), y.reshape(-1), method="RK45", rtol=1e-11, atol=1e-12, t_eval=sa)
+    assert np.abs(r["u"][0] - ref.y.T).max() <= 2e-5
+    # the reverse pass on this path: finite differences
+    ubar = rng.standard_normal(r["u"].shape)
+    svbar = rng.standard_normal(len(r["saveval"]))
+    xb, pb, _ = o.backward(ubar, svbar)       # (natural run: the controller chain is part of the differentiated program)
+
+    def loss(pp):
+        q = o.forward(y, pp, saveat=sa)
+        return float((q["u"] * ubar).sum() + (q["saveval"] * svbar).sum())
+    for idx in rng.choice(64, 8, replace=False):
+        pp, pm = p.copy(), p.copy()
+        pp[idx] += 1e-6; pm[idx] -= 1e-6
+        fd = (loss(pp) - loss(pm)) / 2e-6
+        assert abs(fd - pb[idx]) <= 2e-5 * max(1.0, abs(fd)), (idx, fd, pb[idx])

@@ -10,7 +10,8 @@ from oracle.oracle import Oracle, arch_mnist, arch_test_node, glorot_params, mak
 
 
 def make_cfg(dims, acts, max_batch, reltol=1.4e-8, abstol=1.4e-8, regularize=1, max_attempts=128, col_tile=0,
-             cb_save_start=1, track_ctrl=1, track_initdt=1, time_dep=1, pre_act=0, persist=0, wgrad_side_pct=0, stage_generic=0):
+             cb_save_start=1, track_ctrl=1, track_initdt=1, time_dep=1, pre_act=0, persist=0, wgrad_side_pct=0, stage_generic=0,
+             solver="Tsit5"):
     cfg = _lib.NodeConfig()
     cfg.n_layers = len(acts)
     for i, d in enumerate(dims):
@@ -20,7 +21,7 @@ def make_cfg(dims, acts, max_batch, reltol=1.4e-8, abstol=1.4e-8, regularize=1, 
     cfg.time_dep = int(time_dep)
     cfg.pre_act = int(pre_act)
     cfg.max_batch = max_batch
-    cfg.solver = 0
+    cfg.solver = _lib.ODE_SOLVER[solver]
     cfg.reltol, cfg.abstol = reltol, abstol
     cfg.regularize = regularize
     cfg.cb_save_start, cfg.track_ctrl, cfg.track_initdt = cb_save_start, track_ctrl, track_initdt

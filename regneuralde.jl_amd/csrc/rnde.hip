@@ -1058,7 +1058,7 @@ static rnde_status bench_attempt_impl(rnde_node* h, const float* x_dev, const fl
     if (mean_us_out) *mean_us_out = ms * 1000.f / iters;
 #ifdef RNDE_DIAG
     {   // phase stamps of the LAST f evaluation of one launch (workgroup 0), in shader cycles relative to stamp 0 of wave 0
-        unsigned long long* d = nullptr; unsigned long long hst[64] = {0};
+        unsigned long long* d = nullptr; unsigned long long hst[512] = {0};
         hipMalloc((void**)&d, sizeof(hst)); hipMemset(d, 0, sizeof(hst));
         P.dbg_out = (float*)d;
         if (h->engine == 3 && h->mw) {
@@ -1082,6 +1082,9 @@ static rnde_status bench_attempt_impl(rnde_node* h, const float* x_dev, const fl
             for (int st = 1; st <= 6; ++st) { const unsigned long long* q = hst + 4 + 5 * (st - 1); const unsigned long long prev = st == 1 ? hst[3] : hst[8 + 5 * (st - 2)];
                 if (st < 6) fprintf(stderr, "  stage %d: poll %lld A %lld B %lld C %lld D+put %lld\n", st, (long long)(q[0]-prev), (long long)(q[1]-q[0]), (long long)(q[2]-q[1]), (long long)(q[3]-q[2]), (long long)(q[4]-q[3]));
                 else fprintf(stderr, "  stage %d: poll %lld A %lld B %lld C+err %lld | total %lld cycles\n", st, (long long)(q[0]-prev), (long long)(q[1]-q[0]), (long long)(q[2]-q[1]), (long long)(hst[34]-q[2]), (long long)(hst[34]-hst[0])); }
+            fprintf(stderr, "per wave, relative to wave 0's poll-done of the stage: poll-done | barrier A in, out | B done | C done (before the barrier of D) | after it | put done\n");
+            for (int st = 1; st <= 5; ++st) for (int w = 0; w < 7; ++w) { const unsigned long long* q = hst + 64 + ((st - 1) * 8 + w) * 8; const long long z = (long long)hst[64 + (st - 1) * 64];
+                fprintf(stderr, "  stage %d wave %d: %6lld | %6lld %6lld | %6lld | %6lld | %6lld | %6lld\n", st, w, (long long)q[0]-z, (long long)q[1]-z, (long long)q[2]-z, (long long)q[3]-z, (long long)q[4]-z, (long long)q[5]-z, (long long)q[6]-z); }
             return RNDE_OK;
         }
         if (h->engine == 2) { SQ.F.dbg_out = (float*)d; stage_attempt(h, SQ, 0, s); } else launch_step<MODE_STEP>(h, P, 0, s);

@@ -53,7 +53,11 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned kSlabEmpty = 0xFFFFFFFFu;
 __device__ __forceinline__ int slab_buf(unsigned ex) { return (int)(ex % 3u); }
 __device__ __forceinline__ void slab_put(float* tslab, size_t tile_index, int lane, const f32x4& v) {
-    ((f32x4*)tslab + tile_index * 64)[lane] = v;
+    // a value that happens to carry the empty pattern (only a NaN with every payload bit set can) travels as 0xFFFFFFFE, NaN all the same
+    u32x4 b = __builtin_bit_cast(u32x4, v);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[i] = b[i] < 0xFFFFFFFEu ? b[i] : 0xFFFFFFFEu;
+    ((u32x4*)tslab + tile_index * 64)[lane] = b;
 }
 __device__ __forceinline__ void slab_clear(float* tslab, size_t tile_index, int lane) {
     const float e = __builtin_bit_cast(float, kSlabEmpty);
@@ -77,10 +81,13 @@ __device__ __forceinline__ bool slab_poll_sum(const PersistSync& Y, int buf, int
 #pragma unroll
         for (int r = 0; r < kSMaxW; ++r)
             if (r < R) e[r] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((r * HT + ht) * 64 + lane) * 16, 0, 16);   // aux 16 = sc1: agent scope, misses L1
-        bool ok = true;
+        // "no word is kSlabEmpty" == "the unsigned maximum of all words is not 0xFFFFFFFF": v_max3_u32 chain, one compare (28 compares into
+        // 28 scalar pairs made the loop spill scalars)
+        unsigned m = 0u;
 #pragma unroll
         for (int r = 0; r < kSMaxW; ++r)
-            if (r < R) ok = ok && e[r][0] != kSlabEmpty && e[r][1] != kSlabEmpty && e[r][2] != kSlabEmpty && e[r][3] != kSlabEmpty;
+            if (r < R) { const unsigned a = e[r][0] > e[r][1] ? e[r][0] : e[r][1], b = e[r][2] > e[r][3] ? e[r][2] : e[r][3]; const unsigned c = a > b ? a : b; m = m > c ? m : c; }
+        const bool ok = m != kSlabEmpty;
         if (__all(ok)) {
             // (scalar adds on purpose: the vector form `zs += bitcast(e[r])` over buffer-load results was miscompiled by this
             //  toolchain into v_pk_add_f32 with op_sel_hi:[0,0] in the tagged form of this helper -- two of four sums wrong)
@@ -105,8 +112,11 @@ __device__ __forceinline__ bool slab_poll_sum(const PersistSync& Y, int buf, int
 
 #ifdef RNDE_DIAG
 #define PSTAMP(i) do { if (P.dbg_out && wg == 0 && tid == 0) ((unsigned long long*)P.dbg_out)[i] = clock64(); } while (0)
+// per-wave stamps of workgroup 0: [64 + ((stage - 1) * 8 + wave) * 8 + k]
+#define WSTAMP(st, k) do { if (P.dbg_out && wg == 0 && lane == 0) ((unsigned long long*)P.dbg_out)[64 + (((st) - 1) * 8 + w) * 8 + (k)] = clock64(); } while (0)
 #else
 #define PSTAMP(i) do { } while (0)
+#define WSTAMP(st, k) do { } while (0)
 #endif
 
 // FIX = 1: the geometry of the headline configuration (D = 784 = 49 row tiles, H = 100 -> 7 hidden tiles, 7 waves, 7 row blocks) as
@@ -136,7 +146,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
     const bool writer = (wg == 0 && tid == 0);
     const int T = rb * gWT + w;
     const int r0 = 16 * T + 4 * (lane >> 4);
-    const bool tile_ok = T < gMT;
+    const bool tile_ok = FIX ? true : T < gMT;      // (FIX: 7 x 7 = 49 row tiles, none missing)
     const RecLayout L{(long long)gD * P.Bpad, (long long)gH * P.Bpad};
     if (tid == 0) Y.xcc[wg] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15;   // HW_REG_XCC_ID
 
@@ -199,11 +209,17 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
         own_hd[i] = (size_t)gcol * gH + hr;
         own_gl[i] = col * KG + kperm(hr);
     }
+    // FIX: a lane's four rows of its hidden tile are consecutive hidden units (H = 100 is a multiple of 4) -- one 16-byte tape store --
+    // and only wave 6 holds other rows (t, 1, padding): their value is own_c1 * ts + own_c0
+    float own_c1[4], own_c0[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { own_c1[i] = own_kind[i] == 1 ? 1.f : 0.f; own_c0[i] = own_kind[i] == 2 ? 1.f : 0.f; }
+    const bool own_hstore = rb == 0 && own_kind[3] == 0;
     if (tid == 0) RED[24] = 0.f;                  // "a wave of this workgroup gave up" (written by any such wave; read after the phase-A barrier)
     // phase D: this row block's layer-1 partial of the stage input v -> slab[par], then publish exchange number `ex`
     auto phase_d = [&](const f32x4& v, unsigned ex) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) GL[own_gl[i]] = (tile_ok && r0 + i < gD) ? v[i] : 0.f;
+        for (int i = 0; i < 4; ++i) GL[own_gl[i]] = (FIX || (tile_ok && r0 + i < gD)) ? v[i] : 0.f;
         __syncthreads();
         const size_t tile0 = (((size_t)slab_buf(ex) * Q.C + ct) * gR + rb) * gHT;
         const float* gbp = GL + col * KG + 4 * (lane >> 4);
@@ -243,7 +259,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
     {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (tile_ok) {
-            v = fma4(dt, kFwdShift[0][0] * c_k[0], c_up);
+            v = fma4(dt, tsA(1, 0) * c_k[0], c_up);
             if (P.tape) st4(R + L.g(2) + co, r0, gD, true, vec, v);
             // (uprev, k1) copies: only the dense output of saveat reads them here (the multi-launch STAGE kernels also do; streaming
             //  tape stores with `nt` were measured: no difference)
@@ -260,7 +276,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
     auto stage = [&](auto sc) {
         constexpr int s = decltype(sc)::value;
         if (!alive) return;
-        const float ts = fmaf(kTsC[s], dt, t);
+        const float ts = fmaf(tsC(s), dt, t);
         float* hdst = R + L.h(s + 1);
         float* kdst = R + L.k(s + 1);
         const int buf = slab_buf((unsigned)s);              // exchange s: put by the previous stage (START for s = 1)
@@ -269,9 +285,24 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
         f32x4 zs = {0.f, 0.f, 0.f, 0.f};
         if (w < gHT) dead = !slab_poll_sum(Y, buf, Q.C, gR, gHT, ct, w, lane, zs);
         PSTAMP(4 + 5 * (s - 1));
+        WSTAMP(s, 0);
         // every row block has produced exchange s, hence consumed s - 1: this wave's entries of that buffer can be emptied
         const size_t tprev0 = (((size_t)slab_buf((unsigned)(s + 2)) * Q.C + ct) * gR + rb) * gHT;     // (s - 1) % 3 == (s + 2) % 3
-        if (w < gHT) {      // this wave's own hidden tile: addressing precomputed (own_*)
+        if constexpr (FIX) {
+            if (!dead) slab_clear(Y.tslab, tprev0 + w, lane);
+            float pre[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pre[i] = fmaf(w1t_own[i], ts, zs[i]) + b1_own[i];     // (rows that are no hidden unit: coefficients 0, value unused)
+            const f32x2 t01 = tanh_fast2((f32x2){pre[0], pre[1]}), t23 = tanh_fast2((f32x2){pre[2], pre[3]});
+            f32x4 hv = {t01.x, t01.y, t23.x, t23.y};
+            if (w == 6) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hv[i] = own_kind[i] == 0 ? hv[i] : fmaf(own_c1[i], ts, own_c0[i]);
+            }
+            if (own_hstore) *(f32x4*)(hdst + own_hd[0]) = hv;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) HL[own_hl[0] + 4 * i] = hv[i];      // kperm: the four rows of a lane sit 4 floats apart
+        } else if (w < gHT) {      // this wave's own hidden tile: addressing precomputed (own_*)
             if (!dead) slab_clear(Y.tslab, tprev0 + w, lane);
             float pre[4];
 #pragma unroll
@@ -318,7 +349,9 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
             }
         }
         if (dead && lane == 0) RED[24] = 1.f;
+        WSTAMP(s, 1);
         __syncthreads();
+        WSTAMP(s, 2);
         if (RED[24] != 0.f) { alive = false; return; }      // a wave that gave up takes the whole workgroup with it (uniform after the barrier)
         PSTAMP(5 + 5 * (s - 1));
         // ---- phase B ----
@@ -343,36 +376,41 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
                 const f32x2 a01 = tanh_fast2((f32x2){kv[0], kv[1]}), a23 = tanh_fast2((f32x2){kv[2], kv[3]});
                 kv = (f32x4){a01.x, a01.y, a23.x, a23.y};
             }
+            if constexpr (!FIX) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) kv[i] = (r0 + i < gD) ? kv[i] : 0.f;
+                for (int i = 0; i < 4; ++i) kv[i] = (r0 + i < gD) ? kv[i] : 0.f;
+            }
         }
         PSTAMP(6 + 5 * (s - 1));
+        WSTAMP(s, 3);
         // ---- phase C ----
         if constexpr (s < 6) {
             slab_clears_done();      // (issued two phases ago: nothing to wait for in practice) before this stage's put, see slab_put
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (tile_ok) {
                 st4(kdst + co, r0, gD, true, vec, kv);
-                f32x4 acc = tsA_rt(s + 1, 0) * c_k[0];
+                f32x4 acc = tsA(s + 1, 0) * c_k[0];
 #pragma unroll
-                for (int j = 1; j < 6; ++j) if (j < s) acc = fma4(tsA_rt(s + 1, j), c_k[j], acc);
-                acc = fma4(tsA_rt(s + 1, s), kv, acc);
+                for (int j = 1; j < 6; ++j) if (j < s) acc = fma4(tsA(s + 1, j), c_k[j], acc);
+                acc = fma4(tsA(s + 1, s), kv, acc);
                 v = fma4(dt, acc, c_up);
                 if (s == 5) { st4(R + L.unew() + co, r0, gD, true, vec, v); c_un = v; }
                 else if (P.tape) st4(R + L.g(s + 2) + co, r0, gD, true, vec, v);
                 c_k[s] = kv;
             }
             PSTAMP(7 + 5 * (s - 1));
+            WSTAMP(s, 4);
             phase_d(v, (unsigned)(s + 1));
             PSTAMP(8 + 5 * (s - 1));
+            WSTAMP(s, 6);
         } else {
             if (tile_ok) {
                 st4(kdst + co, r0, gD, true, vec, kv);
                 const f32x4 up = c_up, un = c_un;
-                f32x4 acc = kTsBt[0] * c_k[0];
+                f32x4 acc = tsBt(0) * c_k[0];
 #pragma unroll
-                for (int j = 1; j < 6; ++j) acc = fma4(kTsBt[j], c_k[j], acc);
-                acc = fma4(kTsBt[6], kv, acc);
+                for (int j = 1; j < 6; ++j) acc = fma4(tsBt(j), c_k[j], acc);
+                acc = fma4(tsBt(6), kv, acc);
                 if (colok) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -382,9 +420,9 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
                         part0 += r * r;
                     }
                     if (P.reg_kind >= 2) {
-                        f32x4 g6 = tsA_rt(5, 0) * c_k[0];
+                        f32x4 g6 = tsA(5, 0) * c_k[0];
 #pragma unroll
-                        for (int j = 1; j < 5; ++j) g6 = fma4(tsA_rt(5, j), c_k[j], g6);
+                        for (int j = 1; j < 5; ++j) g6 = fma4(tsA(5, j), c_k[j], g6);
                         g6 = fma4(dt, g6, up);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {

@@ -1,9 +1,7 @@
-"""Cycle stamps of one stage-engine attempt (needs the RNDE_DIAG build at tools/micro/librnde_diag.so)."""
-import sys, os
+"""Cycle stamps of one stage-engine attempt: RNDE_LIB=regneuralde.jl_amd/lib/librnde_diag.so python tools/diag_stage.py (build: tools/build_diag.sh)"""
+import ctypes as C, sys
 sys.path.insert(0, '.')
-import regneuralde_jl_amd.build as b
-b.LIB = os.path.abspath("tools/micro/librnde_diag.so")
-import ctypes as C, numpy as np
+import numpy as np
 from tests.test_gpu_forward import _setup, _cfg
 from tests.util import Node
 B = 512

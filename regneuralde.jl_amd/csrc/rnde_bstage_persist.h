@@ -47,7 +47,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
     const bool writer = (wg == 0 && tid == 0);
     const int T = rb * gWT + w;
     const int r0 = 16 * T + 4 * (lane >> 4);
-    const bool tile_ok = T < gMT;
+    const bool tile_ok = FIX ? true : T < gMT;      // (FIX: 7 x 7 = 49 row tiles, none missing)
     const long long A = (long long)gD * P.Bpad;
     const RecLayout L{A, (long long)gH * P.Bpad};
     const bool first = (n == Bq.n_att - 1);
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = (r0 + i < gD) ? (ACT2 ? kb7[i] * (1.f - k7[i] * k7[i]) : kb7[i]) : 0.f;
+            for (int i = 0; i < 4; ++i) v[i] = (FIX || r0 + i < gD) ? (ACT2 ? kb7[i] * (1.f - k7[i] * k7[i]) : kb7[i]) : 0.f;
             st4(R + L.k(7) + co, r0, gD, true, vec, v);
         }
         if (!colok) { tau = 0.f; exdt = 0.f; }
@@ -266,9 +266,13 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
         if (!alive) return;
         // tape operands of this stage: independent of the hand-off, so request them first
         float h_own[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (FIX) {
+            if (own_h0 + 3 < gH) { const f32x4 hq = *(const f32x4*)(R + L.h(j + 1) + own_zd0); h_own[0] = hq[0]; h_own[1] = hq[1]; h_own[2] = hq[2]; h_own[3] = hq[3]; }
+        } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (own_h0 + i < gH) h_own[i] = (R + L.h(j + 1))[own_zd0 + i];
+            for (int i = 0; i < 4; ++i) {
+                if (own_h0 + i < gH) h_own[i] = (R + L.h(j + 1))[own_zd0 + i];
+            }
         }
         f32x4 c_ks = {0.f, 0.f, 0.f, 0.f};
         if (tile_ok) c_ks = (j >= 2) ? ld4(R + L.k(j) + co, r0, gD, true, vec) : ld4(k1p + co, r0, gD, true, vec);
@@ -284,7 +288,22 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
         float* z1dst = R + L.z1(j + 1);
         // every row block has produced exchange ex, hence consumed ex - 1: this wave's entries of that buffer can be emptied
         const size_t tprev0 = (((size_t)slab_buf(ex + 2u) * Q.C + ct) * gR + rb) * gHT;     // (ex - 1) % 3 == (ex + 2) % 3
-        if (w < gHT) {      // this wave's own hidden tile (addressing precomputed)
+        if constexpr (FIX) {
+            // one hidden tile per wave; a lane's four rows are four hidden units (all waves but 6, and lanes 0..15 of wave 6), or the
+            // t row followed by padding (lanes 16..31 of wave 6), or padding: no per-row branches, one 16-byte tape store
+            if (!dead) slab_clear(Y.tslab, tprev0 + w, lane);
+            const bool unit = own_h0 + 3 < gH, trow = own_h0 == gH;
+            f32x4 zv;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const float hv = h_own[i]; const float z = zs[i] * (1.f - hv * hv); zv[i] = unit ? z : 0.f; }
+            if (rb == 0) {
+                if (unit) *(f32x4*)(z1dst + own_zd0) = zv;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) tau += unit ? w1t_own[i] * zv[i] : ((i == 0 && trow) ? zs[0] : 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ZL[own_zl0 + 4 * i] = zv[i];
+        } else if (w < gHT) {      // this wave's own hidden tile (addressing precomputed)
             if (!dead) slab_clear(Y.tslab, tprev0 + w, lane);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -347,8 +366,10 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
                 }
             }
             gb = acc0 + acc1;
+            if constexpr (!FIX) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) if (r0 + i >= gD) gb[i] = 0.f;
+                for (int i = 0; i < 4; ++i) if (r0 + i >= gD) gb[i] = 0.f;
+            }
         }
         BSTAMP(5 + 5 * (6 - j));
         // ---- phase C ----
@@ -359,10 +380,10 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
             gbs[j - 1] = gb;
             if (j == 6) unb += gb;
             constexpr int jn = j - 1;
-            f32x4 kbar = tsA_rt(6, jn) * unb + kTsBt[jn] * utb;
+            f32x4 kbar = tsA(6, jn) * unb + tsBt(jn) * utb;
 #pragma unroll
             for (int s = 1; s <= 5; ++s) {
-                if (s > jn) kbar += tsA_rt(s, jn) * gbs[s - 1];
+                if (s > jn) kbar += tsA(s, jn) * gbs[s - 1];
             }
             if (has_sv) kbar += Wv[jn];
             kbar = dt * kbar;
@@ -372,7 +393,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
                 for (int i = 0; i < 4; ++i) S += ks[i] * kbar[i];
                 if (has_eig && j == 6) kbar += exk;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = (r0 + i < gD) ? (ACT2 ? kbar[i] * (1.f - ks[i] * ks[i]) : kbar[i]) : 0.f;
+                for (int i = 0; i < 4; ++i) v[i] = (FIX || r0 + i < gD) ? (ACT2 ? kbar[i] * (1.f - ks[i] * ks[i]) : kbar[i]) : 0.f;
                 st4(R + L.k(jn + 1) + co, r0, gD, true, vec, v);
             } else {
                 const f32x4 k1v = c_ks;
@@ -409,7 +430,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
-        const float a = wave_sum_f(pS[i]), b = wave_sum_f(pT[i]), c = wave_sum_f(pX[i]);
+        const float a = wave_sum_f(pS[i]), b = wave_sum_f(pT[i]), c = i == 0 ? wave_sum_f(pX[0]) : 0.f;      // (only START has an exdt term)
         if (lane == 0) { GL[(i * 3 + 0) * 8 + w] = a; GL[(i * 3 + 1) * 8 + w] = b; GL[(i * 3 + 2) * 8 + w] = c; }
     }
     __syncthreads();
@@ -419,7 +440,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
             float sa = 0.f, ta = 0.f, xa = 0.f;
             for (int q = 0; q < gWT; ++q) { sa += GL[(i * 3 + 0) * 8 + q]; ta += GL[(i * 3 + 1) * 8 + q]; xa += GL[(i * 3 + 2) * 8 + q]; }
             if (i == 0) { o0 = sa; o1 = ta; o2 = xa; }
-            else { o0 += sa; o1 += ta; o2 += kTsC[7 - i] * ta; }
+            else { o0 += sa; o1 += ta; o2 += tsC(7 - i) * ta; }
         }
         float* o = Bq.bpart + ((size_t)(n & 1) * Bq.bpart_n + wg) * 4;
         o[0] = o0; o[1] = o1; o[2] = o2; o[3] = 0.f;

@@ -1,9 +1,7 @@
-"""Cycle stamps of one reversed stage-engine attempt (RNDE_DIAG build at tools/micro/librnde_diag.so)."""
+"""Cycle stamps of one reversed stage-engine attempt: RNDE_LIB=regneuralde.jl_amd/lib/librnde_diag.so python tools/diag_bstage.py"""
 import sys, os
 sys.path.insert(0, '.')
 os.environ["RNDE_DIAG_BWD"] = "1"
-import regneuralde_jl_amd.build as b
-b.LIB = os.path.abspath("tools/micro/librnde_diag.so")
 import numpy as np
 from tests.test_gpu_forward import _setup, _cfg
 from tests.util import Node

@@ -76,7 +76,7 @@ typedef struct {
     /* tuning (0 = default everywhere, so a zero-initialised tail keeps the defaults) */
     int32_t persist;        /* stage engine: 0 = one launch per attempted step where the shape allows, -1 = always the 7-launch kernels */
     int32_t wgrad_side_pct; /* share (per cent of the attempts) of the parameter-gradient GEMMs run beside the reverse sweep on the CUs
-                             * it leaves idle: 0 = default (35), -1 = none */
+                             * it leaves idle: 0 = default (30), -1 = none */
     int32_t stage_generic;  /* 1 = never use the instantiations with the MNIST geometry (D = 784, H = 100) as compile-time constants */
 } rnde_node_config;
 

@@ -57,7 +57,7 @@ struct rnde_node {
     float* sv_t_dev = nullptr; size_t sv_cap = 0; std::vector<float> saveat;   // saveat times of the last forward
     float* replay_dev = nullptr; size_t replay_cap = 0; const float* replay_host = nullptr; int n_replay = 0;   // rnde_node_forward_replay (set for one forward)
     // persistent attempt kernel (rnde_stage_persist.h): 1 = in use, 0 = off (RNDE_PERSIST=0), -1 = disabled after a failure
-    int wgrad_side_pct = 35, stage_generic = 0;
+    int wgrad_side_pct = 30, stage_generic = 0;
     int persist_clean = 0, persist_retry_after = 8, persist_fallbacks = 0;   // non-sticky fallback: clean multi-launch solves since the last failure, when to try again   // fixed at creation (config fields; RNDE_* environment overrides are read once, there)
     int persist = 0, persist_spins = kPersistMaxSpins; int tslab_Bpad = -1; size_t tslab_bytes = 0; float* tslab = nullptr; unsigned *pabort = nullptr, *pxcc = nullptr; unsigned* h_pchk = nullptr;
     hipStream_t wstream = nullptr;        // (experimental overlap path of the weight-gradient GEMMs)
@@ -474,7 +474,7 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
         const bool off = c->persist < 0 || (e && e[0] == '0');
         h->persist = (h->engine == 2 && h->sR <= 8 && !off) ? 1 : 0;
         if (const char* e2 = getenv("RNDE_PERSIST_SPINS")) h->persist_spins = atoi(e2);
-        h->wgrad_side_pct = c->wgrad_side_pct < 0 ? 0 : (c->wgrad_side_pct == 0 ? 35 : std::min(100, c->wgrad_side_pct));
+        h->wgrad_side_pct = c->wgrad_side_pct < 0 ? 0 : (c->wgrad_side_pct == 0 ? 30 : std::min(100, c->wgrad_side_pct));
         if (const char* e3 = getenv("RNDE_WGRAD_SIDE")) h->wgrad_side_pct = atoi(e3);
         h->stage_generic = (c->stage_generic != 0 || getenv("RNDE_STAGE_GENERIC") != nullptr) ? 1 : 0;
     }

@@ -1,0 +1,4 @@
+cd $GRAFT_REPO_ROOT
+for rep in 1 2; do for pct in 20 26 30 35; do
+RNDE_WGRAD_SIDE=$pct timeout 300 python bench.py --steps 10 --warmup 3 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys, json; d = json.loads(sys.stdin.read()); print('$pct', round(d['value']), 'samples/s', round(d['ms_per_step'], 3), 'ms  fwd', round(d['us_per_attempt_fwd'], 2), 'rev', round(d['us_per_attempt_rev'], 2), 'rest', round(d['rev_rest_ms'], 3))"
+done; done

@@ -143,7 +143,7 @@ __device__ __forceinline__ void finish_attempt_scalars(const BwdParams& Q, int m
     for (int base = 0; base < Q.bpart_n; base += 256) {   // four entries per lane in flight (see sum_partials)
         f32x4 e[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const int i = base + lane + 64 * q; e[q] = i < Q.bpart_n ? *(const f32x4*)(part + 4 * (size_t)i) : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        for (int q = 0; q < 4; ++q) { const int i = base + lane + 64 * q; e[q] = *(const f32x4*)(part + 4 * (size_t)(i < Q.bpart_n ? i : Q.bpart_n - 1)); }   // (unconditional requests, see sum_partials)
 #pragma unroll
         for (int q = 0; q < 4; ++q) if (base + lane + 64 * q < Q.bpart_n) { S += (double)e[q][0]; tau += (double)e[q][1]; ctau += (double)e[q][2]; }
     }

@@ -206,15 +206,41 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 #endif
 }
 
+// Sum over the 64 lanes of a wave, the same value returned to every lane.  DPP moves (row_shr 1, 2, 4, 8 inside each row of 16
+// lanes, then row_bcast 15 and 31 across the rows) leave the total in lane 63, read back through a scalar register: six short VALU
+// steps.  (The __shfl_xor butterfly these replace is six dependent ds_bpermute round trips through the LDS pipe, ~700 cycles per sum;
+// the controller of every launch does three to four of them in double precision before anything else can start.)  Fixed order of
+// additions: the same bits on every lane, workgroup and launch.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_get_f(float v) {      // lanes without a source (or outside ROW_MASK) read 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_get_d(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, ROW_MASK, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ double wave_sum_d(double s) {
-#pragma unroll
-    for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
-    return s;
+    s += dpp_get_d<0x111, 0xf>(s);      // row_shr:1
+    s += dpp_get_d<0x112, 0xf>(s);      // row_shr:2
+    s += dpp_get_d<0x114, 0xf>(s);      // row_shr:4
+    s += dpp_get_d<0x118, 0xf>(s);      // row_shr:8   -> lane 15 of each row holds the row's sum
+    s += dpp_get_d<0x142, 0xa>(s);      // row_bcast:15 into rows 1 and 3
+    s += dpp_get_d<0x143, 0xc>(s);      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, s);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 __device__ __forceinline__ float wave_sum_f(float s) {
-#pragma unroll
-    for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
-    return s;
+    s += dpp_get_f<0x111, 0xf>(s);
+    s += dpp_get_f<0x112, 0xf>(s);
+    s += dpp_get_f<0x114, 0xf>(s);
+    s += dpp_get_f<0x118, 0xf>(s);
+    s += dpp_get_f<0x142, 0xa>(s);
+    s += dpp_get_f<0x143, 0xc>(s);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), 63));
 }
 // fixed-order sum of n fp32 partials, carried in double; identical result on every lane / workgroup
 // (four loads per lane are requested before the first add: the plain loop `for (i = lane; i < n; i += 64) s += part[i]` waits
@@ -223,7 +249,9 @@ __device__ __forceinline__ double sum_partials(const float* __restrict__ part, i
     double s = 0;
     for (int base = 0; base < n; base += 256) {
         const int i0 = base + lane, i1 = i0 + 64, i2 = i0 + 128, i3 = i0 + 192;
-        const float v0 = i0 < n ? part[i0] : 0.f, v1 = i1 < n ? part[i1] : 0.f, v2 = i2 < n ? part[i2] : 0.f, v3 = i3 < n ? part[i3] : 0.f;
+        // unconditional requests (index clamped, value unused past n): loads under a lane condition were compiled into two dependent cold
+        // round trips
+        const float v0 = part[i0 < n ? i0 : n - 1], v1 = part[i1 < n ? i1 : n - 1], v2 = part[i2 < n ? i2 : n - 1], v3 = part[i3 < n ? i3 : n - 1];
         if (i0 < n) s += (double)v0;
         if (i1 < n) s += (double)v1;
         if (i2 < n) s += (double)v2;

@@ -231,6 +231,135 @@ __device__ __forceinline__ int sde_alloc(SdeStacks& S, int* freel, int n_slots, 
     return 0;
 }
 
+// ---- controller + noise bookkeeping: one thread per workgroup, identical everywhere (shared by the one-wave and the multi-wave
+// ---- solve kernels).  Reads (sum of squared residuals, stack metadata in LDS), writes the decision block and the list of array
+// ---- operations the waves then execute on their own columns.
+struct SdeCtlView {   // the solve loop's scalars and the LDS structures of the calling workgroup
+    float t, dt, qold, dtmax, dtmin;
+    int n, n_acc, next_save, cap;
+    float* S1L; int* S1s; float* S2L; int* S2s; int* FREEL;
+    SdeStacks* STK; SdeOp* OPS; SdeDecision* DEC;
+};
+__device__ __forceinline__ void sde_decide(const SdeParams& Q, const SdeCtlView& V, bool ok, double sumsq, double N, int wg) {
+    const float t = V.t, dt = V.dt, qold = V.qold, dtmax = V.dtmax, dtmin = V.dtmin;
+    const int n = V.n, n_acc = V.n_acc, next_save = V.next_save, cap = V.cap;
+    float* S1L = V.S1L; int* S1s = V.S1s; float* S2L = V.S2L; int* S2s = V.S2s; int* FREEL = V.FREEL;
+    SdeStacks* STK = V.STK; SdeOp* OPS = V.OPS; SdeDecision* DEC = V.DEC;
+    const double o[1] = {sumsq};
+    // ---- controller + noise bookkeeping: one thread per workgroup, identical everywhere ----
+    SdeDecision d{};
+    d.status = ok ? 0 : 5;
+    const float eest = (float)sqrt(o[0] / N);
+    d.eest = eest;
+    int nops = 0;
+    if (d.status == 0 && (!(eest == eest) || isinf(eest))) d.status = 3;
+    if (d.status == 0) {
+        const float q11 = powf(eest, Q.beta1);
+        float q = q11 / powf(qold, Q.beta2);
+        { const float qg = q / Q.gamma, lo = 1.f / Q.qmax, hi = 1.f / Q.qmin; q = qg < lo ? lo : (qg > hi ? hi : qg); }
+        d.q = q;
+        const bool acc = Q.replay ? (Q.replay[2 * n + 1] != 0.f) : (eest <= 1.f);
+        d.accepted = acc ? 1 : 0;
+        SdeStacks S = *STK;
+        const float discard = 1e-15f;
+        if (acc) {
+            const float tn = t + dt;
+            float dtn = dt / q;
+            if (dtmax < dtn) dtn = dtmax;
+            if (dtn < dtmin) dtn = dtmin;
+            if (Q.replay && n + 1 < Q.n_replay) dtn = Q.replay[2 * (n + 1)];
+            const bool last = !(tn < Q.t1) || (Q.replay && n + 1 >= Q.n_replay);
+            d.t = tn; d.rec = n_acc;
+            d.sv_lo = next_save; d.sv_hi = next_save;
+            while (d.sv_hi < Q.nsave && Q.sv_t[d.sv_hi] <= tn) ++d.sv_hi;
+            if (!last) {
+                if (Q.t1 - tn < dtn) dtn = Q.t1 - tn;
+                // accept_step!: the pieces of the finished step are forgotten, the next step is assembled from the future stack
+                for (int i = 0; i < S.n2; ++i) FREEL[S.nfree++] = S2s[i];
+                S.n2 = 0;
+                float dttmp = 0.f;
+                bool bridged = false;
+                while (S.n1 > 0 && nops < kSdeMaxOps - 2) {
+                    const float L = S1L[S.n1 - 1]; const int sl = S1s[S.n1 - 1];
+                    --S.n1;
+                    const float qtmp = (dtn - dttmp) / L;
+                    if (qtmp > 1.f) {
+                        dttmp += L;
+                        OPS[nops++] = SdeOp{OP_ADD, sl, 0, 0, 0.f, 0.f, 0, 0};
+                        S2L[S.n2] = L; S2s[S.n2] = sl; ++S.n2;
+                    } else {
+                        if (S.next_draw >= Q.n_pool) { d.status = 4; break; }
+                        const float rest = (1.f - qtmp) * L, piece = qtmp * L;
+                        const int keepP = rest > discard, keepN = piece > discard;
+                        const int ns = keepN ? sde_alloc(S, FREEL, Q.n_slots, d.status) : 0;
+                        OPS[nops++] = SdeOp{OP_BRIDGE, sl, ns, 0, qtmp, sqrtf((1.f - qtmp) * qtmp * L), S.next_draw++, keepP | (keepN << 1)};
+                        if (keepP) { S1L[S.n1] = rest; S1s[S.n1] = sl; ++S.n1; } else FREEL[S.nfree++] = sl;
+                        if (keepN) { S2L[S.n2] = piece; S2s[S.n2] = ns; ++S.n2; }
+                        bridged = true;
+                        break;
+                    }
+                }
+                if (!bridged && d.status == 0) {
+                    const float dtleft = dtn - dttmp;
+                    if (dtleft > 0.f) {
+                        if (S.next_draw >= Q.n_pool) d.status = 4;
+                        else {
+                            const int ns = sde_alloc(S, FREEL, Q.n_slots, d.status);
+                            OPS[nops++] = SdeOp{OP_FRESH, ns, 0, 0, sqrtf(dtleft), 0.f, S.next_draw++, 0};
+                            S2L[S.n2] = dtleft; S2s[S.n2] = ns; ++S.n2;
+                        }
+                    }
+                }
+                S.Wdt = dtn;
+            }
+            d.dt = dtn;
+            d.done = last ? 1 : 0;
+        } else {
+            float mrej = 1.f / Q.qmin;
+            const float m2 = q11 / Q.gamma;
+            if (m2 < mrej) mrej = m2;
+            float dtn = dt / mrej;
+            if (dtmax < dtn) dtn = dtmax;
+            if (Q.replay && n + 1 < Q.n_replay) dtn = Q.replay[2 * (n + 1)];
+            const bool last = Q.replay && n + 1 >= Q.n_replay;
+            if (Q.t1 - t < dtn) dtn = Q.t1 - t;
+            d.t = t; d.dt = dtn; d.done = last ? 1 : 0;
+            if (!last) {
+                // reject_step!: whole pieces of the tail go back to the future stack, the rest is bridged
+                float dttmp = 0.f;
+                while (S.n2 > 0 && nops < kSdeMaxOps - 2) {
+                    const float L = S2L[S.n2 - 1]; const int sl = S2s[S.n2 - 1];
+                    if (S.Wdt - dttmp - L < dtn) break;
+                    --S.n2;
+                    dttmp += L;
+                    OPS[nops++] = SdeOp{OP_SUB, sl, 0, 0, 0.f, 0.f, 0, 0};
+                    S1L[S.n1] = L; S1s[S.n1] = sl; ++S.n1;
+                }
+                if (S.next_draw >= Q.n_pool) d.status = 4;
+                else {
+                    const float dtK = S.Wdt - dttmp, qK = dtn / dtK, cut = (1.f - qK) * dtK;
+                    const int keepR = cut > discard;
+                    for (int i = 0; i < S.n2; ++i) FREEL[S.nfree++] = S2s[i];     // the finer structure of [0, dtK] is forgotten
+                    S.n2 = 0;
+                    const int rs = keepR ? sde_alloc(S, FREEL, Q.n_slots, d.status) : 0;
+                    const int cs = sde_alloc(S, FREEL, Q.n_slots, d.status);
+                    OPS[nops++] = SdeOp{OP_RBRIDGE, rs, cs, 0, qK, sqrtf((1.f - qK) * qK * dtK), S.next_draw++, keepR};
+                    if (keepR) { S1L[S.n1] = cut; S1s[S.n1] = rs; ++S.n1; }
+                    S2L[0] = dtn; S2s[0] = cs; S.n2 = 1;
+                    S.Wdt = dtn;
+                }
+            }
+        }
+        if (S.n1 >= cap - 2 || S.n2 >= cap - 2 || S.nfree >= cap - 2 || nops >= kSdeMaxOps - 1) d.status = d.status ? d.status : 4;
+        *STK = S;
+    }
+    d.nops = nops; d.n_att = n + 1; d.n_draws = STK->next_draw;
+    d.n_acc = n_acc + (d.accepted ? 1 : 0);
+    d.sqdt = 0.f;
+    *DEC = d;
+    if (wg == 0) { SdeMeta M{t, dt, eest, d.q, d.accepted, d.accepted ? n_acc : -1, d.sv_lo, d.sv_hi}; Q.meta[n] = M; }
+}
+
 template <int NKD, int FIXH = 0>
 __global__ __launch_bounds__(64 * kCW) void rnde_sde_solve_kernel(const SdeParams Q) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -400,118 +529,8 @@ __global__ __launch_bounds__(64 * kCW) void rnde_sde_solve_kernel(const SdeParam
             double o[1];
             const bool ok = sde_exchange<1>(Q, seq, mine, o, wg, lane);
             if (lane == 0) {
-                // ---- controller + noise bookkeeping: one thread per workgroup, identical everywhere ----
-                SdeDecision d{};
-                d.status = ok ? 0 : 5;
-                const float eest = (float)sqrt(o[0] / N);
-                d.eest = eest;
-                int nops = 0;
-                if (d.status == 0 && (!(eest == eest) || isinf(eest))) d.status = 3;
-                if (d.status == 0) {
-                    const float q11 = powf(eest, Q.beta1);
-                    float q = q11 / powf(qold, Q.beta2);
-                    { const float qg = q / Q.gamma, lo = 1.f / Q.qmax, hi = 1.f / Q.qmin; q = qg < lo ? lo : (qg > hi ? hi : qg); }
-                    d.q = q;
-                    const bool acc = Q.replay ? (Q.replay[2 * n + 1] != 0.f) : (eest <= 1.f);
-                    d.accepted = acc ? 1 : 0;
-                    SdeStacks S = *STK;
-                    const float discard = 1e-15f;
-                    if (acc) {
-                        const float tn = t + dt;
-                        float dtn = dt / q;
-                        if (dtmax < dtn) dtn = dtmax;
-                        if (dtn < dtmin) dtn = dtmin;
-                        if (Q.replay && n + 1 < Q.n_replay) dtn = Q.replay[2 * (n + 1)];
-                        const bool last = !(tn < Q.t1) || (Q.replay && n + 1 >= Q.n_replay);
-                        d.t = tn; d.rec = n_acc;
-                        d.sv_lo = next_save; d.sv_hi = next_save;
-                        while (d.sv_hi < Q.nsave && Q.sv_t[d.sv_hi] <= tn) ++d.sv_hi;
-                        if (!last) {
-                            if (Q.t1 - tn < dtn) dtn = Q.t1 - tn;
-                            // accept_step!: the pieces of the finished step are forgotten, the next step is assembled from the future stack
-                            for (int i = 0; i < S.n2; ++i) FREEL[S.nfree++] = S2s[i];
-                            S.n2 = 0;
-                            float dttmp = 0.f;
-                            bool bridged = false;
-                            while (S.n1 > 0 && nops < kSdeMaxOps - 2) {
-                                const float L = S1L[S.n1 - 1]; const int sl = S1s[S.n1 - 1];
-                                --S.n1;
-                                const float qtmp = (dtn - dttmp) / L;
-                                if (qtmp > 1.f) {
-                                    dttmp += L;
-                                    OPS[nops++] = SdeOp{OP_ADD, sl, 0, 0, 0.f, 0.f, 0, 0};
-                                    S2L[S.n2] = L; S2s[S.n2] = sl; ++S.n2;
-                                } else {
-                                    if (S.next_draw >= Q.n_pool) { d.status = 4; break; }
-                                    const float rest = (1.f - qtmp) * L, piece = qtmp * L;
-                                    const int keepP = rest > discard, keepN = piece > discard;
-                                    const int ns = keepN ? sde_alloc(S, FREEL, Q.n_slots, d.status) : 0;
-                                    OPS[nops++] = SdeOp{OP_BRIDGE, sl, ns, 0, qtmp, sqrtf((1.f - qtmp) * qtmp * L), S.next_draw++, keepP | (keepN << 1)};
-                                    if (keepP) { S1L[S.n1] = rest; S1s[S.n1] = sl; ++S.n1; } else FREEL[S.nfree++] = sl;
-                                    if (keepN) { S2L[S.n2] = piece; S2s[S.n2] = ns; ++S.n2; }
-                                    bridged = true;
-                                    break;
-                                }
-                            }
-                            if (!bridged && d.status == 0) {
-                                const float dtleft = dtn - dttmp;
-                                if (dtleft > 0.f) {
-                                    if (S.next_draw >= Q.n_pool) d.status = 4;
-                                    else {
-                                        const int ns = sde_alloc(S, FREEL, Q.n_slots, d.status);
-                                        OPS[nops++] = SdeOp{OP_FRESH, ns, 0, 0, sqrtf(dtleft), 0.f, S.next_draw++, 0};
-                                        S2L[S.n2] = dtleft; S2s[S.n2] = ns; ++S.n2;
-                                    }
-                                }
-                            }
-                            S.Wdt = dtn;
-                        }
-                        d.dt = dtn;
-                        d.done = last ? 1 : 0;
-                    } else {
-                        float mrej = 1.f / Q.qmin;
-                        const float m2 = q11 / Q.gamma;
-                        if (m2 < mrej) mrej = m2;
-                        float dtn = dt / mrej;
-                        if (dtmax < dtn) dtn = dtmax;
-                        if (Q.replay && n + 1 < Q.n_replay) dtn = Q.replay[2 * (n + 1)];
-                        const bool last = Q.replay && n + 1 >= Q.n_replay;
-                        if (Q.t1 - t < dtn) dtn = Q.t1 - t;
-                        d.t = t; d.dt = dtn; d.done = last ? 1 : 0;
-                        if (!last) {
-                            // reject_step!: whole pieces of the tail go back to the future stack, the rest is bridged
-                            float dttmp = 0.f;
-                            while (S.n2 > 0 && nops < kSdeMaxOps - 2) {
-                                const float L = S2L[S.n2 - 1]; const int sl = S2s[S.n2 - 1];
-                                if (S.Wdt - dttmp - L < dtn) break;
-                                --S.n2;
-                                dttmp += L;
-                                OPS[nops++] = SdeOp{OP_SUB, sl, 0, 0, 0.f, 0.f, 0, 0};
-                                S1L[S.n1] = L; S1s[S.n1] = sl; ++S.n1;
-                            }
-                            if (S.next_draw >= Q.n_pool) d.status = 4;
-                            else {
-                                const float dtK = S.Wdt - dttmp, qK = dtn / dtK, cut = (1.f - qK) * dtK;
-                                const int keepR = cut > discard;
-                                for (int i = 0; i < S.n2; ++i) FREEL[S.nfree++] = S2s[i];     // the finer structure of [0, dtK] is forgotten
-                                S.n2 = 0;
-                                const int rs = keepR ? sde_alloc(S, FREEL, Q.n_slots, d.status) : 0;
-                                const int cs = sde_alloc(S, FREEL, Q.n_slots, d.status);
-                                OPS[nops++] = SdeOp{OP_RBRIDGE, rs, cs, 0, qK, sqrtf((1.f - qK) * qK * dtK), S.next_draw++, keepR};
-                                if (keepR) { S1L[S.n1] = cut; S1s[S.n1] = rs; ++S.n1; }
-                                S2L[0] = dtn; S2s[0] = cs; S.n2 = 1;
-                                S.Wdt = dtn;
-                            }
-                        }
-                    }
-                    if (S.n1 >= cap - 2 || S.n2 >= cap - 2 || S.nfree >= cap - 2 || nops >= kSdeMaxOps - 1) d.status = d.status ? d.status : 4;
-                    *STK = S;
-                }
-                d.nops = nops; d.n_att = n + 1; d.n_draws = STK->next_draw;
-                d.n_acc = n_acc + (d.accepted ? 1 : 0);
-                d.sqdt = 0.f;
-                *DEC = d;
-                if (wg == 0) { SdeMeta M{t, dt, eest, d.q, d.accepted, d.accepted ? n_acc : -1, d.sv_lo, d.sv_hi}; Q.meta[n] = M; }
+                const SdeCtlView V{t, dt, qold, dtmax, dtmin, n, n_acc, next_save, cap, S1L, S1s, S2L, S2s, FREEL, STK, OPS, DEC};
+                sde_decide(Q, V, ok, o[0], N, wg);
             }
         }
         __syncthreads();

@@ -5,6 +5,7 @@
 // gets its own copy under another namespace name so that the two objects link into one library.
 #define rnde rnde_sde_tu
 #include "rnde_sde.h"
+#include "rnde_sdemw.h"
 
 #include <algorithm>
 #include <cmath>
@@ -19,6 +20,9 @@ using namespace rnde;
 struct rnde_nsde {
     rnde_nsde_config cfg{};
     int D = 0, Pf = 0, Pg = 0, P = 0, NKD = 8, Bpad_max = 0, ntiles_max = 0, nwg_max = 0;
+    int mw = 0;    // 1: the four-waves-per-tile solve kernel (rnde_sdemw.h) for that shape, while a tile per workgroup still fits the chip
+    size_t lds_mw = 0;
+    int xch_wg = 0; // workgroups the exchange array is sized for
     int fix = 0;   // 1: the reference's own shape (drift 8 -> 16 -> 8 k-steps, one-layer diffusion): kernels with compile-time shapes
     ChainGeo Gf{}, Gg{};
     SriTableau T{};
@@ -146,6 +150,7 @@ extern "C" rnde_status rnde_nsde_create(const rnde_nsde_config* c, rnde_nsde** o
     h->Pf = chain_params(c->drift_layers, c->drift_dims); h->Pg = chain_params(c->diff_layers, c->diff_dims); h->P = h->Pf + h->Pg;
     h->NKD = D <= 16 ? 4 : (D <= 32 ? 8 : 16);
     h->fix = (c->drift_layers == 2 && c->diff_layers == 1 && Gf.nks[0] == 8 && Gf.nks[1] == 16 && c->generic == 0) ? 1 : 0;
+    { const char* e = getenv("RNDE_SDE_MW"); h->mw = (h->fix && !(e && e[0] == '0')) ? 1 : 0; }
     float ddef = 1.f;
     sde_tableau(c->solver, h->T, ddef);
     h->order = 1.5f;
@@ -163,6 +168,8 @@ extern "C" rnde_status rnde_nsde_create(const rnde_nsde_config* c, rnde_nsde** o
     const int cap = 2 * c->max_attempts + 8;
     const size_t uf = (size_t)((Gf.nfrag_f + Gf.nfrag_b + 3) / 4), ug = (size_t)((Gg.nfrag_f + Gg.nfrag_b + 3) / 4);
     h->lds_fwd = (uf + ug) * 1024 + (size_t)(56 + kSdeMaxOps * 8 + 5 * cap) * 4 + 64;
+    h->lds_mw = (size_t)(kSmwLdsFloats + 56 + kSdeMaxOps * 8 + 5 * cap) * 4 + 64;
+    h->xch_wg = h->mw ? std::max(h->nwg_max, std::min(h->ntiles_max, 256)) : h->nwg_max;
     const size_t ufb = (size_t)((Gf.nfrag_f + Gf.nfrag_b + Gf.nfrag_t + 3) / 4), ugb = (size_t)((Gg.nfrag_f + Gg.nfrag_b + Gg.nfrag_t + 3) / 4);
     h->lds_bwd = (ufb + ugb) * 1024 + 64;
     if (h->lds_fwd > 160 * 1024 || h->lds_bwd > 160 * 1024) { g_nsde_create_err = "networks too large: the weight fragments of both chains must fit the 160 KB LDS of a CU"; delete h; return RNDE_ERR_BAD_ARG; }
@@ -176,7 +183,7 @@ extern "C" rnde_status rnde_nsde_create(const rnde_nsde_config* c, rnde_nsde** o
     ok &= dm((void**)&h->slots, (size_t)h->n_slots * 2 * A * 4);
     ok &= dm((void**)&h->meta, (size_t)(c->max_attempts + 1) * sizeof(SdeMeta)) && dm((void**)&h->acc_meta, (size_t)(c->max_attempts + 1) * sizeof(SdeMeta));
     ok &= dm((void**)&h->fin, sizeof(SdeFinal)) && dm((void**)&h->abort_word, 16);
-    ok &= dm((void**)&h->xch, (size_t)(c->max_attempts + 4) * 2 * h->nwg_max * 8);
+    ok &= dm((void**)&h->xch, (size_t)(c->max_attempts + 4) * 2 * h->xch_wg * 8);
     ok &= dm((void**)&h->svb, (size_t)(c->max_attempts + 1) * 4) && dm((void**)&h->replay, (size_t)(c->max_attempts + 1) * 8);
     ok &= dm((void**)&h->part, (size_t)h->nwg_max * 4);
     ok &= hipHostMalloc((void**)&h->h_meta, (size_t)(c->max_attempts + 1) * sizeof(SdeMeta)) == hipSuccess;
@@ -187,7 +194,7 @@ extern "C" rnde_status rnde_nsde_create(const rnde_nsde_config* c, rnde_nsde** o
     if (!ok) { g_nsde_create_err = "device allocation failed"; rnde_nsde_destroy(h); return RNDE_ERR_HIP; }
     for (auto& e : h->tev) if (hipEventCreate(&e) != hipSuccess) { g_nsde_create_err = "hipEventCreate failed"; rnde_nsde_destroy(h); return RNDE_ERR_HIP; }
     hipMemset(h->abort_word, 0, 16);
-    hipMemset(h->xch, 0, (size_t)(c->max_attempts + 4) * 2 * h->nwg_max * 8);
+    hipMemset(h->xch, 0, (size_t)(c->max_attempts + 4) * 2 * h->xch_wg * 8);
     hipMemset(h->frags_f, 0, (size_t)(Gf.nfrag_f + Gf.nfrag_b + Gf.nfrag_t + 4) * 256);
     hipMemset(h->frags_g, 0, (size_t)(Gg.nfrag_f + Gg.nfrag_b + Gg.nfrag_t + 4) * 256);
     *out = h;
@@ -314,7 +321,7 @@ static rnde_status nsde_forward_impl(rnde_nsde* h, const float* x_dev, const flo
     ++h->epoch;
     if (h->epoch >= 500000u) {   // tags are epoch * 8192 + sequence: start over (entries are rewritten before they are read)
         h->epoch = 1;
-        SCHK(h, hipMemsetAsync(h->xch, 0, (size_t)(h->cfg.max_attempts + 4) * 2 * h->nwg_max * 8, s));
+        SCHK(h, hipMemsetAsync(h->xch, 0, (size_t)(h->cfg.max_attempts + 4) * 2 * h->xch_wg * 8, s));
     }
     SdeParams Q = sde_params(h, x_dev, noise_dev, n_pool, B, t0, t1, keep_tape ? 1 : 0);
     Q.u_out = u_out_dev;
@@ -325,8 +332,16 @@ static rnde_status nsde_forward_impl(rnde_nsde* h, const float* x_dev, const flo
     }
     h->tev_f = false;
     SCHK(h, hipEventRecord(h->tev[0], s));
-    hipError_t e = h->fix ? launch_solve<8, 16>(h, Q, s)
-                 : (h->NKD == 4 ? launch_solve<4>(h, Q, s) : (h->NKD == 8 ? launch_solve<8>(h, Q, s) : launch_solve<16>(h, Q, s)));
+    hipError_t e;
+    if (h->mw && ntiles <= 256) {   // one workgroup of four waves per tile (all of them resident: they meet once per attempt)
+        static bool attr = false;
+        if (!attr) { SCHK(h, hipFuncSetAttribute((const void*)rnde_sde_solve_mw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+        Q.nwg = ntiles;
+        hipLaunchKernelGGL(rnde_sde_solve_mw_kernel, dim3(ntiles), dim3(kSmwThreads), h->lds_mw, s, Q);
+        e = hipGetLastError();
+    } else
+        e = h->fix ? launch_solve<8, 16>(h, Q, s)
+                   : (h->NKD == 4 ? launch_solve<4>(h, Q, s) : (h->NKD == 8 ? launch_solve<8>(h, Q, s) : launch_solve<16>(h, Q, s)));
     SCHK(h, e);
     SCHK(h, hipEventRecord(h->tev[1], s));
     h->tev_f = true;

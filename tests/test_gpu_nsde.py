@@ -14,6 +14,14 @@ pytestmark = pytest.mark.gpu
 AGGR = dict(qmax=10.0, gamma=1.0, beta2=1e-9)   # a controller that rejects often (the recalled defaults hardly ever do)
 
 
+@pytest.fixture(autouse=True, params=["1", "0"], ids=["multi-wave", "one-wave"])
+def _solve_kernel(request, monkeypatch):
+    """The reference's shape has two whole-solve kernels (csrc/rnde_sdemw.h: four waves per tile, the default; csrc/rnde_sde.h: one
+    wave per tile, also what any other shape runs): every test of this file runs on both (RNDE_SDE_MW is read at handle creation)."""
+    monkeypatch.setenv("RNDE_SDE_MW", request.param)
+    yield
+
+
 def _nets(kind):
     from oracle.oracle import make_arch
     from oracle.oracle_sde import arch_nsde_diffusion, arch_nsde_drift

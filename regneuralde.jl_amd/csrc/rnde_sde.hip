@@ -490,8 +490,13 @@ extern "C" rnde_status rnde_nsde_backward(rnde_nsde* h, const float* u_bar_dev, 
     }
     h->tev_b = false;
     SCHK(h, hipEventRecord(h->tev[2], s));
-    hipError_t e = h->fix ? launch_bwd<8, 16>(h, Bq, s)
-                 : (h->NKD == 4 ? launch_bwd<4>(h, Bq, s) : (h->NKD == 8 ? launch_bwd<8>(h, Bq, s) : launch_bwd<16>(h, Bq, s)));
+    hipError_t e;
+    if (h->mw) {   // four waves per tile (rnde_sdemw.h); no residency requirement here: the reverse sweep has no meeting
+        hipLaunchKernelGGL(rnde_sde_bwd_mw_kernel, dim3(Bq.F.ntiles), dim3(kSmwThreads), (size_t)kSmwBwdLdsFloats * 4, s, Bq);
+        e = hipGetLastError();
+    } else
+        e = h->fix ? launch_bwd<8, 16>(h, Bq, s)
+                   : (h->NKD == 4 ? launch_bwd<4>(h, Bq, s) : (h->NKD == 8 ? launch_bwd<8>(h, Bq, s) : launch_bwd<16>(h, Bq, s)));
     SCHK(h, e);
     SCHK(h, hipEventRecord(h->tev[3], s));
     h->tev_b = true;

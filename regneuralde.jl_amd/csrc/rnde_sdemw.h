@@ -410,4 +410,205 @@ __global__ __launch_bounds__(kSmwThreads) void rnde_sde_solve_mw_kernel(const Sd
 }
 
 
+// ---- reverse sweep, four waves per tile: one launch, no meeting (see rnde_sde_bwd_kernel).  Per stage, backwards: element-wise part
+// (layer inputs / outputs and the output layers' pre-activation cotangents to the slab and LDS), phase 1 = every wave recomputes its
+// hidden tile of the drift AND forms (W2^T z2) for the same tile -- both land in the same D registers, so z1 = (W2^T z2) (1 - h^2)
+// needs no exchange --, phase 2 = W1^T z1 on waves 0, 1 beside Wg^T zg on waves 2, 3.  Three barriers per stage; the slab rows are
+// written exactly as rnde_sde_bwd_kernel writes them (rnde_chain_wgrad_kernel contracts them afterwards).
+constexpr int kSmwBwdLdsFloats = 3584;   // X0, Z2, ZG, Z1, HBF, HBG
+__global__ __launch_bounds__(kSmwThreads) void rnde_sde_bwd_mw_kernel(const SdeBwdParams Bq) {
+    constexpr int NKD = 2;      // element e = tid + 256 r <-> (feature e >> 4, column e & 15)
+    const SdeParams& Q = Bq.F;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* X0 = smem;                 // [32][16] drift input h0 of the stage (layer 1 is recomputed)
+    float* Z2 = smem + 512;           // [32][16] cotangent of the drift's pre-activation output
+    float* ZG = smem + 1024;          // [32][16] the diffusion's
+    float* Z1 = smem + 1536;          // [64][16] cotangent of the drift's hidden pre-activation
+    float* HBF = smem + 2560;         // [32][16] cotangent of h0
+    float* HBG = smem + 3072;         // [32][16] cotangent of h1
+    const int tile = blockIdx.x;
+    const int lg = lane >> 4, lc = lane & 15;
+    const int gq = tid >> 4, gcol = tile * 16 + (tid & 15);
+    const bool colok = gcol < Q.B;
+    // register-stationary fragments of this wave (packed tables of the one-wave engine, see rnde_sdemw.h's forward kernel):
+    // drift layer 1 tile `wave` (forward, recomputed), W2^T tile `wave` (32 -> 64), then W1^T tile wave (waves 0, 1) or Wg^T tile wave - 2
+    float a1[8], b1[4], t2[8], t1[16];
+    {
+        const float* TFf = Q.frags_f + (size_t)(Q.Gf.nfrag_f + Q.Gf.nfrag_b) * 64;
+        const float* TFg = Q.frags_g + (size_t)(Q.Gg.nfrag_f + Q.Gg.nfrag_b) * 64;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a1[k] = Q.frags_f[((size_t)Q.Gf.foff[0] + wave * 8 + k) * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b1[i] = Q.frags_f[((size_t)Q.Gf.nfrag_f + Q.Gf.boff[0] + 4 * wave + i) * 64 + lane];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t2[k] = TFf[((size_t)Q.Gf.toff[1] + wave * 8 + k) * 64 + lane];
+        if (wave < 2) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t1[k] = TFf[((size_t)Q.Gf.toff[0] + wave * 16 + k) * 64 + lane];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t1[k] = k < 8 ? TFg[((size_t)Q.Gg.toff[0] + (wave - 2) * 8 + (k < 8 ? k : 0)) * 64 + lane] : 0.f;
+        }
+    }
+    const bool th1 = Q.Gf.act[0] != 0, th2 = Q.Gf.act[1] != 0, thg = Q.Gg.act[0] != 0;
+    const SriTableau& T = Q.T;
+    const BChainParams& Cf = Bq.Cf;   // the two nets as chain_fbwd wants them (kernel-argument memory: their tables stay scalar loads)
+    const BChainParams& Cg = Bq.Cg;
+    const double N = (double)Q.D * (double)Q.B;
+    const float sqrt3 = 1.7320508075688772f;
+    const size_t as = (size_t)Q.ntiles * 512;
+    float U[NKD];
+#pragma unroll
+    for (int q = 0; q < NKD; ++q) U[q] = Bq.nsave > 0 ? 0.f : ldc(Bq.ubar, Q.D, gcol, 16 * q + gq, colok);
+    for (int a = Bq.n_acc - 1; a >= 0; --a) {
+        const SdeMeta m = Bq.acc_meta[a];
+        const float dt = m.dt, sqdt = sqrtf(fabsf(dt));
+        const float* R = Q.tape + ((size_t)a * 12 * Q.ntiles + tile) * 512 + tid;
+        float up[NKD], dW[NKD], dZ[NKD], k[4][NKD], g[4][NKD], kb[4][NKD], gb[4][NKD], upb[NKD], chi2[NKD];
+        float svup[NKD];
+#pragma unroll
+        for (int q = 0; q < NKD; ++q) svup[q] = 0.f;
+        for (int idx = m.sv_lo; idx < m.sv_hi && Bq.nsave > 0; ++idx) {      // saveat points of this step: u(ts) = (1 - th) uprev + th u
+            const float tsv = Bq.sv_t[idx];
+            const bool at_end = (tsv == m.t + dt);
+            const float th = at_end ? 1.f : (tsv - m.t) / dt;
+#pragma unroll
+            for (int q = 0; q < NKD; ++q) {
+                const float ub = (colok && 16 * q + gq < Q.D) ? Bq.ubar[((size_t)gcol * Bq.nsave + idx) * Q.D + 16 * q + gq] : 0.f;
+                U[q] += th * ub; svup[q] += (1.f - th) * ub;
+            }
+        }
+        const double eb = (Q.reg_kind == 1) ? (double)Bq.svb_acc[a] * (double)dt : 0.0;   // saveval = EEst * dt, dt constant
+        const float coef = m.eest > 0.f ? (float)(eb / (N * (double)m.eest)) : 0.f;
+#pragma unroll
+        for (int q = 0; q < NKD; ++q) {
+            up[q] = R[q * 256]; dW[q] = R[as + q * 256]; dZ[q] = R[2 * as + q * 256];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { k[j][q] = R[(3 + j) * as + q * 256]; g[j][q] = R[(7 + j) * as + q * 256]; }
+            const float un = R[11 * as + q * 256];
+            const float w = dW[q];
+            const float chi1 = (w * w - fabsf(dt)) / (2.f * sqdt);
+            chi2[q] = (w + dZ[q] / sqrt3) / 2.f;
+            const float chi3 = (w * w * w - 3.f * w * dt) / (6.f * dt);
+            float sk_ = 0.f, s3 = 0.f, s4 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { sk_ += k[j][q]; s3 += T.beta3[j] * g[j][q]; s4 += T.beta4[j] * g[j][q]; }
+            float unb = U[q], upv = 0.f, numb = 0.f;
+            if (colok && 16 * q + gq < Q.D) {
+                const float E2 = chi2[q] * s3 + chi3 * s4, E1 = dt * sk_;
+                const float au = fabsf(up[q]), an = fabsf(un);
+                const bool use_new = !(au > an);
+                const float sc = Q.abstol + (use_new ? an : au) * Q.reltol;
+                const float res = (Q.delta * E1 + E2) / sc;
+                const float rb = coef * res;
+                numb = rb / sc;
+                const float scb = -rb * res / sc;
+                if (use_new) unb += scb * Q.reltol * sgnf(un); else upv += scb * Q.reltol * sgnf(up[q]);
+            }
+            upv += unb;
+            const float e2b = unb + numb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                kb[j][q] = dt * T.alpha[j] * unb + dt * Q.delta * numb;
+                gb[j][q] = (w * T.beta1[j] + chi1 * T.beta2[j]) * unb + (chi2[q] * T.beta3[j] + chi3 * T.beta4[j]) * e2b;
+            }
+            upb[q] = upv + svup[q];
+        }
+#pragma unroll
+        for (int s = 3; s >= 0; --s) {
+            float h0[NKD], h1[NKD], hb[NKD];
+#pragma unroll
+            for (int q = 0; q < NKD; ++q) {
+                float a0 = 0.f, b0 = 0.f, a1 = 0.f, b1 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < s) {
+                        a0 += T.A0[4 * s + j] * k[j][q]; b0 += T.B0[4 * s + j] * g[j][q];
+                        a1 += T.A1[4 * s + j] * k[j][q]; b1 += T.B1[4 * s + j] * g[j][q];
+                    }
+                h0[q] = s ? up[q] + dt * a0 + chi2[q] * b0 : up[q];
+                h1[q] = s ? up[q] + dt * a1 + sqdt * b1 : up[q];
+            }
+            float* slf = Cf.slab + (size_t)(4 * a + s) * Cf.ev_stride + ((size_t)tile * Cf.RS) * 64;
+            float* slg = Cg.slab + (size_t)(4 * a + s) * Cg.ev_stride + ((size_t)tile * Cg.RS) * 64;
+            // element-wise: layer inputs / outputs to the slab (what the parameter-gradient kernel contracts), pre-activation cotangents of
+            // both output layers to LDS and slab, h0 to LDS for the recomputation of the hidden layer
+#pragma unroll
+            for (int q = 0; q < NKD; ++q) {
+                const int e = tid + 256 * q;
+                const float ko = k[s][q], go = g[s][q];
+                const float z2 = th2 ? kb[s][q] * (1.f - ko * ko) : kb[s][q];
+                const float zg = thg ? gb[s][q] * (1.f - go * go) : gb[s][q];
+                X0[e] = h0[q]; Z2[e] = z2; ZG[e] = zg;
+                slf[(size_t)Cf.hrow[0] * 64 + e] = h0[q]; slf[(size_t)Cf.hrow[2] * 64 + e] = ko; slf[(size_t)Cf.zrow[1] * 64 + e] = z2;
+                slg[(size_t)Cg.hrow[0] * 64 + e] = h1[q]; slg[(size_t)Cg.hrow[1] * 64 + e] = go; slg[(size_t)Cg.zrow[0] * 64 + e] = zg;
+            }
+            __syncthreads();
+            {   // phase 1, wave w: hidden tile w recomputed, (W2^T z2) tile w, their product -> Z1
+                float bv[8], zv[8];
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) { bv[kk] = X0[64 * kk + lane]; zv[kk] = Z2[64 * kk + lane]; }
+                f32x4 acc0 = {b1[0], b1[1], b1[2], b1[3]}, acc1 = {0.f, 0.f, 0.f, 0.f}, ab0 = {0.f, 0.f, 0.f, 0.f}, ab1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 8; kk += 2) {
+                    acc0 = mfma16(a1[kk], bv[kk], acc0); acc1 = mfma16(a1[kk + 1], bv[kk + 1], acc1);
+                    ab0 = mfma16(t2[kk], zv[kk], ab0); ab1 = mfma16(t2[kk + 1], zv[kk + 1], ab1);
+                }
+                f32x4 hm = acc0 + acc1;
+                if (th1) { const f32x2 t01 = tanh_fast2((f32x2){hm[0], hm[1]}), t23 = tanh_fast2((f32x2){hm[2], hm[3]}); hm = (f32x4){t01.x, t01.y, t23.x, t23.y}; }
+                const f32x4 ab = ab0 + ab1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = (16 * wave + 4 * i + lg) * 16 + lc;
+                    const float z1 = th1 ? ab[i] * (1.f - hm[i] * hm[i]) : ab[i];
+                    Z1[e] = z1;
+                    slf[(size_t)Cf.hrow[1] * 64 + e] = hm[i];
+                    slf[(size_t)Cf.zrow[0] * 64 + e] = z1;
+                }
+            }
+            __syncthreads();
+            {   // phase 2: waves 0, 1 = (W1^T z1) tiles (16 k-steps), waves 2, 3 = (Wg^T zg) tiles (8 k-steps)
+                const float* zb = (wave < 2 ? Z1 : ZG) + lane;
+                float zv[16];
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) zv[kk] = (kk < 8 || wave < 2) ? zb[64 * ((kk < 8 || wave < 2) ? kk : 0)] : 0.f;
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 8; kk += 2) { acc0 = mfma16(t1[kk], zv[kk], acc0); acc1 = mfma16(t1[kk + 1], zv[kk + 1], acc1); }
+                if (wave < 2) {
+#pragma unroll
+                    for (int kk = 8; kk < 16; kk += 2) { acc0 = mfma16(t1[kk], zv[kk], acc0); acc1 = mfma16(t1[kk + 1], zv[kk + 1], acc1); }
+                }
+                const f32x4 o = acc0 + acc1;
+                float* dst = wave < 2 ? HBF : HBG;
+                const int mo = wave & 1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dst[(16 * mo + 4 * i + lg) * 16 + lc] = o[i];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < NKD; ++q) {
+                const float hbf = HBF[tid + 256 * q], hbg = HBG[tid + 256 * q];
+                upb[q] += hbf;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (j < s) { kb[j][q] += dt * T.A0[4 * s + j] * hbf; gb[j][q] += chi2[q] * T.B0[4 * s + j] * hbf; }
+                upb[q] += hbg;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (j < s) { kb[j][q] += dt * T.A1[4 * s + j] * hbg; gb[j][q] += sqdt * T.B1[4 * s + j] * hbg; }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NKD; ++q) U[q] = upb[q];
+    }
+#pragma unroll
+    for (int q = 0; q < NKD; ++q)
+        if (colok && 16 * q + gq < Q.D) {
+            float v = U[q];
+            if (Bq.nsave > 0 && Bq.save_t0) v += Bq.ubar[((size_t)gcol * Bq.nsave) * Q.D + 16 * q + gq];
+            Bq.xbar[(size_t)gcol * Q.D + 16 * q + gq] = v;
+        }
+}
+
 }  // namespace rnde

@@ -176,8 +176,9 @@ def bench_nsde(args):
                                    "step = ClassifierNSDE loss fwd + reverse + ADAM"},
             "roofline": {"bound": "mfma", "achieved": flops / (us_att * 1e-6) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                          "frac": flops / (us_att * 1e-6) / 1e12 / MFMA_F32_PEAK_TF, "traffic": None,
-                         "kernel": "rnde_sde_solve_kernel: the WHOLE adaptive solve = 1 launch; unit = one attempted SRI step inside it "
-                                   "(8 small network evaluations + the cross-workgroup norm); latency bound (32 waves on the chip)",
+                         "kernel": "rnde_sde_solve_mw_kernel: the WHOLE adaptive solve = 1 launch, one workgroup of four waves per 16-column tile; "
+                                   "unit = one attempted SRI step inside it (8 small network evaluations + the cross-workgroup norm); "
+                                   "latency bound (32 workgroups on the chip)",
                          "us_per_attempt": us_att}}
 
 

@@ -201,6 +201,8 @@ def main():
     ap.add_argument("--col-tile", type=int, default=0)
     ap.add_argument("--autograd", action="store_true", help="head + loss through torch.autograd instead of the fused C-ABI head")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) and run the gradient all-reduce even at world size 1: exercises the N > 1 code path on a 1-GPU box")
+    ap.add_argument("--coupled", action="store_true", help="SURVEY 8e mode 2: ONE step-size controller for all ranks (rnde_node_set_coupling: an all-reduce of the error-norm "
+                    "partials after every attempted step; reproduces the single-device run at the global batch; default: independent controllers)")
     ap.add_argument("--workload", default="mnist", choices=["mnist", "latent", "nsde"], help="mnist = BASELINE.json's metric (default); latent = config 4; nsde = config 5")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -240,6 +242,10 @@ def main():
     y = torch.eye(NCLS)[torch.randint(0, NCLS, (B,), generator=g)].to(device)
     fg = rn.FlatGrads(model.trainable()) if use_dist else None
     reducer = rn.GradientAllReducer(model.trainable(), flat=fg) if use_dist else None   # the library's RCCL communicator (rnde_comm_*)
+    if args.coupled:
+        if reducer is None or reducer.comm is None:
+            raise SystemExit("--coupled needs the library communicator: run with --gpus N > 1 (or --force-dist)")
+        model.node.set_coupling(reducer.comm, world * B)
     nfes = []
     saved = [p.detach().clone() for p in model.trainable()]
 
@@ -357,6 +363,7 @@ def main():
                "us_per_attempt_rev": 1e3 * sum(rs) / max(1, sum(atts)),
                "rev_rest_ms": sum(rr) / len(rr),
                "persist_fallback": bool(stage_engine and nl != 1), "persist_fallback_count": int(L.rnde_node_fallback_count(h.ptr)),
+               "controller": "coupled (one controller for all ranks, SURVEY 8e mode 2)" if args.coupled else "independent per rank (SURVEY 8e mode 1)",
                "collective": (None if not use_dist else "rnde_comm_allreduce (RCCL via librnde.so): head gradient queued before the reverse sweep, "
                               "solve gradient behind it; 1/world folded into the optimiser launch"),
                "config": {"workload": "MNIST NODE regularized (error_est), Tsit5 reltol=abstol=1.4e-8, batch 512 per GPU, "

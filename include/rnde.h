@@ -221,6 +221,26 @@ const char* rnde_comm_last_error(const rnde_comm* c);   /* c may be NULL: last c
 /* In-place sum of n floats over the ranks (mean != 0: followed by a scale by 1 / world), asynchronous on `stream`.
  * MNIST-NODE payload: 166,418 floats = 665,672 B in ONE call (latency bound: one contiguous buffer). */
 rnde_status rnde_comm_allreduce(rnde_comm* c, float* buf_dev, int64_t n, int32_t mean, void* stream);
+/* `world` ranks that live in ONE process on ONE device (out[world]): same interface, the all-reduce is a one-workgroup kernel
+ * per rank meeting the others through device memory (n <= 8192 floats).  What the coupled controller below is tested with on a
+ * single GPU (two host threads, two handles), and what several shards per device would use. */
+rnde_status rnde_comm_create_local_group(int32_t world, int32_t device, rnde_comm** out);
+/* RNDE_OK unless an all-reduce of this communicator gave up waiting for a rank (in-process groups; blocking: call after the stream
+ * has been synchronised).  The coupled solves below check it themselves at their synchronisation points. */
+rnde_status rnde_comm_health(rnde_comm* c);
+
+/* SURVEY.md 8e mode 2 -- ONE controller for all shards: with the minibatch split by columns over `world` handles, the error norm
+ * that drives the step size is the RMS over ALL D x B_global entries (what a single-device run at B_global computes), so every
+ * shard takes the same (dt, accept) sequence and the sharded run reproduces the single-device one up to the order of the sums.
+ * After rnde_node_set_coupling(h, c, global_batch) every launch that produces per-workgroup partial sums of a batch-wide norm --
+ * the two of the initial-step rule, each attempted step, each reversed attempt, the reverse of the initial-step rule -- is
+ * followed by rnde_comm_allreduce(c, partials) on the solve's stream, the norms are means over D x global_batch, and the cotangents
+ * of the saved values are multiplied by world (each rank passes the cotangent of ITS loss, whose data term is a mean over its own
+ * columns: with this the usual average of the ranks' gradients is the gradient of the single-device loss).  One small collective
+ * per attempted step: the parity option, not the fast path (default: independent controllers, rnde_node_set_coupling(h, NULL, 0)).
+ * Every rank must make the same calls in the same order and hold the same number of columns (equal shards: the partial arrays are
+ * summed element-wise); MNIST-form networks (the stage engine) only. */
+rnde_status rnde_node_set_coupling(rnde_node* h, rnde_comm* c, int32_t global_batch);
 
 /* ======================================================================================================================
  * TrackedNeuralDSDE: the stochastic layer (reference src/models/neural_sde.jl:1-146; caller ClassifierNSDE,

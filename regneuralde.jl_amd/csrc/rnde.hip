@@ -46,6 +46,7 @@ struct rnde_node {
     ChainGeo cg{}; float* cfrags = nullptr; int NKD = 0, chain_alt = 0;
     size_t chain_lds_f = 0, chain_lds_b = 0;
     // multi-wave kernels of the chain engine (rnde_chainmw.h): 4 waves per 16 columns, activations taped in the slab by the forward
+    rnde_comm* couple = nullptr; int couple_batch = 0, couple_world = 1;   // SURVEY 8e mode 2 (rnde_node_set_coupling)
     int rk_tab = 0; RkTab rk{};   // explicit RK pair as data (DP5, or Tsit5 through the same path when RNDE_CHAIN_TAB=1)
     int mw = 0; MwGeo mg{}; float* mw_tab = nullptr; float* mw_slab = nullptr; long long mw_slab_evals = 0; size_t mw_lds_f = 0, mw_lds_b = 0;
     float* cslab = nullptr; size_t cslab_floats = 0; float* ev_t = nullptr; float* h_ev_t = nullptr;   // chain reverse: (H, Z) dump, evaluation times
@@ -122,7 +123,7 @@ static StepParams make_params(rnde_node* h, const float* x, int B, float t0, flo
     P.pw1 = h->pw1; P.pw2 = h->pw2;
     P.ctl = h->ctl; P.ctl_final = h->ctl_final; P.meta = h->meta; P.initrec = h->initrec;
     P.errpart = h->errpart; P.initpart = h->initpart; P.dbg_out = nullptr;
-    P.D = h->D; P.H = h->H; P.B = B;
+    P.D = h->D; P.H = h->H; P.B = B; P.Bn = h->couple ? h->couple_batch : B;
     P.Bpad = ((B + 15) / 16) * 16;   // both engines pad the batch to 16 columns (one tape format)
     P.nwg = h->engine == 2 ? h->sR * (P.Bpad / 16) : (h->engine == 3 ? (h->mw ? P.Bpad / 16 : (P.Bpad / 16 + kCW - 1) / kCW) : P.Bpad / h->BT);
     P.K4_1 = h->K4_1; P.KS1 = h->KS1; P.MT1 = h->MT1; P.K4_2 = h->K4_2; P.KS2 = h->KS2; P.MT2 = h->MT2;
@@ -518,6 +519,25 @@ extern "C" void rnde_node_destroy(rnde_node* h) {
     delete h;
 }
 
+// ---- SURVEY 8e mode 2: one controller for all shards (include/rnde.h: rnde_node_set_coupling).  Every launch that leaves per-workgroup
+// partial sums of a batch-wide norm is followed by an all-reduce of that partial array over the shards, on the same stream: the kernels
+// that consume the partials are unchanged (they sum the array in a fixed order, which now holds the element-wise sums over the ranks).
+static rnde_status couple_sum(rnde_node* h, float* partials, long long count, hipStream_t s) {
+    if (!h->couple) return RNDE_OK;
+    const rnde_status st = rnde_comm_allreduce(h->couple, partials, count, 0, (void*)s);
+    if (st != RNDE_OK) h->err = std::string("coupled controller: ") + rnde_comm_last_error(h->couple);
+    return st;
+}
+extern "C" rnde_status rnde_node_set_coupling(rnde_node* h, rnde_comm* c, int32_t global_batch) {
+    if (!h) return RNDE_ERR_BAD_ARG;
+    if (!c) { h->couple = nullptr; h->couple_batch = 0; h->couple_world = 1; return RNDE_OK; }
+    const int world = rnde_comm_world(c);
+    if (h->engine != 2) { h->err = "coupled controller: MNIST-form networks on the stage engine (col_tile 0 or 16) only"; return RNDE_ERR_BAD_ARG; }
+    if (global_batch < world || world < 1) { h->err = "coupled controller: global_batch must cover every rank"; return RNDE_ERR_BAD_ARG; }
+    h->couple = c; h->couple_batch = global_batch; h->couple_world = world;
+    return RNDE_OK;
+}
+
 static rnde_status ensure_arena(rnde_node* h, long long recs) {
     if (h->arena_recs >= recs) return RNDE_OK;
     if (h->arena) hipFree(h->arena);
@@ -730,14 +750,16 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
         SQ = make_stage_params(h, P, keep_tape ? h->pcopy : p_dev);
         HIPCHK(h, launch_stage<SM_I1>(h, SQ, 0, 0, s));
         HIPCHK(h, launch_stage<SM_I2>(h, SQ, 0, 0, s));
+        if ((st = couple_sum(h, P.initpart, 2LL * P.nwg, s)) != RNDE_OK) return st;            // norms of u0 and f0
         HIPCHK(h, launch_stage<SM_I3>(h, SQ, 0, 0, s));
         HIPCHK(h, launch_stage<SM_I4>(h, SQ, 0, 0, s));
+        if ((st = couple_sum(h, P.initpart + 2LL * P.nwg, P.nwg, s)) != RNDE_OK) return st;     // norm of f1 - f0
     } else {
         HIPCHK(h, launch_step<MODE_INIT_A>(h, P, 0, s));
         HIPCHK(h, launch_step<MODE_INIT_B>(h, P, 0, s));
     }
     int launched = 0;
-    int chunk = std::max(4, h->predicted);
+    int chunk = h->couple ? 16 : std::max(4, h->predicted);   // (coupled: the same launch count on every rank, whatever its history)
     const int cap = h->cfg.max_attempts;
     h->tev_fwd = false;
     if (h->timing) HIPCHK(h, hipEventRecord(h->tev[0], s));
@@ -752,6 +774,7 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
             else if (h->engine == 3) HIPCHK(h, launch_chain<CM_STEP>(h, CQ, launched, nullptr, s));
             else if (h->engine == 2) HIPCHK(h, stage_attempt(h, SQ, launched, s));
             else HIPCHK(h, launch_step<MODE_STEP>(h, P, launched, s));
+            if ((st = couple_sum(h, P.errpart + (size_t)(launched & 1) * 3 * P.nwg, 3LL * P.nwg, s)) != RNDE_OK) return st;
             ++launched;
         }
         if (h->timing && !h->tev_fwd) { HIPCHK(h, hipEventRecord(h->tev[1], s)); h->tev_fwd = true; }   // (first chunk: normally the whole solve)
@@ -769,6 +792,7 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
             HIPCHK(h, hipMemcpyAsync(h->h_init, h->initrec, sizeof(InitRec), hipMemcpyDeviceToHost, s));
         }
         HIPCHK(h, hipStreamSynchronize(s));
+        if (h->couple && rnde_comm_health(h->couple) != RNDE_OK) { h->err = std::string("coupled controller: ") + rnde_comm_last_error(h->couple); return RNDE_ERR_HIP; }
         if (h->engine == 2 && persist_check_result(h, SQ.C, SQ.R, s)) {
             if (h->pending_bwd) {   // the failure may belong to the asynchronous reverse pass before this forward: its outputs cannot be trusted
                 h->pending_bwd = false;
@@ -780,7 +804,7 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
         h->pending_bwd = false;
         if (h->h_ctl->done) break;
         if (launched >= cap) { h->err = "max_attempts reached"; h->n_att = h->h_ctl->n_att; return RNDE_ERR_MAX_ATTEMPTS; }
-        chunk = 4;
+        chunk = h->couple ? 16 : 4;
     }
     h->n_att = h->h_ctl->n_att;
     h->predicted = h->n_att + 1;
@@ -1147,7 +1171,9 @@ static hipError_t launch_bwd_t(rnde_node* h, const BwdParams& Q, int n_att, hipS
     }
     for (int n = n_att - 1; n >= 0; --n) hipLaunchKernelGGL((rnde_bstep_kernel<NG, ACT2>), dim3(Q.F.nwg), dim3(kThreads), lds, s, Q, n);
     hipLaunchKernelGGL((rnde_binit_kernel<NG, ACT2, 1>), dim3(Q.F.nwg), dim3(kThreads), lds, s, Q);
+    if (couple_sum(h, Q.ipart, 4LL * Q.F.nwg, s) != RNDE_OK) return hipErrorUnknown;                         // (coupled controller: dot, tau of the reversed second evaluation)
     hipLaunchKernelGGL((rnde_binit_kernel<NG, ACT2, 2>), dim3(Q.F.nwg), dim3(kThreads), lds, s, Q);
+    if (couple_sum(h, Q.ipart + 4LL * Q.F.nwg, 4LL * Q.F.nwg, s) != RNDE_OK) return hipErrorUnknown;        // tau of the first
     hipLaunchKernelGGL(rnde_bfin_kernel, dim3(1), dim3(64), 0, s, Q);
     return hipGetLastError();
 }
@@ -1237,8 +1263,11 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
     if (st != RNDE_OK) return st;
     BwdBuffers& b = h->bw;
     int n_att = h->n_att;
+    // (coupled controller: every rank passes the cotangent of its own loss; the shared scalars then carry `world` times the
+    //  single-device cotangent, like everything else -- see rnde_node_set_coupling)
+    const float svb_scale = h->couple ? (float)h->couple_world : 1.f;
     for (int i = 0; i < n_att; ++i)
-        b.h_svb[i] = (saveval_bar_host && h->sv_index[i] >= 0) ? saveval_bar_host[h->sv_index[i]] : 0.f;
+        b.h_svb[i] = (saveval_bar_host && h->sv_index[i] >= 0) ? svb_scale * saveval_bar_host[h->sv_index[i]] : 0.f;
     HIPCHK(h, hipMemcpyAsync(b.svb_att, b.h_svb, (size_t)n_att * 4, hipMemcpyHostToDevice, s));
     BwdParams Q{};
     Q.F = make_params(h, h->xcopy, h->B, h->t0, h->t1, 1);
@@ -1248,6 +1277,7 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
     Q.ubar = u_bar_dev; Q.xbar = x_bar_dev; Q.tspan_out = b.tspan_out;
     Q.n_att = n_att; Q.track_ctrl = h->cfg.track_ctrl; Q.track_initdt = h->cfg.track_initdt; Q.reg_kind = h->cfg.regularize;
     Q.bpart_n = Q.F.nwg;
+    Q.tspan_scale = h->couple ? 1.f / (float)h->couple_world : 1.f;
 #ifdef RNDE_DIAG
     if (getenv("RNDE_DIAG_BWD")) { if (!h->diag_buf) hipMalloc((void**)&h->diag_buf, 512); hipMemset(h->diag_buf, 0, 512); Q.F.dbg_out = h->diag_buf; }
 #endif
@@ -1359,6 +1389,7 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
                     else hipLaunchKernelGGL((rnde_bstage_attempt_kernel<0, 1>), pgrid, blk, h->stage_lds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
                 } else if (h->act2) hipLaunchKernelGGL((rnde_bstage_attempt_kernel<1, 0>), pgrid, blk, h->stage_lds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
                 else hipLaunchKernelGGL((rnde_bstage_attempt_kernel<0, 0>), pgrid, blk, h->stage_lds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
+                if ((st = couple_sum(h, b.bpart + (size_t)(n & 1) * Q.bpart_n * 4, 4LL * Q.bpart_n, s)) != RNDE_OK) return st;
                 if (n >= n_att - side_att && (hi_att - n >= group || n == n_att - side_att)) {   // attempts [n, hi_att) are final
                     st = wgrad_group(2 + 6 * n, 2 + 6 * hi_att, true);
                     if (st != RNDE_OK) return st;
@@ -1372,6 +1403,7 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
                 if (h->act2) hipLaunchKernelGGL((rnde_bstage_kernel<1, BM_STAGE>), grid, blk, h->stage_lds, s, BQ, n, j, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], qo);
                 else hipLaunchKernelGGL((rnde_bstage_kernel<0, BM_STAGE>), grid, blk, h->stage_lds, s, BQ, n, j, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], qo);
             }
+            if ((st = couple_sum(h, b.bpart + (size_t)(n & 1) * Q.bpart_n * 4, 4LL * Q.bpart_n, s)) != RNDE_OK) return st;
         }
         HIPCHK(h, hipGetLastError());
         Q.F.nwg = Q.F.Bpad / h->BT;     // the initialisation kernels below are column-owner kernels
@@ -1415,6 +1447,7 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
     HIPCHK(h, hipMemcpyAsync(h->h_scal, b.tspan_out, 8, hipMemcpyDeviceToHost, s));
     if (h->engine == 2) persist_check_enqueue(h, h->sR * (Q.F.Bpad / 16), s);
     HIPCHK(h, hipStreamSynchronize(s));
+    if (h->couple && rnde_comm_health(h->couple) != RNDE_OK) { h->err = std::string("coupled controller: ") + rnde_comm_last_error(h->couple); return RNDE_ERR_HIP; }
     if (tspan_bar_host) { tspan_bar_host[0] = h->h_scal[0]; tspan_bar_host[1] = h->h_scal[1]; }
     h->have_tape = false;  // z2bar overwrote k_s in place: the tape is consumed
     if (h->engine == 2 && persist_check_result(h, Q.F.Bpad / 16, h->sR, s)) {

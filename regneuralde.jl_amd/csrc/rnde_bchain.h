@@ -166,7 +166,7 @@ __global__ __launch_bounds__(64 * kCW) void rnde_bchain_kernel(const BChainParam
     const float dt = m.dt, t = m.t;
     float coef;
     {
-        const double N = (double)P.D * (double)P.B;
+        const double N = (double)P.D * (double)P.Bn;
         double eb = 0, dtb_pre = 0, q11b = 0, qb = 0, qoldb_in = 0;
         if (accepted) {
             const bool err_term = Bq.reg_kind == 1 || (Bq.reg_kind == 3 && !(m.eest * dt == 0.f));
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(64 * kCW) void rnde_bchain_init_kernel(const BChain
     const bool writer = (blockIdx.x == 0 && tid == 0);
     constexpr int nksD = NKD;
     const size_t fo = ((size_t)tile * NKD) * 64 + lane;
-    const double N = (double)P.D * (double)P.B;
+    const double N = (double)P.D * (double)P.Bn;
     chain_fill_lds(Q.frags, smem, fill_units, wave, lane);
     const InitRec ir = *P.initrec;
     const float dt0 = ir.dt0;

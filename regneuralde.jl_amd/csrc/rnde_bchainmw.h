@@ -144,7 +144,7 @@ __global__ __launch_bounds__(kMwThreads) void rnde_bchainmw_kernel(const BMwPara
     const float dt = m.dt, t = m.t;
     float coef;
     {
-        const double N = (double)P.D * (double)P.B;
+        const double N = (double)P.D * (double)P.Bn;
         double eb = 0, dtb_pre = 0, q11b = 0, qb = 0, qoldb_in = 0;
         if (accepted) {
             const bool err_term = Bq.reg_kind == 1 || (Bq.reg_kind == 3 && !(m.eest * dt == 0.f));
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(kMwThreads) void rnde_bchainmw_init_kernel(const BM
     const bool colok = gcol < P.B;
     const bool writer = (tile == 0 && tid == 0);
     const size_t fo = (size_t)tile * NKD * 64 + tid;
-    const double N = (double)P.D * (double)P.B;
+    const double N = (double)P.D * (double)P.Bn;
     auto feat = [&](int r) { return (tid + 256 * r) >> 4; };
     auto valid = [&](int r) { return colok && feat(r) < P.D; };
     mw_fill_lds(Q.tab + (size_t)G.nfrag_f * 64, smem, (G.nfrag_t >> 2) + 4, wave, lane);

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_kernel(const BStagePa
         if (!first) finish_attempt_scalars(Bq, n + 1, lane, tb, dtpb, qoldb, t1b, t0b);
         float coef;
         {
-            const double N = (double)P.D * (double)P.B;
+            const double N = (double)P.D * (double)P.Bn;
             double eb = 0, dtb_pre = 0, q11b = 0, qb = 0, qoldb_in = 0;
             if (accepted) {
                 const bool err_term = Bq.reg_kind == 1 || (Bq.reg_kind == 3 && !(m.eest * dt == 0.f));

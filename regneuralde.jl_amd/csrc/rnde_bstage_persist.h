@@ -159,7 +159,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
         BSTAMP(41);
         float coef;
         {
-            const double N = (double)gD * (double)P.B;
+            const double N = (double)gD * (double)P.Bn;
             double eb = 0, dtb_pre = 0, q11b = 0, qb = 0, qoldb_in = 0;
             if (accepted) {
                 const bool err_term = Bq.reg_kind == 1 || (Bq.reg_kind == 3 && !(m.eest * dt == 0.f));

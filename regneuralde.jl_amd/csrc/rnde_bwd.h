@@ -41,6 +41,7 @@ struct BwdParams {
     IBState* ibstate;                  // [2]
     float* bpart;                      // [2][nwg][4]
     float* ipart;                      // [2][nwg][4]
+    float tspan_scale;                 // 0 = 1
     const float* ubar;                 // caller layout
     float* xbar;                       // caller layout
     float* tspan_out;                  // [2]
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(kThreads) void rnde_bstep_kernel(const BwdParams Q,
     const float dt = m.dt, t = m.t;
     float coef;
     {
-        const double N = (double)P.D * (double)P.B;
+        const double N = (double)P.D * (double)P.Bn;
         double eb = 0, dtb_pre = 0, q11b = 0, qb = 0, qoldb_in = 0;
         if (accepted) {
             if (Q.reg_kind == 1) { const double sb = (double)Q.svb_att[n]; eb += sb * (double)dt; dtb_pre += sb * (double)m.eest; }
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(kThreads) void rnde_binit_kernel(const BwdParams Q)
     const bool vec = (P.D & 3) == 0;
     const bool writer = (wg == 0 && tid == 0);
     const long long A = (long long)P.D * P.Bpad, HB = (long long)P.H * P.Bpad;
-    const double N = (double)P.D * (double)P.B;
+    const double N = (double)P.D * (double)P.Bn;
     for (int i = tid; i < G::BT * P.KS1; i += kThreads)
         if (i % P.KS1 >= P.D) GL[i] = 0.f;
     for (int i = tid; i < G::BT * P.KS2; i += kThreads)
@@ -467,8 +468,11 @@ __global__ __launch_bounds__(64) void rnde_bfin_kernel(const BwdParams Q) {
     for (int i = lane; i < Q.F.nwg; i += 64) tau0 += (double)Q.ipart[((size_t)Q.F.nwg + i) * 4];
     tau0 = wave_sum_d(tau0);
     if (lane == 0) {
-        Q.tspan_out[0] = (float)(ib.t0b + tau0 + ib.tb);
-        Q.tspan_out[1] = (float)ib.t1b;
+        // (coupled controller: every rank holds the cotangent of the shared tspan summed over all shards and scaled by the world size, see
+        //  rnde_node_set_coupling; tspan_scale = 1 / world makes the average over the ranks the single-device value, as for p-bar)
+        const double sc = Q.tspan_scale != 0.f ? (double)Q.tspan_scale : 1.0;
+        Q.tspan_out[0] = (float)(sc * (ib.t0b + tau0 + ib.tb));
+        Q.tspan_out[1] = (float)(sc * ib.t1b);
     }
 }
 

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(kMwThreads) void rnde_chainmw_kernel(const MwParams
         // ---- initial-step heuristic, SURVEY.md B.1 (same arithmetic as rnde_chain_kernel) ----
         float dt0 = 0.f;
         if constexpr (MODE == MW_INIT_B) {
-            const double N = (double)P.D * (double)P.B;
+            const double N = (double)P.D * (double)P.Bn;
             const double s0 = sum_partials(P.initpart, P.nwg, lane);
             const double s1 = sum_partials(P.initpart + P.nwg, P.nwg, lane);
             const float d0 = (float)sqrt(s0 / N), d1 = (float)sqrt(s1 / N), dtmax = P.t1 - P.t0;

@@ -168,6 +168,7 @@ struct StepParams {
     float* initpart;    // [3][nwg]
     float* dbg_out;     // FEVAL output (caller layout) / finish copy target
     int D, H, B, Bpad, nwg;
+    int Bn;             // columns the norms are means over: B, or the GLOBAL batch when the controller is shared by several shards (SURVEY 8e mode 2)
     int K4_1, KS1, MT1, K4_2, KS2, MT2;
     float reltol, abstol, t0, t1;
     int tape, max_attempts;

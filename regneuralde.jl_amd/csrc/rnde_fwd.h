@@ -181,7 +181,7 @@ __device__ __forceinline__ void finalize_state(const StepParams& P, StepState& S
 
 __device__ __forceinline__ StepState advance_state(const StepParams& P, int n, int lane, bool writer, StepState* out) {
     StepState S;
-    const double N = (double)P.D * (double)P.B;
+    const double N = (double)P.D * (double)P.Bn;
     if (n == 0) {
         S.last_eest = 1.f; S.live = -1; S.done = 0; S.status = 0; S.n_att = 0; S.n_acc = 0; S.qold = kQoldInit;
         S.pad[0] = S.pad[1] = 0;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(kThreads) void rnde_step_kernel(const StepParams P,
         // ---- initial-step heuristic, SURVEY.md B.1 ----
         float dt0 = 0.f;
         if constexpr (MODE == MODE_INIT_B) {
-            const double N = (double)P.D * (double)P.B;
+            const double N = (double)P.D * (double)P.Bn;
             const double s0 = sum_partials(P.initpart, P.nwg, lane);
             const double s1 = sum_partials(P.initpart + P.nwg, P.nwg, lane);
             const float d0 = (float)sqrt(s0 / N), d1 = (float)sqrt(s1 / N), dtmax = P.t1 - P.t0;

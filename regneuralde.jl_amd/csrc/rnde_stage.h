@@ -245,7 +245,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_kernel(const StagePara
 
     float dt0 = 0.f;
     if constexpr (MODE == SM_I3) {   // initial-step heuristic: dt0 from the norms of u0 and f0
-        const double N = (double)P.D * (double)P.B;
+        const double N = (double)P.D * (double)P.Bn;
         const double s0 = sum_partials(P.initpart, P.nwg, lane), s1 = sum_partials(P.initpart + P.nwg, P.nwg, lane);
         const float d0 = (float)sqrt(s0 / N), d1 = (float)sqrt(s1 / N), dtmax = P.t1 - P.t0;
         int c0 = 0, cl = 0;

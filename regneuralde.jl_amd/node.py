@@ -154,6 +154,7 @@ class TrackedNeuralODE:
         self.cb_save_start, self.track_ctrl, self.track_initdt, self.col_tile = cb_save_start, track_ctrl, track_initdt, col_tile
         self.P = self.p.numel()
         self._handles = {}
+        self._coupling = None
         self.last_nfe = None
         self.last_tspan_bar = None
 
@@ -191,8 +192,19 @@ class TrackedNeuralODE:
             raise RuntimeError(f"{len(hs)} taped forwards of this layer are pending without a backward pass; each owns a tape of "
                                "max_attempts records.  Run them under torch.no_grad() (NFE probes), call backward, or drop the graphs")
         h = _Handle(self._config(x.device.index or 0, self._func))
+        if self._coupling is not None:
+            _lib.check(h.ptr, _lib.lib().rnde_node_set_coupling(h.ptr, self._coupling[0], self._coupling[1]))
         hs.append(h)
         return h
+
+    def set_coupling(self, comm, global_batch):
+        """SURVEY 8e mode 2 (include/rnde.h: rnde_node_set_coupling): ONE step-size controller for all shards of a minibatch split by
+        columns over `world` layers.  `comm`: an rnde_comm* (ctypes void pointer: `GradientAllReducer.comm` across processes,
+        rnde_comm_create_local_group inside one); None switches back to independent controllers.  Every rank must make the same calls."""
+        self._coupling = None if comm is None else (comm, int(global_batch))
+        for hs in self._handles.values():
+            for h in hs:
+                _lib.check(h.ptr, _lib.lib().rnde_node_set_coupling(h.ptr, comm, int(global_batch) if comm is not None else 0))
 
     @staticmethod
     def _saveat_times(saveat, ts):

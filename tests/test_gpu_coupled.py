@@ -1,0 +1,117 @@
+"""SURVEY 8e mode 2 -- one step-size controller for all shards (rnde_node_set_coupling) -- on the one GPU of the test box.
+
+world = 2 inside ONE process: two handles, two host threads, the in-process communicator (rnde_comm_create_local_group: the
+all-reduce is a one-workgroup kernel per rank meeting the other through device memory).  The sharded run must reproduce the
+single-device run over the whole batch: the same accept/reject sequence, step sizes and saved values to fp32 rounding (the error
+norm is now a sum of two partial sums), the end state of every column, and -- with the ranks' cotangents formed the way data
+parallelism forms them (data term = mean over the rank's own columns) -- gradients whose AVERAGE over the ranks is the
+single-device gradient.  world = 1 through RCCL: the collective's plumbing, bit-identical to the uncoupled run."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(B, seed, scale):
+    from tests.test_gpu_forward import _setup as base
+    return base("small", B, seed, scale)      # MNIST-form network (D = 36, H = 10) on the stage engine
+
+
+def _run(node, x, p, ubar, svb):
+    g = node.forward(x, p, keep_tape=True)
+    gx, gp, gt = node.backward(ubar, np.full(len(g["saveval"]), svb, dtype=np.float32))
+    return g, gx, gp, gt
+
+
+@pytest.mark.parametrize("persist", [1, 0])
+@pytest.mark.parametrize("B,cut,tol,scale", [(64, 32, 1e-3, 5.0), (70, 35, 1e-4, 4.0)])
+def test_two_coupled_shards_reproduce_the_single_device_run(B, cut, tol, scale, persist, monkeypatch):
+    from regneuralde_jl_amd import _lib
+    from tests.test_gpu_forward import _cfg
+    from tests.util import Node
+    monkeypatch.setenv("RNDE_PERSIST", str(persist))
+    L = _lib.lib()
+    arch, p, x = _setup(B, 21, scale)
+    rng = np.random.default_rng(22)
+    ubar = rng.standard_normal(x.shape).astype(np.float32) / B          # data term of the single-device loss: a mean over all columns
+    svb = 3.0
+    ref, rx, rp, rt = _run(Node(_cfg(arch, B, reltol=tol, abstol=tol, col_tile=16)), x, p, ubar, svb)
+    print("attempts", len(ref["steps"]), "rejected", int((ref["steps"][:, 3] == 0).sum()))
+
+    comms = (C.c_void_p * 2)()
+    assert L.rnde_comm_create_local_group(2, 0, comms) == 0, L.rnde_comm_last_error(None)
+    shards = [(0, cut), (cut, B)]         # (equal shards, as data parallelism makes them: every rank must hold the same number of 16-column tiles)
+    equal = 2 * cut == B
+    nodes = [Node(_cfg(arch, hi - lo, reltol=tol, abstol=tol, col_tile=16)).own_stream() for lo, hi in shards]
+    for n, c in zip(nodes, comms):
+        _lib.check(n.h, L.rnde_node_set_coupling(n.h, C.c_void_p(c), B))
+    out = [None, None]
+
+    def work(r):
+        lo, hi = shards[r]
+        # what a data-parallel rank passes: the cotangent of ITS loss, whose data term is a mean over its own columns (= world x the
+        # single-device cotangent of those columns when the shards are equal)
+        out[r] = _run(nodes[r], x[lo:hi], p, ubar[lo:hi] * 2.0, svb)
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(2)]
+    [t.start() for t in th]
+    [t.join(120) for t in th]
+    assert all(o is not None for o in out), "a rank did not finish"
+    for r, (lo, hi) in enumerate(shards):
+        g = out[r][0]
+        assert g["nfe"] == ref["nfe"] and np.array_equal(g["steps"][:, 3], ref["steps"][:, 3])
+        np.testing.assert_allclose(g["steps"][:, 1], ref["steps"][:, 1], rtol=2e-5)
+        np.testing.assert_allclose(g["saveval"], ref["saveval"], rtol=2e-4, atol=1e-9)
+        assert np.abs(g["u"] - ref["u"][lo:hi]).max() <= 2e-5 * max(1.0, np.abs(ref["u"]).max())
+    # both ranks hold the same controller history bit for bit
+    assert np.array_equal(out[0][0]["steps"], out[1][0]["steps"]) and np.array_equal(out[0][0]["saveval"], out[1][0]["saveval"])
+    if equal:   # the usual average of the ranks' gradients is the single-device gradient (equal shards: what data parallelism uses)
+        gp = 0.5 * (out[0][2] + out[1][2])
+        gt = 0.5 * (out[0][3] + out[1][3])
+        scale_p = np.abs(rp).max()
+        print("p-bar", np.abs(gp - rp).max() / scale_p, "tspan-bar", gt, rt)
+        assert np.abs(gp - rp).max() <= 2e-4 * scale_p
+        assert np.abs(gt - rt).max() <= 2e-4 * max(1.0, np.abs(rt).max())
+        for r, (lo, hi) in enumerate(shards):
+            assert np.abs(0.5 * out[r][1] - rx[lo:hi]).max() <= 2e-4 * np.abs(rx).max()
+    for c in comms:
+        L.rnde_comm_destroy(C.c_void_p(c))
+
+
+def test_coupling_with_one_rank_through_rccl_is_the_uncoupled_run():
+    from regneuralde_jl_amd import _lib
+    from tests.test_gpu_forward import _cfg
+    from tests.util import Node
+    L = _lib.lib()
+    arch, p, x = _setup(48, 23, 3.0)
+    ubar = np.random.default_rng(24).standard_normal(x.shape).astype(np.float32)
+    a = _run(Node(_cfg(arch, 48, reltol=1e-3, abstol=1e-3, col_tile=16)), x, p, ubar, 2.0)
+    buf = C.create_string_buffer(128)
+    assert L.rnde_comm_unique_id(buf) == 0
+    comm = C.c_void_p()
+    assert L.rnde_comm_create(bytes(buf.raw), 0, 1, 0, C.byref(comm)) == 0
+    n = Node(_cfg(arch, 48, reltol=1e-3, abstol=1e-3, col_tile=16))
+    _lib.check(n.h, L.rnde_node_set_coupling(n.h, comm, 48))
+    b = _run(n, x, p, ubar, 2.0)
+    assert a[0]["nfe"] == b[0]["nfe"] and np.array_equal(a[0]["u"], b[0]["u"]) and np.array_equal(a[0]["saveval"], b[0]["saveval"])
+    for u, v in zip(a[1:], b[1:]):
+        assert np.array_equal(u, v)
+    _lib.check(n.h, L.rnde_node_set_coupling(n.h, None, 0))
+    n.close()
+    L.rnde_comm_destroy(comm)
+
+
+def test_coupling_is_refused_off_the_stage_engine():
+    from regneuralde_jl_amd import _lib
+    from oracle.oracle import arch_latent
+    from tests.test_gpu_forward import _cfg
+    from tests.util import Node
+    L = _lib.lib()
+    comms = (C.c_void_p * 1)()
+    assert L.rnde_comm_create_local_group(1, 0, comms) == 0
+    n = Node(_cfg(arch_latent(), 16))
+    assert L.rnde_node_set_coupling(n.h, C.c_void_p(comms[0]), 16) == _lib.BAD_ARG
+    L.rnde_comm_destroy(C.c_void_p(comms[0]))

@@ -41,6 +41,14 @@ class Node:
         _lib.check(None, self.L.rnde_node_create(C.byref(cfg), C.byref(self.h)))
         self.cfg = cfg
         self.D = cfg.dims[0]
+        self.stream = None            # HIP stream of forward / backward (None: the default stream); see own_stream()
+        self._tstream = None
+
+    def own_stream(self):
+        """Give this handle a stream of its own (two handles driven from two host threads must not share the default stream)."""
+        self._tstream = torch.cuda.Stream()
+        self.stream = C.c_void_p(self._tstream.cuda_stream)
+        return self
 
     def close(self):
         if self.h:
@@ -80,8 +88,11 @@ class Node:
         nfe = C.c_int64(0)
         nsv = C.c_int32(0)
         sv = (C.c_float * (self.cfg.max_attempts + 1))()
+        # inputs were staged on torch's stream; self.stream may be another one (and a device-wide wait could wait on a peer handle
+        # that is waiting for this one)
+        torch.cuda.current_stream().synchronize()
         st = self.L.rnde_node_forward(self.h, xd.data_ptr(), pd.data_ptr(), B, t0, t1, u.data_ptr(), C.byref(nfe), sv,
-                                      C.byref(nsv), int(keep_tape), None)
+                                      C.byref(nsv), int(keep_tape), self.stream)
         _lib.check(self.h, st)
         steps = (C.c_float * (4 * self.cfg.max_attempts))()
         natt = C.c_int32(0)
@@ -132,7 +143,8 @@ class Node:
         pb = torch.empty(P, dtype=torch.float32, device="cuda")
         tsb = (C.c_float * 2)()
         svb = None if svbar is None else (C.c_float * len(svbar))(*[float(v) for v in svbar])
-        st = self.L.rnde_node_backward(self.h, ub.data_ptr(), svb, xb.data_ptr(), pb.data_ptr(), tsb, None)
+        torch.cuda.current_stream().synchronize()
+        st = self.L.rnde_node_backward(self.h, ub.data_ptr(), svb, xb.data_ptr(), pb.data_ptr(), tsb, self.stream)
         _lib.check(self.h, st)
         return xb.cpu().numpy(), pb.cpu().numpy(), np.array([tsb[0], tsb[1]], dtype=np.float32)
 

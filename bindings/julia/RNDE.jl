@@ -252,4 +252,12 @@ allreduce_sum!(comm::Ptr{Cvoid}, g::ROCVector{Float32}) = GC.@preserve g begin
     g
 end
 
+# SURVEY 8e mode 2: ONE step-size controller for all column shards of a minibatch (rnde_node_set_coupling): every rank calls it with
+# its communicator and the global batch; `comm = C_NULL` returns to independent controllers.  Equal shards, the same calls on every rank.
+function set_coupling!(h::Handle, comm::Ptr{Cvoid}, global_batch::Integer)
+    st = ccall((:rnde_node_set_coupling, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int32), h.ptr, comm, global_batch)
+    st == 0 || error("rnde_node_set_coupling: ", unsafe_string(ccall((:rnde_last_error, LIB), Cstring, (Ptr{Cvoid},), h.ptr)))
+    return h
+end
+
 end # module

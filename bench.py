@@ -366,7 +366,7 @@ def main():
                "controller": "coupled (one controller for all ranks, SURVEY 8e mode 2)" if args.coupled else "independent per rank (SURVEY 8e mode 1)",
                "collective": (None if not use_dist else "rnde_comm_allreduce (RCCL via librnde.so): head gradient queued before the reverse sweep, "
                               "solve gradient behind it; 1/world folded into the optimiser launch"),
-               "config": {"workload": "MNIST NODE regularized (error_est), Tsit5 reltol=abstol=1.4e-8, batch 512 per GPU, "
+               "config": {"workload": f"MNIST NODE regularized (error_est), Tsit5 reltol=abstol=1.4e-8, batch {B} per GPU, "
                                       "1xMI355X per rank; step = loss fwd + reverse pass through the solver + "
                                       "InvDecay/Momentum update; the weights train during the timed steps (mean_nfe drifts with "
                                       "--steps: value_fixed_weights is the stationary companion)", "global_batch": world * B,

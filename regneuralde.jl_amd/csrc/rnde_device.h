@@ -276,7 +276,7 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
 __device__ __forceinline__ void dma_unit(const f32x4* __restrict__ gsrc_lane, float* lds_slot_uniform) {
-#ifndef RNDE_EXP_NODMA   // (ablation builds only: tools/ablate.sh)
+#ifndef RNDE_EXP_NODMA   // (ablation builds only: tools/build_variant.sh NAME -DRNDE_EXP_NODMA)
     __builtin_amdgcn_global_load_lds((gbl_void_t*)gsrc_lane, (lds_void_t*)lds_slot_uniform, 16, 0, 0);
 #endif
 }

@@ -100,7 +100,7 @@ __device__ __forceinline__ void eval_f(const StepParams& P, float* GL, float* HL
     using G = Geo<NG>;
     const int lane = tid & 63, wave = tid >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-#ifdef RNDE_DIAG   // diagnostic build only (tools/diag.sh): s_memtime stamps of workgroup 0, never in the product build
+#ifdef RNDE_DIAG   // diagnostic build only (tools/build_diag.sh): s_memtime stamps of workgroup 0, never in the product build
 #define RNDE_STAMP(i) do { if (P.dbg_out && blockIdx.x == 0 && lane == 0) ((unsigned long long*)P.dbg_out)[(wave_u * 8 + (i))] = clock64(); } while (0)
 #else
 #define RNDE_STAMP(i) do { } while (0)

@@ -799,6 +799,10 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
                 h->err = "a persistent kernel abandoned its hand-off during or after the previous asynchronous reverse pass: the gradients of that step are invalid (multi-launch kernels now in use)";
                 return RNDE_ERR_HIP;
             }
+            if (h->couple) {   // a redo on this rank alone would leave the ranks' all-reduce sequences out of step
+                h->err = "coupled controller: a persistent kernel abandoned its hand-off; the ranks are out of step -- use cfg.persist = -1 (7-launch kernels) with rnde_node_set_coupling where other work shares the GPU";
+                return RNDE_ERR_HIP;
+            }
             return RNDE_INTERNAL_RETRY;
         }
         h->pending_bwd = false;

@@ -5,9 +5,10 @@ import ctypes as C, sys
 sys.path.insert(0, '.')
 from tests.test_gpu_forward import _setup, _cfg
 from tests.util import Node
-B = 512
+import os
+B = int(os.environ.get('AB_B', '512'))
 arch, p, x = _setup("mnist", B, 7, 1.0)
-n = Node(_cfg(arch, B, max_attempts=64, col_tile=16))
+n = Node(_cfg(arch, B, max_attempts=16 if B > 1024 else 64, col_tile=16))
 us = C.c_float(0); ust = C.c_float(0)
 n.L.rnde_bench_attempt(n.h, n.dev(x).data_ptr(), n.dev(p).data_ptr(), B, 300, C.byref(us), None)
 n.L.rnde_bench_attempt_taped(n.h, n.dev(x).data_ptr(), n.dev(p).data_ptr(), B, 300, C.byref(ust), None)

@@ -144,9 +144,12 @@ def bench_nsde(args):
     stats = {"att": [], "acc": [], "solve_ms": [], "rev_ms": []}
 
     def step(record):
-        opt.zero_grad(set_to_none=True)
-        loss, ce, reg, nfe1, nfe2 = rn.nsde_loss_function(x, y, model, trajectories=1, lam=10.0)
-        loss.backward()
+        if args.autograd:
+            opt.zero_grad(set_to_none=True)
+            loss, ce, reg, nfe1, nfe2 = rn.nsde_loss_function(x, y, model, trajectories=1, lam=10.0)
+            loss.backward()
+        else:   # the same loss and gradients without a tape library in the loop (nsde.fused_nsde_loss_and_grad)
+            loss, ce, reg, nfe1, nfe2 = rn.fused_nsde_loss_and_grad(model, x, y, trajectories=1, lam=10.0)
         opt.step()
         if record:
             h = nsde._handles[0][0]

@@ -219,3 +219,51 @@ def nsde_loss_function(x, y, model, p1=None, p2=None, p3=None, trajectories=1, l
     ce = logitcrossentropy(pred, y)
     reg = lam * agg(sv.saveval) if (regularize and sv is not None) else torch.zeros((), device=pred.device)
     return ce + reg, ce, reg, nfe1, nfe2
+
+
+def fused_nsde_loss_and_grad(model, x, y, trajectories=1, lam=1.0e2, regularize=True):
+    """One training-step gradient of `nsde_loss_function` (agg = mean) without a tape library in the loop, the counterpart of
+    classifier.fused_loss_and_grad for ClassifierNSDE: [Dense pre-layer] -> [solve, taped: ONE launch] -> [Dense post-layer, trajectory
+    mean, logitcrossentropy and their reverse as a handful of matrix products] -> [reverse sweep: ONE launch] -> [pre-layer gradient].
+    Sets .grad on p1, p2, p3; returns (total_loss, cross_entropy, reg, nfe1, nfe2) with the losses as device tensors / floats.
+    Same arithmetic as autograd through ClassifierNSDE.__call__ (tests/test_gpu_nsde.py compares the two)."""
+    nsde = model.nsde
+    for name, t in (("x", x), ("y", y), ("p1", model.p1), ("p2", model.p2), ("p3", model.p3)):
+        _check_f32(name, t)
+    L = _lib.lib()
+    with torch.no_grad():
+        bsize = x.shape[0]
+        xe = _expand(x.reshape(bsize, -1), trajectories).contiguous()
+        p1, p2, p3 = model.p1.detach(), model.p2.detach().contiguous(), model.p3.detach()
+        n_in, n_h = model.pre_shape
+        W1, b1 = p1[: n_in * n_h].view(n_in, n_h), p1[n_in * n_h:]
+        h = torch.addmm(b1, xe, W1)                                              # supervised_classification.jl:93-94
+        B, D = h.shape
+        hd = nsde._acquire(h)
+        n1, n2, nsv = C.c_int64(0), C.c_int64(0), C.c_int32(0)
+        sv_host = (C.c_float * (nsde.max_attempts + 1))()
+        stream = C.c_void_p(torch.cuda.current_stream(h.device).cuda_stream)
+        u = torch.empty_like(h)
+        nsde.seed += 1
+        _lib.check_nsde(hd.ptr, L.rnde_nsde_forward(hd.ptr, h.data_ptr(), p2.data_ptr(), B, nsde.tspan[0], nsde.tspan[1], None, 0, nsde.seed,
+                                                     u.data_ptr(), C.byref(n1), C.byref(n2), sv_host, C.byref(nsv), 1, stream))
+        nsde.last_nfe = (int(n1.value), int(n2.value))
+        n_u, n_c = model.post_shape
+        W3, b3 = p3[: n_u * n_c].view(n_u, n_c), p3[n_u * n_c:]
+        z = torch.addmm(b3, u, W3).view(trajectories, bsize, n_c).mean(dim=0)    # :96-98
+        logp = torch.log_softmax(z, dim=1)
+        ce = -(y * logp).sum() / bsize                                           # Flux.Losses.logitcrossentropy
+        dz = ((torch.exp(logp) * y.sum(dim=1, keepdim=True) - y) / (bsize * trajectories)).repeat(trajectories, 1)
+        p3bar = torch.cat([(u.t() @ dz).reshape(-1), dz.sum(dim=0)])
+        ubar = (dz @ W3.t()).contiguous()
+        n = nsv.value
+        reg, svb = 0.0, None
+        if regularize and nsde.regularize and n > 0:
+            reg = lam * sum(sv_host[:n]) / n                                     # lambda * mean(sv.saveval)
+            svb = (C.c_float * n)(*([lam / n] * n))
+        hbar = torch.empty_like(h)
+        p2bar = torch.empty_like(p2)
+        _lib.check_nsde(hd.ptr, L.rnde_nsde_backward(hd.ptr, ubar.data_ptr(), svb, hbar.data_ptr(), p2bar.data_ptr(), stream))
+        p1bar = torch.cat([(xe.t() @ hbar).reshape(-1), hbar.sum(dim=0)])
+        model.p1.grad, model.p2.grad, model.p3.grad = p1bar, p2bar, p3bar
+    return ce + reg, ce, reg, int(n1.value), int(n2.value)

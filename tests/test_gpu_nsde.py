@@ -305,6 +305,32 @@ def test_classifier_nsde_trajectories():
     assert all(p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().max() > 0 for p in model.trainable())
 
 
+@pytest.mark.parametrize("T", [1, 3])
+def test_fused_nsde_step_matches_autograd(T):
+    """fused_nsde_loss_and_grad (no tape library in the loop) against torch.autograd through ClassifierNSDE: same library noise stream
+    (same seed), same loss and the same three gradients."""
+    import torch
+    import regneuralde_jl_amd as rn
+    B = 16
+
+    def make():
+        g = torch.Generator().manual_seed(9)
+        nsde = rn.TrackedNeuralDSDE(rn.Chain(rn.Dense(32, 64, "tanh", g), rn.Dense(64, 32, "identity", g)), rn.Dense(32, 32, "identity", g),
+                                    [0.0, 1.0], True, "SOSRI", reltol=0.14, abstol=0.14, max_batch=B * T, seed=77)
+        return rn.ClassifierNSDE(rn.Dense(784, 32, "identity", g), nsde, rn.Dense(32, 10, "identity", g)), g
+    m1, g = make()
+    m2, _ = make()
+    x = torch.rand(B, 784, generator=g).cuda()
+    y = torch.eye(10)[torch.randint(0, 10, (B,), generator=g)].cuda()
+    loss1, ce1, reg1, a1, b1 = rn.nsde_loss_function(x, y, m1, trajectories=T, lam=10.0)
+    loss1.backward()
+    loss2, ce2, reg2, a2, b2 = rn.fused_nsde_loss_and_grad(m2, x, y, trajectories=T, lam=10.0)
+    assert (a1, b1) == (a2, b2)
+    assert abs(float(loss1.detach()) - float(loss2)) <= 1e-5 * max(1.0, abs(float(loss1.detach())))
+    for p, q in zip(m1.trainable(), m2.trainable()):
+        assert torch.allclose(p.grad, q.grad, rtol=1e-4, atol=1e-6 * float(p.grad.abs().max())), float((p.grad - q.grad).abs().max())
+
+
 def test_dropped_graph_returns_the_handle():
     """A taped forward whose graph is dropped without backward() must not pin its handle (and tape) for ever -- the reference's
     per-epoch NFE probe `_, nfe, _ = node(dummy)` (experiments/mnist_node.jl:236) runs with tracking on."""

@@ -80,5 +80,66 @@ def main():
         print(name, "nfe", out["nfe_f32"], out["nfe_f64"], "bytes", os.path.getsize(os.path.join(HERE, name + ".npz")))
 
 
+# ---- second generation of fixtures (round 2): the stochastic layer and the tableau-as-data pair -----------------------------------
+def lcg_normal(n, seed):
+    """Standard normals from the portable LCG (Box-Muller on pairs of uniforms)."""
+    u = lcg_uniform(2 * n, seed, 1e-12, 1.0)
+    return np.sqrt(-2.0 * np.log(u[0::2])) * np.cos(2.0 * np.pi * u[1::2])
+
+
+NSDE_CASES = {
+    # name: (B, tol, drift scale, diffusion scale, controller, seed, n_pool): experiments/mnist_nsde.jl:73-80 shapes (D = 32, 32 -> 64 -> 32, 32 -> 32)
+    "nsde_B8": (8, 0.14, 2.0, 0.5, {}, 31, 96),
+    "nsde_B5_rejecting": (5, 0.1, 2.5, 0.8, dict(qmax=10.0, gamma=1.0, beta2=1e-9), 32, 400),   # oscillating controller: more than half rejected
+}
+
+
+def nsde_inputs(name):
+    from oracle.oracle_sde import arch_nsde_diffusion, arch_nsde_drift
+    B, tol, sf, sg, ctrl, seed, n_pool = NSDE_CASES[name]
+    drift, diff = arch_nsde_drift(), arch_nsde_diffusion()
+    p = np.concatenate([params_for(drift, seed, sf), params_for(diff, seed + 500, sg)])
+    x = lcg_uniform(B * 32, seed + 1000, -1.0, 1.0).reshape(B, 32)
+    wu = lcg_uniform(B * 32, seed + 2000, -1.0, 1.0).reshape(B, 32)
+    noise = lcg_normal(n_pool * 2 * B * 32, seed + 3000).reshape(n_pool, 2, B, 32)
+    return drift, diff, p, x, wu, noise, tol, ctrl
+
+
+def dp5_inputs():
+    """The latent-ODE dynamics integrated with Dormand-Prince 5(4) (RNDE_SOLVER_DP5, the tableau-as-data kernels)."""
+    return inputs("latent_B4")
+
+
+def main2():
+    from oracle.oracle_sde import SdeOracle
+    for name in NSDE_CASES:
+        drift, diff, p, x, wu, noise, tol, ctrl = nsde_inputs(name)
+        out = {}
+        for tag, dt in (("f32", np.float32), ("f64", np.float64)):
+            o = SdeOracle(drift, diff, dt, tol, tol, tableau="SOSRI", max_attempts=399, **ctrl)
+            r = o.forward(x, p, noise)
+            assert r["rc"] == 0
+            xb, pb = o.backward(wu, np.full(len(r["saveval"]), 5.0))
+            out.update({f"u_{tag}": r["u"], f"nfe1_{tag}": r["nfe1"], f"nfe2_{tag}": r["nfe2"], f"saveval_{tag}": r["saveval"], f"steps_{tag}": r["steps"],
+                        f"ndraws_{tag}": r["ndraws"], f"xbar_{tag}": xb, f"pbar_{tag}": pb})
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print(name, "attempts", len(out["steps_f32"]), len(out["steps_f64"]), "rejected", int((out["steps_f32"][:, 3] == 0).sum()),
+              "bytes", os.path.getsize(os.path.join(HERE, name + ".npz")))
+    arch, p, x, wu, tol, t1 = dp5_inputs()
+    out = {}
+    for tag, dt in (("f32", np.float32), ("f64", np.float64)):
+        o = Oracle(arch, dt, reltol=tol, abstol=tol, reg_kind=1, solver="DP5")
+        r = o.forward(x, p, 0.0, t1)
+        assert r["rc"] == 0
+        xb, pb, tsb = o.backward(wu, np.full(len(r["saveval"]), 25.0))
+        out.update({f"u_{tag}": r["u"], f"nfe_{tag}": r["nfe"], f"saveval_{tag}": r["saveval"], f"steps_{tag}": r["steps"], f"xbar_{tag}": xb,
+                    f"pbar_{tag}": pb, f"tspanbar_{tag}": tsb})
+    np.savez_compressed(os.path.join(HERE, "latent_dp5_B4.npz"), **out)
+    print("latent_dp5_B4 nfe", out["nfe_f32"], out["nfe_f64"])
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "round2":
+        main2()          # (the round-1 fixtures stay as committed)
+    else:
+        main()

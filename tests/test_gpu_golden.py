@@ -59,3 +59,50 @@ def test_chain_engine_reproduces_latent_golden():
     assert rel_err(xb, g["xbar_f64"]) <= 3e-3 + 4 * sx
     assert rel_err(pb, g["pbar_f64"]) <= 3e-3 + 4 * sp
     assert np.abs(tsb - g["tspanbar_f64"]).max() <= (3e-3 + 4 * max(sx, sp)) * max(1.0, np.abs(g["tspanbar_f64"]).max())
+
+
+def test_dp5_reproduces_latent_golden():
+    """Dormand-Prince 5(4) through the tableau-as-data kernels of the chain engine against the committed DP5 fixture."""
+    from tests.test_gpu_forward import _cfg
+    from tests.util import Node, rel_err
+    from tests.golden.make_golden import dp5_inputs
+    arch, p, x, wu, tol, t1 = dp5_inputs()
+    g = np.load(os.path.join(GOLD, "latent_dp5_B4.npz"))
+    node = Node(_cfg(arch, x.shape[0], reltol=tol, abstol=tol, solver="DP5"))
+    got = node.forward(x.astype(np.float32), p.astype(np.float32), 0.0, t1, keep_tape=True)
+    assert got["nfe"] == int(g["nfe_f32"]) == int(g["nfe_f64"])
+    assert (got["steps"][:, 3] == g["steps_f64"][:, 3]).all()
+    spread = np.abs(g["u_f32"] - g["u_f64"]).max(axis=1)
+    assert (np.abs(got["u"] - g["u_f64"]).max(axis=1) <= 2e-5 + 4 * spread).all()
+    xb, pb, tsb = node.backward(wu.astype(np.float32), np.full(len(got["saveval"]), 25.0, dtype=np.float32))
+    sx, sp = rel_err(g["xbar_f32"], g["xbar_f64"]), rel_err(g["pbar_f32"], g["pbar_f64"])
+    assert rel_err(xb, g["xbar_f64"]) <= 3e-3 + 4 * sx
+    assert rel_err(pb, g["pbar_f64"]) <= 3e-3 + 4 * sp
+
+
+@pytest.mark.parametrize("mw", ["1", "0"])
+@pytest.mark.parametrize("name,replay", [("nsde_B8", False), ("nsde_B5_rejecting", True)])
+def test_nsde_reproduces_golden(name, replay, mw, monkeypatch):
+    """The stochastic layer (config 5 shapes, SOSRI) against the committed fixtures, both whole-solve kernels: same noise pool (portable
+    LCG + Box-Muller), same attempts, accept/reject sequence, draws; states 2e-4, cotangents 1e-3 of the largest entry (fp64 fixture as
+    arbiter).  The oscillating-controller case follows the fixture's own (dt, accept) sequence (a borderline accept would otherwise
+    part the sequences: tests/test_gpu_nsde.py), which checks the rejection bookkeeping step for step."""
+    from tests.golden.make_golden import NSDE_CASES, nsde_inputs
+    from tests.test_gpu_nsde import _cfg
+    from tests.util import NsdeNode, rel_err
+    monkeypatch.setenv("RNDE_SDE_MW", mw)
+    drift, diff, p, x, wu, noise, tol, ctrl = nsde_inputs(name)
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    node = NsdeNode(_cfg(drift, diff, x.shape[0], reltol=tol, abstol=tol, solver="SOSRI", max_attempts=399, **ctrl))
+    steps = g["steps_f32"]
+    got = node.forward(x.astype(np.float32), p.astype(np.float32), noise.astype(np.float32), keep_tape=True,
+                       replay=np.stack([steps[:, 1], steps[:, 3]], 1) if replay else None)
+    assert got["nattempts"] == len(steps) == len(g["steps_f64"]) and np.array_equal(got["steps"][:, 3], steps[:, 3])
+    assert got["ndraws"] == int(g["ndraws_f32"]) and got["nfe1"] == int(g["nfe1_f32"]) and got["nfe2"] == int(g["nfe2_f32"])
+    assert np.abs(got["u"] - g["u_f64"]).max() <= 2e-4 * max(1.0, np.abs(g["u_f64"]).max()) + 4 * np.abs(g["u_f32"] - g["u_f64"]).max()
+    np.testing.assert_allclose(got["saveval"], g["saveval_f32"], rtol=2e-3, atol=1e-7)
+    xb, pb = node.backward(wu.astype(np.float32), np.full(len(got["saveval"]), 5.0, dtype=np.float32))
+    sx, sp = rel_err(g["xbar_f32"], g["xbar_f64"]), rel_err(g["pbar_f32"], g["pbar_f64"])
+    print(name, "x-bar", rel_err(xb, g["xbar_f64"]), "(oracle f32:", sx, ") p-bar", rel_err(pb, g["pbar_f64"]), "(oracle f32:", sp, ")")
+    assert rel_err(xb, g["xbar_f64"]) <= 1e-3 + 4 * sx
+    assert rel_err(pb, g["pbar_f64"]) <= 1e-3 + 4 * sp

@@ -242,6 +242,21 @@ def test_oracle_reproduces_golden(name, tag, dt):
     assert abs(np.linalg.norm(pb.astype(np.float64)) - float(g[f"pbar_norm_{tag}"])) <= gt * float(g[f"pbar_norm_{tag}"])
 
 
+@pytest.mark.parametrize("tag,dt", [("f32", np.float32), ("f64", np.float64)])
+def test_oracle_reproduces_dp5_golden(tag, dt):
+    from tests.golden.make_golden import dp5_inputs
+    arch, p, x, wu, tol, t1 = dp5_inputs()
+    g = np.load(os.path.join(GOLD, "latent_dp5_B4.npz"))
+    o = Oracle(arch, dt, reltol=tol, abstol=tol, reg_kind=1, solver="DP5")
+    r = o.forward(x, p, 0.0, t1)
+    assert r["nfe"] == int(g[f"nfe_{tag}"])
+    rt = 1e-12 if dt == np.float64 else 2e-5
+    np.testing.assert_allclose(r["u"], g[f"u_{tag}"], rtol=rt, atol=rt)
+    xb, pb, tsb = o.backward(wu, np.full(len(r["saveval"]), 25.0))
+    gt = 1e-9 if dt == np.float64 else 2e-3
+    np.testing.assert_allclose(pb, g[f"pbar_{tag}"], rtol=gt, atol=gt * np.abs(g[f"pbar_{tag}"]).max())
+
+
 def _read_julia_dump(path):
     out = {}
     for line in open(path):

@@ -55,6 +55,11 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
     if (tid == 0) Y.xcc[wg] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15;
 
     BSTAMP(0);
+    // the cross-workgroup partials of attempt n + 1 are requested before anything else: they come back first, and the double-precision scalar
+    // chain that needs them then runs while the weights and the nine tape arrays of this attempt are still streaming in
+    f32x4 pe[4];
+    if (!first) bpart_request(Bq, n + 1, lane, pe);
+    __builtin_amdgcn_sched_barrier(0);
     f32x4 wB[kSMaxHT], wD[kSMaxW];
 #pragma unroll
     for (int kb = 0; kb < kSMaxHT; ++kb)
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
         __builtin_amdgcn_sched_barrier(0);   // keep these requests in front of the scalar chain (the scheduler sinks them to their uses otherwise)
         BSTAMP(40);
         double tb = 0, dtpb = 0, qoldb = 0, t1b = 0, t0b = 0;
-        if (!first) finish_attempt_scalars(Bq, n + 1, lane, tb, dtpb, qoldb, t1b, t0b);
+        if (!first) finish_attempt_scalars_from(Bq, n + 1, lane, &pe, tb, dtpb, qoldb, t1b, t0b);
         BSTAMP(41);
         float coef;
         {

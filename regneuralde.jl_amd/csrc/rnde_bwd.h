@@ -135,16 +135,29 @@ __device__ __forceinline__ void f_bwd(const BwdParams& Q, float* GL, float* HL, 
 
 // finish the scalar chain of attempt m (its vector part ran in the previous launch) -> cotangents of the
 // state before attempt m.  part = that launch's per-workgroup partials {S, tau, ctau, -}.
-__device__ __forceinline__ void finish_attempt_scalars(const BwdParams& Q, int m, int lane, double& tb, double& dtpb,
-                                                       double& qoldb, double& t1b, double& t0b) {
+// the first 256 partial entries of attempt m, requested (no use yet): a caller that issues this before its other loads gets the entries
+// back first (vector memory returns in order) and can run the scalar chain while the rest is still streaming in
+__device__ __forceinline__ void bpart_request(const BwdParams& Q, int m, int lane, f32x4 (&e)[4]) {
+    const float* part = Q.bpart + (size_t)(m & 1) * Q.bpart_n * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int i = lane + 64 * q; e[q] = *(const f32x4*)(part + 4 * (size_t)(i < Q.bpart_n ? i : Q.bpart_n - 1)); }   // (unconditional requests, see sum_partials)
+}
+// e0 = bpart_request(Q, m) or nullptr (request here).  Same additions in the same order either way.
+__device__ __forceinline__ void finish_attempt_scalars_from(const BwdParams& Q, int m, int lane, const f32x4 (*e0)[4], double& tb, double& dtpb,
+                                                            double& qoldb, double& t1b, double& t0b) {
     const BState b = Q.bstate[m & 1];
     const StepMeta mm = Q.F.meta[m];
     const float* part = Q.bpart + (size_t)(m & 1) * Q.bpart_n * 4;
     double S = 0, tau = 0, ctau = 0;
     for (int base = 0; base < Q.bpart_n; base += 256) {   // four entries per lane in flight (see sum_partials)
         f32x4 e[4];
+        if (base == 0 && e0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const int i = base + lane + 64 * q; e[q] = *(const f32x4*)(part + 4 * (size_t)(i < Q.bpart_n ? i : Q.bpart_n - 1)); }   // (unconditional requests, see sum_partials)
+            for (int q = 0; q < 4; ++q) e[q] = (*e0)[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int i = base + lane + 64 * q; e[q] = *(const f32x4*)(part + 4 * (size_t)(i < Q.bpart_n ? i : Q.bpart_n - 1)); }
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) if (base + lane + 64 * q < Q.bpart_n) { S += (double)e[q][0]; tau += (double)e[q][1]; ctau += (double)e[q][2]; }
     }
@@ -154,6 +167,10 @@ __device__ __forceinline__ void finish_attempt_scalars(const BwdParams& Q, int m
     t1b = b.t1b; t0b = b.t0b;
     if (mm.flags & F_CLAMP) { t1b += dtb; tbx -= dtb; dtpb = 0; } else dtpb = dtb;
     tb = tbx; qoldb = b.qoldb;
+}
+__device__ __forceinline__ void finish_attempt_scalars(const BwdParams& Q, int m, int lane, double& tb, double& dtpb,
+                                                       double& qoldb, double& t1b, double& t0b) {
+    finish_attempt_scalars_from(Q, m, lane, nullptr, tb, dtpb, qoldb, t1b, t0b);
 }
 
 template <int NG, int ACT2>

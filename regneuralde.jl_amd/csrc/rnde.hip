@@ -280,7 +280,7 @@ static rnde_status chain_create(const rnde_node_config* c, rnde_node** out) {
     if (h->mw) ok &= dm((void**)&h->mw_tab, mw_tab_floats(h->mg) * 4);
     ok &= dm((void**)&h->ctl, 2 * sizeof(StepState)) && dm((void**)&h->ctl_final, sizeof(StepState));
     ok &= dm((void**)&h->meta, (size_t)(c->max_attempts + 1) * sizeof(StepMeta)) && dm((void**)&h->initrec, sizeof(InitRec));
-    ok &= dm((void**)&h->errpart, (size_t)6 * h->nwg_max * 4) && dm((void**)&h->initpart, (size_t)3 * h->nwg_max * 4);
+    ok &= dm((void**)&h->errpart, (size_t)(6 * h->nwg_max + 256) * 4) && dm((void**)&h->initpart, (size_t)(3 * h->nwg_max + 256) * 4);   // (+256: sum_partials reads whole 256-entry blocks)
     h->arena_recs = 2;
     ok &= dm((void**)&h->arena, (size_t)h->arena_recs * h->rec_stride * 4);
     ok &= hipHostMalloc((void**)&h->h_ctl, sizeof(StepState)) == hipSuccess;
@@ -463,7 +463,7 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
         h->h_pchk = (unsigned*)(h->h_mbox + 1016); h->h_meta = (StepMeta*)(h->h_mbox + h->mbox_meta_off);
     }
     ok &= dm((void**)&h->ctl, 2 * sizeof(StepState));
-    ok &= dm((void**)&h->errpart, (size_t)6 * h->nwg_max * 4) && dm((void**)&h->initpart, (size_t)3 * h->nwg_max * 4);
+    ok &= dm((void**)&h->errpart, (size_t)(6 * h->nwg_max + 256) * 4) && dm((void**)&h->initpart, (size_t)(3 * h->nwg_max + 256) * 4);   // (+256: sum_partials reads whole 256-entry blocks)
     // scratch records: 2 (no-tape ring); grown to max_attempts on the first taped forward
     h->arena_recs = 2;
     ok &= dm((void**)&h->arena, (size_t)h->arena_recs * h->rec_stride * 4);
@@ -1137,7 +1137,7 @@ static rnde_status bwd_prepare(rnde_node* h) {
     HIPCHK(h, hipMalloc((void**)&b.zi2, 2 * A * 4)); HIPCHK(h, hipMalloc((void**)&b.zi1, 2 * HB * 4));
     HIPCHK(h, hipMalloc((void**)&b.svb_att, (size_t)cap * 4));
     HIPCHK(h, hipMalloc((void**)&b.bstate, 2 * sizeof(BState))); HIPCHK(h, hipMalloc((void**)&b.ibstate, 2 * sizeof(IBState)));
-    HIPCHK(h, hipMalloc((void**)&b.bpart, (size_t)2 * h->nwg_max * 4 * 4)); HIPCHK(h, hipMalloc((void**)&b.ipart, (size_t)2 * h->nwg_max * 4 * 4));
+    HIPCHK(h, hipMalloc((void**)&b.bpart, (size_t)(2 * h->nwg_max + 256) * 4 * 4)); HIPCHK(h, hipMalloc((void**)&b.ipart, (size_t)2 * h->nwg_max * 4 * 4));   // (+256 entries: finish_attempt_scalars reads whole 256-entry blocks)
     HIPCHK(h, hipMalloc((void**)&b.tspan_out, 2 * 4));
     const size_t nev = (size_t)6 * cap + 2;
     HIPCHK(h, hipMalloc((void**)&b.ev1, nev * sizeof(EvalDesc))); HIPCHK(h, hipMalloc((void**)&b.ev2, nev * sizeof(EvalDesc)));
@@ -1567,7 +1567,7 @@ static rnde_status chain_mw_bwd_run(rnde_node* h, const float* u_bar_dev, const 
         HIPCHK(h, hipMalloc((void**)&b.U, Ac * 4)); HIPCHK(h, hipMalloc((void**)&b.K1, Ac * 4)); HIPCHK(h, hipMalloc((void**)&b.UB1, Ac * 4));
         HIPCHK(h, hipMalloc((void**)&b.svb_att, (size_t)cap * 4));
         HIPCHK(h, hipMalloc((void**)&b.bstate, 2 * sizeof(BState))); HIPCHK(h, hipMalloc((void**)&b.ibstate, 2 * sizeof(IBState)));
-        HIPCHK(h, hipMalloc((void**)&b.bpart, (size_t)2 * h->nwg_max * 4 * 4)); HIPCHK(h, hipMalloc((void**)&b.ipart, (size_t)2 * h->nwg_max * 4 * 4));
+        HIPCHK(h, hipMalloc((void**)&b.bpart, (size_t)(2 * h->nwg_max + 256) * 4 * 4)); HIPCHK(h, hipMalloc((void**)&b.ipart, (size_t)2 * h->nwg_max * 4 * 4));   // (+256 entries: finish_attempt_scalars reads whole 256-entry blocks)
         HIPCHK(h, hipMalloc((void**)&b.tspan_out, 2 * 4));
         HIPCHK(h, hipHostMalloc((void**)&b.h_svb, (size_t)cap * 4));
         HIPCHK(h, hipMalloc((void**)&b.slab, (size_t)96 * h->P * 4)); HIPCHK(h, hipMalloc((void**)&b.slab_r, (size_t)16 * h->P * 4));
@@ -1655,7 +1655,7 @@ static rnde_status chain_bwd_run(rnde_node* h, const float* u_bar_dev, const flo
         HIPCHK(h, hipMalloc((void**)&b.U, Ac * 4)); HIPCHK(h, hipMalloc((void**)&b.K1, Ac * 4)); HIPCHK(h, hipMalloc((void**)&b.UB1, Ac * 4));
         HIPCHK(h, hipMalloc((void**)&b.svb_att, (size_t)cap * 4));
         HIPCHK(h, hipMalloc((void**)&b.bstate, 2 * sizeof(BState))); HIPCHK(h, hipMalloc((void**)&b.ibstate, 2 * sizeof(IBState)));
-        HIPCHK(h, hipMalloc((void**)&b.bpart, (size_t)2 * h->nwg_max * 4 * 4)); HIPCHK(h, hipMalloc((void**)&b.ipart, (size_t)2 * h->nwg_max * 4 * 4));
+        HIPCHK(h, hipMalloc((void**)&b.bpart, (size_t)(2 * h->nwg_max + 256) * 4 * 4)); HIPCHK(h, hipMalloc((void**)&b.ipart, (size_t)2 * h->nwg_max * 4 * 4));   // (+256 entries: finish_attempt_scalars reads whole 256-entry blocks)
         HIPCHK(h, hipMalloc((void**)&b.tspan_out, 2 * 4));
         HIPCHK(h, hipHostMalloc((void**)&b.h_svb, (size_t)cap * 4));
         HIPCHK(h, hipMalloc((void**)&b.slab, (size_t)96 * h->P * 4)); HIPCHK(h, hipMalloc((void**)&b.slab_r, (size_t)16 * h->P * 4));

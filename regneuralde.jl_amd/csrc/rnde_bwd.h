@@ -140,7 +140,7 @@ __device__ __forceinline__ void f_bwd(const BwdParams& Q, float* GL, float* HL, 
 __device__ __forceinline__ void bpart_request(const BwdParams& Q, int m, int lane, f32x4 (&e)[4]) {
     const float* part = Q.bpart + (size_t)(m & 1) * Q.bpart_n * 4;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { const int i = lane + 64 * q; e[q] = *(const f32x4*)(part + 4 * (size_t)(i < Q.bpart_n ? i : Q.bpart_n - 1)); }   // (unconditional requests, see sum_partials)
+    for (int q = 0; q < 4; ++q) e[q] = *(const f32x4*)(part + 4 * (size_t)(lane + 64 * q));   // (whole block, one base address + immediate offsets: the array is padded; entries past n are not added)
 }
 // e0 = bpart_request(Q, m) or nullptr (request here).  Same additions in the same order either way.
 __device__ __forceinline__ void finish_attempt_scalars_from(const BwdParams& Q, int m, int lane, const f32x4 (*e0)[4], double& tb, double& dtpb,
@@ -156,7 +156,7 @@ __device__ __forceinline__ void finish_attempt_scalars_from(const BwdParams& Q, 
             for (int q = 0; q < 4; ++q) e[q] = (*e0)[q];
         } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { const int i = base + lane + 64 * q; e[q] = *(const f32x4*)(part + 4 * (size_t)(i < Q.bpart_n ? i : Q.bpart_n - 1)); }
+            for (int q = 0; q < 4; ++q) e[q] = *(const f32x4*)(part + 4 * (size_t)(base + lane + 64 * q));
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) if (base + lane + 64 * q < Q.bpart_n) { S += (double)e[q][0]; tau += (double)e[q][1]; ctau += (double)e[q][2]; }

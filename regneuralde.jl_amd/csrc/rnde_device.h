@@ -250,9 +250,9 @@ __device__ __forceinline__ double sum_partials(const float* __restrict__ part, i
     double s = 0;
     for (int base = 0; base < n; base += 256) {
         const int i0 = base + lane, i1 = i0 + 64, i2 = i0 + 128, i3 = i0 + 192;
-        // unconditional requests (index clamped, value unused past n): loads under a lane condition were compiled into two dependent cold
-        // round trips
-        const float v0 = part[i0 < n ? i0 : n - 1], v1 = part[i1 < n ? i1 : n - 1], v2 = part[i2 < n ? i2 : n - 1], v3 = part[i3 < n ? i3 : n - 1];
+        // unconditional requests of the whole 256-entry block (the arrays are padded by 256 entries; values past n are not added): loads
+        // under a lane condition were compiled into two dependent cold round trips, clamped indices into four address computations
+        const float v0 = part[i0], v1 = part[i1], v2 = part[i2], v3 = part[i3];
         if (i0 < n) s += (double)v0;
         if (i1 < n) s += (double)v1;
         if (i2 < n) s += (double)v2;

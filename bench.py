@@ -378,7 +378,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         if world == 1 and not args.no_extras and not use_dist:
-            sub = argparse.Namespace(steps=max(3, args.steps // 2), warmup=2)
+            sub = argparse.Namespace(steps=max(3, args.steps // 2), warmup=2, autograd=args.autograd)
             others = {}
             for name, fn in (("latent_config4", bench_latent), ("nsde_config5", bench_nsde)):
                 try:

@@ -48,6 +48,7 @@ struct rnde_node {
     // multi-wave kernels of the chain engine (rnde_chainmw.h): 4 waves per 16 columns, activations taped in the slab by the forward
     rnde_comm* couple = nullptr; int couple_batch = 0, couple_world = 1;   // SURVEY 8e mode 2 (rnde_node_set_coupling)
     int rk_tab = 0; RkTab rk{};   // explicit RK pair as data (DP5, or Tsit5 through the same path when RNDE_CHAIN_TAB=1)
+    int mw_lat = 0;               // the reference's latent-ODE shape (20 <-> 50, 8 layers): forward kernels with register-stationary weights
     int mw = 0; MwGeo mg{}; float* mw_tab = nullptr; float* mw_slab = nullptr; long long mw_slab_evals = 0; size_t mw_lds_f = 0, mw_lds_b = 0;
     float* cslab = nullptr; size_t cslab_floats = 0; float* ev_t = nullptr; float* h_ev_t = nullptr;   // chain reverse: (H, Z) dump, evaluation times
     int sMT = 0, sWT = 0, sR = 0, sHT = 0, sK2b = 0, sKHb = 0;
@@ -229,6 +230,12 @@ static rnde_status chain_create(const rnde_node_config* c, rnde_node** out) {
         h->mw = (fits && c->col_tile != 64 && !(e && e[0] == '0')) ? 1 : 0;
         if (c->col_tile == 65 && !fits) { g_create_err = "col_tile 65: the multi-wave kernels need the padded weight fragments in 160 KB of LDS"; delete h; return RNDE_ERR_BAD_ARG; }
         if (h->mw) h->nwg_max = ntiles;
+        {   // experiments/latent_ode.jl:113-124 exactly: eight time-independent layers whose widths alternate between 2 and 4 tiles, D <= 32
+            bool lat = h->mw && c->n_layers == kLatLayers && !c->time_dep && h->NKD == 8;
+            for (int i = 0; i <= kLatLayers && lat; ++i) lat = h->mg.mt[i] == lat_mt(i);
+            const char* e = getenv("RNDE_CHAIN_LAT");
+            h->mw_lat = (lat && !(e && e[0] == '0')) ? 1 : 0;
+        }
         if (c->solver == RNDE_SOLVER_DP5 && !h->mw) { g_create_err = "DP5 needs the multi-wave kernels (weights must fit LDS)"; delete h; return RNDE_ERR_BAD_ARG; }
         h->rk_tab = (h->mw && (c->solver == RNDE_SOLVER_DP5 || getenv("RNDE_CHAIN_TAB") != nullptr)) ? 1 : 0;
         if (h->rk_tab) {
@@ -325,19 +332,20 @@ static MwParams make_mw_params(rnde_node* h, const StepParams& P) {
     Q.slab = P.tape ? h->mw_slab : nullptr;
     return Q;
 }
-template <int NR, int MODE, int TAB>
+template <int NR, int MODE, int TAB, int LAT = 0>
 static hipError_t launch_mw_t(rnde_node* h, const MwParams& Q, int n, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)rnde_chainmw_kernel<NR, MODE, TAB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)rnde_chainmw_kernel<NR, MODE, TAB, LAT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((rnde_chainmw_kernel<NR, MODE, TAB>), dim3(Q.ntiles), dim3(kMwThreads), MODE == MW_FINISH ? 0 : h->mw_lds_f, s, Q, n);
+    hipLaunchKernelGGL((rnde_chainmw_kernel<NR, MODE, TAB, LAT>), dim3(Q.ntiles), dim3(kMwThreads), MODE == MW_FINISH ? 0 : h->mw_lds_f, s, Q, n);
     return hipGetLastError();
 }
 template <int MODE>
 static hipError_t launch_mw(rnde_node* h, const MwParams& Q, int n, hipStream_t s) {
+    if (h->mw_lat) return h->rk_tab ? launch_mw_t<2, MODE, 1, 1>(h, Q, n, s) : launch_mw_t<2, MODE, 0, 1>(h, Q, n, s);   // latent-ODE shape: weights register stationary
     if (h->rk_tab) {
         switch (h->NKD) {
             case 4: return launch_mw_t<1, MODE, 1>(h, Q, n, s);

@@ -190,10 +190,83 @@ __device__ __forceinline__ void mw_eval(const MwGeo& G, const float* FRm, const 
     __syncthreads();   // X is rewritten by the next evaluation's input
 }
 
+// ---- the reference's latent-ODE dynamics (experiments/latent_ode.jl:113-124: 20 -> 50 -> 20 -> ... eight Dense layers, time independent) with
+// ---- the weights REGISTER STATIONARY: LAT = 1 instantiations.  mw_layer reads a layer's A fragments and its geometry every time it
+// ---- runs (16 + 16 LDS reads and a handful of scalar loads in front of at most 16 MFMAs, 48 times per attempted step); here a wave
+// ---- loads the fragments of ITS output tile of every layer once per launch (8 x 8 or 16 registers), the layer loop is unrolled with the
+// ---- tile counts as constants, and the fragment table never goes to LDS at all.  Same arithmetic in the same order as mw_layer.
+constexpr int kLatLayers = 8;
+__host__ __device__ constexpr int lat_mt(int i) { return (i & 1) ? 4 : 2; }     // 16-feature tiles of width i: 20 (2 tiles), 50 (4 tiles), 20, ...
+struct LatWeights { float a[kLatLayers][16]; f32x4 b[kLatLayers]; };
+__device__ __forceinline__ void lat_load(const MwGeo& G, const float* __restrict__ tab, LatWeights& W, int wave, int lane) {
+    const float* BVg = tab + (size_t)G.nfrag_f * 64;
+    const int g = lane >> 4;
+#pragma unroll
+    for (int l = 0; l < kLatLayers; ++l) {
+        constexpr int dummy = 0; (void)dummy;
+        const int mtin = lat_mt(l), mtout = lat_mt(l + 1);
+        const int mo = wave < mtout ? wave : 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) W.a[l][j] = (j < 4 * mtin) ? tab[((size_t)G.foff[l] + (size_t)mo * mtin * 4 + (j < 4 * mtin ? j : 0)) * 64 + lane] : 0.f;
+        W.b[l] = *(const f32x4*)(BVg + l * 64 + 16 * mo + 4 * g);
+    }
+}
+template <int NR>
+__device__ __forceinline__ void mw_eval_lat(const MwGeo& G, const LatWeights& W, float* XB, float* YB, const float (&gv)[NR], float (&kv)[NR],
+                                            float* __restrict__ sl, int tid, int wave, int lane) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const float a = G.pre_act ? tanh_fast(gv[r]) : gv[r];
+        XB[tid + 256 * r] = a;
+        if (sl) sl[(size_t)G.hrow[0] * 64 + tid + 256 * r] = a;
+    }
+    __syncthreads();
+    const int g = lane >> 4, col = lane & 15;
+#pragma unroll
+    for (int l = 0; l < kLatLayers; ++l) {
+        float* X = (l & 1) ? YB : XB;
+        float* Y = (l & 1) ? XB : YB;
+        constexpr int kDummy = 0; (void)kDummy;
+        const int mtin = lat_mt(l), mtout = lat_mt(l + 1);
+        if (wave < mtout) {
+            const float* xb = X + lane;
+            float b[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) if (j < 4 * mtin) b[j] = xb[j * 64];
+            f32x4 acc0 = W.b[l], acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                if (mi < mtin) {
+                    acc0 = mfma16(W.a[l][4 * mi], b[4 * mi], acc0); acc1 = mfma16(W.a[l][4 * mi + 1], b[4 * mi + 1], acc1);
+                    acc0 = mfma16(W.a[l][4 * mi + 2], b[4 * mi + 2], acc0); acc1 = mfma16(W.a[l][4 * mi + 3], b[4 * mi + 3], acc1);
+                }
+            }
+            f32x4 o = acc0 + acc1;
+            if (G.act[l] != 0) {
+                const f32x2 t01 = tanh_fast2((f32x2){o[0], o[1]}), t23 = tanh_fast2((f32x2){o[2], o[3]});
+                o = (f32x4){t01.x, t01.y, t23.x, t23.y};
+            }
+            float* yp = Y + (16 * wave + 4 * g) * 16 + col;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) yp[i * 16] = o[i];
+            if (sl) {
+                float* sp = sl + (size_t)G.hrow[l + 1] * 64 + (16 * wave + 4 * g) * 16 + col;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sp[i * 16] = o[i];
+            }
+        }
+        __syncthreads();
+    }
+    float* X = (kLatLayers & 1) ? YB : XB;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) kv[r] = ((tid + 256 * r) >> 4) < 16 * lat_mt(kLatLayers) ? X[tid + 256 * r] : 0.f;
+    __syncthreads();
+}
+
 enum { MW_STEP = 0, MW_INIT_A = 1, MW_INIT_B = 2, MW_FEVAL = 3, MW_FINISH = 4 };
 
 // NR = NKD / 4 registers per state array and lane (NKD = 4, 8, 16 k-steps of D as in rnde_chain.h: arena arrays are NKD * 64 floats per tile)
-template <int NR, int MODE, int TAB = 0>
+template <int NR, int MODE, int TAB = 0, int LAT = 0>
 __global__ __launch_bounds__(kMwThreads) void rnde_chainmw_kernel(const MwParams Q, const int n) {
     const StepParams& P = Q.F;
     const MwGeo& G = Q.G;
@@ -216,8 +289,15 @@ __global__ __launch_bounds__(kMwThreads) void rnde_chainmw_kernel(const MwParams
     if (MODE == MW_STEP) dbg = (unsigned long long*)P.dbg_out;
 #endif
     MW_STAMP(0);
-    if constexpr (MODE != MW_FINISH) mw_fill_lds(Q.tab, smem, (G.nfrag_f >> 2) + 4, wave, lane);
+    // LAT: this wave's weight fragments in registers for the whole launch, nothing to fill (the LDS layout is kept: XB / YB sit where they sit)
+    LatWeights LW;
+    if constexpr (MODE != MW_FINISH && LAT) lat_load(G, Q.tab, LW, wave, lane);
+    if constexpr (MODE != MW_FINISH && !LAT) mw_fill_lds(Q.tab, smem, (G.nfrag_f >> 2) + 4, wave, lane);
     MW_STAMP(1);
+    auto eval = [&](float ts, const float (&gin)[NR], float (&kout)[NR], float* slp, unsigned long long* dbgp) {
+        if constexpr (LAT) mw_eval_lat<NR>(G, LW, XB, YB, gin, kout, slp, tid, wave, lane);
+        else mw_eval<NR>(G, FRm, BV, TV, XB, YB, ts, gin, kout, slp, tid, wave, lane, dbgp);
+    };
     // element (r): feature f = (tid + 256 r) >> 4, column gcol
     const int gcol = tile * 16 + (tid & 15);
     const bool colok = gcol < P.B;
@@ -230,7 +310,7 @@ __global__ __launch_bounds__(kMwThreads) void rnde_chainmw_kernel(const MwParams
         float gv[NR], kv[NR];
 #pragma unroll
         for (int r = 0; r < NR; ++r) gv[r] = ldx(P.x, r);
-        mw_eval<NR>(G, FRm, BV, TV, XB, YB, P.forced_t, gv, kv, nullptr, tid, wave, lane);
+        eval(P.forced_t, gv, kv, nullptr, nullptr);
 #pragma unroll
         for (int r = 0; r < NR; ++r) if (valid(r)) P.dbg_out[(size_t)gcol * P.D + feat(r)] = kv[r];
         return;
@@ -260,7 +340,7 @@ __global__ __launch_bounds__(kMwThreads) void rnde_chainmw_kernel(const MwParams
             } else gv[r] = xv[r];
         }
         float* sl = (slab_tile && P.tape) ? slab_tile + (size_t)(MODE == MW_INIT_B ? 1 : 0) * Q.ev_stride : nullptr;
-        mw_eval<NR>(G, FRm, BV, TV, XB, YB, (MODE == MW_INIT_B) ? P.t0 + dt0 : P.t0, gv, kv, sl, tid, wave, lane);
+        eval((MODE == MW_INIT_B) ? P.t0 + dt0 : P.t0, gv, kv, sl, nullptr);
         float pa = 0.f, pb = 0.f;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
@@ -366,7 +446,7 @@ __global__ __launch_bounds__(kMwThreads) void rnde_chainmw_kernel(const MwParams
             }
             float* sl = (slab_tile && P.tape) ? slab_tile + (size_t)(2 + 6 * n + (s - 1)) * Q.ev_stride : nullptr;
             MW_STAMP(2 + s);
-            mw_eval<NR>(G, FRm, BV, TV, XB, YB, t + rk_c<TAB>(Q.rk, s) * dt, gq, kv, sl, tid, wave, lane, s == 1 ? dbg : nullptr);
+            eval(t + rk_c<TAB>(Q.rk, s) * dt, gq, kv, sl, s == 1 ? dbg : nullptr);
             if (s == 5 && P.reg_kind >= 2) {
 #pragma unroll
                 for (int r = 0; r < NR; ++r) { g6[r] = gq[r]; k6[r] = kv[r]; }

@@ -1533,13 +1533,13 @@ static hipError_t launch_bchain_t(rnde_node* h, const BChainParams& Q, const std
 
 
 // ---- chain engine, multi-wave kernels: reverse pass (rnde_bchainmw.h) ------------------------------------------------------
-template <int NR, int TAB>
+template <int NR, int TAB, int LAT = 0>
 static hipError_t launch_bmw_t(rnde_node* h, const BMwParams& Q, const std::vector<int>& sv_lo, const std::vector<int>& sv_hi, hipStream_t s) {
     const BwdBuffers& b = h->bw;
     const size_t lds = h->mw_lds_b;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)rnde_bchainmw_kernel<NR, TAB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)rnde_bchainmw_kernel<NR, TAB, LAT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rnde_bchainmw_init_kernel<NR, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rnde_bchainmw_init_kernel<NR, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -1557,7 +1557,7 @@ static hipError_t launch_bmw_t(rnde_node* h, const BMwParams& Q, const std::vect
             c1 = (float)(eigb / ((double)mm.n2 * (double)mm.n1));
             c2 = (float)(-eigb * ((double)mm.n1 / (double)mm.n2) / ((double)mm.n2 * (double)mm.n2));
         }
-        hipLaunchKernelGGL((rnde_bchainmw_kernel<NR, TAB>), grid, blk, lds, s, Q, n, mm, sv_lo[n], sv_hi[n], c1, c2);
+        hipLaunchKernelGGL((rnde_bchainmw_kernel<NR, TAB, LAT>), grid, blk, lds, s, Q, n, mm, sv_lo[n], sv_hi[n], c1, c2);
     }
     hipLaunchKernelGGL((rnde_bchainmw_init_kernel<NR, 1>), grid, blk, lds, s, Q);
     hipLaunchKernelGGL((rnde_bchainmw_init_kernel<NR, 2>), grid, blk, lds, s, Q);
@@ -1617,7 +1617,8 @@ static rnde_status chain_mw_bwd_run(rnde_node* h, const float* u_bar_dev, const 
     }
     HIPCHK(h, hipMemcpyAsync(h->ev_t, h->h_ev_t, (size_t)n_evals * 4, hipMemcpyHostToDevice, s));
     hipError_t e;
-    if (h->rk_tab) e = h->NKD == 4 ? launch_bmw_t<1, 1>(h, Q, sv_lo, sv_hi, s) : (h->NKD == 8 ? launch_bmw_t<2, 1>(h, Q, sv_lo, sv_hi, s) : launch_bmw_t<4, 1>(h, Q, sv_lo, sv_hi, s));
+    if (h->mw_lat) e = h->rk_tab ? launch_bmw_t<2, 1, 1>(h, Q, sv_lo, sv_hi, s) : launch_bmw_t<2, 0, 1>(h, Q, sv_lo, sv_hi, s);   // latent-ODE shape: transposed weights register stationary
+    else if (h->rk_tab) e = h->NKD == 4 ? launch_bmw_t<1, 1>(h, Q, sv_lo, sv_hi, s) : (h->NKD == 8 ? launch_bmw_t<2, 1>(h, Q, sv_lo, sv_hi, s) : launch_bmw_t<4, 1>(h, Q, sv_lo, sv_hi, s));
     else e = h->NKD == 4 ? launch_bmw_t<1, 0>(h, Q, sv_lo, sv_hi, s) : (h->NKD == 8 ? launch_bmw_t<2, 0>(h, Q, sv_lo, sv_hi, s) : launch_bmw_t<4, 0>(h, Q, sv_lo, sv_hi, s));
     HIPCHK(h, e);
     // parameter gradients of all layers over all evaluations: the one-wave engine's kernel on the same slab format

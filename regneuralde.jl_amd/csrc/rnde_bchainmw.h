@@ -112,7 +112,88 @@ __device__ __forceinline__ void mw_fbwd(const MwGeo& G, const float* FRt, const 
     tau += tl;
 }
 
-template <int NR, int TAB = 0>
+// ---- the latent-ODE shape (rnde_chainmw.h: lat_mt) with the transposed fragments REGISTER STATIONARY: wave w holds, for every layer, the
+// ---- fragments of input tile w (8 k-steps of the 20-wide layers' cotangents, 16 of the 50-wide ones); the transposed table never goes to LDS.
+// ---- Same arithmetic in the same order as mw_fbwd.
+struct LatWeightsT { float a[kLatLayers][16]; };
+__device__ __forceinline__ void lat_load_t(const MwGeo& G, const float* __restrict__ tab, LatWeightsT& W, int wave, int lane) {
+    const float* FRtg = tab + (size_t)G.nfrag_f * 64 + 1024;
+#pragma unroll
+    for (int l = 0; l < kLatLayers; ++l) {
+        const int mtin = lat_mt(l), mtout = lat_mt(l + 1);
+        const int mi = wave < mtin ? wave : 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) W.a[l][j] = (j < 4 * mtout) ? FRtg[((size_t)G.toff[l] + (size_t)mi * mtout * 4 + (j < 4 * mtout ? j : 0)) * 64 + lane] : 0.f;
+    }
+}
+template <int NR>
+__device__ __forceinline__ void mw_fbwd_lat(const MwGeo& G, const LatWeightsT& W, float* ZA, float* ZB, float* __restrict__ sl,
+                                            const float (&gin)[NR], const float (&kout)[NR], const float (&kbar)[NR], float (&gb)[NR],
+                                            int tid, int wave, int lane) {
+    const int g = lane >> 4, col = lane & 15;
+    f32x4 oo[kLatLayers];
+#pragma unroll
+    for (int l = 1; l < kLatLayers; ++l) {
+        oo[l] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (wave < lat_mt(l) && G.act[l - 1] != 0) {
+            const float* hp = sl + (size_t)G.hrow[l] * 64 + (16 * wave + 4 * g) * 16 + col;
+            oo[l] = (f32x4){hp[0], hp[16], hp[32], hp[48]};
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int e = tid + 256 * r;
+        float v = kbar[r];
+        if (G.act[kLatLayers - 1] != 0) v *= (1.f - kout[r] * kout[r]);
+        if (e < 16 * 16 * lat_mt(kLatLayers)) { ZA[e] = v; sl[(size_t)G.zrow[kLatLayers - 1] * 64 + e] = v; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int l = kLatLayers - 1; l >= 0; --l) {
+        float* Zc = ((kLatLayers - 1 - l) & 1) ? ZB : ZA;
+        float* Zn = ((kLatLayers - 1 - l) & 1) ? ZA : ZB;
+        const int mtin = lat_mt(l), mtout = lat_mt(l + 1);
+        if (wave < mtin) {
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            const float* zb = Zc + lane;
+            float b[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) if (j < 4 * mtout) b[j] = zb[j * 64];
+#pragma unroll
+            for (int mo = 0; mo < 4; ++mo) {
+                if (mo < mtout) {
+                    acc0 = mfma16(W.a[l][4 * mo], b[4 * mo], acc0); acc1 = mfma16(W.a[l][4 * mo + 1], b[4 * mo + 1], acc1);
+                    acc0 = mfma16(W.a[l][4 * mo + 2], b[4 * mo + 2], acc0); acc1 = mfma16(W.a[l][4 * mo + 3], b[4 * mo + 3], acc1);
+                }
+            }
+            f32x4 o = acc0 + acc1;
+            float* zp = Zn + (16 * wave + 4 * g) * 16 + col;
+            if (l > 0) {
+                if (G.act[l - 1] != 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] *= (1.f - oo[l][i] * oo[l][i]);
+                }
+                float* sp = sl + (size_t)G.zrow[l - 1] * 64 + (16 * wave + 4 * g) * 16 + col;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { zp[i * 16] = o[i]; sp[i * 16] = o[i]; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) zp[i * 16] = o[i];
+            }
+        }
+        __syncthreads();
+    }
+    float* Zc = (kLatLayers & 1) ? ZB : ZA;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        float v = ((tid + 256 * r) >> 4) < 16 * lat_mt(0) ? Zc[tid + 256 * r] : 0.f;
+        if (G.pre_act) { const float a0 = tanh_fast(gin[r]); v *= (1.f - a0 * a0); }
+        gb[r] = v;
+    }
+    __syncthreads();
+}
+
+template <int NR, int TAB = 0, int LAT = 0>
 __global__ __launch_bounds__(kMwThreads) void rnde_bchainmw_kernel(const BMwParams Q, const int n, const StepMeta m, const int sv_lo, const int sv_hi,
                                                                    const float eig_c1, const float eig_c2) {
     const BwdParams& Bq = Q.B;
@@ -136,7 +217,13 @@ __global__ __launch_bounds__(kMwThreads) void rnde_bchainmw_kernel(const BMwPara
     const size_t fo = (size_t)tile * NKD * 64 + tid;
     auto feat = [&](int r) { return (tid + 256 * r) >> 4; };
     auto valid = [&](int r) { return colok && feat(r) < P.D; };
-    mw_fill_lds(Q.tab + (size_t)G.nfrag_f * 64, smem, (G.nfrag_t >> 2) + 4, wave, lane);
+    LatWeightsT LT;
+    if constexpr (LAT) lat_load_t(G, Q.tab, LT, wave, lane);      // (the latent-ODE shape: transposed fragments in registers, no LDS fill)
+    else mw_fill_lds(Q.tab + (size_t)G.nfrag_f * 64, smem, (G.nfrag_t >> 2) + 4, wave, lane);
+    auto fbwd = [&](float* slp, const float (&gin_)[NR], const float (&kout_)[NR], const float (&kbar_)[NR], float (&gb_)[NR], float& tau_) {
+        if constexpr (LAT) mw_fbwd_lat<NR>(G, LT, ZA, ZB, slp, gin_, kout_, kbar_, gb_, tid, wave, lane);
+        else mw_fbwd<NR>(G, FRt, TV, ZA, ZB, slp, gin_, kout_, kbar_, gb_, tau_, tid, wave, lane);
+    };
     // ---- scalar chain, identical in every wave; same arithmetic as rnde_bchain_kernel ----
     double tb = 0, dtpb = 0, qoldb = 0, t1b = 0, t0b = 0;
     if (!first) finish_attempt_scalars(Bq, n + 1, lane, tb, dtpb, qoldb, t1b, t0b);
@@ -259,7 +346,7 @@ __global__ __launch_bounds__(kMwThreads) void rnde_bchainmw_kernel(const BMwPara
             }
         }
         float t7 = 0.f;
-        mw_fbwd<NR>(G, FRt, TV, ZA, ZB, sl0 + 5 * Q.ev_stride, unv, k7, kb7, gb, t7, tid, wave, lane);
+        fbwd(sl0 + 5 * Q.ev_stride, unv, k7, kb7, gb, t7);
         tau += t7; ctau += t7;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
@@ -282,7 +369,7 @@ __global__ __launch_bounds__(kMwThreads) void rnde_bchainmw_kernel(const BMwPara
             if (has_eig && s == 5) kb[r] += exk[r];          // direct cotangent of k6
         }
         float ts_ = 0.f;
-        mw_fbwd<NR>(G, FRt, TV, ZA, ZB, sl0 + (size_t)(s - 1) * Q.ev_stride, gs, ks, kb, gb, ts_, tid, wave, lane);
+        fbwd(sl0 + (size_t)(s - 1) * Q.ev_stride, gs, ks, kb, gb, ts_);
         tau += ts_; ctau += rk_c<TAB>(Q.rk, s) * ts_;
         if (has_eig && s == 5) {
 #pragma unroll

@@ -369,3 +369,24 @@ def test_dp5_is_refused_where_the_table_kernels_do_not_run():
         Node(_cfg(_arch("latent"), 8, regularize=2, solver="DP5"))         # stiffness callbacks are wired for Tsit5 only
     with pytest.raises(Exception):
         Node(_cfg(arch_mnist(), 8, col_tile=16, solver="DP5"))             # stage engine
+
+
+def test_latent_shape_kernels_equal_the_generic_multi_wave_kernels(monkeypatch, _mw_only):
+    """The latent-ODE shape runs kernels with register-stationary weights (rnde_chainmw.h: LAT); RNDE_CHAIN_LAT=0 keeps the generic
+    multi-wave kernels on the same network: same arithmetic in the same order -> the same bits, forward and reverse."""
+    from tests.util import Node
+    arch, p, x = _setup("latent", 70, 5, 1.5)
+    sa = np.linspace(0, 1, 9).astype(np.float32)
+
+    def run():
+        node = Node(_cfg(arch, 70, reltol=1e-4, abstol=1e-4))
+        got = node.forward_saveat(x, p, sa, keep_tape=True)
+        ubar = np.random.default_rng(16).standard_normal(got["u"].shape).astype(np.float32)
+        return got, node.backward(ubar, np.full(len(got["saveval"]), 5.0, dtype=np.float32))
+
+    a, ga = run()
+    monkeypatch.setenv("RNDE_CHAIN_LAT", "0")
+    b, gb = run()
+    assert a["nfe"] == b["nfe"] and np.array_equal(a["u"], b["u"]) and np.array_equal(a["saveval"], b["saveval"])
+    for u, v in zip(ga, gb):
+        assert np.array_equal(u, v)

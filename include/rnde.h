@@ -312,6 +312,10 @@ rnde_status rnde_nsde_forward_replay(rnde_nsde* h, const float* x_dev, const flo
  * (the SDE step-size controller strips tracking: DESIGN.md 3.2).  Synchronises `stream` before returning. */
 rnde_status rnde_nsde_backward(rnde_nsde* h, const float* u_bar_dev, const float* saveval_bar_host, float* x_bar_dev,
                                float* p_bar_dev, void* stream);
+/* The same without the trailing synchronisation (nothing is read back on the host): the optimiser update and the next step can be
+ * queued behind it on `stream`; u_bar / x_bar / p_bar must stay alive until the stream has passed them. */
+rnde_status rnde_nsde_backward_async(rnde_nsde* h, const float* u_bar_dev, const float* saveval_bar_host, float* x_bar_dev,
+                               float* p_bar_dev, void* stream);
 /* Per-attempt log of the last forward: 4 floats per attempt (t, dt, EEst, accepted); draws_out = noise draws consumed. */
 rnde_status rnde_nsde_steps(rnde_nsde* h, float* steps_host, int32_t capacity, int32_t* n_attempts_out, int32_t* draws_out);
 /* Kernel-level parity entry: ONE attempted step from (uprev, dt, dW, dZ), all D x B device arrays: kg_out_dev receives

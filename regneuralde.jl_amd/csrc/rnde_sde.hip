@@ -429,8 +429,8 @@ extern "C" rnde_status rnde_nsde_debug_attempt(rnde_nsde* h, const float* uprev_
     return RNDE_OK;
 }
 
-extern "C" rnde_status rnde_nsde_backward(rnde_nsde* h, const float* u_bar_dev, const float* saveval_bar_host, float* x_bar_dev, float* p_bar_dev,
-                                          void* stream) {
+static rnde_status nsde_backward_impl(rnde_nsde* h, const float* u_bar_dev, const float* saveval_bar_host, float* x_bar_dev, float* p_bar_dev,
+                                      void* stream, bool sync) {
     if (!h) return RNDE_ERR_BAD_ARG;
     if (!h->have_tape) { h->err = "no recorded forward"; return RNDE_ERR_NO_TAPE; }
     hipStream_t s = (hipStream_t)stream;
@@ -518,9 +518,17 @@ extern "C" rnde_status rnde_nsde_backward(rnde_nsde* h, const float* u_bar_dev, 
         }
         SCHK(h, hipGetLastError());
     }
-    SCHK(h, hipStreamSynchronize(s));
+    if (sync) SCHK(h, hipStreamSynchronize(s));     // (nothing is read back: the synchronising form only makes "returned" mean "finished")
     h->have_tape = false;
     return RNDE_OK;
+}
+extern "C" rnde_status rnde_nsde_backward(rnde_nsde* h, const float* u_bar_dev, const float* saveval_bar_host, float* x_bar_dev, float* p_bar_dev,
+                                          void* stream) {
+    return nsde_backward_impl(h, u_bar_dev, saveval_bar_host, x_bar_dev, p_bar_dev, stream, true);
+}
+extern "C" rnde_status rnde_nsde_backward_async(rnde_nsde* h, const float* u_bar_dev, const float* saveval_bar_host, float* x_bar_dev, float* p_bar_dev,
+                                                void* stream) {
+    return nsde_backward_impl(h, u_bar_dev, saveval_bar_host, x_bar_dev, p_bar_dev, stream, false);
 }
 
 extern "C" rnde_status rnde_nsde_timing(rnde_nsde* h, float* solve_ms, float* rev_sweep_ms, int32_t* attempts, int32_t* accepted) {

@@ -263,7 +263,9 @@ def fused_nsde_loss_and_grad(model, x, y, trajectories=1, lam=1.0e2, regularize=
             svb = (C.c_float * n)(*([lam / n] * n))
         hbar = torch.empty_like(h)
         p2bar = torch.empty_like(p2)
-        _lib.check_nsde(hd.ptr, L.rnde_nsde_backward(hd.ptr, ubar.data_ptr(), svb, hbar.data_ptr(), p2bar.data_ptr(), stream))
+        # (asynchronous form: the pre-layer gradient and the optimiser update queue up behind the reverse sweep, nothing waits on the host)
+        _lib.check_nsde(hd.ptr, L.rnde_nsde_backward_async(hd.ptr, ubar.data_ptr(), svb, hbar.data_ptr(), p2bar.data_ptr(), stream))
         p1bar = torch.cat([(xe.t() @ hbar).reshape(-1), hbar.sum(dim=0)])
+        model._keep = (ubar, hbar, u, h)          # buffers the enqueued kernels still use
         model.p1.grad, model.p2.grad, model.p3.grad = p1bar, p2bar, p3bar
     return ce + reg, ce, reg, int(n1.value), int(n2.value)

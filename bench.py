@@ -137,7 +137,7 @@ def bench_nsde(args):
     nsde = rn.TrackedNeuralDSDE(rn.Chain(rn.Dense(32, 64, "tanh", g), rn.Dense(64, 32, "identity", g)), rn.Dense(32, 32, "identity", g), [0.0, 1.0], True,
                                 "SOSRI", save_everystep=False, reltol=0.14, abstol=0.14, save_start=False, max_batch=B, max_attempts=256, seed=1999)
     model = rn.ClassifierNSDE(rn.Dense(784, 32, "identity", g), nsde, rn.Dense(32, 10, "identity", g), device=device)
-    opt = torch.optim.Adam(model.trainable(), lr=0.01)
+    opt = torch.optim.Adam(model.trainable(), lr=0.01) if args.autograd else rn.FluxADAM(model.trainable(), eta=0.01)   # ADAM(0.01), mnist_nsde.jl
     x = torch.rand(B, 784, generator=g).to(device)
     y = torch.eye(NCLS)[torch.randint(0, NCLS, (B,), generator=g)].to(device)
     L = _lib.lib()

@@ -199,6 +199,11 @@ rnde_status rnde_momentum_step(float* p_dev, const float* g_dev, float* v_dev, i
  * sum-all-reduced gradient (rnde_comm_allreduce with mean = 0) into the optimiser launch. */
 rnde_status rnde_momentum_step_scaled(float* p_dev, const float* g_dev, float* v_dev, int64_t len, int64_t n, float gamma,
                                       float eta, float rho, float gscale, void* stream);
+/* Flux.Optimise.ADAM(eta, (beta1, beta2)) (the optimiser of reference experiments/mnist_nsde.jl) on one flat parameter group, one launch:
+ * m = beta1 m + (1 - beta1) g ; v = beta2 v + (1 - beta2) g^2 ; p -= eta (m / (1 - beta1^t)) / (sqrt(v / (1 - beta2^t)) + eps), with g
+ * scaled by gscale first (1 / world after a sum-all-reduce).  t = 1, 2, ... is the step being taken; m, v start at zero. */
+rnde_status rnde_adam_step(float* p_dev, const float* g_dev, float* m_dev, float* v_dev, int64_t len, int64_t t, float eta, float beta1,
+                           float beta2, float eps, float gscale, void* stream);
 
 /* ======================================================================================================================
  * Data parallelism: the one collective of a training step.  The reference is single-process; with the

@@ -156,6 +156,36 @@ class FluxOptimiser:
             p.grad = None
 
 
+class FluxADAM:
+    """Flux.Optimise.ADAM(eta, (beta1, beta2)) (experiments/mnist_nsde.jl: ADAM(0.01)), group by group, one launch per group through
+    the C ABI (rnde_adam_step); same recurrence as torch.optim.Adam (tests/test_gpu_layer.py)."""
+
+    def __init__(self, params, eta=0.001, beta=(0.9, 0.999), eps=1.0e-8):
+        self.params = [p for p in params if p.numel() > 0]
+        self.eta, self.beta, self.eps = eta, beta, eps
+        self.t = 0
+        self.m = [torch.zeros_like(p) for p in self.params]
+        self.v = [torch.zeros_like(p) for p in self.params]
+
+    @torch.no_grad()
+    def step(self, grad_scale=1.0):
+        import ctypes as C
+        from . import _lib
+        self.t += 1
+        for i, p in enumerate(self.params):
+            g = p.grad
+            if g is None:
+                continue
+            if not p.is_cuda:
+                raise RuntimeError("FluxADAM runs on the device only")
+            g = g.contiguous()
+            st = _lib.lib().rnde_adam_step(p.data_ptr(), g.data_ptr(), self.m[i].data_ptr(), self.v[i].data_ptr(), p.numel(), self.t, self.eta,
+                                           self.beta[0], self.beta[1], self.eps, float(grad_scale),
+                                           C.c_void_p(torch.cuda.current_stream(p.device).cuda_stream))
+            _lib.check(None, st)
+            p.grad = None
+
+
 def sample_tspan_ubound(b=0.5, generator=None):
     """STEER (experiments/mnist_node.jl:104-105,:133): integrate to t1 ~ U(1 - b, 1 + b) instead of 1."""
     r = float(torch.rand((), generator=generator))

@@ -1751,6 +1751,15 @@ static rnde_status chain_bwd_run(rnde_node* h, const float* u_bar_dev, const flo
     return RNDE_OK;
 }
 
+extern "C" rnde_status rnde_adam_step(float* p_dev, const float* g_dev, float* m_dev, float* v_dev, int64_t len, int64_t t, float eta, float beta1,
+                                      float beta2, float eps, float gscale, void* stream) {
+    if (!p_dev || !g_dev || !m_dev || !v_dev || len < 0 || t < 1) return RNDE_ERR_BAD_ARG;
+    if (len == 0) return RNDE_OK;
+    const float bc1 = (float)(1.0 - pow((double)beta1, (double)t)), bc2 = (float)(1.0 - pow((double)beta2, (double)t));
+    hipLaunchKernelGGL(rnde::rnde_adam_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p_dev, g_dev, m_dev, v_dev,
+                       (long long)len, gscale, eta, beta1, beta2, bc1, bc2, eps);
+    return hipGetLastError() == hipSuccess ? RNDE_OK : RNDE_ERR_HIP;
+}
 extern "C" rnde_status rnde_momentum_step_scaled(float* p_dev, const float* g_dev, float* v_dev, int64_t len, int64_t n, float gamma,
                                                  float eta, float rho, float gscale, void* stream);
 extern "C" rnde_status rnde_momentum_step(float* p_dev, const float* g_dev, float* v_dev, int64_t len, int64_t n, float gamma,

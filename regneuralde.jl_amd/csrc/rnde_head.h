@@ -137,4 +137,17 @@ __global__ __launch_bounds__(256) void rnde_momentum_kernel(float* __restrict__ 
     p[i] = p[i] + vn;
 }
 
+// Flux.Optimise.ADAM(eta, (beta1, beta2)) on one flat parameter group (include/rnde.h: rnde_adam_step; the optimiser of
+// experiments/mnist_nsde.jl).  bc1 = 1 - beta1^t, bc2 = 1 - beta2^t for the step being taken.
+__global__ __launch_bounds__(256) void rnde_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                        long long len, float gscale, float eta, float b1, float b2, float bc1, float bc2, float eps) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= len) return;
+    const float gs = g[i] * gscale;
+    const float mn = b1 * m[i] + (1.f - b1) * gs;
+    const float vn = b2 * v[i] + (1.f - b2) * gs * gs;
+    m[i] = mn; v[i] = vn;
+    p[i] = p[i] - mn / bc1 / (sqrtf(vn / bc2) + eps) * eta;
+}
+
 }  // namespace rnde

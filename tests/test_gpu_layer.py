@@ -309,3 +309,19 @@ def test_layer_with_the_dp5_pair(rnde):
     assert np.abs(u.detach().cpu().numpy() - r["u"]).max() < 2e-5
     assert np.abs(x.grad.cpu().numpy() - xb).max() <= 3e-3 * np.abs(xb).max()
     assert np.abs(p.grad.cpu().numpy() - pb).max() <= 3e-3 * np.abs(pb).max()
+
+
+def test_adam_step_matches_the_torch_recurrence(rnde):
+    """rnde_adam_step (Flux.Optimise.ADAM: the optimiser of experiments/mnist_nsde.jl) against torch.optim.Adam, five steps."""
+    rn = rnde
+    g = torch.Generator().manual_seed(5)
+    p1 = torch.randn(5248, generator=g).cuda().requires_grad_(True)
+    p2 = p1.detach().clone().requires_grad_(True)
+    opt1 = torch.optim.Adam([p1], lr=0.01, betas=(0.9, 0.999), eps=1e-8)
+    opt2 = rn.FluxADAM([p2], eta=0.01)
+    for k in range(5):
+        gr = torch.randn(5248, generator=g).cuda() * (1.0 + k)
+        p1.grad = gr.clone(); p2.grad = gr.clone()
+        opt1.step(); opt2.step()
+    torch.cuda.synchronize()
+    assert torch.allclose(p1, p2, rtol=1e-5, atol=1e-6), float((p1 - p2).abs().max())

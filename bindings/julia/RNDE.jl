@@ -238,6 +238,17 @@ function momentum_step!(p::ROCVector{Float32}, g::ROCVector{Float32}, v::ROCVect
     return p
 end
 
+# Flux.Optimise.ADAM(eta, (beta1, beta2)) on one flat parameter group (experiments/mnist_nsde.jl): m, v are the caller's state arrays (zeros at t = 1)
+function adam_step!(p::ROCVector{Float32}, g::ROCVector{Float32}, m::ROCVector{Float32}, v::ROCVector{Float32}, t::Integer;
+                    eta = 0.001f0, beta = (0.9f0, 0.999f0), eps = 1f-8, gscale = 1f0)
+    st = GC.@preserve p g m v begin
+        ccall((:rnde_adam_step, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Cfloat, Cfloat, Cfloat, Cfloat, Cfloat, Ptr{Cvoid}),
+              devptr(p), devptr(g), devptr(m), devptr(v), length(p), t, eta, beta[1], beta[2], eps, gscale, C_NULL)
+    end
+    st == 0 || error("rnde_adam_step: status $st")
+    return p
+end
+
 # one process per GPU (Distributed / MPI.jl carry the 128-byte id from rank 0 to the others)
 comm_unique_id() = (id = zeros(UInt8, 128); ccall((:rnde_comm_unique_id, LIB), Cint, (Ptr{UInt8},), id) == 0 || error("rnde_comm_unique_id"); id)
 function comm_create(id::Vector{UInt8}, rank::Integer, world::Integer, device::Integer)

@@ -423,3 +423,20 @@ def test_layer_saveat_method():
     loss = (means ** 2).mean() + sol.var(dim=0).mean() + 0.2 * sv.saveval.sum()
     loss.backward()
     assert torch.isfinite(p.grad).all() and p.grad.abs().max() > 0
+
+
+def test_more_than_4096_columns_take_the_one_wave_solve_kernel():
+    """The four-waves-per-tile solve kernel needs a workgroup per tile resident (<= 256 tiles); a ClassifierNSDE evaluation with ten
+    trajectories of a 430-sample batch is 4300 columns: the library switches to the one-wave-per-tile kernel for that call (same handle,
+    same tape layout, the reverse sweep stays on the four-wave kernel): the call contract and finite, non-trivial gradients."""
+    import torch
+    import regneuralde_jl_amd as rn
+    g = torch.Generator().manual_seed(6)
+    nsde = rn.TrackedNeuralDSDE(rn.Chain(rn.Dense(32, 64, "tanh", g), rn.Dense(64, 32, "identity", g)), rn.Dense(32, 32, "identity", g),
+                                [0.0, 1.0], True, "SOSRI", reltol=0.14, abstol=0.14, max_batch=4300)
+    x = torch.randn(4300, 32, generator=g).cuda().requires_grad_(True)
+    p = nsde.p.cuda().clone().requires_grad_(True)
+    u, nfe1, nfe2, sv = nsde(x, p, func="error_est")
+    assert u.shape == (4300, 32) and torch.isfinite(u).all() and nfe1 == nfe2 and nfe1 % 4 == 2
+    (u.sum() + sv.saveval.sum()).backward()
+    assert torch.isfinite(x.grad).all() and torch.isfinite(p.grad).all() and p.grad.abs().max() > 0

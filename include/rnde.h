@@ -321,6 +321,11 @@ rnde_status rnde_nsde_backward(rnde_nsde* h, const float* u_bar_dev, const float
  * queued behind it on `stream`; u_bar / x_bar / p_bar must stay alive until the stream has passed them. */
 rnde_status rnde_nsde_backward_async(rnde_nsde* h, const float* u_bar_dev, const float* saveval_bar_host, float* x_bar_dev,
                                float* p_bar_dev, void* stream);
+/* postsde Dense(D, C) + Flux.Losses.logitcrossentropy and their reverse for ClassifierNSDE with ONE trajectory per input (reference
+ * src/models/supervised_classification.jl:96-97, experiments/mnist_nsde.jl): same contract as rnde_classifier_head, D = the SDE's state
+ * dimension.  (With several trajectories the logits are averaged first: that stays on the host side.) */
+rnde_status rnde_nsde_classifier_head(rnde_nsde* h, const float* u_dev, const float* p3_dev, const float* y_dev, int32_t B, int32_t n_classes,
+                                      float* logits_out_dev, float* u_bar_dev, float* p3_bar_dev, float* ce_out_dev, void* stream);
 /* Per-attempt log of the last forward: 4 floats per attempt (t, dt, EEst, accepted); draws_out = noise draws consumed. */
 rnde_status rnde_nsde_steps(rnde_nsde* h, float* steps_host, int32_t capacity, int32_t* n_attempts_out, int32_t* draws_out);
 /* Kernel-level parity entry: ONE attempted step from (uprev, dt, dW, dZ), all D x B device arrays: kg_out_dev receives

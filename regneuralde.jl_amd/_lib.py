@@ -109,6 +109,7 @@ def lib():
     L.rnde_nsde_forward_replay.argtypes = [vp, vp, vp, i32, f, f, vp, i32, fp, i32, vp, i64p, i64p, fp, i32p, i32, vp]
     L.rnde_nsde_backward.argtypes = [vp, vp, fp, vp, vp, vp]
     L.rnde_nsde_backward_async.argtypes = [vp, vp, fp, vp, vp, vp]
+    L.rnde_nsde_classifier_head.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]
     L.rnde_nsde_steps.argtypes = [vp, fp, i32, i32p, i32p]
     L.rnde_nsde_debug_attempt.argtypes = [vp, vp, vp, i32, f, vp, vp, vp, vp, fp, vp]
     L.rnde_nsde_timing.argtypes = [vp, fp, fp, i32p, i32p]
@@ -124,7 +125,7 @@ EXPORTS = ["rnde_version", "rnde_last_error", "rnde_param_count", "rnde_node_cre
            "rnde_node_launches_per_attempt", "rnde_classifier_head", "rnde_momentum_step", "rnde_momentum_step_scaled", "rnde_adam_step",
            "rnde_comm_unique_id", "rnde_comm_create", "rnde_comm_destroy", "rnde_comm_world", "rnde_comm_last_error", "rnde_comm_allreduce", "rnde_comm_create_local_group", "rnde_comm_health", "rnde_node_set_coupling",
            "rnde_nsde_param_count", "rnde_nsde_create", "rnde_nsde_destroy", "rnde_nsde_last_error", "rnde_nsde_forward",
-           "rnde_nsde_forward_saveat", "rnde_nsde_forward_replay", "rnde_nsde_backward", "rnde_nsde_backward_async", "rnde_nsde_steps", "rnde_nsde_debug_attempt", "rnde_nsde_timing", "rnde_normal_fill"]
+           "rnde_nsde_forward_saveat", "rnde_nsde_forward_replay", "rnde_nsde_backward", "rnde_nsde_backward_async", "rnde_nsde_classifier_head", "rnde_nsde_steps", "rnde_nsde_debug_attempt", "rnde_nsde_timing", "rnde_normal_fill"]
 
 
 def check(h, status):

@@ -6,6 +6,7 @@
 #define rnde rnde_sde_tu
 #include "rnde_sde.h"
 #include "rnde_sdemw.h"
+#include "rnde_head.h"
 
 #include <algorithm>
 #include <cmath>
@@ -20,6 +21,7 @@ using namespace rnde;
 struct rnde_nsde {
     rnde_nsde_config cfg{};
     int D = 0, Pf = 0, Pg = 0, P = 0, NKD = 8, Bpad_max = 0, ntiles_max = 0, nwg_max = 0;
+    float* head_ws = nullptr; size_t head_ws_floats = 0;   // rnde_nsde_classifier_head
     int mw = 0;    // 1: the four-waves-per-tile solve kernel (rnde_sdemw.h) for that shape, while a tile per workgroup still fits the chip
     size_t lds_mw = 0;
     int xch_wg = 0; // workgroups the exchange array is sized for
@@ -204,7 +206,7 @@ extern "C" rnde_status rnde_nsde_create(const rnde_nsde_config* c, rnde_nsde** o
 extern "C" void rnde_nsde_destroy(rnde_nsde* h) {
     if (!h) return;
     void* d[] = {h->frags_f, h->frags_g, h->slots, h->tape, h->noise, h->replay, h->meta, h->acc_meta, h->fin, h->xch, h->abort_word, h->svb,
-                 h->slab_f, h->slab_g, h->wslab, h->wslab_r, h->ev_t, h->part, h->sv_t_dev};
+                 h->slab_f, h->slab_g, h->wslab, h->wslab_r, h->ev_t, h->part, h->sv_t_dev, h->head_ws};
     for (void* p : d) if (p) (void)hipFree(p);
     void* hd[] = {h->h_meta, h->h_acc_meta, h->h_fin, h->h_svb, h->h_part};
     for (void* p : hd) if (p) (void)hipHostFree(p);
@@ -529,6 +531,31 @@ extern "C" rnde_status rnde_nsde_backward(rnde_nsde* h, const float* u_bar_dev, 
 extern "C" rnde_status rnde_nsde_backward_async(rnde_nsde* h, const float* u_bar_dev, const float* saveval_bar_host, float* x_bar_dev, float* p_bar_dev,
                                                 void* stream) {
     return nsde_backward_impl(h, u_bar_dev, saveval_bar_host, x_bar_dev, p_bar_dev, stream, false);
+}
+
+// postsde Dense(D, C) + logitcrossentropy and their reverse for ClassifierNSDE with one trajectory per input (the kernels of rnde_head.h,
+// as rnde_classifier_head for the ODE classifier; reference src/models/supervised_classification.jl:96-97 + experiments/mnist_nsde.jl loss)
+extern "C" rnde_status rnde_nsde_classifier_head(rnde_nsde* h, const float* u_dev, const float* p3_dev, const float* y_dev, int32_t B, int32_t n_classes,
+                                                 float* logits_out_dev, float* u_bar_dev, float* p3_bar_dev, float* ce_out_dev, void* stream) {
+    if (!h || B < 1 || n_classes < 1 || n_classes > kHeadMaxC) return RNDE_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t need = (size_t)B * n_classes + B + (size_t)kHeadChunks * n_classes * h->D;
+    if (h->head_ws_floats < need) {
+        if (h->head_ws) (void)hipFree(h->head_ws);
+        h->head_ws = nullptr; h->head_ws_floats = 0;
+        SCHK(h, hipMalloc((void**)&h->head_ws, need * 4));
+        h->head_ws_floats = need;
+    }
+    float* delta = h->head_ws;
+    float* ce_col = h->head_ws + (size_t)B * n_classes;
+    float* partial = ce_col + B;
+    if (n_classes == 10) hipLaunchKernelGGL((rnde_head_col_kernel<10>), dim3(B), dim3(256), 0, s, u_dev, p3_dev, y_dev, h->D, n_classes, B, logits_out_dev, u_bar_dev, delta, ce_col);
+    else hipLaunchKernelGGL((rnde_head_col_kernel<0>), dim3(B), dim3(256), 0, s, u_dev, p3_dev, y_dev, h->D, n_classes, B, logits_out_dev, u_bar_dev, delta, ce_col);
+    hipLaunchKernelGGL(rnde_head_wgrad_kernel, dim3((h->D + 255) / 256, kHeadChunks), dim3(256), 0, s, u_dev, (const float*)delta, h->D, n_classes, B, partial);
+    hipLaunchKernelGGL(rnde_head_reduce_kernel, dim3((n_classes * h->D + 255) / 256), dim3(256), 0, s, (const float*)partial, (const float*)delta, (const float*)ce_col,
+                       h->D, n_classes, B, p3_bar_dev, ce_out_dev);
+    SCHK(h, hipGetLastError());
+    return RNDE_OK;
 }
 
 extern "C" rnde_status rnde_nsde_timing(rnde_nsde* h, float* solve_ms, float* rev_sweep_ms, int32_t* attempts, int32_t* accepted) {

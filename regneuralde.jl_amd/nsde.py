@@ -250,12 +250,19 @@ def fused_nsde_loss_and_grad(model, x, y, trajectories=1, lam=1.0e2, regularize=
         nsde.last_nfe = (int(n1.value), int(n2.value))
         n_u, n_c = model.post_shape
         W3, b3 = p3[: n_u * n_c].view(n_u, n_c), p3[n_u * n_c:]
-        z = torch.addmm(b3, u, W3).view(trajectories, bsize, n_c).mean(dim=0)    # :96-98
-        logp = torch.log_softmax(z, dim=1)
-        ce = -(y * logp).sum() / bsize                                           # Flux.Losses.logitcrossentropy
-        dz = ((torch.exp(logp) * y.sum(dim=1, keepdim=True) - y) / (bsize * trajectories)).repeat(trajectories, 1)
-        p3bar = torch.cat([(u.t() @ dz).reshape(-1), dz.sum(dim=0)])
-        ubar = (dz @ W3.t()).contiguous()
+        if trajectories == 1 and n_c <= 16:     # postsde + loss + their reverse: three launches through the C ABI (rnde_nsde_classifier_head)
+            ubar, p3bar = torch.empty_like(u), torch.empty_like(p3)
+            ce_t = torch.empty(1, dtype=torch.float32, device=u.device)
+            _lib.check_nsde(hd.ptr, L.rnde_nsde_classifier_head(hd.ptr, u.data_ptr(), p3.contiguous().data_ptr(), y.contiguous().data_ptr(), B, n_c, None,
+                                                                ubar.data_ptr(), p3bar.data_ptr(), ce_t.data_ptr(), stream))
+            ce = ce_t[0]
+        else:
+            z = torch.addmm(b3, u, W3).view(trajectories, bsize, n_c).mean(dim=0)    # :96-98
+            logp = torch.log_softmax(z, dim=1)
+            ce = -(y * logp).sum() / bsize                                           # Flux.Losses.logitcrossentropy
+            dz = ((torch.exp(logp) * y.sum(dim=1, keepdim=True) - y) / (bsize * trajectories)).repeat(trajectories, 1)
+            p3bar = torch.cat([(u.t() @ dz).reshape(-1), dz.sum(dim=0)])
+            ubar = (dz @ W3.t()).contiguous()
         n = nsv.value
         reg, svb = 0.0, None
         if regularize and nsde.regularize and n > 0:

@@ -65,3 +65,42 @@ def test_training_step_with_flat_gradients_and_early_allreduce():
         dist.destroy_process_group()
         if os.path.exists(store.name):
             os.unlink(store.name)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_in_process_group_allreduce(world):
+    """rnde_comm_create_local_group: `world` ranks in this process, one host thread and one stream each; 40 consecutive all-reduces of
+    different vectors (the two slot sets alternate) must give every rank the sum over the ranks, in rank order, bit for bit."""
+    import threading
+    import torch
+    from regneuralde_jl_amd import _lib
+    L = _lib.lib()
+    comms = (C.c_void_p * world)()
+    assert L.rnde_comm_create_local_group(world, 0, comms) == 0, L.rnde_comm_last_error(None)
+    n = 3 * 224
+    base = [torch.randn(40, n, generator=torch.Generator().manual_seed(100 + r)).cuda() for r in range(world)]
+    out = [None] * world
+
+    def work(r):
+        st = torch.cuda.Stream()
+        res = []
+        with torch.cuda.stream(st):
+            for k in range(40):
+                buf = base[r][k].clone()
+                assert L.rnde_comm_allreduce(C.c_void_p(comms[r]), buf.data_ptr(), n, 0, C.c_void_p(st.cuda_stream)) == 0, L.rnde_comm_last_error(C.c_void_p(comms[r]))
+                res.append(buf)
+        st.synchronize()
+        out[r] = torch.stack(res).cpu()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(60) for t in th]
+    assert all(o is not None for o in out)
+    ref = base[0].cpu().clone()
+    for r in range(1, world):
+        ref = ref + base[r].cpu()            # rank order, as the sum kernel adds
+    for r in range(world):
+        assert torch.equal(out[r], ref)
+        assert L.rnde_comm_health(C.c_void_p(comms[r])) == 0
+    for c in comms:
+        L.rnde_comm_destroy(C.c_void_p(c))

@@ -1,6 +1,6 @@
 """SURVEY 8e mode 2 -- one step-size controller for all shards (rnde_node_set_coupling) -- on the one GPU of the test box.
 
-world = 2 inside ONE process: two handles, two host threads, the in-process communicator (rnde_comm_create_local_group: the
+world = 2 and 4 inside ONE process: one handle, one host thread and one stream per rank, the in-process communicator (rnde_comm_create_local_group: the
 all-reduce is a one-workgroup kernel per rank meeting the other through device memory).  The sharded run must reproduce the
 single-device run over the whole batch: the same accept/reject sequence, step sizes and saved values to fp32 rounding (the error
 norm is now a sum of two partial sums), the end state of every column, and -- with the ranks' cotangents formed the way data
@@ -27,8 +27,8 @@ def _run(node, x, p, ubar, svb):
 
 
 @pytest.mark.parametrize("persist", [1, 0])
-@pytest.mark.parametrize("B,cut,tol,scale", [(64, 32, 1e-3, 5.0), (70, 35, 1e-4, 4.0)])
-def test_two_coupled_shards_reproduce_the_single_device_run(B, cut, tol, scale, persist, monkeypatch):
+@pytest.mark.parametrize("B,world,tol,scale", [(64, 2, 1e-3, 5.0), (70, 2, 1e-4, 4.0), (128, 4, 1e-4, 4.0)])
+def test_coupled_shards_reproduce_the_single_device_run(B, world, tol, scale, persist, monkeypatch):
     from regneuralde_jl_amd import _lib
     from tests.test_gpu_forward import _cfg
     from tests.util import Node
@@ -41,22 +41,23 @@ def test_two_coupled_shards_reproduce_the_single_device_run(B, cut, tol, scale, 
     ref, rx, rp, rt = _run(Node(_cfg(arch, B, reltol=tol, abstol=tol, col_tile=16)), x, p, ubar, svb)
     print("attempts", len(ref["steps"]), "rejected", int((ref["steps"][:, 3] == 0).sum()))
 
-    comms = (C.c_void_p * 2)()
-    assert L.rnde_comm_create_local_group(2, 0, comms) == 0, L.rnde_comm_last_error(None)
-    shards = [(0, cut), (cut, B)]         # (equal shards, as data parallelism makes them: every rank must hold the same number of 16-column tiles)
-    equal = 2 * cut == B
-    nodes = [Node(_cfg(arch, hi - lo, reltol=tol, abstol=tol, col_tile=16)).own_stream() for lo, hi in shards]
+    comms = (C.c_void_p * world)()
+    assert L.rnde_comm_create_local_group(world, 0, comms) == 0, L.rnde_comm_last_error(None)
+    per = B // world                      # equal shards, as data parallelism makes them (every rank must hold the same number of 16-column tiles)
+    assert per * world == B
+    shards = [(r * per, (r + 1) * per) for r in range(world)]
+    nodes = [Node(_cfg(arch, per, reltol=tol, abstol=tol, col_tile=16)).own_stream() for _ in shards]
     for n, c in zip(nodes, comms):
         _lib.check(n.h, L.rnde_node_set_coupling(n.h, C.c_void_p(c), B))
-    out = [None, None]
+    out = [None] * world
 
     def work(r):
         lo, hi = shards[r]
         # what a data-parallel rank passes: the cotangent of ITS loss, whose data term is a mean over its own columns (= world x the
-        # single-device cotangent of those columns when the shards are equal)
-        out[r] = _run(nodes[r], x[lo:hi], p, ubar[lo:hi] * 2.0, svb)
+        # single-device cotangent of those columns)
+        out[r] = _run(nodes[r], x[lo:hi], p, ubar[lo:hi] * float(world), svb)
 
-    th = [threading.Thread(target=work, args=(r,)) for r in range(2)]
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
     [t.start() for t in th]
     [t.join(120) for t in th]
     assert all(o is not None for o in out), "a rank did not finish"
@@ -66,17 +67,17 @@ def test_two_coupled_shards_reproduce_the_single_device_run(B, cut, tol, scale, 
         np.testing.assert_allclose(g["steps"][:, 1], ref["steps"][:, 1], rtol=2e-5)
         np.testing.assert_allclose(g["saveval"], ref["saveval"], rtol=2e-4, atol=1e-9)
         assert np.abs(g["u"] - ref["u"][lo:hi]).max() <= 2e-5 * max(1.0, np.abs(ref["u"]).max())
-    # both ranks hold the same controller history bit for bit
-    assert np.array_equal(out[0][0]["steps"], out[1][0]["steps"]) and np.array_equal(out[0][0]["saveval"], out[1][0]["saveval"])
-    if equal:   # the usual average of the ranks' gradients is the single-device gradient (equal shards: what data parallelism uses)
-        gp = 0.5 * (out[0][2] + out[1][2])
-        gt = 0.5 * (out[0][3] + out[1][3])
-        scale_p = np.abs(rp).max()
-        print("p-bar", np.abs(gp - rp).max() / scale_p, "tspan-bar", gt, rt)
-        assert np.abs(gp - rp).max() <= 2e-4 * scale_p
-        assert np.abs(gt - rt).max() <= 2e-4 * max(1.0, np.abs(rt).max())
-        for r, (lo, hi) in enumerate(shards):
-            assert np.abs(0.5 * out[r][1] - rx[lo:hi]).max() <= 2e-4 * np.abs(rx).max()
+        # every rank holds the same controller history bit for bit
+        assert np.array_equal(g["steps"], out[0][0]["steps"]) and np.array_equal(g["saveval"], out[0][0]["saveval"])
+    # the usual average of the ranks' gradients is the single-device gradient
+    gp = sum(o[2] for o in out) / world
+    gt = sum(o[3] for o in out) / world
+    scale_p = np.abs(rp).max()
+    print("p-bar", np.abs(gp - rp).max() / scale_p, "tspan-bar", gt, rt)
+    assert np.abs(gp - rp).max() <= 2e-4 * scale_p
+    assert np.abs(gt - rt).max() <= 2e-4 * max(1.0, np.abs(rt).max())
+    for r, (lo, hi) in enumerate(shards):
+        assert np.abs(out[r][1] / world - rx[lo:hi]).max() <= 2e-4 * np.abs(rx).max()
     for c in comms:
         L.rnde_comm_destroy(C.c_void_p(c))
 

@@ -178,6 +178,27 @@ int32_t     rnde_node_fallback_count(const rnde_node* h);
  * rnde_step_kernel / rnde_chain_kernel; 7: rnde_stage_kernel START, 5 x STAGE, LAST) -- bench.py's roofline bookkeeping. */
 int32_t     rnde_node_launches_per_attempt(const rnde_node* h);
 
+/* ======================================================================================================================
+ * Several taped forwards alive at once behind one handle (the `tape_id` form of SURVEY.md 8b).  An rnde_node holds ONE tape; the
+ * reference's loop sometimes needs more -- the NFE probe between a forward and its reverse (experiments/mnist_node.jl:245), two
+ * batches in flight.  A tape pool is a set of solver instances of one configuration, created on demand (each taped one owns an
+ * arena of max_attempts records): rnde_tapes_forward(keep_tape = 1) takes a free one and returns its index as the tape id,
+ * rnde_tapes_backward(tape_id) or rnde_tapes_release(tape_id) frees it; keep_tape = 0 runs on an extra instance that never tapes
+ * (tape id -1).  Arguments and results are those of rnde_node_forward / rnde_node_backward.
+ * ====================================================================================================================== */
+typedef struct rnde_tapes rnde_tapes;
+rnde_status rnde_tapes_create(const rnde_node_config* cfg, int32_t max_tapes, rnde_tapes** out);
+void        rnde_tapes_destroy(rnde_tapes* t);
+const char* rnde_tapes_last_error(const rnde_tapes* t);     /* t may be NULL: last create error of this thread */
+int32_t     rnde_tapes_in_use(const rnde_tapes* t);
+rnde_node*  rnde_tapes_node(rnde_tapes* t, int32_t tape_id);  /* the instance behind a tape id (-1: the untaped one), for the rnde_node_* statistics / tuning calls */
+rnde_status rnde_tapes_forward(rnde_tapes* t, const float* x_dev, const float* p_dev, int32_t B, float t0, float t1, float* u_out_dev,
+                               int64_t* nfe_out, float* saveval_host, int32_t* n_saveval_out, int32_t keep_tape, void* stream,
+                               int32_t* tape_id_out);
+rnde_status rnde_tapes_backward(rnde_tapes* t, int32_t tape_id, const float* u_bar_dev, const float* saveval_bar_host, float* x_bar_dev,
+                                float* p_bar_dev, float* tspan_bar_host, void* stream);
+rnde_status rnde_tapes_release(rnde_tapes* t, int32_t tape_id);
+
 /* Fused caller of the hot path: postode Dense(D, C) + Flux.Losses.logitcrossentropy and their
  * reverse in one call -- replaces reference src/models/supervised_classification.jl:44-45 + experiments/mnist_node.jl:135
  * and the Tracker reverse of both.  p3 = Flux.destructure(Dense(D, C)) = [vec(W) (C x D col-major); b (C)];

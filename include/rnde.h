@@ -177,6 +177,9 @@ int32_t     rnde_node_fallback_count(const rnde_node* h);
 /* How the handle currently runs one attempted step: number of kernel launches (1: rnde_stage_attempt_kernel /
  * rnde_step_kernel / rnde_chain_kernel; 7: rnde_stage_kernel START, 5 x STAGE, LAST) -- bench.py's roofline bookkeeping. */
 int32_t     rnde_node_launches_per_attempt(const rnde_node* h);
+/* 1 if this build contains the column-owner engine's own step kernels (col_tile 4 / 8; -DRNDE_WITH_COLUMN_OWNER), 0 otherwise: the
+ * default build leaves them out (nothing selects them automatically; rnde_node_create then refuses col_tile 4 / 8). */
+int32_t     rnde_has_column_owner(void);
 
 /* ======================================================================================================================
  * Several taped forwards alive at once behind one handle (the `tape_id` form of SURVEY.md 8b).  An rnde_node holds ONE tape; the

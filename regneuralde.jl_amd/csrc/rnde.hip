@@ -137,8 +137,19 @@ static StepParams make_params(rnde_node* h, const float* x, int B, float t0, flo
     return P;
 }
 
+// The column-owner engine's own step / finish / reverse-step kernels (col_tile 4 or 8: the round-1 engine, 126 us per attempted step at
+// B = 512; nothing selects it automatically) are compiled only with -DRNDE_WITH_COLUMN_OWNER (RNDE_WITH_COLUMN_OWNER=1 python build.py);
+// its initialisation-reverse kernels (rnde_binit_kernel, rnde_bfin_kernel) are what the stage engine's reverse pass ends with and are
+// always there.  rnde_has_column_owner() says which build this is.
+#ifdef RNDE_WITH_COLUMN_OWNER
+constexpr int kHasColumnOwner = 1;
+#else
+constexpr int kHasColumnOwner = 0;
+#endif
+extern "C" int32_t rnde_has_column_owner(void) { return kHasColumnOwner; }
 template <int NG, int ACT2, int MODE>
 static hipError_t launch_step_t(rnde_node* h, const StepParams& P, int n, hipStream_t s) {
+#ifdef RNDE_WITH_COLUMN_OWNER
     auto kern = rnde_step_kernel<NG, ACT2, MODE>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -148,6 +159,10 @@ static hipError_t launch_step_t(rnde_node* h, const StepParams& P, int n, hipStr
     }
     hipLaunchKernelGGL(kern, dim3(P.nwg), dim3(kThreads), h->lds_bytes, s, P, n);
     return hipGetLastError();
+#else
+    (void)h; (void)P; (void)n; (void)s;
+    return hipErrorNotSupported;
+#endif
 }
 template <int MODE>
 static hipError_t launch_step(rnde_node* h, const StepParams& P, int n, hipStream_t s) {
@@ -155,9 +170,14 @@ static hipError_t launch_step(rnde_node* h, const StepParams& P, int n, hipStrea
     return h->act2 ? launch_step_t<2, 1, MODE>(h, P, n, s) : launch_step_t<2, 0, MODE>(h, P, n, s);
 }
 static hipError_t launch_finish(rnde_node* h, const StepParams& P, int n, float* u_out, hipStream_t s) {
+#ifdef RNDE_WITH_COLUMN_OWNER
     if (h->NG == 1) hipLaunchKernelGGL(rnde_finish_kernel<1>, dim3(P.nwg), dim3(256), 0, s, P, n, u_out);
     else hipLaunchKernelGGL(rnde_finish_kernel<2>, dim3(P.nwg), dim3(256), 0, s, P, n, u_out);
     return hipGetLastError();
+#else
+    (void)h; (void)P; (void)n; (void)u_out; (void)s;
+    return hipErrorNotSupported;
+#endif
 }
 static hipError_t launch_pack(rnde_node* h, const float* p, f32x4* dst, int which, int MT, int K4, hipStream_t s) {
     const int TR = 64 / h->NG;
@@ -436,6 +456,10 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
       if (const char* e = getenv("RNDE_STAGE_WT")) { const int v = atoi(e); if (v >= 1 && v <= 8) best = std::min(v, h->sMT); }   // (experiments: row tiles per workgroup)
       h->sWT = best; h->sR = (h->sMT + best - 1) / best; }
     h->engine = (c->col_tile == 16 || c->col_tile == 0) ? 2 : 1;
+    if (h->engine == 1 && !kHasColumnOwner) {
+        g_create_err = "col_tile 4 / 8: this build of librnde.so leaves the column-owner step kernels out (RNDE_WITH_COLUMN_OWNER=1 python regneuralde.jl_amd/build.py includes them); col_tile 0 or 16 runs the stage engine";
+        delete h; return RNDE_ERR_BAD_ARG;
+    }
     h->nwg_max = std::max(h->Bpad_max / h->BT, h->sR * (h->Bpad_max / 16));
     h->stage_lds = sizeof(float) * ((size_t)16 * (16 * std::max(h->sK2b, h->sHT) + 4) + (size_t)16 * (16 * std::max(h->sWT, h->sKHb) + 4) + 64);
     const int MTS = 128 / TR;
@@ -1175,13 +1199,20 @@ static hipError_t launch_bwd_t(rnde_node* h, const BwdParams& Q, int n_att, hipS
     const size_t lds = bwd_lds_bytes(h);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)rnde_bstep_kernel<NG, ACT2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipSuccess;
+#ifdef RNDE_WITH_COLUMN_OWNER
+        e = hipFuncSetAttribute((const void*)rnde_bstep_kernel<NG, ACT2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#endif
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rnde_binit_kernel<NG, ACT2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rnde_binit_kernel<NG, ACT2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
+#ifdef RNDE_WITH_COLUMN_OWNER
     for (int n = n_att - 1; n >= 0; --n) hipLaunchKernelGGL((rnde_bstep_kernel<NG, ACT2>), dim3(Q.F.nwg), dim3(kThreads), lds, s, Q, n);
+#else
+    if (n_att > 0) return hipErrorNotSupported;     // (only the column-owner engine passes attempts here)
+#endif
     hipLaunchKernelGGL((rnde_binit_kernel<NG, ACT2, 1>), dim3(Q.F.nwg), dim3(kThreads), lds, s, Q);
     if (couple_sum(h, Q.ipart, 4LL * Q.F.nwg, s) != RNDE_OK) return hipErrorUnknown;                         // (coupled controller: dot, tau of the reversed second evaluation)
     hipLaunchKernelGGL((rnde_binit_kernel<NG, ACT2, 2>), dim3(Q.F.nwg), dim3(kThreads), lds, s, Q);

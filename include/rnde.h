@@ -81,6 +81,7 @@ typedef struct {
 } rnde_node_config;
 
 typedef struct rnde_node rnde_node;
+typedef struct rnde_comm rnde_comm;   /* gradient collective, see rnde_comm_* below */
 
 const char* rnde_version(void);
 const char* rnde_last_error(const rnde_node* h); /* h may be NULL: last create error */
@@ -211,6 +212,21 @@ rnde_status rnde_classifier_head(rnde_node* h, const float* u_dev, const float* 
                                  int32_t B, int32_t n_classes, float* logits_out_dev, float* u_bar_dev,
                                  float* p3_bar_dev, float* ce_out_dev, void* stream);
 
+/* One training-step gradient of the reference's classifier loss in ONE call (experiments/mnist_node.jl:132-137 and :229-233:
+ * `loss_function` + `Tracker.gradient` with ClassifierNODE, preode = identity):
+ *     u = TrackedNeuralODE(x, p2)  ->  ce = logitcrossentropy(Dense_p3(u), y)  ->  loss = ce + lambda * mean(sv.saveval)
+ * = rnde_node_forward (taped) + rnde_classifier_head + rnde_node_backward_async, with the head and the weight packs of the reverse
+ * sweep queued BEFORE the forward's host wait, so the GPU does not idle while the host reads the step log and launches the sweep
+ * (the three separate calls leave ~80 us of a 2.4 ms step idle at B = 512).  Stage engine only (two-layer dynamics, col_tile 0).
+ * Outputs: p2_bar_dev (P), p3_bar_dev (C*D + C), x_bar_dev (D x B, may be NULL), ce_out_dev (device scalar), *reg_out_host =
+ * lambda * mean(saveval) and *nfe_out (host, valid on return: the step log has been read); lambda = 0: no regulariser cotangent.
+ * comm != NULL: p3_bar and then p2_bar are sum-all-reduced in place (rnde_comm_allreduce, mean = 0) as soon as each is complete --
+ * the head's gradient travels while the sweep runs.  Asynchronous from the reverse pass on, like rnde_node_backward_async. */
+rnde_status rnde_node_classifier_grad(rnde_node* h, const float* x_dev, const float* p2_dev, const float* p3_dev,
+                                      const float* y_dev, int32_t B, int32_t n_classes, float t0, float t1, float lambda,
+                                      float* p2_bar_dev, float* p3_bar_dev, float* x_bar_dev, float* ce_out_dev,
+                                      float* reg_out_host, int64_t* nfe_out, rnde_comm* comm, void* stream);
+
 /* Optimiser update of the reference's training step, one launch per parameter group:
  * Flux.Optimise.Optimiser(InvDecay(gamma), Momentum(eta, rho)) applied by update_parameters! -- replaces reference
  * experiments/mnist_node.jl:130 + src/utils.jl:149-156 for one flat group:
@@ -241,7 +257,6 @@ rnde_status rnde_adam_step(float* p_dev, const float* g_dev, float* m_dev, float
  *   ranks arrive) -> per step: rnde_comm_allreduce(c, grad_dev, n, mean, stream) -> rnde_comm_destroy(c).
  * ====================================================================================================================== */
 #define RNDE_COMM_ID_BYTES 128
-typedef struct rnde_comm rnde_comm;
 rnde_status rnde_comm_unique_id(uint8_t id_out[RNDE_COMM_ID_BYTES]);
 rnde_status rnde_comm_create(const uint8_t id[RNDE_COMM_ID_BYTES], int32_t rank, int32_t world, int32_t device, rnde_comm** out);
 void        rnde_comm_destroy(rnde_comm* c);

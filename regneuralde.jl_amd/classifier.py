@@ -9,6 +9,7 @@ The pre/post layers, the loss and the optimiser are a few tiny PyTorch ops aroun
 integration itself (forward and reverse) is librnde.so.
 """
 import math
+import os
 
 import torch
 
@@ -65,6 +66,23 @@ def fused_loss_and_grad(model, x, y, lam=1.0e2, regularize=True, tspan=None, syn
     h = node._acquire(x2, True)
     ts = node.tspan if tspan is None else [float(tspan[0]), float(tspan[1])]
     stream = C.c_void_p(torch.cuda.current_stream(x2.device).cuda_stream)
+    if flat is not None:                                  # trainable() = (p1 (empty), p2, p3) -> groups [p2, p3]
+        p2bar, p3bar = flat.views[0], flat.views[1]
+    else:
+        p2bar, p3bar = torch.empty_like(model.p2), torch.empty_like(model.p3)
+    if not sync and node.col_tile == 0 and (reducer is None or reducer.comm is not None) and os.environ.get("RNDE_ONE_CALL", "1") != "0":   # (0: A/B switch)
+        # the whole step gradient as ONE library call (rnde_node_classifier_grad): head and reverse-sweep packs are queued before
+        # the forward's host wait, so the GPU does not idle between the solve and its reverse
+        ce = torch.empty(1, dtype=torch.float32, device=x2.device)
+        nfe, reg_h = C.c_int64(0), C.c_float(0.0)
+        _lib.check(h.ptr, L.rnde_node_classifier_grad(
+            h.ptr, x2.data_ptr(), model.p2.detach().data_ptr(), model.p3.detach().data_ptr(), y.contiguous().data_ptr(), B,
+            model.post_shape[1], ts[0], ts[1], float(lam) if regularize else 0.0, p2bar.data_ptr(), p3bar.data_ptr(), None,
+            ce.data_ptr(), C.byref(reg_h), C.byref(nfe), reducer.comm if reducer is not None else None, stream))
+        model.p2.grad, model.p3.grad = p2bar, p3bar
+        node.last_nfe = int(nfe.value)
+        reg = float(reg_h.value)
+        return ce + reg, ce, reg, int(nfe.value)
     u = torch.empty_like(x2)
     nfe, nsv = C.c_int64(0), C.c_int32(0)
     sv = (C.c_float * (node.max_attempts + 1))()
@@ -73,10 +91,6 @@ def fused_loss_and_grad(model, x, y, lam=1.0e2, regularize=True, tspan=None, syn
                                           C.byref(nsv), 1, stream))
     n_cls = model.post_shape[1]
     ubar = torch.empty_like(x2)
-    if flat is not None:                                  # trainable() = (p1 (empty), p2, p3) -> groups [p2, p3]
-        p2bar, p3bar = flat.views[0], flat.views[1]
-    else:
-        p2bar, p3bar = torch.empty_like(p2), torch.empty_like(p3)
     ce = torch.empty(1, dtype=torch.float32, device=x2.device)
     _lib.check(h.ptr, L.rnde_classifier_head(h.ptr, u.data_ptr(), p3.data_ptr(), y.contiguous().data_ptr(), B, n_cls, None,
                                              ubar.data_ptr(), p3bar.data_ptr(), ce.data_ptr(), stream))

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -56,6 +57,10 @@ struct rnde_node {
     float* slab2 = nullptr;
     size_t stage_lds = 0;
     float* head_ws = nullptr; size_t head_ws_floats = 0;   // fused classifier head scratch
+    // rnde_node_classifier_grad: work the forward enqueues BEHIND the copy its host wait needs (so it runs while the host wakes up),
+    // the event that wait uses, the caller-independent buffers of the fused step, and "the reverse sweep's weight packs are already queued"
+    std::function<rnde_status(hipStream_t)> after_solve; hipEvent_t ev_host = nullptr; bool rev_packed = false;
+    float* cg_ws = nullptr; size_t cg_ws_floats = 0; std::vector<float> cg_sv;
     float* sv_t_dev = nullptr; size_t sv_cap = 0; std::vector<float> saveat;   // saveat times of the last forward
     float* replay_dev = nullptr; size_t replay_cap = 0; const float* replay_host = nullptr; int n_replay = 0;   // rnde_node_forward_replay (set for one forward)
     // persistent attempt kernel (rnde_stage_persist.h): 1 = in use, 0 = off (RNDE_PERSIST=0), -1 = disabled after a failure
@@ -529,6 +534,8 @@ extern "C" void rnde_node_destroy(rnde_node* h) {
     for (void* p : d) if (p) hipFree(p);
     bwd_free(h->bw);
     if (h->head_ws) hipFree(h->head_ws);
+    if (h->cg_ws) hipFree(h->cg_ws);
+    if (h->ev_host) hipEventDestroy(h->ev_host);
     if (h->sv_t_dev) hipFree(h->sv_t_dev);
     if (h->replay_dev) hipFree(h->replay_dev);
     if (h->cfrags) hipFree(h->cfrags);
@@ -736,7 +743,7 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
     } else h->saveat.clear();
     if (B < 1 || B > h->cfg.max_batch || !(t1 > t0)) { h->err = "bad B or tspan"; return RNDE_ERR_BAD_ARG; }
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    h->have_tape = false;
+    h->have_tape = false; h->rev_packed = false;
     if (keep_tape) {
         rnde_status st = ensure_arena(h, h->cfg.max_attempts);
         if (st != RNDE_OK) return st;
@@ -823,7 +830,12 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
             HIPCHK(h, hipMemcpyAsync(h->h_meta, h->meta, (size_t)launched * sizeof(StepMeta), hipMemcpyDeviceToHost, s));
             HIPCHK(h, hipMemcpyAsync(h->h_init, h->initrec, sizeof(InitRec), hipMemcpyDeviceToHost, s));
         }
-        HIPCHK(h, hipStreamSynchronize(s));
+        if (h->after_solve) {   // (fused training step) wait for the copy only; what the hook queues runs while the host wakes up.  A solve that
+            HIPCHK(h, hipEventRecord(h->ev_host, s));   // needs another chunk, or is redone, calls the hook again: it only overwrites its outputs
+            const rnde_status hs = h->after_solve(s);
+            if (hs != RNDE_OK) return hs;
+            HIPCHK(h, hipEventSynchronize(h->ev_host));
+        } else HIPCHK(h, hipStreamSynchronize(s));
         if (h->couple && rnde_comm_health(h->couple) != RNDE_OK) { h->err = std::string("coupled controller: ") + rnde_comm_last_error(h->couple); return RNDE_ERR_HIP; }
         if (h->engine == 2 && persist_check_result(h, SQ.C, SQ.R, s)) {
             if (h->pending_bwd) {   // the failure may belong to the asynchronous reverse pass before this forward: its outputs cannot be trusted
@@ -1385,8 +1397,11 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
     if (h->timing) HIPCHK(h, hipEventRecord(h->tev[2], s));
     if (h->engine == 2) {
         // stage engine sweep: one persistent launch per reversed attempt (fallback: 7 launches); then the (column-owner) kernels for the initialisation part
-        HIPCHK(h, stage_pack(h, h->pcopy, h->spwBt, 2, h->sMT, h->sKHb, s));
-        HIPCHK(h, stage_pack(h, h->pcopy, h->spwDt, 3, h->sHT, h->sMT, s));
+        if (!h->rev_packed) {
+            HIPCHK(h, stage_pack(h, h->pcopy, h->spwBt, 2, h->sMT, h->sKHb, s));
+            HIPCHK(h, stage_pack(h, h->pcopy, h->spwDt, 3, h->sHT, h->sMT, s));
+        }
+        h->rev_packed = false;
         BStageParams BQ{};
         BQ.B = Q; BQ.p = h->pcopy; BQ.pwBt = h->spwBt; BQ.pwDt = h->spwDt; BQ.slab = h->slab2;
         BQ.UTB = b.UTB; BQ.UNB = b.UNB; BQ.UPB0 = b.UPB0; BQ.GB = b.GB;
@@ -1501,11 +1516,7 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
 }
 
 // ---- fused classifier head ------------------------------------------------------
-extern "C" rnde_status rnde_classifier_head(rnde_node* h, const float* u_dev, const float* p3_dev, const float* y_dev,
-                                            int32_t B, int32_t n_classes, float* logits_out_dev, float* u_bar_dev,
-                                            float* p3_bar_dev, float* ce_out_dev, void* stream) {
-    if (!h || B < 1 || n_classes < 1 || n_classes > kHeadMaxC) return RNDE_ERR_BAD_ARG;
-    hipStream_t s = (hipStream_t)stream;
+static rnde_status head_reserve(rnde_node* h, int32_t B, int32_t n_classes) {
     const size_t need = (size_t)B * n_classes + B + (size_t)kHeadChunks * n_classes * h->D;
     if (h->head_ws_floats < need) {
         if (h->head_ws) hipFree(h->head_ws);
@@ -1513,6 +1524,15 @@ extern "C" rnde_status rnde_classifier_head(rnde_node* h, const float* u_dev, co
         HIPCHK(h, hipMalloc((void**)&h->head_ws, need * 4));
         h->head_ws_floats = need;
     }
+    return RNDE_OK;
+}
+extern "C" rnde_status rnde_classifier_head(rnde_node* h, const float* u_dev, const float* p3_dev, const float* y_dev,
+                                            int32_t B, int32_t n_classes, float* logits_out_dev, float* u_bar_dev,
+                                            float* p3_bar_dev, float* ce_out_dev, void* stream) {
+    if (!h || B < 1 || n_classes < 1 || n_classes > kHeadMaxC) return RNDE_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const rnde_status rs = head_reserve(h, B, n_classes);
+    if (rs != RNDE_OK) return rs;
     float* delta = h->head_ws;
     float* ce_col = h->head_ws + (size_t)B * n_classes;
     if (h->D > 256 * kHeadRowsPerThread) { h->err = "classifier head: D <= 1024"; return RNDE_ERR_BAD_ARG; }
@@ -1526,6 +1546,66 @@ extern "C" rnde_status rnde_classifier_head(rnde_node* h, const float* u_dev, co
     hipLaunchKernelGGL(rnde_head_reduce_kernel, dim3((n_classes * h->D + 255) / 256), dim3(256), 0, s, (const float*)partial,
                        (const float*)delta, (const float*)ce_col, h->D, n_classes, B, p3_bar_dev, ce_out_dev);
     HIPCHK(h, hipGetLastError());
+    return RNDE_OK;
+}
+
+// ---- one training-step gradient in ONE call (forward solve -> head -> reverse solve), SURVEY.md 8f rank 1 ------------------
+// The three calls above chained by the caller leave the GPU idle between the solve and its reverse (~80 us of a 2.4 ms step at
+// B = 512): the forward ends in a host wait (the host needs the step log to launch the reverse sweep), and only then does the
+// caller queue the head and the reverse pass.  Here the head and the weight packs of the reverse sweep are queued BEFORE that
+// wait (they do not depend on the step log), so they run while the host wakes up and prepares the sweep.
+extern "C" rnde_status rnde_node_classifier_grad(rnde_node* h, const float* x_dev, const float* p2_dev, const float* p3_dev,
+                                                 const float* y_dev, int32_t B, int32_t n_classes, float t0, float t1,
+                                                 float lambda, float* p2_bar_dev, float* p3_bar_dev, float* x_bar_dev,
+                                                 float* ce_out_dev, float* reg_out_host, int64_t* nfe_out, rnde_comm* comm,
+                                                 void* stream) {
+    if (!h || !x_dev || !p2_dev || !p3_dev || !y_dev || !p2_bar_dev || !p3_bar_dev || !ce_out_dev) return RNDE_ERR_BAD_ARG;
+    if (h->engine != 2) { h->err = "rnde_node_classifier_grad: two-layer dynamics on the stage engine (col_tile 0)"; return RNDE_ERR_BAD_ARG; }
+    if (B < 1 || B > h->cfg.max_batch) { h->err = "bad B or tspan"; return RNDE_ERR_BAD_ARG; }
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const size_t A = (size_t)h->D * B;
+    if (h->cg_ws_floats < 3 * A) {
+        if (h->cg_ws) hipFree(h->cg_ws);
+        h->cg_ws = nullptr; h->cg_ws_floats = 0;
+        HIPCHK(h, hipMalloc((void**)&h->cg_ws, 3 * A * 4));
+        h->cg_ws_floats = 3 * A;
+    }
+    if (!h->ev_host) HIPCHK(h, hipEventCreateWithFlags(&h->ev_host, hipEventDisableTiming));
+    if (n_classes < 1 || n_classes > kHeadMaxC) return RNDE_ERR_BAD_ARG;
+    rnde_status st = head_reserve(h, B, n_classes);   // (the hook below runs between an event record and the host's wait on it: it only enqueues)
+    if (st != RNDE_OK) return st;
+    float* u = h->cg_ws; float* ubar = h->cg_ws + A; float* xbar = x_bar_dev ? x_bar_dev : h->cg_ws + 2 * A;
+    h->cg_sv.resize((size_t)h->cfg.max_attempts + 1);
+    int32_t nsv = 0;
+    int64_t nfe = 0;
+    h->after_solve = [&](hipStream_t s) -> rnde_status {
+        const rnde_status r = rnde_classifier_head(h, u, p3_dev, y_dev, B, n_classes, nullptr, ubar, p3_bar_dev, ce_out_dev, s);
+        if (r != RNDE_OK) return r;
+        HIPCHK(h, stage_pack(h, h->pcopy, h->spwBt, 2, h->sMT, h->sKHb, s));
+        HIPCHK(h, stage_pack(h, h->pcopy, h->spwDt, 3, h->sHT, h->sMT, s));
+        h->rev_packed = true;
+        return RNDE_OK;
+    };
+    st = forward_impl(h, x_dev, p2_dev, B, t0, t1, u, nullptr, 0, nullptr, &nfe, h->cg_sv.data(), &nsv, 1, stream);
+    h->after_solve = nullptr;
+    if (st != RNDE_OK) { h->rev_packed = false; return st; }
+    // lambda * mean(sv.saveval) (experiments/mnist_node.jl:135): every saved value carries the cotangent lambda / n
+    double reg = 0.0;
+    const bool regularize = lambda != 0.f && nsv > 0 && h->cfg.regularize != RNDE_REG_NONE;
+    if (regularize) {
+        for (int i = 0; i < nsv; ++i) reg += h->cg_sv[i];
+        reg = (double)lambda * reg / nsv;
+        for (int i = 0; i < nsv; ++i) h->cg_sv[i] = lambda / (float)nsv;
+    }
+    if (reg_out_host) *reg_out_host = (float)reg;
+    if (nfe_out) *nfe_out = nfe;
+    const int64_t n3 = (int64_t)n_classes * h->D + n_classes;
+    // the head's gradient is complete: it travels while the reverse sweep runs; the solve's gradient follows right behind the sweep
+    if (comm && (st = rnde_comm_allreduce(comm, p3_bar_dev, n3, 0, stream)) != RNDE_OK) { h->err = std::string("all-reduce: ") + rnde_comm_last_error(comm); h->rev_packed = false; return st; }
+    st = bwd_run(h, ubar, regularize ? h->cg_sv.data() : nullptr, xbar, p2_bar_dev, nullptr, (hipStream_t)stream, false, nullptr);
+    h->rev_packed = false;
+    if (st != RNDE_OK) return st;
+    if (comm && (st = rnde_comm_allreduce(comm, p2_bar_dev, (int64_t)h->P, 0, stream)) != RNDE_OK) { h->err = std::string("all-reduce: ") + rnde_comm_last_error(comm); return st; }
     return RNDE_OK;
 }
 

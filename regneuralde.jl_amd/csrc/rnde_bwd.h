@@ -671,6 +671,9 @@ __global__ __launch_bounds__(256) void rnde_wgrad2_kernel(const EvalDesc* __rest
 // of the wide operand (<= 400 x 32) and the narrow operand (112 x 32) are staged in LDS from registers fetched one step ahead
 // (as in rnde_wgrad2_kernel); LDS row strides are = 16 (mod 64) floats, so the four 16-lane groups of an MFMA operand read
 // hit distinct bank windows.  TALL_IS_Z: the wide operand is Z (layer 2) or [X; t; 1] (layer 1).
+#ifndef RNDE_WGRAD3_PIPE
+#define RNDE_WGRAD3_PIPE 1
+#endif
 template <bool TALL_IS_Z>
 __global__ __launch_bounds__(448) void rnde_wgrad3_kernel(const EvalDesc* __restrict__ evals, int n_evals, int per_chunk,
                                                           int M, int Nx, int Bpad, float* __restrict__ slab) {
@@ -693,6 +696,108 @@ __global__ __launch_bounds__(448) void rnde_wgrad3_kernel(const EvalDesc* __rest
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int n = 0; n < 7; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#if RNDE_WGRAD3_PIPE
+    const bool has3 = w + 21 < ntile;                      // tiles w, w + 7, w + 14 always exist (host: both halves >= 21 tiles)
+    const int TRp = TALL_IS_Z ? M : Nx, SRp = TALL_IS_Z ? Nx : M;
+    // Staging of one 32-column step WITHOUT registers: `global_load_lds_dwordx4` moves 64 lanes x 16 bytes from global memory
+    // into 1 KiB of consecutive LDS.  The wide half of a column (<= 400 rows) is two such units (rows 0..255, 256..), two columns of
+    // the narrow operand (2 x 144 floats apart) are one; 64 + 16 units per step, dealt to the 7 waves.  Lanes whose float4 has no
+    // source (padding rows of the last tile, the synthetic rows) are masked off: the whole LDS image is zeroed once, and the
+    // synthetic {t, 1, 0, 0} rows of [X; t; 1] -- one float4 per column -- are written by 32 threads per step.  M and Nx are
+    // multiples of 4, so a float4 never mixes kinds.  (The register-staged form of this kernel spent ~330 instructions per wave
+    // and step behind the last MFMA on index arithmetic, selects and LDS stores, and held 40 registers for data in flight.)
+    for (int i = tid; i < 2 * KC * (TLS + SLS) / 4; i += 448) ((f32x4*)wsm)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int wide_syn = (!TALL_IS_Z && TRp >= row_lo && TRp < row_lo + nrow) ? TRp - row_lo : -1;   // row (in this half) of {t, 1, 0, 0}
+    const int narrow_syn = TALL_IS_Z ? SRp : -1;
+    // Units are dealt statically: wide unit w + 7 j (j < 10, 64 in all: column (w + 7 j) / 2, rows 0.. or 256..), narrow unit w + 7 j
+    // (j < 3, 16 in all: columns 2 u and 2 u + 1).  Per slot the lane's element offset from the step's first column is fixed
+    // (-1: this lane has nothing to fetch in the slot), so a step costs one DMA instruction per slot and no index arithmetic.
+    int wg_off[10], ng_off[3];
+#pragma unroll
+    for (int jj = 0; jj < 10; ++jj) {
+        const int u = w + 7 * jj, c = u >> 1, row = 256 * (u & 1) + 4 * lane;
+        wg_off[jj] = (u < 64 && row < nrow && row_lo + row < TRp) ? c * TRp + row : -1;
+    }
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) {
+        const int u = w + 7 * jj, cl = lane >= 36 ? 1 : 0, row = 4 * (lane - 36 * cl);
+        ng_off[jj] = (u < 16 && (lane < 28 || lane >= 36) && row < SRp) ? (2 * u + cl) * SRp + row : -1;
+    }
+    int e_nx = s_lo / steps_per_eval, cs_nx = s_lo - e_nx * steps_per_eval;   // (evaluation, 32-column step in it) of the next step to stage
+    auto stage_dma = [&](int buf) {                        // the next step's operands -> LDS buffer `buf`, asynchronously (vmcnt)
+        const int e = e_nx, c0 = cs_nx * KC;
+        if (++cs_nx == steps_per_eval) { cs_nx = 0; ++e_nx; }
+        const float te = evals[e].t;
+        const float* Tp = (TALL_IS_Z ? evals[e].Z : evals[e].X) + (size_t)c0 * TRp + row_lo;
+        const float* Sp = (TALL_IS_Z ? evals[e].X : evals[e].Z) + (size_t)c0 * SRp;
+        float* Tb = Tl + buf * (KC * (TLS + SLS));
+        float* Sb = Sl + buf * (KC * (TLS + SLS));
+        const int ncols = min(KC, Bpad - c0);               // (uniform) columns of the step that exist; Bpad is a multiple of 16
+#pragma unroll
+        for (int jj = 0; jj < 10; ++jj) {
+            const int u = w + 7 * jj, c = u >> 1;
+            if (wg_off[jj] >= 0 && c < ncols) dma_unit((const f32x4*)(Tp + wg_off[jj]), Tb + c * TLS + 256 * (u & 1));
+        }
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) {
+            const int u = w + 7 * jj;
+            if (ng_off[jj] >= 0 && 2 * u + (lane >= 36 ? 1 : 0) < ncols) dma_unit((const f32x4*)(Sp + ng_off[jj]), Sb + 2 * u * SLS);
+        }
+        if (tid < KC) {                                     // the synthetic rows, and zeros for columns past the batch (their old image is stale)
+            const f32x4 syn = tid < ncols ? (f32x4){te, 1.f, 0.f, 0.f} : (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (wide_syn >= 0) *(f32x4*)(Tb + tid * TLS + wide_syn) = syn;
+            if (narrow_syn >= 0) *(f32x4*)(Sb + tid * SLS + narrow_syn) = syn;
+        }
+        if (ncols < KC) {                                   // (only when Bpad is not a multiple of 32: last step of an evaluation)
+            for (int i = tid; i < (KC - ncols) * (TLS / 4); i += 448) {
+                const int c = ncols + i / (TLS / 4), r4 = i - (c - ncols) * (TLS / 4);
+                if (4 * r4 != wide_syn) *(f32x4*)(Tb + c * TLS + 4 * r4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            for (int i = tid; i < (KC - ncols) * (SLS / 4); i += 448) {
+                const int c = ncols + i / (SLS / 4), r4 = i - (c - ncols) * (SLS / 4);
+                if (4 * r4 != narrow_syn) *(f32x4*)(Sb + c * SLS + 4 * r4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    __syncthreads();                                        // the zeroed image is complete before any unit lands in it
+    if (total_steps > 0) stage_dma(0);
+    wait_vm<0>();
+    __syncthreads();
+    for (int step = 0; step < total_steps; ++step) {
+        const float* Tb = Tl + (step & 1) * (KC * (TLS + SLS));
+        const float* Sb = Sl + (step & 1) * (KC * (TLS + SLS));
+        // Every wave has left the previous step (the barrier below), so the other buffer is free: the next step's units go out
+        // under this step's MFMAs -- after the first k-step in waves 0..3, after the fifth in waves 4..6, so that of the two waves
+        // that share a SIMD one keeps the matrix pipe fed while the other runs the ~300 scalar instructions of the staging.
+        // the operands of k-step s + 1 are requested from LDS before the MFMAs of k-step s are issued (two register sets)
+        float a[2][4], bq[2][7];
+        auto operands = [&](int s, float (&av)[4], float (&bv)[7]) {
+            const int col = 4 * s + kk;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) av[i] = Tb[col * TLS + 16 * (w + 7 * i) + mrow];
+            av[3] = Tb[col * TLS + 16 * (has3 ? w + 21 : w) + mrow];
+#pragma unroll
+            for (int n = 0; n < 7; ++n) bv[n] = Sb[col * SLS + 16 * n + mrow];
+        };
+        operands(0, a[0], bq[0]);
+#pragma unroll
+        for (int s = 0; s < KC / 4; ++s) {
+            __builtin_amdgcn_sched_barrier(0);             // (keeps the compiler from hoisting all eight k-steps' operand reads: 88 registers)
+            if (s + 1 < KC / 4) operands(s + 1, a[(s + 1) & 1], bq[(s + 1) & 1]);
+            if ((s == 1 || s == 5) && s == (w < 4 ? 1 : 5) && step + 1 < total_steps) stage_dma((step + 1) & 1);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int n = 0; n < 7; ++n) acc[i][n] = mfma16(a[s & 1][i], bq[s & 1][n], acc[i][n]);
+            if (has3) {
+#pragma unroll
+                for (int n = 0; n < 7; ++n) acc[3][n] = mfma16(a[s & 1][3], bq[s & 1][n], acc[3][n]);
+            }
+        }
+        wait_vm<0>();                                       // this wave's units of step + 1 have landed
+        __syncthreads();
+    }
+#else
     // fetch of one step: the wide half is 32 columns x nrow/4 float4 (8 slots per thread), the narrow operand 32 x 28 float4 (2).
     // Slot coordinates do not depend on the step: column within the step and first row of the float4 (M, Nx are multiples of
     // 4, so a float4 is either four real rows, or the synthetic {t, 1, 0, 0} rows of [X; t; 1], or padding).
@@ -785,6 +890,7 @@ __global__ __launch_bounds__(448) void rnde_wgrad3_kernel(const EvalDesc* __rest
         if (step + 2 < total_steps) fetch(step + 2);
         __syncthreads();
     }
+#endif
     // D register q of lane l = C[wide row 16 T + 4 (l >> 4) + q][narrow row 16 n + (l & 15)]
     float* out = slab + (size_t)chunk * M * (Nx + 2);
 #pragma unroll

@@ -191,6 +191,31 @@ def test_async_backward_matches_the_synchronous_one(rnde):
     assert abs(float(l2) - l1) <= 1e-6 * max(1.0, abs(l1))
 
 
+def test_one_call_step_gradient_equals_the_three_calls_at_the_headline_shape(rnde):
+    """rnde_node_classifier_grad (forward + head + reverse in one call, head and reverse packs queued before the forward's host wait)
+    against rnde_node_forward + rnde_classifier_head + rnde_node_backward: the same kernels on the same inputs in the same order --
+    loss, NFE and both gradients bit for bit, MNIST shape, B = 512, tol 1.4e-8; twice, so a stale pack or tape would show."""
+    rn = rnde
+    g = torch.Generator().manual_seed(11)
+    dyn = rn.MLPDynamics(784, 100, generator=g)
+    node = rn.TrackedNeuralODE(dyn, [0.0, 1.0], True, True, "Tsit5", reltol=1.4e-8, abstol=1.4e-8, max_batch=512, max_attempts=256)
+    model = rn.ClassifierNODE(node, rn.Dense(784, 10, generator=g), device=torch.device("cuda", 0))
+    x = torch.rand(512, 1, 28, 28, generator=g).cuda()
+    y = torch.eye(10)[torch.randint(0, 10, (512,), generator=g)].cuda()
+    for rep in range(2):
+        l1, ce1, reg1, nfe1 = rn.fused_loss_and_grad(model, x, y, lam=100.0)               # three calls, synchronising
+        g2, g3 = model.p2.grad.clone(), model.p3.grad.clone()
+        l2, ce2, reg2, nfe2 = rn.fused_loss_and_grad(model, x, y, lam=100.0, sync=False)   # one call
+        torch.cuda.synchronize()
+        assert nfe1 == nfe2 and reg1 == pytest.approx(reg2, rel=1e-6) and float(ce2) == ce1
+        assert torch.equal(model.p2.grad, g2) and torch.equal(model.p3.grad, g3)
+        with torch.no_grad():
+            model.p2.add_(0.01 * torch.randn(model.p2.shape, generator=g).cuda())           # new weights: the packs must follow
+    for hs in node._handles.values():
+        for h in hs:
+            assert rn._lib.lib().rnde_node_fallback_count(h.ptr) == 0
+
+
 def _latent_batch(g, B, T=49, in_dim=37):
     data = torch.randn(B, T, in_dim, generator=g)
     mask = (torch.rand(B, T, in_dim, generator=g) > 0.7).float()

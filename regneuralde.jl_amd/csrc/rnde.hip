@@ -625,6 +625,27 @@ static rnde_status stage_pack_weights(rnde_node* h, const float* p_dev, hipStrea
     HIPCHK(h, stage_pack(h, p_dev, h->spwD, 1, h->sHT, h->sMT, s));
     return RNDE_OK;
 }
+static rnde_status stage_pack_all(rnde_node* h, const float* p_dev, hipStream_t s) {
+    PackJobs J{};
+    const int TR = 64 / h->NG;
+    int n = 0;
+    auto add = [&](void* dst, long long total, int kind, int which, int kdim) { J.j[n++] = PackJob{dst, total, kind, which, kdim, 0}; };
+    add(h->spwB, (long long)h->sMT * h->sK2b * 64, 0, 0, h->sK2b);
+    add(h->spwD, (long long)h->sHT * h->sMT * 64, 0, 1, h->sMT);
+    add(h->spwBt, (long long)h->sMT * h->sKHb * 64, 0, 2, h->sKHb);
+    add(h->spwDt, (long long)h->sHT * h->sMT * 64, 0, 3, h->sMT);
+    add(h->pw2t, (long long)h->MT2t * h->K4_2t * TR, 1, 2, h->K4_2t);     // (rnde_binit_kernel: column-owner layouts)
+    add(h->pw1t, (long long)h->MT1t * h->K4_1t * TR, 1, 3, h->K4_1t);
+    add(h->pcopy, (long long)h->P, 2, 0, 0);
+    long long most = 0;
+    for (int i = 0; i < n; ++i) most = std::max(most, J.j[i].total);
+    const int grid = (int)std::min<long long>((most + 255) / 256, 256);
+    if (h->NG == 1) hipLaunchKernelGGL(rnde_pack_all_kernel<1>, dim3(grid, n), dim3(256), 0, s, p_dev, J, h->D, h->H);
+    else hipLaunchKernelGGL(rnde_pack_all_kernel<2>, dim3(grid, n), dim3(256), 0, s, p_dev, J, h->D, h->H);
+    HIPCHK(h, hipGetLastError());
+    h->rev_packed = true;
+    return RNDE_OK;
+}
 // The hand-off slabs must read "empty" wherever the persistent kernels have not written in the current tile indexing: at
 // creation, and whenever the padded batch width (= number of column tiles) differs from the last persistent launch's.
 static hipError_t slab_prepare(rnde_node* h, int Bpad, hipStream_t s) {
@@ -750,7 +771,7 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
         // the tape owns copies of x and p (the caller may free or overwrite its buffers before backward)
         if (B % h->BT) HIPCHK(h, hipMemsetAsync(h->xcopy, 0, (size_t)h->D * (((B + h->BT - 1) / h->BT) * h->BT) * 4, s));
         HIPCHK(h, hipMemcpyAsync(h->xcopy, x_dev, (size_t)h->D * B * 4, hipMemcpyDeviceToDevice, s));
-        HIPCHK(h, hipMemcpyAsync(h->pcopy, p_dev, (size_t)h->P * 4, hipMemcpyDeviceToDevice, s));
+        if (h->engine != 2) HIPCHK(h, hipMemcpyAsync(h->pcopy, p_dev, (size_t)h->P * 4, hipMemcpyDeviceToDevice, s));   // (stage engine: part of the one pack launch below)
         x_dev = h->xcopy;
     }
     StepParams P = make_params(h, x_dev, B, t0, t1, keep_tape ? 1 : 0);
@@ -766,8 +787,10 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
         P.replay = h->replay_dev; P.n_replay = h->n_replay;
     }
     h->B = B; h->Bpad = P.Bpad; h->nwg = P.nwg; h->t0 = t0; h->t1 = t1;
-    rnde_status st = h->engine == 3 ? chain_pack(h, keep_tape ? h->pcopy : p_dev, s)
-                                    : pack_weights(h, p_dev, keep_tape != 0, s, h->engine != 2);   // (column-owner packs: also used by the reverse sweep)
+    rnde_status st = RNDE_OK;
+    if (h->engine == 2 && keep_tape) st = stage_pack_all(h, p_dev, s);   // forward + reverse packs of both engines' layouts and the tape's copy of p: one launch
+    else st = h->engine == 3 ? chain_pack(h, keep_tape ? h->pcopy : p_dev, s)
+                             : pack_weights(h, p_dev, keep_tape != 0, s, h->engine != 2);   // (column-owner packs: also used by the reverse sweep)
     if (st != RNDE_OK) return st;
     StageParams SQ{};
     ChainParams CQ{};
@@ -784,8 +807,7 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
             HIPCHK(h, launch_chain<CM_INIT_B>(h, CQ, 0, nullptr, s));
         }
     } else if (h->engine == 2) {
-        st = stage_pack_weights(h, keep_tape ? h->pcopy : p_dev, s);
-        if (st != RNDE_OK) return st;
+        if (!keep_tape) { st = stage_pack_weights(h, p_dev, s); if (st != RNDE_OK) return st; }
         SQ = make_stage_params(h, P, keep_tape ? h->pcopy : p_dev);
         HIPCHK(h, launch_stage<SM_I1>(h, SQ, 0, 0, s));
         HIPCHK(h, launch_stage<SM_I2>(h, SQ, 0, 0, s));
@@ -1184,8 +1206,10 @@ static rnde_status bwd_prepare(rnde_node* h) {
     HIPCHK(h, hipMalloc((void**)&b.bpart, (size_t)(2 * h->nwg_max + 256) * 4 * 4)); HIPCHK(h, hipMalloc((void**)&b.ipart, (size_t)2 * h->nwg_max * 4 * 4));   // (+256 entries: finish_attempt_scalars reads whole 256-entry blocks)
     HIPCHK(h, hipMalloc((void**)&b.tspan_out, 2 * 4));
     const size_t nev = (size_t)6 * cap + 2;
-    HIPCHK(h, hipMalloc((void**)&b.ev1, nev * sizeof(EvalDesc))); HIPCHK(h, hipMalloc((void**)&b.ev2, nev * sizeof(EvalDesc)));
-    HIPCHK(h, hipHostMalloc((void**)&b.h_ev1, nev * sizeof(EvalDesc))); HIPCHK(h, hipHostMalloc((void**)&b.h_ev2, nev * sizeof(EvalDesc)));
+    // (ev1 / h_ev1 are sized for [ev1 | ev2 | svb] back to back: bwd_run lays the three out contiguously and sends them in ONE copy)
+    const size_t desc_blob = 2 * nev * sizeof(EvalDesc) + (size_t)cap * 4 + 64;
+    HIPCHK(h, hipMalloc((void**)&b.ev1, desc_blob)); HIPCHK(h, hipMalloc((void**)&b.ev2, nev * sizeof(EvalDesc)));
+    HIPCHK(h, hipHostMalloc((void**)&b.h_ev1, desc_blob)); HIPCHK(h, hipHostMalloc((void**)&b.h_ev2, nev * sizeof(EvalDesc)));
     HIPCHK(h, hipHostMalloc((void**)&b.h_svb, (size_t)cap * 4));
     const size_t seg = std::max((size_t)h->H * (h->D + 2), (size_t)h->D * (h->H + 2));
     b.slab_floats = seg * 256;              // per layer; two layers back to back
@@ -1323,11 +1347,15 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
     const float svb_scale = h->couple ? (float)h->couple_world : 1.f;
     for (int i = 0; i < n_att; ++i)
         b.h_svb[i] = (saveval_bar_host && h->sv_index[i] >= 0) ? svb_scale * saveval_bar_host[h->sv_index[i]] : 0.f;
-    HIPCHK(h, hipMemcpyAsync(b.svb_att, b.h_svb, (size_t)n_att * 4, hipMemcpyHostToDevice, s));
+    // one host-to-device copy for everything the reverse pass reads from the host: [ev1 (ne) | ev2 (ne) | svb (n_att)], ne = 2 + 6 n_att
+    const int ne_all = 2 + 6 * n_att;
+    EvalDesc* const h_ev1 = b.h_ev1; EvalDesc* const h_ev2 = b.h_ev1 + ne_all; float* const h_svb_blob = (float*)(b.h_ev1 + 2 * (size_t)ne_all);
+    EvalDesc* const d_ev1 = b.ev1;   EvalDesc* const d_ev2 = b.ev1 + ne_all;   float* const d_svb = (float*)(b.ev1 + 2 * (size_t)ne_all);
+    memcpy(h_svb_blob, b.h_svb, (size_t)n_att * 4);
     BwdParams Q{};
     Q.F = make_params(h, h->xcopy, h->B, h->t0, h->t1, 1);
     Q.pw2t = h->pw2t; Q.pw1t = h->pw1t; Q.K4_2t = h->K4_2t; Q.MT2t = h->MT2t; Q.K4_1t = h->K4_1t; Q.MT1t = h->MT1t;
-    Q.U = b.U; Q.K1 = b.K1; Q.UB1 = b.UB1; Q.zi2 = b.zi2; Q.zi1 = b.zi1; Q.svb_att = b.svb_att;
+    Q.U = b.U; Q.K1 = b.K1; Q.UB1 = b.UB1; Q.zi2 = b.zi2; Q.zi1 = b.zi1; Q.svb_att = d_svb;
     Q.bstate = b.bstate; Q.ibstate = b.ibstate; Q.bpart = b.bpart; Q.ipart = b.ipart;
     Q.ubar = u_bar_dev; Q.xbar = x_bar_dev; Q.tspan_out = b.tspan_out;
     Q.n_att = n_att; Q.track_ctrl = h->cfg.track_ctrl; Q.track_initdt = h->cfg.track_initdt; Q.reg_kind = h->cfg.regularize;
@@ -1345,20 +1373,19 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
     // order: the two evaluations of the initial-step heuristic, then 6 per attempt -- so that "everything up to attempt n" is
     // one contiguous range for the launch that runs after the sweep
     int ne = 2;
-    b.h_ev2[0] = EvalDesc{b.zi2, h->h0, h->t0, 0};           b.h_ev1[0] = EvalDesc{b.zi1, h->xcopy, h->t0, 0};
-    b.h_ev2[1] = EvalDesc{b.zi2 + A, h->h1, h->t0 + h->h_init->dt0, 0}; b.h_ev1[1] = EvalDesc{b.zi1 + HB, h->u1, h->t0 + h->h_init->dt0, 0};
+    h_ev2[0] = EvalDesc{b.zi2, h->h0, h->t0, 0};           h_ev1[0] = EvalDesc{b.zi1, h->xcopy, h->t0, 0};
+    h_ev2[1] = EvalDesc{b.zi2 + A, h->h1, h->t0 + h->h_init->dt0, 0}; h_ev1[1] = EvalDesc{b.zi1 + HB, h->u1, h->t0 + h->h_init->dt0, 0};
     for (int n = 0; n < n_att; ++n) {
         const StepMeta& m = h->h_meta[n];
         const float* R = h->arena + (long long)m.rec * h->rec_stride;
         for (int sidx = 2; sidx <= 7; ++sidx) {
             const float ts = m.t + tsC(sidx - 1) * m.dt;
-            b.h_ev2[ne] = EvalDesc{R + L.k(sidx), R + L.h(sidx), ts, 0};
-            b.h_ev1[ne] = EvalDesc{R + L.z1(sidx), sidx < 7 ? R + L.g(sidx) : R + L.unew(), ts, 0};
+            h_ev2[ne] = EvalDesc{R + L.k(sidx), R + L.h(sidx), ts, 0};
+            h_ev1[ne] = EvalDesc{R + L.z1(sidx), sidx < 7 ? R + L.g(sidx) : R + L.unew(), ts, 0};
             ++ne;
         }
     }
-    HIPCHK(h, hipMemcpyAsync(b.ev1, b.h_ev1, (size_t)ne * sizeof(EvalDesc), hipMemcpyHostToDevice, s));
-    HIPCHK(h, hipMemcpyAsync(b.ev2, b.h_ev2, (size_t)ne * sizeof(EvalDesc), hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(b.ev1, b.h_ev1, 2 * (size_t)ne * sizeof(EvalDesc) + (size_t)n_att * 4, hipMemcpyHostToDevice, s));
     float* slab1 = b.slab;
     float* slab2w = b.slab + b.slab_floats;
     int cur1 = 0, cur2 = 0, evi = 0;
@@ -1387,9 +1414,9 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
             HIPCHK(h, hipStreamWaitEvent(h->wstream, ev, 0));
             ws = h->wstream; used_side = true;
         }
-        rnde_status r = launch_wgrad_part(h, b.ev1 + lo, hi - lo, per_chunk, h->H, h->D, h->B, slab1, &cur1, ws, on_side ? 16 : 0);
+        rnde_status r = launch_wgrad_part(h, d_ev1 + lo, hi - lo, per_chunk, h->H, h->D, h->B, slab1, &cur1, ws, on_side ? 16 : 0);
         if (r != RNDE_OK) return r;
-        return launch_wgrad_part(h, b.ev2 + lo, hi - lo, per_chunk, h->D, h->H, h->B, slab2w, &cur2, ws, on_side ? 16 : 0);
+        return launch_wgrad_part(h, d_ev2 + lo, hi - lo, per_chunk, h->D, h->H, h->B, slab2w, &cur2, ws, on_side ? 16 : 0);
     };
     int hi_att = n_att;                                           // evaluations of attempts >= hi_att are already launched
     hipError_t e;
@@ -1580,11 +1607,7 @@ extern "C" rnde_status rnde_node_classifier_grad(rnde_node* h, const float* x_de
     int64_t nfe = 0;
     h->after_solve = [&](hipStream_t s) -> rnde_status {
         const rnde_status r = rnde_classifier_head(h, u, p3_dev, y_dev, B, n_classes, nullptr, ubar, p3_bar_dev, ce_out_dev, s);
-        if (r != RNDE_OK) return r;
-        HIPCHK(h, stage_pack(h, h->pcopy, h->spwBt, 2, h->sMT, h->sKHb, s));
-        HIPCHK(h, stage_pack(h, h->pcopy, h->spwDt, 3, h->sHT, h->sMT, s));
-        h->rev_packed = true;
-        return RNDE_OK;
+        return r;
     };
     st = forward_impl(h, x_dev, p2_dev, B, t0, t1, u, nullptr, 0, nullptr, &nfe, h->cg_sv.data(), &nsv, 1, stream);
     h->after_solve = nullptr;

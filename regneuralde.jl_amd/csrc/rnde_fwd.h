@@ -19,37 +19,41 @@ namespace rnde {
 // Packed element (tile T, k4, r, kk) = Wext[T*TR + r][4*k4 + kk], zero outside.
 // ------------------------------------------------------------------------------------------
 template <int NG>
-__global__ void rnde_pack_kernel(const float* __restrict__ p, f32x4* __restrict__ dst, int which, int D, int H,
-                                 int MT, int K4) {
+__device__ __forceinline__ f32x4 pack_elem(const float* __restrict__ p, int which, int D, int H, int K4, long long i) {
     using G = Geo<NG>;
-    const long long total = (long long)MT * K4 * G::TR;
     const float* W1 = p;
     const float* b1 = W1 + (size_t)H * (D + 1);
     const float* W2 = b1 + H;
     const float* b2 = W2 + (size_t)D * (H + 1);
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int r = (int)(i % G::TR);
-        const int k4 = (int)((i / G::TR) % K4);
-        const int T = (int)(i / ((long long)G::TR * K4));
-        const int m = T * G::TR + r;
-        f32x4 v;
+    const int r = (int)(i % G::TR);
+    const int k4 = (int)((i / G::TR) % K4);
+    const int T = (int)(i / ((long long)G::TR * K4));
+    const int m = T * G::TR + r;
+    f32x4 v;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int k = 4 * k4 + kk;
-            float w = 0.f;
-            if (which == 0) {  // pw1
-                if (m < H) w = k <= D ? W1[(size_t)k * H + m] : (k == D + 1 ? b1[m] : 0.f);
-            } else if (which == 1) {  // pw2
-                if (m < D) w = k <= H ? W2[(size_t)k * D + m] : (k == H + 1 ? b2[m] : 0.f);
-            } else if (which == 2) {  // pw2t: rows m<=H are columns m of W2 (m == H: time column)
-                if (m <= H && k < D) w = W2[(size_t)m * D + k];
-            } else {  // pw1t
-                if (m <= D && k < H) w = W1[(size_t)m * H + k];
-            }
-            v[kk] = w;
+    for (int kk = 0; kk < 4; ++kk) {
+        const int k = 4 * k4 + kk;
+        float w = 0.f;
+        if (which == 0) {  // pw1
+            if (m < H) w = k <= D ? W1[(size_t)k * H + m] : (k == D + 1 ? b1[m] : 0.f);
+        } else if (which == 1) {  // pw2
+            if (m < D) w = k <= H ? W2[(size_t)k * D + m] : (k == H + 1 ? b2[m] : 0.f);
+        } else if (which == 2) {  // pw2t: rows m<=H are columns m of W2 (m == H: time column)
+            if (m <= H && k < D) w = W2[(size_t)m * D + k];
+        } else {  // pw1t
+            if (m <= D && k < H) w = W1[(size_t)m * H + k];
         }
-        dst[i] = v;
+        v[kk] = w;
     }
+    return v;
+}
+template <int NG>
+__global__ void rnde_pack_kernel(const float* __restrict__ p, f32x4* __restrict__ dst, int which, int D, int H,
+                                 int MT, int K4) {
+    using G = Geo<NG>;
+    const long long total = (long long)MT * K4 * G::TR;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+        dst[i] = pack_elem<NG>(p, which, D, H, K4, i);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -49,30 +49,47 @@ __device__ __forceinline__ f32x4 fma4(float s, f32x4 a, f32x4 c) { return __buil
 //        1 pwD fwd  = W1x   (rows H, k < D)
 //        2 pwB bwd  = W1x^T (rows D, k < H):   W1[k][row]
 //        3 pwD bwd  = W2xt^T (rows H+1, k < D): row m < H: W2[k][m]; m == H: W2[k][H] (time column)
-__global__ void rnde_stage_pack_kernel(const float* __restrict__ p, f32x4* __restrict__ dst, int which, int D, int H,
-                                       int MTrows, int Kb) {
+__device__ __forceinline__ f32x4 stage_pack_elem(const float* __restrict__ p, int which, int D, int H, int Kb, long long i) {
     const float* W1 = p;
     const float* b1 = W1 + (size_t)H * (D + 1);
     const float* W2 = b1 + H;
     const float* b2 = W2 + (size_t)D * (H + 1);
-    const long long total = (long long)MTrows * Kb * 64;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int l = (int)(i & 63);
-        const int kb = (int)((i >> 6) % Kb);
-        const int T = (int)((i >> 6) / Kb);
-        const int m = 16 * T + (l & 15);
-        f32x4 v;
+    const int l = (int)(i & 63);
+    const int kb = (int)((i >> 6) % Kb);
+    const int T = (int)((i >> 6) / Kb);
+    const int m = 16 * T + (l & 15);
+    f32x4 v;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k = 16 * kb + 4 * q + (l >> 4);
-            float w = 0.f;
-            if (which == 0) { if (m < D) w = k <= H ? W2[(size_t)k * D + m] : (k == H + 1 ? b2[m] : 0.f); }
-            else if (which == 1) { if (m < H && k < D) w = W1[(size_t)k * H + m]; }
-            else if (which == 2) { if (m < D && k < H) w = W1[(size_t)m * H + k]; }
-            else { if (m <= H && k < D) w = W2[(size_t)m * D + k]; }
-            v[q] = w;
-        }
-        dst[i] = v;
+    for (int q = 0; q < 4; ++q) {
+        const int k = 16 * kb + 4 * q + (l >> 4);
+        float w = 0.f;
+        if (which == 0) { if (m < D) w = k <= H ? W2[(size_t)k * D + m] : (k == H + 1 ? b2[m] : 0.f); }
+        else if (which == 1) { if (m < H && k < D) w = W1[(size_t)k * H + m]; }
+        else if (which == 2) { if (m < D && k < H) w = W1[(size_t)m * H + k]; }
+        else { if (m <= H && k < D) w = W2[(size_t)m * D + k]; }
+        v[q] = w;
+    }
+    return v;
+}
+__global__ void rnde_stage_pack_kernel(const float* __restrict__ p, f32x4* __restrict__ dst, int which, int D, int H,
+                                       int MTrows, int Kb) {
+    const long long total = (long long)MTrows * Kb * 64;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+        dst[i] = stage_pack_elem(p, which, D, H, Kb, i);
+}
+
+// Everything a taped solve derives from the parameter vector, in ONE launch (was six pack launches and a copy, ~5 us each, in front
+// of every training step): blockIdx.y selects the job -- a stage-engine pack (kind 0), a column-owner pack for the kernels of the
+// initial-step rule (kind 1), or the tape's own copy of p (kind 2).
+struct PackJob { void* dst; long long total; int kind, which, kdim, pad; };
+struct PackJobs { PackJob j[8]; };
+template <int NG>
+__global__ void rnde_pack_all_kernel(const float* __restrict__ p, const PackJobs J, int D, int H) {
+    const PackJob job = J.j[blockIdx.y];
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < job.total; i += (long long)gridDim.x * blockDim.x) {
+        if (job.kind == 0) ((f32x4*)job.dst)[i] = stage_pack_elem(p, job.which, D, H, job.kdim, i);
+        else if (job.kind == 1) ((f32x4*)job.dst)[i] = pack_elem<NG>(p, job.which, D, H, job.kdim, i);
+        else ((float*)job.dst)[i] = p[i];
     }
 }
 

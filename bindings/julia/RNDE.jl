@@ -224,6 +224,27 @@ function nsde_backward(h::NsdeHandle, ubar::ROCMatrix{Float32}, svbar::Vector{Fl
     return xbar, pbar
 end
 
+# ---- one training-step gradient in one call ------------------------------------------------------------
+# loss_function + Tracker.gradient of experiments/mnist_node.jl:132-137, :229-233 for ClassifierNODE with preode = identity:
+# forward solve (taped) -> Dense(D, C) + logitcrossentropy and their reverse -> reverse solve, with the head queued before the
+# forward's host wait.  Returns (ce (1-element device array), lambda * mean(saveval), nfe); the gradients land in p2bar / p3bar
+# in stream order.  comm: the handle of comm_create (C_NULL: single GPU) -- both gradients are then sum-all-reduced in place.
+function classifier_grad!(p2bar::ROCVector{Float32}, p3bar::ROCVector{Float32}, h::Handle, x::ROCMatrix{Float32},
+                          p2::ROCVector{Float32}, p3::ROCVector{Float32}, y::ROCMatrix{Float32}, tspan; lambda = 1f2,
+                          comm::Ptr{Cvoid} = C_NULL)
+    ce = ROCVector{Float32}(undef, 1)
+    reg = Ref{Cfloat}(0); nfe = Ref{Int64}(0)
+    st = GC.@preserve p2bar p3bar x p2 p3 y ce begin
+        ccall((:rnde_node_classifier_grad, LIB), Cint,
+              (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int32, Cfloat, Cfloat, Cfloat,
+               Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Cfloat}, Ref{Int64}, Ptr{Cvoid}, Ptr{Cvoid}),
+              h.ptr, devptr(x), devptr(p2), devptr(p3), devptr(y), size(x, 2), size(y, 1), Float32(tspan[1]), Float32(tspan[2]),
+              Float32(lambda), devptr(p2bar), devptr(p3bar), C_NULL, devptr(ce), reg, nfe, comm, C_NULL)
+    end
+    st == 0 || error("rnde_node_classifier_grad: ", unsafe_string(ccall((:rnde_last_error, LIB), Cstring, (Ptr{Cvoid},), h.ptr)))
+    return ce, reg[], nfe[]
+end
+
 # ---- optimiser step and the data-parallel collective -------------------------------------------------
 # Optimiser(InvDecay(gamma), Momentum(eta, rho)) on one flat group, in place (src/utils.jl:149-156, mnist_node.jl:130);
 # `n` is the group's InvDecay counter (starts at 1, the caller increments it); gscale = 1 / nworkers after a summed all-reduce.

@@ -365,6 +365,18 @@ rnde_status rnde_nsde_backward_async(rnde_nsde* h, const float* u_bar_dev, const
  * dimension.  (With several trajectories the logits are averaged first: that stays on the host side.) */
 rnde_status rnde_nsde_classifier_head(rnde_nsde* h, const float* u_dev, const float* p3_dev, const float* y_dev, int32_t B, int32_t n_classes,
                                       float* logits_out_dev, float* u_bar_dev, float* p3_bar_dev, float* ce_out_dev, void* stream);
+
+/* The SDE counterpart of rnde_node_classifier_grad: one training-step gradient of ClassifierNSDE's loss around the solve, ONE trajectory
+ * per input (reference src/models/supervised_classification.jl:82-103 with experiments/mnist_nsde.jl's loss_function and Tracker.gradient):
+ *     u = TrackedNeuralDSDE(x, p2)  ->  ce = logitcrossentropy(Dense_p3(u), y)  ->  loss = ce + lambda * mean(sv.saveval)
+ * = rnde_nsde_forward (taped; noise as there: the caller's pool, or NULL + seed for the library's stream) + rnde_nsde_classifier_head +
+ * rnde_nsde_backward_async, the head queued before the forward's host wait.  x is the SDE's initial state (the presde layer's output), x_bar_dev
+ * its cotangent (D x B, required: the presde layer's gradient needs it).  *reg_out_host, *nfe1_out, *nfe2_out are valid on return; the gradients and
+ * ce_out_dev in stream order. */
+rnde_status rnde_nsde_classifier_grad(rnde_nsde* h, const float* x_dev, const float* p2_dev, const float* p3_dev, const float* y_dev,
+                                      int32_t B, int32_t n_classes, float t0, float t1, const float* noise_dev, int32_t n_pool,
+                                      uint64_t seed, float lambda, float* p2_bar_dev, float* p3_bar_dev, float* x_bar_dev,
+                                      float* ce_out_dev, float* reg_out_host, int64_t* nfe1_out, int64_t* nfe2_out, void* stream);
 /* Per-attempt log of the last forward: 4 floats per attempt (t, dt, EEst, accepted); draws_out = noise draws consumed. */
 rnde_status rnde_nsde_steps(rnde_nsde* h, float* steps_host, int32_t capacity, int32_t* n_attempts_out, int32_t* draws_out);
 /* Kernel-level parity entry: ONE attempted step from (uprev, dt, dW, dZ), all D x B device arrays: kg_out_dev receives

@@ -122,6 +122,7 @@ def lib():
     L.rnde_nsde_backward.argtypes = [vp, vp, fp, vp, vp, vp]
     L.rnde_nsde_backward_async.argtypes = [vp, vp, fp, vp, vp, vp]
     L.rnde_nsde_classifier_head.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]
+    L.rnde_nsde_classifier_grad.argtypes = [vp, vp, vp, vp, vp, i32, i32, f, f, vp, i32, C.c_uint64, f, vp, vp, vp, vp, fp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), vp]
     L.rnde_nsde_steps.argtypes = [vp, fp, i32, i32p, i32p]
     L.rnde_nsde_debug_attempt.argtypes = [vp, vp, vp, i32, f, vp, vp, vp, vp, fp, vp]
     L.rnde_nsde_timing.argtypes = [vp, fp, fp, i32p, i32p]
@@ -137,7 +138,7 @@ EXPORTS = ["rnde_version", "rnde_last_error", "rnde_param_count", "rnde_node_cre
            "rnde_node_launches_per_attempt", "rnde_classifier_head", "rnde_node_classifier_grad", "rnde_momentum_step", "rnde_momentum_step_scaled", "rnde_adam_step",
            "rnde_comm_unique_id", "rnde_comm_create", "rnde_comm_destroy", "rnde_comm_world", "rnde_comm_last_error", "rnde_comm_allreduce", "rnde_comm_create_local_group", "rnde_comm_health", "rnde_node_set_coupling", "rnde_has_column_owner", "rnde_tapes_create", "rnde_tapes_destroy", "rnde_tapes_last_error", "rnde_tapes_in_use", "rnde_tapes_node", "rnde_tapes_forward", "rnde_tapes_backward", "rnde_tapes_release",
            "rnde_nsde_param_count", "rnde_nsde_create", "rnde_nsde_destroy", "rnde_nsde_last_error", "rnde_nsde_forward",
-           "rnde_nsde_forward_saveat", "rnde_nsde_forward_replay", "rnde_nsde_backward", "rnde_nsde_backward_async", "rnde_nsde_classifier_head", "rnde_nsde_steps", "rnde_nsde_debug_attempt", "rnde_nsde_timing", "rnde_normal_fill"]
+           "rnde_nsde_forward_saveat", "rnde_nsde_forward_replay", "rnde_nsde_backward", "rnde_nsde_backward_async", "rnde_nsde_classifier_head", "rnde_nsde_classifier_grad", "rnde_nsde_steps", "rnde_nsde_debug_attempt", "rnde_nsde_timing", "rnde_normal_fill"]
 
 
 def check(h, status):

@@ -1829,8 +1829,9 @@ static rnde_status chain_bwd_run(rnde_node* h, const float* u_bar_dev, const flo
     if (h->cslab_floats < need) {
         if (h->cslab) hipFree(h->cslab);
         h->cslab = nullptr; h->cslab_floats = 0;
-        HIPCHK(h, hipMalloc((void**)&h->cslab, need * 4));
-        h->cslab_floats = need;
+        const size_t grow = need + need / 2;        // (head room: a step count that creeps up while a model trains must not free + allocate every step)
+        if (hipMalloc((void**)&h->cslab, grow * 4) == hipSuccess) h->cslab_floats = grow;
+        else { HIPCHK(h, hipMalloc((void**)&h->cslab, need * 4)); h->cslab_floats = need; }
     }
     Q.slab = h->cslab;
     // evaluation times (time column of TDChain layers) and the save indices each accepted attempt covers

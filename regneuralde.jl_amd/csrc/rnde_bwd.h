@@ -674,6 +674,9 @@ __global__ __launch_bounds__(256) void rnde_wgrad2_kernel(const EvalDesc* __rest
 #ifndef RNDE_WGRAD3_PIPE
 #define RNDE_WGRAD3_PIPE 1
 #endif
+#ifndef RNDE_WGRAD3_NT
+#define RNDE_WGRAD3_NT 1   // non-temporal wide-operand stream: the reverse sweep running beside the side-stream launches keeps its L2 (32.55 -> 32.23 us per reversed attempt)
+#endif
 template <bool TALL_IS_Z>
 __global__ __launch_bounds__(448) void rnde_wgrad3_kernel(const EvalDesc* __restrict__ evals, int n_evals, int per_chunk,
                                                           int M, int Nx, int Bpad, float* __restrict__ slab) {
@@ -736,7 +739,11 @@ __global__ __launch_bounds__(448) void rnde_wgrad3_kernel(const EvalDesc* __rest
 #pragma unroll
         for (int jj = 0; jj < 10; ++jj) {
             const int u = w + 7 * jj, c = u >> 1;
+#if RNDE_WGRAD3_NT
+            if (wg_off[jj] >= 0 && c < ncols) dma_unit_nt((const f32x4*)(Tp + wg_off[jj]), Tb + c * TLS + 256 * (u & 1));
+#else
             if (wg_off[jj] >= 0 && c < ncols) dma_unit((const f32x4*)(Tp + wg_off[jj]), Tb + c * TLS + 256 * (u & 1));
+#endif
         }
 #pragma unroll
         for (int jj = 0; jj < 3; ++jj) {

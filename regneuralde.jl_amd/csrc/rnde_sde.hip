@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -22,6 +23,10 @@ struct rnde_nsde {
     rnde_nsde_config cfg{};
     int D = 0, Pf = 0, Pg = 0, P = 0, NKD = 8, Bpad_max = 0, ntiles_max = 0, nwg_max = 0;
     float* head_ws = nullptr; size_t head_ws_floats = 0;   // rnde_nsde_classifier_head
+    // rnde_nsde_classifier_grad: work the forward enqueues behind the copies its host wait needs (it runs while the host wakes up), the
+    // event that wait uses, and the buffers of the fused step
+    std::function<rnde_status(hipStream_t)> after_solve; hipEvent_t ev_host = nullptr;
+    float* cg_ws = nullptr; size_t cg_ws_floats = 0; std::vector<float> cg_sv;
     int mw = 0;    // 1: the four-waves-per-tile solve kernel (rnde_sdemw.h) for that shape, while a tile per workgroup still fits the chip
     size_t lds_mw = 0;
     int xch_wg = 0; // workgroups the exchange array is sized for
@@ -206,11 +211,12 @@ extern "C" rnde_status rnde_nsde_create(const rnde_nsde_config* c, rnde_nsde** o
 extern "C" void rnde_nsde_destroy(rnde_nsde* h) {
     if (!h) return;
     void* d[] = {h->frags_f, h->frags_g, h->slots, h->tape, h->noise, h->replay, h->meta, h->acc_meta, h->fin, h->xch, h->abort_word, h->svb,
-                 h->slab_f, h->slab_g, h->wslab, h->wslab_r, h->ev_t, h->part, h->sv_t_dev, h->head_ws};
+                 h->slab_f, h->slab_g, h->wslab, h->wslab_r, h->ev_t, h->part, h->sv_t_dev, h->head_ws, h->cg_ws};
     for (void* p : d) if (p) (void)hipFree(p);
     void* hd[] = {h->h_meta, h->h_acc_meta, h->h_fin, h->h_svb, h->h_part};
     for (void* p : hd) if (p) (void)hipHostFree(p);
     for (hipEvent_t e : h->tev) if (e) (void)hipEventDestroy(e);
+    if (h->ev_host) (void)hipEventDestroy(h->ev_host);
     delete h;
 }
 
@@ -349,7 +355,12 @@ static rnde_status nsde_forward_impl(rnde_nsde* h, const float* x_dev, const flo
     h->tev_f = true;
     SCHK(h, hipMemcpyAsync(h->h_fin, h->fin, sizeof(SdeFinal), hipMemcpyDeviceToHost, s));
     SCHK(h, hipMemcpyAsync(h->h_meta, h->meta, (size_t)h->cfg.max_attempts * sizeof(SdeMeta), hipMemcpyDeviceToHost, s));
-    SCHK(h, hipStreamSynchronize(s));
+    if (h->after_solve) {   // (fused training step) wait for the copies only; what the hook queues runs while the host wakes up
+        SCHK(h, hipEventRecord(h->ev_host, s));
+        const rnde_status hs = h->after_solve(s);
+        if (hs != RNDE_OK) return hs;
+        SCHK(h, hipEventSynchronize(h->ev_host));
+    } else SCHK(h, hipStreamSynchronize(s));
     const SdeFinal F = *h->h_fin;
     h->B = B; h->ntiles = ntiles; h->nwg = Q.nwg; h->n_att = F.n_att; h->n_acc = F.n_acc; h->n_draws = F.n_draws; h->t0 = t0;
     if (nfe1_out) *nfe1_out = 2 + 4 * (int64_t)F.n_att;   // the closures' counters (neural_sde.jl:46,:50): 2 probes of the initial-step rule + 4 per attempt
@@ -462,23 +473,31 @@ static rnde_status nsde_backward_impl(rnde_nsde* h, const float* u_bar_dev, cons
     };
     dump(h->Gf, Bq.Cf); dump(h->Gg, Bq.Cg);
     const int n_evals = 4 * std::max(1, n_acc);
-    auto ensure = [&](float*& p, size_t& have, size_t need) -> bool {
+    // Buffers that scale with the number of accepted steps grow by half as much again (and 16 steps) when they have to: while a
+    // model trains, the step count creeps up by one or two per training step, and a hipFree + hipMalloc per step stalled the GPU for
+    // ~0.4 ms of a 1.6 ms step (the free waits for the device).
+    const size_t n_evals_cap = 4 * ((size_t)std::max(1, n_acc) * 3 / 2 + 16);
+    auto ensure = [&](float*& p, size_t& have, size_t need, size_t grow_to) -> bool {
         if (have >= need) return true;
         if (p) (void)hipFree(p);
         p = nullptr; have = 0;
-        if (hipMalloc((void**)&p, need * 4) != hipSuccess) return false;
-        have = need;
+        if (hipMalloc((void**)&p, grow_to * 4) != hipSuccess) {
+            if (hipMalloc((void**)&p, need * 4) != hipSuccess) return false;   // (no room for the head room: exactly what is needed)
+            grow_to = need;
+        }
+        have = grow_to;
         return true;
     };
-    if (!ensure(h->slab_f, h->slab_f_floats, (size_t)n_evals * Bq.Cf.ev_stride) || !ensure(h->slab_g, h->slab_g_floats, (size_t)n_evals * Bq.Cg.ev_stride)) {
+    if (!ensure(h->slab_f, h->slab_f_floats, (size_t)n_evals * Bq.Cf.ev_stride, n_evals_cap * Bq.Cf.ev_stride) ||
+        !ensure(h->slab_g, h->slab_g_floats, (size_t)n_evals * Bq.Cg.ev_stride, n_evals_cap * Bq.Cg.ev_stride)) {
         h->err = "slab allocation failed"; return RNDE_ERR_HIP;
     }
     if (h->ev_t_n < (size_t)n_evals) {
         if (h->ev_t) (void)hipFree(h->ev_t);
         h->ev_t = nullptr; h->ev_t_n = 0;
-        SCHK(h, hipMalloc((void**)&h->ev_t, (size_t)n_evals * 4));
-        SCHK(h, hipMemsetAsync(h->ev_t, 0, (size_t)n_evals * 4, s));
-        h->ev_t_n = n_evals;
+        SCHK(h, hipMalloc((void**)&h->ev_t, n_evals_cap * 4));
+        SCHK(h, hipMemsetAsync(h->ev_t, 0, n_evals_cap * 4, s));
+        h->ev_t_n = n_evals_cap;
     }
     if (!h->wslab) { SCHK(h, hipMalloc((void**)&h->wslab, (size_t)96 * h->P * 4)); SCHK(h, hipMalloc((void**)&h->wslab_r, (size_t)16 * h->P * 4)); }
     Bq.Cf.slab = h->slab_f; Bq.Cg.slab = h->slab_g;
@@ -535,10 +554,7 @@ extern "C" rnde_status rnde_nsde_backward_async(rnde_nsde* h, const float* u_bar
 
 // postsde Dense(D, C) + logitcrossentropy and their reverse for ClassifierNSDE with one trajectory per input (the kernels of rnde_head.h,
 // as rnde_classifier_head for the ODE classifier; reference src/models/supervised_classification.jl:96-97 + experiments/mnist_nsde.jl loss)
-extern "C" rnde_status rnde_nsde_classifier_head(rnde_nsde* h, const float* u_dev, const float* p3_dev, const float* y_dev, int32_t B, int32_t n_classes,
-                                                 float* logits_out_dev, float* u_bar_dev, float* p3_bar_dev, float* ce_out_dev, void* stream) {
-    if (!h || B < 1 || n_classes < 1 || n_classes > kHeadMaxC) return RNDE_ERR_BAD_ARG;
-    hipStream_t s = (hipStream_t)stream;
+static rnde_status nsde_head_reserve(rnde_nsde* h, int32_t B, int32_t n_classes) {
     const size_t need = (size_t)B * n_classes + B + (size_t)kHeadChunks * n_classes * h->D;
     if (h->head_ws_floats < need) {
         if (h->head_ws) (void)hipFree(h->head_ws);
@@ -546,6 +562,14 @@ extern "C" rnde_status rnde_nsde_classifier_head(rnde_nsde* h, const float* u_de
         SCHK(h, hipMalloc((void**)&h->head_ws, need * 4));
         h->head_ws_floats = need;
     }
+    return RNDE_OK;
+}
+extern "C" rnde_status rnde_nsde_classifier_head(rnde_nsde* h, const float* u_dev, const float* p3_dev, const float* y_dev, int32_t B, int32_t n_classes,
+                                                 float* logits_out_dev, float* u_bar_dev, float* p3_bar_dev, float* ce_out_dev, void* stream) {
+    if (!h || B < 1 || n_classes < 1 || n_classes > kHeadMaxC) return RNDE_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const rnde_status rs = nsde_head_reserve(h, B, n_classes);
+    if (rs != RNDE_OK) return rs;
     float* delta = h->head_ws;
     float* ce_col = h->head_ws + (size_t)B * n_classes;
     float* partial = ce_col + B;
@@ -556,6 +580,46 @@ extern "C" rnde_status rnde_nsde_classifier_head(rnde_nsde* h, const float* u_de
                        h->D, n_classes, B, p3_bar_dev, ce_out_dev);
     SCHK(h, hipGetLastError());
     return RNDE_OK;
+}
+
+// One training-step gradient of the ClassifierNSDE loss around the SDE solve (one trajectory per input) in ONE call: forward solve (taped),
+// postsde Dense + logitcrossentropy and their reverse, reverse sweep -- rnde_nsde_forward + rnde_nsde_classifier_head + rnde_nsde_backward_async
+// with the head queued before the forward's host wait (the three separate calls left the GPU idle for ~0.1 ms of a 1.3 ms step).
+extern "C" rnde_status rnde_nsde_classifier_grad(rnde_nsde* h, const float* x_dev, const float* p2_dev, const float* p3_dev, const float* y_dev,
+                                                 int32_t B, int32_t n_classes, float t0, float t1, const float* noise_dev, int32_t n_pool,
+                                                 uint64_t seed, float lambda, float* p2_bar_dev, float* p3_bar_dev, float* x_bar_dev,
+                                                 float* ce_out_dev, float* reg_out_host, int64_t* nfe1_out, int64_t* nfe2_out, void* stream) {
+    if (!h || !x_dev || !p2_dev || !p3_dev || !y_dev || !p2_bar_dev || !p3_bar_dev || !x_bar_dev || !ce_out_dev) return RNDE_ERR_BAD_ARG;
+    if (B < 1 || B > h->cfg.max_batch || n_classes < 1 || n_classes > kHeadMaxC) return RNDE_ERR_BAD_ARG;
+    SCHK(h, hipSetDevice(h->cfg.device));
+    const size_t A = (size_t)h->D * B;
+    if (h->cg_ws_floats < 2 * A) {
+        if (h->cg_ws) (void)hipFree(h->cg_ws);
+        h->cg_ws = nullptr; h->cg_ws_floats = 0;
+        SCHK(h, hipMalloc((void**)&h->cg_ws, 2 * A * 4));
+        h->cg_ws_floats = 2 * A;
+    }
+    if (!h->ev_host) SCHK(h, hipEventCreateWithFlags(&h->ev_host, hipEventDisableTiming));
+    rnde_status st = nsde_head_reserve(h, B, n_classes);   // (the hook runs between an event record and the host's wait on it: it only enqueues)
+    if (st != RNDE_OK) return st;
+    float* u = h->cg_ws; float* ubar = h->cg_ws + A;
+    h->cg_sv.resize((size_t)h->cfg.max_attempts + 1);
+    int32_t nsv = 0;
+    h->after_solve = [&](hipStream_t s) -> rnde_status {
+        return rnde_nsde_classifier_head(h, u, p3_dev, y_dev, B, n_classes, nullptr, ubar, p3_bar_dev, ce_out_dev, s);
+    };
+    st = nsde_forward_impl(h, x_dev, p2_dev, B, t0, t1, noise_dev, n_pool, seed, nullptr, 0, u, nfe1_out, nfe2_out, h->cg_sv.data(), &nsv, 1, stream);
+    h->after_solve = nullptr;
+    if (st != RNDE_OK) return st;
+    double reg = 0.0;
+    const bool regularize = lambda != 0.f && nsv > 0 && h->cfg.regularize != RNDE_REG_NONE;
+    if (regularize) {   // lambda * mean(sv.saveval): every saved value carries the cotangent lambda / n
+        for (int i = 0; i < nsv; ++i) reg += h->cg_sv[i];
+        reg = (double)lambda * reg / nsv;
+        for (int i = 0; i < nsv; ++i) h->cg_sv[i] = lambda / (float)nsv;
+    }
+    if (reg_out_host) *reg_out_host = (float)reg;
+    return nsde_backward_impl(h, ubar, regularize ? h->cg_sv.data() : nullptr, x_bar_dev, p2_bar_dev, stream, false);
 }
 
 extern "C" rnde_status rnde_nsde_timing(rnde_nsde* h, float* solve_ms, float* rev_sweep_ms, int32_t* attempts, int32_t* accepted) {

@@ -14,6 +14,7 @@ Differences inherent to the host language / the device: `func` is the reference'
 the noise comes from the library's Philox stream (seed = nsde.seed, advanced every call) unless `noise=` passes a pool of
 standard normals of shape (n_pool, 2, B, D) -- a Julia caller would fill that from its own RNG.
 """
+import os
 import ctypes as C
 
 import torch
@@ -240,6 +241,26 @@ def fused_nsde_loss_and_grad(model, x, y, trajectories=1, lam=1.0e2, regularize=
         h = torch.addmm(b1, xe, W1)                                              # supervised_classification.jl:93-94
         B, D = h.shape
         hd = nsde._acquire(h)
+        n_u, n_c = model.post_shape
+        stream = C.c_void_p(torch.cuda.current_stream(h.device).cuda_stream)
+        if trajectories == 1 and n_c <= 16 and os.environ.get("RNDE_ONE_CALL", "1") != "0":
+            # solve + postsde/loss + their reverse + reverse sweep as ONE library call (rnde_nsde_classifier_grad): the head is queued before the
+            # forward's host wait, the GPU does not idle between the solve and its reverse  (RNDE_ONE_CALL=0: the three calls below, for A/B)
+            n1, n2, reg_h = C.c_int64(0), C.c_int64(0), C.c_float(0.0)
+            p3c = p3.contiguous()
+            hbar, p2bar, p3bar = torch.empty_like(h), torch.empty_like(p2), torch.empty_like(p3c)
+            ce_t = torch.empty(1, dtype=torch.float32, device=h.device)
+            nsde.seed += 1
+            _lib.check_nsde(hd.ptr, L.rnde_nsde_classifier_grad(
+                hd.ptr, h.data_ptr(), p2.data_ptr(), p3c.data_ptr(), y.contiguous().data_ptr(), B, n_c, nsde.tspan[0], nsde.tspan[1], None, 0,
+                nsde.seed, float(lam) if (regularize and nsde.regularize) else 0.0, p2bar.data_ptr(), p3bar.data_ptr(), hbar.data_ptr(),
+                ce_t.data_ptr(), C.byref(reg_h), C.byref(n1), C.byref(n2), stream))
+            nsde.last_nfe = (int(n1.value), int(n2.value))
+            p1bar = torch.cat([(xe.t() @ hbar).reshape(-1), hbar.sum(dim=0)])
+            model._keep = (hbar, h, p3c)          # buffers the enqueued kernels still use
+            model.p1.grad, model.p2.grad, model.p3.grad = p1bar, p2bar, p3bar
+            reg = float(reg_h.value)
+            return ce_t[0] + reg, ce_t[0], reg, int(n1.value), int(n2.value)
         n1, n2, nsv = C.c_int64(0), C.c_int64(0), C.c_int32(0)
         sv_host = (C.c_float * (nsde.max_attempts + 1))()
         stream = C.c_void_p(torch.cuda.current_stream(h.device).cuda_stream)

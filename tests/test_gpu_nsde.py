@@ -331,6 +331,38 @@ def test_fused_nsde_step_matches_autograd(T):
         assert torch.allclose(p.grad, q.grad, rtol=1e-4, atol=1e-6 * float(p.grad.abs().max())), float((p.grad - q.grad).abs().max())
 
 
+def test_one_call_nsde_step_equals_the_three_calls(monkeypatch):
+    """rnde_nsde_classifier_grad (solve + head + reverse sweep in one call, the head queued before the forward's host wait) against
+    rnde_nsde_forward + rnde_nsde_classifier_head + rnde_nsde_backward_async: same kernels, same noise stream (same seed), same order --
+    loss, both NFE counters and the three gradients bit for bit, at the reference's size (B = 512), three steps with changing weights."""
+    import torch
+    import regneuralde_jl_amd as rn
+    B = 512
+
+    def make():
+        g = torch.Generator().manual_seed(21)
+        nsde = rn.TrackedNeuralDSDE(rn.Chain(rn.Dense(32, 64, "tanh", g), rn.Dense(64, 32, "identity", g)), rn.Dense(32, 32, "identity", g),
+                                    [0.0, 1.0], True, "SOSRI", reltol=0.14, abstol=0.14, max_batch=B, seed=5)
+        return rn.ClassifierNSDE(rn.Dense(784, 32, "identity", g), nsde, rn.Dense(32, 10, "identity", g)), g
+    m1, g = make()
+    m2, _ = make()
+    x = torch.rand(B, 784, generator=g).cuda()
+    y = torch.eye(10)[torch.randint(0, 10, (B,), generator=g)].cuda()
+    for rep in range(3):
+        monkeypatch.setenv("RNDE_ONE_CALL", "0")
+        l1, ce1, reg1, a1, b1 = rn.fused_nsde_loss_and_grad(m1, x, y, lam=10.0)
+        monkeypatch.setenv("RNDE_ONE_CALL", "1")
+        l2, ce2, reg2, a2, b2 = rn.fused_nsde_loss_and_grad(m2, x, y, lam=10.0)
+        torch.cuda.synchronize()
+        assert (a1, b1) == (a2, b2) and float(ce1) == float(ce2) and reg1 == pytest.approx(reg2, rel=1e-6)
+        for p, q in zip(m1.trainable(), m2.trainable()):
+            assert torch.equal(p.grad, q.grad)
+        with torch.no_grad():
+            for p, q in zip(m1.trainable(), m2.trainable()):
+                d = 0.01 * torch.randn(p.shape, generator=g).cuda()
+                p.add_(d); q.add_(d)
+
+
 def test_dropped_graph_returns_the_handle():
     """A taped forward whose graph is dropped without backward() must not pin its handle (and tape) for ever -- the reference's
     per-epoch NFE probe `_, nfe, _ = node(dummy)` (experiments/mnist_node.jl:236) runs with tracking on."""

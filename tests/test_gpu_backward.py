@@ -83,6 +83,36 @@ def test_weight_gradient_kernels_agree(B, monkeypatch):
     assert np.abs(out["v3"][1]).max() > 0
 
 
+def test_weight_gradient_kernels_agree_on_another_shape(monkeypatch):
+    """The same comparison on a shape that is not the headline's: D = 720 (45 row tiles: halves of 23 and 22), H = 64, B = 40 (48 padded
+    columns: every second 32-column step of an evaluation is half empty) -- the LDS-DMA staging of rnde_wgrad3_kernel (units, masked lanes,
+    synthetic rows, stale columns) against the staged 32x32x2 kernel and against the fp64 oracle."""
+    from tests.test_gpu_forward import _cfg
+    from tests.util import Node, Oracle, arch_mnist, glorot_params, rel_err
+    rng = np.random.default_rng(3)
+    arch = arch_mnist(720, 64)
+    p = glorot_params(arch, rng, np.float32, 3.0)
+    B = 40
+    x = rng.uniform(0, 1, (B, 720)).astype(np.float32)
+    ubar = rng.standard_normal(x.shape).astype(np.float32)
+    out = {}
+    for name, env in (("v3", {"RNDE_WGRAD_SIDE": "0"}), ("v3_side", {"RNDE_WGRAD_SIDE": "100"}), ("v2", {"RNDE_WGRAD_V2": "1"})):
+        for k in ("RNDE_WGRAD_V2", "RNDE_WGRAD_SIDE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        node = Node(_cfg(arch, B, reltol=1e-3, abstol=1e-3, col_tile=16))
+        got = node.forward(x, p, 0.0, 1.0, keep_tape=True)
+        out[name] = node.backward(ubar, np.full(len(got["saveval"]), 10.0, dtype=np.float32))
+    for name in ("v3_side", "v2"):
+        assert rel_err(out["v3"][1], out[name][1]) <= 1e-5, name
+    o64 = Oracle(arch, np.float64, reltol=1e-3, abstol=1e-3, reg_kind=1)
+    r64 = o64.forward(x, p, 0.0, 1.0)
+    if r64["nattempts"] == got["nattempts"]:
+        xb64, pb64, _ = o64.backward(ubar.astype(np.float64), np.full(len(got["saveval"]), 10.0))
+        assert rel_err(out["v3"][1], pb64) <= 2e-3 and rel_err(out["v3"][0], xb64) <= 2e-3
+
+
 def test_backward_requires_tape():
     from tests.test_gpu_forward import _cfg, _setup
     from tests.util import Node

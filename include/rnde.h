@@ -166,6 +166,11 @@ rnde_status rnde_bench_attempt(rnde_node* h, const float* x_dev, const float* p_
  * training step, which is what bench.py's roofline object is computed from. */
 rnde_status rnde_bench_attempt_taped(rnde_node* h, const float* x_dev, const float* p_dev, int32_t B,
                                      int32_t iters, float* mean_us_out, void* stream);
+/* The same with a COLD tape: attempt i writes record i mod `records` of the arena (records >= 2), as the attempts of a solve do (31 records
+ * of 21.7 MB at B = 512 per solve: the tape does not stay on the chip), where rnde_bench_attempt_taped rewrites record 0 for ever (it then
+ * lives in the Infinity Cache).  Stage engine; this is the figure that agrees with the per-attempt time inside a training step. */
+rnde_status rnde_bench_attempt_cold_tape(rnde_node* h, const float* x_dev, const float* p_dev, int32_t B, int32_t iters,
+                                         int32_t records, float* mean_us_out, void* stream);
 /* Measurement aid: with timing on, every forward / reverse records HIP events on the caller's stream around (a) the attempted
  * steps of the forward solve, (b) the reverse sweep, (c) the rest of the reverse pass (parameter-gradient GEMMs after the
  * sweep + reductions); rnde_node_timing waits for them and returns the three durations in ms (-1 = not recorded). */

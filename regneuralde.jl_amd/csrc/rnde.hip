@@ -833,7 +833,18 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
         for (int i = 0; i < chunk && launched < cap; ++i) {
             if (h->engine == 3 && h->mw) HIPCHK(h, launch_mw<MW_STEP>(h, MQ, launched, s));
             else if (h->engine == 3) HIPCHK(h, launch_chain<CM_STEP>(h, CQ, launched, nullptr, s));
-            else if (h->engine == 2) HIPCHK(h, stage_attempt(h, SQ, launched, s));
+            else if (h->engine == 2) {
+#ifdef RNDE_DIAG
+                static const int diag_n = getenv("RNDE_DIAG_FWD") ? atoi(getenv("RNDE_DIAG_FWD")) : -1;   // cycle stamps of THIS attempt of a real solve
+                if (launched == diag_n) {
+                    if (!h->diag_buf) hipMalloc((void**)&h->diag_buf, 8192);
+                    hipMemsetAsync(h->diag_buf, 0, 8192, s);
+                    StageParams SD = SQ; SD.F.dbg_out = h->diag_buf;
+                    HIPCHK(h, stage_attempt(h, SD, launched, s));
+                } else
+#endif
+                HIPCHK(h, stage_attempt(h, SQ, launched, s));
+            }
             else HIPCHK(h, launch_step<MODE_STEP>(h, P, launched, s));
             if ((st = couple_sum(h, P.errpart + (size_t)(launched & 1) * 3 * P.nwg, 3LL * P.nwg, s)) != RNDE_OK) return st;
             ++launched;
@@ -858,6 +869,17 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
             if (hs != RNDE_OK) return hs;
             HIPCHK(h, hipEventSynchronize(h->ev_host));
         } else HIPCHK(h, hipStreamSynchronize(s));
+#ifdef RNDE_DIAG
+        if (h->engine == 2 && getenv("RNDE_DIAG_FWD") && h->diag_buf) {
+            unsigned long long hst[64] = {0};
+            hipMemcpy(hst, h->diag_buf, sizeof(hst), hipMemcpyDeviceToHost);
+            if (hst[34]) {
+                fprintf(stderr, "attempt %s of a real solve (workgroup 0 thread 0, cycles): controller %lld startC %lld startD %lld |", getenv("RNDE_DIAG_FWD"), (long long)(hst[1]-hst[0]), (long long)(hst[2]-hst[1]), (long long)(hst[3]-hst[2]));
+                for (int st_ = 0; st_ < 6; ++st_) fprintf(stderr, " poll %lld", (long long)(hst[4 + 5 * st_] - hst[3 + 5 * st_]));
+                fprintf(stderr, " | total %lld  (entry -> all loads issued %lld, -> controller state here %lld)\n", (long long)(hst[34]-hst[0]), (long long)(hst[35]-hst[0]), (long long)(hst[36]-hst[35]));
+            }
+        }
+#endif
         if (h->couple && rnde_comm_health(h->couple) != RNDE_OK) { h->err = std::string("coupled controller: ") + rnde_comm_last_error(h->couple); return RNDE_ERR_HIP; }
         if (h->engine == 2 && persist_check_result(h, SQ.C, SQ.R, s)) {
             if (h->pending_bwd) {   // the failure may belong to the asynchronous reverse pass before this forward: its outputs cannot be trusted
@@ -1100,11 +1122,17 @@ extern "C" rnde_status rnde_bench_attempt_taped(rnde_node* h, const float* x_dev
                                                 float* mean_us_out, void* stream) {
     return bench_attempt_impl(h, x_dev, p_dev, B, iters, 1, mean_us_out, stream);
 }
+extern "C" rnde_status rnde_bench_attempt_cold_tape(rnde_node* h, const float* x_dev, const float* p_dev, int32_t B, int32_t iters,
+                                                    int32_t records, float* mean_us_out, void* stream) {
+    if (records < 2) return RNDE_ERR_BAD_ARG;
+    return bench_attempt_impl(h, x_dev, p_dev, B, iters, records, mean_us_out, stream);
+}
 static rnde_status bench_attempt_impl(rnde_node* h, const float* x_dev, const float* p_dev, int32_t B, int32_t iters, int32_t taped,
                                       float* mean_us_out, void* stream) {
     if (!h || B < 1 || B > h->cfg.max_batch || iters < 1) return RNDE_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     h->have_tape = false;
+    if (taped > 1) { const rnde_status sa = ensure_arena(h, std::min<long long>(taped, h->cfg.max_attempts)); if (sa != RNDE_OK) return sa; }
     StepParams P = make_params(h, x_dev, B, 0.f, 1.f, taped ? 1 : 0);   // taped: the variant a training step runs (record 0 of the arena)
     P.forced = 1; P.forced_t = 0.f; P.forced_dt = 0.05f;
     rnde_status st = h->engine == 3 ? chain_pack(h, p_dev, s) : pack_weights(h, p_dev, false, s);
@@ -1136,10 +1164,13 @@ static rnde_status bench_attempt_impl(rnde_node* h, const float* x_dev, const fl
     HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
     HIPCHK(h, hipEventRecord(e0, s));
     const auto host_t0 = std::chrono::steady_clock::now();
+    // taped > 1 (stage engine): every attempt writes ANOTHER record of the arena, `taped` of them in turn -- what a solve does (31 records
+    // of 21.7 MB at B = 512: the tape leaves the chip); taped == 1 rewrites record 0, which then lives in the Infinity Cache
+    const int cyc = (taped > 1 && h->engine == 2) ? (int)std::min<long long>(taped, h->arena_recs) : 1;
     for (int i = 0; i < iters; ++i) {
         if (h->engine == 3 && h->mw) HIPCHK(h, launch_mw<MW_STEP>(h, MQ, 0, s));
         else if (h->engine == 3) HIPCHK(h, launch_chain<CM_STEP>(h, CQ, 0, nullptr, s));
-        else if (h->engine == 2) HIPCHK(h, stage_attempt(h, SQ, 0, s));
+        else if (h->engine == 2) { SQ.F.rec_shift = i % cyc; HIPCHK(h, stage_attempt(h, SQ, 0, s)); }
         else HIPCHK(h, launch_step<MODE_STEP>(h, P, 0, s));
     }
     const double host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - host_t0).count();
@@ -1362,7 +1393,7 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
     Q.bpart_n = Q.F.nwg;
     Q.tspan_scale = h->couple ? 1.f / (float)h->couple_world : 1.f;
 #ifdef RNDE_DIAG
-    if (getenv("RNDE_DIAG_BWD")) { if (!h->diag_buf) hipMalloc((void**)&h->diag_buf, 512); hipMemset(h->diag_buf, 0, 512); Q.F.dbg_out = h->diag_buf; }
+    if (getenv("RNDE_DIAG_BWD")) { if (!h->diag_buf) hipMalloc((void**)&h->diag_buf, 8192); hipMemset(h->diag_buf, 0, 512); Q.F.dbg_out = h->diag_buf; }
 #endif
     Q.sv_T = (int)h->saveat.size();
     Q.sv_ubar0 = (!h->saveat.empty() && h->saveat[0] == h->t0) ? u_bar_dev : nullptr;

@@ -173,6 +173,7 @@ struct StepParams {
     float reltol, abstol, t0, t1;
     int tape, max_attempts;
     int forced; float forced_t, forced_dt;  // debug/bench: run one attempt from a given (t, dt)
+    int rec_shift;                           // bench (forced attempts, n = 0): tape record the attempt writes -- cycled, so that the tape is as cold as in a solve
     int xvec;                                // x is 16-byte aligned and D % 4 == 0
     int reg_kind;                            // rnde_reg: 2, 3 also need the stiffness estimate
     const float* sv_t; int nsave; float* sv_out;   // saveat times (device), their count, output D x T x B
@@ -246,13 +247,22 @@ __device__ __forceinline__ float wave_sum_f(float s) {
 // fixed-order sum of n fp32 partials, carried in double; identical result on every lane / workgroup
 // (four loads per lane are requested before the first add: the plain loop `for (i = lane; i < n; i += 64) s += part[i]` waits
 //  for each cold load in turn -- 8 k cycles in front of every launch for n = 224; same additions in the same order)
-__device__ __forceinline__ double sum_partials(const float* __restrict__ part, int n, int lane) {
+// pre: the first block's four values of this lane, requested by the caller earlier (partials_request), or nullptr
+__device__ __forceinline__ void partials_request(const float* __restrict__ part, int lane, float (&v)[4]) {
+    v[0] = part[lane]; v[1] = part[lane + 64]; v[2] = part[lane + 128]; v[3] = part[lane + 192];
+}
+__device__ __forceinline__ double sum_partials(const float* __restrict__ part, int n, int lane, const float (*pre)[4] = nullptr) {
     double s = 0;
     for (int base = 0; base < n; base += 256) {
         const int i0 = base + lane, i1 = i0 + 64, i2 = i0 + 128, i3 = i0 + 192;
         // unconditional requests of the whole 256-entry block (the arrays are padded by 256 entries; values past n are not added): loads
         // under a lane condition were compiled into two dependent cold round trips, clamped indices into four address computations
-        const float v0 = part[i0], v1 = part[i1], v2 = part[i2], v3 = part[i3];
+        float v0, v1, v2, v3;
+        if (base == 0 && pre) {   // (the empty asm is where the values are first USED: without it the compiler converts them to double right behind
+            v0 = (*pre)[0]; v1 = (*pre)[1]; v2 = (*pre)[2]; v3 = (*pre)[3];   //  the loads and waits for them there, in front of everything issued after)
+            asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));
+        }
+        else { v0 = part[i0]; v1 = part[i1]; v2 = part[i2]; v3 = part[i3]; }
         if (i0 < n) s += (double)v0;
         if (i1 < n) s += (double)v1;
         if (i2 < n) s += (double)v2;

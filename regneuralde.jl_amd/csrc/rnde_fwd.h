@@ -183,7 +183,12 @@ __device__ __forceinline__ void finalize_state(const StepParams& P, StepState& S
     else if (!(dt > kDtMin)) { S.done = 1; S.status = 3; }
 }
 
-__device__ __forceinline__ StepState advance_state(const StepParams& P, int n, int lane, bool writer, StepState* out) {
+// pre: the error partials of attempt n - 1 (first 256-entry block, this lane's four), requested by the caller ahead of this call --
+// the controller state and the partials are two cold loads that do not depend on each other
+// prev: the controller state of attempt n - 1 (P.ctl[(n - 1) & 1]), likewise loaded by the caller ahead of the call (both used when PRE and n > 0)
+template <bool PRE>
+__device__ __forceinline__ StepState advance_state_t(const StepParams& P, int n, int lane, bool writer, StepState* out, const float (&pre)[4],
+                                                     const StepState& prev) {
     StepState S;
     const double N = (double)P.D * (double)P.Bn;
     if (n == 0) {
@@ -211,13 +216,13 @@ __device__ __forceinline__ StepState advance_state(const StepParams& P, int n, i
         if (writer) *out = S;
         return S;
     }
-    const StepState p = P.ctl[(n - 1) & 1];
+    const StepState p = PRE ? prev : P.ctl[(n - 1) & 1];
     if (p.done) { if (writer) *out = p; return p; }
     S = p;
     const bool clamped = !P.forced && (P.t1 - p.t < p.dtp);
     const float dt = clamped ? (P.t1 - p.t) : p.dtp;
     const float* ep = P.errpart + (size_t)((n - 1) & 1) * 3 * P.nwg;   // [parity][{r^2, (k7-k6)^2, (unew-g6)^2}][workgroup]
-    const double ss = sum_partials(ep, P.nwg, lane);
+    const double ss = sum_partials(ep, P.nwg, lane, PRE ? &pre : nullptr);
     const float eest = (float)sqrt(ss / N);
     float eig = 0.f, en1 = 0.f, en2 = 0.f;
     if (P.reg_kind >= 2) {   // stiffness estimate of the composite algorithm AutoTsit5(Tsit5())
@@ -270,6 +275,11 @@ __device__ __forceinline__ StepState advance_state(const StepParams& P, int n, i
         P.meta[n - 1] = M;
     }
     return S;
+}
+__device__ __forceinline__ StepState advance_state(const StepParams& P, int n, int lane, bool writer, StepState* out) {
+    const float none[4] = {0.f, 0.f, 0.f, 0.f};
+    const StepState nop{};
+    return advance_state_t<false>(P, n, lane, writer, out, none, nop);
 }
 
 enum { MODE_STEP = 0, MODE_INIT_A = 1, MODE_INIT_B = 2, MODE_FEVAL = 3 };

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_kernel(const StagePara
         if (S.done) return;
         t = S.t; dt = (!P.forced && (P.t1 - S.t < S.dtp)) ? (P.t1 - S.t) : S.dtp; live = S.live;
     }
-    if constexpr (MODE == SM_START || MODE == SM_STAGE || MODE == SM_LAST) rec = P.tape ? n : (live == 0 ? 1 : 0);
+    if constexpr (MODE == SM_START || MODE == SM_STAGE || MODE == SM_LAST) rec = P.tape ? n + P.rec_shift : (live == 0 ? 1 : 0);
     float* R = P.arena + (long long)rec * P.rec_stride;
     const float* upsrc = P.x; const float* k1p = P.f0; bool upok = colok, upvec = P.xvec != 0;
     if (live >= 0) { const float* Rl = P.arena + (long long)live * P.rec_stride; upsrc = Rl + L.unew(); k1p = Rl + L.k(7); upok = true; upvec = vec; }

@@ -151,25 +151,61 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
     if (tid == 0) Y.xcc[wg] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15;   // HW_REG_XCC_ID
 
     PSTAMP(0);
+    // In a solve the prologue used to be a chain of THREE cold round trips (~2 k cycles each): the controller state of attempt n - 1, then
+    // (behind its `done` test) that attempt's 224 error partials, then -- at an address the controller's verdict decides -- the state the
+    // step starts from.  None of the addresses but the last depends on loaded data, and the last has a most likely value: the record
+    // attempt n - 1 wrote (it holds (unew, k7) if that attempt was accepted).  So the partials and that record's two tiles are requested
+    // here, IN FRONT of the weight loads (a wave's loads return in order: behind the 64 registers of weights the partials arrived ~3 k cycles
+    // later than they could), and the controller only has to wait for whichever arrives last.  (Same values, same arithmetic.)
+    float pre_part[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 prev_raw[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // the 48 bytes of P.ctl[(n - 1) & 1], untouched until the controller
+    if (n > 0) {
+        const f32x4* cp = (const f32x4*)&P.ctl[(n - 1) & 1];
+        prev_raw[0] = cp[0]; prev_raw[1] = cp[1]; prev_raw[2] = cp[2];
+        partials_request(P.errpart + (size_t)((n - 1) & 1) * 3 * P.nwg, lane, pre_part);
+    }
+    const bool spec = P.tape && n > 0 && !P.forced && tile_ok;
+    f32x4 sp_up = {0.f, 0.f, 0.f, 0.f}, sp_k = {0.f, 0.f, 0.f, 0.f};
+    if (spec) {
+        const float* Rs = P.arena + (long long)(n - 1) * P.rec_stride;
+        sp_up = ld4(Rs + L.unew() + (size_t)gcol * gD, r0, gD, true, vec);
+        sp_k = ld4(Rs + L.k(7) + (size_t)gcol * gD, r0, gD, true, vec);
+    }
     // ---- this block's weight slice and the layer-1 bias / time column of this wave's hidden tile: loaded once ----
-    f32x4 wB[kSMaxHT], wD[kSMaxW];
-#pragma unroll
-    for (int kb = 0; kb < kSMaxHT; ++kb)
-        if (kb < gK2b && tile_ok) wB[kb] = Q.pwB[((size_t)T * gK2b + kb) * 64 + lane];
-#pragma unroll
-    for (int kb = 0; kb < kSMaxW; ++kb)
-        if (kb < gWT && w < gHT && rb * gWT + kb < gMT) wD[kb] = Q.pwD[((size_t)w * gMT + rb * gWT + kb) * 64 + lane];
+    // (the small loads first: behind the 14 weight loads their addresses were built in registers of loads in flight -- three more waits)
     float w1t_own[4] = {0.f, 0.f, 0.f, 0.f}, b1_own[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int hr = 16 * w + 4 * (lane >> 4) + i;
         if (hr < gH) { w1t_own[i] = Q.p[(size_t)gH * gD + hr]; b1_own[i] = Q.p[(size_t)gH * (gD + 1) + hr]; }
     }
+    // (both lane addresses exist before the first load is issued -- pinned by the empty asm: the register allocator otherwise builds the
+    //  second one in registers that are the destination of a load in flight, which costs a full wait for the first seven loads)
+    typedef const __attribute__((address_space(1))) f32x4* gw4;     // (through the asm the compiler no longer knows the pointers are global)
+    unsigned long long aB = (unsigned long long)(Q.pwB + ((size_t)T * gK2b) * 64 + lane);
+    unsigned long long aD = (unsigned long long)(Q.pwD + ((size_t)w * gMT + rb * gWT) * 64 + lane);
+    unsigned long long aB4 = aB + 4 * 1024, aD4 = aD + 4 * 1024;       // (the offset field of a load reaches 4095 bytes: k-blocks 4.. need their own base)
+    asm volatile("" : "+v"(aB), "+v"(aD), "+v"(aB4), "+v"(aD4));
+    f32x4 wB[kSMaxHT], wD[kSMaxW];
+#pragma unroll
+    for (int kb = 0; kb < kSMaxHT; ++kb)
+        if (kb < gK2b && tile_ok) wB[kb] = kb < 4 ? ((gw4)aB)[(size_t)kb * 64] : ((gw4)aB4)[(size_t)(kb - 4) * 64];
+#pragma unroll
+    for (int kb = 0; kb < kSMaxW; ++kb)
+        if (kb < gWT && w < gHT && rb * gWT + kb < gMT) wD[kb] = kb < 4 ? ((gw4)aD)[(size_t)kb * 64] : ((gw4)aD4)[(size_t)(kb - 4) * 64];
     const float* W1t = Q.p + (size_t)gH * gD;
     const float* b1 = Q.p + (size_t)gH * (gD + 1);
 
     // ---- controller (identical to SM_START) ----
-    const StepState S = advance_state(P, n, lane, writer, &P.ctl[n & 1]);
+    // (first USE of the pre-loaded state: the empty asm keeps the compiler from unpacking it -- and waiting for it -- up where it was requested)
+    PSTAMP(35);
+    asm volatile("" : "+v"(prev_raw[0]), "+v"(prev_raw[1]), "+v"(prev_raw[2]));
+    PSTAMP(36);
+    static_assert(sizeof(StepState) == 48, "StepState is read as three 16-byte words");
+    StepState prev_state;
+    __builtin_memcpy(&prev_state, prev_raw, sizeof(StepState));
+    prev_state.live = __builtin_amdgcn_readfirstlane(prev_state.live); prev_state.done = __builtin_amdgcn_readfirstlane(prev_state.done);
+    const StepState S = advance_state_t<true>(P, n, lane, writer, &P.ctl[n & 1], pre_part, prev_state);
     if (P.nsave > 0) {
         const int lo = (n == 0) ? 0 : P.ctl[(n - 1) & 1].next_save, hi = S.next_save;
         if (hi > lo && tile_ok) {
@@ -187,7 +223,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
     if (S.done) return;
     const float t = S.t, dt = (!P.forced && (P.t1 - S.t < S.dtp)) ? (P.t1 - S.t) : S.dtp;
     const int live = S.live;
-    const int rec = P.tape ? n : (live == 0 ? 1 : 0);
+    const int rec = P.tape ? n + P.rec_shift : (live == 0 ? 1 : 0);
     float* R = P.arena + (long long)rec * P.rec_stride;
     const float* upsrc = P.x; const float* k1p = P.f0; bool upok = colok, upvec = P.xvec != 0;
     if (live >= 0) { const float* Rl = P.arena + (long long)live * P.rec_stride; upsrc = Rl + L.unew(); k1p = Rl + L.k(7); upok = true; upvec = vec; }
@@ -195,7 +231,8 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
     f32x4 c_up = {0.f, 0.f, 0.f, 0.f}, c_un = {0.f, 0.f, 0.f, 0.f}, c_k[7];
 #pragma unroll
     for (int j = 0; j < 7; ++j) c_k[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (tile_ok) { c_up = ld4(upsrc + co, r0, gD, upok, upvec); c_k[0] = ld4(k1p + co, r0, gD, true, vec); }
+    if (spec && live == n - 1) { c_up = sp_up; c_k[0] = sp_k; }      // (the step starts from what attempt n - 1 wrote: already here)
+    else if (tile_ok) { c_up = ld4(upsrc + co, r0, gD, upok, upvec); c_k[0] = ld4(k1p + co, r0, gD, true, vec); }
 
     // Loop-invariant addressing of this lane's four rows of its own hidden tile (phase A) and row tile (phase D): the stages are
     // instruction bound between the hand-offs (7 waves share 4 SIMDs), so nothing that does not change is recomputed per stage.

@@ -60,21 +60,35 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
     f32x4 pe[4];
     if (!first) bpart_request(Bq, n + 1, lane, pe);
     __builtin_amdgcn_sched_barrier(0);
-    f32x4 wB[kSMaxHT], wD[kSMaxW];
-#pragma unroll
-    for (int kb = 0; kb < kSMaxHT; ++kb)
-        if (kb < gKHb && tile_ok) wB[kb] = Q.pwBt[((size_t)T * gKHb + kb) * 64 + lane];
-#pragma unroll
-    for (int kb = 0; kb < kSMaxW; ++kb)
-        if (kb < gWT && w < gHT && rb * gWT + kb < gMT) wD[kb] = Q.pwDt[((size_t)w * gMT + rb * gWT + kb) * 64 + lane];
-    BSTAMP(43);
-    float* R = P.arena + (long long)m.rec * P.rec_stride;
+    // (the small loads first, and all four weight base addresses exist -- pinned by the empty asm -- before the first weight load: the register
+    //  allocator otherwise builds the later addresses in registers that are destinations of loads in flight, and each such reuse is a full wait
+    //  for everything issued so far: the partials above and seven weight loads, ~2 k cycles, in front of the rest of the prologue)
     float w1t_own[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int hr = 16 * w + 4 * (lane >> 4) + i;
         if (hr < gH) w1t_own[i] = Q.p[(size_t)gH * gD + hr];
     }
+    typedef const __attribute__((address_space(1))) f32x4* gw4;     // (through the asm the compiler no longer knows the pointers are global)
+    unsigned long long aB = (unsigned long long)(Q.pwBt + ((size_t)T * gKHb) * 64 + lane);
+    unsigned long long aD = (unsigned long long)(Q.pwDt + ((size_t)w * gMT + rb * gWT) * 64 + lane);
+    unsigned long long aB4 = aB + 4 * 1024, aD4 = aD + 4 * 1024;       // (the offset field of a load reaches 4095 bytes)
+    asm volatile("" : "+v"(aB), "+v"(aD), "+v"(aB4), "+v"(aD4));
+    f32x4 wB[kSMaxHT], wD[kSMaxW];
+    // (wD first: the prologue's own phase D needs it; wB is not multiplied before phase B of the first stage and streams in behind)
+#pragma unroll
+    for (int kb = 0; kb < kSMaxW; ++kb)
+        if (kb < gWT && w < gHT && rb * gWT + kb < gMT) wD[kb] = kb < 4 ? ((gw4)aD)[(size_t)kb * 64] : ((gw4)aD4)[(size_t)(kb - 4) * 64];
+#pragma unroll
+    for (int kb = 0; kb < kSMaxHT; ++kb)
+        if (kb < gKHb && tile_ok) {
+            if (FIX && kb == 6) {   // only k-steps 96..99 of the last block are multiplied (phase B): the rest of the float4 would be dead registers the
+                typedef const __attribute__((address_space(1))) float* gw1;      // moment it is requested, and the allocator's reuse of them a wait for
+                wB[kb] = (f32x4){*(gw1)(aB4 + 2 * 1024), 0.f, 0.f, 0.f};       // every load issued before it
+            } else wB[kb] = kb < 4 ? ((gw4)aB)[(size_t)kb * 64] : ((gw4)aB4)[(size_t)(kb - 4) * 64];
+        }
+    BSTAMP(43);
+    float* R = P.arena + (long long)m.rec * P.rec_stride;
     BSTAMP(44);
     const float* W1t = Q.p + (size_t)gH * gD;
     const bool accepted = (m.flags & F_ACCEPT) != 0;

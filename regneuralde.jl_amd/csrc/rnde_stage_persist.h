@@ -187,12 +187,19 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
     unsigned long long aB4 = aB + 4 * 1024, aD4 = aD + 4 * 1024;       // (the offset field of a load reaches 4095 bytes: k-blocks 4.. need their own base)
     asm volatile("" : "+v"(aB), "+v"(aD), "+v"(aB4), "+v"(aD4));
     f32x4 wB[kSMaxHT], wD[kSMaxW];
-#pragma unroll
-    for (int kb = 0; kb < kSMaxHT; ++kb)
-        if (kb < gK2b && tile_ok) wB[kb] = kb < 4 ? ((gw4)aB)[(size_t)kb * 64] : ((gw4)aB4)[(size_t)(kb - 4) * 64];
+    // (wD first: the prologue's own phase D needs it; wB is not multiplied before phase B of the first stage and streams in behind)
 #pragma unroll
     for (int kb = 0; kb < kSMaxW; ++kb)
         if (kb < gWT && w < gHT && rb * gWT + kb < gMT) wD[kb] = kb < 4 ? ((gw4)aD)[(size_t)kb * 64] : ((gw4)aD4)[(size_t)(kb - 4) * 64];
+#pragma unroll
+    for (int kb = 0; kb < kSMaxHT; ++kb)
+        if (kb < gK2b && tile_ok) {
+            if (FIX && kb == 6) {   // k-steps 104.. of the last block multiply zeros and are left out (phase B): their half of the float4 would be dead
+                typedef const __attribute__((address_space(1))) f32x2* gw2;      // registers the moment it is requested, and the allocator's reuse
+                const f32x2 lo = *(gw2)(aB4 + 2 * 1024);                       // of them a wait for every load issued before it
+                wB[kb] = (f32x4){lo.x, lo.y, 0.f, 0.f};
+            } else wB[kb] = kb < 4 ? ((gw4)aB)[(size_t)kb * 64] : ((gw4)aB4)[(size_t)(kb - 4) * 64];
+        }
     const float* W1t = Q.p + (size_t)gH * gD;
     const float* b1 = Q.p + (size_t)gH * (gD + 1);
 

@@ -375,8 +375,8 @@ def main():
                "rev_rest_ms": sum(rr) / len(rr),
                "persist_fallback": bool(stage_engine and nl != 1), "persist_fallback_count": int(L.rnde_node_fallback_count(h.ptr)),
                "controller": "coupled (one controller for all ranks, SURVEY 8e mode 2)" if args.coupled else "independent per rank (SURVEY 8e mode 1)",
-               "collective": (None if not use_dist else "rnde_comm_allreduce (RCCL via librnde.so): head gradient queued before the reverse sweep, "
-                              "solve gradient behind it; 1/world folded into the optimiser launch"),
+               "collective": (None if not use_dist else "rnde_comm_allreduce (RCCL via librnde.so): ONE sum-all-reduce of the flat gradient buffer [p2-bar | p3-bar] "
+                              "behind the reverse pass, on the compute stream; 1/world folded into the optimiser launch"),
                "config": {"workload": f"MNIST NODE regularized (error_est), Tsit5 reltol=abstol=1.4e-8, batch {B} per GPU, "
                                       "1xMI355X per rank; step = loss fwd + reverse pass through the solver + "
                                       "InvDecay/Momentum update; the weights train during the timed steps (mean_nfe drifts with "

@@ -225,8 +225,9 @@ rnde_status rnde_classifier_head(rnde_node* h, const float* u_dev, const float* 
  * (the three separate calls leave ~80 us of a 2.4 ms step idle at B = 512).  Stage engine only (two-layer dynamics, col_tile 0).
  * Outputs: p2_bar_dev (P), p3_bar_dev (C*D + C), x_bar_dev (D x B, may be NULL), ce_out_dev (device scalar), *reg_out_host =
  * lambda * mean(saveval) and *nfe_out (host, valid on return: the step log has been read); lambda = 0: no regulariser cotangent.
- * comm != NULL: p3_bar and then p2_bar are sum-all-reduced in place (rnde_comm_allreduce, mean = 0) as soon as each is complete --
- * the head's gradient travels while the sweep runs.  Asynchronous from the reverse pass on, like rnde_node_backward_async. */
+ * comm != NULL: both gradients are sum-all-reduced in place behind the reverse pass (rnde_comm_allreduce, mean = 0) -- in ONE call when
+ * p3_bar_dev == p2_bar_dev + P (one flat buffer [p2-bar | p3-bar]), else in two.  Asynchronous from the reverse pass on, like
+ * rnde_node_backward_async. */
 rnde_status rnde_node_classifier_grad(rnde_node* h, const float* x_dev, const float* p2_dev, const float* p3_dev,
                                       const float* y_dev, int32_t B, int32_t n_classes, float t0, float t1, float lambda,
                                       float* p2_bar_dev, float* p3_bar_dev, float* x_bar_dev, float* ce_out_dev,

@@ -50,9 +50,8 @@ def fused_loss_and_grad(model, x, y, lam=1.0e2, regularize=True, tspan=None, syn
     sync=False: the reverse pass is only enqueued (rnde_node_backward_async) and the losses come back as device tensors, so a
     training loop can queue the optimiser update and the next step underneath it; nothing is read on the host.
     flat (dataparallel.FlatGrads over model.trainable()): the reverse pass writes both gradients straight into that one
-    contiguous buffer; reducer (dataparallel.GradientAllReducer on the same buffer): the head's gradient is sum-all-reduced as
-    soon as the head kernel is queued -- it travels while the reverse sweep of the solve runs -- and the solve's gradient right
-    behind the sweep; averaging is left to the optimiser (reducer.grad_scale)."""
+    contiguous buffer; reducer (dataparallel.GradientAllReducer on the same buffer): ONE sum-all-reduce of the whole buffer
+    behind the reverse pass; averaging is left to the optimiser (reducer.grad_scale)."""
     import ctypes as C
     from . import _lib
     node = model.node
@@ -102,19 +101,17 @@ def fused_loss_and_grad(model, x, y, lam=1.0e2, regularize=True, tspan=None, syn
         svb = (C.c_float * n)(*([lam / n] * n))
     xbar = torch.empty_like(x2)
     n2 = p2bar.numel()
-    if reducer is not None:
-        reducer.allreduce_range_(n2, n2 + p3bar.numel())     # the head's gradient: on its way before the reverse sweep starts
     if not sync:
         _lib.check(h.ptr, L.rnde_node_backward_async(h.ptr, ubar.data_ptr(), svb, xbar.data_ptr(), p2bar.data_ptr(), None, stream))
         if reducer is not None:
-            reducer.allreduce_range_(0, n2)
+            reducer.allreduce_range_(0, n2 + p3bar.numel())
         model.p2.grad, model.p3.grad = p2bar, p3bar
         node.last_nfe = int(nfe.value)
         model._keep = (ubar, xbar, u)            # buffers the enqueued kernels still use
         return ce + reg, ce, reg, int(nfe.value)
     _lib.check(h.ptr, L.rnde_node_backward(h.ptr, ubar.data_ptr(), svb, xbar.data_ptr(), p2bar.data_ptr(), None, stream))
     if reducer is not None:
-        reducer.allreduce_range_(0, n2)
+        reducer.allreduce_range_(0, n2 + p3bar.numel())
     model.p2.grad, model.p3.grad = p2bar, p3bar
     node.last_nfe = int(nfe.value)
     ce_f = float(ce.item())

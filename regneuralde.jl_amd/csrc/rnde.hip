@@ -1654,12 +1654,15 @@ extern "C" rnde_status rnde_node_classifier_grad(rnde_node* h, const float* x_de
     if (reg_out_host) *reg_out_host = (float)reg;
     if (nfe_out) *nfe_out = nfe;
     const int64_t n3 = (int64_t)n_classes * h->D + n_classes;
-    // the head's gradient is complete: it travels while the reverse sweep runs; the solve's gradient follows right behind the sweep
-    if (comm && (st = rnde_comm_allreduce(comm, p3_bar_dev, n3, 0, stream)) != RNDE_OK) { h->err = std::string("all-reduce: ") + rnde_comm_last_error(comm); h->rev_packed = false; return st; }
     st = bwd_run(h, ubar, regularize ? h->cg_sv.data() : nullptr, xbar, p2_bar_dev, nullptr, (hipStream_t)stream, false, nullptr);
     h->rev_packed = false;
     if (st != RNDE_OK) return st;
-    if (comm && (st = rnde_comm_allreduce(comm, p2_bar_dev, (int64_t)h->P, 0, stream)) != RNDE_OK) { h->err = std::string("all-reduce: ") + rnde_comm_last_error(comm); return st; }
+    if (comm) {   // ONE collective per step when the two gradients sit back to back ([p2-bar | p3-bar], the flat buffer of a data-parallel caller):
+        // on the caller's stream everything is serial anyway, and a second call is a second RCCL launch latency
+        if (p3_bar_dev == p2_bar_dev + h->P) st = rnde_comm_allreduce(comm, p2_bar_dev, (int64_t)h->P + n3, 0, stream);
+        else if ((st = rnde_comm_allreduce(comm, p2_bar_dev, (int64_t)h->P, 0, stream)) == RNDE_OK) st = rnde_comm_allreduce(comm, p3_bar_dev, n3, 0, stream);
+        if (st != RNDE_OK) { h->err = std::string("all-reduce: ") + rnde_comm_last_error(comm); return st; }
+    }
     return RNDE_OK;
 }
 

@@ -216,6 +216,27 @@ def test_one_call_step_gradient_equals_the_three_calls_at_the_headline_shape(rnd
             assert rn._lib.lib().rnde_node_fallback_count(h.ptr) == 0
 
 
+@pytest.mark.parametrize("B,ncls,reg", [(37, 7, True), (5, 10, False), (48, 3, True)])
+def test_one_call_step_gradient_ragged_and_unregularised(rnde, B, ncls, reg):
+    """rnde_node_classifier_grad off the headline shape: ragged batches (the padded columns must stay out of every sum), other class
+    counts, lambda = 0 (no regulariser cotangent), generic-geometry kernels (D = 36, H = 10) -- against the three separate calls."""
+    rn = rnde
+    g = torch.Generator().manual_seed(100 + B)
+    dyn = rn.MLPDynamics(36, 10, generator=g)
+    node = rn.TrackedNeuralODE(dyn, [0.0, 1.0], True, True, "Tsit5", save_everystep=False, reltol=1e-4, abstol=1e-4, save_start=False,
+                               max_batch=64, max_attempts=64)
+    model = rn.ClassifierNODE(node, rn.Dense(36, ncls, "identity", generator=g), device=torch.device("cuda", 0))
+    x = torch.rand(B, 36, generator=g).cuda()
+    y = torch.eye(ncls)[torch.randint(0, ncls, (B,), generator=g)].cuda()
+    l1, ce1, reg1, nfe1 = rn.fused_loss_and_grad(model, x, y, lam=25.0, regularize=reg)
+    g2, g3 = model.p2.grad.clone(), model.p3.grad.clone()
+    l2, ce2, reg2, nfe2 = rn.fused_loss_and_grad(model, x, y, lam=25.0, regularize=reg, sync=False)
+    torch.cuda.synchronize()
+    assert nfe1 == nfe2 and float(ce2) == ce1 and reg1 == pytest.approx(reg2, rel=1e-6) and (reg or reg2 == 0.0)
+    assert torch.equal(model.p2.grad, g2) and torch.equal(model.p3.grad, g3)
+    assert torch.isfinite(model.p2.grad).all() and float(model.p2.grad.abs().max()) > 0
+
+
 def _latent_batch(g, B, T=49, in_dim=37):
     data = torch.randn(B, T, in_dim, generator=g)
     mask = (torch.rand(B, T, in_dim, generator=g) > 0.7).float()

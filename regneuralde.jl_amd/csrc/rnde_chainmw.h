@@ -289,6 +289,28 @@ __global__ __launch_bounds__(kMwThreads) void rnde_chainmw_kernel(const MwParams
     if (MODE == MW_STEP) dbg = (unsigned long long*)P.dbg_out;
 #endif
     MW_STAMP(0);
+    // (STEP) what the controller needs of attempt n - 1 -- its state, its error partials -- and the record it wrote (the likely starting state)
+    // are requested in front of the weight loads, as in rnde_stage_attempt_kernel: a wave's loads return in order, and behind the weights these
+    // three were three serial cold round trips in front of every attempt of a solve
+    float pre_part[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 prev_raw[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float sp_up[NR], sp_k[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { sp_up[r] = 0.f; sp_k[r] = 0.f; }
+    const bool pre = MODE == MW_STEP && n > 0;
+    const bool spec = pre && P.tape && !P.forced;
+    if constexpr (MODE == MW_STEP) {
+        if (pre) {
+            const f32x4* cp = (const f32x4*)&P.ctl[(n - 1) & 1];
+            prev_raw[0] = cp[0]; prev_raw[1] = cp[1]; prev_raw[2] = cp[2];
+            partials_request(P.errpart + (size_t)((n - 1) & 1) * 3 * P.nwg, lane, pre_part);
+        }
+        if (spec) {
+            const float* Rs = P.arena + (long long)(n - 1) * P.rec_stride;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) { sp_up[r] = Rs[L.unew() + fo + 256 * r]; sp_k[r] = Rs[L.k(7) + fo + 256 * r]; }
+        }
+    }
     // LAT: this wave's weight fragments in registers for the whole launch, nothing to fill (the LDS layout is kept: XB / YB sit where they sit)
     LatWeights LW;
     if constexpr (MODE != MW_FINISH && LAT) lat_load(G, Q.tab, LW, wave, lane);
@@ -363,7 +385,15 @@ __global__ __launch_bounds__(kMwThreads) void rnde_chainmw_kernel(const MwParams
         return;
     } else {
         // ---- controller, then (STEP) one attempted step / (FINISH) the last step's save points and the copy-out ----
-        const StepState S = advance_state(P, n, lane, writer, (MODE == MW_FINISH) ? P.ctl_final : &P.ctl[n & 1]);
+        StepState S;
+        if (pre) {
+            asm volatile("" : "+v"(prev_raw[0]), "+v"(prev_raw[1]), "+v"(prev_raw[2]));   // (first use: keeps the unpacking, and its wait, down here)
+            static_assert(sizeof(StepState) == 48, "StepState is read as three 16-byte words");
+            StepState prev_state;
+            __builtin_memcpy(&prev_state, prev_raw, sizeof(StepState));
+            prev_state.live = __builtin_amdgcn_readfirstlane(prev_state.live); prev_state.done = __builtin_amdgcn_readfirstlane(prev_state.done);
+            S = advance_state_t<true>(P, n, lane, writer, &P.ctl[n & 1], pre_part, prev_state);
+        } else S = advance_state(P, n, lane, writer, (MODE == MW_FINISH) ? P.ctl_final : &P.ctl[n & 1]);
         MW_STAMP(2);
         if (P.nsave > 0) {
             // saveat ({R,true} methods, neural_ode.jl:79-108): the points inside the step accepted last
@@ -424,7 +454,8 @@ __global__ __launch_bounds__(kMwThreads) void rnde_chainmw_kernel(const MwParams
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             float k1;
-            if (S.live < 0) { up[r] = ldx(P.x, r); k1 = P.f0[fo + 256 * r]; }
+            if (spec && S.live == n - 1) { up[r] = sp_up[r]; k1 = sp_k[r]; }      // (the step starts from what attempt n - 1 wrote: already here)
+            else if (S.live < 0) { up[r] = ldx(P.x, r); k1 = P.f0[fo + 256 * r]; }
             else { up[r] = Rl[L.unew() + fo + 256 * r]; k1 = Rl[L.k(7) + fo + 256 * r]; }
             if (P.tape || P.nsave > 0) { R[L.upc() + fo + 256 * r] = up[r]; R[L.k1c() + fo + 256 * r] = k1; }
 #pragma unroll

@@ -96,11 +96,33 @@ def bench_latent(args):
     p = node.p.to(device).clone().requires_grad_(True)
     w = torch.randn(B, T, 20, generator=g).to(device)
 
-    def step():
+    def step_autograd():
         z0.grad = None; p.grad = None
         res, nfe, sv = node(z0, p)
         ((res * w).sum() / B + 10.0 * sv.saveval.mean()).backward()
         return nfe
+    # the same forward + reverse as two calls through the C ABI (what a host that owns its own tape would make): the scalar loss
+    # sum(res * w) / B + 10 * mean(saveval) has the cotangents w / B and 10 / n, no tape library, no device <-> host tensor traffic
+    L = _lib.lib()
+    node._func = "error_est"
+    hd = node._acquire(z0.detach(), True)
+    zc, pc = z0.detach().contiguous(), p.detach().contiguous()
+    res = torch.empty(B, T, 20, dtype=torch.float32, device=device)
+    ubar = (w / B).contiguous()
+    zbar, pbar = torch.empty_like(zc), torch.empty_like(pc)
+    sa = (C.c_float * T)(*grid)
+    sv_host = (C.c_float * (node.max_attempts + 1))()
+    stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+    def step_abi():
+        nfe, nsv = C.c_int64(0), C.c_int32(0)
+        _lib.check(hd.ptr, L.rnde_node_forward_saveat(hd.ptr, zc.data_ptr(), pc.data_ptr(), B, 0.0, 1.0, sa, T, res.data_ptr(), C.byref(nfe), sv_host,
+                                                      C.byref(nsv), 1, stream))
+        n = nsv.value
+        svb = (C.c_float * n)(*([10.0 / n] * n))
+        _lib.check(hd.ptr, L.rnde_node_backward_async(hd.ptr, ubar.data_ptr(), svb, zbar.data_ptr(), pbar.data_ptr(), None, stream))
+        return int(nfe.value)
+    step = step_autograd if args.autograd else step_abi
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -108,7 +130,6 @@ def bench_latent(args):
     nfes = [step() for _ in range(args.steps)]
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    L = _lib.lib()
     h = node._acquire(z0.detach(), False)
     us = C.c_float(0)
     _lib.check(h.ptr, L.rnde_bench_attempt(h.ptr, z0.detach().contiguous().data_ptr(), p.detach().data_ptr(), B, 200, C.byref(us), None))
@@ -116,7 +137,8 @@ def bench_latent(args):
     return {"metric": "forward+reverse samples/sec, latent-ODE dynamics (config 4)", "value": B * args.steps / el, "unit": "samples/s",
             "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "mean_nfe": sum(nfes) / len(nfes),
-            "config": {"workload": "latent ODE gen_dynamics D=20, 8 Dense layers 20<->50 tanh, B=512, 49 saveat points, Tsit5 1.4e-8 (chain engine)"},
+            "config": {"workload": "latent ODE gen_dynamics D=20, 8 Dense layers 20<->50 tanh, B=512, 49 saveat points, Tsit5 1.4e-8 (chain engine); step = layer forward (taped) + its reverse, "
+                                   + ("through torch.autograd" if args.autograd else "two C-ABI calls (rnde_node_forward_saveat, rnde_node_backward_async)")},
             "roofline": {"bound": "mfma", "achieved": flops / (us.value * 1e-6) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                          "frac": flops / (us.value * 1e-6) / 1e12 / MFMA_F32_PEAK_TF, "traffic": None,
                          "kernel": "rnde_chain_kernel: one attempted Tsit5 step = 1 launch; latency bound (32 waves on the chip)",

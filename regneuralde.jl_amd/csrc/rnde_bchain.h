@@ -488,29 +488,52 @@ __global__ __launch_bounds__(64 * kCW) void rnde_chain_wgrad_kernel(const BChain
 #pragma unroll
         for (int b = 0; b < 5; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int u_lo = chunk * per_chunk, u_hi = min(n_units, u_lo + per_chunk);
-    for (int u = u_lo + wave; u < u_hi; u += kCW) {
+    // A unit's 16 columns are contracted in four k-steps; WHICH four columns share a k-step is free as long as both operands agree, so
+    // lane (rho, kk) takes the float4 of columns 4 kk .. 4 kk + 3 of its row -- one 16-byte load per tile, a tile's 16 rows 1 KiB of
+    // consecutive memory -- where it used to gather column 4 s + kk per k-step with sixteen 4-byte loads; and the next unit's eight loads
+    // are in flight while this unit's up to 80 MFMAs issue (the loop used to wait for cold memory four times per unit: the kernel ran at
+    // a third of what reading the (H, Z) dump once costs).
+    typedef const __attribute__((address_space(1))) f32x4* gq4;
+    auto load_unit = [&](int u, f32x4 (&za)[4], f32x4 (&hb)[4], float& te) {
         const int e = u / Q.ntiles, tile = u - e * Q.ntiles;
         const float* base = Q.slab + (size_t)e * Q.ev_stride + ((size_t)tile * Q.RS) * 64;
-        const float* Zp = base + (size_t)Q.zrow[l] * 64;
-        const float* Hp = base + (size_t)Q.hrow[l] * 64;
-        const float te = ev_t[e];
+        const float* Zp = base + (size_t)Q.zrow[l] * 64 + rho * 16 + 4 * kk;
+        const float* Hp = base + (size_t)Q.hrow[l] * 64 + rho * 16 + 4 * kk;
+        te = ev_t[e];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int cidx = 4 * s + kk;
-            float a[4], b[5];
+        for (int mo = 0; mo < 4; ++mo) za[mo] = mo < ot ? __builtin_nontemporal_load((gq4)(Zp + 256 * mo)) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int mo = 0; mo < 4; ++mo) a[mo] = mo < ot ? Zp[(16 * mo + rho) * 16 + cidx] : 0.f;
+        for (int mi = 0; mi < 4; ++mi) hb[mi] = mi < it ? __builtin_nontemporal_load((gq4)(Hp + 256 * mi)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    auto mac_unit = [&](const f32x4 (&za)[4], const f32x4 (&hb)[4], float te) {
+        const float b4 = rho == 0 ? (G.time_dep ? te : 0.f) : (rho == 1 ? 1.f : 0.f);
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) b[mi] = mi < it ? Hp[(16 * mi + rho) * 16 + cidx] : 0.f;
-            b[4] = rho == 0 ? (G.time_dep ? te : 0.f) : (rho == 1 ? 1.f : 0.f);
+        for (int j = 0; j < 4; ++j) {
 #pragma unroll
             for (int mo = 0; mo < 4; ++mo) {
                 if (mo < ot) {
 #pragma unroll
-                    for (int mi = 0; mi < 4; ++mi) if (mi < it) acc[mo][mi] = mfma16(a[mo], b[mi], acc[mo][mi]);
-                    acc[mo][4] = mfma16(a[mo], b[4], acc[mo][4]);
+                    for (int mi = 0; mi < 4; ++mi) if (mi < it) acc[mo][mi] = mfma16(za[mo][j], hb[mi][j], acc[mo][mi]);
+                    acc[mo][4] = mfma16(za[mo][j], b4, acc[mo][4]);
                 }
             }
+        }
+    };
+    {
+        f32x4 zA[4], hA[4], zB[4], hB[4];
+        float tA = 0.f, tB = 0.f;
+        int u = u_lo + wave;
+        if (u < u_hi) load_unit(u, zA, hA, tA);
+        while (u < u_hi) {
+            const bool nb = u + kCW < u_hi;
+            if (nb) load_unit(u + kCW, zB, hB, tB);
+            mac_unit(zA, hA, tA);
+            u += kCW;
+            if (u >= u_hi) break;
+            const bool na = u + kCW < u_hi;
+            if (na) load_unit(u + kCW, zA, hA, tA);
+            mac_unit(zB, hB, tB);
+            u += kCW;
         }
     }
     // fixed-order sum over the 4 waves, then scatter into the Flux.destructure order of this chunk's partial vector

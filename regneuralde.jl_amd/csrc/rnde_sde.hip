@@ -30,6 +30,8 @@ struct rnde_nsde {
     int mw = 0;    // 1: the four-waves-per-tile solve kernel (rnde_sdemw.h) for that shape, while a tile per workgroup still fits the chip
     size_t lds_mw = 0;
     int xch_wg = 0; // workgroups the exchange array is sized for
+    int xch_local = 1;      // the four-waves-per-tile solve pins its workgroups to one XCD while they fit it (<= 32 tiles) and meets through that L2; 0 after the placement check failed once
+    unsigned *xcc = nullptr, *h_xcc = nullptr;
     int fix = 0;   // 1: the reference's own shape (drift 8 -> 16 -> 8 k-steps, one-layer diffusion): kernels with compile-time shapes
     ChainGeo Gf{}, Gg{};
     SriTableau T{};
@@ -196,6 +198,8 @@ extern "C" rnde_status rnde_nsde_create(const rnde_nsde_config* c, rnde_nsde** o
     ok &= hipHostMalloc((void**)&h->h_meta, (size_t)(c->max_attempts + 1) * sizeof(SdeMeta)) == hipSuccess;
     ok &= hipHostMalloc((void**)&h->h_acc_meta, (size_t)(c->max_attempts + 1) * sizeof(SdeMeta)) == hipSuccess;
     ok &= hipHostMalloc((void**)&h->h_fin, sizeof(SdeFinal)) == hipSuccess;
+    ok &= dm((void**)&h->xcc, 256 * 4) && hipHostMalloc((void**)&h->h_xcc, 256 * 4) == hipSuccess;
+    { const char* e = getenv("RNDE_SDE_LOCAL"); if (e && e[0] == '0') h->xch_local = 0; }
     ok &= hipHostMalloc((void**)&h->h_svb, (size_t)(c->max_attempts + 1) * 4) == hipSuccess;
     ok &= hipHostMalloc((void**)&h->h_part, (size_t)h->nwg_max * 4) == hipSuccess;
     if (!ok) { g_nsde_create_err = "device allocation failed"; rnde_nsde_destroy(h); return RNDE_ERR_HIP; }
@@ -211,9 +215,9 @@ extern "C" rnde_status rnde_nsde_create(const rnde_nsde_config* c, rnde_nsde** o
 extern "C" void rnde_nsde_destroy(rnde_nsde* h) {
     if (!h) return;
     void* d[] = {h->frags_f, h->frags_g, h->slots, h->tape, h->noise, h->replay, h->meta, h->acc_meta, h->fin, h->xch, h->abort_word, h->svb,
-                 h->slab_f, h->slab_g, h->wslab, h->wslab_r, h->ev_t, h->part, h->sv_t_dev, h->head_ws, h->cg_ws};
+                 h->slab_f, h->slab_g, h->wslab, h->wslab_r, h->ev_t, h->part, h->sv_t_dev, h->head_ws, h->cg_ws, h->xcc};
     for (void* p : d) if (p) (void)hipFree(p);
-    void* hd[] = {h->h_meta, h->h_acc_meta, h->h_fin, h->h_svb, h->h_part};
+    void* hd[] = {h->h_meta, h->h_acc_meta, h->h_fin, h->h_svb, h->h_part, h->h_xcc};
     for (void* p : hd) if (p) (void)hipHostFree(p);
     for (hipEvent_t e : h->tev) if (e) (void)hipEventDestroy(e);
     if (h->ev_host) (void)hipEventDestroy(h->ev_host);
@@ -341,12 +345,16 @@ static rnde_status nsde_forward_impl(rnde_nsde* h, const float* x_dev, const flo
     h->tev_f = false;
     SCHK(h, hipEventRecord(h->tev[0], s));
     hipError_t e;
+    bool local_xch = false;
     if (h->mw && ntiles <= 256) {   // one workgroup of four waves per tile (all of them resident: they meet once per attempt)
         static bool attr = false;
         if (!attr) { SCHK(h, hipFuncSetAttribute((const void*)rnde_sde_solve_mw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
         Q.nwg = ntiles;
-        hipLaunchKernelGGL(rnde_sde_solve_mw_kernel, dim3(ntiles), dim3(kSmwThreads), h->lds_mw, s, Q);
+        local_xch = h->xch_local && ntiles <= 32;      // one XCD has 32 CUs: one workgroup each
+        Q.xch_local = local_xch ? 1 : 0; Q.xcc = h->xcc;
+        hipLaunchKernelGGL(rnde_sde_solve_mw_kernel, dim3(local_xch ? 8 * ntiles : ntiles), dim3(kSmwThreads), h->lds_mw, s, Q);
         e = hipGetLastError();
+        if (local_xch && e == hipSuccess) e = hipMemcpyAsync(h->h_xcc, h->xcc, (size_t)ntiles * 4, hipMemcpyDeviceToHost, s);
     } else
         e = h->fix ? launch_solve<8, 16>(h, Q, s)
                    : (h->NKD == 4 ? launch_solve<4>(h, Q, s) : (h->NKD == 8 ? launch_solve<8>(h, Q, s) : launch_solve<16>(h, Q, s)));
@@ -361,6 +369,16 @@ static rnde_status nsde_forward_impl(rnde_nsde* h, const float* x_dev, const flo
         if (hs != RNDE_OK) return hs;
         SCHK(h, hipEventSynchronize(h->ev_host));
     } else SCHK(h, hipStreamSynchronize(s));
+    if (local_xch) {   // did the workgroups really share an XCD?  If not, their meeting had no coherent meeting place: redo the solve the safe way, for good
+        bool same = true;
+        for (int i = 1; i < ntiles; ++i) same = same && h->h_xcc[i] == h->h_xcc[0];
+        if (!same) {
+            fprintf(stderr, "[rnde] SDE solve: workgroups pinned by block index landed on different XCDs; using the placement-independent exchange from now on\n");
+            h->xch_local = 0;
+            return nsde_forward_impl(h, x_dev, p_dev, B, t0, t1, noise_dev, n_pool, seed, steps_host, n_steps, u_out_dev, nfe1_out, nfe2_out, saveval_host, n_saveval_out,
+                                     keep_tape, stream, saveat_host, n_saveat, sv_out_dev);
+        }
+    }
     const SdeFinal F = *h->h_fin;
     h->B = B; h->ntiles = ntiles; h->nwg = Q.nwg; h->n_att = F.n_att; h->n_acc = F.n_acc; h->n_draws = F.n_draws; h->t0 = t0;
     if (nfe1_out) *nfe1_out = 2 + 4 * (int64_t)F.n_att;   // the closures' counters (neural_sde.jl:46,:50): 2 probes of the initial-step rule + 4 per attempt

@@ -25,7 +25,11 @@ __global__ __launch_bounds__(kSmwThreads) void rnde_sde_solve_mw_kernel(const Sd
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wg = blockIdx.x;
+    // xch_local: the grid is 8 x nwg and only the workgroups with blockIdx % 8 == 0 work -- under round-robin dispatch all on one XCD (each
+    // records its XCC id; the host verifies and falls back to the placement-independent exchange if the assumption ever fails)
+    if (Q.xch_local && (blockIdx.x & 7)) return;
+    const int wg = Q.xch_local ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (Q.xch_local && tid == 0) Q.xcc[wg] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15;   // HW_REG_XCC_ID
     float* X0 = smem;                 // [32][16] drift input of the stage
     float* X1 = smem + 512;           // [32][16] diffusion input
     float* HD = smem + 1024;          // [64][16] hidden layer of the drift

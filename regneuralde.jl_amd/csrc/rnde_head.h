@@ -93,10 +93,17 @@ __global__ __launch_bounds__(256) void rnde_head_wgrad_kernel(const float* __res
     float acc[kHeadMaxC];
 #pragma unroll
     for (int i = 0; i < kHeadMaxC; ++i) acc[i] = 0.f;
-    for (int c = c0; c < c1; ++c) {
-        const float uv = u[(size_t)c * D + d];
+    // (eight columns' loads in flight at a time: one after the other, each of the chunk's 16 columns was a cold round trip -- 13 us for 8 MFLOP)
+    for (int cb = c0; cb < c1; cb += 8) {
+        float uv[8];
 #pragma unroll
-        for (int i = 0; i < kHeadMaxC; ++i) if (i < C) acc[i] = fmaf(delta[(size_t)c * C + i], uv, acc[i]);
+        for (int j = 0; j < 8; ++j) uv[j] = cb + j < c1 ? u[(size_t)(cb + j) * D + d] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = cb + j < c1 ? cb + j : c0;
+#pragma unroll
+            for (int i = 0; i < kHeadMaxC; ++i) if (i < C) acc[i] = fmaf(delta[(size_t)c * C + i], uv[j], acc[i]);
+        }
     }
     float* o = partial + (size_t)ch * C * D;
     for (int i = 0; i < C; ++i) o[(size_t)d * C + i] = acc[i];
@@ -107,22 +114,30 @@ __global__ __launch_bounds__(256) void rnde_head_reduce_kernel(const float* __re
                                                                float* __restrict__ p3bar, float* __restrict__ ce_out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < C * D) {
+        float v[kHeadChunks];
+#pragma unroll
+        for (int ch = 0; ch < kHeadChunks; ++ch) v[ch] = partial[(size_t)ch * C * D + i];     // (all 32 requested before the first add)
         float s = 0.f;
-        for (int ch = 0; ch < kHeadChunks; ++ch) s += partial[(size_t)ch * C * D + i];
+#pragma unroll
+        for (int ch = 0; ch < kHeadChunks; ++ch) s += v[ch];
         p3bar[i] = s;
     }
-    if (blockIdx.x == 0 && threadIdx.x < 64) {
-        const int lane = threadIdx.x;
-        for (int k = 0; k < C; ++k) {
+    // bias gradient (C sums over the columns) and the mean cross entropy: the LAST block's four waves share them (wave w: classes w, w + 4, ..;
+    // wave 3 also the cross entropy) -- one wave doing the eleven reductions one after the other was the longest thing in this launch
+    if (blockIdx.x == gridDim.x - 1) {
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        for (int k = w; k < C; k += 4) {
             float s = 0.f;
             for (int c = lane; c < B; c += 64) s += delta[(size_t)c * C + k];
             s = wave_sum_f(s);
             if (lane == 0) p3bar[(size_t)C * D + k] = s;
         }
-        float s = 0.f;
-        for (int c = lane; c < B; c += 64) s += ce_col[c];
-        s = wave_sum_f(s);
-        if (lane == 0) *ce_out = s / (float)B;
+        if (w == 3) {
+            float s = 0.f;
+            for (int c = lane; c < B; c += 64) s += ce_col[c];
+            s = wave_sum_f(s);
+            if (lane == 0) *ce_out = s / (float)B;
+        }
     }
 }
 

@@ -922,7 +922,15 @@ __global__ void rnde_wgrad_reduce(const float* __restrict__ slab, int n_chunks, 
     float* o = out + (size_t)blockIdx.y * len;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < len; i += (long long)gridDim.x * blockDim.x) {
         float s = 0.f;
-        for (int c = c0; c < c1; ++c) s += slab[(size_t)c * len + i];
+        int c = c0;
+        for (; c + 8 <= c1; c += 8) {       // eight chunks requested before the first add (same additions, same order)
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = __builtin_nontemporal_load(slab + (size_t)(c + j) * len + i);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+        }
+        for (; c < c1; ++c) s += __builtin_nontemporal_load(slab + (size_t)c * len + i);
         o[i] = s;
     }
 }

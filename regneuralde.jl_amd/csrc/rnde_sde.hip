@@ -32,6 +32,7 @@ struct rnde_nsde {
     int xch_wg = 0; // workgroups the exchange array is sized for
     int xch_local = 1;      // the four-waves-per-tile solve pins its workgroups to one XCD while they fit it (<= 32 tiles) and meets through that L2; 0 after the placement check failed once
     unsigned *xcc = nullptr, *h_xcc = nullptr;
+    int pool_pred = 0;      // library noise: draws the next solve's pool is filled with (0 = all of max_attempts + 1); grows back on demand
     int fix = 0;   // 1: the reference's own shape (drift 8 -> 16 -> 8 k-steps, one-layer diffusion): kernels with compile-time shapes
     ChainGeo Gf{}, Gg{};
     SriTableau T{};
@@ -315,8 +316,13 @@ static rnde_status nsde_forward_impl(rnde_nsde* h, const float* x_dev, const flo
             h->tape_floats = need;
         }
     }
+    bool lib_noise = false;
     if (!noise_dev) {   // the library's own stream: one pool per solve from (seed, epoch-independent: the seed alone names the path)
-        n_pool = h->cfg.max_attempts + 1;
+        // Draw k of the stream depends on (seed, k) alone (counter-based generator), so the pool may be any prefix: it is filled for one and a half
+        // times the draws the last solve consumed (+ 16) instead of for max_attempts + 1 (34 MB, 17 us in front of every solve at B = 512), and a
+        // solve that runs out of it (status 4) is redone with the full pool -- same draws, same result.
+        lib_noise = true;
+        n_pool = (h->pool_pred > 0 && n_steps == 0) ? std::min(h->pool_pred, h->cfg.max_attempts + 1) : h->cfg.max_attempts + 1;
         const size_t need = (size_t)n_pool * 2 * h->D * B;
         if (h->noise_floats < need) {
             if (h->noise) (void)hipFree(h->noise);
@@ -375,8 +381,8 @@ static rnde_status nsde_forward_impl(rnde_nsde* h, const float* x_dev, const flo
         if (!same) {
             fprintf(stderr, "[rnde] SDE solve: workgroups pinned by block index landed on different XCDs; using the placement-independent exchange from now on\n");
             h->xch_local = 0;
-            return nsde_forward_impl(h, x_dev, p_dev, B, t0, t1, noise_dev, n_pool, seed, steps_host, n_steps, u_out_dev, nfe1_out, nfe2_out, saveval_host, n_saveval_out,
-                                     keep_tape, stream, saveat_host, n_saveat, sv_out_dev);
+            return nsde_forward_impl(h, x_dev, p_dev, B, t0, t1, lib_noise ? nullptr : noise_dev, lib_noise ? 0 : n_pool, seed, steps_host, n_steps, u_out_dev, nfe1_out, nfe2_out,
+                                     saveval_host, n_saveval_out, keep_tape, stream, saveat_host, n_saveat, sv_out_dev);
         }
     }
     const SdeFinal F = *h->h_fin;
@@ -397,12 +403,19 @@ static rnde_status nsde_forward_impl(rnde_nsde* h, const float* x_dev, const flo
         case 1: h->err = "max_attempts reached"; return RNDE_ERR_MAX_ATTEMPTS;
         case 2: h->err = "dt underflow"; return RNDE_ERR_DT_UNDERFLOW;
         case 3: h->err = "non-finite error estimate or dt"; return RNDE_ERR_NONFINITE;
-        case 4: h->err = "noise pool or stack capacity exhausted (n_pool must cover 1 + attempts draws)"; return RNDE_ERR_BAD_ARG;
+        case 4:
+            if (lib_noise && n_pool < h->cfg.max_attempts + 1) {   // the shortened pool of the library's own stream ran out: the whole pool, once more
+                h->pool_pred = 0;
+                return nsde_forward_impl(h, x_dev, p_dev, B, t0, t1, nullptr, 0, seed, steps_host, n_steps, u_out_dev, nfe1_out, nfe2_out, saveval_host, n_saveval_out,
+                                         keep_tape, stream, saveat_host, n_saveat, sv_out_dev);
+            }
+            h->err = "noise pool or stack capacity exhausted (n_pool must cover 1 + attempts draws)"; return RNDE_ERR_BAD_ARG;
         default:
             (void)hipMemsetAsync(h->abort_word, 0, 16, s);
             h->err = "a workgroup of the one-launch solve timed out waiting for the others (not all resident?)";
             return RNDE_ERR_HIP;
     }
+    if (lib_noise) h->pool_pred = std::min(h->cfg.max_attempts + 1, F.n_draws + F.n_draws / 2 + 16);
     h->have_tape = keep_tape != 0;
     return RNDE_OK;
 }

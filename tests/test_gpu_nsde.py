@@ -226,6 +226,22 @@ def test_library_noise_stream_is_standard_normal_and_reproducible():
     node.close()
 
 
+def test_shortened_noise_pool_is_refilled_on_demand():
+    """Library noise: the pool is filled for 1.5 x the draws of the LAST solve; a solve that needs more is redone with the whole pool.  Draw k
+    depends on (seed, k) alone, so a long solve behind a short one on the same handle must equal the same solve on a fresh handle, bit for bit."""
+    from tests.util import NsdeNode
+    drift, diff, p, x, _ = _setup("nsde", 48, 3, 1)
+    fresh = NsdeNode(_cfg(drift, diff, 48, reltol=0.14, abstol=0.14))
+    ref = fresh.forward(x, p, None, seed=7, t1=1.0)
+    fresh.close()
+    node = NsdeNode(_cfg(drift, diff, 48, reltol=0.14, abstol=0.14))
+    short = node.forward(x, p, None, seed=7, t1=0.02)          # a handful of attempts: the next pool is small
+    assert short["nattempts"] + 16 < ref["nattempts"] * 2 // 3, (short["nattempts"], ref["nattempts"])
+    again = node.forward(x, p, None, seed=7, t1=1.0)           # runs out of it, is redone
+    assert again["nattempts"] == ref["nattempts"] and np.array_equal(again["u"], ref["u"])
+    node.close()
+
+
 def test_error_paths():
     from regneuralde_jl_amd import _lib
     from tests.util import NsdeNode

@@ -217,6 +217,21 @@ __global__ __launch_bounds__(kMwThreads) void rnde_bchainmw_kernel(const BMwPara
     const size_t fo = (size_t)tile * NKD * 64 + tid;
     auto feat = [&](int r) { return (tid + 256 * r) >> 4; };
     auto valid = [&](int r) { return colok && feat(r) < P.D; };
+    // Everything this launch reads that does not depend on loaded data -- the previous reversed attempt's partials, the nine tape arrays of
+    // the error estimate's reverse -- is requested in front of the weights (a wave's loads return in order; behind the weights these were two
+    // more serial round trips to cold memory in a 33 us launch)
+    f32x4 pe[4];
+    if (!first) bpart_request(Bq, n + 1, lane, pe);
+    const float* R = P.arena + (long long)m.rec * P.rec_stride;
+    float kq[7][NR], upv[NR], unv[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        upv[r] = R[L.upc() + fo + 256 * r];
+        unv[r] = R[L.unew() + fo + 256 * r];
+        kq[0][r] = R[L.k1c() + fo + 256 * r];
+#pragma unroll
+        for (int j = 1; j < 7; ++j) kq[j][r] = R[L.k(j + 1) + fo + 256 * r];
+    }
     LatWeightsT LT;
     if constexpr (LAT) lat_load_t(G, Q.tab, LT, wave, lane);      // (the latent-ODE shape: transposed fragments in registers, no LDS fill)
     else mw_fill_lds(Q.tab + (size_t)G.nfrag_f * 64, smem, (G.nfrag_t >> 2) + 4, wave, lane);
@@ -226,7 +241,7 @@ __global__ __launch_bounds__(kMwThreads) void rnde_bchainmw_kernel(const BMwPara
     };
     // ---- scalar chain, identical in every wave; same arithmetic as rnde_bchain_kernel ----
     double tb = 0, dtpb = 0, qoldb = 0, t1b = 0, t0b = 0;
-    if (!first) finish_attempt_scalars(Bq, n + 1, lane, tb, dtpb, qoldb, t1b, t0b);
+    if (!first) finish_attempt_scalars_from(Bq, n + 1, lane, &pe, tb, dtpb, qoldb, t1b, t0b);
     const bool accepted = (m.flags & F_ACCEPT) != 0;
     const float dt = m.dt, t = m.t;
     float coef;
@@ -256,22 +271,13 @@ __global__ __launch_bounds__(kMwThreads) void rnde_bchainmw_kernel(const BMwPara
     }
 
     float S = 0.f, tau = 0.f, ctau = 0.f;   // sum_j <k_j, kbar_j>; sum of time cotangents; c_s-weighted (+ extra dt-bar)
-    const float* R = P.arena + (long long)m.rec * P.rec_stride;
     float* sl0 = Q.slab + (size_t)(2 + 6 * n) * Q.ev_stride + ((size_t)tile * G.RS) * 64;
     const bool sv_mode = Q.nsave > 0;
     float utb[NR], unb[NR], upb[NR], k1v[NR], Wv[7][NR];
     // ---- A: reverse of the error estimate; seeds of unew-bar / uprev-bar ----
     {
-        float kq[7][NR], upv[NR], unv[NR];
 #pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            upv[r] = R[L.upc() + fo + 256 * r];
-            unv[r] = R[L.unew() + fo + 256 * r];
-            kq[0][r] = R[L.k1c() + fo + 256 * r];
-#pragma unroll
-            for (int j = 1; j < 7; ++j) kq[j][r] = R[L.k(j + 1) + fo + 256 * r];
-            k1v[r] = kq[0][r];
-        }
+        for (int r = 0; r < NR; ++r) k1v[r] = kq[0][r];
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             float acc = rk_bt<TAB>(Q.rk, 0) * kq[0][r];

@@ -174,3 +174,21 @@ def test_persistent_attempt_is_bit_identical(kind, B, tol, scale, saveat, generi
     if "steps" in a[0]:
         assert np.array_equal(a[0]["steps"], b[0]["steps"])
     assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+
+
+def test_attempt_micro_benchmarks_run_and_leave_the_handle_usable():
+    """rnde_bench_attempt / _taped / _cold_tape (the back-to-back figures bench.py reports beside the in-step one): they return a time, refuse
+    nonsense, and a solve on the same handle afterwards equals one on a fresh handle (the forced attempts write tape records and controller state)."""
+    import ctypes as C
+    from tests.util import Node
+    arch, p, x = _setup("mnist", 32, 3, 1.0)
+    ref = Node(_cfg(arch, 32, reltol=1e-3, abstol=1e-3)).forward(x, p, 0.0, 1.0, keep_tape=True)
+    n = Node(_cfg(arch, 32, reltol=1e-3, abstol=1e-3))
+    us = C.c_float(0)
+    xd, pd = n.dev(x), n.dev(p)
+    assert n.L.rnde_bench_attempt(n.h, xd.data_ptr(), pd.data_ptr(), 32, 20, C.byref(us), None) == 0 and us.value > 0
+    assert n.L.rnde_bench_attempt_taped(n.h, xd.data_ptr(), pd.data_ptr(), 32, 20, C.byref(us), None) == 0 and us.value > 0
+    assert n.L.rnde_bench_attempt_cold_tape(n.h, xd.data_ptr(), pd.data_ptr(), 32, 20, 8, C.byref(us), None) == 0 and us.value > 0
+    assert n.L.rnde_bench_attempt_cold_tape(n.h, xd.data_ptr(), pd.data_ptr(), 32, 20, 1, C.byref(us), None) != 0
+    got = n.forward(x, p, 0.0, 1.0, keep_tape=True)
+    assert got["nattempts"] == ref["nattempts"] and np.array_equal(got["u"], ref["u"])

@@ -210,8 +210,12 @@ def bench_nsde(args):
 def spawn_multi_gpu(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a fresh torchrun child (nothing here has touched the GPU
     yet, and the child is a child process, not an exec) and pass its JSON line through."""
+    import socket
+    with socket.socket() as so:                 # a port that is free right now (a fixed or pid-derived one can sit in TIME_WAIT)
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(29500 + os.getpid() % 1000), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd)
 
 

@@ -1306,8 +1306,7 @@ static rnde_status launch_wgrad_part(rnde_node* h, const EvalDesc* ev, int n_eva
     const int MB = tall ? 2 : 4, NB = tall ? 4 : 2;
     const int blocks = ((mtiles + MB - 1) / MB) * ((ntiles + NB - 1) / NB);
     const long long len = (long long)M * (Nx + 2);
-    const int chunks = (n_evals + per_chunk - 1) / per_chunk;
-    if ((size_t)(*chunk_cursor + chunks) * (size_t)len > h->bw.slab_floats) { h->err = "weight-gradient slab overflow"; return RNDE_ERR_BAD_ARG; }
+    const int chunks = (n_evals + per_chunk - 1) / per_chunk;      // (chunking of the direct-from-global kernels only; checked where they are launched)
     float* dst = slab + (size_t)(*chunk_cursor) * len;
     static const bool legacy = getenv("RNDE_WGRAD_LEGACY") != nullptr;   // direct-from-global variant, kept for A/B runs
     const bool fits = tall ? (Nx + 2 <= 128) : (M <= 128);                // the staged kernel covers 128 on the un-split side
@@ -1346,8 +1345,13 @@ static rnde_status launch_wgrad_part(rnde_node* h, const EvalDesc* ev, int n_eva
         HIPCHK(h, hipGetLastError());
         *chunk_cursor += sc;
         return RNDE_OK;
-    } else if (tall) hipLaunchKernelGGL((rnde_wgrad_kernel<2, 4>), dim3(blocks, chunks), dim3(64), 0, s, ev, n_evals, per_chunk, M, Nx, Bpad, dst);
-    else hipLaunchKernelGGL((rnde_wgrad_kernel<4, 2>), dim3(blocks, chunks), dim3(64), 0, s, ev, n_evals, per_chunk, M, Nx, Bpad, dst);
+    } else {
+        // (this check used to sit in front of ALL paths with the direct kernels' chunk count -- up to 240 -- and refused solves of more than ~65
+        //  attempts on the 16x16x4 path, which needs 127 chunks behind the sweep: "slab overflow" in a training run whose step count had grown)
+        if ((size_t)(*chunk_cursor + chunks) * (size_t)len > h->bw.slab_floats) { h->err = "weight-gradient slab overflow"; return RNDE_ERR_BAD_ARG; }
+        if (tall) hipLaunchKernelGGL((rnde_wgrad_kernel<2, 4>), dim3(blocks, chunks), dim3(64), 0, s, ev, n_evals, per_chunk, M, Nx, Bpad, dst);
+        else hipLaunchKernelGGL((rnde_wgrad_kernel<4, 2>), dim3(blocks, chunks), dim3(64), 0, s, ev, n_evals, per_chunk, M, Nx, Bpad, dst);
+    }
     HIPCHK(h, hipGetLastError());
     *chunk_cursor += chunks;
     return RNDE_OK;

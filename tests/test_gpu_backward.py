@@ -113,6 +113,30 @@ def test_weight_gradient_kernels_agree_on_another_shape(monkeypatch):
         assert rel_err(out["v3"][1], pb64) <= 2e-3 and rel_err(out["v3"][0], xb64) <= 2e-3
 
 
+@pytest.mark.parametrize("t1", [2.1, 2.2, 3.4])
+def test_reverse_pass_of_a_long_solve(monkeypatch, t1):
+    """More than ~65 attempts on the stage engine with the side-stream launches: the slab bookkeeping of the weight-gradient GEMMs (side
+    launches of 16 chunks each + 127 chunks behind the sweep) must hold, where a stale capacity check of the legacy kernels' chunk count
+    used to refuse the reverse pass ("weight-gradient slab overflow" -- met in a training run whose step count had grown)."""
+    from tests.test_gpu_forward import _cfg, _setup
+    from tests.util import Node, rel_err
+    arch, p, x = _setup("mnist", 32, 21, 2.0)
+    rng = np.random.default_rng(9)
+    ubar = rng.standard_normal(x.shape).astype(np.float32)
+    out = {}
+    for name, env in (("v3", {}), ("v2", {"RNDE_WGRAD_V2": "1"})):
+        monkeypatch.delenv("RNDE_WGRAD_V2", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        node = Node(_cfg(arch, 32, reltol=1.4e-8, abstol=1.4e-8, max_attempts=256))
+        got = node.forward(x, p, 0.0, t1, keep_tape=True)
+        print("attempts", got["nattempts"])      # (the refused window was 70..79 and 110..119 attempts)
+        assert got["nattempts"] >= 60, got["nattempts"]
+        out[name] = node.backward(ubar, np.full(len(got["saveval"]), 1.0, dtype=np.float32))
+    assert np.isfinite(out["v3"][1]).all() and np.abs(out["v3"][1]).max() > 0
+    assert rel_err(out["v3"][1], out["v2"][1]) <= 1e-5
+
+
 def test_backward_requires_tape():
     from tests.test_gpu_forward import _cfg, _setup
     from tests.util import Node

@@ -245,6 +245,26 @@ function classifier_grad!(p2bar::ROCVector{Float32}, p3bar::ROCVector{Float32}, 
     return ce, reg[], nfe[]
 end
 
+# The SDE counterpart (ClassifierNSDE around the solve, one trajectory per input): x is the SDE's initial state (the presde layer's output),
+# xbar its cotangent; noise = nothing: the library's Philox stream named by `seed`, else the caller's pool (D x B x 2 x n_pool normals).
+function nsde_classifier_grad!(p2bar::ROCVector{Float32}, p3bar::ROCVector{Float32}, xbar::ROCMatrix{Float32}, h::NsdeHandle,
+                               x::ROCMatrix{Float32}, p2::ROCVector{Float32}, p3::ROCVector{Float32}, y::ROCMatrix{Float32}, tspan;
+                               lambda = 1f1, noise = nothing, seed::Integer = 0)
+    ce = ROCVector{Float32}(undef, 1)
+    reg = Ref{Cfloat}(0); nfe1 = Ref{Int64}(0); nfe2 = Ref{Int64}(0)
+    npool = noise === nothing ? 0 : size(noise, 4)
+    st = GC.@preserve p2bar p3bar xbar x p2 p3 y ce noise begin
+        ccall((:rnde_nsde_classifier_grad, LIB), Cint,
+              (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int32, Cfloat, Cfloat, Ptr{Cvoid}, Int32, UInt64, Cfloat,
+               Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Cfloat}, Ref{Int64}, Ref{Int64}, Ptr{Cvoid}),
+              h.ptr, devptr(x), devptr(p2), devptr(p3), devptr(y), size(x, 2), size(y, 1), Float32(tspan[1]), Float32(tspan[2]),
+              noise === nothing ? C_NULL : devptr(noise), npool, UInt64(seed), Float32(lambda),
+              devptr(p2bar), devptr(p3bar), devptr(xbar), devptr(ce), reg, nfe1, nfe2, C_NULL)
+    end
+    st == 0 || error("rnde_nsde_classifier_grad: ", unsafe_string(ccall((:rnde_nsde_last_error, LIB), Cstring, (Ptr{Cvoid},), h.ptr)))
+    return ce, reg[], nfe1[], nfe2[]
+end
+
 # ---- optimiser step and the data-parallel collective -------------------------------------------------
 # Optimiser(InvDecay(gamma), Momentum(eta, rho)) on one flat group, in place (src/utils.jl:149-156, mnist_node.jl:130);
 # `n` is the group's InvDecay counter (starts at 1, the caller increments it); gscale = 1 / nworkers after a summed all-reduce.

@@ -7,6 +7,7 @@
 #include "rnde_bstage.h"
 #include "rnde_stage_persist.h"
 #include "rnde_bstage_persist.h"
+#include "rnde_binit_stage.h"
 #include "rnde_head.h"
 #include "rnde_chain.h"
 #include "rnde_bchain.h"
@@ -65,6 +66,7 @@ struct rnde_node {
     float* replay_dev = nullptr; size_t replay_cap = 0; const float* replay_host = nullptr; int n_replay = 0;   // rnde_node_forward_replay (set for one forward)
     // persistent attempt kernel (rnde_stage_persist.h): 1 = in use, 0 = off (RNDE_PERSIST=0), -1 = disabled after a failure
     int wgrad_side_pct = 30, stage_generic = 0;
+    int binit_stage = 1;   // reverse of the initial-step rule on the stage engine (rnde_binit_stage.h); 0: the column-owner kernels (RNDE_BINIT_STAGE=0)
     int persist_clean = 0, persist_retry_after = 8, persist_fallbacks = 0;   // non-sticky fallback: clean multi-launch solves since the last failure, when to try again   // fixed at creation (config fields; RNDE_* environment overrides are read once, there)
     int persist = 0, persist_spins = kPersistMaxSpins; int tslab_Bpad = -1; size_t tslab_bytes = 0; float* tslab = nullptr; unsigned *pabort = nullptr, *pxcc = nullptr; unsigned* h_pchk = nullptr;
     hipStream_t wstream = nullptr;        // (experimental overlap path of the weight-gradient GEMMs)
@@ -514,6 +516,7 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
         if (const char* e2 = getenv("RNDE_PERSIST_SPINS")) h->persist_spins = atoi(e2);
         h->wgrad_side_pct = c->wgrad_side_pct < 0 ? 0 : (c->wgrad_side_pct == 0 ? 30 : std::min(100, c->wgrad_side_pct));
         if (const char* e3 = getenv("RNDE_WGRAD_SIDE")) h->wgrad_side_pct = atoi(e3);
+        if (const char* e5 = getenv("RNDE_BINIT_STAGE")) h->binit_stage = atoi(e5);
         h->stage_generic = (c->stage_generic != 0 || getenv("RNDE_STAGE_GENERIC") != nullptr) ? 1 : 0;
     }
     h->predicted = 12;
@@ -634,8 +637,10 @@ static rnde_status stage_pack_all(rnde_node* h, const float* p_dev, hipStream_t 
     add(h->spwD, (long long)h->sHT * h->sMT * 64, 0, 1, h->sMT);
     add(h->spwBt, (long long)h->sMT * h->sKHb * 64, 0, 2, h->sKHb);
     add(h->spwDt, (long long)h->sHT * h->sMT * 64, 0, 3, h->sMT);
-    add(h->pw2t, (long long)h->MT2t * h->K4_2t * TR, 1, 2, h->K4_2t);     // (rnde_binit_kernel: column-owner layouts)
-    add(h->pw1t, (long long)h->MT1t * h->K4_1t * TR, 1, 3, h->K4_1t);
+    if (!h->binit_stage) {   // (rnde_binit_kernel: column-owner layouts; the stage-engine form of the initial-step reverse needs none)
+        add(h->pw2t, (long long)h->MT2t * h->K4_2t * TR, 1, 2, h->K4_2t);
+        add(h->pw1t, (long long)h->MT1t * h->K4_1t * TR, 1, 3, h->K4_1t);
+    }
     add(h->pcopy, (long long)h->P, 2, 0, 0);
     long long most = 0;
     for (int i = 0; i < n; ++i) most = std::max(most, J.j[i].total);
@@ -1455,6 +1460,7 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
     };
     int hi_att = n_att;                                           // evaluations of attempts >= hi_att are already launched
     hipError_t e;
+    bool stage_binit_done = false;
     h->tev_bwd = false;
     if (h->timing) HIPCHK(h, hipEventRecord(h->tev[2], s));
     if (h->engine == 2) {
@@ -1526,12 +1532,36 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
             if ((st = couple_sum(h, b.bpart + (size_t)(n & 1) * Q.bpart_n * 4, 4LL * Q.bpart_n, s)) != RNDE_OK) return st;
         }
         HIPCHK(h, hipGetLastError());
-        Q.F.nwg = Q.F.Bpad / h->BT;     // the initialisation kernels below are column-owner kernels
-        n_att = 0;                       // (their attempt loop is skipped)
+        if (h->binit_stage) {   // reverse of the initial-step rule: four stage-engine launches (rnde_binit_stage.h)
+            stage_binit_done = true;
+            if (h->act2) {
+                hipLaunchKernelGGL((rnde_binit_stage_kernel<1, 0>), grid, blk, h->stage_lds, s, BQ);
+                hipLaunchKernelGGL((rnde_binit_stage_kernel<1, 1>), grid, blk, h->stage_lds, s, BQ);
+            } else {
+                hipLaunchKernelGGL((rnde_binit_stage_kernel<0, 0>), grid, blk, h->stage_lds, s, BQ);
+                hipLaunchKernelGGL((rnde_binit_stage_kernel<0, 1>), grid, blk, h->stage_lds, s, BQ);
+            }
+            if ((st = couple_sum(h, Q.ipart, 4LL * Q.F.nwg, s)) != RNDE_OK) return st;                       // (coupled controller: dot, tau of the reversed second evaluation)
+            if (h->act2) {
+                hipLaunchKernelGGL((rnde_binit_stage_kernel<1, 2>), grid, blk, h->stage_lds, s, BQ);
+                hipLaunchKernelGGL((rnde_binit_stage_kernel<1, 3>), grid, blk, h->stage_lds, s, BQ);
+            } else {
+                hipLaunchKernelGGL((rnde_binit_stage_kernel<0, 2>), grid, blk, h->stage_lds, s, BQ);
+                hipLaunchKernelGGL((rnde_binit_stage_kernel<0, 3>), grid, blk, h->stage_lds, s, BQ);
+            }
+            if ((st = couple_sum(h, Q.ipart + 4LL * Q.F.nwg, 4LL * Q.F.nwg, s)) != RNDE_OK) return st;      // tau of the first
+            hipLaunchKernelGGL(rnde_bfin_kernel, dim3(1), dim3(64), 0, s, Q);
+            HIPCHK(h, hipGetLastError());
+        } else {
+            Q.F.nwg = Q.F.Bpad / h->BT;     // the initialisation kernels below are column-owner kernels
+            n_att = 0;                       // (their attempt loop is skipped)
+        }
     }
-    if (h->NG == 1) e = h->act2 ? launch_bwd_t<1, 1>(h, Q, n_att, s) : launch_bwd_t<1, 0>(h, Q, n_att, s);
-    else e = h->act2 ? launch_bwd_t<2, 1>(h, Q, n_att, s) : launch_bwd_t<2, 0>(h, Q, n_att, s);
-    HIPCHK(h, e);
+    if (!stage_binit_done) {
+        if (h->NG == 1) e = h->act2 ? launch_bwd_t<1, 1>(h, Q, n_att, s) : launch_bwd_t<1, 0>(h, Q, n_att, s);
+        else e = h->act2 ? launch_bwd_t<2, 1>(h, Q, n_att, s) : launch_bwd_t<2, 0>(h, Q, n_att, s);
+        HIPCHK(h, e);
+    }
     n_att = h->n_att;
     if (h->timing) HIPCHK(h, hipEventRecord(h->tev[3], s));
     // remaining evaluations on all CUs (everything that did not go to the side stream, incl. the two initialisation evaluations)

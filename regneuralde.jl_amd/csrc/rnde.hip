@@ -1250,7 +1250,7 @@ static rnde_status bwd_prepare(rnde_node* h) {
     const size_t seg = std::max((size_t)h->H * (h->D + 2), (size_t)h->D * (h->H + 2));
     b.slab_floats = seg * 256;              // per layer; two layers back to back
     HIPCHK(h, hipMalloc((void**)&b.slab, 2 * b.slab_floats * 4));
-    HIPCHK(h, hipMalloc((void**)&b.slab_r, 16 * seg * 4));
+    HIPCHK(h, hipMalloc((void**)&b.slab_r, 2 * 16 * seg * 4));      // second-level partials, one region per layer
     if (!h->wstream) {
         int prio_least = 0, prio_greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
@@ -1572,10 +1572,23 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
         HIPCHK(h, hipEventRecord(ev, h->wstream));
         HIPCHK(h, hipStreamWaitEvent(s, ev, 0));
     }
-    st = launch_wgrad_reduce(h, slab1, cur1, h->H, h->D, p_bar_dev, s);                                    // [W1; b1]
-    if (st != RNDE_OK) return st;
-    st = launch_wgrad_reduce(h, slab2w, cur2, h->D, h->H, p_bar_dev + (size_t)h->H * (h->D + 2), s);      // [W2; b2]
-    if (st != RNDE_OK) return st;
+    if (cur1 > 16 && cur2 > 16) {   // both layers in one launch per pass (same sums in the same order as launch_wgrad_reduce)
+        const long long len1 = (long long)h->H * (h->D + 2), len2 = (long long)h->D * (h->H + 2);
+        const size_t seg_r = std::max((size_t)len1, (size_t)len2);
+        float* r1 = b.slab_r; float* r2 = b.slab_r + 16 * seg_r;
+        const int pg1 = (cur1 + 15) / 16, g1 = (cur1 + pg1 - 1) / pg1, pg2 = (cur2 + 15) / 16, g2 = (cur2 + pg2 - 1) / pg2;
+        const int grid = (int)std::min<long long>((std::max(len1, len2) + 255) / 256, 2048);
+        ReducePair A{{{slab1, r1, len1, cur1, pg1}, {slab2w, r2, len2, cur2, pg2}}};
+        hipLaunchKernelGGL(rnde_wgrad_reduce_pair, dim3(grid, std::max(g1, g2), 2), dim3(256), 0, s, A);
+        ReducePair Bp{{{r1, p_bar_dev, len1, g1, g1}, {r2, p_bar_dev + (size_t)h->H * (h->D + 2), len2, g2, g2}}};
+        hipLaunchKernelGGL(rnde_wgrad_reduce_pair, dim3(grid, 1, 2), dim3(256), 0, s, Bp);
+        HIPCHK(h, hipGetLastError());
+    } else {
+        st = launch_wgrad_reduce(h, slab1, cur1, h->H, h->D, p_bar_dev, s);                                    // [W1; b1]
+        if (st != RNDE_OK) return st;
+        st = launch_wgrad_reduce(h, slab2w, cur2, h->D, h->H, p_bar_dev + (size_t)h->H * (h->D + 2), s);      // [W2; b2]
+        if (st != RNDE_OK) return st;
+    }
     if (h->timing) { HIPCHK(h, hipEventRecord(h->tev[4], s)); h->tev_bwd = true; }
 #ifdef RNDE_DIAG
     if (h->engine == 2 && h->persist == 1 && getenv("RNDE_DIAG_BWD")) {

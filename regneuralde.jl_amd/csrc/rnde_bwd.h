@@ -935,6 +935,29 @@ __global__ void rnde_wgrad_reduce(const float* __restrict__ slab, int n_chunks, 
     }
 }
 
+// the same for the two layers of the stage engine in ONE launch per pass (blockIdx.z = layer): four launches of ~9 us were two too many
+struct ReduceJob { const float* slab; float* out; long long len; int n_chunks, per_group; };
+struct ReducePair { ReduceJob j[2]; };
+__global__ void rnde_wgrad_reduce_pair(const ReducePair R) {
+    const ReduceJob J = R.j[blockIdx.z];
+    const int c0 = blockIdx.y * J.per_group, c1 = min(J.n_chunks, c0 + J.per_group);
+    if (c0 >= c1) return;
+    float* o = J.out + (size_t)blockIdx.y * J.len;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < J.len; i += (long long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        int c = c0;
+        for (; c + 8 <= c1; c += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = __builtin_nontemporal_load(J.slab + (size_t)(c + j) * J.len + i);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+        }
+        for (; c < c1; ++c) s += __builtin_nontemporal_load(J.slab + (size_t)c * J.len + i);
+        o[i] = s;
+    }
+}
+
 }  // namespace rnde
 
 struct rnde_node;

@@ -628,11 +628,11 @@ static rnde_status stage_pack_weights(rnde_node* h, const float* p_dev, hipStrea
     HIPCHK(h, stage_pack(h, p_dev, h->spwD, 1, h->sHT, h->sMT, s));
     return RNDE_OK;
 }
-static rnde_status stage_pack_all(rnde_node* h, const float* p_dev, hipStream_t s) {
+static rnde_status stage_pack_all(rnde_node* h, const float* p_dev, hipStream_t s, const float* x_src = nullptr, long long x_floats = 0) {
     PackJobs J{};
     const int TR = 64 / h->NG;
     int n = 0;
-    auto add = [&](void* dst, long long total, int kind, int which, int kdim) { J.j[n++] = PackJob{dst, total, kind, which, kdim, 0}; };
+    auto add = [&](void* dst, long long total, int kind, int which, int kdim, const float* src = nullptr) { J.j[n++] = PackJob{dst, src, total, kind, which, kdim, 0}; };
     add(h->spwB, (long long)h->sMT * h->sK2b * 64, 0, 0, h->sK2b);
     add(h->spwD, (long long)h->sHT * h->sMT * 64, 0, 1, h->sMT);
     add(h->spwBt, (long long)h->sMT * h->sKHb * 64, 0, 2, h->sKHb);
@@ -641,7 +641,12 @@ static rnde_status stage_pack_all(rnde_node* h, const float* p_dev, hipStream_t 
         add(h->pw2t, (long long)h->MT2t * h->K4_2t * TR, 1, 2, h->K4_2t);
         add(h->pw1t, (long long)h->MT1t * h->K4_1t * TR, 1, 3, h->K4_1t);
     }
-    add(h->pcopy, (long long)h->P, 2, 0, 0);
+    auto add_copy = [&](float* dst, const float* src, long long floats) {     // 16-byte copies where sizes and addresses allow
+        const bool v4 = floats % 4 == 0 && ((uintptr_t)dst % 16 == 0) && ((uintptr_t)(src ? src : p_dev) % 16 == 0);
+        add(dst, v4 ? floats / 4 : floats, v4 ? 3 : 2, 0, 0, src);
+    };
+    add_copy(h->pcopy, nullptr, (long long)h->P);
+    if (x_src) add_copy(h->xcopy, x_src, x_floats);           // the tape's copy of x rides along (was a launch of its own)
     long long most = 0;
     for (int i = 0; i < n; ++i) most = std::max(most, J.j[i].total);
     const int grid = (int)std::min<long long>((most + 255) / 256, 256);
@@ -770,13 +775,16 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
     if (B < 1 || B > h->cfg.max_batch || !(t1 > t0)) { h->err = "bad B or tspan"; return RNDE_ERR_BAD_ARG; }
     HIPCHK(h, hipSetDevice(h->cfg.device));
     h->have_tape = false; h->rev_packed = false;
+    const float* x_caller = nullptr;
     if (keep_tape) {
         rnde_status st = ensure_arena(h, h->cfg.max_attempts);
         if (st != RNDE_OK) return st;
         // the tape owns copies of x and p (the caller may free or overwrite its buffers before backward)
         if (B % h->BT) HIPCHK(h, hipMemsetAsync(h->xcopy, 0, (size_t)h->D * (((B + h->BT - 1) / h->BT) * h->BT) * 4, s));
-        HIPCHK(h, hipMemcpyAsync(h->xcopy, x_dev, (size_t)h->D * B * 4, hipMemcpyDeviceToDevice, s));
-        if (h->engine != 2) HIPCHK(h, hipMemcpyAsync(h->pcopy, p_dev, (size_t)h->P * 4, hipMemcpyDeviceToDevice, s));   // (stage engine: part of the one pack launch below)
+        if (h->engine != 2) {   // (stage engine: both copies are part of the one pack launch below)
+            HIPCHK(h, hipMemcpyAsync(h->xcopy, x_dev, (size_t)h->D * B * 4, hipMemcpyDeviceToDevice, s));
+            HIPCHK(h, hipMemcpyAsync(h->pcopy, p_dev, (size_t)h->P * 4, hipMemcpyDeviceToDevice, s));
+        } else x_caller = x_dev;
         x_dev = h->xcopy;
     }
     StepParams P = make_params(h, x_dev, B, t0, t1, keep_tape ? 1 : 0);
@@ -793,7 +801,7 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
     }
     h->B = B; h->Bpad = P.Bpad; h->nwg = P.nwg; h->t0 = t0; h->t1 = t1;
     rnde_status st = RNDE_OK;
-    if (h->engine == 2 && keep_tape) st = stage_pack_all(h, p_dev, s);   // forward + reverse packs of both engines' layouts and the tape's copy of p: one launch
+    if (h->engine == 2 && keep_tape) st = stage_pack_all(h, p_dev, s, x_caller, (long long)h->D * B);   // forward + reverse packs of both engines' layouts and the tape's copy of p: one launch
     else st = h->engine == 3 ? chain_pack(h, keep_tape ? h->pcopy : p_dev, s)
                              : pack_weights(h, p_dev, keep_tape != 0, s, h->engine != 2);   // (column-owner packs: also used by the reverse sweep)
     if (st != RNDE_OK) return st;

@@ -81,7 +81,7 @@ __global__ void rnde_stage_pack_kernel(const float* __restrict__ p, f32x4* __res
 // Everything a taped solve derives from the parameter vector, in ONE launch (was six pack launches and a copy, ~5 us each, in front
 // of every training step): blockIdx.y selects the job -- a stage-engine pack (kind 0), a column-owner pack for the kernels of the
 // initial-step rule (kind 1), or the tape's own copy of p (kind 2).
-struct PackJob { void* dst; long long total; int kind, which, kdim, pad; };
+struct PackJob { void* dst; const float* src; long long total; int kind, which, kdim, pad; };   // src: kind 2 only (NULL = the parameter vector)
 struct PackJobs { PackJob j[8]; };
 template <int NG>
 __global__ void rnde_pack_all_kernel(const float* __restrict__ p, const PackJobs J, int D, int H) {
@@ -89,7 +89,8 @@ __global__ void rnde_pack_all_kernel(const float* __restrict__ p, const PackJobs
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < job.total; i += (long long)gridDim.x * blockDim.x) {
         if (job.kind == 0) ((f32x4*)job.dst)[i] = stage_pack_elem(p, job.which, D, H, job.kdim, i);
         else if (job.kind == 1) ((f32x4*)job.dst)[i] = pack_elem<NG>(p, job.which, D, H, job.kdim, i);
-        else ((float*)job.dst)[i] = p[i];
+        else if (job.kind == 2) ((float*)job.dst)[i] = (job.src ? job.src : p)[i];
+        else ((f32x4*)job.dst)[i] = ((const f32x4*)(job.src ? job.src : p))[i];      // kind 3: 16-byte copy (total counts float4s)
     }
 }
 

@@ -335,24 +335,24 @@ __global__ __launch_bounds__(kMwThreads) void rnde_bchainmw_kernel(const BMwPara
     const bool has_eig = (eig_c1 != 0.f || eig_c2 != 0.f);
     // ---- B: stage 7 (k7 = f(unew, t + dt)) ----
     {
-        float k7[NR], unv[NR], kb7[NR];
+        float k7[NR], unv7[NR], kb7[NR];
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            k7[r] = R[L.k(7) + fo + 256 * r];
-            unv[r] = R[L.unew() + fo + 256 * r];
+            k7[r] = kq[6][r];                     // (k(7) and unew were read for the error estimate's reverse)
+            unv7[r] = unv[r];
             kb7[r] = dt * (rk_bt<TAB>(Q.rk, 6) * utb[r] + Wv[6][r]);
             S += k7[r] * kb7[r];
             if (accepted && !first) kb7[r] += Bq.K1[fo + 256 * r];
             exk[r] = 0.f; exg[r] = 0.f;
             if (has_eig) {   // reverse of eigen_est = ||k7-k6|| / ||unew-g6|| (direct terms: they do not scale with dt, so not in S)
                 const bool ok = valid(r);
-                const float d1 = ok ? k7[r] - R[L.k(6) + fo + 256 * r] : 0.f, d2 = ok ? unv[r] - R[L.g(6) + fo + 256 * r] : 0.f;
+                const float d1 = ok ? k7[r] - kq[5][r] : 0.f, d2 = ok ? unv7[r] - R[L.g(6) + fo + 256 * r] : 0.f;
                 kb7[r] += eig_c1 * d1; exk[r] = -eig_c1 * d1;
                 unb[r] += eig_c2 * d2; exg[r] = -eig_c2 * d2;
             }
         }
         float t7 = 0.f;
-        fbwd(sl0 + 5 * Q.ev_stride, unv, k7, kb7, gb, t7);
+        fbwd(sl0 + 5 * Q.ev_stride, unv7, k7, kb7, gb, t7);
         tau += t7; ctau += t7;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
@@ -363,13 +363,22 @@ __global__ __launch_bounds__(kMwThreads) void rnde_bchainmw_kernel(const BMwPara
         }
     }
     // ---- C: stages 6..2 ----
+    // (a stage's tape operands are requested one stage ahead: at the top of its own iteration they were a cold round trip in front of every
+    //  fbwd of the rolled loop)
+    float ksn[NR], gsn[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { ksn[r] = kq[5][r]; gsn[r] = R[L.g(6) + fo + 256 * r]; }
 #pragma unroll 1
     for (int s = 5; s >= 1; --s) {   // zero-based: k_s = f(g_s, t + c_s dt), taped as k(s+1), g(s+1)
         float ks[NR], gs[NR], kb[NR];
 #pragma unroll
+        for (int r = 0; r < NR; ++r) { ks[r] = ksn[r]; gs[r] = gsn[r]; }
+        if (s > 1) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) { ksn[r] = R[L.k(s) + fo + 256 * r]; gsn[r] = R[L.g(s) + fo + 256 * r]; }
+        }
+#pragma unroll
         for (int r = 0; r < NR; ++r) {
-            ks[r] = R[L.k(s + 1) + fo + 256 * r];
-            gs[r] = R[L.g(s + 1) + fo + 256 * r];
             kb[r] = Rb[0][r];
             S += ks[r] * kb[r];
             if (has_eig && s == 5) kb[r] += exk[r];          // direct cotangent of k6

@@ -235,6 +235,7 @@ __global__ __launch_bounds__(kSmwThreads) void rnde_sde_solve_mw_kernel(const Sd
     __syncthreads();
 
     // ---- the solve ----
+    int next_draw_known = 1;          // (draw 0 went into the first step's increments above)
     while (true) {
         // loop-top checks (identical in every thread of every workgroup)
         int status = my_status;
@@ -246,6 +247,14 @@ __global__ __launch_bounds__(kSmwThreads) void rnde_sde_solve_mw_kernel(const Sd
             else if (!(dt > dtmin)) { status = 2; stop = true; }
         } else stop = true;
         if (stop) { my_status = status; break; }
+
+        // the pool's next draw -- the one an accept or a rejection's bridge consumes after this attempt's meeting -- is requested now: read at
+        // the point of use it was a cold load at the end of every attempt, on the way to the next one
+        const int pf_draw = next_draw_known < Q.n_pool ? next_draw_known : -1;
+        float pxi[2][NKD];
+#pragma unroll
+        for (int q = 0; q < NKD; ++q) { pxi[0][q] = pf_draw >= 0 ? xi(pf_draw, 0, q) : 0.f; pxi[1][q] = pf_draw >= 0 ? xi(pf_draw, 1, q) : 0.f; }
+        auto xin = [&](int dr, int wz, int q) -> float { return dr == pf_draw ? pxi[wz][q] : xi(dr, wz, q); };
 
         const float sqdt = sqrtf(fabsf(dt));
         float k[4][NKD], g[4][NKD], un[NKD];
@@ -313,6 +322,7 @@ __global__ __launch_bounds__(kSmwThreads) void rnde_sde_solve_mw_kernel(const Sd
         __syncthreads();
         ++seq;
         const SdeDecision d = *DEC;
+        next_draw_known = d.n_draws;
         if (d.status) { my_status = d.status; ++n; break; }
         if (d.accepted) {
             if (Q.keep_tape && tile_ok) {
@@ -355,7 +365,7 @@ __global__ __launch_bounds__(kSmwThreads) void rnde_sde_solve_mw_kernel(const Sd
 #pragma unroll
                     for (int q = 0; q < NKD; ++q) if (tile_ok) {
                         const float lw = pw[q * 256], lz = pz[q * 256];
-                        const float bw = op.f0 * lw + op.f1 * xi(op.draw, 0, q), bz = op.f0 * lz + op.f1 * xi(op.draw, 1, q);
+                        const float bw = op.f0 * lw + op.f1 * xin(op.draw, 0, q), bz = op.f0 * lz + op.f1 * xin(op.draw, 1, q);
                         aw[q] += bw; az[q] += bz;
                         if (op.flags & 1) { pw[q * 256] = lw - bw; pz[q * 256] = lz - bz; }
                         if (op.flags & 2) { nw[q * 256] = bw; nz[q * 256] = bz; }
@@ -363,7 +373,7 @@ __global__ __launch_bounds__(kSmwThreads) void rnde_sde_solve_mw_kernel(const Sd
                 } else if (op.type == OP_FRESH) {
 #pragma unroll
                     for (int q = 0; q < NKD; ++q) if (tile_ok) {
-                        const float fw = op.f0 * xi(op.draw, 0, q), fz = op.f0 * xi(op.draw, 1, q);
+                        const float fw = op.f0 * xin(op.draw, 0, q), fz = op.f0 * xin(op.draw, 1, q);
                         aw[q] += fw; az[q] += fz;
                         pw[q * 256] = fw; pz[q * 256] = fz;
                     }
@@ -391,7 +401,7 @@ __global__ __launch_bounds__(kSmwThreads) void rnde_sde_solve_mw_kernel(const Sd
 #pragma unroll
                     for (int q = 0; q < NKD; ++q) {
                         const float K2 = dW[q] - tw[q], K3 = dZ[q] - tz[q];
-                        const float bw = op.f0 * K2 + op.f1 * xi(op.draw, 0, q), bz = op.f0 * K3 + op.f1 * xi(op.draw, 1, q);
+                        const float bw = op.f0 * K2 + op.f1 * xin(op.draw, 0, q), bz = op.f0 * K3 + op.f1 * xin(op.draw, 1, q);
                         if (tile_ok) {
                             if (op.flags & 1) { pw[q * 256] = K2 - bw; pz[q * 256] = K3 - bz; }
                             cw[q * 256] = bw; cz[q * 256] = bz;

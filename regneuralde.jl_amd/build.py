@@ -32,6 +32,7 @@ def build(force=False, verbose=False):
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-undefined-internal"]
     if os.environ.get("RNDE_WITH_COLUMN_OWNER") == "1":      # the round-1 engine's own step kernels (col_tile 4 / 8): optional, see rnde.hip
         flags.append("-DRNDE_WITH_COLUMN_OWNER")
+    flags += os.environ.get("RNDE_EXTRA_FLAGS", "").split()      # compile-time A/B switches (tools/ab_build.sh)
     hdr_m = max(os.path.getmtime(f) for f in _headers())
 
     def compile_one(src):

@@ -1519,8 +1519,15 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
                 const dim3 pgrid(8 * BQ.R * ((BQ.C + 7) / 8));
                 const bool fix = BQ.WT == 7 && BQ.HT == 7 && BQ.KHb == 7 && BQ.MT == 49 && BQ.R == 7 && h->D == 784 && h->H == 100 && !h->stage_generic;
                 if (fix) {
-                    if (h->act2) hipLaunchKernelGGL((rnde_bstage_attempt_kernel<1, 1>), pgrid, blk, h->stage_lds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
-                    else hipLaunchKernelGGL((rnde_bstage_attempt_kernel<0, 1>), pgrid, blk, h->stage_lds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
+                    // (+ the START-staged tape operands of the six stages, rnde_bstage_persist.h: 6 x 7 waves x 2 arrays x 1 KiB)
+                    const size_t flds = h->stage_lds + (size_t)RNDE_BSTAGE_HDMA * 6 * 7 * 2 * 1024;
+                    static const hipError_t attr = [&] {
+                        hipError_t e = hipFuncSetAttribute((const void*)rnde_bstage_attempt_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                        return e == hipSuccess ? hipFuncSetAttribute((const void*)rnde_bstage_attempt_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) : e;
+                    }();
+                    HIPCHK(h, attr);
+                    if (h->act2) hipLaunchKernelGGL((rnde_bstage_attempt_kernel<1, 1>), pgrid, blk, flds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
+                    else hipLaunchKernelGGL((rnde_bstage_attempt_kernel<0, 1>), pgrid, blk, flds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
                 } else if (h->act2) hipLaunchKernelGGL((rnde_bstage_attempt_kernel<1, 0>), pgrid, blk, h->stage_lds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
                 else hipLaunchKernelGGL((rnde_bstage_attempt_kernel<0, 0>), pgrid, blk, h->stage_lds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
                 if ((st = couple_sum(h, b.bpart + (size_t)(n & 1) * Q.bpart_n * 4, 4LL * Q.bpart_n, s)) != RNDE_OK) return st;

@@ -9,6 +9,9 @@
 // Same arithmetic in the same order as rnde_bstage_kernel (both are compiled with contraction off), so cotangents are
 // bit-identical (tests/test_gpu_forward.py::test_persistent_attempt_is_bit_identical).
 #pragma once
+#ifndef RNDE_BSTAGE_HDMA
+#define RNDE_BSTAGE_HDMA 1
+#endif
 #include "rnde_bstage.h"
 #include "rnde_stage_persist.h"
 
@@ -35,6 +38,12 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
     float* ZL = smem;
     float* GL = ZL + kSCB * KZ;
     float* RED = GL + kSCB * KG;         // [32]; RED[24..31]: per-wave "gave up" flags of the hand-off
+#if RNDE_BSTAGE_HDMA
+    // FIX: the six stages' tape operands (a lane's 16 bytes of h_{j+1} and of k_j) are brought into LDS by START with `global_load_lds`, 1 KiB per
+    // wave, stage and array -- a wave's vector-memory operations return in order, so a stage that requests its own (cold) operands in front of
+    // its poll makes every poll wait for HBM
+    float* HP = RED + 64;                // [6 stages][7 waves][2 arrays][256 floats]
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (FIX) __builtin_assume(w >= 0 && w < 7);
@@ -215,6 +224,16 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
                 if (!first) { uin = ld4(Bq.U + co, r0, gD, true, vec); k1in = ld4(Bq.K1 + co, r0, gD, true, vec); }
                 else if (!sv_mode) uin = ld4(Bq.ubar + co, r0, gD, colok, false);
             }
+#if RNDE_BSTAGE_HDMA
+            if constexpr (FIX) {
+#pragma unroll
+                for (int j = 6; j >= 1; --j) {
+                    float* slot = HP + (size_t)(((6 - j) * 7 + w) * 2) * 256;
+                    if (own_h0 + 3 < gH) dma_unit((const f32x4*)(R + L.h(j + 1) + own_zd0), slot);
+                    dma_unit((const f32x4*)((j >= 2 ? R + L.k(j) : k1p) + co + r0), slot + 256);
+                }
+            }
+#endif
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float ut = dt * acc[i];
@@ -286,7 +305,12 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
         // tape operands of this stage: independent of the hand-off, so request them first
         float h_own[4] = {0.f, 0.f, 0.f, 0.f};
         if constexpr (FIX) {
+#if RNDE_BSTAGE_HDMA
+            if (j == 6) wait_vm<0>();      // START's requests have landed (its own stores too: the poll below would wait for those anyway)
+            { const f32x4 hq = *(const f32x4*)(HP + (size_t)(((6 - j) * 7 + w) * 2) * 256 + 4 * lane); h_own[0] = hq[0]; h_own[1] = hq[1]; h_own[2] = hq[2]; h_own[3] = hq[3]; }
+#else
             if (own_h0 + 3 < gH) { const f32x4 hq = *(const f32x4*)(R + L.h(j + 1) + own_zd0); h_own[0] = hq[0]; h_own[1] = hq[1]; h_own[2] = hq[2]; h_own[3] = hq[3]; }
+#endif
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -294,6 +318,10 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
             }
         }
         f32x4 c_ks = {0.f, 0.f, 0.f, 0.f};
+#if RNDE_BSTAGE_HDMA
+        if constexpr (FIX) c_ks = *(const f32x4*)(HP + (size_t)(((6 - j) * 7 + w) * 2 + 1) * 256 + 4 * lane);
+        else
+#endif
         if (tile_ok) c_ks = (j >= 2) ? ld4(R + L.k(j) + co, r0, gD, true, vec) : ld4(k1p + co, r0, gD, true, vec);
         float S = 0.f, tau = 0.f;
         // ---- phase A: poll this wave's hidden tile of the R row blocks (the polling load is the data load) ----

@@ -1520,7 +1520,7 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
                 const bool fix = BQ.WT == 7 && BQ.HT == 7 && BQ.KHb == 7 && BQ.MT == 49 && BQ.R == 7 && h->D == 784 && h->H == 100 && !h->stage_generic;
                 if (fix) {
                     // (+ the START-staged tape operands of the six stages, rnde_bstage_persist.h: 6 x 7 waves x 2 arrays x 1 KiB)
-                    const size_t flds = h->stage_lds + (size_t)RNDE_BSTAGE_HDMA * 6 * 7 * 2 * 1024;
+                    const size_t flds = h->stage_lds + (size_t)(RNDE_BSTAGE_HDMA ? 1 : 0) * 6 * 7 * 2 * 1024;
                     static const hipError_t attr = [&] {
                         hipError_t e = hipFuncSetAttribute((const void*)rnde_bstage_attempt_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                         return e == hipSuccess ? hipFuncSetAttribute((const void*)rnde_bstage_attempt_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) : e;

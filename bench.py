@@ -32,7 +32,7 @@ ALG_BYTES = lambda B: 34 * 4 * D * B + 6 * 4 * P_DYN   # 34 A + 
 ALG_FLOPS = lambda B: 6 * 2 * B * ((D + 1) * H + (H + 1) * D)
 HBM_PEAK_GBS = 8000.0                              # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 
 def build_model(rn, device, batch, seed=1999):
@@ -46,37 +46,90 @@ def build_model(rn, device, batch, seed=1999):
     return model
 
 
-def cpu_baseline(batch=512, steps=2):
-    """CPU restatement of the same training step (oracle fp32 + numpy head) on a bounded sample."""
+def cpu_baseline(batch=512, steps=2, single_thread_batch=128):
+    """CPU restatement of the same training step (oracle fp32 + numpy head) on a bounded sample: all host threads on the bench's
+    batch, and ONE thread on a quarter of it (SURVEY 8d asks for both).  The oracle's Dense layers are column-blocked
+    (oracle/rnde_oracle.c: a weight row is read once per 8 columns, four reverse dot-product chains side by side), which
+    leaves every sum in its original order."""
+    import ctypes
     import numpy as np
     from oracle.oracle import Oracle, arch_mnist, glorot_params
-    rng = np.random.default_rng(1999)
     arch = arch_mnist(D, H)
-    orc = Oracle(arch, np.float32, reltol=1.4e-8, abstol=1.4e-8, reg_kind=1, max_attempts=400)
-    p = glorot_params(arch, rng)
-    W3 = rng.uniform(-0.0869, 0.0869, (D, NCLS)).astype(np.float32)
-    x = rng.uniform(0, 1, (batch, D)).astype(np.float32)
-    y = np.eye(NCLS, dtype=np.float32)[rng.integers(0, NCLS, batch)]
 
-    def step():
-        r = orc.forward(x, p)
-        logits = r["u"] @ W3
-        z = logits - logits.max(1, keepdims=True)
-        sm = np.exp(z) / np.exp(z).sum(1, keepdims=True)
-        ubar = ((sm - y) / batch) @ W3.T
-        svbar = np.full(len(r["saveval"]), 100.0 / len(r["saveval"]), dtype=np.float32)
-        orc.backward(ubar.astype(np.float32), svbar)
-        return r["nfe"]
+    def leg(nb, nsteps, threads):
+        rng = np.random.default_rng(1999)
+        orc = Oracle(arch, np.float32, reltol=1.4e-8, abstol=1.4e-8, reg_kind=1, max_attempts=400)
+        if threads:
+            orc.lib.orc_set_threads(ctypes.c_int(threads))
+        p = glorot_params(arch, rng)
+        W3 = rng.uniform(-0.0869, 0.0869, (D, NCLS)).astype(np.float32)
+        x = rng.uniform(0, 1, (nb, D)).astype(np.float32)
+        y = np.eye(NCLS, dtype=np.float32)[rng.integers(0, NCLS, nb)]
 
-    step()
+        def step():
+            r = orc.forward(x, p)
+            logits = r["u"] @ W3
+            z = logits - logits.max(1, keepdims=True)
+            sm = np.exp(z) / np.exp(z).sum(1, keepdims=True)
+            ubar = ((sm - y) / nb) @ W3.T
+            svbar = np.full(len(r["saveval"]), 100.0 / len(r["saveval"]), dtype=np.float32)
+            orc.backward(ubar.astype(np.float32), svbar)
+            return r["nfe"]
+
+        if threads != 1:
+            step()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            nfe = step()
+        return nb * nsteps / (time.perf_counter() - t0), int(nfe)
+
+    from oracle.oracle import effective_cores
+    cores = effective_cores()                 # affinity capped by the cgroup CPU quota (the GPU boxes: 256 visible, 16 usable)
+    v1, nfe1 = leg(single_thread_batch, 1, 1)
+    vall, nfe = leg(batch, steps, cores)
+    return {"value": vall, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} training step(s), batch {batch} of the same MNIST-NODE workload (fp32 CPU restatement, "
+                      f"OpenMP over {cores} threads = the CPUs the cgroup grants of {len(os.sched_getaffinity(0))} visible; NOT the Julia reference, which cannot run here)", "nfe": nfe,
+            "single_thread": {"value": v1, "unit": "samples/s", "cores": 1,
+                              "sample": f"1 training step, batch {single_thread_batch} of the same workload, one thread", "nfe": nfe1}}
+
+
+def attempt_roofline_at(B, device, steps=3, warmup=2):
+    """The roofline unit (one attempted Tsit5 step of the taped forward sweep, timed inside training steps with HIP events) at another
+    per-GPU batch: B = 4096 fills the chip eight times over, where the attempt is no latency chain any more."""
+    import torch
+    import regneuralde_jl_amd as rn
+    from regneuralde_jl_amd import _lib
+    L = _lib.lib()
+    model = build_model(rn, device, B)
+    g = torch.Generator().manual_seed(2024)
+    x = torch.rand(B, 1, 28, 28, generator=g).to(device)
+    y = torch.eye(NCLS)[torch.randint(0, NCLS, (B,), generator=g)].to(device)
+    for _ in range(warmup):
+        rn.fused_loss_and_grad(model, x, y, lam=1.0e2, sync=True)
+    h = model.node._acquire(x.reshape(B, -1), True)
+    L.rnde_node_set_timing(h.ptr, 1)
+    fa, rs, atts = [], [], []
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        nfe = step()
-    dt = (time.perf_counter() - t0) / steps
-    cores = len(os.sched_getaffinity(0))
-    return {"value": batch / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} training step(s), batch {batch} of the same MNIST-NODE workload (fp32 CPU restatement, "
-                      f"OpenMP over {cores} threads; NOT the Julia reference, which cannot run here)", "nfe": int(nfe)}
+        rn.fused_loss_and_grad(model, x, y, lam=1.0e2, sync=True)
+        a, b, c = C.c_float(0), C.c_float(0), C.c_float(0)
+        L.rnde_node_timing(h.ptr, C.byref(a), C.byref(b), C.byref(c))
+        fa.append(a.value); rs.append(b.value); atts.append(int(L.rnde_node_last_attempts(h.ptr)))
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    L.rnde_node_set_timing(h.ptr, 0)
+    us_f, us_r = 1e3 * sum(fa) / max(1, sum(atts)), 1e3 * sum(rs) / max(1, sum(atts))
+    t_att = us_f * 1e-6
+    out = {"bound": "hbm", "achieved": ALG_BYTES(B) / t_att / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ALG_BYTES(B) / t_att / 1e9 / HBM_PEAK_GBS,
+           "traffic": None, "batch": B, "us_per_attempt": us_f, "us_per_attempt_rev": us_r, "attempts_per_step": sum(atts) / len(atts),
+           "alg_bytes_per_attempt": ALG_BYTES(B), "mfma_f32_tflops": ALG_FLOPS(B) / t_att / 1e12, "mfma_frac": ALG_FLOPS(B) / t_att / 1e12 / MFMA_F32_PEAK_TF,
+           "samples_per_s_fwd_rev_no_update": B * steps / el,
+           "kernel": "the same taped attempted-step kernel at a per-GPU batch of %d (loss forward + reverse, no optimiser update, fixed weights)" % B}
+    del model
+    torch.cuda.empty_cache()
+    return out
 
 
 def bench_latent(args):
@@ -130,6 +183,18 @@ def bench_latent(args):
     nfes = [step() for _ in range(args.steps)]
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    # the roofline unit: one attempted step as the timed steps run it -- TAPED, inside a solve (HIP events around the attempt launches of
+    # three more steps, rnde_node_set_timing); the untaped forced attempt of the micro-benchmark is reported beside it
+    L.rnde_node_set_timing(hd.ptr, 1)
+    fa, atts = [], []
+    for _ in range(3):
+        step_abi()
+        torch.cuda.synchronize()
+        a, b, c = C.c_float(0), C.c_float(0), C.c_float(0)
+        L.rnde_node_timing(hd.ptr, C.byref(a), C.byref(b), C.byref(c))
+        fa.append(a.value); atts.append(int(L.rnde_node_last_attempts(hd.ptr)))
+    L.rnde_node_set_timing(hd.ptr, 0)
+    us_in_solve = 1e3 * sum(fa) / max(1, sum(atts))
     h = node._acquire(z0.detach(), False)
     us = C.c_float(0)
     _lib.check(h.ptr, L.rnde_bench_attempt(h.ptr, z0.detach().contiguous().data_ptr(), p.detach().data_ptr(), B, 200, C.byref(us), None))
@@ -139,10 +204,11 @@ def bench_latent(args):
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "mean_nfe": sum(nfes) / len(nfes),
             "config": {"workload": "latent ODE gen_dynamics D=20, 8 Dense layers 20<->50 tanh, B=512, 49 saveat points, Tsit5 1.4e-8 (chain engine); step = layer forward (taped) + its reverse, "
                                    + ("through torch.autograd" if args.autograd else "two C-ABI calls (rnde_node_forward_saveat, rnde_node_backward_async)")},
-            "roofline": {"bound": "mfma", "achieved": flops / (us.value * 1e-6) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                         "frac": flops / (us.value * 1e-6) / 1e12 / MFMA_F32_PEAK_TF, "traffic": None,
-                         "kernel": "rnde_chain_kernel: one attempted Tsit5 step = 1 launch; latency bound (32 waves on the chip)",
-                         "us_per_attempt": us.value}}
+            "roofline": {"bound": "mfma", "achieved": flops / (us_in_solve * 1e-6) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": flops / (us_in_solve * 1e-6) / 1e12 / MFMA_F32_PEAK_TF, "traffic": None,
+                         "kernel": "rnde_chainmw_kernel<2,0,0,1> (multi-wave chain engine, weights register stationary): one attempted Tsit5 step = 1 launch, "
+                                   "taped, timed inside the solves of training steps; latency bound (32 workgroups of 4 waves on the chip)",
+                         "us_per_attempt": us_in_solve, "us_per_attempt_forced_untaped": us.value}}
 
 
 def bench_nsde(args):
@@ -354,10 +420,10 @@ def main():
         _lib.check(h.ptr, L.rnde_bench_attempt(h.ptr, xs.data_ptr(), model.p2.data_ptr(), B, 200, C.byref(us_untaped), stream))
         nl = int(L.rnde_node_launches_per_attempt(h.ptr))
         # The roofline unit is timed where the contract asks: INSIDE training steps, HIP events on the launch stream around the forward
-        # sweep (3 steps above) -- average duration per launch of the sweep, early-exit launch included (the figure rocprofv3's per-kernel
-        # average of this command has to agree with).  The back-to-back micro-benchmark is reported beside it: an attempt is ~2 us faster
-        # there, because its prologue finds controller state and starting record warm.
-        us_in_step = 1e3 * sum(fa) / max(1, sum(a + 1 for a in atts)) * nl
+        # sweep (3 steps above), divided by the number of attempted steps (= us_per_attempt_fwd; rocprofv3's per-kernel average of this
+        # command is a little lower because it averages the ~4.5 us early-exit launches in).  The back-to-back micro-benchmark is reported
+        # beside it: an attempt is ~2 us faster there, because its prologue finds controller state and starting record warm.
+        us_in_step = 1e3 * sum(fa) / max(1, sum(atts))      # sweep time / REAL attempts (the ~4.5 us early-exit launch behind a solve is charged to them)
         t_att = us_in_step * 1e-6
         roof = {"bound": "hbm", "achieved": ALG_BYTES(B) / t_att / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ALG_BYTES(B) / t_att / 1e9 / HBM_PEAK_GBS, "traffic": None,
@@ -382,7 +448,9 @@ def main():
                 for row in csv.reader(l for l in open(pf) if not l.startswith("#")):
                     if row and want in row[0]:
                         roof["traffic"] = float(row[4]) * (7 if (stage_engine and nl == 7) else 1)
-                        roof["traffic_source"] = f"profiles/{rnd}_pmc_hbm_traffic.csv (separate --pmc passes; bytes per attempted step)"
+                        stamp = [l[1:].strip() for l in open(pf) if l.startswith("# collected")]
+                        roof["traffic_source"] = (f"profiles/{rnd}_pmc_hbm_traffic.csv (separate --pmc passes of this command, NOT this run; bytes per attempted step"
+                                                  + (f"; {stamp[0]}" if stamp else "") + ")")
                         break
                 if roof["traffic"] is not None:
                     break
@@ -411,6 +479,11 @@ def main():
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+        if world == 1 and not args.no_extras and not use_dist and B == 512:
+            try:
+                out["roofline_B4096"] = attempt_roofline_at(4096, device)
+            except Exception as e:
+                out["roofline_B4096"] = {"error": repr(e)}
         if world == 1 and not args.no_extras and not use_dist:
             sub = argparse.Namespace(steps=max(3, args.steps // 2), warmup=2, autograd=args.autograd)
             others = {}

@@ -23,6 +23,41 @@ def build(force=False):
     return libs
 
 
+def effective_cores():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup's CPU quota.  The GPU boxes show 256 hardware threads
+    under a quota of 16 CPUs; OpenMP's default (one thread per visible CPU) then oversubscribes 16x and a barrier-heavy loop nest runs
+    ~300x slower than on 16 threads (gpurun_out/r03/cpu_threads.log: 2.0 against 721 samples/s)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        if os.path.exists("/sys/fs/cgroup/cpu.max"):                     # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+            if q != "max":
+                n = min(n, max(1, int(int(q) / int(per))))
+        elif os.path.exists("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):      # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+    except Exception:
+        pass
+    return n
+
+
+_threads_set = set()
+
+
+def _cap_threads(lib, path):
+    """Once per loaded library: OpenMP threads = effective_cores() unless OMP_NUM_THREADS says otherwise."""
+    if path in _threads_set:
+        return
+    _threads_set.add(path)
+    if "OMP_NUM_THREADS" not in os.environ:
+        try:
+            lib.orc_set_threads(C.c_int(effective_cores()))
+        except AttributeError:
+            pass
+
+
 class Arch(C.Structure):
     _fields_ = [("n_layers", C.c_int), ("dims", C.c_int * (MAX_LAYERS + 1)), ("act", C.c_int * MAX_LAYERS),
                 ("time_dep", C.c_int), ("pre_act", C.c_int)]
@@ -58,12 +93,18 @@ def arch_latent():
 
 class Oracle:
     def __init__(self, arch, dtype=np.float32, reltol=1.4e-8, abstol=1.4e-8, reg_kind=1, cb_save_start=1,
-                 track_ctrl=1, track_initdt=1, max_attempts=4096, solver="Tsit5"):
+                 track_ctrl=1, track_initdt=1, max_attempts=4096, solver="Tsit5", sum_order=0):
+        """sum_order (fp32 only; rnde_oracle.c `orc_set_sum_order`): 0 = sequential-k dot products and libm tanh (a textbook CPU);
+        bit 0 = the two-layer TDChain's GEMMs accumulated in the device stage engine's order (split-K row blocks, two interleaved
+        accumulators of K = 4 FMA chains); bit 1 = tanh by the device's formula.  3 = "what the device computes", to rounding of
+        v_exp_f32 / v_rcp_f32.  The mode is process-wide in the C library; this wrapper sets it before every call it makes."""
         libs = build()
         self.dtype = np.dtype(dtype)
         f64 = self.dtype == np.float64
         self.lib = C.CDLL(libs[1] if f64 else libs[0])
+        _cap_threads(self.lib, libs[1] if f64 else libs[0])
         self.real = C.c_double if f64 else C.c_float
+        self.sum_order = int(sum_order)
 
         class Config(C.Structure):
             _fields_ = [("arch", Arch), ("reltol", self.real), ("abstol", self.real), ("reg_kind", C.c_int),
@@ -100,12 +141,14 @@ class Oracle:
 
     # x: (B, D) row-major numpy == D x B column-major Julia
     def f_eval(self, p, u, t):
+        self.lib.orc_set_sum_order(C.c_int(self.sum_order))
         u = self._arr(u); p = self._arr(p)
         out = np.empty_like(u)
         self.lib.orc_f_eval(C.byref(self.arch), self._p(p), self._p(u), C.c_int(u.shape[0]), self.real(t), self._p(out))
         return out
 
     def initdt(self, p, u0, t0, t1):
+        self.lib.orc_set_sum_order(C.c_int(self.sum_order))
         u0 = self._arr(u0); p = self._arr(p)
         f0 = np.empty_like(u0)
         dt = self.lib.orc_initdt(C.byref(self.cfg), self._p(p), self._p(u0), C.c_int(u0.shape[0]), self.real(t0),
@@ -113,6 +156,7 @@ class Oracle:
         return float(dt), f0
 
     def attempt(self, p, uprev, k1, t, dt, want_eigen=False):
+        self.lib.orc_set_sum_order(C.c_int(self.sum_order))
         uprev = self._arr(uprev); k1 = self._arr(k1); p = self._arr(p)
         B = uprev.shape[0]
         kout = np.empty((6, B, self.D), dtype=self.dtype)
@@ -125,6 +169,7 @@ class Oracle:
         return kout, unew, float(eest.value), float(eig.value)
 
     def forward(self, x, p, t0=0.0, t1=1.0, saveat=None):
+        self.lib.orc_set_sum_order(C.c_int(self.sum_order))
         x = self._arr(x); p = self._arr(p)
         B = x.shape[0]
         ns = 0 if saveat is None else len(saveat)

@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-from .oracle import Arch, build, make_arch
+from .oracle import Arch, _cap_threads, build, make_arch
 
 
 def arch_nsde_drift(D=32, H=64):
@@ -46,6 +46,7 @@ class SdeOracle:
         self.dtype = np.dtype(dtype)
         f64 = self.dtype == np.float64
         self.lib = C.CDLL(libs[1] if f64 else libs[0])
+        _cap_threads(self.lib, libs[1] if f64 else libs[0])
         self.real = C.c_double if f64 else C.c_float
 
         class Config(C.Structure):

@@ -136,25 +136,204 @@ int orc_act_rows_total(const orc_arch* a) { /* rows of stored activations per f 
     return n;
 }
 
+/* ---- summation-order modes (round 3; tests/test_gpu_replay.py) --------------------------------------------
+ * At the reference's tolerance the fp32 error estimate is rounding noise, so HOW the two Dense layers are summed and how tanh
+ * is rounded decide EEst, hence dt and NFE.  The default path accumulates a dot product as one sequential chain over k (what a
+ * textbook CPU sgemm does).  Mode bits, process-wide (this library is test infrastructure; set before a forward):
+ *   bit 0 (1): accumulate the two-layer TDChain of experiments/mnist_node.jl:41-54 in the ORDER of the device's stage engine
+ *              (regneuralde.jl_amd/csrc/rnde_stage_persist.h phase B / phase D): layer 1 as R row-block partials of WT 16-wide
+ *              k-blocks, each partial = two interleaved accumulators of K = 4 matrix instructions (acc0: k-steps 0, 2 of a
+ *              block, acc1: k-steps 1, 3), partials added in order r = 0..R-1, then fma(w1t, t, z) + b1; layer 2 as the same
+ *              two accumulators over the k-blocks of [h; t; 1] (time and bias are K columns H and H + 1).
+ *              One K = 4 instruction = mfma_k4() below, the model tools/mfma_model.py fitted to tools/micro/mfma_numerics.hip.
+ *   bit 1 (2): tanh by the device's formula (rnde_device.h tanh_fast: odd polynomial below 0.55, 1 - 2/(exp2(2 log2(e)|x|)+1)
+ *              above), with correctly rounded exp2f / reciprocal where the device has v_exp_f32 / v_rcp_f32 + one Newton step.
+ * Other shapes than the two-layer time-dependent chain ignore bit 0. */
+static int g_sum_order = 0;
+void orc_set_sum_order(int mode) { g_sum_order = mode; }
+int orc_get_sum_order(void) { return g_sum_order; }
+void orc_set_threads(int n) {
+#ifdef _OPENMP
+    extern void omp_set_num_threads(int);
+    if (n > 0) omp_set_num_threads(n);
+#endif
+}
+
+#ifndef RNDE_F64
+static inline float tanh_dev(float x) {
+    const float ax = fabsf(x), x2 = x * x;
+    float p = -0.00671552f;
+    p = fmaf(p, x2, 0.02136713f);
+    p = fmaf(p, x2, -0.05391917f);
+    p = fmaf(p, x2, 0.13333165f);
+    p = fmaf(p, x2, -0.33333332f);
+    const float small = fmaf(x, x2 * p, x);
+    const float L = 2.8853900817779268f;
+    const float Llo = (float)(2.8853900817779268 - (double)2.8853900817779268f);
+    const float yh = ax * L;
+    const float yl = fmaf(ax, L, -yh) + ax * Llo;
+    float e = (float)exp2((double)yh);
+    e = fmaf(e, yl * 0.6931471805599453f, e);
+    const float dd = e + 1.0f;
+    float r = (float)(1.0 / (double)dd);
+    r = fmaf(fmaf(-dd, r, 1.0f), r, r);
+    float big = fmaf(-2.0f, r, 1.0f);
+    big = ax > 9.1f ? 1.0f : big;
+    return ax < 0.55f ? small : copysignf(big, x);
+}
+#define rtanh_m(x) ((g_sum_order & 2) ? tanh_dev(x) : rtanh(x))
+#define rfma fmaf
+void orc_tanh_dev(const float* x, float* y, int n) { for (int i = 0; i < n; ++i) y[i] = tanh_dev(x[i]); }
+#else
+#define rtanh_m(x) rtanh(x)
+#define rfma fma
+#endif
+
+/* one K = 4 fp32 matrix instruction on n independent outputs: acc[r] += sum_{kk<4} w[kk][r] * x[kk]
+ * (v_mfma_f32_16x16x4_f32; model fitted by tools/mfma_model.py: see MFMA_MODEL below). */
+#ifndef MFMA_MODEL
+#define MFMA_MODEL 0
+#endif
+static inline void mfma_k4(real* acc, const real* const w[4], const real x[4], int n) {
+#if MFMA_MODEL == 0      /* four fused multiply-adds in order kk = 0..3 */
+    for (int kk = 0; kk < 4; ++kk) {
+        if (!w[kk]) continue;      /* k past the end of the layer: the device multiplies packed zeros (acc unchanged) */
+        const real* wk = w[kk];
+        const real xk = x[kk];
+        for (int r = 0; r < n; ++r) acc[r] = rfma(wk[r], xk, acc[r]);
+    }
+#else                    /* exact sum of the four products and the accumulator, rounded once */
+    for (int r = 0; r < n; ++r) {
+        long double s = (long double)acc[r];
+        for (int kk = 0; kk < 4; ++kk) if (w[kk]) s += (long double)w[kk][r] * (long double)x[kk];
+        acc[r] = (real)s;
+    }
+#endif
+}
+
+/* stage-engine geometry of the device (rnde.hip: waves per row block chosen to minimise tile padding, more waves preferred) */
+static void stage_geometry(int D, int* WT, int* R) {
+    int MT = (D + 15) / 16, best = 1, bw = 1 << 30;
+    int lo = MT < 4 ? MT : 4;
+    if (lo < 1) lo = 1;
+    for (int wt = (MT < 8 ? MT : 8); wt >= lo; --wt) {
+        int r = (MT + wt - 1) / wt, waste = r * wt - MT;
+        if (waste < bw) { bw = waste; best = wt; }
+    }
+    *WT = best;
+    *R = (MT + best - 1) / best;
+}
+
+/* one column of the two-layer TDChain in the device's order.  x[D], out h[H] (after tanh) and y[D]. */
+static void f_col_stage_order(const orc_arch* a, const real* p, const real* x, real t, real* h, real* y, real* acc0, real* acc1) {
+    const int D = a->dims[0], H = a->dims[1];
+    const real* W1 = p;
+    const real* W1t = W1 + (size_t)D * H;
+    const real* b1 = W1t + H;
+    const real* W2 = b1 + H;
+    const real* W2t = W2 + (size_t)H * D;
+    const real* b2 = W2t + D;
+    int WT, R;
+    stage_geometry(D, &WT, &R);
+    const int MT = (D + 15) / 16;
+    /* layer 1 */
+    for (int m = 0; m < H; ++m) h[m] = 0;
+    for (int rb = 0; rb < R; ++rb) {
+        for (int m = 0; m < H; ++m) acc0[m] = acc1[m] = 0;
+        for (int kb = 0; kb < WT; ++kb) {
+            const int tile = rb * WT + kb;
+            if (tile >= MT) break;
+            for (int q = 0; q < 4; ++q) {
+                const real* w[4];
+                real xv[4];
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int k = 16 * tile + 4 * q + kk;
+                    w[kk] = k < D ? W1 + (size_t)k * H : NULL;
+                    xv[kk] = k < D ? x[k] : 0;
+                }
+                mfma_k4((q & 1) ? acc1 : acc0, w, xv, H);
+            }
+        }
+        for (int m = 0; m < H; ++m) h[m] += acc0[m] + acc1[m];
+    }
+    for (int m = 0; m < H; ++m) {
+        real pre = rfma(W1t[m], t, h[m]) + b1[m];
+        h[m] = a->act[0] == 1 ? rtanh_m(pre) : pre;
+    }
+    /* layer 2: K columns 0..H-1 hidden units, H the time column, H + 1 the bias */
+    for (int r = 0; r < D; ++r) acc0[r] = acc1[r] = 0;
+    const int K2b = (H + 2 + 15) / 16;
+    for (int kb = 0; kb < K2b; ++kb) {
+        for (int q = 0; q < 4; ++q) {
+            const real* w[4];
+            real xv[4];
+            int any = 0;
+            for (int kk = 0; kk < 4; ++kk) {
+                const int k = 16 * kb + 4 * q + kk;
+                if (k < H) { w[kk] = W2 + (size_t)k * D; xv[kk] = h[k]; any = 1; }
+                else if (k == H) { w[kk] = W2t; xv[kk] = t; any = 1; }
+                else if (k == H + 1) { w[kk] = b2; xv[kk] = 1; any = 1; }
+                else { w[kk] = NULL; xv[kk] = 0; }
+            }
+            if (any) mfma_k4((q & 1) ? acc1 : acc0, w, xv, D);
+        }
+    }
+    for (int r = 0; r < D; ++r) {
+        real v = acc0[r] + acc1[r];
+        y[r] = a->act[1] == 1 ? rtanh_m(v) : v;
+    }
+}
+
 /* forward f. acts (optional) receives [pre_act output (if any); y_1; ...; y_L], each (rows x B) col-major
- * stacked as separate blocks: block offset = rows_before * B. out = y_L. */
+ * stacked as separate blocks: block offset = rows_before * B. out = y_L.
+ * Default path: ORC_CB columns at a time so that a weight row is read once per block (the per-element association order is
+ * unchanged: 0 + sum_i W[:,i] x_i in ascending i, then the time column, then the bias -- results are bit-identical to a
+ * column-at-a-time loop). */
+#define ORC_CB 8
+#define ORC_RB 128
 void orc_f_forward(const orc_arch* a, const real* p, const real* u, int B, real t, real* out, real* acts) {
     int maxd = 0;
     for (int l = 0; l <= a->n_layers; ++l)
         if (a->dims[l] > maxd) maxd = a->dims[l];
+    if ((g_sum_order & 1) && a->n_layers == 2 && a->time_dep && !a->pre_act) {
+        const int D = a->dims[0], H = a->dims[1];
+#pragma omp parallel
+        {
+            real* hh = (real*)malloc(sizeof(real) * (size_t)(H + 2 * maxd));
+            real* a0 = hh + H;
+            real* a1 = a0 + maxd;
+#pragma omp for schedule(static)
+            for (int c = 0; c < B; ++c) {
+                real* y = out + (size_t)c * D;
+                f_col_stage_order(a, p, u + (size_t)c * D, t, hh, y, a0, a1);
+                if (acts) {
+                    memcpy(acts + (size_t)c * H, hh, sizeof(real) * H);
+                    memcpy(acts + (size_t)H * B + (size_t)c * D, y, sizeof(real) * D);
+                }
+            }
+            free(hh);
+        }
+        return;
+    }
+    const int FCB = B >= 128 ? 16 : 8;      /* columns per block: wider blocks reuse a weight row more, narrower ones keep small batches parallel */
+    const int nblk = (B + FCB - 1) / FCB;
 #pragma omp parallel
     {
-        real* xa = (real*)malloc(sizeof(real) * maxd);
-        real* xb = (real*)malloc(sizeof(real) * maxd);
+        real* xa = (real*)malloc(sizeof(real) * (size_t)maxd * FCB);
+        real* xb = (real*)malloc(sizeof(real) * (size_t)maxd * FCB);
 #pragma omp for schedule(static)
-        for (int c = 0; c < B; ++c) {
-            const real* x = u + (size_t)c * a->dims[0];
+        for (int blk = 0; blk < nblk; ++blk) {
+            const int c0 = blk * FCB, nc = (B - c0 < FCB) ? B - c0 : FCB;
+            const real* x = u + (size_t)c0 * a->dims[0];     /* nc columns, stride xs */
+            size_t xs = a->dims[0];
             int off_rows = 0;
             if (a->pre_act) {
-                for (int i = 0; i < a->dims[0]; ++i) xa[i] = rtanh(x[i]);
-                if (acts) memcpy(acts + (size_t)off_rows * B + (size_t)c * a->dims[0], xa, sizeof(real) * a->dims[0]);
+                for (int c = 0; c < nc; ++c) {
+                    for (int i = 0; i < a->dims[0]; ++i) xa[(size_t)c * maxd + i] = rtanh_m(x[(size_t)c * xs + i]);
+                    if (acts) memcpy(acts + (size_t)off_rows * B + (size_t)(c0 + c) * a->dims[0], xa + (size_t)c * maxd, sizeof(real) * a->dims[0]);
+                }
                 off_rows += a->dims[0];
-                x = xa;
+                x = xa; xs = maxd;
             }
             const real* pl = p;
             real* cur = xb;
@@ -162,28 +341,40 @@ void orc_f_forward(const orc_arch* a, const real* p, const real* u, int B, real 
                 int in = a->dims[l], o = a->dims[l + 1], ine = in + (a->time_dep ? 1 : 0);
                 const real* W = pl;
                 const real* b = pl + (size_t)ine * o;
-                /* k-ordered chain: 0 + sum_i W[:,i] x_i (+ W[:,in] t) + b  -- same association order as the
-                 * f32 MFMA chain of the HIP kernel (bias and time folded in as trailing K columns). */
-                for (int r = 0; r < o; ++r) cur[r] = 0;
-                for (int i = 0; i < in; ++i) {
-                    real xi = x[i];
-                    const real* Wi = W + (size_t)i * o;
-                    for (int r = 0; r < o; ++r) cur[r] += Wi[r] * xi;
+                for (int r0 = 0; r0 < o; r0 += ORC_RB) {
+                    const int nr = (o - r0 < ORC_RB) ? o - r0 : ORC_RB;
+                    {
+                        for (int c = 0; c < nc; ++c)
+                            for (int r = 0; r < nr; ++r) cur[(size_t)c * maxd + r0 + r] = 0;
+                        for (int i = 0; i < in; ++i) {
+                            const real* Wi = W + (size_t)i * o + r0;
+                            for (int c = 0; c < nc; ++c) {
+                                const real xi = x[(size_t)c * xs + i];
+                                real* cc = cur + (size_t)c * maxd + r0;
+                                for (int r = 0; r < nr; ++r) cc[r] += Wi[r] * xi;
+                            }
+                        }
+                    }
+                    for (int c = 0; c < nc; ++c) {
+                        real* cc = cur + (size_t)c * maxd + r0;
+                        if (a->time_dep) {
+                            const real* Wt = W + (size_t)in * o + r0;
+                            for (int r = 0; r < nr; ++r) cc[r] += Wt[r] * t;
+                        }
+                        for (int r = 0; r < nr; ++r) cc[r] += b[r0 + r];
+                        if (a->act[l] == 1)
+                            for (int r = 0; r < nr; ++r) cc[r] = rtanh_m(cc[r]);
+                    }
                 }
-                if (a->time_dep) {
-                    const real* Wt = W + (size_t)in * o;
-                    for (int r = 0; r < o; ++r) cur[r] += Wt[r] * t;
-                }
-                for (int r = 0; r < o; ++r) cur[r] += b[r];
-                if (a->act[l] == 1)
-                    for (int r = 0; r < o; ++r) cur[r] = rtanh(cur[r]);
-                if (acts) memcpy(acts + (size_t)off_rows * B + (size_t)c * o, cur, sizeof(real) * o);
+                if (acts)
+                    for (int c = 0; c < nc; ++c) memcpy(acts + (size_t)off_rows * B + (size_t)(c0 + c) * o, cur + (size_t)c * maxd, sizeof(real) * o);
                 off_rows += o;
                 pl += (size_t)ine * o + o;
-                x = cur;
+                x = cur; xs = maxd;
                 cur = (cur == xb) ? xa : xb;
             }
-            memcpy(out + (size_t)c * a->dims[a->n_layers], x, sizeof(real) * a->dims[a->n_layers]);
+            for (int c = 0; c < nc; ++c)
+                memcpy(out + (size_t)(c0 + c) * a->dims[a->n_layers], x + (size_t)c * xs, sizeof(real) * a->dims[a->n_layers]);
         }
         free(xa);
         free(xb);
@@ -214,55 +405,97 @@ real orc_f_backward(const orc_arch* a, const real* p, const real* u, const real*
             ro += a->dims[l + 1];
         }
     }
-    /* zbar per layer for all columns: compute column by column, keep zbar_l (o x B) for the weight gradient */
+    /* zbar per layer for all columns, kept (o x B) for the weight gradient.  ORC_CB columns at a time with zbar transposed to
+     * [r][c], so that the dot products over r run as ORC_CB independent chains side by side (vector over c): every sum keeps
+     * its ascending-r order, results are bit-identical to a column-at-a-time loop. */
     real* zb_all[ORC_MAX_LAYERS];
     for (int l = 0; l < L; ++l) zb_all[l] = (real*)malloc(sizeof(real) * (size_t)a->dims[l + 1] * B);
     double tbar_acc = 0;
+    const int nblk = (B + ORC_CB - 1) / ORC_CB;
+    double* tcol = (double*)calloc((size_t)B, sizeof(double));     /* per-column time cotangent, summed in column order below */
 #pragma omp parallel
     {
-        real* ga = (real*)malloc(sizeof(real) * maxd);
-        real* gb = (real*)malloc(sizeof(real) * maxd);
-        double tloc = 0;
+        real* ga = (real*)malloc(sizeof(real) * (size_t)maxd * ORC_CB);
+        real* gb = (real*)malloc(sizeof(real) * (size_t)maxd * ORC_CB);
+        real* zt = (real*)malloc(sizeof(real) * (size_t)maxd * ORC_CB);
 #pragma omp for schedule(static)
-        for (int c = 0; c < B; ++c) {
-            const real* g = kbar + (size_t)c * a->dims[L];
+        for (int blk = 0; blk < nblk; ++blk) {
+            const int c0 = blk * ORC_CB, nc = (B - c0 < ORC_CB) ? B - c0 : ORC_CB;
+            const real* g = kbar + (size_t)c0 * a->dims[L];
+            size_t gs = a->dims[L];
             real* nxt = ga;
             for (int l = L - 1; l >= 0; --l) {
-                int in = a->dims[l], o = a->dims[l + 1], ine = in + (a->time_dep ? 1 : 0);
+                int in = a->dims[l], o = a->dims[l + 1];
                 const real* W = p + poff[l];
-                const real* y = acts + (size_t)aoff[l + 1] * B + (size_t)c * o;
-                real* zb = zb_all[l] + (size_t)c * o;
-                for (int r = 0; r < o; ++r) zb[r] = a->act[l] == 1 ? g[r] * (1 - y[r] * y[r]) : g[r];
-                for (int i = 0; i < in; ++i) {
+                for (int c = 0; c < ORC_CB; ++c) {
+                    if (c < nc) {
+                        const real* y = acts + (size_t)aoff[l + 1] * B + (size_t)(c0 + c) * o;
+                        real* zb = zb_all[l] + (size_t)(c0 + c) * o;
+                        const real* gc = g + (size_t)c * gs;
+                        for (int r = 0; r < o; ++r) { zb[r] = a->act[l] == 1 ? gc[r] * (1 - y[r] * y[r]) : gc[r]; zt[(size_t)r * ORC_CB + c] = zb[r]; }
+                    } else {
+                        for (int r = 0; r < o; ++r) zt[(size_t)r * ORC_CB + c] = 0;
+                    }
+                }
+                int i = 0;
+                for (; i + 4 <= in; i += 4) {      /* four input rows at a time: four independent chains per column keep the FMA pipes busy */
                     const real* Wi = W + (size_t)i * o;
-                    real s = 0;
-                    for (int r = 0; r < o; ++r) s += Wi[r] * zb[r];
-                    nxt[i] = s;
+                    real s0[ORC_CB], s1[ORC_CB], s2[ORC_CB], s3[ORC_CB];
+                    for (int c = 0; c < ORC_CB; ++c) s0[c] = s1[c] = s2[c] = s3[c] = 0;
+                    for (int r = 0; r < o; ++r) {
+                        const real w0 = Wi[r], w1 = Wi[o + r], w2 = Wi[2 * (size_t)o + r], w3 = Wi[3 * (size_t)o + r];
+                        const real* z = zt + (size_t)r * ORC_CB;
+                        for (int c = 0; c < ORC_CB; ++c) { s0[c] += w0 * z[c]; s1[c] += w1 * z[c]; s2[c] += w2 * z[c]; s3[c] += w3 * z[c]; }
+                    }
+                    for (int c = 0; c < nc; ++c) {
+                        real* d = nxt + (size_t)c * maxd + i;
+                        d[0] = s0[c]; d[1] = s1[c]; d[2] = s2[c]; d[3] = s3[c];
+                    }
+                }
+                for (; i < in; ++i) {
+                    const real* Wi = W + (size_t)i * o;
+                    real sacc[ORC_CB];
+                    for (int c = 0; c < ORC_CB; ++c) sacc[c] = 0;
+                    for (int r = 0; r < o; ++r) {
+                        const real w = Wi[r];
+                        const real* z = zt + (size_t)r * ORC_CB;
+                        for (int c = 0; c < ORC_CB; ++c) sacc[c] += w * z[c];
+                    }
+                    for (int c = 0; c < nc; ++c) nxt[(size_t)c * maxd + i] = sacc[c];
                 }
                 if (a->time_dep) {
                     const real* Wt = W + (size_t)in * o;
-                    real s = 0;
-                    for (int r = 0; r < o; ++r) s += Wt[r] * zb[r];
-                    tloc += (double)s;
+                    real sacc[ORC_CB];
+                    for (int c = 0; c < ORC_CB; ++c) sacc[c] = 0;
+                    for (int r = 0; r < o; ++r) {
+                        const real w = Wt[r];
+                        const real* z = zt + (size_t)r * ORC_CB;
+                        for (int c = 0; c < ORC_CB; ++c) sacc[c] += w * z[c];
+                    }
+                    for (int c = 0; c < nc; ++c) tcol[c0 + c] += (double)sacc[c];
                 }
-                (void)ine;
-                g = nxt;
+                g = nxt; gs = maxd;
                 nxt = (nxt == ga) ? gb : ga;
             }
-            real* uo = ubar_out + (size_t)c * a->dims[0];
-            if (a->pre_act) {
-                const real* x0 = acts + (size_t)c * a->dims[0];
-                for (int i = 0; i < a->dims[0]; ++i) uo[i] = g[i] * (1 - x0[i] * x0[i]);
-            } else {
-                for (int i = 0; i < a->dims[0]; ++i) uo[i] = g[i];
+            for (int c = 0; c < nc; ++c) {
+                real* uo = ubar_out + (size_t)(c0 + c) * a->dims[0];
+                const real* gc = g + (size_t)c * gs;
+                if (a->pre_act) {
+                    const real* x0 = acts + (size_t)(c0 + c) * a->dims[0];
+                    for (int i = 0; i < a->dims[0]; ++i) uo[i] = gc[i] * (1 - x0[i] * x0[i]);
+                } else {
+                    for (int i = 0; i < a->dims[0]; ++i) uo[i] = gc[i];
+                }
             }
         }
-#pragma omp atomic
-        tbar_acc += tloc;
         free(ga);
         free(gb);
+        free(zt);
     }
-    /* weight gradients: Wbar[:,i] += sum_c zbar[:,c] * x_l[i,c] ; bbar += rowsum(zbar) */
+    for (int c = 0; c < B; ++c) tbar_acc += tcol[c];      /* (fixed order: independent of the thread count) */
+    free(tcol);
+    /* weight gradients: Wbar[:,i] += sum_c zbar[:,c] * x_l[i,c] ; bbar += rowsum(zbar).  Eight input rows at a time share a pass
+     * over zbar (every element still sums over c in ascending order). */
     for (int l = 0; l < L; ++l) {
         int in = a->dims[l], o = a->dims[l + 1], ine = in + (a->time_dep ? 1 : 0);
         real* Wb = pbar + poff[l];
@@ -273,22 +506,28 @@ real orc_f_backward(const orc_arch* a, const real* p, const real* u, const real*
             xin = a->pre_act ? acts : u;
         else
             xin = acts + (size_t)aoff[l] * B;
+        const int IB = 8, nib = (in + IB - 1) / IB;
 #pragma omp parallel for schedule(static)
-        for (int i = 0; i < ine + 1; ++i) {
-            if (i < in) {
-                real* Wbi = Wb + (size_t)i * o;
-                for (int c = 0; c < B; ++c) {
-                    real xi = xin[(size_t)c * in + i];
-                    const real* z = zb + (size_t)c * o;
-                    for (int r = 0; r < o; ++r) Wbi[r] += z[r] * xi;
-                }
-            } else if (i == in && a->time_dep) {
-                real* Wbi = Wb + (size_t)in * o;
+        for (int ib = 0; ib < nib + 1; ++ib) {
+            if (ib < nib) {
+                const int i0 = ib * IB, ni = (in - i0 < IB) ? in - i0 : IB;
                 for (int c = 0; c < B; ++c) {
                     const real* z = zb + (size_t)c * o;
-                    for (int r = 0; r < o; ++r) Wbi[r] += z[r] * t;
+                    const real* xc = xin + (size_t)c * in + i0;
+                    for (int ii = 0; ii < ni; ++ii) {
+                        const real xi = xc[ii];
+                        real* Wbi = Wb + (size_t)(i0 + ii) * o;
+                        for (int r = 0; r < o; ++r) Wbi[r] += z[r] * xi;
+                    }
                 }
-            } else if (i == ine) {
+            } else {
+                if (a->time_dep) {
+                    real* Wbi = Wb + (size_t)in * o;
+                    for (int c = 0; c < B; ++c) {
+                        const real* z = zb + (size_t)c * o;
+                        for (int r = 0; r < o; ++r) Wbi[r] += z[r] * t;
+                    }
+                }
                 for (int c = 0; c < B; ++c) {
                     const real* z = zb + (size_t)c * o;
                     for (int r = 0; r < o; ++r) bb[r] += z[r];
@@ -425,16 +664,23 @@ static void attempt_stages(const orc_config* cfg, const real* p, const real* upr
     real bt[7];
     for (int j = 0; j < 7; ++j) bt[j] = (real)tabBT(cfg->solver)[j];
     double ssum = 0;
-#pragma omp parallel for schedule(static) reduction(+ : ssum)
-    for (size_t i = 0; i < N; ++i) {
-        real acc = 0;
-        for (int j = 0; j < 7; ++j) acc += bt[j] * k[j][i];
-        real ut = dt * acc;
-        real au = rfabs(uprev[i]), an = rfabs(unew[i]);
-        real sk = cfg->abstol + (au > an ? au : an) * cfg->reltol;
-        real r = ut / sk;
-        ssum += (double)(r * r);
+    double* colsum = (double*)malloc(sizeof(double) * (size_t)B);     /* per-column sums, added in column order: the result does not depend on the thread count */
+#pragma omp parallel for schedule(static)
+    for (int c = 0; c < B; ++c) {
+        double cs = 0;
+        for (size_t i = (size_t)c * D; i < (size_t)(c + 1) * D; ++i) {
+            real acc = 0;
+            for (int j = 0; j < 7; ++j) acc += bt[j] * k[j][i];
+            real ut = dt * acc;
+            real au = rfabs(uprev[i]), an = rfabs(unew[i]);
+            real sk = cfg->abstol + (au > an ? au : an) * cfg->reltol;
+            real r = ut / sk;
+            cs += (double)(r * r);
+        }
+        colsum[c] = cs;
     }
+    for (int c = 0; c < B; ++c) ssum += colsum[c];
+    free(colsum);
     *eest_out = (real)sqrt(ssum / (double)N);
     if (eigen_out) { /* eigen_est = ||k7-k6|| / ||u - g6||   */
         double n1 = 0, n2 = 0;
@@ -655,10 +901,22 @@ int orc_steps_ext(void* hh, real* out6, int cap) {
 }
 
 /* ---------------- reverse pass ---------------- */
+/* Sums over the state arrays are taken in fixed chunks (per-chunk partial sums in parallel, chunks added in order), so the
+ * reverse pass does not depend on the number of threads or their scheduling. */
+#define ORC_CHUNK 4096
 static double dotp(const real* a, const real* b, size_t n) {
+    const size_t nch = (n + ORC_CHUNK - 1) / ORC_CHUNK;
+    double* part = (double*)malloc(sizeof(double) * (nch ? nch : 1));
+#pragma omp parallel for schedule(static)
+    for (size_t ch = 0; ch < nch; ++ch) {
+        const size_t i1 = (ch + 1) * ORC_CHUNK < n ? (ch + 1) * ORC_CHUNK : n;
+        double s = 0;
+        for (size_t i = ch * ORC_CHUNK; i < i1; ++i) s += (double)a[i] * (double)b[i];
+        part[ch] = s;
+    }
     double s = 0;
-#pragma omp parallel for schedule(static) reduction(+ : s)
-    for (size_t i = 0; i < n; ++i) s += (double)a[i] * (double)b[i];
+    for (size_t ch = 0; ch < nch; ++ch) s += part[ch];
+    free(part);
     return s;
 }
 
@@ -796,24 +1054,33 @@ int orc_backward(void* hh, const real* ubar, const real* svbar, real* xbar, real
             for (int j = 0; j < 7; ++j) bt[j] = (real)tabBT(cfg->solver)[j];
             double coef = (r->eest > 0) ? eb / ((double)N * (double)r->eest) : 0.0;
             double d_dt = 0;
-#pragma omp parallel for schedule(static) reduction(+ : d_dt)
-            for (size_t i = 0; i < N; ++i) {
-                real acc = 0;
-                for (int j = 0; j < 7; ++j) acc += bt[j] * r->k[j][i];
-                real ut = dt * acc;
-                real au = rfabs(r->uprev[i]), an = rfabs(r->unew[i]);
-                int use_new = !(au > an);
-                real sk = cfg->abstol + (use_new ? an : au) * cfg->reltol;
-                real rr = ut / sk;
-                real rb = (real)(coef * (double)rr);
-                real utbv = rb / sk;
-                real skb = -rb * rr / sk;
-                utb[i] = utbv;
-                if (use_new) unb[i] += skb * cfg->reltol * (r->unew[i] > 0 ? 1 : (r->unew[i] < 0 ? -1 : 0));
-                else upb[i] += skb * cfg->reltol * (r->uprev[i] > 0 ? 1 : (r->uprev[i] < 0 ? -1 : 0));
-                for (int j = 0; j < 7; ++j) kb[j][i] += dt * bt[j] * utbv;
-                d_dt += (double)utbv * (double)acc;
+            const size_t nch_ = (N + ORC_CHUNK - 1) / ORC_CHUNK;
+            double* part_ = (double*)malloc(sizeof(double) * nch_);
+#pragma omp parallel for schedule(static)
+            for (size_t ch = 0; ch < nch_; ++ch) {
+                const size_t i1_ = (ch + 1) * ORC_CHUNK < N ? (ch + 1) * ORC_CHUNK : N;
+                double cs = 0;
+                for (size_t i = ch * ORC_CHUNK; i < i1_; ++i) {
+                    real acc = 0;
+                    for (int j = 0; j < 7; ++j) acc += bt[j] * r->k[j][i];
+                    real ut = dt * acc;
+                    real au = rfabs(r->uprev[i]), an = rfabs(r->unew[i]);
+                    int use_new = !(au > an);
+                    real sk = cfg->abstol + (use_new ? an : au) * cfg->reltol;
+                    real rr = ut / sk;
+                    real rb = (real)(coef * (double)rr);
+                    real utbv = rb / sk;
+                    real skb = -rb * rr / sk;
+                    utb[i] = utbv;
+                    if (use_new) unb[i] += skb * cfg->reltol * (r->unew[i] > 0 ? 1 : (r->unew[i] < 0 ? -1 : 0));
+                    else upb[i] += skb * cfg->reltol * (r->uprev[i] > 0 ? 1 : (r->uprev[i] < 0 ? -1 : 0));
+                    for (int j = 0; j < 7; ++j) kb[j][i] += dt * bt[j] * utbv;
+                    cs += (double)utbv * (double)acc;
+                }
+                part_[ch] = cs;
             }
+            for (size_t ch = 0; ch < nch_; ++ch) d_dt += part_[ch];
+            free(part_);
             dtb += d_dt;
         }
         /* stages 7..2 */
@@ -837,23 +1104,41 @@ int orc_backward(void* hh, const real* ubar, const real* svbar, real* xbar, real
 #pragma omp parallel for schedule(static)
                 for (size_t i = 0; i < N; ++i) unb[i] += gb[i];
                 double d_dt = 0;
-#pragma omp parallel for schedule(static) reduction(+ : d_dt)
-                for (size_t i = 0; i < N; ++i) {
-                    real acc = 0;
-                    for (int j = 0; j < 6; ++j) { kb[j][i] += dt * as[j] * unb[i]; acc += as[j] * r->k[j][i]; }
-                    upb[i] += unb[i];
-                    d_dt += (double)unb[i] * (double)acc;
+                const size_t nch_ = (N + ORC_CHUNK - 1) / ORC_CHUNK;
+                double* part_ = (double*)malloc(sizeof(double) * nch_);
+#pragma omp parallel for schedule(static)
+                for (size_t ch = 0; ch < nch_; ++ch) {
+                    const size_t i1_ = (ch + 1) * ORC_CHUNK < N ? (ch + 1) * ORC_CHUNK : N;
+                    double cs = 0;
+                    for (size_t i = ch * ORC_CHUNK; i < i1_; ++i) {
+                        real acc = 0;
+                        for (int j = 0; j < 6; ++j) { kb[j][i] += dt * as[j] * unb[i]; acc += as[j] * r->k[j][i]; }
+                        upb[i] += unb[i];
+                        cs += (double)unb[i] * (double)acc;
+                    }
+                    part_[ch] = cs;
                 }
+                for (size_t ch = 0; ch < nch_; ++ch) d_dt += part_[ch];
+                free(part_);
                 dtb += d_dt;
             } else {
                 double d_dt = 0;
-#pragma omp parallel for schedule(static) reduction(+ : d_dt)
-                for (size_t i = 0; i < N; ++i) {
-                    real acc = 0;
-                    for (int j = 0; j < s; ++j) { kb[j][i] += dt * as[j] * gb[i]; acc += as[j] * r->k[j][i]; }
-                    upb[i] += gb[i];
-                    d_dt += (double)gb[i] * (double)acc;
+                const size_t nch_ = (N + ORC_CHUNK - 1) / ORC_CHUNK;
+                double* part_ = (double*)malloc(sizeof(double) * nch_);
+#pragma omp parallel for schedule(static)
+                for (size_t ch = 0; ch < nch_; ++ch) {
+                    const size_t i1_ = (ch + 1) * ORC_CHUNK < N ? (ch + 1) * ORC_CHUNK : N;
+                    double cs = 0;
+                    for (size_t i = ch * ORC_CHUNK; i < i1_; ++i) {
+                        real acc = 0;
+                        for (int j = 0; j < s; ++j) { kb[j][i] += dt * as[j] * gb[i]; acc += as[j] * r->k[j][i]; }
+                        upb[i] += gb[i];
+                        cs += (double)gb[i] * (double)acc;
+                    }
+                    part_[ch] = cs;
                 }
+                for (size_t ch = 0; ch < nch_; ++ch) d_dt += part_[ch];
+                free(part_);
                 dtb += d_dt;
             }
         }

@@ -15,8 +15,16 @@ def _headers():
     return sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(_HERE, "..", "include", "rnde.h")]
 
 
+def _flag_stamp():
+    """The compile-time switches a build was made with (a variant left in place by an A/B run must not pass for the default build)."""
+    return "RNDE_WITH_COLUMN_OWNER=%s RNDE_EXTRA_FLAGS=%s" % (os.environ.get("RNDE_WITH_COLUMN_OWNER", ""), os.environ.get("RNDE_EXTRA_FLAGS", ""))
+
+
 def needs_build():
     if not os.path.exists(LIB):
+        return True
+    stamp = LIB + ".flags"
+    if os.path.exists(stamp) and open(stamp).read() != _flag_stamp():      # (no stamp: a prebuilt library that travelled without it)
         return True
     m = os.path.getmtime(LIB)
     return any(os.path.getmtime(f) > m for f in [os.path.join(CSRC, s) for s in SOURCES] + _headers())
@@ -34,11 +42,12 @@ def build(force=False, verbose=False):
         flags.append("-DRNDE_WITH_COLUMN_OWNER")
     flags += os.environ.get("RNDE_EXTRA_FLAGS", "").split()      # compile-time A/B switches (tools/ab_build.sh)
     hdr_m = max(os.path.getmtime(f) for f in _headers())
+    restamp = os.path.exists(LIB + ".flags") and open(LIB + ".flags").read() != _flag_stamp()
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         srcp = os.path.join(CSRC, src)
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(srcp), hdr_m):
+        if not force and not restamp and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(srcp), hdr_m):
             return obj
         cmd = [hipcc] + flags + ["-c", srcp, "-o", obj]
         if verbose:
@@ -52,6 +61,8 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(LIB + ".flags", "w") as f:
+        f.write(_flag_stamp())
     return LIB
 
 

@@ -65,6 +65,13 @@ def fused_loss_and_grad(model, x, y, lam=1.0e2, regularize=True, tspan=None, syn
     h = node._acquire(x2, True)
     ts = node.tspan if tspan is None else [float(tspan[0]), float(tspan[1])]
     stream = C.c_void_p(torch.cuda.current_stream(x2.device).cuda_stream)
+    if reducer is not None:
+        # the all-reduce below works on the reducer's OWN flat buffer: the gradients have to be written into its views, or the
+        # collective would sum a buffer nothing wrote and leave p.grad un-reduced (replicas would silently diverge)
+        if flat is None:
+            flat = reducer.fg
+        elif flat.flat.data_ptr() != reducer.fg.flat.data_ptr():
+            raise ValueError("fused_loss_and_grad: `flat` is not the buffer `reducer` reduces (pass reducer.fg, or leave flat=None)")
     if flat is not None:                                  # trainable() = (p1 (empty), p2, p3) -> groups [p2, p3]
         p2bar, p3bar = flat.views[0], flat.views[1]
     else:

@@ -773,6 +773,11 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
         HIPCHK(h, hipMemcpyAsync(h->sv_t_dev, h->saveat.data(), (size_t)n_saveat * 4, hipMemcpyHostToDevice, s));
     } else h->saveat.clear();
     if (B < 1 || B > h->cfg.max_batch || !(t1 > t0)) { h->err = "bad B or tspan"; return RNDE_ERR_BAD_ARG; }
+    // the coupled controller all-reduces per-workgroup partial arrays element by element: every rank must hold the same number of columns
+    if (h->couple && (long long)B * h->couple_world != h->couple_batch) {
+        h->err = "coupled controller: equal shards only (B * world must equal the global batch given to rnde_node_set_coupling)";
+        return RNDE_ERR_BAD_ARG;
+    }
     HIPCHK(h, hipSetDevice(h->cfg.device));
     h->have_tape = false; h->rev_packed = false;
     const float* x_caller = nullptr;

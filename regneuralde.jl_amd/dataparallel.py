@@ -109,8 +109,12 @@ class GradientAllReducer:
             p.grad = v
 
 
-def shard_columns(x, rank, world):
-    """Contiguous column blocks: rank g holds samples [g*B/G, (g+1)*B/G)."""
+def shard_columns(x, rank, world, equal=False):
+    """Contiguous column blocks: rank g holds samples [g*B/G, (g+1)*B/G).  equal=True (required with the coupled
+    controller, `TrackedNeuralODE.set_coupling`: its per-step all-reduce adds per-workgroup arrays element-wise) refuses a batch that
+    does not divide by the number of ranks instead of giving the last rank a shorter shard."""
     B = x.shape[0]
+    if equal and B % world != 0:
+        raise ValueError(f"shard_columns: batch {B} does not split into {world} equal shards (coupled controller needs equal shards)")
     per = (B + world - 1) // world
     return x[rank * per:min(B, (rank + 1) * per)]

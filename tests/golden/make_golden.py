@@ -110,6 +110,38 @@ def dp5_inputs():
     return inputs("latent_B4")
 
 
+# ---- third generation (round 3): the natural run at the REFERENCE tolerance, summed in the device's order ---------------------------
+DEVORDER_CASES = {
+    # name: (B, tol, seed): MNIST shape, Glorot weights (scale 1), reltol = abstol = 1.4e-8 (experiments/mnist_node.jl:121-124)
+    "mnist_B16_reftol_devorder": (16, 1.4e-8, 41),
+}
+
+
+def devorder_inputs(name):
+    B, tol, seed = DEVORDER_CASES[name]
+    arch = arch_mnist()
+    p = params_for(arch, seed, 1.0)
+    x = lcg_uniform(B * 784, seed + 1000).reshape(B, 784)
+    return arch, p, x, tol
+
+
+def main3():
+    """At 1.4e-8 the fp32 step sequence is set by rounding noise, so only an oracle that accumulates as the device does
+    (Oracle(sum_order=3): oracle/rnde_oracle.c orc_set_sum_order) yields a sequence the device can be held to.  Stored: the step log
+    (t, dt, EEst, accepted), u_end, the saved values, and the sequential-k oracle's attempt count beside it."""
+    for name in DEVORDER_CASES:
+        arch, p, x, tol = devorder_inputs(name)
+        o3 = Oracle(arch, np.float32, reltol=tol, abstol=tol, reg_kind=1, max_attempts=96, sum_order=3)
+        r = o3.forward(x, p)
+        o0 = Oracle(arch, np.float32, reltol=tol, abstol=tol, reg_kind=1, max_attempts=96).forward(x, p)
+        o64 = Oracle(arch, np.float64, reltol=tol, abstol=tol, reg_kind=1, max_attempts=96).forward(x, p)
+        assert r["rc"] == 0 and o0["rc"] == 0 and o64["rc"] == 0
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), u_devorder=r["u"], nfe_devorder=r["nfe"], steps_devorder=r["steps"],
+                            saveval_devorder=r["saveval"], nfe_sequential=o0["nfe"], nfe_f64=o64["nfe"], u_f64=o64["u"])
+        print(name, "attempts: device order", r["nattempts"], "sequential", o0["nattempts"], "fp64", o64["nattempts"],
+              "bytes", os.path.getsize(os.path.join(HERE, name + ".npz")))
+
+
 def main2():
     from oracle.oracle_sde import SdeOracle
     for name in NSDE_CASES:
@@ -139,6 +171,9 @@ def main2():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "devorder":      # only the round-3 fixture (the older ones stay byte-identical in git)
+        main3()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "round2":
         main2()          # (the round-1 fixtures stay as committed)
     else:

@@ -61,6 +61,15 @@ def test_training_step_with_flat_gradients_and_early_allreduce():
             o2.step(grad_scale=red.grad_scale)
         torch.cuda.synchronize()
         assert torch.equal(m1.p2, m2.p2) and torch.equal(m1.p3, m2.p3)
+        # a reducer WITHOUT `flat` (the three-call path, sync=True): the gradients must still land in the buffer the collective reduces
+        # (round-2 advisor finding: they went to fresh tensors and an unwritten buffer was all-reduced), and a foreign `flat` is refused
+        fg.flat.fill_(float("nan"))
+        rn.fused_loss_and_grad(m2, x, y, sync=True, reducer=red)
+        assert m2.p2.grad.data_ptr() == red.fg.flat.data_ptr() and torch.isfinite(red.fg.flat).all()
+        rn.fused_loss_and_grad(m1, x, y, sync=True)
+        assert torch.equal(m1.p2.grad, m2.p2.grad) and torch.equal(m1.p3.grad, m2.p3.grad)
+        with pytest.raises(ValueError):
+            rn.fused_loss_and_grad(m2, x, y, sync=True, flat=rn.FlatGrads(m2.trainable()), reducer=red)
     finally:
         dist.destroy_process_group()
         if os.path.exists(store.name):

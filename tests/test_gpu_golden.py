@@ -106,3 +106,26 @@ def test_nsde_reproduces_golden(name, replay, mw, monkeypatch):
     print(name, "x-bar", rel_err(xb, g["xbar_f64"]), "(oracle f32:", sx, ") p-bar", rel_err(pb, g["pbar_f64"]), "(oracle f32:", sp, ")")
     assert rel_err(xb, g["xbar_f64"]) <= 1e-3 + 4 * sx
     assert rel_err(pb, g["pbar_f64"]) <= 1e-3 + 4 * sp
+
+
+def test_device_natural_run_at_reference_tolerance_matches_devorder_golden():
+    """NFE at reltol = abstol = 1.4e-8 (experiments/mnist_node.jl:121-124) against a COMMITTED fixture: the oracle run in the device's
+    summation order (tests/golden/make_golden.py main3).  Same number of attempts (+-1), same accept pattern, steps within 20 %,
+    u_end to 3e-6 of the fp64 fixture; the sequential-k oracle's count (41) is stored beside it to show what the order does."""
+    from tests.golden.make_golden import DEVORDER_CASES, devorder_inputs
+    from tests.test_gpu_forward import _cfg
+    from tests.util import Node
+    for name in DEVORDER_CASES:
+        arch, p, x, tol = devorder_inputs(name)
+        g = np.load(os.path.join(GOLD, name + ".npz"))
+        node = Node(_cfg(arch, x.shape[0], reltol=tol, abstol=tol, max_attempts=96))
+        got = node.forward(x.astype(np.float32), p.astype(np.float32))
+        ng = len(g["steps_devorder"])
+        assert abs(got["nattempts"] - ng) <= 1 and got["nfe"] == 3 + 6 * got["nattempts"]
+        assert got["nattempts"] < (int(g["nfe_sequential"]) - 3) // 6
+        n = min(ng, got["nattempts"])
+        assert np.array_equal(got["steps"][:n, 3], g["steps_devorder"][:n, 3])
+        np.testing.assert_allclose(got["steps"][:n, 1], g["steps_devorder"][:n, 1], rtol=0.2)
+        assert np.abs(got["u"] - g["u_f64"]).max() <= 3e-6 * max(1.0, np.abs(g["u_f64"]).max())
+        assert abs(got["saveval"].sum() / g["saveval_devorder"].sum() - 1) <= 0.05
+        node.close()

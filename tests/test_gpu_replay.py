@@ -18,6 +18,15 @@ on the noise comparable element-wise:
 
 Also here: the vanilla (regularize = 0) B = 64 solve of BASELINE config 1 against the oracle, and the distribution of the
 number of attempts over 16 seeds, device vs fp32 oracle.
+
+Round 3 -- the oracle in the DEVICE'S ORDER (`Oracle(sum_order=3)`, oracle/rnde_oracle.c `orc_set_sum_order`): the two Dense
+layers accumulated exactly as the stage engine does (7 split-K row-block partials of two interleaved K = 4 FMA chains -- an fp32
+MFMA is four fused multiply-adds in k order, tools/mfma_model.py fits that to raw matrix-pipe output bit for bit -- added in order
+r = 0..6; layer 2 likewise over [h; t; 1]) and tanh by the device's formula.  With that the fp32 noise floor is the SAME noise:
+one f evaluation agrees bit for bit in ~95 % of its entries (1 ulp in the rest: v_exp_f32 / v_rcp_f32 against correctly rounded
+exp2 / reciprocal), natural runs take the SAME number of attempts (B = 64 x 16 seeds and B = 512: 30 and 30; the sequential-k
+oracle: 40.8), per-attempt EEst agrees to 0.6 % at B = 512 (10 % at B = 64 per attempt, 0.5 % in the mean).  So the -27 % NFE
+offset of round 2 IS the summation order, and natural-run NFE parity is now an equality test.
 """
 import numpy as np
 import pytest
@@ -45,14 +54,15 @@ def _cfg(B, **kw):
 _cache = {}
 
 
-def _oracle_runs(B, seed, track):
-    """fp32 oracle natural run + its reverse; fp64 oracle replayed along the same sequence + its reverse."""
-    key = (B, seed, track)
+def _oracle_runs(B, seed, track, sum_order=0):
+    """fp32 oracle natural run + its reverse; fp64 oracle replayed along the same sequence + its reverse.
+    sum_order = 3: the fp32 oracle accumulates and rounds as the device does (module docstring)."""
+    key = (B, seed, track, sum_order)
     if key in _cache:
         return _cache[key]
     from tests.util import Oracle
     arch, p, x, ubar = _problem(B, seed)
-    o32 = Oracle(arch, np.float32, TOL, TOL, reg_kind=1, track_ctrl=track, track_initdt=track, max_attempts=96)
+    o32 = Oracle(arch, np.float32, TOL, TOL, reg_kind=1, track_ctrl=track, track_initdt=track, max_attempts=96, sum_order=sum_order)
     r32 = o32.forward(x, p)
     assert r32["rc"] == 0
     se = o32.steps_ext()
@@ -178,9 +188,89 @@ def test_attempt_count_distribution_at_reference_tolerance():
         g = node.forward(x, p)
         dev.append(g["nattempts"]); o32.append(a["nattempts"]); o64.append(b["nattempts"])
         assert g["nattempts"] <= 1.15 * a["nattempts"] + 1
+        o3 = Oracle(arch, np.float32, TOL, TOL, reg_kind=1, max_attempts=96, sum_order=3).forward(x, p)     # the oracle in the device's order:
+        assert abs(g["nattempts"] - o3["nattempts"]) <= 1                                                   # the SAME count (round 3)
     dev, o32, o64 = np.array(dev, float), np.array(o32, float), np.array(o64, float)
     print(f"attempts over 16 seeds (B=64, tol 1.4e-8): device {dev.mean():.1f} +- {dev.std():.1f} (NFE {3 + 6 * dev.mean():.0f}), "
           f"fp32 oracle {o32.mean():.1f} +- {o32.std():.1f} (NFE {3 + 6 * o32.mean():.0f}), fp64 oracle {o64.mean():.1f} +- {o64.std():.1f}")
     assert 0.6 * o32.mean() <= dev.mean() <= 1.05 * o32.mean()
     assert dev.std() <= 2.0 * o32.std() + 1.0
+    node.close()
+
+
+def test_f_evaluation_equals_the_device_order_oracle_almost_bit_for_bit():
+    """One f evaluation, MNIST shape: against the sequential-k oracle the device differs in nearly every entry (rounding), against
+    the oracle in the device's order it is bit-identical in >= 90 % of the entries and within 1 ulp of a value < 1 in the rest
+    (measured 95 %, 1.19e-7; sequential: 6 %, 4.7e-7).  This is the statement 'the GEMMs are summed as the oracle says'."""
+    from tests.util import Node, Oracle
+    arch, p, x, _ = _problem(64, 3)
+    node = Node(_cfg(64, regularize=1))
+    fd = node.feval(x, p, 0.37)
+    f0 = Oracle(arch, np.float32, TOL, TOL, sum_order=0).f_eval(p, x, 0.37)
+    f1 = Oracle(arch, np.float32, TOL, TOL, sum_order=1).f_eval(p, x, 0.37)
+    f3 = Oracle(arch, np.float32, TOL, TOL, sum_order=3).f_eval(p, x, 0.37)
+    eq0, eq1, eq3 = float(np.mean(fd == f0)), float(np.mean(fd == f1)), float(np.mean(fd == f3))
+    print(f"f evaluation, entries bit-equal to the device: sequential-k oracle {eq0:.3f}, device-order GEMMs {eq1:.3f}, + device tanh {eq3:.3f}; "
+          f"max |diff| {np.abs(fd - f0).max():.2e} / {np.abs(fd - f1).max():.2e} / {np.abs(fd - f3).max():.2e}")
+    assert eq3 >= 0.90 and np.abs(fd - f3).max() <= 1.2e-7
+    assert eq3 > eq1 > eq0
+    node.close()
+
+
+def test_natural_run_attempts_equal_the_device_order_oracle():
+    """NFE parity at the reference tolerance as an EQUALITY (north star: 'trajectories and NFE counts within a stated fp32
+    tolerance on identical inputs'): natural runs, device vs the oracle in the device's order, B = 64 over 16 seeds and B = 512
+    over 2 -- the same number of attempts (+-1 allowed, 0 observed), the same accept/reject pattern, step sizes within 15 %
+    (B = 64; 0.3 % observed at B = 512), per-attempt EEst within 12 % (B = 64) / 2 % (B = 512), u_end to 3e-6."""
+    from tests.util import Node, Oracle
+    for B, seeds, dt_tol, ee_tol in ((64, range(100, 116), 0.15, 0.12), (512, (11, 12), 0.01, 0.02)):
+        node = Node(_cfg(B, regularize=1))
+        worst_dt = worst_ee = 0.0
+        for seed in seeds:
+            arch, p, x, _ = _problem(B, seed)
+            o3 = Oracle(arch, np.float32, TOL, TOL, reg_kind=1, max_attempts=96, sum_order=3)
+            r3 = o3.forward(x, p)
+            se = o3.steps_ext()
+            g = node.forward(x, p)
+            assert abs(g["nattempts"] - r3["nattempts"]) <= 1, (B, seed, g["nattempts"], r3["nattempts"])
+            assert g["nfe"] == 3 + 6 * g["nattempts"]
+            n = min(g["nattempts"], r3["nattempts"])
+            assert np.array_equal(g["steps"][:n, 3].astype(np.int32), se[:n, 4].astype(np.int32))      # accept / reject pattern
+            worst_dt = max(worst_dt, float(np.abs(g["steps"][:n, 1] / se[:n, 1] - 1).max()))
+            worst_ee = max(worst_ee, float(np.abs(g["steps"][:n, 2] / se[:n, 3] - 1).max()))
+            assert _rel(g["u"], r3["u"]) <= 3e-6
+            assert abs(g["saveval"].sum() / r3["saveval"].sum() - 1) <= 0.02
+        print(f"B = {B}: attempts equal over {len(list(seeds))} seeds; worst |dt_dev / dt_oracle - 1| {worst_dt:.2e}, worst |EEst ratio - 1| {worst_ee:.2e}")
+        assert worst_dt <= dt_tol and worst_ee <= ee_tol
+        node.close()
+
+
+def test_replay_eest_matches_device_order_oracle():
+    """Replay along the device-order oracle's own sequence, B = 512: per-attempt EEst device / oracle in [0.9, 1.1] (VERDICT r02 item 2;
+    measured 0.994..1.006), saved values and the regulariser term likewise, and the full training-step gradient (cotangent on u_end and
+    lambda / n on every EEst * dt, everything tracked) now agrees with THAT oracle's gradient far better than either agrees with fp64 --
+    the noise-defined part of the gradient is the same noise."""
+    from tests.util import Node
+    R = _oracle_runs(B512, 11, 1, sum_order=3)
+    node = Node(_cfg(B512, regularize=1))
+    got = node.forward_replay(R["x"], R["p"], R["dtp"], R["acc"], keep_tape=True)
+    assert got["nattempts"] == len(R["dtp"]) and got["nfe"] == R["r32"]["nfe"]
+    ratio = got["steps"][:, 2] / R["se32"][:, 3]
+    print("EEst device / device-order oracle per attempt: min %.4f mean %.4f max %.4f" % (ratio.min(), ratio.mean(), ratio.max()))
+    assert 0.9 <= ratio.min() and ratio.max() <= 1.1
+    assert got["saveval"][0] == 0.0
+    sv_ratio = got["saveval"][1:] / R["r32"]["saveval"][1:]
+    assert 0.9 <= sv_ratio.min() and sv_ratio.max() <= 1.1
+    reg_dev, reg_o = 100.0 * got["saveval"].mean(), 100.0 * R["r32"]["saveval"].mean()
+    assert abs(reg_dev / reg_o - 1) <= 0.02
+    xb, pb, tsb = node.backward(R["ubar"], R["svbar"])
+
+    def dist(a, b):
+        a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+        return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    dx, dp = dist(xb, R["g32"][0]), dist(pb, R["g32"][1])
+    sx, sp = dist(R["g32"][0], R["g64"][0]), dist(R["g32"][1], R["g64"][1])
+    print(f"full gradient, relative L2: device vs device-order oracle x_bar {dx:.3e} p_bar {dp:.3e}; that oracle vs fp64 x_bar {sx:.3e} p_bar {sp:.3e}; "
+          f"regulariser term device {reg_dev:.4f} oracle {reg_o:.4f}")
+    assert dx <= 0.5 * sx + 1e-4 and dp <= 0.5 * sp + 1e-4
     node.close()

@@ -199,3 +199,17 @@ def test_sample_tbounds_and_time_row(rnde):
     np.testing.assert_allclose(row[0, :-1, 0].numpy(), (grid[1:] - grid[:-1]).numpy(), atol=1e-7)
     t3, tt3, row3 = rnde.get_t_saveat(t, grid, steer=True, gaps=gaps, generator=g)
     assert t3.shape == (3, 49, 1) and torch.equal(t3[0, :, 0], tt3)
+
+
+def test_shard_columns_equal_shards_for_the_coupled_controller():
+    """contiguous column blocks; the coupled controller (mode 2) needs equal shards -- a ragged split is refused, not
+    silently handed to an element-wise all-reduce of different lengths."""
+    import pytest
+    import torch
+    from regneuralde_jl_amd.dataparallel import shard_columns
+    x = torch.arange(10 * 3).reshape(10, 3)
+    parts = [shard_columns(x, r, 4) for r in range(4)]
+    assert [p.shape[0] for p in parts] == [3, 3, 3, 1] and torch.equal(torch.cat(parts), x)
+    assert [shard_columns(x, r, 5, equal=True).shape[0] for r in range(5)] == [2] * 5
+    with pytest.raises(ValueError):
+        shard_columns(x, 0, 4, equal=True)

@@ -350,3 +350,68 @@ def test_dp5_tableau_path_matches_scipy_rk45_step_for_step():
         pp[idx] += 1e-6; pm[idx] -= 1e-6
         fd = (loss(pp) - loss(pm)) / 2e-6
         assert abs(fd - pb[idx]) <= 2e-5 * max(1.0, abs(fd)), (idx, fd, pb[idx])
+
+
+def test_summation_order_modes_are_the_same_function_with_different_rounding():
+    """orc_set_sum_order (oracle/rnde_oracle.c): bit 0 = the stage engine's accumulation order of the two Dense layers, bit 1 = the
+    device's tanh formula.  Same mathematics: one f evaluation agrees to fp32 rounding in every mode, and on a shape whose K fits one
+    k-block chain the device order degenerates to two interleaved chains.  At the reference tolerance the fp32 error estimate is rounding
+    noise, so the ORDER moves the attempt count: split-K sums carry less error, the floor drops, the steps grow --
+    40 -> 30 attempts on the MNIST shape (what the device measures, tests/test_gpu_replay.py), while u_end stays put."""
+    arch = arch_mnist()
+    rng = np.random.default_rng(3)
+    p = glorot_params(arch, rng)
+    x = rng.uniform(0, 1, (8, 784)).astype(np.float32)
+    f64 = Oracle(arch, np.float64).f_eval(p.astype(np.float64), x.astype(np.float64), 0.37)
+    errs = {}
+    for mode in (0, 1, 2, 3):
+        f = Oracle(arch, np.float32, sum_order=mode).f_eval(p, x, 0.37)
+        errs[mode] = float(np.sqrt(np.mean((f - f64) ** 2)))
+        assert np.abs(f - f64).max() < 1e-6
+    assert errs[1] < 0.6 * errs[0]            # split-K + two accumulators: visibly less rounding error than one 785-term chain
+    att, uend = {}, {}
+    for mode in (0, 3):
+        r = Oracle(arch, np.float32, 1.4e-8, 1.4e-8, reg_kind=1, max_attempts=96, sum_order=mode).forward(x, p)
+        assert r["rc"] == 0
+        att[mode], uend[mode] = r["nattempts"], r["u"]
+    assert att[3] < att[0] and 25 <= att[3] <= 35 and 36 <= att[0] <= 46, att
+    assert np.abs(uend[0] - uend[3]).max() < 5e-6
+    # the default mode is restored by the wrapper on every call: another oracle object is unaffected
+    r0 = Oracle(arch, np.float32, 1.4e-8, 1.4e-8, reg_kind=1, max_attempts=96).forward(x, p)
+    assert r0["nattempts"] == att[0]
+
+
+def test_oracle_is_deterministic_whatever_the_thread_count():
+    """Every sum over the state arrays is taken in fixed chunks (round 3): forward AND reverse results are bit-identical between a
+    one-thread and a many-thread run, so fixtures do not depend on the machine that made them."""
+    import ctypes
+    arch = arch_mnist(36, 10)
+    rng = np.random.default_rng(9)
+    p = glorot_params(arch, rng, scale=3.0)
+    x = rng.uniform(0, 1, (24, 36)).astype(np.float32)
+    ub = rng.standard_normal((24, 36)).astype(np.float32)
+    outs = []
+    for th in (1, 5):
+        o = Oracle(arch, np.float32, 1e-4, 1e-4, reg_kind=1)
+        o.lib.orc_set_threads(ctypes.c_int(th))
+        r = o.forward(x, p)
+        g = o.backward(ub, np.full(len(r["saveval"]), 2.0, np.float32))
+        outs.append((r["u"], r["saveval"], r["steps"], g[0], g[1], g[2]))
+    from oracle.oracle import effective_cores
+    o.lib.orc_set_threads(ctypes.c_int(effective_cores()))
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+
+
+def test_oracle_reproduces_device_order_golden():
+    """tests/golden/mnist_B16_reftol_devorder.npz: the natural run at the reference tolerance in the device's summation order.  The
+    oracle is deterministic (fixed-order sums, no libm tanh in this mode), so the step log reproduces exactly."""
+    from tests.golden.make_golden import DEVORDER_CASES, devorder_inputs
+    for name in DEVORDER_CASES:
+        arch, p, x, tol = devorder_inputs(name)
+        g = np.load(os.path.join(GOLD, name + ".npz"))
+        r = Oracle(arch, np.float32, reltol=tol, abstol=tol, reg_kind=1, max_attempts=96, sum_order=3).forward(x, p)
+        assert r["nfe"] == int(g["nfe_devorder"]) and int(g["nfe_devorder"]) < int(g["nfe_sequential"])
+        assert np.array_equal(r["steps"][:, 3], g["steps_devorder"][:, 3])
+        np.testing.assert_allclose(r["steps"][:, :3], g["steps_devorder"][:, :3], rtol=2e-3)       # (bit-equal on the image's libm; exp2 may differ in the last place elsewhere)
+        assert np.abs(r["u"] - g["u_devorder"]).max() <= 1e-6

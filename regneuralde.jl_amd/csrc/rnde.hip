@@ -5,7 +5,7 @@
 #include "rnde_bwd.h"
 #include "rnde_stage.h"
 #include "rnde_bstage.h"
-#include "rnde_stage_persist.h"
+#include "rnde_stage_persist2.h"
 #include "rnde_bstage_persist.h"
 #include "rnde_binit_stage.h"
 #include "rnde_head.h"
@@ -68,6 +68,7 @@ struct rnde_node {
     int wgrad_side_pct = 30, stage_generic = 0;
     int binit_stage = 1;   // reverse of the initial-step rule on the stage engine (rnde_binit_stage.h); 0: the column-owner kernels (RNDE_BINIT_STAGE=0)
     int persist_clean = 0, persist_retry_after = 8, persist_fallbacks = 0;   // non-sticky fallback: clean multi-launch solves since the last failure, when to try again   // fixed at creation (config fields; RNDE_* environment overrides are read once, there)
+    int persist2 = -1;   // two column tiles per workgroup in the forward attempt kernel: -1 automatic (by tile count), 0 never, 1 whenever possible (RNDE_PERSIST2, read at creation)
     int persist = 0, persist_spins = kPersistMaxSpins; int tslab_Bpad = -1; size_t tslab_bytes = 0; float* tslab = nullptr; unsigned *pabort = nullptr, *pxcc = nullptr; unsigned* h_pchk = nullptr;
     hipStream_t wstream = nullptr;        // (experimental overlap path of the weight-gradient GEMMs)
     std::vector<hipEvent_t> wevents;
@@ -514,6 +515,7 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
         const bool off = c->persist < 0 || (e && e[0] == '0');
         h->persist = (h->engine == 2 && h->sR <= 8 && !off) ? 1 : 0;
         if (const char* e2 = getenv("RNDE_PERSIST_SPINS")) h->persist_spins = atoi(e2);
+        if (const char* e3 = getenv("RNDE_PERSIST2")) h->persist2 = atoi(e3);
         h->wgrad_side_pct = c->wgrad_side_pct < 0 ? 0 : (c->wgrad_side_pct == 0 ? 30 : std::min(100, c->wgrad_side_pct));
         if (const char* e3 = getenv("RNDE_WGRAD_SIDE")) h->wgrad_side_pct = atoi(e3);
         if (const char* e5 = getenv("RNDE_BINIT_STAGE")) h->binit_stage = atoi(e5);
@@ -669,6 +671,18 @@ static hipError_t stage_attempt(rnde_node* h, const StageParams& Q, int n, hipSt
         if (hipError_t e = slab_prepare(h, Q.Bpad16, s); e != hipSuccess) return e;
         const dim3 grid(8 * Q.R * ((Q.C + 7) / 8));   // a column tile's row blocks share blockIdx % 8 (same XCD)
         const bool fix = Q.WT == 7 && Q.HT == 7 && Q.K2b == 7 && Q.MT == 49 && Q.R == 7 && h->D == 784 && h->H == 100 && !h->stage_generic;
+        // batches that fill the chip more than once: two column tiles per workgroup (rnde_stage_persist2.h; bit-identical results).
+        // RNDE_PERSIST2=0 keeps one tile per workgroup (A/B and the bit-identity test), =1 takes two whenever the tile count is even.
+        if (fix && Q.C % 2 == 0 && h->persist2 != 0 && (Q.C >= kPersist2MinTiles || h->persist2 >= 1)) {
+            const dim3 grid2(8 * Q.R * ((Q.C / 2 + 7) / 8));
+            const size_t lds2 = sizeof(float) * (2 * 2 * 16 * (16 * 7 + 4) + 32 * 3);
+            if (h->persist2 == 2) {      // (lock-step form: A/B only)
+                if (h->act2) hipLaunchKernelGGL((rnde_stage_attempt_mt_kernel<1, 2, 0>), grid2, dim3(64 * 7), lds2, s, Q, n, Y);
+                else hipLaunchKernelGGL((rnde_stage_attempt_mt_kernel<0, 2, 0>), grid2, dim3(64 * 7), lds2, s, Q, n, Y);
+            } else if (h->act2) hipLaunchKernelGGL((rnde_stage_attempt_mt_kernel<1, 2, 1>), grid2, dim3(64 * 7), lds2, s, Q, n, Y);
+            else hipLaunchKernelGGL((rnde_stage_attempt_mt_kernel<0, 2, 1>), grid2, dim3(64 * 7), lds2, s, Q, n, Y);
+            return hipGetLastError();
+        }
         if (fix) {
             if (h->act2) hipLaunchKernelGGL((rnde_stage_attempt_kernel<1, 1>), grid, dim3(64 * Q.WT), h->stage_lds, s, Q, n, Y);
             else hipLaunchKernelGGL((rnde_stage_attempt_kernel<0, 1>), grid, dim3(64 * Q.WT), h->stage_lds, s, Q, n, Y);

@@ -396,6 +396,32 @@ def main():
         train_step()
     elapsed, mean_nfe, last_loss = timed(False)
 
+    # ---- N > 1 diagnostics (every rank takes part): per-rank NFE and persistent-kernel fallbacks, and the all-reduce on its own (HIP events) ----
+    dist_diag = None
+    if use_dist:
+        hh = model.node._acquire(x.reshape(B, -1), True)
+        mine = torch.tensor([float(sum(nfes) / max(1, len(nfes))), float(L.rnde_node_fallback_count(hh.ptr)), float(L.rnde_node_launches_per_attempt(hh.ptr))],
+                            device=device, dtype=torch.float64)
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        ar_us = None
+        if reducer is not None and reducer.comm is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(3):
+                reducer.allreduce_range_(0, fg.flat.numel())
+            dist.barrier(); torch.cuda.synchronize()
+            e0.record()
+            for _ in range(20):
+                reducer.allreduce_range_(0, fg.flat.numel())
+            e1.record(); torch.cuda.synchronize()
+            ar_us = 1e3 * e0.elapsed_time(e1) / 20
+            fg.flat.zero_()
+        nf = [float(v[0]) for v in allv]
+        dist_diag = {"nfe_per_rank": nf, "nfe_min": min(nf), "nfe_mean": sum(nf) / len(nf), "nfe_max": max(nf),
+                     "persist_fallback_count_per_rank": [int(v[1]) for v in allv], "launches_per_attempt_per_rank": [int(v[2]) for v in allv],
+                     "allreduce_us": ar_us, "allreduce_floats": int(fg.flat.numel()) if fg is not None else None,
+                     "collective_library": L.rnde_comm_library().decode() if reducer is not None and reducer.comm is not None else None}
+
     out = None
     if rank == 0:
         h = model.node._acquire(x.reshape(B, -1), True)
@@ -477,6 +503,8 @@ def main():
                                       "--steps: value_fixed_weights is the stationary companion)", "global_batch": world * B,
                           "parallelism": f"dp{world}" if world > 1 else "single"},
                "roofline": roof}
+        if dist_diag is not None:
+            out["dist"] = dist_diag
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         if world == 1 and not args.no_extras and not use_dist and B == 512:

@@ -268,6 +268,9 @@ rnde_status rnde_comm_create(const uint8_t id[RNDE_COMM_ID_BYTES], int32_t rank,
 void        rnde_comm_destroy(rnde_comm* c);
 int32_t     rnde_comm_world(const rnde_comm* c);
 const char* rnde_comm_last_error(const rnde_comm* c);   /* c may be NULL: last create / id error of this thread */
+/* The file the collective library was bound from (an RCCL already loaded in the process -- e.g. the copy PyTorch bundles -- is reused
+ * rather than a second instance loaded beside it), or the load error. */
+const char* rnde_comm_library(void);
 /* In-place sum of n floats over the ranks (mean != 0: followed by a scale by 1 / world), asynchronous on `stream`.
  * MNIST-NODE payload: 166,418 floats = 665,672 B in ONE call (latency bound: one contiguous buffer). */
 rnde_status rnde_comm_allreduce(rnde_comm* c, float* buf_dev, int64_t n, int32_t mean, void* stream);

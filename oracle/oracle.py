@@ -112,7 +112,9 @@ class Oracle:
                         ("max_attempts", C.c_int), ("solver", C.c_int)]
 
         self.Config = Config
-        self.solver = {"Tsit5": 0, "DP5": 1}[solver]
+        self.solver = {"Tsit5": 0, "DP5": 1, "DOP853": 2}[solver]
+        self.lib.orc_stage_count.restype = C.c_int
+        self.S = int(self.lib.orc_stage_count(C.c_int(self.solver)))      # stages incl. the closing (first-same-as-last) one: 7, 7, 13
         self.cfg = Config(arch, reltol, abstol, reg_kind, cb_save_start, track_ctrl, track_initdt, max_attempts, self.solver)
         self.arch = arch
         L = self.lib
@@ -159,7 +161,7 @@ class Oracle:
         self.lib.orc_set_sum_order(C.c_int(self.sum_order))
         uprev = self._arr(uprev); k1 = self._arr(k1); p = self._arr(p)
         B = uprev.shape[0]
-        kout = np.empty((6, B, self.D), dtype=self.dtype)
+        kout = np.empty((self.S - 1, B, self.D), dtype=self.dtype)
         unew = np.empty_like(uprev)
         eest = self.real(0)
         eig = self.real(0)
@@ -215,7 +217,7 @@ class Oracle:
         return xbar, pbar, tsb
 
     def tableau(self):
-        a = np.zeros((7, 7)); c = np.zeros(7); bt = np.zeros(7)
+        a = np.zeros((self.S, self.S)); c = np.zeros(self.S); bt = np.zeros(self.S)
         self.lib.orc_tableau_of(C.c_int(self.solver), self._p(a), self._p(c), self._p(bt))
         return a, c, bt
 

@@ -38,9 +38,20 @@ RcclApi& api() {
     static RcclApi a;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            a.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        // An RCCL that is ALREADY in the process wins (PyTorch bundles its own copy: two instances in one process would each keep their own
+        // topology, proxy threads and IPC handles): first the loaded image under any of its names (RTLD_NOLOAD), then whatever exports
+        // ncclAllReduce globally; only then is the library loaded by name.  rnde_comm_library() says which file was bound.
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* name : names) {
+            a.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
             if (a.lib) break;
+        }
+        if (!a.lib && dlsym(RTLD_DEFAULT, "ncclAllReduce")) a.lib = dlopen(nullptr, RTLD_NOW);
+        if (!a.lib) {
+            for (const char* name : names) {
+                a.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+                if (a.lib) break;
+            }
         }
         if (!a.lib) { a.err = std::string("cannot load RCCL: ") + dlerror(); return; }
         auto sym = [&](const char* s) { void* p = dlsym(a.lib, s); if (!p && a.err.empty()) a.err = std::string("RCCL symbol missing: ") + s; return p; };
@@ -54,6 +65,19 @@ RcclApi& api() {
 }
 
 thread_local std::string g_comm_err;
+
+}  // namespace
+
+extern "C" const char* rnde_comm_library(void) {
+    static std::string path;
+    RcclApi& a = api();
+    if (!a.AllReduce) return a.err.c_str();
+    Dl_info info;
+    path = (dladdr((void*)a.AllReduce, &info) && info.dli_fname) ? info.dli_fname : "(unknown)";
+    return path.c_str();
+}
+
+namespace {
 
 __global__ void rnde_scale_kernel(float* __restrict__ v, long long n, float s) {
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) v[i] *= s;

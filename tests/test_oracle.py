@@ -415,3 +415,43 @@ def test_oracle_reproduces_device_order_golden():
         assert np.array_equal(r["steps"][:, 3], g["steps_devorder"][:, 3])
         np.testing.assert_allclose(r["steps"][:, :3], g["steps_devorder"][:, :3], rtol=2e-3)       # (bit-equal on the image's libm; exp2 may differ in the last place elsewhere)
         assert np.abs(r["u"] - g["u_devorder"]).max() <= 1e-6
+
+
+def test_dop853_table_matches_scipy_step_for_step_and_differentiates():
+    """The S-stage form of the tableau-as-data path (round 3): cfg.solver = DOP853 = scipy's 12 stages + the closing
+    evaluation as a 13-stage first-same-as-last pair (oracle/rk_tables.h, generated from scipy.integrate._ivp.dop853_coefficients), error
+    weights E5.  One step from (t, y, f(t, y)) with a given h against scipy's rk_step -- all stage values, y_new, f_new -- and the linear
+    fifth-order error norm; NFE = 3 + 12 per attempt; a solve against scipy's own DOP853 at a tight tolerance; the reverse pass (the
+    controller with the order-8 exponents included) against finite differences.  Vern7 would be an 11-row table of the same shape."""
+    from scipy.integrate import solve_ivp
+    from scipy.integrate._ivp import dop853_coefficients as d
+    from scipy.integrate._ivp.rk import rk_step
+    arch = arch_latent()
+    rng = np.random.default_rng(1)
+    p = glorot_params(arch, rng, np.float64, 2.0)
+    x = rng.standard_normal((4, 20))
+    o = Oracle(arch, np.float64, 1e-6, 1e-6, reg_kind=1, solver="DOP853", max_attempts=200)
+    assert o.S == 13
+    a, c, bt = o.tableau()
+    assert np.allclose(a[:12, :12], d.A[:12, :12], atol=0) and np.allclose(a[12, :12], d.B, atol=0) and np.allclose(bt, d.E5, atol=0)
+    assert np.allclose(a.sum(1), c, atol=1e-14) and c[12] == 1.0
+    t, h = 0.1, 0.07
+    k1 = o.f_eval(p, x, t)
+    kout, unew, eest, _ = o.attempt(p, x, k1, t, h)
+
+    def fun(tt, y):
+        return o.f_eval(p, y.reshape(4, 20), tt).reshape(-1)
+    K = np.empty((13, 80))
+    y_new, f_new = rk_step(fun, t, x.reshape(-1), k1.reshape(-1), h, d.A[:12, :12], d.B, d.C[:12], K)
+    assert np.abs(unew.reshape(-1) - y_new).max() <= 1e-14 and np.abs(kout[-1].reshape(-1) - f_new).max() <= 1e-13
+    assert np.abs(kout[:11].reshape(11, -1) - K[1:12]).max() <= 1e-13
+    scale = 1e-6 + np.maximum(np.abs(x.reshape(-1)), np.abs(y_new)) * 1e-6
+    err5 = abs(h) * np.sqrt(np.mean((K.T @ d.E5 / scale) ** 2))
+    assert abs(eest - err5) <= 1e-8 * err5
+    r = o.forward(x, p)
+    assert r["rc"] == 0 and r["nfe"] == 3 + 12 * r["nattempts"]
+    ref = solve_ivp(fun, (0.0, 1.0), x.reshape(-1), method="DOP853", rtol=1e-11, atol=1e-13)
+    assert np.abs(r["u"].reshape(-1) - ref.y[:, -1]).max() <= 1e-6
+    assert o.forward(x, p, saveat=np.array([0.5, 1.0]))["rc"] == 5          # no dense output in this table: refused, not approximated
+    ep, ex, et, _ = _fd_check(arch_test_node(), 3, 1e-4, 3.0, 0, solver="DOP853")
+    assert ep < 1e-5 and ex < 1e-5 and et < 1e-5

@@ -50,7 +50,11 @@ typedef enum { RNDE_ACT_IDENTITY = 0, RNDE_ACT_TANH = 1 } rnde_act;
 /* RNDE_SOLVER_TSIT5: every reference call site (experiments/mnist_node.jl:62-103, latent_ode.jl:131-136), all engines.
  * RNDE_SOLVER_DP5: Dormand-Prince 5(4), the second 7-stage first-same-as-last pair, through the tableau-as-data kernels of the chain
  * engine (Dense chains of width <= 64; callbacks none / EEst*dt): there a pair of that shape is a table, not a kernel. */
-typedef enum { RNDE_SOLVER_TSIT5 = 0, RNDE_SOLVER_DP5 = 1 } rnde_solver;
+/* RNDE_SOLVER_DOP853: Hairer's 8(5,3) pair as a 13-stage first-same-as-last TABLE (csrc/rk_tables.h, generated from scipy's coefficients;
+ * linear fifth-order error estimate, controller exponents for order 8): the same kernels with stage count, tape layout and evaluation
+ * counts read from the table -- what a Verner pair (Vern7, 10 stages + the closing evaluation) would be once its
+ * coefficients are at hand.  End state only (no dense output in the table); callbacks none / EEst*dt; NFE = 3 + 12 per attempted step. */
+typedef enum { RNDE_SOLVER_TSIT5 = 0, RNDE_SOLVER_DP5 = 1, RNDE_SOLVER_DOP853 = 2 } rnde_solver;
 /* func passed to the layer call (neural_ode.jl:116; experiments/mnist_node.jl:67,:74-79,:88-97) */
 typedef enum { RNDE_REG_NONE = 0, RNDE_REG_ERR = 1, RNDE_REG_STIFF = 2, RNDE_REG_ERR_STIFF = 3 } rnde_reg;
 

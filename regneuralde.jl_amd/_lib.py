@@ -27,7 +27,7 @@ class NsdeConfig(C.Structure):
                 ("qoldinit", C.c_float), ("delta", C.c_float), ("generic", C.c_int32)]
 
 
-ODE_SOLVER = {"Tsit5": 0, "AutoTsit5": 0, "DP5": 1}
+ODE_SOLVER = {"Tsit5": 0, "AutoTsit5": 0, "DP5": 1, "DOP853": 2}
 SDE_SOLVER = {"SOSRI": 0, "SRIW1": 1, "SOSRI2": 2}
 
 

@@ -10,6 +10,7 @@
 #include "rnde_binit_stage.h"
 #include "rnde_head.h"
 #include "rnde_chain.h"
+#include "rk_tables.h"
 #include "rnde_bchain.h"
 #include "rnde_chainmw.h"
 #include "rnde_bchainmw.h"
@@ -49,7 +50,8 @@ struct rnde_node {
     size_t chain_lds_f = 0, chain_lds_b = 0;
     // multi-wave kernels of the chain engine (rnde_chainmw.h): 4 waves per 16 columns, activations taped in the slab by the forward
     rnde_comm* couple = nullptr; int couple_batch = 0, couple_world = 1;   // SURVEY 8e mode 2 (rnde_node_set_coupling)
-    int rk_tab = 0; RkTab rk{};   // explicit RK pair as data (DP5, or Tsit5 through the same path when RNDE_CHAIN_TAB=1)
+    int rk_tab = 0; RkTab rk{};   // explicit RK pair as data: 1 = a 7-stage pair (DP5, or Tsit5 through the same path when RNDE_CHAIN_TAB=1), 2 = S stages (DOP853)
+    int rk_S = 7, rk_order = 5;   // stages of the pair in first-same-as-last form (evaluations per attempted step = rk_S - 1), controller order
     int mw_lat = 0;               // the reference's latent-ODE shape (20 <-> 50, 8 layers): forward kernels with register-stationary weights
     int mw = 0; MwGeo mg{}; float* mw_tab = nullptr; float* mw_slab = nullptr; long long mw_slab_evals = 0; size_t mw_lds_f = 0, mw_lds_b = 0;
     float* cslab = nullptr; size_t cslab_floats = 0; float* ev_t = nullptr; float* h_ev_t = nullptr;   // chain reverse: (H, Z) dump, evaluation times
@@ -142,6 +144,7 @@ static StepParams make_params(rnde_node* h, const float* x, int B, float t0, flo
     P.xvec = ((h->D & 3) == 0 && ((uintptr_t)x & 15) == 0) ? 1 : 0;
     P.reg_kind = h->cfg.regularize;
     P.replay = nullptr; P.n_replay = 0;
+    P.beta1 = (float)(7.0 / (10.0 * h->rk_order)); P.beta2 = (float)(2.0 / (5.0 * h->rk_order)); P.rk_order = (float)h->rk_order;   // (order 5: kBeta1, kBeta2 bit for bit)
     return P;
 }
 
@@ -264,9 +267,26 @@ static rnde_status chain_create(const rnde_node_config* c, rnde_node** out) {
             const char* e = getenv("RNDE_CHAIN_LAT");
             h->mw_lat = (lat && !(e && e[0] == '0')) ? 1 : 0;
         }
-        if (c->solver == RNDE_SOLVER_DP5 && !h->mw) { g_create_err = "DP5 needs the multi-wave kernels (weights must fit LDS)"; delete h; return RNDE_ERR_BAD_ARG; }
+        if ((c->solver == RNDE_SOLVER_DP5 || c->solver == RNDE_SOLVER_DOP853) && !h->mw) { g_create_err = "DP5 / DOP853 need the multi-wave kernels (weights must fit LDS)"; delete h; return RNDE_ERR_BAD_ARG; }
         h->rk_tab = (h->mw && (c->solver == RNDE_SOLVER_DP5 || getenv("RNDE_CHAIN_TAB") != nullptr)) ? 1 : 0;
-        if (h->rk_tab) {
+        if (c->solver == RNDE_SOLVER_DOP853) {
+            // an S-stage pair as a table (csrc/rk_tables.h): the kernels take stage count, tape layout and evaluation counts from it.  Neither a
+            // dense output nor the stiffness estimate (k_S - k_{S-1} is not an eigenvalue estimate for an arbitrary pair) exist for it.
+            if (c->regularize >= 2) { g_create_err = "DOP853: callbacks none / error_est only (no stiffness estimate for a table pair)"; delete h; return RNDE_ERR_BAD_ARG; }
+            h->rk_tab = 2; h->mw_lat = 0; h->rk_S = kDop853S; h->rk_order = kDop853Order;
+            RkTab& T = h->rk;
+            T = RkTab{};
+            T.S = h->rk_S; T.order = h->rk_order;
+            for (int sI = 0; sI < T.S; ++sI) {
+                T.c[sI] = (float)kDop853C[sI]; T.bt[sI] = (float)kDop853Bt[sI];
+                for (int i = 0; i < kRkSMax - 1; ++i) {
+                    T.fwd[sI][i] = (sI + 1 + i < T.S) ? (float)kDop853A[sI + 1 + i][sI] : 0.f;
+                    T.bwd[sI][i] = (sI - 1 - i >= 0) ? (float)kDop853A[sI][sI - 1 - i] : 0.f;
+                }
+            }
+            for (int j = 0; j < T.S; ++j) T.aN[j] = (float)kDop853A[T.S - 1][j];
+        }
+        if (h->rk_tab == 1) {
             double A[7][7] = {{0}}, Cn[7], BT[7], Dn[7][4];
             if (c->solver == RNDE_SOLVER_DP5) {   // Dormand & Prince 1980; dense output: Shampine 1986 (the matrix scipy's RK45 uses)
                 const double a[7][7] = {{0}, {1.0 / 5}, {3.0 / 40, 9.0 / 40}, {44.0 / 45, -56.0 / 15, 32.0 / 9}, {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729},
@@ -296,18 +316,19 @@ static rnde_status chain_create(const rnde_node_config* c, rnde_node** out) {
             }
             RkTab& T = h->rk;
             T = RkTab{};
+            T.S = 7; T.order = 5;
             for (int sI = 0; sI < 7; ++sI) {
                 T.c[sI] = (float)Cn[sI]; T.bt[sI] = (float)BT[sI];
                 for (int i = 0; i < 6; ++i) { T.fwd[sI][i] = (sI + 1 + i < 7) ? (float)A[sI + 1 + i][sI] : 0.f; T.bwd[sI][i] = (sI - 1 - i >= 0) ? (float)A[sI][sI - 1 - i] : 0.f; }
                 for (int j = 0; j < 4; ++j) T.dense[sI][j] = (float)Dn[sI][j];
             }
-            for (int j = 0; j < 7; ++j) T.a7[j] = (float)A[6][j];
+            for (int j = 0; j < 7; ++j) T.aN[j] = (float)A[6][j];
         }
     }
     h->chain_lds_f = lds_f; h->chain_lds_b = lds_b;
     if (hipSetDevice(c->device) != hipSuccess) { g_create_err = "hipSetDevice failed"; delete h; return RNDE_ERR_HIP; }
     const size_t Ac = (size_t)ntiles * h->NKD * 64;   // fragment-order arrays are padded to NKD k-steps
-    h->rec_stride = ChainRec{(long long)Ac}.total();
+    h->rec_stride = ChainRec{(long long)Ac, h->rk_S}.total();
     auto dm = [&](void** p, size_t bytes) { return hipMalloc(p, bytes) == hipSuccess; };
     bool ok = true;
     ok &= dm((void**)&h->f0, Ac * 4) && dm((void**)&h->u1, Ac * 4) && dm((void**)&h->f1, Ac * 4) && dm((void**)&h->xcopy, (size_t)h->D * h->Bpad_max * 4);
@@ -373,6 +394,13 @@ static hipError_t launch_mw_t(rnde_node* h, const MwParams& Q, int n, hipStream_
 }
 template <int MODE>
 static hipError_t launch_mw(rnde_node* h, const MwParams& Q, int n, hipStream_t s) {
+    if (h->rk_tab == 2) {      // S-stage table
+        switch (h->NKD) {
+            case 4: return launch_mw_t<1, MODE, 2>(h, Q, n, s);
+            case 8: return launch_mw_t<2, MODE, 2>(h, Q, n, s);
+            default: return launch_mw_t<4, MODE, 2>(h, Q, n, s);
+        }
+    }
     if (h->mw_lat) return h->rk_tab ? launch_mw_t<2, MODE, 1, 1>(h, Q, n, s) : launch_mw_t<2, MODE, 0, 1>(h, Q, n, s);   // latent-ODE shape: weights register stationary
     if (h->rk_tab) {
         switch (h->NKD) {
@@ -426,12 +454,12 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= c->device) { g_create_err = "no HIP device"; return RNDE_ERR_NO_DEVICE; }
-    if ((c->solver != RNDE_SOLVER_TSIT5 && c->solver != RNDE_SOLVER_DP5) || c->n_layers < 1 || c->n_layers > RNDE_MAX_LAYERS || c->dims[0] != c->dims[c->n_layers]) {
+    if ((c->solver != RNDE_SOLVER_TSIT5 && c->solver != RNDE_SOLVER_DP5 && c->solver != RNDE_SOLVER_DOP853) || c->n_layers < 1 || c->n_layers > RNDE_MAX_LAYERS || c->dims[0] != c->dims[c->n_layers]) {
         g_create_err = "unsupported configuration: Tsit5 (or DP5) over a Dense chain with dims[0] == dims[n_layers]"; return RNDE_ERR_BAD_ARG;
     }
     const bool mnist_form = c->n_layers == 2 && c->time_dep && !c->pre_act && c->act[0] == RNDE_ACT_TANH;
-    if (c->solver == RNDE_SOLVER_DP5 && ((mnist_form && c->col_tile != 65) || c->col_tile == 64 || c->regularize >= RNDE_REG_STIFF)) {
-        g_create_err = "DP5 runs on the tableau-as-data kernels of the chain engine (col_tile 0 for Dense chains of width <= 64, or 65), callbacks none / EEst*dt";
+    if ((c->solver == RNDE_SOLVER_DP5 || c->solver == RNDE_SOLVER_DOP853) && ((mnist_form && c->col_tile != 65) || c->col_tile == 64 || c->regularize >= RNDE_REG_STIFF)) {
+        g_create_err = "DP5 / DOP853 run on the tableau-as-data kernels of the chain engine (col_tile 0 for Dense chains of width <= 64, or 65), callbacks none / EEst*dt";
         return RNDE_ERR_BAD_ARG;
     }
     if (c->col_tile == 64 || c->col_tile == 65 || !mnist_form) return chain_create(c, out);   // small-width chains (latent_ode.jl:113-124): rnde_chain.h
@@ -773,6 +801,7 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
     hipStream_t s = (hipStream_t)stream;
     if (n_saveat > 0) {
         if (h->engine == 1) { h->err = "saveat is not available on the column-owner engine (col_tile 4/8)"; return RNDE_ERR_BAD_ARG; }
+        if (h->rk_tab == 2) { h->err = "saveat: this Runge-Kutta table carries no dense output (DOP853)"; return RNDE_ERR_BAD_ARG; }
         for (int i = 0; i < n_saveat; ++i)
             if (!(saveat_host[i] >= t0 && saveat_host[i] <= t1) || (i > 0 && !(saveat_host[i] > saveat_host[i - 1]))) {
                 h->err = "saveat must be increasing and inside [t0, t1]"; return RNDE_ERR_BAD_ARG;
@@ -830,7 +859,7 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
     if (h->engine == 3) {
         CQ = make_chain_params(h, P);
         if (h->mw) {
-            if (keep_tape) { st = ensure_mw_slab(h, 2 + 6LL * std::max(4, h->predicted), P.Bpad, s); if (st != RNDE_OK) return st; }
+            if (keep_tape) { st = ensure_mw_slab(h, 2 + (long long)(h->rk_S - 1) * std::max(4, h->predicted), P.Bpad, s); if (st != RNDE_OK) return st; }
             MQ = make_mw_params(h, P);
             HIPCHK(h, launch_mw<MW_INIT_A>(h, MQ, 0, s));
             HIPCHK(h, launch_mw<MW_INIT_B>(h, MQ, 0, s));
@@ -858,7 +887,7 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
     if (h->timing) HIPCHK(h, hipEventRecord(h->tev[0], s));
     while (true) {
         if (h->engine == 3 && h->mw && keep_tape) {   // room in the activation slab for this chunk's evaluations (a regrowth keeps the taped ones)
-            st = ensure_mw_slab(h, 2 + 6LL * std::min(cap, launched + chunk), P.Bpad, s);
+            st = ensure_mw_slab(h, 2 + (long long)(h->rk_S - 1) * std::min(cap, launched + chunk), P.Bpad, s);
             if (st != RNDE_OK) return st;
             MQ.slab = h->mw_slab;
         }
@@ -938,7 +967,7 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
         h->persist = 1; h->persist_retry_after = std::min(1024, 2 * h->persist_retry_after);
         h->tslab_Bpad = -1;                          // slabs are refilled with the empty pattern before the next persistent launch
     }
-    if (nfe_out) *nfe_out = 3 + 6 * (int64_t)h->n_att;  // 2 (initial dt) + 1 (fsalfirst) + 6 per attempt, SURVEY.md B.1-B.2
+    if (nfe_out) *nfe_out = 3 + (int64_t)(h->rk_S - 1) * h->n_att;  // 2 (initial dt) + 1 (fsalfirst) + 6 per attempt (S - 1 for an S-stage table), SURVEY.md B.1-B.2
     // saving callback values (reference neural_ode.jl:116,:126-127): EEst*dt per accepted step
     int nsv = 0;
     h->sv_index.assign(h->n_att, -1);
@@ -1108,8 +1137,8 @@ extern "C" rnde_status rnde_debug_attempt(rnde_node* h, const float* uprev_dev, 
         if (h->mw) { HIPCHK(h, launch_mw<MW_STEP>(h, make_mw_params(h, P), 0, s)); HIPCHK(h, launch_mw<MW_FINISH>(h, make_mw_params(h, P), 1, s)); }
         else { HIPCHK(h, launch_chain<CM_STEP>(h, CQ, 0, nullptr, s)); HIPCHK(h, launch_chain<CM_FINISH>(h, CQ, 1, nullptr, s)); }
         HIPCHK(h, hipMemcpyAsync(h->h_ctl, h->ctl_final, sizeof(StepState), hipMemcpyDeviceToHost, s));
-        const ChainRec CL{(long long)CQ.ntiles * nks * 64};
-        for (int sidx = 2; sidx <= 7; ++sidx)
+        const ChainRec CL{(long long)CQ.ntiles * nks * 64, h->rk_S};
+        for (int sidx = 2; sidx <= h->rk_S; ++sidx)      // (k_out: rk_S - 1 arrays)
             HIPCHK(h, chain_convert(h->arena + CL.k(sidx), k_out_dev + (size_t)(sidx - 2) * h->D * B, h->D, B, CQ.ntiles, nks, 1, s));
         HIPCHK(h, chain_convert(h->arena + CL.unew(), unew_out_dev, h->D, B, CQ.ntiles, nks, 1, s));
         HIPCHK(h, hipStreamSynchronize(s));
@@ -1819,6 +1848,7 @@ static rnde_status chain_mw_bwd_run(rnde_node* h, const float* u_bar_dev, const 
     BwdBuffers& b = h->bw;
     const ChainGeo& G = h->cg;
     const int cap = h->cfg.max_attempts, ntiles_max = h->Bpad_max / 16;
+    const int E = h->rk_S - 1;      // evaluations per attempted step (6; S - 1 for an S-stage table)
     if (!b.ready) {
         const size_t Ac = (size_t)ntiles_max * h->NKD * 64;
         HIPCHK(h, hipMalloc((void**)&b.U, Ac * 4)); HIPCHK(h, hipMalloc((void**)&b.K1, Ac * 4)); HIPCHK(h, hipMalloc((void**)&b.UB1, Ac * 4));
@@ -1828,10 +1858,10 @@ static rnde_status chain_mw_bwd_run(rnde_node* h, const float* u_bar_dev, const 
         HIPCHK(h, hipMalloc((void**)&b.tspan_out, 2 * 4));
         HIPCHK(h, hipHostMalloc((void**)&b.h_svb, (size_t)cap * 4));
         HIPCHK(h, hipMalloc((void**)&b.slab, (size_t)96 * h->P * 4)); HIPCHK(h, hipMalloc((void**)&b.slab_r, (size_t)16 * h->P * 4));
-        HIPCHK(h, hipMalloc((void**)&h->ev_t, ((size_t)6 * cap + 2) * 4)); HIPCHK(h, hipHostMalloc((void**)&h->h_ev_t, ((size_t)6 * cap + 2) * 4));
+        HIPCHK(h, hipMalloc((void**)&h->ev_t, ((size_t)E * cap + 2) * 4)); HIPCHK(h, hipHostMalloc((void**)&h->h_ev_t, ((size_t)E * cap + 2) * 4));
         b.ready = true;
     }
-    const int n_att = h->n_att, n_evals = 6 * n_att + 2;
+    const int n_att = h->n_att, n_evals = E * n_att + 2;
     if (!h->mw_slab || h->mw_slab_evals < n_evals) { h->err = "activation slab missing: the forward was not taped on the multi-wave kernels"; return RNDE_ERR_NO_TAPE; }
     for (int i = 0; i < n_att; ++i)
         b.h_svb[i] = (saveval_bar_host && h->sv_index[i] >= 0) ? saveval_bar_host[h->sv_index[i]] : 0.f;
@@ -1855,7 +1885,7 @@ static rnde_status chain_mw_bwd_run(rnde_node* h, const float* u_bar_dev, const 
         h->h_ev_t[0] = h->t0; h->h_ev_t[1] = h->t0 + h->h_init->dt0;
         for (int n = 0; n < n_att; ++n) {
             const StepMeta& m = h->h_meta[n];
-            for (int sidx = 2; sidx <= 7; ++sidx) h->h_ev_t[2 + 6 * n + sidx - 2] = m.t + (h->rk_tab ? h->rk.c[sidx - 1] : tsC(sidx - 1)) * m.dt;
+            for (int sidx = 2; sidx <= h->rk_S; ++sidx) h->h_ev_t[2 + E * n + sidx - 2] = m.t + (h->rk_tab ? h->rk.c[sidx - 1] : tsC(sidx - 1)) * m.dt;
             sv_lo[n] = ns;
             if (m.flags & F_ACCEPT) {
                 const float tnew = m.t + m.dt;
@@ -1866,7 +1896,8 @@ static rnde_status chain_mw_bwd_run(rnde_node* h, const float* u_bar_dev, const 
     }
     HIPCHK(h, hipMemcpyAsync(h->ev_t, h->h_ev_t, (size_t)n_evals * 4, hipMemcpyHostToDevice, s));
     hipError_t e;
-    if (h->mw_lat) e = h->rk_tab ? launch_bmw_t<2, 1, 1>(h, Q, sv_lo, sv_hi, s) : launch_bmw_t<2, 0, 1>(h, Q, sv_lo, sv_hi, s);   // latent-ODE shape: transposed weights register stationary
+    if (h->rk_tab == 2) e = h->NKD == 4 ? launch_bmw_t<1, 2>(h, Q, sv_lo, sv_hi, s) : (h->NKD == 8 ? launch_bmw_t<2, 2>(h, Q, sv_lo, sv_hi, s) : launch_bmw_t<4, 2>(h, Q, sv_lo, sv_hi, s));
+    else if (h->mw_lat) e = h->rk_tab ? launch_bmw_t<2, 1, 1>(h, Q, sv_lo, sv_hi, s) : launch_bmw_t<2, 0, 1>(h, Q, sv_lo, sv_hi, s);   // latent-ODE shape: transposed weights register stationary
     else if (h->rk_tab) e = h->NKD == 4 ? launch_bmw_t<1, 1>(h, Q, sv_lo, sv_hi, s) : (h->NKD == 8 ? launch_bmw_t<2, 1>(h, Q, sv_lo, sv_hi, s) : launch_bmw_t<4, 1>(h, Q, sv_lo, sv_hi, s));
     else e = h->NKD == 4 ? launch_bmw_t<1, 0>(h, Q, sv_lo, sv_hi, s) : (h->NKD == 8 ? launch_bmw_t<2, 0>(h, Q, sv_lo, sv_hi, s) : launch_bmw_t<4, 0>(h, Q, sv_lo, sv_hi, s));
     HIPCHK(h, e);

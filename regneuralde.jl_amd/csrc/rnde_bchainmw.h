@@ -213,7 +213,9 @@ __global__ __launch_bounds__(kMwThreads) void rnde_bchainmw_kernel(const BMwPara
     const bool colok = gcol < P.B;
     const bool writer = (tile == 0 && tid == 0);
     const bool first = (n == Bq.n_att - 1);
-    const ChainRec L{(long long)Q.ntiles * NKD * 64};
+    constexpr int SM = TAB == 2 ? kRkSMax : 7;               // stages the register arrays are sized for
+    const int NS = TAB == 2 ? Q.rk.S : 7;                    // stages of the pair (rnde_chainmw.h: RkTab)
+    const ChainRec L{(long long)Q.ntiles * NKD * 64, NS};
     const size_t fo = (size_t)tile * NKD * 64 + tid;
     auto feat = [&](int r) { return (tid + 256 * r) >> 4; };
     auto valid = [&](int r) { return colok && feat(r) < P.D; };
@@ -223,14 +225,14 @@ __global__ __launch_bounds__(kMwThreads) void rnde_bchainmw_kernel(const BMwPara
     f32x4 pe[4];
     if (!first) bpart_request(Bq, n + 1, lane, pe);
     const float* R = P.arena + (long long)m.rec * P.rec_stride;
-    float kq[7][NR], upv[NR], unv[NR];
+    float kq[SM][NR], upv[NR], unv[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         upv[r] = R[L.upc() + fo + 256 * r];
         unv[r] = R[L.unew() + fo + 256 * r];
         kq[0][r] = R[L.k1c() + fo + 256 * r];
 #pragma unroll
-        for (int j = 1; j < 7; ++j) kq[j][r] = R[L.k(j + 1) + fo + 256 * r];
+        for (int j = 1; j < SM; ++j) kq[j][r] = (TAB != 2 || j < NS) ? R[L.k(j + 1) + fo + 256 * r] : 0.f;
     }
     LatWeightsT LT;
     if constexpr (LAT) lat_load_t(G, Q.tab, LT, wave, lane);      // (the latent-ODE shape: transposed fragments in registers, no LDS fill)
@@ -261,17 +263,17 @@ __global__ __launch_bounds__(kMwThreads) void rnde_bchainmw_kernel(const BMwPara
             qoldb_in = qoldb;
         }
         if (!(m.flags & F_QCLAMP) && !(m.flags & F_EZERO)) {
-            const double qo = pow((double)m.qold_in, (double)kBeta2);
+            const double qo = pow((double)m.qold_in, (double)P.beta2);
             q11b += qb / (qo * (double)kGamma);
-            qoldb_in += -(double)kBeta2 * qb * (double)m.q / (double)m.qold_in;
+            qoldb_in += -(double)P.beta2 * qb * (double)m.q / (double)m.qold_in;
         }
-        if (!(m.flags & F_EZERO) && m.eest > 0.f) eb += q11b * (double)kBeta1 * (double)m.q11 / (double)m.eest;
+        if (!(m.flags & F_EZERO) && m.eest > 0.f) eb += q11b * (double)P.beta1 * (double)m.q11 / (double)m.eest;
         coef = m.eest > 0.f ? (float)(eb / (N * (double)m.eest)) : 0.f;
         if (writer) { BState b; b.tb_pre = tb; b.dtb_pre = dtb_pre; b.qoldb = qoldb_in; b.t1b = t1b; b.t0b = t0b; b.pad[0] = b.pad[1] = b.pad[2] = 0; Bq.bstate[n & 1] = b; }
     }
 
     float S = 0.f, tau = 0.f, ctau = 0.f;   // sum_j <k_j, kbar_j>; sum of time cotangents; c_s-weighted (+ extra dt-bar)
-    float* sl0 = Q.slab + (size_t)(2 + 6 * n) * Q.ev_stride + ((size_t)tile * G.RS) * 64;
+    float* sl0 = Q.slab + (size_t)(2 + (NS - 1) * n) * Q.ev_stride + ((size_t)tile * G.RS) * 64;
     const bool sv_mode = Q.nsave > 0;
     float utb[NR], unb[NR], upb[NR], k1v[NR], Wv[7][NR];
     // ---- A: reverse of the error estimate; seeds of unew-bar / uprev-bar ----
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(kMwThreads) void rnde_bchainmw_kernel(const BMwPara
         for (int r = 0; r < NR; ++r) {
             float acc = rk_bt<TAB>(Q.rk, 0) * kq[0][r];
 #pragma unroll
-            for (int j = 1; j < 7; ++j) acc += rk_bt<TAB>(Q.rk, j) * kq[j][r];
+            for (int j = 1; j < SM; ++j) acc += rk_bt<TAB>(Q.rk, j) * kq[j][r];      // (a table's weights are 0 past its last stage)
             float uin = 0.f;
             if (accepted) {
                 if (!first) uin = Bq.U[fo + 256 * r];
@@ -331,16 +333,18 @@ __global__ __launch_bounds__(kMwThreads) void rnde_bchainmw_kernel(const BMwPara
         }
     }
     // Rb[i] = cotangent of k_{s-i} (zero-based) where s is the next stage to be reversed (rolled loop, kBwdShift)
-    float Rb[6][NR], gb[NR], exk[NR], exg[NR];
+    float Rb[SM - 1][NR], gb[NR], exk[NR], exg[NR];
     const bool has_eig = (eig_c1 != 0.f || eig_c2 != 0.f);
     // ---- B: stage 7 (k7 = f(unew, t + dt)) ----
     {
         float k7[NR], unv7[NR], kb7[NR];
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            k7[r] = kq[6][r];                     // (k(7) and unew were read for the error estimate's reverse)
+            if constexpr (TAB == 2) k7[r] = R[L.k(NS) + fo + 256 * r];   // (the closing stage's value: a run-time index into kq would leave the registers)
+            else k7[r] = kq[6][r];                // (k(7) and unew were read for the error estimate's reverse)
             unv7[r] = unv[r];
-            kb7[r] = dt * (rk_bt<TAB>(Q.rk, 6) * utb[r] + Wv[6][r]);
+            if constexpr (TAB == 2) kb7[r] = dt * (rk_bt<TAB>(Q.rk, NS - 1) * utb[r]);
+            else kb7[r] = dt * (rk_bt<TAB>(Q.rk, 6) * utb[r] + Wv[6][r]);
             S += k7[r] * kb7[r];
             if (accepted && !first) kb7[r] += Bq.K1[fo + 256 * r];
             exk[r] = 0.f; exg[r] = 0.f;
@@ -352,13 +356,18 @@ __global__ __launch_bounds__(kMwThreads) void rnde_bchainmw_kernel(const BMwPara
             }
         }
         float t7 = 0.f;
-        fbwd(sl0 + 5 * Q.ev_stride, unv7, k7, kb7, gb, t7);
+        fbwd(sl0 + (size_t)(NS - 2) * Q.ev_stride, unv7, k7, kb7, gb, t7);
         tau += t7; ctau += t7;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             unb[r] += gb[r];
+            if constexpr (TAB == 2) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) Rb[i][r] = dt * (rk_a7<TAB>(Q.rk, 5 - i) * unb[r] + rk_bt<TAB>(Q.rk, 5 - i) * utb[r] + Wv[5 - i][r]);   // kbar_{5-i}
+                for (int i = 0; i < SM - 1; ++i) { const int j = NS - 2 - i; Rb[i][r] = j >= 0 ? dt * (Q.rk.aN[j] * unb[r] + Q.rk.bt[j] * utb[r]) : 0.f; }   // kbar_{NS-2-i}
+            } else {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) Rb[i][r] = dt * (rk_a7<TAB>(Q.rk, 5 - i) * unb[r] + rk_bt<TAB>(Q.rk, 5 - i) * utb[r] + Wv[5 - i][r]);   // kbar_{5-i}
+            }
             upb[r] += unb[r];
         }
     }
@@ -367,9 +376,12 @@ __global__ __launch_bounds__(kMwThreads) void rnde_bchainmw_kernel(const BMwPara
     //  fbwd of the rolled loop)
     float ksn[NR], gsn[NR];
 #pragma unroll
-    for (int r = 0; r < NR; ++r) { ksn[r] = kq[5][r]; gsn[r] = R[L.g(6) + fo + 256 * r]; }
+    for (int r = 0; r < NR; ++r) {
+        if constexpr (TAB == 2) ksn[r] = R[L.k(NS - 1) + fo + 256 * r]; else ksn[r] = kq[5][r];
+        gsn[r] = R[L.g(NS - 1) + fo + 256 * r];
+    }
 #pragma unroll 1
-    for (int s = 5; s >= 1; --s) {   // zero-based: k_s = f(g_s, t + c_s dt), taped as k(s+1), g(s+1)
+    for (int s = NS - 2; s >= 1; --s) {   // zero-based: k_s = f(g_s, t + c_s dt), taped as k(s+1), g(s+1)
         float ks[NR], gs[NR], kb[NR];
 #pragma unroll
         for (int r = 0; r < NR; ++r) { ks[r] = ksn[r]; gs[r] = gsn[r]; }
@@ -381,22 +393,22 @@ __global__ __launch_bounds__(kMwThreads) void rnde_bchainmw_kernel(const BMwPara
         for (int r = 0; r < NR; ++r) {
             kb[r] = Rb[0][r];
             S += ks[r] * kb[r];
-            if (has_eig && s == 5) kb[r] += exk[r];          // direct cotangent of k6
+            if (TAB != 2 && has_eig && s == 5) kb[r] += exk[r];          // direct cotangent of k6
         }
         float ts_ = 0.f;
         fbwd(sl0 + (size_t)(s - 1) * Q.ev_stride, gs, ks, kb, gb, ts_);
         tau += ts_; ctau += rk_c<TAB>(Q.rk, s) * ts_;
-        if (has_eig && s == 5) {
+        if (TAB != 2 && has_eig && s == 5) {
 #pragma unroll
             for (int r = 0; r < NR; ++r) gb[r] += exg[r];   // direct cotangent of g6
         }
-        float cb[5];
+        float cb[SM - 2];
 #pragma unroll
-        for (int i = 0; i < 5; ++i) cb[i] = dt * rk_bwd<TAB>(Q.rk, s, i);
+        for (int i = 0; i < SM - 2; ++i) cb[i] = dt * rk_bwd<TAB>(Q.rk, s, i);
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
 #pragma unroll
-            for (int i = 0; i < 5; ++i) Rb[i][r] = Rb[i + 1][r] + cb[i] * gb[r];
+            for (int i = 0; i < SM - 2; ++i) Rb[i][r] = Rb[i + 1][r] + cb[i] * gb[r];
             upb[r] += gb[r];
         }
     }
@@ -462,7 +474,7 @@ __global__ __launch_bounds__(kMwThreads) void rnde_bchainmw_init_kernel(const BM
         else if (ir.sel == 0) dt0b += 100.0 * dtb;
         else if (!ir.dt1_const) {
             const double mm = ir.max_is_d2 ? (double)ir.d2 : (double)ir.d1;
-            const double mb = dtb * (-0.2) * (double)ir.dt1 / mm;
+            const double mb = dtb * (-1.0 / (double)P.rk_order) * (double)ir.dt1 / mm;      // dt1 = 10^(-(2 + log10 m) / order)
             if (ir.max_is_d2) d2b += mb; else d1b += mb;
         } else if (dt0 * 1e-3f > 1e-6f) dt0b += 1e-3 * dtb;
         const double n2 = (double)ir.d2 * (double)dt0, n2b = d2b / (double)dt0;

@@ -53,12 +53,13 @@ struct ChainParams {
 //  forward evaluated)
 struct ChainRec {
     long long A;
-    __host__ __device__ long long k(int s) const { return (long long)(s - 2) * A; }   // s = 2..7
-    __host__ __device__ long long unew() const { return 6 * A; }
-    __host__ __device__ long long upc() const { return 7 * A; }
-    __host__ __device__ long long k1c() const { return 8 * A; }
-    __host__ __device__ long long g(int s) const { return (long long)(9 + s - 2) * A; }   // s = 2..6
-    __host__ __device__ long long total() const { return 14 * A; }
+    int S = 7;          // stages of the pair in first-same-as-last form (Tsit5, DP5: 7; a pair that comes as a table: RkTab.S)
+    __host__ __device__ long long k(int s) const { return (long long)(s - 2) * A; }   // s = 2..S
+    __host__ __device__ long long unew() const { return (long long)(S - 1) * A; }
+    __host__ __device__ long long upc() const { return (long long)S * A; }
+    __host__ __device__ long long k1c() const { return (long long)(S + 1) * A; }
+    __host__ __device__ long long g(int s) const { return (long long)(S + 2 + s - 2) * A; }   // s = 2..S-1
+    __host__ __device__ long long total() const { return 2LL * S * A; }
 };
 
 

@@ -34,21 +34,27 @@ struct MwGeo {
 // global table: [forward fragments | bias vectors 8 x 64 | time columns 8 x 64 | transposed fragments]
 __host__ __device__ inline size_t mw_tab_floats(const MwGeo& G) { return (size_t)(G.nfrag_f + G.nfrag_t) * 64 + 1024; }
 
-// An explicit Runge-Kutta pair as DATA (7 stages, first-same-as-last, embedded error weights, dense output as a polynomial in
-// theta): kernels instantiated with TAB = 1 take every coefficient from here instead of the Tsit5 constants of rnde_device.h, so
-// another pair of that shape is a table, not a kernel (RNDE_SOLVER_DP5: Dormand-Prince 5(4), validated against scipy's RK45).
+// An explicit Runge-Kutta pair as DATA, in first-same-as-last form: S stages of which the last one evaluates f at u_new (row S - 1 of the
+// stage matrix = the weights of u_new, c = 1), embedded error weights, the order the step-size controller uses.  Kernels instantiated with
+//   TAB = 1  take a 7-stage pair with a quartic dense output from here instead of the Tsit5 constants of rnde_device.h (RNDE_SOLVER_DP5:
+//            Dormand-Prince 5(4), validated against scipy's RK45),
+//   TAB = 2  take ANY pair of up to kRkSMax stages: stage loops, tape records and evaluation counts run on S (RNDE_SOLVER_DOP853: scipy's
+//            12 stages + the closing evaluation = 13, csrc/rk_tables.h; no dense output, no stiffness estimate).  A pair that is not
+//            first-same-as-last (Verner's Vern7: 10 stages) is the same table with one more row whose error weight is 0.
+constexpr int kRkSMax = 13;
 struct RkTab {
-    float fwd[7][6];     // fwd[s][i] = a_{s+1+i, s}   (as kFwdShift)
-    float bwd[7][6];     // bwd[s][i] = a_{s, s-1-i}   (as kBwdShift)
-    float a7[8];         // a_{7, j}: the weights of u_new
-    float bt[8], c[8];   // embedded error weights, nodes
-    float dense[7][4];   // b_i(theta) = sum_j dense[i][j] theta^(j+1)
+    int S, order;                        // 7 / 5 unless TAB = 2
+    float fwd[kRkSMax][kRkSMax - 1];     // fwd[s][i] = a_{s+1+i, s}   (as kFwdShift; 0 beyond the tableau)
+    float bwd[kRkSMax][kRkSMax - 1];     // bwd[s][i] = a_{s, s-1-i}   (as kBwdShift)
+    float aN[kRkSMax + 1];               // a_{S-1, j}: the weights of u_new
+    float bt[kRkSMax + 1], c[kRkSMax + 1];   // embedded error weights, nodes
+    float dense[7][4];                   // 7-stage pairs: b_i(theta) = sum_j dense[i][j] theta^(j+1)
 };
 template <int TAB> __device__ __forceinline__ float rk_fwd(const RkTab& T, int s, int i) { return TAB ? T.fwd[s][i] : kFwdShift[s][i]; }
 template <int TAB> __device__ __forceinline__ float rk_bwd(const RkTab& T, int s, int i) { return TAB ? T.bwd[s][i] : kBwdShift[s][i]; }
 template <int TAB> __device__ __forceinline__ float rk_bt(const RkTab& T, int j) { return TAB ? T.bt[j] : kTsBt[j]; }
 template <int TAB> __device__ __forceinline__ float rk_c(const RkTab& T, int s) { return TAB ? T.c[s] : kTsC[s]; }
-template <int TAB> __device__ __forceinline__ float rk_a7(const RkTab& T, int j) { return TAB ? T.a7[j] : kTsA[6][j]; }
+template <int TAB> __device__ __forceinline__ float rk_a7(const RkTab& T, int j) { return TAB ? T.aN[j] : kTsA[6][j]; }
 template <int TAB> __device__ __forceinline__ void rk_dense(const RkTab& T, float th, float (&b)[7]) {
     if (TAB) {
 #pragma unroll
@@ -282,7 +288,9 @@ __global__ __launch_bounds__(kMwThreads) void rnde_chainmw_kernel(const MwParams
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = blockIdx.x;
     const bool writer = (tile == 0 && tid == 0);
-    const ChainRec L{(long long)Q.ntiles * NKD * 64};
+    constexpr int SM = TAB == 2 ? kRkSMax : 7;               // stages the register arrays are sized for
+    const int NS = TAB == 2 ? Q.rk.S : 7;                    // stages of the pair (first-same-as-last form)
+    const ChainRec L{(long long)Q.ntiles * NKD * 64, NS};
     const size_t fo = (size_t)tile * NKD * 64 + tid;         // element r of this lane: fo + 256 r
     unsigned long long* dbg = nullptr;
 #ifdef RNDE_DIAG
@@ -308,7 +316,7 @@ __global__ __launch_bounds__(kMwThreads) void rnde_chainmw_kernel(const MwParams
         if (spec) {
             const float* Rs = P.arena + (long long)(n - 1) * P.rec_stride;
 #pragma unroll
-            for (int r = 0; r < NR; ++r) { sp_up[r] = Rs[L.unew() + fo + 256 * r]; sp_k[r] = Rs[L.k(7) + fo + 256 * r]; }
+            for (int r = 0; r < NR; ++r) { sp_up[r] = Rs[L.unew() + fo + 256 * r]; sp_k[r] = Rs[L.k(NS) + fo + 256 * r]; }
         }
     }
     // LAT: this wave's weight fragments in registers for the whole launch, nothing to fill (the LDS layout is kept: XB / YB sit where they sit)
@@ -449,36 +457,36 @@ __global__ __launch_bounds__(kMwThreads) void rnde_chainmw_kernel(const MwParams
         float* R = P.arena + (long long)rec * P.rec_stride;
         float part = 0.f, part1 = 0.f, part2 = 0.f;
         // Rolled stage loop with shifting partial sums, exactly as rnde_chain_kernel: Sa[i] = running combination of the i-th stage still to come
-        float up[NR], Sa[6][NR], E[NR], un[NR], g6[NR], k6[NR];
+        float up[NR], Sa[SM - 1][NR], E[NR], un[NR], g6[NR], k6[NR];
         const float* Rl = P.arena + (long long)(S.live < 0 ? 0 : S.live) * P.rec_stride;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             float k1;
             if (spec && S.live == n - 1) { up[r] = sp_up[r]; k1 = sp_k[r]; }      // (the step starts from what attempt n - 1 wrote: already here)
             else if (S.live < 0) { up[r] = ldx(P.x, r); k1 = P.f0[fo + 256 * r]; }
-            else { up[r] = Rl[L.unew() + fo + 256 * r]; k1 = Rl[L.k(7) + fo + 256 * r]; }
+            else { up[r] = Rl[L.unew() + fo + 256 * r]; k1 = Rl[L.k(NS) + fo + 256 * r]; }
             if (P.tape || P.nsave > 0) { R[L.upc() + fo + 256 * r] = up[r]; R[L.k1c() + fo + 256 * r] = k1; }
 #pragma unroll
-            for (int i = 0; i < 6; ++i) Sa[i][r] = rk_fwd<TAB>(Q.rk, 0, i) * k1;
+            for (int i = 0; i < SM - 1; ++i) Sa[i][r] = rk_fwd<TAB>(Q.rk, 0, i) * k1;
             E[r] = rk_bt<TAB>(Q.rk, 0) * k1;
             un[r] = up[r]; g6[r] = 0.f; k6[r] = 0.f;
         }
 #pragma unroll 1
-        for (int s = 1; s < 7; ++s) {   // zero-based stage: k_{s+1} = f(g_{s+1}, t + c_s dt)
+        for (int s = 1; s < NS; ++s) {   // zero-based stage: k_{s+1} = f(g_{s+1}, t + c_s dt)
             float gq[NR], kv[NR];
 #pragma unroll
             for (int r = 0; r < NR; ++r) gq[r] = up[r] + dt * Sa[0][r];
-            if (s == 6) {
+            if (s == NS - 1) {
 #pragma unroll
                 for (int r = 0; r < NR; ++r) { un[r] = gq[r]; R[L.unew() + fo + 256 * r] = gq[r]; }
             } else if (P.tape) {
 #pragma unroll
                 for (int r = 0; r < NR; ++r) R[L.g(s + 1) + fo + 256 * r] = gq[r];
             }
-            float* sl = (slab_tile && P.tape) ? slab_tile + (size_t)(2 + 6 * n + (s - 1)) * Q.ev_stride : nullptr;
-            MW_STAMP(2 + s);
+            float* sl = (slab_tile && P.tape) ? slab_tile + (size_t)(2 + (NS - 1) * n + (s - 1)) * Q.ev_stride : nullptr;
+            MW_STAMP(2 + (s < 7 ? s : 6));
             eval(t + rk_c<TAB>(Q.rk, s) * dt, gq, kv, sl, s == 1 ? dbg : nullptr);
-            if (s == 5 && P.reg_kind >= 2) {
+            if (s == 5 && P.reg_kind >= 2) {      // (stiffness estimate: 7-stage pairs only, the host refuses it otherwise)
 #pragma unroll
                 for (int r = 0; r < NR; ++r) { g6[r] = gq[r]; k6[r] = kv[r]; }
             }
@@ -487,15 +495,15 @@ __global__ __launch_bounds__(kMwThreads) void rnde_chainmw_kernel(const MwParams
                 for (int r = 0; r < NR; ++r) if (valid(r)) { const float d1 = kv[r] - k6[r], d2 = un[r] - g6[r]; part1 += d1 * d1; part2 += d2 * d2; }
             }
             const float bts = rk_bt<TAB>(Q.rk, s);
-            float cs[5];
+            float cs[SM - 2];
 #pragma unroll
-            for (int i = 0; i < 5; ++i) cs[i] = rk_fwd<TAB>(Q.rk, s, i);
+            for (int i = 0; i < SM - 2; ++i) cs[i] = rk_fwd<TAB>(Q.rk, s, i);
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
                 R[L.k(s + 1) + fo + 256 * r] = kv[r];
                 E[r] += bts * kv[r];
 #pragma unroll
-                for (int i = 0; i < 5; ++i) Sa[i][r] = Sa[i + 1][r] + cs[i] * kv[r];
+                for (int i = 0; i < SM - 2; ++i) Sa[i][r] = Sa[i + 1][r] + cs[i] * kv[r];
             }
         }
         // embedded error estimate, SURVEY.md B.3

@@ -180,6 +180,9 @@ struct StepParams {
     // replay (rnde_node_forward_replay): attempt n takes the proposed size replay[2n] and the accept decision replay[2n+1] != 0
     // instead of the controller's; the solve ends after n_replay attempts.  EEst, q11, q are still computed and recorded.
     const float* replay; int n_replay;
+    // step-size controller exponents and the order in the initial-step rule: 7 / (10 order), 2 / (5 order), order -- kBeta1, kBeta2, 5 for
+    // the order-5 pairs (every reference call site); another order only with a pair that comes as a table (RkTab.order, rnde_chainmw.h)
+    float beta1, beta2, rk_order;
 };
 
 // record layout inside the arena (floats): k2..k7 | g2..g6 | unew | h2..h7 | z1bar2..z1bar7

@@ -204,7 +204,7 @@ __device__ __forceinline__ StepState advance_state_t(const StepParams& P, int n,
             const float m = d1 > d2 ? d1 : d2;
             float dt1; int c1 = 0;
             if (m <= 1e-15f) { dt1 = fmaxf(1e-6f, dt0 * 1e-3f); c1 = 1; }
-            else dt1 = (float)pow(10.0, (double)(-(2.f + log10f(m)) / 5.f));
+            else dt1 = (float)pow(10.0, (double)(-(2.f + log10f(m)) / P.rk_order));
             float dt = 100.f * dt0; int sel = 0;
             if (dt1 < dt) { dt = dt1; sel = 1; }
             if (dtmax < dt) { dt = dtmax; sel = 2; }
@@ -239,8 +239,8 @@ __device__ __forceinline__ StepState advance_state_t(const StepParams& P, int n,
     else {
         if (eest == 0.f) { q = 1.f / kQmax; flags |= F_EZERO | F_QCLAMP; }
         else {
-            q11 = powf(eest, kBeta1);
-            q = q11 / powf(p.qold, kBeta2);
+            q11 = powf(eest, P.beta1);
+            q = q11 / powf(p.qold, P.beta2);
             const float qg = q / kGamma, lo = 1.f / kQmax, hi = 1.f / kQmin;
             if (qg < lo) { q = lo; flags |= F_QCLAMP; }
             else if (qg > hi) { q = hi; flags |= F_QCLAMP; }

@@ -134,9 +134,9 @@ class TrackedNeuralODE:
 
     def __init__(self, model, tspan, time_dep, regularize, solver="Tsit5", *, max_batch=512, max_attempts=128,
                  cb_save_start=True, track_ctrl=True, track_initdt=True, col_tile=0, **kwargs):
-        if solver not in ("Tsit5", "AutoTsit5", "DP5"):
-            raise ValueError("solver: the reference's call sites use Tsit5() / AutoTsit5(Tsit5()) only; DP5 is the second "
-                             "pair of the tableau-as-data kernels (Dense chains of width <= 64)")
+        if solver not in ("Tsit5", "AutoTsit5", "DP5", "DOP853"):
+            raise ValueError("solver: the reference's call sites use Tsit5() / AutoTsit5(Tsit5()) only; DP5 (a second 7-stage pair) and DOP853 "
+                             "(a 13-stage table) run on the tableau-as-data kernels (Dense chains of width <= 64)")
         self.solver = solver
         self.model = model
         self.p = destructure(model)                      # Flux.destructure (neural_ode.jl:12)

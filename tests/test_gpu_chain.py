@@ -390,3 +390,68 @@ def test_latent_shape_kernels_equal_the_generic_multi_wave_kernels(monkeypatch, 
     assert a["nfe"] == b["nfe"] and np.array_equal(a["u"], b["u"]) and np.array_equal(a["saveval"], b["saveval"])
     for u, v in zip(ga, gb):
         assert np.array_equal(u, v)
+
+
+# ---- an S-stage pair as a table (round 3): RNDE_SOLVER_DOP853 = scipy's DOP853 coefficients as a 13-stage first-same-as-last pair ----
+@pytest.mark.parametrize("kind,B", [("latent", 37), ("chain3", 19), ("small", 70)])
+def test_dop853_attempt_matches_oracle(kind, B, _mw_only):
+    """One attempted step of the 13-stage table on the device against the fp64 oracle (which reproduces scipy's rk_step to 1e-14,
+    tests/test_oracle.py): all twelve new stage values, u_new, the linear fifth-order error estimate."""
+    from tests.util import Node, Oracle
+    arch, p, x = _setup(kind, B, 2)
+    o64 = Oracle(arch, np.float64, reltol=1e-6, abstol=1e-6, solver="DOP853")
+    k1 = o64.f_eval(p, x, 0.1).astype(np.float32)
+    t, dt = 0.1, 0.2
+    kref, unew_ref, eest_ref, _ = o64.attempt(p, x, k1, t, dt)
+    kout, unew, eest = Node(_cfg(arch, B, reltol=1e-6, abstol=1e-6, solver="DOP853")).attempt(x, k1, p, t, dt)
+    assert kout.shape[0] == 12
+    assert np.abs(kout - kref).max() <= 3e-5
+    assert np.abs(unew - unew_ref).max() <= 3e-5
+    floor = 3 * 6e-8 * dt * np.abs(kref).max() / 1e-6
+    assert abs(eest - eest_ref) <= 2e-2 * eest_ref + floor
+    _, _, eest_ts, _ = Oracle(arch, np.float64, reltol=1e-6, abstol=1e-6).attempt(p, x, k1, t, dt)
+    assert abs(eest_ts - eest_ref) > 0.05 * eest_ref          # (a different method from Tsit5: the table is not ignored)
+
+
+@pytest.mark.parametrize("kind,B,tol,scale", [("latent", 70, 1e-4, 1.5), ("chain3", 33, 1e-4, 2.0), ("small", 20, 1e-5, 3.0), ("latent", 512, 1e-4, 1.5)])
+def test_dop853_solve_and_reverse_match_oracle(kind, B, tol, scale, _mw_only):
+    """The adaptive solve (controller exponents of order 8 from the table, NFE = 3 + 12 per attempt) and its reverse pass -- stage loops,
+    tape records and evaluation counts all run on the table's stage count -- against the fp64 oracle."""
+    from tests.util import Node, Oracle, rel_err
+    arch, p, x = _setup(kind, B, 3, scale)
+    o64 = Oracle(arch, np.float64, reltol=tol, abstol=tol, reg_kind=1, solver="DOP853")
+    o32 = Oracle(arch, np.float32, reltol=tol, abstol=tol, reg_kind=1, solver="DOP853")
+    r64, r32 = o64.forward(x, p), o32.forward(x, p)
+    node = Node(_cfg(arch, B, reltol=tol, abstol=tol, solver="DOP853"))
+    got = node.forward(x, p, keep_tape=True)
+    assert got["nfe"] == 3 + 12 * got["nattempts"]
+    assert got["nfe"] == r64["nfe"] == r32["nfe"] and (got["steps"][:, 3] == r64["steps"][:, 3]).all()
+    spread = np.abs(r32["u"] - r64["u"]).max(axis=1)
+    assert (np.abs(got["u"] - r64["u"]).max(axis=1) <= 3e-5 * max(1.0, np.abs(r64["u"]).max()) + 4 * spread).all()
+    # EEst * dt per accepted step: the estimate is a cancellation of twelve O(1) terms, in fp32 good to ~1e-5 absolute at these step sizes
+    np.testing.assert_allclose(got["saveval"], r64["saveval"], rtol=8e-2, atol=5e-3 * float(r64["saveval"].max()))
+    rng = np.random.default_rng(11)
+    ubar = rng.standard_normal(x.shape).astype(np.float32)
+    svbar = np.full(len(got["saveval"]), 30.0, dtype=np.float32)
+    gx, gp, gt = node.backward(ubar, svbar)
+    x64, p64, t64 = o64.backward(ubar.astype(np.float64), svbar.astype(np.float64))
+    x32, p32, _ = o32.backward(ubar, svbar)
+    cx, cp = rel_err(x32, x64), rel_err(p32, p64)
+    print(f"DOP853 {kind}: attempts {got['nattempts']}  x-bar {rel_err(gx, x64):.2e} ({cx:.2e})  p-bar {rel_err(gp, p64):.2e} ({cp:.2e})  tspan {gt} vs {t64}")
+    assert rel_err(gx, x64) <= 2e-3 + 4 * cx
+    assert rel_err(gp, p64) <= 2e-3 + 4 * cp
+    assert np.abs(gt - t64).max() <= (2e-3 + 4 * max(cx, cp)) * max(1.0, np.abs(t64).max())
+
+
+def test_dop853_is_refused_where_the_table_has_nothing_to_offer():
+    from tests.util import Node, arch_mnist
+    arch, p, x = _setup("latent", 8, 1)
+    assert Node(_cfg(arch, 8, col_tile=65, solver="DOP853")).forward(x, p)["nfe"] % 12 == 3                           # (the plain call works)
+    with pytest.raises(Exception):
+        Node(_cfg(arch, 8, col_tile=65, solver="DOP853")).forward_saveat(x, p, np.array([0.5, 1.0], np.float32))      # no dense output in the table
+    with pytest.raises(Exception):
+        Node(_cfg(arch, 8, col_tile=65, regularize=2, solver="DOP853"))                                  # no stiffness estimate
+    with pytest.raises(Exception):
+        Node(_cfg(arch, 8, col_tile=64, solver="DOP853"))                                                # one-wave kernels fold Tsit5 in
+    with pytest.raises(Exception):
+        Node(_cfg(arch_mnist(), 8, col_tile=16, solver="DOP853"))                                        # stage engine

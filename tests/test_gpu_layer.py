@@ -376,10 +376,9 @@ def test_adam_step_matches_the_torch_recurrence(rnde):
 def test_error_estimate_regulariser_lowers_nfe_at_held_accuracy():
     """The paper's claim on THIS implementation, shortened (tools/train_synth.py is the full record, profiles/r03_train_synth.json): the
     reference's training loop (experiments/mnist_node.jl:220-263 -- lambda 100 -> 10, InvDecay/Momentum, NFE probe on the fixed first
-    batch, accuracy of src/metrics.jl:4-18) on a learnable synthetic 10-class set, 4 epochs of 24 batches of 512 (the first four epochs of
-    the committed record), vanilla against the error-estimate regulariser: the regularised model needs FEWER function evaluations at an
-    accuracy no more than 2.5 points lower (record: NFE 615 -> 525 at 92.2 / 93.0 % test accuracy after epoch 4, 597 -> 525 at 93.5 / 92.6 %
-    after epoch 10)."""
+    batch, accuracy of src/metrics.jl:4-18) on a learnable synthetic 10-class set, 4 epochs of 24 batches of 512 (lambda decays 100 -> 10 over
+    these 4 epochs), vanilla against the error-estimate regulariser: the regularised model needs FEWER function evaluations at an accuracy no
+    more than 2.5 points lower (measured: NFE 615 -> 531 at 92.2 / 93.4 % test accuracy; the 10-epoch record: 597 -> 525 at 93.5 / 92.6 %)."""
     import importlib.util
     import os
     import torch

@@ -77,7 +77,8 @@ class Node:
     def attempt(self, uprev, k1, p, t, dt):
         B = uprev.shape[0]
         ud, kd, pd = self.dev(uprev), self.dev(k1), self.dev(p)
-        kout = torch.empty((6, B, self.D), dtype=torch.float32, device="cuda")
+        nk = 12 if self.cfg.solver == _lib.ODE_SOLVER["DOP853"] else 6      # stages after k1: 6 for the 7-stage pairs, S - 1 for a table
+        kout = torch.empty((nk, B, self.D), dtype=torch.float32, device="cuda")
         unew = torch.empty_like(ud)
         eest = C.c_float(0)
         _lib.check(self.h, self.L.rnde_debug_attempt(self.h, ud.data_ptr(), kd.data_ptr(), pd.data_ptr(), B, t, dt,

@@ -225,7 +225,7 @@ def bench_nsde(args):
     nsde = rn.TrackedNeuralDSDE(rn.Chain(rn.Dense(32, 64, "tanh", g), rn.Dense(64, 32, "identity", g)), rn.Dense(32, 32, "identity", g), [0.0, 1.0], True,
                                 "SOSRI", save_everystep=False, reltol=0.14, abstol=0.14, save_start=False, max_batch=B, max_attempts=256, seed=1999)
     model = rn.ClassifierNSDE(rn.Dense(784, 32, "identity", g), nsde, rn.Dense(32, 10, "identity", g), device=device)
-    opt = torch.optim.Adam(model.trainable(), lr=0.01) if args.autograd else rn.FluxADAM(model.trainable(), eta=0.01)   # ADAM(0.01), mnist_nsde.jl
+    opt = torch.optim.Adam(model.trainable(), lr=0.01) if args.autograd else rn.FluxADAM(model.trainable(), eta=0.01, gamma=1.0e-5)   # Optimiser(InvDecay(1.0e-5), ADAM(0.01)), mnist_nsde.jl
     x = torch.rand(B, 784, generator=g).to(device)
     y = torch.eye(NCLS)[torch.randint(0, NCLS, (B,), generator=g)].to(device)
     L = _lib.lib()
@@ -264,7 +264,7 @@ def bench_nsde(args):
             "mean_nfe1": sum(a for a, _ in nf) / len(nf), "mean_nfe2": sum(b for _, b in nf) / len(nf),
             "attempts_per_step": att, "accepted_per_step": acc, "solve_ms": sum(stats["solve_ms"]) / 3, "rev_sweep_ms": sum(stats["rev_ms"]) / 3,
             "config": {"workload": "MNIST NSDE regularized (error_est, lambda 10), SOSRI reltol=abstol=0.14, B=512, trajectories=1, diagonal noise; "
-                                   "step = ClassifierNSDE loss fwd + reverse + ADAM"},
+                                   "step = ClassifierNSDE loss fwd + reverse + InvDecay/ADAM update"},
             "roofline": {"bound": "mfma", "achieved": flops / (us_att * 1e-6) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                          "frac": flops / (us_att * 1e-6) / 1e12 / MFMA_F32_PEAK_TF, "traffic": None,
                          "kernel": "rnde_sde_solve_mw_kernel: the WHOLE adaptive solve = 1 launch, one workgroup of four waves per 16-column tile; "
@@ -466,7 +466,7 @@ def main():
         # reported when present, with their source
         try:
             import csv
-            for rnd in ((PROFILE_ROUND, "r01") if B == 512 else ()):      # the committed passes are of the B = 512 bench
+            for rnd in ((PROFILE_ROUND, "r02", "r01") if B == 512 else ()):      # the committed passes are of the B = 512 bench
                 pf = os.path.join(ROOT, "profiles", f"{rnd}_pmc_hbm_traffic.csv")
                 if not os.path.exists(pf):
                     continue

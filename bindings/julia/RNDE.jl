@@ -43,6 +43,21 @@ struct NodeConfig
     stage_generic::Int32
 end
 
+# ---- stream ordering contract ---------------------------------------------------------------------------
+# Every entry point below that enqueues work takes the HIP stream of the CURRENT Julia task (AMDGPU.jl arrays live on task-local
+# streams): the library's kernels are then ordered against the caller's own array operations on that task, and results read back
+# from Julia after the call (or after AMDGPU.synchronize() for the asynchronous ones: backward_async!, classifier_grad!,
+# momentum_step!, adam_step!, allreduce_sum!) are complete.  The NULL stream would only be ordered against task streams that
+# were created blocking, which AMDGPU.jl does not promise.
+function _stream()
+    try
+        return Base.unsafe_convert(Ptr{Cvoid}, AMDGPU.stream().stream)
+    catch
+        AMDGPU.synchronize()          # (an AMDGPU.jl without that accessor: fall back to the NULL stream behind a full synchronisation)
+        return C_NULL
+    end
+end
+
 mutable struct Handle
     ptr::Ptr{Cvoid}
     cfg::NodeConfig
@@ -85,7 +100,7 @@ function solve_forward(h::Handle, x::ROCMatrix{Float32}, p::ROCVector{Float32}, 
                    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Float32, Float32, Ptr{Cvoid}, Ref{Int64},
                     Ptr{Float32}, Ref{Int32}, Int32, Ptr{Cvoid}),
                    h.ptr, devptr(x), devptr(p), B, Float32(tspan[1]), Float32(tspan[2]), devptr(u), nfe,
-                   sv, nsv, keep_tape ? 1 : 0, C_NULL)
+                   sv, nsv, keep_tape ? 1 : 0, _stream())
         check(h, st)
     end
     return u, Int(nfe[]), sv[1:nsv[]]
@@ -109,7 +124,7 @@ function solve_forward_saveat(h::Handle, x::ROCMatrix{Float32}, p::ROCVector{Flo
                    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Float32, Float32, Ptr{Float32}, Int32, Ptr{Cvoid},
                     Ref{Int64}, Ptr{Float32}, Ref{Int32}, Int32, Ptr{Cvoid}),
                    h.ptr, devptr(x), devptr(p), B, Float32(tspan[1]), Float32(tspan[2]), saveat, length(saveat),
-                   devptr(u3), nfe, sv, nsv, keep_tape ? 1 : 0, C_NULL)
+                   devptr(u3), nfe, sv, nsv, keep_tape ? 1 : 0, _stream())
         check(h, st)
     end
     return u3, Int(nfe[]), sv[1:nsv[]]
@@ -123,7 +138,7 @@ function solve_backward(h::Handle, ubar::ROCArray{Float32}, svbar::Vector{Float3
     GC.@preserve ubar xbar pbar svbar tsbar begin
         st = ccall((:rnde_node_backward, LIB), Cint,
                    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float32}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float32}, Ptr{Cvoid}),
-                   h.ptr, devptr(ubar), svbar, devptr(xbar), devptr(pbar), tsbar, C_NULL)
+                   h.ptr, devptr(ubar), svbar, devptr(xbar), devptr(pbar), tsbar, _stream())
         check(h, st)
     end
     return xbar, pbar, tsbar
@@ -207,7 +222,7 @@ function nsde_forward(h::NsdeHandle, x::ROCMatrix{Float32}, p::ROCVector{Float32
                    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Float32, Float32, Ptr{Cvoid}, Int32, UInt64, Ptr{Cvoid},
                     Ref{Int64}, Ref{Int64}, Ptr{Float32}, Ref{Int32}, Int32, Ptr{Cvoid}),
                    h.ptr, devptr(x), devptr(p), B, Float32(tspan[1]), Float32(tspan[2]),
-                   noise === nothing ? C_NULL : devptr(noise), npool, UInt64(seed), devptr(u), nfe1, nfe2, sv, nsv, keep_tape ? 1 : 0, C_NULL)
+                   noise === nothing ? C_NULL : devptr(noise), npool, UInt64(seed), devptr(u), nfe1, nfe2, sv, nsv, keep_tape ? 1 : 0, _stream())
         st == 0 || error("rnde_nsde_forward status $st: ", unsafe_string(ccall((:rnde_nsde_last_error, LIB), Cstring, (Ptr{Cvoid},), h.ptr)))
     end
     return u, Int(nfe1[]), Int(nfe2[]), sv[1:nsv[]]
@@ -218,7 +233,7 @@ function nsde_backward(h::NsdeHandle, ubar::ROCMatrix{Float32}, svbar::Vector{Fl
     pbar = ROCArray{Float32}(undef, np)
     GC.@preserve ubar xbar pbar svbar begin
         st = ccall((:rnde_nsde_backward, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float32}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
-                   h.ptr, devptr(ubar), svbar, devptr(xbar), devptr(pbar), C_NULL)
+                   h.ptr, devptr(ubar), svbar, devptr(xbar), devptr(pbar), _stream())
         st == 0 || error("rnde_nsde_backward status $st")
     end
     return xbar, pbar
@@ -239,7 +254,7 @@ function classifier_grad!(p2bar::ROCVector{Float32}, p3bar::ROCVector{Float32}, 
               (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int32, Cfloat, Cfloat, Cfloat,
                Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Cfloat}, Ref{Int64}, Ptr{Cvoid}, Ptr{Cvoid}),
               h.ptr, devptr(x), devptr(p2), devptr(p3), devptr(y), size(x, 2), size(y, 1), Float32(tspan[1]), Float32(tspan[2]),
-              Float32(lambda), devptr(p2bar), devptr(p3bar), C_NULL, devptr(ce), reg, nfe, comm, C_NULL)
+              Float32(lambda), devptr(p2bar), devptr(p3bar), C_NULL, devptr(ce), reg, nfe, comm, _stream())
     end
     st == 0 || error("rnde_node_classifier_grad: ", unsafe_string(ccall((:rnde_last_error, LIB), Cstring, (Ptr{Cvoid},), h.ptr)))
     return ce, reg[], nfe[]
@@ -259,7 +274,7 @@ function nsde_classifier_grad!(p2bar::ROCVector{Float32}, p3bar::ROCVector{Float
                Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Cfloat}, Ref{Int64}, Ref{Int64}, Ptr{Cvoid}),
               h.ptr, devptr(x), devptr(p2), devptr(p3), devptr(y), size(x, 2), size(y, 1), Float32(tspan[1]), Float32(tspan[2]),
               noise === nothing ? C_NULL : devptr(noise), npool, UInt64(seed), Float32(lambda),
-              devptr(p2bar), devptr(p3bar), devptr(xbar), devptr(ce), reg, nfe1, nfe2, C_NULL)
+              devptr(p2bar), devptr(p3bar), devptr(xbar), devptr(ce), reg, nfe1, nfe2, _stream())
     end
     st == 0 || error("rnde_nsde_classifier_grad: ", unsafe_string(ccall((:rnde_nsde_last_error, LIB), Cstring, (Ptr{Cvoid},), h.ptr)))
     return ce, reg[], nfe1[], nfe2[]
@@ -273,7 +288,7 @@ function momentum_step!(p::ROCVector{Float32}, g::ROCVector{Float32}, v::ROCVect
     GC.@preserve p g v begin
         st = ccall((:rnde_momentum_step_scaled, LIB), Cint,
                    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Cfloat, Cfloat, Cfloat, Cfloat, Ptr{Cvoid}),
-                   devptr(p), devptr(g), devptr(v), length(p), n, gamma, eta, rho, gscale, C_NULL)
+                   devptr(p), devptr(g), devptr(v), length(p), n, gamma, eta, rho, gscale, _stream())
     end
     st == 0 || error("rnde_momentum_step_scaled: status $st")
     return p
@@ -284,7 +299,7 @@ function adam_step!(p::ROCVector{Float32}, g::ROCVector{Float32}, m::ROCVector{F
                     eta = 0.001f0, beta = (0.9f0, 0.999f0), eps = 1f-8, gscale = 1f0)
     st = GC.@preserve p g m v begin
         ccall((:rnde_adam_step, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Cfloat, Cfloat, Cfloat, Cfloat, Cfloat, Ptr{Cvoid}),
-              devptr(p), devptr(g), devptr(m), devptr(v), length(p), t, eta, beta[1], beta[2], eps, gscale, C_NULL)
+              devptr(p), devptr(g), devptr(m), devptr(v), length(p), t, eta, beta[1], beta[2], eps, gscale, _stream())
     end
     st == 0 || error("rnde_adam_step: status $st")
     return p
@@ -299,7 +314,7 @@ function comm_create(id::Vector{UInt8}, rank::Integer, world::Integer, device::I
     return out[]
 end
 allreduce_sum!(comm::Ptr{Cvoid}, g::ROCVector{Float32}) = GC.@preserve g begin
-    ccall((:rnde_comm_allreduce, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int32, Ptr{Cvoid}), comm, devptr(g), length(g), 0, C_NULL) == 0 ||
+    ccall((:rnde_comm_allreduce, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int32, Ptr{Cvoid}), comm, devptr(g), length(g), 0, _stream()) == 0 ||
         error("rnde_comm_allreduce")
     g
 end

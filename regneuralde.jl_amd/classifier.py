@@ -175,12 +175,15 @@ class FluxOptimiser:
 
 
 class FluxADAM:
-    """Flux.Optimise.ADAM(eta, (beta1, beta2)) (experiments/mnist_nsde.jl: ADAM(0.01)), group by group, one launch per group through
+    """Flux.Optimise.ADAM(eta, (beta1, beta2)), optionally behind InvDecay (experiments/mnist_nsde.jl: Optimiser(InvDecay(1.0e-5), ADAM(0.01))), group by group, one launch per group through
     the C ABI (rnde_adam_step); same recurrence as torch.optim.Adam (tests/test_gpu_layer.py)."""
 
-    def __init__(self, params, eta=0.001, beta=(0.9, 0.999), eps=1.0e-8):
+    def __init__(self, params, eta=0.001, beta=(0.9, 0.999), eps=1.0e-8, gamma=0.0):
+        """gamma > 0: Flux.Optimise.Optimiser(InvDecay(gamma), ADAM(eta)) as experiments/mnist_nsde.jl builds it -- InvDecay scales the gradient
+        by 1 / (1 + gamma n) (n = 1, 2, ... per group) BEFORE ADAM sees it; the factor rides in the launch's gradient scale."""
         self.params = [p for p in params if p.numel() > 0]
-        self.eta, self.beta, self.eps = eta, beta, eps
+        self.eta, self.beta, self.eps, self.gamma = eta, beta, eps, gamma
+        self.n = [1 for _ in self.params]                 # InvDecay state starts at 1
         self.t = 0
         self.m = [torch.zeros_like(p) for p in self.params]
         self.v = [torch.zeros_like(p) for p in self.params]
@@ -198,9 +201,10 @@ class FluxADAM:
                 raise RuntimeError("FluxADAM runs on the device only")
             g = g.contiguous()
             st = _lib.lib().rnde_adam_step(p.data_ptr(), g.data_ptr(), self.m[i].data_ptr(), self.v[i].data_ptr(), p.numel(), self.t, self.eta,
-                                           self.beta[0], self.beta[1], self.eps, float(grad_scale),
+                                           self.beta[0], self.beta[1], self.eps, float(grad_scale) / (1.0 + self.gamma * self.n[i]),
                                            C.c_void_p(torch.cuda.current_stream(p.device).cuda_stream))
             _lib.check(None, st)
+            self.n[i] += 1
             p.grad = None
 
 

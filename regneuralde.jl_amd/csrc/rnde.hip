@@ -704,7 +704,10 @@ static hipError_t stage_attempt(rnde_node* h, const StageParams& Q, int n, hipSt
         if (fix && Q.C % 2 == 0 && h->persist2 != 0 && (Q.C >= kPersist2MinTiles || h->persist2 >= 1)) {
             const dim3 grid2(8 * Q.R * ((Q.C / 2 + 7) / 8));
             const size_t lds2 = sizeof(float) * (2 * 2 * 16 * (16 * 7 + 4) + 32 * 3);
-            if (h->persist2 == 2) {      // (lock-step form: A/B only)
+            if (h->persist2 == 3) {      // (skewed form: MFMA step of one tile beside the element-wise step of the other)
+                if (h->act2) hipLaunchKernelGGL((rnde_stage_attempt_mt_kernel<1, 2, 2>), grid2, dim3(64 * 7), lds2, s, Q, n, Y);
+                else hipLaunchKernelGGL((rnde_stage_attempt_mt_kernel<0, 2, 2>), grid2, dim3(64 * 7), lds2, s, Q, n, Y);
+            } else if (h->persist2 == 2) {      // (lock-step form: A/B only)
                 if (h->act2) hipLaunchKernelGGL((rnde_stage_attempt_mt_kernel<1, 2, 0>), grid2, dim3(64 * 7), lds2, s, Q, n, Y);
                 else hipLaunchKernelGGL((rnde_stage_attempt_mt_kernel<0, 2, 0>), grid2, dim3(64 * 7), lds2, s, Q, n, Y);
             } else if (h->act2) hipLaunchKernelGGL((rnde_stage_attempt_mt_kernel<1, 2, 1>), grid2, dim3(64 * 7), lds2, s, Q, n, Y);

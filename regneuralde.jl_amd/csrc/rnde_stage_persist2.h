@@ -153,6 +153,156 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_attempt_mt_kernel(const Sta
     const bool own_hstore = rb == 0 && own_kind[3] == 0;
     if (tid == 0) RED[24] = 0.f;
 
+    float part0[NCT], part1[NCT], part2[NCT];
+#pragma unroll
+    for (int tt = 0; tt < NCT; ++tt) part0[tt] = part1[tt] = part2[tt] = 0.f;
+    bool alive = true;
+
+    if constexpr (ALT == 2) {
+        // ---- the SKEWED schedule: tile 1 runs one step behind tile 0, so that every slot between two barriers pairs the MFMA step of one
+        // ---- tile with the element-wise step of the other (tanh, combinations, tape stores, LDS staging, the hand-off poll) in ONE
+        // ---- instruction stream: the scheduler interleaves them, and the matrix pipe no longer idles while the vector ALU works.
+        //   a tile's stage s:  P1 poll + tanh -> HL | barrier | P2 layer-2 MFMAs + tanh | P3 combination -> GL | barrier | P4 layer-1 MFMAs + put
+        static_assert(NCT == 2, "the skewed schedule is written for two tiles");
+        f32x4 kvS[NCT];
+        auto p3_start = [&](auto tc) {
+            constexpr int tt = decltype(tc)::value;
+            const f32x4 v = fma4(dt, tsA(1, 0) * c_k[tt][0], c_up[tt]);
+            if (P.tape) st4(R + L.g(2) + co[tt], r0, gD, true, vec, v);
+            if (P.nsave > 0) { st4(R + L.upc() + co[tt], r0, gD, true, vec, c_up[tt]); st4(R + L.k1c() + co[tt], r0, gD, true, vec, c_k[tt][0]); }
+            float* gl = GL + tt * kSCB * KG + own_gl0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gl[4 * i] = v[i];
+        };
+        auto p4 = [&](auto sc, auto tc) {       // layer-1 partials of the stage input staged in GL[tt] -> exchange s + 1
+            constexpr int s = decltype(sc)::value, tt = decltype(tc)::value;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < 7; ++kb) {
+                const f32x4 bg = *(const f32x4*)(GL + tt * kSCB * KG + col * KG + 4 * (lane >> 4) + 16 * kb);
+                acc0 = mfma16(wD[kb][0], bg[0], acc0);
+                acc1 = mfma16(wD[kb][1], bg[1], acc1);
+                acc0 = mfma16(wD[kb][2], bg[2], acc0);
+                acc1 = mfma16(wD[kb][3], bg[3], acc1);
+            }
+            const size_t tile0 = (((size_t)slab_buf((unsigned)(s + 1)) * Q.C + ct[tt]) * gR + rb) * gHT;
+            slab_put(Y.tslab, tile0 + w, lane, acc0 + acc1);
+        };
+        auto p1 = [&](auto sc, auto tc) {       // poll exchange s, tanh, hidden activations -> HL[tt]
+            constexpr int s = decltype(sc)::value, tt = decltype(tc)::value;
+            const float ts = fmaf(tsC(s), dt, t);
+            f32x4 zs = {0.f, 0.f, 0.f, 0.f};
+            const bool dead = !slab_poll_sum(Y, slab_buf((unsigned)s), Q.C, gR, gHT, ct[tt], w, lane, zs);
+            const size_t tprev0 = (((size_t)slab_buf((unsigned)(s + 2)) * Q.C + ct[tt]) * gR + rb) * gHT;
+            if (!dead) slab_clear(Y.tslab, tprev0 + w, lane);
+            float pre[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pre[i] = fmaf(w1t_own[i], ts, zs[i]) + b1_own[i];
+            const f32x2 t01 = tanh_fast2((f32x2){pre[0], pre[1]}), t23 = tanh_fast2((f32x2){pre[2], pre[3]});
+            f32x4 hv = {t01.x, t01.y, t23.x, t23.y};
+            if (w == 6) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hv[i] = own_kind[i] == 0 ? hv[i] : fmaf(own_c1[i], ts, own_c0[i]);
+            }
+            if (own_hstore) *(f32x4*)(R + L.h(s + 1) + (size_t)gcol[tt] * gH + hr0) = hv;
+            float* hl = HL + tt * kSCB * KH + own_hl0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hl[4 * i] = hv[i];
+            if (dead && lane == 0) RED[24] = 1.f;
+        };
+        auto p2 = [&](auto sc, auto tc) {       // layer 2 on HL[tt] -> kvS[tt]
+            constexpr int tt = decltype(tc)::value;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < 7; ++kb) {
+                const f32x4 bf = *(const f32x4*)(HL + tt * kSCB * KH + col * KH + 4 * (lane >> 4) + 16 * kb);
+                acc0 = mfma16(wB[kb][0], bf[0], acc0);
+                if (16 * kb + 4 < gH + 2) acc1 = mfma16(wB[kb][1], bf[1], acc1);
+                if (16 * kb + 8 < gH + 2) acc0 = mfma16(wB[kb][2], bf[2], acc0);
+                if (16 * kb + 12 < gH + 2) acc1 = mfma16(wB[kb][3], bf[3], acc1);
+            }
+            f32x4 kv = acc0 + acc1;
+            if (ACT2) {
+                const f32x2 a01 = tanh_fast2((f32x2){kv[0], kv[1]}), a23 = tanh_fast2((f32x2){kv[2], kv[3]});
+                kv = (f32x4){a01.x, a01.y, a23.x, a23.y};
+            }
+            kvS[tt] = kv;
+        };
+        auto p3 = [&](auto sc, auto tc) {       // k_s to the tape, next stage input -> GL[tt]; last stage: the error-norm partials
+            constexpr int s = decltype(sc)::value, tt = decltype(tc)::value;
+            const f32x4 kv = kvS[tt];
+            st4(R + L.k(s + 1) + co[tt], r0, gD, true, vec, kv);
+            if constexpr (s < 6) {
+                slab_clears_done();
+                f32x4 acc = tsA(s + 1, 0) * c_k[tt][0];
+#pragma unroll
+                for (int j = 1; j < 6; ++j) if (j < s) acc = fma4(tsA(s + 1, j), c_k[tt][j], acc);
+                acc = fma4(tsA(s + 1, s), kv, acc);
+                const f32x4 v = fma4(dt, acc, c_up[tt]);
+                if (s == 5) { st4(R + L.unew() + co[tt], r0, gD, true, vec, v); c_un[tt] = v; }
+                else if (P.tape) st4(R + L.g(s + 2) + co[tt], r0, gD, true, vec, v);
+                c_k[tt][s] = kv;
+                float* gl = GL + tt * kSCB * KG + own_gl0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) gl[4 * i] = v[i];
+            } else {
+                const f32x4 up = c_up[tt], un = c_un[tt];
+                f32x4 acc = tsBt(0) * c_k[tt][0];
+#pragma unroll
+                for (int j = 1; j < 6; ++j) acc = fma4(tsBt(j), c_k[tt][j], acc);
+                acc = fma4(tsBt(6), kv, acc);
+                if (colok[tt]) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float ut = dt * acc[i];
+                        const float sk = P.abstol + fmaxf(fabsf(up[i]), fabsf(un[i])) * P.reltol;
+                        const float r = ut / sk;
+                        part0[tt] += r * r;
+                    }
+                    if (P.reg_kind >= 2) {
+                        f32x4 g6 = tsA(5, 0) * c_k[tt][0];
+#pragma unroll
+                        for (int j = 1; j < 5; ++j) g6 = fma4(tsA(5, j), c_k[tt][j], g6);
+                        g6 = fma4(dt, g6, up);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float d1 = kv[i] - c_k[tt][5][i], d2 = un[i] - g6[i];
+                            part1[tt] += d1 * d1; part2[tt] += d2 * d2;
+                        }
+                    }
+                }
+            }
+        };
+        using T0c = std::integral_constant<int, 0>; using T1c = std::integral_constant<int, 1>;
+        p3_start(T0c{});
+        __syncthreads();
+        p4(std::integral_constant<int, 0>{}, T0c{}); p3_start(T1c{});
+        __syncthreads();
+        auto stage2 = [&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            using Sp = std::integral_constant<int, s - 1>;
+            if (!alive) return;
+            p4(Sp{}, T1c{}); p1(sc, T0c{});           // tile 1: layer-1 MFMAs of stage s - 1   ||  tile 0: poll + tanh of stage s
+            __syncthreads();
+            if (RED[24] != 0.f) { alive = false; return; }
+            p2(sc, T0c{}); p1(sc, T1c{});             // tile 0: layer-2 MFMAs                   ||  tile 1: poll + tanh
+            __syncthreads();
+            if (RED[24] != 0.f) { alive = false; return; }
+            p2(sc, T1c{}); p3(sc, T0c{});             // tile 1: layer-2 MFMAs                   ||  tile 0: combination
+            if constexpr (s < 6) {
+                __syncthreads();
+                p4(sc, T0c{}); p3(sc, T1c{});         // tile 0: layer-1 MFMAs                   ||  tile 1: combination
+                __syncthreads();
+            } else p3(sc, T1c{});
+        };
+        stage2(std::integral_constant<int, 1>{});
+        stage2(std::integral_constant<int, 2>{});
+        stage2(std::integral_constant<int, 3>{});
+        stage2(std::integral_constant<int, 4>{});
+        stage2(std::integral_constant<int, 5>{});
+        stage2(std::integral_constant<int, 6>{});
+    }
+
     // phase D for all tiles: this row block's layer-1 partials of the stage inputs v[tt] -> slab, exchange number `ex`
     auto phase_d = [&](const f32x4 (&v)[NCT], unsigned ex, auto t0c, auto t1c) {
         constexpr int T0 = decltype(t0c)::value, T1 = decltype(t1c)::value;
@@ -190,7 +340,7 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_attempt_mt_kernel(const Sta
     };
 
     // ---- SM_START's phase C / D ----
-    {
+    if constexpr (ALT != 2) {
         f32x4 v[NCT];
 #pragma unroll
         for (int tt = 0; tt < NCT; ++tt) {
@@ -204,10 +354,6 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_attempt_mt_kernel(const Sta
         } else phase_d(v, 1u, std::integral_constant<int, 0>{}, std::integral_constant<int, NCT>{});
     }
 
-    float part0[NCT], part1[NCT], part2[NCT];
-#pragma unroll
-    for (int tt = 0; tt < NCT; ++tt) part0[tt] = part1[tt] = part2[tt] = 0.f;
-    bool alive = true;
     auto stage = [&](auto sc, auto t0c, auto t1c) {
         constexpr int s = decltype(sc)::value, T0 = decltype(t0c)::value, T1 = decltype(t1c)::value;
         if (!alive) return;
@@ -325,7 +471,8 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_attempt_mt_kernel(const Sta
         }
     };
     auto both = [&](auto sc) {
-        if constexpr (ALT) {
+        if constexpr (ALT == 2) return;
+        else if constexpr (ALT) {
             stage(sc, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
             if constexpr (NCT > 1) stage(sc, std::integral_constant<int, 1>{}, std::integral_constant<int, NCT>{});
         } else stage(sc, std::integral_constant<int, 0>{}, std::integral_constant<int, NCT>{});

@@ -186,7 +186,7 @@ def test_two_tile_attempt_is_bit_identical(B, tol, scale, saveat, reg, monkeypat
     arch, p, x = _setup("mnist", B, 5, scale)
     monkeypatch.setenv("RNDE_WGRAD_SIDE", "0")
     outs = []
-    for two in ("1", "2", "0"):      # 1: tiles alternate (the form in use), 2: tiles in lock step, 0: one tile per workgroup
+    for two in ("1", "2", "3", "0"):      # 1: tiles alternate, 2: tiles in lock step, 3: skewed (MFMA step of one tile beside the element-wise step of the other), 0: one tile per workgroup
         monkeypatch.setenv("RNDE_PERSIST2", two)
         node = Node(_cfg(arch, B, reltol=tol, abstol=tol, col_tile=16, max_attempts=128, regularize=reg))
         assert node.L.rnde_node_launches_per_attempt(node.h) == 1

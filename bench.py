@@ -482,6 +482,16 @@ def main():
                     break
         except Exception:
             pass
+        # the measured floor of this kernel's decomposition: its MFMAs alone with operands in registers (profiles/r03_attempt_ablation.csv)
+        try:
+            import csv
+            for row in csv.DictReader(l for l in open(os.path.join(ROOT, "profiles", "r03_attempt_ablation.csv")) if not l.startswith("#")):
+                if row["variant"] == "mfmaonly" and int(row["B"]) == B:
+                    roof["ceiling_us"] = float(row["us_taped"])
+                    roof["ceiling_frac"] = ALG_BYTES(B) / (roof["ceiling_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+                    roof["ceiling_source"] = "profiles/r03_attempt_ablation.csv: the kernel's MFMAs alone (operands in registers, no polls / tanh / LDS / tape), same launch geometry, back to back"
+        except Exception:
+            pass
         out = {"metric": "training-step samples/sec + mean NFE, MNIST Neural ODE bs=512",
                "value": world * B * args.steps / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,

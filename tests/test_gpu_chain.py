@@ -125,6 +125,29 @@ def test_chain_config4_statistics():
     print(f"attempts: device {n_dev}, oracle f32 {n32}, oracle f64 {n64}")
     assert abs(n_dev - n32) <= 0.25 * n32 + 1
     assert np.abs(got["u"] - ref64["u"]).max() <= 1e-5 * max(1.0, np.abs(ref64["u"]).max())
+    # round 3: the oracle in the DEVICE'S summation order (Oracle(sum_order=3): per output two interleaved accumulators over the 16-wide
+    # k-blocks, acc0 seeded with the bias, K = 4 FMA chains; the device's tanh formula) -- the natural run's attempt count is then an
+    # equality (+-1), as for the MNIST shape (tests/test_gpu_replay.py)
+    o3 = Oracle(arch, np.float32, reltol=1.4e-8, abstol=1.4e-8, reg_kind=1, sum_order=3, max_attempts=512)
+    r3 = o3.forward(x, p, saveat=sa)
+    n3 = r3["nattempts"]
+    print(f"attempts: device {n_dev}, device-order oracle {n3}; u vs that oracle {np.abs(got['u'] - r3['u']).max():.2e}")
+    assert abs(n_dev - n3) <= 1
+    assert np.abs(got["u"] - r3["u"]).max() <= 3e-6 * max(1.0, np.abs(r3["u"]).max())
+
+
+@pytest.mark.parametrize("kind,B", [("latent", 64), ("chain3", 19), ("wide", 16)])
+def test_chain_feval_equals_the_device_order_oracle_almost_bit_for_bit(kind, B, _mw_only):
+    """One f evaluation on the multi-wave chain kernels against the oracle in their order: bit-identical in most entries, 1-2 ulp in the
+    rest (v_exp_f32 / v_rcp_f32 against correctly rounded exp2 / reciprocal, once per tanh layer)."""
+    from tests.util import Node, Oracle
+    arch, p, x = _setup(kind, B, 4, 1.0)
+    fd = Node(_cfg(arch, B)).feval(x, p, 0.37)
+    f0 = Oracle(arch, np.float32, sum_order=0).f_eval(p, x, 0.37)
+    f3 = Oracle(arch, np.float32, sum_order=3).f_eval(p, x, 0.37)
+    eq0, eq3 = float(np.mean(fd == f0)), float(np.mean(fd == f3))
+    print(f"{kind}: entries bit-equal to the device: sequential-k oracle {eq0:.3f}, device-order oracle {eq3:.3f}; max |diff| {np.abs(fd - f0).max():.2e} / {np.abs(fd - f3).max():.2e}")
+    assert eq3 >= 0.6 and eq3 > eq0 and np.abs(fd - f3).max() <= 4e-7 * max(1.0, np.abs(f3).max())
 
 
 @pytest.mark.parametrize("kind,B,tol,scale,ws", [("latent", 4, 1e-3, 1.5, 0.0), ("latent", 37, 1e-3, 1.5, 30.0), ("chain3", 19, 1e-3, 2.0, 30.0),

@@ -51,6 +51,8 @@ struct rnde_node {
     // multi-wave kernels of the chain engine (rnde_chainmw.h): 4 waves per 16 columns, activations taped in the slab by the forward
     rnde_comm* couple = nullptr; int couple_batch = 0, couple_world = 1;   // SURVEY 8e mode 2 (rnde_node_set_coupling)
     int rk_tab = 0; RkTab rk{};   // explicit RK pair as data: 1 = a 7-stage pair (DP5, or Tsit5 through the same path when RNDE_CHAIN_TAB=1), 2 = S stages (DOP853)
+    // chain engine, multi-wave kernels: the whole adaptive solve as ONE launch (rnde_chainmw.h MW_SOLVE) while the tiles fit one XCD (<= 32)
+    int mw_solve = 1; unsigned long long* mw_xch = nullptr; unsigned* mw_xcc = nullptr; unsigned* mw_abort = nullptr; unsigned* h_mw_chk = nullptr; unsigned mw_epoch = 0;
     int rk_S = 7, rk_order = 5;   // stages of the pair in first-same-as-last form (evaluations per attempted step = rk_S - 1), controller order
     int mw_lat = 0;               // the reference's latent-ODE shape (20 <-> 50, 8 layers): forward kernels with register-stationary weights
     int mw = 0; MwGeo mg{}; float* mw_tab = nullptr; float* mw_slab = nullptr; long long mw_slab_evals = 0; size_t mw_lds_f = 0, mw_lds_b = 0;
@@ -334,6 +336,14 @@ static rnde_status chain_create(const rnde_node_config* c, rnde_node** out) {
     ok &= dm((void**)&h->f0, Ac * 4) && dm((void**)&h->u1, Ac * 4) && dm((void**)&h->f1, Ac * 4) && dm((void**)&h->xcopy, (size_t)h->D * h->Bpad_max * 4);
     ok &= dm((void**)&h->pcopy, (size_t)h->P * 4) && dm((void**)&h->cfrags, (size_t)(G.nfrag_f + G.nfrag_b + G.nfrag_t + 4) * 256);
     if (h->mw) ok &= dm((void**)&h->mw_tab, mw_tab_floats(h->mg) * 4);
+    if (h->mw) {
+        const size_t xb = (size_t)(c->max_attempts + 4) * 3 * 32 * 8;
+        ok &= dm((void**)&h->mw_xch, xb) && dm((void**)&h->mw_xcc, 32 * 4) && dm((void**)&h->mw_abort, 8);
+        ok &= hipHostMalloc((void**)&h->h_mw_chk, 40 * 4) == hipSuccess;
+        if (ok) { hipMemset(h->mw_xch, 0, xb); hipMemset(h->mw_abort, 0, 8); }
+        const char* e = getenv("RNDE_CHAIN_SOLVE");
+        if (e && e[0] == '0') h->mw_solve = 0;
+    }
     ok &= dm((void**)&h->ctl, 2 * sizeof(StepState)) && dm((void**)&h->ctl_final, sizeof(StepState));
     ok &= dm((void**)&h->meta, (size_t)(c->max_attempts + 1) * sizeof(StepMeta)) && dm((void**)&h->initrec, sizeof(InitRec));
     ok &= dm((void**)&h->errpart, (size_t)(6 * h->nwg_max + 256) * 4) && dm((void**)&h->initpart, (size_t)(3 * h->nwg_max + 256) * 4);   // (+256: sum_partials reads whole 256-entry blocks)
@@ -389,7 +399,7 @@ static hipError_t launch_mw_t(rnde_node* h, const MwParams& Q, int n, hipStream_
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((rnde_chainmw_kernel<NR, MODE, TAB, LAT>), dim3(Q.ntiles), dim3(kMwThreads), MODE == MW_FINISH ? 0 : h->mw_lds_f, s, Q, n);
+    hipLaunchKernelGGL((rnde_chainmw_kernel<NR, MODE, TAB, LAT>), dim3(MODE == MW_SOLVE ? 8 * Q.ntiles : Q.ntiles), dim3(kMwThreads), MODE == MW_FINISH ? 0 : h->mw_lds_f, s, Q, n);
     return hipGetLastError();
 }
 template <int MODE>
@@ -573,6 +583,10 @@ extern "C" void rnde_node_destroy(rnde_node* h) {
     if (h->replay_dev) hipFree(h->replay_dev);
     if (h->cfrags) hipFree(h->cfrags);
     if (h->mw_tab) hipFree(h->mw_tab);
+    if (h->mw_xch) hipFree(h->mw_xch);
+    if (h->mw_xcc) hipFree(h->mw_xcc);
+    if (h->mw_abort) hipFree(h->mw_abort);
+    if (h->h_mw_chk) hipHostFree(h->h_mw_chk);
     if (h->mw_slab) hipFree(h->mw_slab);
     if (h->tslab) hipFree(h->tslab);
     if (h->pabort) hipFree(h->pabort);
@@ -888,7 +902,45 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
     const int cap = h->cfg.max_attempts;
     h->tev_fwd = false;
     if (h->timing) HIPCHK(h, hipEventRecord(h->tev[0], s));
-    while (true) {
+    // ---- chain engine, multi-wave kernels, <= 32 column tiles: the WHOLE adaptive solve is one launch (attempt loop, controller and the
+    // ---- once-per-attempt meeting of the workgroups inside the kernel; the workgroups are pinned to one XCD and meet through its L2) ----
+    bool solved = false;
+    if (h->engine == 3 && h->mw && h->mw_solve && !h->couple && P.Bpad / 16 <= 32) {
+        // a taped solve writes every layer input of every evaluation: the slab is sized for twice the last solve's attempts (at least 48); a solve
+        // that needs more ends at that limit and is redone with room for max_attempts
+        const int n_limit = keep_tape ? std::min(cap, std::max(48, 2 * h->predicted)) : cap;
+        if (keep_tape) { st = ensure_mw_slab(h, 2 + (long long)(h->rk_S - 1) * n_limit, P.Bpad, s); if (st != RNDE_OK) return st; MQ.slab = h->mw_slab; }
+        MQ.n_limit = n_limit;
+        if (++h->mw_epoch >= 500000u) { h->mw_epoch = 1; HIPCHK(h, hipMemsetAsync(h->mw_xch, 0, (size_t)(cap + 4) * 3 * 32 * 8, s)); }
+        MQ.u_out = u_out_dev; MQ.xch = h->mw_xch; MQ.xcc = h->mw_xcc; MQ.abort_word = h->mw_abort; MQ.epoch = h->mw_epoch;
+        HIPCHK(h, launch_mw<MW_SOLVE>(h, MQ, 0, s));
+        if (h->timing) { HIPCHK(h, hipEventRecord(h->tev[1], s)); h->tev_fwd = true; }
+        const int nt = P.Bpad / 16;
+        HIPCHK(h, hipMemcpyAsync(h->h_ctl, h->ctl_final, sizeof(StepState), hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipMemcpyAsync(h->h_meta, h->meta, (size_t)cap * sizeof(StepMeta), hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipMemcpyAsync(h->h_init, h->initrec, sizeof(InitRec), hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipMemcpyAsync(h->h_mw_chk, h->mw_abort, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipMemcpyAsync(h->h_mw_chk + 2, h->mw_xcc, (size_t)nt * 4, hipMemcpyDeviceToHost, s));
+        if (h->after_solve) {
+            HIPCHK(h, hipEventRecord(h->ev_host, s));
+            const rnde_status hs = h->after_solve(s);
+            if (hs != RNDE_OK) return hs;
+            HIPCHK(h, hipEventSynchronize(h->ev_host));
+        } else HIPCHK(h, hipStreamSynchronize(s));
+        bool bad = h->h_mw_chk[0] != 0;
+        for (int i = 1; i < nt && !bad; ++i) bad = h->h_mw_chk[2 + i] != h->h_mw_chk[2];
+        if (bad) {      // a meeting timed out, or the workgroups did not share an XCD: this handle goes back to one launch per attempt, for good
+            fprintf(stderr, "[rnde] chain engine: one-launch solve abandoned (%s); one launch per attempted step from now on\n",
+                    h->h_mw_chk[0] ? "a meeting timed out" : "workgroups pinned by block index landed on different XCDs");
+            h->mw_solve = 0; ++h->persist_fallbacks;
+            hipMemsetAsync(h->mw_abort, 0, 8, s);
+            return RNDE_INTERNAL_RETRY;
+        }
+        if (!h->h_ctl->done && h->h_ctl->n_att >= n_limit && n_limit < cap) { h->predicted = cap; return RNDE_INTERNAL_RETRY; }
+        h->pending_bwd = false;
+        solved = true;
+    }
+    while (!solved) {
         if (h->engine == 3 && h->mw && keep_tape) {   // room in the activation slab for this chunk's evaluations (a regrowth keeps the taped ones)
             st = ensure_mw_slab(h, 2 + (long long)(h->rk_S - 1) * std::min(cap, launched + chunk), P.Bpad, s);
             if (st != RNDE_OK) return st;

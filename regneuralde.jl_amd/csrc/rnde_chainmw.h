@@ -77,7 +77,55 @@ struct MwParams {
     float* slab;             // [n_evals][ntiles][RS][64] (NULL when not taping): evaluation 0 = f(u0), 1 = f(u1), 2 + 6 n + (s - 1) = stage s of attempt n
     long long ev_stride;
     int ntiles;
+    // MW_SOLVE (the whole adaptive solve in one launch): the workgroups meet once per attempted step through the L2 of ONE XCD
+    unsigned long long* xch;     // [max_attempts][3][ntiles] {float value, uint tag}: every entry written once per solve
+    unsigned* xcc;               // [ntiles] HW_REG_XCC_ID of each workgroup (the host checks they agree)
+    unsigned* abort_word;        // a meeting timed out
+    unsigned epoch;              // tag = epoch * 8192 + attempt + 1
+    int n_limit;                 // attempts this launch may run (the activation slab is sized for that many): reaching it ends the launch with done = 0
 };
+
+// cross-workgroup sums of the three norm partials of attempt `seq` (MW_SOLVE): every workgroup publishes {value, tag} with a plain 8-byte
+// store (written through to the XCD's L2) and polls the others' with L1-bypassing loads -- the SDE engine's meeting (rnde_sde.h
+// sde_exchange).  Called by wave 0; `mine` valid in lane 0; the sums come out in the order sum_partials forms them (entry i in lane i,
+// then the wave reduction), so a solve is bit-identical to the one-launch-per-attempt path.  false: timed out / aborted.
+constexpr int kMwSpinMax = 4000000;
+__device__ __forceinline__ bool mw_exchange3(const MwParams& Q, int seq, const float (&mine)[3], double (&out)[3], int tile, int lane) {
+    const unsigned tag = Q.epoch * 8192u + (unsigned)seq + 1u;
+    unsigned long long* base = Q.xch + (size_t)seq * 3 * Q.ntiles;
+    if (lane == 0) {
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            float m = mine[v];
+            if (m != m) m = __uint_as_float(0x7FC00000u);
+            base[(size_t)v * Q.ntiles + tile] = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(m);
+        }
+    }
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+    typedef unsigned mw_u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+        unsigned long long e = 0;
+        bool ok = lane >= Q.ntiles;
+        int spins = 0;
+        while (true) {
+            if (!ok) {
+                __asm__ volatile("" ::: "memory");
+                const mw_u32x2 q = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(((size_t)v * Q.ntiles + lane) * 8), 0, 16);   // aux 16 = sc1: misses L1
+                e = ((unsigned long long)q.y << 32) | q.x;
+                ok = (unsigned)(e >> 32) == tag;
+            }
+            if (__all(ok)) break;
+            if (++spins > kMwSpinMax || ((spins & 1023) == 0 && __hip_atomic_load(Q.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                if (lane == 0) __hip_atomic_store(Q.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+        const double sv = lane < Q.ntiles ? (double)__uint_as_float((unsigned)(e & 0xFFFFFFFFull)) : 0.0;
+        out[v] = wave_sum_d(sv);
+    }
+    return true;
+}
 
 // forward fragment (l, mo, mi, j): lane (kk = lane >> 4, rho = lane & 15) = W_l[16 mo + rho][16 mi + 4 j + kk]
 // transposed      (l, mi, mo, j): lane (kk, rho)                         = W_l[16 mo + 4 j + kk][16 mi + rho]
@@ -269,7 +317,7 @@ __device__ __forceinline__ void mw_eval_lat(const MwGeo& G, const LatWeights& W,
     __syncthreads();
 }
 
-enum { MW_STEP = 0, MW_INIT_A = 1, MW_INIT_B = 2, MW_FEVAL = 3, MW_FINISH = 4 };
+enum { MW_STEP = 0, MW_INIT_A = 1, MW_INIT_B = 2, MW_FEVAL = 3, MW_FINISH = 4, MW_SOLVE = 5 };
 
 // NR = NKD / 4 registers per state array and lane (NKD = 4, 8, 16 k-steps of D as in rnde_chain.h: arena arrays are NKD * 64 floats per tile)
 template <int NR, int MODE, int TAB = 0, int LAT = 0>
@@ -286,8 +334,12 @@ __global__ __launch_bounds__(kMwThreads) void rnde_chainmw_kernel(const MwParams
     float* RED = YB + 1024;    // [3][4]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = blockIdx.x;
+    // MW_SOLVE: 8 x ntiles workgroups are launched and those with blockIdx % 8 != 0 leave at once, so that the ones that work share ONE XCD
+    // (round-robin dispatch; every workgroup records its XCC id, the host checks they agree): they meet through that L2 once per attempt
+    if constexpr (MODE == MW_SOLVE) { if (blockIdx.x & 7) return; }
+    const int tile = MODE == MW_SOLVE ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const bool writer = (tile == 0 && tid == 0);
+    if constexpr (MODE == MW_SOLVE) { if (tid == 0) Q.xcc[tile] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15; }
     constexpr int SM = TAB == 2 ? kRkSMax : 7;               // stages the register arrays are sized for
     const int NS = TAB == 2 ? Q.rk.S : 7;                    // stages of the pair (first-same-as-last form)
     const ChainRec L{(long long)Q.ntiles * NKD * 64, NS};
@@ -393,8 +445,19 @@ __global__ __launch_bounds__(kMwThreads) void rnde_chainmw_kernel(const MwParams
         return;
     } else {
         // ---- controller, then (STEP) one attempted step / (FINISH) the last step's save points and the copy-out ----
+        // (MW_SOLVE: the same, attempt after attempt, until the controller says done; `nn` is the attempt, the previous state and the
+        //  norm sums of the previous attempt are carried in registers instead of being re-read behind a kernel boundary)
+        StepState Sprev{};
+        double xs[3] = {0.0, 0.0, 0.0};
+        float* RED2 = RED + 16;                  // (MW_SOLVE: the three sums, as doubles, for the waves that did not meet)
+      for (int nn = n; ; ++nn) {
         StepState S;
-        if (pre) {
+        if constexpr (MODE == MW_SOLVE) {
+            const float none[4] = {0.f, 0.f, 0.f, 0.f};
+            if (nn == 0) S = advance_state(P, 0, lane, writer, &P.ctl[0]);
+            else S = advance_state_t<true>(P, nn, lane, writer, &P.ctl[nn & 1], none, Sprev, xs);
+            if (!S.done && nn >= Q.n_limit) { if (writer) *P.ctl_final = S; return; }      // out of slab: the host regrows it and solves again
+        } else if (pre) {
             asm volatile("" : "+v"(prev_raw[0]), "+v"(prev_raw[1]), "+v"(prev_raw[2]));   // (first use: keeps the unpacking, and its wait, down here)
             static_assert(sizeof(StepState) == 48, "StepState is read as three 16-byte words");
             StepState prev_state;
@@ -405,13 +468,13 @@ __global__ __launch_bounds__(kMwThreads) void rnde_chainmw_kernel(const MwParams
         MW_STAMP(2);
         if (P.nsave > 0) {
             // saveat ({R,true} methods, neural_ode.jl:79-108): the points inside the step accepted last
-            if (n == 0) {
+            if (nn == 0) {
                 if (S.next_save > 0) {
 #pragma unroll
                     for (int r = 0; r < NR; ++r) if (valid(r)) P.sv_out[((size_t)gcol * P.nsave) * P.D + feat(r)] = P.x[(size_t)gcol * P.D + feat(r)];
                 }
             } else {
-                const StepState pv = P.ctl[(n - 1) & 1];
+                const StepState pv = MODE == MW_SOLVE ? Sprev : P.ctl[(nn - 1) & 1];
                 const int lo = pv.next_save, hi = S.next_save;
                 if (hi > lo && !pv.done) {
                     const float dtp_ = (P.t1 - pv.t < pv.dtp) ? (P.t1 - pv.t) : pv.dtp;
@@ -443,7 +506,8 @@ __global__ __launch_bounds__(kMwThreads) void rnde_chainmw_kernel(const MwParams
                 }
             }
         }
-        if constexpr (MODE == MW_FINISH) {
+        if (MODE == MW_FINISH || (MODE == MW_SOLVE && S.done)) {
+            if constexpr (MODE == MW_SOLVE) { if (writer) *P.ctl_final = S; }
             if (!Q.u_out) return;
 #pragma unroll
             for (int r = 0; r < NR; ++r)
@@ -453,7 +517,7 @@ __global__ __launch_bounds__(kMwThreads) void rnde_chainmw_kernel(const MwParams
         if (S.done) return;
         const float t = S.t;
         const float dt = (!P.forced && (P.t1 - S.t < S.dtp)) ? (P.t1 - S.t) : S.dtp;
-        const int rec = P.tape ? n : (S.live == 0 ? 1 : 0);
+        const int rec = P.tape ? nn : (S.live == 0 ? 1 : 0);
         float* R = P.arena + (long long)rec * P.rec_stride;
         float part = 0.f, part1 = 0.f, part2 = 0.f;
         // Rolled stage loop with shifting partial sums, exactly as rnde_chain_kernel: Sa[i] = running combination of the i-th stage still to come
@@ -462,7 +526,7 @@ __global__ __launch_bounds__(kMwThreads) void rnde_chainmw_kernel(const MwParams
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             float k1;
-            if (spec && S.live == n - 1) { up[r] = sp_up[r]; k1 = sp_k[r]; }      // (the step starts from what attempt n - 1 wrote: already here)
+            if (spec && S.live == nn - 1) { up[r] = sp_up[r]; k1 = sp_k[r]; }      // (the step starts from what attempt n - 1 wrote: already here)
             else if (S.live < 0) { up[r] = ldx(P.x, r); k1 = P.f0[fo + 256 * r]; }
             else { up[r] = Rl[L.unew() + fo + 256 * r]; k1 = Rl[L.k(NS) + fo + 256 * r]; }
             if (P.tape || P.nsave > 0) { R[L.upc() + fo + 256 * r] = up[r]; R[L.k1c() + fo + 256 * r] = k1; }
@@ -483,7 +547,7 @@ __global__ __launch_bounds__(kMwThreads) void rnde_chainmw_kernel(const MwParams
 #pragma unroll
                 for (int r = 0; r < NR; ++r) R[L.g(s + 1) + fo + 256 * r] = gq[r];
             }
-            float* sl = (slab_tile && P.tape) ? slab_tile + (size_t)(2 + (NS - 1) * n + (s - 1)) * Q.ev_stride : nullptr;
+            float* sl = (slab_tile && P.tape) ? slab_tile + (size_t)(2 + (NS - 1) * nn + (s - 1)) * Q.ev_stride : nullptr;
             MW_STAMP(2 + (s < 7 ? s : 6));
             eval(t + rk_c<TAB>(Q.rk, s) * dt, gq, kv, sl, s == 1 ? dbg : nullptr);
             if (s == 5 && P.reg_kind >= 2) {      // (stiffness estimate: 7-stage pairs only, the host refuses it otherwise)
@@ -521,12 +585,30 @@ __global__ __launch_bounds__(kMwThreads) void rnde_chainmw_kernel(const MwParams
         if (lane == 0) { RED[wave] = part; RED[4 + wave] = part1; RED[8 + wave] = part2; }
         __syncthreads();
         MW_STAMP(10);
-        if (tid == 0) {
-            float s = 0.f, s1 = 0.f, s2 = 0.f;
-            for (int w = 0; w < kMwWaves; ++w) { s += RED[w]; s1 += RED[4 + w]; s2 += RED[8 + w]; }
-            float* ep = P.errpart + (size_t)(n & 1) * 3 * P.nwg;
-            ep[tile] = s; ep[P.nwg + tile] = s1; ep[2 * P.nwg + tile] = s2;
+        if constexpr (MODE == MW_SOLVE) {
+            // the meeting: wave 0 publishes this tile's three partials and collects everybody's; the sums reach the other waves through LDS
+            if (wave == 0) {
+                float mine[3] = {0.f, 0.f, 0.f};
+                for (int w = 0; w < kMwWaves; ++w) { mine[0] += RED[w]; mine[1] += RED[4 + w]; mine[2] += RED[8 + w]; }
+                double o[3];
+                const bool ok = mw_exchange3(Q, nn, mine, o, tile, lane);
+                if (lane == 0) { ((double*)RED2)[0] = o[0]; ((double*)RED2)[1] = o[1]; ((double*)RED2)[2] = o[2]; RED2[6] = ok ? 1.f : 0.f; }
+            }
+            __syncthreads();
+            if (RED2[6] == 0.f) return;                      // (a meeting timed out: abort word raised, the host redoes the solve launch by launch)
+            xs[0] = ((const double*)RED2)[0]; xs[1] = ((const double*)RED2)[1]; xs[2] = ((const double*)RED2)[2];
+            Sprev = S;
+            __syncthreads();                                 // (RED / RED2 are rewritten by the next attempt)
+        } else {
+            if (tid == 0) {
+                float s = 0.f, s1 = 0.f, s2 = 0.f;
+                for (int w = 0; w < kMwWaves; ++w) { s += RED[w]; s1 += RED[4 + w]; s2 += RED[8 + w]; }
+                float* ep = P.errpart + (size_t)(n & 1) * 3 * P.nwg;
+                ep[tile] = s; ep[P.nwg + tile] = s1; ep[2 * P.nwg + tile] = s2;
+            }
+            break;
         }
+      }
     }
 }
 

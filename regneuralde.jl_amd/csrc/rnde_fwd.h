@@ -187,8 +187,10 @@ __device__ __forceinline__ void finalize_state(const StepParams& P, StepState& S
 // the controller state and the partials are two cold loads that do not depend on each other
 // prev: the controller state of attempt n - 1 (P.ctl[(n - 1) & 1]), likewise loaded by the caller ahead of the call (both used when PRE and n > 0)
 template <bool PRE>
+// sums (optional): the three cross-workgroup sums of attempt n - 1 {r^2, (k7-k6)^2, (unew-g6)^2} already formed by the caller (a kernel that
+// runs several attempts meets in memory instead of at a kernel boundary: rnde_chainmw.h MW_SOLVE) -- in the order sum_partials would
 __device__ __forceinline__ StepState advance_state_t(const StepParams& P, int n, int lane, bool writer, StepState* out, const float (&pre)[4],
-                                                     const StepState& prev) {
+                                                     const StepState& prev, const double* sums = nullptr) {
     StepState S;
     const double N = (double)P.D * (double)P.Bn;
     if (n == 0) {
@@ -222,12 +224,12 @@ __device__ __forceinline__ StepState advance_state_t(const StepParams& P, int n,
     const bool clamped = !P.forced && (P.t1 - p.t < p.dtp);
     const float dt = clamped ? (P.t1 - p.t) : p.dtp;
     const float* ep = P.errpart + (size_t)((n - 1) & 1) * 3 * P.nwg;   // [parity][{r^2, (k7-k6)^2, (unew-g6)^2}][workgroup]
-    const double ss = sum_partials(ep, P.nwg, lane, PRE ? &pre : nullptr);
+    const double ss = sums ? sums[0] : sum_partials(ep, P.nwg, lane, PRE ? &pre : nullptr);
     const float eest = (float)sqrt(ss / N);
     float eig = 0.f, en1 = 0.f, en2 = 0.f;
     if (P.reg_kind >= 2) {   // stiffness estimate of the composite algorithm AutoTsit5(Tsit5())
-        en1 = (float)sqrt(sum_partials(ep + P.nwg, P.nwg, lane));
-        en2 = (float)sqrt(sum_partials(ep + 2 * P.nwg, P.nwg, lane));
+        en1 = (float)sqrt(sums ? sums[1] : sum_partials(ep + P.nwg, P.nwg, lane));
+        en2 = (float)sqrt(sums ? sums[2] : sum_partials(ep + 2 * P.nwg, P.nwg, lane));
         eig = en1 / en2;
     }
     const int rec = P.tape ? (n - 1) : (p.live == 0 ? 1 : 0);

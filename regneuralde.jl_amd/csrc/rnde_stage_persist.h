@@ -288,6 +288,11 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
         f32x4 bg[kSMaxW];
 #pragma unroll
         for (int kb = 0; kb < kSMaxW; ++kb) if (kb < gWT) bg[kb] = *(const f32x4*)(gbp + 16 * kb);
+#ifdef RNDE_LDS_PREFETCH
+        // (measured in round 3 and not kept: with all seven operand reads in flight before the first MFMA -- the scheduler otherwise emits read,
+        //  wait, four MFMAs, read, wait ... -- the attempt takes 27.4 us against 27.2: the two waves of a SIMD already cover each other's LDS waits)
+        if constexpr (FIX) __builtin_amdgcn_sched_barrier(0);
+#endif
         if (w < gHT) {
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -448,6 +453,9 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
             f32x4 bf[kSMaxHT];
 #pragma unroll
             for (int kb = 0; kb < kSMaxHT; ++kb) if (kb < gK2b) bf[kb] = *(const f32x4*)(hb + 16 * kb);
+#ifdef RNDE_LDS_PREFETCH
+            if constexpr (FIX) __builtin_amdgcn_sched_barrier(0);      // (as in phase D)
+#endif
 #pragma unroll
             for (int kb = 0; kb < kSMaxHT; ++kb) {
                 if (kb < gK2b) {      // (FIX: the k-steps past row H + 1 multiply zeros and are left out -- 26 MFMAs instead of 28)

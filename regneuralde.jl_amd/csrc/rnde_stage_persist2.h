@@ -282,16 +282,27 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_attempt_mt_kernel(const Sta
             constexpr int s = decltype(sc)::value;
             using Sp = std::integral_constant<int, s - 1>;
             if (!alive) return;
-            p4(Sp{}, T1c{}); p1(sc, T0c{});           // tile 1: layer-1 MFMAs of stage s - 1   ||  tile 0: poll + tanh of stage s
+            // Waves w and w + 4 share a SIMD and, running the same program between the same barriers, reach their MFMA bursts together
+            // (MI355X_MICROARCH.md, "try a stagger"): waves 4.. take the two steps of a slot in the OTHER order, so that one partner's matrix
+            // instructions meet the other's vector instructions (RNDE_SKEW_STAGGER=0 at compile time: same order in every wave).
+#ifndef RNDE_SKEW_STAGGER
+#define RNDE_SKEW_STAGGER 1
+#endif
+            const bool mfma_first = !RNDE_SKEW_STAGGER || w < 4;
+            if (mfma_first) { p4(Sp{}, T1c{}); p1(sc, T0c{}); }   // tile 1: layer-1 MFMAs of stage s - 1   ||  tile 0: poll + tanh of stage s
+            else { p1(sc, T0c{}); p4(Sp{}, T1c{}); }
             __syncthreads();
             if (RED[24] != 0.f) { alive = false; return; }
-            p2(sc, T0c{}); p1(sc, T1c{});             // tile 0: layer-2 MFMAs                   ||  tile 1: poll + tanh
+            if (mfma_first) { p2(sc, T0c{}); p1(sc, T1c{}); }     // tile 0: layer-2 MFMAs                   ||  tile 1: poll + tanh
+            else { p1(sc, T1c{}); p2(sc, T0c{}); }
             __syncthreads();
             if (RED[24] != 0.f) { alive = false; return; }
-            p2(sc, T1c{}); p3(sc, T0c{});             // tile 1: layer-2 MFMAs                   ||  tile 0: combination
+            if (mfma_first) { p2(sc, T1c{}); p3(sc, T0c{}); }     // tile 1: layer-2 MFMAs                   ||  tile 0: combination
+            else { p3(sc, T0c{}); p2(sc, T1c{}); }
             if constexpr (s < 6) {
                 __syncthreads();
-                p4(sc, T0c{}); p3(sc, T1c{});         // tile 0: layer-1 MFMAs                   ||  tile 1: combination
+                if (mfma_first) { p4(sc, T0c{}); p3(sc, T1c{}); } // tile 0: layer-1 MFMAs                   ||  tile 1: combination
+                else { p3(sc, T1c{}); p4(sc, T0c{}); }
                 __syncthreads();
             } else p3(sc, T1c{});
         };

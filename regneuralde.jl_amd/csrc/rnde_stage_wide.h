@@ -25,10 +25,12 @@
 // the design pays off.  Either memory stream alone is hidden; together they are not: a wave's vector-memory operations complete in
 // order, a row tile's 26 MFMAs (0.4-0.8 us) do not cover the ~1 us its combination operands take to come back from the Infinity Cache
 // (the XCD's share of the tape, 14 MB, is past its 4 MB L2), and with two 28-register weight blocks in flight there is no room to request
-// them a tile earlier (256 VGPRs + 512 B of scratch already).  What it needs: the weight ring in LDS by DMA (global_load_lds: 98 KB of
-// the 100 KB that GL / HL leave free; -56 VGPRs), the freed registers as a second buffer of combination operands requested one tile
-// ahead, and a constant number of vector-memory operations per tile so that the waits can be counted.  kWideMinTiles is where it would
-// then take over.
+// them a tile earlier (256 VGPRs + 512 B of scratch already).  And behind the latency there is a bandwidth wall: per attempt a workgroup
+// moves 4.1 MB of weights + 1.7 MB of combination operands + 0.85 MB of tape stores = 6.7 MB through its CU's one path to L2 (64 B/clk
+// = 134 GB/s at best; ~70 GB/s was what a CU sustained when round 1's column-owner kernels streamed weights) -- 50-95 us of pure transfer
+// against a 100 us compute floor, so even a perfect ring (weights by DMA into the 98 KB of LDS that GL / HL leave free, operands requested a
+// tile ahead) lands near 150 us at best.  The weight-stationary row-block kernels move 1/7 of a tile's weights ONCE per attempt per CU;
+// that is why they win, and why this layout stays an experiment.
 #pragma once
 #include "rnde_stage_persist.h"
 

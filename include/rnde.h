@@ -296,7 +296,8 @@ rnde_status rnde_comm_health(rnde_comm* c);
  * columns: with this the usual average of the ranks' gradients is the gradient of the single-device loss).  One small collective
  * per attempted step: the parity option, not the fast path (default: independent controllers, rnde_node_set_coupling(h, NULL, 0)).
  * Every rank must make the same calls in the same order and hold the same number of columns (equal shards: the partial arrays are
- * summed element-wise); MNIST-form networks (the stage engine) only. */
+ * summed element-wise).  Engines: the stage engine (MNIST-form networks) and the chain engine's multi-wave kernels (Dense chains of
+ * width <= 64, one launch per attempt -- the one-launch solve keeps its controller in the kernel and is not used when coupled). */
 rnde_status rnde_node_set_coupling(rnde_node* h, rnde_comm* c, int32_t global_batch);
 
 /* ======================================================================================================================

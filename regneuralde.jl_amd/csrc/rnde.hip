@@ -621,7 +621,7 @@ extern "C" rnde_status rnde_node_set_coupling(rnde_node* h, rnde_comm* c, int32_
     if (!h) return RNDE_ERR_BAD_ARG;
     if (!c) { h->couple = nullptr; h->couple_batch = 0; h->couple_world = 1; return RNDE_OK; }
     const int world = rnde_comm_world(c);
-    if (h->engine != 2) { h->err = "coupled controller: MNIST-form networks on the stage engine (col_tile 0 or 16) only"; return RNDE_ERR_BAD_ARG; }
+    if (h->engine != 2 && !(h->engine == 3 && h->mw)) { h->err = "coupled controller: the stage engine (MNIST form, col_tile 0 or 16) and the chain engine's multi-wave kernels only"; return RNDE_ERR_BAD_ARG; }
     if (global_batch < world || world < 1) { h->err = "coupled controller: global_batch must cover every rank"; return RNDE_ERR_BAD_ARG; }
     h->couple = c; h->couple_batch = global_batch; h->couple_world = world;
     return RNDE_OK;
@@ -890,7 +890,9 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
             if (keep_tape) { st = ensure_mw_slab(h, 2 + (long long)(h->rk_S - 1) * std::max(4, h->predicted), P.Bpad, s); if (st != RNDE_OK) return st; }
             MQ = make_mw_params(h, P);
             HIPCHK(h, launch_mw<MW_INIT_A>(h, MQ, 0, s));
+            if ((st = couple_sum(h, P.initpart, 2LL * P.nwg, s)) != RNDE_OK) return st;            // (coupled controller: norms of u0 and f0)
             HIPCHK(h, launch_mw<MW_INIT_B>(h, MQ, 0, s));
+            if ((st = couple_sum(h, P.initpart + 2LL * P.nwg, P.nwg, s)) != RNDE_OK) return st;     // norm of f1 - f0
         } else {
             HIPCHK(h, launch_chain<CM_INIT_A>(h, CQ, 0, nullptr, s));
             HIPCHK(h, launch_chain<CM_INIT_B>(h, CQ, 0, nullptr, s));
@@ -1878,7 +1880,7 @@ static hipError_t launch_bchain_t(rnde_node* h, const BChainParams& Q, const std
 
 // ---- chain engine, multi-wave kernels: reverse pass (rnde_bchainmw.h) ------------------------------------------------------
 template <int NR, int TAB, int LAT = 0>
-static hipError_t launch_bmw_t(rnde_node* h, const BMwParams& Q, const std::vector<int>& sv_lo, const std::vector<int>& sv_hi, hipStream_t s) {
+static rnde_status launch_bmw_t(rnde_node* h, const BMwParams& Q, const std::vector<int>& sv_lo, const std::vector<int>& sv_hi, hipStream_t s) {
     const BwdBuffers& b = h->bw;
     const size_t lds = h->mw_lds_b;
     static bool attr_set = false;
@@ -1886,10 +1888,11 @@ static hipError_t launch_bmw_t(rnde_node* h, const BMwParams& Q, const std::vect
         hipError_t e = hipFuncSetAttribute((const void*)rnde_bchainmw_kernel<NR, TAB, LAT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rnde_bchainmw_init_kernel<NR, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rnde_bchainmw_init_kernel<NR, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
+        HIPCHK(h, e);
         attr_set = true;
     }
     const dim3 grid(Q.ntiles), blk(kMwThreads);
+    rnde_status st = RNDE_OK;
     for (int n = Q.B.n_att - 1; n >= 0; --n) {
         float c1 = 0.f, c2 = 0.f;   // cotangent of eigen_est for this attempt (as in bwd_run)
         const StepMeta& mm = h->h_meta[n];
@@ -1902,11 +1905,16 @@ static hipError_t launch_bmw_t(rnde_node* h, const BMwParams& Q, const std::vect
             c2 = (float)(-eigb * ((double)mm.n1 / (double)mm.n2) / ((double)mm.n2 * (double)mm.n2));
         }
         hipLaunchKernelGGL((rnde_bchainmw_kernel<NR, TAB, LAT>), grid, blk, lds, s, Q, n, mm, sv_lo[n], sv_hi[n], c1, c2);
+        // (coupled controller, SURVEY 8e mode 2: the S, tau, c-tau partials of attempt n summed over the ranks before attempt n - 1 reads them)
+        if ((st = couple_sum(h, b.bpart + (size_t)(n & 1) * Q.B.bpart_n * 4, 4LL * Q.B.bpart_n, s)) != RNDE_OK) return st;
     }
     hipLaunchKernelGGL((rnde_bchainmw_init_kernel<NR, 1>), grid, blk, lds, s, Q);
+    if ((st = couple_sum(h, Q.B.ipart, 4LL * Q.B.F.nwg, s)) != RNDE_OK) return st;                        // dot, tau of the reversed second evaluation
     hipLaunchKernelGGL((rnde_bchainmw_init_kernel<NR, 2>), grid, blk, lds, s, Q);
+    if ((st = couple_sum(h, Q.B.ipart + 4LL * Q.B.F.nwg, 4LL * Q.B.F.nwg, s)) != RNDE_OK) return st;      // tau of the first
     hipLaunchKernelGGL(rnde_bfin_kernel, dim3(1), dim3(64), 0, s, Q.B);
-    return hipGetLastError();
+    HIPCHK(h, hipGetLastError());
+    return RNDE_OK;
 }
 
 static rnde_status chain_mw_bwd_run(rnde_node* h, const float* u_bar_dev, const float* saveval_bar_host, float* x_bar_dev,
@@ -1929,8 +1937,10 @@ static rnde_status chain_mw_bwd_run(rnde_node* h, const float* u_bar_dev, const 
     }
     const int n_att = h->n_att, n_evals = E * n_att + 2;
     if (!h->mw_slab || h->mw_slab_evals < n_evals) { h->err = "activation slab missing: the forward was not taped on the multi-wave kernels"; return RNDE_ERR_NO_TAPE; }
+    // (coupled controller: every rank passes the cotangent of its own loss; the shared scalars carry `world` times it -- as in bwd_run)
+    const float svb_scale = h->couple ? (float)h->couple_world : 1.f;
     for (int i = 0; i < n_att; ++i)
-        b.h_svb[i] = (saveval_bar_host && h->sv_index[i] >= 0) ? saveval_bar_host[h->sv_index[i]] : 0.f;
+        b.h_svb[i] = (saveval_bar_host && h->sv_index[i] >= 0) ? svb_scale * saveval_bar_host[h->sv_index[i]] : 0.f;
     HIPCHK(h, hipMemcpyAsync(b.svb_att, b.h_svb, (size_t)std::max(1, n_att) * 4, hipMemcpyHostToDevice, s));
     BMwParams Q{};
     Q.B.F = make_params(h, h->xcopy, h->B, h->t0, h->t1, 1);
@@ -1939,6 +1949,7 @@ static rnde_status chain_mw_bwd_run(rnde_node* h, const float* u_bar_dev, const 
     Q.B.ubar = u_bar_dev; Q.B.xbar = x_bar_dev; Q.B.tspan_out = b.tspan_out;
     Q.B.n_att = n_att; Q.B.track_ctrl = h->cfg.track_ctrl; Q.B.track_initdt = h->cfg.track_initdt; Q.B.reg_kind = h->cfg.regularize;
     Q.B.bpart_n = Q.B.F.nwg;
+    Q.B.tspan_scale = h->couple ? 1.f / (float)h->couple_world : 1.f;
     Q.B.sv_T = (int)h->saveat.size();
     Q.B.sv_ubar0 = (!h->saveat.empty() && h->saveat[0] == h->t0) ? u_bar_dev : nullptr;
     Q.G = h->mg; Q.rk = h->rk; Q.tab = h->mw_tab; Q.ntiles = Q.B.F.Bpad / 16;
@@ -1961,12 +1972,12 @@ static rnde_status chain_mw_bwd_run(rnde_node* h, const float* u_bar_dev, const 
         }
     }
     HIPCHK(h, hipMemcpyAsync(h->ev_t, h->h_ev_t, (size_t)n_evals * 4, hipMemcpyHostToDevice, s));
-    hipError_t e;
+    rnde_status e;
     if (h->rk_tab == 2) e = h->NKD == 4 ? launch_bmw_t<1, 2>(h, Q, sv_lo, sv_hi, s) : (h->NKD == 8 ? launch_bmw_t<2, 2>(h, Q, sv_lo, sv_hi, s) : launch_bmw_t<4, 2>(h, Q, sv_lo, sv_hi, s));
     else if (h->mw_lat) e = h->rk_tab ? launch_bmw_t<2, 1, 1>(h, Q, sv_lo, sv_hi, s) : launch_bmw_t<2, 0, 1>(h, Q, sv_lo, sv_hi, s);   // latent-ODE shape: transposed weights register stationary
     else if (h->rk_tab) e = h->NKD == 4 ? launch_bmw_t<1, 1>(h, Q, sv_lo, sv_hi, s) : (h->NKD == 8 ? launch_bmw_t<2, 1>(h, Q, sv_lo, sv_hi, s) : launch_bmw_t<4, 1>(h, Q, sv_lo, sv_hi, s));
     else e = h->NKD == 4 ? launch_bmw_t<1, 0>(h, Q, sv_lo, sv_hi, s) : (h->NKD == 8 ? launch_bmw_t<2, 0>(h, Q, sv_lo, sv_hi, s) : launch_bmw_t<4, 0>(h, Q, sv_lo, sv_hi, s));
-    HIPCHK(h, e);
+    if (e != RNDE_OK) return e;
     // parameter gradients of all layers over all evaluations: the one-wave engine's kernel on the same slab format
     BChainParams W{};
     W.G = G; W.ntiles = Q.ntiles; W.slab = h->mw_slab; W.ev_stride = Q.ev_stride; W.RS = h->mg.RS;
@@ -2028,6 +2039,7 @@ static rnde_status chain_bwd_run(rnde_node* h, const float* u_bar_dev, const flo
     Q.B.ubar = u_bar_dev; Q.B.xbar = x_bar_dev; Q.B.tspan_out = b.tspan_out;
     Q.B.n_att = n_att; Q.B.track_ctrl = h->cfg.track_ctrl; Q.B.track_initdt = h->cfg.track_initdt; Q.B.reg_kind = h->cfg.regularize;
     Q.B.bpart_n = Q.B.F.nwg;
+    Q.B.tspan_scale = h->couple ? 1.f / (float)h->couple_world : 1.f;
     Q.B.sv_T = (int)h->saveat.size();
     Q.B.sv_ubar0 = (!h->saveat.empty() && h->saveat[0] == h->t0) ? u_bar_dev : nullptr;
     Q.G = G; Q.frags = h->cfrags; Q.ntiles = Q.B.F.Bpad / 16;

@@ -15,9 +15,12 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _setup(B, seed, scale):
-    from tests.test_gpu_forward import _setup as base
-    return base("small", B, seed, scale)      # MNIST-form network (D = 36, H = 10) on the stage engine
+def _setup(B, seed, scale, kind="small"):
+    if kind == "small":
+        from tests.test_gpu_forward import _setup as base
+        return base("small", B, seed, scale)      # MNIST-form network (D = 36, H = 10) on the stage engine
+    from tests.test_gpu_chain import _setup as chain
+    return chain(kind, B, seed, scale)            # Dense chains on the chain engine's multi-wave kernels (col_tile 65)
 
 
 def _run(node, x, p, ubar, svb):
@@ -29,15 +32,30 @@ def _run(node, x, p, ubar, svb):
 @pytest.mark.parametrize("persist", [1, 0])
 @pytest.mark.parametrize("B,world,tol,scale", [(64, 2, 1e-3, 5.0), (70, 2, 1e-4, 4.0), (128, 4, 1e-4, 4.0)])
 def test_coupled_shards_reproduce_the_single_device_run(B, world, tol, scale, persist, monkeypatch):
-    from regneuralde_jl_amd import _lib
-    from tests.test_gpu_forward import _cfg
-    from tests.util import Node
     monkeypatch.setenv("RNDE_PERSIST", str(persist))
+    _coupled_case("small", 16, B, world, tol, scale)
+
+
+@pytest.mark.parametrize("kind,B,world,tol,scale", [("latent", 64, 2, 1e-4, 2.0), ("latent", 70, 2, 1e-3, 2.0), ("chain3", 128, 4, 1e-4, 2.0),
+                                                      ("wide", 96, 2, 1e-3, 1.5)])
+@pytest.mark.parametrize("svb,gtol", [(0.0, 2e-4), (3.0, 1e-3)])
+def test_coupled_shards_on_the_chain_engine(kind, B, world, tol, scale, svb, gtol):
+    """The same property on the chain engine's multi-wave kernels (one launch per attempt when coupled: the one-launch solve keeps its
+    controller inside the kernel and is not used with a shared controller).  Without a cotangent on the saved EEst*dt values the
+    gradients agree as on the stage engine; with one, the term's own fp32 noise (the gradient of a rounding-floor quantity)
+    sets the bound."""
+    _coupled_case(kind, 65, B, world, tol, scale, svb, gtol)
+
+
+def _coupled_case(kind, tile, B, world, tol, scale, svb=3.0, gtol=2e-4):
+    from regneuralde_jl_amd import _lib
+    from tests.test_gpu_forward import _cfg as _cfg0
+    from tests.util import Node
+    _cfg = lambda a, b, **kw: _cfg0(a, b, **{**kw, "col_tile": tile})
     L = _lib.lib()
-    arch, p, x = _setup(B, 21, scale)
+    arch, p, x = _setup(B, 21, scale, kind)
     rng = np.random.default_rng(22)
     ubar = rng.standard_normal(x.shape).astype(np.float32) / B          # data term of the single-device loss: a mean over all columns
-    svb = 3.0
     ref, rx, rp, rt = _run(Node(_cfg(arch, B, reltol=tol, abstol=tol, col_tile=16)), x, p, ubar, svb)
     print("attempts", len(ref["steps"]), "rejected", int((ref["steps"][:, 3] == 0).sum()))
 
@@ -65,7 +83,9 @@ def test_coupled_shards_reproduce_the_single_device_run(B, world, tol, scale, pe
         g = out[r][0]
         assert g["nfe"] == ref["nfe"] and np.array_equal(g["steps"][:, 3], ref["steps"][:, 3])
         np.testing.assert_allclose(g["steps"][:, 1], ref["steps"][:, 1], rtol=2e-5)
-        np.testing.assert_allclose(g["saveval"], ref["saveval"], rtol=2e-4, atol=1e-9)
+        # (EEst*dt: the error estimate is a difference of stage values, so last-bit differences of dt show at ~1e-3 relative on the
+        #  three-layer chains at tol 1e-4, where it sits closer to its fp32 rounding floor than on the MNIST form)
+        np.testing.assert_allclose(g["saveval"], ref["saveval"], rtol=2e-4 if kind == "small" else 2e-3, atol=1e-9)
         assert np.abs(g["u"] - ref["u"][lo:hi]).max() <= 2e-5 * max(1.0, np.abs(ref["u"]).max())
         # every rank holds the same controller history bit for bit
         assert np.array_equal(g["steps"], out[0][0]["steps"]) and np.array_equal(g["saveval"], out[0][0]["saveval"])
@@ -74,10 +94,10 @@ def test_coupled_shards_reproduce_the_single_device_run(B, world, tol, scale, pe
     gt = sum(o[3] for o in out) / world
     scale_p = np.abs(rp).max()
     print("p-bar", np.abs(gp - rp).max() / scale_p, "tspan-bar", gt, rt)
-    assert np.abs(gp - rp).max() <= 2e-4 * scale_p
-    assert np.abs(gt - rt).max() <= 2e-4 * max(1.0, np.abs(rt).max())
+    assert np.abs(gp - rp).max() <= gtol * scale_p
+    assert np.abs(gt - rt).max() <= gtol * max(1.0, np.abs(rt).max())
     for r, (lo, hi) in enumerate(shards):
-        assert np.abs(out[r][1] / world - rx[lo:hi]).max() <= 2e-4 * np.abs(rx).max()
+        assert np.abs(out[r][1] / world - rx[lo:hi]).max() <= gtol * np.abs(rx).max()
     for c in comms:
         L.rnde_comm_destroy(C.c_void_p(c))
 
@@ -105,7 +125,9 @@ def test_coupling_with_one_rank_through_rccl_is_the_uncoupled_run():
     L.rnde_comm_destroy(comm)
 
 
-def test_coupling_is_refused_off_the_stage_engine():
+@pytest.mark.parametrize("tile", [64])
+def test_coupling_is_refused_on_the_one_wave_kernels(tile):
+    """The shared controller lives where the headline paths live: the stage engine and the chain engine's multi-wave kernels."""
     from regneuralde_jl_amd import _lib
     from oracle.oracle import arch_latent
     from tests.test_gpu_forward import _cfg
@@ -113,6 +135,6 @@ def test_coupling_is_refused_off_the_stage_engine():
     L = _lib.lib()
     comms = (C.c_void_p * 1)()
     assert L.rnde_comm_create_local_group(1, 0, comms) == 0
-    n = Node(_cfg(arch_latent(), 16))
+    n = Node(_cfg(arch_latent(), 16, col_tile=tile))
     assert L.rnde_node_set_coupling(n.h, C.c_void_p(comms[0]), 16) == _lib.BAD_ARG
     L.rnde_comm_destroy(C.c_void_p(comms[0]))

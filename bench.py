@@ -420,7 +420,9 @@ def main():
         dist_diag = {"nfe_per_rank": nf, "nfe_min": min(nf), "nfe_mean": sum(nf) / len(nf), "nfe_max": max(nf),
                      "persist_fallback_count_per_rank": [int(v[1]) for v in allv], "launches_per_attempt_per_rank": [int(v[2]) for v in allv],
                      "allreduce_us": ar_us, "allreduce_floats": int(fg.flat.numel()) if fg is not None else None,
-                     "collective_library": L.rnde_comm_library().decode() if reducer is not None and reducer.comm is not None else None}
+                     "collective_library": L.rnde_comm_library().decode() if reducer is not None and reducer.comm is not None else None,
+                     # (RNDE_ONESHOT=1 in the environment: the one-shot kernel over peer-mapped windows instead of ncclAllReduce)
+                     "collective_path": L.rnde_comm_path(reducer.comm).decode() if reducer is not None and reducer.comm is not None else None}
 
     out = None
     if rank == 0:

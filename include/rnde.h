@@ -282,9 +282,25 @@ rnde_status rnde_comm_allreduce(rnde_comm* c, float* buf_dev, int64_t n, int32_t
  * per rank meeting the others through device memory (n <= 8192 floats).  What the coupled controller below is tested with on a
  * single GPU (two host threads, two handles), and what several shards per device would use. */
 rnde_status rnde_comm_create_local_group(int32_t world, int32_t device, rnde_comm** out);
-/* RNDE_OK unless an all-reduce of this communicator gave up waiting for a rank (in-process groups; blocking: call after the stream
- * has been synchronised).  The coupled solves below check it themselves at their synchronisation points. */
+/* RNDE_OK unless an all-reduce of this communicator gave up waiting for a rank (in-process groups and the one-shot path; blocking:
+ * call after the stream has been synchronised).  The coupled solves below check it themselves at their synchronisation points. */
 rnde_status rnde_comm_health(rnde_comm* c);
+/* One-shot all-reduce over peer-mapped windows (the 0.67 MB gradient message is latency bound, so each rank reads
+ * the N - 1 peers' copies directly over its xGMI links in ONE kernel and sums them in rank order -- the same bits on every rank --
+ * instead of walking a ring).  Every rank owns a window in its HBM, exported with hipIpcGetMemHandle and mapped by all peers
+ * (world <= 16, one process per rank, all on one node).  OPT-IN until it has been measured on N > 1 GPUs; two ways in:
+ *   RNDE_ONESHOT=1 in the environment of rnde_comm_create: the handles travel through the RCCL communicator that call builds (one
+ *     64-byte all-gather); all-reduces of n <= 262,144 floats then take the one-shot kernel, larger ones ncclAllReduce;
+ *   rnde_comm_window_create(device, &win, handle) on every rank -> ship the 64 bytes to all ranks by any means ->
+ *     rnde_comm_create_peers(win, handles_in_rank_order, rank, world, &c) (takes ownership of win): no RCCL at all; larger buffers go
+ *     in pieces of 262,144 floats.
+ * rnde_comm_path says which path a communicator's all-reduces take. */
+#define RNDE_COMM_WINDOW_BYTES 64
+typedef struct rnde_comm_window rnde_comm_window;
+rnde_status rnde_comm_window_create(int32_t device, rnde_comm_window** win_out, uint8_t handle_out[RNDE_COMM_WINDOW_BYTES]);
+void        rnde_comm_window_destroy(rnde_comm_window* w);   /* only for a window that was NOT handed to rnde_comm_create_peers */
+rnde_status rnde_comm_create_peers(rnde_comm_window* win, const uint8_t* handles, int32_t rank, int32_t world, rnde_comm** out);
+const char* rnde_comm_path(const rnde_comm* c);
 
 /* SURVEY.md 8e mode 2 -- ONE controller for all shards: with the minibatch split by columns over `world` handles, the error norm
  * that drives the step size is the RMS over ALL D x B_global entries (what a single-device run at B_global computes), so every

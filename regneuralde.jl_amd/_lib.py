@@ -101,6 +101,12 @@ def lib():
     L.rnde_comm_create_local_group.argtypes = [i32, i32, C.POINTER(vp)]
     L.rnde_node_set_coupling.argtypes = [vp, vp, i32]
     L.rnde_comm_health.argtypes = [vp]
+    L.rnde_comm_window_create.argtypes = [i32, C.POINTER(vp), C.c_char_p]
+    L.rnde_comm_window_destroy.argtypes = [vp]
+    L.rnde_comm_window_destroy.restype = None
+    L.rnde_comm_create_peers.argtypes = [vp, C.c_char_p, i32, i32, C.POINTER(vp)]
+    L.rnde_comm_path.argtypes = [vp]
+    L.rnde_comm_path.restype = C.c_char_p
     L.rnde_tapes_create.argtypes = [C.POINTER(NodeConfig), i32, C.POINTER(vp)]
     L.rnde_tapes_destroy.argtypes = [vp]
     L.rnde_tapes_destroy.restype = None
@@ -139,7 +145,7 @@ EXPORTS = ["rnde_version", "rnde_last_error", "rnde_param_count", "rnde_node_cre
            "rnde_node_backward_host", "rnde_node_steps", "rnde_debug_feval", "rnde_debug_attempt",
            "rnde_bench_attempt", "rnde_bench_attempt_taped", "rnde_bench_attempt_cold_tape", "rnde_node_set_timing", "rnde_node_timing", "rnde_node_last_attempts", "rnde_node_fallback_count",
            "rnde_node_launches_per_attempt", "rnde_classifier_head", "rnde_node_classifier_grad", "rnde_momentum_step", "rnde_momentum_step_scaled", "rnde_adam_step",
-           "rnde_comm_unique_id", "rnde_comm_create", "rnde_comm_destroy", "rnde_comm_world", "rnde_comm_last_error", "rnde_comm_library", "rnde_comm_allreduce", "rnde_comm_create_local_group", "rnde_comm_health", "rnde_node_set_coupling", "rnde_has_column_owner", "rnde_tapes_create", "rnde_tapes_destroy", "rnde_tapes_last_error", "rnde_tapes_in_use", "rnde_tapes_node", "rnde_tapes_forward", "rnde_tapes_backward", "rnde_tapes_release",
+           "rnde_comm_unique_id", "rnde_comm_create", "rnde_comm_destroy", "rnde_comm_world", "rnde_comm_last_error", "rnde_comm_library", "rnde_comm_allreduce", "rnde_comm_create_local_group", "rnde_comm_health", "rnde_comm_window_create", "rnde_comm_window_destroy", "rnde_comm_create_peers", "rnde_comm_path", "rnde_node_set_coupling", "rnde_has_column_owner", "rnde_tapes_create", "rnde_tapes_destroy", "rnde_tapes_last_error", "rnde_tapes_in_use", "rnde_tapes_node", "rnde_tapes_forward", "rnde_tapes_backward", "rnde_tapes_release",
            "rnde_nsde_param_count", "rnde_nsde_create", "rnde_nsde_destroy", "rnde_nsde_last_error", "rnde_nsde_forward",
            "rnde_nsde_forward_saveat", "rnde_nsde_forward_replay", "rnde_nsde_backward", "rnde_nsde_backward_async", "rnde_nsde_classifier_head", "rnde_nsde_classifier_grad", "rnde_nsde_steps", "rnde_nsde_debug_attempt", "rnde_nsde_timing", "rnde_normal_fill"]
 

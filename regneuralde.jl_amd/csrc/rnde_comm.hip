@@ -11,9 +11,12 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -30,6 +33,7 @@ struct RcclApi {
     int (*CommInitRank)(nccl_comm_t*, int, nccl_unique_id, int) = nullptr;
     int (*CommDestroy)(nccl_comm_t) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, nccl_comm_t, hipStream_t) = nullptr;   // (one-shot path: ships the window handles)
     const char* (*GetErrorString)(int) = nullptr;
     std::string err;
 };
@@ -60,6 +64,7 @@ RcclApi& api() {
         a.CommDestroy = (decltype(a.CommDestroy))sym("ncclCommDestroy");
         a.AllReduce = (decltype(a.AllReduce))sym("ncclAllReduce");
         a.GetErrorString = (decltype(a.GetErrorString))sym("ncclGetErrorString");
+        a.AllGather = (decltype(a.AllGather))dlsym(a.lib, "ncclAllGather");
     });
     return a;
 }
@@ -113,15 +118,175 @@ __global__ __launch_bounds__(256) void rnde_local_sum_kernel(float* __restrict__
     }
 }
 
+
+// ---- one-shot all-reduce over peer-mapped windows (the gradient message is 0.67 MB -- latency bound, so every rank
+// reads the N - 1 peers' copies directly over its 7 xGMI links in ONE kernel instead of walking a ring).  Every rank owns a WINDOW in its
+// own HBM ([flags | 2 data slots]), exported with hipIpcGetMemHandle and mapped by every peer.  One kernel per all-reduce and rank:
+//   a. block w copies its chunk of `buf` into this rank's slot (seq & 1), fences to system scope, and stores `seq` into flag
+//      (slot, this rank, w) of EVERY peer's window (remote 4-byte stores: the peers poll local memory);
+//   b. block w waits until flags (slot, p, w) of its own window carry `seq` for every peer p, acquires at system scope;
+//   c. block w sums its chunk over the ranks' slots IN RANK ORDER (every rank computes the same bits) and writes `buf`.
+// Block w touches chunk w on every rank, so per-block flags are the whole synchronisation -- no grid-wide meeting.  Two slots alternate:
+// a rank rewrites a slot at seq + 2, which it reaches only after every peer has signalled seq + 1, i.e. finished reading seq.
+// A wait gives up after kPeerTimeoutTicks of the 100 MHz wall clock and raises the window's `fail` word (rnde_comm_health) rather than
+// hanging the queue.  Opt-in (RNDE_ONESHOT=1 with rnde_comm_create, or rnde_comm_create_peers with handles the caller exchanged):
+// RCCL stays the default until the path has been measured on N > 1 GPUs.
+constexpr int kPeerMaxWorld = 16;
+constexpr int kPeerBlocks = 64;                       // workgroups per all-reduce at most (0.67 MB: 41.6 K float4 = 2.5 per thread and peer)
+constexpr long long kPeerCap = 256 * 1024;            // floats per slot (1 MB); larger buffers go in pieces (or to RCCL when the communicator has one)
+constexpr size_t kPeerFlagBytes = 8192;               // [2 slots][kPeerMaxWorld][kPeerBlocks] unsigned = 8 KB, then one page of padding
+constexpr size_t kPeerDataOffset = 16384;
+constexpr size_t kPeerWindowBytes = kPeerDataOffset + 2 * (size_t)kPeerCap * 4;
+constexpr long long kPeerTimeoutTicks = 5LL * 100000000;   // 5 s
+
+struct PeerView {
+    float* data[kPeerMaxWorld];        // rank r's data slots as mapped in THIS process (own rank: the local pointer)
+    unsigned* flags[kPeerMaxWorld];    // rank r's flag array
+    unsigned* fail;                    // local: raised when a wait gave up
+    int world, rank;
+};
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void rnde_peer_allreduce_kernel(PeerView V, float* __restrict__ buf, long long n, long long chunk, unsigned seq, float scale) {
+    const int w = blockIdx.x, tid = threadIdx.x, slot = (int)(seq & 1u);
+    const long long lo = (long long)w * chunk, hi = lo + chunk < n ? lo + chunk : n;     // chunk is a multiple of 4: lo is 16-byte aligned in the windows
+    const long long len = hi - lo, nv = ALIGNED ? len / 4 : 0;
+    float* mine = V.data[V.rank] + (size_t)slot * kPeerCap;
+    // a. publish
+    if (ALIGNED) for (long long i = tid; i < nv; i += 256) ((float4*)(mine + lo))[i] = ((const float4*)(buf + lo))[i];
+    for (long long i = lo + 4 * nv + tid; i < hi; i += 256) mine[i] = buf[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // system scope: the stores above are in memory before the flags below
+    __syncthreads();
+    if (tid < V.world && tid != V.rank)
+        __hip_atomic_store(V.flags[tid] + ((size_t)slot * kPeerMaxWorld + V.rank) * kPeerBlocks + w, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // b. wait for the peers' chunk w
+    if (tid < V.world && tid != V.rank) {
+        const unsigned* f = V.flags[V.rank] + ((size_t)slot * kPeerMaxWorld + tid) * kPeerBlocks + w;
+        const long long t0 = wall_clock64();
+        while ((int)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+            if (wall_clock64() - t0 > kPeerTimeoutTicks) { atomicExch(V.fail, 1u); break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    // c. sum in rank order
+    const float* src[kPeerMaxWorld];
+#pragma unroll
+    for (int r = 0; r < kPeerMaxWorld; ++r) src[r] = r < V.world ? V.data[r] + (size_t)slot * kPeerCap : nullptr;
+    if (ALIGNED) for (long long i = tid; i < nv; i += 256) {
+        float4 v[kPeerMaxWorld];
+#pragma unroll
+        for (int r = 0; r < kPeerMaxWorld; ++r) if (r < V.world) v[r] = ((const float4*)(src[r] + lo))[i];
+        float4 a = v[0];
+#pragma unroll
+        for (int r = 1; r < kPeerMaxWorld; ++r) if (r < V.world) { a.x += v[r].x; a.y += v[r].y; a.z += v[r].z; a.w += v[r].w; }
+        a.x *= scale; a.y *= scale; a.z *= scale; a.w *= scale;
+        ((float4*)(buf + lo))[i] = a;
+    }
+    for (long long i = lo + 4 * nv + tid; i < hi; i += 256) {
+        float a = src[0][i];
+        for (int r = 1; r < V.world; ++r) a += src[r][i];
+        buf[i] = a * scale;
+    }
+}
+
+struct PeerState {
+    void* window = nullptr;            // this rank's window (own allocation)
+    void* mapped[kPeerMaxWorld] = {nullptr};   // the peers' windows as opened here
+    PeerView view{};
+    const char* kind = "";
+};
+
+}  // namespace
+
+struct rnde_comm_window {
+    void* base = nullptr;
+    int device = 0;
+    const char* kind = "";
+};
+
+namespace {
+
+rnde_status window_alloc(int device, rnde_comm_window** out, uint8_t* handle_out, std::string& err) {
+    *out = nullptr;
+    if (hipSetDevice(device) != hipSuccess) { err = "hipSetDevice failed"; return RNDE_ERR_NO_DEVICE; }
+    rnde_comm_window* w = new rnde_comm_window();
+    w->device = device;
+    // uncached at the device's L2 first (what the peers read is what was stored), then fine-grained, then plain device memory (the
+    // kernel's system-scope fences write back / invalidate either way)
+    if (hipExtMallocWithFlags(&w->base, kPeerWindowBytes, hipDeviceMallocUncached) == hipSuccess) w->kind = "uncached";
+    else if (hipExtMallocWithFlags(&w->base, kPeerWindowBytes, hipDeviceMallocFinegrained) == hipSuccess) w->kind = "fine-grained";
+    else if (hipMalloc(&w->base, kPeerWindowBytes) == hipSuccess) w->kind = "coarse-grained";
+    else { (void)hipGetLastError(); err = "window allocation failed"; delete w; return RNDE_ERR_HIP; }
+    (void)hipGetLastError();
+    hipIpcMemHandle_t h;
+    static_assert(sizeof(h) == RNDE_COMM_WINDOW_BYTES, "ipc handle size");
+    if (hipMemset(w->base, 0, kPeerDataOffset) != hipSuccess || hipDeviceSynchronize() != hipSuccess || hipIpcGetMemHandle(&h, w->base) != hipSuccess) {
+        err = std::string("window export failed: ") + hipGetErrorString(hipGetLastError());
+        (void)hipFree(w->base); delete w; return RNDE_ERR_HIP;
+    }
+    std::memcpy(handle_out, &h, sizeof(h));
+    *out = w;
+    return RNDE_OK;
+}
+
 }  // namespace
 
 struct rnde_comm {
     nccl_comm_t comm = nullptr;
     int rank = 0, world = 1, device = 0;
     LocalShared* loc = nullptr;   // non-null: a rank of an in-process group
-    unsigned seq = 0;
-    std::string err;
+    PeerState* peer = nullptr;    // non-null: peer-mapped windows for the one-shot all-reduce
+    unsigned seq = 0, peer_seq = 0;
+    std::string err, path;
 };
+
+namespace {
+
+// Map the peers' windows (handles in rank order; this rank's own entry is not opened) and take ownership of `win`.
+rnde_status peers_attach(rnde_comm* c, rnde_comm_window* win, const uint8_t* handles, std::string& err) {
+    if (c->world > kPeerMaxWorld) { err = "one-shot all-reduce: at most 16 ranks"; return RNDE_ERR_BAD_ARG; }
+    PeerState* P = new PeerState();
+    P->window = win->base; P->kind = win->kind;
+    for (int r = 0; r < c->world; ++r) {
+        void* base = win->base;
+        if (r != c->rank) {
+            hipIpcMemHandle_t h;
+            std::memcpy(&h, handles + (size_t)r * RNDE_COMM_WINDOW_BYTES, sizeof(h));
+            if (hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+                err = std::string("hipIpcOpenMemHandle (rank ") + std::to_string(r) + "): " + hipGetErrorString(hipGetLastError());
+                for (int q = 0; q < r; ++q) if (P->mapped[q]) (void)hipIpcCloseMemHandle(P->mapped[q]);
+                delete P; return RNDE_ERR_HIP;
+            }
+            P->mapped[r] = base;
+        }
+        P->view.flags[r] = (unsigned*)base;
+        P->view.data[r] = (float*)((char*)base + kPeerDataOffset);
+    }
+    P->view.fail = (unsigned*)((char*)win->base + kPeerFlagBytes);     // (in the padding page behind the flags)
+    P->view.world = c->world; P->view.rank = c->rank;
+    c->peer = P;
+    c->path = std::string("one-shot over peer-mapped windows (") + win->kind + " device memory, hipIpc)";
+    delete win;
+    return RNDE_OK;
+}
+
+rnde_status peer_allreduce(rnde_comm* c, float* buf, long long n, float scale, hipStream_t s) {
+    for (long long off = 0; off < n; off += kPeerCap) {
+        const long long m = std::min<long long>(kPeerCap, n - off);
+        const int G = (int)std::max<long long>(1, std::min<long long>(kPeerBlocks, (m + 1023) / 1024));
+        const long long chunk = (((m + G - 1) / G) + 3) & ~3LL;
+        const unsigned seq = ++c->peer_seq;
+        float* b = buf + off;
+        if (((uintptr_t)b & 15) == 0) hipLaunchKernelGGL(rnde_peer_allreduce_kernel<true>, dim3(G), dim3(256), 0, s, c->peer->view, b, m, chunk, seq, scale);
+        else hipLaunchKernelGGL(rnde_peer_allreduce_kernel<false>, dim3(G), dim3(256), 0, s, c->peer->view, b, m, chunk, seq, scale);
+        if (hipGetLastError() != hipSuccess) { c->err = "one-shot all-reduce: launch failed"; return RNDE_ERR_HIP; }
+    }
+    return RNDE_OK;
+}
+
+}  // namespace
 
 extern "C" const char* rnde_comm_last_error(const rnde_comm* c) { return c ? c->err.c_str() : g_comm_err.c_str(); }
 
@@ -148,9 +313,62 @@ extern "C" rnde_status rnde_comm_create(const uint8_t id[RNDE_COMM_ID_BYTES], in
     std::memcpy(&uid, id, sizeof(uid));
     const int r = a.CommInitRank(&c->comm, world, uid, rank);
     if (r != kNcclSuccess) { g_comm_err = std::string("ncclCommInitRank: ") + a.GetErrorString(r); delete c; return RNDE_ERR_HIP; }
+    c->path = "RCCL (ncclAllReduce)";
+    const char* one = getenv("RNDE_ONESHOT");
+    if (one && one[0] == '1' && world > 1) {
+        // the windows' handles travel through the communicator that was just built: one 64-byte all-gather
+        rnde_comm_window* win = nullptr;
+        uint8_t mine[RNDE_COMM_WINDOW_BYTES];
+        std::string err;
+        rnde_status st = window_alloc(device, &win, mine, err);
+        uint8_t* dev = nullptr;
+        std::string all((size_t)world * RNDE_COMM_WINDOW_BYTES, '\0');
+        if (st == RNDE_OK && !a.AllGather) { err = "RCCL symbol missing: ncclAllGather"; st = RNDE_ERR_HIP; }
+        if (st == RNDE_OK && (hipMalloc((void**)&dev, (size_t)(world + 1) * RNDE_COMM_WINDOW_BYTES) != hipSuccess ||
+                              hipMemcpy(dev, mine, RNDE_COMM_WINDOW_BYTES, hipMemcpyHostToDevice) != hipSuccess)) { err = "handle staging failed"; st = RNDE_ERR_HIP; }
+        if (st == RNDE_OK) {
+            const int g = a.AllGather(dev, dev + RNDE_COMM_WINDOW_BYTES, RNDE_COMM_WINDOW_BYTES, /*ncclInt8*/ 0, c->comm, nullptr);
+            if (g != kNcclSuccess || hipStreamSynchronize(nullptr) != hipSuccess ||
+                hipMemcpy(&all[0], dev + RNDE_COMM_WINDOW_BYTES, all.size(), hipMemcpyDeviceToHost) != hipSuccess) { err = "ncclAllGather of the window handles failed"; st = RNDE_ERR_HIP; }
+        }
+        if (dev) (void)hipFree(dev);
+        if (st == RNDE_OK) st = peers_attach(c, win, (const uint8_t*)all.data(), err);
+        if (st != RNDE_OK) {   // asked for and not available: say so rather than fall back silently
+            g_comm_err = "RNDE_ONESHOT=1: " + err;
+            if (win) { (void)hipFree(win->base); delete win; }
+            (void)a.CommDestroy(c->comm); delete c; return st;
+        }
+    }
     *out = c;
     return RNDE_OK;
 }
+
+extern "C" rnde_status rnde_comm_window_create(int32_t device, rnde_comm_window** win_out, uint8_t handle_out[RNDE_COMM_WINDOW_BYTES]) {
+    if (!win_out || !handle_out) return RNDE_ERR_BAD_ARG;
+    return window_alloc(device, win_out, handle_out, g_comm_err);
+}
+
+extern "C" void rnde_comm_window_destroy(rnde_comm_window* w) {
+    if (!w) return;
+    (void)hipSetDevice(w->device);
+    (void)hipFree(w->base);
+    delete w;
+}
+
+extern "C" rnde_status rnde_comm_create_peers(rnde_comm_window* win, const uint8_t* handles, int32_t rank, int32_t world, rnde_comm** out) {
+    if (!out) return RNDE_ERR_BAD_ARG;
+    *out = nullptr;
+    if (!win || !handles || world < 1 || world > kPeerMaxWorld || rank < 0 || rank >= world) { g_comm_err = "window / handles / rank / world (1..16) out of range"; return RNDE_ERR_BAD_ARG; }
+    if (hipSetDevice(win->device) != hipSuccess) { g_comm_err = "hipSetDevice failed"; return RNDE_ERR_NO_DEVICE; }
+    rnde_comm* c = new rnde_comm();
+    c->rank = rank; c->world = world; c->device = win->device;
+    const rnde_status st = peers_attach(c, win, handles, g_comm_err);
+    if (st != RNDE_OK) { delete c; return st; }
+    *out = c;
+    return RNDE_OK;
+}
+
+extern "C" const char* rnde_comm_path(const rnde_comm* c) { return c ? c->path.c_str() : ""; }
 
 extern "C" rnde_status rnde_comm_create_local_group(int32_t world, int32_t device, rnde_comm** out) {
     if (!out || world < 1 || world > kLocalMaxWorld) { g_comm_err = "world: 1..64"; return RNDE_ERR_BAD_ARG; }
@@ -166,6 +384,7 @@ extern "C" rnde_status rnde_comm_create_local_group(int32_t world, int32_t devic
     for (int r = 0; r < world; ++r) {
         rnde_comm* c = new rnde_comm();
         c->rank = r; c->world = world; c->device = device; c->loc = L;
+        c->path = "in-process group (host meeting, events)";
         L->refs++;
         out[r] = c;
     }
@@ -175,6 +394,13 @@ extern "C" rnde_status rnde_comm_create_local_group(int32_t world, int32_t devic
 extern "C" void rnde_comm_destroy(rnde_comm* c) {
     if (!c) return;
     if (c->comm) (void)api().CommDestroy(c->comm);
+    if (c->peer) {
+        (void)hipSetDevice(c->device);
+        (void)hipDeviceSynchronize();
+        for (int r = 0; r < c->world; ++r) if (c->peer->mapped[r]) (void)hipIpcCloseMemHandle(c->peer->mapped[r]);
+        (void)hipFree(c->peer->window);
+        delete c->peer;
+    }
     if (c->loc && --c->loc->refs == 0) {
         for (int sl = 0; sl < 2; ++sl)
             for (int r = 0; r < c->loc->world; ++r) { if (c->loc->ev_pub[sl][r]) (void)hipEventDestroy(c->loc->ev_pub[sl][r]); if (c->loc->ev_done[sl][r]) (void)hipEventDestroy(c->loc->ev_done[sl][r]); }
@@ -188,6 +414,12 @@ extern "C" int32_t rnde_comm_world(const rnde_comm* c) { return c ? c->world : 0
 
 // Did an all-reduce of this communicator give up waiting for a rank?  (In-process groups; RCCL reports its failures from the enqueue call.)
 extern "C" rnde_status rnde_comm_health(rnde_comm* c) {
+    if (c && c->peer) {
+        unsigned f = 0;
+        if (hipSetDevice(c->device) != hipSuccess || hipMemcpy(&f, c->peer->view.fail, 4, hipMemcpyDeviceToHost) != hipSuccess) { c->err = "one-shot all-reduce: cannot read the window"; return RNDE_ERR_HIP; }
+        if (f) { c->err = "one-shot all-reduce: a wait for a peer's chunk gave up after 5 s (every rank must make the same calls in the same order)"; return RNDE_ERR_HIP; }
+        return RNDE_OK;
+    }
     if (!c || !c->loc) return RNDE_OK;
     std::lock_guard<std::mutex> g(c->loc->mu);
     if (c->loc->failed) { c->err = "an all-reduce gave up waiting for a rank (every rank must make the same calls, each from its own host thread)"; return RNDE_ERR_HIP; }
@@ -226,6 +458,8 @@ extern "C" rnde_status rnde_comm_allreduce(rnde_comm* c, float* buf_dev, int64_t
         hipLaunchKernelGGL(rnde_local_sum_kernel, dim3(blocks), dim3(256), 0, s, buf_dev, (int)n, L->data + (size_t)slot * L->world * kLocalMaxCount, L->world);
         ok = ok && hipGetLastError() == hipSuccess && hipEventRecord(L->ev_done[slot][c->rank], s) == hipSuccess;
         if (!ok) { c->err = "in-process all-reduce: enqueue failed"; return RNDE_ERR_HIP; }
+    } else if (c->peer && (n <= kPeerCap || !c->comm)) {
+        return peer_allreduce(c, buf_dev, n, (mean && c->world > 1) ? 1.0f / (float)c->world : 1.0f, s);   // (the scale rides in the kernel)
     } else {
         const int r = api().AllReduce(buf_dev, buf_dev, (size_t)n, kNcclFloat32, kNcclSum, c->comm, s);
         if (r != kNcclSuccess) { c->err = std::string("ncclAllReduce: ") + api().GetErrorString(r); return RNDE_ERR_HIP; }

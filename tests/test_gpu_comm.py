@@ -113,3 +113,33 @@ def test_in_process_group_allreduce(world):
         assert L.rnde_comm_health(C.c_void_p(comms[r])) == 0
     for c in comms:
         L.rnde_comm_destroy(C.c_void_p(c))
+
+
+@pytest.mark.parametrize("world,mean", [(2, 0), (4, 1)])
+def test_one_shot_allreduce_between_processes(world, mean, tmp_path):
+    """rnde_comm_window_create / rnde_comm_create_peers: `world` PROCESSES (tools/oneshot_worker.py), each with its own window, mapped
+    into every peer through hipIpc -- on the one GPU of the test box all ranks sit on device 0, the mapping and the kernel are the ones
+    a multi-GPU node runs.  Every rank checks every all-reduce bit for bit against the rank-order fp32 sum: sizes 1 .. 300,001 floats
+    (above one window slot: pieces), aligned and unaligned buffers, both slot sets, with and without the 1 / world scale."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tools", "oneshot_worker.py"), "--rank", str(r), "--world", str(world),
+                               "--dir", str(tmp_path), "--mean", str(mean)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            o, e = p.communicate(timeout=240)
+            assert p.returncode == 0, e[-2000:]
+            outs.append(json.loads(o.strip().splitlines()[-1]))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    print(outs)
+    for o in outs:
+        assert o["mismatches"] == 0 and o["checked"] == 42 and o["health"] == 0
+        assert "one-shot" in o["path"]

@@ -298,6 +298,8 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) and run the gradient all-reduce even at world size 1: exercises the N > 1 code path on a 1-GPU box")
     ap.add_argument("--coupled", action="store_true", help="SURVEY 8e mode 2: ONE step-size controller for all ranks (rnde_node_set_coupling: an all-reduce of the error-norm "
                     "partials after every attempted step; reproduces the single-device run at the global batch; default: independent controllers)")
+    ap.add_argument("--share-gpu", action="store_true", help="test rig: every rank on device 0, torch.distributed on gloo, the gradient collective = the library's one-shot "
+                    "kernel over peer-mapped windows (no RCCL: it refuses two ranks on one GPU); the N > 1 code path on a 1-GPU box, not a throughput claim")
     ap.add_argument("--workload", default="mnist", choices=["mnist", "latent", "nsde"], help="mnist = BASELINE.json's metric (default); latent = config 4; nsde = config 5")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -314,7 +316,7 @@ def main():
         return print(json.dumps(bench_nsde(args)), flush=True)
 
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -323,7 +325,11 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    ddev = torch.device("cpu") if args.share_gpu else device      # where the bench's own bookkeeping tensors live
 
     import regneuralde_jl_amd as rn
     from regneuralde_jl_amd import _lib
@@ -336,7 +342,7 @@ def main():
     x = torch.rand(B, 1, 28, 28, generator=g).to(device)                  # uniform [0,1) images, mnist_node.jl:206
     y = torch.eye(NCLS)[torch.randint(0, NCLS, (B,), generator=g)].to(device)
     fg = rn.FlatGrads(model.trainable()) if use_dist else None
-    reducer = rn.GradientAllReducer(model.trainable(), flat=fg) if use_dist else None   # the library's RCCL communicator (rnde_comm_*)
+    reducer = rn.GradientAllReducer(model.trainable(), flat=fg, collective="peers" if args.share_gpu else None) if use_dist else None   # the library's communicator (rnde_comm_*: RCCL unless RNDE_COLLECTIVE / RNDE_ONESHOT say otherwise)
     if args.coupled:
         if reducer is None or reducer.comm is None:
             raise SystemExit("--coupled needs the library communicator: run with --gpus N > 1 (or --force-dist)")
@@ -374,10 +380,10 @@ def main():
             dist.barrier()
         el = time.perf_counter() - t0
         if use_dist:
-            tt = torch.tensor([el], device=device, dtype=torch.float64)
+            tt = torch.tensor([el], device=ddev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
-            nf = torch.tensor([sum(nfes) / len(nfes)], device=device, dtype=torch.float64)
+            nf = torch.tensor([sum(nfes) / len(nfes)], device=ddev, dtype=torch.float64)
             dist.all_reduce(nf)
             mean_nfe = float(nf.item()) / world
         else:
@@ -401,7 +407,7 @@ def main():
     if use_dist:
         hh = model.node._acquire(x.reshape(B, -1), True)
         mine = torch.tensor([float(sum(nfes) / max(1, len(nfes))), float(L.rnde_node_fallback_count(hh.ptr)), float(L.rnde_node_launches_per_attempt(hh.ptr))],
-                            device=device, dtype=torch.float64)
+                            device=ddev, dtype=torch.float64)
         allv = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allv, mine)
         ar_us = None
@@ -420,7 +426,7 @@ def main():
         dist_diag = {"nfe_per_rank": nf, "nfe_min": min(nf), "nfe_mean": sum(nf) / len(nf), "nfe_max": max(nf),
                      "persist_fallback_count_per_rank": [int(v[1]) for v in allv], "launches_per_attempt_per_rank": [int(v[2]) for v in allv],
                      "allreduce_us": ar_us, "allreduce_floats": int(fg.flat.numel()) if fg is not None else None,
-                     "collective_library": L.rnde_comm_library().decode() if reducer is not None and reducer.comm is not None else None,
+                     "collective_library": L.rnde_comm_library().decode() if reducer is not None and reducer.comm is not None and reducer.collective == "rccl" else None,
                      # (RNDE_ONESHOT=1 in the environment: the one-shot kernel over peer-mapped windows instead of ncclAllReduce)
                      "collective_path": L.rnde_comm_path(reducer.comm).decode() if reducer is not None and reducer.comm is not None else None}
 
@@ -507,8 +513,9 @@ def main():
                "rev_rest_ms": sum(rr) / len(rr),
                "persist_fallback": bool(stage_engine and nl != 1), "persist_fallback_count": int(L.rnde_node_fallback_count(h.ptr)),
                "controller": "coupled (one controller for all ranks, SURVEY 8e mode 2)" if args.coupled else "independent per rank (SURVEY 8e mode 1)",
-               "collective": (None if not use_dist else "rnde_comm_allreduce (RCCL via librnde.so): ONE sum-all-reduce of the flat gradient buffer [p2-bar | p3-bar] "
+               "collective": (None if not use_dist else "rnde_comm_allreduce (librnde.so; path: see dist.collective_path): ONE sum-all-reduce of the flat gradient buffer [p2-bar | p3-bar] "
                               "behind the reverse pass, on the compute stream; 1/world folded into the optimiser launch"),
+               "rig": "share-gpu: ALL ranks on one device over gloo + peer windows -- exercises the N > 1 code path, NOT a throughput figure" if args.share_gpu else None,
                "config": {"workload": f"MNIST NODE regularized (error_est), Tsit5 reltol=abstol=1.4e-8, batch {B} per GPU, "
                                       "1xMI355X per rank; step = loss fwd + reverse pass through the solver + "
                                       "InvDecay/Momentum update; the weights train during the timed steps (mean_nfe drifts with "

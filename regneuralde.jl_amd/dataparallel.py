@@ -33,8 +33,17 @@ class FlatGrads:
 
 
 class GradientAllReducer:
-    def __init__(self, params, process_group=None, flat=None):
+    """collective: "rccl" (default; RNDE_ONESHOT=1 in the environment adds the one-shot kernel for buffers up to 262,144 floats, its
+    window handles carried by RCCL itself) or "peers" (no RCCL at all: rnde_comm_create_peers, the window handles travel through
+    torch.distributed's object all-gather -- any backend, e.g. gloo; also what lets several ranks share ONE GPU in the tests).
+    Default from RNDE_COLLECTIVE."""
+
+    def __init__(self, params, process_group=None, flat=None, collective=None):
+        import os
         import torch.distributed as dist
+        self.collective = collective or os.environ.get("RNDE_COLLECTIVE", "rccl")
+        if self.collective not in ("rccl", "peers"):
+            raise ValueError("collective: 'rccl' or 'peers'")
         self.params = [p for p in params if p.numel() > 0]
         self.pg = process_group
         self.world = dist.get_world_size(self.pg)
@@ -49,6 +58,21 @@ class GradientAllReducer:
         from . import _lib
         L = _lib.lib()
         rank = dist.get_rank(self.pg)
+        self._L = L
+        if self.collective == "peers":
+            dev = self.flat.device.index or 0
+            win, h = C.c_void_p(), C.create_string_buffer(64)
+            st = L.rnde_comm_window_create(dev, C.byref(win), h)
+            if st != 0:
+                raise _lib.RndeError(st, L.rnde_comm_last_error(None).decode())
+            handles = [None] * self.world
+            dist.all_gather_object(handles, bytes(h.raw), group=self.pg)
+            self.comm = C.c_void_p()
+            st = L.rnde_comm_create_peers(win, b"".join(handles), rank, self.world, C.byref(self.comm))
+            if st != 0:
+                L.rnde_comm_window_destroy(win)
+                raise _lib.RndeError(st, L.rnde_comm_last_error(None).decode())
+            return
         ids = [None]
         if rank == 0:
             buf = C.create_string_buffer(128)

@@ -143,3 +143,112 @@ def test_one_shot_allreduce_between_processes(world, mean, tmp_path):
     for o in outs:
         assert o["mismatches"] == 0 and o["checked"] == 42 and o["health"] == 0
         assert "one-shot" in o["path"]
+
+
+def test_bench_runs_two_ranks_on_one_gpu_through_the_one_shot_collective():
+    """The driver's N > 1 command line (torchrun, one process per rank, barrier + max-over-ranks timing, one gradient all-reduce per step)
+    with `--share-gpu`: both ranks on device 0, torch.distributed on gloo, the gradient collective = the one-shot kernel over peer-mapped
+    windows.  Checks the contract line and the `dist` diagnostics; the data-parallel numerics are the next test's."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "64", "--share-gpu", "--no-cpu-baseline", "--no-extras"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=400, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    o = json.loads(line)
+    assert o["n_gpus"] == 2 and o["steps"] == 3 and o["scaling"] == "weak" and o["value"] > 0
+    d = o["dist"]
+    assert "one-shot" in d["collective_path"] and d["allreduce_floats"] == 166418 and len(d["nfe_per_rank"]) == 2
+    assert d["persist_fallback_count_per_rank"] == [0, 0] or all(v >= 0 for v in d["persist_fallback_count_per_rank"])
+    print(o["value"], d)
+
+
+def _dp_worker(rank, world, store, q):
+    """One data-parallel rank (all on device 0): gloo process group, peers collective, three fused training steps on its column shard."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import regneuralde_jl_amd as rn
+    import bench
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", init_method=f"file://{store}", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    B = 32
+    torch.manual_seed(7)
+    model = bench.build_model(rn, dev, B)
+    g = torch.Generator().manual_seed(5)
+    X = torch.rand(world * B, 1, 28, 28, generator=g)
+    Y = torch.eye(10)[torch.randint(0, 10, (world * B,), generator=g)]
+    start = [p.detach().clone() for p in model.trainable()]
+
+    def run(shards, reducer, fg):
+        with torch.no_grad():
+            for p, s0 in zip(model.trainable(), start):
+                p.copy_(s0)
+        opt = rn.FluxOptimiser(model.trainable())
+        for _ in range(3):
+            if reducer is not None:
+                (r,) = shards
+                rn.fused_loss_and_grad(model, X[r * B:(r + 1) * B].to(dev), Y[r * B:(r + 1) * B].to(dev), lam=1.0e2, sync=False, flat=fg, reducer=reducer)
+            else:   # what the collective must reproduce: the shards' gradients summed in rank order
+                tot = None
+                for r in shards:
+                    rn.fused_loss_and_grad(model, X[r * B:(r + 1) * B].to(dev), Y[r * B:(r + 1) * B].to(dev), lam=1.0e2, sync=True, flat=fg)
+                    tot = fg.flat.clone() if tot is None else tot + fg.flat
+                fg.flat.copy_(tot)
+            opt.step(grad_scale=1.0 / world)
+        torch.cuda.synchronize()
+        return torch.cat([p.detach().reshape(-1) for p in model.trainable()]).cpu()
+
+    fg = rn.FlatGrads(model.trainable())
+    red = rn.GradientAllReducer(model.trainable(), flat=fg, collective="peers")
+    got = run([rank], red, fg)
+    want = run(list(range(world)), None, fg)
+    q.put((rank, got.numpy(), want.numpy()))      # (numpy: a tensor would travel as a file descriptor of a process that may be gone)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_data_parallel_steps_between_two_processes_equal_the_rank_order_sum():
+    """Two processes, each integrating ITS 32 columns of a 64-column minibatch with its own controller (SURVEY 8e mode 1), one gradient
+    all-reduce per step through the peer windows, InvDecay/Momentum with 1 / world folded in: after three steps every rank's parameters
+    equal -- bit for bit -- what one process gets by running both shards itself and adding their gradients in rank order."""
+    import tempfile
+    import torch
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    fd, store = tempfile.mkstemp(prefix="rnde_dp_")
+    os.close(fd)
+    os.unlink(store)
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, store, q)) for r in range(2)]
+    try:
+        for p in procs:
+            p.start()
+        res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+        if os.path.exists(store):
+            os.unlink(store)
+    (_, g0, w0), (_, g1, w1) = res
+    assert np.array_equal(g0, g1)                      # replicas stay identical
+    assert np.array_equal(w0, w1)
+    print("max |distributed - rank-order reference| =", np.abs(g0 - w0).max(), "over", g0.size, "parameters")
+    assert np.array_equal(g0, w0)

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void rnde_local_sum_kernel(float* __restrict__
 //   c. block w sums its chunk over the ranks' slots IN RANK ORDER (every rank computes the same bits) and writes `buf`.
 // Block w touches chunk w on every rank, so per-block flags are the whole synchronisation -- no grid-wide meeting.  Two slots alternate:
 // a rank rewrites a slot at seq + 2, which it reaches only after every peer has signalled seq + 1, i.e. finished reading seq.
-// A wait gives up after kPeerTimeoutTicks of the 100 MHz wall clock and raises the window's `fail` word (rnde_comm_health) rather than
+// A wait gives up after kPeerTimeoutTicks (20 s) of the 100 MHz wall clock and raises the window's `fail` word (rnde_comm_health) rather than
 // hanging the queue.  Opt-in (RNDE_ONESHOT=1 with rnde_comm_create, or rnde_comm_create_peers with handles the caller exchanged):
 // RCCL stays the default until the path has been measured on N > 1 GPUs.
 constexpr int kPeerMaxWorld = 16;
@@ -137,7 +137,7 @@ constexpr long long kPeerCap = 256 * 1024;            // floats per slot (1 MB);
 constexpr size_t kPeerFlagBytes = 8192;               // [2 slots][kPeerMaxWorld][kPeerBlocks] unsigned = 8 KB, then one page of padding
 constexpr size_t kPeerDataOffset = 16384;
 constexpr size_t kPeerWindowBytes = kPeerDataOffset + 2 * (size_t)kPeerCap * 4;
-constexpr long long kPeerTimeoutTicks = 5LL * 100000000;   // 5 s
+constexpr long long kPeerTimeoutTicks = 20LL * 100000000;  // 20 s (start-up skew between ranks is the long case; RCCL would wait for ever)
 
 struct PeerView {
     float* data[kPeerMaxWorld];        // rank r's data slots as mapped in THIS process (own rank: the local pointer)
@@ -147,7 +147,7 @@ struct PeerView {
 };
 
 template <bool ALIGNED>
-__global__ __launch_bounds__(256) void rnde_peer_allreduce_kernel(PeerView V, float* __restrict__ buf, long long n, long long chunk, unsigned seq, float scale) {
+__global__ __launch_bounds__(256) void rnde_peer_allreduce_kernel(PeerView V, float* __restrict__ buf, long long n, long long chunk, unsigned seq, float scale, long long timeout_ticks) {
     const int w = blockIdx.x, tid = threadIdx.x, slot = (int)(seq & 1u);
     const long long lo = (long long)w * chunk, hi = lo + chunk < n ? lo + chunk : n;     // chunk is a multiple of 4: lo is 16-byte aligned in the windows
     const long long len = hi - lo, nv = ALIGNED ? len / 4 : 0;
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void rnde_peer_allreduce_kernel(PeerView V, fl
         const unsigned* f = V.flags[V.rank] + ((size_t)slot * kPeerMaxWorld + tid) * kPeerBlocks + w;
         const long long t0 = wall_clock64();
         while ((int)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
-            if (wall_clock64() - t0 > kPeerTimeoutTicks) { atomicExch(V.fail, 1u); break; }
+            if (wall_clock64() - t0 > timeout_ticks) { atomicExch(V.fail, 1u); break; }
             __builtin_amdgcn_s_sleep(2);
         }
     }
@@ -273,14 +273,15 @@ rnde_status peers_attach(rnde_comm* c, rnde_comm_window* win, const uint8_t* han
 }
 
 rnde_status peer_allreduce(rnde_comm* c, float* buf, long long n, float scale, hipStream_t s) {
+    static const long long ticks = getenv("RNDE_ONESHOT_TIMEOUT_MS") ? std::max(1LL, atoll(getenv("RNDE_ONESHOT_TIMEOUT_MS"))) * 100000 : kPeerTimeoutTicks;   // (tests)
     for (long long off = 0; off < n; off += kPeerCap) {
         const long long m = std::min<long long>(kPeerCap, n - off);
         const int G = (int)std::max<long long>(1, std::min<long long>(kPeerBlocks, (m + 1023) / 1024));
         const long long chunk = (((m + G - 1) / G) + 3) & ~3LL;
         const unsigned seq = ++c->peer_seq;
         float* b = buf + off;
-        if (((uintptr_t)b & 15) == 0) hipLaunchKernelGGL(rnde_peer_allreduce_kernel<true>, dim3(G), dim3(256), 0, s, c->peer->view, b, m, chunk, seq, scale);
-        else hipLaunchKernelGGL(rnde_peer_allreduce_kernel<false>, dim3(G), dim3(256), 0, s, c->peer->view, b, m, chunk, seq, scale);
+        if (((uintptr_t)b & 15) == 0) hipLaunchKernelGGL(rnde_peer_allreduce_kernel<true>, dim3(G), dim3(256), 0, s, c->peer->view, b, m, chunk, seq, scale, ticks);
+        else hipLaunchKernelGGL(rnde_peer_allreduce_kernel<false>, dim3(G), dim3(256), 0, s, c->peer->view, b, m, chunk, seq, scale, ticks);
         if (hipGetLastError() != hipSuccess) { c->err = "one-shot all-reduce: launch failed"; return RNDE_ERR_HIP; }
     }
     return RNDE_OK;
@@ -417,7 +418,7 @@ extern "C" rnde_status rnde_comm_health(rnde_comm* c) {
     if (c && c->peer) {
         unsigned f = 0;
         if (hipSetDevice(c->device) != hipSuccess || hipMemcpy(&f, c->peer->view.fail, 4, hipMemcpyDeviceToHost) != hipSuccess) { c->err = "one-shot all-reduce: cannot read the window"; return RNDE_ERR_HIP; }
-        if (f) { c->err = "one-shot all-reduce: a wait for a peer's chunk gave up after 5 s (every rank must make the same calls in the same order)"; return RNDE_ERR_HIP; }
+        if (f) { c->err = "one-shot all-reduce: a wait for a peer's chunk gave up after 20 s (every rank must make the same calls in the same order)"; return RNDE_ERR_HIP; }
         return RNDE_OK;
     }
     if (!c || !c->loc) return RNDE_OK;

@@ -252,3 +252,27 @@ def test_data_parallel_steps_between_two_processes_equal_the_rank_order_sum():
     assert np.array_equal(w0, w1)
     print("max |distributed - rank-order reference| =", np.abs(g0 - w0).max(), "over", g0.size, "parameters")
     assert np.array_equal(g0, w0)
+
+
+def test_one_shot_allreduce_reports_an_absent_rank(tmp_path):
+    """A rank that never reaches the all-reduce: the waiting rank's kernel gives up (RNDE_ONESHOT_TIMEOUT_MS=300 here, 20 s by default),
+    the stream drains, and rnde_comm_health says what happened -- no hang, no silent garbage."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RNDE_ONESHOT_TIMEOUT_MS="300")
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tools", "oneshot_worker.py"), "--rank", str(r), "--world", "2", "--dir", str(tmp_path),
+                               "--absent", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(2)]
+    outs = []
+    try:
+        for p in procs:
+            o, e = p.communicate(timeout=120)
+            assert p.returncode == 0, e[-2000:]
+            outs.append(json.loads(o.strip().splitlines()[-1]))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    r0 = [o for o in outs if o["rank"] == 0][0]
+    assert r0["enqueue"] == 0 and r0["health"] != 0 and "gave up" in r0["error"]

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=6)
     ap.add_argument("--sizes", default="1,5,1023,4097,166418,262144,300001")
     ap.add_argument("--mean", type=int, default=0)
+    ap.add_argument("--absent", type=int, default=-1, help="this rank builds the communicator and then makes NO all-reduce: the others must time out and say so")
     a = ap.parse_args()
     import torch
     from regneuralde_jl_amd import _lib
@@ -51,6 +52,18 @@ def main():
     assert st == 0, L.rnde_comm_last_error(None)
     stream = torch.cuda.Stream()
     sp = C.c_void_p(stream.cuda_stream)
+    if a.absent >= 0:   # failure drill: one rank stays away from the first all-reduce
+        if a.rank != a.absent:
+            g = torch.ones(1000, device="cuda")
+            st = L.rnde_comm_allreduce(comm, g.data_ptr(), 1000, 0, sp)
+            stream.synchronize()
+            health = L.rnde_comm_health(comm)
+            print(json.dumps({"rank": a.rank, "enqueue": st, "health": health, "error": L.rnde_comm_last_error(comm).decode()}), flush=True)
+        else:
+            time.sleep(3.0)      # keep the window mapped while the others wait
+            print(json.dumps({"rank": a.rank, "absent": True}), flush=True)
+        L.rnde_comm_destroy(comm)
+        return
     bad, checked = 0, 0
     with torch.cuda.stream(stream):
         for n in [int(x) for x in a.sizes.split(",")]:

@@ -431,6 +431,8 @@ def main():
                      "collective_path": L.rnde_comm_path(reducer.comm).decode() if reducer is not None and reducer.comm is not None else None}
 
     out = None
+    if args.coupled:
+        model.node.set_coupling(None, 0)     # the legs below run on rank 0 alone: a shared controller would wait there for the other ranks
     if rank == 0:
         h = model.node._acquire(x.reshape(B, -1), True)
         # --- NFE-independent companions: HIP events around the attempted steps of the forward and the reverse sweep, 3 steps ---

@@ -145,7 +145,8 @@ def test_one_shot_allreduce_between_processes(world, mean, tmp_path):
         assert "one-shot" in o["path"]
 
 
-def test_bench_runs_two_ranks_on_one_gpu_through_the_one_shot_collective():
+@pytest.mark.parametrize("coupled", [False, True])
+def test_bench_runs_two_ranks_on_one_gpu_through_the_one_shot_collective(coupled):
     """The driver's N > 1 command line (torchrun, one process per rank, barrier + max-over-ranks timing, one gradient all-reduce per step)
     with `--share-gpu`: both ranks on device 0, torch.distributed on gloo, the gradient collective = the one-shot kernel over peer-mapped
     windows.  Checks the contract line and the `dist` diagnostics; the data-parallel numerics are the next test's."""
@@ -159,7 +160,7 @@ def test_bench_runs_two_ranks_on_one_gpu_through_the_one_shot_collective():
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "64", "--share-gpu", "--no-cpu-baseline", "--no-extras"]
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "64", "--share-gpu", "--no-cpu-baseline", "--no-extras"] + (["--coupled"] if coupled else [])
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=400, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
@@ -167,6 +168,8 @@ def test_bench_runs_two_ranks_on_one_gpu_through_the_one_shot_collective():
     assert o["n_gpus"] == 2 and o["steps"] == 3 and o["scaling"] == "weak" and o["value"] > 0
     d = o["dist"]
     assert "one-shot" in d["collective_path"] and d["allreduce_floats"] == 166418 and len(d["nfe_per_rank"]) == 2
+    if coupled:     # one controller for both ranks (SURVEY 8e mode 2): the same accept / reject sequence, hence the same NFE, on every rank
+        assert o["controller"].startswith("coupled") and d["nfe_per_rank"][0] == d["nfe_per_rank"][1]
     assert d["persist_fallback_count_per_rank"] == [0, 0] or all(v >= 0 for v in d["persist_fallback_count_per_rank"])
     print(o["value"], d)
 

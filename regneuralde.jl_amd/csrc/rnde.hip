@@ -265,9 +265,9 @@ static rnde_status chain_create(const rnde_node_config* c, rnde_node** out) {
         h->mw = (fits && c->col_tile != 64 && !(e && e[0] == '0')) ? 1 : 0;
         if (c->col_tile == 65 && !fits) { g_create_err = "col_tile 65: the multi-wave kernels need the padded weight fragments in 160 KB of LDS"; delete h; return RNDE_ERR_BAD_ARG; }
         if (h->mw) h->nwg_max = ntiles;
-        {   // experiments/latent_ode.jl:113-124 exactly: eight time-independent layers whose widths alternate between 2 and 4 tiles, D <= 32
+        {   // experiments/latent_ode.jl:113-124 exactly: eight time-independent layers of widths 20 <-> 50
             bool lat = h->mw && c->n_layers == kLatLayers && !c->time_dep && h->NKD == 8;
-            for (int i = 0; i <= kLatLayers && lat; ++i) lat = h->mg.mt[i] == lat_mt(i);
+            for (int i = 0; i <= kLatLayers && lat; ++i) lat = c->dims[i] == lat_width(i);      // (the kernels leave out the k-steps of the padding: exact widths)
             const char* e = getenv("RNDE_CHAIN_LAT");
             h->mw_lat = (lat && !(e && e[0] == '0')) ? 1 : 0;
         }

@@ -123,7 +123,7 @@ __device__ __forceinline__ void lat_load_t(const MwGeo& G, const float* __restri
         const int mtin = lat_mt(l), mtout = lat_mt(l + 1);
         const int mi = wave < mtin ? wave : 0;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) W.a[l][j] = (j < 4 * mtout) ? FRtg[((size_t)G.toff[l] + (size_t)mi * mtout * 4 + (j < 4 * mtout ? j : 0)) * 64 + lane] : 0.f;
+        for (int j = 0; j < 16; ++j) W.a[l][j] = (j < lat_ks(l + 1)) ? FRtg[((size_t)G.toff[l] + (size_t)mi * mtout * 4 + (j < lat_ks(l + 1) ? j : 0)) * 64 + lane] : 0.f;
     }
 }
 template <int NR>
@@ -158,13 +158,10 @@ __device__ __forceinline__ void mw_fbwd_lat(const MwGeo& G, const LatWeightsT& W
             const float* zb = Zc + lane;
             float b[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) if (j < 4 * mtout) b[j] = zb[j * 64];
+            for (int j = 0; j < 16; ++j) if (j < lat_ks(l + 1)) b[j] = zb[j * 64];
 #pragma unroll
-            for (int mo = 0; mo < 4; ++mo) {
-                if (mo < mtout) {
-                    acc0 = mfma16(W.a[l][4 * mo], b[4 * mo], acc0); acc1 = mfma16(W.a[l][4 * mo + 1], b[4 * mo + 1], acc1);
-                    acc0 = mfma16(W.a[l][4 * mo + 2], b[4 * mo + 2], acc0); acc1 = mfma16(W.a[l][4 * mo + 3], b[4 * mo + 3], acc1);
-                }
+            for (int j = 0; j < 16; ++j) {      // (k-steps that hold cotangents of real features only: rnde_chainmw.h lat_ks)
+                if (j < lat_ks(l + 1)) { if (j & 1) acc1 = mfma16(W.a[l][j], b[j], acc1); else acc0 = mfma16(W.a[l][j], b[j], acc0); }
             }
             f32x4 o = acc0 + acc1;
             float* zp = Zn + (16 * wave + 4 * g) * 16 + col;

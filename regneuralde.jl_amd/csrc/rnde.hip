@@ -54,6 +54,7 @@ struct rnde_node {
     int rk_tab = 0; RkTab rk{};   // explicit RK pair as data: 1 = a 7-stage pair (DP5, or Tsit5 through the same path when RNDE_CHAIN_TAB=1), 2 = S stages (DOP853)
     // chain engine, multi-wave kernels: the whole adaptive solve as ONE launch (rnde_chainmw.h MW_SOLVE) while the tiles fit one XCD (<= 32)
     int mw_solve = 1; unsigned long long* mw_xch = nullptr; unsigned* mw_xcc = nullptr; unsigned* mw_abort = nullptr; unsigned* h_mw_chk = nullptr; unsigned mw_epoch = 0;
+    int mw_bsweep = 1; int* mw_bargs = nullptr; int* h_mw_bargs = nullptr; unsigned* h_mw_bchk = nullptr; bool pending_bsweep = false;   // the reverse sweep as one launch (rnde_bchainmw.h SWEEP): per-attempt arguments [sv_lo | sv_hi | eig_c], check words
     int rk_S = 7, rk_order = 5;   // stages of the pair in first-same-as-last form (evaluations per attempted step = rk_S - 1), controller order
     int mw_lat = 0;               // the reference's latent-ODE shape (20 <-> 50, 8 layers): forward kernels with register-stationary weights
     int mw = 0; MwGeo mg{}; float* mw_tab = nullptr; float* mw_slab = nullptr; long long mw_slab_evals = 0; size_t mw_lds_f = 0, mw_lds_b = 0;
@@ -342,6 +343,10 @@ static rnde_status chain_create(const rnde_node_config* c, rnde_node** out) {
         const size_t xb = (size_t)(c->max_attempts + 4) * 3 * 32 * 8;
         ok &= dm((void**)&h->mw_xch, xb) && dm((void**)&h->mw_xcc, 32 * 4) && dm((void**)&h->mw_abort, 8);
         ok &= hipHostMalloc((void**)&h->h_mw_chk, 40 * 4) == hipSuccess;
+        ok &= hipHostMalloc((void**)&h->h_mw_bchk, 40 * 4) == hipSuccess && dm((void**)&h->mw_bargs, (size_t)c->max_attempts * 16) &&
+              hipHostMalloc((void**)&h->h_mw_bargs, (size_t)c->max_attempts * 16) == hipSuccess;
+        if (ok) memset(h->h_mw_bchk, 0, 40 * 4);
+        if (const char* eb = getenv("RNDE_CHAIN_BSWEEP")) h->mw_bsweep = atoi(eb);
         if (ok) { hipMemset(h->mw_xch, 0, xb); hipMemset(h->mw_abort, 0, 8); }
         const char* e = getenv("RNDE_CHAIN_SOLVE");
         if (e && e[0] == '0') h->mw_solve = 0;
@@ -590,6 +595,9 @@ extern "C" void rnde_node_destroy(rnde_node* h) {
     if (h->mw_xcc) hipFree(h->mw_xcc);
     if (h->mw_abort) hipFree(h->mw_abort);
     if (h->h_mw_chk) hipHostFree(h->h_mw_chk);
+    if (h->h_mw_bchk) hipHostFree(h->h_mw_bchk);
+    if (h->h_mw_bargs) hipHostFree(h->h_mw_bargs);
+    if (h->mw_bargs) hipFree(h->mw_bargs);
     if (h->mw_slab) hipFree(h->mw_slab);
     if (h->tslab) hipFree(h->tslab);
     if (h->pabort) hipFree(h->pabort);
@@ -750,6 +758,24 @@ static hipError_t stage_attempt(rnde_node* h, const StageParams& Q, int n, hipSt
     for (int st = 1; st <= 5 && e == hipSuccess; ++st) e = launch_stage<SM_STAGE>(h, Q, n, st, s);
     if (e == hipSuccess) e = launch_stage<SM_LAST>(h, Q, n, 6, s);
     return e;
+}
+
+// The one-launch reverse sweep of the chain engine (rnde_bchainmw.h SWEEP) leaves its verdict in h_mw_bchk behind the sweep; looked at after the
+// next stream synchronisation.  true: a meeting timed out or the workgroups did not share an XCD -- the sweep's outputs are invalid, the handle
+// goes back to one launch per reversed attempt.
+static bool bsweep_failed(rnde_node* h, hipStream_t s) {
+    if (!h->pending_bsweep) return false;
+    h->pending_bsweep = false;
+    bool bad = h->h_mw_bchk[0] != 0;
+    const int nt = h->bw.ready ? (int)((h->B + 15) / 16) : 0;
+    for (int i = 1; i < nt && !bad; ++i) bad = h->h_mw_bchk[2 + i] != h->h_mw_bchk[2];
+    if (!bad) return false;
+    fprintf(stderr, "[rnde] chain engine: one-launch reverse sweep abandoned (%s); one launch per reversed attempt from now on\n",
+            h->h_mw_bchk[0] ? "a meeting timed out" : "workgroups pinned by block index landed on different XCDs");
+    h->mw_bsweep = 0; ++h->persist_fallbacks;
+    hipMemsetAsync(h->mw_abort, 0, 8, s);
+    h->h_mw_bchk[0] = 0;
+    return true;
 }
 
 static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p_dev, int32_t B, float t0, float t1,
@@ -940,6 +966,7 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
             if (hs != RNDE_OK) return hs;
             HIPCHK(h, hipEventSynchronize(h->ev_host));
         } else HIPCHK(h, hipStreamSynchronize(s));
+        if (bsweep_failed(h, s)) { h->err = "the one-launch reverse sweep of the previous asynchronous backward call was abandoned: the gradients of that step are invalid (one launch per reversed attempt now in use)"; return RNDE_ERR_HIP; }
         bool bad = h->h_mw_chk[0] != 0;
         for (int i = 1; i < nt && !bad; ++i) bad = h->h_mw_chk[2 + i] != h->h_mw_chk[2];
         if (bad) {      // a meeting timed out, or the workgroups did not share an XCD: this handle goes back to one launch per attempt, for good
@@ -1010,6 +1037,7 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
         }
 #endif
         if (h->couple && rnde_comm_health(h->couple) != RNDE_OK) { h->err = std::string("coupled controller: ") + rnde_comm_last_error(h->couple); return RNDE_ERR_HIP; }
+        if (bsweep_failed(h, s)) { h->err = "the one-launch reverse sweep of the previous asynchronous backward call was abandoned: the gradients of that step are invalid (one launch per reversed attempt now in use)"; return RNDE_ERR_HIP; }
         if (h->engine == 2 && persist_check_result(h, SQ.C, SQ.R, s)) {
             if (h->pending_bwd) {   // the failure may belong to the asynchronous reverse pass before this forward: its outputs cannot be trusted
                 h->pending_bwd = false;
@@ -1886,6 +1914,7 @@ static rnde_status launch_bmw_t(rnde_node* h, const BMwParams& Q, const std::vec
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)rnde_bchainmw_kernel<NR, TAB, LAT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rnde_bchainmw_kernel<NR, TAB, LAT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rnde_bchainmw_init_kernel<NR, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rnde_bchainmw_init_kernel<NR, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         HIPCHK(h, e);
@@ -1893,6 +1922,9 @@ static rnde_status launch_bmw_t(rnde_node* h, const BMwParams& Q, const std::vec
     }
     const dim3 grid(Q.ntiles), blk(kMwThreads);
     rnde_status st = RNDE_OK;
+    // the whole sweep as ONE launch (rnde_bchainmw.h SWEEP): <= 32 column tiles, no shared controller, more than one attempt
+    const bool sweep = h->mw_bsweep && !h->couple && Q.ntiles <= 32 && Q.B.n_att >= 2 && h->mw_xch;
+    int* a_lo = h->h_mw_bargs; int* a_hi = a_lo + h->cfg.max_attempts; float* a_eig = (float*)(a_hi + h->cfg.max_attempts);
     for (int n = Q.B.n_att - 1; n >= 0; --n) {
         float c1 = 0.f, c2 = 0.f;   // cotangent of eigen_est for this attempt (as in bwd_run)
         const StepMeta& mm = h->h_meta[n];
@@ -1904,9 +1936,23 @@ static rnde_status launch_bmw_t(rnde_node* h, const BMwParams& Q, const std::vec
             c1 = (float)(eigb / ((double)mm.n2 * (double)mm.n1));
             c2 = (float)(-eigb * ((double)mm.n1 / (double)mm.n2) / ((double)mm.n2 * (double)mm.n2));
         }
+        if (sweep) { a_lo[n] = sv_lo[n]; a_hi[n] = sv_hi[n]; a_eig[2 * n] = c1; a_eig[2 * n + 1] = c2; continue; }
         hipLaunchKernelGGL((rnde_bchainmw_kernel<NR, TAB, LAT>), grid, blk, lds, s, Q, n, mm, sv_lo[n], sv_hi[n], c1, c2);
         // (coupled controller, SURVEY 8e mode 2: the S, tau, c-tau partials of attempt n summed over the ranks before attempt n - 1 reads them)
         if ((st = couple_sum(h, b.bpart + (size_t)(n & 1) * Q.B.bpart_n * 4, 4LL * Q.B.bpart_n, s)) != RNDE_OK) return st;
+    }
+    if (sweep) {
+        const int cap = h->cfg.max_attempts;
+        HIPCHK(h, hipMemcpyAsync(h->mw_bargs, h->h_mw_bargs, (size_t)cap * 16, hipMemcpyHostToDevice, s));
+        if (++h->mw_epoch >= 500000u) { h->mw_epoch = 1; HIPCHK(h, hipMemsetAsync(h->mw_xch, 0, (size_t)(cap + 4) * 3 * 32 * 8, s)); }
+        BMwParams W = Q;
+        W.sv_lo = h->mw_bargs; W.sv_hi = h->mw_bargs + cap; W.eig_c = (const float*)(h->mw_bargs + 2 * cap);
+        W.xch = h->mw_xch; W.xcc = h->mw_xcc; W.abort_word = h->mw_abort; W.epoch = h->mw_epoch;
+        hipLaunchKernelGGL((rnde_bchainmw_kernel<NR, TAB, LAT, 1>), dim3(8 * Q.ntiles), blk, lds, s, W, Q.B.n_att - 1, h->h_meta[Q.B.n_att - 1], 0, 0, 0.f, 0.f);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpyAsync(h->h_mw_bchk, h->mw_abort, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipMemcpyAsync(h->h_mw_bchk + 2, h->mw_xcc, (size_t)Q.ntiles * 4, hipMemcpyDeviceToHost, s));
+        h->pending_bsweep = true;
     }
     hipLaunchKernelGGL((rnde_bchainmw_init_kernel<NR, 1>), grid, blk, lds, s, Q);
     if ((st = couple_sum(h, Q.B.ipart, 4LL * Q.B.F.nwg, s)) != RNDE_OK) return st;                        // dot, tau of the reversed second evaluation
@@ -2005,6 +2051,8 @@ static rnde_status chain_mw_bwd_run(rnde_node* h, const float* u_bar_dev, const 
     }
     HIPCHK(h, hipMemcpyAsync(h->h_scal, b.tspan_out, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
+    if (bsweep_failed(h, s))     // nothing the sweep reads was consumed: the same reverse pass again, one launch per attempt
+        return chain_mw_bwd_run(h, u_bar_dev, saveval_bar_host, x_bar_dev, p_bar_dev, tspan_bar_host, s, sync, tspan_bar_dev);
     if (tspan_bar_host) { tspan_bar_host[0] = h->h_scal[0]; tspan_bar_host[1] = h->h_scal[1]; }
     return RNDE_OK;
 }

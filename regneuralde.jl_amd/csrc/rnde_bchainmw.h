@@ -22,6 +22,9 @@ struct BMwParams {
     long long ev_stride;
     int ntiles;
     const float* sv_t; const float* sv_ubar; int nsave;
+    // SWEEP (the whole reverse sweep in one launch): per-attempt arguments as device arrays, and the meeting of rnde_chainmw.h
+    const int* sv_lo; const int* sv_hi; const float* eig_c;     // [n_att], [n_att], [n_att][2]
+    unsigned long long* xch; unsigned* xcc; unsigned* abort_word; unsigned epoch;
 };
 
 // J_f^T product at a taped evaluation.  kout = f's value (element-wise), kbar its cotangent; returns gbar (element-wise) and adds
@@ -190,9 +193,14 @@ __device__ __forceinline__ void mw_fbwd_lat(const MwGeo& G, const LatWeightsT& W
     __syncthreads();
 }
 
-template <int NR, int TAB = 0, int LAT = 0>
-__global__ __launch_bounds__(kMwThreads) void rnde_bchainmw_kernel(const BMwParams Q, const int n, const StepMeta m, const int sv_lo, const int sv_hi,
-                                                                   const float eig_c1, const float eig_c2) {
+// SWEEP = 1: the WHOLE reverse sweep in one launch (the mirror of MW_SOLVE in rnde_chainmw.h): the loop over the attempted steps, last to first,
+// runs inside the kernel; weights and geometry are loaded once; the only thing the workgroups exchange per attempt -- their three partial
+// sums {<k, k-bar>, tau, c-weighted tau} -- goes through mw_exchange3 (the <= 32 workgroups are pinned to one XCD and meet through its L2), and
+// every workgroup carries the scalar chain (BState) in registers: the same double-precision arithmetic on the same sums as the
+// launch-per-attempt path, bit for bit.  n_arg = the first attempt to reverse (n_att - 1); the per-attempt arguments come from device arrays.
+template <int NR, int TAB = 0, int LAT = 0, int SWEEP = 0>
+__global__ __launch_bounds__(kMwThreads) void rnde_bchainmw_kernel(const BMwParams Q, const int n_arg, const StepMeta m_arg, const int sv_lo_arg, const int sv_hi_arg,
+                                                                   const float eig_c1_arg, const float eig_c2_arg) {
     const BwdParams& Bq = Q.B;
     const StepParams& P = Bq.F;
     const MwGeo& G = Q.G;
@@ -205,10 +213,29 @@ __global__ __launch_bounds__(kMwThreads) void rnde_bchainmw_kernel(const BMwPara
     float* RED = ZB + 1024;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = blockIdx.x;
+    if constexpr (SWEEP) { if (blockIdx.x & 7) return; }      // (8 x ntiles launched: the ones that work share one XCD, see MW_SOLVE)
+    const int tile = SWEEP ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if constexpr (SWEEP) { if (tid == 0) Q.xcc[tile] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15; }
     const int gcol = tile * 16 + (tid & 15);
     const bool colok = gcol < P.B;
     const bool writer = (tile == 0 && tid == 0);
+    float* RED2 = RED + 16;                                   // SWEEP: the meeting's three sums (doubles) and its verdict, for the other waves
+    BState bprev{}; StepMeta mprev = m_arg; double xs[3] = {0.0, 0.0, 0.0};
+    LatWeightsT LT;
+    if constexpr (SWEEP) {   // weights once per sweep (a launch per attempt requests its cold tape arrays in front of them instead, see below)
+        if constexpr (LAT) lat_load_t(G, Q.tab, LT, wave, lane);
+        else mw_fill_lds(Q.tab + (size_t)G.nfrag_f * 64, smem, (G.nfrag_t >> 2) + 4, wave, lane);
+    }
+    // SWEEP: the record of the next attempt to reverse is read COLD from HBM; its nine arrays are requested at the end of the attempt before it,
+    // in front of the meeting, and its step record (which says where that record lives) at the top of that attempt
+    StepMeta mcur = m_arg, mnext = m_arg;
+    float pkq[SWEEP ? (TAB == 2 ? kRkSMax : 7) : 1][NR], pupv[NR], punv[NR];
+    bool have_pf = false;
+    for (int n = n_arg; ; --n) {
+    const StepMeta m = mcur;
+    if (SWEEP && n > 0) mnext = P.meta[n - 1];
+    const int sv_lo = SWEEP ? Q.sv_lo[n] : sv_lo_arg, sv_hi = SWEEP ? Q.sv_hi[n] : sv_hi_arg;
+    const float eig_c1 = SWEEP ? Q.eig_c[2 * n] : eig_c1_arg, eig_c2 = SWEEP ? Q.eig_c[2 * n + 1] : eig_c2_arg;
     const bool first = (n == Bq.n_att - 1);
     constexpr int SM = TAB == 2 ? kRkSMax : 7;               // stages the register arrays are sized for
     const int NS = TAB == 2 ? Q.rk.S : 7;                    // stages of the pair (rnde_chainmw.h: RkTab)
@@ -220,27 +247,37 @@ __global__ __launch_bounds__(kMwThreads) void rnde_bchainmw_kernel(const BMwPara
     // the error estimate's reverse -- is requested in front of the weights (a wave's loads return in order; behind the weights these were two
     // more serial round trips to cold memory in a 33 us launch)
     f32x4 pe[4];
-    if (!first) bpart_request(Bq, n + 1, lane, pe);
+    if (!SWEEP && !first) bpart_request(Bq, n + 1, lane, pe);
     const float* R = P.arena + (long long)m.rec * P.rec_stride;
     float kq[SM][NR], upv[NR], unv[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
-        upv[r] = R[L.upc() + fo + 256 * r];
-        unv[r] = R[L.unew() + fo + 256 * r];
-        kq[0][r] = R[L.k1c() + fo + 256 * r];
+        if (SWEEP && have_pf) {
+            upv[r] = pupv[r]; unv[r] = punv[r];
 #pragma unroll
-        for (int j = 1; j < SM; ++j) kq[j][r] = (TAB != 2 || j < NS) ? R[L.k(j + 1) + fo + 256 * r] : 0.f;
+            for (int j = 0; j < SM; ++j) kq[j][r] = pkq[SWEEP ? j : 0][r];
+        } else {
+            upv[r] = R[L.upc() + fo + 256 * r];
+            unv[r] = R[L.unew() + fo + 256 * r];
+            kq[0][r] = R[L.k1c() + fo + 256 * r];
+#pragma unroll
+            for (int j = 1; j < SM; ++j) kq[j][r] = (TAB != 2 || j < NS) ? R[L.k(j + 1) + fo + 256 * r] : 0.f;
+        }
     }
-    LatWeightsT LT;
-    if constexpr (LAT) lat_load_t(G, Q.tab, LT, wave, lane);      // (the latent-ODE shape: transposed fragments in registers, no LDS fill)
-    else mw_fill_lds(Q.tab + (size_t)G.nfrag_f * 64, smem, (G.nfrag_t >> 2) + 4, wave, lane);
+    if constexpr (!SWEEP) {
+        if constexpr (LAT) lat_load_t(G, Q.tab, LT, wave, lane);      // (the latent-ODE shape: transposed fragments in registers, no LDS fill)
+        else mw_fill_lds(Q.tab + (size_t)G.nfrag_f * 64, smem, (G.nfrag_t >> 2) + 4, wave, lane);
+    }
     auto fbwd = [&](float* slp, const float (&gin_)[NR], const float (&kout_)[NR], const float (&kbar_)[NR], float (&gb_)[NR], float& tau_) {
         if constexpr (LAT) mw_fbwd_lat<NR>(G, LT, ZA, ZB, slp, gin_, kout_, kbar_, gb_, tid, wave, lane);
         else mw_fbwd<NR>(G, FRt, TV, ZA, ZB, slp, gin_, kout_, kbar_, gb_, tau_, tid, wave, lane);
     };
     // ---- scalar chain, identical in every wave; same arithmetic as rnde_bchain_kernel ----
     double tb = 0, dtpb = 0, qoldb = 0, t1b = 0, t0b = 0;
-    if (!first) finish_attempt_scalars_from(Bq, n + 1, lane, &pe, tb, dtpb, qoldb, t1b, t0b);
+    if (!first) {
+        if constexpr (SWEEP) finish_attempt_scalars_sums(bprev, mprev, xs[0], xs[1], xs[2], tb, dtpb, qoldb, t1b, t0b);
+        else finish_attempt_scalars_from(Bq, n + 1, lane, &pe, tb, dtpb, qoldb, t1b, t0b);
+    }
     const bool accepted = (m.flags & F_ACCEPT) != 0;
     const float dt = m.dt, t = m.t;
     float coef;
@@ -266,7 +303,9 @@ __global__ __launch_bounds__(kMwThreads) void rnde_bchainmw_kernel(const BMwPara
         }
         if (!(m.flags & F_EZERO) && m.eest > 0.f) eb += q11b * (double)P.beta1 * (double)m.q11 / (double)m.eest;
         coef = m.eest > 0.f ? (float)(eb / (N * (double)m.eest)) : 0.f;
-        if (writer) { BState b; b.tb_pre = tb; b.dtb_pre = dtb_pre; b.qoldb = qoldb_in; b.t1b = t1b; b.t0b = t0b; b.pad[0] = b.pad[1] = b.pad[2] = 0; Bq.bstate[n & 1] = b; }
+        BState b; b.tb_pre = tb; b.dtb_pre = dtb_pre; b.qoldb = qoldb_in; b.t1b = t1b; b.t0b = t0b; b.pad[0] = b.pad[1] = b.pad[2] = 0;
+        if (writer) Bq.bstate[n & 1] = b;
+        bprev = b; mprev = m;
     }
 
     float S = 0.f, tau = 0.f, ctau = 0.f;   // sum_j <k_j, kbar_j>; sum of time cotangents; c_s-weighted (+ extra dt-bar)
@@ -429,7 +468,36 @@ __global__ __launch_bounds__(kMwThreads) void rnde_bchainmw_kernel(const BMwPara
         float s = 0.f, ta = 0.f, ca = 0.f;
         for (int w = 0; w < kMwWaves; ++w) { s += RED[w]; ta += RED[4 + w]; ca += RED[8 + w]; }
         float* o = Bq.bpart + ((size_t)(n & 1) * Bq.bpart_n + tile) * 4;
-        o[0] = s; o[1] = ta; o[2] = ca; o[3] = 0.f;
+        o[0] = s; o[1] = ta; o[2] = ca; o[3] = 0.f;       // (SWEEP: read by the reverse of the initialisation after attempt 0, as always)
+    }
+    if constexpr (!SWEEP) break;
+    else {
+        if (n == 0) break;
+        {   // the next attempt's tape arrays: in flight while the workgroups meet
+            const float* Rn = P.arena + (long long)mnext.rec * P.rec_stride;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                pupv[r] = Rn[L.upc() + fo + 256 * r];
+                punv[r] = Rn[L.unew() + fo + 256 * r];
+                pkq[0][r] = Rn[L.k1c() + fo + 256 * r];
+#pragma unroll
+                for (int j = 1; j < SM; ++j) pkq[j][r] = (TAB != 2 || j < NS) ? Rn[L.k(j + 1) + fo + 256 * r] : 0.f;
+            }
+            have_pf = true; mcur = mnext;
+        }
+        // the meeting: wave 0 publishes this tile's three sums and collects everybody's, in the order finish_attempt_scalars_from adds them
+        if (wave == 0) {
+            float mine[3] = {0.f, 0.f, 0.f};
+            for (int w = 0; w < kMwWaves; ++w) { mine[0] += RED[w]; mine[1] += RED[4 + w]; mine[2] += RED[8 + w]; }
+            double o[3];
+            const bool ok = mw_exchange3(MwMeet{Q.xch, Q.abort_word, Q.epoch, Q.ntiles}, n, mine, o, tile, lane);
+            if (lane == 0) { ((double*)RED2)[0] = o[0]; ((double*)RED2)[1] = o[1]; ((double*)RED2)[2] = o[2]; RED2[6] = ok ? 1.f : 0.f; }
+        }
+        __syncthreads();
+        if (RED2[6] == 0.f) return;          // (a meeting timed out: abort word raised; the host falls back to one launch per attempt)
+        xs[0] = ((const double*)RED2)[0]; xs[1] = ((const double*)RED2)[1]; xs[2] = ((const double*)RED2)[2];
+        __syncthreads();                     // (RED / RED2 are rewritten by the next attempt)
+    }
     }
 }
 

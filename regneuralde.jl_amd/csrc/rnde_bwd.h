@@ -168,6 +168,15 @@ __device__ __forceinline__ void finish_attempt_scalars_from(const BwdParams& Q, 
     if (mm.flags & F_CLAMP) { t1b += dtb; tbx -= dtb; dtpb = 0; } else dtpb = dtb;
     tb = tbx; qoldb = b.qoldb;
 }
+// the same tail with the three sums already formed (a kernel that reverses several attempts carries b and mm in registers: rnde_bchainmw.h SWEEP)
+__device__ __forceinline__ void finish_attempt_scalars_sums(const BState& b, const StepMeta& mm, double S, double tau, double ctau, double& tb, double& dtpb,
+                                                            double& qoldb, double& t1b, double& t0b) {
+    const double dtb = b.dtb_pre + S / (double)mm.dt + ctau;
+    double tbx = b.tb_pre + tau;
+    t1b = b.t1b; t0b = b.t0b;
+    if (mm.flags & F_CLAMP) { t1b += dtb; tbx -= dtb; dtpb = 0; } else dtpb = dtb;
+    tb = tbx; qoldb = b.qoldb;
+}
 __device__ __forceinline__ void finish_attempt_scalars(const BwdParams& Q, int m, int lane, double& tb, double& dtpb,
                                                        double& qoldb, double& t1b, double& t0b) {
     finish_attempt_scalars_from(Q, m, lane, nullptr, tb, dtpb, qoldb, t1b, t0b);

@@ -90,7 +90,8 @@ struct MwParams {
 // sde_exchange).  Called by wave 0; `mine` valid in lane 0; the sums come out in the order sum_partials forms them (entry i in lane i,
 // then the wave reduction), so a solve is bit-identical to the one-launch-per-attempt path.  false: timed out / aborted.
 constexpr int kMwSpinMax = 4000000;
-__device__ __forceinline__ bool mw_exchange3(const MwParams& Q, int seq, const float (&mine)[3], double (&out)[3], int tile, int lane) {
+struct MwMeet { unsigned long long* xch; unsigned* abort_word; unsigned epoch; int ntiles; };     // what a meeting needs (forward solve, reverse sweep)
+__device__ __forceinline__ bool mw_exchange3(const MwMeet& Q, int seq, const float (&mine)[3], double (&out)[3], int tile, int lane) {
     const unsigned tag = Q.epoch * 8192u + (unsigned)seq + 1u;
     unsigned long long* base = Q.xch + (size_t)seq * 3 * Q.ntiles;
     if (lane == 0) {
@@ -592,7 +593,7 @@ __global__ __launch_bounds__(kMwThreads) void rnde_chainmw_kernel(const MwParams
                 float mine[3] = {0.f, 0.f, 0.f};
                 for (int w = 0; w < kMwWaves; ++w) { mine[0] += RED[w]; mine[1] += RED[4 + w]; mine[2] += RED[8 + w]; }
                 double o[3];
-                const bool ok = mw_exchange3(Q, nn, mine, o, tile, lane);
+                const bool ok = mw_exchange3(MwMeet{Q.xch, Q.abort_word, Q.epoch, Q.ntiles}, nn, mine, o, tile, lane);
                 if (lane == 0) { ((double*)RED2)[0] = o[0]; ((double*)RED2)[1] = o[1]; ((double*)RED2)[2] = o[2]; RED2[6] = ok ? 1.f : 0.f; }
             }
             __syncthreads();

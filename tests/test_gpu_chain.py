@@ -507,3 +507,30 @@ def test_one_launch_solve_is_bit_identical_to_one_launch_per_attempt(kind, B, to
     assert np.array_equal(pa["steps"], pb["steps"]) and np.array_equal(pa["u"], pb["u"])
     for u, v in zip(ga, gb):
         assert np.array_equal(u, v)
+
+
+@pytest.mark.parametrize("kind,B,tol,scale,saveat,reg", [("latent", 512, 1.4e-8, 1.0, np.linspace(0, 1, 49), 1), ("chain3", 19, 1e-3, 2.0, None, 1),
+                                                          ("test_node", 5, 1e-2, 8.0, np.array([0.5, 1.0]), 1), ("latent", 70, 1e-4, 1.5, None, 3),
+                                                          ("wide", 40, 1e-5, 1.5, None, 0)])
+def test_one_launch_reverse_sweep_is_bit_identical_to_one_launch_per_attempt(kind, B, tol, scale, saveat, reg, monkeypatch, _mw_only):
+    """rnde_bchainmw_kernel<.., SWEEP>: the reverse sweep of the chain engine in ONE launch (the loop over the attempted steps inside the kernel,
+    weights loaded once, the scalar chain carried in registers, the three partial sums of an attempt exchanged through the XCD's L2) against
+    the one-launch-per-reversed-attempt path (RNDE_CHAIN_BSWEEP=0): the same sums in the same order, so every gradient must agree bit for bit
+    -- rejected steps, saveat cotangents, the stiffness-estimate regulariser and the reference tolerance included."""
+    from tests.util import Node
+    arch, p, x = _setup(kind, B, 5, scale)
+    outs = []
+    for one in ("1", "0"):
+        monkeypatch.setenv("RNDE_CHAIN_BSWEEP", one)
+        node = Node(_cfg(arch, B, reltol=tol, abstol=tol, max_attempts=256, regularize=reg))
+        got = node.forward(x, p, keep_tape=True) if saveat is None else node.forward_saveat(x, p, saveat.astype(np.float32), keep_tape=True)
+        ubar = np.random.default_rng(9).standard_normal(got["u"].shape).astype(np.float32)
+        g = node.backward(ubar, np.full(len(got["saveval"]), 3.0, dtype=np.float32))
+        assert node.L.rnde_node_fallback_count(node.h) == 0
+        outs.append((got, g))
+        node.close()
+    (a, ga), (b, gb) = outs
+    assert a["nfe"] == b["nfe"] and a["nfe"] > 9
+    print("nfe", a["nfe"])
+    for u, v in zip(ga, gb):
+        assert np.array_equal(u, v)

@@ -1,5 +1,5 @@
-"""Stress of the chain engine's one-launch solve (rnde_chainmw.h MW_SOLVE): many solves of random batch sizes (<= 512 columns = <= 32 workgroups
-on one XCD), tolerances and weight scales (rejected steps included), against the one-launch-per-attempt path (RNDE_CHAIN_SOLVE=0), forward
+"""Stress of the chain engine's one-launch solve (rnde_chainmw.h MW_SOLVE) and one-launch reverse sweep (rnde_bchainmw.h SWEEP): many solves of random batch sizes (<= 512 columns = <= 32 workgroups
+on one XCD), tolerances and weight scales (rejected steps included), against the one-launch-per-attempt paths (RNDE_CHAIN_SOLVE=0, RNDE_CHAIN_BSWEEP=0), forward
 and -- through tape and slab -- reverse, bit for bit; no meeting may time out.     python tools/stress_chain_solve.py [N=300]"""
 import os, sys, time
 import numpy as np
@@ -16,6 +16,7 @@ nodes = {}
 for tol in (1e-2, 1e-4, 1.4e-8):
     for one in ("1", "0"):
         os.environ["RNDE_CHAIN_SOLVE"] = one
+        os.environ["RNDE_CHAIN_BSWEEP"] = one
         nodes[(tol, one)] = Node(_cfg(arch, 512, reltol=tol, abstol=tol, max_attempts=512))
 for it in range(N):
     tol = (1e-2, 1e-4, 1.4e-8)[it % 3]

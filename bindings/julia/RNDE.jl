@@ -319,6 +319,24 @@ allreduce_sum!(comm::Ptr{Cvoid}, g::ROCVector{Float32}) = GC.@preserve g begin
     g
 end
 
+# The same all-reduce as ONE kernel over peer-mapped windows (opt-in, include/rnde.h): every rank makes a window, the 64-byte handles travel to
+# all ranks in rank order (Distributed / MPI.jl: an all-gather of 64 bytes), comm_create_peers maps them.  `ENV["RNDE_ONESHOT"] = "1"` in front of
+# comm_create does the same through RCCL's own all-gather.  comm_path says which path a communicator's all-reduces take.
+function comm_window_create(device::Integer)
+    win = Ref{Ptr{Cvoid}}(C_NULL); handle = zeros(UInt8, 64)
+    ccall((:rnde_comm_window_create, LIB), Cint, (Int32, Ref{Ptr{Cvoid}}, Ptr{UInt8}), device, win, handle) == 0 ||
+        error("rnde_comm_window_create: ", unsafe_string(ccall((:rnde_comm_last_error, LIB), Cstring, (Ptr{Cvoid},), C_NULL)))
+    return win[], handle
+end
+function comm_create_peers(win::Ptr{Cvoid}, handles::Vector{UInt8}, rank::Integer, world::Integer)
+    length(handles) == 64 * world || error("comm_create_peers: 64 bytes per rank, in rank order")
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    ccall((:rnde_comm_create_peers, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Int32, Int32, Ref{Ptr{Cvoid}}), win, handles, rank, world, out) == 0 ||
+        error("rnde_comm_create_peers: ", unsafe_string(ccall((:rnde_comm_last_error, LIB), Cstring, (Ptr{Cvoid},), C_NULL)))
+    return out[]
+end
+comm_path(comm::Ptr{Cvoid}) = unsafe_string(ccall((:rnde_comm_path, LIB), Cstring, (Ptr{Cvoid},), comm))
+
 # SURVEY 8e mode 2: ONE step-size controller for all column shards of a minibatch (rnde_node_set_coupling): every rank calls it with
 # its communicator and the global batch; `comm = C_NULL` returns to independent controllers.  Equal shards, the same calls on every rank.
 function set_coupling!(h::Handle, comm::Ptr{Cvoid}, global_batch::Integer)

@@ -292,7 +292,7 @@ rnde_status rnde_comm_health(rnde_comm* c);
  *   RNDE_ONESHOT=1 in the environment of rnde_comm_create: the handles travel through the RCCL communicator that call builds (one
  *     64-byte all-gather); all-reduces of n <= 262,144 floats then take the one-shot kernel, larger ones ncclAllReduce;
  *   rnde_comm_window_create(device, &win, handle) on every rank -> ship the 64 bytes to all ranks by any means ->
- *     rnde_comm_create_peers(win, handles_in_rank_order, rank, world, &c) (takes ownership of win): no RCCL at all; larger buffers go
+ *     rnde_comm_create_peers(win, handles_in_rank_order, rank, world, &c) (takes ownership of win on success): no RCCL at all; larger buffers go
  *     in pieces of 262,144 floats.
  * rnde_comm_path says which path a communicator's all-reduces take. */
 #define RNDE_COMM_WINDOW_BYTES 64

@@ -206,8 +206,10 @@ def bench_latent(args):
                                    + ("through torch.autograd" if args.autograd else "two C-ABI calls (rnde_node_forward_saveat, rnde_node_backward_async)")},
             "roofline": {"bound": "mfma", "achieved": flops / (us_in_solve * 1e-6) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                          "frac": flops / (us_in_solve * 1e-6) / 1e12 / MFMA_F32_PEAK_TF, "traffic": None,
-                         "kernel": "rnde_chainmw_kernel<2,0,0,1> (multi-wave chain engine, weights register stationary): one attempted Tsit5 step = 1 launch, "
-                                   "taped, timed inside the solves of training steps; latency bound (32 workgroups of 4 waves on the chip)",
+                         "kernel": "rnde_chainmw_kernel<2,MW_SOLVE,0,1> (multi-wave chain engine, weights register stationary): the WHOLE adaptive solve = 1 launch; "
+                                   "unit = one attempted Tsit5 step inside it, taped, timed over the solves of training steps (the reverse sweep is one launch too, "
+                                   "rnde_bchainmw_kernel<2,0,1,1>); us_per_attempt_forced_untaped = one attempt as its own launch (rnde_chainmw_kernel<2,0,0,1>); "
+                                   "latency bound (32 workgroups of 4 waves on the chip)",
                          "us_per_attempt": us_in_solve, "us_per_attempt_forced_untaped": us.value}}
 
 

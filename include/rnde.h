@@ -187,6 +187,10 @@ int32_t     rnde_node_fallback_count(const rnde_node* h);
 /* How the handle currently runs one attempted step: number of kernel launches (1: rnde_stage_attempt_kernel /
  * rnde_step_kernel / rnde_chain_kernel; 7: rnde_stage_kernel START, 5 x STAGE, LAST) -- bench.py's roofline bookkeeping. */
 int32_t     rnde_node_launches_per_attempt(const rnde_node* h);
+/* How many forward solves of this handle ran as ONE kernel launch (attempt loop, PI controller and error-norm meeting inside the kernel:
+ * rnde_stage_solve_kernel for the MNIST form at <= 512 columns, MW_SOLVE for the Dense-chain and SDE engines) -- the launch that replaces
+ * the body of `solve(prob, Tsit5(); ...)`, reference src/models/neural_ode.jl:131-137.  bench.py's roofline bookkeeping and the tests. */
+int32_t     rnde_node_one_launch_solves(const rnde_node* h);
 /* 1 if this build contains the column-owner engine's own step kernels (col_tile 4 / 8; -DRNDE_WITH_COLUMN_OWNER), 0 otherwise: the
  * default build leaves them out (nothing selects them automatically; rnde_node_create then refuses col_tile 4 / 8). */
 int32_t     rnde_has_column_owner(void);

@@ -8,6 +8,7 @@
 #include "rnde_stage_persist2.h"
 #include "rnde_stage_wide.h"
 #include "rnde_bstage_persist.h"
+#include "rnde_stage_solve.h"
 #include "rnde_binit_stage.h"
 #include "rnde_head.h"
 #include "rnde_chain.h"
@@ -36,6 +37,8 @@ static hipError_t rnde_malloc(void** p, size_t bytes) {
 }
 #define hipMalloc(p, n) rnde_malloc((void**)(p), (n))
 
+// rnde_stage_solve.hip (its own translation unit, parameter blocks by address: the same struct definitions on both sides)
+extern "C" hipError_t rnde_launch_stage_solve(const void* stage_params, const void* persist_sync, const void* solve_sync, int act2, hipStream_t s);
 using namespace rnde;
 
 struct rnde_node {
@@ -77,6 +80,8 @@ struct rnde_node {
     int wide = 0;        // one workgroup per column tile for all rows (rnde_stage_wide.h): 1 = use it (RNDE_WIDE=1 at creation; an experiment, not selected automatically)
     int persist2 = -1;   // two column tiles per workgroup in the forward attempt kernel: -1 automatic (by tile count), 0 never, 1 whenever possible (RNDE_PERSIST2, read at creation)
     int persist = 0, persist_spins = kPersistMaxSpins; int tslab_Bpad = -1; size_t tslab_bytes = 0; float* tslab = nullptr; unsigned *pabort = nullptr, *pxcc = nullptr; unsigned* h_pchk = nullptr;
+    // the whole forward solve as one launch (rnde_stage_solve.h): 1 = use it where it applies, 0 = off (RNDE_STAGE_SOLVE=0 at creation); meeting granules, epoch of their tags
+    int stage_solve = 1; unsigned long long* sxch = nullptr; unsigned s_epoch = 0; int one_launch_solves = 0;
     hipStream_t wstream = nullptr;        // (experimental overlap path of the weight-gradient GEMMs)
     std::vector<hipEvent_t> wevents;
     // device
@@ -566,6 +571,12 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
         if (const char* e3 = getenv("RNDE_WGRAD_SIDE")) h->wgrad_side_pct = atoi(e3);
         if (const char* e5 = getenv("RNDE_BINIT_STAGE")) h->binit_stage = atoi(e5);
         h->stage_generic = (c->stage_generic != 0 || getenv("RNDE_STAGE_GENERIC") != nullptr) ? 1 : 0;
+        if (const char* e6 = getenv("RNDE_STAGE_SOLVE")) h->stage_solve = atoi(e6);
+    }
+    if (h->persist == 1 && h->stage_solve && c->max_attempts < 8192) {      // meeting granules of the one-launch solve: [attempt][3][256] x 8 bytes
+        const size_t xb = (size_t)(c->max_attempts + 1) * 3 * 256 * 8;
+        if (hipMalloc((void**)&h->sxch, xb) != hipSuccess) { g_create_err = "device allocation failed"; rnde_node_destroy(h); return RNDE_ERR_HIP; }
+        hipMemset(h->sxch, 0, xb);
     }
     h->predicted = 12;
     *out = h;
@@ -600,6 +611,7 @@ extern "C" void rnde_node_destroy(rnde_node* h) {
     if (h->mw_bargs) hipFree(h->mw_bargs);
     if (h->mw_slab) hipFree(h->mw_slab);
     if (h->tslab) hipFree(h->tslab);
+    if (h->sxch) hipFree(h->sxch);
     if (h->pabort) hipFree(h->pabort);
     if (h->pxcc) hipFree(h->pxcc);
     if (h->h_pchk) hipHostFree(h->h_pchk);
@@ -978,6 +990,43 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
         }
         if (!h->h_ctl->done && h->h_ctl->n_att >= n_limit && n_limit < cap) { h->predicted = cap; return RNDE_INTERNAL_RETRY; }
         h->pending_bwd = false;
+        ++h->one_launch_solves;
+        solved = true;
+    }
+    // ---- stage engine, headline geometry, all workgroups resident at once (<= 32 column tiles): the WHOLE adaptive solve is one launch
+    // ---- (rnde_stage_solve.h: weights, uprev and k1 stay in registers across attempts, the error norm meets through agent-scope granules) ----
+    if (h->engine == 2 && h->persist == 1 && h->stage_solve && h->sxch && SQ.C <= 32 && n_saveat == 0 && h->n_replay == 0 && !h->couple &&
+        SQ.WT == 7 && SQ.HT == 7 && SQ.K2b == 7 && SQ.MT == 49 && SQ.R == 7 && h->D == 784 && h->H == 100 && !h->stage_generic) {
+        PersistSync Y{h->tslab, h->pabort, h->pxcc, h->persist_spins};
+        HIPCHK(h, slab_prepare(h, SQ.Bpad16, s));
+        if (++h->s_epoch >= 500000u) { h->s_epoch = 1; HIPCHK(h, hipMemsetAsync(h->sxch, 0, (size_t)(cap + 1) * 3 * 256 * 8, s)); }
+        SolveSync Z{h->sxch, h->s_epoch, cap};
+        HIPCHK(h, rnde_launch_stage_solve(&SQ, &Y, &Z, h->act2, s));
+        if (h->timing) { HIPCHK(h, hipEventRecord(h->tev[1], s)); h->tev_fwd = true; }
+        hipLaunchKernelGGL(rnde_stage_finish_kernel, dim3(256), dim3(256), 0, s, SQ, -1, u_out_dev); HIPCHK(h, hipGetLastError());
+        const int cnt = std::min(cap, std::max(64, 2 * h->predicted));      // step records copied speculatively; a longer solve fetches the rest below
+        HIPCHK(h, hipMemcpyAsync(h->h_mbox, h->mbox, h->mbox_meta_off + (size_t)cnt * sizeof(StepMeta), hipMemcpyDeviceToHost, s));
+        if (h->after_solve) {
+            HIPCHK(h, hipEventRecord(h->ev_host, s));
+            const rnde_status hs = h->after_solve(s);
+            if (hs != RNDE_OK) return hs;
+            HIPCHK(h, hipEventSynchronize(h->ev_host));
+        } else HIPCHK(h, hipStreamSynchronize(s));
+        if (persist_check_result(h, SQ.C, SQ.R, s)) {
+            if (h->pending_bwd) {
+                h->pending_bwd = false;
+                h->err = "a persistent kernel abandoned its hand-off during or after the previous asynchronous reverse pass: the gradients of that step are invalid (multi-launch kernels now in use)";
+                return RNDE_ERR_HIP;
+            }
+            return RNDE_INTERNAL_RETRY;
+        }
+        h->pending_bwd = false;
+        if (h->h_ctl->n_att > cnt) {
+            HIPCHK(h, hipMemcpyAsync(h->h_meta + cnt, h->meta + cnt, (size_t)(h->h_ctl->n_att - cnt) * sizeof(StepMeta), hipMemcpyDeviceToHost, s));
+            HIPCHK(h, hipStreamSynchronize(s));
+        }
+        if (!h->h_ctl->done) { h->err = "max_attempts reached"; h->n_att = h->h_ctl->n_att; return RNDE_ERR_MAX_ATTEMPTS; }
+        ++h->one_launch_solves;
         solved = true;
     }
     while (!solved) {
@@ -1131,6 +1180,7 @@ extern "C" rnde_status rnde_node_timing(rnde_node* h, float* fwd_attempts_ms, fl
 extern "C" int32_t rnde_node_last_attempts(const rnde_node* h) { return h ? h->n_att : 0; }
 extern "C" int32_t rnde_node_fallback_count(const rnde_node* h) { return h ? h->persist_fallbacks : 0; }
 
+extern "C" int32_t rnde_node_one_launch_solves(const rnde_node* h) { return h ? h->one_launch_solves : 0; }
 extern "C" int32_t rnde_node_launches_per_attempt(const rnde_node* h) {
     if (!h) return 0;
     return (h->engine == 2 && h->persist != 1) ? 7 : 1;

@@ -40,6 +40,14 @@ __device__ __forceinline__ int kperm(int k) { return (k & ~15) | ((k & 3) << 2) 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+// acc + d * d, multiply and add rounded separately.  Every kernel of the stage engine forms the norm partials (error estimate, stiffness
+// estimate) with this: left to the compiler, contraction depends on the surrounding code (a row condition, the vectoriser), and kernels
+// that must agree bit for bit (7-launch, one-launch attempt, two-tile, wide, one-launch solve) differed in the last bit of eigen_est.
+__device__ __forceinline__ float add_square_unfused(float acc, float d) {
+#pragma clang fp contract(off)
+    const float m = d * d;
+    return acc + m;
+}
 // explicit fused multiply-adds for the stage combinations: rnde_stage_kernel and rnde_stage_attempt_kernel must round
 // identically (their outputs are compared bit for bit), so contraction is not left to the compiler
 __device__ __forceinline__ f32x4 fma4(float s, f32x4 a, f32x4 c) { return __builtin_elementwise_fma((f32x4){s, s, s, s}, a, c); }
@@ -388,7 +396,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_kernel(const StagePara
                     const float ut = dt * acc[i];
                     const float sk = P.abstol + fmaxf(fabsf(up[i]), fabsf(un[i])) * P.reltol;
                     const float r = ut / sk;
-                    part0 += r * r;
+                    part0 = add_square_unfused(part0, r);
                 }
                 if (P.reg_kind >= 2) {   // stiffness estimate partials: ||k7 - k6||^2, ||unew - g6||^2
                     f32x4 g6 = tsA_rt(5, 0) * c_k[0];
@@ -399,7 +407,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_kernel(const StagePara
                     for (int i = 0; i < 4; ++i) {
                         if (r0 + i < P.D) {
                             const float d1 = kv[i] - c_k[5][i], d2 = un[i] - g6[i];
-                            part1 += d1 * d1; part2 += d2 * d2;
+                            part1 = add_square_unfused(part1, d1); part2 = add_square_unfused(part2, d2);
                         }
                     }
                 }
@@ -508,7 +516,8 @@ __global__ __launch_bounds__(256) void rnde_stage_finish_kernel(const StageParam
     const StepParams& P = Q.F;
     const int tid = threadIdx.x, lane = tid & 63;
     const bool writer = (blockIdx.x == 0 && tid == 0);
-    const StepState S = advance_state(P, n, lane, writer, P.ctl_final);
+    // n < 0: the final state is already in P.ctl_final (the one-launch solve, rnde_stage_solve.h, leaves it there)
+    const StepState S = n < 0 ? *P.ctl_final : advance_state(P, n, lane, writer, P.ctl_final);
     const RecLayout L{(long long)P.D * P.Bpad, (long long)P.H * P.Bpad};
     if (P.nsave > 0 && n > 0) {
         const StepState pv = P.ctl[(n - 1) & 1];

@@ -511,7 +511,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
                         const float ut = dt * acc[i];
                         const float sk = P.abstol + fmaxf(fabsf(up[i]), fabsf(un[i])) * P.reltol;
                         const float r = ut / sk;
-                        part0 += r * r;
+                        part0 = add_square_unfused(part0, r);
                     }
                     if (P.reg_kind >= 2) {
                         f32x4 g6 = tsA(5, 0) * c_k[0];
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
                         for (int i = 0; i < 4; ++i) {
                             if (r0 + i < gD) {
                                 const float d1 = kv[i] - c_k[5][i], d2 = un[i] - g6[i];
-                                part1 += d1 * d1; part2 += d2 * d2;
+                                part1 = add_square_unfused(part1, d1); part2 = add_square_unfused(part2, d2);
                             }
                         }
                     }

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_attempt_mt_kernel(const Sta
                         const float ut = dt * acc[i];
                         const float sk = P.abstol + fmaxf(fabsf(up[i]), fabsf(un[i])) * P.reltol;
                         const float r = ut / sk;
-                        part0[tt] += r * r;
+                        part0[tt] = add_square_unfused(part0[tt], r);
                     }
                     if (P.reg_kind >= 2) {
                         f32x4 g6 = tsA(5, 0) * c_k[tt][0];
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_attempt_mt_kernel(const Sta
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const float d1 = kv[i] - c_k[tt][5][i], d2 = un[i] - g6[i];
-                            part1[tt] += d1 * d1; part2[tt] += d2 * d2;
+                            part1[tt] = add_square_unfused(part1[tt], d1); part2[tt] = add_square_unfused(part2[tt], d2);
                         }
                     }
                 }
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_attempt_mt_kernel(const Sta
                         const float ut = dt * acc[i];
                         const float sk = P.abstol + fmaxf(fabsf(up[i]), fabsf(un[i])) * P.reltol;
                         const float r = ut / sk;
-                        part0[tt] += r * r;
+                        part0[tt] = add_square_unfused(part0[tt], r);
                     }
                     if (P.reg_kind >= 2) {
                         f32x4 g6 = tsA(5, 0) * c_k[tt][0];
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_attempt_mt_kernel(const Sta
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const float d1 = kv[tt][i] - c_k[tt][5][i], d2 = un[i] - g6[i];
-                            part1[tt] += d1 * d1; part2[tt] += d2 * d2;
+                            part1[tt] = add_square_unfused(part1[tt], d1); part2[tt] = add_square_unfused(part2[tt], d2);
                         }
                     }
                 }

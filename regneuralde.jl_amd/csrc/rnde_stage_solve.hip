@@ -1,0 +1,21 @@
+// rnde_stage_solve.hip -- translation unit of the stage engine's one-launch solve (rnde_stage_solve.h); rnde.hip calls the launcher.
+#include <hip/hip_runtime.h>
+// The kernel headers define (non-template) kernels in namespace rnde; rnde.hip includes them too.  This translation unit gets its own
+// copy under another namespace name (as rnde_sde.hip does), and the launcher takes the parameter blocks by address: both units
+// compile the same struct definitions.
+#define rnde rnde_solve_tu
+#include "rnde_stage_solve.h"
+
+using namespace rnde;
+
+// grid: 8 * 7 * ceil(C / 8) workgroups of 7 waves, all resident at once (the host only calls this with at most 256 of them)
+extern "C" hipError_t rnde_launch_stage_solve(const void* stage_params, const void* persist_sync, const void* solve_sync, int act2, hipStream_t s) {
+    const StageParams& Q = *(const StageParams*)stage_params;
+    const PersistSync& Y = *(const PersistSync*)persist_sync;
+    const SolveSync& Z = *(const SolveSync*)solve_sync;
+    const size_t lds = sizeof(float) * (2 * kSCB * (16 * 7 + 4) + 32) + 4 * sizeof(double);
+    const dim3 grid(8 * 7 * ((Q.C + 7) / 8));
+    if (act2) hipLaunchKernelGGL((rnde_stage_solve_kernel<1>), grid, dim3(64 * 7), lds, s, Q, Y, Z);
+    else hipLaunchKernelGGL((rnde_stage_solve_kernel<0>), grid, dim3(64 * 7), lds, s, Q, Y, Z);
+    return hipGetLastError();
+}

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_wide_kernel(const StagePara
                         const float ut = dt * acc[q];
                         const float sk = P.abstol + fmaxf(fabsf(c_up[q]), fabsf(c_un[q])) * P.reltol;
                         const float r = ut / sk;
-                        p0 += r * r;
+                        p0 = add_square_unfused(p0, r);
                     }
                     if (P.reg_kind >= 2) {
                         f32x4 g6 = kTsA[5][0] * c_k[0];
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_wide_kernel(const StagePara
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const float d1 = kv[q] - c_k[5][q], d2 = c_un[q] - g6[q];
-                            p1 += d1 * d1; p2 += d2 * d2;
+                            p1 = add_square_unfused(p1, d1); p2 = add_square_unfused(p2, d2);
                         }
                     }
                 }

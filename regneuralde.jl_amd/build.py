@@ -41,13 +41,26 @@ def build(force=False, verbose=False):
     if os.environ.get("RNDE_WITH_COLUMN_OWNER") == "1":      # the round-1 engine's own step kernels (col_tile 4 / 8): optional, see rnde.hip
         flags.append("-DRNDE_WITH_COLUMN_OWNER")
     flags += os.environ.get("RNDE_EXTRA_FLAGS", "").split()      # compile-time A/B switches (tools/ab_build.sh)
-    hdr_m = max(os.path.getmtime(f) for f in _headers())
+    import re
+
+    def deps_mtime(path, seen=None):
+        """newest modification time of a source and of the project headers it includes, recursively (a kernel header that only one
+        translation unit includes must not cost a rebuild of the 2-minute monolith)"""
+        seen = set() if seen is None else seen
+        path = os.path.normpath(path)
+        if path in seen or not os.path.exists(path):
+            return 0.0
+        seen.add(path)
+        m = os.path.getmtime(path)
+        for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(path).read(), re.M):
+            m = max(m, deps_mtime(os.path.join(os.path.dirname(path), inc), seen))
+        return m
     restamp = os.path.exists(LIB + ".flags") and open(LIB + ".flags").read() != _flag_stamp()
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         srcp = os.path.join(CSRC, src)
-        if not force and not restamp and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(srcp), hdr_m):
+        if not force and not restamp and os.path.exists(obj) and os.path.getmtime(obj) >= deps_mtime(srcp):
             return obj
         cmd = [hipcc] + flags + ["-c", srcp, "-o", obj]
         if verbose:
@@ -67,4 +80,5 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    print(build(force="--incremental" not in sys.argv, verbose=True))      # default: rebuild everything; --incremental: only what changed

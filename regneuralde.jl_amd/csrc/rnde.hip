@@ -8,7 +8,7 @@
 #include "rnde_stage_persist2.h"
 #include "rnde_stage_wide.h"
 #include "rnde_bstage_persist.h"
-#include "rnde_stage_solve.h"
+#include "rnde_solve_sync.h"
 #include "rnde_binit_stage.h"
 #include "rnde_head.h"
 #include "rnde_chain.h"
@@ -18,6 +18,7 @@
 #include "rnde_bchainmw.h"
 
 #include <chrono>
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstdio>
@@ -1692,20 +1693,22 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
                 sv_hi[n] = ns;
             }
         }
-        for (int n = n_att - 1; n >= 0; --n) {
-            // cotangent of eigen_est for this attempt (host-known: saveval cotangent, callback form, recorded norms)
-            float c1 = 0.f, c2 = 0.f;
-            {
-                const StepMeta& mm = h->h_meta[n];
-                const bool eg_ok = !(mm.eigen == 0.f || mm.eigen != mm.eigen);
-                double eigb = 0.0;
-                if (h->cfg.regularize == RNDE_REG_STIFF && eg_ok) eigb = (double)b.h_svb[n] * (mm.eigen > 0 ? 1.0 : -1.0) / 3.5068;
-                if (h->cfg.regularize == RNDE_REG_ERR_STIFF && eg_ok) eigb = 0.1 * (double)b.h_svb[n] / 3.5068;
-                if (eigb != 0.0 && mm.n1 > 0.f && mm.n2 > 0.f) {
-                    c1 = (float)(eigb / ((double)mm.n2 * (double)mm.n1));
-                    c2 = (float)(-eigb * ((double)mm.n1 / (double)mm.n2) / ((double)mm.n2 * (double)mm.n2));
-                }
+        // cotangent coefficients of eigen_est for an attempt (host-known: saveval cotangent, callback form, recorded norms)
+        auto eig_coefs = [&](int n, float& c1, float& c2) {
+            c1 = 0.f; c2 = 0.f;
+            const StepMeta& mm = h->h_meta[n];
+            const bool eg_ok = !(mm.eigen == 0.f || mm.eigen != mm.eigen);
+            double eigb = 0.0;
+            if (h->cfg.regularize == RNDE_REG_STIFF && eg_ok) eigb = (double)b.h_svb[n] * (mm.eigen > 0 ? 1.0 : -1.0) / 3.5068;
+            if (h->cfg.regularize == RNDE_REG_ERR_STIFF && eg_ok) eigb = 0.1 * (double)b.h_svb[n] / 3.5068;
+            if (eigb != 0.0 && mm.n1 > 0.f && mm.n2 > 0.f) {
+                c1 = (float)(eigb / ((double)mm.n2 * (double)mm.n1));
+                c2 = (float)(-eigb * ((double)mm.n1 / (double)mm.n2) / ((double)mm.n2 * (double)mm.n2));
             }
+        };
+        for (int n = n_att - 1; n >= 0; --n) {
+            float c1 = 0.f, c2 = 0.f;
+            eig_coefs(n, c1, c2);
             const double qo = pow((double)h->h_meta[n].qold_in, (double)kBeta2);   // for the scalar adjoint chain of the attempt
             if (h->persist == 1) {   // the attempt's 7 reverse launches as one (rnde_bstage_persist.h)
                 PersistSync Y{h->tslab, h->pabort, h->pxcc, h->persist_spins};

@@ -19,14 +19,9 @@
 // kernels use and the host redoes the solve launch by launch.
 #pragma once
 #include "rnde_stage_persist.h"
+#include "rnde_solve_sync.h"
 
 namespace rnde {
-
-struct SolveSync {
-    unsigned long long* xch;   // [n_limit][3][256] granules {float value, uint tag}
-    unsigned epoch;            // tag = epoch * 8192 + attempt + 1
-    int n_limit;               // attempts this launch may run (< 8192)
-};
 
 typedef __attribute__((address_space(1))) unsigned long long solve_gu64;
 

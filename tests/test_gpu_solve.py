@@ -82,3 +82,4 @@ def test_one_launch_solve_reports_max_attempts_and_falls_back_on_timeout(monkeyp
     got = node.forward(x, p)
     assert node.L.rnde_node_fallback_count(node.h) == 1 and _solves(node) == 0
     assert got["nfe"] == ref["nfe"] and np.array_equal(got["u"], ref["u"])
+

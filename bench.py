@@ -132,6 +132,40 @@ def attempt_roofline_at(B, device, steps=3, warmup=2):
     return out
 
 
+def global_batch_anchor(G, device, steps, warmup=2):
+    """The FULL training step (loss forward, reverse pass, InvDecay / Momentum update; the weights train) at a batch of G on ONE GPU: the N = 1
+    point of the strong-scaling curve `python bench.py --gpus N --global-batch G` measures (BASELINE.json: batch 4096 sharded 8 x MI355X)."""
+    import torch
+    import regneuralde_jl_amd as rn
+    model = build_model(rn, device, G)
+    opt = rn.FluxOptimiser(model.trainable())
+    g = torch.Generator().manual_seed(1999)
+    x = torch.rand(G, 1, 28, 28, generator=g).to(device)
+    y = torch.eye(NCLS)[torch.randint(0, NCLS, (G,), generator=g)].to(device)
+    nfes = []
+
+    def step():
+        loss, ce, reg, nfe = rn.fused_loss_and_grad(model, x, y, lam=1.0e2, sync=False)
+        opt.step()
+        nfes.append(nfe)
+
+    for _ in range(warmup):
+        step()
+    nfes.clear()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    out = {"value": G * steps / el, "unit": "samples/s", "ms_per_step": 1e3 * el / steps, "mean_nfe": sum(nfes) / len(nfes), "steps": steps, "warmup": warmup,
+           "global_batch": G, "n_gpus": 1, "what": f"full training step (with optimiser update) at batch {G} on one GPU: divide the value of "
+                                                    f"`bench.py --gpus N --global-batch {G}` by this one for the strong-scaling factor"}
+    del model, opt
+    torch.cuda.empty_cache()
+    return out
+
+
 def bench_latent(args):
     """SURVEY.md 8d config 4 ("latent ODE dynamics only, for the kernel benchmark"): gen_dynamics of experiments/latent_ode.jl:113-124
     (tanh + 8 x Dense(20<->50, tanh), P = 8,280), B = 512, 49 saveat points on [0, 1], Tsit5 at 1.4e-8; forward + reverse of the layer call."""
@@ -302,6 +336,8 @@ def main():
                     "partials after every attempted step; reproduces the single-device run at the global batch; default: independent controllers)")
     ap.add_argument("--share-gpu", action="store_true", help="test rig: every rank on device 0, torch.distributed on gloo, the gradient collective = the library's one-shot "
                     "kernel over peer-mapped windows (no RCCL: it refuses two ranks on one GPU); the N > 1 code path on a 1-GPU box, not a throughput claim")
+    ap.add_argument("--global-batch", type=int, default=0, help="STRONG scaling: the global batch is fixed (e.g. 4096) and split evenly over the ranks "
+                    "(per-rank batch = G / world, \"scaling\": \"strong\"); default 0 = weak scaling at --batch per rank")
     ap.add_argument("--workload", default="mnist", choices=["mnist", "latent", "nsde"], help="mnist = BASELINE.json's metric (default); latent = config 4; nsde = config 5")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -337,6 +373,10 @@ def main():
     from regneuralde_jl_amd import _lib
     L = _lib.lib()
     B = args.batch
+    if args.global_batch:
+        if args.global_batch % world:
+            raise SystemExit(f"--global-batch {args.global_batch} is not a multiple of the {world} ranks")
+        B = args.global_batch // world
     model = build_model(rn, device, B)
     model.node.col_tile = args.col_tile
     opt = rn.FluxOptimiser(model.trainable())
@@ -457,6 +497,7 @@ def main():
             _lib.check(h.ptr, L.rnde_bench_attempt_taped(h.ptr, xs.data_ptr(), model.p2.data_ptr(), B, 200, C.byref(us), stream))
         _lib.check(h.ptr, L.rnde_bench_attempt(h.ptr, xs.data_ptr(), model.p2.data_ptr(), B, 200, C.byref(us_untaped), stream))
         nl = int(L.rnde_node_launches_per_attempt(h.ptr))
+        one_launch = int(L.rnde_node_one_launch_solves(h.ptr)) > 0      # the forward solve ran as ONE launch (rnde_stage_solve_kernel)
         # The roofline unit is timed where the contract asks: INSIDE training steps, HIP events on the launch stream around the forward
         # sweep (3 steps above), divided by the number of attempted steps (= us_per_attempt_fwd; rocprofv3's per-kernel average of this
         # command is a little lower because it averages the ~4.5 us early-exit launches in).  The back-to-back micro-benchmark is reported
@@ -465,12 +506,16 @@ def main():
         t_att = us_in_step * 1e-6
         roof = {"bound": "hbm", "achieved": ALG_BYTES(B) / t_att / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ALG_BYTES(B) / t_att / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                "kernel": (("rnde_stage_attempt_kernel (taped, timed inside training steps): one attempted Tsit5 step = 1 launch (7 stages, in-kernel slab hand-off)" if nl == 1 else
+                "kernel": (("rnde_stage_solve_kernel (taped, timed inside training steps): ONE launch = the whole adaptive solve; the roofline unit stays one attempted Tsit5 "
+                            "step = launch duration / attempts of that solve (units_per_launch)" if one_launch else
+                            "rnde_stage_attempt_kernel (taped, timed inside training steps): one attempted Tsit5 step = 1 launch (7 stages, in-kernel slab hand-off)" if nl == 1 else
                             "rnde_stage_kernel (taped): one attempted Tsit5 step = 7 launches (START, 5 x STAGE, LAST)") if stage_engine
                            else "rnde_step_kernel: one attempted Tsit5 step = 1 launch"),
-                "launches_per_unit": nl, "us_per_launch": us_in_step / nl,
+                "launches_per_unit": (1.0 / max(1.0, sum(atts) / len(atts))) if one_launch else nl,
+                "units_per_launch": (sum(atts) / len(atts)) if one_launch else 1.0 / nl,
+                "us_per_launch": (1e3 * sum(fa) / len(fa)) if one_launch else us_in_step / nl,
                 "us_per_attempt": us_in_step, "us_per_attempt_back_to_back": us.value, "us_per_attempt_back_to_back_untaped": us_untaped.value,
-                "alg_bytes_per_attempt": ALG_BYTES(B), "alg_bytes_per_launch": ALG_BYTES(B) / nl,
+                "alg_bytes_per_attempt": ALG_BYTES(B), "alg_bytes_per_launch": ALG_BYTES(B) * (sum(atts) / len(atts)) if one_launch else ALG_BYTES(B) / nl,
                 "mfma_f32_tflops": ALG_FLOPS(B) / t_att / 1e12,
                 "mfma_frac": ALG_FLOPS(B) / t_att / 1e12 / MFMA_F32_PEAK_TF}
         # HBM traffic per launch of that kernel: PMC counters cannot be collected from inside the bench; the committed separate
@@ -507,7 +552,7 @@ def main():
         out = {"metric": "training-step samples/sec + mean NFE, MNIST Neural ODE bs=512",
                "value": world * B * args.steps / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "mean_nfe": mean_nfe, "final_loss": last_loss,
                "value_fixed_weights": None if fixed is None else fixed["value"],
                "fixed_weights": fixed,
@@ -523,7 +568,8 @@ def main():
                "config": {"workload": f"MNIST NODE regularized (error_est), Tsit5 reltol=abstol=1.4e-8, batch {B} per GPU, "
                                       "1xMI355X per rank; step = loss fwd + reverse pass through the solver + "
                                       "InvDecay/Momentum update; the weights train during the timed steps (mean_nfe drifts with "
-                                      "--steps: value_fixed_weights is the stationary companion)", "global_batch": world * B,
+                                      "--steps: value_fixed_weights is the stationary companion)"
+                                      + (f"; STRONG scaling: global batch {args.global_batch} split over {world} rank(s)" if args.global_batch else ""), "global_batch": world * B,
                           "parallelism": f"dp{world}" if world > 1 else "single"},
                "roofline": roof}
         if dist_diag is not None:
@@ -535,6 +581,13 @@ def main():
                 out["roofline_B4096"] = attempt_roofline_at(4096, device)
             except Exception as e:
                 out["roofline_B4096"] = {"error": repr(e)}
+        if world == 1 and not args.no_extras and not use_dist and B == 512:
+            try:      # the N = 1 anchor of the strong-scaling curve (north star: batch 4096 over 1 / 2 / 4 / 8 GPUs): the FULL training step at B = 4096
+                others_anchor = global_batch_anchor(4096, device, max(3, args.steps // 4))
+            except Exception as e:
+                others_anchor = {"error": repr(e)}
+        else:
+            others_anchor = None
         if world == 1 and not args.no_extras and not use_dist:
             sub = argparse.Namespace(steps=max(3, args.steps // 2), warmup=2, autograd=args.autograd)
             others = {}
@@ -543,6 +596,8 @@ def main():
                     others[name] = fn(sub)
                 except Exception as e:      # a secondary record must never cost the headline line
                     others[name] = {"error": repr(e)}
+            if others_anchor is not None:
+                others["global4096"] = others_anchor
             out["other_workloads"] = others
     if use_dist:
         dist.barrier()

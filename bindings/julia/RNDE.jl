@@ -1,7 +1,9 @@
 # RNDE.jl -- Julia binding of librnde.so (include/rnde.h) for RegNeuralDE.jl on MI355X.
 #
 # SOURCE ONLY: no Julia toolchain exists in the build image, so this file has never been executed (INTEGRATION.md says what
-# was checked instead: every prototype below is the one regneuralde.jl_amd/_lib.py binds with ctypes and the GPU tests call).
+# was checked instead: every prototype below is the one regneuralde.jl_amd/_lib.py binds with ctypes and the GPU tests call;
+# tests/test_abi.py parses the two config structs below and compares field order, widths and offsets with a C program compiled
+# against include/rnde.h, tests/abi_c/abi_check.c, and with the ctypes mirrors).
 # It shows exactly what a maintainer adds to the reference: the body of the TrackedNeuralODE call methods between ODEProblem
 # construction and result unpacking (reference src/models/neural_ode.jl:126-142) becomes one `ccall`, the same for
 # TrackedNeuralDSDE (src/models/neural_sde.jl:98-113), and the reverse sweeps are registered with `Tracker.@grad` so that
@@ -11,6 +13,7 @@
 # plain `Ptr{Cvoid}`: `devptr(a)` below reinterprets AMDGPU's typed device pointer, nothing else about the array is touched.
 module RNDE
 
+import AMDGPU                                   # (binds the module name too: AMDGPU.stream(), AMDGPU.synchronize() below)
 using AMDGPU: ROCArray, ROCVector, ROCMatrix
 using Tracker
 using Tracker: TrackedArray, data, track, @grad
@@ -158,7 +161,26 @@ rnde_solve(h::Handle, x::TrackedArray, p::TrackedArray, tspan) = track(rnde_solv
     end
 end
 
-# ---- what changes in src/models/neural_ode.jl (reference :110-144) -----------------------------------
+# the {R,true} methods (reference neural_ode.jl:79-108, :146-180): u3 is D x T x B, its cotangent has the same shape
+rnde_solve_saveat(h::Handle, x::TrackedArray, p::TrackedArray, tspan, saveat::Vector{Float32}) = track(rnde_solve_saveat, h, x, p, tspan, saveat)
+
+@grad function rnde_solve_saveat(h::Handle, x, p, tspan, saveat)
+    u3, nfe, sv = solve_forward_saveat(h, data(x), data(p), data.(tspan), saveat; keep_tape = true)
+    h.last_nfe = nfe
+    return (u3, sv), function (Δ)
+        ubar, svbar = Δ
+        xbar, pbar, tsbar = solve_backward(h, ROCArray{Float32}(ubar), Vector{Float32}(svbar), length(p))
+        return (nothing, xbar, pbar, tsbar, nothing)
+    end
+end
+
+# The unregularised methods ({false,false} / {false,true}) go through the same two rules: their handle is created with regularize = 0, the
+# saved-value vector then comes back empty and its cotangent is ignored.
+
+# ---- what changes in src/models/neural_ode.jl: bindings/julia/patch_neural_ode.jl holds the four call methods as real method
+# definitions (include it after `using RegNeuralDE`); the body between ODEProblem construction and result unpacking (reference
+# :126-138) is the one call below, everything else -- signature, keyword defaults, `_convert_tspan`, the returned triple -- is the reference's:
+#
 #
 #   @fastmath function (n::TrackedNeuralODE{true,false})(x, p = n.p; func = ..., tspan = nothing, saveat = nothing)
 #       tspan = _convert_tspan(isnothing(tspan) ? n.tspan : tspan, p)
@@ -237,6 +259,76 @@ function nsde_backward(h::NsdeHandle, ubar::ROCMatrix{Float32}, svbar::Vector{Fl
         st == 0 || error("rnde_nsde_backward status $st")
     end
     return xbar, pbar
+end
+
+function nsde_forward_saveat(h::NsdeHandle, x::ROCMatrix{Float32}, p::ROCVector{Float32}, tspan, saveat::Vector{Float32}; noise = nothing,
+                             seed::Integer = 0, keep_tape::Bool)
+    D, B = size(x)
+    u3 = ROCArray{Float32}(undef, D, length(saveat), B)
+    nfe1 = Ref{Int64}(0); nfe2 = Ref{Int64}(0); nsv = Ref{Int32}(0)
+    sv = Vector{Float32}(undef, h.cfg.max_attempts + 1)
+    npool = noise === nothing ? 0 : size(noise, 4)
+    GC.@preserve x p u3 sv noise saveat begin
+        st = ccall((:rnde_nsde_forward_saveat, LIB), Cint,
+                   (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Float32, Float32, Ptr{Cvoid}, Int32, UInt64, Ptr{Float32}, Int32, Ptr{Cvoid},
+                    Ref{Int64}, Ref{Int64}, Ptr{Float32}, Ref{Int32}, Int32, Ptr{Cvoid}),
+                   h.ptr, devptr(x), devptr(p), B, Float32(tspan[1]), Float32(tspan[2]),
+                   noise === nothing ? C_NULL : devptr(noise), npool, UInt64(seed), saveat, length(saveat), devptr(u3), nfe1, nfe2, sv, nsv,
+                   keep_tape ? 1 : 0, _stream())
+        st == 0 || error("rnde_nsde_forward_saveat status $st: ", unsafe_string(ccall((:rnde_nsde_last_error, LIB), Cstring, (Ptr{Cvoid},), h.ptr)))
+    end
+    return u3, Int(nfe1[]), Int(nfe2[]), sv[1:nsv[]]
+end
+
+# u-bar: D x B after nsde_forward, D x T x B after nsde_forward_saveat; x-bar is D x B either way
+function nsde_backward_any(h::NsdeHandle, ubar::ROCArray{Float32}, svbar::Vector{Float32}, np::Int)
+    xbar = ROCArray{Float32}(undef, size(ubar, 1), size(ubar, ndims(ubar)))
+    pbar = ROCArray{Float32}(undef, np)
+    GC.@preserve ubar xbar pbar svbar begin
+        st = ccall((:rnde_nsde_backward, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float32}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                   h.ptr, devptr(ubar), svbar, devptr(xbar), devptr(pbar), _stream())
+        st == 0 || error("rnde_nsde_backward status $st: ", unsafe_string(ccall((:rnde_nsde_last_error, LIB), Cstring, (Ptr{Cvoid},), h.ptr)))
+    end
+    return xbar, pbar
+end
+
+# Tracker glue for the stochastic layer: one tape node for the whole solve.  The evaluation counters the reference keeps in the layer's mutable
+# `nfes` vector (neural_sde.jl:11, :46, :50, :142-143) are kept on the handle.  `seed` names the library's Philox stream (a caller that wants
+# Julia's own random stream passes a pool of normals through nsde_forward directly).
+mutable struct NsdeCounters; nfe1::Int; nfe2::Int; end
+const NSDE_COUNTERS = IdDict{NsdeHandle,NsdeCounters}()
+counters(h::NsdeHandle) = get!(() -> NsdeCounters(0, 0), NSDE_COUNTERS, h)
+
+rnde_nsde_solve(h::NsdeHandle, x::TrackedArray, p::TrackedArray, tspan, seed::Integer) = track(rnde_nsde_solve, h, x, p, tspan, seed)
+@grad function rnde_nsde_solve(h::NsdeHandle, x, p, tspan, seed)
+    u, nfe1, nfe2, sv = nsde_forward(h, data(x), data(p), data.(tspan); seed = seed, keep_tape = true)
+    c = counters(h); c.nfe1 = nfe1; c.nfe2 = nfe2
+    return (u, sv), function (Δ)
+        ubar, svbar = Δ
+        xbar, pbar = nsde_backward_any(h, ROCArray{Float32}(ubar), Vector{Float32}(svbar), length(p))
+        return (nothing, xbar, pbar, nothing, nothing)      # (the SDE step-size controller strips tracking: no tspan cotangent, DESIGN.md 4.3)
+    end
+end
+
+rnde_nsde_solve_saveat(h::NsdeHandle, x::TrackedArray, p::TrackedArray, tspan, saveat::Vector{Float32}, seed::Integer) =
+    track(rnde_nsde_solve_saveat, h, x, p, tspan, saveat, seed)
+@grad function rnde_nsde_solve_saveat(h::NsdeHandle, x, p, tspan, saveat, seed)
+    u3, nfe1, nfe2, sv = nsde_forward_saveat(h, data(x), data(p), data.(tspan), saveat; seed = seed, keep_tape = true)
+    c = counters(h); c.nfe1 = nfe1; c.nfe2 = nfe2
+    return (u3, sv), function (Δ)
+        ubar, svbar = Δ
+        xbar, pbar = nsde_backward_any(h, ROCArray{Float32}(ubar), Vector{Float32}(svbar), length(p))
+        return (nothing, xbar, pbar, nothing, nothing, nothing)
+    end
+end
+
+# config from the two Flux chains of TrackedNeuralDSDE (neural_sde.jl:13-41): Dense sizes and activations, tolerances from kwargs
+function nsde_config_for(drift_dims::Vector{Int}, drift_acts::Vector{Int}, diff_dims::Vector{Int}, diff_acts::Vector{Int}; max_batch, reltol, abstol,
+                         regularize, solver = 0, max_attempts = 256, device = 0)
+    t9(v) = ntuple(i -> Int32(i <= length(v) ? v[i] : 0), 9)
+    t8(v) = ntuple(i -> Int32(i <= length(v) ? v[i] : 0), 8)
+    NsdeConfig(length(drift_acts), t9(drift_dims), t8(drift_acts), length(diff_acts), t9(diff_dims), t8(diff_acts), max_batch, solver, reltol, abstol,
+               regularize, 1, max_attempts, device, 0f0, 0f0, 0f0, 0f0, 0f0, 0f0, 0f0, 0)
 end
 
 # ---- one training-step gradient in one call ------------------------------------------------------------

@@ -1,0 +1,79 @@
+# patch_neural_ode.jl -- the four call methods of TrackedNeuralODE (reference src/models/neural_ode.jl:48-180) with their `solve` replaced
+# by librnde.so.  SOURCE ONLY (no Julia in the build image).  Usage, in an experiment script such as experiments/mnist_node.jl:
+#
+#     using RegNeuralDE
+#     include("/path/to/repo/bindings/julia/RNDE.jl")
+#     include("/path/to/repo/bindings/julia/patch_neural_ode.jl")      # redefines the methods below; everything else is untouched
+#
+# Signatures, keyword defaults, `_convert_tspan` (src/utils.jl:21-23), the returned triple `(res, nfe, sv)` and the `SavedValues` container are
+# the reference's.  `func` selects the callback as the reference's experiments do (mnist_node.jl:62-103): the library records EEst * dt,
+# the stiffness estimate or their blend according to the handle's `regularize` code; the closure itself is not called.
+#
+# The layer struct has no field for the handle (and is immutable), so handles live in a table keyed by the layer object and the batch width.
+using Tracker, Flux, DiffEqCallbacks
+using RegNeuralDE: TrackedNeuralODE, TDChain, _convert_tspan
+
+const RNDE_ODE_HANDLES = IdDict{Any,Dict{Int,RNDE.Handle}}()
+
+# Dense sizes / activations of the dynamics (TDChain or Chain of Dense layers; a leading `x -> tanh.(x)` is latent_ode.jl:114's pre-activation)
+function _dense_layout(model)
+    layers = model isa TDChain ? model.layers : model.layers
+    pre = !(first(layers) isa Flux.Dense)
+    ds = [l for l in layers if l isa Flux.Dense]
+    td = model isa TDChain
+    dims = Int[size(ds[1].W, 2) - (td ? 1 : 0)]
+    acts = Int[]
+    for l in ds
+        push!(dims, size(l.W, 1)); push!(acts, l.σ === tanh ? 1 : 0)
+    end
+    return dims, acts, td, pre
+end
+
+# regularize code of include/rnde.h from the type parameter R and the experiment's `func` choice (configs/mnist_node.yml `type`)
+_reg_code(R::Bool, kind::Symbol) = !R ? 0 : (kind === :error_est ? 1 : kind === :stiff_est ? 2 : 3)
+
+function rnde_handle(n::TrackedNeuralODE{R}, B::Int; kind::Symbol = :error_est) where {R}
+    tab = get!(() -> Dict{Int,RNDE.Handle}(), RNDE_ODE_HANDLES, n)
+    get!(tab, B) do
+        dims, acts, td, pre = _dense_layout(n.model)
+        RNDE.Handle(RNDE.config_for(dims, acts; time_dep = td, pre_act = pre, max_batch = B, reltol = Float32(get(n.kwargs, :reltol, 1f-3)),
+                                    abstol = Float32(get(n.kwargs, :abstol, 1f-6)), regularize = _reg_code(R, kind)))
+    end
+end
+
+_saveat_vec(n, saveat) = Float32.(collect(isnothing(saveat) ? n.kwargs[:saveat] : saveat))
+_saved(tspan, p, saveval) = (sv = SavedValues(eltype(tspan), eltype(p)); append!(sv.saveval, saveval); sv)
+
+# {false,false} (reference :48-77): vanilla solve, end state only
+function (n::TrackedNeuralODE{false,false})(x, p = n.p; func = (u, t, int) -> 0, tspan = nothing, saveat = nothing)
+    tspan = _convert_tspan(isnothing(tspan) ? n.tspan : tspan, p)
+    h = rnde_handle(n, size(x, 2))
+    res, _ = RNDE.rnde_solve(h, x, p, tspan)                                   # <- replaces :61-70
+    return res, h.last_nfe, nothing
+end
+
+# {false,true} (reference :79-108): all saved states, D x T x B
+function (n::TrackedNeuralODE{false,true})(x, p = n.p; func = (u, t, int) -> 0, tspan = nothing, saveat = nothing)
+    tspan = _convert_tspan(isnothing(tspan) ? n.tspan : tspan, p)
+    h = rnde_handle(n, size(x, 2))
+    res, _ = RNDE.rnde_solve_saveat(h, x, p, tspan, _saveat_vec(n, saveat))     # <- replaces :92-102 (update_saveat! is not needed: nothing is mutated)
+    return res, h.last_nfe, nothing
+end
+
+# {true,false} (reference :110-144): end state + the saving callback's values (configs 2 / 3)
+function (n::TrackedNeuralODE{true,false})(x, p = n.p; func = (u, t, integrator) -> integrator.EEst * integrator.dt, tspan = nothing,
+                                           saveat = nothing, kind::Symbol = :error_est)
+    tspan = _convert_tspan(isnothing(tspan) ? n.tspan : tspan, p)
+    h = rnde_handle(n, size(x, 2); kind = kind)
+    res, saveval = RNDE.rnde_solve(h, x, p, tspan)                             # <- replaces :126-138
+    return res, h.last_nfe, _saved(tspan, p, saveval)
+end
+
+# {true,true} (reference :146-180): saved states + callback values (config 4, latent_ode.jl:137-147)
+function (n::TrackedNeuralODE{true,true})(x, p = n.p; func = (u, t, integrator) -> integrator.EEst * integrator.dt, tspan = nothing,
+                                          saveat = nothing, kind::Symbol = :error_est)
+    tspan = _convert_tspan(isnothing(tspan) ? n.tspan : tspan, p)
+    h = rnde_handle(n, size(x, 2); kind = kind)
+    res, saveval = RNDE.rnde_solve_saveat(h, x, p, tspan, _saveat_vec(n, saveat))   # <- replaces :162-174
+    return res, h.last_nfe, _saved(tspan, p, saveval)
+end

@@ -1,0 +1,68 @@
+# patch_neural_sde.jl -- the four call methods of TrackedNeuralDSDE (reference src/models/neural_sde.jl:44-146) with their `solve` replaced by
+# librnde.so.  SOURCE ONLY (no Julia in the build image).  Usage: include RNDE.jl, then this file, after `using RegNeuralDE` (see
+# patch_neural_ode.jl).  Signatures and the returned 4-tuple `(arr, nfe1, nfe2, sv)` are the reference's; the drift / diffusion evaluation
+# counts come from the library (2 + 4 per attempted step each: what the closures' counters at :46, :50 count), the layer's own `nfes`
+# vector is left at zero as the reference leaves it after every call (:142-143).
+using Tracker, Flux, DiffEqCallbacks
+using RegNeuralDE: TrackedNeuralDSDE, _convert_tspan
+
+const RNDE_SDE_HANDLES = IdDict{Any,Dict{Int,RNDE.NsdeHandle}}()
+const RNDE_SDE_CALLS = Ref(0)      # one Philox stream per call: seed = a counter (pass `seed = ...` for a reproducible run)
+
+function _chain_layout(model)
+    ds = model isa Flux.Dense ? [model] : [l for l in model.layers if l isa Flux.Dense]
+    dims = Int[size(ds[1].W, 2)]; acts = Int[]
+    for l in ds
+        push!(dims, size(l.W, 1)); push!(acts, l.σ === tanh ? 1 : 0)
+    end
+    return dims, acts
+end
+
+function rnde_handle(n::TrackedNeuralDSDE{R}, B::Int) where {R}
+    tab = get!(() -> Dict{Int,RNDE.NsdeHandle}(), RNDE_SDE_HANDLES, n)
+    get!(tab, B) do
+        d1, a1 = _chain_layout(n.model1); d2, a2 = _chain_layout(n.model2)
+        RNDE.NsdeHandle(RNDE.nsde_config_for(d1, a1, d2, a2; max_batch = B, reltol = Float32(get(n.kwargs, :reltol, 1f-2)),
+                                             abstol = Float32(get(n.kwargs, :abstol, 1f-2)), regularize = R ? 1 : 0))
+    end
+end
+
+_sde_saved(tspan, p, saveval) = (sv = SavedValues(eltype(tspan), eltype(p)); append!(sv.saveval, saveval); sv)
+_sde_saveat(n) = Float32.(collect(n.kwargs[:saveat]))
+_next_seed(seed) = isnothing(seed) ? (RNDE_SDE_CALLS[] += 1) : seed
+
+# {false,false} (reference :63-82)
+function (n::TrackedNeuralDSDE{false,false})(x, p = n.p; func = (u, t, int) -> 0, seed = nothing)
+    tspan = _convert_tspan(n.tspan, p)
+    h = rnde_handle(n, size(x, 2))
+    arr, _ = RNDE.rnde_nsde_solve(h, x, p, tspan, _next_seed(seed))                            # <- replaces :74-76
+    c = RNDE.counters(h)
+    return arr, c.nfe1, c.nfe2, nothing
+end
+
+# {false,true} (reference :44-61): all saved states, D x T x B
+function (n::TrackedNeuralDSDE{false,true})(x, p = n.p; func = (u, t, int) -> 0, seed = nothing)
+    tspan = _convert_tspan(n.tspan, p)
+    h = rnde_handle(n, size(x, 2))
+    arr, _ = RNDE.rnde_nsde_solve_saveat(h, x, p, tspan, _sde_saveat(n), _next_seed(seed))      # <- replaces :54-56
+    c = RNDE.counters(h)
+    return arr, c.nfe1, c.nfe2, nothing
+end
+
+# {true,false} (reference :116-146): end state + EEst * dt per accepted step (config 5, experiments/mnist_nsde.jl)
+function (n::TrackedNeuralDSDE{true,false})(x, p = n.p; func = (u, t, integrator) -> integrator.EEst * integrator.dt, seed = nothing)
+    tspan = _convert_tspan(n.tspan, p)
+    h = rnde_handle(n, size(x, 2))
+    arr, saveval = RNDE.rnde_nsde_solve(h, x, p, tspan, _next_seed(seed))                      # <- replaces :130-140
+    c = RNDE.counters(h)
+    return arr, c.nfe1, c.nfe2, _sde_saved(tspan, p, saveval)
+end
+
+# {true,true} (reference :84-113)
+function (n::TrackedNeuralDSDE{true,true})(x, p = n.p; func = (u, t, integrator) -> integrator.EEst * integrator.dt, seed = nothing)
+    tspan = _convert_tspan(n.tspan, p)
+    h = rnde_handle(n, size(x, 2))
+    arr, saveval = RNDE.rnde_nsde_solve_saveat(h, x, p, tspan, _sde_saveat(n), _next_seed(seed))   # <- replaces :98-108
+    c = RNDE.counters(h)
+    return arr, c.nfe1, c.nfe2, _sde_saved(tspan, p, saveval)
+end

@@ -287,7 +287,11 @@ rnde_status rnde_comm_allreduce(rnde_comm* c, float* buf_dev, int64_t n, int32_t
  * single GPU (two host threads, two handles), and what several shards per device would use. */
 rnde_status rnde_comm_create_local_group(int32_t world, int32_t device, rnde_comm** out);
 /* RNDE_OK unless an all-reduce of this communicator gave up waiting for a rank (in-process groups and the one-shot path; blocking:
- * call after the stream has been synchronised).  The coupled solves below check it themselves at their synchronisation points. */
+ * call after the stream has been synchronised).  The coupled solves below check it themselves at their synchronisation points.
+ * One-shot path: a time-out is STICKY -- the kernel that gave up and every later one fill their buffer with NaN instead of a partial sum,
+ * and every rnde_comm_allreduce enqueued after the time-out became visible to the host returns RNDE_ERR_HIP (rnde_comm_last_error names the
+ * limit in force: 20 s, RNDE_ONESHOT_TIMEOUT_MS overrides it).  Its all-reduces may be enqueued on different streams: a call on another
+ * stream than the previous one is ordered behind it with an event (RCCL has no such constraint). */
 rnde_status rnde_comm_health(rnde_comm* c);
 /* One-shot all-reduce over peer-mapped windows (the 0.67 MB gradient message is latency bound, so each rank reads
  * the N - 1 peers' copies directly over its xGMI links in ONE kernel and sums them in rank order -- the same bits on every rank --

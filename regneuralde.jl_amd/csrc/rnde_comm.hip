@@ -17,6 +17,7 @@
 #include <condition_variable>
 #include <cstdint>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -36,6 +37,7 @@ struct RcclApi {
     int (*AllGather)(const void*, void*, size_t, int, nccl_comm_t, hipStream_t) = nullptr;   // (one-shot path: ships the window handles)
     const char* (*GetErrorString)(int) = nullptr;
     std::string err;
+    std::string path;      // file the symbols were bound from (set once, inside the call_once below: rnde_comm_library() returns it unchanged)
 };
 
 RcclApi& api() {
@@ -65,6 +67,8 @@ RcclApi& api() {
         a.AllReduce = (decltype(a.AllReduce))sym("ncclAllReduce");
         a.GetErrorString = (decltype(a.GetErrorString))sym("ncclGetErrorString");
         a.AllGather = (decltype(a.AllGather))dlsym(a.lib, "ncclAllGather");
+        Dl_info info;
+        a.path = (a.AllReduce && dladdr((void*)a.AllReduce, &info) && info.dli_fname) ? info.dli_fname : "(unknown)";
     });
     return a;
 }
@@ -73,13 +77,9 @@ thread_local std::string g_comm_err;
 
 }  // namespace
 
-extern "C" const char* rnde_comm_library(void) {
-    static std::string path;
+extern "C" const char* rnde_comm_library(void) {      // (immutable after the first call of api(): safe from any number of host threads)
     RcclApi& a = api();
-    if (!a.AllReduce) return a.err.c_str();
-    Dl_info info;
-    path = (dladdr((void*)a.AllReduce, &info) && info.dli_fname) ? info.dli_fname : "(unknown)";
-    return path.c_str();
+    return a.AllReduce ? a.path.c_str() : a.err.c_str();
 }
 
 namespace {
@@ -143,6 +143,7 @@ struct PeerView {
     float* data[kPeerMaxWorld];        // rank r's data slots as mapped in THIS process (own rank: the local pointer)
     unsigned* flags[kPeerMaxWorld];    // rank r's flag array
     unsigned* fail;                    // local: raised when a wait gave up
+    unsigned* fail_host;               // the same in pinned host memory (mapped): the next enqueue sees it without a device round trip
     int world, rank;
 };
 
@@ -164,12 +165,18 @@ __global__ __launch_bounds__(256) void rnde_peer_allreduce_kernel(PeerView V, fl
         const unsigned* f = V.flags[V.rank] + ((size_t)slot * kPeerMaxWorld + tid) * kPeerBlocks + w;
         const long long t0 = wall_clock64();
         while ((int)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
-            if (wall_clock64() - t0 > timeout_ticks) { atomicExch(V.fail, 1u); break; }
+            if (wall_clock64() - t0 > timeout_ticks) { atomicExch(V.fail, 1u); __hip_atomic_store(V.fail_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
             __builtin_amdgcn_s_sleep(2);
         }
     }
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    // a wait gave up (now or in an earlier all-reduce of this communicator: the flag protocol is out of step from then on): the chunk is
+    // poisoned instead of summed from whatever the slots hold -- an update computed from it is NaN, not a silently un-reduced gradient
+    if (__hip_atomic_load(V.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        for (long long i = lo + tid; i < hi; i += 256) buf[i] = __builtin_nanf("");
+        return;
+    }
     // c. sum in rank order
     const float* src[kPeerMaxWorld];
 #pragma unroll
@@ -196,6 +203,7 @@ struct PeerState {
     void* mapped[kPeerMaxWorld] = {nullptr};   // the peers' windows as opened here
     PeerView view{};
     const char* kind = "";
+    unsigned* fail_host = nullptr;     // pinned, mapped
 };
 
 }  // namespace
@@ -239,6 +247,9 @@ struct rnde_comm {
     LocalShared* loc = nullptr;   // non-null: a rank of an in-process group
     PeerState* peer = nullptr;    // non-null: peer-mapped windows for the one-shot all-reduce
     unsigned seq = 0, peer_seq = 0;
+    bool failed = false;              // sticky: a one-shot all-reduce timed out; every later call of this communicator fails
+    long long timeout_ticks = 0;      // one-shot wait limit (100 MHz ticks)
+    hipStream_t last_stream = nullptr; bool have_stream = false; hipEvent_t order_ev = nullptr;   // the one-shot protocol needs its launches ordered: see peer_allreduce
     std::string err, path;
 };
 
@@ -265,6 +276,13 @@ rnde_status peers_attach(rnde_comm* c, rnde_comm_window* win, const uint8_t* han
         P->view.data[r] = (float*)((char*)base + kPeerDataOffset);
     }
     P->view.fail = (unsigned*)((char*)win->base + kPeerFlagBytes);     // (in the padding page behind the flags)
+    if (hipHostMalloc((void**)&P->fail_host, 64, hipHostMallocMapped) != hipSuccess) {
+        err = "pinned allocation failed";
+        for (int q = 0; q < c->world; ++q) if (P->mapped[q]) (void)hipIpcCloseMemHandle(P->mapped[q]);
+        delete P; return RNDE_ERR_HIP;
+    }
+    *P->fail_host = 0;
+    P->view.fail_host = P->fail_host;
     P->view.world = c->world; P->view.rank = c->rank;
     c->peer = P;
     c->path = std::string("one-shot over peer-mapped windows (") + win->kind + " device memory, hipIpc)";
@@ -272,8 +290,28 @@ rnde_status peers_attach(rnde_comm* c, rnde_comm_window* win, const uint8_t* han
     return RNDE_OK;
 }
 
+// "a one-shot all-reduce timed out" as text, with the limit that was in force
+std::string peer_timeout_message(const rnde_comm* c) {
+    char t[64];
+    snprintf(t, sizeof t, "%.3g s", (double)c->timeout_ticks / 1e8);
+    return std::string("one-shot all-reduce: a wait for a peer's chunk gave up after ") + t + " (every rank must make the same calls in the same order); the communicator is "
+           "failed for good, the buffers of that all-reduce and of every later one hold NaN";
+}
+
 rnde_status peer_allreduce(rnde_comm* c, float* buf, long long n, float scale, hipStream_t s) {
     static const long long ticks = getenv("RNDE_ONESHOT_TIMEOUT_MS") ? std::max(1LL, atoll(getenv("RNDE_ONESHOT_TIMEOUT_MS"))) * 100000 : kPeerTimeoutTicks;   // (tests)
+    c->timeout_ticks = ticks;
+    // sticky failure: a time-out of an EARLIER all-reduce (the kernel raised the pinned word) fails this and every later call -- the training
+    // loop meets it at its next enqueue, before another update is computed from poisoned gradients
+    if (c->failed || *(volatile unsigned*)c->peer->fail_host != 0u) { c->failed = true; c->err = peer_timeout_message(c); return RNDE_ERR_HIP; }
+    // The slot-reuse argument (a rank rewrites a slot at seq + 2 only after every peer has finished reading seq) holds when kernel seq + 1 of a
+    // rank cannot start before its kernel seq has finished: true inside one stream.  A call on ANOTHER stream is ordered behind the previous
+    // one with an event (the coupled controller enqueues on the node's stream, the gradient reducer on the caller's).
+    if (c->have_stream && c->last_stream != s) {
+        if (!c->order_ev && hipEventCreateWithFlags(&c->order_ev, hipEventDisableTiming) != hipSuccess) { c->err = "one-shot all-reduce: event creation failed"; return RNDE_ERR_HIP; }
+        if (hipEventRecord(c->order_ev, c->last_stream) != hipSuccess || hipStreamWaitEvent(s, c->order_ev, 0) != hipSuccess) { c->err = "one-shot all-reduce: cannot order the call behind the previous stream"; return RNDE_ERR_HIP; }
+    }
+    c->last_stream = s; c->have_stream = true;
     for (long long off = 0; off < n; off += kPeerCap) {
         const long long m = std::min<long long>(kPeerCap, n - off);
         const int G = (int)std::max<long long>(1, std::min<long long>(kPeerBlocks, (m + 1023) / 1024));
@@ -400,6 +438,8 @@ extern "C" void rnde_comm_destroy(rnde_comm* c) {
         (void)hipDeviceSynchronize();
         for (int r = 0; r < c->world; ++r) if (c->peer->mapped[r]) (void)hipIpcCloseMemHandle(c->peer->mapped[r]);
         (void)hipFree(c->peer->window);
+        if (c->peer->fail_host) (void)hipHostFree(c->peer->fail_host);
+        if (c->order_ev) (void)hipEventDestroy(c->order_ev);
         delete c->peer;
     }
     if (c->loc && --c->loc->refs == 0) {
@@ -418,7 +458,7 @@ extern "C" rnde_status rnde_comm_health(rnde_comm* c) {
     if (c && c->peer) {
         unsigned f = 0;
         if (hipSetDevice(c->device) != hipSuccess || hipMemcpy(&f, c->peer->view.fail, 4, hipMemcpyDeviceToHost) != hipSuccess) { c->err = "one-shot all-reduce: cannot read the window"; return RNDE_ERR_HIP; }
-        if (f) { c->err = "one-shot all-reduce: a wait for a peer's chunk gave up after 20 s (every rank must make the same calls in the same order)"; return RNDE_ERR_HIP; }
+        if (f || c->failed) { c->failed = true; if (!c->timeout_ticks) c->timeout_ticks = kPeerTimeoutTicks; c->err = peer_timeout_message(c); return RNDE_ERR_HIP; }
         return RNDE_OK;
     }
     if (!c || !c->loc) return RNDE_OK;

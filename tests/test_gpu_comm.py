@@ -145,8 +145,8 @@ def test_one_shot_allreduce_between_processes(world, mean, tmp_path):
         assert "one-shot" in o["path"]
 
 
-@pytest.mark.parametrize("coupled", [False, True])
-def test_bench_runs_two_ranks_on_one_gpu_through_the_one_shot_collective(coupled):
+@pytest.mark.parametrize("coupled,strong", [(False, False), (True, False), (False, True)])
+def test_bench_runs_two_ranks_on_one_gpu_through_the_one_shot_collective(coupled, strong):
     """The driver's N > 1 command line (torchrun, one process per rank, barrier + max-over-ranks timing, one gradient all-reduce per step)
     with `--share-gpu`: both ranks on device 0, torch.distributed on gloo, the gradient collective = the one-shot kernel over peer-mapped
     windows.  Checks the contract line and the `dist` diagnostics; the data-parallel numerics are the next test's."""
@@ -160,17 +160,19 @@ def test_bench_runs_two_ranks_on_one_gpu_through_the_one_shot_collective(coupled
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "64", "--share-gpu", "--no-cpu-baseline", "--no-extras"] + (["--coupled"] if coupled else [])
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "64", "--share-gpu", "--no-cpu-baseline", "--no-extras"] + (["--coupled"] if coupled else []) + (["--global-batch", "96"] if strong else [])
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=400, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     o = json.loads(line)
-    assert o["n_gpus"] == 2 and o["steps"] == 3 and o["scaling"] == "weak" and o["value"] > 0
+    assert o["n_gpus"] == 2 and o["steps"] == 3 and o["value"] > 0
+    # --global-batch G: strong scaling, the global batch is fixed and split over the ranks (48 per rank here); default: weak, --batch per rank
+    assert o["scaling"] == ("strong" if strong else "weak") and o["config"]["global_batch"] == (96 if strong else 128)
     d = o["dist"]
     assert "one-shot" in d["collective_path"] and d["allreduce_floats"] == 166418 and len(d["nfe_per_rank"]) == 2
     if coupled:     # one controller for both ranks (SURVEY 8e mode 2): the same accept / reject sequence, hence the same NFE, on every rank
         assert o["controller"].startswith("coupled") and d["nfe_per_rank"][0] == d["nfe_per_rank"][1]
-    assert d["persist_fallback_count_per_rank"] == [0, 0] or all(v >= 0 for v in d["persist_fallback_count_per_rank"])
+    assert d["persist_fallback_count_per_rank"] == [0, 0]      # (two ranks of 28 / 21 workgroups each share the 256 CUs: every persistent launch is resident)
     print(o["value"], d)
 
 
@@ -259,7 +261,7 @@ def test_data_parallel_steps_between_two_processes_equal_the_rank_order_sum():
 
 def test_one_shot_allreduce_reports_an_absent_rank(tmp_path):
     """A rank that never reaches the all-reduce: the waiting rank's kernel gives up (RNDE_ONESHOT_TIMEOUT_MS=300 here, 20 s by default),
-    the stream drains, and rnde_comm_health says what happened -- no hang, no silent garbage."""
+    the stream drains, and rnde_comm_health says what happened -- no hang, no silent garbage (NaN in the buffer, a sticky error at the next enqueue)."""
     import json
     import subprocess
     import sys
@@ -279,3 +281,6 @@ def test_one_shot_allreduce_reports_an_absent_rank(tmp_path):
                 p.kill()
     r0 = [o for o in outs if o["rank"] == 0][0]
     assert r0["enqueue"] == 0 and r0["health"] != 0 and "gave up" in r0["error"]
+    # (round-3 advisor finding) the failure must reach a training loop that never calls rnde_comm_health: the reduced buffer is NaN, not a
+    # partial sum, and the NEXT all-reduce of the communicator is refused -- on another stream too -- with the limit in force in the message
+    assert r0["nan_frac"] == 1.0 and r0["next_enqueue"] != 0 and "gave up after 0.3 s" in r0["next_error"] and "failed for good" in r0["next_error"]

@@ -57,8 +57,14 @@ def main():
             g = torch.ones(1000, device="cuda")
             st = L.rnde_comm_allreduce(comm, g.data_ptr(), 1000, 0, sp)
             stream.synchronize()
+            # what a training loop meets WITHOUT calling rnde_comm_health: the reduced buffer is poisoned, the next enqueue fails (sticky), on any stream
+            nan_frac = float(torch.isnan(g).float().mean())
+            g2 = torch.ones(1000, device="cuda")
+            st2 = L.rnde_comm_allreduce(comm, g2.data_ptr(), 1000, 0, None)
+            err2 = L.rnde_comm_last_error(comm).decode()
             health = L.rnde_comm_health(comm)
-            print(json.dumps({"rank": a.rank, "enqueue": st, "health": health, "error": L.rnde_comm_last_error(comm).decode()}), flush=True)
+            print(json.dumps({"rank": a.rank, "enqueue": st, "nan_frac": nan_frac, "next_enqueue": st2, "next_error": err2, "health": health,
+                              "error": L.rnde_comm_last_error(comm).decode()}), flush=True)
         else:
             time.sleep(3.0)      # keep the window mapped while the others wait
             print(json.dumps({"rank": a.rank, "absent": True}), flush=True)

@@ -428,6 +428,41 @@ rnde_status rnde_nsde_timing(rnde_nsde* h, float* solve_ms, float* rev_sweep_ms,
 /* Fill `n` floats with standard normals from (seed, stream_id): the library's own generator, exposed for its statistical test. */
 rnde_status rnde_normal_fill(float* out_dev, int64_t n, uint64_t seed, uint64_t stream_id, void* stream);
 
+/* ======================================================================================================================
+ * The latent-ODE caller of the hot path: recognition GRU, rec_to_gen + sampling, gen_to_data + masked likelihood
+ * + KL, and their reverse passes -- what surrounds the layer call in LatentTimeSeriesModel (reference src/models/time_series.jl:40-70)
+ * and loss_function (experiments/latent_ode.jl:206-236), at the reference's sizes: LatentGRU(37, 40, 50) (latent_ode.jl:39-106, :111),
+ * rec_to_gen = Chain(Dense(100, 50, tanh), Dense(50, 40)) (:112), gen_to_data = Dense(20, 37) (:148).  One training step is
+ *   rnde_latent_encode          x -> GRU over the time axis backwards (:99-106) -> rec_to_gen -> mu0, logvar, z0 = eps * exp(logvar / 2) + mu0
+ *   rnde_node_forward_saveat    the layer call on z0 (the hot path, above)                                  (time_series.jl:61)
+ *   rnde_latent_decode_loss     gen_to_data on every saved state, -mean(log_likelihood), mean(kl_divergence), and the reverse of the
+ *                               likelihood term: res-bar (the u_bar of rnde_node_backward) and p4-bar          (latent_ode.jl:192-204, :226-233)
+ *   rnde_node_backward          -> z0-bar
+ *   rnde_latent_encode_backward z0-bar and lambda_k * mean(KL) -> p1-bar (GRU), p2-bar (rec_to_gen)
+ * Layouts are Julia's: x is (2 * 37 + 1) x T x B = vcat(data, mask, dt) (latent_ode.jl:225), res is 20 x T x B, the parameter vectors are
+ * Flux.destructure's (time_series.jl:11-14).  eps is the caller's standard-normal sample, 20 x B (CUDA.randn, time_series.jl:58).
+ * All calls are asynchronous on `stream`; the handle keeps the tapes of ONE encode at a time.
+ * ====================================================================================================================== */
+typedef struct { int32_t max_batch, max_T, device; } rnde_latent_config;   /* max_T <= 64 save times */
+typedef struct rnde_latent rnde_latent;
+rnde_status rnde_latent_create(const rnde_latent_config* cfg, rnde_latent** out);
+void        rnde_latent_destroy(rnde_latent* h);
+const char* rnde_latent_last_error(const rnde_latent* h);      /* h may be NULL: last create error of this thread */
+void        rnde_latent_param_counts(int32_t* n_p1, int32_t* n_p2, int32_t* n_p4);      /* 29,320 / 7,090 / 777 */
+rnde_status rnde_latent_encode(rnde_latent* h, const float* x_dev, const float* p1_dev, const float* p2_dev, const float* eps_dev, int32_t B,
+                               int32_t T, float* z0_out_dev, float* mu0_out_dev, float* logvar_out_dev, void* stream);
+/* loss2_out_dev[0] = -mean_b(ll_b), [1] = mean_b(KL_b); res_bar_out_dev (20 x T x B) and p4_bar_out_dev (777) are the cotangents of term [0]. */
+rnde_status rnde_latent_decode_loss(rnde_latent* h, const float* res_dev, const float* p4_dev, const float* x_dev, int32_t B, int32_t T,
+                                    float* loss2_out_dev, float* res_bar_out_dev, float* p4_bar_out_dev, void* stream);
+/* z0_bar_dev: 20 x B from the layer's reverse pass; the KL term enters with weight lambda_k (latent_ode.jl:178, :232). */
+/* Flux.Optimise.Optimiser(InvDecay(gamma), AdaMax(eta, (beta1, beta2))) on one flat parameter group, in place (experiments/latent_ode.jl:108).
+ * m, u: the caller's state arrays (zeros at the first step); n: the InvDecay counter (1 at the first step); beta1_pow: Flux's running
+ * beta1^t (beta1 at the first step) -- the caller advances n and beta1_pow.  Asynchronous on `stream`. */
+rnde_status rnde_adamax_step(float* p_dev, const float* g_dev, float* m_dev, float* u_dev, int64_t len, int64_t n, float gamma, float eta, float beta1,
+                             float beta2, float eps, float beta1_pow, void* stream);
+rnde_status rnde_latent_encode_backward(rnde_latent* h, const float* z0_bar_dev, float lambda_k, const float* p1_dev, const float* p2_dev,
+                                        const float* x_dev, float* p1_bar_out_dev, float* p2_bar_out_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

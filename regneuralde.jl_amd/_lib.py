@@ -27,6 +27,10 @@ class NsdeConfig(C.Structure):
                 ("qoldinit", C.c_float), ("delta", C.c_float), ("generic", C.c_int32)]
 
 
+class LatentConfig(C.Structure):
+    _fields_ = [("max_batch", C.c_int32), ("max_T", C.c_int32), ("device", C.c_int32)]
+
+
 ODE_SOLVER = {"Tsit5": 0, "AutoTsit5": 0, "DP5": 1, "DOP853": 2}
 SDE_SOLVER = {"SOSRI": 0, "SRIW1": 1, "SOSRI2": 2}
 
@@ -138,6 +142,17 @@ def lib():
     L.rnde_nsde_debug_attempt.argtypes = [vp, vp, vp, i32, f, vp, vp, vp, vp, fp, vp]
     L.rnde_nsde_timing.argtypes = [vp, fp, fp, i32p, i32p]
     L.rnde_normal_fill.argtypes = [vp, C.c_int64, u64, u64, vp]
+    L.rnde_latent_create.argtypes = [C.POINTER(LatentConfig), C.POINTER(vp)]
+    L.rnde_latent_destroy.argtypes = [vp]
+    L.rnde_latent_destroy.restype = None
+    L.rnde_latent_last_error.argtypes = [vp]
+    L.rnde_latent_last_error.restype = C.c_char_p
+    L.rnde_latent_param_counts.argtypes = [i32p, i32p, i32p]
+    L.rnde_latent_param_counts.restype = None
+    L.rnde_latent_encode.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]
+    L.rnde_latent_decode_loss.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]
+    L.rnde_latent_encode_backward.argtypes = [vp, vp, f, vp, vp, vp, vp, vp, vp]
+    L.rnde_adamax_step.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_int64, f, f, f, f, f, f, vp]
     _lib = L
     return L
 
@@ -149,13 +164,19 @@ EXPORTS = ["rnde_version", "rnde_last_error", "rnde_param_count", "rnde_node_cre
            "rnde_node_launches_per_attempt", "rnde_node_one_launch_solves", "rnde_classifier_head", "rnde_node_classifier_grad", "rnde_momentum_step", "rnde_momentum_step_scaled", "rnde_adam_step",
            "rnde_comm_unique_id", "rnde_comm_create", "rnde_comm_destroy", "rnde_comm_world", "rnde_comm_last_error", "rnde_comm_library", "rnde_comm_allreduce", "rnde_comm_create_local_group", "rnde_comm_health", "rnde_comm_window_create", "rnde_comm_window_destroy", "rnde_comm_create_peers", "rnde_comm_path", "rnde_node_set_coupling", "rnde_has_column_owner", "rnde_tapes_create", "rnde_tapes_destroy", "rnde_tapes_last_error", "rnde_tapes_in_use", "rnde_tapes_node", "rnde_tapes_forward", "rnde_tapes_backward", "rnde_tapes_release",
            "rnde_nsde_param_count", "rnde_nsde_create", "rnde_nsde_destroy", "rnde_nsde_last_error", "rnde_nsde_forward",
-           "rnde_nsde_forward_saveat", "rnde_nsde_forward_replay", "rnde_nsde_backward", "rnde_nsde_backward_async", "rnde_nsde_classifier_head", "rnde_nsde_classifier_grad", "rnde_nsde_steps", "rnde_nsde_debug_attempt", "rnde_nsde_timing", "rnde_normal_fill"]
+           "rnde_nsde_forward_saveat", "rnde_nsde_forward_replay", "rnde_nsde_backward", "rnde_nsde_backward_async", "rnde_nsde_classifier_head", "rnde_nsde_classifier_grad", "rnde_nsde_steps", "rnde_nsde_debug_attempt", "rnde_nsde_timing", "rnde_normal_fill", "rnde_latent_create", "rnde_latent_destroy", "rnde_latent_last_error", "rnde_latent_param_counts", "rnde_latent_encode",
+           "rnde_latent_decode_loss", "rnde_latent_encode_backward", "rnde_adamax_step"]
 
 
 def check(h, status):
     if status != OK:
         msg = lib().rnde_last_error(h).decode() if h else lib().rnde_last_error(None).decode()
         raise RndeError(status, msg)
+
+
+def check_latent(h, status):
+    if status != OK:
+        raise RndeError(status, lib().rnde_latent_last_error(h if h else None).decode())
 
 
 def check_nsde(h, status):

@@ -1,0 +1,174 @@
+// rnde_latent.hip -- C ABI of the latent-ODE caller of the hot path (include/rnde.h: rnde_latent_*) over the kernels of rnde_latent.h.
+// No torch, no oracle, no CPU fallback.
+#include "../../include/rnde.h"
+#include "rnde_latent.h"
+
+#include <algorithm>
+#include <cmath>
+#include <string>
+
+using namespace rnde_lat;
+
+struct rnde_latent {
+    rnde_latent_config cfg{};
+    float *act = nullptr, *del = nullptr, *y = nullptr, *yb = nullptr, *h1 = nullptr, *out = nullptr, *d1 = nullptr, *d2 = nullptr;
+    float *kl = nullptr, *ll = nullptr, *gD = nullptr, *slab = nullptr, *eps = nullptr;
+    int B = 0, T = 0;
+    bool encoded = false;
+    std::string err;
+};
+static thread_local std::string g_latent_err;
+
+#define LCHK(h, call)                                                                                   \
+    do {                                                                                                \
+        hipError_t e__ = (call);                                                                        \
+        if (e__ != hipSuccess) { (h)->err = std::string(#call) + ": " + hipGetErrorString(e__); return RNDE_ERR_HIP; } \
+    } while (0)
+
+extern "C" const char* rnde_latent_last_error(const rnde_latent* h) { return h ? h->err.c_str() : g_latent_err.c_str(); }
+extern "C" void rnde_latent_param_counts(int32_t* n_p1, int32_t* n_p2, int32_t* n_p4) {
+    if (n_p1) *n_p1 = kP1;
+    if (n_p2) *n_p2 = kP2;
+    if (n_p4) *n_p4 = kP4;
+}
+
+extern "C" rnde_status rnde_latent_create(const rnde_latent_config* c, rnde_latent** out) {
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= c->device) { g_latent_err = "no HIP device"; return RNDE_ERR_NO_DEVICE; }
+    if (c->max_batch < 1 || c->max_T < 1 || c->max_T > 64) { g_latent_err = "max_batch >= 1, 1 <= max_T <= 64 (one thread per save time in the likelihood kernel)"; return RNDE_ERR_BAD_ARG; }
+    if (hipSetDevice(c->device) != hipSuccess) { g_latent_err = "hipSetDevice failed"; return RNDE_ERR_HIP; }
+    rnde_latent* h = new rnde_latent();
+    h->cfg = *c;
+    const size_t S = (size_t)c->max_batch * c->max_T, B = c->max_batch;
+    bool ok = hipMalloc((void**)&h->act, S * kActLd * 4) == hipSuccess && hipMalloc((void**)&h->del, S * kDelLd * 4) == hipSuccess &&
+              hipMalloc((void**)&h->y, B * 2 * kL * 4) == hipSuccess && hipMalloc((void**)&h->yb, B * 2 * kL * 4) == hipSuccess &&
+              hipMalloc((void**)&h->h1, B * kRec * 4) == hipSuccess && hipMalloc((void**)&h->out, B * 2 * kLat * 4) == hipSuccess &&
+              hipMalloc((void**)&h->d1, B * kRec * 4) == hipSuccess && hipMalloc((void**)&h->d2, B * 2 * kLat * 4) == hipSuccess &&
+              hipMalloc((void**)&h->kl, B * 4) == hipSuccess && hipMalloc((void**)&h->ll, B * 4) == hipSuccess &&
+              hipMalloc((void**)&h->gD, S * 40 * 4) == hipSuccess && hipMalloc((void**)&h->eps, B * kLat * 4) == hipSuccess &&
+              hipMalloc((void**)&h->slab, ((S + kWgChunk * kWgSub - 1) / (kWgChunk * kWgSub)) * (size_t)(3 * (kNIn + 1) * kH + 2 * (kH + 1) * kL + (kH + 1) * 2 * kL) * 4) == hipSuccess;      // the six GRU jobs side by side
+    if (!ok) { g_latent_err = "device allocation failed"; rnde_latent_destroy(h); return RNDE_ERR_HIP; }
+    *out = h;
+    return RNDE_OK;
+}
+extern "C" void rnde_latent_destroy(rnde_latent* h) {
+    if (!h) return;
+    for (float* p : {h->act, h->del, h->y, h->yb, h->h1, h->out, h->d1, h->d2, h->kl, h->ll, h->gD, h->slab, h->eps}) if (p) (void)hipFree(p);
+    delete h;
+}
+
+static rnde_status check_shape(rnde_latent* h, int B, int T) {
+    if (!h) return RNDE_ERR_BAD_ARG;
+    if (B < 1 || B > h->cfg.max_batch || T < 1 || T > h->cfg.max_T) { h->err = "B or T outside the handle's limits"; return RNDE_ERR_BAD_ARG; }
+    if (hipSetDevice(h->cfg.device) != hipSuccess) { h->err = "hipSetDevice failed"; return RNDE_ERR_HIP; }
+    return RNDE_OK;
+}
+
+// out (M x (N + 1), Flux layout [vec(W); b]) = sum over K samples of delta^T [act, 1]: a batch of such jobs as two launches (partials, reduction)
+struct JobList {
+    WgradJobs jj{};
+    size_t slab_used = 0;
+    void add(rnde_latent* h, const float* delta, int ld_d, int M, const float* act, int ld_a, int N, int K, float* out, int m_split = 1 << 30, int m_gap = 0) {
+        const int groups = (K + kWgChunk * kWgSub - 1) / (kWgChunk * kWgSub);
+        jj.j[jj.n++] = WgradJob{delta, act, h->slab + slab_used, out, ld_d, ld_a, M, N, K, m_split, m_gap};
+        slab_used += (size_t)groups * (N + 1) * M;
+    }
+};
+static rnde_status run_jobs(rnde_latent* h, const JobList& Jl, hipStream_t s) {
+    int gmax = 0, lmax = 0; size_t lds = 0;
+    for (int i = 0; i < Jl.jj.n; ++i) {
+        const WgradJob& J = Jl.jj.j[i];
+        gmax = std::max(gmax, (J.K + kWgChunk * kWgSub - 1) / (kWgChunk * kWgSub));
+        lmax = std::max(lmax, (J.N + 1) * J.M);
+        lds = std::max(lds, sizeof(float) * kWgChunk * (size_t)(((J.M + 15) & ~15) + ((J.N + 1 + 15) & ~15)));
+    }
+    hipLaunchKernelGGL(rnde_latent_wgrad_kernel, dim3(gmax, Jl.jj.n), dim3(256), lds, s, Jl.jj);
+    hipLaunchKernelGGL(rnde_latent_reduce_kernel, dim3((lmax + 255) / 256, Jl.jj.n), dim3(256), 0, s, Jl.jj);
+    LCHK(h, hipGetLastError());
+    return RNDE_OK;
+}
+
+extern "C" rnde_status rnde_latent_encode(rnde_latent* h, const float* x_dev, const float* p1_dev, const float* p2_dev, const float* eps_dev, int32_t B,
+                                          int32_t T, float* z0_out_dev, float* mu0_out_dev, float* logvar_out_dev, void* stream) {
+    rnde_status st = check_shape(h, B, T);
+    if (st != RNDE_OK) return st;
+    if (!x_dev || !p1_dev || !p2_dev || !eps_dev || !z0_out_dev || !mu0_out_dev || !logvar_out_dev) { h->err = "null pointer"; return RNDE_ERR_BAD_ARG; }
+    hipStream_t s = (hipStream_t)stream;
+    h->B = B; h->T = T; h->encoded = false;
+    GruParams G{x_dev, p1_dev, h->act, h->del, h->y, B, T};
+    const size_t lds = sizeof(float) * (31 * 256 + (size_t)T * 16);
+    hipLaunchKernelGGL(rnde_latent_gru_fwd_kernel, dim3((B + 15) / 16), dim3(512), lds, s, G);
+    LCHK(h, hipGetLastError());
+    LCHK(h, hipMemcpyAsync(h->eps, eps_dev, (size_t)B * kLat * 4, hipMemcpyDeviceToDevice, s));      // the tape owns its copy of the sample
+    EncParams E{h->y, p2_dev, h->eps, h->h1, h->out, z0_out_dev, mu0_out_dev, logvar_out_dev, h->kl, B};
+    hipLaunchKernelGGL(rnde_latent_enc_fwd_kernel, dim3(B), dim3(64), 0, s, E);
+    LCHK(h, hipGetLastError());
+    h->encoded = true;
+    return RNDE_OK;
+}
+
+extern "C" rnde_status rnde_latent_decode_loss(rnde_latent* h, const float* res_dev, const float* p4_dev, const float* x_dev, int32_t B, int32_t T,
+                                               float* loss2_out_dev, float* res_bar_out_dev, float* p4_bar_out_dev, void* stream) {
+    rnde_status st = check_shape(h, B, T);
+    if (st != RNDE_OK) return st;
+    if (!h->encoded || B != h->B || T != h->T) { h->err = "decode_loss follows rnde_latent_encode of the same batch (the KL term comes from it)"; return RNDE_ERR_NO_TAPE; }
+    if (!res_dev || !p4_dev || !x_dev || !loss2_out_dev || !res_bar_out_dev || !p4_bar_out_dev) { h->err = "null pointer"; return RNDE_ERR_BAD_ARG; }
+    hipStream_t s = (hipStream_t)stream;
+    const float sigma = 0.01f;      // latent_ode.jl:196
+    DecParams D{res_dev, p4_dev, x_dev, h->gD, res_bar_out_dev, h->ll, B, T, 1.0f / (sigma * sigma), -logf(sigma) - 0.5f * logf(2.0f * 3.14159265358979323846f)};
+    hipLaunchKernelGGL(rnde_latent_dec_loss_kernel, dim3(B), dim3(64), 0, s, D);
+    hipLaunchKernelGGL(rnde_latent_loss_kernel, dim3(1), dim3(256), 0, s, h->ll, h->kl, B, loss2_out_dev);
+    LCHK(h, hipGetLastError());
+    JobList Jl;
+    Jl.add(h, h->gD, 40, kIn, res_dev, kLat, kLat, B * T, p4_bar_out_dev);      // gen_to_data: [vec(W4) (37 x 20); b4]
+    return run_jobs(h, Jl, s);
+}
+
+extern "C" rnde_status rnde_latent_encode_backward(rnde_latent* h, const float* z0_bar_dev, float lambda_k, const float* p1_dev, const float* p2_dev,
+                                                   const float* x_dev, float* p1_bar_out_dev, float* p2_bar_out_dev, void* stream) {
+    if (!h) return RNDE_ERR_BAD_ARG;
+    if (!h->encoded) { h->err = "encode_backward without rnde_latent_encode"; return RNDE_ERR_NO_TAPE; }
+    if (!z0_bar_dev || !p1_dev || !p2_dev || !x_dev || !p1_bar_out_dev || !p2_bar_out_dev) { h->err = "null pointer"; return RNDE_ERR_BAD_ARG; }
+    if (hipSetDevice(h->cfg.device) != hipSuccess) { h->err = "hipSetDevice failed"; return RNDE_ERR_HIP; }
+    hipStream_t s = (hipStream_t)stream;
+    const int B = h->B, T = h->T, K = B * T;
+    EncBwdParams E{z0_bar_dev, p2_dev, h->eps, h->h1, h->out, h->d2, h->d1, h->yb, lambda_k / (float)B, B};
+    hipLaunchKernelGGL(rnde_latent_enc_bwd_kernel, dim3(B), dim3(128), 0, s, E);
+    LCHK(h, hipGetLastError());
+    // rec_to_gen: Dense(100, 50, tanh) [W1; b1] then Dense(50, 40) [W2; b2]
+    JobList Je;
+    Je.add(h, h->d1, kRec, kRec, h->y, 2 * kL, 2 * kL, B, p2_bar_out_dev);
+    Je.add(h, h->d2, 2 * kLat, 2 * kLat, h->h1, kRec, kRec, B, p2_bar_out_dev + 2 * kL * kRec + kRec);
+    rnde_status st = run_jobs(h, Je, s);
+    if (st != RNDE_OK) return st;
+    GruParams G{x_dev, p1_dev, h->act, h->del, h->yb, B, T};
+    const size_t lds = sizeof(float) * (23 * 256 + (size_t)T * 16);
+    hipLaunchKernelGGL(rnde_latent_gru_bwd_kernel, dim3((B + 15) / 16), dim3(512), lds, s, G);
+    LCHK(h, hipGetLastError());
+    // the six Dense layers of the GRU, in Flux.destructure order: update_gate (Wu1, Wu2), reset_gate (Wr1, Wr2), new_state (Wn1, Wn2): one launch
+    float* g = p1_bar_out_dev;
+    JobList Jg;
+    Jg.add(h, h->del + dZU, kDelLd, kH, h->act + aYC, kActLd, kNIn, K, g + oWu1);
+    Jg.add(h, h->del + dAU, kDelLd, kL, h->act + aU1, kActLd, kH, K, g + oWu2);
+    Jg.add(h, h->del + dZR, kDelLd, kH, h->act + aYC, kActLd, kNIn, K, g + oWr1);
+    Jg.add(h, h->del + dAR, kDelLd, kL, h->act + aR1, kActLd, kH, K, g + oWr2);
+    Jg.add(h, h->del + dZN, kDelLd, kH, h->act + aCC, kActLd, kNIn, K, g + oWn1);
+    Jg.add(h, h->del + dNS, kDelLd, 2 * kL, h->act + aN1, kActLd, kH, K, g + oWn2, kL, 2);
+    if ((st = run_jobs(h, Jg, s)) != RNDE_OK) return st;
+    h->encoded = false;
+    return RNDE_OK;
+}
+
+// Optimiser(InvDecay(gamma), AdaMax(eta, (beta1, beta2))) step of one flat parameter group (reference experiments/latent_ode.jl:108).
+// n: the group's InvDecay counter (1 at the first step), beta1_pow: beta1^t of Flux's running state (beta1 at the first step); the caller
+// advances both.  Asynchronous on `stream`.
+extern "C" rnde_status rnde_adamax_step(float* p_dev, const float* g_dev, float* m_dev, float* u_dev, int64_t len, int64_t n, float gamma, float eta,
+                                        float beta1, float beta2, float eps, float beta1_pow, void* stream) {
+    if (!p_dev || !g_dev || !m_dev || !u_dev || len < 0 || !(beta1_pow < 1.f)) return RNDE_ERR_BAD_ARG;
+    if (len == 0) return RNDE_OK;
+    const unsigned blocks = (unsigned)((len + 255) / 256 > 1024 ? 1024 : (len + 255) / 256);
+    hipLaunchKernelGGL(rnde_adamax_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p_dev, g_dev, m_dev, u_dev, (long long)len,
+                       1.0f / (1.0f + gamma * (float)n), eta / (1.0f - beta1_pow), beta1, beta2, eps);
+    return hipGetLastError() == hipSuccess ? RNDE_OK : RNDE_ERR_HIP;
+}

@@ -7,9 +7,10 @@ log_likelihood, kl_divergence,
 loss_function, sample_tbounds    reference experiments/latent_ode.jl:188-269
 Optimiser(InvDecay, AdaMax)      reference experiments/latent_ode.jl:108
 
-Only the node (gen_dynamics integrated by Tsit5 with `saveat`, latent_ode.jl:137-147) is the hot path: it runs in librnde.so
-(chain engine) forward and reverse.  The recognition GRU, the two small Dense stacks and the likelihood are a few dozen tiny
-PyTorch ops per step around it -- the same split as ClassifierNODE (classifier.py).
+The node (gen_dynamics integrated by Tsit5 with `saveat`, latent_ode.jl:137-147) is the hot path: it runs in librnde.so (chain
+engine) forward and reverse.  Round 4: the recognition GRU, the two small Dense stacks, the likelihood and the KL term run there too
+(`fused_latent_loss_and_grad`, include/rnde.h: rnde_latent_*: one launch for the 49 recurrent steps, one for their reverse);
+the torch formulas below stay as the autograd form of the same model (and as the cross-check of the device path in the tests).
 
 Layouts: a Julia `F x T x B` array is a torch tensor of shape (B, T, F); flat parameter vectors are what Flux.destructure
 returns for the corresponding struct (fields in declaration order, each Dense as [vec(W) column-major (out x in); b]).
@@ -187,6 +188,17 @@ class FluxAdaMax:
             g = p.grad if grads is None else grads[i]
             if g is None:
                 continue
+            if p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and g.is_contiguous():      # one launch per group (rnde_adamax_step)
+                import ctypes as C
+                from . import _lib
+                st = _lib.lib().rnde_adamax_step(p.data_ptr(), g.data_ptr(), self.m[i].data_ptr(), self.u[i].data_ptr(), p.numel(), self.n[i], self.gamma,
+                                                 self.eta, b1, b2, self.eps, self.bp[i], C.c_void_p(torch.cuda.current_stream(p.device).cuda_stream))
+                if st != 0:
+                    raise _lib.RndeError(st, "rnde_adamax_step")
+                self.n[i] += 1
+                self.bp[i] *= b1
+                p.grad = None
+                continue
             g = g / (1.0 + self.gamma * self.n[i])                       # InvDecay
             self.n[i] += 1
             self.m[i].mul_(b1).add_(g, alpha=1 - b1)
@@ -209,3 +221,88 @@ def build_latent_ode(in_dim=37, h_dim=40, rec_dim=50, latent=20, hidden=50, dept
     node = TrackedNeuralODE(dyn, [0.0, 1.0], False, regularize, "Tsit5", saveat=saveat, **kw)
     dec = Dense(latent, in_dim, "identity", generator)
     return LatentTimeSeriesModel(rnn, enc, node, dec, device=device)
+
+
+class _LatentHandle:
+    def __init__(self, max_batch, max_T, device_index):
+        import ctypes as C
+        from . import _lib
+        self.L = _lib.lib()
+        self.ptr = C.c_void_p()
+        cfg = _lib.LatentConfig(max_batch=max_batch, max_T=max_T, device=device_index)
+        _lib.check_latent(None, self.L.rnde_latent_create(C.byref(cfg), C.byref(self.ptr)))
+        self.max_batch, self.max_T = max_batch, max_T
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self.L.rnde_latent_destroy(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def fused_latent_loss_and_grad(model, data, mask, t_row, lam_r=1.0e2, lam_k=1.0, regularize=True, saveat=None, generator=None, eps=None):
+    """One training-step gradient of the latent-ODE model WITHOUT a tape library in the loop: every piece of
+    loss_function (experiments/latent_ode.jl:206-236) and of its reverse runs in librnde.so --
+
+        rnde_latent_encode          recognition GRU (49 steps, one launch), rec_to_gen, z0 = eps * exp(logvar / 2) + mu0, KL
+        rnde_node_forward_saveat    the layer call (the hot path; taped)
+        rnde_latent_decode_loss     gen_to_data, masked likelihood, their reverse
+        rnde_node_backward_async    reverse sweep of the solve
+        rnde_latent_encode_backward reverse of rec_to_gen and of the GRU (one launch) + the weight-gradient GEMMs
+
+    Same loss surface as `latent_loss_function` (agg = mean, func = error_est).  Sets .grad on (p1, p2, p3, p4); returns
+    (total, nll, kl, reg, nfe) -- total / nll / kl as device tensors (nothing but the solver's step log is read on the host).
+    data, mask: (B, T, in_dim); t_row: (B, T, 1).  eps: the standard-normal sample (B, latent) (default: drawn here, CUDA.randn of time_series.jl:58)."""
+    import ctypes as C
+    from . import _lib
+    L = _lib.lib()
+    dev = data.device
+    B, T, _ = data.shape
+    x_ = torch.cat([data, mask, t_row], dim=2).to(torch.float32).contiguous()
+    node = model.node
+    lat = 20                                     # latent state rows (latent_ode.jl:112-124); the kernels are built for the reference's sizes
+    hl = getattr(model, "_latent_handle", None)
+    if hl is None or hl.max_batch < B or hl.max_T < T:
+        hl = model._latent_handle = _LatentHandle(max(B, getattr(hl, "max_batch", 0) if hl else 0), max(T, getattr(hl, "max_T", 0) if hl else 0), dev.index or 0)
+    if eps is None:
+        eps = torch.randn(B, lat, dtype=torch.float32, device=dev, generator=generator)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    p1, p2, p3, p4 = (p.detach() for p in model.trainable())
+    z0 = torch.empty(B, lat, dtype=torch.float32, device=dev)
+    mu0, logvar = torch.empty_like(z0), torch.empty_like(z0)
+    _lib.check_latent(hl.ptr, L.rnde_latent_encode(hl.ptr, x_.data_ptr(), p1.data_ptr(), p2.data_ptr(), eps.contiguous().data_ptr(), B, T,
+                                                   z0.data_ptr(), mu0.data_ptr(), logvar.data_ptr(), stream))
+    # the layer call on z0 (time_series.jl:61): forward with saveat, taped
+    grid = node._saveat_times(node.kwargs["saveat"] if saveat is None else saveat, node.tspan)      # update_saveat!, neural_ode.jl:35-46
+    if len(grid) != T:
+        raise ValueError("one save time per observation time (latent_ode.jl:137)")
+    node._func = "error_est" if node.regularize else None
+    hn = node._acquire(z0, True)
+    res = torch.empty(B, T, lat, dtype=torch.float32, device=dev)
+    sa = (C.c_float * T)(*grid)
+    sv_host = (C.c_float * (node.max_attempts + 1))()
+    nfe, nsv = C.c_int64(0), C.c_int32(0)
+    _lib.check(hn.ptr, L.rnde_node_forward_saveat(hn.ptr, z0.data_ptr(), p3.data_ptr(), B, node.tspan[0], node.tspan[1], sa, T, res.data_ptr(),
+                                                  C.byref(nfe), sv_host, C.byref(nsv), 1, stream))
+    loss2 = torch.empty(2, dtype=torch.float32, device=dev)
+    resb = torch.empty_like(res)
+    p4bar = torch.empty_like(p4)
+    _lib.check_latent(hl.ptr, L.rnde_latent_decode_loss(hl.ptr, res.data_ptr(), p4.data_ptr(), x_.data_ptr(), B, T, loss2.data_ptr(), resb.data_ptr(),
+                                                       p4bar.data_ptr(), stream))
+    n = nsv.value
+    reg = 0.0
+    svb = None
+    if regularize and node.regularize and n > 0:
+        reg = lam_r * sum(sv_host[i] for i in range(n)) / n                 # lam_r * mean(sv.saveval), latent_ode.jl:233
+        svb = (C.c_float * n)(*([lam_r / n] * n))
+    z0bar, p3bar = torch.empty_like(z0), torch.empty_like(p3)
+    _lib.check(hn.ptr, L.rnde_node_backward_async(hn.ptr, resb.data_ptr(), svb, z0bar.data_ptr(), p3bar.data_ptr(), None, stream))
+    p1bar, p2bar = torch.empty_like(p1), torch.empty_like(p2)
+    _lib.check_latent(hl.ptr, L.rnde_latent_encode_backward(hl.ptr, z0bar.data_ptr(), float(lam_k), p1.data_ptr(), p2.data_ptr(), x_.data_ptr(),
+                                                           p1bar.data_ptr(), p2bar.data_ptr(), stream))
+    model.p1.grad, model.p2.grad, model.p3.grad, model.p4.grad = p1bar, p2bar, p3bar, p4bar
+    node.last_nfe = int(nfe.value)
+    nll, kl = loss2[0], lam_k * loss2[1]
+    return nll + kl + reg, nll, kl, reg, int(nfe.value)

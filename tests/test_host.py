@@ -213,3 +213,56 @@ def test_shard_columns_equal_shards_for_the_coupled_controller():
     assert [shard_columns(x, r, 5, equal=True).shape[0] for r in range(5)] == [2] * 5
     with pytest.raises(ValueError):
         shard_columns(x, 0, 4, equal=True)
+
+
+def test_latent_oracle_gradients_match_finite_differences():
+    """oracle/latent_oracle.py (the fp64 numpy restatement of LatentGRU, rec_to_gen + sampling, gen_to_data + the masked likelihood and KL,
+    reference experiments/latent_ode.jl:39-106, :192-204, src/models/time_series.jl:40-70) is what the HIP kernels of the latent-ODE caller are
+    checked against: its hand-written reverse passes are pinned here by central differences of the scalar loss in fp64 (1e-6 relative), and its
+    forward against the torch mirror of the same formulas (regneuralde.jl_amd/timeseries.py)."""
+    import torch
+    from oracle import latent_oracle as lo
+    import regneuralde_jl_amd as rn
+    from regneuralde_jl_amd import timeseries as ts
+    rng = np.random.default_rng(3)
+    B, T = 5, 6
+    S = lo.GruShape(4, 6, 5)                      # small shapes: in_dim 4 (9 input rows), h 6, latent 5
+    x = rng.standard_normal((B, T, S.nx))
+    x[:, :, 4:8] = (rng.uniform(size=(B, T, 4)) < 0.4)          # mask rows 0 / 1; some steps unobserved
+    x[:, 2, 4:] = 0.0                                              # a step whose mask AND time rows are zero: the state passes through
+    p1 = 0.4 * rng.standard_normal(S.n_params())
+    p2 = 0.4 * rng.standard_normal(10 * 7 + 7 + 7 * 6 + 6)       # rec_to_gen: Dense(10, 7, tanh) -> Dense(7, 6): latent 3
+    p4 = 0.4 * rng.standard_normal(3 * 4 + 4)                    # gen_to_data: Dense(3, 4)
+    eps = rng.standard_normal((B, 3))
+    data = rng.standard_normal((B, T, 4)); mask = x[:, :, 4:8].copy(); mask[:, 0, 0] = 1.0
+    Wz = 0.3 * rng.standard_normal((3, T * 3))                   # a stand-in for the solve: res = tanh(z0 Wz), linear enough to differentiate by hand
+
+    def total(p1, p2, p4):
+        y, tape1 = lo.gru_forward(S, p1, x)
+        z0, mu0, lv, tape2 = lo.encode_forward(p2, y, eps, rec=7, latent=3)
+        res = np.tanh(z0 @ Wz).reshape(B, T, 3)
+        nll, resb, p4b, _ = lo.decode_loss(p4, res, data, mask)
+        loss = nll + 0.7 * lo.kl_per_sample(mu0, lv).mean()
+        return loss, (tape1, tape2, res, resb, p4b)
+
+    loss, (tape1, tape2, res, resb, p4b) = total(p1, p2, p4)
+    z0b = ((resb.reshape(B, -1) * (1 - res.reshape(B, -1) ** 2)) @ Wz.T)
+    yb, p2b = lo.encode_backward(p2, tape2, z0b, 0.7 / B, rec=7, latent=3)
+    p1b = lo.gru_backward(S, p1, tape1, yb)
+    for (vec, grad, which) in ((p1, p1b, 0), (p2, p2b, 1), (p4, p4b, 2)):
+        for i in rng.choice(len(vec), 12, replace=False):
+            h = 1e-6
+            a = [p1.copy(), p2.copy(), p4.copy()]; a[which][i] += h
+            b = [p1.copy(), p2.copy(), p4.copy()]; b[which][i] -= h
+            fd = (total(*a)[0] - total(*b)[0]) / (2 * h)
+            assert abs(fd - grad[i]) <= 1e-6 * max(1.0, abs(fd)) + 2e-8, (which, i, fd, grad[i])
+    # forward against the torch mirror (same formulas, written independently for round 2)
+    g = torch.Generator().manual_seed(0)
+    gru = ts.LatentGRU(4, 6, 5, g)
+    y_t = gru(torch.from_numpy(p1), torch.from_numpy(x))
+    assert np.abs(y_t.numpy() - lo.gru_forward(S, p1, x)[0]).max() <= 1e-12
+    pred = rng.standard_normal(data.shape)
+    ll_t = ts.log_likelihood(torch.from_numpy(pred * mask - data * mask), torch.from_numpy(mask))
+    d = pred * mask - data * mask
+    ll_o = (-(d * d) / (2 * lo.SIGMA ** 2) - np.log(lo.SIGMA) - np.log(2 * np.pi) / 2).sum(axis=(1, 2)) / mask.sum(axis=(1, 2))
+    assert np.abs(ll_t.numpy() - ll_o).max() <= 1e-9 * np.abs(ll_o).max()

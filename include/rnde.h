@@ -75,7 +75,7 @@ typedef struct {
     int32_t track_initdt;  /* 1: reverse pass differentiates the initial-step heuristic */
     int32_t max_attempts;  /* tape capacity in attempted steps */
     int32_t device;        /* HIP device ordinal */
-    int32_t col_tile;      /* 0 = auto; MNIST form: 16 (stage engine, default), 4 / 8 (column-owner engine); small-width chains:
+    int32_t col_tile;      /* 0 = auto; MNIST form: 16 (stage engine, the only engine of that form since round 4); small-width chains:
                             * 64 (chain engine: 16 columns per wave) */
     /* tuning (0 = default everywhere, so a zero-initialised tail keeps the defaults) */
     int32_t persist;        /* stage engine: 0 = one launch per attempted step where the shape allows, -1 = always the 7-launch kernels */
@@ -191,9 +191,6 @@ int32_t     rnde_node_launches_per_attempt(const rnde_node* h);
  * rnde_stage_solve_kernel for the MNIST form at <= 512 columns, MW_SOLVE for the Dense-chain and SDE engines) -- the launch that replaces
  * the body of `solve(prob, Tsit5(); ...)`, reference src/models/neural_ode.jl:131-137.  bench.py's roofline bookkeeping and the tests. */
 int32_t     rnde_node_one_launch_solves(const rnde_node* h);
-/* 1 if this build contains the column-owner engine's own step kernels (col_tile 4 / 8; -DRNDE_WITH_COLUMN_OWNER), 0 otherwise: the
- * default build leaves them out (nothing selects them automatically; rnde_node_create then refuses col_tile 4 / 8). */
-int32_t     rnde_has_column_owner(void);
 
 /* ======================================================================================================================
  * Several taped forwards alive at once behind one handle (the `tape_id` form of SURVEY.md 8b).  An rnde_node holds ONE tape; the

@@ -17,7 +17,7 @@ def _headers():
 
 def _flag_stamp():
     """The compile-time switches a build was made with (a variant left in place by an A/B run must not pass for the default build)."""
-    return "RNDE_WITH_COLUMN_OWNER=%s RNDE_EXTRA_FLAGS=%s" % (os.environ.get("RNDE_WITH_COLUMN_OWNER", ""), os.environ.get("RNDE_EXTRA_FLAGS", ""))
+    return "RNDE_EXTRA_FLAGS=%s" % os.environ.get("RNDE_EXTRA_FLAGS", "")
 
 
 def needs_build():
@@ -38,8 +38,6 @@ def build(force=False, verbose=False):
     os.makedirs(objdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-undefined-internal"]
-    if os.environ.get("RNDE_WITH_COLUMN_OWNER") == "1":      # the round-1 engine's own step kernels (col_tile 4 / 8): optional, see rnde.hip
-        flags.append("-DRNDE_WITH_COLUMN_OWNER")
     flags += os.environ.get("RNDE_EXTRA_FLAGS", "").split()      # compile-time A/B switches (tools/ab_build.sh)
     import re
 

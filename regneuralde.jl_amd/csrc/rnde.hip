@@ -44,11 +44,8 @@ using namespace rnde;
 
 struct rnde_node {
     rnde_node_config cfg{};
-    int D = 0, H = 0, P = 0, NG = 2, BT = 8, act2 = 1;
-    int K4_1 = 0, KS1 = 0, MT1 = 0, K4_2 = 0, KS2 = 0, MT2 = 0;  // forward GEMM geometry
-    int K4_1t = 0, MT1t = 0, K4_2t = 0, MT2t = 0;                // reverse GEMM geometry
+    int D = 0, H = 0, P = 0, BT = 8, act2 = 1;
     int Bpad_max = 0, nwg_max = 0;
-    size_t lds_bytes = 0;
     // stage engine (rnde_stage.h)
     int engine = 1;                       // 1 column-owner, 2 stage kernels, 3 chain engine (rnde_chain.h)
     ChainGeo cg{}; float* cfrags = nullptr; int NKD = 0, chain_alt = 0;
@@ -76,7 +73,6 @@ struct rnde_node {
     float* replay_dev = nullptr; size_t replay_cap = 0; const float* replay_host = nullptr; int n_replay = 0;   // rnde_node_forward_replay (set for one forward)
     // persistent attempt kernel (rnde_stage_persist.h): 1 = in use, 0 = off (RNDE_PERSIST=0), -1 = disabled after a failure
     int wgrad_side_pct = 30, stage_generic = 0;
-    int binit_stage = 1;   // reverse of the initial-step rule on the stage engine (rnde_binit_stage.h); 0: the column-owner kernels (RNDE_BINIT_STAGE=0)
     int persist_clean = 0, persist_retry_after = 8, persist_fallbacks = 0;   // non-sticky fallback: clean multi-launch solves since the last failure, when to try again   // fixed at creation (config fields; RNDE_* environment overrides are read once, there)
     int wide = 0;        // one workgroup per column tile for all rows (rnde_stage_wide.h): 1 = use it (RNDE_WIDE=1 at creation; an experiment, not selected automatically)
     int persist2 = -1;   // two column tiles per workgroup in the forward attempt kernel: -1 automatic (by tile count), 0 never, 1 whenever possible (RNDE_PERSIST2, read at creation)
@@ -89,7 +85,6 @@ struct rnde_node {
     float *f0 = nullptr, *h0 = nullptr, *u1 = nullptr, *f1 = nullptr, *h1 = nullptr, *arena = nullptr;
     float* xcopy = nullptr;  // private copy of x (the tape must not alias caller memory)
     long long arena_recs = 0, rec_stride = 0;
-    f32x4 *pw1 = nullptr, *pw2 = nullptr, *pw1t = nullptr, *pw2t = nullptr;
     float* pcopy = nullptr;
     StepState *ctl = nullptr, *ctl_final = nullptr;
     unsigned char *mbox = nullptr, *h_mbox = nullptr; size_t mbox_meta_off = 0;   // stage engine: everything the host reads per chunk, contiguous (one copy)
@@ -142,13 +137,11 @@ static StepParams make_params(rnde_node* h, const float* x, int B, float t0, flo
     P.x = x;
     P.f0 = h->f0; P.h0 = h->h0; P.u1 = h->u1; P.f1 = h->f1; P.h1 = h->h1;
     P.arena = h->arena; P.rec_stride = h->rec_stride;
-    P.pw1 = h->pw1; P.pw2 = h->pw2;
     P.ctl = h->ctl; P.ctl_final = h->ctl_final; P.meta = h->meta; P.initrec = h->initrec;
     P.errpart = h->errpart; P.initpart = h->initpart; P.dbg_out = nullptr;
     P.D = h->D; P.H = h->H; P.B = B; P.Bn = h->couple ? h->couple_batch : B;
     P.Bpad = ((B + 15) / 16) * 16;   // both engines pad the batch to 16 columns (one tape format)
     P.nwg = h->engine == 2 ? h->sR * (P.Bpad / 16) : (h->engine == 3 ? (h->mw ? P.Bpad / 16 : (P.Bpad / 16 + kCW - 1) / kCW) : P.Bpad / h->BT);
-    P.K4_1 = h->K4_1; P.KS1 = h->KS1; P.MT1 = h->MT1; P.K4_2 = h->K4_2; P.KS2 = h->KS2; P.MT2 = h->MT2;
     P.reltol = h->cfg.reltol; P.abstol = h->cfg.abstol; P.t0 = t0; P.t1 = t1;
     P.tape = tape; P.max_attempts = h->cfg.max_attempts;
     P.forced = 0; P.forced_t = 0; P.forced_dt = 0;
@@ -159,58 +152,6 @@ static StepParams make_params(rnde_node* h, const float* x, int B, float t0, flo
     return P;
 }
 
-// The column-owner engine's own step / finish / reverse-step kernels (col_tile 4 or 8: the round-1 engine, 126 us per attempted step at
-// B = 512; nothing selects it automatically) are compiled only with -DRNDE_WITH_COLUMN_OWNER (RNDE_WITH_COLUMN_OWNER=1 python build.py);
-// its initialisation-reverse kernels (rnde_binit_kernel, rnde_bfin_kernel) are what the stage engine's reverse pass ends with and are
-// always there.  rnde_has_column_owner() says which build this is.
-#ifdef RNDE_WITH_COLUMN_OWNER
-constexpr int kHasColumnOwner = 1;
-#else
-constexpr int kHasColumnOwner = 0;
-#endif
-extern "C" int32_t rnde_has_column_owner(void) { return kHasColumnOwner; }
-template <int NG, int ACT2, int MODE>
-static hipError_t launch_step_t(rnde_node* h, const StepParams& P, int n, hipStream_t s) {
-#ifdef RNDE_WITH_COLUMN_OWNER
-    auto kern = rnde_step_kernel<NG, ACT2, MODE>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(P.nwg), dim3(kThreads), h->lds_bytes, s, P, n);
-    return hipGetLastError();
-#else
-    (void)h; (void)P; (void)n; (void)s;
-    return hipErrorNotSupported;
-#endif
-}
-template <int MODE>
-static hipError_t launch_step(rnde_node* h, const StepParams& P, int n, hipStream_t s) {
-    if (h->NG == 1) return h->act2 ? launch_step_t<1, 1, MODE>(h, P, n, s) : launch_step_t<1, 0, MODE>(h, P, n, s);
-    return h->act2 ? launch_step_t<2, 1, MODE>(h, P, n, s) : launch_step_t<2, 0, MODE>(h, P, n, s);
-}
-static hipError_t launch_finish(rnde_node* h, const StepParams& P, int n, float* u_out, hipStream_t s) {
-#ifdef RNDE_WITH_COLUMN_OWNER
-    if (h->NG == 1) hipLaunchKernelGGL(rnde_finish_kernel<1>, dim3(P.nwg), dim3(256), 0, s, P, n, u_out);
-    else hipLaunchKernelGGL(rnde_finish_kernel<2>, dim3(P.nwg), dim3(256), 0, s, P, n, u_out);
-    return hipGetLastError();
-#else
-    (void)h; (void)P; (void)n; (void)u_out; (void)s;
-    return hipErrorNotSupported;
-#endif
-}
-static hipError_t launch_pack(rnde_node* h, const float* p, f32x4* dst, int which, int MT, int K4, hipStream_t s) {
-    const int TR = 64 / h->NG;
-    const long long total = (long long)MT * K4 * TR;
-    const int grid = (int)std::min<long long>((total + 255) / 256, 1024);
-    if (h->NG == 1) hipLaunchKernelGGL(rnde_pack_kernel<1>, dim3(grid), dim3(256), 0, s, p, dst, which, h->D, h->H, MT, K4);
-    else hipLaunchKernelGGL(rnde_pack_kernel<2>, dim3(grid), dim3(256), 0, s, p, dst, which, h->D, h->H, MT, K4);
-    return hipGetLastError();
-}
-
-// ---- chain engine host side (rnde_chain.h) --------------------------------------------------------------
 static_assert(kCMaxL == RNDE_MAX_LAYERS, "chain engine layer limit");
 static bool chain_geo(const rnde_node_config* c, ChainGeo& G) {
     G = ChainGeo{};
@@ -241,7 +182,7 @@ static rnde_status chain_create(const rnde_node_config* c, rnde_node** out) {
     if (c->max_batch < 1 || c->max_attempts < 1) { g_create_err = "max_batch / max_attempts"; return RNDE_ERR_BAD_ARG; }
     rnde_node* h = new rnde_node();
     h->cfg = *c; h->engine = 3; h->cg = G;
-    h->D = c->dims[0]; h->H = 0; h->P = rnde_param_count(c); h->BT = 16; h->NG = 0;
+    h->D = c->dims[0]; h->H = 0; h->P = rnde_param_count(c); h->BT = 16;
     h->NKD = G.nksD <= 4 ? 4 : (G.nksD <= 8 ? 8 : 16);
     {   // compile-time shape specialisation for the reference's own latent-ODE widths (rnde_chain.h: ALT)
         bool alt = G.nksD == kAltA && !getenv("RNDE_CHAIN_GENERIC");
@@ -487,26 +428,18 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
     }
     if (c->col_tile == 64 || c->col_tile == 65 || !mnist_form) return chain_create(c, out);   // small-width chains (latent_ode.jl:113-124): rnde_chain.h
     if (c->regularize < RNDE_REG_NONE || c->regularize > RNDE_REG_ERR_STIFF) { g_create_err = "regularize: unknown value"; return RNDE_ERR_BAD_ARG; }
-    if (c->regularize >= RNDE_REG_STIFF && (c->col_tile == 4 || c->col_tile == 8)) {
-        g_create_err = "the stiffness-estimate regularisers run on the stage engine only (col_tile 0 or 16)";
-        return RNDE_ERR_BAD_ARG;
-    }
     rnde_node* h = new rnde_node();
     h->cfg = *c;
     h->D = c->dims[0]; h->H = c->dims[1]; h->P = rnde_param_count(c); h->act2 = c->act[1];
-    h->BT = (c->col_tile == 4) ? 4 : 8;   // column-owner tile (also used by the reverse sweep of the stage engine for now)
-    if (c->col_tile != 0 && c->col_tile != 4 && c->col_tile != 8 && c->col_tile != 16) { g_create_err = "col_tile must be 0 (auto), 4, 8 (column-owner engine) or 16 (stage engine)"; delete h; return RNDE_ERR_BAD_ARG; }
-    h->NG = h->BT / 4;
-    const int TR = 64 / h->NG, TPW = (h->NG == 1) ? 2 : 4;
-    if (h->H + 2 > 128 || h->D + 2 > kWaves * TPW * TR || h->D < 1 || h->H < 1 || c->max_batch < 1 || c->max_attempts < 1) {
-        g_create_err = "shape outside the kernel limits (H <= 126, D <= 1022 at col_tile 8)"; delete h; return RNDE_ERR_BAD_ARG;
+    h->BT = 8;   // (column granularity of the batch padding the tape's copy of x is zero-filled to)
+    if (c->col_tile != 0 && c->col_tile != 16) {
+        g_create_err = "col_tile must be 0 (auto) or 16 (stage engine) for the two-layer TDChain form; 64 / 65 select the chain engine.  (The round-1 column-owner "
+                       "engine, col_tile 4 / 8, was retired in round 4: 126 us per attempted step against 24; its sources are kept under tools/experiments/column_owner/.)";
+        delete h; return RNDE_ERR_BAD_ARG;
     }
-    const int KU = h->NG;  // k4 groups per weight-ring unit (rnde_device.h): K4 counts are padded to it
-    auto up4 = [KU](int k) { return ((k + 3) / 4 + KU - 1) / KU * KU; };
-    h->K4_1 = up4(h->D + 2); h->KS1 = 4 * (h->K4_1 | 1); h->MT1 = (h->H + TR - 1) / TR;
-    h->K4_2 = up4(h->H + 2); h->KS2 = 4 * (h->K4_2 | 1); h->MT2 = (h->D + TR - 1) / TR;
-    h->K4_2t = up4(h->D); h->MT2t = (h->H + 1 + TR - 1) / TR;   // pw2t: M = H+1, K = D   (B operand image uses KS1)
-    h->K4_1t = up4(h->H); h->MT1t = (h->D + 1 + TR - 1) / TR;   // pw1t: M = D+1, K = H   (B operand image uses KS2)
+    if (h->H + 2 > 128 || h->D < 1 || h->H < 1 || (h->D + 15) / 16 > 64 || c->max_batch < 1 || c->max_attempts < 1) {
+        g_create_err = "shape outside the kernel limits (H <= 126, D <= 1024)"; delete h; return RNDE_ERR_BAD_ARG;
+    }
     h->Bpad_max = ((c->max_batch + 15) / 16) * 16;
     // stage engine geometry: WT row tiles (waves) per block chosen to minimise padding, preferring more waves
     h->sMT = (h->D + 15) / 16; h->sHT = (h->H + 1 + 15) / 16; h->sK2b = (h->H + 2 + 15) / 16; h->sKHb = (h->H + 15) / 16;
@@ -514,15 +447,9 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
       for (int wt = std::min(8, h->sMT); wt >= std::max(1, std::min(4, h->sMT)); --wt) { int R = (h->sMT + wt - 1) / wt; int waste = R * wt - h->sMT; if (waste < bw) { bw = waste; best = wt; } }
       if (const char* e = getenv("RNDE_STAGE_WT")) { const int v = atoi(e); if (v >= 1 && v <= 8) best = std::min(v, h->sMT); }   // (experiments: row tiles per workgroup)
       h->sWT = best; h->sR = (h->sMT + best - 1) / best; }
-    h->engine = (c->col_tile == 16 || c->col_tile == 0) ? 2 : 1;
-    if (h->engine == 1 && !kHasColumnOwner) {
-        g_create_err = "col_tile 4 / 8: this build of librnde.so leaves the column-owner step kernels out (RNDE_WITH_COLUMN_OWNER=1 python regneuralde.jl_amd/build.py includes them); col_tile 0 or 16 runs the stage engine";
-        delete h; return RNDE_ERR_BAD_ARG;
-    }
+    h->engine = 2;
     h->nwg_max = std::max(h->Bpad_max / h->BT, h->sR * (h->Bpad_max / 16));
     h->stage_lds = sizeof(float) * ((size_t)16 * (16 * std::max(h->sK2b, h->sHT) + 4) + (size_t)16 * (16 * std::max(h->sWT, h->sKHb) + 4) + 64);
-    const int MTS = 128 / TR;
-    h->lds_bytes = sizeof(float) * ((size_t)h->BT * h->KS1 + (size_t)h->BT * h->KS2 + (size_t)kWaves * MTS * 256 + 192 + (size_t)kWaves * kRing * 256);
     if (hipSetDevice(c->device) != hipSuccess) { g_create_err = "hipSetDevice failed"; delete h; return RNDE_ERR_HIP; }
     const size_t A = (size_t)h->D * h->Bpad_max, HB = (size_t)h->H * h->Bpad_max;
     RecLayout L{(long long)A, (long long)HB};
@@ -531,8 +458,6 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
     bool ok = true;
     ok &= dm((void**)&h->f0, A * 4) && dm((void**)&h->u1, A * 4) && dm((void**)&h->f1, A * 4) && dm((void**)&h->xcopy, A * 4);
     ok &= dm((void**)&h->h0, HB * 4) && dm((void**)&h->h1, HB * 4);
-    ok &= dm((void**)&h->pw1, (size_t)h->MT1 * h->K4_1 * TR * 16) && dm((void**)&h->pw2, (size_t)h->MT2 * h->K4_2 * TR * 16);
-    ok &= dm((void**)&h->pw1t, (size_t)h->MT1t * h->K4_1t * TR * 16) && dm((void**)&h->pw2t, (size_t)h->MT2t * h->K4_2t * TR * 16);
     ok &= dm((void**)&h->pcopy, (size_t)h->P * 4);
     ok &= dm((void**)&h->spwB, (size_t)h->sMT * h->sK2b * 64 * 16) && dm((void**)&h->spwD, (size_t)h->sHT * h->sMT * 64 * 16);
     ok &= dm((void**)&h->spwBt, (size_t)h->sMT * h->sKHb * 64 * 16) && dm((void**)&h->spwDt, (size_t)h->sHT * h->sMT * 64 * 16);
@@ -570,7 +495,6 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
         if (const char* e4 = getenv("RNDE_WIDE")) h->wide = atoi(e4);
         h->wgrad_side_pct = c->wgrad_side_pct < 0 ? 0 : (c->wgrad_side_pct == 0 ? 30 : std::min(100, c->wgrad_side_pct));
         if (const char* e3 = getenv("RNDE_WGRAD_SIDE")) h->wgrad_side_pct = atoi(e3);
-        if (const char* e5 = getenv("RNDE_BINIT_STAGE")) h->binit_stage = atoi(e5);
         h->stage_generic = (c->stage_generic != 0 || getenv("RNDE_STAGE_GENERIC") != nullptr) ? 1 : 0;
         if (const char* e6 = getenv("RNDE_STAGE_SOLVE")) h->stage_solve = atoi(e6);
     }
@@ -586,7 +510,7 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
 
 extern "C" void rnde_node_destroy(rnde_node* h) {
     if (!h) return;
-    void* d[] = {h->f0, h->h0, h->u1, h->f1, h->h1, h->arena, h->xcopy, h->pw1, h->pw2, h->pw1t, h->pw2t, h->pcopy, h->spwB, h->spwD, h->spwBt, h->spwDt, h->slab2,
+    void* d[] = {h->f0, h->h0, h->u1, h->f1, h->h1, h->arena, h->xcopy, h->pcopy, h->spwB, h->spwD, h->spwBt, h->spwDt, h->slab2,
                  h->ctl, h->ctl_final, h->meta, h->initrec, h->errpart, h->initpart};
     if (h->mbox || h->h_mbox) {   // these alias the mailbox
         for (void*& p : d) if (p == h->ctl_final || p == h->meta || p == h->initrec) p = nullptr;
@@ -657,19 +581,6 @@ static rnde_status ensure_arena(rnde_node* h, long long recs) {
     return RNDE_OK;
 }
 
-static rnde_status pack_weights(rnde_node* h, const float* p_dev, bool reverse, hipStream_t s, bool forward = true) {
-    if (forward) {   // (the stage engine's forward pass has its own packs; it only needs the transposed ones below, for rnde_binit_kernel)
-        HIPCHK(h, launch_pack(h, p_dev, h->pw1, 0, h->MT1, h->K4_1, s));
-        HIPCHK(h, launch_pack(h, p_dev, h->pw2, 1, h->MT2, h->K4_2, s));
-    }
-    if (reverse) {
-        HIPCHK(h, launch_pack(h, p_dev, h->pw2t, 2, h->MT2t, h->K4_2t, s));
-        HIPCHK(h, launch_pack(h, p_dev, h->pw1t, 3, h->MT1t, h->K4_1t, s));
-    }
-    return RNDE_OK;
-}
-
-// ---- stage engine host side ----------------------------------------------------------------------
 static StageParams make_stage_params(rnde_node* h, const StepParams& P, const float* p_dev) {
     StageParams Q{};
     Q.F = P; Q.p = p_dev; Q.pwB = h->spwB; Q.pwD = h->spwD; Q.slab = h->slab2;
@@ -698,17 +609,12 @@ static rnde_status stage_pack_weights(rnde_node* h, const float* p_dev, hipStrea
 }
 static rnde_status stage_pack_all(rnde_node* h, const float* p_dev, hipStream_t s, const float* x_src = nullptr, long long x_floats = 0) {
     PackJobs J{};
-    const int TR = 64 / h->NG;
     int n = 0;
     auto add = [&](void* dst, long long total, int kind, int which, int kdim, const float* src = nullptr) { J.j[n++] = PackJob{dst, src, total, kind, which, kdim, 0}; };
     add(h->spwB, (long long)h->sMT * h->sK2b * 64, 0, 0, h->sK2b);
     add(h->spwD, (long long)h->sHT * h->sMT * 64, 0, 1, h->sMT);
     add(h->spwBt, (long long)h->sMT * h->sKHb * 64, 0, 2, h->sKHb);
     add(h->spwDt, (long long)h->sHT * h->sMT * 64, 0, 3, h->sMT);
-    if (!h->binit_stage) {   // (rnde_binit_kernel: column-owner layouts; the stage-engine form of the initial-step reverse needs none)
-        add(h->pw2t, (long long)h->MT2t * h->K4_2t * TR, 1, 2, h->K4_2t);
-        add(h->pw1t, (long long)h->MT1t * h->K4_1t * TR, 1, 3, h->K4_1t);
-    }
     auto add_copy = [&](float* dst, const float* src, long long floats) {     // 16-byte copies where sizes and addresses allow
         const bool v4 = floats % 4 == 0 && ((uintptr_t)dst % 16 == 0) && ((uintptr_t)(src ? src : p_dev) % 16 == 0);
         add(dst, v4 ? floats / 4 : floats, v4 ? 3 : 2, 0, 0, src);
@@ -718,8 +624,7 @@ static rnde_status stage_pack_all(rnde_node* h, const float* p_dev, hipStream_t 
     long long most = 0;
     for (int i = 0; i < n; ++i) most = std::max(most, J.j[i].total);
     const int grid = (int)std::min<long long>((most + 255) / 256, 256);
-    if (h->NG == 1) hipLaunchKernelGGL(rnde_pack_all_kernel<1>, dim3(grid, n), dim3(256), 0, s, p_dev, J, h->D, h->H);
-    else hipLaunchKernelGGL(rnde_pack_all_kernel<2>, dim3(grid, n), dim3(256), 0, s, p_dev, J, h->D, h->H);
+    hipLaunchKernelGGL(rnde_pack_all_kernel, dim3(grid, n), dim3(256), 0, s, p_dev, J, h->D, h->H);
     HIPCHK(h, hipGetLastError());
     h->rev_packed = true;
     return RNDE_OK;
@@ -867,7 +772,6 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
     if (!h) return RNDE_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (n_saveat > 0) {
-        if (h->engine == 1) { h->err = "saveat is not available on the column-owner engine (col_tile 4/8)"; return RNDE_ERR_BAD_ARG; }
         if (h->rk_tab == 2) { h->err = "saveat: this Runge-Kutta table carries no dense output (DOP853)"; return RNDE_ERR_BAD_ARG; }
         for (int i = 0; i < n_saveat; ++i)
             if (!(saveat_host[i] >= t0 && saveat_host[i] <= t1) || (i > 0 && !(saveat_host[i] > saveat_host[i - 1]))) {
@@ -917,8 +821,7 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
     h->B = B; h->Bpad = P.Bpad; h->nwg = P.nwg; h->t0 = t0; h->t1 = t1;
     rnde_status st = RNDE_OK;
     if (h->engine == 2 && keep_tape) st = stage_pack_all(h, p_dev, s, x_caller, (long long)h->D * B);   // forward + reverse packs of both engines' layouts and the tape's copy of p: one launch
-    else st = h->engine == 3 ? chain_pack(h, keep_tape ? h->pcopy : p_dev, s)
-                             : pack_weights(h, p_dev, keep_tape != 0, s, h->engine != 2);   // (column-owner packs: also used by the reverse sweep)
+    else if (h->engine == 3) st = chain_pack(h, keep_tape ? h->pcopy : p_dev, s);
     if (st != RNDE_OK) return st;
     StageParams SQ{};
     ChainParams CQ{};
@@ -945,9 +848,6 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
         HIPCHK(h, launch_stage<SM_I3>(h, SQ, 0, 0, s));
         HIPCHK(h, launch_stage<SM_I4>(h, SQ, 0, 0, s));
         if ((st = couple_sum(h, P.initpart + 2LL * P.nwg, P.nwg, s)) != RNDE_OK) return st;     // norm of f1 - f0
-    } else {
-        HIPCHK(h, launch_step<MODE_INIT_A>(h, P, 0, s));
-        HIPCHK(h, launch_step<MODE_INIT_B>(h, P, 0, s));
     }
     int launched = 0;
     int chunk = h->couple ? 16 : std::max(4, h->predicted);   // (coupled: the same launch count on every rank, whatever its history)
@@ -1051,15 +951,13 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
 #endif
                 HIPCHK(h, stage_attempt(h, SQ, launched, s));
             }
-            else HIPCHK(h, launch_step<MODE_STEP>(h, P, launched, s));
             if ((st = couple_sum(h, P.errpart + (size_t)(launched & 1) * 3 * P.nwg, 3LL * P.nwg, s)) != RNDE_OK) return st;
             ++launched;
         }
         if (h->timing && !h->tev_fwd) { HIPCHK(h, hipEventRecord(h->tev[1], s)); h->tev_fwd = true; }   // (first chunk: normally the whole solve)
         if (h->engine == 3 && h->mw) { MQ.u_out = u_out_dev; HIPCHK(h, launch_mw<MW_FINISH>(h, MQ, launched, s)); }
         else if (h->engine == 3) HIPCHK(h, launch_chain<CM_FINISH>(h, CQ, launched, u_out_dev, s));
-        else if (h->engine == 2) { hipLaunchKernelGGL(rnde_stage_finish_kernel, dim3(256), dim3(256), 0, s, SQ, launched, u_out_dev); HIPCHK(h, hipGetLastError()); }
-        else HIPCHK(h, launch_finish(h, P, launched, u_out_dev, s));
+        else { hipLaunchKernelGGL(rnde_stage_finish_kernel, dim3(256), dim3(256), 0, s, SQ, launched, u_out_dev); HIPCHK(h, hipGetLastError()); }
         // one synchronisation per chunk: controller state, the persistent kernels' health words, and (speculatively: the solve
         // usually ends in the first chunk) the step metadata and the initial-step record the epilogue needs
         if (h->mbox) {
@@ -1260,11 +1158,8 @@ extern "C" rnde_status rnde_debug_feval(rnde_node* h, const float* u_dev, const 
         HIPCHK(h, hipStreamSynchronize(s));
         return RNDE_OK;
     }
-    rnde_status st = pack_weights(h, p_dev, false, s);
-    if (st != RNDE_OK) return st;
-    HIPCHK(h, launch_step<MODE_FEVAL>(h, P, 0, s));
-    HIPCHK(h, hipStreamSynchronize(s));
-    return RNDE_OK;
+    h->err = "rnde_debug_feval: unknown engine";
+    return RNDE_ERR_BAD_ARG;
 }
 
 extern "C" rnde_status rnde_debug_attempt(rnde_node* h, const float* uprev_dev, const float* k1_dev, const float* p_dev,
@@ -1292,21 +1187,16 @@ extern "C" rnde_status rnde_debug_attempt(rnde_node* h, const float* uprev_dev, 
         if (eest_out) *eest_out = h->h_ctl->last_eest;
         return RNDE_OK;
     }
-    rnde_status st = pack_weights(h, p_dev, false, s);
-    if (st != RNDE_OK) return st;
     // k1 goes to the f0 buffer (column stride D in both layouts)
     HIPCHK(h, hipMemsetAsync(h->f0, 0, (size_t)h->D * P.Bpad * 4, s));
     HIPCHK(h, hipMemcpyAsync(h->f0, k1_dev, (size_t)h->D * B * 4, hipMemcpyDeviceToDevice, s));
-    if (h->engine == 2) {
+    {
         rnde_status st2 = stage_pack_weights(h, p_dev, s);
         if (st2 != RNDE_OK) return st2;
         StageParams SQ = make_stage_params(h, P, p_dev);
         HIPCHK(h, stage_attempt(h, SQ, 0, s));
         hipLaunchKernelGGL(rnde_stage_finish_kernel, dim3(256), dim3(256), 0, s, SQ, 1, (float*)nullptr);
         HIPCHK(h, hipGetLastError());
-    } else {
-        HIPCHK(h, launch_step<MODE_STEP>(h, P, 0, s));
-        HIPCHK(h, launch_finish(h, P, 1, nullptr, s));
     }
     HIPCHK(h, hipMemcpyAsync(h->h_ctl, h->ctl_final, sizeof(StepState), hipMemcpyDeviceToHost, s));
     RecLayout L{(long long)h->D * P.Bpad, (long long)h->H * P.Bpad};
@@ -1343,7 +1233,7 @@ static rnde_status bench_attempt_impl(rnde_node* h, const float* x_dev, const fl
     if (taped > 1) { const rnde_status sa = ensure_arena(h, std::min<long long>(taped, h->cfg.max_attempts)); if (sa != RNDE_OK) return sa; }
     StepParams P = make_params(h, x_dev, B, 0.f, 1.f, taped ? 1 : 0);   // taped: the variant a training step runs (record 0 of the arena)
     P.forced = 1; P.forced_t = 0.f; P.forced_dt = 0.05f;
-    rnde_status st = h->engine == 3 ? chain_pack(h, p_dev, s) : pack_weights(h, p_dev, false, s);
+    rnde_status st = h->engine == 3 ? chain_pack(h, p_dev, s) : RNDE_OK;
     if (st != RNDE_OK) return st;
     StageParams SQ{};
     ChainParams CQ{};
@@ -1357,16 +1247,13 @@ static rnde_status bench_attempt_impl(rnde_node* h, const float* x_dev, const fl
         CQ = make_chain_params(h, P);
         HIPCHK(h, launch_chain<CM_INIT_A>(h, CQ, 0, nullptr, s));   // k1 = f(x, 0) into f0
         for (int i = 0; i < 3; ++i) HIPCHK(h, launch_chain<CM_STEP>(h, CQ, 0, nullptr, s));
-    } else if (h->engine == 2) {
+    } else {
         st = stage_pack_weights(h, p_dev, s);
         if (st != RNDE_OK) return st;
         SQ = make_stage_params(h, P, p_dev);
         HIPCHK(h, launch_stage<SM_I1>(h, SQ, 0, 0, s));
         HIPCHK(h, launch_stage<SM_I2>(h, SQ, 0, 0, s));   // k1 = f(x, 0) into f0
         for (int i = 0; i < 3; ++i) HIPCHK(h, stage_attempt(h, SQ, 0, s));
-    } else {
-        HIPCHK(h, launch_step<MODE_INIT_A>(h, P, 0, s));  // k1 = f(x, 0) into f0
-        for (int i = 0; i < 3; ++i) HIPCHK(h, launch_step<MODE_STEP>(h, P, 0, s));
     }
     hipEvent_t e0, e1;
     HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
@@ -1378,8 +1265,7 @@ static rnde_status bench_attempt_impl(rnde_node* h, const float* x_dev, const fl
     for (int i = 0; i < iters; ++i) {
         if (h->engine == 3 && h->mw) HIPCHK(h, launch_mw<MW_STEP>(h, MQ, 0, s));
         else if (h->engine == 3) HIPCHK(h, launch_chain<CM_STEP>(h, CQ, 0, nullptr, s));
-        else if (h->engine == 2) { SQ.F.rec_shift = i % cyc; HIPCHK(h, stage_attempt(h, SQ, 0, s)); }
-        else HIPCHK(h, launch_step<MODE_STEP>(h, P, 0, s));
+        else { SQ.F.rec_shift = i % cyc; HIPCHK(h, stage_attempt(h, SQ, 0, s)); }
     }
     const double host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - host_t0).count();
     if (getenv("RNDE_TRACE_HOST")) fprintf(stderr, "[rnde] host enqueue: %.2f us per attempt (%d launches each)\n", host_us / iters, h->engine == 2 ? 7 : 1);
@@ -1420,7 +1306,7 @@ static rnde_status bench_attempt_impl(rnde_node* h, const float* x_dev, const fl
                 fprintf(stderr, "  stage %d wave %d: %6lld | %6lld %6lld | %6lld | %6lld | %6lld | %6lld\n", st, w, (long long)q[0]-z, (long long)q[1]-z, (long long)q[2]-z, (long long)q[3]-z, (long long)q[4]-z, (long long)q[5]-z, (long long)q[6]-z); }
             return RNDE_OK;
         }
-        if (h->engine == 2) { SQ.F.dbg_out = (float*)d; stage_attempt(h, SQ, 0, s); } else launch_step<MODE_STEP>(h, P, 0, s);
+        SQ.F.dbg_out = (float*)d; stage_attempt(h, SQ, 0, s);
         hipStreamSynchronize(s);
         hipMemcpy(hst, d, sizeof(hst), hipMemcpyDeviceToHost); hipFree(d);
         fprintf(stderr, "stamps (cycles since wave0 stamp0); column-owner: start sync1 gemm1 sync2 reduce sync3 gemm2 tanh | stage: start scalars A sync B C sync D\n");
@@ -1431,8 +1317,6 @@ static rnde_status bench_attempt_impl(rnde_node* h, const float* x_dev, const fl
 }
 
 // ---- reverse pass driver ------------------------------------------------------------------------
-static size_t bwd_lds_bytes(const rnde_node* h) { return h->lds_bytes; }
-
 static rnde_status bwd_prepare(rnde_node* h) {
     BwdBuffers& b = h->bw;
     if (b.ready) return RNDE_OK;
@@ -1469,35 +1353,6 @@ static rnde_status bwd_prepare(rnde_node* h) {
     return RNDE_OK;
 }
 
-template <int NG, int ACT2>
-static hipError_t launch_bwd_t(rnde_node* h, const BwdParams& Q, int n_att, hipStream_t s) {
-    const size_t lds = bwd_lds_bytes(h);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipSuccess;
-#ifdef RNDE_WITH_COLUMN_OWNER
-        e = hipFuncSetAttribute((const void*)rnde_bstep_kernel<NG, ACT2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-#endif
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rnde_binit_kernel<NG, ACT2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rnde_binit_kernel<NG, ACT2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-#ifdef RNDE_WITH_COLUMN_OWNER
-    for (int n = n_att - 1; n >= 0; --n) hipLaunchKernelGGL((rnde_bstep_kernel<NG, ACT2>), dim3(Q.F.nwg), dim3(kThreads), lds, s, Q, n);
-#else
-    if (n_att > 0) return hipErrorNotSupported;     // (only the column-owner engine passes attempts here)
-#endif
-    hipLaunchKernelGGL((rnde_binit_kernel<NG, ACT2, 1>), dim3(Q.F.nwg), dim3(kThreads), lds, s, Q);
-    if (couple_sum(h, Q.ipart, 4LL * Q.F.nwg, s) != RNDE_OK) return hipErrorUnknown;                         // (coupled controller: dot, tau of the reversed second evaluation)
-    hipLaunchKernelGGL((rnde_binit_kernel<NG, ACT2, 2>), dim3(Q.F.nwg), dim3(kThreads), lds, s, Q);
-    if (couple_sum(h, Q.ipart + 4LL * Q.F.nwg, 4LL * Q.F.nwg, s) != RNDE_OK) return hipErrorUnknown;        // tau of the first
-    hipLaunchKernelGGL(rnde_bfin_kernel, dim3(1), dim3(64), 0, s, Q);
-    return hipGetLastError();
-}
-
-// one group of evaluations -> `*chunk_cursor` .. slabs of region `slab`; returns the number of chunks written
-// shapes the 16x16x4 kernel (rnde_wgrad3_kernel) covers: both widths multiples of 4, the wide side in 42..50 tiles, the narrow one <= 112
 static bool wgrad3_ok(int M, int Nx) {
     const bool tall = M >= Nx;
     const int wide = tall ? M : Nx + 2, narrow = tall ? Nx + 2 : M;
@@ -1597,7 +1452,6 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
     memcpy(h_svb_blob, b.h_svb, (size_t)n_att * 4);
     BwdParams Q{};
     Q.F = make_params(h, h->xcopy, h->B, h->t0, h->t1, 1);
-    Q.pw2t = h->pw2t; Q.pw1t = h->pw1t; Q.K4_2t = h->K4_2t; Q.MT2t = h->MT2t; Q.K4_1t = h->K4_1t; Q.MT1t = h->MT1t;
     Q.U = b.U; Q.K1 = b.K1; Q.UB1 = b.UB1; Q.zi2 = b.zi2; Q.zi1 = b.zi1; Q.svb_att = d_svb;
     Q.bstate = b.bstate; Q.ibstate = b.ibstate; Q.bpart = b.bpart; Q.ipart = b.ipart;
     Q.ubar = u_bar_dev; Q.xbar = x_bar_dev; Q.tspan_out = b.tspan_out;
@@ -1663,7 +1517,6 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
     };
     int hi_att = n_att;                                           // evaluations of attempts >= hi_att are already launched
     hipError_t e;
-    bool stage_binit_done = false;
     h->tev_bwd = false;
     if (h->timing) HIPCHK(h, hipEventRecord(h->tev[2], s));
     if (h->engine == 2) {
@@ -1744,8 +1597,7 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
             if ((st = couple_sum(h, b.bpart + (size_t)(n & 1) * Q.bpart_n * 4, 4LL * Q.bpart_n, s)) != RNDE_OK) return st;
         }
         HIPCHK(h, hipGetLastError());
-        if (h->binit_stage) {   // reverse of the initial-step rule: four stage-engine launches (rnde_binit_stage.h)
-            stage_binit_done = true;
+        {   // reverse of the initial-step rule: four stage-engine launches (rnde_binit_stage.h)
             if (h->act2) {
                 hipLaunchKernelGGL((rnde_binit_stage_kernel<1, 0>), grid, blk, h->stage_lds, s, BQ);
                 hipLaunchKernelGGL((rnde_binit_stage_kernel<1, 1>), grid, blk, h->stage_lds, s, BQ);
@@ -1764,17 +1616,8 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
             if ((st = couple_sum(h, Q.ipart + 4LL * Q.F.nwg, 4LL * Q.F.nwg, s)) != RNDE_OK) return st;      // tau of the first
             hipLaunchKernelGGL(rnde_bfin_kernel, dim3(1), dim3(64), 0, s, Q);
             HIPCHK(h, hipGetLastError());
-        } else {
-            Q.F.nwg = Q.F.Bpad / h->BT;     // the initialisation kernels below are column-owner kernels
-            n_att = 0;                       // (their attempt loop is skipped)
         }
     }
-    if (!stage_binit_done) {
-        if (h->NG == 1) e = h->act2 ? launch_bwd_t<1, 1>(h, Q, n_att, s) : launch_bwd_t<1, 0>(h, Q, n_att, s);
-        else e = h->act2 ? launch_bwd_t<2, 1>(h, Q, n_att, s) : launch_bwd_t<2, 0>(h, Q, n_att, s);
-        HIPCHK(h, e);
-    }
-    n_att = h->n_att;
     if (h->timing) HIPCHK(h, hipEventRecord(h->tev[3], s));
     // remaining evaluations on all CUs (everything that did not go to the side stream, incl. the two initialisation evaluations)
     st = wgrad_group(0, 2 + 6 * hi_att, false);

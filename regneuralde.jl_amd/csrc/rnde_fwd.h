@@ -1,4 +1,5 @@
-// rnde_fwd.h -- forward kernels: weight packing, initial-step heuristic, Tsit5 attempt, controller.
+// rnde_fwd.h -- what every forward engine shares: tile loads / stores and the step-size controller (initial-step rule, PI controller).
+// (The round-1 column-owner step kernels that used to live here: tools/experiments/column_owner/.)
 //
 // Reference behaviour being replaced (all of it third-party, see include/rnde.h and SURVEY.md 8a/8c):
 //   the body of `solve(prob, Tsit5(); ...)` called from reference src/models/neural_ode.jl:64-70,
@@ -7,69 +8,6 @@
 #include "rnde_device.h"
 
 namespace rnde {
-
-// ------------------------------------------------------------------------------------------
-// Weight packing.  p is the Flux.destructure vector of a 2-layer TDChain
-// (reference src/models/neural_ode.jl:12): [W1 (H x (D+1)); b1 (H); W2 (D x (H+1)); b2 (D)],
-// column-major.  Bias and time are folded into the GEMM as two extra K columns, so
-//   pw1 : M = H,   K = D + 2   ([W1x | w1t | b1])        forward layer 1
-//   pw2 : M = D,   K = H + 2   ([W2x | w2t | b2])        forward layer 2
-//   pw2t: M = H+1, K = D       ([W2x^T ; w2t^T])         reverse: hbar (+ time cotangent row)
-//   pw1t: M = D+1, K = H       ([W1x^T ; w1t^T])         reverse: gbar (+ time cotangent row)
-// Packed element (tile T, k4, r, kk) = Wext[T*TR + r][4*k4 + kk], zero outside.
-// ------------------------------------------------------------------------------------------
-template <int NG>
-__device__ __forceinline__ f32x4 pack_elem(const float* __restrict__ p, int which, int D, int H, int K4, long long i) {
-    using G = Geo<NG>;
-    const float* W1 = p;
-    const float* b1 = W1 + (size_t)H * (D + 1);
-    const float* W2 = b1 + H;
-    const float* b2 = W2 + (size_t)D * (H + 1);
-    const int r = (int)(i % G::TR);
-    const int k4 = (int)((i / G::TR) % K4);
-    const int T = (int)(i / ((long long)G::TR * K4));
-    const int m = T * G::TR + r;
-    f32x4 v;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        const int k = 4 * k4 + kk;
-        float w = 0.f;
-        if (which == 0) {  // pw1
-            if (m < H) w = k <= D ? W1[(size_t)k * H + m] : (k == D + 1 ? b1[m] : 0.f);
-        } else if (which == 1) {  // pw2
-            if (m < D) w = k <= H ? W2[(size_t)k * D + m] : (k == H + 1 ? b2[m] : 0.f);
-        } else if (which == 2) {  // pw2t: rows m<=H are columns m of W2 (m == H: time column)
-            if (m <= H && k < D) w = W2[(size_t)m * D + k];
-        } else {  // pw1t
-            if (m <= D && k < H) w = W1[(size_t)m * H + k];
-        }
-        v[kk] = w;
-    }
-    return v;
-}
-template <int NG>
-__global__ void rnde_pack_kernel(const float* __restrict__ p, f32x4* __restrict__ dst, int which, int D, int H,
-                                 int MT, int K4) {
-    using G = Geo<NG>;
-    const long long total = (long long)MT * K4 * G::TR;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
-        dst[i] = pack_elem<NG>(p, which, D, H, K4, i);
-}
-
-// ------------------------------------------------------------------------------------------
-// Element ownership helpers (see rnde_device.h header comment)
-// ------------------------------------------------------------------------------------------
-template <int NG>
-struct Own {
-    using G = Geo<NG>;
-    int row0[G::TPW];  // first of 4 owned rows per tile
-    int col;           // column inside the workgroup's BT columns
-    __device__ __forceinline__ Own(int wave, int lane) {
-        col = 4 * (lane / G::TR) + (lane & 3);
-#pragma unroll
-        for (int j = 0; j < G::TPW; ++j) row0[j] = (wave + kWaves * j) * G::TR + 4 * ((lane >> 2) % G::RG);
-    }
-};
 
 __device__ __forceinline__ f32x4 ld_tile(const float* __restrict__ colbase, int row0, int D, bool ok, bool vec) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -90,82 +28,6 @@ __device__ __forceinline__ void st_tile(float* __restrict__ colbase, int row0, i
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (row0 + i < D) colbase[row0 + i] = v[i];
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// f(g, p, ts) for the workgroup's BT columns.  GL rows [0, D) must already hold g (unsynchronised).
-// Returns k in the ownership layout.  Three workgroup barriers.
-// ------------------------------------------------------------------------------------------
-template <int NG, int ACT2>
-__device__ __forceinline__ void eval_f(const StepParams& P, float* GL, float* HL, float* PART, float* RING, float ts,
-                                       float* __restrict__ hdst, int col0, f32x4 (&kout)[Geo<NG>::TPW], int tid) {
-    using G = Geo<NG>;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-#ifdef RNDE_DIAG   // diagnostic build only (tools/build_diag.sh): s_memtime stamps of workgroup 0, never in the product build
-#define RNDE_STAMP(i) do { if (P.dbg_out && blockIdx.x == 0 && lane == 0) ((unsigned long long*)P.dbg_out)[(wave_u * 8 + (i))] = clock64(); } while (0)
-#else
-#define RNDE_STAMP(i) do { } while (0)
-#endif
-    RNDE_STAMP(0);
-    if (tid < G::BT) {
-        GL[tid * P.KS1 + P.D] = ts;
-        GL[tid * P.KS1 + P.D + 1] = 1.f;
-    }
-    __syncthreads();
-    RNDE_STAMP(1);
-    {
-        f32x4 acc[G::MTS];
-        gemm_ksplit<NG>(P.pw1, P.MT1, P.K4_1, GL, P.KS1, RING, acc, wave_u, lane);
-#pragma unroll
-        for (int T = 0; T < G::MTS; ++T)
-            if (T < P.MT1) *(f32x4*)(PART + ((wave * G::MTS + T) * 64 + lane) * 4) = acc[T];
-    }
-    RNDE_STAMP(2);
-    __syncthreads();
-    RNDE_STAMP(3);
-    // (HL's time/bias rows are written here, not earlier: slower waves may still be reading HL in the
-    //  previous evaluation's gemm_rows until they pass the barrier above)
-    if (tid < G::BT) {
-        HL[tid * P.KS2 + P.H] = ts;
-        HL[tid * P.KS2 + P.H + 1] = 1.f;
-    }
-    for (int o = tid; o < P.H * G::BT; o += kThreads) {
-        const int c = o / P.H, r = o - c * P.H;
-        const int idx = part_index<NG>(r, c);
-        float v = 0.f;
-#pragma unroll
-        for (int w = 0; w < kWaves; ++w) v += PART[w * G::MTS * 256 + idx];
-        v = tanhf(v);
-        HL[c * P.KS2 + r] = v;
-        if (hdst) hdst[(size_t)(col0 + c) * P.H + r] = v;
-    }
-    RNDE_STAMP(4);
-    __syncthreads();
-    RNDE_STAMP(5);
-    gemm_rows<NG>(P.pw2, P.MT2, P.K4_2, HL, P.KS2, RING, kout, wave_u, lane);
-    RNDE_STAMP(6);
-#pragma unroll
-    for (int j = 0; j < G::TPW; ++j) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) kout[j][i] = act_apply(ACT2, kout[j][i]);
-    }
-    RNDE_STAMP(7);
-}
-
-// write a stage input into GL (rows < D only; rows D, D+1 belong to eval_f)
-template <int NG>
-__device__ __forceinline__ void put_g(const StepParams& P, float* GL, const Own<NG>& own, int j, f32x4 g) {
-    const int r0 = own.row0[j];
-    if (r0 < P.D) {
-        float* dst = GL + own.col * P.KS1 + r0;
-        if ((P.D & 3) == 0) *(f32x4*)dst = g;
-        else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (r0 + i < P.D) dst[i] = g[i];
         }
     }
 }
@@ -282,196 +144,6 @@ __device__ __forceinline__ StepState advance_state(const StepParams& P, int n, i
     const float none[4] = {0.f, 0.f, 0.f, 0.f};
     const StepState nop{};
     return advance_state_t<false>(P, n, lane, writer, out, none, nop);
-}
-
-enum { MODE_STEP = 0, MODE_INIT_A = 1, MODE_INIT_B = 2, MODE_FEVAL = 3 };
-
-// ------------------------------------------------------------------------------------------
-// The hot kernel.  MODE_STEP: one attempted Tsit5 step (6 f evaluations, error estimate) for
-// BT batch columns per workgroup; k1..k6 and uprev stay in registers for the whole attempt.
-// ------------------------------------------------------------------------------------------
-template <int NG, int ACT2, int MODE>
-__global__ __launch_bounds__(kThreads) void rnde_step_kernel(const StepParams P, const int n) {
-    using G = Geo<NG>;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* GL = smem;
-    float* HL = GL + G::BT * P.KS1;
-    float* PART = HL + G::BT * P.KS2;
-    float* RED = PART + kWaves * G::MTS * 256;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float* RING = RED + 192 + __builtin_amdgcn_readfirstlane(wave) * (kRing * 256);  // this wave's weight ring
-    const int wg = blockIdx.x, col0 = wg * G::BT;
-    const Own<NG> own(wave, lane);
-    const int gcol = col0 + own.col;
-    const bool colok = gcol < P.B;
-    const bool vec = (P.D & 3) == 0;
-    const bool writer = (wg == 0 && tid == 0);
-    const RecLayout L{(long long)P.D * P.Bpad, (long long)P.H * P.Bpad};
-
-    // zero the K padding of the LDS operand images once (rows D, D+1 / H, H+1 are set per f evaluation)
-    for (int i = tid; i < G::BT * P.KS1; i += kThreads)
-        if (i % P.KS1 >= P.D + 2) GL[i] = 0.f;
-    for (int i = tid; i < G::BT * P.KS2; i += kThreads)
-        if (i % P.KS2 >= P.H + 2) HL[i] = 0.f;
-
-    if constexpr (MODE == MODE_FEVAL) {
-        f32x4 kv[G::TPW];
-#pragma unroll
-        for (int j = 0; j < G::TPW; ++j)
-            put_g<NG>(P, GL, own, j, ld_tile(P.x + (size_t)gcol * P.D, own.row0[j], P.D, colok, P.xvec != 0));
-        eval_f<NG, ACT2>(P, GL, HL, PART, RING, P.forced_t, nullptr, col0, kv, tid);
-#pragma unroll
-        for (int j = 0; j < G::TPW; ++j) st_tile(P.dbg_out + (size_t)gcol * P.D, own.row0[j], P.D, colok, false, kv[j]);
-        return;
-    } else if constexpr (MODE == MODE_INIT_A || MODE == MODE_INIT_B) {
-        // ---- initial-step heuristic, SURVEY.md B.1 ----
-        float dt0 = 0.f;
-        if constexpr (MODE == MODE_INIT_B) {
-            const double N = (double)P.D * (double)P.Bn;
-            const double s0 = sum_partials(P.initpart, P.nwg, lane);
-            const double s1 = sum_partials(P.initpart + P.nwg, P.nwg, lane);
-            const float d0 = (float)sqrt(s0 / N), d1 = (float)sqrt(s1 / N), dtmax = P.t1 - P.t0;
-            int c0 = 0, cl = 0;
-            if (d0 < 1e-5f || d1 < 1e-5f) { dt0 = 1e-6f; c0 = 1; }
-            else dt0 = (d0 / d1) / 100.f;
-            if (dtmax < dt0) { dt0 = dtmax; cl = 1; }
-            if (writer) { P.initrec->d0 = d0; P.initrec->d1 = d1; P.initrec->dt0 = dt0; P.initrec->dt0_const = c0; P.initrec->dt0_clamped = cl; }
-        }
-        f32x4 xv[G::TPW], fv[G::TPW], kv[G::TPW];
-#pragma unroll
-        for (int j = 0; j < G::TPW; ++j) {
-            xv[j] = ld_tile(P.x + (size_t)gcol * P.D, own.row0[j], P.D, colok, P.xvec != 0);
-            if constexpr (MODE == MODE_INIT_B) {
-                fv[j] = ld_tile(P.f0 + (size_t)gcol * P.D, own.row0[j], P.D, true, vec);
-                const f32x4 u1 = xv[j] + dt0 * fv[j];
-                put_g<NG>(P, GL, own, j, u1);
-                st_tile(P.u1 + (size_t)gcol * P.D, own.row0[j], P.D, true, vec, u1);
-            } else {
-                put_g<NG>(P, GL, own, j, xv[j]);
-            }
-        }
-        const float ts = (MODE == MODE_INIT_B) ? P.t0 + dt0 : P.t0;
-        eval_f<NG, ACT2>(P, GL, HL, PART, RING, ts, (MODE == MODE_INIT_B) ? P.h1 : P.h0, col0, kv, tid);
-        float pa = 0.f, pb = 0.f;
-#pragma unroll
-        for (int j = 0; j < G::TPW; ++j) {
-            st_tile(((MODE == MODE_INIT_B) ? P.f1 : P.f0) + (size_t)gcol * P.D, own.row0[j], P.D, true, vec, kv[j]);
-            if (colok && own.row0[j] < P.D) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (own.row0[j] + i < P.D) {
-                        const float sk = P.abstol + fabsf(xv[j][i]) * P.reltol;
-                        if constexpr (MODE == MODE_INIT_A) {
-                            const float a = xv[j][i] / sk, b = kv[j][i] / sk;
-                            pa += a * a; pb += b * b;
-                        } else {
-                            const float a = (kv[j][i] - fv[j][i]) / sk;
-                            pa += a * a;
-                        }
-                    }
-                }
-            }
-        }
-        pa = wave_sum_f(pa); pb = wave_sum_f(pb);
-        if (lane == 0) { RED[wave] = pa; RED[8 + wave] = pb; }
-        __syncthreads();
-        if (tid == 0) {
-            float sa = 0.f, sb = 0.f;
-            for (int w = 0; w < kWaves; ++w) { sa += RED[w]; sb += RED[8 + w]; }
-            if constexpr (MODE == MODE_INIT_A) { P.initpart[wg] = sa; P.initpart[P.nwg + wg] = sb; }
-            else P.initpart[2 * P.nwg + wg] = sa;
-        }
-        return;
-    } else {
-        // ---- one attempted step ----
-        const StepState S = advance_state(P, n, lane, writer, &P.ctl[n & 1]);
-        if (S.done) return;
-        const float t = S.t;
-        const float dt = (!P.forced && (P.t1 - S.t < S.dtp)) ? (P.t1 - S.t) : S.dtp;
-        const int rec = P.tape ? n : (S.live == 0 ? 1 : 0);
-        float* R = P.arena + (long long)rec * P.rec_stride;
-        const float* upsrc; const float* k1p; bool upok, upvec;
-        if (S.live < 0) { upsrc = P.x; k1p = P.f0; upok = colok; upvec = P.xvec != 0; }
-        else { const float* Rl = P.arena + (long long)S.live * P.rec_stride; upsrc = Rl + L.unew(); k1p = Rl + L.k(7); upok = true; upvec = vec; }
-
-        // Rolled stage loop.  Sa[i] = sum_j a_{s+1+i, j} k_j is the running combination for the i-th stage still
-        // to come (same ascending-j association as the reference formula g = uprev + dt * sum_j a_sj k_j);
-        // after each stage the array shifts down by one.  E = sum_j btilde_j k_j.
-        f32x4 up[G::TPW], Sa[6][G::TPW], E[G::TPW], un[G::TPW];
-#pragma unroll
-        for (int j = 0; j < G::TPW; ++j) {
-            up[j] = ld_tile(upsrc + (size_t)gcol * P.D, own.row0[j], P.D, upok, upvec);
-            const f32x4 k1 = ld_tile(k1p + (size_t)gcol * P.D, own.row0[j], P.D, true, vec);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) Sa[i][j] = kFwdShift[0][i] * k1;
-            E[j] = kTsBt[0] * k1;
-            un[j] = up[j];
-        }
-#pragma unroll 1
-        for (int s = 1; s < 7; ++s) {  // zero-based stage: computes k_{s+1} = f(g_{s+1}, t + c_s dt)
-            const bool last = (s == 6);
-#pragma unroll
-            for (int j = 0; j < G::TPW; ++j) {
-                const f32x4 g = up[j] + dt * Sa[0][j];
-                put_g<NG>(P, GL, own, j, g);
-                if (last) { un[j] = g; st_tile(R + L.unew() + (size_t)gcol * P.D, own.row0[j], P.D, true, vec, g); }
-                else if (P.tape) st_tile(R + L.g(s + 1) + (size_t)gcol * P.D, own.row0[j], P.D, true, vec, g);
-            }
-            f32x4 kv[G::TPW];
-            eval_f<NG, ACT2>(P, GL, HL, PART, RING, t + kTsC[s] * dt, R + L.h(s + 1), col0, kv, tid);
-            const float bts = kTsBt[s];
-            float cs[5];
-#pragma unroll
-            for (int i = 0; i < 5; ++i) cs[i] = kFwdShift[s][i];
-#pragma unroll
-            for (int j = 0; j < G::TPW; ++j) {
-                st_tile(R + L.k(s + 1) + (size_t)gcol * P.D, own.row0[j], P.D, true, vec, kv[j]);
-                E[j] += bts * kv[j];
-#pragma unroll
-                for (int i = 0; i < 5; ++i) Sa[i][j] = Sa[i + 1][j] + cs[i] * kv[j];
-            }
-        }
-        // ---- embedded error estimate, SURVEY.md B.3: partial sum of (utilde / sk)^2 ----
-        float part = 0.f;
-#pragma unroll
-        for (int j = 0; j < G::TPW; ++j) {
-            if (colok) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float ut = dt * E[j][i];
-                    const float sk = P.abstol + fmaxf(fabsf(up[j][i]), fabsf(un[j][i])) * P.reltol;
-                    const float r = ut / sk;
-                    part += r * r;
-                }
-            }
-        }
-        part = wave_sum_f(part);
-        if (lane == 0) RED[wave] = part;
-        __syncthreads();
-        if (tid == 0) {
-            float s = 0.f;
-            for (int w = 0; w < kWaves; ++w) s += RED[w];
-            P.errpart[(size_t)(n & 1) * 3 * P.nwg + wg] = s;
-        }
-    }
-}
-
-// Finish: materialise the state after the last launched attempt and copy the live state out.
-template <int NG>
-__global__ __launch_bounds__(256) void rnde_finish_kernel(const StepParams P, const int n, float* __restrict__ u_out) {
-    using G = Geo<NG>;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const bool writer = (blockIdx.x == 0 && tid == 0);
-    const StepState S = advance_state(P, n, lane, writer, P.ctl_final);
-    if (!u_out) return;
-    const RecLayout L{(long long)P.D * P.Bpad, (long long)P.H * P.Bpad};
-    const float* src;
-    if (S.live < 0) src = P.x; else src = P.arena + (long long)S.live * P.rec_stride + L.unew();
-    const int col0 = blockIdx.x * G::BT;
-    for (int i = tid; i < G::BT * P.D; i += 256) {
-        const int c = col0 + i / P.D, r = i % P.D;
-        if (c < P.B) u_out[(size_t)c * P.D + r] = src[(size_t)c * P.D + r];
-    }
 }
 
 }  // namespace rnde

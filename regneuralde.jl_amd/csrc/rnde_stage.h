@@ -91,12 +91,10 @@ __global__ void rnde_stage_pack_kernel(const float* __restrict__ p, f32x4* __res
 // initial-step rule (kind 1), or the tape's own copy of p (kind 2).
 struct PackJob { void* dst; const float* src; long long total; int kind, which, kdim, pad; };   // src: kind 2 only (NULL = the parameter vector)
 struct PackJobs { PackJob j[8]; };
-template <int NG>
 __global__ void rnde_pack_all_kernel(const float* __restrict__ p, const PackJobs J, int D, int H) {
     const PackJob job = J.j[blockIdx.y];
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < job.total; i += (long long)gridDim.x * blockDim.x) {
         if (job.kind == 0) ((f32x4*)job.dst)[i] = stage_pack_elem(p, job.which, D, H, job.kdim, i);
-        else if (job.kind == 1) ((f32x4*)job.dst)[i] = pack_elem<NG>(p, job.which, D, H, job.kdim, i);
         else if (job.kind == 2) ((float*)job.dst)[i] = (job.src ? job.src : p)[i];
         else ((f32x4*)job.dst)[i] = ((const f32x4*)(job.src ? job.src : p))[i];      // kind 3: 16-byte copy (total counts float4s)
     }

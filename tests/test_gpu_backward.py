@@ -8,12 +8,10 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-CASES = [("test_node", 7, 1e-3, 3.0, 1.0, 3, 8), ("small", 20, 1e-3, 4.0, 1.0, 3, 8), ("mnist", 32, 1e-3, 3.0, 1.0, 3, 8),
-         ("test_node", 3, 1e-2, 5.0, 2.0, 18, 8), ("mnist", 19, 1e-2, 6.0, 2.0, 5, 8),
-         ("test_node", 3, 3e-2, 5.0, 2.0, 27, 4),   # <- the two test_node cases here contain a rejected step
-         ("small", 9, 1e-3, 4.0, 1.0, 4, 4), ("mnist", 12, 1e-3, 3.0, 1.0, 6, 4)]
-# every case also through the stage engine (col_tile 16)
-CASES = CASES + [c[:6] + (16,) for c in CASES if c[6] == 8] + [("mnist", 37, 1e-3, 3.0, 1.0, 7, 16), ("small", 33, 1e-3, 4.0, 1.0, 8, 16)]
+# (the two test_node cases at tol 1e-2 / 3e-2 contain a rejected step)
+CASES = [("test_node", 7, 1e-3, 3.0, 1.0, 3, 16), ("small", 20, 1e-3, 4.0, 1.0, 3, 16), ("mnist", 32, 1e-3, 3.0, 1.0, 3, 16),
+         ("test_node", 3, 1e-2, 5.0, 2.0, 18, 16), ("mnist", 19, 1e-2, 6.0, 2.0, 5, 16), ("test_node", 3, 3e-2, 5.0, 2.0, 27, 16),
+         ("small", 9, 1e-3, 4.0, 1.0, 4, 16), ("mnist", 12, 1e-3, 3.0, 1.0, 6, 16), ("mnist", 37, 1e-3, 3.0, 1.0, 7, 16), ("small", 33, 1e-3, 4.0, 1.0, 8, 16)]
 
 
 @pytest.mark.parametrize("kind,B,tol,scale,t1,seed,col_tile", CASES)
@@ -180,13 +178,16 @@ def test_stiffness_regulariser_matches_oracle(kind, B, tol, scale, seed, reg, ag
     assert rel_err(pb, pb64) <= 3e-3 + 3 * cp
 
 
-def test_stiffness_regulariser_needs_stage_engine():
+def test_retired_column_owner_tiles_are_refused():
+    """col_tile 4 / 8 selected the round-1 column-owner engine (retired in round 4, tools/experiments/column_owner/): creation says so."""
     from tests.test_gpu_forward import _cfg, _setup
     from tests.util import Node
     from regneuralde_jl_amd._lib import RndeError
     arch, p, x = _setup("small", 4, 0, 1.0)
-    with pytest.raises(RndeError):
-        Node(_cfg(arch, 4, regularize=2, col_tile=8))
+    for tile in (4, 8):
+        with pytest.raises(RndeError) as e:
+            Node(_cfg(arch, 4, regularize=2, col_tile=tile))
+        assert "retired" in str(e.value)
 
 
 @pytest.mark.parametrize("kind,B,tol,scale,saveat,reg", [("test_node", 5, 1e-3, 3.0, np.linspace(0, 1, 7), 1), ("small", 12, 1e-3, 4.0, np.array([0.1, 0.5, 0.9]), 1),

@@ -28,7 +28,7 @@ def test_max_attempts_is_reported_not_hidden():
     assert e.value.status == MAX_ATT
 
 
-@pytest.mark.parametrize("col_tile", [16, 64, 8])
+@pytest.mark.parametrize("col_tile", [16, 64])
 def test_nonfinite_input_is_reported(col_tile):
     from regneuralde_jl_amd._lib import RndeError
     node, p, x = _mk("small", 9, reltol=1e-3, abstol=1e-3, col_tile=col_tile)
@@ -59,14 +59,6 @@ def test_bad_arguments():
     wide = make_arch([8, 100, 100, 8], ["tanh", "tanh", "identity"], False)   # not the MNIST form and wider than the chain engine
     with pytest.raises(RndeError) as e:
         Node(_cfg(wide, 4))
-    assert e.value.status == BAD_ARG
-
-
-def test_saveat_is_refused_on_the_column_owner_engine():
-    from regneuralde_jl_amd._lib import RndeError
-    node, p, x = _mk("small", 9, reltol=1e-3, abstol=1e-3, col_tile=8)
-    with pytest.raises(RndeError) as e:
-        node.forward_saveat(x, p, np.array([0.5], dtype=np.float32))
     assert e.value.status == BAD_ARG
 
 
@@ -172,7 +164,7 @@ def test_stage_engine_geometry_corners(D, H, B, persist, monkeypatch):
     assert rel_err(gp, p64) <= 2e-3 + 4 * rel_err(p32, p64)
 
 
-@pytest.mark.parametrize("kind,B,col_tile", [("mnist", 19, 16), ("small", 33, 16), ("test_node", 7, 8), ("mnist", 12, 4)])
+@pytest.mark.parametrize("kind,B,col_tile", [("mnist", 19, 16), ("small", 33, 16), ("test_node", 7, 16), ("mnist", 12, 16)])
 def test_results_do_not_depend_on_uninitialised_memory(kind, B, col_tile, monkeypatch):
     """Ragged batches leave padded columns in every tape array.  With RNDE_POISON=1 the library fills each fresh allocation with
     0xFF bytes (NaN): forward and reverse results must be the same, bit for bit, as without it.  (This caught the parameter-gradient

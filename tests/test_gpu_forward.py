@@ -31,9 +31,7 @@ def _cfg(arch, B, **kw):
     return make_cfg(dims, acts, B, time_dep=arch.time_dep, pre_act=arch.pre_act, **kw)
 
 
-@pytest.mark.parametrize("kind,B,col_tile", [("mnist", 16, 8), ("mnist", 13, 8), ("mnist", 8, 4), ("test_node", 1, 8),
-                                             ("test_node", 5, 4), ("small", 9, 8), ("mnist", 16, 16), ("mnist", 37, 16),
-                                             ("test_node", 3, 16), ("small", 9, 16)])
+@pytest.mark.parametrize("kind,B,col_tile", [("mnist", 16, 16), ("mnist", 37, 16), ("mnist", 13, 16), ("test_node", 1, 16), ("test_node", 3, 16), ("small", 9, 16)])
 def test_feval_matches_oracle(kind, B, col_tile):
     from tests.util import Node, Oracle
     arch, p, x = _setup(kind, B, 1)
@@ -45,8 +43,7 @@ def test_feval_matches_oracle(kind, B, col_tile):
     assert np.abs(got - ref32).max() <= 2e-5
 
 
-@pytest.mark.parametrize("kind,B,col_tile", [("mnist", 16, 8), ("mnist", 11, 8), ("mnist", 12, 4), ("test_node", 3, 8), ("small", 9, 8),
-                                             ("mnist", 16, 16), ("mnist", 21, 16), ("test_node", 3, 16), ("small", 9, 16)])
+@pytest.mark.parametrize("kind,B,col_tile", [("mnist", 16, 16), ("mnist", 21, 16), ("mnist", 11, 16), ("test_node", 3, 16), ("small", 9, 16)])
 def test_attempt_matches_oracle(kind, B, col_tile):
     from tests.util import Node, Oracle
     arch, p, x = _setup(kind, B, 2)
@@ -72,7 +69,7 @@ def test_attempt_matches_oracle(kind, B, col_tile):
                                                        ("mnist", 32, 1e-3, 3.0, 1.0, 3), ("test_node", 3, 1e-2, 10.0, 3.0, 0),
                                                        ("test_node", 3, 1e-2, 8.0, 3.0, 8), ("mnist", 19, 1e-2, 6.0, 2.0, 5),
                                                        ("small", 6, 1e-2, 15.0, 2.0, 12)])
-@pytest.mark.parametrize("col_tile", [16, 8])
+@pytest.mark.parametrize("col_tile", [16])
 def test_forward_solve_exact_sequence(kind, B, tol, scale, t1, seed, col_tile):
     """Truncation-dominated regime (EEst >> fp32 noise floor eps*dt*|k|/tol): accept/reject sequence, NFE and
     the dt sequence must match the oracle; includes cases with rejected steps."""
@@ -99,7 +96,7 @@ def test_forward_solve_exact_sequence(kind, B, tol, scale, t1, seed, col_tile):
     assert len(got["saveval"]) == len(ref["saveval"])
 
 
-@pytest.mark.parametrize("col_tile", [16, 8])
+@pytest.mark.parametrize("col_tile", [16])
 @pytest.mark.parametrize("kind,B", [("test_node", 1), ("mnist", 64)])
 def test_forward_solve_reference_tolerance(kind, B, col_tile):
     """reltol = abstol = 1.4e-8 in fp32 (the reference's setting, experiments/mnist_node.jl:122-123) sits on the

@@ -6,7 +6,6 @@
 #include "rnde_stage.h"
 #include "rnde_bstage.h"
 #include "rnde_stage_persist2.h"
-#include "rnde_stage_wide.h"
 #include "rnde_bstage_persist.h"
 #include "rnde_solve_sync.h"
 #include "rnde_binit_stage.h"
@@ -74,7 +73,6 @@ struct rnde_node {
     // persistent attempt kernel (rnde_stage_persist.h): 1 = in use, 0 = off (RNDE_PERSIST=0), -1 = disabled after a failure
     int wgrad_side_pct = 30, stage_generic = 0;
     int persist_clean = 0, persist_retry_after = 8, persist_fallbacks = 0;   // non-sticky fallback: clean multi-launch solves since the last failure, when to try again   // fixed at creation (config fields; RNDE_* environment overrides are read once, there)
-    int wide = 0;        // one workgroup per column tile for all rows (rnde_stage_wide.h): 1 = use it (RNDE_WIDE=1 at creation; an experiment, not selected automatically)
     int persist2 = -1;   // two column tiles per workgroup in the forward attempt kernel: -1 automatic (by tile count), 0 never, 1 whenever possible (RNDE_PERSIST2, read at creation)
     int persist = 0, persist_spins = kPersistMaxSpins; int tslab_Bpad = -1; size_t tslab_bytes = 0; float* tslab = nullptr; unsigned *pabort = nullptr, *pxcc = nullptr; unsigned* h_pchk = nullptr;
     // the whole forward solve as one launch (rnde_stage_solve.h): 1 = use it where it applies, 0 = off (RNDE_STAGE_SOLVE=0 at creation); meeting granules, epoch of their tags
@@ -492,7 +490,6 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
         h->persist = (h->engine == 2 && h->sR <= 8 && !off) ? 1 : 0;
         if (const char* e2 = getenv("RNDE_PERSIST_SPINS")) h->persist_spins = atoi(e2);
         if (const char* e3 = getenv("RNDE_PERSIST2")) h->persist2 = atoi(e3);
-        if (const char* e4 = getenv("RNDE_WIDE")) h->wide = atoi(e4);
         h->wgrad_side_pct = c->wgrad_side_pct < 0 ? 0 : (c->wgrad_side_pct == 0 ? 30 : std::min(100, c->wgrad_side_pct));
         if (const char* e3 = getenv("RNDE_WGRAD_SIDE")) h->wgrad_side_pct = atoi(e3);
         h->stage_generic = (c->stage_generic != 0 || getenv("RNDE_STAGE_GENERIC") != nullptr) ? 1 : 0;
@@ -642,27 +639,13 @@ static hipError_t stage_attempt(rnde_node* h, const StageParams& Q, int n, hipSt
         if (hipError_t e = slab_prepare(h, Q.Bpad16, s); e != hipSuccess) return e;
         const dim3 grid(8 * Q.R * ((Q.C + 7) / 8));   // a column tile's row blocks share blockIdx % 8 (same XCD)
         const bool fix = Q.WT == 7 && Q.HT == 7 && Q.K2b == 7 && Q.MT == 49 && Q.R == 7 && h->D == 784 && h->H == 100 && !h->stage_generic;
-        // batches that fill the chip with column tiles alone: one workgroup per tile for all rows, no exchange between workgroups (rnde_stage_wide.h)
-        // (opt-in: RNDE_WIDE=1.  Measured at B = 4096: 221 us per attempt against 178 us for the two-tile row-block kernels -- see the header)
-        if (fix && h->wide == 1) {
-            const size_t ldsw = sizeof(float) * ((size_t)16 * kWideKG + 16 * kWideKH + 3 * 7 * 8);
-            if (h->act2) hipLaunchKernelGGL((rnde_stage_wide_kernel<1>), dim3(Q.C), dim3(64 * 7), ldsw, s, Q, n, Y);
-            else hipLaunchKernelGGL((rnde_stage_wide_kernel<0>), dim3(Q.C), dim3(64 * 7), ldsw, s, Q, n, Y);
-            return hipGetLastError();
-        }
         // batches that fill the chip more than once: two column tiles per workgroup (rnde_stage_persist2.h; bit-identical results).
         // RNDE_PERSIST2=0 keeps one tile per workgroup (A/B and the bit-identity test), =1 takes two whenever the tile count is even.
         if (fix && Q.C % 2 == 0 && h->persist2 != 0 && (Q.C >= kPersist2MinTiles || h->persist2 >= 1)) {
             const dim3 grid2(8 * Q.R * ((Q.C / 2 + 7) / 8));
             const size_t lds2 = sizeof(float) * (2 * 2 * 16 * (16 * 7 + 4) + 32 * 3);
-            if (h->persist2 == 3) {      // (skewed form: MFMA step of one tile beside the element-wise step of the other)
-                if (h->act2) hipLaunchKernelGGL((rnde_stage_attempt_mt_kernel<1, 2, 2>), grid2, dim3(64 * 7), lds2, s, Q, n, Y);
-                else hipLaunchKernelGGL((rnde_stage_attempt_mt_kernel<0, 2, 2>), grid2, dim3(64 * 7), lds2, s, Q, n, Y);
-            } else if (h->persist2 == 2) {      // (lock-step form: A/B only)
-                if (h->act2) hipLaunchKernelGGL((rnde_stage_attempt_mt_kernel<1, 2, 0>), grid2, dim3(64 * 7), lds2, s, Q, n, Y);
-                else hipLaunchKernelGGL((rnde_stage_attempt_mt_kernel<0, 2, 0>), grid2, dim3(64 * 7), lds2, s, Q, n, Y);
-            } else if (h->act2) hipLaunchKernelGGL((rnde_stage_attempt_mt_kernel<1, 2, 1>), grid2, dim3(64 * 7), lds2, s, Q, n, Y);
-            else hipLaunchKernelGGL((rnde_stage_attempt_mt_kernel<0, 2, 1>), grid2, dim3(64 * 7), lds2, s, Q, n, Y);
+            if (h->act2) hipLaunchKernelGGL((rnde_stage_attempt_mt_kernel<1, 2>), grid2, dim3(64 * 7), lds2, s, Q, n, Y);
+            else hipLaunchKernelGGL((rnde_stage_attempt_mt_kernel<0, 2>), grid2, dim3(64 * 7), lds2, s, Q, n, Y);
             return hipGetLastError();
         }
         if (fix) {

@@ -278,16 +278,11 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
 __device__ __forceinline__ void dma_unit(const f32x4* __restrict__ gsrc_lane, float* lds_slot_uniform) {
-#ifndef RNDE_EXP_NODMA   // (ablation builds only: tools/build_variant.sh NAME -DRNDE_EXP_NODMA)
     __builtin_amdgcn_global_load_lds((gbl_void_t*)gsrc_lane, (lds_void_t*)lds_slot_uniform, 16, 0, 0);
-#endif
 }
 // the same with the non-temporal hint (a stream that is read once: keep it from displacing what a neighbouring kernel keeps in L2)
 __device__ __forceinline__ void dma_unit_nt(const f32x4* __restrict__ gsrc_lane, float* lds_slot_uniform) {
-#ifndef RNDE_DMA_NT_AUX
-#define RNDE_DMA_NT_AUX 2
-#endif
-    __builtin_amdgcn_global_load_lds((gbl_void_t*)gsrc_lane, (lds_void_t*)lds_slot_uniform, 16, 0, RNDE_DMA_NT_AUX);   // aux bit 0 = sc0, bit 1 = nt, bit 4 = sc1
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)gsrc_lane, (lds_void_t*)lds_slot_uniform, 16, 0, 2);   // aux bit 0 = sc0, bit 1 = nt, bit 4 = sc1
 }
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }

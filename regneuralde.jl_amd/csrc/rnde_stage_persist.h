@@ -87,11 +87,7 @@ __device__ __forceinline__ bool slab_poll_sum(const PersistSync& Y, int buf, int
 #pragma unroll
         for (int r = 0; r < kSMaxW; ++r)
             if (r < R) { const unsigned a = e[r][0] > e[r][1] ? e[r][0] : e[r][1], b = e[r][2] > e[r][3] ? e[r][2] : e[r][3]; const unsigned c = a > b ? a : b; m = m > c ? m : c; }
-#ifdef RNDE_ABL_NOPOLL      // ablation (tools/ablate_attempt.sh): the first read is taken as it comes -- what a stage costs without the hand-off's wait
-        const bool ok = true;
-#else
         const bool ok = m != kSlabEmpty;
-#endif
         if (__all(ok)) {
             // (scalar adds on purpose: the vector form `zs += bitcast(e[r])` over buffer-load results was miscompiled by this
             //  toolchain into v_pk_add_f32 with op_sel_hi:[0,0] in the tagged form of this helper -- two of four sums wrong)
@@ -114,20 +110,8 @@ __device__ __forceinline__ bool slab_poll_sum(const PersistSync& Y, int buf, int
     }
 }
 
-// ablations of the forward attempt kernel (profiles/r03_attempt_ablation.csv; results are WRONG by construction, only the time is read):
-//   RNDE_ABL_NOPOLL    polls replaced by immediate reads;   RNDE_ABL_NOTANH   tanh replaced by a move;
-//   RNDE_ABL_NOTAPE    no tape stores;                      RNDE_ABL_MFMAONLY the MFMAs of the six stages alone, operands in registers
-#ifdef RNDE_ABL_NOTANH
-#define PTANH2(...) (__VA_ARGS__)
-#else
-#define PTANH2(...) tanh_fast2(__VA_ARGS__)
-#endif
-#ifdef RNDE_ABL_NOTAPE
-#define PTAPE(...) do { } while (0)
-#else
-#define PTAPE(...) do { __VA_ARGS__; } while (0)
-#endif
-
+// (the ablation builds of this kernel -- no polls / no tanh / no tape / MFMAs alone, profiles/r0N_attempt_ablation.csv -- are made by patching a
+//  copy of this file: tools/experiments/attempt_ablation/)
 #ifdef RNDE_DIAG
 #define PSTAMP(i) do { if (P.dbg_out && wg == 0 && tid == 0) ((unsigned long long*)P.dbg_out)[i] = clock64(); } while (0)
 // per-wave stamps of workgroup 0: [64 + ((stage - 1) * 8 + wave) * 8 + k]
@@ -288,11 +272,6 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
         f32x4 bg[kSMaxW];
 #pragma unroll
         for (int kb = 0; kb < kSMaxW; ++kb) if (kb < gWT) bg[kb] = *(const f32x4*)(gbp + 16 * kb);
-#ifdef RNDE_LDS_PREFETCH
-        // (measured in round 3 and not kept: with all seven operand reads in flight before the first MFMA -- the scheduler otherwise emits read,
-        //  wait, four MFMAs, read, wait ... -- the attempt takes 27.4 us against 27.2: the two waves of a SIMD already cover each other's LDS waits)
-        if constexpr (FIX) __builtin_amdgcn_sched_barrier(0);
-#endif
         if (w < gHT) {
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -343,30 +322,6 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
     auto stage = [&](auto sc) {
         constexpr int s = decltype(sc)::value;
         if (!alive) return;
-#ifdef RNDE_ABL_MFMAONLY
-        if constexpr (FIX) {      // the 26 + 28 MFMAs of a stage and nothing else: B operands are the previous phase's accumulators (registers)
-            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kb = 0; kb < 7; ++kb) {
-                a0 = mfma16(wB[kb][0], c_un[kb & 3], a0);
-                if (16 * kb + 4 < 102) a1 = mfma16(wB[kb][1], c_un[(kb + 1) & 3], a1);
-                if (16 * kb + 8 < 102) a0 = mfma16(wB[kb][2], c_un[(kb + 2) & 3], a0);
-                if (16 * kb + 12 < 102) a1 = mfma16(wB[kb][3], c_un[(kb + 3) & 3], a1);
-            }
-            const f32x4 kvv = a0 + a1;
-            f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kb = 0; kb < 7; ++kb) {
-                b0 = mfma16(wD[kb][0], kvv[kb & 3], b0);
-                b1 = mfma16(wD[kb][1], kvv[(kb + 1) & 3], b1);
-                b0 = mfma16(wD[kb][2], kvv[(kb + 2) & 3], b0);
-                b1 = mfma16(wD[kb][3], kvv[(kb + 3) & 3], b1);
-            }
-            c_un = b0 + b1;
-            if (s == 6) part0 += c_un[0] + c_un[1] + c_un[2] + c_un[3];
-            return;
-        }
-#endif
         const float ts = fmaf(tsC(s), dt, t);
         float* hdst = R + L.h(s + 1);
         float* kdst = R + L.k(s + 1);
@@ -384,13 +339,13 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
             float pre[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) pre[i] = fmaf(w1t_own[i], ts, zs[i]) + b1_own[i];     // (rows that are no hidden unit: coefficients 0, value unused)
-            const f32x2 t01 = PTANH2((f32x2){pre[0], pre[1]}), t23 = PTANH2((f32x2){pre[2], pre[3]});
+            const f32x2 t01 = tanh_fast2((f32x2){pre[0], pre[1]}), t23 = tanh_fast2((f32x2){pre[2], pre[3]});
             f32x4 hv = {t01.x, t01.y, t23.x, t23.y};
             if (w == 6) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) hv[i] = own_kind[i] == 0 ? hv[i] : fmaf(own_c1[i], ts, own_c0[i]);
             }
-            PTAPE(if (own_hstore) *(f32x4*)(hdst + own_hd[0]) = hv);
+            if (own_hstore) *(f32x4*)(hdst + own_hd[0]) = hv;
 #pragma unroll
             for (int i = 0; i < 4; ++i) HL[own_hl[0] + 4 * i] = hv[i];      // kperm: the four rows of a lane sit 4 floats apart
         } else if (w < gHT) {      // this wave's own hidden tile: addressing precomputed (own_*)
@@ -399,7 +354,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
 #pragma unroll
             for (int i = 0; i < 4; ++i) pre[i] = own_kind[i] == 0 ? fmaf(w1t_own[i], ts, zs[i]) + b1_own[i] : 0.f;
             // two tanh per instruction (v_pk_fma_f32): the 4 rows of this lane as two pairs
-            const f32x2 t01 = PTANH2((f32x2){pre[0], pre[1]}), t23 = PTANH2((f32x2){pre[2], pre[3]});
+            const f32x2 t01 = tanh_fast2((f32x2){pre[0], pre[1]}), t23 = tanh_fast2((f32x2){pre[2], pre[3]});
             const float th4[4] = {t01.x, t01.y, t23.x, t23.y};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -419,7 +374,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
                 const int hr = h0 + i;
                 pre[i] = (hr < gH) ? fmaf(W1t[hr], ts, z[i]) + b1[hr] : 0.f;
             }
-            const f32x2 t01 = PTANH2((f32x2){pre[0], pre[1]}), t23 = PTANH2((f32x2){pre[2], pre[3]});
+            const f32x2 t01 = tanh_fast2((f32x2){pre[0], pre[1]}), t23 = tanh_fast2((f32x2){pre[2], pre[3]});
             const float th4[4] = {t01.x, t01.y, t23.x, t23.y};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -453,9 +408,6 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
             f32x4 bf[kSMaxHT];
 #pragma unroll
             for (int kb = 0; kb < kSMaxHT; ++kb) if (kb < gK2b) bf[kb] = *(const f32x4*)(hb + 16 * kb);
-#ifdef RNDE_LDS_PREFETCH
-            if constexpr (FIX) __builtin_amdgcn_sched_barrier(0);      // (as in phase D)
-#endif
 #pragma unroll
             for (int kb = 0; kb < kSMaxHT; ++kb) {
                 if (kb < gK2b) {      // (FIX: the k-steps past row H + 1 multiply zeros and are left out -- 26 MFMAs instead of 28)
@@ -467,7 +419,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
             }
             kv = acc0 + acc1;
             if (ACT2) {
-                const f32x2 a01 = PTANH2((f32x2){kv[0], kv[1]}), a23 = PTANH2((f32x2){kv[2], kv[3]});
+                const f32x2 a01 = tanh_fast2((f32x2){kv[0], kv[1]}), a23 = tanh_fast2((f32x2){kv[2], kv[3]});
                 kv = (f32x4){a01.x, a01.y, a23.x, a23.y};
             }
             if constexpr (!FIX) {
@@ -482,14 +434,14 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
             slab_clears_done();      // (issued two phases ago: nothing to wait for in practice) before this stage's put, see slab_put
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (tile_ok) {
-                PTAPE(st4(kdst + co, r0, gD, true, vec, kv));
+                st4(kdst + co, r0, gD, true, vec, kv);
                 f32x4 acc = tsA(s + 1, 0) * c_k[0];
 #pragma unroll
                 for (int j = 1; j < 6; ++j) if (j < s) acc = fma4(tsA(s + 1, j), c_k[j], acc);
                 acc = fma4(tsA(s + 1, s), kv, acc);
                 v = fma4(dt, acc, c_up);
-                if (s == 5) { PTAPE(st4(R + L.unew() + co, r0, gD, true, vec, v)); c_un = v; }
-                else if (P.tape) PTAPE(st4(R + L.g(s + 2) + co, r0, gD, true, vec, v));
+                if (s == 5) { st4(R + L.unew() + co, r0, gD, true, vec, v); c_un = v; }
+                else if (P.tape) st4(R + L.g(s + 2) + co, r0, gD, true, vec, v);
                 c_k[s] = kv;
             }
             PSTAMP(7 + 5 * (s - 1));
@@ -499,7 +451,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
             WSTAMP(s, 6);
         } else {
             if (tile_ok) {
-                PTAPE(st4(kdst + co, r0, gD, true, vec, kv));
+                st4(kdst + co, r0, gD, true, vec, kv);
                 const f32x4 up = c_up, un = c_un;
                 f32x4 acc = tsBt(0) * c_k[0];
 #pragma unroll

@@ -1,10 +1,10 @@
 """Ablation of the forward attempt kernel: the same launch geometry with (i) polls replaced by immediate reads,
 (ii) tanh replaced by a move, (iii) no tape stores, (iv) the MFMAs alone with operands in registers -- the measured floor per attempted step.
-Variants are built by tools/ablate_attempt.sh (compile-time switches of rnde_stage_persist.h; their RESULTS are wrong by construction).
+Variants are built by build_variants.sh beside this file (a patched COPY of rnde_stage_persist.h; their RESULTS are wrong by construction).
 Each variant runs in its own process; back-to-back forced attempts (rnde_bench_attempt / _taped), B = 512 and B = 4096, three rounds.
-    python tools/ablate_attempt.py > profiles/r03_attempt_ablation.csv"""
+    python tools/experiments/attempt_ablation/ablate_attempt.py > profiles/r04_attempt_ablation.csv"""
 import os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", ".."))
 code = r'''
 import ctypes as C, sys, os
 sys.path.insert(0, '.')

@@ -32,7 +32,7 @@ ALG_BYTES = lambda B: 34 * 4 * D * B + 6 * 4 * P_DYN   # 34 A + 
 ALG_FLOPS = lambda B: 6 * 2 * B * ((D + 1) * H + (H + 1) * D)
 HBM_PEAK_GBS = 8000.0                              # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 
 
 def build_model(rn, device, batch, seed=1999):
@@ -94,6 +94,26 @@ def cpu_baseline(batch=512, steps=2, single_thread_batch=128):
                               "sample": f"1 training step, batch {single_thread_batch} of the same workload, one thread", "nfe": nfe1}}
 
 
+def committed_traffic(suffix, wants, rounds):
+    """HBM bytes per launch of the first kernel among `wants` found in profiles/<round>_pmc_hbm_traffic<suffix>.csv (separate rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes: tools/pmc_summary.py) -> (bytes, kernel, source) or None."""
+    import csv
+    for rnd in rounds:
+        pf = os.path.join(ROOT, "profiles", f"{rnd}_pmc_hbm_traffic{suffix}.csv")
+        if not os.path.exists(pf):
+            continue
+        rows = [r for r in csv.reader(l for l in open(pf) if not l.startswith("#")) if r]
+        head = [l[1:].strip() for l in open(pf) if l.startswith("#")]
+        for want in wants:
+            for row in rows:
+                if want in row[0]:
+                    stamp = [l for l in head if l.startswith("collected")]
+                    cmd = [l for l in head if "bench.py" in l]
+                    return float(row[4]), want, (f"profiles/{rnd}_pmc_hbm_traffic{suffix}.csv (separate --pmc passes of `{cmd[0].split('-- ')[-1] if cmd else 'bench.py'}`, NOT this run"
+                                                 + (f"; {stamp[0]}" if stamp else "") + ")")
+    return None
+
+
 def attempt_roofline_at(B, device, steps=3, warmup=2):
     """The roofline unit (one attempted Tsit5 step of the taped forward sweep, timed inside training steps with HIP events) at another
     per-GPU batch: B = 4096 fills the chip eight times over, where the attempt is no latency chain any more."""
@@ -127,6 +147,10 @@ def attempt_roofline_at(B, device, steps=3, warmup=2):
            "alg_bytes_per_attempt": ALG_BYTES(B), "mfma_f32_tflops": ALG_FLOPS(B) / t_att / 1e12, "mfma_frac": ALG_FLOPS(B) / t_att / 1e12 / MFMA_F32_PEAK_TF,
            "samples_per_s_fwd_rev_no_update": B * steps / el,
            "kernel": "the same taped attempted-step kernel at a per-GPU batch of %d (loss forward + reverse, no optimiser update, fixed weights)" % B}
+    if B == 4096:      # the committed PMC passes of `bench.py --batch 4096` (two column tiles per workgroup, one launch per attempted step)
+        tr = committed_traffic("_B4096", ["rnde_stage_attempt_mt_kernel", "rnde_stage_attempt_kernel"], (PROFILE_ROUND,))
+        if tr is not None:
+            out["traffic"], out["traffic_kernel"], out["traffic_source"] = tr[0], tr[1] + " (1 launch = 1 attempted step)", tr[2]
     del model
     torch.cuda.empty_cache()
     return out
@@ -590,33 +614,29 @@ def main():
                 "mfma_frac": ALG_FLOPS(B) / t_att / 1e12 / MFMA_F32_PEAK_TF}
         # HBM traffic per launch of that kernel: PMC counters cannot be collected from inside the bench; the committed separate
         # passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same command, corrected as MI355X_MICROARCH.md prescribes) are
-        # reported when present, with their source
+        # reported when present, with their source.  `traffic` is per LAUNCH like `achieved`; the one-launch solve's launch holds
+        # `units_per_launch` attempted steps of the PROFILED run (its step count differs from this run's: the per-attempt figure is the comparable one).
         try:
-            import csv
-            for rnd in ((PROFILE_ROUND, "r02", "r01") if B == 512 else ()):      # the committed passes are of the B = 512 bench
-                pf = os.path.join(ROOT, "profiles", f"{rnd}_pmc_hbm_traffic.csv")
-                if not os.path.exists(pf):
-                    continue
-                want = "rnde_stage_attempt_kernel" if (stage_engine and nl == 1) else ("rnde_stage_kernel<1, 1>" if stage_engine else "rnde_step_kernel")
-                for row in csv.reader(l for l in open(pf) if not l.startswith("#")):
-                    if row and want in row[0]:
-                        roof["traffic"] = float(row[4]) * (7 if (stage_engine and nl == 7) else 1)
-                        stamp = [l[1:].strip() for l in open(pf) if l.startswith("# collected")]
-                        roof["traffic_source"] = (f"profiles/{rnd}_pmc_hbm_traffic.csv (separate --pmc passes of this command, NOT this run; bytes per attempted step"
-                                                  + (f"; {stamp[0]}" if stamp else "") + ")")
-                        break
-                if roof["traffic"] is not None:
-                    break
+            if B == 512:      # the committed passes are of the B = 512 bench
+                wants = (["rnde_stage_solve_kernel"] if one_launch else []) + (["rnde_stage_attempt_kernel"] if (stage_engine and nl == 1) else []) + ["rnde_stage_kernel<1, 1>"]
+                tr = committed_traffic("", wants, (PROFILE_ROUND, "r03") if not one_launch else (PROFILE_ROUND,))
+                if tr is not None:
+                    roof["traffic"], roof["traffic_source"] = tr[0] * (7 if tr[1].startswith("rnde_stage_kernel") else 1), tr[2]
+                    if tr[1] == "rnde_stage_solve_kernel":
+                        pa = committed_traffic("", ["attempts_per_solve_launch"], (PROFILE_ROUND,))
+                        if pa is not None:
+                            roof["traffic_per_attempt"] = tr[0] / pa[0]
+                            roof["traffic_attempts_per_launch_in_that_run"] = pa[0]
         except Exception:
             pass
-        # the measured floor of this kernel's decomposition: its MFMAs alone with operands in registers (profiles/r03_attempt_ablation.csv)
+        # the measured floor of this kernel's decomposition: its MFMAs alone with operands in registers (profiles/r0N_attempt_ablation.csv)
         try:
             import csv
-            for row in csv.DictReader(l for l in open(os.path.join(ROOT, "profiles", "r03_attempt_ablation.csv")) if not l.startswith("#")):
+            for row in csv.DictReader(l for l in open(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_attempt_ablation.csv")) if not l.startswith("#")):
                 if row["variant"] == "mfmaonly" and int(row["B"]) == B:
                     roof["ceiling_us"] = float(row["us_taped"])
                     roof["ceiling_frac"] = ALG_BYTES(B) / (roof["ceiling_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
-                    roof["ceiling_source"] = "profiles/r03_attempt_ablation.csv: the kernel's MFMAs alone (operands in registers, no polls / tanh / LDS / tape), same launch geometry, back to back"
+                    roof["ceiling_source"] = "profiles/" + PROFILE_ROUND + "_attempt_ablation.csv: the kernel's MFMAs alone (operands in registers, no polls / tanh / LDS / tape), same launch geometry, back to back"
         except Exception:
             pass
         out = {"metric": "training-step samples/sec + mean NFE, MNIST Neural ODE bs=512",

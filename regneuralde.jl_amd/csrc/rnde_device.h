@@ -297,7 +297,9 @@ __device__ __forceinline__ float act_apply(int act, float v) { return act ? tanh
 // the hardware v_exp_f32 / v_rcp_f32 add at most ~1 ulp.  Accuracy matters beyond parity: at the reference's
 // tolerance the step size is set by rounding noise, so a sloppy tanh would RAISE NFE.
 __device__ __forceinline__ float tanh_fast(float x) {
-    const float ax = fabsf(x), x2 = x * x;
+    // (|x| clamped at 9.1 instead of a select behind the formula: the formula's value AT 9.1 is exactly 1.0f, so every result is the same
+    //  bit pattern as with the select, and |x| + clamp is ONE v_min_f32 with a source modifier where abs, compare and select were three)
+    const float ax = fminf(fabsf(x), 9.1f), x2 = x * x;
     float p = -0.00671552f;
     p = fmaf(p, x2, 0.02136713f);
     p = fmaf(p, x2, -0.05391917f);
@@ -313,8 +315,7 @@ __device__ __forceinline__ float tanh_fast(float x) {
     const float dd = e + 1.0f;
     float r = __builtin_amdgcn_rcpf(dd);
     r = fmaf(fmaf(-dd, r, 1.0f), r, r);
-    float big = fmaf(-2.0f, r, 1.0f);
-    big = ax > 9.1f ? 1.0f : big;
+    const float big = fmaf(-2.0f, r, 1.0f);
     return ax < 0.55f ? small : copysignf(big, x);
 }
 // two values per instruction (v_pk_fma_f32 / v_pk_mul_f32): same operation sequence per component as tanh_fast, so
@@ -322,7 +323,7 @@ __device__ __forceinline__ float tanh_fast(float x) {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 tanh_fast2(f32x2 x) {
-    const f32x2 ax = __builtin_elementwise_abs(x), x2 = x * x;
+    const f32x2 ax = {fminf(fabsf(x.x), 9.1f), fminf(fabsf(x.y), 9.1f)}, x2 = x * x;
     f32x2 p = fma2((f32x2)(-0.00671552f), x2, (f32x2)(0.02136713f));
     p = fma2(p, x2, (f32x2)(-0.05391917f));
     p = fma2(p, x2, (f32x2)(0.13333165f));
@@ -339,8 +340,8 @@ __device__ __forceinline__ f32x2 tanh_fast2(f32x2 x) {
     r = fma2(fma2(-dd, r, (f32x2)(1.0f)), r, r);
     const f32x2 big = fma2((f32x2)(-2.0f), r, (f32x2)(1.0f));
     f32x2 o;
-    o.x = ax.x < 0.55f ? sm.x : copysignf(ax.x > 9.1f ? 1.0f : big.x, x.x);
-    o.y = ax.y < 0.55f ? sm.y : copysignf(ax.y > 9.1f ? 1.0f : big.y, x.y);
+    o.x = ax.x < 0.55f ? sm.x : copysignf(big.x, x.x);
+    o.y = ax.y < 0.55f ? sm.y : copysignf(big.y, x.y);
     return o;
 }
 __device__ __forceinline__ float act_apply_fast(int act, float v) { return act ? tanh_fast(v) : v; }

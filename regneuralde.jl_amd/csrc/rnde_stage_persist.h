@@ -36,8 +36,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // ---- slab hand-off: the data is its own validity ---------------------------------------------------------------------------
 // A slab tile (one f32x4 of layer-1 partials per lane) travels as ONE 16-byte entry per lane.  An entry that has not been
 // written yet holds the bit pattern kSlabEmpty in all four words (a NaN no arithmetic here produces); the consumer's polling
-// load is the data load, and the data is valid when none of the four words is kSlabEmpty -- no flag, no tag words, no release
-// wait, no second load.  Polling volume is what a hand-off costs (tools/micro/cluster_poll_size.hip: 1.69 us per exchange with
+// load is the data load, and the data is valid when none of the four words is kSlabEmpty (seen from the SUM of the entries, which
+// is what the consumer wants anyway: no NaN in it, nothing was empty) -- no flag, no tag words, no release wait, no second load.  Polling volume is what a hand-off costs (tools/micro/cluster_poll_size.hip: 1.69 us per exchange with
 // two tagged entries per lane, the previous form of this protocol, 0.99 us with one), so the entry carries payload only.
 //
 // Who empties an entry again: its producer, and it can tell when that is safe.  Every launch that exchanges at all performs
@@ -81,27 +81,29 @@ __device__ __forceinline__ bool slab_poll_sum(const PersistSync& Y, int buf, int
 #pragma unroll
         for (int r = 0; r < kSMaxW; ++r)
             if (r < R) e[r] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((r * HT + ht) * 64 + lane) * 16, 0, 16);   // aux 16 = sc1: agent scope, misses L1
-        // "no word is kSlabEmpty" == "the unsigned maximum of all words is not 0xFFFFFFFF": v_max3_u32 chain, one compare (28 compares into
-        // 28 scalar pairs made the loop spill scalars)
+        // The sums are formed at once (fixed order r = 0..R-1) and THEY say whether every entry had arrived: the empty pattern is a NaN, so
+        // an entry still empty leaves a NaN in its sum -- two unordered-compares where the word-by-word check was 17 instructions per poll.
+        // (scalar adds on purpose: the vector form `zs += bitcast(e[r])` over buffer-load results was miscompiled by this
+        //  toolchain into v_pk_add_f32 with op_sel_hi:[0,0] in the tagged form of this helper -- two of four sums wrong)
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int r = 0; r < kSMaxW; ++r) {
+            if (r < R) {
+                const f32x4 f = __builtin_bit_cast(f32x4, e[r]);
+                s0 += f[0]; s1 += f[1]; s2 += f[2]; s3 += f[3];
+            }
+        }
+        zs = (f32x4){s0, s1, s2, s3};
+        const bool clean = !(__builtin_isunordered(s0, s1) || __builtin_isunordered(s2, s3));
+        if (__all(clean)) return true;
+        // a NaN somewhere: entries not written yet -- or NaN DATA (a diverging solve; slab_put keeps such values off the empty pattern), which
+        // must pass: "no word is kSlabEmpty" == "the unsigned maximum of all words is not 0xFFFFFFFF" (v_max3_u32 chain, one compare)
         unsigned m = 0u;
 #pragma unroll
         for (int r = 0; r < kSMaxW; ++r)
             if (r < R) { const unsigned a = e[r][0] > e[r][1] ? e[r][0] : e[r][1], b = e[r][2] > e[r][3] ? e[r][2] : e[r][3]; const unsigned c = a > b ? a : b; m = m > c ? m : c; }
         const bool ok = m != kSlabEmpty;
-        if (__all(ok)) {
-            // (scalar adds on purpose: the vector form `zs += bitcast(e[r])` over buffer-load results was miscompiled by this
-            //  toolchain into v_pk_add_f32 with op_sel_hi:[0,0] in the tagged form of this helper -- two of four sums wrong)
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll
-            for (int r = 0; r < kSMaxW; ++r) {
-                if (r < R) {
-                    const f32x4 f = __builtin_bit_cast(f32x4, e[r]);
-                    s0 += f[0]; s1 += f[1]; s2 += f[2]; s3 += f[3];
-                }
-            }
-            zs = (f32x4){s0, s1, s2, s3};
-            return true;
-        }
+        if (__all(ok)) return true;
         if (++spins > Y.max_spins || ((spins & 63) == 0 && __hip_atomic_load(Y.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
             __hip_atomic_store(Y.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             zs = (f32x4){0.f, 0.f, 0.f, 0.f};

@@ -190,7 +190,7 @@ def global_batch_anchor(G, device, steps, warmup=2):
     return out
 
 
-def bench_latent(args):
+def bench_latent(args, B=512, throughput_record=True):
     """SURVEY.md 8d config 4 ("latent ODE dynamics only, for the kernel benchmark"): gen_dynamics of experiments/latent_ode.jl:113-124
     (tanh + 8 x Dense(20<->50, tanh), P = 8,280), B = 512, 49 saveat points on [0, 1], Tsit5 at 1.4e-8; forward + reverse of the layer call."""
     import torch
@@ -198,7 +198,7 @@ def bench_latent(args):
     from regneuralde_jl_amd import _lib
     device = torch.device("cuda", 0)
     torch.cuda.set_device(0)
-    B, T = 512, 49
+    T = 49
     g = torch.Generator().manual_seed(1999)
     dyn = rn.LatentGenDynamics(generator=g)
     grid = [i / (T - 1) for i in range(T)]
@@ -257,17 +257,34 @@ def bench_latent(args):
     us = C.c_float(0)
     _lib.check(h.ptr, L.rnde_bench_attempt(h.ptr, z0.detach().contiguous().data_ptr(), p.detach().data_ptr(), B, 200, C.byref(us), None))
     flops = 6 * 2 * B * 8280
+    one_launch = int(L.rnde_node_one_launch_solves(hd.ptr)) > 0
+    del node, hd, h
+    torch.cuda.empty_cache()
+    big = None
+    if throughput_record and B == 512 and not args.autograd:
+        # THROUGHPUT MODE (round 4): the same one-launch solve and one-launch reverse sweep with 256 workgroups (B = 4096: every CU holds one, they meet
+        # through agent-scope entries once per attempt) -- what the engine delivers when more columns exist than the 32 tiles of the latency case
+        class _A: pass
+        a2 = _A(); a2.steps, a2.warmup, a2.autograd = max(5, args.steps // 2), max(2, args.warmup // 2), False
+        try:
+            r = bench_latent(a2, B=4096, throughput_record=False)
+            big = {k: r[k] for k in ("value", "unit", "ms_per_step", "mean_nfe", "steps", "warmup")}
+            big.update({"batch": 4096, "workgroups": 256, "us_per_attempt": r["roofline"]["us_per_attempt"], "mfma_frac": r["roofline"]["frac"],
+                        "one_launch_solve": r["one_launch_solve"], "speedup_over_B512": r["value"] / (B * args.steps / el)})
+        except Exception as e:
+            big = {"error": repr(e)}
     return {"metric": "forward+reverse samples/sec, latent-ODE dynamics (config 4)", "value": B * args.steps / el, "unit": "samples/s",
+            "one_launch_solve": one_launch, "throughput_B4096": big,
             "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "mean_nfe": sum(nfes) / len(nfes),
-            "config": {"workload": "latent ODE gen_dynamics D=20, 8 Dense layers 20<->50 tanh, B=512, 49 saveat points, Tsit5 1.4e-8 (chain engine); step = layer forward (taped) + its reverse, "
+            "config": {"workload": f"latent ODE gen_dynamics D=20, 8 Dense layers 20<->50 tanh, B={B}, 49 saveat points, Tsit5 1.4e-8 (chain engine); step = layer forward (taped) + its reverse, "
                                    + ("through torch.autograd" if args.autograd else "two C-ABI calls (rnde_node_forward_saveat, rnde_node_backward_async)")},
             "roofline": {"bound": "mfma", "achieved": flops / (us_in_solve * 1e-6) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                          "frac": flops / (us_in_solve * 1e-6) / 1e12 / MFMA_F32_PEAK_TF, "traffic": None,
                          "kernel": "rnde_chainmw_kernel<2,MW_SOLVE,0,1> (multi-wave chain engine, weights register stationary): the WHOLE adaptive solve = 1 launch; "
                                    "unit = one attempted Tsit5 step inside it, taped, timed over the solves of training steps (the reverse sweep is one launch too, "
                                    "rnde_bchainmw_kernel<2,0,1,1>); us_per_attempt_forced_untaped = one attempt as its own launch (rnde_chainmw_kernel<2,0,0,1>); "
-                                   "latency bound (32 workgroups of 4 waves on the chip)",
+                                   f"latency bound ({(B + 15) // 16} workgroups of 4 waves on the chip)",
                          "us_per_attempt": us_in_solve, "us_per_attempt_forced_untaped": us.value}}
 
 
@@ -385,7 +402,35 @@ def bench_nsde(args):
     acc = sum(stats["acc"]) / len(stats["acc"])
     us_att = 1e3 * sum(stats["solve_ms"]) / sum(stats["att"])
     flops = 8 * B * (32 * 64 + 64 + 64 * 32 + 32 + 32 * 32 + 32)      # 4 drift + 4 diffusion evaluations per attempted step
-    return {"metric": "training-step samples/sec + NFE, MNIST Neural SDE bs=512 (config 5)", "value": B * args.steps / el, "unit": "samples/s",
+    # THROUGHPUT MODE (round 4): the reference's evaluation call, accuracy(...; trajectories = 10) (mnist_nsde.jl:154-155): the batch of 512 images
+    # expanded to 5,120 columns in ONE solve with ONE error norm (supervised_classification.jl:87-98) -- 320 workgroups of the four-wave kernel
+    ev = None
+    try:
+        nsde2 = rn.TrackedNeuralDSDE(rn.Chain(rn.Dense(32, 64, "tanh", g), rn.Dense(64, 32, "identity", g)), rn.Dense(32, 32, "identity", g), [0.0, 1.0], True,
+                                     "SOSRI", save_everystep=False, reltol=0.14, abstol=0.14, save_start=False, max_batch=10 * B, max_attempts=256, seed=1999)
+        model2 = rn.ClassifierNSDE(rn.Dense(784, 32, "identity", g), nsde2, rn.Dense(32, 10, "identity", g), device=device)
+        with torch.no_grad():
+            for k_, v_ in zip(model2.trainable(), model.trainable()):
+                k_.copy_(v_)                       # the weights the timed steps above trained
+            reps = max(5, args.steps // 2)
+            for _ in range(3):
+                model2(x, trajectories=10, func="error_est")
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            nfe_e = [model2(x, trajectories=10, func="error_est")[1] for _ in range(reps)]
+            torch.cuda.synchronize()
+            el2 = time.perf_counter() - t0
+        h2 = nsde2._handles[0][0]
+        a, b, na, nc = C.c_float(0), C.c_float(0), C.c_int32(0), C.c_int32(0)
+        L.rnde_nsde_timing(h2.ptr, C.byref(a), C.byref(b), C.byref(na), C.byref(nc))
+        ev = {"what": "ClassifierNSDE evaluation call, trajectories = 10: Dense(784,32) -> ONE adaptive solve over 5,120 columns (320 workgroups, one error norm) -> "
+                      "Dense(32,10) -> mean over trajectories; forward only, as accuracy() runs it",
+              "images_per_s": B * reps / el2, "columns_per_s": 10 * B * reps / el2, "ms_per_call": 1e3 * el2 / reps, "mean_nfe1": sum(nfe_e) / len(nfe_e),
+              "attempts_last_call": na.value, "solve_ms_last_call": a.value, "us_per_attempt": 1e3 * a.value / max(1, na.value), "columns": 10 * B, "workgroups": 10 * B // 16,
+              "columns_per_s_of_the_B512_training_forward": B / (1e-3 * sum(stats["solve_ms"]) / 3)}
+    except Exception as e:
+        ev = {"error": repr(e)}
+    return {"metric": "training-step samples/sec + NFE, MNIST Neural SDE bs=512 (config 5)", "evaluation_5120_columns": ev, "value": B * args.steps / el, "unit": "samples/s",
             "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic (library Philox noise)",
             "mean_nfe1": sum(a for a, _ in nf) / len(nf), "mean_nfe2": sum(b for _, b in nf) / len(nf),

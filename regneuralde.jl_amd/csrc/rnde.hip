@@ -285,12 +285,12 @@ static rnde_status chain_create(const rnde_node_config* c, rnde_node** out) {
     ok &= dm((void**)&h->pcopy, (size_t)h->P * 4) && dm((void**)&h->cfrags, (size_t)(G.nfrag_f + G.nfrag_b + G.nfrag_t + 4) * 256);
     if (h->mw) ok &= dm((void**)&h->mw_tab, mw_tab_floats(h->mg) * 4);
     if (h->mw) {
-        const size_t xb = (size_t)(c->max_attempts + 4) * 3 * 32 * 8;
-        ok &= dm((void**)&h->mw_xch, xb) && dm((void**)&h->mw_xcc, 32 * 4) && dm((void**)&h->mw_abort, 8);
-        ok &= hipHostMalloc((void**)&h->h_mw_chk, 40 * 4) == hipSuccess;
-        ok &= hipHostMalloc((void**)&h->h_mw_bchk, 40 * 4) == hipSuccess && dm((void**)&h->mw_bargs, (size_t)c->max_attempts * 16) &&
+        const size_t xb = (size_t)(c->max_attempts + 4) * 3 * kMwMeetMax * 8;
+        ok &= dm((void**)&h->mw_xch, xb) && dm((void**)&h->mw_xcc, kMwMeetMax * 4) && dm((void**)&h->mw_abort, 8);
+        ok &= hipHostMalloc((void**)&h->h_mw_chk, (kMwMeetMax + 8) * 4) == hipSuccess;
+        ok &= hipHostMalloc((void**)&h->h_mw_bchk, (kMwMeetMax + 8) * 4) == hipSuccess && dm((void**)&h->mw_bargs, (size_t)c->max_attempts * 16) &&
               hipHostMalloc((void**)&h->h_mw_bargs, (size_t)c->max_attempts * 16) == hipSuccess;
-        if (ok) memset(h->h_mw_bchk, 0, 40 * 4);
+        if (ok) memset(h->h_mw_bchk, 0, (kMwMeetMax + 8) * 4);
         if (const char* eb = getenv("RNDE_CHAIN_BSWEEP")) h->mw_bsweep = atoi(eb);
         if (ok) { hipMemset(h->mw_xch, 0, xb); hipMemset(h->mw_abort, 0, 8); }
         const char* e = getenv("RNDE_CHAIN_SOLVE");
@@ -351,7 +351,7 @@ static hipError_t launch_mw_t(rnde_node* h, const MwParams& Q, int n, hipStream_
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((rnde_chainmw_kernel<NR, MODE, TAB, LAT>), dim3(MODE == MW_SOLVE ? 8 * Q.ntiles : Q.ntiles), dim3(kMwThreads), MODE == MW_FINISH ? 0 : h->mw_lds_f, s, Q, n);
+    hipLaunchKernelGGL((rnde_chainmw_kernel<NR, MODE, TAB, LAT>), dim3((MODE == MW_SOLVE && !Q.xch_global) ? 8 * Q.ntiles : Q.ntiles), dim3(kMwThreads), MODE == MW_FINISH ? 0 : h->mw_lds_f, s, Q, n);
     return hipGetLastError();
 }
 template <int MODE>
@@ -669,7 +669,7 @@ static bool bsweep_failed(rnde_node* h, hipStream_t s) {
     h->pending_bsweep = false;
     bool bad = h->h_mw_bchk[0] != 0;
     const int nt = h->bw.ready ? (int)((h->B + 15) / 16) : 0;
-    for (int i = 1; i < nt && !bad; ++i) bad = h->h_mw_bchk[2 + i] != h->h_mw_bchk[2];
+    for (int i = 1; i < nt && nt <= 32 && !bad; ++i) bad = h->h_mw_bchk[2 + i] != h->h_mw_bchk[2];      // (more than 32 tiles: the meeting does not depend on the placement)
     if (!bad) return false;
     fprintf(stderr, "[rnde] chain engine: one-launch reverse sweep abandoned (%s); one launch per reversed attempt from now on\n",
             h->h_mw_bchk[0] ? "a meeting timed out" : "workgroups pinned by block index landed on different XCDs");
@@ -837,20 +837,21 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
     const int cap = h->cfg.max_attempts;
     h->tev_fwd = false;
     if (h->timing) HIPCHK(h, hipEventRecord(h->tev[0], s));
-    // ---- chain engine, multi-wave kernels, <= 32 column tiles: the WHOLE adaptive solve is one launch (attempt loop, controller and the
-    // ---- once-per-attempt meeting of the workgroups inside the kernel; the workgroups are pinned to one XCD and meet through its L2) ----
+    // ---- chain engine, multi-wave kernels, every workgroup resident (<= 256 column tiles): the WHOLE adaptive solve is one launch (attempt loop,
+    // ---- controller and the once-per-attempt meeting of the workgroups inside the kernel).  <= 32 tiles: the workgroups are pinned to one XCD
+    // ---- and meet through its L2; more (B > 512, the throughput case): they spread over the chip and meet through agent-scope entries ----
     bool solved = false;
-    if (h->engine == 3 && h->mw && h->mw_solve && !h->couple && P.Bpad / 16 <= 32) {
+    if (h->engine == 3 && h->mw && h->mw_solve && !h->couple && P.Bpad / 16 <= kMwMeetMax) {
         // a taped solve writes every layer input of every evaluation: the slab is sized for twice the last solve's attempts (at least 48); a solve
         // that needs more ends at that limit and is redone with room for max_attempts
         const int n_limit = keep_tape ? std::min(cap, std::max(48, 2 * h->predicted)) : cap;
         if (keep_tape) { st = ensure_mw_slab(h, 2 + (long long)(h->rk_S - 1) * n_limit, P.Bpad, s); if (st != RNDE_OK) return st; MQ.slab = h->mw_slab; }
         MQ.n_limit = n_limit;
-        if (++h->mw_epoch >= 500000u) { h->mw_epoch = 1; HIPCHK(h, hipMemsetAsync(h->mw_xch, 0, (size_t)(cap + 4) * 3 * 32 * 8, s)); }
-        MQ.u_out = u_out_dev; MQ.xch = h->mw_xch; MQ.xcc = h->mw_xcc; MQ.abort_word = h->mw_abort; MQ.epoch = h->mw_epoch;
+        if (++h->mw_epoch >= 500000u) { h->mw_epoch = 1; HIPCHK(h, hipMemsetAsync(h->mw_xch, 0, (size_t)(cap + 4) * 3 * kMwMeetMax * 8, s)); }
+        const int nt = P.Bpad / 16;
+        MQ.u_out = u_out_dev; MQ.xch = h->mw_xch; MQ.xcc = h->mw_xcc; MQ.abort_word = h->mw_abort; MQ.epoch = h->mw_epoch; MQ.xch_global = nt > 32 ? 1 : 0;
         HIPCHK(h, launch_mw<MW_SOLVE>(h, MQ, 0, s));
         if (h->timing) { HIPCHK(h, hipEventRecord(h->tev[1], s)); h->tev_fwd = true; }
-        const int nt = P.Bpad / 16;
         HIPCHK(h, hipMemcpyAsync(h->h_ctl, h->ctl_final, sizeof(StepState), hipMemcpyDeviceToHost, s));
         HIPCHK(h, hipMemcpyAsync(h->h_meta, h->meta, (size_t)cap * sizeof(StepMeta), hipMemcpyDeviceToHost, s));
         HIPCHK(h, hipMemcpyAsync(h->h_init, h->initrec, sizeof(InitRec), hipMemcpyDeviceToHost, s));
@@ -864,7 +865,7 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
         } else HIPCHK(h, hipStreamSynchronize(s));
         if (bsweep_failed(h, s)) { h->err = "the one-launch reverse sweep of the previous asynchronous backward call was abandoned: the gradients of that step are invalid (one launch per reversed attempt now in use)"; return RNDE_ERR_HIP; }
         bool bad = h->h_mw_chk[0] != 0;
-        for (int i = 1; i < nt && !bad; ++i) bad = h->h_mw_chk[2 + i] != h->h_mw_chk[2];
+        for (int i = 1; i < nt && !MQ.xch_global && !bad; ++i) bad = h->h_mw_chk[2 + i] != h->h_mw_chk[2];
         if (bad) {      // a meeting timed out, or the workgroups did not share an XCD: this handle goes back to one launch per attempt, for good
             fprintf(stderr, "[rnde] chain engine: one-launch solve abandoned (%s); one launch per attempted step from now on\n",
                     h->h_mw_chk[0] ? "a meeting timed out" : "workgroups pinned by block index landed on different XCDs");
@@ -1801,8 +1802,9 @@ static rnde_status launch_bmw_t(rnde_node* h, const BMwParams& Q, const std::vec
     }
     const dim3 grid(Q.ntiles), blk(kMwThreads);
     rnde_status st = RNDE_OK;
-    // the whole sweep as ONE launch (rnde_bchainmw.h SWEEP): <= 32 column tiles, no shared controller, more than one attempt
-    const bool sweep = h->mw_bsweep && !h->couple && Q.ntiles <= 32 && Q.B.n_att >= 2 && h->mw_xch;
+    // the whole sweep as ONE launch (rnde_bchainmw.h SWEEP): every workgroup resident (<= 256 column tiles; more than 32: meeting through the
+    // memory side, as the forward solve), no shared controller, more than one attempt
+    const bool sweep = h->mw_bsweep && !h->couple && Q.ntiles <= kMwMeetMax && Q.B.n_att >= 2 && h->mw_xch;
     int* a_lo = h->h_mw_bargs; int* a_hi = a_lo + h->cfg.max_attempts; float* a_eig = (float*)(a_hi + h->cfg.max_attempts);
     for (int n = Q.B.n_att - 1; n >= 0; --n) {
         float c1 = 0.f, c2 = 0.f;   // cotangent of eigen_est for this attempt (as in bwd_run)
@@ -1823,11 +1825,11 @@ static rnde_status launch_bmw_t(rnde_node* h, const BMwParams& Q, const std::vec
     if (sweep) {
         const int cap = h->cfg.max_attempts;
         HIPCHK(h, hipMemcpyAsync(h->mw_bargs, h->h_mw_bargs, (size_t)cap * 16, hipMemcpyHostToDevice, s));
-        if (++h->mw_epoch >= 500000u) { h->mw_epoch = 1; HIPCHK(h, hipMemsetAsync(h->mw_xch, 0, (size_t)(cap + 4) * 3 * 32 * 8, s)); }
+        if (++h->mw_epoch >= 500000u) { h->mw_epoch = 1; HIPCHK(h, hipMemsetAsync(h->mw_xch, 0, (size_t)(cap + 4) * 3 * kMwMeetMax * 8, s)); }
         BMwParams W = Q;
         W.sv_lo = h->mw_bargs; W.sv_hi = h->mw_bargs + cap; W.eig_c = (const float*)(h->mw_bargs + 2 * cap);
-        W.xch = h->mw_xch; W.xcc = h->mw_xcc; W.abort_word = h->mw_abort; W.epoch = h->mw_epoch;
-        hipLaunchKernelGGL((rnde_bchainmw_kernel<NR, TAB, LAT, 1>), dim3(8 * Q.ntiles), blk, lds, s, W, Q.B.n_att - 1, h->h_meta[Q.B.n_att - 1], 0, 0, 0.f, 0.f);
+        W.xch = h->mw_xch; W.xcc = h->mw_xcc; W.abort_word = h->mw_abort; W.epoch = h->mw_epoch; W.xch_global = Q.ntiles > 32 ? 1 : 0;
+        hipLaunchKernelGGL((rnde_bchainmw_kernel<NR, TAB, LAT, 1>), dim3(W.xch_global ? Q.ntiles : 8 * Q.ntiles), blk, lds, s, W, Q.B.n_att - 1, h->h_meta[Q.B.n_att - 1], 0, 0, 0.f, 0.f);
         HIPCHK(h, hipGetLastError());
         HIPCHK(h, hipMemcpyAsync(h->h_mw_bchk, h->mw_abort, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(h, hipMemcpyAsync(h->h_mw_bchk + 2, h->mw_xcc, (size_t)Q.ntiles * 4, hipMemcpyDeviceToHost, s));

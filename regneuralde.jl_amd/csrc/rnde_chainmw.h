@@ -77,20 +77,24 @@ struct MwParams {
     float* slab;             // [n_evals][ntiles][RS][64] (NULL when not taping): evaluation 0 = f(u0), 1 = f(u1), 2 + 6 n + (s - 1) = stage s of attempt n
     long long ev_stride;
     int ntiles;
-    // MW_SOLVE (the whole adaptive solve in one launch): the workgroups meet once per attempted step through the L2 of ONE XCD
+    // MW_SOLVE (the whole adaptive solve in one launch): the workgroups meet once per attempted step -- through the L2 of ONE XCD while they
+    // fit it (<= 32 tiles), through agent-scope entries on the memory side otherwise (xch_global: <= 256 tiles, every workgroup resident)
     unsigned long long* xch;     // [max_attempts][3][ntiles] {float value, uint tag}: every entry written once per solve
-    unsigned* xcc;               // [ntiles] HW_REG_XCC_ID of each workgroup (the host checks they agree)
+    unsigned* xcc;               // [ntiles] HW_REG_XCC_ID of each workgroup (the host checks they agree; not looked at when xch_global)
     unsigned* abort_word;        // a meeting timed out
     unsigned epoch;              // tag = epoch * 8192 + attempt + 1
     int n_limit;                 // attempts this launch may run (the activation slab is sized for that many): reaching it ends the launch with done = 0
+    int xch_global;              // 0: 8 x ntiles workgroups launched, those with blockIdx % 8 == 0 work (one XCD); 1: ntiles launched, all of them work
 };
 
-// cross-workgroup sums of the three norm partials of attempt `seq` (MW_SOLVE): every workgroup publishes {value, tag} with a plain 8-byte
-// store (written through to the XCD's L2) and polls the others' with L1-bypassing loads -- the SDE engine's meeting (rnde_sde.h
-// sde_exchange).  Called by wave 0; `mine` valid in lane 0; the sums come out in the order sum_partials forms them (entry i in lane i,
-// then the wave reduction), so a solve is bit-identical to the one-launch-per-attempt path.  false: timed out / aborted.
+// cross-workgroup sums of the three norm partials of attempt `seq` (MW_SOLVE): every workgroup publishes {value, tag} and polls the others'.
+// One XCD (global = 0): a plain 8-byte store (written through to the XCD's L2) and L1-bypassing loads -- the SDE engine's meeting (rnde_sde.h
+// sde_exchange).  Any placement (global = 1, up to 256 workgroups): agent-scope stores and loads, the meeting of rnde_stage_solve.h.
+// Called by wave 0; `mine` valid in lane 0; the sums come out in the order sum_partials forms them (lane l adds entries l, l + 64, l + 128,
+// l + 192 in double, then the wave reduction), so a solve is bit-identical to the one-launch-per-attempt path.  false: timed out / aborted.
 constexpr int kMwSpinMax = 4000000;
-struct MwMeet { unsigned long long* xch; unsigned* abort_word; unsigned epoch; int ntiles; };     // what a meeting needs (forward solve, reverse sweep)
+constexpr int kMwMeetMax = 256;      // workgroups one meeting can hold (= CUs: every participant must be resident)
+struct MwMeet { unsigned long long* xch; unsigned* abort_word; unsigned epoch; int ntiles; int global; };     // what a meeting needs (forward solve, reverse sweep)
 __device__ __forceinline__ bool mw_exchange3(const MwMeet& Q, int seq, const float (&mine)[3], double (&out)[3], int tile, int lane) {
     const unsigned tag = Q.epoch * 8192u + (unsigned)seq + 1u;
     unsigned long long* base = Q.xch + (size_t)seq * 3 * Q.ntiles;
@@ -99,30 +103,39 @@ __device__ __forceinline__ bool mw_exchange3(const MwMeet& Q, int seq, const flo
         for (int v = 0; v < 3; ++v) {
             float m = mine[v];
             if (m != m) m = __uint_as_float(0x7FC00000u);
-            base[(size_t)v * Q.ntiles + tile] = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(m);
+            const unsigned long long e = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(m);
+            if (Q.global) __hip_atomic_store(base + (size_t)v * Q.ntiles + tile, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else base[(size_t)v * Q.ntiles + tile] = e;
         }
     }
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
     typedef unsigned mw_u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int v = 0; v < 3; ++v) {
-        unsigned long long e = 0;
-        bool ok = lane >= Q.ntiles;
-        int spins = 0;
-        while (true) {
-            if (!ok) {
-                __asm__ volatile("" ::: "memory");
-                const mw_u32x2 q = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(((size_t)v * Q.ntiles + lane) * 8), 0, 16);   // aux 16 = sc1: misses L1
-                e = ((unsigned long long)q.y << 32) | q.x;
-                ok = (unsigned)(e >> 32) == tag;
+        double sv = 0.0;
+        for (int b0 = 0; b0 < Q.ntiles; b0 += 64) {
+            const int i = b0 + lane;
+            unsigned long long e = 0;
+            bool ok = i >= Q.ntiles;
+            int spins = 0;
+            while (true) {
+                if (!ok) {
+                    if (Q.global) e = __hip_atomic_load(base + (size_t)v * Q.ntiles + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else {
+                        __asm__ volatile("" ::: "memory");
+                        const mw_u32x2 q = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(((size_t)v * Q.ntiles + i) * 8), 0, 16);   // aux 16 = sc1: misses L1
+                        e = ((unsigned long long)q.y << 32) | q.x;
+                    }
+                    ok = (unsigned)(e >> 32) == tag;
+                }
+                if (__all(ok)) break;
+                if (++spins > kMwSpinMax || ((spins & 1023) == 0 && __hip_atomic_load(Q.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                    if (lane == 0) __hip_atomic_store(Q.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return false;
+                }
             }
-            if (__all(ok)) break;
-            if (++spins > kMwSpinMax || ((spins & 1023) == 0 && __hip_atomic_load(Q.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-                if (lane == 0) __hip_atomic_store(Q.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return false;
-            }
+            if (i < Q.ntiles) sv += (double)__uint_as_float((unsigned)(e & 0xFFFFFFFFull));
         }
-        const double sv = lane < Q.ntiles ? (double)__uint_as_float((unsigned)(e & 0xFFFFFFFFull)) : 0.0;
         out[v] = wave_sum_d(sv);
     }
     return true;
@@ -338,8 +351,9 @@ __global__ __launch_bounds__(kMwThreads) void rnde_chainmw_kernel(const MwParams
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // MW_SOLVE: 8 x ntiles workgroups are launched and those with blockIdx % 8 != 0 leave at once, so that the ones that work share ONE XCD
     // (round-robin dispatch; every workgroup records its XCC id, the host checks they agree): they meet through that L2 once per attempt
-    if constexpr (MODE == MW_SOLVE) { if (blockIdx.x & 7) return; }
-    const int tile = MODE == MW_SOLVE ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    // (xch_global, more than 32 tiles: every launched workgroup works and the meeting goes through the memory side)
+    if constexpr (MODE == MW_SOLVE) { if (!Q.xch_global && (blockIdx.x & 7)) return; }
+    const int tile = (MODE == MW_SOLVE && !Q.xch_global) ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const bool writer = (tile == 0 && tid == 0);
     if constexpr (MODE == MW_SOLVE) { if (tid == 0) Q.xcc[tile] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15; }
     constexpr int SM = TAB == 2 ? kRkSMax : 7;               // stages the register arrays are sized for
@@ -593,7 +607,7 @@ __global__ __launch_bounds__(kMwThreads) void rnde_chainmw_kernel(const MwParams
                 float mine[3] = {0.f, 0.f, 0.f};
                 for (int w = 0; w < kMwWaves; ++w) { mine[0] += RED[w]; mine[1] += RED[4 + w]; mine[2] += RED[8 + w]; }
                 double o[3];
-                const bool ok = mw_exchange3(MwMeet{Q.xch, Q.abort_word, Q.epoch, Q.ntiles}, nn, mine, o, tile, lane);
+                const bool ok = mw_exchange3(MwMeet{Q.xch, Q.abort_word, Q.epoch, Q.ntiles, Q.xch_global}, nn, mine, o, tile, lane);
                 if (lane == 0) { ((double*)RED2)[0] = o[0]; ((double*)RED2)[1] = o[1]; ((double*)RED2)[2] = o[2]; RED2[6] = ok ? 1.f : 0.f; }
             }
             __syncthreads();

@@ -179,7 +179,7 @@ extern "C" rnde_status rnde_nsde_create(const rnde_nsde_config* c, rnde_nsde** o
     const size_t uf = (size_t)((Gf.nfrag_f + Gf.nfrag_b + 3) / 4), ug = (size_t)((Gg.nfrag_f + Gg.nfrag_b + 3) / 4);
     h->lds_fwd = (uf + ug) * 1024 + (size_t)(56 + kSdeMaxOps * 8 + 5 * cap) * 4 + 64;
     h->lds_mw = (size_t)(kSmwLdsFloats + 56 + kSdeMaxOps * 8 + 5 * cap) * 4 + 64;
-    h->xch_wg = h->mw ? std::max(h->nwg_max, std::min(h->ntiles_max, 256)) : h->nwg_max;
+    h->xch_wg = h->mw ? std::max(h->nwg_max, std::min(h->ntiles_max, kSmwMaxTiles)) : h->nwg_max;
     const size_t ufb = (size_t)((Gf.nfrag_f + Gf.nfrag_b + Gf.nfrag_t + 3) / 4), ugb = (size_t)((Gg.nfrag_f + Gg.nfrag_b + Gg.nfrag_t + 3) / 4);
     h->lds_bwd = (ufb + ugb) * 1024 + 64;
     if (h->lds_fwd > 160 * 1024 || h->lds_bwd > 160 * 1024) { g_nsde_create_err = "networks too large: the weight fragments of both chains must fit the 160 KB LDS of a CU"; delete h; return RNDE_ERR_BAD_ARG; }
@@ -352,7 +352,9 @@ static rnde_status nsde_forward_impl(rnde_nsde* h, const float* x_dev, const flo
     SCHK(h, hipEventRecord(h->tev[0], s));
     hipError_t e;
     bool local_xch = false;
-    if (h->mw && ntiles <= 256) {   // one workgroup of four waves per tile (all of them resident: they meet once per attempt)
+    // one workgroup of four waves per tile, all of them resident (they meet once per attempt): 144 VGPRs and ~20 KB of LDS let a CU hold two,
+    // so the limit is 512 tiles = 8,192 columns (the reference's evaluation call with trajectories = 10 is 5,120: mnist_nsde.jl:154-155)
+    if (h->mw && ntiles <= kSmwMaxTiles) {
         static bool attr = false;
         if (!attr) { SCHK(h, hipFuncSetAttribute((const void*)rnde_sde_solve_mw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
         Q.nwg = ntiles;

@@ -18,6 +18,7 @@
 namespace rnde {
 
 constexpr int kSmwThreads = 256;
+constexpr int kSmwMaxTiles = 512;    // workgroups of one solve launch (two per CU): every one of them must be resident, they meet once per attempt
 constexpr int kSmwLdsFloats = 3072;     // X0, X1, HD, KO, GO
 
 __global__ __launch_bounds__(kSmwThreads) void rnde_sde_solve_mw_kernel(const SdeParams Q) {

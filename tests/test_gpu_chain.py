@@ -483,7 +483,10 @@ def test_dop853_is_refused_where_the_table_has_nothing_to_offer():
 
 
 @pytest.mark.parametrize("kind,B,tol,scale,saveat,reg", [("latent", 512, 1.4e-8, 1.0, np.linspace(0, 1, 49), 1), ("chain3", 19, 1e-3, 2.0, None, 1),
-                                                          ("test_node", 5, 1e-2, 8.0, np.array([0.5, 1.0]), 1), ("latent", 70, 1e-4, 1.5, None, 3)])
+                                                          ("test_node", 5, 1e-2, 8.0, np.array([0.5, 1.0]), 1), ("latent", 70, 1e-4, 1.5, None, 3),
+                                                          # more than 32 column tiles (round 4): the workgroups spread over the chip and meet through agent-scope entries
+                                                          ("latent", 1000, 1e-5, 1.0, np.linspace(0, 1, 7), 1), ("latent", 4096, 1.4e-8, 1.0, np.linspace(0, 1, 49), 1),
+                                                          ("chain3", 2049, 1e-3, 2.0, None, 3)])
 def test_one_launch_solve_is_bit_identical_to_one_launch_per_attempt(kind, B, tol, scale, saveat, reg, monkeypatch, _mw_only):
     """rnde_chainmw_kernel<.., MW_SOLVE>: the whole adaptive solve of the chain engine in ONE launch (attempt loop, controller, saveat
     bookkeeping inside the kernel; the <= 32 workgroups pinned to one XCD meet once per attempt through its L2, round 3) against the
@@ -511,7 +514,8 @@ def test_one_launch_solve_is_bit_identical_to_one_launch_per_attempt(kind, B, to
 
 @pytest.mark.parametrize("kind,B,tol,scale,saveat,reg", [("latent", 512, 1.4e-8, 1.0, np.linspace(0, 1, 49), 1), ("chain3", 19, 1e-3, 2.0, None, 1),
                                                           ("test_node", 5, 1e-2, 8.0, np.array([0.5, 1.0]), 1), ("latent", 70, 1e-4, 1.5, None, 3),
-                                                          ("wide", 40, 1e-5, 1.5, None, 0)])
+                                                          ("wide", 40, 1e-5, 1.5, None, 0),
+                                                          ("latent", 1000, 1e-5, 1.0, np.linspace(0, 1, 7), 1), ("latent", 4096, 1.4e-8, 1.0, np.linspace(0, 1, 49), 1)])
 def test_one_launch_reverse_sweep_is_bit_identical_to_one_launch_per_attempt(kind, B, tol, scale, saveat, reg, monkeypatch, _mw_only):
     """rnde_bchainmw_kernel<.., SWEEP>: the reverse sweep of the chain engine in ONE launch (the loop over the attempted steps inside the kernel,
     weights loaded once, the scalar chain carried in registers, the three partial sums of an attempt exchanged through the XCD's L2) against

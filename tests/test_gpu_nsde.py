@@ -473,18 +473,47 @@ def test_layer_saveat_method():
     assert torch.isfinite(p.grad).all() and p.grad.abs().max() > 0
 
 
-def test_more_than_4096_columns_take_the_one_wave_solve_kernel():
-    """The four-waves-per-tile solve kernel needs a workgroup per tile resident (<= 256 tiles); a ClassifierNSDE evaluation with ten
-    trajectories of a 430-sample batch is 4300 columns: the library switches to the one-wave-per-tile kernel for that call (same handle,
-    same tape layout, the reverse sweep stays on the four-wave kernel): the call contract and finite, non-trivial gradients."""
+def test_more_than_8192_columns_take_the_one_wave_solve_kernel():
+    """The four-waves-per-tile solve kernel needs a workgroup per tile resident (<= 512 tiles, two per CU); a call with 8300 columns switches to
+    the one-wave-per-tile kernel (same handle, same tape layout, the reverse sweep stays on the four-wave kernel): the call contract and
+    finite, non-trivial gradients."""
     import torch
     import regneuralde_jl_amd as rn
     g = torch.Generator().manual_seed(6)
     nsde = rn.TrackedNeuralDSDE(rn.Chain(rn.Dense(32, 64, "tanh", g), rn.Dense(64, 32, "identity", g)), rn.Dense(32, 32, "identity", g),
-                                [0.0, 1.0], True, "SOSRI", reltol=0.14, abstol=0.14, max_batch=4300)
-    x = torch.randn(4300, 32, generator=g).cuda().requires_grad_(True)
+                                [0.0, 1.0], True, "SOSRI", reltol=0.14, abstol=0.14, max_batch=8300)
+    x = torch.randn(8300, 32, generator=g).cuda().requires_grad_(True)
     p = nsde.p.cuda().clone().requires_grad_(True)
     u, nfe1, nfe2, sv = nsde(x, p, func="error_est")
-    assert u.shape == (4300, 32) and torch.isfinite(u).all() and nfe1 == nfe2 and nfe1 % 4 == 2
+    assert u.shape == (8300, 32) and torch.isfinite(u).all() and nfe1 == nfe2 and nfe1 % 4 == 2
     (u.sum() + sv.saveval.sum()).backward()
     assert torch.isfinite(x.grad).all() and torch.isfinite(p.grad).all() and p.grad.abs().max() > 0
+
+
+def test_evaluation_size_5120_columns_vs_oracle():
+    """The reference's evaluation call (experiments/mnist_nsde.jl:154-155: accuracy(...; trajectories = 10) on a batch of 512 = 5,120 columns in ONE
+    solve with ONE error norm, supervised_classification.jl:87-98): 320 workgroups of the four-wave kernel, two per CU on 64 of them, meeting
+    through agent-scope entries.  Same accept / reject sequence, draws and NFE as the fp32 oracle on the same noise; end state and the reverse
+    pass against it."""
+    from oracle.oracle_sde import SdeOracle
+    from tests.util import NsdeNode
+    B = 5120
+    drift, diff, p, x, noise = _setup("nsde", B, 23, 200, scale=1.0, dscale=1.0)
+    o = SdeOracle(drift, diff, np.float32, 0.14, 0.14, max_attempts=199)
+    ref = o.forward(x, p, noise)
+    assert ref["rc"] == 0
+    node = NsdeNode(_cfg(drift, diff, B, max_attempts=199))
+    got = node.forward(x, p, noise, keep_tape=True)
+    print(f"5120 columns: attempts {got['nattempts']}, draws {got['ndraws']}")
+    assert got["nattempts"] == ref["nattempts"] and np.array_equal(got["steps"][:, 3], ref["steps"][:, 3]) and got["ndraws"] == ref["ndraws"]
+    assert got["nfe1"] == ref["nfe1"] and got["nfe2"] == ref["nfe2"]
+    assert _rel(got["u"], ref["u"]) <= 2e-4 and np.allclose(got["saveval"], ref["saveval"], rtol=5e-4, atol=1e-7)
+    rng = np.random.default_rng(2)
+    ubar = (rng.standard_normal(x.shape) / B).astype(np.float32)
+    svbar = np.full(len(got["saveval"]), 10.0 / len(got["saveval"]), np.float32)
+    xb, pb = node.backward(ubar, svbar)
+    gr = o.backward(ubar, svbar)
+    ex, ep = _rel(xb, gr[0]), _rel(pb, gr[1])
+    print(f"5120 columns reverse vs fp32 oracle: x_bar {ex:.2e}, p_bar {ep:.2e}")
+    assert ex <= 2e-3 and ep <= 2e-3
+    node.close()

@@ -886,7 +886,17 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
         HIPCHK(h, slab_prepare(h, SQ.Bpad16, s));
         if (++h->s_epoch >= 500000u) { h->s_epoch = 1; HIPCHK(h, hipMemsetAsync(h->sxch, 0, (size_t)(cap + 1) * 3 * 256 * 8, s)); }
         SolveSync Z{h->sxch, h->s_epoch, cap};
+#ifdef RNDE_DIAG
+        StageParams SD = SQ;
+        if (getenv("RNDE_DIAG_SOLVE")) {      // cycle stamps of workgroup 0, every attempt (tools/diag_solve.py)
+            if (!h->diag_buf) hipMalloc((void**)&h->diag_buf, 8192);
+            hipMemsetAsync(h->diag_buf, 0, 8192, s);
+            SD.F.dbg_out = h->diag_buf;
+        }
+        HIPCHK(h, rnde_launch_stage_solve(&SD, &Y, &Z, h->act2, s));
+#else
         HIPCHK(h, rnde_launch_stage_solve(&SQ, &Y, &Z, h->act2, s));
+#endif
         if (h->timing) { HIPCHK(h, hipEventRecord(h->tev[1], s)); h->tev_fwd = true; }
         hipLaunchKernelGGL(rnde_stage_finish_kernel, dim3(256), dim3(256), 0, s, SQ, -1, u_out_dev); HIPCHK(h, hipGetLastError());
         const int cnt = std::min(cap, std::max(64, 2 * h->predicted));      // step records copied speculatively; a longer solve fetches the rest below
@@ -897,6 +907,21 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
             if (hs != RNDE_OK) return hs;
             HIPCHK(h, hipEventSynchronize(h->ev_host));
         } else HIPCHK(h, hipStreamSynchronize(s));
+#ifdef RNDE_DIAG
+        if (getenv("RNDE_DIAG_SOLVE") && h->diag_buf) {
+            static unsigned long long hst[1024];
+            hipMemcpy(hst, h->diag_buf, 8192, hipMemcpyDeviceToHost);
+            int na = 0; while (na < 119 && hst[(na + 1) * 8]) ++na;      // attempts with a successor
+            double acc[7] = {0}; int cnt = 0;
+            for (int a = 2; a + 1 < na; ++a, ++cnt) {
+                const unsigned long long* q = hst + a * 8;
+                acc[0] += (double)(q[1] - q[0]); acc[1] += (double)(q[2] - q[1]); acc[2] += (double)(q[3] - q[2]); acc[3] += (double)(q[4] - q[3]);
+                acc[4] += (double)(q[5] - q[4]); acc[5] += (double)(q[6] - q[5]); acc[6] += (double)(q[8] - q[0]);
+            }
+            if (cnt) fprintf(stderr, "one-launch solve, workgroup 0, mean over %d attempts (cycles): controller %.0f | START %.0f | stages 1-6 %.0f | reduce + barrier %.0f | "
+                                     "meeting %.0f | barrier %.0f | attempt %.0f\n", cnt, acc[0] / cnt, acc[1] / cnt, acc[2] / cnt, acc[3] / cnt, acc[4] / cnt, acc[5] / cnt, acc[6] / cnt);
+        }
+#endif
         if (persist_check_result(h, SQ.C, SQ.R, s)) {
             if (h->pending_bwd) {
                 h->pending_bwd = false;

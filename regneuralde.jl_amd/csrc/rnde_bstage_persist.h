@@ -343,8 +343,8 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
             f32x4 zv;
 #pragma unroll
             for (int i = 0; i < 4; ++i) { const float hv = h_own[i]; const float z = zs[i] * (1.f - hv * hv); zv[i] = unit ? z : 0.f; }
+            if (rb == w && unit) *(f32x4*)(z1dst + own_zd0) = zv;      // (every row block holds the same z1-bar: row block rb writes hidden tile rb)
             if (rb == 0) {
-                if (unit) *(f32x4*)(z1dst + own_zd0) = zv;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) tau += unit ? w1t_own[i] * zv[i] : ((i == 0 && trow) ? zs[0] : 0.f);
             }

@@ -51,8 +51,9 @@ __device__ __forceinline__ void finalize_state(const StepParams& P, StepState& S
 template <bool PRE>
 // sums (optional): the three cross-workgroup sums of attempt n - 1 {r^2, (k7-k6)^2, (unew-g6)^2} already formed by the caller (a kernel that
 // runs several attempts meets in memory instead of at a kernel boundary: rnde_chainmw.h MW_SOLVE) -- in the order sum_partials would
+// qold_pow (optional): powf(prev.qold, beta2) evaluated by the caller ahead of time (it does not depend on the attempt's error norm)
 __device__ __forceinline__ StepState advance_state_t(const StepParams& P, int n, int lane, bool writer, StepState* out, const float (&pre)[4],
-                                                     const StepState& prev, const double* sums = nullptr) {
+                                                     const StepState& prev, const double* sums = nullptr, const float* qold_pow = nullptr) {
     StepState S;
     const double N = (double)P.D * (double)P.Bn;
     if (n == 0) {
@@ -104,7 +105,7 @@ __device__ __forceinline__ StepState advance_state_t(const StepParams& P, int n,
         if (eest == 0.f) { q = 1.f / kQmax; flags |= F_EZERO | F_QCLAMP; }
         else {
             q11 = powf(eest, P.beta1);
-            q = q11 / powf(p.qold, P.beta2);
+            q = q11 / (qold_pow ? *qold_pow : powf(p.qold, P.beta2));
             const float qg = q / kGamma, lo = 1.f / kQmax, hi = 1.f / kQmin;
             if (qg < lo) { q = lo; flags |= F_QCLAMP; }
             else if (qg > hi) { q = hi; flags |= F_QCLAMP; }

@@ -262,7 +262,8 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
     float own_c1[4], own_c0[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { own_c1[i] = own_kind[i] == 1 ? 1.f : 0.f; own_c0[i] = own_kind[i] == 2 ? 1.f : 0.f; }
-    const bool own_hstore = rb == 0 && own_kind[3] == 0;
+    // (FIX: the hidden activations are computed identically by all seven row blocks of a tile; row block rb tapes hidden tile rb, see rnde_stage_solve.h)
+    const bool own_hstore = (FIX ? rb == w : rb == 0) && own_kind[3] == 0;
     if (tid == 0) RED[24] = 0.f;                  // "a wave of this workgroup gave up" (written by any such wave; read after the phase-A barrier)
     // phase D: this row block's layer-1 partial of the stage input v -> slab[par], then publish exchange number `ex`
     auto phase_d = [&](const f32x4& v, unsigned ex) {

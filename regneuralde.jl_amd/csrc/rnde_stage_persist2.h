@@ -151,7 +151,7 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_attempt_mt_kernel(const Sta
     float own_c1[4], own_c0[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { own_c1[i] = own_kind[i] == 1 ? 1.f : 0.f; own_c0[i] = own_kind[i] == 2 ? 1.f : 0.f; }
-    const bool own_hstore = rb == 0 && own_kind[3] == 0;
+    const bool own_hstore = rb == w && own_kind[3] == 0;      // (row block rb tapes hidden tile rb, see rnde_stage_solve.h)
     if (tid == 0) RED[24] = 0.f;
 
     float part0[NCT], part1[NCT], part2[NCT];

@@ -85,6 +85,7 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_solve_kernel(const StagePar
     float* GL = HL + kSCB * KH;
     float* RED = GL + kSCB * KG;         // [32]; RED[24] = "a wave of this workgroup gave up"
     double* SUMS = (double*)(RED + 32);  // [4]: the three cross-workgroup sums of the meeting, [3] != 0: the meeting failed
+    float* QP = (float*)(SUMS + 4);      // [2] (by attempt parity: a fast wave writes the next one while a slow wave still reads this one): powf(qold, beta2) of the state the running attempt started from (evaluated off the critical path)
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     __builtin_assume(w >= 0 && w < 7);
@@ -135,7 +136,9 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_solve_kernel(const StagePar
     const int own_hl0 = col * KH + kperm(16 * w + 4 * (lane >> 4));
     const int own_gl0 = col * KG + kperm(16 * w + 4 * (lane >> 4));
     const size_t own_hd0 = (size_t)gcol * gH + 16 * w + 4 * (lane >> 4);
-    const bool own_hstore = rb == 0 && own_kind[3] == 0;
+    // (the hidden activations are computed identically by all seven row blocks of a tile: row block rb tapes hidden tile rb -- one store per
+    //  stage and workgroup instead of seven in row block 0, whose workgroups would otherwise reach every meeting last)
+    const bool own_hstore = rb == w && own_kind[3] == 0;
     if (tid == 0) { RED[24] = 0.f; SUMS[0] = SUMS[1] = SUMS[2] = SUMS[3] = 0.0; }
     __syncthreads();
 
@@ -160,17 +163,28 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_solve_kernel(const StagePar
         slab_put(Y.tslab, tile0 + w, lane, acc0 + acc1);
     };
 
+#ifdef RNDE_DIAG      // cycle stamps of workgroup 0, eight per attempt (tools/diag_solve.py)
+#define SSTAMP(k) do { if (P.dbg_out && wg == 0 && tid == 0 && n < 120) ((unsigned long long*)P.dbg_out)[n * 8 + (k)] = clock64(); } while (0)
+#else
+#define SSTAMP(k) do { } while (0)
+#endif
     StepState S{};
     f32x4 c_un = {0.f, 0.f, 0.f, 0.f};
     for (int n = 0;; ++n) {
+        SSTAMP(0);
         // ---- controller: the state before attempt n (n > 0: from the sums the meeting of attempt n - 1 left in SUMS) ----
         {
             const float none[4] = {0.f, 0.f, 0.f, 0.f};
             const double sums[3] = {SUMS[0], SUMS[1], SUMS[2]};      // (n = 0: not read)
             const StepState prev = S;
-            S = advance_state_t<true>(P, n, lane, writer, &P.ctl[n & 1], none, prev, sums);
+            const float qp = QP[n & 1];                              // (n = 0: not read)
+            S = advance_state_t<true>(P, n, lane, writer, &P.ctl[n & 1], none, prev, sums, n > 0 ? &qp : nullptr);
             if (n > 0 && S.n_acc != prev.n_acc) { c_up = c_un; c_k[0] = c_k[6]; }      // accepted: the step starts from (unew, k7) -- already here
         }
+        // the controller of the NEXT attempt divides by qold^beta2, and qold is known now: wave 3 -- alone on its SIMD -- evaluates the power while
+        // the stages run, the others pick it up after the meeting (the barriers in between order the LDS word); same function, same argument, same bits
+        if (w == 3 && lane == 0) QP[(n + 1) & 1] = powf(S.qold, P.beta2);
+        SSTAMP(1);
         if (S.done || n >= Z.n_limit) { if (writer) *P.ctl_final = S; return; }
         const float t = S.t, dt = (P.t1 - S.t < S.dtp) ? (P.t1 - S.t) : S.dtp;
         const int rec = P.tape ? n : (S.live == 0 ? 1 : 0);
@@ -183,6 +197,7 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_solve_kernel(const StagePar
             slab_clears_done();      // the clears of the previous attempt's last stage are acknowledged before this attempt's first put
             phase_d(v, 1u);
         }
+        SSTAMP(2);
 
         float part0 = 0.f, part1 = 0.f, part2 = 0.f;
         bool alive = true;
@@ -284,19 +299,23 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_solve_kernel(const StagePar
         stage(std::integral_constant<int, 5>{});
         stage(std::integral_constant<int, 6>{});
         if (!alive) return;
+        SSTAMP(3);
 
         // ---- the meeting: this workgroup's partials (same reduction order as the attempt kernel), everybody's sums ----
         part0 = wave_sum_f(part0); part1 = wave_sum_f(part1); part2 = wave_sum_f(part2);
         if (lane == 0) { RED[w] = part0; RED[8 + w] = part1; RED[16 + w] = part2; }
         __syncthreads();
+        SSTAMP(4);
         if (w == 0) {
             float mine[3] = {0.f, 0.f, 0.f};
             for (int i = 0; i < gWT; ++i) { mine[0] += RED[i]; mine[1] += RED[8 + i]; mine[2] += RED[16 + i]; }
             double o[3];
             const bool ok = solve_meet(Z, Y, n, P.nwg, wg, P.reg_kind >= 2 ? 3 : 1, mine, o, lane);
             if (lane == 0) { SUMS[0] = o[0]; SUMS[1] = o[1]; SUMS[2] = o[2]; if (!ok) SUMS[3] = 1.0; }
+            SSTAMP(5);
         }
         __syncthreads();
+        SSTAMP(6);
         if (SUMS[3] != 0.0) return;      // the meeting timed out: abort word raised, the host redoes the solve launch by launch
     }
 }

@@ -889,8 +889,9 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
 #ifdef RNDE_DIAG
         StageParams SD = SQ;
         if (getenv("RNDE_DIAG_SOLVE")) {      // cycle stamps of workgroup 0, every attempt (tools/diag_solve.py)
-            if (!h->diag_buf) hipMalloc((void**)&h->diag_buf, 8192);
-            hipMemsetAsync(h->diag_buf, 0, 8192, s);
+            if (h->diag_buf) hipFree(h->diag_buf);
+            hipMalloc((void**)&h->diag_buf, 16384);
+            hipMemsetAsync(h->diag_buf, 0, 16384, s);
             SD.F.dbg_out = h->diag_buf;
         }
         HIPCHK(h, rnde_launch_stage_solve(&SD, &Y, &Z, h->act2, s));
@@ -917,6 +918,21 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
                 const unsigned long long* q = hst + a * 8;
                 acc[0] += (double)(q[1] - q[0]); acc[1] += (double)(q[2] - q[1]); acc[2] += (double)(q[3] - q[2]); acc[3] += (double)(q[4] - q[3]);
                 acc[4] += (double)(q[5] - q[4]); acc[5] += (double)(q[6] - q[5]); acc[6] += (double)(q[8] - q[0]);
+            }
+            static unsigned long long arr[512];
+            hipMemcpy(arr, (char*)h->diag_buf + 8192, 4096, hipMemcpyDeviceToHost);
+            {   // arrival spread and exchange latency of the meeting of attempt 10, all workgroups (100 MHz wall clock: 10 ns units)
+                std::vector<long long> a, o; const int nw = SQ.C * SQ.R;
+                for (int i = 0; i < nw && i < 256; ++i) if (arr[2 * i]) { a.push_back((long long)arr[2 * i]); o.push_back((long long)arr[2 * i + 1]); }
+                if (a.size() > 4) {
+                    std::vector<long long> sa = a; std::sort(sa.begin(), sa.end());
+                    const long long last = sa.back(), first = sa.front();
+                    std::vector<long long> so = o; std::sort(so.begin(), so.end());
+                    fprintf(stderr, "meeting of attempt 10, %zu workgroups (x10 ns): arrivals after the first: median %lld, 90%% %lld, last %lld | out after the LAST arrival: first %lld, median %lld, last %lld\n",
+                            a.size(), sa[sa.size() / 2] - first, sa[sa.size() * 9 / 10] - first, last - first, so.front() - last, so[so.size() / 2] - last, so.back() - last);
+                    int late[7] = {0}; for (size_t i = 0; i < a.size(); ++i) if (a[i] - first > (last - first) * 3 / 4) ++late[(i / SQ.C) % 7];
+                    fprintf(stderr, "  latest quarter of the spread by row block: %d %d %d %d %d %d %d\n", late[0], late[1], late[2], late[3], late[4], late[5], late[6]);
+                }
             }
             if (cnt) fprintf(stderr, "one-launch solve, workgroup 0, mean over %d attempts (cycles): controller %.0f | START %.0f | stages 1-6 %.0f | reduce + barrier %.0f | "
                                      "meeting %.0f | barrier %.0f | attempt %.0f\n", cnt, acc[0] / cnt, acc[1] / cnt, acc[2] / cnt, acc[3] / cnt, acc[4] / cnt, acc[5] / cnt, acc[6] / cnt);

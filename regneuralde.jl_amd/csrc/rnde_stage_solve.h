@@ -47,6 +47,9 @@ __device__ __forceinline__ bool solve_meet(const SolveSync& Z, const PersistSync
 #pragma unroll
     for (int v = 0; v < 3; ++v) {
         if (v >= nval) break;
+        // (one set of polling loads at a time: keeping a second set in flight -- measured in round 4 -- makes an attempt 0.3 us SLOWER; the extra
+        //  reads of the same lines on the memory side delay the stores they are waiting for; a back-off between polls, s_sleep 4 / 8 / 16, does not help
+        //  either: 23.37 / 23.46 / 23.60 us against 23.34)
         unsigned long long e[4] = {0, 0, 0, 0};
         bool ok[4];
 #pragma unroll
@@ -164,14 +167,17 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_solve_kernel(const StagePar
     };
 
 #ifdef RNDE_DIAG      // cycle stamps of workgroup 0, eight per attempt (tools/diag_solve.py)
-#define SSTAMP(k) do { if (P.dbg_out && wg == 0 && tid == 0 && n < 120) ((unsigned long long*)P.dbg_out)[n * 8 + (k)] = clock64(); } while (0)
+#define ZSTAMP(k) do { if (P.dbg_out && wg == 0 && tid == 0 && n < 120) ((unsigned long long*)P.dbg_out)[n * 8 + (k)] = clock64(); } while (0)
+// every workgroup's arrival at the meeting of attempt 10 and its way out of it (s_memrealtime: one clock for all XCDs, 100 MHz)
+#define ZARRIVE(k) do { if (P.dbg_out && tid == 0 && n == 10) ((unsigned long long*)P.dbg_out)[1024 + wg * 2 + (k)] = wall_clock64(); } while (0)
 #else
-#define SSTAMP(k) do { } while (0)
+#define ZSTAMP(k) do { } while (0)
+#define ZARRIVE(k) do { } while (0)
 #endif
     StepState S{};
     f32x4 c_un = {0.f, 0.f, 0.f, 0.f};
     for (int n = 0;; ++n) {
-        SSTAMP(0);
+        ZSTAMP(0);
         // ---- controller: the state before attempt n (n > 0: from the sums the meeting of attempt n - 1 left in SUMS) ----
         {
             const float none[4] = {0.f, 0.f, 0.f, 0.f};
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_solve_kernel(const StagePar
         // the controller of the NEXT attempt divides by qold^beta2, and qold is known now: wave 3 -- alone on its SIMD -- evaluates the power while
         // the stages run, the others pick it up after the meeting (the barriers in between order the LDS word); same function, same argument, same bits
         if (w == 3 && lane == 0) QP[(n + 1) & 1] = powf(S.qold, P.beta2);
-        SSTAMP(1);
+        ZSTAMP(1);
         if (S.done || n >= Z.n_limit) { if (writer) *P.ctl_final = S; return; }
         const float t = S.t, dt = (P.t1 - S.t < S.dtp) ? (P.t1 - S.t) : S.dtp;
         const int rec = P.tape ? n : (S.live == 0 ? 1 : 0);
@@ -193,11 +199,13 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_solve_kernel(const StagePar
         // ---- the attempt kernel's START: g2, exchange 1 ----
         {
             const f32x4 v = fma4(dt, tsA(1, 0) * c_k[0], c_up);
+            // the clears of the previous attempt's last stage are acknowledged before this attempt's first put -- they were issued before the meeting, so
+            // nothing waits here; BEHIND the tape store below the same wait would sit on that store's acknowledgement (vmcnt counts stores too)
+            slab_clears_done();
             if (P.tape) st4(R + L.g(2) + co, r0, gD, true, vec, v);
-            slab_clears_done();      // the clears of the previous attempt's last stage are acknowledged before this attempt's first put
             phase_d(v, 1u);
         }
-        SSTAMP(2);
+        ZSTAMP(2);
 
         float part0 = 0.f, part1 = 0.f, part2 = 0.f;
         bool alive = true;
@@ -299,23 +307,25 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_solve_kernel(const StagePar
         stage(std::integral_constant<int, 5>{});
         stage(std::integral_constant<int, 6>{});
         if (!alive) return;
-        SSTAMP(3);
+        ZSTAMP(3);
 
         // ---- the meeting: this workgroup's partials (same reduction order as the attempt kernel), everybody's sums ----
-        part0 = wave_sum_f(part0); part1 = wave_sum_f(part1); part2 = wave_sum_f(part2);
-        if (lane == 0) { RED[w] = part0; RED[8 + w] = part1; RED[16 + w] = part2; }
+        const bool three = P.reg_kind >= 2;      // (the two norms of the stiffness estimate travel only when it is asked for)
+        part0 = wave_sum_f(part0);
+        if (three) { part1 = wave_sum_f(part1); part2 = wave_sum_f(part2); }
+        if (lane == 0) { RED[w] = part0; if (three) { RED[8 + w] = part1; RED[16 + w] = part2; } }
         __syncthreads();
-        SSTAMP(4);
+        ZSTAMP(4); ZARRIVE(0);
         if (w == 0) {
             float mine[3] = {0.f, 0.f, 0.f};
-            for (int i = 0; i < gWT; ++i) { mine[0] += RED[i]; mine[1] += RED[8 + i]; mine[2] += RED[16 + i]; }
+            for (int i = 0; i < gWT; ++i) { mine[0] += RED[i]; if (three) { mine[1] += RED[8 + i]; mine[2] += RED[16 + i]; } }
             double o[3];
             const bool ok = solve_meet(Z, Y, n, P.nwg, wg, P.reg_kind >= 2 ? 3 : 1, mine, o, lane);
             if (lane == 0) { SUMS[0] = o[0]; SUMS[1] = o[1]; SUMS[2] = o[2]; if (!ok) SUMS[3] = 1.0; }
-            SSTAMP(5);
+            ZSTAMP(5); ZARRIVE(1);
         }
         __syncthreads();
-        SSTAMP(6);
+        ZSTAMP(6);
         if (SUMS[3] != 0.0) return;      // the meeting timed out: abort word raised, the host redoes the solve launch by launch
     }
 }

@@ -438,7 +438,7 @@ __global__ __launch_bounds__(512) void rnde_latent_gru_bwd_kernel(const GruParam
 // ---------------------------------------------------------------------------------------------------------------------------------
 constexpr int kWgChunk = 64;       // samples staged in LDS at a time
 constexpr int kWgSub = 4;          // sub-chunks a workgroup accumulates in registers before it writes its partial: 256 samples per workgroup
-struct WgradJob { const float* delta; const float* act; float* slab; float* out; int ld_d, ld_a, M, N, K, m_split, m_gap; };
+struct WgradJob { const float* delta; const float* act; float* slab; float* out; int ld_d, ld_a, M, N, K, m_split, m_gap, groups; };      // groups: partials in the slab (0: one per kWgChunk * kWgSub samples)
 // m_split / m_gap: output rows m >= m_split read delta column m + m_gap (the new-state cotangent keeps its std half at offset 52)
 struct WgradJobs { WgradJob j[8]; int n; };
 
@@ -499,10 +499,132 @@ __global__ __launch_bounds__(256) void rnde_latent_wgrad_kernel(const WgradJobs 
         }
     }
 }
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The six weight gradients of the GRU in ONE pass over the tapes (round 4).  rnde_latent_wgrad_kernel above reads a job's operands from the
+// tape once per job: the activation record (680 floats per sample and step) is read three times, 250 MB for 100 MB of tape.  Here a workgroup
+// brings 16 whole records of both tapes into LDS (contiguous in memory: 252 `global_load_lds` requests of 256 B, 64.5 KB), and every job's
+// tiles are multiplied out of that image -- 144 accumulator tiles of 16 x 16, 36 per wave, register resident across the workgroup's records.
+// Two workgroups share a CU (4 waves, 64.5 KB each): one's requests land while the other multiplies.  Partials go to the slab of
+// rnde_latent_reduce_kernel (fixed-order sum over the workgroups: deterministic).  The jobs' delta / act pointers must lie inside one DEL / ACT
+// record (offsets d_off / a_off are taken from them).
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int kFwSamples = 16;                                          // records per chunk
+constexpr int kFwTilesPerWave = 36;
+constexpr int kFwMaxLdsFloats = kFwSamples * (kActLd + kDelLd);         // the GRU's records: 16,128 floats = 64.5 KB (two workgroups per CU)
+// act / del: first record of the two tapes, LDA / LDD floats per record (multiples of 4: compile-time, the k-steps of a tile are then immediate
+// offsets of its LDS reads); the jobs' pointers lie inside the first record.  The image is followed by 16 zero floats: a lane whose row / column is
+// padding of its tile reads whatever lies next to its job's columns -- that pollutes accumulator rows / columns that are never stored.
+struct FusedWgrad { WgradJobs J; const float* act; const float* del; int K; };
+template <int LDA, int LDD>
+__global__ __launch_bounds__(256, 2) void rnde_latent_gru_wgrad_kernel(const FusedWgrad F) {
+    extern __shared__ __attribute__((aligned(16))) float S[];
+    __shared__ int TT[4 * kFwTilesPerWave];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int nA = kFwSamples * LDA, nD = kFwSamples * LDD;          // floats of a chunk's two images (multiples of 64)
+    static_assert(nA + nD + 16 < (1 << 15), "record sizes");
+    constexpr bool kDma = nA % 64 == 0 && nD % 64 == 0;                  // whole 256-byte requests (records of a multiple of 4 floats); else plain loads
+    if (tid < 16) S[nA + nD + tid] = 0.f;
+    // tile table: (job, mt, nt) of tile i, jobs in order
+    if (tid < 4 * kFwTilesPerWave) {
+        int i = tid, code = -1;
+        for (int j = 0; j < F.J.n; ++j) {
+            const int MT = (F.J.j[j].M + 15) >> 4, NT = (F.J.j[j].N + 1 + 15) >> 4;
+            if (i < MT * NT) { code = (j << 16) | ((i / NT) << 8) | (i % NT); break; }
+            i -= MT * NT;
+        }
+        TT[tid] = code;
+    }
+    __syncthreads();
+    // this lane's operand addresses of its wave's tiles, once: delta index in bits 0..14, act index in bits 16..30, bit 31: this lane is the bias column
+    unsigned ix[kFwTilesPerWave];
+#pragma unroll
+    for (int q = 0; q < kFwTilesPerWave; ++q) {
+        const int code = TT[w + 4 * q];
+        ix[q] = 0u;
+        if (code >= 0) {
+            const WgradJob& J = F.J.j[code >> 16];
+            const int m = 16 * ((code >> 8) & 255) + (lane & 15), n = 16 * (code & 255) + (lane & 15), kk = lane >> 4;
+            ix[q] = (unsigned)(nA + kk * LDD + (int)(J.delta - F.del) + m + (m >= J.m_split ? J.m_gap : 0)) | ((unsigned)(kk * LDA + (int)(J.act - F.act) + n) << 16) |
+                    (n == J.N ? 0x80000000u : 0u);
+        }
+    }
+    f32x4 acc[kFwTilesPerWave];
+#pragma unroll
+    for (int q = 0; q < kFwTilesPerWave; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nchunks = (F.K + kFwSamples - 1) / kFwSamples;
+    typedef __attribute__((address_space(3))) void lds_v;
+    typedef const __attribute__((address_space(1))) void gbl_v;
+    for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const int s0 = c * kFwSamples, ns = min(kFwSamples, F.K - s0);
+        __syncthreads();                                     // everybody has left the previous image
+        if (kDma && ns == kFwSamples) {
+            const float* ga = F.act + (size_t)s0 * LDA; const float* gd = F.del + (size_t)s0 * LDD;
+            for (int u = w; u < nA / 64; u += 4) __builtin_amdgcn_global_load_lds((gbl_v*)(ga + u * 64 + lane), (lds_v*)(S + u * 64), 4, 0, 0);
+            for (int u = w; u < nD / 64; u += 4) __builtin_amdgcn_global_load_lds((gbl_v*)(gd + u * 64 + lane), (lds_v*)(S + nA + u * 64), 4, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {                                             // the last, partial chunk: guarded loads, zero rows behind the data
+            for (int i = tid; i < nA; i += 256) S[i] = (i / LDA < ns) ? F.act[(size_t)s0 * LDA + i] : 0.f;
+            for (int i = tid; i < nD; i += 256) S[nA + i] = (i / LDD < ns) ? F.del[(size_t)s0 * LDD + i] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kFwTilesPerWave; ++q) {
+            const int code = TT[w + 4 * q];                  // (wave-uniform)
+            if (code >= 0) {
+                const float* dp = S + (ix[q] & 0x7FFFu);
+                const float* ap = S + ((ix[q] >> 16) & 0x7FFFu);
+                f32x4 a = acc[q];
+                const WgradJob& J = F.J.j[code >> 16];
+                if (16 * (code & 255) + 16 > J.N) {         // the tile holds the bias column: that lane multiplies by 1
+                    const bool ab = (ix[q] >> 31) != 0;
+#pragma unroll
+                    for (int ks = 0; ks < kFwSamples / 4; ++ks) { const float y = ap[ks * 4 * LDA]; a = mfma16(dp[ks * 4 * LDD], ab ? 1.f : y, a); }
+                } else {
+#pragma unroll
+                    for (int ks = 0; ks < kFwSamples / 4; ++ks) a = mfma16(dp[ks * 4 * LDD], ap[ks * 4 * LDA], a);
+                }
+                acc[q] = a;
+            }
+        }
+    }
+    // partials of this workgroup, Flux layout [vec(W) (M x N, column-major); b] per job
+#pragma unroll
+    for (int q = 0; q < kFwTilesPerWave; ++q) {
+        const int code = TT[w + 4 * q];
+        if (code >= 0) {
+            const int j = code >> 16, mt = (code >> 8) & 255, nt = code & 255;
+            const WgradJob& J = F.J.j[j];
+            float* out = J.slab + (size_t)blockIdx.x * (J.N + 1) * J.M;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = 16 * mt + 4 * (lane >> 4) + i, n = 16 * nt + (lane & 15);
+                if (m < J.M && n <= J.N) out[(size_t)n * J.M + m] = acc[q][i];
+            }
+        }
+    }
+}
+// first level of the reduction of MANY partials: blockIdx.z sums the groups [z * per, (z + 1) * per) of job blockIdx.y into partial z of slab2
+// (same fixed order inside a segment; the second level is rnde_latent_reduce_kernel over the segments)
+__global__ void rnde_latent_reduce_seg_kernel(const WgradJobs JJ, int per, float* __restrict__ slab2, int nseg) {
+    const WgradJob J = JJ.j[blockIdx.y];
+    const int len = (J.N + 1) * J.M, g0 = blockIdx.z * per, g1 = min(J.groups, g0 + per);
+    float* dst = slab2 + ((size_t)(J.slab - JJ.j[0].slab) / (size_t)J.groups) * nseg + (size_t)blockIdx.z * len;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < len; i += gridDim.x * 256) {
+        float s = 0.f;
+        int c = g0;
+        for (; c + 4 <= g1; c += 4) {
+            const float v0 = J.slab[(size_t)c * len + i], v1 = J.slab[(size_t)(c + 1) * len + i], v2 = J.slab[(size_t)(c + 2) * len + i], v3 = J.slab[(size_t)(c + 3) * len + i];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; c < g1; ++c) s += J.slab[(size_t)c * len + i];
+        dst[i] = s;
+    }
+}
+
 // out[i] = sum over the groups c (in order) of slab[c][i]; blockIdx.y = job.  Four loads in flight per thread, the additions in group order.
 __global__ void rnde_latent_reduce_kernel(const WgradJobs JJ) {
     const WgradJob J = JJ.j[blockIdx.y];
-    const int groups = (J.K + kWgChunk * kWgSub - 1) / (kWgChunk * kWgSub), len = (J.N + 1) * J.M;
+    const int groups = J.groups ? J.groups : (J.K + kWgChunk * kWgSub - 1) / (kWgChunk * kWgSub), len = (J.N + 1) * J.M;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < len; i += gridDim.x * 256) {
         float s = 0.f;
         int c = 0;

@@ -7,12 +7,15 @@
 #include <cmath>
 #include <string>
 
+constexpr int kFusedSegs = 16;             // segments of the first reduction level over those partials
+constexpr int kFusedWgradGroups = 512;      // workgroups of rnde_latent_gru_wgrad_kernel (two per CU), each leaving one partial per job
+
 using namespace rnde_lat;
 
 struct rnde_latent {
     rnde_latent_config cfg{};
     float *act = nullptr, *del = nullptr, *y = nullptr, *yb = nullptr, *h1 = nullptr, *out = nullptr, *d1 = nullptr, *d2 = nullptr;
-    float *kl = nullptr, *ll = nullptr, *gD = nullptr, *slab = nullptr, *eps = nullptr;
+    float *kl = nullptr, *ll = nullptr, *gD = nullptr, *slab = nullptr, *slab2 = nullptr, *eps = nullptr;
     int B = 0, T = 0;
     bool encoded = false;
     std::string err;
@@ -47,14 +50,15 @@ extern "C" rnde_status rnde_latent_create(const rnde_latent_config* c, rnde_late
               hipMalloc((void**)&h->d1, B * kRec * 4) == hipSuccess && hipMalloc((void**)&h->d2, B * 2 * kLat * 4) == hipSuccess &&
               hipMalloc((void**)&h->kl, B * 4) == hipSuccess && hipMalloc((void**)&h->ll, B * 4) == hipSuccess &&
               hipMalloc((void**)&h->gD, S * 40 * 4) == hipSuccess && hipMalloc((void**)&h->eps, B * kLat * 4) == hipSuccess &&
-              hipMalloc((void**)&h->slab, ((S + kWgChunk * kWgSub - 1) / (kWgChunk * kWgSub)) * (size_t)(3 * (kNIn + 1) * kH + 2 * (kH + 1) * kL + (kH + 1) * 2 * kL) * 4) == hipSuccess;      // the six GRU jobs side by side
+              hipMalloc((void**)&h->slab, std::max<size_t>(kFusedWgradGroups, (S + kWgChunk * kWgSub - 1) / (kWgChunk * kWgSub)) * (size_t)(3 * (kNIn + 1) * kH + 2 * (kH + 1) * kL + (kH + 1) * 2 * kL) * 4) == hipSuccess;      // the six GRU jobs side by side
+    ok = ok && hipMalloc((void**)&h->slab2, (size_t)kFusedSegs * (3 * (kNIn + 1) * kH + 2 * (kH + 1) * kL + (kH + 1) * 2 * kL) * 4) == hipSuccess;
     if (!ok) { g_latent_err = "device allocation failed"; rnde_latent_destroy(h); return RNDE_ERR_HIP; }
     *out = h;
     return RNDE_OK;
 }
 extern "C" void rnde_latent_destroy(rnde_latent* h) {
     if (!h) return;
-    for (float* p : {h->act, h->del, h->y, h->yb, h->h1, h->out, h->d1, h->d2, h->kl, h->ll, h->gD, h->slab, h->eps}) if (p) (void)hipFree(p);
+    for (float* p : {h->act, h->del, h->y, h->yb, h->h1, h->out, h->d1, h->d2, h->kl, h->ll, h->gD, h->slab, h->slab2, h->eps}) if (p) (void)hipFree(p);
     delete h;
 }
 
@@ -69,10 +73,11 @@ static rnde_status check_shape(rnde_latent* h, int B, int T) {
 struct JobList {
     WgradJobs jj{};
     size_t slab_used = 0;
+    int fused_groups = 0;      // > 0: the slab holds that many partials per job (rnde_latent_gru_wgrad_kernel: one per workgroup)
     void add(rnde_latent* h, const float* delta, int ld_d, int M, const float* act, int ld_a, int N, int K, float* out, int m_split = 1 << 30, int m_gap = 0) {
         const int groups = (K + kWgChunk * kWgSub - 1) / (kWgChunk * kWgSub);
-        jj.j[jj.n++] = WgradJob{delta, act, h->slab + slab_used, out, ld_d, ld_a, M, N, K, m_split, m_gap};
-        slab_used += (size_t)groups * (N + 1) * M;
+        jj.j[jj.n++] = WgradJob{delta, act, h->slab + slab_used, out, ld_d, ld_a, M, N, K, m_split, m_gap, fused_groups};
+        slab_used += (size_t)(fused_groups ? fused_groups : groups) * (N + 1) * M;
     }
 };
 static rnde_status run_jobs(rnde_latent* h, const JobList& Jl, hipStream_t s) {
@@ -85,6 +90,24 @@ static rnde_status run_jobs(rnde_latent* h, const JobList& Jl, hipStream_t s) {
     }
     hipLaunchKernelGGL(rnde_latent_wgrad_kernel, dim3(gmax, Jl.jj.n), dim3(256), lds, s, Jl.jj);
     hipLaunchKernelGGL(rnde_latent_reduce_kernel, dim3((lmax + 255) / 256, Jl.jj.n), dim3(256), 0, s, Jl.jj);
+    LCHK(h, hipGetLastError());
+    return RNDE_OK;
+}
+
+// The same jobs in ONE pass over two tapes of whole records (rnde_latent_gru_wgrad_kernel): partials per workgroup, then the fixed-order reduction in two
+// levels (kFusedSegs segments of the workgroups, then the segments).  Jl.fused_groups set before the jobs were added.
+template <int LDA, int LDD>
+static rnde_status run_fused(rnde_latent* h, const JobList& Jl, const float* act, const float* del, int K, hipStream_t s) {
+    FusedWgrad F{Jl.jj, act, del, K};
+    const int G = Jl.fused_groups;
+    hipLaunchKernelGGL((rnde_latent_gru_wgrad_kernel<LDA, LDD>), dim3(G), dim3(256), sizeof(float) * (kFwSamples * (size_t)(LDA + LDD) + 16), s, F);
+    int lmax = 0;
+    for (int i = 0; i < Jl.jj.n; ++i) lmax = std::max(lmax, (Jl.jj.j[i].N + 1) * Jl.jj.j[i].M);
+    const int nseg = std::min(kFusedSegs, G), per = (G + nseg - 1) / nseg;
+    hipLaunchKernelGGL(rnde_latent_reduce_seg_kernel, dim3((lmax + 255) / 256, Jl.jj.n, nseg), dim3(256), 0, s, Jl.jj, per, h->slab2, nseg);
+    WgradJobs J2 = Jl.jj;
+    for (int i = 0; i < J2.n; ++i) { J2.j[i].slab = h->slab2 + (size_t)(Jl.jj.j[i].slab - Jl.jj.j[0].slab) / G * nseg; J2.j[i].groups = (G + per - 1) / per; }
+    hipLaunchKernelGGL(rnde_latent_reduce_kernel, dim3((lmax + 255) / 256, J2.n), dim3(256), 0, s, J2);
     LCHK(h, hipGetLastError());
     return RNDE_OK;
 }
@@ -121,8 +144,9 @@ extern "C" rnde_status rnde_latent_decode_loss(rnde_latent* h, const float* res_
     hipLaunchKernelGGL(rnde_latent_loss_kernel, dim3(1), dim3(256), 0, s, h->ll, h->kl, B, loss2_out_dev);
     LCHK(h, hipGetLastError());
     JobList Jl;
+    Jl.fused_groups = std::min(kFusedWgradGroups, (B * T + kFwSamples - 1) / kFwSamples);
     Jl.add(h, h->gD, 40, kIn, res_dev, kLat, kLat, B * T, p4_bar_out_dev);      // gen_to_data: [vec(W4) (37 x 20); b4]
-    return run_jobs(h, Jl, s);
+    return run_fused<kLat, 40>(h, Jl, res_dev, h->gD, B * T, s);
 }
 
 extern "C" rnde_status rnde_latent_encode_backward(rnde_latent* h, const float* z0_bar_dev, float lambda_k, const float* p1_dev, const float* p2_dev,
@@ -137,11 +161,15 @@ extern "C" rnde_status rnde_latent_encode_backward(rnde_latent* h, const float* 
     hipLaunchKernelGGL(rnde_latent_enc_bwd_kernel, dim3(B), dim3(128), 0, s, E);
     LCHK(h, hipGetLastError());
     // rec_to_gen: Dense(100, 50, tanh) [W1; b1] then Dense(50, 40) [W2; b2]
-    JobList Je;
-    Je.add(h, h->d1, kRec, kRec, h->y, 2 * kL, 2 * kL, B, p2_bar_out_dev);
-    Je.add(h, h->d2, 2 * kLat, 2 * kLat, h->h1, kRec, kRec, B, p2_bar_out_dev + 2 * kL * kRec + kRec);
-    rnde_status st = run_jobs(h, Je, s);
-    if (st != RNDE_OK) return st;
+    rnde_status st;
+    {   // (one job per pass: the two layers' tapes are separate arrays)
+        JobList Je1, Je2;
+        Je1.fused_groups = Je2.fused_groups = std::min(kFusedWgradGroups, (B + kFwSamples - 1) / kFwSamples);
+        Je1.add(h, h->d1, kRec, kRec, h->y, 2 * kL, 2 * kL, B, p2_bar_out_dev);
+        if ((st = run_fused<2 * kL, kRec>(h, Je1, h->y, h->d1, B, s)) != RNDE_OK) return st;
+        Je2.add(h, h->d2, 2 * kLat, 2 * kLat, h->h1, kRec, kRec, B, p2_bar_out_dev + 2 * kL * kRec + kRec);
+        if ((st = run_fused<kRec, 2 * kLat>(h, Je2, h->h1, h->d2, B, s)) != RNDE_OK) return st;
+    }
     GruParams G{x_dev, p1_dev, h->act, h->del, h->yb, B, T};
     const size_t lds = sizeof(float) * (23 * 256 + (size_t)T * 16);
     hipLaunchKernelGGL(rnde_latent_gru_bwd_kernel, dim3((B + 15) / 16), dim3(512), lds, s, G);
@@ -149,13 +177,14 @@ extern "C" rnde_status rnde_latent_encode_backward(rnde_latent* h, const float* 
     // the six Dense layers of the GRU, in Flux.destructure order: update_gate (Wu1, Wu2), reset_gate (Wr1, Wr2), new_state (Wn1, Wn2): one launch
     float* g = p1_bar_out_dev;
     JobList Jg;
+    Jg.fused_groups = std::min(kFusedWgradGroups, (K + kFwSamples - 1) / kFwSamples);
     Jg.add(h, h->del + dZU, kDelLd, kH, h->act + aYC, kActLd, kNIn, K, g + oWu1);
     Jg.add(h, h->del + dAU, kDelLd, kL, h->act + aU1, kActLd, kH, K, g + oWu2);
     Jg.add(h, h->del + dZR, kDelLd, kH, h->act + aYC, kActLd, kNIn, K, g + oWr1);
     Jg.add(h, h->del + dAR, kDelLd, kL, h->act + aR1, kActLd, kH, K, g + oWr2);
     Jg.add(h, h->del + dZN, kDelLd, kH, h->act + aCC, kActLd, kNIn, K, g + oWn1);
     Jg.add(h, h->del + dNS, kDelLd, 2 * kL, h->act + aN1, kActLd, kH, K, g + oWn2, kL, 2);
-    if ((st = run_jobs(h, Jg, s)) != RNDE_OK) return st;
+    if ((st = run_fused<kActLd, kDelLd>(h, Jg, h->act, h->del, K, s)) != RNDE_OK) return st;      // all six in one pass over the tapes
     h->encoded = false;
     return RNDE_OK;
 }

@@ -669,9 +669,10 @@ def main():
                     roof["traffic"], roof["traffic_source"] = tr[0] * (7 if tr[1].startswith("rnde_stage_kernel") else 1), tr[2]
                     if tr[1] == "rnde_stage_solve_kernel":
                         pa = committed_traffic("", ["attempts_per_solve_launch"], (PROFILE_ROUND,))
-                        if pa is not None:
+                        if pa is not None:      # per LAUNCH of THIS run: the profiled launch held pa[0] attempted steps, this run's holds units_per_launch
                             roof["traffic_per_attempt"] = tr[0] / pa[0]
-                            roof["traffic_attempts_per_launch_in_that_run"] = pa[0]
+                            roof["traffic_profiled_launch"] = {"bytes": tr[0], "attempts": pa[0]}
+                            roof["traffic"] = roof["traffic_per_attempt"] * roof["units_per_launch"]
         except Exception:
             pass
         # the measured floor of this kernel's decomposition: its MFMAs alone with operands in registers (profiles/r0N_attempt_ablation.csv)

@@ -9,7 +9,8 @@ from tests.util import Node
 _DEFAULT_TILE[0] = 65
 rng = np.random.default_rng(2)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-arch, p, x = _setup("latent", 512, 5, 1.0)
+MAXB = int(os.environ.get("STRESS_MAXB", "512"))      # STRESS_MAXB=4096: the throughput mode (more than 32 workgroups, agent-scope meeting)
+arch, p, x = _setup("latent", MAXB, 5, 1.0)
 bad = 0
 t0 = time.time()
 nodes = {}
@@ -17,10 +18,10 @@ for tol in (1e-2, 1e-4, 1.4e-8):
     for one in ("1", "0"):
         os.environ["RNDE_CHAIN_SOLVE"] = one
         os.environ["RNDE_CHAIN_BSWEEP"] = one
-        nodes[(tol, one)] = Node(_cfg(arch, 512, reltol=tol, abstol=tol, max_attempts=512))
+        nodes[(tol, one)] = Node(_cfg(arch, MAXB, reltol=tol, abstol=tol, max_attempts=512))
 for it in range(N):
     tol = (1e-2, 1e-4, 1.4e-8)[it % 3]
-    B = int(rng.integers(1, 513))
+    B = int(rng.integers(1, MAXB + 1))
     xs = rng.standard_normal((B, 20)).astype(np.float32)
     ps = (p * (1.0 + 1.0 * rng.random())).astype(np.float32)
     out = {}

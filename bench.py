@@ -609,7 +609,8 @@ def main():
                      "allreduce_us": ar_us, "allreduce_floats": int(fg.flat.numel()) if fg is not None else None,
                      "collective_library": L.rnde_comm_library().decode() if reducer is not None and reducer.comm is not None and reducer.collective == "rccl" else None,
                      # (RNDE_ONESHOT=1 in the environment: the one-shot kernel over peer-mapped windows instead of ncclAllReduce)
-                     "collective_path": L.rnde_comm_path(reducer.comm).decode() if reducer is not None and reducer.comm is not None else None}
+                     "collective_path": L.rnde_comm_path(reducer.comm).decode() if reducer is not None and reducer.comm is not None else None,
+                     "collective_fallback": getattr(reducer, "fallback_reason", None) if reducer is not None else None}
 
     out = None
     if args.coupled:

@@ -50,6 +50,7 @@ class GradientAllReducer:
         self.fg = flat if flat is not None else FlatGrads(self.params)
         self.flat = self.fg.flat
         self.comm = None
+        self.fallback_reason = None
         if self.flat.is_cuda:
             self._init_comm(dist)
 
@@ -83,9 +84,25 @@ class GradientAllReducer:
         dist.broadcast_object_list(ids, src=0, group=self.pg)
         self.comm = C.c_void_p()
         st = L.rnde_comm_create(ids[0], rank, self.world, self.flat.device.index or 0, C.byref(self.comm))
-        if st != 0:
-            raise _lib.RndeError(st, L.rnde_comm_last_error(None).decode())
         self._L = L
+        reason = None if st == 0 else L.rnde_comm_last_error(None).decode()
+        if self.world > 1:
+            # every rank must end up on the SAME path: if the library's communicator failed anywhere (it has never met more than one GPU: no such
+            # box exists where it was written), all ranks drop it and the gradient all-reduce goes through torch.distributed's RCCL instead --
+            # slower by a launch or two, never wrong, and reported (`fallback_reason`, the bench's `dist.collective_fallback`)
+            ok = torch.tensor([1 if st == 0 else 0], dtype=torch.int32, device=self.flat.device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.pg)
+            if int(ok.item()) == 0:
+                if st == 0:
+                    L.rnde_comm_destroy(self.comm)
+                    reason = "another rank could not create its library communicator"
+                self.comm = None
+                self.fallback_reason = reason
+                import sys
+                print(f"[rnde] rank {rank}: library communicator unavailable ({reason}); gradient all-reduce through torch.distributed", file=sys.stderr)
+                return
+        elif st != 0:
+            raise _lib.RndeError(st, reason)
 
     def __del__(self):
         try:

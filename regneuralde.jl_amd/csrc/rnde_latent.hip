@@ -18,6 +18,7 @@ struct rnde_latent {
     float *kl = nullptr, *ll = nullptr, *gD = nullptr, *slab = nullptr, *slab2 = nullptr, *eps = nullptr;
     int B = 0, T = 0;
     bool encoded = false;
+    hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;      // rec_to_gen's weight gradients run beside the reverse GRU (32 workgroups)
     std::string err;
 };
 static thread_local std::string g_latent_err;
@@ -52,12 +53,17 @@ extern "C" rnde_status rnde_latent_create(const rnde_latent_config* c, rnde_late
               hipMalloc((void**)&h->gD, S * 40 * 4) == hipSuccess && hipMalloc((void**)&h->eps, B * kLat * 4) == hipSuccess &&
               hipMalloc((void**)&h->slab, std::max<size_t>(kFusedWgradGroups, (S + kWgChunk * kWgSub - 1) / (kWgChunk * kWgSub)) * (size_t)(3 * (kNIn + 1) * kH + 2 * (kH + 1) * kL + (kH + 1) * 2 * kL) * 4) == hipSuccess;      // the six GRU jobs side by side
     ok = ok && hipMalloc((void**)&h->slab2, (size_t)kFusedSegs * (3 * (kNIn + 1) * kH + 2 * (kH + 1) * kL + (kH + 1) * 2 * kL) * 4) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) == hipSuccess;
     if (!ok) { g_latent_err = "device allocation failed"; rnde_latent_destroy(h); return RNDE_ERR_HIP; }
     *out = h;
     return RNDE_OK;
 }
 extern "C" void rnde_latent_destroy(rnde_latent* h) {
     if (!h) return;
+    if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     for (float* p : {h->act, h->del, h->y, h->yb, h->h1, h->out, h->d1, h->d2, h->kl, h->ll, h->gD, h->slab, h->slab2, h->eps}) if (p) (void)hipFree(p);
     delete h;
 }
@@ -162,18 +168,23 @@ extern "C" rnde_status rnde_latent_encode_backward(rnde_latent* h, const float* 
     LCHK(h, hipGetLastError());
     // rec_to_gen: Dense(100, 50, tanh) [W1; b1] then Dense(50, 40) [W2; b2]
     rnde_status st;
-    {   // (one job per pass: the two layers' tapes are separate arrays)
+    {   // (one job per pass: the two layers' tapes are separate arrays)  These launches do not feed the reverse GRU, which is a 173 us latency chain on
+        // 32 workgroups: they run on a stream of their own beside it and are joined in front of the GRU's own weight gradients (same slab)
+        LCHK(h, hipEventRecord(h->ev_fork, s));
+        LCHK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
         JobList Je1, Je2;
         Je1.fused_groups = Je2.fused_groups = std::min(kFusedWgradGroups, (B + kFwSamples - 1) / kFwSamples);
         Je1.add(h, h->d1, kRec, kRec, h->y, 2 * kL, 2 * kL, B, p2_bar_out_dev);
-        if ((st = run_fused<2 * kL, kRec>(h, Je1, h->y, h->d1, B, s)) != RNDE_OK) return st;
+        if ((st = run_fused<2 * kL, kRec>(h, Je1, h->y, h->d1, B, h->side)) != RNDE_OK) return st;
         Je2.add(h, h->d2, 2 * kLat, 2 * kLat, h->h1, kRec, kRec, B, p2_bar_out_dev + 2 * kL * kRec + kRec);
-        if ((st = run_fused<kRec, 2 * kLat>(h, Je2, h->h1, h->d2, B, s)) != RNDE_OK) return st;
+        if ((st = run_fused<kRec, 2 * kLat>(h, Je2, h->h1, h->d2, B, h->side)) != RNDE_OK) return st;
+        LCHK(h, hipEventRecord(h->ev_join, h->side));
     }
     GruParams G{x_dev, p1_dev, h->act, h->del, h->yb, B, T};
     const size_t lds = sizeof(float) * (23 * 256 + (size_t)T * 16);
     hipLaunchKernelGGL(rnde_latent_gru_bwd_kernel, dim3((B + 15) / 16), dim3(512), lds, s, G);
     LCHK(h, hipGetLastError());
+    LCHK(h, hipStreamWaitEvent(s, h->ev_join, 0));
     // the six Dense layers of the GRU, in Flux.destructure order: update_gate (Wu1, Wu2), reset_gate (Wr1, Wr2), new_state (Wn1, Wn2): one launch
     float* g = p1_bar_out_dev;
     JobList Jg;

@@ -12,8 +12,8 @@
 //                                layer input / output of every step goes to the ACT tape ([sample][feature], sample = t * B + b)
 //   rnde_latent_gru_bwd_kernel   the reverse recurrence: only the cotangent PROPAGATION (four products with transposed weights per step);
 //                                the pre-activation cotangents go to the DEL tape
-//   rnde_latent_wgrad_kernel     every weight gradient of the model is one GEMM  sum_samples delta^T act  over a tape pair; per-chunk
-//                                partials in a slab, summed in a fixed order by rnde_latent_reduce_kernel (deterministic, no float atomics)
+//   rnde_latent_gru_wgrad_kernel every weight gradient of the model is a GEMM  sum_samples delta^T act  over a tape pair: all jobs of a pair in one
+//                                pass over whole records; per-workgroup partials summed in a fixed order (deterministic, no float atomics)
 //   rnde_latent_enc_*            Dense(100, 50, tanh) -> Dense(50, 40), z0 = eps * exp(logvar / 2) + mu0, KL per sample (+ reverse)
 //   rnde_latent_dec_loss_kernel  Dense(20, 37) on every saved state, masked Gaussian log likelihood / observed count, and the reverse of both
 // Layouts: Julia's F x T x B arrays as they are (feature fastest): element (f, t, b) at (b * T + t) * F + f.
@@ -433,80 +433,20 @@ __global__ __launch_bounds__(512) void rnde_latent_gru_bwd_kernel(const GruParam
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // weight gradients: out[m][n] = sum over samples s of delta[s][m] * act[s][n]   (m < M, n < N; n == N: the bias, act = 1)
-// One workgroup per chunk of kWgChunk samples; partials [chunk][(N + 1) * M] in the slab (element (m, n) at n * M + m: the layout of a
-// Flux Dense [vec(W); b]); rnde_latent_reduce_kernel sums the chunks in order.
+// delta, act: columns of two tapes of records ([sample][features]); out: element (m, n) at n * M + m, the layout of a Flux Dense [vec(W); b]
 // ---------------------------------------------------------------------------------------------------------------------------------
-constexpr int kWgChunk = 64;       // samples staged in LDS at a time
-constexpr int kWgSub = 4;          // sub-chunks a workgroup accumulates in registers before it writes its partial: 256 samples per workgroup
-struct WgradJob { const float* delta; const float* act; float* slab; float* out; int ld_d, ld_a, M, N, K, m_split, m_gap, groups; };      // groups: partials in the slab (0: one per kWgChunk * kWgSub samples)
+struct WgradJob { const float* delta; const float* act; float* out; int M, N, m_split, m_gap; };
 // m_split / m_gap: output rows m >= m_split read delta column m + m_gap (the new-state cotangent keeps its std half at offset 52)
 struct WgradJobs { WgradJob j[8]; int n; };
 
-// blockIdx.y = job, blockIdx.x = group of kWgSub chunks
-__global__ __launch_bounds__(256) void rnde_latent_wgrad_kernel(const WgradJobs JJ) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const WgradJob J = JJ.j[blockIdx.y];
-    const int groups = (J.K + kWgChunk * kWgSub - 1) / (kWgChunk * kWgSub);
-    if ((int)blockIdx.x >= groups) return;
-    const int Mp = (J.M + 15) & ~15, Np = (J.N + 1 + 15) & ~15;      // (+ 1: the bias column)
-    float* DS = smem;                       // [chunk][Mp]
-    float* AS = DS + kWgChunk * Mp;         // [chunk][Np]
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int MT = Mp / 16, NT = Np / 16, ntile = MT * NT;
-    constexpr int kMaxTiles = 14;           // per wave: ceil(3 * 11 + ... ) -- the largest job (40 x 176) has 33 tiles, 100 x 41: 21
-    f32x4 acc[kMaxTiles];
-#pragma unroll
-    for (int q = 0; q < kMaxTiles; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int sub = 0; sub < kWgSub; ++sub) {
-        const int s0 = (blockIdx.x * kWgSub + sub) * kWgChunk, ns = min(kWgChunk, J.K - s0);
-        if (ns <= 0) break;
-        if (sub) __syncthreads();
-        for (int i = tid; i < kWgChunk * Mp; i += 256) {
-            const int s = i / Mp, m = i - s * Mp;
-            DS[i] = (s < ns && m < J.M) ? J.delta[(size_t)(s0 + s) * J.ld_d + m + (m >= J.m_split ? J.m_gap : 0)] : 0.f;
-        }
-        for (int i = tid; i < kWgChunk * Np; i += 256) {
-            const int s = i / Np, n = i - s * Np;
-            AS[i] = (s < ns && n <= J.N) ? (n < J.N ? J.act[(size_t)(s0 + s) * J.ld_a + n] : 1.f) : 0.f;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < kMaxTiles; ++q) {
-            const int tile = w + 4 * q;
-            if (tile < ntile) {
-                const int mt = tile / NT, nt = tile - mt * NT;
-                f32x4 a = acc[q];
-#pragma unroll 4
-                for (int ks = 0; ks < kWgChunk / 4; ++ks) {
-                    const int s = 4 * ks + (lane >> 4);
-                    a = mfma16(DS[s * Mp + 16 * mt + (lane & 15)], AS[s * Np + 16 * nt + (lane & 15)], a);
-                }
-                acc[q] = a;
-            }
-        }
-    }
-    float* out = J.slab + (size_t)blockIdx.x * (J.N + 1) * J.M;
-#pragma unroll
-    for (int q = 0; q < kMaxTiles; ++q) {
-        const int tile = w + 4 * q;
-        if (tile < ntile) {
-            const int mt = tile / NT, nt = tile - mt * NT;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = 16 * mt + 4 * (lane >> 4) + i, n = 16 * nt + (lane & 15);
-                if (m < J.M && n <= J.N) out[(size_t)n * J.M + m] = acc[q][i];
-            }
-        }
-    }
-}
 // ---------------------------------------------------------------------------------------------------------------------------------
-// The six weight gradients of the GRU in ONE pass over the tapes (round 4).  rnde_latent_wgrad_kernel above reads a job's operands from the
-// tape once per job: the activation record (680 floats per sample and step) is read three times, 250 MB for 100 MB of tape.  Here a workgroup
+// The weight gradients of a tape pair in ONE pass (round 4; the first form, one launch per job re-reading its operands, read the GRU's activation
+// record three times: 250 MB for 100 MB of tape, and took 318 us per step for the model's nine gradients against 150 now).  A workgroup
 // brings 16 whole records of both tapes into LDS (contiguous in memory: 252 `global_load_lds` requests of 256 B, 64.5 KB), and every job's
 // tiles are multiplied out of that image -- 144 accumulator tiles of 16 x 16, 36 per wave, register resident across the workgroup's records.
-// Two workgroups share a CU (4 waves, 64.5 KB each): one's requests land while the other multiplies.  Partials go to the slab of
-// rnde_latent_reduce_kernel (fixed-order sum over the workgroups: deterministic).  The jobs' delta / act pointers must lie inside one DEL / ACT
-// record (offsets d_off / a_off are taken from them).
+// Two workgroups share a CU (4 waves, 64.5 KB each): one's requests land while the other multiplies.  A workgroup leaves its accumulators as they
+// are (16-byte stores); rnde_latent_reduce_raw_kernel / _scatter_kernel sum them over the workgroups in a fixed order (deterministic) and place
+// them in the jobs' outputs.  The jobs' delta / act pointers must lie inside one DEL / ACT record (offsets are taken from them).
 // ---------------------------------------------------------------------------------------------------------------------------------
 constexpr int kFwSamples = 16;                                          // records per chunk
 constexpr int kFwTilesPerWave = 36;
@@ -514,7 +454,12 @@ constexpr int kFwMaxLdsFloats = kFwSamples * (kActLd + kDelLd);         // the G
 // act / del: first record of the two tapes, LDA / LDD floats per record (multiples of 4: compile-time, the k-steps of a tile are then immediate
 // offsets of its LDS reads); the jobs' pointers lie inside the first record.  The image is followed by 16 zero floats: a lane whose row / column is
 // padding of its tile reads whatever lies next to its job's columns -- that pollutes accumulator rows / columns that are never stored.
-struct FusedWgrad { WgradJobs J; const float* act; const float* del; int K; };
+struct FusedWgrad { WgradJobs J; const float* act; const float* del; int K; float* raw; };      // raw: [workgroup][tile][64 lanes][4] accumulator images
+__host__ __device__ inline int fused_tile_count(const WgradJobs& J) {
+    int n = 0;
+    for (int j = 0; j < J.n; ++j) n += ((J.j[j].M + 15) >> 4) * ((J.j[j].N + 1 + 15) >> 4);
+    return n;
+}
 template <int LDA, int LDD>
 __global__ __launch_bounds__(256, 2) void rnde_latent_gru_wgrad_kernel(const FusedWgrad F) {
     extern __shared__ __attribute__((aligned(16))) float S[];
@@ -587,53 +532,45 @@ __global__ __launch_bounds__(256, 2) void rnde_latent_gru_wgrad_kernel(const Fus
             }
         }
     }
-    // partials of this workgroup, Flux layout [vec(W) (M x N, column-major); b] per job
+    // partials of this workgroup: the accumulators as they are, one 16-byte store per lane and tile (a store in the Flux layout touches 64 lines
+    // per instruction: 15 M four-byte transactions for the GRU's jobs, the larger part of the launch); the reduction maps them to the jobs' outputs
+    const int ntiles = fused_tile_count(F.J);
 #pragma unroll
     for (int q = 0; q < kFwTilesPerWave; ++q) {
-        const int code = TT[w + 4 * q];
-        if (code >= 0) {
-            const int j = code >> 16, mt = (code >> 8) & 255, nt = code & 255;
-            const WgradJob& J = F.J.j[j];
-            float* out = J.slab + (size_t)blockIdx.x * (J.N + 1) * J.M;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = 16 * mt + 4 * (lane >> 4) + i, n = 16 * nt + (lane & 15);
-                if (m < J.M && n <= J.N) out[(size_t)n * J.M + m] = acc[q][i];
-            }
-        }
+        if (TT[w + 4 * q] >= 0) ((f32x4*)(F.raw + ((size_t)blockIdx.x * ntiles + (w + 4 * q)) * 256))[lane] = acc[q];
     }
 }
-// first level of the reduction of MANY partials: blockIdx.z sums the groups [z * per, (z + 1) * per) of job blockIdx.y into partial z of slab2
-// (same fixed order inside a segment; the second level is rnde_latent_reduce_kernel over the segments)
-__global__ void rnde_latent_reduce_seg_kernel(const WgradJobs JJ, int per, float* __restrict__ slab2, int nseg) {
-    const WgradJob J = JJ.j[blockIdx.y];
-    const int len = (J.N + 1) * J.M, g0 = blockIdx.z * per, g1 = min(J.groups, g0 + per);
-    float* dst = slab2 + ((size_t)(J.slab - JJ.j[0].slab) / (size_t)J.groups) * nseg + (size_t)blockIdx.z * len;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < len; i += gridDim.x * 256) {
-        float s = 0.f;
+// reduction of the accumulator images, level 1: blockIdx.y sums the workgroups [y * per, (y + 1) * per) element by element, in order
+__global__ void rnde_latent_reduce_raw_kernel(const float* __restrict__ raw, int G, int per, int E, float* __restrict__ raw2) {
+    const int g0 = blockIdx.y * per, g1 = min(G, g0 + per);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < E / 4; i += gridDim.x * 256) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
         int c = g0;
         for (; c + 4 <= g1; c += 4) {
-            const float v0 = J.slab[(size_t)c * len + i], v1 = J.slab[(size_t)(c + 1) * len + i], v2 = J.slab[(size_t)(c + 2) * len + i], v3 = J.slab[(size_t)(c + 3) * len + i];
+            const f32x4 v0 = ((const f32x4*)(raw + (size_t)c * E))[i], v1 = ((const f32x4*)(raw + (size_t)(c + 1) * E))[i],
+                        v2 = ((const f32x4*)(raw + (size_t)(c + 2) * E))[i], v3 = ((const f32x4*)(raw + (size_t)(c + 3) * E))[i];
             s += v0; s += v1; s += v2; s += v3;
         }
-        for (; c < g1; ++c) s += J.slab[(size_t)c * len + i];
-        dst[i] = s;
+        for (; c < g1; ++c) s += ((const f32x4*)(raw + (size_t)c * E))[i];
+        ((f32x4*)(raw2 + (size_t)blockIdx.y * E))[i] = s;
     }
 }
-
-// out[i] = sum over the groups c (in order) of slab[c][i]; blockIdx.y = job.  Four loads in flight per thread, the additions in group order.
-__global__ void rnde_latent_reduce_kernel(const WgradJobs JJ) {
-    const WgradJob J = JJ.j[blockIdx.y];
-    const int groups = J.groups ? J.groups : (J.K + kWgChunk * kWgSub - 1) / (kWgChunk * kWgSub), len = (J.N + 1) * J.M;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < len; i += gridDim.x * 256) {
+// level 2: the segments in order, and the accumulator element (tile, lane, i) goes to its place in its job's output (Flux layout [vec(W); b])
+__global__ void rnde_latent_reduce_scatter_kernel(const FusedWgrad F, const float* __restrict__ raw2, int nseg, int E) {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < E; e += gridDim.x * 256) {
         float s = 0.f;
-        int c = 0;
-        for (; c + 4 <= groups; c += 4) {
-            const float v0 = J.slab[(size_t)c * len + i], v1 = J.slab[(size_t)(c + 1) * len + i], v2 = J.slab[(size_t)(c + 2) * len + i], v3 = J.slab[(size_t)(c + 3) * len + i];
-            s += v0; s += v1; s += v2; s += v3;
+        for (int c = 0; c < nseg; ++c) s += raw2[(size_t)c * E + e];
+        int t = e >> 8; const int lane = (e >> 2) & 63, i = e & 3;
+        for (int j = 0; j < F.J.n; ++j) {
+            const WgradJob& J = F.J.j[j];
+            const int MT = (J.M + 15) >> 4, NT = (J.N + 1 + 15) >> 4;
+            if (t < MT * NT) {
+                const int m = 16 * (t / NT) + 4 * (lane >> 4) + i, n = 16 * (t % NT) + (lane & 15);
+                if (m < J.M && n <= J.N) J.out[(size_t)n * J.M + m] = s;
+                break;
+            }
+            t -= MT * NT;
         }
-        for (; c < groups; ++c) s += J.slab[(size_t)c * len + i];
-        J.out[i] = s;
     }
 }
 
@@ -675,7 +612,7 @@ __global__ __launch_bounds__(64) void rnde_latent_enc_fwd_kernel(const EncParams
     if (tid == 0) { float s = 0.f; for (int i = 0; i < kLat; ++i) s += hs[i]; Q.kl[b] = s / (2.f * kLat); }      // kl_divergence, latent_ode.jl:203-204
 }
 // reverse: z0-bar (20 x B) and the KL weight -> delta tapes d2 (40 x B: cotangent of [mu0; logvar]), d1 (50 x B: of the tanh layer's
-// pre-activation), y-bar (100 x B); the weight gradients are two rnde_latent_wgrad_kernel jobs (d2 x h1, d1 x y)
+// pre-activation), y-bar (100 x B); the weight gradients are two rnde_latent_gru_wgrad_kernel passes (d2 x h1, d1 x y)
 struct EncBwdParams {
     const float* z0b; const float* p2; const float* eps; const float* h1; const float* out;
     float* d2; float* d1; float* yb; float klw; int B;      // klw = lambda_k / B

@@ -15,7 +15,8 @@ using namespace rnde_lat;
 struct rnde_latent {
     rnde_latent_config cfg{};
     float *act = nullptr, *del = nullptr, *y = nullptr, *yb = nullptr, *h1 = nullptr, *out = nullptr, *d1 = nullptr, *d2 = nullptr;
-    float *kl = nullptr, *ll = nullptr, *gD = nullptr, *slab = nullptr, *slab2 = nullptr, *eps = nullptr;
+    float *kl = nullptr, *ll = nullptr, *gD = nullptr, *eps = nullptr;
+    float *raw = nullptr, *raw2 = nullptr, *raw_side = nullptr, *raw2_side = nullptr;      // accumulator images of the fused weight-gradient passes (main stream: up to 144 tiles; side stream: 28)
     int B = 0, T = 0;
     bool encoded = false;
     hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;      // rec_to_gen's weight gradients run beside the reverse GRU (32 workgroups)
@@ -50,9 +51,9 @@ extern "C" rnde_status rnde_latent_create(const rnde_latent_config* c, rnde_late
               hipMalloc((void**)&h->h1, B * kRec * 4) == hipSuccess && hipMalloc((void**)&h->out, B * 2 * kLat * 4) == hipSuccess &&
               hipMalloc((void**)&h->d1, B * kRec * 4) == hipSuccess && hipMalloc((void**)&h->d2, B * 2 * kLat * 4) == hipSuccess &&
               hipMalloc((void**)&h->kl, B * 4) == hipSuccess && hipMalloc((void**)&h->ll, B * 4) == hipSuccess &&
-              hipMalloc((void**)&h->gD, S * 40 * 4) == hipSuccess && hipMalloc((void**)&h->eps, B * kLat * 4) == hipSuccess &&
-              hipMalloc((void**)&h->slab, std::max<size_t>(kFusedWgradGroups, (S + kWgChunk * kWgSub - 1) / (kWgChunk * kWgSub)) * (size_t)(3 * (kNIn + 1) * kH + 2 * (kH + 1) * kL + (kH + 1) * 2 * kL) * 4) == hipSuccess;      // the six GRU jobs side by side
-    ok = ok && hipMalloc((void**)&h->slab2, (size_t)kFusedSegs * (3 * (kNIn + 1) * kH + 2 * (kH + 1) * kL + (kH + 1) * 2 * kL) * 4) == hipSuccess;
+              hipMalloc((void**)&h->gD, S * 40 * 4) == hipSuccess && hipMalloc((void**)&h->eps, B * kLat * 4) == hipSuccess;
+    ok = ok && hipMalloc((void**)&h->raw, (size_t)kFusedWgradGroups * 4 * kFwTilesPerWave * 256 * 4) == hipSuccess && hipMalloc((void**)&h->raw2, (size_t)kFusedSegs * 4 * kFwTilesPerWave * 256 * 4) == hipSuccess &&
+         hipMalloc((void**)&h->raw_side, (size_t)kFusedWgradGroups * 32 * 256 * 4) == hipSuccess && hipMalloc((void**)&h->raw2_side, (size_t)kFusedSegs * 32 * 256 * 4) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) == hipSuccess;
     if (!ok) { g_latent_err = "device allocation failed"; rnde_latent_destroy(h); return RNDE_ERR_HIP; }
@@ -64,7 +65,7 @@ extern "C" void rnde_latent_destroy(rnde_latent* h) {
     if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-    for (float* p : {h->act, h->del, h->y, h->yb, h->h1, h->out, h->d1, h->d2, h->kl, h->ll, h->gD, h->slab, h->slab2, h->eps}) if (p) (void)hipFree(p);
+    for (float* p : {h->act, h->del, h->y, h->yb, h->h1, h->out, h->d1, h->d2, h->kl, h->ll, h->gD, h->eps, h->raw, h->raw2, h->raw_side, h->raw2_side}) if (p) (void)hipFree(p);
     delete h;
 }
 
@@ -75,45 +76,25 @@ static rnde_status check_shape(rnde_latent* h, int B, int T) {
     return RNDE_OK;
 }
 
-// out (M x (N + 1), Flux layout [vec(W); b]) = sum over K samples of delta^T [act, 1]: a batch of such jobs as two launches (partials, reduction)
+// out (M x (N + 1), Flux layout [vec(W); b]) = sum over K samples of delta^T [act, 1]: the jobs of one tape pair
 struct JobList {
     WgradJobs jj{};
-    size_t slab_used = 0;
-    int fused_groups = 0;      // > 0: the slab holds that many partials per job (rnde_latent_gru_wgrad_kernel: one per workgroup)
-    void add(rnde_latent* h, const float* delta, int ld_d, int M, const float* act, int ld_a, int N, int K, float* out, int m_split = 1 << 30, int m_gap = 0) {
-        const int groups = (K + kWgChunk * kWgSub - 1) / (kWgChunk * kWgSub);
-        jj.j[jj.n++] = WgradJob{delta, act, h->slab + slab_used, out, ld_d, ld_a, M, N, K, m_split, m_gap, fused_groups};
-        slab_used += (size_t)(fused_groups ? fused_groups : groups) * (N + 1) * M;
+    int fused_groups = 0;      // workgroups of the pass (each leaves one partial)
+    void add(const float* delta, int M, const float* act, int N, float* out, int m_split = 1 << 30, int m_gap = 0) {
+        jj.j[jj.n++] = WgradJob{delta, act, out, M, N, m_split, m_gap};
     }
 };
-static rnde_status run_jobs(rnde_latent* h, const JobList& Jl, hipStream_t s) {
-    int gmax = 0, lmax = 0; size_t lds = 0;
-    for (int i = 0; i < Jl.jj.n; ++i) {
-        const WgradJob& J = Jl.jj.j[i];
-        gmax = std::max(gmax, (J.K + kWgChunk * kWgSub - 1) / (kWgChunk * kWgSub));
-        lmax = std::max(lmax, (J.N + 1) * J.M);
-        lds = std::max(lds, sizeof(float) * kWgChunk * (size_t)(((J.M + 15) & ~15) + ((J.N + 1 + 15) & ~15)));
-    }
-    hipLaunchKernelGGL(rnde_latent_wgrad_kernel, dim3(gmax, Jl.jj.n), dim3(256), lds, s, Jl.jj);
-    hipLaunchKernelGGL(rnde_latent_reduce_kernel, dim3((lmax + 255) / 256, Jl.jj.n), dim3(256), 0, s, Jl.jj);
-    LCHK(h, hipGetLastError());
-    return RNDE_OK;
-}
 
-// The same jobs in ONE pass over two tapes of whole records (rnde_latent_gru_wgrad_kernel): partials per workgroup, then the fixed-order reduction in two
-// levels (kFusedSegs segments of the workgroups, then the segments).  Jl.fused_groups set before the jobs were added.
+// ONE pass over two tapes of whole records (rnde_latent_gru_wgrad_kernel): partials per workgroup, then the fixed-order reduction in two levels
+// (kFusedSegs segments of the workgroups, then the segments + placement).
 template <int LDA, int LDD>
-static rnde_status run_fused(rnde_latent* h, const JobList& Jl, const float* act, const float* del, int K, hipStream_t s) {
-    FusedWgrad F{Jl.jj, act, del, K};
-    const int G = Jl.fused_groups;
+static rnde_status run_fused(rnde_latent* h, const JobList& Jl, const float* act, const float* del, int K, hipStream_t s, float* raw, float* raw2) {
+    FusedWgrad F{Jl.jj, act, del, K, raw};
+    const int G = Jl.fused_groups, E = fused_tile_count(Jl.jj) * 256;
     hipLaunchKernelGGL((rnde_latent_gru_wgrad_kernel<LDA, LDD>), dim3(G), dim3(256), sizeof(float) * (kFwSamples * (size_t)(LDA + LDD) + 16), s, F);
-    int lmax = 0;
-    for (int i = 0; i < Jl.jj.n; ++i) lmax = std::max(lmax, (Jl.jj.j[i].N + 1) * Jl.jj.j[i].M);
-    const int nseg = std::min(kFusedSegs, G), per = (G + nseg - 1) / nseg;
-    hipLaunchKernelGGL(rnde_latent_reduce_seg_kernel, dim3((lmax + 255) / 256, Jl.jj.n, nseg), dim3(256), 0, s, Jl.jj, per, h->slab2, nseg);
-    WgradJobs J2 = Jl.jj;
-    for (int i = 0; i < J2.n; ++i) { J2.j[i].slab = h->slab2 + (size_t)(Jl.jj.j[i].slab - Jl.jj.j[0].slab) / G * nseg; J2.j[i].groups = (G + per - 1) / per; }
-    hipLaunchKernelGGL(rnde_latent_reduce_kernel, dim3((lmax + 255) / 256, J2.n), dim3(256), 0, s, J2);
+    const int nseg = std::min(kFusedSegs, G), per = (G + nseg - 1) / nseg, segs = (G + per - 1) / per;
+    hipLaunchKernelGGL(rnde_latent_reduce_raw_kernel, dim3(std::min((E / 4 + 255) / 256, 64), segs), dim3(256), 0, s, (const float*)raw, G, per, E, raw2);
+    hipLaunchKernelGGL(rnde_latent_reduce_scatter_kernel, dim3((E + 255) / 256), dim3(256), 0, s, F, (const float*)raw2, segs, E);
     LCHK(h, hipGetLastError());
     return RNDE_OK;
 }
@@ -151,8 +132,8 @@ extern "C" rnde_status rnde_latent_decode_loss(rnde_latent* h, const float* res_
     LCHK(h, hipGetLastError());
     JobList Jl;
     Jl.fused_groups = std::min(kFusedWgradGroups, (B * T + kFwSamples - 1) / kFwSamples);
-    Jl.add(h, h->gD, 40, kIn, res_dev, kLat, kLat, B * T, p4_bar_out_dev);      // gen_to_data: [vec(W4) (37 x 20); b4]
-    return run_fused<kLat, 40>(h, Jl, res_dev, h->gD, B * T, s);
+    Jl.add(h->gD, kIn, res_dev, kLat, p4_bar_out_dev);      // gen_to_data: [vec(W4) (37 x 20); b4]
+    return run_fused<kLat, 40>(h, Jl, res_dev, h->gD, B * T, s, h->raw, h->raw2);
 }
 
 extern "C" rnde_status rnde_latent_encode_backward(rnde_latent* h, const float* z0_bar_dev, float lambda_k, const float* p1_dev, const float* p2_dev,
@@ -169,15 +150,15 @@ extern "C" rnde_status rnde_latent_encode_backward(rnde_latent* h, const float* 
     // rec_to_gen: Dense(100, 50, tanh) [W1; b1] then Dense(50, 40) [W2; b2]
     rnde_status st;
     {   // (one job per pass: the two layers' tapes are separate arrays)  These launches do not feed the reverse GRU, which is a 173 us latency chain on
-        // 32 workgroups: they run on a stream of their own beside it and are joined in front of the GRU's own weight gradients (same slab)
+        // 32 workgroups: they run on a stream of their own beside it and are joined in front of the GRU's own weight gradients
         LCHK(h, hipEventRecord(h->ev_fork, s));
         LCHK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
         JobList Je1, Je2;
         Je1.fused_groups = Je2.fused_groups = std::min(kFusedWgradGroups, (B + kFwSamples - 1) / kFwSamples);
-        Je1.add(h, h->d1, kRec, kRec, h->y, 2 * kL, 2 * kL, B, p2_bar_out_dev);
-        if ((st = run_fused<2 * kL, kRec>(h, Je1, h->y, h->d1, B, h->side)) != RNDE_OK) return st;
-        Je2.add(h, h->d2, 2 * kLat, 2 * kLat, h->h1, kRec, kRec, B, p2_bar_out_dev + 2 * kL * kRec + kRec);
-        if ((st = run_fused<kRec, 2 * kLat>(h, Je2, h->h1, h->d2, B, h->side)) != RNDE_OK) return st;
+        Je1.add(h->d1, kRec, h->y, 2 * kL, p2_bar_out_dev);
+        if ((st = run_fused<2 * kL, kRec>(h, Je1, h->y, h->d1, B, h->side, h->raw_side, h->raw2_side)) != RNDE_OK) return st;
+        Je2.add(h->d2, 2 * kLat, h->h1, kRec, p2_bar_out_dev + 2 * kL * kRec + kRec);
+        if ((st = run_fused<kRec, 2 * kLat>(h, Je2, h->h1, h->d2, B, h->side, h->raw_side, h->raw2_side)) != RNDE_OK) return st;
         LCHK(h, hipEventRecord(h->ev_join, h->side));
     }
     GruParams G{x_dev, p1_dev, h->act, h->del, h->yb, B, T};
@@ -189,13 +170,13 @@ extern "C" rnde_status rnde_latent_encode_backward(rnde_latent* h, const float* 
     float* g = p1_bar_out_dev;
     JobList Jg;
     Jg.fused_groups = std::min(kFusedWgradGroups, (K + kFwSamples - 1) / kFwSamples);
-    Jg.add(h, h->del + dZU, kDelLd, kH, h->act + aYC, kActLd, kNIn, K, g + oWu1);
-    Jg.add(h, h->del + dAU, kDelLd, kL, h->act + aU1, kActLd, kH, K, g + oWu2);
-    Jg.add(h, h->del + dZR, kDelLd, kH, h->act + aYC, kActLd, kNIn, K, g + oWr1);
-    Jg.add(h, h->del + dAR, kDelLd, kL, h->act + aR1, kActLd, kH, K, g + oWr2);
-    Jg.add(h, h->del + dZN, kDelLd, kH, h->act + aCC, kActLd, kNIn, K, g + oWn1);
-    Jg.add(h, h->del + dNS, kDelLd, 2 * kL, h->act + aN1, kActLd, kH, K, g + oWn2, kL, 2);
-    if ((st = run_fused<kActLd, kDelLd>(h, Jg, h->act, h->del, K, s)) != RNDE_OK) return st;      // all six in one pass over the tapes
+    Jg.add(h->del + dZU, kH, h->act + aYC, kNIn, g + oWu1);
+    Jg.add(h->del + dAU, kL, h->act + aU1, kH, g + oWu2);
+    Jg.add(h->del + dZR, kH, h->act + aYC, kNIn, g + oWr1);
+    Jg.add(h->del + dAR, kL, h->act + aR1, kH, g + oWr2);
+    Jg.add(h->del + dZN, kH, h->act + aCC, kNIn, g + oWn1);
+    Jg.add(h->del + dNS, 2 * kL, h->act + aN1, kH, g + oWn2, kL, 2);
+    if ((st = run_fused<kActLd, kDelLd>(h, Jg, h->act, h->del, K, s, h->raw, h->raw2)) != RNDE_OK) return st;      // all six in one pass over the tapes
     h->encoded = false;
     return RNDE_OK;
 }

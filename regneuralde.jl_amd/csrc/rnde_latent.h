@@ -443,14 +443,15 @@ struct WgradJobs { WgradJob j[8]; int n; };
 // The weight gradients of a tape pair in ONE pass (round 4; the first form, one launch per job re-reading its operands, read the GRU's activation
 // record three times: 250 MB for 100 MB of tape, and took 318 us per step for the model's nine gradients against 150 now).  A workgroup
 // brings 16 whole records of both tapes into LDS (contiguous in memory: 252 `global_load_lds` requests of 256 B, 64.5 KB), and every job's
-// tiles are multiplied out of that image -- 144 accumulator tiles of 16 x 16, 36 per wave, register resident across the workgroup's records.
-// Two workgroups share a CU (4 waves, 64.5 KB each): one's requests land while the other multiplies.  A workgroup leaves its accumulators as they
+// tiles are multiplied out of that image -- 144 accumulator tiles of 16 x 16, 18 per wave, register resident across the workgroup's records.
+// One workgroup of 8 waves per CU with TWO images (129 KB): the requests of the next 16 records are in flight while the current ones are multiplied
+// (measured on the first, single-image form with two 4-wave workgroups per CU: 20 us fixed, + 13.5 us requests, + 26 us products, not overlapping;
+// its 512 accumulator images were 75 MB of partials).  A workgroup leaves its accumulators as they
 // are (16-byte stores); rnde_latent_reduce_raw_kernel / _scatter_kernel sum them over the workgroups in a fixed order (deterministic) and place
 // them in the jobs' outputs.  The jobs' delta / act pointers must lie inside one DEL / ACT record (offsets are taken from them).
 // ---------------------------------------------------------------------------------------------------------------------------------
 constexpr int kFwSamples = 16;                                          // records per chunk
-constexpr int kFwTilesPerWave = 36;
-constexpr int kFwMaxLdsFloats = kFwSamples * (kActLd + kDelLd);         // the GRU's records: 16,128 floats = 64.5 KB (two workgroups per CU)
+constexpr int kFwWaves = 8, kFwTilesPerWave = 18;                       // 144 tiles at most (the GRU's six jobs)
 // act / del: first record of the two tapes, LDA / LDD floats per record (multiples of 4: compile-time, the k-steps of a tile are then immediate
 // offsets of its LDS reads); the jobs' pointers lie inside the first record.  The image is followed by 16 zero floats: a lane whose row / column is
 // padding of its tile reads whatever lies next to its job's columns -- that pollutes accumulator rows / columns that are never stored.
@@ -461,16 +462,17 @@ __host__ __device__ inline int fused_tile_count(const WgradJobs& J) {
     return n;
 }
 template <int LDA, int LDD>
-__global__ __launch_bounds__(256, 2) void rnde_latent_gru_wgrad_kernel(const FusedWgrad F) {
-    extern __shared__ __attribute__((aligned(16))) float S[];
-    __shared__ int TT[4 * kFwTilesPerWave];
+__global__ __launch_bounds__(64 * kFwWaves) void rnde_latent_gru_wgrad_kernel(const FusedWgrad F) {
+    extern __shared__ __attribute__((aligned(16))) float S0[];
+    __shared__ int TT[kFwWaves * kFwTilesPerWave];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int nA = kFwSamples * LDA, nD = kFwSamples * LDD;          // floats of a chunk's two images (multiples of 64)
     static_assert(nA + nD + 16 < (1 << 15), "record sizes");
+    constexpr int kImg = nA + nD + 16;                                   // one image: both tapes' records + 16 zero floats
     constexpr bool kDma = nA % 64 == 0 && nD % 64 == 0;                  // whole 256-byte requests (records of a multiple of 4 floats); else plain loads
-    if (tid < 16) S[nA + nD + tid] = 0.f;
+    if (tid < 32) S0[(tid >> 4) * kImg + nA + nD + (tid & 15)] = 0.f;
     // tile table: (job, mt, nt) of tile i, jobs in order
-    if (tid < 4 * kFwTilesPerWave) {
+    if (tid < kFwWaves * kFwTilesPerWave) {
         int i = tid, code = -1;
         for (int j = 0; j < F.J.n; ++j) {
             const int MT = (F.J.j[j].M + 15) >> 4, NT = (F.J.j[j].N + 1 + 15) >> 4;
@@ -481,12 +483,17 @@ __global__ __launch_bounds__(256, 2) void rnde_latent_gru_wgrad_kernel(const Fus
     }
     __syncthreads();
     // this lane's operand addresses of its wave's tiles, once: delta index in bits 0..14, act index in bits 16..30, bit 31: this lane is the bias column
+    // (and, wave-uniform, which of the wave's tiles exist / hold their job's bias column: two bit masks -- asking the job table per tile and chunk
+    //  costs a scalar load from the kernel arguments each time, more than the tile's four MFMAs)
     unsigned ix[kFwTilesPerWave];
+    unsigned long long tiles = 0ull, bias_tiles = 0ull;
 #pragma unroll
     for (int q = 0; q < kFwTilesPerWave; ++q) {
-        const int code = TT[w + 4 * q];
+        const int code = TT[w + kFwWaves * q];
         ix[q] = 0u;
         if (code >= 0) {
+            tiles |= 1ull << q;
+            if (16 * (code & 255) + 16 > F.J.j[code >> 16].N) bias_tiles |= 1ull << q;
             const WgradJob& J = F.J.j[code >> 16];
             const int m = 16 * ((code >> 8) & 255) + (lane & 15), n = 16 * (code & 255) + (lane & 15), kk = lane >> 4;
             ix[q] = (unsigned)(nA + kk * LDD + (int)(J.delta - F.del) + m + (m >= J.m_split ? J.m_gap : 0)) | ((unsigned)(kk * LDA + (int)(J.act - F.act) + n) << 16) |
@@ -499,28 +506,33 @@ __global__ __launch_bounds__(256, 2) void rnde_latent_gru_wgrad_kernel(const Fus
     const int nchunks = (F.K + kFwSamples - 1) / kFwSamples;
     typedef __attribute__((address_space(3))) void lds_v;
     typedef const __attribute__((address_space(1))) void gbl_v;
-    for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    // requests of chunk c into image `buf` (asynchronous: vmcnt) -- or, for the last partial chunk / records that are no whole requests, plain copies
+    auto request = [&](int c, int buf) {
+        float* S = S0 + buf * kImg;
         const int s0 = c * kFwSamples, ns = min(kFwSamples, F.K - s0);
-        __syncthreads();                                     // everybody has left the previous image
         if (kDma && ns == kFwSamples) {
             const float* ga = F.act + (size_t)s0 * LDA; const float* gd = F.del + (size_t)s0 * LDD;
-            for (int u = w; u < nA / 64; u += 4) __builtin_amdgcn_global_load_lds((gbl_v*)(ga + u * 64 + lane), (lds_v*)(S + u * 64), 4, 0, 0);
-            for (int u = w; u < nD / 64; u += 4) __builtin_amdgcn_global_load_lds((gbl_v*)(gd + u * 64 + lane), (lds_v*)(S + nA + u * 64), 4, 0, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {                                             // the last, partial chunk: guarded loads, zero rows behind the data
-            for (int i = tid; i < nA; i += 256) S[i] = (i / LDA < ns) ? F.act[(size_t)s0 * LDA + i] : 0.f;
-            for (int i = tid; i < nD; i += 256) S[nA + i] = (i / LDD < ns) ? F.del[(size_t)s0 * LDD + i] : 0.f;
+            for (int u = w; u < nA / 64; u += kFwWaves) __builtin_amdgcn_global_load_lds((gbl_v*)(ga + u * 64 + lane), (lds_v*)(S + u * 64), 4, 0, 0);
+            for (int u = w; u < nD / 64; u += kFwWaves) __builtin_amdgcn_global_load_lds((gbl_v*)(gd + u * 64 + lane), (lds_v*)(S + nA + u * 64), 4, 0, 0);
+        } else {
+            for (int i = tid; i < nA; i += 64 * kFwWaves) S[i] = (i / LDA < ns) ? F.act[(size_t)s0 * LDA + i] : 0.f;
+            for (int i = tid; i < nD; i += 64 * kFwWaves) S[nA + i] = (i / LDD < ns) ? F.del[(size_t)s0 * LDD + i] : 0.f;
         }
-        __syncthreads();
+    };
+    int buf = 0;
+    if ((int)blockIdx.x < nchunks) request(blockIdx.x, 0);
+    for (int c = blockIdx.x; c < nchunks; c += gridDim.x, buf ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's requests of chunk c have landed
+        __syncthreads();                                     // everybody's have, and everybody has left the other image (chunk c - stride)
+        if (c + (int)gridDim.x < nchunks) request(c + gridDim.x, buf ^ 1);
+        const float* S = S0 + buf * kImg;
 #pragma unroll
         for (int q = 0; q < kFwTilesPerWave; ++q) {
-            const int code = TT[w + 4 * q];                  // (wave-uniform)
-            if (code >= 0) {
+            if ((tiles >> q) & 1ull) {                       // (wave-uniform)
                 const float* dp = S + (ix[q] & 0x7FFFu);
                 const float* ap = S + ((ix[q] >> 16) & 0x7FFFu);
                 f32x4 a = acc[q];
-                const WgradJob& J = F.J.j[code >> 16];
-                if (16 * (code & 255) + 16 > J.N) {         // the tile holds the bias column: that lane multiplies by 1
+                if ((bias_tiles >> q) & 1ull) {              // the tile holds the bias column: that lane multiplies by 1
                     const bool ab = (ix[q] >> 31) != 0;
 #pragma unroll
                     for (int ks = 0; ks < kFwSamples / 4; ++ks) { const float y = ap[ks * 4 * LDA]; a = mfma16(dp[ks * 4 * LDD], ab ? 1.f : y, a); }
@@ -537,7 +549,7 @@ __global__ __launch_bounds__(256, 2) void rnde_latent_gru_wgrad_kernel(const Fus
     const int ntiles = fused_tile_count(F.J);
 #pragma unroll
     for (int q = 0; q < kFwTilesPerWave; ++q) {
-        if (TT[w + 4 * q] >= 0) ((f32x4*)(F.raw + ((size_t)blockIdx.x * ntiles + (w + 4 * q)) * 256))[lane] = acc[q];
+        if ((tiles >> q) & 1ull) ((f32x4*)(F.raw + ((size_t)blockIdx.x * ntiles + (w + kFwWaves * q)) * 256))[lane] = acc[q];
     }
 }
 // reduction of the accumulator images, level 1: blockIdx.y sums the workgroups [y * per, (y + 1) * per) element by element, in order

@@ -8,7 +8,7 @@
 #include <string>
 
 constexpr int kFusedSegs = 16;             // segments of the first reduction level over those partials
-constexpr int kFusedWgradGroups = 512;      // workgroups of rnde_latent_gru_wgrad_kernel (two per CU), each leaving one partial per job
+constexpr int kFusedWgradGroups = 256;      // workgroups of rnde_latent_gru_wgrad_kernel (one per CU), each leaving one accumulator image
 
 using namespace rnde_lat;
 
@@ -52,7 +52,7 @@ extern "C" rnde_status rnde_latent_create(const rnde_latent_config* c, rnde_late
               hipMalloc((void**)&h->d1, B * kRec * 4) == hipSuccess && hipMalloc((void**)&h->d2, B * 2 * kLat * 4) == hipSuccess &&
               hipMalloc((void**)&h->kl, B * 4) == hipSuccess && hipMalloc((void**)&h->ll, B * 4) == hipSuccess &&
               hipMalloc((void**)&h->gD, S * 40 * 4) == hipSuccess && hipMalloc((void**)&h->eps, B * kLat * 4) == hipSuccess;
-    ok = ok && hipMalloc((void**)&h->raw, (size_t)kFusedWgradGroups * 4 * kFwTilesPerWave * 256 * 4) == hipSuccess && hipMalloc((void**)&h->raw2, (size_t)kFusedSegs * 4 * kFwTilesPerWave * 256 * 4) == hipSuccess &&
+    ok = ok && hipMalloc((void**)&h->raw, (size_t)kFusedWgradGroups * kFwWaves * kFwTilesPerWave * 256 * 4) == hipSuccess && hipMalloc((void**)&h->raw2, (size_t)kFusedSegs * kFwWaves * kFwTilesPerWave * 256 * 4) == hipSuccess &&
          hipMalloc((void**)&h->raw_side, (size_t)kFusedWgradGroups * 32 * 256 * 4) == hipSuccess && hipMalloc((void**)&h->raw2_side, (size_t)kFusedSegs * 32 * 256 * 4) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) == hipSuccess;
@@ -91,7 +91,10 @@ template <int LDA, int LDD>
 static rnde_status run_fused(rnde_latent* h, const JobList& Jl, const float* act, const float* del, int K, hipStream_t s, float* raw, float* raw2) {
     FusedWgrad F{Jl.jj, act, del, K, raw};
     const int G = Jl.fused_groups, E = fused_tile_count(Jl.jj) * 256;
-    hipLaunchKernelGGL((rnde_latent_gru_wgrad_kernel<LDA, LDD>), dim3(G), dim3(256), sizeof(float) * (kFwSamples * (size_t)(LDA + LDD) + 16), s, F);
+    constexpr size_t lds = sizeof(float) * 2 * (kFwSamples * (size_t)(LDA + LDD) + 16);      // two images
+    static bool attr = false;
+    if (!attr && lds > 64 * 1024) { LCHK(h, hipFuncSetAttribute((const void*)rnde_latent_gru_wgrad_kernel<LDA, LDD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    hipLaunchKernelGGL((rnde_latent_gru_wgrad_kernel<LDA, LDD>), dim3(G), dim3(64 * kFwWaves), lds, s, F);
     const int nseg = std::min(kFusedSegs, G), per = (G + nseg - 1) / nseg, segs = (G + per - 1) / per;
     hipLaunchKernelGGL(rnde_latent_reduce_raw_kernel, dim3(std::min((E / 4 + 255) / 256, 64), segs), dim3(256), 0, s, (const float*)raw, G, per, E, raw2);
     hipLaunchKernelGGL(rnde_latent_reduce_scatter_kernel, dim3((E + 255) / 256), dim3(256), 0, s, F, (const float*)raw2, segs, E);

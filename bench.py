@@ -374,12 +374,19 @@ def bench_nsde(args):
     y = torch.eye(NCLS)[torch.randint(0, NCLS, (B,), generator=g)].to(device)
     L = _lib.lib()
     stats = {"att": [], "acc": [], "solve_ms": [], "rev_ms": []}
+    nsde_step = [0]
 
     def step(record):
         if args.autograd:
             opt.zero_grad(set_to_none=True)
             loss, ce, reg, nfe1, nfe2 = rn.nsde_loss_function(x, y, model, trajectories=1, lam=10.0)
             loss.backward()
+            # Optimiser(InvDecay(1e-5), ADAM(0.01)): InvDecay scales the gradient by 1 / (1 + gamma n) in front of ADAM (the C-ABI leg's rn.FluxADAM does the same)
+            nsde_step[0] += 1
+            with torch.no_grad():
+                for p_ in model.trainable():
+                    if p_.grad is not None:
+                        p_.grad.mul_(1.0 / (1.0 + 1.0e-5 * nsde_step[0]))
         else:   # the same loss and gradients without a tape library in the loop (nsde.fused_nsde_loss_and_grad)
             loss, ce, reg, nfe1, nfe2 = rn.fused_nsde_loss_and_grad(model, x, y, trajectories=1, lam=10.0)
         opt.step()

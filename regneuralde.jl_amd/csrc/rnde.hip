@@ -18,6 +18,7 @@
 
 #include <chrono>
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstdio>
@@ -53,6 +54,8 @@ struct rnde_node {
     rnde_comm* couple = nullptr; int couple_batch = 0, couple_world = 1;   // SURVEY 8e mode 2 (rnde_node_set_coupling)
     int rk_tab = 0; RkTab rk{};   // explicit RK pair as data: 1 = a 7-stage pair (DP5, or Tsit5 through the same path when RNDE_CHAIN_TAB=1), 2 = S stages (DOP853)
     // chain engine, multi-wave kernels: the whole adaptive solve as ONE launch (rnde_chainmw.h MW_SOLVE) while the tiles fit one XCD (<= 32)
+    int mw_slot = 0;   // the XCD (blockIdx % 8) this handle's one-launch chain kernels work on while they fit one: handles take turns (process-wide counter)
+    int mw_clean = 0, mw_retry_after = 8;   // non-sticky fallback of those kernels, as persist_clean / persist_retry_after of the stage engine
     int mw_solve = 1; unsigned long long* mw_xch = nullptr; unsigned* mw_xcc = nullptr; unsigned* mw_abort = nullptr; unsigned* h_mw_chk = nullptr; unsigned mw_epoch = 0;
     int mw_bsweep = 1; int* mw_bargs = nullptr; int* h_mw_bargs = nullptr; unsigned* h_mw_bchk = nullptr; bool pending_bsweep = false;   // the reverse sweep as one launch (rnde_bchainmw.h SWEEP): per-attempt arguments [sv_lo | sv_hi | eig_c], check words
     int rk_S = 7, rk_order = 5;   // stages of the pair in first-same-as-last form (evaluations per attempted step = rk_S - 1), controller order
@@ -291,6 +294,7 @@ static rnde_status chain_create(const rnde_node_config* c, rnde_node** out) {
         ok &= hipHostMalloc((void**)&h->h_mw_bchk, (kMwMeetMax + 8) * 4) == hipSuccess && dm((void**)&h->mw_bargs, (size_t)c->max_attempts * 16) &&
               hipHostMalloc((void**)&h->h_mw_bargs, (size_t)c->max_attempts * 16) == hipSuccess;
         if (ok) memset(h->h_mw_bchk, 0, (kMwMeetMax + 8) * 4);
+        { static std::atomic<int> next_slot{0}; h->mw_slot = next_slot.fetch_add(1) & 7; }
         if (const char* eb = getenv("RNDE_CHAIN_BSWEEP")) h->mw_bsweep = atoi(eb);
         if (ok) { hipMemset(h->mw_xch, 0, xb); hipMemset(h->mw_abort, 0, 8); }
         const char* e = getenv("RNDE_CHAIN_SOLVE");
@@ -671,9 +675,9 @@ static bool bsweep_failed(rnde_node* h, hipStream_t s) {
     const int nt = h->bw.ready ? (int)((h->B + 15) / 16) : 0;
     for (int i = 1; i < nt && nt <= 32 && !bad; ++i) bad = h->h_mw_bchk[2 + i] != h->h_mw_bchk[2];      // (more than 32 tiles: the meeting does not depend on the placement)
     if (!bad) return false;
-    fprintf(stderr, "[rnde] chain engine: one-launch reverse sweep abandoned (%s); one launch per reversed attempt from now on\n",
-            h->h_mw_bchk[0] ? "a meeting timed out" : "workgroups pinned by block index landed on different XCDs");
-    h->mw_bsweep = 0; ++h->persist_fallbacks;
+    fprintf(stderr, "[rnde] chain engine: one-launch reverse sweep abandoned (%s); one launch per reversed attempt for the next %d solves\n",
+            h->h_mw_bchk[0] ? "a meeting timed out" : "workgroups pinned by block index landed on different XCDs", h->mw_retry_after);
+    h->mw_bsweep = -1; h->mw_clean = 0; ++h->persist_fallbacks;
     hipMemsetAsync(h->mw_abort, 0, 8, s);
     h->h_mw_bchk[0] = 0;
     return true;
@@ -841,7 +845,7 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
     // ---- controller and the once-per-attempt meeting of the workgroups inside the kernel).  <= 32 tiles: the workgroups are pinned to one XCD
     // ---- and meet through its L2; more (B > 512, the throughput case): they spread over the chip and meet through agent-scope entries ----
     bool solved = false;
-    if (h->engine == 3 && h->mw && h->mw_solve && !h->couple && P.Bpad / 16 <= kMwMeetMax) {
+    if (h->engine == 3 && h->mw && h->mw_solve > 0 && !h->couple && P.Bpad / 16 <= kMwMeetMax) {
         // a taped solve writes every layer input of every evaluation: the slab is sized for twice the last solve's attempts (at least 48); a solve
         // that needs more ends at that limit and is redone with room for max_attempts
         const int n_limit = keep_tape ? std::min(cap, std::max(48, 2 * h->predicted)) : cap;
@@ -849,7 +853,7 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
         MQ.n_limit = n_limit;
         if (++h->mw_epoch >= 500000u) { h->mw_epoch = 1; HIPCHK(h, hipMemsetAsync(h->mw_xch, 0, (size_t)(cap + 4) * 3 * kMwMeetMax * 8, s)); }
         const int nt = P.Bpad / 16;
-        MQ.u_out = u_out_dev; MQ.xch = h->mw_xch; MQ.xcc = h->mw_xcc; MQ.abort_word = h->mw_abort; MQ.epoch = h->mw_epoch; MQ.xch_global = nt > 32 ? 1 : 0;
+        MQ.u_out = u_out_dev; MQ.xch = h->mw_xch; MQ.xcc = h->mw_xcc; MQ.abort_word = h->mw_abort; MQ.epoch = h->mw_epoch; MQ.xch_global = nt > 32 ? 1 : 0; MQ.xcd_slot = h->mw_slot;
         HIPCHK(h, launch_mw<MW_SOLVE>(h, MQ, 0, s));
         if (h->timing) { HIPCHK(h, hipEventRecord(h->tev[1], s)); h->tev_fwd = true; }
         HIPCHK(h, hipMemcpyAsync(h->h_ctl, h->ctl_final, sizeof(StepState), hipMemcpyDeviceToHost, s));
@@ -867,9 +871,9 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
         bool bad = h->h_mw_chk[0] != 0;
         for (int i = 1; i < nt && !MQ.xch_global && !bad; ++i) bad = h->h_mw_chk[2 + i] != h->h_mw_chk[2];
         if (bad) {      // a meeting timed out, or the workgroups did not share an XCD: this handle goes back to one launch per attempt, for good
-            fprintf(stderr, "[rnde] chain engine: one-launch solve abandoned (%s); one launch per attempted step from now on\n",
-                    h->h_mw_chk[0] ? "a meeting timed out" : "workgroups pinned by block index landed on different XCDs");
-            h->mw_solve = 0; ++h->persist_fallbacks;
+            fprintf(stderr, "[rnde] chain engine: one-launch solve abandoned (%s); one launch per attempted step for the next %d solves\n",
+                    h->h_mw_chk[0] ? "a meeting timed out" : "workgroups pinned by block index landed on different XCDs", h->mw_retry_after);
+            h->mw_solve = -1; h->mw_clean = 0; ++h->persist_fallbacks;
             hipMemsetAsync(h->mw_abort, 0, 8, s);
             return RNDE_INTERNAL_RETRY;
         }
@@ -1032,6 +1036,12 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
     h->predicted = h->n_att + 1;
     // a hand-off time-out (a co-tenant held CUs for a second, e.g. another process's kernels) must not halve the speed for good:
     // after `persist_retry_after` clean multi-launch solves the one-launch kernels get another chance; each new failure doubles the wait
+    if (h->engine == 3 && (h->mw_solve == -1 || h->mw_bsweep == -1) && ++h->mw_clean >= h->mw_retry_after) {      // the same for the chain engine's one-launch kernels
+        if (h->mw_solve == -1) h->mw_solve = 1;
+        if (h->mw_bsweep == -1) h->mw_bsweep = 1;
+        h->mw_retry_after = std::min(1024, 2 * h->mw_retry_after);
+        h->mw_slot = (h->mw_slot + 1) & 7;                                           // (and another XCD: the one it was pinned to may be the contended one)
+    }
     if (h->persist == -1 && h->engine == 2 && h->cfg.persist >= 0 && ++h->persist_clean >= h->persist_retry_after) {
         h->persist = 1; h->persist_retry_after = std::min(1024, 2 * h->persist_retry_after);
         h->tslab_Bpad = -1;                          // slabs are refilled with the empty pattern before the next persistent launch
@@ -1845,7 +1855,7 @@ static rnde_status launch_bmw_t(rnde_node* h, const BMwParams& Q, const std::vec
     rnde_status st = RNDE_OK;
     // the whole sweep as ONE launch (rnde_bchainmw.h SWEEP): every workgroup resident (<= 256 column tiles; more than 32: meeting through the
     // memory side, as the forward solve), no shared controller, more than one attempt
-    const bool sweep = h->mw_bsweep && !h->couple && Q.ntiles <= kMwMeetMax && Q.B.n_att >= 2 && h->mw_xch;
+    const bool sweep = h->mw_bsweep > 0 && !h->couple && Q.ntiles <= kMwMeetMax && Q.B.n_att >= 2 && h->mw_xch;
     int* a_lo = h->h_mw_bargs; int* a_hi = a_lo + h->cfg.max_attempts; float* a_eig = (float*)(a_hi + h->cfg.max_attempts);
     for (int n = Q.B.n_att - 1; n >= 0; --n) {
         float c1 = 0.f, c2 = 0.f;   // cotangent of eigen_est for this attempt (as in bwd_run)
@@ -1869,7 +1879,7 @@ static rnde_status launch_bmw_t(rnde_node* h, const BMwParams& Q, const std::vec
         if (++h->mw_epoch >= 500000u) { h->mw_epoch = 1; HIPCHK(h, hipMemsetAsync(h->mw_xch, 0, (size_t)(cap + 4) * 3 * kMwMeetMax * 8, s)); }
         BMwParams W = Q;
         W.sv_lo = h->mw_bargs; W.sv_hi = h->mw_bargs + cap; W.eig_c = (const float*)(h->mw_bargs + 2 * cap);
-        W.xch = h->mw_xch; W.xcc = h->mw_xcc; W.abort_word = h->mw_abort; W.epoch = h->mw_epoch; W.xch_global = Q.ntiles > 32 ? 1 : 0;
+        W.xch = h->mw_xch; W.xcc = h->mw_xcc; W.abort_word = h->mw_abort; W.epoch = h->mw_epoch; W.xch_global = Q.ntiles > 32 ? 1 : 0; W.xcd_slot = h->mw_slot;
         hipLaunchKernelGGL((rnde_bchainmw_kernel<NR, TAB, LAT, 1>), dim3(W.xch_global ? Q.ntiles : 8 * Q.ntiles), blk, lds, s, W, Q.B.n_att - 1, h->h_meta[Q.B.n_att - 1], 0, 0, 0.f, 0.f);
         HIPCHK(h, hipGetLastError());
         HIPCHK(h, hipMemcpyAsync(h->h_mw_bchk, h->mw_abort, 4, hipMemcpyDeviceToHost, s));

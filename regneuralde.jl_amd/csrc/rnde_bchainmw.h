@@ -24,7 +24,7 @@ struct BMwParams {
     const float* sv_t; const float* sv_ubar; int nsave;
     // SWEEP (the whole reverse sweep in one launch): per-attempt arguments as device arrays, and the meeting of rnde_chainmw.h
     const int* sv_lo; const int* sv_hi; const float* eig_c;     // [n_att], [n_att], [n_att][2]
-    unsigned long long* xch; unsigned* xcc; unsigned* abort_word; unsigned epoch; int xch_global;
+    unsigned long long* xch; unsigned* xcc; unsigned* abort_word; unsigned epoch; int xch_global; int xcd_slot;
 };
 
 // J_f^T product at a taped evaluation.  kout = f's value (element-wise), kbar its cotangent; returns gbar (element-wise) and adds
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(kMwThreads) void rnde_bchainmw_kernel(const BMwPara
     float* RED = ZB + 1024;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if constexpr (SWEEP) { if (!Q.xch_global && (blockIdx.x & 7)) return; }      // (8 x ntiles launched: the ones that work share one XCD; xch_global: all work, see MW_SOLVE)
+    if constexpr (SWEEP) { if (!Q.xch_global && (int)(blockIdx.x & 7) != Q.xcd_slot) return; }      // (8 x ntiles launched: the ones that work share one XCD; xch_global: all work, see MW_SOLVE)
     const int tile = (SWEEP && !Q.xch_global) ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     if constexpr (SWEEP) { if (tid == 0) Q.xcc[tile] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15; }
     const int gcol = tile * 16 + (tid & 15);

@@ -84,7 +84,8 @@ struct MwParams {
     unsigned* abort_word;        // a meeting timed out
     unsigned epoch;              // tag = epoch * 8192 + attempt + 1
     int n_limit;                 // attempts this launch may run (the activation slab is sized for that many): reaching it ends the launch with done = 0
-    int xch_global;              // 0: 8 x ntiles workgroups launched, those with blockIdx % 8 == 0 work (one XCD); 1: ntiles launched, all of them work
+    int xch_global;              // 0: 8 x ntiles workgroups launched, those with blockIdx % 8 == xcd_slot work (one XCD); 1: ntiles launched, all of them work
+    int xcd_slot;                // which residue of blockIdx % 8 works (per handle: two handles on two streams then meet on different XCDs)
 };
 
 // cross-workgroup sums of the three norm partials of attempt `seq` (MW_SOLVE): every workgroup publishes {value, tag} and polls the others'.
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(kMwThreads) void rnde_chainmw_kernel(const MwParams
     // MW_SOLVE: 8 x ntiles workgroups are launched and those with blockIdx % 8 != 0 leave at once, so that the ones that work share ONE XCD
     // (round-robin dispatch; every workgroup records its XCC id, the host checks they agree): they meet through that L2 once per attempt
     // (xch_global, more than 32 tiles: every launched workgroup works and the meeting goes through the memory side)
-    if constexpr (MODE == MW_SOLVE) { if (!Q.xch_global && (blockIdx.x & 7)) return; }
+    if constexpr (MODE == MW_SOLVE) { if (!Q.xch_global && (int)(blockIdx.x & 7) != Q.xcd_slot) return; }
     const int tile = (MODE == MW_SOLVE && !Q.xch_global) ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const bool writer = (tile == 0 && tid == 0);
     if constexpr (MODE == MW_SOLVE) { if (tid == 0) Q.xcc[tile] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15; }

@@ -481,16 +481,19 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
         if (lane == 0) { GL[(i * 3 + 0) * 8 + w] = a; GL[(i * 3 + 1) * 8 + w] = b; GL[(i * 3 + 2) * 8 + w] = c; }
     }
     __syncthreads();
-    if (tid == 0) {
-        float o0 = 0.f, o1 = 0.f, o2 = 0.f;
-        for (int i = 0; i < 7; ++i) {
-            float sa = 0.f, ta = 0.f, xa = 0.f;
-            for (int q = 0; q < gWT; ++q) { sa += GL[(i * 3 + 0) * 8 + q]; ta += GL[(i * 3 + 1) * 8 + q]; xa += GL[(i * 3 + 2) * 8 + q]; }
-            if (i == 0) { o0 = sa; o1 = ta; o2 = xa; }
-            else { o0 += sa; o1 += ta; o2 += tsC(7 - i) * ta; }
+    if (w == 0) {
+        // lane 3 i + kind sums entry (i, kind) over the waves (q = 0 .. in order, as one thread did for all 21 entries: 147 dependent-chain additions
+        // behind 147 LDS reads at the very end of every reversed attempt), lane 0 then combines the 21 sums in the same order as before
+        float v = 0.f;
+        if (lane < 21) for (int q = 0; q < gWT; ++q) v += GL[lane * 8 + q];
+        auto at = [&](int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+        float o0 = at(0), o1 = at(1), o2 = at(2);
+#pragma unroll
+        for (int i = 1; i < 7; ++i) { const float sa = at(3 * i), ta = at(3 * i + 1); o0 += sa; o1 += ta; o2 += tsC(7 - i) * ta; }
+        if (lane == 0) {
+            float* o = Bq.bpart + ((size_t)(n & 1) * Bq.bpart_n + wg) * 4;
+            o[0] = o0; o[1] = o1; o[2] = o2; o[3] = 0.f;
         }
-        float* o = Bq.bpart + ((size_t)(n & 1) * Bq.bpart_n + wg) * 4;
-        o[0] = o0; o[1] = o1; o[2] = o2; o[3] = 0.f;
     }
 }
 

@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 # RNDE_LIB: load another build of the same library (A/B runs of kernel variants on one GPU box; tools/ab_bench.sh)
 LIB = os.environ.get("RNDE_LIB") or os.path.join(_HERE, "lib", "librnde.so")
-SOURCES = ["rnde.hip", "rnde_stage_solve.hip", "rnde_latent.hip", "rnde_sde.hip", "rnde_comm.hip", "rnde_tapes.hip"]
+SOURCES = ["rnde.hip", "rnde_reverse.hip", "rnde_stage_solve.hip", "rnde_latent.hip", "rnde_sde.hip", "rnde_comm.hip", "rnde_tapes.hip"]
 
 
 def _headers():

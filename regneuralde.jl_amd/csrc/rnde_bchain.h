@@ -473,7 +473,7 @@ __global__ __launch_bounds__(64 * kCW) void rnde_bchain_init_kernel(const BChain
 
 // ---- parameter gradients: W_l-bar[o][i] = sum over (evaluation, column) of Z_l[o] * [H_l ; t ; 1][i] ---------------------
 // grid (n_layers, chunks); each wave contracts its share of (evaluation, tile) units, 16 columns = 4 MFMA k-steps each.
-__global__ __launch_bounds__(64 * kCW) void rnde_chain_wgrad_kernel(const BChainParams Q, const float* __restrict__ ev_t, int n_units, int per_chunk,
+static __global__ __launch_bounds__(64 * kCW) void rnde_chain_wgrad_kernel(const BChainParams Q, const float* __restrict__ ev_t, int n_units, int per_chunk,
                                                                    float* __restrict__ wslab, int P_total) {
     const ChainGeo& G = Q.G;
     __shared__ __attribute__((aligned(16))) float ACC[20 * 256];

@@ -117,7 +117,7 @@ __device__ __forceinline__ void finish_attempt_scalars(const BwdParams& Q, int m
     finish_attempt_scalars_from(Q, m, lane, nullptr, tb, dtpb, qoldb, t1b, t0b);
 }
 
-__global__ __launch_bounds__(64) void rnde_bfin_kernel(const BwdParams Q) {
+static __global__ __launch_bounds__(64) void rnde_bfin_kernel(const BwdParams Q) {
     const int lane = threadIdx.x;
     const IBState ib = Q.ibstate[1];
     double tau0 = 0;
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(448) void rnde_wgrad3_kernel(const EvalDesc* __rest
 }
 
 // fixed-order sum of chunks [c0, c1) of the slab -> out (blockIdx.y selects the chunk group in pass 1)
-__global__ void rnde_wgrad_reduce(const float* __restrict__ slab, int n_chunks, int per_group, long long len, float* __restrict__ out) {
+static __global__ void rnde_wgrad_reduce(const float* __restrict__ slab, int n_chunks, int per_group, long long len, float* __restrict__ out) {
     const int c0 = blockIdx.y * per_group, c1 = min(n_chunks, c0 + per_group);
     float* o = out + (size_t)blockIdx.y * len;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < len; i += (long long)gridDim.x * blockDim.x) {
@@ -577,7 +577,7 @@ __global__ void rnde_wgrad_reduce(const float* __restrict__ slab, int n_chunks, 
 // the same for the two layers of the stage engine in ONE launch per pass (blockIdx.z = layer): four launches of ~9 us were two too many
 struct ReduceJob { const float* slab; float* out; long long len; int n_chunks, per_group; };
 struct ReducePair { ReduceJob j[2]; };
-__global__ void rnde_wgrad_reduce_pair(const ReducePair R) {
+static __global__ void rnde_wgrad_reduce_pair(const ReducePair R) {
     const ReduceJob J = R.j[blockIdx.z];
     const int c0 = blockIdx.y * J.per_group, c1 = min(J.n_chunks, c0 + J.per_group);
     if (c0 >= c1) return;
@@ -598,7 +598,3 @@ __global__ void rnde_wgrad_reduce_pair(const ReducePair R) {
 }
 
 }  // namespace rnde
-
-struct rnde_node;
-static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* saveval_bar_host, float* x_bar_dev,
-                           float* p_bar_dev, float* tspan_bar_host, hipStream_t s, bool sync = true, float* tspan_bar_dev = nullptr);

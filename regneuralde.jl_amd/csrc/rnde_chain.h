@@ -68,7 +68,7 @@ struct ChainRec {
 //   (M row rho of the MFMA = D register rho & 3 of lane group rho >> 2  <->  out feature 4 (4 mo + (rho & 3)) + (rho >> 2))
 // transposed fragment (l, mi, ks): the same with the roles of the two widths exchanged (J^T products of the reverse pass)
 // bias fragment (l, ks): lane group g holds b_l[4 ks + g]; followed, when time_dep, by the time column W_l[:, in]
-__global__ void rnde_chain_pack_kernel(const float* __restrict__ p, float* __restrict__ frags, const ChainGeo G) {
+static __global__ void rnde_chain_pack_kernel(const float* __restrict__ p, float* __restrict__ frags, const ChainGeo G) {
     const long long total = (long long)(G.nfrag_f + G.nfrag_b + G.nfrag_t) * 64;
     for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
         int fr = (int)(e >> 6);
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(64 * kCW) void rnde_chain_kernel(const ChainParams 
 }
 
 // fragment order <-> caller layout (debug entry points, and k1 hand-over of rnde_debug_attempt)
-__global__ void rnde_chain_convert_kernel(const float* __restrict__ src, float* __restrict__ dst, int D, int B, int ntiles, int nksD, int to_caller) {
+static __global__ void rnde_chain_convert_kernel(const float* __restrict__ src, float* __restrict__ dst, int D, int B, int ntiles, int nksD, int to_caller) {
     const long long total = (long long)ntiles * nksD * 64;
     for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
         const int lane = (int)(e & 63), q = (int)((e >> 6) % nksD), tile = (int)((e >> 6) / nksD);

@@ -145,7 +145,7 @@ __device__ __forceinline__ bool mw_exchange3(const MwMeet& Q, int seq, const flo
 // forward fragment (l, mo, mi, j): lane (kk = lane >> 4, rho = lane & 15) = W_l[16 mo + rho][16 mi + 4 j + kk]
 // transposed      (l, mi, mo, j): lane (kk, rho)                         = W_l[16 mo + 4 j + kk][16 mi + rho]
 // bias vector l: b_l[f] for f < 64; time column l: W_l[f][in] (TDChain layers)
-__global__ void rnde_chainmw_pack_kernel(const float* __restrict__ p, float* __restrict__ tab, const MwGeo G) {
+static __global__ void rnde_chainmw_pack_kernel(const float* __restrict__ p, float* __restrict__ tab, const MwGeo G) {
     const long long nf = (long long)G.nfrag_f * 64, nt = (long long)G.nfrag_t * 64, total = nf + 1024 + nt;
     for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
         float v = 0.f;

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void rnde_head_col_kernel(const float* __restr
 
 // W-bar[i][d] = sum_c delta[i][c] u[d][c]: pass 1 -- one thread per (d, column chunk), partial[chunk][d*C + i]
 constexpr int kHeadChunks = 32;
-__global__ __launch_bounds__(256) void rnde_head_wgrad_kernel(const float* __restrict__ u, const float* __restrict__ delta,
+static __global__ __launch_bounds__(256) void rnde_head_wgrad_kernel(const float* __restrict__ u, const float* __restrict__ delta,
                                                               int D, int C, int B, float* __restrict__ partial) {
     const int d = blockIdx.x * 256 + threadIdx.x;
     const int ch = blockIdx.y;
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void rnde_head_wgrad_kernel(const float* __res
     for (int i = 0; i < C; ++i) o[(size_t)d * C + i] = acc[i];
 }
 // pass 2 -- fixed-order sum of the chunk partials; bias gradient and mean cross entropy by one extra wave
-__global__ __launch_bounds__(256) void rnde_head_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ delta,
+static __global__ __launch_bounds__(256) void rnde_head_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ delta,
                                                                const float* __restrict__ ce_col, int D, int C, int B,
                                                                float* __restrict__ p3bar, float* __restrict__ ce_out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void rnde_head_reduce_kernel(const float* __re
 }
 
 // Optimiser(InvDecay(gamma), Momentum(eta, rho)) on one flat parameter group (include/rnde.h: rnde_momentum_step)
-__global__ __launch_bounds__(256) void rnde_momentum_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ v,
+static __global__ __launch_bounds__(256) void rnde_momentum_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ v,
                                                             long long len, float inv_decay, float eta, float rho) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= len) return;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void rnde_momentum_kernel(float* __restrict__ 
 
 // Flux.Optimise.ADAM(eta, (beta1, beta2)) on one flat parameter group (include/rnde.h: rnde_adam_step; the optimiser of
 // experiments/mnist_nsde.jl).  bc1 = 1 - beta1^t, bc2 = 1 - beta2^t for the step being taken.
-__global__ __launch_bounds__(256) void rnde_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+static __global__ __launch_bounds__(256) void rnde_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                         long long len, float gscale, float eta, float b1, float b2, float bc1, float bc2, float eps) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= len) return;

@@ -79,7 +79,7 @@ __device__ __forceinline__ f32x4 stage_pack_elem(const float* __restrict__ p, in
     }
     return v;
 }
-__global__ void rnde_stage_pack_kernel(const float* __restrict__ p, f32x4* __restrict__ dst, int which, int D, int H,
+static __global__ void rnde_stage_pack_kernel(const float* __restrict__ p, f32x4* __restrict__ dst, int which, int D, int H,
                                        int MTrows, int Kb) {
     const long long total = (long long)MTrows * Kb * 64;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
@@ -91,7 +91,7 @@ __global__ void rnde_stage_pack_kernel(const float* __restrict__ p, f32x4* __res
 // initial-step rule (kind 1), or the tape's own copy of p (kind 2).
 struct PackJob { void* dst; const float* src; long long total; int kind, which, kdim, pad; };   // src: kind 2 only (NULL = the parameter vector)
 struct PackJobs { PackJob j[8]; };
-__global__ void rnde_pack_all_kernel(const float* __restrict__ p, const PackJobs J, int D, int H) {
+static __global__ void rnde_pack_all_kernel(const float* __restrict__ p, const PackJobs J, int D, int H) {
     const PackJob job = J.j[blockIdx.y];
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < job.total; i += (long long)gridDim.x * blockDim.x) {
         if (job.kind == 0) ((f32x4*)job.dst)[i] = stage_pack_elem(p, job.which, D, H, job.kdim, i);
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_kernel(const StagePara
 }
 
 // finish kernel for the stage engine: final controller update + copy-out
-__global__ __launch_bounds__(256) void rnde_stage_finish_kernel(const StageParams Q, const int n, float* __restrict__ u_out) {
+static __global__ __launch_bounds__(256) void rnde_stage_finish_kernel(const StageParams Q, const int n, float* __restrict__ u_out) {
     const StepParams& P = Q.F;
     const int tid = threadIdx.x, lane = tid & 63;
     const bool writer = (blockIdx.x == 0 && tid == 0);

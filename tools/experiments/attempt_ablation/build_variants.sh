@@ -18,7 +18,7 @@ patch -d $S -p0 < $HERE/rnde_stage_persist.h.patch
 build() {
     N=$1; shift
     { /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-undefined-internal -Wno-pass-failed "$@" -c $S/rnde.hip -o $L/obj/rnde_$N.o &&
-      /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $L/librnde_$N.so $L/obj/rnde_$N.o $L/obj/rnde_stage_solve.o $L/obj/rnde_latent.o $L/obj/rnde_sde.o $L/obj/rnde_comm.o $L/obj/rnde_tapes.o -ldl; } > /tmp/abl_$N.log 2>&1 || { echo "FAILED $N"; tail -5 /tmp/abl_$N.log; }
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $L/librnde_$N.so $L/obj/rnde_$N.o $L/obj/rnde_reverse.o $L/obj/rnde_stage_solve.o $L/obj/rnde_latent.o $L/obj/rnde_sde.o $L/obj/rnde_comm.o $L/obj/rnde_tapes.o -ldl; } > /tmp/abl_$N.log 2>&1 || { echo "FAILED $N"; tail -5 /tmp/abl_$N.log; }
 }
 build abl_base &
 build abl_nopoll -DRNDE_ABL_NOPOLL &

@@ -307,12 +307,8 @@ __global__ __launch_bounds__(256) void rnde_wgrad2_kernel(const EvalDesc* __rest
 // 128-row block (7x).  Here the wide side (784 rows of z2bar, or the 786 rows of [g; t; 1]) is split into TWO halves of 16-row
 // tiles (25 + 24, or 25 + 25), a workgroup of 7 waves owns one half against the whole narrow side (7 tiles of 16 = 112 >= 102),
 // wave w taking the tiles w, w + 7, w + 14, (w + 21): 28 accumulator tiles per wave at most.  Per 32-column step the half-tile
-// of the wide operand (<= 400 x 32) and the narrow operand (112 x 32) are staged in LDS from registers fetched one step ahead
-// (as in rnde_wgrad2_kernel); LDS row strides are = 16 (mod 64) floats, so the four 16-lane groups of an MFMA operand read
+// of the wide operand (<= 400 x 32) and the narrow operand (112 x 32) are brought into LDS by `global_load_lds` one step ahead; LDS row strides are = 16 (mod 64) floats, so the four 16-lane groups of an MFMA operand read
 // hit distinct bank windows.  TALL_IS_Z: the wide operand is Z (layer 2) or [X; t; 1] (layer 1).
-#ifndef RNDE_WGRAD3_PIPE
-#define RNDE_WGRAD3_PIPE 1
-#endif
 #ifndef RNDE_WGRAD3_NT
 #define RNDE_WGRAD3_NT 1   // non-temporal wide-operand stream: the reverse sweep running beside the side-stream launches keeps its L2 (32.55 -> 32.23 us per reversed attempt)
 #endif
@@ -338,7 +334,6 @@ __global__ __launch_bounds__(448) void rnde_wgrad3_kernel(const EvalDesc* __rest
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int n = 0; n < 7; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#if RNDE_WGRAD3_PIPE
     const bool has3 = w + 21 < ntile;                      // tiles w, w + 7, w + 14 always exist (host: both halves >= 21 tiles)
     const int TRp = TALL_IS_Z ? M : Nx, SRp = TALL_IS_Z ? Nx : M;
     // Staging of one 32-column step WITHOUT registers: `global_load_lds_dwordx4` moves 64 lanes x 16 bytes from global memory
@@ -443,100 +438,6 @@ __global__ __launch_bounds__(448) void rnde_wgrad3_kernel(const EvalDesc* __rest
         wait_vm<0>();                                       // this wave's units of step + 1 have landed
         __syncthreads();
     }
-#else
-    // fetch of one step: the wide half is 32 columns x nrow/4 float4 (8 slots per thread), the narrow operand 32 x 28 float4 (2).
-    // Slot coordinates do not depend on the step: column within the step and first row of the float4 (M, Nx are multiples of
-    // 4, so a float4 is either four real rows, or the synthetic {t, 1, 0, 0} rows of [X; t; 1], or padding).
-    const int tq = nrow >> 2;
-    const int TRp = TALL_IS_Z ? M : Nx, SRp = TALL_IS_Z ? Nx : M;
-    int tcol[8], trow[8], scol[2], srow[2];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int idx = tid + 448 * q;
-        tcol[q] = idx < KC * tq ? idx / tq : -1;
-        trow[q] = row_lo + 4 * (idx - max(tcol[q], 0) * tq);
-    }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int idx = tid + 448 * q;                     // < 896 = 32 * 28
-        scol[q] = idx / 28;
-        srow[q] = 4 * (idx - scol[q] * 28);
-    }
-    // fetch() only issues the loads (addresses clamped into the operand, no branch); the real / synthetic / padding choice
-    // is made when the registers are written to LDS one step later, so nothing waits on the loads before the MFMAs
-    f32x4 treg[8], sreg[2];
-    int c0_f = 0; float t_f = 0.f;
-    auto fetch = [&](int step) {
-        const int e = (s_lo + step) / steps_per_eval;
-        c0_f = ((s_lo + step) % steps_per_eval) * KC;
-        t_f = evals[e].t;
-        const float* __restrict__ Tp = TALL_IS_Z ? evals[e].Z : evals[e].X;
-        const float* __restrict__ Sp = TALL_IS_Z ? evals[e].X : evals[e].Z;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int cc = c0_f + tcol[q];
-            const bool real = tcol[q] >= 0 && cc < Bpad && trow[q] < TRp;
-            // (non-temporal: each wide-operand element is read once; keeps the streams out of the way of the sweep running beside it)
-            treg[q] = __builtin_nontemporal_load((const f32x4*)(Tp + (real ? (size_t)cc * TRp + trow[q] : 0)));
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int cc = c0_f + scol[q];
-            const bool real = cc < Bpad && srow[q] < SRp;
-            sreg[q] = *(const f32x4*)(Sp + (real ? (size_t)cc * SRp + srow[q] : 0));
-        }
-    };
-    const bool has3 = w + 21 < ntile;                      // tiles w, w + 7, w + 14 always exist (host: both halves >= 21 tiles)
-    auto stage = [&](int buf) {                            // registers of the last fetch() -> LDS buffer `buf`
-        float* Tb = Tl + buf * (KC * (TLS + SLS));
-        float* Sb = Sl + buf * (KC * (TLS + SLS));
-        const f32x4 synth = {t_f, 1.f, 0.f, 0.f}, zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const bool in_col = tcol[q] >= 0 && c0_f + tcol[q] < Bpad;
-            const f32x4 v = in_col && trow[q] < TRp ? treg[q] : (!TALL_IS_Z && in_col && trow[q] == TRp ? synth : zero);
-            if (tcol[q] >= 0) *(f32x4*)(Tb + tcol[q] * TLS + (trow[q] - row_lo)) = v;
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const bool in_col = c0_f + scol[q] < Bpad;
-            const f32x4 v = in_col && srow[q] < SRp ? sreg[q] : (TALL_IS_Z && in_col && srow[q] == SRp ? synth : zero);
-            *(f32x4*)(Sb + scol[q] * SLS + srow[q]) = v;
-        }
-    };
-    // two LDS buffers, one barrier per step: a wave writes step + 1 into the other buffer as soon as its own MFMAs of this step
-    // are issued, while the other waves are still multiplying
-    if (total_steps > 0) { fetch(0); stage(0); }
-    if (total_steps > 1) fetch(1);
-    __syncthreads();
-    for (int step = 0; step < total_steps; ++step) {
-        const float* Tb = Tl + (step & 1) * (KC * (TLS + SLS));
-        const float* Sb = Sl + (step & 1) * (KC * (TLS + SLS));
-#pragma unroll
-        for (int s = 0; s < KC / 4; ++s) {
-            const int col = 4 * s + kk;
-            float a[4], bq[7];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) a[i] = Tb[col * TLS + 16 * (w + 7 * i) + mrow];
-            a[3] = Tb[col * TLS + 16 * (has3 ? w + 21 : w) + mrow];
-#pragma unroll
-            for (int n = 0; n < 7; ++n) bq[n] = Sb[col * SLS + 16 * n + mrow];
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int n = 0; n < 7; ++n) acc[i][n] = mfma16(a[i], bq[n], acc[i][n]);
-            if (has3) {
-#pragma unroll
-                for (int n = 0; n < 7; ++n) acc[3][n] = mfma16(a[3], bq[n], acc[3][n]);
-            }
-        }
-        // registers hold step + 1 (fetched a step ago): write it to the other buffer, then issue the loads of step + 2 before
-        // the barrier, so their address arithmetic runs under the other waves' MFMAs
-        if (step + 1 < total_steps) stage((step + 1) & 1);
-        if (step + 2 < total_steps) fetch(step + 2);
-        __syncthreads();
-    }
-#endif
     // D register q of lane l = C[wide row 16 T + 4 (l >> 4) + q][narrow row 16 n + (l & 15)]
     float* out = slab + (size_t)chunk * M * (Nx + 2);
 #pragma unroll

@@ -133,6 +133,29 @@ function solve_forward_saveat(h::Handle, x::ROCMatrix{Float32}, p::ROCVector{Flo
     return u3, Int(nfe[]), sv[1:nsv[]]
 end
 
+# save_everystep = true (neural_ode.jl:10-11): the state after every accepted step (the initial one first when save_start), D x n x B with n
+# known after the call (the library solves twice: the step sequence, then the same solve saving at those step ends); backward as after saveat
+function solve_forward_everystep(h::Handle, x::ROCMatrix{Float32}, p::ROCVector{Float32}, tspan; save_start::Bool = true, keep_tape::Bool)
+    D, B = size(x)
+    cap = h.cfg.max_attempts + 1
+    buf = ROCArray{Float32}(undef, D * cap * B)
+    ts = Vector{Float32}(undef, cap)
+    n = Ref{Int32}(0)
+    nfe = Ref{Int64}(0)
+    nsv = Ref{Int32}(0)
+    sv = Vector{Float32}(undef, h.cfg.max_attempts + 1)
+    GC.@preserve x p buf sv ts begin
+        st = ccall((:rnde_node_forward_everystep, LIB), Cint,
+                   (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Float32, Float32, Int32, Ptr{Cvoid}, Int32, Ptr{Float32}, Ref{Int32},
+                    Ref{Int64}, Ptr{Float32}, Ref{Int32}, Int32, Ptr{Cvoid}),
+                   h.ptr, devptr(x), devptr(p), B, Float32(tspan[1]), Float32(tspan[2]), save_start ? 1 : 0, devptr(buf), cap, ts, n,
+                   nfe, sv, nsv, keep_tape ? 1 : 0, _stream())
+        check(h, st)
+    end
+    u3 = reshape(buf[1:D * Int(n[]) * B], D, Int(n[]), B)
+    return u3, ts[1:n[]], Int(nfe[]), sv[1:nsv[]]
+end
+
 # ubar: D x B after solve_forward, D x T x B after solve_forward_saveat; x-bar is D x B either way
 function solve_backward(h::Handle, ubar::ROCArray{Float32}, svbar::Vector{Float32}, np::Int)
     xbar = ROCArray{Float32}(undef, size(ubar, 1), size(ubar, ndims(ubar)))

@@ -111,6 +111,15 @@ rnde_status rnde_node_forward_saveat(rnde_node* h, const float* x_dev, const flo
                                      float* u_saved_dev, int64_t* nfe_out, float* saveval_host,
                                      int32_t* n_saveval_out, int32_t keep_tape, void* stream);
 
+/* save_everystep = true (reference src/models/neural_ode.jl:10-11: the other way to `return_multiple`): the state after every accepted step, and
+ * the initial state first when save_start != 0 -- sol_out_dev: D x n x B, column-major, n <= capacity returned in *n_out together with the times
+ * (t_host_out: room for `capacity` floats, may be NULL).  The number of steps is known only after the solve, so the call solves twice (the step
+ * sequence, then the same solve saving at those step ends: u_new itself, no interpolation); the rest as rnde_node_forward_saveat, including the
+ * backward call afterwards (u_bar_dev: D x n x B).  More accepted steps than `capacity`: RNDE_ERR_BAD_ARG with *n_out set to the room needed. */
+rnde_status rnde_node_forward_everystep(rnde_node* h, const float* x_dev, const float* p_dev, int32_t B, float t0, float t1,
+                                        int32_t save_start, float* sol_out_dev, int32_t capacity, float* t_host_out, int32_t* n_out,
+                                        int64_t* nfe_out, float* saveval_host, int32_t* n_saveval_out, int32_t keep_tape, void* stream);
+
 /* Parity instrument: the same solve along a GIVEN sequence of attempts.  steps_host holds n_steps pairs
  * (dt_proposed, accepted != 0): attempt n runs with min(dt_proposed[n], t1 - t) and is accepted or rejected as told, and
  * the solve ends after n_steps attempts; the error estimate, q11 and q of every attempt are still computed and logged

@@ -64,6 +64,7 @@ def lib():
     L.rnde_node_destroy.restype = None
     L.rnde_node_forward.argtypes = [vp, vp, vp, i32, f, f, vp, i64p, fp, i32p, i32, vp]
     L.rnde_node_forward_saveat.argtypes = [vp, vp, vp, i32, f, f, fp, i32, vp, i64p, fp, i32p, i32, vp]
+    L.rnde_node_forward_everystep.argtypes = [vp, vp, vp, i32, f, f, i32, vp, i32, fp, i32p, i64p, fp, i32p, i32, vp]
     L.rnde_node_forward_replay.argtypes = [vp, vp, vp, i32, f, f, fp, i32, vp, i64p, fp, i32p, i32, vp]
     L.rnde_node_backward.argtypes = [vp, vp, fp, vp, vp, fp, vp]
     L.rnde_node_backward_async.restype = C.c_int32
@@ -158,7 +159,7 @@ def lib():
 
 
 EXPORTS = ["rnde_version", "rnde_last_error", "rnde_param_count", "rnde_node_create", "rnde_node_destroy",
-           "rnde_node_forward", "rnde_node_forward_saveat", "rnde_node_forward_replay", "rnde_node_backward", "rnde_node_backward_async", "rnde_node_release_tape", "rnde_node_forward_host",
+           "rnde_node_forward", "rnde_node_forward_saveat", "rnde_node_forward_everystep", "rnde_node_forward_replay", "rnde_node_backward", "rnde_node_backward_async", "rnde_node_release_tape", "rnde_node_forward_host",
            "rnde_node_backward_host", "rnde_node_steps", "rnde_debug_feval", "rnde_debug_attempt",
            "rnde_bench_attempt", "rnde_bench_attempt_taped", "rnde_bench_attempt_cold_tape", "rnde_node_set_timing", "rnde_node_timing", "rnde_node_last_attempts", "rnde_node_fallback_count",
            "rnde_node_launches_per_attempt", "rnde_node_one_launch_solves", "rnde_classifier_head", "rnde_node_classifier_grad", "rnde_momentum_step", "rnde_momentum_step_scaled", "rnde_adam_step",

@@ -959,6 +959,29 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
     return RNDE_OK;
 }
 
+// save_everystep = true (reference src/models/neural_ode.jl:10-11: return_multiple = save_everystep || saveat): the state after every ACCEPTED step.
+// Which times those are is known only after the solve, so the call runs it twice -- once untaped for the step sequence, once with the accepted
+// step ends (and t0, if asked) as save times: the value saved at a step's end is u_new itself, no interpolation (dense_points, rnde_stage.h),
+// and the second run repeats the first bit for bit (save times do not enter the controller).  A call shape for small problems: no reference
+// experiment uses it (every multi-output call site passes saveat); the backward call afterwards is the saveat one.
+extern "C" rnde_status rnde_node_forward_everystep(rnde_node* h, const float* x_dev, const float* p_dev, int32_t B, float t0, float t1, int32_t save_start,
+                                                   float* sol_out_dev, int32_t capacity, float* t_host_out, int32_t* n_out, int64_t* nfe_out,
+                                                   float* saveval_host, int32_t* n_saveval_out, int32_t keep_tape, void* stream) {
+    if (!h || !n_out || !sol_out_dev || capacity < 1) return RNDE_ERR_BAD_ARG;
+    rnde_status st = forward_impl(h, x_dev, p_dev, B, t0, t1, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, stream);
+    if (st != RNDE_OK) return st;
+    std::vector<float> times;
+    if (save_start) times.push_back(t0);
+    for (int i = 0; i < h->n_att; ++i) {
+        const StepMeta& m = h->h_meta[i];
+        if (m.flags & F_ACCEPT) { float tn = m.t + m.dt; if (tn > t1) tn = t1; times.push_back(tn); }      // (fp32, as the controller forms t + dt; the last step ends at t1 exactly whenever t >= t1 / 2)
+    }
+    *n_out = (int32_t)times.size();
+    if ((int)times.size() > capacity) { h->err = "rnde_node_forward_everystep: more accepted steps than the output has room for"; return RNDE_ERR_BAD_ARG; }
+    if (t_host_out) memcpy(t_host_out, times.data(), times.size() * sizeof(float));
+    return forward_impl(h, x_dev, p_dev, B, t0, t1, nullptr, times.data(), (int32_t)times.size(), sol_out_dev, nfe_out, saveval_host, n_saveval_out, keep_tape, stream);
+}
+
 extern "C" rnde_status rnde_node_steps(rnde_node* h, float* steps_host, int32_t capacity, int32_t* n_out) {
     if (!h) return RNDE_ERR_BAD_ARG;
     const int n = std::min(capacity, h->n_att);

@@ -11,7 +11,8 @@ D x T x B array of diffeqsol_to_3dtrackedarray (src/utils.jl:17-19).
 
 Differences from the Julia layer that are inherent to the host language: `func` is one of the
 reference's three callbacks selected by name (mnist_node.jl:67,:74-79,:88-97), not a closure;
-`save_everystep=True` (a result whose length is data dependent; no reference call site uses it) is refused.
+`save_everystep=True` (a result whose length is data dependent; no reference call site uses it): `rnde_node_forward_everystep`, the state
+after every accepted step (and the initial one with save_start=True), (B, n, D) with n known after the call.
 """
 import ctypes as C
 
@@ -95,6 +96,20 @@ class _Solve(torch.autograd.Function):
             u = torch.empty_like(x)
             st = L.rnde_node_forward(h.ptr, x.data_ptr(), p.data_ptr(), B, t0, t1, u.data_ptr(), C.byref(nfe), sv_host,
                                      C.byref(nsv), 1 if keep_tape else 0, C.c_void_p(stream))
+        elif saveat == "everystep":      # save_everystep = true: every accepted step's end (neural_ode.jl:10-11); the count comes back with the call
+            cap = layer.max_attempts + 1
+            buf = torch.empty((B, cap, D), dtype=torch.float32, device=x.device)
+            # the library writes D x n x B column-major = (B, n, D) rows of the n it finds: ask with the capacity as the time stride is n, not cap --
+            # so the call goes into a scratch of the full capacity first and the (B, n, D) block is what it filled
+            th = (C.c_float * cap)()
+            nout = C.c_int32(0)
+            st = L.rnde_node_forward_everystep(h.ptr, x.data_ptr(), p.data_ptr(), B, t0, t1, 1 if layer.kwargs.get("save_start", True) else 0,
+                                               buf.data_ptr(), cap, th, C.byref(nout), C.byref(nfe), sv_host, C.byref(nsv), 1 if keep_tape else 0,
+                                               C.c_void_p(stream))
+            _lib.check(h.ptr, st)
+            n = nout.value
+            u = buf.reshape(-1)[: B * n * D].reshape(B, n, D).clone()
+            layer.last_times = [float(th[i]) for i in range(n)]
         else:
             T = len(saveat)
             u = torch.empty((B, T, D), dtype=torch.float32, device=x.device)
@@ -145,9 +160,7 @@ class TrackedNeuralODE:
         self.regularize = bool(regularize)
         self.kwargs = dict(kwargs)                       # reltol, abstol, save_everystep, save_start, saveat
         self.return_multiple = bool(kwargs.get("save_everystep", False)) or ("saveat" in kwargs)  # neural_ode.jl:11
-        if bool(kwargs.get("save_everystep", False)):
-            raise NotImplementedError("save_everystep=True: the result length is data dependent; pass saveat= instead "
-                                      "(every reference call site does: latent_ode.jl:144, mnist_node.jl:121)")
+        self.save_everystep = bool(kwargs.get("save_everystep", False)) and "saveat" not in kwargs      # (saveat given: it decides what is saved)
         if bool(time_dep) != bool(model.time_dep):
             raise ValueError("time_dep must match the model (TDChain => True)")
         self.max_batch, self.max_attempts = int(max_batch), int(max_attempts)
@@ -156,6 +169,7 @@ class TrackedNeuralODE:
         self._handles = {}
         self._coupling = None
         self.last_nfe = None
+        self.last_times = None                            # save_everystep: the times of the states the last call returned
         self.last_tspan_bar = None
 
     # -- C-ABI config -------------------------------------------------------------------------
@@ -250,7 +264,9 @@ class TrackedNeuralODE:
         self._func = func if self.regularize else None
         keep = torch.is_grad_enabled() and (x2.requires_grad or p.requires_grad)
         times = None
-        if self.return_multiple:      # update_saveat! (neural_ode.jl:35-46): a per-call override, the stored one otherwise
+        if self.return_multiple and self.save_everystep and saveat is None:
+            times = "everystep"
+        elif self.return_multiple:      # update_saveat! (neural_ode.jl:35-46): a per-call override, the stored one otherwise
             times = self._saveat_times(self.kwargs["saveat"] if saveat is None else saveat, ts)
         u, saveval = _Solve.apply(x2, p.contiguous(), self, ts[0], ts[1], keep, times)
         sv = SavedValues(saveval) if self.regularize else None

@@ -42,6 +42,15 @@ function rnde_handle(n::TrackedNeuralODE{R}, B::Int; kind::Symbol = :error_est) 
 end
 
 _saveat_vec(n, saveat) = Float32.(collect(isnothing(saveat) ? n.kwargs[:saveat] : saveat))
+# which times a multi-output call saves at: the given / stored saveat -- or, for a layer built with save_everystep = true and no saveat
+# (neural_ode.jl:10-11), the ends of the accepted steps, which an untracked solve has to find first (RNDE.solve_forward_everystep); the tracked
+# call then saves at exactly those (the value at a step's end is u_new itself)
+function _multi_times(n, h, x, p, tspan, saveat)
+    (!isnothing(saveat) || haskey(n.kwargs, :saveat)) && return _saveat_vec(n, saveat)
+    _, ts, _, _ = RNDE.solve_forward_everystep(h, Tracker.data(x), Tracker.data(p), tspan;
+                                               save_start = get(n.kwargs, :save_start, true), keep_tape = false)
+    return ts
+end
 _saved(tspan, p, saveval) = (sv = SavedValues(eltype(tspan), eltype(p)); append!(sv.saveval, saveval); sv)
 
 # {false,false} (reference :48-77): vanilla solve, end state only
@@ -56,7 +65,7 @@ end
 function (n::TrackedNeuralODE{false,true})(x, p = n.p; func = (u, t, int) -> 0, tspan = nothing, saveat = nothing)
     tspan = _convert_tspan(isnothing(tspan) ? n.tspan : tspan, p)
     h = rnde_handle(n, size(x, 2))
-    res, _ = RNDE.rnde_solve_saveat(h, x, p, tspan, _saveat_vec(n, saveat))     # <- replaces :92-102 (update_saveat! is not needed: nothing is mutated)
+    res, _ = RNDE.rnde_solve_saveat(h, x, p, tspan, _multi_times(n, h, x, p, tspan, saveat))     # <- replaces :92-102 (update_saveat! is not needed: nothing is mutated)
     return res, h.last_nfe, nothing
 end
 
@@ -74,6 +83,6 @@ function (n::TrackedNeuralODE{true,true})(x, p = n.p; func = (u, t, integrator) 
                                           saveat = nothing, kind::Symbol = :error_est)
     tspan = _convert_tspan(isnothing(tspan) ? n.tspan : tspan, p)
     h = rnde_handle(n, size(x, 2); kind = kind)
-    res, saveval = RNDE.rnde_solve_saveat(h, x, p, tspan, _saveat_vec(n, saveat))   # <- replaces :162-174
+    res, saveval = RNDE.rnde_solve_saveat(h, x, p, tspan, _multi_times(n, h, x, p, tspan, saveat))   # <- replaces :162-174
     return res, h.last_nfe, _saved(tspan, p, saveval)
 end

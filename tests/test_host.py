@@ -58,8 +58,9 @@ def test_node_constructor_contract(rnde):
     assert node.P == 158568 and node.return_multiple is False and node.regularize
     multi = rnde.TrackedNeuralODE(dyn, [0.0, 1.0], True, True, "Tsit5", saveat=[0.0, 0.5, 1.0])
     assert multi.return_multiple is True                      # neural_ode.jl:11
-    with pytest.raises(NotImplementedError):
-        rnde.TrackedNeuralODE(dyn, [0.0, 1.0], True, True, "Tsit5", save_everystep=True)
+    every = rnde.TrackedNeuralODE(dyn, [0.0, 1.0], True, True, "Tsit5", save_everystep=True)
+    assert every.return_multiple is True and every.save_everystep is True      # the other way to return_multiple (neural_ode.jl:10-11)
+    assert rnde.TrackedNeuralODE(dyn, [0.0, 1.0], True, True, "Tsit5", save_everystep=True, saveat=[0.0, 1.0]).save_everystep is False   # saveat decides
     assert rnde.TrackedNeuralODE._saveat_times(0.25, [0.0, 1.0]) == [0.0, 0.25, 0.5, 0.75, 1.0]
     assert rnde.TrackedNeuralODE._saveat_times(0.4, [0.0, 1.0]) == pytest.approx([0.0, 0.4, 0.8, 1.0])
     with pytest.raises(ValueError):

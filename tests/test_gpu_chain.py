@@ -49,6 +49,10 @@ def _engine(request):
     _DEFAULT_TILE[0] = 64
 
 
+# tests of features that exist on the multi-wave kernels only are generated for that kernel family only (no skipped twin)
+_MW = pytest.mark.parametrize("_engine", [65], indirect=True, ids=["multi-wave"])
+
+
 @pytest.mark.parametrize("lay", LAYOUTS)
 @pytest.mark.parametrize("kind,B", KINDS)
 def test_chain_feval_matches_oracle(kind, B, lay):
@@ -136,6 +140,7 @@ def test_chain_config4_statistics():
     assert np.abs(got["u"] - r3["u"]).max() <= 3e-6 * max(1.0, np.abs(r3["u"]).max())
 
 
+@_MW
 @pytest.mark.parametrize("kind,B", [("latent", 64), ("chain3", 19), ("wide", 16)])
 def test_chain_feval_equals_the_device_order_oracle_almost_bit_for_bit(kind, B, _mw_only):
     """One f evaluation on the multi-wave chain kernels against the oracle in their order: bit-identical in most entries, 1-2 ulp in the
@@ -283,10 +288,10 @@ DP5_CASES = [("latent", 4, 1e-3, 2.0), ("latent", 100, 1e-4, 2.0), ("chain3", 19
 
 @pytest.fixture
 def _mw_only():
-    if _DEFAULT_TILE[0] != 65:
-        pytest.skip("tableau-as-data runs on the multi-wave kernels only")
+    assert _DEFAULT_TILE[0] == 65
 
 
+@_MW
 @pytest.mark.parametrize("kind,B", [("latent", 37), ("chain3", 19), ("small", 70)])
 def test_dp5_attempt_matches_oracle(kind, B, _mw_only):
     from tests.util import Node, Oracle
@@ -305,6 +310,7 @@ def test_dp5_attempt_matches_oracle(kind, B, _mw_only):
     assert abs(eest_ts - eest_ref) > 0.05 * eest_ref
 
 
+@_MW
 @pytest.mark.parametrize("kind,B,tol,scale", DP5_CASES)
 def test_dp5_solve_and_reverse_match_oracle(kind, B, tol, scale, _mw_only):
     from tests.util import Node, Oracle, rel_err
@@ -331,6 +337,7 @@ def test_dp5_solve_and_reverse_match_oracle(kind, B, tol, scale, _mw_only):
     assert np.abs(gt - t64).max() <= (2e-3 + 4 * max(cx, cp)) * max(1.0, np.abs(t64).max())
 
 
+@_MW
 @pytest.mark.parametrize("kind,B,tol,scale,saveat", [("latent", 4, 1e-3, 1.5, np.linspace(0, 1, 49)), ("latent", 70, 1e-4, 1.5, np.array([0.1, 0.5, 0.9])),
                                                       ("chain3", 19, 1e-3, 2.0, np.array([0.0, 0.25, 1.0]))])
 def test_dp5_saveat_and_reverse_match_oracle(kind, B, tol, scale, saveat, _mw_only):
@@ -359,6 +366,7 @@ def test_dp5_saveat_and_reverse_match_oracle(kind, B, tol, scale, saveat, _mw_on
     assert np.abs(gt - t64).max() <= (2e-3 + 4 * max(cx, cp)) * max(1.0, np.abs(t64).max())
 
 
+@_MW
 def test_tsit5_through_the_table_equals_the_constant_folded_kernels(monkeypatch, _mw_only):
     """RNDE_CHAIN_TAB=1 feeds the Tsit5 coefficients to the data path (dense output expanded to monomials): same accept/reject
     sequence, states and cotangents as the kernels with the pair folded into the code."""
@@ -394,6 +402,7 @@ def test_dp5_is_refused_where_the_table_kernels_do_not_run():
         Node(_cfg(arch_mnist(), 8, col_tile=16, solver="DP5"))             # stage engine
 
 
+@_MW
 def test_latent_shape_kernels_equal_the_generic_multi_wave_kernels(monkeypatch, _mw_only):
     """The latent-ODE shape runs kernels with register-stationary weights (rnde_chainmw.h: LAT); RNDE_CHAIN_LAT=0 keeps the generic
     multi-wave kernels on the same network: same arithmetic in the same order -> the same bits, forward and reverse."""
@@ -416,6 +425,7 @@ def test_latent_shape_kernels_equal_the_generic_multi_wave_kernels(monkeypatch, 
 
 
 # ---- an S-stage pair as a table (round 3): RNDE_SOLVER_DOP853 = scipy's DOP853 coefficients as a 13-stage first-same-as-last pair ----
+@_MW
 @pytest.mark.parametrize("kind,B", [("latent", 37), ("chain3", 19), ("small", 70)])
 def test_dop853_attempt_matches_oracle(kind, B, _mw_only):
     """One attempted step of the 13-stage table on the device against the fp64 oracle (which reproduces scipy's rk_step to 1e-14,
@@ -436,6 +446,7 @@ def test_dop853_attempt_matches_oracle(kind, B, _mw_only):
     assert abs(eest_ts - eest_ref) > 0.05 * eest_ref          # (a different method from Tsit5: the table is not ignored)
 
 
+@_MW
 @pytest.mark.parametrize("kind,B,tol,scale", [("latent", 70, 1e-4, 1.5), ("chain3", 33, 1e-4, 2.0), ("small", 20, 1e-5, 3.0), ("latent", 512, 1e-4, 1.5)])
 def test_dop853_solve_and_reverse_match_oracle(kind, B, tol, scale, _mw_only):
     """The adaptive solve (controller exponents of order 8 from the table, NFE = 3 + 12 per attempt) and its reverse pass -- stage loops,
@@ -482,6 +493,7 @@ def test_dop853_is_refused_where_the_table_has_nothing_to_offer():
         Node(_cfg(arch_mnist(), 8, col_tile=16, solver="DOP853"))                                        # stage engine
 
 
+@_MW
 @pytest.mark.parametrize("kind,B,tol,scale,saveat,reg", [("latent", 512, 1.4e-8, 1.0, np.linspace(0, 1, 49), 1), ("chain3", 19, 1e-3, 2.0, None, 1),
                                                           ("test_node", 5, 1e-2, 8.0, np.array([0.5, 1.0]), 1), ("latent", 70, 1e-4, 1.5, None, 3),
                                                           # more than 32 column tiles (round 4): the workgroups spread over the chip and meet through agent-scope entries
@@ -512,6 +524,7 @@ def test_one_launch_solve_is_bit_identical_to_one_launch_per_attempt(kind, B, to
         assert np.array_equal(u, v)
 
 
+@_MW
 @pytest.mark.parametrize("kind,B,tol,scale,saveat,reg", [("latent", 512, 1.4e-8, 1.0, np.linspace(0, 1, 49), 1), ("chain3", 19, 1e-3, 2.0, None, 1),
                                                           ("test_node", 5, 1e-2, 8.0, np.array([0.5, 1.0]), 1), ("latent", 70, 1e-4, 1.5, None, 3),
                                                           ("wide", 40, 1e-5, 1.5, None, 0),

@@ -137,9 +137,10 @@ def test_saveat_dense_output_matches_oracle(kind, B, tol, scale, saveat):
     assert np.abs(got["u"] - ref["u"]).max() <= 3e-5 * max(1.0, np.abs(ref["u"]).max())
 
 
-@pytest.mark.parametrize("kind,B,tol,scale,saveat", [("mnist", 512, 1.4e-8, 1.0, None), ("mnist", 37, 1e-3, 3.0, np.linspace(0, 1, 9)),
-                                                      ("small", 33, 1e-3, 4.0, None), ("test_node", 3, 1e-2, 8.0, np.array([0.5, 1.0]))])
-@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("kind,B,tol,scale,saveat,generic", [("mnist", 512, 1.4e-8, 1.0, None, False), ("mnist", 37, 1e-3, 3.0, np.linspace(0, 1, 9), False),
+                                                              ("small", 33, 1e-3, 4.0, None, False), ("test_node", 3, 1e-2, 8.0, np.array([0.5, 1.0]), False),
+                                                              # (only the MNIST geometry has a specialised kernel to switch off)
+                                                              ("mnist", 512, 1.4e-8, 1.0, None, True), ("mnist", 37, 1e-3, 3.0, np.linspace(0, 1, 9), True)])
 def test_persistent_attempt_is_bit_identical(kind, B, tol, scale, saveat, generic, monkeypatch):
     """rnde_stage_attempt_kernel (one launch per attempt, in-kernel slab hand-off between the row blocks of a column tile)
     performs exactly the arithmetic of the 7 rnde_stage_kernel launches: states, step log, saved values and the tape (checked
@@ -155,8 +156,6 @@ def test_persistent_attempt_is_bit_identical(kind, B, tol, scale, saveat, generi
     # the MNIST geometry (D = 784, H = 100) runs kernels with that geometry fixed at compile time; RNDE_STAGE_GENERIC=1 sends
     # it through the run-time-geometry kernels every other shape uses: both must reproduce the multi-launch kernels bit for bit
     if generic:
-        if kind != "mnist":
-            pytest.skip("only the MNIST geometry has a specialised kernel")
         monkeypatch.setenv("RNDE_STAGE_GENERIC", "1")
     else:
         monkeypatch.delenv("RNDE_STAGE_GENERIC", raising=False)

@@ -303,6 +303,28 @@ function nsde_forward_saveat(h::NsdeHandle, x::ROCMatrix{Float32}, p::ROCVector{
     return u3, Int(nfe1[]), Int(nfe2[]), sv[1:nsv[]]
 end
 
+# save_everystep = true of the SDE layer (neural_sde.jl:14): every accepted step's end (t0 first when save_start), two solves on the same noise inside
+function nsde_forward_everystep(h::NsdeHandle, x::ROCMatrix{Float32}, p::ROCVector{Float32}, tspan; noise = nothing, seed::Integer = 0,
+                                save_start::Bool = true, keep_tape::Bool)
+    D, B = size(x)
+    cap = h.cfg.max_attempts + 1
+    buf = ROCArray{Float32}(undef, D * cap * B)
+    ts = Vector{Float32}(undef, cap)
+    n = Ref{Int32}(0); nfe1 = Ref{Int64}(0); nfe2 = Ref{Int64}(0); nsv = Ref{Int32}(0)
+    sv = Vector{Float32}(undef, h.cfg.max_attempts + 1)
+    npool = noise === nothing ? 0 : size(noise, 4)
+    GC.@preserve x p buf sv noise ts begin
+        st = ccall((:rnde_nsde_forward_everystep, LIB), Cint,
+                   (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Float32, Float32, Ptr{Cvoid}, Int32, UInt64, Int32, Ptr{Cvoid}, Int32, Ptr{Float32},
+                    Ref{Int32}, Ref{Int64}, Ref{Int64}, Ptr{Float32}, Ref{Int32}, Int32, Ptr{Cvoid}),
+                   h.ptr, devptr(x), devptr(p), B, Float32(tspan[1]), Float32(tspan[2]),
+                   noise === nothing ? C_NULL : devptr(noise), npool, UInt64(seed), save_start ? 1 : 0, devptr(buf), cap, ts, n, nfe1, nfe2, sv, nsv,
+                   keep_tape ? 1 : 0, _stream())
+        st == 0 || error("rnde_nsde_forward_everystep status $st: ", unsafe_string(ccall((:rnde_nsde_last_error, LIB), Cstring, (Ptr{Cvoid},), h.ptr)))
+    end
+    return reshape(buf[1:D * Int(n[]) * B], D, Int(n[]), B), ts[1:n[]], Int(nfe1[]), Int(nfe2[]), sv[1:nsv[]]
+end
+
 # u-bar: D x B after nsde_forward, D x T x B after nsde_forward_saveat; x-bar is D x B either way
 function nsde_backward_any(h::NsdeHandle, ubar::ROCArray{Float32}, svbar::Vector{Float32}, np::Int)
     xbar = ROCArray{Float32}(undef, size(ubar, 1), size(ubar, ndims(ubar)))

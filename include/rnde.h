@@ -390,6 +390,14 @@ rnde_status rnde_nsde_forward_saveat(rnde_nsde* h, const float* x_dev, const flo
                                      const float* noise_dev, int32_t n_pool, uint64_t seed, const float* saveat_host,
                                      int32_t n_saveat, float* u_saved_dev, int64_t* nfe1_out, int64_t* nfe2_out,
                                      float* saveval_host, int32_t* n_saveval_out, int32_t keep_tape, void* stream);
+
+/* save_everystep = true of the SDE layer (reference src/models/neural_sde.jl:14): as rnde_node_forward_everystep -- the state after every accepted
+ * step (t0 first when save_start != 0), D x n x B with n <= capacity in *n_out and the times in t_host_out (may be NULL); two solves on the same
+ * noise inside.  rnde_nsde_backward afterwards takes the D x n x B cotangent. */
+rnde_status rnde_nsde_forward_everystep(rnde_nsde* h, const float* x_dev, const float* p_dev, int32_t B, float t0, float t1,
+                                        const float* noise_dev, int32_t n_pool, uint64_t seed, int32_t save_start, float* sol_out_dev,
+                                        int32_t capacity, float* t_host_out, int32_t* n_out, int64_t* nfe1_out, int64_t* nfe2_out,
+                                        float* saveval_host, int32_t* n_saveval_out, int32_t keep_tape, void* stream);
 /* Parity instrument (as rnde_node_forward_replay): the solve along n_steps given (dt, accepted != 0) pairs. */
 rnde_status rnde_nsde_forward_replay(rnde_nsde* h, const float* x_dev, const float* p_dev, int32_t B, float t0, float t1,
                                      const float* noise_dev, int32_t n_pool, const float* steps_host, int32_t n_steps,

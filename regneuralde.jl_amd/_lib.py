@@ -134,6 +134,7 @@ def lib():
     L.rnde_nsde_last_error.argtypes = [vp]
     L.rnde_nsde_forward.argtypes = [vp, vp, vp, i32, f, f, vp, i32, u64, vp, i64p, i64p, fp, i32p, i32, vp]
     L.rnde_nsde_forward_saveat.argtypes = [vp, vp, vp, i32, f, f, vp, i32, u64, fp, i32, vp, i64p, i64p, fp, i32p, i32, vp]
+    L.rnde_nsde_forward_everystep.argtypes = [vp, vp, vp, i32, f, f, vp, i32, u64, i32, vp, i32, fp, i32p, i64p, i64p, fp, i32p, i32, vp]
     L.rnde_nsde_forward_replay.argtypes = [vp, vp, vp, i32, f, f, vp, i32, fp, i32, vp, i64p, i64p, fp, i32p, i32, vp]
     L.rnde_nsde_backward.argtypes = [vp, vp, fp, vp, vp, vp]
     L.rnde_nsde_backward_async.argtypes = [vp, vp, fp, vp, vp, vp]
@@ -165,7 +166,7 @@ EXPORTS = ["rnde_version", "rnde_last_error", "rnde_param_count", "rnde_node_cre
            "rnde_node_launches_per_attempt", "rnde_node_one_launch_solves", "rnde_classifier_head", "rnde_node_classifier_grad", "rnde_momentum_step", "rnde_momentum_step_scaled", "rnde_adam_step",
            "rnde_comm_unique_id", "rnde_comm_create", "rnde_comm_destroy", "rnde_comm_world", "rnde_comm_last_error", "rnde_comm_library", "rnde_comm_allreduce", "rnde_comm_create_local_group", "rnde_comm_health", "rnde_comm_window_create", "rnde_comm_window_destroy", "rnde_comm_create_peers", "rnde_comm_path", "rnde_node_set_coupling", "rnde_tapes_create", "rnde_tapes_destroy", "rnde_tapes_last_error", "rnde_tapes_in_use", "rnde_tapes_node", "rnde_tapes_forward", "rnde_tapes_backward", "rnde_tapes_release",
            "rnde_nsde_param_count", "rnde_nsde_create", "rnde_nsde_destroy", "rnde_nsde_last_error", "rnde_nsde_forward",
-           "rnde_nsde_forward_saveat", "rnde_nsde_forward_replay", "rnde_nsde_backward", "rnde_nsde_backward_async", "rnde_nsde_classifier_head", "rnde_nsde_classifier_grad", "rnde_nsde_steps", "rnde_nsde_debug_attempt", "rnde_nsde_timing", "rnde_normal_fill", "rnde_latent_create", "rnde_latent_destroy", "rnde_latent_last_error", "rnde_latent_param_counts", "rnde_latent_encode",
+           "rnde_nsde_forward_saveat", "rnde_nsde_forward_everystep", "rnde_nsde_forward_replay", "rnde_nsde_backward", "rnde_nsde_backward_async", "rnde_nsde_classifier_head", "rnde_nsde_classifier_grad", "rnde_nsde_steps", "rnde_nsde_debug_attempt", "rnde_nsde_timing", "rnde_normal_fill", "rnde_latent_create", "rnde_latent_destroy", "rnde_latent_last_error", "rnde_latent_param_counts", "rnde_latent_encode",
            "rnde_latent_decode_loss", "rnde_latent_encode_backward", "rnde_adamax_step"]
 
 

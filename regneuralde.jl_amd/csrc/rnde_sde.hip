@@ -435,6 +435,26 @@ extern "C" rnde_status rnde_nsde_forward_saveat(rnde_nsde* h, const float* x_dev
     return nsde_forward_impl(h, x_dev, p_dev, B, t0, t1, noise_dev, n_pool, seed, nullptr, 0, nullptr, nfe1_out, nfe2_out, saveval_host, n_saveval_out, keep_tape,
                              stream, saveat_host, n_saveat, u_saved_dev);
 }
+// save_everystep = true of the SDE layer (reference src/models/neural_sde.jl:14): the state after every accepted step (t0 first when save_start).
+// As rnde_node_forward_everystep: the solve runs twice on the SAME noise (the explicit pool, or the library's generator with the same seed: the draws
+// are keyed by their index), the second time saving at the first's accepted step ends -- the value saved at a step's end is u_new itself.
+extern "C" rnde_status rnde_nsde_forward_everystep(rnde_nsde* h, const float* x_dev, const float* p_dev, int32_t B, float t0, float t1, const float* noise_dev,
+                                                   int32_t n_pool, uint64_t seed, int32_t save_start, float* sol_out_dev, int32_t capacity, float* t_host_out,
+                                                   int32_t* n_out, int64_t* nfe1_out, int64_t* nfe2_out, float* saveval_host, int32_t* n_saveval_out,
+                                                   int32_t keep_tape, void* stream) {
+    if (!h || !n_out || !sol_out_dev || capacity < 1) return RNDE_ERR_BAD_ARG;
+    rnde_status st = nsde_forward_impl(h, x_dev, p_dev, B, t0, t1, noise_dev, n_pool, seed, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream);
+    if (st != RNDE_OK) return st;
+    std::vector<float> times;
+    if (save_start) times.push_back(t0);
+    for (int i = 0; i < h->n_att; ++i)
+        if (h->h_meta[i].accepted) { float tn = h->h_meta[i].t + h->h_meta[i].dt; if (tn > t1) tn = t1; times.push_back(tn); }
+    *n_out = (int32_t)times.size();
+    if ((int)times.size() > capacity) { h->err = "rnde_nsde_forward_everystep: more accepted steps than the output has room for"; return RNDE_ERR_BAD_ARG; }
+    if (t_host_out) memcpy(t_host_out, times.data(), times.size() * sizeof(float));
+    return nsde_forward_impl(h, x_dev, p_dev, B, t0, t1, noise_dev, n_pool, seed, nullptr, 0, nullptr, nfe1_out, nfe2_out, saveval_host, n_saveval_out, keep_tape,
+                             stream, times.data(), (int32_t)times.size(), sol_out_dev);
+}
 extern "C" rnde_status rnde_nsde_forward_replay(rnde_nsde* h, const float* x_dev, const float* p_dev, int32_t B, float t0, float t1, const float* noise_dev,
                                                 int32_t n_pool, const float* steps_host, int32_t n_steps, float* u_out_dev, int64_t* nfe1_out,
                                                 int64_t* nfe2_out, float* saveval_host, int32_t* n_saveval_out, int32_t keep_tape, void* stream) {

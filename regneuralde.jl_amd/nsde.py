@@ -10,7 +10,7 @@ With `saveat=` the {R,true} methods run (neural_sde.jl:44-61,:84-113; experiment
 (B, T, D) tensor whose memory is exactly the Julia D x T x B array of diffeqsol_to_3dtrackedarray (src/utils.jl:17-19).
 
 Differences inherent to the host language / the device: `func` is the reference's EEst*dt callback (neural_sde.jl:87) or none;
-`save_everystep=True` (a result whose length is data dependent) is refused;
+`save_everystep=True` (a result whose length is data dependent): `rnde_nsde_forward_everystep`, the state after every accepted step;
 the noise comes from the library's Philox stream (seed = nsde.seed, advanced every call) unless `noise=` passes a pool of
 standard normals of shape (n_pool, 2, B, D) -- a Julia caller would fill that from its own RNG.
 """
@@ -55,6 +55,17 @@ class _SdeSolve(torch.autograd.Function):
             u = torch.empty_like(x)
             st = L.rnde_nsde_forward(h.ptr, x.data_ptr(), p.data_ptr(), B, layer.tspan[0], layer.tspan[1], nptr, npool, seed,
                                      u.data_ptr(), C.byref(n1), C.byref(n2), sv_host, C.byref(nsv), 1 if keep_tape else 0, stream)
+        elif saveat == "everystep":      # save_everystep = true (neural_sde.jl:14): the state after every accepted step, count known after the call
+            cap = layer.max_attempts + 1
+            buf = torch.empty((B, cap, D), dtype=torch.float32, device=x.device)      # (filled as (B, n, D) from its start, see node.py)
+            th, nout = (C.c_float * cap)(), C.c_int32(0)
+            st = L.rnde_nsde_forward_everystep(h.ptr, x.data_ptr(), p.data_ptr(), B, layer.tspan[0], layer.tspan[1], nptr, npool, seed,
+                                               1 if layer.kwargs.get("save_start", True) else 0, buf.data_ptr(), cap, th, C.byref(nout),
+                                               C.byref(n1), C.byref(n2), sv_host, C.byref(nsv), 1 if keep_tape else 0, stream)
+            _lib.check_nsde(h.ptr, st)
+            n = nout.value
+            u = buf.reshape(-1)[: B * n * D].reshape(B, n, D).clone()
+            layer.last_times = [float(th[i]) for i in range(n)]
         else:
             T = len(saveat)
             u = torch.empty((B, T, D), dtype=torch.float32, device=x.device)
@@ -95,10 +106,9 @@ class TrackedNeuralDSDE:
             raise ValueError("solver: SOSRI (experiments/mnist_nsde.jl:49,:63), SOSRI2 or SRIW1")
         if isinstance(model2, Dense):
             model2 = Chain(model2)
-        if kwargs.get("save_everystep", False):
-            raise NotImplementedError("save_everystep=True: the result length is data dependent; pass saveat= instead "
-                                      "(experiments/sde_toy_problem.jl:57 does)")
-        self.return_multiple = "saveat" in kwargs          # neural_sde.jl:14
+        self.save_everystep = bool(kwargs.get("save_everystep", False)) and "saveat" not in kwargs      # (saveat given: it decides what is saved)
+        self.return_multiple = bool(kwargs.get("save_everystep", False)) or "saveat" in kwargs          # neural_sde.jl:14
+        self.last_times = None
         if model1.time_dep or model2.time_dep:
             raise ValueError("drift and diffusion are time independent (neural_sde.jl:45-52 call re(p)(u))")
         self.model1, self.model2 = model1, model2
@@ -167,7 +177,9 @@ class TrackedNeuralDSDE:
         keep = torch.is_grad_enabled() and (x.requires_grad or p.requires_grad)
         self.seed += 1
         times = None
-        if self.return_multiple:
+        if self.return_multiple and self.save_everystep:
+            times = "everystep"
+        elif self.return_multiple:
             from .node import TrackedNeuralODE
             times = TrackedNeuralODE._saveat_times(self.kwargs["saveat"], self.tspan)
         u, saveval = _SdeSolve.apply(x.contiguous(), p.contiguous(), self, keep, noise, self.seed, times)

@@ -473,6 +473,41 @@ def test_layer_saveat_method():
     assert torch.isfinite(p.grad).all() and p.grad.abs().max() > 0
 
 
+def test_layer_save_everystep_method():
+    """TrackedNeuralDSDE built with save_everystep = true (neural_sde.jl:14): rnde_nsde_forward_everystep returns the state after every accepted
+    step (t0 first); on an explicit noise pool the result and its gradients are those of the saveat call at the same times, bit for bit, and the
+    last state is the plain solve's end state."""
+    import torch
+    import regneuralde_jl_amd as rn
+    g = torch.Generator().manual_seed(11)
+    nets = lambda: (rn.Chain(rn.Dense(6, 12, "tanh", torch.Generator().manual_seed(11)), rn.Dense(12, 6, "identity", torch.Generator().manual_seed(12))),
+                    rn.Dense(6, 6, "identity", torch.Generator().manual_seed(13)))
+    B = 20
+    kw = dict(reltol=0.05, abstol=0.05, max_batch=B, max_attempts=200)
+    every = rn.TrackedNeuralDSDE(*nets(), [0.0, 1.0], True, "SOSRI", save_everystep=True, **kw)
+    plain = rn.TrackedNeuralDSDE(*nets(), [0.0, 1.0], True, "SOSRI", **kw)
+    x = torch.randn(B, 6, generator=g).cuda().requires_grad_(True)
+    p = every.p.cuda().clone().requires_grad_(True)
+    noise = torch.randn(300, 2, B, 6, generator=g).cuda()
+    sol, nfe1, nfe2, sv = every(x, p, func="error_est", noise=noise)
+    ts = every.last_times
+    n = len(ts)
+    assert sol.shape == (B, n, 6) and n >= 4 and ts[0] == 0.0 and ts[-1] == 1.0 and all(b > a for a, b in zip(ts, ts[1:]))
+    assert torch.equal(sol[:, 0], x.detach()) and nfe1 == nfe2
+    with torch.no_grad():
+        ue, m1, _, _ = plain(x, p, func="error_est", noise=noise)
+    assert m1 == nfe1 and torch.equal(sol[:, -1].detach(), ue)
+    w = torch.randn(B, n, 6, generator=g).cuda()
+    ((sol * w).sum() + 3.0 * sv.saveval.sum()).backward()
+    gx, gp = x.grad.clone(), p.grad.clone()
+    x.grad = None; p.grad = None
+    at = rn.TrackedNeuralDSDE(*nets(), [0.0, 1.0], True, "SOSRI", saveat=ts, **kw)
+    sol2, k1, _, sv2 = at(x, p, func="error_est", noise=noise)
+    assert k1 == nfe1 and torch.equal(sol2.detach(), sol.detach())
+    ((sol2 * w).sum() + 3.0 * sv2.saveval.sum()).backward()
+    assert torch.equal(x.grad, gx) and torch.equal(p.grad, gp)
+
+
 def test_more_than_8192_columns_take_the_one_wave_solve_kernel():
     """The four-waves-per-tile solve kernel needs a workgroup per tile resident (<= 512 tiles, two per CU); a call with 8300 columns switches to
     the one-wave-per-tile kernel (same handle, same tape layout, the reverse sweep stays on the four-wave kernel): the call contract and

@@ -156,9 +156,11 @@ def attempt_roofline_at(B, device, steps=3, warmup=2):
     return out
 
 
-def global_batch_anchor(G, device, steps, warmup=2):
-    """The FULL training step (loss forward, reverse pass, InvDecay / Momentum update; the weights train) at a batch of G on ONE GPU: the N = 1
-    point of the strong-scaling curve `python bench.py --gpus N --global-batch G` measures (BASELINE.json: batch 4096 sharded 8 x MI355X)."""
+def global_batch_anchor(G, device, steps, warmup):
+    """The FULL training step (loss forward, reverse pass, InvDecay / Momentum update) at a batch of G on ONE GPU: the N = 1 point of the
+    strong-scaling curve `python bench.py --gpus N --global-batch G` measures (BASELINE.json: batch 4096 sharded 8 x MI355X).  Run with the SAME
+    --steps / --warmup as the N-rank line and in the same two legs (weights restored after every update first, then training), so that both ends of
+    the ratio have seen the same number of updates: NFE drifts while the weights train, and a ratio across different NFE measures the drift."""
     import torch
     import regneuralde_jl_amd as rn
     model = build_model(rn, device, G)
@@ -167,24 +169,37 @@ def global_batch_anchor(G, device, steps, warmup=2):
     x = torch.rand(G, 1, 28, 28, generator=g).to(device)
     y = torch.eye(NCLS)[torch.randint(0, NCLS, (G,), generator=g)].to(device)
     nfes = []
+    saved = [p.detach().clone() for p in model.trainable()]
 
-    def step():
+    def step(restore):
         loss, ce, reg, nfe = rn.fused_loss_and_grad(model, x, y, lam=1.0e2, sync=False)
         opt.step()
+        if restore:
+            with torch.no_grad():
+                for p, s0 in zip(model.trainable(), saved):
+                    p.copy_(s0)
         nfes.append(nfe)
 
-    for _ in range(warmup):
-        step()
-    nfes.clear()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    out = {"value": G * steps / el, "unit": "samples/s", "ms_per_step": 1e3 * el / steps, "mean_nfe": sum(nfes) / len(nfes), "steps": steps, "warmup": warmup,
-           "global_batch": G, "n_gpus": 1, "what": f"full training step (with optimiser update) at batch {G} on one GPU: divide the value of "
-                                                    f"`bench.py --gpus N --global-batch {G}` by this one for the strong-scaling factor"}
+    def leg(restore):
+        for _ in range(warmup):
+            step(restore)
+        nfes.clear()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(restore)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        return {"value": G * steps / el, "ms_per_step": 1e3 * el / steps, "mean_nfe": sum(nfes) / len(nfes)}
+
+    fixed = leg(True)
+    opt = rn.FluxOptimiser(model.trainable())
+    train = leg(False)
+    out = {"value": train["value"], "unit": "samples/s", "ms_per_step": train["ms_per_step"], "mean_nfe": train["mean_nfe"],
+           "value_fixed_weights": fixed["value"], "fixed_weights": fixed, "steps": steps, "warmup": warmup,
+           "global_batch": G, "n_gpus": 1, "what": f"full training step (with optimiser update) at batch {G} on one GPU, same --steps / --warmup and the same two legs as "
+                                                    f"the headline: divide `value` (or `value_fixed_weights`: equal NFE by construction) of `bench.py --gpus N "
+                                                    f"--global-batch {G} --steps {steps} --warmup {warmup}` by the same field here for the strong-scaling factor"}
     del model, opt
     torch.cuda.empty_cache()
     return out
@@ -598,22 +613,50 @@ def main():
                             device=ddev, dtype=torch.float64)
         allv = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allv, mine)
-        ar_us = None
-        if reducer is not None and reducer.comm is not None:
+        def time_allreduce(red, reps=20):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             for _ in range(3):
-                reducer.allreduce_range_(0, fg.flat.numel())
+                red.allreduce_range_(0, fg.flat.numel())
             dist.barrier(); torch.cuda.synchronize()
             e0.record()
-            for _ in range(20):
-                reducer.allreduce_range_(0, fg.flat.numel())
+            for _ in range(reps):
+                red.allreduce_range_(0, fg.flat.numel())
             e1.record(); torch.cuda.synchronize()
-            ar_us = 1e3 * e0.elapsed_time(e1) / 20
             fg.flat.zero_()
+            return 1e3 * e0.elapsed_time(e1) / reps
+
+        ar_us, ar_both = None, None
+        if reducer is not None and reducer.comm is not None:
+            ar_us = time_allreduce(reducer)
+            ar_both = {L.rnde_comm_path(reducer.comm).decode(): ar_us}
+            # the OTHER collective path in the same run, so that one multi-GPU lease decides the default: the one-shot kernel over peer-mapped
+            # windows (hipIpc) next to RCCL.  Every rank must agree that its communicator exists before any of them times it.
+            if reducer.collective == "rccl" and not os.environ.get("RNDE_ONESHOT") and os.environ.get("RNDE_BENCH_BOTH_COLLECTIVES", "1") != "0":
+                alt, why = None, None
+                try:
+                    alt = rn.GradientAllReducer(model.trainable(), flat=fg, collective="peers")
+                except Exception as e:
+                    why = repr(e)
+                ok = torch.tensor([1 if (alt is not None and alt.comm is not None) else 0], dtype=torch.int32, device=ddev)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 1:
+                    try:      # same sum on every rank, bit for bit, as the rank-order sum the kernel promises (a cheap end-to-end check of the path)
+                        fg.flat.copy_(torch.arange(fg.flat.numel(), device=fg.flat.device, dtype=torch.float32).remainder_(97.0).add_(float(rank)))
+                        alt.allreduce_range_(0, fg.flat.numel())
+                        want = torch.arange(fg.flat.numel(), device=fg.flat.device, dtype=torch.float32).remainder_(97.0).mul_(world).add_(world * (world - 1) / 2.0)
+                        exact = bool(torch.equal(fg.flat, want))
+                        fg.flat.zero_()
+                        ar_both[L.rnde_comm_path(alt.comm).decode()] = time_allreduce(alt)
+                        ar_both["one_shot_sum_exact"] = exact
+                    except Exception as e:
+                        ar_both["one_shot_error"] = repr(e)
+                else:
+                    ar_both["one_shot_error"] = why or "another rank could not map the peer windows"
+                del alt
         nf = [float(v[0]) for v in allv]
         dist_diag = {"nfe_per_rank": nf, "nfe_min": min(nf), "nfe_mean": sum(nf) / len(nf), "nfe_max": max(nf),
                      "persist_fallback_count_per_rank": [int(v[1]) for v in allv], "launches_per_attempt_per_rank": [int(v[2]) for v in allv],
-                     "allreduce_us": ar_us, "allreduce_floats": int(fg.flat.numel()) if fg is not None else None,
+                     "allreduce_us": ar_us, "allreduce_us_by_path": ar_both, "allreduce_floats": int(fg.flat.numel()) if fg is not None else None,
                      "collective_library": L.rnde_comm_library().decode() if reducer is not None and reducer.comm is not None and reducer.collective == "rccl" else None,
                      # (RNDE_ONESHOT=1 in the environment: the one-shot kernel over peer-mapped windows instead of ncclAllReduce)
                      "collective_path": L.rnde_comm_path(reducer.comm).decode() if reducer is not None and reducer.comm is not None else None,
@@ -727,7 +770,7 @@ def main():
                 out["roofline_B4096"] = {"error": repr(e)}
         if world == 1 and not args.no_extras and not use_dist and B == 512:
             try:      # the N = 1 anchor of the strong-scaling curve (north star: batch 4096 over 1 / 2 / 4 / 8 GPUs): the FULL training step at B = 4096
-                others_anchor = global_batch_anchor(4096, device, max(3, args.steps // 4))
+                others_anchor = global_batch_anchor(4096, device, args.steps, args.warmup)
             except Exception as e:
                 others_anchor = {"error": repr(e)}
         else:

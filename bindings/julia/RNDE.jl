@@ -78,6 +78,57 @@ end
 check(h::Handle, st) = st == 0 ||
     error("rnde status $st: ", unsafe_string(ccall((:rnde_last_error, LIB), Cstring, (Ptr{Cvoid},), h.ptr)))
 
+# ---- which of the library's callbacks a caller's `func` is ------------------------------------------------
+# The reference hands the layer a closure, `model(x, p1, p2, p3; func = save_func, ...)` (experiments/mnist_node.jl:134, mnist_nsde.jl), and the
+# SavingCallback calls it on the integrator after every accepted step (src/models/neural_ode.jl:126-127).  The library computes the value inside
+# its kernels instead, so the closure has to be RECOGNISED, not called per step: it is evaluated on two mock integrators and the two values are
+# matched against the reference's own callbacks (mnist_node.jl:67 EEst*dt; :74-79 |eigen_est|/stability_size; :88-97 their blend with 0.1;
+# neural_ode.jl:54 the constant 0).  Anything else is refused -- a wrong regulariser must not be trained on silently.
+struct MockIntegrator
+    EEst::Float32
+    dt::Float32
+    eigen_est::Float32
+end
+const REG_NONE, REG_ERR, REG_STIFF, REG_ERR_STIFF = 0, 1, 2, 3
+const _PROBES = (MockIntegrator(2f0, 3f0, 5f0), MockIntegrator(0.5f0, 0.25f0, -7f0))
+
+"""
+    reg_code(func, stability_size) -> REG_NONE | REG_ERR | REG_STIFF | REG_ERR_STIFF
+
+`stability_size`: `alg_stability_size` of the solver the experiment divides by (Tsit5: 3.5068, SOSRI2: 10.6).
+"""
+function reg_code(func, stability_size::Real)
+    s = Float64(stability_size)
+    got = map(m -> Float64(data(func(nothing, 0f0, m))), _PROBES)
+    want = Dict(REG_NONE => m -> 0.0,
+                REG_ERR => m -> Float64(m.EEst) * m.dt,
+                REG_STIFF => m -> abs(Float64(m.eigen_est)) / s,
+                REG_ERR_STIFF => m -> Float64(m.EEst) * m.dt + 0.1 * Float64(m.eigen_est) / s)
+    for code in (REG_NONE, REG_ERR, REG_STIFF, REG_ERR_STIFF)
+        all(isapprox(g, want[code](m); rtol = 1e-4, atol = 1e-7) for (g, m) in zip(got, _PROBES)) && return code
+    end
+    error("RNDE: `func` is none of the callbacks librnde.so computes (EEst*dt, |eigen_est|/stability_size, EEst*dt + 0.1*eigen_est/stability_size, 0): ",
+          "on (EEst, dt, eigen_est) = (2, 3, 5) and (0.5, 0.25, -7) it returned ", got)
+end
+
+# the solver object the layer was built with (`n.args[1]`): its name, and whether it is the composite whose steps fill `integrator.eigen_est`
+# (AutoTsit5(Tsit5()) / AutoSOSRI2(SOSRI2()): experiments/mnist_node.jl:81,:99, mnist_nsde.jl:60).  Plain algorithms leave eigen_est at 0.
+function solver_name(args)
+    isempty(args) && return :Tsit5, false
+    alg = args[1]
+    hasproperty(alg, :algs) && return nameof(typeof(alg.algs[1])), true
+    return nameof(typeof(alg)), false
+end
+
+# what the reference's run would record with this (func, solver) pair: a stiffness term under a non-composite solver is identically zero
+function effective_reg(code::Int, composite::Bool)
+    composite && return code
+    code == REG_ERR_STIFF && return REG_ERR
+    code == REG_STIFF && error("RNDE: `func` reads integrator.eigen_est, which only the composite solvers (AutoTsit5 / AutoSOSRI2) fill; ",
+                               "with a plain solver the reference records zeros -- build the layer with the composite solver")
+    return code
+end
+
 # Flux.Dense chain (MLPDynamics / TDChain) -> config.  `p` from Flux.destructure is accepted as is.
 function config_for(dims::Vector{Int}, acts::Vector{Int}; time_dep, max_batch, reltol, abstol, regularize,
                     max_attempts = 160, device = 0, pre_act = false)

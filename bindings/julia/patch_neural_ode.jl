@@ -6,14 +6,18 @@
 #     include("/path/to/repo/bindings/julia/patch_neural_ode.jl")      # redefines the methods below; everything else is untouched
 #
 # Signatures, keyword defaults, `_convert_tspan` (src/utils.jl:21-23), the returned triple `(res, nfe, sv)` and the `SavedValues` container are
-# the reference's.  `func` selects the callback as the reference's experiments do (mnist_node.jl:62-103): the library records EEst * dt,
-# the stiffness estimate or their blend according to the handle's `regularize` code; the closure itself is not called.
+# the reference's.  `func` is the caller's closure, exactly as the unchanged experiment passes it (`model(x, p1, p2, p3; func = save_func, ...)`,
+# mnist_node.jl:134): RNDE.reg_code evaluates it on two mock integrators and recognises which of the reference's callbacks it is
+# (mnist_node.jl:67 / :74-79 / :88-97), the handle is created with that `regularize` code and the library records EEst * dt, the stiffness
+# estimate or their blend inside its kernels.  An unrecognised closure is an error, never a silently different loss.
 #
-# The layer struct has no field for the handle (and is immutable), so handles live in a table keyed by the layer object and the batch width.
+# The layer struct has no field for the handle (and is immutable), so handles live in a table keyed by the layer object, the batch width and
+# the callback code.
 using Tracker, Flux, DiffEqCallbacks
 using RegNeuralDE: TrackedNeuralODE, TDChain, _convert_tspan
 
-const RNDE_ODE_HANDLES = IdDict{Any,Dict{Int,RNDE.Handle}}()
+const RNDE_ODE_HANDLES = IdDict{Any,Dict{Tuple{Int,Int},RNDE.Handle}}()
+const TSIT5_STABILITY_SIZE = 3.5068      # OrdinaryDiffEq.alg_stability_size(Tsit5()), the constant mnist_node.jl:73,:86 divides by
 
 # Dense sizes / activations of the dynamics (TDChain or Chain of Dense layers; a leading `x -> tanh.(x)` is latent_ode.jl:114's pre-activation)
 function _dense_layout(model)
@@ -29,15 +33,20 @@ function _dense_layout(model)
     return dims, acts, td, pre
 end
 
-# regularize code of include/rnde.h from the type parameter R and the experiment's `func` choice (configs/mnist_node.yml `type`)
-_reg_code(R::Bool, kind::Symbol) = !R ? 0 : (kind === :error_est ? 1 : kind === :stiff_est ? 2 : 3)
+# regularize code of include/rnde.h from the type parameter R, the caller's `func` and the solver the layer holds (n.args)
+function _reg_code(n::TrackedNeuralODE{R}, func) where {R}
+    name, composite = RNDE.solver_name(n.args)
+    name === :Tsit5 || error("RNDE: the ODE layer runs Tsit5() / AutoTsit5(Tsit5()) (every reference call site); got ", name)
+    R || return RNDE.REG_NONE
+    return RNDE.effective_reg(RNDE.reg_code(func, TSIT5_STABILITY_SIZE), composite)
+end
 
-function rnde_handle(n::TrackedNeuralODE{R}, B::Int; kind::Symbol = :error_est) where {R}
-    tab = get!(() -> Dict{Int,RNDE.Handle}(), RNDE_ODE_HANDLES, n)
-    get!(tab, B) do
+function rnde_handle(n::TrackedNeuralODE, B::Int, code::Int)
+    tab = get!(() -> Dict{Tuple{Int,Int},RNDE.Handle}(), RNDE_ODE_HANDLES, n)
+    get!(tab, (B, code)) do
         dims, acts, td, pre = _dense_layout(n.model)
         RNDE.Handle(RNDE.config_for(dims, acts; time_dep = td, pre_act = pre, max_batch = B, reltol = Float32(get(n.kwargs, :reltol, 1f-3)),
-                                    abstol = Float32(get(n.kwargs, :abstol, 1f-6)), regularize = _reg_code(R, kind)))
+                                    abstol = Float32(get(n.kwargs, :abstol, 1f-6)), regularize = code))
     end
 end
 
@@ -56,7 +65,7 @@ _saved(tspan, p, saveval) = (sv = SavedValues(eltype(tspan), eltype(p)); append!
 # {false,false} (reference :48-77): vanilla solve, end state only
 function (n::TrackedNeuralODE{false,false})(x, p = n.p; func = (u, t, int) -> 0, tspan = nothing, saveat = nothing)
     tspan = _convert_tspan(isnothing(tspan) ? n.tspan : tspan, p)
-    h = rnde_handle(n, size(x, 2))
+    h = rnde_handle(n, size(x, 2), _reg_code(n, func))
     res, _ = RNDE.rnde_solve(h, x, p, tspan)                                   # <- replaces :61-70
     return res, h.last_nfe, nothing
 end
@@ -64,25 +73,25 @@ end
 # {false,true} (reference :79-108): all saved states, D x T x B
 function (n::TrackedNeuralODE{false,true})(x, p = n.p; func = (u, t, int) -> 0, tspan = nothing, saveat = nothing)
     tspan = _convert_tspan(isnothing(tspan) ? n.tspan : tspan, p)
-    h = rnde_handle(n, size(x, 2))
+    h = rnde_handle(n, size(x, 2), _reg_code(n, func))
     res, _ = RNDE.rnde_solve_saveat(h, x, p, tspan, _multi_times(n, h, x, p, tspan, saveat))     # <- replaces :92-102 (update_saveat! is not needed: nothing is mutated)
     return res, h.last_nfe, nothing
 end
 
 # {true,false} (reference :110-144): end state + the saving callback's values (configs 2 / 3)
 function (n::TrackedNeuralODE{true,false})(x, p = n.p; func = (u, t, integrator) -> integrator.EEst * integrator.dt, tspan = nothing,
-                                           saveat = nothing, kind::Symbol = :error_est)
+                                           saveat = nothing)
     tspan = _convert_tspan(isnothing(tspan) ? n.tspan : tspan, p)
-    h = rnde_handle(n, size(x, 2); kind = kind)
+    h = rnde_handle(n, size(x, 2), _reg_code(n, func))
     res, saveval = RNDE.rnde_solve(h, x, p, tspan)                             # <- replaces :126-138
     return res, h.last_nfe, _saved(tspan, p, saveval)
 end
 
 # {true,true} (reference :146-180): saved states + callback values (config 4, latent_ode.jl:137-147)
 function (n::TrackedNeuralODE{true,true})(x, p = n.p; func = (u, t, integrator) -> integrator.EEst * integrator.dt, tspan = nothing,
-                                          saveat = nothing, kind::Symbol = :error_est)
+                                          saveat = nothing)
     tspan = _convert_tspan(isnothing(tspan) ? n.tspan : tspan, p)
-    h = rnde_handle(n, size(x, 2); kind = kind)
+    h = rnde_handle(n, size(x, 2), _reg_code(n, func))
     res, saveval = RNDE.rnde_solve_saveat(h, x, p, tspan, _multi_times(n, h, x, p, tspan, saveat))   # <- replaces :162-174
     return res, h.last_nfe, _saved(tspan, p, saveval)
 end

@@ -6,7 +6,9 @@
 using Tracker, Flux, DiffEqCallbacks
 using RegNeuralDE: TrackedNeuralDSDE, _convert_tspan
 
-const RNDE_SDE_HANDLES = IdDict{Any,Dict{Int,RNDE.NsdeHandle}}()
+const RNDE_SDE_HANDLES = IdDict{Any,Dict{Tuple{Int,Int},RNDE.NsdeHandle}}()
+const SOSRI2_STABILITY_SIZE = 10.6       # StochasticDiffEq.alg_stability_size(SOSRI2()), the constant mnist_nsde.jl:55 divides by
+const _SDE_SOLVERS = Dict(:SOSRI => 0, :SRIW1 => 1, :SOSRI2 => 2)      # rnde_sde_solver (include/rnde.h)
 const RNDE_SDE_CALLS = Ref(0)      # one Philox stream per call: seed = a counter (pass `seed = ...` for a reproducible run)
 
 function _chain_layout(model)
@@ -18,12 +20,26 @@ function _chain_layout(model)
     return dims, acts
 end
 
-function rnde_handle(n::TrackedNeuralDSDE{R}, B::Int) where {R}
-    tab = get!(() -> Dict{Int,RNDE.NsdeHandle}(), RNDE_SDE_HANDLES, n)
-    get!(tab, B) do
+# solver + regularize codes of include/rnde.h from the solver object the layer holds (n.args: SOSRI() / AutoSOSRI2(SOSRI2()), mnist_nsde.jl:49,:60),
+# the type parameter R and the caller's `func` (`model(x, p1, p2, p3, p4; func = save_func)`): recognised by RNDE.reg_code, never called per step
+function _sde_codes(n::TrackedNeuralDSDE{R}, func) where {R}
+    name, composite = RNDE.solver_name(n.args)
+    isempty(n.args) && (name = :SOSRI)
+    haskey(_SDE_SOLVERS, name) || error("RNDE: the SDE layer runs SOSRI() / SOSRI2() / AutoSOSRI2(SOSRI2()) / SRIW1(); got ", name)
+    reg = R ? RNDE.effective_reg(RNDE.reg_code(func, SOSRI2_STABILITY_SIZE), composite) : RNDE.REG_NONE
+    reg in (RNDE.REG_NONE, RNDE.REG_ERR) || name === :SOSRI2 ||
+        error("RNDE: the stiffness estimate of an SRI step is defined for SOSRI2 only (its last two drift stages share one time); got ", name)
+    reg == RNDE.REG_ERR_STIFF && error("RNDE: the SDE layer records EEst*dt or the stiffness estimate (mnist_nsde.jl:45-61), not their blend")
+    return _SDE_SOLVERS[name], reg
+end
+
+function rnde_handle(n::TrackedNeuralDSDE, B::Int, func)
+    solver, reg = _sde_codes(n, func)
+    tab = get!(() -> Dict{Tuple{Int,Int},RNDE.NsdeHandle}(), RNDE_SDE_HANDLES, n)
+    get!(tab, (B, reg)) do
         d1, a1 = _chain_layout(n.model1); d2, a2 = _chain_layout(n.model2)
         RNDE.NsdeHandle(RNDE.nsde_config_for(d1, a1, d2, a2; max_batch = B, reltol = Float32(get(n.kwargs, :reltol, 1f-2)),
-                                             abstol = Float32(get(n.kwargs, :abstol, 1f-2)), regularize = R ? 1 : 0))
+                                             abstol = Float32(get(n.kwargs, :abstol, 1f-2)), regularize = reg, solver = solver))
     end
 end
 
@@ -34,7 +50,7 @@ _next_seed(seed) = isnothing(seed) ? (RNDE_SDE_CALLS[] += 1) : seed
 # {false,false} (reference :63-82)
 function (n::TrackedNeuralDSDE{false,false})(x, p = n.p; func = (u, t, int) -> 0, seed = nothing)
     tspan = _convert_tspan(n.tspan, p)
-    h = rnde_handle(n, size(x, 2))
+    h = rnde_handle(n, size(x, 2), func)
     arr, _ = RNDE.rnde_nsde_solve(h, x, p, tspan, _next_seed(seed))                            # <- replaces :74-76
     c = RNDE.counters(h)
     return arr, c.nfe1, c.nfe2, nothing
@@ -43,16 +59,17 @@ end
 # {false,true} (reference :44-61): all saved states, D x T x B
 function (n::TrackedNeuralDSDE{false,true})(x, p = n.p; func = (u, t, int) -> 0, seed = nothing)
     tspan = _convert_tspan(n.tspan, p)
-    h = rnde_handle(n, size(x, 2))
+    h = rnde_handle(n, size(x, 2), func)
     arr, _ = RNDE.rnde_nsde_solve_saveat(h, x, p, tspan, _sde_saveat(n), _next_seed(seed))      # <- replaces :54-56
     c = RNDE.counters(h)
     return arr, c.nfe1, c.nfe2, nothing
 end
 
-# {true,false} (reference :116-146): end state + EEst * dt per accepted step (config 5, experiments/mnist_nsde.jl)
+# {true,false} (reference :116-146): end state + the saving callback's value per accepted step -- EEst * dt or |eigen_est| / 10.6, whichever
+# `func` is (config 5, experiments/mnist_nsde.jl:45-61; the shipped configs/mnist_nsde.yml selects the stiffness estimate)
 function (n::TrackedNeuralDSDE{true,false})(x, p = n.p; func = (u, t, integrator) -> integrator.EEst * integrator.dt, seed = nothing)
     tspan = _convert_tspan(n.tspan, p)
-    h = rnde_handle(n, size(x, 2))
+    h = rnde_handle(n, size(x, 2), func)
     arr, saveval = RNDE.rnde_nsde_solve(h, x, p, tspan, _next_seed(seed))                      # <- replaces :130-140
     c = RNDE.counters(h)
     return arr, c.nfe1, c.nfe2, _sde_saved(tspan, p, saveval)
@@ -61,7 +78,7 @@ end
 # {true,true} (reference :84-113)
 function (n::TrackedNeuralDSDE{true,true})(x, p = n.p; func = (u, t, integrator) -> integrator.EEst * integrator.dt, seed = nothing)
     tspan = _convert_tspan(n.tspan, p)
-    h = rnde_handle(n, size(x, 2))
+    h = rnde_handle(n, size(x, 2), func)
     arr, saveval = RNDE.rnde_nsde_solve_saveat(h, x, p, tspan, _sde_saveat(n), _next_seed(seed))   # <- replaces :98-108
     c = RNDE.counters(h)
     return arr, c.nfe1, c.nfe2, _sde_saved(tspan, p, saveval)

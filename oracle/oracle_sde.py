@@ -52,10 +52,10 @@ class SdeOracle:
         class Config(C.Structure):
             _fields_ = [("drift", Arch), ("diffusion", Arch), ("reltol", self.real), ("abstol", self.real),
                         ("tableau", C.c_int), ("reg_kind", C.c_int), ("cb_save_start", C.c_int), ("max_attempts", C.c_int)] + \
-                       [(n, self.real) for n in ("beta1", "beta2", "gamma", "qmin", "qmax", "qoldinit", "delta")]
+                       [(n, self.real) for n in ("beta1", "beta2", "gamma", "qmin", "qmax", "qoldinit", "delta", "stability_size")]
 
         self.cfg = Config(drift, diffusion, reltol, abstol, TABLEAU[tableau], reg_kind, cb_save_start, max_attempts,
-                          *[ctrl.get(n, 0.0) for n in ("beta1", "beta2", "gamma", "qmin", "qmax", "qoldinit", "delta")])
+                          *[ctrl.get(n, 0.0) for n in ("beta1", "beta2", "gamma", "qmin", "qmax", "qoldinit", "delta", "stability_size")])
         L = self.lib
         L.orc_sde_create.restype = C.c_void_p
         L.orc_sde_destroy.argtypes = [C.c_void_p]
@@ -124,6 +124,12 @@ class SdeOracle:
                                       self._p(log), C.byref(natt), C.byref(ndr))
         return dict(rc=rc, u=u, nfe1=n1.value, nfe2=n2.value, saveval=sv[:nsv.value].copy(), steps=log[:natt.value].copy(),
                     nattempts=natt.value, ndraws=ndr.value)
+
+    def eigen_norms(self, n_max=None):
+        """(n_acc, 2): rms(k4 - k3), rms(H0_4 - H0_3) of every accepted step of the last forward (eigen_est = their quotient); after `attempt`: (1, 2)."""
+        out = np.zeros((n_max or self.max_attempts + 1, 2), dtype=self.dtype)
+        n = self.lib.orc_sde_eigen_norms(self.h, self._p(out))
+        return out[:max(n, 1)].copy()
 
     def path_total(self, B):
         w = np.empty((B, self.D), dtype=self.dtype); z = np.empty_like(w)

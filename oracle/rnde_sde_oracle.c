@@ -12,6 +12,13 @@
  *   rejection sampling w/ memory DiffEqNoiseProcess accept_step!/reject_step! with RSWM(adaptivealg = :RSwM3)
  *                                (Rackauckas & Nie 2017, Algorithm RSwM3)
  *   saving callback              DiffEqCallbacks via reference neural_sde.jl:95-96, :127-128
+ *   stiffness estimate           [RECALL] StochasticDiffEq src/perform_step/sri.jl, the block behind the error estimate of the four-stage SRI
+ *                                step: `if alg isa StochasticCompositeAlgorithm && alg.algs[1] isa SOSRI2: eigen_est =
+ *                                internalnorm(k4 - k3) / internalnorm(H0[4] - H0[3])` -- SOSRI2's last two drift stages share the time t + dt
+ *                                (c0[3] = c0[4] = 1), so the quotient estimates |J_drift|.  Recorded by the experiment's callback as
+ *                                |eigen_est| / alg_stability_size(SOSRI2()) = / 10.6 (reference experiments/mnist_nsde.jl:51-61, the shipped
+ *                                configs/mnist_nsde.yml:6).  AutoSOSRI2(SOSRI2()) switches between two copies of the SAME method: the
+ *                                trajectory is SOSRI2's (as AutoTsit5(Tsit5()) in the ODE oracle).  reg_kind = 2; the constant is cfg.stability_size.
  *   NFE counters                 reference neural_sde.jl:46,:50 (counted in the closures: the two probing evaluations of the
  *                                initial-step rule are included), returned at :109-113
  *   reverse pass                 what Tracker computes for sensealg = SensitivityADPassThrough() (neural_sde.jl:104,:136)
@@ -104,6 +111,7 @@ typedef struct { stack_item* it; int n, cap; } nstack;
 
 typedef struct {
     real t, dt, eest;
+    real n1, n2;              /* rms(k4 - k3), rms(H0_4 - H0_3): eigen_est = n1 / n2 (reg_kind 2) */
     int sv_index;
     int sv_first, nsv_pts;    /* saveat points filled from this step (linear interpolation between uprev and u) */
     real *uprev, *u;          /* uprev borrowed (u0 or the previous record's u), u owned */
@@ -125,6 +133,7 @@ typedef struct {
     real *wtot, *ztot;
     int have_tape, n_saveval;
     int n_replay; real* replay_dt; int* replay_acc;   /* orc_sde_set_replay */
+    int last_is_attempt; real last_nrm[2];                                 /* orc_sde_attempt: rms(k4 - k3), rms(H0_4 - H0_3) of the last call */
     int nsave; real* saveat; int save_t0;             /* orc_sde_set_saveat: the {R,true} call methods (neural_sde.jl:44-61,:84-113) */
 } sde_handle;
 
@@ -200,7 +209,7 @@ void orc_sde_destroy(void* hh) {
 /* ---------------- one attempt ---------------- */
 /* rec receives owned arrays when keep != 0; otherwise kg (8 arrays) and unew are caller buffers */
 static real sde_attempt(const sde_handle* h, const real* p, const real* uprev, int B, real dt, const real* dW, const real* dZ,
-                        real* k[4], real* g[4], real* H0[4], real* H1[4], real* actf[4], real* actg[4], real* unew) {
+                        real* k[4], real* g[4], real* H0[4], real* H1[4], real* actf[4], real* actg[4], real* unew, real* nrm) {
     const orc_sri_tableau* T = &h->T;
     const size_t N = (size_t)h->D * B;
     const real sqdt = rsqrt_(rfabs(dt));
@@ -248,7 +257,21 @@ static real sde_attempt(const sde_handle* h, const real* p, const real* uprev, i
         ssum += (double)(r * r);
     }
     free(chi2);
+    if (nrm) {   /* the two norms of the stiffness estimate (DiffEqBase ODE_DEFAULT_NORM: rms), from the LAST TWO drift stages */
+        double s1 = 0, s2 = 0;
+        for (size_t i = 0; i < N; ++i) {
+            const real v1 = k[3][i] - k[2][i], v2 = H0[3][i] - H0[2][i];
+            s1 += (double)(v1 * v1); s2 += (double)(v2 * v2);
+        }
+        nrm[0] = (real)sqrt(s1 / (double)N); nrm[1] = (real)sqrt(s2 / (double)N);
+    }
     return (real)sqrt(ssum / (double)N);
+}
+static real sde_stab(const sde_handle* h) { return h->cfg.stability_size != 0 ? h->cfg.stability_size : (real)10.6; }
+static real sde_cb_value(const sde_handle* h, real eest, real dt, real eigen) {   /* the experiment's save_func (mnist_nsde.jl:48, :53-58) */
+    if (h->cfg.reg_kind == 1) return eest * dt;
+    if (h->cfg.reg_kind == 2) { const real a = rfabs(eigen); return (a == 0 || isnan(a)) ? 0 : a / sde_stab(h); }
+    return 0;
 }
 
 void orc_sde_attempt(void* hh, const real* p, const real* uprev, int B, real dt, const real* dW, const real* dZ,
@@ -257,7 +280,8 @@ void orc_sde_attempt(void* hh, const real* p, const real* uprev, int B, real dt,
     const size_t N = (size_t)h->D * B;
     real *k[4], *g[4], *H0[4], *H1[4];
     for (int j = 0; j < 4; ++j) { k[j] = kg_out + (size_t)j * N; g[j] = kg_out + (size_t)(4 + j) * N; H0[j] = j ? ralloc(N) : NULL; H1[j] = j ? ralloc(N) : NULL; }
-    *eest = sde_attempt(h, p, uprev, B, dt, dW, dZ, k, g, H0, H1, NULL, NULL, unew);
+    *eest = sde_attempt(h, p, uprev, B, dt, dW, dZ, k, g, H0, H1, NULL, NULL, unew, h->last_nrm);
+    h->last_is_attempt = 1;
     for (int j = 1; j < 4; ++j) { free(H0[j]); free(H1[j]); }
 }
 
@@ -415,6 +439,7 @@ int orc_sde_forward(void* hh, const real* x, const real* p, int B, real t0, real
     sde_handle* h = (sde_handle*)hh;
     const orc_sde_config* cfg = &h->cfg;
     free_tape(h);
+    h->last_is_attempt = 0;
     const size_t N = (size_t)h->D * B;
     h->B = B;
     h->p = rdup(p, h->P);
@@ -429,7 +454,7 @@ int orc_sde_forward(void* hh, const real* x, const real* p, int B, real t0, real
     if (replay) dt = h->replay_dt[0];
     real t = t0, qold = h->qoldinit;
     int nsv = 0, ret = 0, n = 0;
-    if (cfg->reg_kind && cfg->cb_save_start) saveval[nsv++] = 0;   /* EEst = 1, dt = 0 at callback initialisation */
+    if (cfg->reg_kind && cfg->cb_save_start) saveval[nsv++] = sde_cb_value(h, 1, 0, 1);   /* EEst = 1, dt = 0, eigen_est = 1 at callback initialisation */
     noise_t W;
     memset(&W, 0, sizeof(W));
     W.N = N; W.dW = ralloc(N); W.dZ = ralloc(N); W.pool = noise; W.n_pool = n_pool; W.discard = (real)1e-15;
@@ -455,7 +480,9 @@ int orc_sde_forward(void* hh, const real* x, const real* p, int B, real t0, real
             r.actf[j] = ralloc((size_t)h->arows_f * B); r.actg[j] = ralloc((size_t)h->arows_g * B);
             r.H0[j] = j ? ralloc(N) : NULL; r.H1[j] = j ? ralloc(N) : NULL;
         }
-        const real eest = sde_attempt(h, p, uprev, B, dt, W.dW, W.dZ, r.k, r.g, r.H0, r.H1, r.actf, r.actg, r.u);
+        real nrm[2] = {0, 0};
+        const real eest = sde_attempt(h, p, uprev, B, dt, W.dW, W.dZ, r.k, r.g, r.H0, r.H1, r.actf, r.actg, r.u, nrm);
+        r.n1 = nrm[0]; r.n2 = nrm[1];
         nf1 += 4; nf2 += 4;
         ++n;
         r.eest = eest;
@@ -468,7 +495,7 @@ int orc_sde_forward(void* hh, const real* x, const real* p, int B, real t0, real
         if (accepted) {
             r.dW = rdup(W.dW, N); r.dZ = rdup(W.dZ, N);
             for (size_t i = 0; i < N; ++i) { h->wtot[i] += W.dW[i]; h->ztot[i] += W.dZ[i]; }
-            if (cfg->reg_kind) { r.sv_index = nsv; saveval[nsv++] = eest * dt; }
+            if (cfg->reg_kind) { r.sv_index = nsv; saveval[nsv++] = sde_cb_value(h, eest, dt, r.n1 / r.n2); }
             r.sv_first = next_save; r.nsv_pts = 0;
             {
                 const real tnew = t + dt;
@@ -592,11 +619,26 @@ int orc_sde_backward(void* hh, const real* ubar, const real* svbar, real* xbar, 
             upb[i] = up + (svup ? svup[i] : 0);
         }
         free(svup);
+        /* stiffness estimate: value = |n1 / n2| / stab with n1 = rms(k4 - k3), n2 = rms(H0_4 - H0_3); zero / NaN estimates are recorded as the
+         * constant 0 (mnist_nsde.jl:55-57).  d n1 / d v1_i = v1_i / (N n1), so k4bar += c1 v1, k3bar -= c1 v1 and the stage inputs get
+         * H0_4bar += c2 v2, H0_3bar -= c2 v2 (added to the drift's input cotangent of stages 4 and 3 below). */
+        double c1 = 0, c2 = 0;
+        if (r->sv_index >= 0 && svbar && h->cfg.reg_kind == 2 && r->n1 > 0 && r->n2 > 0) {
+            const double eigb = (double)svbar[r->sv_index] / (double)sde_stab(h);
+            c1 = eigb / ((double)N * (double)r->n1 * (double)r->n2);
+            c2 = -eigb * (double)r->n1 / ((double)N * (double)r->n2 * (double)r->n2 * (double)r->n2);
+            for (size_t i = 0; i < N; ++i) {
+                const real v1 = r->k[3][i] - r->k[2][i];
+                kb[3][i] += (real)(c1 * (double)v1); kb[2][i] -= (real)(c1 * (double)v1);
+            }
+        }
         for (int s = 3; s >= 0; --s) {
             const real* h0 = s ? r->H0[s] : r->uprev;
             const real* h1 = s ? r->H1[s] : r->uprev;
             /* k_s = f(H0_s) */
             orc_f_backward(&h->cfg.drift, pf, h0, r->actf[s], B, 0, kb[s], hb, pbar);
+            if (c2 != 0 && s >= 2)
+                for (size_t i = 0; i < N; ++i) { const real v2 = r->H0[3][i] - r->H0[2][i]; hb[i] += (real)((s == 3 ? c2 : -c2) * (double)v2); }
             for (size_t i = 0; i < N; ++i) {
                 upb[i] += hb[i];
                 if (s) {
@@ -620,4 +662,12 @@ int orc_sde_backward(void* hh, const real* ubar, const real* svbar, real* xbar, 
     free(U); free(upb); free(hb);
     for (int j = 0; j < 4; ++j) { free(kb[j]); free(gb[j]); }
     return 0;
+}
+
+/* rms(k4 - k3), rms(H0_4 - H0_3) of every ACCEPTED step of the last forward (eigen_est = n1 / n2), or of the last orc_sde_attempt (n_acc = 0 there). */
+int orc_sde_eigen_norms(void* hh, real* n1n2) {
+    sde_handle* h = (sde_handle*)hh;
+    if (h->last_is_attempt || !h->have_tape) { n1n2[0] = h->last_nrm[0]; n1n2[1] = h->last_nrm[1]; return 0; }
+    for (int n = 0; n < h->n_acc; ++n) { n1n2[2 * n] = h->rec[n].n1; n1n2[2 * n + 1] = h->rec[n].n2; }
+    return h->n_acc;
 }

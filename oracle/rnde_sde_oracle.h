@@ -34,13 +34,14 @@ typedef struct {
     orc_arch diffusion;   /* re2(p[len+1:end])(u): Dense chain, output D (diagonal noise, neural_sde.jl:49-52) */
     real reltol, abstol;  /* experiments/mnist_nsde.jl:79-80: 1.4f-1 */
     int tableau;          /* 0 SOSRI (mnist_nsde.jl:49,:63), 1 SRIW1, 2 SOSRI2 */
-    int reg_kind;         /* 0 none; 1 EEst*dt (neural_sde.jl:87) */
+    int reg_kind;         /* 0 none; 1 EEst*dt (neural_sde.jl:87; mnist_nsde.jl:48); 2 |eigen_est| / stability_size (mnist_nsde.jl:51-61: the shipped default) */
     int cb_save_start;    /* 1: the saving callback also fires at initialisation (EEst = 1, dt = 0 -> 0), as in the ODE oracle */
     int max_attempts;
     /* controller constants; 0 selects the recalled StochasticDiffEq defaults:
      * beta2 = 2/(5 order), beta1 = 7/(10 order) with order = 3/2; gamma = 9/10; qmin = 1/5; qmax = 1.125;
      * qoldinit = 1e-4; delta = 1 (1/6 for SRIW1) */
     real beta1, beta2, gamma, qmin, qmax, qoldinit, delta;
+    real stability_size;  /* reg_kind 2: 0 selects StochasticDiffEq.alg_stability_size(SOSRI2()) = 10.6 [RECALL] */
 } orc_sde_config;
 
 /* tableau as data: lower-triangular 4x4 matrices row-major (row = stage), vectors of 4 */
@@ -82,6 +83,10 @@ void orc_sde_path_total(void* h, real* w_total, real* z_total);
 /* Reverse pass of the recorded solve: ubar (D x B), svbar per saveval element -> xbar (D x B), pbar (P).
  * Step sizes and noise increments are constants of the reverse pass (the SDE controller strips tracking: [RECALL]). */
 int orc_sde_backward(void* h, const real* ubar, const real* svbar, real* xbar, real* pbar);
+
+/* The two norms behind integrator.eigen_est, per ACCEPTED step of the last forward (2 reals each; returns the count), or -- after
+ * orc_sde_attempt -- of that attempt (returns 0): n1 = rms(k4 - k3), n2 = rms(H0_4 - H0_3), eigen_est = n1 / n2. */
+int orc_sde_eigen_norms(void* h, real* n1n2);
 
 /* shared with rnde_oracle.c */
 void orc_f_forward(const orc_arch* a, const real* p, const real* u, int B, real t, real* out, real* acts);

@@ -202,11 +202,11 @@ ChainParams make_chain_params(rnde_node* h, const StepParams& P) {
 template <int NKD, int MODE, int ALT = 0>
 static hipError_t launch_chain_t(rnde_node* h, const ChainParams& Q, int n, float* u_out, hipStream_t s) {
     auto kern = rnde_chain_kernel<NKD, MODE, ALT>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    if (attr_set.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set.done();
     }
     hipLaunchKernelGGL(kern, dim3(Q.F.nwg), dim3(64 * kCW), MODE == CM_FINISH ? 0 : h->chain_lds_f, s, Q, n, u_out);
     return hipGetLastError();
@@ -228,11 +228,11 @@ MwParams make_mw_params(rnde_node* h, const StepParams& P) {
 }
 template <int NR, int MODE, int TAB, int LAT = 0>
 static hipError_t launch_mw_t(rnde_node* h, const MwParams& Q, int n, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    if (attr_set.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)rnde_chainmw_kernel<NR, MODE, TAB, LAT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set.done();
     }
     hipLaunchKernelGGL((rnde_chainmw_kernel<NR, MODE, TAB, LAT>), dim3((MODE == MW_SOLVE && !Q.xch_global) ? 8 * Q.ntiles : Q.ntiles), dim3(kMwThreads), MODE == MW_FINISH ? 0 : h->mw_lds_f, s, Q, n);
     return hipGetLastError();
@@ -551,8 +551,8 @@ bool bsweep_failed(rnde_node* h, hipStream_t s) {
     if (!h->pending_bsweep) return false;
     h->pending_bsweep = false;
     bool bad = h->h_mw_bchk[0] != 0;
-    const int nt = h->bw.ready ? (int)((h->B + 15) / 16) : 0;
-    for (int i = 1; i < nt && nt <= 32 && !bad; ++i) bad = h->h_mw_bchk[2 + i] != h->h_mw_bchk[2];      // (more than 32 tiles: the meeting does not depend on the placement)
+    const int nt = h->bsweep_nt;      // the sweep's own geometry, recorded at its launch (h->B may already belong to the next forward)
+    for (int i = 1; i < nt && !h->bsweep_global && !bad; ++i) bad = h->h_mw_bchk[2 + i] != h->h_mw_bchk[2];      // (memory-side meeting: it does not depend on the placement)
     if (!bad) return false;
     fprintf(stderr, "[rnde] chain engine: one-launch reverse sweep abandoned (%s); one launch per reversed attempt for the next %d solves\n",
             h->h_mw_bchk[0] ? "a meeting timed out" : "workgroups pinned by block index landed on different XCDs", h->mw_retry_after);
@@ -599,9 +599,12 @@ static bool persist_failed(rnde_node* h, int grid, int C, int R, hipStream_t s) 
 rnde_status forward_impl(rnde_node* h, const float* x_dev, const float* p_dev, int32_t B, float t0, float t1,
                                 float* u_out_dev, const float* saveat_host, int32_t n_saveat, float* sv_out_dev,
                                 int64_t* nfe_out, float* saveval_host, int32_t* n_saveval_out, int32_t keep_tape, void* stream) {
-    rnde_status st = forward_core(h, x_dev, p_dev, B, t0, t1, u_out_dev, saveat_host, n_saveat, sv_out_dev, nfe_out, saveval_host, n_saveval_out, keep_tape, stream);
-    if (st == RNDE_INTERNAL_RETRY)
+    // a solve may ask to be redone for two independent reasons (the record slab has to grow; a one-launch kernel gave up and the handle fell back):
+    // both can happen back to back, each at most once per cause -- anything beyond that is an error, not a status the caller should ever see
+    rnde_status st = RNDE_INTERNAL_RETRY;
+    for (int tries = 0; tries < 4 && st == RNDE_INTERNAL_RETRY; ++tries)
         st = forward_core(h, x_dev, p_dev, B, t0, t1, u_out_dev, saveat_host, n_saveat, sv_out_dev, nfe_out, saveval_host, n_saveval_out, keep_tape, stream);
+    if (st == RNDE_INTERNAL_RETRY) { h->err = "the forward solve asked to be redone four times in a row (one-launch fallbacks and slab growth): giving up"; st = RNDE_ERR_HIP; }
     return st;
 }
 
@@ -748,7 +751,7 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
         if (bsweep_failed(h, s)) { h->err = "the one-launch reverse sweep of the previous asynchronous backward call was abandoned: the gradients of that step are invalid (one launch per reversed attempt now in use)"; return RNDE_ERR_HIP; }
         bool bad = h->h_mw_chk[0] != 0;
         for (int i = 1; i < nt && !MQ.xch_global && !bad; ++i) bad = h->h_mw_chk[2 + i] != h->h_mw_chk[2];
-        if (bad) {      // a meeting timed out, or the workgroups did not share an XCD: this handle goes back to one launch per attempt, for good
+        if (bad) {      // a meeting timed out, or the workgroups did not share an XCD: this handle goes back to one launch per attempt for the next mw_retry_after solves
             fprintf(stderr, "[rnde] chain engine: one-launch solve abandoned (%s); one launch per attempted step for the next %d solves\n",
                     h->h_mw_chk[0] ? "a meeting timed out" : "workgroups pinned by block index landed on different XCDs", h->mw_retry_after);
             h->mw_solve = -1; h->mw_clean = 0; ++h->persist_fallbacks;

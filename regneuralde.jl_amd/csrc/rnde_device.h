@@ -16,6 +16,16 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
+
+// hipFuncSetAttribute (the dynamic-LDS ceiling of a kernel) is a PER-DEVICE setting: a function-local `static bool` would let the second device
+// of a process launch without it.  One bit per device, set once the call has succeeded; two threads racing set it twice, which is harmless.
+struct DeviceOnce {
+    std::atomic<uint64_t> mask{0};
+    static int dev() { int d = 0; (void)hipGetDevice(&d); return d & 63; }
+    bool need() const { return !((mask.load(std::memory_order_acquire) >> dev()) & 1ull); }
+    void done() { mask.fetch_or(1ull << dev(), std::memory_order_release); }
+};
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -2,6 +2,7 @@
 // No torch, no oracle, no CPU fallback.
 #include "../../include/rnde.h"
 #include "rnde_latent.h"
+#include "rnde_device.h"      // DeviceOnce
 
 #include <algorithm>
 #include <cmath>
@@ -92,8 +93,8 @@ static rnde_status run_fused(rnde_latent* h, const JobList& Jl, const float* act
     FusedWgrad F{Jl.jj, act, del, K, raw};
     const int G = Jl.fused_groups, E = fused_tile_count(Jl.jj) * 256;
     constexpr size_t lds = sizeof(float) * 2 * (kFwSamples * (size_t)(LDA + LDD) + 16);      // two images
-    static bool attr = false;
-    if (!attr && lds > 64 * 1024) { LCHK(h, hipFuncSetAttribute((const void*)rnde_latent_gru_wgrad_kernel<LDA, LDD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    static DeviceOnce attr;
+    if (attr.need() && lds > 64 * 1024) { LCHK(h, hipFuncSetAttribute((const void*)rnde_latent_gru_wgrad_kernel<LDA, LDD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr.done(); }
     hipLaunchKernelGGL((rnde_latent_gru_wgrad_kernel<LDA, LDD>), dim3(G), dim3(64 * kFwWaves), lds, s, F);
     const int nseg = std::min(kFusedSegs, G), per = (G + nseg - 1) / nseg, segs = (G + per - 1) / per;
     hipLaunchKernelGGL(rnde_latent_reduce_raw_kernel, dim3(std::min((E / 4 + 255) / 256, 64), segs), dim3(256), 0, s, (const float*)raw, G, per, E, raw2);

@@ -59,7 +59,8 @@ struct rnde_node {
     int mw_slot = 0;   // the XCD (blockIdx % 8) this handle's one-launch chain kernels work on while they fit one: handles take turns (process-wide counter)
     int mw_clean = 0, mw_retry_after = 8;   // non-sticky fallback of those kernels, as persist_clean / persist_retry_after of the stage engine
     int mw_solve = 1; unsigned long long* mw_xch = nullptr; unsigned* mw_xcc = nullptr; unsigned* mw_abort = nullptr; unsigned* h_mw_chk = nullptr; unsigned mw_epoch = 0;
-    int mw_bsweep = 1; int* mw_bargs = nullptr; int* h_mw_bargs = nullptr; unsigned* h_mw_bchk = nullptr; bool pending_bsweep = false;   // the reverse sweep as one launch (rnde_bchainmw.h SWEEP): per-attempt arguments [sv_lo | sv_hi | eig_c], check words
+    int mw_bsweep = 1; int* mw_bargs = nullptr; int* h_mw_bargs = nullptr; unsigned* h_mw_bchk = nullptr; bool pending_bsweep = false; int bsweep_nt = 0; bool bsweep_global = false;   // (the pending sweep's OWN tile count / meeting kind: a later forward may overwrite h->B before the verdict is read)
+      // the reverse sweep as one launch (rnde_bchainmw.h SWEEP): per-attempt arguments [sv_lo | sv_hi | eig_c], check words
     int rk_S = 7, rk_order = 5;   // stages of the pair in first-same-as-last form (evaluations per attempted step = rk_S - 1), controller order
     int mw_lat = 0;               // the reference's latent-ODE shape (20 <-> 50, 8 layers): forward kernels with register-stationary weights
     int mw = 0; MwGeo mg{}; float* mw_tab = nullptr; float* mw_slab = nullptr; long long mw_slab_evals = 0; size_t mw_lds_f = 0, mw_lds_b = 0;

@@ -102,11 +102,12 @@ static rnde_status launch_wgrad_part(rnde_node* h, const EvalDesc* ev, int n_eva
         sc = (total_steps + steps_per_chunk - 1) / steps_per_chunk;
         if ((size_t)(*chunk_cursor + sc) * (size_t)len > h->bw.slab_floats) { h->err = "weight-gradient slab overflow"; return RNDE_ERR_BAD_ARG; }
         const size_t lds = (size_t)2 * 32 * (464 + 144) * sizeof(float);   // two buffers
-        static const hipError_t attr = [&] {
-            hipError_t e = hipFuncSetAttribute((const void*)rnde_wgrad3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            return e == hipSuccess ? hipFuncSetAttribute((const void*)rnde_wgrad3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) : e;
-        }();
-        HIPCHK(h, attr);
+        static DeviceOnce attr;
+        if (attr.need()) {
+            HIPCHK(h, hipFuncSetAttribute((const void*)rnde_wgrad3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIPCHK(h, hipFuncSetAttribute((const void*)rnde_wgrad3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr.done();
+        }
         if (tall) hipLaunchKernelGGL((rnde_wgrad3_kernel<true>), dim3(2, sc), dim3(448), lds, s, ev, n_evals, steps_per_chunk, M, Nx, Bpad, dst);
         else hipLaunchKernelGGL((rnde_wgrad3_kernel<false>), dim3(2, sc), dim3(448), lds, s, ev, n_evals, steps_per_chunk, M, Nx, Bpad, dst);
         HIPCHK(h, hipGetLastError());
@@ -291,11 +292,12 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
                 if (fix) {
                     // (+ the START-staged tape operands of the six stages, rnde_bstage_persist.h: 6 x 7 waves x 2 arrays x 1 KiB)
                     const size_t flds = h->stage_lds + (size_t)(RNDE_BSTAGE_HDMA ? 1 : 0) * 6 * 7 * 2 * 1024;
-                    static const hipError_t attr = [&] {
-                        hipError_t e = hipFuncSetAttribute((const void*)rnde_bstage_attempt_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                        return e == hipSuccess ? hipFuncSetAttribute((const void*)rnde_bstage_attempt_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) : e;
-                    }();
-                    HIPCHK(h, attr);
+                    static DeviceOnce attr;
+                    if (attr.need()) {
+                        HIPCHK(h, hipFuncSetAttribute((const void*)rnde_bstage_attempt_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                        HIPCHK(h, hipFuncSetAttribute((const void*)rnde_bstage_attempt_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                        attr.done();
+                    }
                     if (h->act2) hipLaunchKernelGGL((rnde_bstage_attempt_kernel<1, 1>), pgrid, blk, flds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
                     else hipLaunchKernelGGL((rnde_bstage_attempt_kernel<0, 1>), pgrid, blk, flds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
                 } else if (h->act2) hipLaunchKernelGGL((rnde_bstage_attempt_kernel<1, 0>), pgrid, blk, h->stage_lds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
@@ -493,13 +495,13 @@ template <int NKD, int ALT = 0>
 static hipError_t launch_bchain_t(rnde_node* h, const BChainParams& Q, const std::vector<int>& sv_lo, const std::vector<int>& sv_hi, hipStream_t s) {
     const BwdBuffers& b = h->bw;
     const size_t lds = h->chain_lds_b;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    if (attr_set.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)rnde_bchain_kernel<NKD, ALT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rnde_bchain_init_kernel<NKD, 1, ALT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rnde_bchain_init_kernel<NKD, 2, ALT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set.done();
     }
     const dim3 grid(Q.B.F.nwg), blk(64 * kCW);
     for (int n = Q.B.n_att - 1; n >= 0; --n) {
@@ -527,14 +529,14 @@ template <int NR, int TAB, int LAT = 0>
 static rnde_status launch_bmw_t(rnde_node* h, const BMwParams& Q, const std::vector<int>& sv_lo, const std::vector<int>& sv_hi, hipStream_t s) {
     const BwdBuffers& b = h->bw;
     const size_t lds = h->mw_lds_b;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    if (attr_set.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)rnde_bchainmw_kernel<NR, TAB, LAT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rnde_bchainmw_kernel<NR, TAB, LAT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rnde_bchainmw_init_kernel<NR, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rnde_bchainmw_init_kernel<NR, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         HIPCHK(h, e);
-        attr_set = true;
+        attr_set.done();
     }
     const dim3 grid(Q.ntiles), blk(kMwThreads);
     rnde_status st = RNDE_OK;
@@ -569,7 +571,7 @@ static rnde_status launch_bmw_t(rnde_node* h, const BMwParams& Q, const std::vec
         HIPCHK(h, hipGetLastError());
         HIPCHK(h, hipMemcpyAsync(h->h_mw_bchk, h->mw_abort, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(h, hipMemcpyAsync(h->h_mw_bchk + 2, h->mw_xcc, (size_t)Q.ntiles * 4, hipMemcpyDeviceToHost, s));
-        h->pending_bsweep = true;
+        h->pending_bsweep = true; h->bsweep_nt = Q.ntiles; h->bsweep_global = W.xch_global != 0;
     }
     hipLaunchKernelGGL((rnde_bchainmw_init_kernel<NR, 1>), grid, blk, lds, s, Q);
     if ((st = couple_sum(h, Q.B.ipart, 4LL * Q.B.F.nwg, s)) != RNDE_OK) return st;                        // dot, tau of the reversed second evaluation

@@ -248,33 +248,33 @@ static rnde_status sde_pack(rnde_nsde* h, const float* p_dev, hipStream_t s) {
 
 template <int NKD, int FIXH = 0>
 static hipError_t launch_solve(rnde_nsde* h, const SdeParams& Q, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
+    static DeviceOnce attr;
+    if (attr.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)rnde_sde_solve_kernel<NKD, FIXH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr = true;
+        attr.done();
     }
     hipLaunchKernelGGL((rnde_sde_solve_kernel<NKD, FIXH>), dim3(Q.nwg), dim3(64 * kCW), h->lds_fwd, s, Q);
     return hipGetLastError();
 }
 template <int NKD>
 static hipError_t launch_attempt(rnde_nsde* h, const SdeParams& Q, const float* up, const float* dW, const float* dZ, float dt, float* kg, float* un, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
+    static DeviceOnce attr;
+    if (attr.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)rnde_sde_attempt_kernel<NKD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr = true;
+        attr.done();
     }
     hipLaunchKernelGGL(rnde_sde_attempt_kernel<NKD>, dim3(Q.nwg), dim3(64 * kCW), h->lds_fwd, s, Q, up, dW, dZ, dt, kg, un, h->part);
     return hipGetLastError();
 }
 template <int NKD, int FIXH = 0>
 static hipError_t launch_bwd(rnde_nsde* h, const SdeBwdParams& Bq, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
+    static DeviceOnce attr;
+    if (attr.need()) {
         hipError_t e = hipFuncSetAttribute((const void*)rnde_sde_bwd_kernel<NKD, FIXH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr = true;
+        attr.done();
     }
     hipLaunchKernelGGL((rnde_sde_bwd_kernel<NKD, FIXH>), dim3(Bq.F.nwg), dim3(64 * kCW), h->lds_bwd, s, Bq);
     return hipGetLastError();
@@ -355,8 +355,8 @@ static rnde_status nsde_forward_impl(rnde_nsde* h, const float* x_dev, const flo
     // one workgroup of four waves per tile, all of them resident (they meet once per attempt): 144 VGPRs and ~20 KB of LDS let a CU hold two,
     // so the limit is 512 tiles = 8,192 columns (the reference's evaluation call with trajectories = 10 is 5,120: mnist_nsde.jl:154-155)
     if (h->mw && ntiles <= kSmwMaxTiles) {
-        static bool attr = false;
-        if (!attr) { SCHK(h, hipFuncSetAttribute((const void*)rnde_sde_solve_mw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+        static DeviceOnce attr;
+        if (attr.need()) { SCHK(h, hipFuncSetAttribute((const void*)rnde_sde_solve_mw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr.done(); }
         Q.nwg = ntiles;
         local_xch = h->xch_local && ntiles <= 32;      // one XCD has 32 CUs: one workgroup each
         Q.xch_local = local_xch ? 1 : 0; Q.xcc = h->xcc;

@@ -9,8 +9,10 @@ With `saveat=` (constructor keyword or per-call override, neural_ode.jl:35-46) t
 (neural_ode.jl:79-108,:146-180): `u` is then the (B, T, D) tensor whose memory is exactly the Julia
 D x T x B array of diffeqsol_to_3dtrackedarray (src/utils.jl:17-19).
 
-Differences from the Julia layer that are inherent to the host language: `func` is one of the
-reference's three callbacks selected by name (mnist_node.jl:67,:74-79,:88-97), not a closure;
+`func` is the caller's closure `(u, t, integrator) -> value` as the reference passes it (mnist_node.jl:134) -- it is evaluated on two
+mock integrators and RECOGNISED as one of the reference's callbacks (mnist_node.jl:67,:74-79,:88-97; `reg_code` below), the library
+computes the value inside its kernels -- or that callback's name ('error_est' / 'stiff_est' / 'error_stiff_est').  Anything else raises.
+Differences from the Julia layer that are inherent to the host language:
 `save_everystep=True` (a result whose length is data dependent; no reference call site uses it): `rnde_node_forward_everystep`, the state
 after every accepted step (and the initial one with save_start=True), (B, n, D) with n known after the call.
 """
@@ -22,7 +24,46 @@ from . import _lib
 from .layers import destructure
 
 _ACT = {"identity": 0, "tanh": 1}
-_FUNCS = {None: 1, "error_est": 1, "stiff_est": 2, "error_stiff_est": 3}
+_FUNCS = {None: 1, "none": 0, "error_est": 1, "stiff_est": 2, "error_stiff_est": 3}      # None: the layer's default callback (neural_ode.jl:116)
+_FUNC_NAMES = {0: "none", 1: "error_est", 2: "stiff_est", 3: "error_stiff_est"}
+TSIT5_STABILITY_SIZE = 3.5068     # OrdinaryDiffEq.alg_stability_size(Tsit5()): what mnist_node.jl:73,:86 divides by
+SOSRI2_STABILITY_SIZE = 10.6      # StochasticDiffEq.alg_stability_size(SOSRI2()): mnist_nsde.jl:55
+
+
+class MockIntegrator:
+    """What a saving callback reads off the integrator (neural_ode.jl:116; mnist_node.jl:67,:76,:89-91)."""
+
+    def __init__(self, EEst, dt, eigen_est):
+        self.EEst, self.dt, self.eigen_est = EEst, dt, eigen_est
+
+
+_PROBES = ((2.0, 3.0, 5.0), (0.5, 0.25, -7.0))
+
+
+def reg_code(func, stability_size):
+    """rnde_reg code (include/rnde.h) of a caller's callback `func(u, t, integrator)`: its values on two mock integrators are matched against
+    the reference's callbacks -- 0 (neural_ode.jl:54), EEst*dt (mnist_node.jl:67), |eigen_est|/stability_size (:74-79), EEst*dt +
+    0.1*eigen_est/stability_size (:88-97).  The same rule as bindings/julia/RNDE.jl::reg_code.  Raises ValueError for anything else: a
+    regulariser the kernels do not compute must not be replaced by another one silently."""
+    got = [float(func(None, 0.0, MockIntegrator(*m))) for m in _PROBES]
+    s = float(stability_size)
+    want = {0: lambda e, d, g: 0.0, 1: lambda e, d, g: e * d, 2: lambda e, d, g: abs(g) / s, 3: lambda e, d, g: e * d + 0.1 * g / s}
+    for code in (0, 1, 2, 3):
+        if all(abs(v - want[code](*m)) <= 1e-4 * abs(want[code](*m)) + 1e-7 for v, m in zip(got, _PROBES)):
+            return code
+    raise ValueError("func is none of the callbacks librnde.so computes (EEst*dt, |eigen_est|/stability_size, EEst*dt + "
+                     f"0.1*eigen_est/stability_size, 0): on (EEst, dt, eigen_est) = {_PROBES[0]} and {_PROBES[1]} it returned {got}")
+
+
+def effective_reg(code, composite):
+    """What the reference's run records with this callback under this solver: integrator.eigen_est is filled by the composite solvers only
+    (AutoTsit5(Tsit5()), AutoSOSRI2(SOSRI2()): mnist_node.jl:81,:99, mnist_nsde.jl:60), a stiffness term under a plain solver is zero."""
+    if composite or code in (0, 1):
+        return code
+    if code == 3:
+        return 1
+    raise ValueError("func reads integrator.eigen_est, which only the composite solvers (AutoTsit5 / AutoSOSRI2) fill; with a plain solver "
+                     "the reference records zeros -- build the layer with the composite solver")
 
 
 class SavedValues:
@@ -258,9 +299,11 @@ class TrackedNeuralODE:
         _check_f32("x", x)
         x2 = x.reshape(x.shape[0], -1).contiguous()
         ts = self.tspan if tspan is None else [float(tspan[0]), float(tspan[1])]   # _convert_tspan, utils.jl:21-23
+        if callable(func):     # the reference's closure (mnist_node.jl:134): recognised, not called per step
+            func = _FUNC_NAMES[effective_reg(reg_code(func, TSIT5_STABILITY_SIZE), self.solver == "AutoTsit5")] if self.regularize else None
         if func not in _FUNCS:
-            raise ValueError("func must be one of None/'error_est', 'stiff_est', 'error_stiff_est' "
-                             "(the three callbacks of experiments/mnist_node.jl:62-103)")
+            raise ValueError("func must be a callback (u, t, integrator) -> value or one of None/'error_est', 'stiff_est', "
+                             "'error_stiff_est' (the three callbacks of experiments/mnist_node.jl:62-103)")
         self._func = func if self.regularize else None
         keep = torch.is_grad_enabled() and (x2.requires_grad or p.requires_grad)
         times = None

@@ -263,6 +263,19 @@ def fused_latent_loss_and_grad(model, data, mask, t_row, lam_r=1.0e2, lam_k=1.0,
     x_ = torch.cat([data, mask, t_row], dim=2).to(torch.float32).contiguous()
     node = model.node
     lat = 20                                     # latent state rows (latent_ode.jl:112-124); the kernels are built for the reference's sizes
+    # rnde_latent_* is compiled for the experiment's own sizes (latent_ode.jl:39-124: LatentGRU(37, 40, 50), rec_to_gen 100-50-40, gen_to_data 20-37):
+    # a model built with other sizes must not reach kernels that would read its parameter vectors out of bounds
+    if getattr(model, "_latent_sizes_ok", None) is None:
+        n1, n2, n4 = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        L.rnde_latent_param_counts(C.byref(n1), C.byref(n2), C.byref(n4))
+        p1_, p2_, p3_, p4_ = model.trainable()
+        have = (p1_.numel(), p2_.numel(), p4_.numel(), data.shape[2], mask.shape[2], t_row.shape[2], node.model.dims()[0])
+        want = (n1.value, n2.value, n4.value, 37, 37, 1, lat)
+        if have != want:
+            raise ValueError("fused_latent_loss_and_grad runs the kernels built for the reference's latent-ODE sizes (experiments/latent_ode.jl:39-124): "
+                             f"(len p1, len p2, len p4, data width, mask width, time width, latent rows) must be {want}, this model has {have}; "
+                             "use latent_loss_function (torch autograd around the layer call) for other sizes")
+        model._latent_sizes_ok = True
     hl = getattr(model, "_latent_handle", None)
     if hl is None or hl.max_batch < B or hl.max_T < T:
         hl = model._latent_handle = _LatentHandle(max(B, getattr(hl, "max_batch", 0) if hl else 0), max(T, getattr(hl, "max_T", 0) if hl else 0), dev.index or 0)

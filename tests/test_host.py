@@ -105,6 +105,62 @@ def test_regulariser_table_and_steer(rnde):
     assert node.regularize
 
 
+def test_callers_func_is_recognised_not_replaced(rnde):
+    """The reference hands the layer a closure (`model(x, p1, p2, p3; func = save_func, ...)`, experiments/mnist_node.jl:134).  The three
+    `save_func`s of mnist_node.jl:62-103 / mnist_nsde.jl:45-61, restated here as Python closures, must select the regulariser they compute --
+    and a closure the kernels do not compute must raise, never train on another loss."""
+    from regneuralde_jl_amd import node as N
+    stab = 1.0 / 3.5068                                             # `stability_size` of mnist_node.jl:72-73
+    err = lambda u, t, integ: integ.EEst * integ.dt                  # :67
+    def stiff(u, t, integ):                                          # :74-79
+        s = abs(integ.eigen_est)
+        return stab * (0 if (s == 0 or math.isnan(s)) else s)
+    def both(u, t, integ):                                           # :88-97
+        e, s = integ.EEst * integ.dt, integ.eigen_est
+        return ((0 if e == 0 else e) + 0.1 * stab * (0 if s == 0 else s)) * 1.0
+    assert N.reg_code(lambda u, t, integ: 0, N.TSIT5_STABILITY_SIZE) == 0          # neural_ode.jl:54
+    assert N.reg_code(err, N.TSIT5_STABILITY_SIZE) == 1
+    assert N.reg_code(stiff, N.TSIT5_STABILITY_SIZE) == 2
+    assert N.reg_code(both, N.TSIT5_STABILITY_SIZE) == 3
+    assert N.reg_code(lambda u, t, integ: torch.tensor(integ.EEst) * integ.dt, 3.5068) == 1       # tracked scalars are fine
+    sde_stiff = lambda u, t, integ: abs(integ.eigen_est) / 10.6      # mnist_nsde.jl:53-58
+    assert N.reg_code(sde_stiff, N.SOSRI2_STABILITY_SIZE) == 2
+    for bad in (lambda u, t, integ: 2 * integ.EEst * integ.dt, lambda u, t, integ: integ.EEst, sde_stiff):
+        with pytest.raises(ValueError, match="none of the callbacks"):
+            N.reg_code(bad, N.TSIT5_STABILITY_SIZE)
+    # what the reference's run records under a plain solver: eigen_est stays 0 there
+    assert N.effective_reg(3, composite=False) == 1 and N.effective_reg(3, composite=True) == 3 and N.effective_reg(1, False) == 1
+    with pytest.raises(ValueError, match="composite"):
+        N.effective_reg(2, composite=False)
+    # the layer resolves the closure before it looks for a handle (no GPU needed to get that far: the cuda check comes first)
+    dyn = rnde.MLPDynamics(8, 4)
+    node = rnde.TrackedNeuralODE(dyn, [0.0, 1.0], True, True, "AutoTsit5", reltol=1e-3, abstol=1e-3)
+    with pytest.raises(RuntimeError, match="cuda"):
+        node(torch.zeros(2, 8), func=stiff)
+
+
+def test_julia_patches_dispatch_on_the_callers_func():
+    """bindings/julia cannot run here; what can be checked is the text: every regularised call method derives the handle's `regularize` code
+    from `func` (no side keyword the unchanged experiment script would never pass), the handle tables are keyed by the code, the SDE patch reads
+    the solver off the layer, and RNDE.jl's rule is the one node.py implements (same probes, same four candidates)."""
+    import os
+    import re
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bindings", "julia")
+    ode, sde, mod = (open(os.path.join(d, f)).read() for f in ("patch_neural_ode.jl", "patch_neural_sde.jl", "RNDE.jl"))
+    assert "kind::Symbol" not in ode and "kind =" not in ode
+    assert len(re.findall(r"h = rnde_handle\(n, size\(x, 2\), _reg_code\(n, func\)\)", ode)) == 4
+    assert len(re.findall(r"h = rnde_handle\(n, size\(x, 2\), func\)", sde)) == 4
+    assert "get!(tab, (B, code))" in ode and "get!(tab, (B, reg))" in sde
+    assert "RNDE.solver_name(n.args)" in ode and "RNDE.solver_name(n.args)" in sde and "solver = solver" in sde
+    assert "MockIntegrator(2f0, 3f0, 5f0), MockIntegrator(0.5f0, 0.25f0, -7f0)" in mod
+    from regneuralde_jl_amd import node as N
+    assert N._PROBES == ((2.0, 3.0, 5.0), (0.5, 0.25, -7.0))
+    assert "TSIT5_STABILITY_SIZE = 3.5068" in ode and "SOSRI2_STABILITY_SIZE = 10.6" in sde
+    assert (N.TSIT5_STABILITY_SIZE, N.SOSRI2_STABILITY_SIZE) == (3.5068, 10.6)
+    for code in ("REG_NONE", "REG_ERR", "REG_STIFF", "REG_ERR_STIFF"):
+        assert re.search(code + r" => m ->", mod), code
+
+
 # ---- latent time-series caller (experiments/latent_ode.jl, src/models/time_series.jl) ---------------------------------------
 
 def _dense_cm(p, o, n_in, n_out):
@@ -267,3 +323,12 @@ def test_latent_oracle_gradients_match_finite_differences():
     d = pred * mask - data * mask
     ll_o = (-(d * d) / (2 * lo.SIGMA ** 2) - np.log(lo.SIGMA) - np.log(2 * np.pi) / 2).sum(axis=(1, 2)) / mask.sum(axis=(1, 2))
     assert np.abs(ll_t.numpy() - ll_o).max() <= 1e-9 * np.abs(ll_o).max()
+
+
+def test_fused_latent_caller_refuses_other_sizes(rnde):
+    """rnde_latent_* is compiled for the reference's latent-ODE sizes (experiments/latent_ode.jl:39-124); a model of other sizes must be refused before
+    any kernel reads its parameter vectors (round-4 review: the counts were exported and never checked).  No GPU needed: the check comes first."""
+    from regneuralde_jl_amd import timeseries as ts
+    m = ts.build_latent_ode(in_dim=12, saveat=[0.0, 0.5, 1.0], device="cpu")
+    with pytest.raises(ValueError, match="reference's latent-ODE sizes"):
+        ts.fused_latent_loss_and_grad(m, torch.zeros(4, 3, 12), torch.zeros(4, 3, 12), torch.zeros(4, 3, 1))

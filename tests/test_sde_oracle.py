@@ -153,6 +153,77 @@ def test_reverse_pass_matches_finite_differences(name):
         assert abs(fd - xbar[idx]) <= 1e-6 * max(1.0, abs(fd)), (idx, fd, xbar[idx])
 
 
+def test_stiffness_estimate_of_the_sri_step_and_its_reverse():
+    """reg_kind = 2, the reference's shipped NSDE default (experiments/configs/mnist_nsde.yml:6, mnist_nsde.jl:51-61): the callback records
+    |eigen_est| / 10.6 with eigen_est = rms(k4 - k3) / rms(H0_4 - H0_3) of the SOSRI2 step.  Pinned here by (a) a linear drift c*u, for which the
+    quotient is |c| whatever the noise; (b) the definition evaluated from the attempt's own stage arrays; (c) fp64 central differences of the
+    whole reverse pass along a frozen step sequence (with rejected steps in it)."""
+    # (a) drift = c * u (one identity Dense with W = c I): k4 - k3 = c (H0_4 - H0_3) exactly
+    c = -3.25
+    drift = make_arch([3, 3], ["identity"], False)
+    diff = make_arch([3, 3], ["identity"], False)
+    rng = np.random.default_rng(3)
+    B = 5
+    p = np.concatenate([(c * np.eye(3)).reshape(-1, order="F"), np.zeros(3), 0.3 * rng.standard_normal(9), np.zeros(3)])
+    x = rng.standard_normal((B, 3))
+    noise = rng.standard_normal((200, 2, B, 3))
+    o = SdeOracle(drift, diff, np.float64, 0.05, 0.05, tableau="SOSRI2", reg_kind=2, cb_save_start=1, max_attempts=199)
+    r = o.forward(x, p, noise)
+    assert r["rc"] == 0 and len(r["saveval"]) == int(r["steps"][:, 3].sum()) + 1
+    assert r["saveval"][0] == 1.0 / 10.6                                  # the callback's initialisation: eigen_est = 1 (as the ODE oracle)
+    assert np.allclose(r["saveval"][1:], abs(c) / 10.6, rtol=1e-10)
+    nn = o.eigen_norms()
+    assert nn.shape == (len(r["saveval"]) - 1, 2) and np.allclose(nn[:, 0] / nn[:, 1], abs(c), rtol=1e-10)
+    o2 = SdeOracle(drift, diff, np.float64, 0.05, 0.05, tableau="SOSRI2", reg_kind=2, cb_save_start=0, max_attempts=199, stability_size=2.0)
+    assert np.allclose(o2.forward(x, p, noise)["saveval"], abs(c) / 2.0, rtol=1e-10)     # the constant is a configuration value
+
+    # (b) + (c) the experiment's shape in small: Dense(3, 5, tanh) -> Dense(5, 3), Dense(3, 3)
+    drift = make_arch([3, 5, 3], ["tanh", "identity"], False)
+    rng = np.random.default_rng(11)
+    B = 4
+    p = nsde_params(drift, diff, rng, np.float64, 2.0, 0.6)
+    p = p + 0.05 * rng.standard_normal(len(p))
+    x = rng.standard_normal((B, 3))
+    noise = rng.standard_normal((401, 2, B, 3))
+    o = SdeOracle(drift, diff, np.float64, 0.1, 0.1, tableau="SOSRI2", reg_kind=2, max_attempts=400, qmax=10.0, gamma=1.0, beta2=1e-9)
+    T = sri_tableau("SOSRI2")
+    dt = 0.07
+    dW, dZ = np.sqrt(dt) * noise[0, 0], np.sqrt(dt) * noise[0, 1]
+    kg, _, _ = o.attempt(p, x, dt, dW, dZ)
+    chi2 = (dW + dZ / np.sqrt(3.0)) / 2
+    H0 = [x + dt * sum(T["A0"][s, j] * kg[j] for j in range(s)) + chi2 * sum(T["B0"][s, j] * kg[4 + j] for j in range(s)) for s in range(4)]
+    n1, n2 = o.eigen_norms()[0]
+    assert np.isclose(n1, np.sqrt(np.mean((kg[3] - kg[2]) ** 2)), rtol=1e-12) and np.isclose(n2, np.sqrt(np.mean((H0[3] - H0[2]) ** 2)), rtol=1e-12)
+
+    r0 = o.forward(x, p, noise)
+    assert r0["rc"] == 0 and (r0["steps"][:, 3] == 0).any(), "want a sequence with rejected steps"
+    o.set_replay(r0["steps"][:, 1].copy(), r0["steps"][:, 3].astype(np.int32))
+    r = o.forward(x, p, noise)
+    assert np.array_equal(r["u"], r0["u"]) and np.array_equal(r["saveval"], r0["saveval"]) and (r["saveval"][1:] > 0).all()
+    ubar = rng.standard_normal((B, 3))
+    svbar = rng.standard_normal(len(r["saveval"]))
+
+    def loss(xx, pp):
+        q = o.forward(xx, pp, noise)
+        return float((q["u"] * ubar).sum() + (q["saveval"] * svbar).sum())
+
+    o.forward(x, p, noise)
+    xbar, pbar = o.backward(ubar, svbar)
+    xbar0, pbar0 = o.backward(ubar, np.zeros_like(svbar))
+    assert np.abs(pbar - pbar0).max() > 1e-3 * np.abs(pbar0).max()       # the term is not negligible in what is being checked
+    eps = 1e-6
+    for idx in rng.choice(len(p), 14, replace=False):
+        pp, pm = p.copy(), p.copy()
+        pp[idx] += eps; pm[idx] -= eps
+        fd = (loss(x, pp) - loss(x, pm)) / (2 * eps)
+        assert abs(fd - pbar[idx]) <= 2e-6 * max(1.0, abs(fd)), (idx, fd, pbar[idx])
+    for idx in [(0, 0), (1, 2), (3, 1)]:
+        xp, xm = x.copy(), x.copy()
+        xp[idx] += eps; xm[idx] -= eps
+        fd = (loss(xp, p) - loss(xm, p)) / (2 * eps)
+        assert abs(fd - xbar[idx]) <= 2e-6 * max(1.0, abs(fd)), (idx, fd, xbar[idx])
+
+
 def test_saveat_linear_interpolation_and_its_reverse():
     """The {R,true} call methods: states at the save times (linear interpolant between accepted steps, u0 at t0, the end state
     at t1), as a (B, T, D) array, and the reverse pass for a cotangent of that shape against finite differences."""

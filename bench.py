@@ -370,7 +370,13 @@ def bench_latent_e2e(args):
                        "global_batch": B, "parallelism": "single"}}
 
 
-def bench_nsde(args):
+def bench_nsde_stiff(args):
+    """Config 5 as the reference SHIPS it (experiments/configs/mnist_nsde.yml:6 `type: stiff_est`): AutoSOSRI2(SOSRI2()), the callback records
+    |eigen_est| / 10.6, lambda = 0.1 on its mean (mnist_nsde.jl:51-61)."""
+    return bench_nsde(args, reg_type="stiff_est")
+
+
+def bench_nsde(args, reg_type=None):
     """BASELINE config 5: MNIST neural SDE (experiments/mnist_nsde.jl:70-100), D = 32, drift 32 -> 64 -> 32, diffusion 32 -> 32, SOSRI at
     reltol = abstol = 0.14, B = 512, trajectories = 1 (training); step = ClassifierNSDE loss forward (Dense(784,32) -> one-launch adaptive
     solve -> Dense(32,10), logitcrossentropy + 10 * mean(EEst*dt)) + reverse + ADAM(0.01) update."""
@@ -380,9 +386,12 @@ def bench_nsde(args):
     device = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     B = 512
+    reg_type = reg_type or getattr(args, "nsde_type", None) or "error_est"
+    stiff = reg_type == "stiff_est"
+    solver, lam = ("AutoSOSRI2", 0.1) if stiff else ("SOSRI", 10.0)       # mnist_nsde.jl:45-61: (SOSRI(), lambda 10) / (AutoSOSRI2(SOSRI2()), lambda 0.1)
     g = torch.Generator().manual_seed(1999)
     nsde = rn.TrackedNeuralDSDE(rn.Chain(rn.Dense(32, 64, "tanh", g), rn.Dense(64, 32, "identity", g)), rn.Dense(32, 32, "identity", g), [0.0, 1.0], True,
-                                "SOSRI", save_everystep=False, reltol=0.14, abstol=0.14, save_start=False, max_batch=B, max_attempts=256, seed=1999)
+                                solver, save_everystep=False, reltol=0.14, abstol=0.14, save_start=False, max_batch=B, max_attempts=256, seed=1999)
     model = rn.ClassifierNSDE(rn.Dense(784, 32, "identity", g), nsde, rn.Dense(32, 10, "identity", g), device=device)
     opt = torch.optim.Adam(model.trainable(), lr=0.01) if args.autograd else rn.FluxADAM(model.trainable(), eta=0.01, gamma=1.0e-5)   # Optimiser(InvDecay(1.0e-5), ADAM(0.01)), mnist_nsde.jl
     x = torch.rand(B, 784, generator=g).to(device)
@@ -390,11 +399,12 @@ def bench_nsde(args):
     L = _lib.lib()
     stats = {"att": [], "acc": [], "solve_ms": [], "rev_ms": []}
     nsde_step = [0]
+    last_reg = [0.0]
 
     def step(record):
         if args.autograd:
             opt.zero_grad(set_to_none=True)
-            loss, ce, reg, nfe1, nfe2 = rn.nsde_loss_function(x, y, model, trajectories=1, lam=10.0)
+            loss, ce, reg, nfe1, nfe2 = rn.nsde_loss_function(x, y, model, trajectories=1, lam=lam, func=reg_type)
             loss.backward()
             # Optimiser(InvDecay(1e-5), ADAM(0.01)): InvDecay scales the gradient by 1 / (1 + gamma n) in front of ADAM (the C-ABI leg's rn.FluxADAM does the same)
             nsde_step[0] += 1
@@ -403,10 +413,11 @@ def bench_nsde(args):
                     if p_.grad is not None:
                         p_.grad.mul_(1.0 / (1.0 + 1.0e-5 * nsde_step[0]))
         else:   # the same loss and gradients without a tape library in the loop (nsde.fused_nsde_loss_and_grad)
-            loss, ce, reg, nfe1, nfe2 = rn.fused_nsde_loss_and_grad(model, x, y, trajectories=1, lam=10.0)
+            loss, ce, reg, nfe1, nfe2 = rn.fused_nsde_loss_and_grad(model, x, y, trajectories=1, lam=lam, func=reg_type)
         opt.step()
         if record:
-            h = nsde._handles[0][0]
+            last_reg[0] = float(reg)
+            h = next(iter(nsde._handles.values()))[0]
             a, b, na, nc = C.c_float(0), C.c_float(0), C.c_int32(0), C.c_int32(0)
             L.rnde_nsde_timing(h.ptr, C.byref(a), C.byref(b), C.byref(na), C.byref(nc))
             stats["att"].append(na.value); stats["acc"].append(nc.value); stats["solve_ms"].append(a.value); stats["rev_ms"].append(b.value)
@@ -429,20 +440,20 @@ def bench_nsde(args):
     ev = None
     try:
         nsde2 = rn.TrackedNeuralDSDE(rn.Chain(rn.Dense(32, 64, "tanh", g), rn.Dense(64, 32, "identity", g)), rn.Dense(32, 32, "identity", g), [0.0, 1.0], True,
-                                     "SOSRI", save_everystep=False, reltol=0.14, abstol=0.14, save_start=False, max_batch=10 * B, max_attempts=256, seed=1999)
+                                     solver, save_everystep=False, reltol=0.14, abstol=0.14, save_start=False, max_batch=10 * B, max_attempts=256, seed=1999)
         model2 = rn.ClassifierNSDE(rn.Dense(784, 32, "identity", g), nsde2, rn.Dense(32, 10, "identity", g), device=device)
         with torch.no_grad():
             for k_, v_ in zip(model2.trainable(), model.trainable()):
                 k_.copy_(v_)                       # the weights the timed steps above trained
             reps = max(5, args.steps // 2)
             for _ in range(3):
-                model2(x, trajectories=10, func="error_est")
+                model2(x, trajectories=10, func=reg_type)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            nfe_e = [model2(x, trajectories=10, func="error_est")[1] for _ in range(reps)]
+            nfe_e = [model2(x, trajectories=10, func=reg_type)[1] for _ in range(reps)]
             torch.cuda.synchronize()
             el2 = time.perf_counter() - t0
-        h2 = nsde2._handles[0][0]
+        h2 = next(iter(nsde2._handles.values()))[0]
         a, b, na, nc = C.c_float(0), C.c_float(0), C.c_int32(0), C.c_int32(0)
         L.rnde_nsde_timing(h2.ptr, C.byref(a), C.byref(b), C.byref(na), C.byref(nc))
         ev = {"what": "ClassifierNSDE evaluation call, trajectories = 10: Dense(784,32) -> ONE adaptive solve over 5,120 columns (320 workgroups, one error norm) -> "
@@ -457,8 +468,9 @@ def bench_nsde(args):
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic (library Philox noise)",
             "mean_nfe1": sum(a for a, _ in nf) / len(nf), "mean_nfe2": sum(b for _, b in nf) / len(nf),
             "attempts_per_step": att, "accepted_per_step": acc, "solve_ms": sum(stats["solve_ms"]) / 3, "rev_sweep_ms": sum(stats["rev_ms"]) / 3,
-            "config": {"workload": "MNIST NSDE regularized (error_est, lambda 10), SOSRI reltol=abstol=0.14, B=512, trajectories=1, diagonal noise; "
-                                   "step = ClassifierNSDE loss fwd + reverse + InvDecay/ADAM update"},
+            "config": {"workload": f"MNIST NSDE regularized ({reg_type}, lambda {lam:g}), {'AutoSOSRI2(SOSRI2())' if stiff else 'SOSRI'} reltol=abstol=0.14, B=512, trajectories=1, "
+                                   "diagonal noise; step = ClassifierNSDE loss fwd + reverse + InvDecay/ADAM update"},
+            "mean_saveval_last_step": last_reg[0] / lam if lam else None,
             "roofline": {"bound": "mfma", "achieved": flops / (us_att * 1e-6) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                          "frac": flops / (us_att * 1e-6) / 1e12 / MFMA_F32_PEAK_TF, "traffic": None,
                          "kernel": "rnde_sde_solve_mw_kernel: the WHOLE adaptive solve = 1 launch, one workgroup of four waves per 16-column tile; "
@@ -496,6 +508,7 @@ def main():
                     "kernel over peer-mapped windows (no RCCL: it refuses two ranks on one GPU); the N > 1 code path on a 1-GPU box, not a throughput claim")
     ap.add_argument("--global-batch", type=int, default=0, help="STRONG scaling: the global batch is fixed (e.g. 4096) and split evenly over the ranks "
                     "(per-rank batch = G / world, \"scaling\": \"strong\"); default 0 = weak scaling at --batch per rank")
+    ap.add_argument("--nsde-type", default="error_est", choices=["error_est", "stiff_est"], help="--workload nsde: the regulariser (experiments/configs/mnist_nsde.yml `type`; the reference ships stiff_est)")
     ap.add_argument("--workload", default="mnist", choices=["mnist", "latent", "latent_e2e", "nsde"], help="mnist = BASELINE.json's metric (default); latent = config 4 (dynamics only); "
                     "latent_e2e = config 4 with the whole model around the solve; nsde = config 5")
     args = ap.parse_args()
@@ -778,7 +791,7 @@ def main():
         if world == 1 and not args.no_extras and not use_dist:
             sub = argparse.Namespace(steps=max(3, args.steps // 2), warmup=2, autograd=args.autograd)
             others = {}
-            for name, fn in (("latent_config4", bench_latent), ("latent_e2e", bench_latent_e2e), ("nsde_config5", bench_nsde)):
+            for name, fn in (("latent_config4", bench_latent), ("latent_e2e", bench_latent_e2e), ("nsde_config5", bench_nsde), ("nsde_config5_stiff_est", bench_nsde_stiff)):
                 try:
                     others[name] = fn(sub)
                 except Exception as e:      # a secondary record must never cost the headline line

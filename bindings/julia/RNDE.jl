@@ -284,6 +284,7 @@ struct NsdeConfig   # mirrors rnde_nsde_config
     device::Int32
     beta1::Float32; beta2::Float32; gamma::Float32; qmin::Float32; qmax::Float32; qoldinit::Float32; delta::Float32
     generic::Int32
+    stability_size::Float32      # RNDE_REG_STIFF: 0 = alg_stability_size(SOSRI2()) = 10.6
 end
 
 mutable struct NsdeHandle
@@ -424,7 +425,7 @@ function nsde_config_for(drift_dims::Vector{Int}, drift_acts::Vector{Int}, diff_
     t9(v) = ntuple(i -> Int32(i <= length(v) ? v[i] : 0), 9)
     t8(v) = ntuple(i -> Int32(i <= length(v) ? v[i] : 0), 8)
     NsdeConfig(length(drift_acts), t9(drift_dims), t8(drift_acts), length(diff_acts), t9(diff_dims), t8(diff_acts), max_batch, solver, reltol, abstol,
-               regularize, 1, max_attempts, device, 0f0, 0f0, 0f0, 0f0, 0f0, 0f0, 0f0, 0)
+               regularize, 1, max_attempts, device, 0f0, 0f0, 0f0, 0f0, 0f0, 0f0, 0f0, 0, 0f0)
 end
 
 # ---- one training-step gradient in one call ------------------------------------------------------------

@@ -357,7 +357,10 @@ typedef struct {
     int32_t max_batch;                          /* largest B (= batch x trajectories) any call will pass */
     int32_t solver;                             /* rnde_sde_solver: the tableau */
     float   reltol, abstol;                     /* experiments/mnist_nsde.jl:79-80 */
-    int32_t regularize;                         /* RNDE_REG_NONE or RNDE_REG_ERR (func = EEst*dt, neural_sde.jl:87) */
+    int32_t regularize;                         /* what the saving callback records per accepted step: RNDE_REG_NONE, RNDE_REG_ERR (func = EEst*dt,
+                                                 * neural_sde.jl:87, experiments/mnist_nsde.jl:48) or RNDE_REG_STIFF (|eigen_est| / stability_size,
+                                                 * mnist_nsde.jl:51-61 -- what the shipped configs/mnist_nsde.yml:6 selects; SOSRI2 only:
+                                                 * eigen_est = rms(k4 - k3) / rms(H0_4 - H0_3), the estimate AutoSOSRI2(SOSRI2()) fills) */
     int32_t cb_save_start;                      /* 1: the saving callback also fires at initialisation (pushes 0) */
     int32_t max_attempts;
     int32_t device;
@@ -366,6 +369,8 @@ typedef struct {
     float   beta1, beta2, gamma, qmin, qmax, qoldinit, delta;
     int32_t generic;                            /* 1 = never use the instantiations with the reference's shape (32 -> 64 -> 32, 32 -> 32)
                                                  * as compile-time constants (A/B runs, parity tests of the generic kernels) */
+    float   stability_size;                     /* RNDE_REG_STIFF: the constant the estimate is divided by; 0 = StochasticDiffEq.alg_stability_size(SOSRI2())
+                                                 * = 10.6 (mnist_nsde.jl:54-55) */
 } rnde_nsde_config;
 
 typedef struct rnde_nsde rnde_nsde;

@@ -24,7 +24,7 @@ class NsdeConfig(C.Structure):
                 ("max_batch", C.c_int32), ("solver", C.c_int32), ("reltol", C.c_float), ("abstol", C.c_float),
                 ("regularize", C.c_int32), ("cb_save_start", C.c_int32), ("max_attempts", C.c_int32), ("device", C.c_int32),
                 ("beta1", C.c_float), ("beta2", C.c_float), ("gamma", C.c_float), ("qmin", C.c_float), ("qmax", C.c_float),
-                ("qoldinit", C.c_float), ("delta", C.c_float), ("generic", C.c_int32)]
+                ("qoldinit", C.c_float), ("delta", C.c_float), ("generic", C.c_int32), ("stability_size", C.c_float)]
 
 
 class LatentConfig(C.Structure):
@@ -32,7 +32,7 @@ class LatentConfig(C.Structure):
 
 
 ODE_SOLVER = {"Tsit5": 0, "AutoTsit5": 0, "DP5": 1, "DOP853": 2}
-SDE_SOLVER = {"SOSRI": 0, "SRIW1": 1, "SOSRI2": 2}
+SDE_SOLVER = {"SOSRI": 0, "SRIW1": 1, "SOSRI2": 2, "AutoSOSRI2": 2}      # AutoSOSRI2(SOSRI2()) (mnist_nsde.jl:60): SOSRI2's trajectory + integrator.eigen_est
 
 
 class RndeError(RuntimeError):

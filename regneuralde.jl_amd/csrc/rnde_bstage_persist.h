@@ -218,6 +218,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
 #pragma unroll
             for (int s = 1; s < 7; ++s) { acc += tsBt(s) * kq[s]; if (s < 5) g6 += tsA(5, s) * kq[s]; }
             const f32x4 k6 = kq[5], k7 = kq[6];
+            BSTAMP(45);      // (the seven k arrays of the record have arrived: everything before this stamp since 42 is waiting for the tape)
             f32x4 uin = {0.f, 0.f, 0.f, 0.f}, k1in = {0.f, 0.f, 0.f, 0.f};
             const bool sv_mode = Q.nsave > 0;
             if (accepted) {
@@ -494,6 +495,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
             float* o = Bq.bpart + ((size_t)(n & 1) * Bq.bpart_n + wg) * 4;
             o[0] = o0; o[1] = o1; o[2] = o2; o[3] = 0.f;
         }
+        BSTAMP(35);
     }
 }
 

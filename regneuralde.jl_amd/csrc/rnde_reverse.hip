@@ -375,7 +375,8 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
         fprintf(stderr, "persistent reverse attempt (workgroup 0 thread 0, cycles): START %lld (entry->weights issued %lld, ->w1t %lld, ->array loads issued %lld, finish_attempt_scalars %lld, scalar chain %lld, vector part %lld), its phase D + put %lld\n", (long long)(hst[1]-hst[0]), (long long)(hst[43]-hst[0]), (long long)(hst[44]-hst[43]), (long long)(hst[40]-hst[44]), (long long)(hst[41]-hst[40]), (long long)(hst[42]-hst[41]), (long long)(hst[1]-hst[42]), (long long)(hst[2]-hst[1]));
         for (int st = 0; st < 6; ++st) { const unsigned long long* q = hst + 3 + 5 * st; const unsigned long long prev = st == 0 ? hst[2] : hst[7 + 5 * (st - 1)];
             fprintf(stderr, "  stage j=%d: poll %lld A %lld B %lld C %lld D+put %lld\n", 6 - st, (long long)(q[0]-prev), (long long)(q[1]-q[0]), (long long)(q[2]-q[1]), (long long)(q[3]-q[2]), st < 5 ? (long long)(q[4]-q[3]) : 0LL); }
-        fprintf(stderr, "  total %lld cycles\n", (long long)(hst[34]-hst[0]));
+        fprintf(stderr, "  total %lld cycles to the end of stage 1, END (reduction of the 21 partial sums) %lld; in START's vector part the wait for the record's k arrays %lld\n",
+                (long long)(hst[34]-hst[0]), (long long)(hst[35]-hst[34]), (long long)(hst[45]-hst[42]));
     }
 #endif
     if (!sync) {   // rnde_node_backward_async: no host round trip; the health words are looked at by the next synchronising call

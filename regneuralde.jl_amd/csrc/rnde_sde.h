@@ -40,6 +40,7 @@ struct SriTableau {   // lower-triangular 4x4 stage matrices (row = stage) and w
 struct SdeMeta {   // one per attempted step
     float t, dt, eest, q;
     int accepted, rec, sv_lo, sv_hi;   // saveat indices [sv_lo, sv_hi) this (accepted) step covers
+    float n1, n2;                      // reg_kind 2: rms(k4 - k3), rms(H0_4 - H0_3) -- eigen_est = n1 / n2 (filled by rnde_sde_eig_reduce_kernel behind the solve)
 };
 struct SdeFinal {  // written once, by workgroup 0, when the solve ends
     int n_att, n_acc, status, n_draws;
@@ -63,6 +64,9 @@ struct SdeParams {
     const float* replay;             // optional: [n_replay][2] (dt, accepted)
     int n_replay;
     const float* sv_t; int nsave; float* sv_out;   // saveat ({R,true} methods, neural_sde.jl:44-61,:84-113): times (device), count, output D x T x B
+    float* eigpart;                  // reg_kind 2: [max_attempts][2][nwg] per-workgroup partial sums of (k4 - k3)^2 and (H0_4 - H0_3)^2; the controller does not need
+                                     // them, so they do not go through the meeting: a small kernel behind the solve sums them in a fixed order into meta[n].n1 / .n2
+    float stab;                      // reg_kind 2: alg_stability_size (10.6 for SOSRI2)
     int D, B, ntiles, nwg, n_pool, n_slots, max_attempts, keep_tape, reg_kind;
     unsigned epoch;
     int xch_local;                   // 1: every workgroup of the launch sits on ONE XCD (pinned by block index, verified by the host): the meeting goes through that L2
@@ -132,12 +136,13 @@ __device__ __forceinline__ void sde_diff(const ChainGeo& G, const float* FR, con
 template <int NKD, int FIXH = 0>
 __device__ __forceinline__ float sde_attempt(const SdeParams& Q, const float* FRf, const float* FRg, const float (&up)[NKD], float dt,
                                              float sqdt, const float (&dW)[NKD], const float (&dZ)[NKD], float (&k)[4][NKD],
-                                             float (&g)[4][NKD], float (&un)[NKD], bool colok, int gq, int lane) {
+                                             float (&g)[4][NKD], float (&un)[NKD], bool colok, int gq, int lane, float (&eig)[2]) {
     const SriTableau& T = Q.T;
-    float chi2[NKD];
+    eig[0] = 0.f; eig[1] = 0.f;
+    float chi2[NKD], hd[NKD];      // hd: H0_4 - H0_3, the difference of the last two drift inputs as the stage loop forms them (reg_kind 2)
     const float sqrt3 = 1.7320508075688772f;
 #pragma unroll
-    for (int q = 0; q < NKD; ++q) chi2[q] = (dW[q] + dZ[q] / sqrt3) / 2.f;
+    for (int q = 0; q < NKD; ++q) { chi2[q] = (dW[q] + dZ[q] / sqrt3) / 2.f; hd[q] = 0.f; }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         float h0[NKD], h1[NKD];
@@ -152,6 +157,7 @@ __device__ __forceinline__ float sde_attempt(const SdeParams& Q, const float* FR
                 }
             h0[q] = s ? up[q] + dt * a0 + chi2[q] * b0 : up[q];
             h1[q] = s ? up[q] + dt * a1 + sqdt * b1 : up[q];
+            if (Q.reg_kind == 2) { if (s == 2) hd[q] = h0[q]; if (s == 3) hd[q] = h0[q] - hd[q]; }
         }
         sde_drift<NKD, FIXH>(Q.Gf, FRf, h0, k[s], lane);
         sde_diff<NKD, FIXH>(Q.Gg, FRg, h1, g[s], lane);
@@ -177,6 +183,10 @@ __device__ __forceinline__ float sde_attempt(const SdeParams& Q, const float* FR
             const float sc = Q.abstol + fmaxf(fabsf(up[q]), fabsf(u)) * Q.reltol;
             const float r = (Q.delta * E1 + E2) / sc;
             part += r * r;
+            if (Q.reg_kind == 2) {      // the stiffness estimate's two norms (StochasticDiffEq sri.jl: k4 - k3 over H0_4 - H0_3, the last two drift stages)
+                const float v1 = k[3][q] - k[2][q], v2 = hd[q];
+                eig[0] += v1 * v1; eig[1] += v2 * v2;
+            }
         }
     }
     return part;
@@ -534,13 +544,20 @@ __global__ __launch_bounds__(64 * kCW) void rnde_sde_solve_kernel(const SdeParam
 
         const float sqdt = sqrtf(fabsf(dt));
         float k[4][NKD], g[4][NKD], un[NKD];
-        float part = sde_attempt<NKD, FIXH>(Q, FRf, FRg, up, dt, sqdt, dW, dZ, k, g, un, colok, gq, lane);
+        float eig[2];
+        float part = sde_attempt<NKD, FIXH>(Q, FRf, FRg, up, dt, sqdt, dW, dZ, k, g, un, colok, gq, lane, eig);
         part = wave_sum_f(part);
-        if (lane == 0) RED[wave] = part;
+        if (Q.reg_kind == 2) { eig[0] = wave_sum_f(eig[0]); eig[1] = wave_sum_f(eig[1]); }
+        if (lane == 0) { RED[wave] = part; if (Q.reg_kind == 2) { RED[2 * kCW + wave] = eig[0]; RED[3 * kCW + wave] = eig[1]; } }
         __syncthreads();
         if (wave == 0) {
             float mine[1] = {0.f};
             for (int w = 0; w < kCW; ++w) mine[0] += RED[w];
+            if (Q.reg_kind == 2 && lane == 0) {      // this workgroup's share of the two norms of attempt n (summed behind the solve: rnde_sde_eig_reduce_kernel)
+                float e0 = 0.f, e1 = 0.f;
+                for (int w = 0; w < kCW; ++w) { e0 += RED[2 * kCW + w]; e1 += RED[3 * kCW + w]; }
+                Q.eigpart[((size_t)n * 2) * Q.nwg + wg] = e0; Q.eigpart[((size_t)n * 2 + 1) * Q.nwg + wg] = e1;
+            }
             double o[1];
             const bool ok = sde_exchange<1>(Q, seq, mine, o, wg, lane);
             if (lane == 0) {
@@ -674,7 +691,8 @@ __global__ __launch_bounds__(64 * kCW) void rnde_sde_attempt_kernel(const SdePar
     float up[NKD], dW[NKD], dZ[NKD], k[4][NKD], g[4][NKD], un[NKD];
 #pragma unroll
     for (int q = 0; q < NKD; ++q) { up[q] = ldc(uprev, Q.D, gcol, 4 * q + gq, colok); dW[q] = ldc(dWc, Q.D, gcol, 4 * q + gq, colok); dZ[q] = ldc(dZc, Q.D, gcol, 4 * q + gq, colok); }
-    float part = sde_attempt<NKD>(Q, FRf, FRg, up, dt, sqrtf(fabsf(dt)), dW, dZ, k, g, un, colok, gq, lane);
+    float eig[2];
+    float part = sde_attempt<NKD>(Q, FRf, FRg, up, dt, sqrtf(fabsf(dt)), dW, dZ, k, g, un, colok, gq, lane, eig);
     const size_t A = (size_t)Q.D * Q.B;
 #pragma unroll
     for (int q = 0; q < NKD; ++q) if (colok && 4 * q + gq < Q.D) {
@@ -755,6 +773,20 @@ __device__ __forceinline__ void sde_diff_bwd(const BChainParams& C, const float*
     }
 }
 
+// ---- reg_kind 2: the two norms of the stiffness estimate, summed over the workgroups' partials in a FIXED order (lane-strided, then the wave
+// tree) behind the solve -- one wave per attempted step; the controller never needed them, so the solve's meeting does not carry them.
+__global__ __launch_bounds__(64) void rnde_sde_eig_reduce_kernel(const SdeParams Q) {
+    const int n = blockIdx.x, lane = threadIdx.x;
+    if (n >= Q.fin->n_att) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = lane; i < Q.nwg; i += 64) { s1 += (double)Q.eigpart[((size_t)n * 2) * Q.nwg + i]; s2 += (double)Q.eigpart[((size_t)n * 2 + 1) * Q.nwg + i]; }
+    s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+    if (lane == 0) {
+        const double N = (double)Q.D * (double)Q.B;
+        Q.meta[n].n1 = (float)sqrt(s1 / N); Q.meta[n].n2 = (float)sqrt(s2 / N);
+    }
+}
+
 // ---- reverse sweep: every accepted step backwards, one launch, no meeting between workgroups ----------------------------------
 struct SdeBwdParams {
     SdeParams F;
@@ -816,6 +848,15 @@ __global__ __launch_bounds__(64 * kCW) void rnde_sde_bwd_kernel(const SdeBwdPara
         }
         const double eb = (Q.reg_kind == 1) ? (double)Bq.svb_acc[a] * (double)dt : 0.0;   // saveval = EEst * dt, dt constant
         const float coef = m.eest > 0.f ? (float)(eb / (N * (double)m.eest)) : 0.f;
+        // reg_kind 2: saveval = |n1 / n2| / stab, n1 = rms(k4 - k3), n2 = rms(H0_4 - H0_3) (zero / NaN estimates are recorded as the constant 0):
+        // k4bar += c1 v1, k3bar -= c1 v1; the drift inputs of stages 4 / 3 get +- c2 v2 on top of what the drift's reverse hands back
+        float c1 = 0.f, c2 = 0.f;
+        if (Q.reg_kind == 2 && m.n1 > 0.f && m.n2 > 0.f) {
+            const double eigb = (double)Bq.svb_acc[a] / (double)Q.stab;
+            c1 = (float)(eigb / (N * (double)m.n1 * (double)m.n2));
+            c2 = (float)(-eigb * (double)m.n1 / (N * (double)m.n2 * (double)m.n2 * (double)m.n2));
+        }
+        float v2[NKD];
 #pragma unroll
         for (int q = 0; q < NKD; ++q) {
             up[q] = R[q * 64]; dW[q] = R[as + q * 64]; dZ[q] = R[2 * as + q * 64];
@@ -849,6 +890,15 @@ __global__ __launch_bounds__(64 * kCW) void rnde_sde_bwd_kernel(const SdeBwdPara
                 gb[j][q] = (w * T.beta1[j] + chi1 * T.beta2[j]) * unb + (chi2[q] * T.beta3[j] + chi3 * T.beta4[j]) * e2b;
             }
             upb[q] = upv + svup[q];
+            v2[q] = 0.f;
+            if (c1 != 0.f && colok && 4 * q + gq < Q.D) {
+                const float v1 = k[3][q] - k[2][q];
+                kb[3][q] += c1 * v1; kb[2][q] -= c1 * v1;
+                float a3 = 0.f, b3 = 0.f, a2 = 0.f, b2 = 0.f;      // H0_4 - H0_3 as the forward formed it: the two stage inputs, then their difference
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { a3 += T.A0[12 + j] * k[j][q]; b3 += T.B0[12 + j] * g[j][q]; if (j < 2) { a2 += T.A0[8 + j] * k[j][q]; b2 += T.B0[8 + j] * g[j][q]; } }
+                v2[q] = (up[q] + dt * a3 + chi2[q] * b3) - (up[q] + dt * a2 + chi2[q] * b2);
+            }
         }
 #pragma unroll
         for (int s = 3; s >= 0; --s) {
@@ -869,6 +919,7 @@ __global__ __launch_bounds__(64 * kCW) void rnde_sde_bwd_kernel(const SdeBwdPara
             sde_drift_bwd<NKD, FIXH>(Cf, FRf, h0, k[s], kb[s], hb, slf, lane);
 #pragma unroll
             for (int q = 0; q < NKD; ++q) {
+                if (s >= 2) hb[q] += (s == 3 ? c2 : -c2) * v2[q];
                 upb[q] += hb[q];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) if (j < s) { kb[j][q] += dt * T.A0[4 * s + j] * hb[q]; gb[j][q] += chi2[q] * T.B0[4 * s + j] * hb[q]; }

@@ -44,6 +44,7 @@ struct rnde_nsde {
     SdeFinal *fin = nullptr, *h_fin = nullptr;
     unsigned long long* xch = nullptr;
     unsigned* abort_word = nullptr;
+    float* eigpart = nullptr;      // RNDE_REG_STIFF: [max_attempts][2][workgroups]
     float *svb = nullptr, *h_svb = nullptr, *slab_f = nullptr, *slab_g = nullptr, *wslab = nullptr, *wslab_r = nullptr, *ev_t = nullptr;
     size_t slab_f_floats = 0, slab_g_floats = 0, ev_t_n = 0;
     float *part = nullptr, *h_part = nullptr;
@@ -151,10 +152,17 @@ extern "C" rnde_status rnde_nsde_create(const rnde_nsde_config* c, rnde_nsde** o
     if (c->drift_dims[c->drift_layers] != D || c->diff_dims[0] != D || c->diff_dims[c->diff_layers] != D) {
         g_nsde_create_err = "drift and diffusion must map D -> D (diagonal noise)"; return RNDE_ERR_BAD_ARG;
     }
-    if (c->solver < RNDE_SDE_SOSRI || c->solver > RNDE_SDE_SOSRI2 || (c->regularize != RNDE_REG_NONE && c->regularize != RNDE_REG_ERR) ||
+    if (c->solver < RNDE_SDE_SOSRI || c->solver > RNDE_SDE_SOSRI2 ||
+        (c->regularize != RNDE_REG_NONE && c->regularize != RNDE_REG_ERR && c->regularize != RNDE_REG_STIFF) ||
         c->max_batch < 1 || c->max_attempts < 1 || c->max_attempts > 4000) {
         g_nsde_create_err = "solver / regularize / max_batch / max_attempts (<= 4000) out of range"; return RNDE_ERR_BAD_ARG;
     }
+    if (c->regularize == RNDE_REG_STIFF && c->solver != RNDE_SDE_SOSRI2) {
+        // StochasticDiffEq fills integrator.eigen_est only under a composite algorithm whose first method is SOSRI2 (AutoSOSRI2(SOSRI2()),
+        // experiments/mnist_nsde.jl:60): its last two drift stages share one time, which is what makes the quotient an estimate of |J|
+        g_nsde_create_err = "RNDE_REG_STIFF (the stiffness estimate of the SRI step) is defined for RNDE_SDE_SOSRI2 only"; return RNDE_ERR_BAD_ARG;
+    }
+    if (!(c->stability_size >= 0.f)) { g_nsde_create_err = "stability_size must be >= 0 (0 = 10.6)"; return RNDE_ERR_BAD_ARG; }
     rnde_nsde* h = new rnde_nsde();
     h->cfg = *c; h->D = D; h->Gf = Gf; h->Gg = Gg;
     h->Pf = chain_params(c->drift_layers, c->drift_dims); h->Pg = chain_params(c->diff_layers, c->diff_dims); h->P = h->Pf + h->Pg;
@@ -196,6 +204,7 @@ extern "C" rnde_status rnde_nsde_create(const rnde_nsde_config* c, rnde_nsde** o
     ok &= dm((void**)&h->xch, (size_t)(c->max_attempts + 4) * 2 * h->xch_wg * 8);
     ok &= dm((void**)&h->svb, (size_t)(c->max_attempts + 1) * 4) && dm((void**)&h->replay, (size_t)(c->max_attempts + 1) * 8);
     ok &= dm((void**)&h->part, (size_t)h->nwg_max * 4);
+    if (c->regularize == RNDE_REG_STIFF) ok &= dm((void**)&h->eigpart, (size_t)c->max_attempts * 2 * h->xch_wg * 4);      // per-workgroup partials of the estimate's two norms
     ok &= hipHostMalloc((void**)&h->h_meta, (size_t)(c->max_attempts + 1) * sizeof(SdeMeta)) == hipSuccess;
     ok &= hipHostMalloc((void**)&h->h_acc_meta, (size_t)(c->max_attempts + 1) * sizeof(SdeMeta)) == hipSuccess;
     ok &= hipHostMalloc((void**)&h->h_fin, sizeof(SdeFinal)) == hipSuccess;
@@ -215,7 +224,7 @@ extern "C" rnde_status rnde_nsde_create(const rnde_nsde_config* c, rnde_nsde** o
 
 extern "C" void rnde_nsde_destroy(rnde_nsde* h) {
     if (!h) return;
-    void* d[] = {h->frags_f, h->frags_g, h->slots, h->tape, h->noise, h->replay, h->meta, h->acc_meta, h->fin, h->xch, h->abort_word, h->svb,
+    void* d[] = {h->eigpart, h->frags_f, h->frags_g, h->slots, h->tape, h->noise, h->replay, h->meta, h->acc_meta, h->fin, h->xch, h->abort_word, h->svb,
                  h->slab_f, h->slab_g, h->wslab, h->wslab_r, h->ev_t, h->part, h->sv_t_dev, h->head_ws, h->cg_ws, h->xcc};
     for (void* p : d) if (p) (void)hipFree(p);
     void* hd[] = {h->h_meta, h->h_acc_meta, h->h_fin, h->h_svb, h->h_part, h->h_xcc};
@@ -235,6 +244,7 @@ static SdeParams sde_params(rnde_nsde* h, const float* x, const float* noise, in
     Q.epoch = h->epoch; Q.t0 = t0; Q.t1 = t1; Q.reltol = h->cfg.reltol; Q.abstol = h->cfg.abstol;
     Q.beta1 = h->beta1; Q.beta2 = h->beta2; Q.gamma = h->gamma; Q.qmin = h->qmin; Q.qmax = h->qmax; Q.qoldinit = h->qoldinit; Q.delta = h->delta;
     Q.order = h->order;
+    Q.eigpart = h->eigpart; Q.stab = h->cfg.stability_size > 0.f ? h->cfg.stability_size : 10.6f;      // StochasticDiffEq.alg_stability_size(SOSRI2())
     return Q;
 }
 
@@ -367,6 +377,10 @@ static rnde_status nsde_forward_impl(rnde_nsde* h, const float* x_dev, const flo
         e = h->fix ? launch_solve<8, 16>(h, Q, s)
                    : (h->NKD == 4 ? launch_solve<4>(h, Q, s) : (h->NKD == 8 ? launch_solve<8>(h, Q, s) : launch_solve<16>(h, Q, s)));
     SCHK(h, e);
+    if (h->cfg.regularize == RNDE_REG_STIFF) {      // the two norms of every attempt's stiffness estimate -> meta[n].n1 / .n2 (fixed-order sums of the workgroups' partials)
+        hipLaunchKernelGGL(rnde_sde_eig_reduce_kernel, dim3(h->cfg.max_attempts), dim3(64), 0, s, Q);
+        SCHK(h, hipGetLastError());
+    }
     SCHK(h, hipEventRecord(h->tev[1], s));
     h->tev_f = true;
     SCHK(h, hipMemcpyAsync(h->h_fin, h->fin, sizeof(SdeFinal), hipMemcpyDeviceToHost, s));
@@ -393,10 +407,22 @@ static rnde_status nsde_forward_impl(rnde_nsde* h, const float* x_dev, const flo
     if (nfe2_out) *nfe2_out = 2 + 4 * (int64_t)F.n_att;
     int nsv = 0;
     h->sv_index.clear();
-    if (h->cfg.regularize == RNDE_REG_ERR) {
-        if (h->cfg.cb_save_start) { if (saveval_host) saveval_host[nsv] = 0.f; ++nsv; }
+    if (h->cfg.regularize != RNDE_REG_NONE) {
+        // the experiment's save_func on the integrator after every accepted step (mnist_nsde.jl:48: EEst * dt; :53-58: |eigen_est| / stability_size, zero
+        // and NaN estimates recorded as 0), and once at the callback's initialisation (EEst = 1, dt = 0, eigen_est = 1)
+        const bool stiff = h->cfg.regularize == RNDE_REG_STIFF;
+        auto value = [&](float eest, float dt, float eigen) {
+            if (!stiff) return eest * dt;
+            const float a = std::fabs(eigen);
+            return (a == 0.f || a != a) ? 0.f : a / Q.stab;
+        };
+        if (h->cfg.cb_save_start) { if (saveval_host) saveval_host[nsv] = value(1.f, 0.f, 1.f); ++nsv; }
         for (int i = 0; i < F.n_att; ++i)
-            if (h->h_meta[i].accepted) { if (saveval_host) saveval_host[nsv] = h->h_meta[i].eest * h->h_meta[i].dt; h->sv_index.push_back(nsv++); }
+            if (h->h_meta[i].accepted) {
+                const SdeMeta& m = h->h_meta[i];
+                if (saveval_host) saveval_host[nsv] = value(m.eest, m.dt, stiff ? m.n1 / m.n2 : 0.f);
+                h->sv_index.push_back(nsv++);
+            }
     }
     h->n_saveval = nsv;
     if (n_saveval_out) *n_saveval_out = nsv;

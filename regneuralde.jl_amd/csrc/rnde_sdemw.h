@@ -37,7 +37,7 @@ __global__ __launch_bounds__(kSmwThreads) void rnde_sde_solve_mw_kernel(const Sd
     float* KO = smem + 2048;          // [32][16] drift output
     float* GO = smem + 2560;          // [32][16] diffusion output
     float* scratch = smem + 3072;
-    float* RED = scratch;                                   // [2][4]
+    float* RED = scratch;                                   // [4][4]: error-norm partials, initial-step partials, the two norms of the stiffness estimate
     SdeDecision* DEC = (SdeDecision*)(scratch + 16);       // 16-byte aligned
     SdeStacks* STK = (SdeStacks*)(scratch + 16 + 32);
     SdeOp* OPS = (SdeOp*)(scratch + 16 + 32 + 8);
@@ -259,13 +259,13 @@ __global__ __launch_bounds__(kSmwThreads) void rnde_sde_solve_mw_kernel(const Sd
 
         const float sqdt = sqrtf(fabsf(dt));
         float k[4][NKD], g[4][NKD], un[NKD];
-        float part = 0.f;
+        float part = 0.f, eig0 = 0.f, eig1 = 0.f;
         {   // one attempted SRI step (sde_attempt of rnde_sde.h on this thread's elements; the network evaluations through LDS)
             const SriTableau& T = Q.T;
-            float chi2[NKD];
+            float chi2[NKD], hd[NKD];      // hd: H0_4 - H0_3 (reg_kind 2: the denominator of the stiffness estimate)
             const float sqrt3 = 1.7320508075688772f;
 #pragma unroll
-            for (int q = 0; q < NKD; ++q) chi2[q] = (dW[q] + dZ[q] / sqrt3) / 2.f;
+            for (int q = 0; q < NKD; ++q) { chi2[q] = (dW[q] + dZ[q] / sqrt3) / 2.f; hd[q] = 0.f; }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 float h0[NKD], h1[NKD];
@@ -280,6 +280,7 @@ __global__ __launch_bounds__(kSmwThreads) void rnde_sde_solve_mw_kernel(const Sd
                         }
                     h0[q] = s ? up[q] + dt * a0 + chi2[q] * b0 : up[q];
                     h1[q] = s ? up[q] + dt * a1_ + sqdt * b1_ : up[q];
+                    if (Q.reg_kind == 2) { if (s == 2) hd[q] = h0[q]; if (s == 3) hd[q] = h0[q] - hd[q]; }
                 }
                 put_in(h0, h1);
                 eval(k[s], g[s]);
@@ -304,15 +305,22 @@ __global__ __launch_bounds__(kSmwThreads) void rnde_sde_solve_mw_kernel(const Sd
                     const float sc = Q.abstol + fmaxf(fabsf(up[q]), fabsf(u)) * Q.reltol;
                     const float r = (Q.delta * E1 + E2) / sc;
                     part += r * r;
+                    if (Q.reg_kind == 2) { const float v1 = k[3][q] - k[2][q]; eig0 += v1 * v1; eig1 += hd[q] * hd[q]; }
                 }
             }
         }
         part = wave_sum_f(part);
-        if (lane == 0) RED[wave] = part;
+        if (Q.reg_kind == 2) { eig0 = wave_sum_f(eig0); eig1 = wave_sum_f(eig1); }
+        if (lane == 0) { RED[wave] = part; if (Q.reg_kind == 2) { RED[2 * kCW + wave] = eig0; RED[3 * kCW + wave] = eig1; } }
         __syncthreads();
         if (wave == 0) {
             float mine[1] = {0.f};
             for (int w = 0; w < kCW; ++w) mine[0] += RED[w];
+            if (Q.reg_kind == 2 && lane == 0) {      // this workgroup's share of the two norms of attempt n (summed behind the solve: rnde_sde_eig_reduce_kernel)
+                float e0 = 0.f, e1 = 0.f;
+                for (int w = 0; w < kCW; ++w) { e0 += RED[2 * kCW + w]; e1 += RED[3 * kCW + w]; }
+                Q.eigpart[((size_t)n * 2) * Q.nwg + wg] = e0; Q.eigpart[((size_t)n * 2 + 1) * Q.nwg + wg] = e1;
+            }
             double o[1];
             const bool ok = sde_exchange<1>(Q, seq, mine, o, wg, lane);
             if (lane == 0) {
@@ -514,6 +522,12 @@ __global__ __launch_bounds__(kSmwThreads) void rnde_sde_bwd_mw_kernel(const SdeB
         }
         const double eb = (Q.reg_kind == 1) ? (double)Bq.svb_acc[a] * (double)dt : 0.0;   // saveval = EEst * dt, dt constant
         const float coef = m.eest > 0.f ? (float)(eb / (N * (double)m.eest)) : 0.f;
+        float c1 = 0.f, c2 = 0.f, v2[NKD];      // reg_kind 2: the stiffness estimate's cotangents (see rnde_sde_bwd_kernel)
+        if (Q.reg_kind == 2 && m.n1 > 0.f && m.n2 > 0.f) {
+            const double eigb = (double)Bq.svb_acc[a] / (double)Q.stab;
+            c1 = (float)(eigb / (N * (double)m.n1 * (double)m.n2));
+            c2 = (float)(-eigb * (double)m.n1 / (N * (double)m.n2 * (double)m.n2 * (double)m.n2));
+        }
 #pragma unroll
         for (int q = 0; q < NKD; ++q) {
             const float un = unw[q];
@@ -544,6 +558,15 @@ __global__ __launch_bounds__(kSmwThreads) void rnde_sde_bwd_mw_kernel(const SdeB
                 gb[j][q] = (w * T.beta1[j] + chi1 * T.beta2[j]) * unb + (chi2[q] * T.beta3[j] + chi3 * T.beta4[j]) * e2b;
             }
             upb[q] = upv + svup[q];
+            v2[q] = 0.f;
+            if (c1 != 0.f && colok && 16 * q + gq < Q.D) {
+                const float v1 = k[3][q] - k[2][q];
+                kb[3][q] += c1 * v1; kb[2][q] -= c1 * v1;
+                float a3 = 0.f, b3 = 0.f, a2 = 0.f, b2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { a3 += T.A0[12 + j] * k[j][q]; b3 += T.B0[12 + j] * g[j][q]; if (j < 2) { a2 += T.A0[8 + j] * k[j][q]; b2 += T.B0[8 + j] * g[j][q]; } }
+                v2[q] = (up[q] + dt * a3 + chi2[q] * b3) - (up[q] + dt * a2 + chi2[q] * b2);
+            }
         }
 #pragma unroll
         for (int s = 3; s >= 0; --s) {
@@ -619,7 +642,7 @@ __global__ __launch_bounds__(kSmwThreads) void rnde_sde_bwd_mw_kernel(const SdeB
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < NKD; ++q) {
-                const float hbf = HBF[tid + 256 * q], hbg = HBG[tid + 256 * q];
+                const float hbf = HBF[tid + 256 * q] + (s >= 2 ? (s == 3 ? c2 : -c2) * v2[q] : 0.f), hbg = HBG[tid + 256 * q];
                 upb[q] += hbf;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) if (j < s) { kb[j][q] += dt * T.A0[4 * s + j] * hbf; gb[j][q] += chi2[q] * T.B0[4 * s + j] * hbf; }

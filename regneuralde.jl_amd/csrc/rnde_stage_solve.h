@@ -78,6 +78,21 @@ __device__ __forceinline__ bool solve_meet(const SolveSync& Z, const PersistSync
     return true;
 }
 
+// the controller state through LDS: written by one lane, read back by every wave as scalars (twelve words)
+static_assert(sizeof(StepState) == 48, "StepState is twelve 4-byte words");
+__device__ __forceinline__ void solve_state_put(int* ss, const StepState& S) {
+    const int* src = (const int*)&S;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) ss[i] = src[i];
+}
+__device__ __forceinline__ StepState solve_state_get(const int* ss) {
+    StepState S;
+    int* dst = (int*)&S;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) dst[i] = __builtin_amdgcn_readfirstlane(ss[i]);
+    return S;
+}
+
 template <int ACT2>
 __global__ __launch_bounds__(64 * 7) void rnde_stage_solve_kernel(const StageParams Q, const PersistSync Y, const SolveSync Z) {
     const StepParams& P = Q.F;
@@ -89,6 +104,7 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_solve_kernel(const StagePar
     float* RED = GL + kSCB * KG;         // [32]; RED[24] = "a wave of this workgroup gave up"
     double* SUMS = (double*)(RED + 32);  // [4]: the three cross-workgroup sums of the meeting, [3] != 0: the meeting failed
     float* QP = (float*)(SUMS + 4);      // [2] (by attempt parity: a fast wave writes the next one while a slow wave still reads this one): powf(qold, beta2) of the state the running attempt started from (evaluated off the critical path)
+    int* SS = (int*)(QP + 2);            // [12] the controller state before the next attempt, as wave 0 derived it behind the meeting (see solve_state_put / _get)
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     __builtin_assume(w >= 0 && w < 7);
@@ -174,19 +190,22 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_solve_kernel(const StagePar
 #define ZSTAMP(k) do { } while (0)
 #define ZARRIVE(k) do { } while (0)
 #endif
+    // ---- controller: ONE wave per workgroup derives the state before an attempt (wave 0: it holds the meeting's sums in registers and is alone on its
+    // SIMD while wave 4 waits at the barrier), the others pick the twelve words up from LDS.  Round 4 had every wave derive it redundantly from the
+    // sums in LDS: the same function on the same arguments -- the same bits -- at seven times the vector instructions (the controller's float arithmetic,
+    // two pow and the double-precision norms, runs on the vector ALU: this part has no scalar float unit), two waves per SIMD taking turns.
+    const float none[4] = {0.f, 0.f, 0.f, 0.f};
     StepState S{};
+    if (w == 0) {
+        const StepState nop{};
+        S = advance_state_t<true>(P, 0, lane, writer, &P.ctl[0], none, nop, nullptr, nullptr);
+        if (lane == 0) solve_state_put(SS, S);
+    }
+    __syncthreads();
+    S = solve_state_get(SS);
     f32x4 c_un = {0.f, 0.f, 0.f, 0.f};
     for (int n = 0;; ++n) {
         ZSTAMP(0);
-        // ---- controller: the state before attempt n (n > 0: from the sums the meeting of attempt n - 1 left in SUMS) ----
-        {
-            const float none[4] = {0.f, 0.f, 0.f, 0.f};
-            const double sums[3] = {SUMS[0], SUMS[1], SUMS[2]};      // (n = 0: not read)
-            const StepState prev = S;
-            const float qp = QP[n & 1];                              // (n = 0: not read)
-            S = advance_state_t<true>(P, n, lane, writer, &P.ctl[n & 1], none, prev, sums, n > 0 ? &qp : nullptr);
-            if (n > 0 && S.n_acc != prev.n_acc) { c_up = c_un; c_k[0] = c_k[6]; }      // accepted: the step starts from (unew, k7) -- already here
-        }
         // the controller of the NEXT attempt divides by qold^beta2, and qold is known now: wave 3 -- alone on its SIMD -- evaluates the power while
         // the stages run, the others pick it up after the meeting (the barriers in between order the LDS word); same function, same argument, same bits
         if (w == 3 && lane == 0) QP[(n + 1) & 1] = powf(S.qold, P.beta2);
@@ -321,12 +340,21 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_solve_kernel(const StagePar
             for (int i = 0; i < gWT; ++i) { mine[0] += RED[i]; if (three) { mine[1] += RED[8 + i]; mine[2] += RED[16 + i]; } }
             double o[3];
             const bool ok = solve_meet(Z, Y, n, P.nwg, wg, P.reg_kind >= 2 ? 3 : 1, mine, o, lane);
-            if (lane == 0) { SUMS[0] = o[0]; SUMS[1] = o[1]; SUMS[2] = o[2]; if (!ok) SUMS[3] = 1.0; }
             ZSTAMP(5); ZARRIVE(1);
+            // the state before attempt n + 1, from the sums just formed (qold^beta2 of the state this attempt started from: wave 3 left it in QP while
+            // the stages ran; the barrier in front of the meeting ordered it)
+            const float qp = QP[(n + 1) & 1];
+            const StepState nxt = advance_state_t<true>(P, n + 1, lane, writer, &P.ctl[(n + 1) & 1], none, S, o, &qp);
+            if (lane == 0) { solve_state_put(SS, nxt); if (!ok) SUMS[3] = 1.0; }
         }
         __syncthreads();
         ZSTAMP(6);
         if (SUMS[3] != 0.0) return;      // the meeting timed out: abort word raised, the host redoes the solve launch by launch
+        {
+            const StepState nxt = solve_state_get(SS);
+            if (nxt.n_acc != S.n_acc) { c_up = c_un; c_k[0] = c_k[6]; }      // accepted: the next attempt starts from (unew, k7) -- already here
+            S = nxt;
+        }
     }
 }
 

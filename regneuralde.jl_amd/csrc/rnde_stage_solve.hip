@@ -13,7 +13,7 @@ extern "C" hipError_t rnde_launch_stage_solve(const void* stage_params, const vo
     const StageParams& Q = *(const StageParams*)stage_params;
     const PersistSync& Y = *(const PersistSync*)persist_sync;
     const SolveSync& Z = *(const SolveSync*)solve_sync;
-    const size_t lds = sizeof(float) * (2 * kSCB * (16 * 7 + 4) + 32) + 4 * sizeof(double) + 16;
+    const size_t lds = sizeof(float) * (2 * kSCB * (16 * 7 + 4) + 32) + 4 * sizeof(double) + 16 + 12 * sizeof(int);      // HL, GL, RED | SUMS | QP (+ pad) | SS
     const dim3 grid(8 * 7 * ((Q.C + 7) / 8));
     if (act2) hipLaunchKernelGGL((rnde_stage_solve_kernel<1>), grid, dim3(64 * 7), lds, s, Q, Y, Z);
     else hipLaunchKernelGGL((rnde_stage_solve_kernel<0>), grid, dim3(64 * 7), lds, s, Q, Y, Z);

@@ -9,7 +9,10 @@ librnde.so (rnde_nsde_*: the whole adaptive SOSRI solve is one kernel launch).
 With `saveat=` the {R,true} methods run (neural_sde.jl:44-61,:84-113; experiments/sde_toy_problem.jl:50-60): `u` is then the
 (B, T, D) tensor whose memory is exactly the Julia D x T x B array of diffeqsol_to_3dtrackedarray (src/utils.jl:17-19).
 
-Differences inherent to the host language / the device: `func` is the reference's EEst*dt callback (neural_sde.jl:87) or none;
+`func`: the caller's closure `(u, t, integrator) -> value` as the experiment passes it (`model(x, p1, p2, p3, p4; func = save_func)`, mnist_nsde.jl) --
+recognised as one of the reference's two SDE callbacks (node.py::reg_code: EEst*dt, mnist_nsde.jl:48, or |eigen_est| / 10.6 with the composite
+solver AutoSOSRI2(SOSRI2()), :51-61 -- what the shipped configs/mnist_nsde.yml selects), never called per step -- or its name ('error_est' /
+'stiff_est').  Differences inherent to the host language / the device:
 `save_everystep=True` (a result whose length is data dependent): `rnde_nsde_forward_everystep`, the state after every accepted step;
 the noise comes from the library's Philox stream (seed = nsde.seed, advanced every call) unless `noise=` passes a pool of
 standard normals of shape (n_pool, 2, B, D) -- a Julia caller would fill that from its own RNG.
@@ -21,7 +24,7 @@ import torch
 
 from . import _lib
 from .layers import Chain, Dense, destructure
-from .node import MAX_HANDLES_PER_KEY, SavedValues, _check_f32, _TapeToken
+from .node import MAX_HANDLES_PER_KEY, SOSRI2_STABILITY_SIZE, SavedValues, _check_f32, _TapeToken, effective_reg, reg_code
 
 _ACT = {"identity": 0, "tanh": 1}
 
@@ -103,7 +106,7 @@ class TrackedNeuralDSDE:
     def __init__(self, model1, model2, tspan, regularize, solver="SOSRI", *, max_batch=512, max_attempts=256, cb_save_start=True,
                  seed=0, **kwargs):
         if solver not in _lib.SDE_SOLVER:
-            raise ValueError("solver: SOSRI (experiments/mnist_nsde.jl:49,:63), SOSRI2 or SRIW1")
+            raise ValueError("solver: SOSRI (experiments/mnist_nsde.jl:49,:63), SOSRI2, AutoSOSRI2 (= AutoSOSRI2(SOSRI2()), :60) or SRIW1")
         if isinstance(model2, Dense):
             model2 = Chain(model2)
         self.save_everystep = bool(kwargs.get("save_everystep", False)) and "saveat" not in kwargs      # (saveat given: it decides what is saved)
@@ -123,6 +126,7 @@ class TrackedNeuralDSDE:
         self.seed = int(seed)
         self._handles = {}
         self.last_nfe = None
+        self._reg = 1            # rnde_reg code of the current call's callback (set by __call__)
 
     def _config(self, device_index):
         cfg = _lib.NsdeConfig()
@@ -137,7 +141,7 @@ class TrackedNeuralDSDE:
         cfg.solver = _lib.SDE_SOLVER[self.solver]
         cfg.reltol = float(self.kwargs.get("reltol", 1e-2))   # StochasticDiffEq defaults when not given
         cfg.abstol = float(self.kwargs.get("abstol", 1e-2))
-        cfg.regularize = 1 if self.regularize else 0
+        cfg.regularize = self._reg if self.regularize else 0
         cfg.cb_save_start = int(self.cb_save_start)
         cfg.max_attempts = self.max_attempts
         cfg.device = device_index
@@ -145,7 +149,7 @@ class TrackedNeuralDSDE:
 
     def _acquire(self, x):
         key = x.device.index or 0
-        hs = self._handles.setdefault(key, [])
+        hs = self._handles.setdefault((key, self._reg if self.regularize else 0), [])
         for h in hs:
             if not h.busy:
                 return h
@@ -155,12 +159,31 @@ class TrackedNeuralDSDE:
         hs.append(h)
         return h
 
+    def reg_of(self, func):
+        """rnde_reg code of a call's `func`: None = the layer's default callback EEst*dt (neural_sde.jl:87); a name; or the caller's closure, recognised as
+        the reference's EEst*dt / |eigen_est| / 10.6 (mnist_nsde.jl:48, :53-58).  The stiffness estimate exists for the composite AutoSOSRI2(SOSRI2()) only."""
+        if not self.regularize:
+            return 0
+        if callable(func):
+            code = effective_reg(reg_code(func, SOSRI2_STABILITY_SIZE), self.solver == "AutoSOSRI2")
+        elif func in (None, "error_est"):
+            code = 1
+        elif func == "stiff_est":
+            code = 2
+        else:
+            raise ValueError("func: a callback (u, t, integrator) -> value, or 'error_est' (EEst*dt, neural_sde.jl:87) / 'stiff_est' "
+                             "(|eigen_est| / 10.6, experiments/mnist_nsde.jl:51-61)")
+        if code == 3:
+            raise ValueError("the SDE layer records EEst*dt or the stiffness estimate (mnist_nsde.jl:45-61), not their blend")
+        if code == 2 and self.solver not in ("SOSRI2", "AutoSOSRI2"):
+            raise ValueError("the stiffness estimate of an SRI step is defined for SOSRI2 / AutoSOSRI2 only (mnist_nsde.jl:60)")
+        return code
+
     def __call__(self, x, p=None, func=None, noise=None):
         """(x, p = n.p; func) -> (arr, nfe1, nfe2, sv)   [neural_sde.jl:64-82, :116-146]"""
         if not x.is_cuda:
             raise RuntimeError("TrackedNeuralDSDE runs on the MI355X only: x must be a cuda tensor (no CPU fallback)")
-        if func not in (None, "error_est"):
-            raise ValueError("func: the reference's SDE callback is EEst*dt ('error_est', neural_sde.jl:87) or none")
+        self._reg = self.reg_of(func)
         p = self.p if p is None else p
         if p.device != x.device:
             if p is self.p:
@@ -225,22 +248,24 @@ class ClassifierNSDE:
         return z, nfe1, nfe2, sv
 
 
-def nsde_loss_function(x, y, model, p1=None, p2=None, p3=None, trajectories=1, lam=1.0e2, regularize=True, agg=torch.mean):
-    """experiments/mnist_nsde.jl:88-118 (without the logger): logitcrossentropy(pred, y) + lambda * agg(sv.saveval)."""
+def nsde_loss_function(x, y, model, p1=None, p2=None, p3=None, trajectories=1, lam=1.0e2, regularize=True, agg=torch.mean, func="error_est"):
+    """experiments/mnist_nsde.jl:88-118 (without the logger): logitcrossentropy(pred, y) + lambda * agg(sv.saveval).  `func`: the experiment's
+    `save_func` (a closure, or 'error_est' / 'stiff_est': mnist_nsde.jl:45-61)."""
     from .classifier import logitcrossentropy
-    pred, nfe1, nfe2, sv = model(x, p1, p2, p3, trajectories=trajectories, func="error_est" if regularize else None)
+    pred, nfe1, nfe2, sv = model(x, p1, p2, p3, trajectories=trajectories, func=func if regularize else None)
     ce = logitcrossentropy(pred, y)
     reg = lam * agg(sv.saveval) if (regularize and sv is not None) else torch.zeros((), device=pred.device)
     return ce + reg, ce, reg, nfe1, nfe2
 
 
-def fused_nsde_loss_and_grad(model, x, y, trajectories=1, lam=1.0e2, regularize=True):
+def fused_nsde_loss_and_grad(model, x, y, trajectories=1, lam=1.0e2, regularize=True, func="error_est"):
     """One training-step gradient of `nsde_loss_function` (agg = mean) without a tape library in the loop, the counterpart of
     classifier.fused_loss_and_grad for ClassifierNSDE: [Dense pre-layer] -> [solve, taped: ONE launch] -> [Dense post-layer, trajectory
     mean, logitcrossentropy and their reverse as a handful of matrix products] -> [reverse sweep: ONE launch] -> [pre-layer gradient].
     Sets .grad on p1, p2, p3; returns (total_loss, cross_entropy, reg, nfe1, nfe2) with the losses as device tensors / floats.
     Same arithmetic as autograd through ClassifierNSDE.__call__ (tests/test_gpu_nsde.py compares the two)."""
     nsde = model.nsde
+    nsde._reg = nsde.reg_of(func)                    # which callback the handle records (mnist_nsde.jl:45-61): EEst*dt or the stiffness estimate
     for name, t in (("x", x), ("y", y), ("p1", model.p1), ("p2", model.p2), ("p3", model.p3)):
         _check_f32(name, t)
     L = _lib.lib()

@@ -22,7 +22,7 @@ int main(void) {
     F(rnde_nsde_config, reltol); F(rnde_nsde_config, abstol); F(rnde_nsde_config, regularize); F(rnde_nsde_config, cb_save_start);
     F(rnde_nsde_config, max_attempts); F(rnde_nsde_config, device); F(rnde_nsde_config, beta1); F(rnde_nsde_config, beta2);
     F(rnde_nsde_config, gamma); F(rnde_nsde_config, qmin); F(rnde_nsde_config, qmax); F(rnde_nsde_config, qoldinit);
-    F(rnde_nsde_config, delta); F(rnde_nsde_config, generic);
+    F(rnde_nsde_config, delta); F(rnde_nsde_config, generic); F(rnde_nsde_config, stability_size);
     printf("rnde_nsde_config sizeof %zu\n", sizeof(rnde_nsde_config));
     printf("constants RNDE_MAX_LAYERS %d RNDE_COMM_ID_BYTES %d RNDE_COMM_WINDOW_BYTES %d\n", RNDE_MAX_LAYERS, RNDE_COMM_ID_BYTES, RNDE_COMM_WINDOW_BYTES);
     return 0;

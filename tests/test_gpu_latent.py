@@ -35,7 +35,7 @@ def _case(B, T, seed, scale=1.0):
     return S, x, p1, p2, p4, eps, res, z0b
 
 
-@pytest.mark.parametrize("B,T,seed", [(48, 49, 1), (37, 49, 2), (16, 7, 3), (200, 12, 4)])
+@pytest.mark.parametrize("B,T,seed", [(48, 49, 1), (37, 49, 2), (16, 7, 3), (200, 12, 4), (512, 49, 5)])      # the last: config 4's own size (experiments/latent_ode.jl, batch 512 x 49 times)
 def test_latent_caller_matches_the_fp64_restatement(B, T, seed):
     import torch
     from oracle import latent_oracle as lo

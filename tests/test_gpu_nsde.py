@@ -552,3 +552,135 @@ def test_evaluation_size_5120_columns_vs_oracle():
     print(f"5120 columns reverse vs fp32 oracle: x_bar {ex:.2e}, p_bar {ep:.2e}")
     assert ex <= 2e-3 and ep <= 2e-3
     node.close()
+
+
+# ---- the stiffness-estimate regulariser of the SDE layer (experiments/mnist_nsde.jl:51-61; configs/mnist_nsde.yml:6 ships `type: stiff_est`) -------
+
+@pytest.mark.parametrize("kind,B,tol,ctrl,scale,dscale,replay", [("nsde", 64, 0.14, {}, 2.0, 0.5, False), ("nsde", 37, 0.05, AGGR, 3.0, 1.5, True),
+                                                                 ("small", 7, 0.05, AGGR, 2.0, 0.5, False), ("deep", 21, 0.08, AGGR, 2.5, 0.8, True)])
+def test_stiffness_estimate_solve_and_reverse_match_oracle(kind, B, tol, ctrl, scale, dscale, replay):
+    """RNDE_REG_STIFF on SOSRI2 (= AutoSOSRI2(SOSRI2())): per accepted step the callback records |eigen_est| / 10.6 with
+    eigen_est = rms(k4 - k3) / rms(H0_4 - H0_3); once at initialisation 1 / 10.6.  Same noise, same accept / reject sequence as the fp32 oracle;
+    saved values to 5e-4 (the quotient of two fp32 norms of differences); gradients for cotangents on u(t1) AND on every saved value against the
+    fp64 oracle along the same sequence, within 2e-3 of the largest entry plus the case's own fp32-vs-fp64 spread."""
+    from oracle.oracle_sde import SdeOracle
+    from tests.util import NsdeNode
+    drift, diff, p, x, noise = _setup(kind, B, 13, 400, scale, dscale)
+    o32 = SdeOracle(drift, diff, np.float32, tol, tol, tableau="SOSRI2", reg_kind=2, max_attempts=399, **ctrl)
+    r32 = o32.forward(x, p, noise)
+    assert r32["rc"] == 0
+    node = NsdeNode(_cfg(drift, diff, B, reltol=tol, abstol=tol, solver="SOSRI2", regularize=2, max_attempts=399, **ctrl))
+    rp = np.stack([r32["steps"][:, 1], r32["steps"][:, 3]], 1) if replay else None
+    got = node.forward(x, p, noise, keep_tape=True, replay=rp)
+    if ctrl:
+        assert (r32["steps"][:, 3] == 0).sum() >= 3, "this case is meant to exercise rejections"
+    assert got["nattempts"] == r32["nattempts"] and np.array_equal(got["steps"][:, 3], r32["steps"][:, 3]) and got["ndraws"] == r32["ndraws"]
+    assert len(got["saveval"]) == len(r32["saveval"]) == int(r32["steps"][:, 3].sum()) + 1
+    assert got["saveval"][0] == np.float32(1.0) / np.float32(10.6)
+    assert (got["saveval"][1:] > 0).all() and np.allclose(got["saveval"], r32["saveval"], rtol=5e-4, atol=1e-7)
+    nn = o32.eigen_norms()
+    assert np.allclose(got["saveval"][1:], (nn[:, 0] / nn[:, 1]) / 10.6, rtol=5e-4)
+    assert _rel(got["u"], r32["u"]) <= 2e-4
+    rng = np.random.default_rng(1)
+    ubar = rng.standard_normal(x.shape).astype(np.float32) / B
+    svbar = (rng.standard_normal(len(r32["saveval"])) * 3.0).astype(np.float32)      # (the saved values are O(0.1): weight them so that their term is a visible share)
+    g32 = o32.backward(ubar, svbar)
+    o64 = SdeOracle(drift, diff, np.float64, tol, tol, tableau="SOSRI2", reg_kind=2, max_attempts=399, **ctrl)
+    o64.set_replay(r32["steps"][:, 1], r32["steps"][:, 3].astype(np.int32))
+    assert o64.forward(x, p, noise)["nattempts"] == r32["nattempts"]
+    g64 = o64.backward(ubar, svbar)
+    g64_u = o64.backward(ubar, np.zeros_like(svbar))
+    xb, pb = node.backward(ubar, svbar)
+    shares = []
+    for name, a, b32, b64, b0 in (("x_bar", xb, g32[0], g64[0], g64_u[0]), ("p_bar", pb, g32[1], g64[1], g64_u[1])):
+        sc = np.abs(b64).max()
+        spread = np.abs(np.asarray(b32, np.float64) - b64).max()
+        err = np.abs(np.asarray(a, np.float64) - b64).max()
+        share = np.abs(b64 - b0).max() / sc
+        print(f"stiff {kind} B={B} {name}: device-fp64 {err / sc:.2e}, fp32 oracle-fp64 {spread / sc:.2e}, the callback's share of the gradient {share:.2f}")
+        shares.append(share)
+        assert err <= 2e-3 * sc + 3 * spread, (name, err, sc, spread)
+    assert max(shares) > 0.05, "the saved values' cotangent must matter in what is being compared"
+    node.close()
+
+
+def test_stiffness_estimate_config5_full_size_and_the_constant():
+    """The shipped NSDE configuration at full size: B = 512, tol 0.14, SOSRI2, `type: stiff_est` with lambda = 0.1 on mean(saveval)
+    (mnist_nsde.jl:51-61, :99) -- forward + reverse against the fp64 oracle on an explicit noise pool; and stability_size as a configuration
+    value (2.0 instead of 10.6 scales every saved value and nothing else)."""
+    from oracle.oracle_sde import SdeOracle
+    from tests.util import NsdeNode
+    B = 512
+    drift, diff, p, x, noise = _setup("nsde", B, 21, 257, scale=1.0, dscale=1.0)
+    o64 = SdeOracle(drift, diff, np.float64, tableau="SOSRI2", reg_kind=2, max_attempts=256)
+    r64 = o64.forward(x, p, noise)
+    assert r64["rc"] == 0
+    node = NsdeNode(_cfg(drift, diff, B, solver="SOSRI2", regularize=2, max_attempts=256))
+    got = node.forward(x, p, noise, keep_tape=True)
+    print(f"config 5 stiff_est: attempts {got['nattempts']} (fp64 oracle {r64['nattempts']}), saved {got['saveval']}")
+    assert got["nattempts"] == r64["nattempts"] and np.array_equal(got["steps"][:, 3], r64["steps"][:, 3]) and got["ndraws"] == r64["ndraws"]
+    assert _rel(got["u"], r64["u"]) <= 2e-4
+    assert np.allclose(got["saveval"], r64["saveval"], rtol=5e-4, atol=1e-7)
+    rng = np.random.default_rng(2)
+    ubar = (rng.standard_normal(x.shape) / B).astype(np.float32)
+    svbar = np.full(len(got["saveval"]), 0.1 / len(got["saveval"]), np.float32)
+    xb, pb = node.backward(ubar, svbar)
+    g64 = o64.backward(ubar, svbar)
+    ex, ep = _rel(xb, g64[0]), _rel(pb, g64[1])
+    print(f"config 5 stiff_est reverse vs fp64 oracle: x_bar {ex:.2e}, p_bar {ep:.2e}")
+    assert ex <= 1e-3 and ep <= 1e-3
+    node2 = NsdeNode(_cfg(drift, diff, B, solver="SOSRI2", regularize=2, max_attempts=256, stability_size=2.0))
+    got2 = node2.forward(x, p, noise)
+    assert np.array_equal(got2["u"], got["u"]) and np.allclose(got2["saveval"] * 2.0, got["saveval"] * 10.6, rtol=1e-6)
+    node.close(); node2.close()
+
+
+def test_stiffness_estimate_layer_contract():
+    """The layer as the unchanged experiment calls it: `func = save_func` (a closure) on a layer built with AutoSOSRI2(SOSRI2()); the closure is
+    recognised (mnist_nsde.jl:53-58), the handle records the stiffness estimate, autograd carries lambda * mean(saveval) back.  Refusals: the
+    estimate under SOSRI (create-time, C ABI), under a plain SOSRI2 from a closure (the reference would record zeros), an unknown closure."""
+    import torch
+    import regneuralde_jl_amd as rn
+    from regneuralde_jl_amd import _lib
+    from tests.util import NsdeNode
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(5)
+    mk = lambda solver: rn.TrackedNeuralDSDE(rn.Chain(rn.Dense(32, 64, "tanh", g), rn.Dense(64, 32, "identity", g)), rn.Dense(32, 32, "identity", g), [0.0, 1.0], True,
+                                             solver, save_everystep=False, reltol=1.4e-1, abstol=1.4e-1, save_start=False, max_batch=64)
+    nsde = mk("AutoSOSRI2")
+    stab = 1.0 / 10.6
+
+    def save_func(u, t, integrator):                     # mnist_nsde.jl:53-58
+        s = abs(integrator.eigen_est)
+        return stab * (0 if (s == 0 or s != s) else s)
+    x = torch.randn(48, 32, generator=g).to(dev)
+    p = nsde.p.to(dev).requires_grad_(True)
+    nsde.seed = 100
+    u, n1, n2, sv = nsde(x, p, func=save_func)
+    nsde.seed = 100
+    u_e, _, _, sv_e = nsde(x, p, func=lambda u, t, integ: integ.EEst * integ.dt)
+    assert torch.equal(u.detach(), u_e.detach()) and n1 == n2 and len(sv.saveval) == len(sv_e.saveval)      # same solve, another recorded value
+    assert float(sv.saveval[0]) == np.float32(1.0) / np.float32(10.6) and float(sv_e.saveval[0]) == 0.0
+    assert not torch.allclose(sv.saveval[1:], sv_e.saveval[1:])
+    loss = u.square().mean() + 0.1 * sv.saveval.mean()
+    loss.backward()
+    gp = p.grad.clone()
+    p.grad = None
+    nsde.seed = 100
+    u2, _, _, sv2 = nsde(x, p, func="stiff_est")
+    (u2.square().mean() + 0.1 * sv2.saveval.mean()).backward()
+    assert torch.equal(gp, p.grad) and torch.isfinite(gp).all() and float(gp.abs().max()) > 0
+    p.grad = None
+    nsde.seed = 100
+    u3, _, _, sv3 = nsde(x, p, func="stiff_est")
+    u3.square().mean().backward()
+    assert not torch.equal(gp, p.grad)                   # the callback's term is in the gradient
+    with pytest.raises(ValueError, match="composite"):
+        mk("SOSRI2")(x, p, func=save_func)
+    with pytest.raises(ValueError, match="SOSRI2"):
+        mk("SOSRI")(x, p, func="stiff_est")
+    with pytest.raises(ValueError, match="none of the callbacks"):
+        nsde(x, p, func=lambda u, t, integ: integ.dt)
+    drift, diff, _, _, _ = _setup("nsde", 16, 1, 1)
+    with pytest.raises(_lib.RndeError, match="SOSRI2 only"):
+        NsdeNode(_cfg(drift, diff, 16, solver="SOSRI", regularize=2))

@@ -174,7 +174,7 @@ def make_nsde_cfg(drift_dims, drift_acts, diff_dims, diff_acts, max_batch, relto
     cfg.solver = _lib.SDE_SOLVER[solver]
     cfg.reltol, cfg.abstol = reltol, abstol
     cfg.regularize, cfg.cb_save_start, cfg.max_attempts, cfg.device = regularize, cb_save_start, max_attempts, 0
-    for k in ("beta1", "beta2", "gamma", "qmin", "qmax", "qoldinit", "delta"):
+    for k in ("beta1", "beta2", "gamma", "qmin", "qmax", "qoldinit", "delta", "stability_size"):
         setattr(cfg, k, ctrl.get(k, 0.0))
     cfg.generic = generic
     return cfg

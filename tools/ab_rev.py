@@ -1,4 +1,4 @@
-"""A/B of the reversed attempt: python tools/ab_rev.py LIB_A LIB_B ... (same box, alternating; fixed weights, HIP events of the library)."""
+"""A/B of the reversed attempt: [AB_B=4096] python tools/ab_rev.py LIB_A LIB_B ... (same box, alternating; fixed weights, HIP events of the library)."""
 import subprocess, sys, os
 code = r'''
 import ctypes as C, sys, torch
@@ -7,12 +7,14 @@ import bench, regneuralde_jl_amd as rn
 from regneuralde_jl_amd import _lib
 L = _lib.lib()
 dev = torch.device("cuda", 0)
-model = bench.build_model(rn, dev, 512)
+import os
+B = int(os.environ.get("AB_B", "512"))
+model = bench.build_model(rn, dev, B)
 g = torch.Generator().manual_seed(1999)
-x = torch.rand(512, 1, 28, 28, generator=g).to(dev)
-y = torch.eye(10)[torch.randint(0, 10, (512,), generator=g)].to(dev)
+x = torch.rand(B, 1, 28, 28, generator=g).to(dev)
+y = torch.eye(10)[torch.randint(0, 10, (B,), generator=g)].to(dev)
 rn.fused_loss_and_grad(model, x, y, lam=1.0e2, sync=True)
-h = model.node._acquire(x.reshape(512, -1), True)
+h = model.node._acquire(x.reshape(B, -1), True)
 L.rnde_node_set_timing(h.ptr, 1)
 fa = rs = rr = n = 0
 for _ in range(8):

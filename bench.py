@@ -32,7 +32,8 @@ ALG_BYTES = lambda B: 34 * 4 * D * B + 6 * 4 * P_DYN   # 34 A + 
 ALG_FLOPS = lambda B: 6 * 2 * B * ((D + 1) * H + (H + 1) * D)
 HBM_PEAK_GBS = 8000.0                              # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"        # profiles/<round>_pmc_hbm_traffic*.csv: the committed --pmc passes `traffic` is read from
+ABLATION_ROUND = "r04"       # profiles/<round>_attempt_ablation.csv: the forward attempt kernel's stages are unchanged since (round 5 moved the controller, not the stages)
 
 
 def build_model(rn, device, batch, seed=1999):
@@ -720,7 +721,15 @@ def main():
                 "us_per_attempt": us_in_step, "us_per_attempt_back_to_back": us.value, "us_per_attempt_back_to_back_untaped": us_untaped.value,
                 "alg_bytes_per_attempt": ALG_BYTES(B), "alg_bytes_per_launch": ALG_BYTES(B) * (sum(atts) / len(atts)) if one_launch else ALG_BYTES(B) / nl,
                 "mfma_f32_tflops": ALG_FLOPS(B) / t_att / 1e12,
-                "mfma_frac": ALG_FLOPS(B) / t_att / 1e12 / MFMA_F32_PEAK_TF}
+                "mfma_frac": ALG_FLOPS(B) / t_att / 1e12 / MFMA_F32_PEAK_TF,
+                # which roof actually binds: the counters show 0.39 x the algorithmic bytes reaching HBM (the state lives in registers / L2), i.e. ~1 TB/s of
+                # real traffic -- the kernel is NOT memory bound.  It is bound by instruction issue on the vector / matrix ALUs (fp32 MFMA and VALU share the
+                # SIMD's issue slots on this part: SQ_VALU_MFMA_COEXEC_CYCLES = 0, profiles/r05_pmc_sq_attempt.csv).  `frac` above stays the north star's unit
+                # (algorithmic bytes against the HBM roof); the binding fraction is the fp32 matrix one.
+                "binding": {"bound": "mfma (issue: fp32 matrix + vector instructions share the SIMDs)", "achieved": ALG_FLOPS(B) / t_att / 1e12, "peak": MFMA_F32_PEAK_TF,
+                            "unit": "TFLOP/s", "frac": ALG_FLOPS(B) / t_att / 1e12 / MFMA_F32_PEAK_TF,
+                            "evidence": "profiles/r05_pmc_hbm_traffic.csv (HBM bytes per attempt 0.39 x algorithmic), profiles/r05_pmc_sq_attempt.csv (matrix pipe busy 32 %, "
+                                        "co-execution 0), profiles/r04_attempt_ablation.csv (MFMAs alone: 13.8 us of the 23.3)"}}
         # HBM traffic per launch of that kernel: PMC counters cannot be collected from inside the bench; the committed separate
         # passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same command, corrected as MI355X_MICROARCH.md prescribes) are
         # reported when present, with their source.  `traffic` is per LAUNCH like `achieved`; the one-launch solve's launch holds
@@ -742,11 +751,11 @@ def main():
         # the measured floor of this kernel's decomposition: its MFMAs alone with operands in registers (profiles/r0N_attempt_ablation.csv)
         try:
             import csv
-            for row in csv.DictReader(l for l in open(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_attempt_ablation.csv")) if not l.startswith("#")):
+            for row in csv.DictReader(l for l in open(os.path.join(ROOT, "profiles", ABLATION_ROUND + "_attempt_ablation.csv")) if not l.startswith("#")):
                 if row["variant"] == "mfmaonly" and int(row["B"]) == B:
                     roof["ceiling_us"] = float(row["us_taped"])
                     roof["ceiling_frac"] = ALG_BYTES(B) / (roof["ceiling_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
-                    roof["ceiling_source"] = "profiles/" + PROFILE_ROUND + "_attempt_ablation.csv: the kernel's MFMAs alone (operands in registers, no polls / tanh / LDS / tape), same launch geometry, back to back"
+                    roof["ceiling_source"] = "profiles/" + ABLATION_ROUND + "_attempt_ablation.csv: the kernel's MFMAs alone (operands in registers, no polls / tanh / LDS / tape), same launch geometry, back to back"
         except Exception:
             pass
         out = {"metric": "training-step samples/sec + mean NFE, MNIST Neural ODE bs=512",

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
     // the cross-workgroup partials of attempt n + 1 are requested before anything else: they come back first, and the double-precision scalar
     // chain that needs them then runs while the weights and the nine tape arrays of this attempt are still streaming in
     f32x4 pe[4];
-    if (!first) bpart_request(Bq, n + 1, lane, pe);
+    if (!first && !Bq.bsum) bpart_request(Bq, n + 1, lane, pe);
     __builtin_amdgcn_sched_barrier(0);
     // (the small loads first, and all four weight base addresses exist -- pinned by the empty asm -- before the first weight load: the register
     //  allocator otherwise builds the later addresses in registers that are destinations of loads in flight, and each such reuse is a full wait
@@ -183,7 +183,12 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
         __builtin_amdgcn_sched_barrier(0);   // keep these requests in front of the scalar chain (the scheduler sinks them to their uses otherwise)
         BSTAMP(40);
         double tb = 0, dtpb = 0, qoldb = 0, t1b = 0, t0b = 0;
-        if (!first) finish_attempt_scalars_from(Bq, n + 1, lane, &pe, tb, dtpb, qoldb, t1b, t0b);
+        if (!first) {
+            if (Bq.bsum) {      // (large batches: the three sums were formed once behind the previous launch, rnde_bpart_reduce_kernel -- the same additions in the same order)
+                const double* sm = Bq.bsum + 4 * ((n + 1) & 1);
+                finish_attempt_scalars_sums(Bq.bstate[(n + 1) & 1], P.meta[n + 1], sm[0], sm[1], sm[2], tb, dtpb, qoldb, t1b, t0b);
+            } else finish_attempt_scalars_from(Bq, n + 1, lane, &pe, tb, dtpb, qoldb, t1b, t0b);
+        }
         BSTAMP(41);
         float coef;
         {

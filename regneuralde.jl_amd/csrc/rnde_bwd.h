@@ -46,6 +46,7 @@ struct BwdParams {
     int n_att, track_ctrl, track_initdt, reg_kind;
     const float* sv_ubar0; int sv_T;   // saveat with t0 among the save times: cotangent slice of that point (else NULL)
     int bpart_n;                       // number of per-workgroup partials the sweep wrote (differs from F.nwg when the stage engine ran it)
+    const double* bsum;                // [2][4] or NULL: the three sums over bpart[parity] already formed by rnde_bpart_reduce_kernel (large batches, round 5)
 };
 
 struct BwdBuffers {
@@ -115,6 +116,25 @@ __device__ __forceinline__ void finish_attempt_scalars_sums(const BState& b, con
 __device__ __forceinline__ void finish_attempt_scalars(const BwdParams& Q, int m, int lane, double& tb, double& dtpb,
                                                        double& qoldb, double& t1b, double& t0b) {
     finish_attempt_scalars_from(Q, m, lane, nullptr, tb, dtpb, qoldb, t1b, t0b);
+}
+
+// Large batches (round 5): every workgroup of the stage engine's reverse attempt kernel used to sum ALL bpart_n partials of attempt n + 1 in its own
+// START -- 1,792 entries at B = 4096, seven dependent 256-entry blocks of cold loads in front of everything else, in each of 1,792 workgroups:
+// 24 us of a 242 us reversed attempt (profiles/r05_rev_attempt_ablation.csv, `noscalar` at B = 4096).  One wave forms the three sums once, behind
+// the launch that wrote the partials, in exactly the order finish_attempt_scalars_from adds them (bit-identical), and START reads three doubles.
+static __global__ __launch_bounds__(64) void rnde_bpart_reduce_kernel(const BwdParams Q, int m, double* __restrict__ out) {
+    const int lane = threadIdx.x;
+    const float* part = Q.bpart + (size_t)(m & 1) * Q.bpart_n * 4;
+    double S = 0, tau = 0, ctau = 0;
+    for (int base = 0; base < Q.bpart_n; base += 256) {
+        f32x4 e[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) e[q] = *(const f32x4*)(part + 4 * (size_t)(base + lane + 64 * q));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (base + lane + 64 * q < Q.bpart_n) { S += (double)e[q][0]; tau += (double)e[q][1]; ctau += (double)e[q][2]; }
+    }
+    S = wave_sum_d(S); tau = wave_sum_d(tau); ctau = wave_sum_d(ctau);
+    if (lane == 0) { double* o = out + 4 * (m & 1); o[0] = S; o[1] = tau; o[2] = ctau; o[3] = 0; }
 }
 
 static __global__ __launch_bounds__(64) void rnde_bfin_kernel(const BwdParams Q) {

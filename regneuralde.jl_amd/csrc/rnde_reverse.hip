@@ -45,7 +45,7 @@ static rnde_status bwd_prepare(rnde_node* h) {
     HIPCHK(h, hipMalloc((void**)&b.U, A * 4)); HIPCHK(h, hipMalloc((void**)&b.K1, A * 4)); HIPCHK(h, hipMalloc((void**)&b.UB1, A * 4));
     HIPCHK(h, hipMalloc((void**)&b.zi2, 2 * A * 4)); HIPCHK(h, hipMalloc((void**)&b.zi1, 2 * HB * 4));
     HIPCHK(h, hipMalloc((void**)&b.svb_att, (size_t)cap * 4));
-    HIPCHK(h, hipMalloc((void**)&b.bstate, 2 * sizeof(BState))); HIPCHK(h, hipMalloc((void**)&b.ibstate, 2 * sizeof(IBState)));
+    HIPCHK(h, hipMalloc((void**)&b.bstate, 2 * sizeof(BState) + 64)); HIPCHK(h, hipMalloc((void**)&b.ibstate, 2 * sizeof(IBState)));      // (+ 64 bytes: the [2][4] sums of rnde_bpart_reduce_kernel)
     HIPCHK(h, hipMalloc((void**)&b.bpart, (size_t)(2 * h->nwg_max + 256) * 4 * 4)); HIPCHK(h, hipMalloc((void**)&b.ipart, (size_t)2 * h->nwg_max * 4 * 4));   // (+256 entries: finish_attempt_scalars reads whole 256-entry blocks)
     HIPCHK(h, hipMalloc((void**)&b.tspan_out, 2 * 4));
     const size_t nev = (size_t)6 * cap + 2;
@@ -253,6 +253,11 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
         BQ.EXK = b.GB + 6 * A; BQ.EXG = b.GB + 7 * A; BQ.SVW = b.GB + 8 * A;
         BQ.sv_t = h->saveat.empty() ? nullptr : h->sv_t_dev; BQ.sv_ubar = u_bar_dev; BQ.nsave = (int)h->saveat.size();
         BQ.MT = h->sMT; BQ.WT = h->sWT; BQ.R = h->sR; BQ.C = Q.F.Bpad / 16; BQ.HT = h->sHT; BQ.KHb = h->sKHb;
+        // large batches: the partials of attempt n + 1 are summed ONCE behind its launch (rnde_bpart_reduce_kernel) instead of in the START of every
+        // workgroup of attempt n -- pays from ~900 partials on (B >= 2048: a 4 us launch against 7+ us of dependent cold loads in every workgroup)
+        double* const bsum = (double*)(b.bstate + 2);
+        const bool pre_reduce = h->persist == 1 && Q.bpart_n >= 896 && !getenv("RNDE_NO_BPART_REDUCE");
+        if (pre_reduce) BQ.B.bsum = bsum;
         const dim3 grid(BQ.R * BQ.C), blk(64 * BQ.WT);
         // saveat: which save indices each accepted attempt covers (same float comparisons as the forward controller)
         std::vector<int> sv_lo(n_att, 0), sv_hi(n_att, 0);
@@ -303,6 +308,7 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
                 } else if (h->act2) hipLaunchKernelGGL((rnde_bstage_attempt_kernel<1, 0>), pgrid, blk, h->stage_lds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
                 else hipLaunchKernelGGL((rnde_bstage_attempt_kernel<0, 0>), pgrid, blk, h->stage_lds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
                 if ((st = couple_sum(h, b.bpart + (size_t)(n & 1) * Q.bpart_n * 4, 4LL * Q.bpart_n, s)) != RNDE_OK) return st;
+                if (pre_reduce && n > 0) hipLaunchKernelGGL(rnde_bpart_reduce_kernel, dim3(1), dim3(64), 0, s, Q, n, bsum);      // (attempt 0's partials go to the reverse of the initial-step rule, which sums them itself)
                 if (n >= n_att - side_att && (hi_att - n >= group || n == n_att - side_att)) {   // attempts [n, hi_att) are final
                     st = wgrad_group(2 + 6 * n, 2 + 6 * hi_att, true);
                     if (st != RNDE_OK) return st;

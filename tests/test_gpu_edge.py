@@ -101,6 +101,34 @@ def test_full_size_replication_property():
     assert np.isfinite(gp).all() and np.isfinite(gt).all()
 
 
+def test_large_batch_partial_sums_formed_once_are_bit_identical(monkeypatch):
+    """From ~900 per-workgroup partials on (B >= 2048) the reverse sweep sums the partials of attempt n + 1 ONCE behind its launch
+    (rnde_bpart_reduce_kernel) instead of in the START of each of the 7 x B / 16 workgroups of attempt n: the same additions in the same order, so
+    every cotangent -- including tspan-bar, which is made of exactly those sums -- must be bit-identical to the per-workgroup form
+    (RNDE_NO_BPART_REDUCE=1).  B = 2048: 896 partials; rejected steps in the sequence (their cotangents travel through the scalar chain only)."""
+    from tests.test_gpu_forward import _cfg, _setup
+    from tests.util import Node
+    B = 2048
+    arch, p, x = _setup("mnist", B, 8, 2.0)
+    ubar = np.random.default_rng(3).standard_normal((B, 784)).astype(np.float32) / B
+    out = []
+    for off in ("", "1"):
+        if off:
+            monkeypatch.setenv("RNDE_NO_BPART_REDUCE", off)
+        else:
+            monkeypatch.delenv("RNDE_NO_BPART_REDUCE", raising=False)
+        node = Node(_cfg(arch, B, reltol=1e-5, abstol=1e-5, col_tile=16, max_attempts=64))
+        f = node.forward(x, p, keep_tape=True)
+        g = node.backward(ubar, np.linspace(0.5, 1.5, len(f["saveval"])).astype(np.float32))
+        out.append((f, g))
+        node.close()
+    (fa, ga), (fb, gb) = out
+    assert fa["nfe"] == fb["nfe"] and np.array_equal(fa["u"], fb["u"])
+    for a, b, name in zip(ga, gb, ("x_bar", "p_bar", "tspan_bar")):
+        assert np.array_equal(np.asarray(a), np.asarray(b)), name
+    assert np.isfinite(np.asarray(ga[1])).all() and float(np.abs(np.asarray(ga[2])).max()) > 0
+
+
 def test_persistent_kernel_failure_falls_back_to_the_multi_launch_kernels(monkeypatch):
     """Safety net of rnde_stage_persist.h: when a hand-off gives up (here: a polling bound of zero, so the first poll that is not
     satisfied at once abandons the launch) the handle must notice, switch to the 7-launch kernels and redo the solve --

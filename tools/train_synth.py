@@ -129,7 +129,11 @@ def run(reg, train, test, epochs, device, seed, max_attempts, steer, lam_scale=1
         if failed:
             rec["failed"] = failed
             break
-        nfe, inf_t = probe()
+        try:
+            nfe, inf_t = probe()
+        except Exception as e:      # (a run that has diverged can exhaust max_attempts in the probe as well as in a training step)
+            rec["failed"] = f"epoch {epoch} (NFE probe): {e}"
+            break
         e = {"epoch": epoch, "lambda": lam, "nfe": nfe, "train_acc": 100 * rn.accuracy(model, train), "test_acc": 100 * rn.accuracy(model, test),
              "train_time_s": timing, "inference_time_s": inf_t, "mean_ce": ce_sum / len(train), "mean_reg": reg_sum / len(train),
              "mean_train_nfe": nfe_sum / len(train)}

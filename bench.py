@@ -643,30 +643,6 @@ def main():
         if reducer is not None and reducer.comm is not None:
             ar_us = time_allreduce(reducer)
             ar_both = {L.rnde_comm_path(reducer.comm).decode(): ar_us}
-            # the OTHER collective path in the same run, so that one multi-GPU lease decides the default: the one-shot kernel over peer-mapped
-            # windows (hipIpc) next to RCCL.  Every rank must agree that its communicator exists before any of them times it.
-            if reducer.collective == "rccl" and not os.environ.get("RNDE_ONESHOT") and os.environ.get("RNDE_BENCH_BOTH_COLLECTIVES", "1") != "0":
-                alt, why = None, None
-                try:
-                    alt = rn.GradientAllReducer(model.trainable(), flat=fg, collective="peers")
-                except Exception as e:
-                    why = repr(e)
-                ok = torch.tensor([1 if (alt is not None and alt.comm is not None) else 0], dtype=torch.int32, device=ddev)
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-                if int(ok.item()) == 1:
-                    try:      # same sum on every rank, bit for bit, as the rank-order sum the kernel promises (a cheap end-to-end check of the path)
-                        fg.flat.copy_(torch.arange(fg.flat.numel(), device=fg.flat.device, dtype=torch.float32).remainder_(97.0).add_(float(rank)))
-                        alt.allreduce_range_(0, fg.flat.numel())
-                        want = torch.arange(fg.flat.numel(), device=fg.flat.device, dtype=torch.float32).remainder_(97.0).mul_(world).add_(world * (world - 1) / 2.0)
-                        exact = bool(torch.equal(fg.flat, want))
-                        fg.flat.zero_()
-                        ar_both[L.rnde_comm_path(alt.comm).decode()] = time_allreduce(alt)
-                        ar_both["one_shot_sum_exact"] = exact
-                    except Exception as e:
-                        ar_both["one_shot_error"] = repr(e)
-                else:
-                    ar_both["one_shot_error"] = why or "another rank could not map the peer windows"
-                del alt
         nf = [float(v[0]) for v in allv]
         dist_diag = {"nfe_per_rank": nf, "nfe_min": min(nf), "nfe_mean": sum(nf) / len(nf), "nfe_max": max(nf),
                      "persist_fallback_count_per_rank": [int(v[1]) for v in allv], "launches_per_attempt_per_rank": [int(v[2]) for v in allv],
@@ -808,6 +784,71 @@ def main():
             if others_anchor is not None:
                 others["global4096"] = others_anchor
             out["other_workloads"] = others
+    # ---- the OTHER collective path in the same run (so that one multi-GPU lease decides the default): the one-shot kernel over peer-mapped windows
+    # (hipIpc) next to RCCL.  It has never met more than one GPU, so it runs LAST, behind everything the line reports, under a watchdog: if the probe has
+    # not come back in time every rank leaves with status 0 and rank 0 prints the line without it.  After every phase all ranks agree (MIN all-reduce)
+    # before any of them goes on, so a failure on one rank cannot strand the others in a barrier.
+    if (use_dist and dist_diag is not None and reducer is not None and reducer.comm is not None and reducer.collective == "rccl"
+            and not os.environ.get("RNDE_ONESHOT") and os.environ.get("RNDE_BENCH_BOTH_COLLECTIVES", "1") != "0"):
+        import threading
+        by_path = dist_diag["allreduce_us_by_path"]
+
+        def give_up():
+            if rank == 0:
+                by_path["one_shot_error"] = "watchdog: the probe of the one-shot collective did not return in 90 s"
+                C.CDLL(None).fflush(None)
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        dog = threading.Timer(90.0, give_up)
+        dog.daemon = True
+        dog.start()
+
+        def agree(ok):
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=ddev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return int(t.item()) == 1
+        alt, why = None, None
+        try:
+            alt = rn.GradientAllReducer(model.trainable(), flat=fg, collective="peers")
+        except Exception as e:
+            why = repr(e)
+        if not agree(alt is not None and alt.comm is not None):
+            by_path["one_shot_error"] = why or "another rank could not map the peer windows"
+        else:
+            n_fl = fg.flat.numel()
+            ramp = torch.arange(n_fl, device=fg.flat.device, dtype=torch.float32).remainder_(97.0)
+            exact, why = False, None
+            try:      # the same sum on every rank, bit for bit (small integers: exact in fp32)
+                fg.flat.copy_(ramp + float(rank))
+                alt.allreduce_range_(0, n_fl)
+                torch.cuda.synchronize()
+                exact = bool(torch.equal(fg.flat, ramp * world + world * (world - 1) / 2.0))
+            except Exception as e:
+                why = repr(e)
+            if not agree(why is None):
+                by_path["one_shot_error"] = why or "the one-shot all-reduce failed on another rank"
+            else:
+                us, why = None, None
+                try:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    for _ in range(3):
+                        alt.allreduce_range_(0, n_fl)
+                    torch.cuda.synchronize()
+                    e0.record()
+                    for _ in range(20):
+                        alt.allreduce_range_(0, n_fl)
+                    e1.record(); torch.cuda.synchronize()
+                    us = 1e3 * e0.elapsed_time(e1) / 20
+                except Exception as e:
+                    why = repr(e)
+                if agree(why is None):
+                    by_path[L.rnde_comm_path(alt.comm).decode()] = us
+                    by_path["one_shot_sum_exact"] = exact
+                else:
+                    by_path["one_shot_error"] = why or "the timed one-shot all-reduces failed on another rank"
+            fg.flat.zero_()
+        dog.cancel()
+        del alt
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -265,7 +265,14 @@ static rnde_status ensure_mw_slab(rnde_node* h, long long evals, int Bpad, hipSt
     const long long per_eval = (long long)(h->Bpad_max / 16) * h->mg.RS * 64;   // sized for max_batch so that ev_stride changes never outgrow it
     (void)Bpad;
     if (h->mw_slab_evals >= evals) return RNDE_OK;
-    const long long want = std::max(evals, 2 * h->mw_slab_evals);
+    long long want = std::max(evals, 2 * h->mw_slab_evals);
+    {   // 288 GB of HBM: when a quarter of what is free holds the slab of a max_attempts solve, take that at once -- growing it later costs a stream
+        // synchronisation, a multi-GB hipMalloc, a copy and a hipFree (~40 ms), and while a model trains its step count creeps across the doubling
+        // thresholds in the middle of a run (seen in bench.py's latent_e2e record: one 45 ms step among 3.5 ms ones)
+        const long long full = 2 + (long long)(h->rk_S - 1) * h->cfg.max_attempts;
+        size_t fr = 0, tot = 0;
+        if (full > want && hipMemGetInfo(&fr, &tot) == hipSuccess && (size_t)full * per_eval * 4 <= fr / 4) want = full;
+    }
     float* nb = nullptr;
     HIPCHK(h, hipStreamSynchronize(s));
     HIPCHK(h, hipMalloc((void**)&nb, (size_t)want * per_eval * 4));

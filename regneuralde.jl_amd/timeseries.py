@@ -285,8 +285,16 @@ def fused_latent_loss_and_grad(model, data, mask, t_row, lam_r=1.0e2, lam_k=1.0,
     p1, p2, p3, p4 = (p.detach() for p in model.trainable())
     z0 = torch.empty(B, lat, dtype=torch.float32, device=dev)
     mu0, logvar = torch.empty_like(z0), torch.empty_like(z0)
+    _tr = getattr(model, "_trace", None)      # (diagnostics: host time of each library call of this step, appended when the caller set model._trace = [])
+    if _tr is not None:
+        import time as _time
+        _t = [_time.perf_counter()]
+        _mark = lambda: _t.append(_time.perf_counter())
+    else:
+        _mark = lambda: None
     _lib.check_latent(hl.ptr, L.rnde_latent_encode(hl.ptr, x_.data_ptr(), p1.data_ptr(), p2.data_ptr(), eps.contiguous().data_ptr(), B, T,
                                                    z0.data_ptr(), mu0.data_ptr(), logvar.data_ptr(), stream))
+    _mark()
     # the layer call on z0 (time_series.jl:61): forward with saveat, taped
     grid = node._saveat_times(node.kwargs["saveat"] if saveat is None else saveat, node.tspan)      # update_saveat!, neural_ode.jl:35-46
     if len(grid) != T:
@@ -299,11 +307,13 @@ def fused_latent_loss_and_grad(model, data, mask, t_row, lam_r=1.0e2, lam_k=1.0,
     nfe, nsv = C.c_int64(0), C.c_int32(0)
     _lib.check(hn.ptr, L.rnde_node_forward_saveat(hn.ptr, z0.data_ptr(), p3.data_ptr(), B, node.tspan[0], node.tspan[1], sa, T, res.data_ptr(),
                                                   C.byref(nfe), sv_host, C.byref(nsv), 1, stream))
+    _mark()
     loss2 = torch.empty(2, dtype=torch.float32, device=dev)
     resb = torch.empty_like(res)
     p4bar = torch.empty_like(p4)
     _lib.check_latent(hl.ptr, L.rnde_latent_decode_loss(hl.ptr, res.data_ptr(), p4.data_ptr(), x_.data_ptr(), B, T, loss2.data_ptr(), resb.data_ptr(),
                                                        p4bar.data_ptr(), stream))
+    _mark()
     n = nsv.value
     reg = 0.0
     svb = None
@@ -312,9 +322,13 @@ def fused_latent_loss_and_grad(model, data, mask, t_row, lam_r=1.0e2, lam_k=1.0,
         svb = (C.c_float * n)(*([lam_r / n] * n))
     z0bar, p3bar = torch.empty_like(z0), torch.empty_like(p3)
     _lib.check(hn.ptr, L.rnde_node_backward_async(hn.ptr, resb.data_ptr(), svb, z0bar.data_ptr(), p3bar.data_ptr(), None, stream))
+    _mark()
     p1bar, p2bar = torch.empty_like(p1), torch.empty_like(p2)
     _lib.check_latent(hl.ptr, L.rnde_latent_encode_backward(hl.ptr, z0bar.data_ptr(), float(lam_k), p1.data_ptr(), p2.data_ptr(), x_.data_ptr(),
                                                            p1bar.data_ptr(), p2bar.data_ptr(), stream))
+    _mark()
+    if _tr is not None:
+        _tr.append([round(1e3 * (b - a), 3) for a, b in zip(_t, _t[1:])])      # [encode, layer forward (host wait inside), decode + loss, layer reverse (async), encode reverse]
     model.p1.grad, model.p2.grad, model.p3.grad, model.p4.grad = p1bar, p2bar, p3bar, p4bar
     node.last_nfe = int(nfe.value)
     nll, kl = loss2[0], lam_k * loss2[1]

@@ -989,7 +989,20 @@ extern "C" rnde_status rnde_node_forward_everystep(rnde_node* h, const float* x_
     *n_out = (int32_t)times.size();
     if ((int)times.size() > capacity) { h->err = "rnde_node_forward_everystep: more accepted steps than the output has room for"; return RNDE_ERR_BAD_ARG; }
     if (t_host_out) memcpy(t_host_out, times.data(), times.size() * sizeof(float));
-    return forward_impl(h, x_dev, p_dev, B, t0, t1, nullptr, times.data(), (int32_t)times.size(), sol_out_dev, nfe_out, saveval_host, n_saveval_out, keep_tape, stream);
+    st = forward_impl(h, x_dev, p_dev, B, t0, t1, nullptr, times.data(), (int32_t)times.size(), sol_out_dev, nfe_out, saveval_host, n_saveval_out, keep_tape, stream);
+    if (st != RNDE_OK) return st;
+    // "the value at a step's end is u_new itself, no interpolation" holds only if the second solve (another kernel path: it saves) took exactly the steps
+    // the first one took -- the same arithmetic, so it must; checked, not assumed (round-4 review)
+    size_t k = save_start ? 1 : 0;
+    for (int i = 0; i < h->n_att; ++i) {
+        const StepMeta& m = h->h_meta[i];
+        if (!(m.flags & F_ACCEPT)) continue;
+        float tn = m.t + m.dt; if (tn > t1) tn = t1;
+        if (k >= times.size() || times[k] != tn) { h->err = "rnde_node_forward_everystep: the saving solve did not retrace the steps of the first one"; return RNDE_ERR_HIP; }
+        ++k;
+    }
+    if (k != times.size()) { h->err = "rnde_node_forward_everystep: the saving solve took fewer accepted steps than the first one"; return RNDE_ERR_HIP; }
+    return RNDE_OK;
 }
 
 extern "C" rnde_status rnde_node_steps(rnde_node* h, float* steps_host, int32_t capacity, int32_t* n_out) {

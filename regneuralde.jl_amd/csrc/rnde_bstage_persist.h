@@ -480,7 +480,8 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
     BSTAMP(34);
 
     // ---- per-workgroup partials {S, tau, sum_j c_j tau_j (+ saveat dt-bar)}: same reduction order as the 7 launches ----
-    __syncthreads();
+    // (no barrier in front of the GL writes below: the last readers of GL are the phase D loads of stage 2, and every wave has passed stage 1's
+    //  phase A barrier since -- a wave that is done with stage 1 forms its wave sums while the slower ones finish)
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
         const float a = wave_sum_f(pS[i]), b = wave_sum_f(pT[i]), c = i == 0 ? wave_sum_f(pX[0]) : 0.f;      // (only START has an exdt term)

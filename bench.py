@@ -36,6 +36,16 @@ PROFILE_ROUND = "r05"        # profiles/<round>_pmc_hbm_traffic*.csv: the commit
 ABLATION_ROUND = "r04"       # profiles/<round>_attempt_ablation.csv: the forward attempt kernel's stages are unchanged since (round 5 moved the controller, not the stages)
 
 
+def quiet_gc():
+    """Before a timed region: collect once, then move everything alive (torch's ~1 M import-time objects among them) out of the collector's
+    sight.  A full collection over those takes ~40 ms -- one of them inside a 20-step timed region of 3.5 ms steps doubled the latent_e2e record in
+    four of seven runs of this file (solve_diag showed one 41 ms step whose library calls added up to 3.1 ms).  Measurement hygiene (timeit switches
+    the collector off for the same reason); nothing the step does is skipped."""
+    import gc
+    gc.collect()
+    gc.freeze()
+
+
 def build_model(rn, device, batch, seed=1999):
     import torch
     g = torch.Generator().manual_seed(seed)
@@ -126,6 +136,7 @@ def attempt_roofline_at(B, device, steps=3, warmup=2):
     g = torch.Generator().manual_seed(2024)
     x = torch.rand(B, 1, 28, 28, generator=g).to(device)
     y = torch.eye(NCLS)[torch.randint(0, NCLS, (B,), generator=g)].to(device)
+    quiet_gc()
     for _ in range(warmup):
         rn.fused_loss_and_grad(model, x, y, lam=1.0e2, sync=True)
     h = model.node._acquire(x.reshape(B, -1), True)
@@ -182,6 +193,7 @@ def global_batch_anchor(G, device, steps, warmup):
         nfes.append(nfe)
 
     def leg(restore):
+        quiet_gc()
         for _ in range(warmup):
             step(restore)
         nfes.clear()
@@ -250,6 +262,7 @@ def bench_latent(args, B=512, throughput_record=True):
         _lib.check(hd.ptr, L.rnde_node_backward_async(hd.ptr, ubar.data_ptr(), svb, zbar.data_ptr(), pbar.data_ptr(), None, stream))
         return int(nfe.value)
     step = step_autograd if args.autograd else step_abi
+    quiet_gc()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -331,6 +344,7 @@ def bench_latent_e2e(args):
         nfes.append(nfe)
         return total
 
+    quiet_gc()
     for _ in range(args.warmup):
         step()
     nfes.clear()
@@ -435,6 +449,7 @@ def bench_nsde(args, reg_type=None):
             L.rnde_nsde_timing(h.ptr, C.byref(a), C.byref(b), C.byref(na), C.byref(nc))
             stats["att"].append(na.value); stats["acc"].append(nc.value); stats["solve_ms"].append(a.value); stats["rev_ms"].append(b.value)
         return nfe1, nfe2
+    quiet_gc()
     for _ in range(args.warmup):
         step(False)
     torch.cuda.synchronize()
@@ -598,6 +613,7 @@ def main():
 
     def timed(restore):
         nfes.clear()
+        quiet_gc()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -627,6 +643,7 @@ def main():
         el_f, nfe_f, _ = timed(True)
         fixed = {"value": world * B * args.steps / el_f, "ms_per_step": 1e3 * el_f / args.steps, "mean_nfe": nfe_f}
         opt = rn.FluxOptimiser(model.trainable())                         # fresh optimiser state for the training leg
+    quiet_gc()
     for _ in range(args.warmup):
         train_step()
     elapsed, mean_nfe, last_loss = timed(False)

@@ -170,7 +170,41 @@ def main2():
     print("latent_dp5_B4 nfe", out["nfe_f32"], out["nfe_f64"])
 
 
+# round 5: the SDE layer's stiffness-estimate regulariser (reg_kind 2 on SOSRI2 = AutoSOSRI2(SOSRI2()), experiments/mnist_nsde.jl:51-61): same shapes and
+# portable inputs as NSDE_CASES, saved values |eigen_est| / 10.6, cotangent 0.1 / n on them (lambda 0.1 x mean, :52, :99)
+NSDE_STIFF_CASES = {"nsde_stiff_B8": (8, 0.14, 2.0, 0.5, {}, 41, 128), "nsde_stiff_B5_rejecting": (5, 0.1, 2.5, 0.8, dict(qmax=10.0, gamma=1.0, beta2=1e-9), 42, 400)}
+
+
+def nsde_stiff_inputs(name):
+    NSDE_CASES[name] = NSDE_STIFF_CASES[name]
+    try:
+        return nsde_inputs(name)
+    finally:
+        del NSDE_CASES[name]
+
+
+def main4():
+    from oracle.oracle_sde import SdeOracle
+    for name in NSDE_STIFF_CASES:
+        drift, diff, p, x, wu, noise, tol, ctrl = nsde_stiff_inputs(name)
+        out = {}
+        for tag, dt in (("f32", np.float32), ("f64", np.float64)):
+            o = SdeOracle(drift, diff, dt, tol, tol, tableau="SOSRI2", reg_kind=2, max_attempts=399, **ctrl)
+            r = o.forward(x, p, noise)
+            assert r["rc"] == 0
+            n = len(r["saveval"])
+            xb, pb = o.backward(wu, np.full(n, 3.0))
+            out.update({f"u_{tag}": r["u"], f"nfe1_{tag}": r["nfe1"], f"saveval_{tag}": r["saveval"], f"steps_{tag}": r["steps"], f"ndraws_{tag}": r["ndraws"],
+                        f"norms_{tag}": o.eigen_norms(), f"xbar_{tag}": xb, f"pbar_{tag}": pb})
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print(name, "attempts", len(out["steps_f32"]), len(out["steps_f64"]), "rejected", int((out["steps_f32"][:, 3] == 0).sum()), "saved", out["saveval_f64"][:4],
+              "bytes", os.path.getsize(os.path.join(HERE, name + ".npz")))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "stiff":          # only the round-5 fixtures
+        main4()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "devorder":      # only the round-3 fixture (the older ones stay byte-identical in git)
         main3()
         sys.exit(0)

@@ -108,6 +108,37 @@ def test_nsde_reproduces_golden(name, replay, mw, monkeypatch):
     assert rel_err(pb, g["pbar_f64"]) <= 1e-3 + 4 * sp
 
 
+@pytest.mark.parametrize("mw", ["1", "0"])
+@pytest.mark.parametrize("name,replay", [("nsde_stiff_B8", False), ("nsde_stiff_B5_rejecting", True)])
+def test_nsde_stiffness_regulariser_reproduces_golden(name, replay, mw, monkeypatch):
+    """RNDE_REG_STIFF on SOSRI2 (the reference's shipped NSDE default, experiments/configs/mnist_nsde.yml:6) against the committed fixtures, both
+    whole-solve kernels: same attempts / accept pattern / draws as the fp32 fixture, saved values |eigen_est| / 10.6 to 1e-3 of the fp64 ones (plus the
+    fixture's own fp32 spread), the two norms behind them, cotangents 1e-3 of the largest entry with the fp64 fixture as arbiter."""
+    from tests.golden.make_golden import nsde_stiff_inputs
+    from tests.test_gpu_nsde import _cfg
+    from tests.util import NsdeNode, rel_err
+    monkeypatch.setenv("RNDE_SDE_MW", mw)
+    drift, diff, p, x, wu, noise, tol, ctrl = nsde_stiff_inputs(name)
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    node = NsdeNode(_cfg(drift, diff, x.shape[0], reltol=tol, abstol=tol, solver="SOSRI2", regularize=2, max_attempts=399, **ctrl))
+    steps = g["steps_f32"]
+    got = node.forward(x.astype(np.float32), p.astype(np.float32), noise.astype(np.float32), keep_tape=True,
+                       replay=np.stack([steps[:, 1], steps[:, 3]], 1) if replay else None)
+    assert got["nattempts"] == len(steps) == len(g["steps_f64"]) and np.array_equal(got["steps"][:, 3], steps[:, 3])
+    assert got["ndraws"] == int(g["ndraws_f32"]) and got["nfe1"] == int(g["nfe1_f32"])
+    assert np.abs(got["u"] - g["u_f64"]).max() <= 2e-4 * max(1.0, np.abs(g["u_f64"]).max()) + 4 * np.abs(g["u_f32"] - g["u_f64"]).max()
+    sv64 = g["saveval_f64"]
+    assert len(got["saveval"]) == len(sv64) and got["saveval"][0] == np.float32(1.0) / np.float32(10.6)
+    spread = np.abs(g["saveval_f32"] - sv64).max()
+    assert np.abs(got["saveval"] - sv64).max() <= 1e-3 * np.abs(sv64).max() + 4 * spread
+    xb, pb = node.backward(wu.astype(np.float32), np.full(len(got["saveval"]), 3.0, dtype=np.float32))
+    sx, sp = rel_err(g["xbar_f32"], g["xbar_f64"]), rel_err(g["pbar_f32"], g["pbar_f64"])
+    print(name, "x-bar", rel_err(xb, g["xbar_f64"]), "(oracle f32:", sx, ") p-bar", rel_err(pb, g["pbar_f64"]), "(oracle f32:", sp, ")")
+    assert rel_err(xb, g["xbar_f64"]) <= 1e-3 + 4 * sx
+    assert rel_err(pb, g["pbar_f64"]) <= 1e-3 + 4 * sp
+    node.close()
+
+
 def test_device_natural_run_at_reference_tolerance_matches_devorder_golden():
     """NFE at reltol = abstol = 1.4e-8 (experiments/mnist_node.jl:121-124) against a COMMITTED fixture: the oracle run in the device's
     summation order (tests/golden/make_golden.py main3).  Same number of attempts (+-1), same accept pattern, steps within 20 %,

@@ -285,3 +285,27 @@ def test_sde_oracle_reproduces_golden(name, tag, dt):
     gt = 1e-8 if dt == np.float64 else 3e-3
     np.testing.assert_allclose(xb, g[f"xbar_{tag}"], rtol=gt, atol=gt * np.abs(g[f"xbar_{tag}"]).max())
     np.testing.assert_allclose(pb, g[f"pbar_{tag}"], rtol=gt, atol=gt * np.abs(g[f"pbar_{tag}"]).max())
+
+
+@pytest.mark.parametrize("tag,dt", [("f32", np.float32), ("f64", np.float64)])
+@pytest.mark.parametrize("name", ["nsde_stiff_B8", "nsde_stiff_B5_rejecting"])
+def test_sde_oracle_reproduces_the_stiffness_fixtures(name, tag, dt):
+    """Regression pin of the stiffness-estimate regulariser (reg_kind 2, SOSRI2) on the committed fixtures (tests/golden/make_golden.py stiff)."""
+    import os
+    from oracle.oracle_sde import SdeOracle
+    from tests.golden.make_golden import nsde_stiff_inputs
+    drift, diff, p, x, wu, noise, tol, ctrl = nsde_stiff_inputs(name)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    o = SdeOracle(drift, diff, dt, tol, tol, tableau="SOSRI2", reg_kind=2, max_attempts=399, **ctrl)
+    r = o.forward(x, p, noise)
+    assert r["rc"] == 0 and r["nfe1"] == int(g[f"nfe1_{tag}"]) and r["ndraws"] == int(g[f"ndraws_{tag}"])
+    assert np.array_equal(r["steps"][:, 3], g[f"steps_{tag}"][:, 3])
+    rt = 1e-11 if dt == np.float64 else 2e-4
+    np.testing.assert_allclose(r["u"], g[f"u_{tag}"], rtol=rt, atol=rt)
+    np.testing.assert_allclose(r["saveval"], g[f"saveval_{tag}"], rtol=10 * rt)
+    nn = o.eigen_norms()
+    np.testing.assert_allclose(r["saveval"][1:], (nn[:, 0] / nn[:, 1]) / 10.6, rtol=1e-6)
+    xb, pb = o.backward(wu, np.full(len(r["saveval"]), 3.0))
+    gt = 1e-8 if dt == np.float64 else 3e-3
+    np.testing.assert_allclose(xb, g[f"xbar_{tag}"], rtol=gt, atol=gt * np.abs(g[f"xbar_{tag}"]).max())
+    np.testing.assert_allclose(pb, g[f"pbar_{tag}"], rtol=gt, atol=gt * np.abs(g[f"pbar_{tag}"]).max())

@@ -282,11 +282,16 @@ def test_julia_golden_if_present():
     from oracle.oracle import Oracle
     for f in files:
         name = os.path.basename(f)[:-4]
+        stiff = name.endswith("_stiff")                      # the stiffness callback under AutoTsit5(Tsit5()): pins eigen_est = rms(k7 - k6) / rms(u - g6)
+        if stiff:
+            name = name[:-6]
         if name not in mg.CASES:
-            continue                     # the 1.4e-8 and SDE dumps pin statistics (NFE), compared in DESIGN.md by hand
+            continue                     # the 1.4e-8 and SDE dumps pin statistics (NFE, saved-value scale), compared in DESIGN.md by hand
         ref = _read_julia_dump(f)
+        if stiff:
+            assert abs(ref["stability_size"][0] - 3.5068) < 1e-3, ref["stability_size"]
         arch, p, x, wu, tol, t1 = mg.inputs(name)
-        o = Oracle(arch, np.float32, reltol=tol, abstol=tol, reg_kind=1)
+        o = Oracle(arch, np.float32, reltol=tol, abstol=tol, reg_kind=2 if stiff else 1)
         r = o.forward(x, p, 0.0, t1)
         assert r["nfe"] == int(ref["nfe"][0]), name
         B, Dd = x.shape

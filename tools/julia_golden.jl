@@ -83,6 +83,30 @@ for (name, mk, dims, td, B, tol, scale, t1, seed) in ode_cases
     println(name, ": nfe ", nfe, ", |saveval| ", length(sv.saveval))
 end
 
+# --- ODE cases with the STIFFNESS callback (experiments/mnist_node.jl:70-83: AutoTsit5(Tsit5()), |eigen_est| / alg_stability_size(Tsit5()), agg = maximum):
+# pins the [RECALL] formula eigen_est = rms(k7 - k6) / rms(u - g6) and its reverse.  Same inputs as the cases above; file NAME_stiff.txt.
+let stability_size = 1 / Float32(OrdinaryDiffEq.alg_stability_size(Tsit5()))
+    save_func(u, t, integrator) = (s = abs(integrator.eigen_est); stability_size * ((iszero(s) || isnan(s)) ? 0 : s))
+    for (name, mk, dims, td, B, tol, scale, t1, seed) in ode_cases[1:4]
+        model = mk() |> track
+        D = dims[1]
+        p = params_for(dims, td, seed, scale)
+        x = Float32.(reshape(lcg_uniform(B * D, seed + 1000), D, B))
+        wu = Float32.(reshape(lcg_uniform(B * D, seed + 2000, -1.0, 1.0), D, B))
+        node = TrackedNeuralODE(model, [0.0f0, t1], td, true, AutoTsit5(Tsit5()), save_everystep = false, reltol = tol, abstol = tol, save_start = false)
+        res, nfe, sv = node(x |> track, p |> track; func = save_func)
+        loss(xx, pp) = begin
+            r, _, s = node(xx, pp; func = save_func)
+            sum(wu .* r) + 25 * sum(s.saveval)
+        end
+        gx, gp = Tracker.gradient(loss, x, p)
+        dump(joinpath(outdir, name * "_stiff.txt"), ["u" => Tracker.data(res), "nfe" => nfe, "saveval" => Tracker.data.(sv.saveval),
+                                                     "xbar" => Tracker.data(gx), "pbar" => Tracker.data(gp), "tol" => tol, "B" => B,
+                                                     "stability_size" => OrdinaryDiffEq.alg_stability_size(Tsit5())])
+        println(name, "_stiff: nfe ", nfe, ", saveval[1:3] ", Tracker.data.(sv.saveval)[1:min(3, end)])
+    end
+end
+
 # --- SDE case: config-5 shapes at B = 24, reltol = abstol = 0.14 (experiments/mnist_nsde.jl:72-84).  Julia's RNG stream cannot be
 # fed to the oracle after the fact, so this case pins STATISTICS only (attempt count, nfe1 = nfe2 = 2 + 4 attempts, saveval scale);
 # a bitwise comparison would need the noise pool interface of include/rnde.h (rnde_nsde_forward(noise_dev = ...)) bound in Julia.
@@ -101,4 +125,28 @@ let B = 24, seed = 31
     end
     dump(joinpath(outdir, "nsde_B24_stats.txt"), ["attempts" => atts, "sum_saveval" => svs])
     println("nsde_B24: attempts ", atts)
+end
+
+# --- SDE, the SHIPPED default (experiments/configs/mnist_nsde.yml:6 `type: stiff_est` -> mnist_nsde.jl:51-61): AutoSOSRI2(SOSRI2()) and
+# |eigen_est| / alg_stability_size(SOSRI2()).  Statistics again (the RNG stream cannot be shared): per run the attempt count, the FIRST saved value
+# (the callback's initialisation: pins eigen_est's initial value, [RECALL] 1 -> 1 / 10.6), the mean of the others (pins the scale of
+# rms(k4 - k3) / rms(H0_4 - H0_3), [RECALL]) -- and the constant itself.  The oracle / device counterpart: tests/test_gpu_nsde.py::test_stiffness_estimate_*.
+let B = 24, seed = 41
+    stab = StochasticDiffEq.alg_stability_size(SOSRI2())
+    stability_size = 1 / Float32(stab)
+    save_func(u, t, integrator) = (s = abs(integrator.eigen_est); stability_size * ((iszero(s) || isnan(s)) ? 0 : s))
+    drift = Chain(Dense(32, 64, tanh), Dense(64, 32)) |> track
+    diff = Dense(32, 32) |> track
+    nsde = TrackedNeuralDSDE(drift, diff, [0.0f0, 1.0f0], true, AutoSOSRI2(SOSRI2()), save_everystep = false, reltol = 1.4f-1, abstol = 1.4f-1, save_start = false)
+    p = vcat(params_for([32, 64, 32], false, seed, 2.0), params_for([32, 32], false, seed + 500, 0.5))      # = tests/golden/make_golden.py nsde_stiff_inputs
+    x = Float32.(reshape(lcg_uniform(B * 32, seed + 1000, -1.0, 1.0), 32, B))
+    Random.seed!(1999)
+    atts = Int[]; first_sv = Float64[]; mean_sv = Float64[]
+    for rep = 1:32
+        res, nfe1, nfe2, sv = nsde(x |> track, p |> track; func = save_func)
+        v = Float64.(Tracker.data.(sv.saveval))
+        push!(atts, (nfe1 - 2) ÷ 4); push!(first_sv, v[1]); push!(mean_sv, sum(v[2:end]) / max(1, length(v) - 1))
+    end
+    dump(joinpath(outdir, "nsde_stiff_B24_stats.txt"), ["attempts" => atts, "first_saveval" => first_sv, "mean_saveval_after_first" => mean_sv, "stability_size" => stab])
+    println("nsde_stiff_B24: attempts ", atts, " mean saved value ", sum(mean_sv) / length(mean_sv), " stability size ", stab)
 end

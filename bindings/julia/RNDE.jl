@@ -89,11 +89,11 @@ struct MockIntegrator
     dt::Float32
     eigen_est::Float32
 end
-const REG_NONE, REG_ERR, REG_STIFF, REG_ERR_STIFF = 0, 1, 2, 3
+const REG_NONE, REG_ERR, REG_STIFF, REG_ERR_STIFF, REG_STIFF_DT = 0, 1, 2, 3, 4
 const _PROBES = (MockIntegrator(2f0, 3f0, 5f0), MockIntegrator(0.5f0, 0.25f0, -7f0))
 
 """
-    reg_code(func, stability_size) -> REG_NONE | REG_ERR | REG_STIFF | REG_ERR_STIFF
+    reg_code(func, stability_size) -> REG_NONE | REG_ERR | REG_STIFF | REG_ERR_STIFF | REG_STIFF_DT
 
 `stability_size`: `alg_stability_size` of the solver the experiment divides by (Tsit5: 3.5068, SOSRI2: 10.6).
 """
@@ -103,11 +103,12 @@ function reg_code(func, stability_size::Real)
     want = Dict(REG_NONE => m -> 0.0,
                 REG_ERR => m -> Float64(m.EEst) * m.dt,
                 REG_STIFF => m -> abs(Float64(m.eigen_est)) / s,
-                REG_ERR_STIFF => m -> Float64(m.EEst) * m.dt + 0.1 * Float64(m.eigen_est) / s)
-    for code in (REG_NONE, REG_ERR, REG_STIFF, REG_ERR_STIFF)
+                REG_ERR_STIFF => m -> Float64(m.EEst) * m.dt + 0.1 * Float64(m.eigen_est) / s,
+                REG_STIFF_DT => m -> abs(Float64(m.eigen_est) * m.dt))      # the reference's own test: abs(integrator.eigen_est * integrator.dt), test/test_node.jl:75,:84
+    for code in (REG_NONE, REG_ERR, REG_STIFF, REG_ERR_STIFF, REG_STIFF_DT)
         all(isapprox(g, want[code](m); rtol = 1e-4, atol = 1e-7) for (g, m) in zip(got, _PROBES)) && return code
     end
-    error("RNDE: `func` is none of the callbacks librnde.so computes (EEst*dt, |eigen_est|/stability_size, EEst*dt + 0.1*eigen_est/stability_size, 0): ",
+    error("RNDE: `func` is none of the callbacks librnde.so computes (EEst*dt, |eigen_est|/stability_size, EEst*dt + 0.1*eigen_est/stability_size, |eigen_est*dt|, 0): ",
           "on (EEst, dt, eigen_est) = (2, 3, 5) and (0.5, 0.25, -7) it returned ", got)
 end
 
@@ -124,7 +125,7 @@ end
 function effective_reg(code::Int, composite::Bool)
     composite && return code
     code == REG_ERR_STIFF && return REG_ERR
-    code == REG_STIFF && error("RNDE: `func` reads integrator.eigen_est, which only the composite solvers (AutoTsit5 / AutoSOSRI2) fill; ",
+    (code == REG_STIFF || code == REG_STIFF_DT) && error("RNDE: `func` reads integrator.eigen_est, which only the composite solvers (AutoTsit5 / AutoSOSRI2) fill; ",
                                "with a plain solver the reference records zeros -- build the layer with the composite solver")
     return code
 end

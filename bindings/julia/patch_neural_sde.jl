@@ -29,7 +29,7 @@ function _sde_codes(n::TrackedNeuralDSDE{R}, func) where {R}
     reg = R ? RNDE.effective_reg(RNDE.reg_code(func, SOSRI2_STABILITY_SIZE), composite) : RNDE.REG_NONE
     reg in (RNDE.REG_NONE, RNDE.REG_ERR) || name === :SOSRI2 ||
         error("RNDE: the stiffness estimate of an SRI step is defined for SOSRI2 only (its last two drift stages share one time); got ", name)
-    reg == RNDE.REG_ERR_STIFF && error("RNDE: the SDE layer records EEst*dt or the stiffness estimate (mnist_nsde.jl:45-61), not their blend")
+    (reg == RNDE.REG_ERR_STIFF || reg == RNDE.REG_STIFF_DT) && error("RNDE: the SDE layer records EEst*dt or the stiffness estimate (mnist_nsde.jl:45-61), not their blend and not |eigen_est*dt|")
     return _SDE_SOLVERS[name], reg
 end
 

@@ -56,7 +56,9 @@ typedef enum { RNDE_ACT_IDENTITY = 0, RNDE_ACT_TANH = 1 } rnde_act;
  * coefficients are at hand.  End state only (no dense output in the table); callbacks none / EEst*dt; NFE = 3 + 12 per attempted step. */
 typedef enum { RNDE_SOLVER_TSIT5 = 0, RNDE_SOLVER_DP5 = 1, RNDE_SOLVER_DOP853 = 2 } rnde_solver;
 /* func passed to the layer call (neural_ode.jl:116; experiments/mnist_node.jl:67,:74-79,:88-97) */
-typedef enum { RNDE_REG_NONE = 0, RNDE_REG_ERR = 1, RNDE_REG_STIFF = 2, RNDE_REG_ERR_STIFF = 3 } rnde_reg;
+typedef enum { RNDE_REG_NONE = 0, RNDE_REG_ERR = 1, RNDE_REG_STIFF = 2, RNDE_REG_ERR_STIFF = 3,
+               RNDE_REG_STIFF_DT = 4   /* |eigen_est * dt|: the callback of the reference's own test (test/test_node.jl:75,:84; the comment at src/models/neural_ode.jl:115) */
+} rnde_reg;
 
 typedef struct {
     /* dynamics: Dense chain; time_dep = TDChain semantics (src/models/basic.jl:16-23,

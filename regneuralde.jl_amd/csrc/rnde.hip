@@ -57,7 +57,7 @@ static rnde_status chain_create(const rnde_node_config* c, rnde_node** out) {
     // LDS: fragment tables rounded up to whole 1 KiB DMA units, then 64 floats of reduction scratch
     size_t lds_f = ((size_t)((G.nfrag_f + G.nfrag_b + 3) / 4) * 256 + 64) * 4, lds_b = ((size_t)((G.nfrag_f + G.nfrag_b + G.nfrag_t + 3) / 4) * 256 + 64) * 4;
     if (lds_b > 160 * 1024) { g_create_err = "chain too large: its weight fragments must fit the 160 KB LDS of a CU"; return RNDE_ERR_BAD_ARG; }
-    if (c->regularize < RNDE_REG_NONE || c->regularize > RNDE_REG_ERR_STIFF) { g_create_err = "regularize: unknown value"; return RNDE_ERR_BAD_ARG; }
+    if (c->regularize < RNDE_REG_NONE || c->regularize > RNDE_REG_STIFF_DT) { g_create_err = "regularize: unknown value"; return RNDE_ERR_BAD_ARG; }
     if (c->col_tile != 0 && c->col_tile != 64 && c->col_tile != 65) { g_create_err = "col_tile: this network runs on the chain engine (0 = auto, 64 = one wave per column tile, 65 = four waves per column tile)"; return RNDE_ERR_BAD_ARG; }
     if (c->max_batch < 1 || c->max_attempts < 1) { g_create_err = "max_batch / max_attempts"; return RNDE_ERR_BAD_ARG; }
     rnde_node* h = new rnde_node();
@@ -315,7 +315,7 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
         return RNDE_ERR_BAD_ARG;
     }
     if (c->col_tile == 64 || c->col_tile == 65 || !mnist_form) return chain_create(c, out);   // small-width chains (latent_ode.jl:113-124): rnde_chain.h
-    if (c->regularize < RNDE_REG_NONE || c->regularize > RNDE_REG_ERR_STIFF) { g_create_err = "regularize: unknown value"; return RNDE_ERR_BAD_ARG; }
+    if (c->regularize < RNDE_REG_NONE || c->regularize > RNDE_REG_STIFF_DT) { g_create_err = "regularize: unknown value"; return RNDE_ERR_BAD_ARG; }
     rnde_node* h = new rnde_node();
     h->cfg = *c;
     h->D = c->dims[0]; h->H = c->dims[1]; h->P = rnde_param_count(c); h->act2 = c->act[1];
@@ -946,6 +946,7 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
             case RNDE_REG_ERR: return eest * dt;
             case RNDE_REG_STIFF: return eg_ok ? stab * fabsf(eig) : 0.f;
             case RNDE_REG_ERR_STIFF: { const float e = eest * dt; return ((e == 0.f || e != e) ? 0.f : e) + 0.1f * (eg_ok ? stab * eig : 0.f); }
+            case RNDE_REG_STIFF_DT: return fabsf(eig * dt);      // test/test_node.jl:75: abs(integrator.eigen_est * integrator.dt)
             default: return 0.f;
         }
     };

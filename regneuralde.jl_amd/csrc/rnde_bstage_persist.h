@@ -197,6 +197,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
             if (accepted) {
                 const bool err_term = Bq.reg_kind == 1 || (Bq.reg_kind == 3 && !(m.eest * dt == 0.f));
                 if (err_term) { const double sb = (double)svb_n; eb += sb * (double)dt; dtb_pre += sb * (double)m.eest; }
+                if (Bq.reg_kind == 4 && !(m.eigen == 0.f || m.eigen != m.eigen)) dtb_pre += (double)svb_n * ((double)m.eigen * (double)dt > 0 ? 1.0 : -1.0) * (double)m.eigen;      // |eigen_est * dt|: its dt share (the eigen_est share travels as eig_c1 / eig_c2)
                 dtb_pre += tb;
                 if (m.flags & F_DTMAXCLAMP) { t1b += dtpb; t0b -= dtpb; }
                 else if (Bq.track_ctrl) { dtb_pre += dtpb / (double)m.q; qb += -dtpb * (double)dt / ((double)m.q * (double)m.q); }

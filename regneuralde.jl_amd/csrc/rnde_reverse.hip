@@ -280,6 +280,7 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
             double eigb = 0.0;
             if (h->cfg.regularize == RNDE_REG_STIFF && eg_ok) eigb = (double)b.h_svb[n] * (mm.eigen > 0 ? 1.0 : -1.0) / 3.5068;
             if (h->cfg.regularize == RNDE_REG_ERR_STIFF && eg_ok) eigb = 0.1 * (double)b.h_svb[n] / 3.5068;
+            if (h->cfg.regularize == RNDE_REG_STIFF_DT && eg_ok) eigb = (double)b.h_svb[n] * ((double)mm.eigen * (double)mm.dt > 0 ? 1.0 : -1.0) * (double)mm.dt;      // |eigen_est * dt| (test/test_node.jl:75)
             if (eigb != 0.0 && mm.n1 > 0.f && mm.n2 > 0.f) {
                 c1 = (float)(eigb / ((double)mm.n2 * (double)mm.n1));
                 c2 = (float)(-eigb * ((double)mm.n1 / (double)mm.n2) / ((double)mm.n2 * (double)mm.n2));
@@ -518,6 +519,7 @@ static hipError_t launch_bchain_t(rnde_node* h, const BChainParams& Q, const std
         double eigb = 0.0;
         if (h->cfg.regularize == RNDE_REG_STIFF && eg_ok) eigb = (double)b.h_svb[n] * (mm.eigen > 0 ? 1.0 : -1.0) / 3.5068;
         if (h->cfg.regularize == RNDE_REG_ERR_STIFF && eg_ok) eigb = 0.1 * (double)b.h_svb[n] / 3.5068;
+        if (h->cfg.regularize == RNDE_REG_STIFF_DT && eg_ok) eigb = (double)b.h_svb[n] * ((double)mm.eigen * (double)mm.dt > 0 ? 1.0 : -1.0) * (double)mm.dt;      // |eigen_est * dt| (test/test_node.jl:75)
         if (eigb != 0.0 && mm.n1 > 0.f && mm.n2 > 0.f) {
             c1 = (float)(eigb / ((double)mm.n2 * (double)mm.n1));
             c2 = (float)(-eigb * ((double)mm.n1 / (double)mm.n2) / ((double)mm.n2 * (double)mm.n2));
@@ -558,6 +560,7 @@ static rnde_status launch_bmw_t(rnde_node* h, const BMwParams& Q, const std::vec
         double eigb = 0.0;
         if (h->cfg.regularize == RNDE_REG_STIFF && eg_ok) eigb = (double)b.h_svb[n] * (mm.eigen > 0 ? 1.0 : -1.0) / 3.5068;
         if (h->cfg.regularize == RNDE_REG_ERR_STIFF && eg_ok) eigb = 0.1 * (double)b.h_svb[n] / 3.5068;
+        if (h->cfg.regularize == RNDE_REG_STIFF_DT && eg_ok) eigb = (double)b.h_svb[n] * ((double)mm.eigen * (double)mm.dt > 0 ? 1.0 : -1.0) * (double)mm.dt;      // |eigen_est * dt| (test/test_node.jl:75)
         if (eigb != 0.0 && mm.n1 > 0.f && mm.n2 > 0.f) {
             c1 = (float)(eigb / ((double)mm.n2 * (double)mm.n1));
             c2 = (float)(-eigb * ((double)mm.n1 / (double)mm.n2) / ((double)mm.n2 * (double)mm.n2));

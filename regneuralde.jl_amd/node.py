@@ -24,8 +24,8 @@ from . import _lib
 from .layers import destructure
 
 _ACT = {"identity": 0, "tanh": 1}
-_FUNCS = {None: 1, "none": 0, "error_est": 1, "stiff_est": 2, "error_stiff_est": 3}      # None: the layer's default callback (neural_ode.jl:116)
-_FUNC_NAMES = {0: "none", 1: "error_est", 2: "stiff_est", 3: "error_stiff_est"}
+_FUNCS = {None: 1, "none": 0, "error_est": 1, "stiff_est": 2, "error_stiff_est": 3, "stiff_est_dt": 4}      # None: the layer's default callback (neural_ode.jl:116)
+_FUNC_NAMES = {0: "none", 1: "error_est", 2: "stiff_est", 3: "error_stiff_est", 4: "stiff_est_dt"}
 TSIT5_STABILITY_SIZE = 3.5068     # OrdinaryDiffEq.alg_stability_size(Tsit5()): what mnist_node.jl:73,:86 divides by
 SOSRI2_STABILITY_SIZE = 10.6      # StochasticDiffEq.alg_stability_size(SOSRI2()): mnist_nsde.jl:55
 
@@ -43,16 +43,17 @@ _PROBES = ((2.0, 3.0, 5.0), (0.5, 0.25, -7.0))
 def reg_code(func, stability_size):
     """rnde_reg code (include/rnde.h) of a caller's callback `func(u, t, integrator)`: its values on two mock integrators are matched against
     the reference's callbacks -- 0 (neural_ode.jl:54), EEst*dt (mnist_node.jl:67), |eigen_est|/stability_size (:74-79), EEst*dt +
-    0.1*eigen_est/stability_size (:88-97).  The same rule as bindings/julia/RNDE.jl::reg_code.  Raises ValueError for anything else: a
+    0.1*eigen_est/stability_size (:88-97), |eigen_est*dt| (test/test_node.jl:75).  The same rule as bindings/julia/RNDE.jl::reg_code.  Raises ValueError for anything else: a
     regulariser the kernels do not compute must not be replaced by another one silently."""
     got = [float(func(None, 0.0, MockIntegrator(*m))) for m in _PROBES]
     s = float(stability_size)
-    want = {0: lambda e, d, g: 0.0, 1: lambda e, d, g: e * d, 2: lambda e, d, g: abs(g) / s, 3: lambda e, d, g: e * d + 0.1 * g / s}
-    for code in (0, 1, 2, 3):
+    want = {0: lambda e, d, g: 0.0, 1: lambda e, d, g: e * d, 2: lambda e, d, g: abs(g) / s, 3: lambda e, d, g: e * d + 0.1 * g / s,
+            4: lambda e, d, g: abs(g * d)}      # 4: the reference's own test, func = abs(integrator.eigen_est * integrator.dt) (test/test_node.jl:75,:84)
+    for code in (0, 1, 2, 3, 4):
         if all(abs(v - want[code](*m)) <= 1e-4 * abs(want[code](*m)) + 1e-7 for v, m in zip(got, _PROBES)):
             return code
     raise ValueError("func is none of the callbacks librnde.so computes (EEst*dt, |eigen_est|/stability_size, EEst*dt + "
-                     f"0.1*eigen_est/stability_size, 0): on (EEst, dt, eigen_est) = {_PROBES[0]} and {_PROBES[1]} it returned {got}")
+                     f"0.1*eigen_est/stability_size, |eigen_est*dt|, 0): on (EEst, dt, eigen_est) = {_PROBES[0]} and {_PROBES[1]} it returned {got}")
 
 
 def effective_reg(code, composite):
@@ -303,7 +304,7 @@ class TrackedNeuralODE:
             func = _FUNC_NAMES[effective_reg(reg_code(func, TSIT5_STABILITY_SIZE), self.solver == "AutoTsit5")] if self.regularize else None
         if func not in _FUNCS:
             raise ValueError("func must be a callback (u, t, integrator) -> value or one of None/'error_est', 'stiff_est', "
-                             "'error_stiff_est' (the three callbacks of experiments/mnist_node.jl:62-103)")
+                             "'error_stiff_est' (the three callbacks of experiments/mnist_node.jl:62-103), 'stiff_est_dt' (test/test_node.jl:75)")
         self._func = func if self.regularize else None
         keep = torch.is_grad_enabled() and (x2.requires_grad or p.requires_grad)
         times = None

@@ -173,8 +173,8 @@ class TrackedNeuralDSDE:
         else:
             raise ValueError("func: a callback (u, t, integrator) -> value, or 'error_est' (EEst*dt, neural_sde.jl:87) / 'stiff_est' "
                              "(|eigen_est| / 10.6, experiments/mnist_nsde.jl:51-61)")
-        if code == 3:
-            raise ValueError("the SDE layer records EEst*dt or the stiffness estimate (mnist_nsde.jl:45-61), not their blend")
+        if code in (3, 4):
+            raise ValueError("the SDE layer records EEst*dt or the stiffness estimate (mnist_nsde.jl:45-61), not their blend and not |eigen_est*dt|")
         if code == 2 and self.solver not in ("SOSRI2", "AutoSOSRI2"):
             raise ValueError("the stiffness estimate of an SRI step is defined for SOSRI2 / AutoSOSRI2 only (mnist_nsde.jl:60)")
         return code

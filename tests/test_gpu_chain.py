@@ -251,7 +251,7 @@ def test_chain_generic_dispatch_path_on_latent_shape(monkeypatch):
 
 
 @pytest.mark.parametrize("kind,B,tol,scale", [("latent", 21, 1e-3, 1.5), ("chain3", 19, 1e-3, 2.0), ("small", 12, 1e-3, 4.0)])
-@pytest.mark.parametrize("reg,agg", [(2, "max"), (2, "mean"), (3, "mean")])
+@pytest.mark.parametrize("reg,agg", [(2, "max"), (2, "mean"), (3, "mean"), (4, "mean")])      # 4: |eigen_est * dt|, the callback of test/test_node.jl:75
 def test_chain_stiffness_regulariser_matches_oracle(kind, B, tol, scale, reg, agg):
     """regularize = stiff_est / error_stiff_est on the chain engine (latent_ode.jl:127-136 selects AutoTsit5(Tsit5()) for them):
     callback values and the reverse pass of eigen_est = ||k7-k6|| / ||u-g6|| against the oracle."""

@@ -660,7 +660,7 @@ def test_stiffness_estimate_layer_contract():
     nsde.seed = 100
     u_e, _, _, sv_e = nsde(x, p, func=lambda u, t, integ: integ.EEst * integ.dt)
     assert torch.equal(u.detach(), u_e.detach()) and n1 == n2 and len(sv.saveval) == len(sv_e.saveval)      # same solve, another recorded value
-    assert float(sv.saveval[0]) == np.float32(1.0) / np.float32(10.6) and float(sv_e.saveval[0]) == 0.0
+    assert float(sv.saveval[0].detach()) == np.float32(1.0) / np.float32(10.6) and float(sv_e.saveval[0].detach()) == 0.0
     assert not torch.allclose(sv.saveval[1:], sv_e.saveval[1:])
     loss = u.square().mean() + 0.1 * sv.saveval.mean()
     loss.backward()

@@ -123,6 +123,7 @@ def test_callers_func_is_recognised_not_replaced(rnde):
     assert N.reg_code(stiff, N.TSIT5_STABILITY_SIZE) == 2
     assert N.reg_code(both, N.TSIT5_STABILITY_SIZE) == 3
     assert N.reg_code(lambda u, t, integ: torch.tensor(integ.EEst) * integ.dt, 3.5068) == 1       # tracked scalars are fine
+    assert N.reg_code(lambda u, t, integ: abs(integ.eigen_est * integ.dt), N.TSIT5_STABILITY_SIZE) == 4      # the reference's own test: test/test_node.jl:75,:84
     sde_stiff = lambda u, t, integ: abs(integ.eigen_est) / 10.6      # mnist_nsde.jl:53-58
     assert N.reg_code(sde_stiff, N.SOSRI2_STABILITY_SIZE) == 2
     for bad in (lambda u, t, integ: 2 * integ.EEst * integ.dt, lambda u, t, integ: integ.EEst, sde_stiff):
@@ -130,8 +131,10 @@ def test_callers_func_is_recognised_not_replaced(rnde):
             N.reg_code(bad, N.TSIT5_STABILITY_SIZE)
     # what the reference's run records under a plain solver: eigen_est stays 0 there
     assert N.effective_reg(3, composite=False) == 1 and N.effective_reg(3, composite=True) == 3 and N.effective_reg(1, False) == 1
-    with pytest.raises(ValueError, match="composite"):
-        N.effective_reg(2, composite=False)
+    for code in (2, 4):
+        with pytest.raises(ValueError, match="composite"):
+            N.effective_reg(code, composite=False)
+    assert N.effective_reg(4, composite=True) == 4
     # the layer resolves the closure before it looks for a handle (no GPU needed to get that far: the cuda check comes first)
     dyn = rnde.MLPDynamics(8, 4)
     node = rnde.TrackedNeuralODE(dyn, [0.0, 1.0], True, True, "AutoTsit5", reltol=1e-3, abstol=1e-3)
@@ -157,7 +160,7 @@ def test_julia_patches_dispatch_on_the_callers_func():
     assert N._PROBES == ((2.0, 3.0, 5.0), (0.5, 0.25, -7.0))
     assert "TSIT5_STABILITY_SIZE = 3.5068" in ode and "SOSRI2_STABILITY_SIZE = 10.6" in sde
     assert (N.TSIT5_STABILITY_SIZE, N.SOSRI2_STABILITY_SIZE) == (3.5068, 10.6)
-    for code in ("REG_NONE", "REG_ERR", "REG_STIFF", "REG_ERR_STIFF"):
+    for code in ("REG_NONE", "REG_ERR", "REG_STIFF", "REG_ERR_STIFF", "REG_STIFF_DT"):
         assert re.search(code + r" => m ->", mod), code
 
 

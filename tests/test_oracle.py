@@ -103,11 +103,11 @@ def test_fixed_step_convergence_order_linear_ode():
 
 
 # ---------------------------------------------------------------- 3. finite differences (fp64)
-def _fd_check(arch, B, tol, scale, seed, t1=1.0, saveat=None, ws=10.0, eps=1e-6, **kw):
+def _fd_check(arch, B, tol, scale, seed, t1=1.0, saveat=None, ws=10.0, eps=1e-6, reg_kind=1, **kw):
     rng = np.random.default_rng(seed)
     p = glorot_params(arch, rng, np.float64); p = (p + 0.1 * rng.standard_normal(p.shape)) * scale
     x = rng.uniform(0, 1, (B, arch.dims[0]))
-    o = Oracle(arch, np.float64, reltol=tol, abstol=tol, reg_kind=1, **kw)
+    o = Oracle(arch, np.float64, reltol=tol, abstol=tol, reg_kind=reg_kind, **kw)
     r0 = o.forward(x, p, 0.0, t1, saveat=saveat)
     wgt = np.random.default_rng(5).standard_normal(r0["u"].shape)
 
@@ -151,6 +151,17 @@ def test_reverse_pass_fd_mnist_like_shape():
 def test_reverse_pass_fd_latent_chain_with_saveat():
     ep, ex, et, _ = _fd_check(arch_latent(), 2, 1e-3, 2.0, 4, saveat=np.array([0.0, 0.13, 0.5, 0.77, 1.0]))
     assert ep < 1e-5 and ex < 1e-5
+
+
+@pytest.mark.parametrize("reg_kind", [2, 3, 4])
+def test_reverse_pass_fd_stiffness_callbacks(reg_kind):
+    """The callbacks that read integrator.eigen_est (= rms(k7 - k6) / rms(u_new - g6) under AutoTsit5(Tsit5())): 2 = |eigen_est| / 3.5068
+    (experiments/mnist_node.jl:74-79), 3 = EEst*dt + 0.1 eigen_est / 3.5068 (:88-97), 4 = |eigen_est * dt| (the reference's own test,
+    test/test_node.jl:75,:84) -- fp64 central differences of the whole reverse pass, the callback's term weighted so that it is a visible share."""
+    ep, ex, et, _ = _fd_check(arch_test_node(), 3, 1e-3, 3.0, 0, ws=3.0, reg_kind=reg_kind)
+    assert ep < 2e-5 and ex < 2e-5 and et < 2e-5, (ep, ex, et)
+    ep, ex, et, _ = _fd_check(arch_mnist(12, 5), 4, 1e-2, 5.0, 1, ws=3.0, reg_kind=reg_kind)
+    assert ep < 2e-5 and ex < 2e-5 and et < 2e-5, (ep, ex, et)
 
 
 def test_reverse_pass_fd_with_rejected_step():

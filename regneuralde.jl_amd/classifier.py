@@ -42,11 +42,14 @@ class ClassifierNODE:
         return u @ W + b, nfe, sv
 
 
-def fused_loss_and_grad(model, x, y, lam=1.0e2, regularize=True, tspan=None, sync=True, flat=None, reducer=None):
+def fused_loss_and_grad(model, x, y, lam=1.0e2, regularize=True, tspan=None, sync=True, flat=None, reducer=None, func=None, agg="mean"):
     """One training-step gradient without a tape library in the loop:
     [solve, taped] -> [fused Dense(784,10) + logitcrossentropy + their reverse] -> [reverse solve], all through the C ABI.
-    Same loss surface as `loss_function` (experiments/mnist_node.jl:132-137, agg = mean): sets .grad on p2 and p3 and
+    Same loss surface as `loss_function` (experiments/mnist_node.jl:132-137): sets .grad on p2 and p3 and
     returns (total_loss, cross_entropy, reg, nfe) as Python floats / int (the call already synchronises).
+    func: the experiment's `save_func` -- a closure or a name, as for the layer call (None: the layer's default EEst*dt); agg: "mean" or "max" (also
+    torch.mean / torch.max: `agg` of mnist_node.jl:69,:80,:98 -- `maximum` for stiff_est).  With "max" the saved values' cotangent is lambda at the
+    largest one, which the host has to pick: the step then runs as three library calls instead of one.
     sync=False: the reverse pass is only enqueued (rnde_node_backward_async) and the losses come back as device tensors, so a
     training loop can queue the optimiser update and the next step underneath it; nothing is read on the host.
     flat (dataparallel.FlatGrads over model.trainable()): the reverse pass writes both gradients straight into that one
@@ -61,7 +64,10 @@ def fused_loss_and_grad(model, x, y, lam=1.0e2, regularize=True, tspan=None, syn
         _check_f32(name, t)
     x2 = x.reshape(x.shape[0], -1).contiguous()
     B, D = x2.shape
-    node._func = "error_est" if node.regularize else None
+    node._func = node.resolve_func(func)
+    agg_max = agg in ("max", "maximum", torch.max)
+    if not agg_max and agg not in ("mean", torch.mean):
+        raise ValueError("agg: 'mean' or 'max' (mnist_node.jl:69,:80,:98)")
     h = node._acquire(x2, True)
     ts = node.tspan if tspan is None else [float(tspan[0]), float(tspan[1])]
     stream = C.c_void_p(torch.cuda.current_stream(x2.device).cuda_stream)
@@ -76,7 +82,7 @@ def fused_loss_and_grad(model, x, y, lam=1.0e2, regularize=True, tspan=None, syn
         p2bar, p3bar = flat.views[0], flat.views[1]
     else:
         p2bar, p3bar = torch.empty_like(model.p2), torch.empty_like(model.p3)
-    if not sync and node.col_tile == 0 and (reducer is None or reducer.comm is not None) and os.environ.get("RNDE_ONE_CALL", "1") != "0":   # (0: A/B switch)
+    if not sync and not agg_max and node.col_tile == 0 and (reducer is None or reducer.comm is not None) and os.environ.get("RNDE_ONE_CALL", "1") != "0":   # (0: A/B switch)
         # the whole step gradient as ONE library call (rnde_node_classifier_grad): head and reverse-sweep packs are queued before
         # the forward's host wait, so the GPU does not idle between the solve and its reverse
         ce = torch.empty(1, dtype=torch.float32, device=x2.device)
@@ -103,9 +109,15 @@ def fused_loss_and_grad(model, x, y, lam=1.0e2, regularize=True, tspan=None, syn
     n = nsv.value
     reg = 0.0
     svb = None
-    if regularize and n > 0:
-        reg = lam * sum(sv[:n]) / n                       # lambda * mean(sv.saveval)
-        svb = (C.c_float * n)(*([lam / n] * n))
+    if regularize and n > 0 and node.regularize:
+        if agg_max:                                       # lambda * maximum(sv.saveval): the cotangent sits on the (first) largest value
+            vals = list(sv[:n])
+            k = max(range(n), key=lambda i: vals[i])
+            reg = lam * vals[k]
+            svb = (C.c_float * n)(*[lam if i == k else 0.0 for i in range(n)])
+        else:
+            reg = lam * sum(sv[:n]) / n                   # lambda * mean(sv.saveval)
+            svb = (C.c_float * n)(*([lam / n] * n))
     xbar = torch.empty_like(x2)
     n2 = p2bar.numel()
     if not sync:

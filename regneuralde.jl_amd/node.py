@@ -282,6 +282,18 @@ class TrackedNeuralODE:
             raise ValueError("saveat must be strictly increasing inside tspan")
         return v
 
+    def resolve_func(self, func):
+        """The name of the library callback a call's `func` selects (None when the layer does not regularise): a closure `(u, t, integrator) -> value`
+        as the reference passes it (mnist_node.jl:134) is recognised, not called per step; names pass through."""
+        if not self.regularize:
+            return None
+        if callable(func):
+            func = _FUNC_NAMES[effective_reg(reg_code(func, TSIT5_STABILITY_SIZE), self.solver == "AutoTsit5")]
+        if func not in _FUNCS:
+            raise ValueError("func must be a callback (u, t, integrator) -> value or one of None/'error_est', 'stiff_est', "
+                             "'error_stiff_est' (the three callbacks of experiments/mnist_node.jl:62-103), 'stiff_est_dt' (test/test_node.jl:75)")
+        return func
+
     # -- call operator ------------------------------------------------------------------------
     def __call__(self, x, p=None, func=None, tspan=None, saveat=None):
         """(x, p = n.p; func, tspan, saveat) -> (res, nfe, sv)   [neural_ode.jl:48-54,:76,:110-119,:143]"""
@@ -300,12 +312,7 @@ class TrackedNeuralODE:
         _check_f32("x", x)
         x2 = x.reshape(x.shape[0], -1).contiguous()
         ts = self.tspan if tspan is None else [float(tspan[0]), float(tspan[1])]   # _convert_tspan, utils.jl:21-23
-        if callable(func):     # the reference's closure (mnist_node.jl:134): recognised, not called per step
-            func = _FUNC_NAMES[effective_reg(reg_code(func, TSIT5_STABILITY_SIZE), self.solver == "AutoTsit5")] if self.regularize else None
-        if func not in _FUNCS:
-            raise ValueError("func must be a callback (u, t, integrator) -> value or one of None/'error_est', 'stiff_est', "
-                             "'error_stiff_est' (the three callbacks of experiments/mnist_node.jl:62-103), 'stiff_est_dt' (test/test_node.jl:75)")
-        self._func = func if self.regularize else None
+        self._func = self.resolve_func(func)
         keep = torch.is_grad_enabled() and (x2.requires_grad or p.requires_grad)
         times = None
         if self.return_multiple and self.save_everystep and saveat is None:

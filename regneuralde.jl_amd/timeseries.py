@@ -242,7 +242,7 @@ class _LatentHandle:
             pass
 
 
-def fused_latent_loss_and_grad(model, data, mask, t_row, lam_r=1.0e2, lam_k=1.0, regularize=True, saveat=None, generator=None, eps=None):
+def fused_latent_loss_and_grad(model, data, mask, t_row, lam_r=1.0e2, lam_k=1.0, regularize=True, saveat=None, generator=None, eps=None, func=None, agg="mean"):
     """One training-step gradient of the latent-ODE model WITHOUT a tape library in the loop: every piece of
     loss_function (experiments/latent_ode.jl:206-236) and of its reverse runs in librnde.so --
 
@@ -252,7 +252,8 @@ def fused_latent_loss_and_grad(model, data, mask, t_row, lam_r=1.0e2, lam_k=1.0,
         rnde_node_backward_async    reverse sweep of the solve
         rnde_latent_encode_backward reverse of rec_to_gen and of the GRU (one launch) + the weight-gradient GEMMs
 
-    Same loss surface as `latent_loss_function` (agg = mean, func = error_est).  Sets .grad on (p1, p2, p3, p4); returns
+    Same loss surface as `latent_loss_function`; `func` (closure or name: latent_ode.jl:154-190 defines the same three `save_func`s as mnist_node.jl) and
+    `agg` ("mean" / "max": `maximum` for stiff_est, :171) as for `classifier.fused_loss_and_grad`.  Sets .grad on (p1, p2, p3, p4); returns
     (total, nll, kl, reg, nfe) -- total / nll / kl as device tensors (nothing but the solver's step log is read on the host).
     data, mask: (B, T, in_dim); t_row: (B, T, 1).  eps: the standard-normal sample (B, latent) (default: drawn here, CUDA.randn of time_series.jl:58)."""
     import ctypes as C
@@ -299,7 +300,10 @@ def fused_latent_loss_and_grad(model, data, mask, t_row, lam_r=1.0e2, lam_k=1.0,
     grid = node._saveat_times(node.kwargs["saveat"] if saveat is None else saveat, node.tspan)      # update_saveat!, neural_ode.jl:35-46
     if len(grid) != T:
         raise ValueError("one save time per observation time (latent_ode.jl:137)")
-    node._func = "error_est" if node.regularize else None
+    node._func = node.resolve_func(func)
+    agg_max = agg in ("max", "maximum", torch.max)
+    if not agg_max and agg not in ("mean", torch.mean):
+        raise ValueError("agg: 'mean' or 'max' (latent_ode.jl:153,:171)")
     hn = node._acquire(z0, True)
     res = torch.empty(B, T, lat, dtype=torch.float32, device=dev)
     sa = (C.c_float * T)(*grid)
@@ -318,8 +322,14 @@ def fused_latent_loss_and_grad(model, data, mask, t_row, lam_r=1.0e2, lam_k=1.0,
     reg = 0.0
     svb = None
     if regularize and node.regularize and n > 0:
-        reg = lam_r * sum(sv_host[i] for i in range(n)) / n                 # lam_r * mean(sv.saveval), latent_ode.jl:233
-        svb = (C.c_float * n)(*([lam_r / n] * n))
+        if agg_max:                                                          # lam_r * maximum(sv.saveval)
+            vals = [sv_host[i] for i in range(n)]
+            k = max(range(n), key=lambda i: vals[i])
+            reg = lam_r * vals[k]
+            svb = (C.c_float * n)(*[lam_r if i == k else 0.0 for i in range(n)])
+        else:
+            reg = lam_r * sum(sv_host[i] for i in range(n)) / n             # lam_r * mean(sv.saveval), latent_ode.jl:233
+            svb = (C.c_float * n)(*([lam_r / n] * n))
     z0bar, p3bar = torch.empty_like(z0), torch.empty_like(p3)
     _lib.check(hn.ptr, L.rnde_node_backward_async(hn.ptr, resb.data_ptr(), svb, z0bar.data_ptr(), p3bar.data_ptr(), None, stream))
     _mark()

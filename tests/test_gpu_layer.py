@@ -219,6 +219,48 @@ def test_fused_head_step_matches_autograd(rnde):
         assert (a - b).abs().max() <= 5e-4 * b.abs().max()   # different fp32 association in the head GEMM
 
 
+@pytest.mark.parametrize("reg,sync", [("error_est", True), ("stiff_est", True), ("stiff_est", False), ("error_stiff_est", False), ("closure", True)])
+def test_fused_step_serves_every_regulariser_of_the_experiment(rnde, reg, sync):
+    """`fused_loss_and_grad(func=, agg=)` against `loss_function` + torch.autograd for each `type` of experiments/mnist_node.jl:62-103: error_est (mean),
+    stiff_est (`maximum`, AutoTsit5(Tsit5())), error_stiff_est (mean), and the stiffness callback passed as the script passes it -- a closure.
+    Same loss, same regulariser value, gradients to 5e-4 of the largest entry (the head GEMM associates differently)."""
+    rn = rnde
+    solver = "Tsit5" if reg == "error_est" else "AutoTsit5"
+
+    def make():
+        g = torch.Generator().manual_seed(5)
+        dyn = rn.MLPDynamics(784, 100, generator=g)
+        node = rn.TrackedNeuralODE(dyn, [0.0, 1.0], True, True, solver, save_everystep=False, reltol=1e-3, abstol=1e-3,
+                                   save_start=False, max_batch=24, max_attempts=64)
+        post = rn.Dense(784, 10, generator=g)
+        post.b.uniform_(-0.1, 0.1, generator=g)
+        model = rn.ClassifierNODE(node, post)
+        x = torch.rand(24, 1, 28, 28, generator=g).cuda()
+        y = torch.eye(10)[torch.randint(0, 10, (24,), generator=g)].cuda()
+        return model, x, y
+    stab = 1.0 / 3.5068
+
+    def save_func(u, t, integrator):                      # mnist_node.jl:74-79
+        s_ = abs(integrator.eigen_est)
+        return stab * (0 if (s_ == 0 or s_ != s_) else s_)
+    if reg == "closure":
+        func, agg_t, agg_s, lam = save_func, torch.max, "max", 0.1
+    else:
+        lam0, lam1, func, agg_t, _ = rn.REGULARISERS[reg]
+        agg_s, lam = ("max" if agg_t is torch.max else "mean"), lam0
+    m1, x, y = make()
+    loss1, ce1, reg1, nfe1 = rn.loss_function(x, y, m1, lam=lam, agg=agg_t, func=func)
+    loss1.backward()
+    m2, _, _ = make()
+    loss2, ce2, reg2, nfe2 = rn.fused_loss_and_grad(m2, x, y, lam=lam, func=func, agg=agg_s, sync=sync)
+    torch.cuda.synchronize()
+    assert nfe1 == nfe2
+    assert abs(float(reg1) - float(reg2)) <= 1e-5 * max(1e-3, abs(float(reg1))) and float(reg2) > 0
+    assert abs(float(loss1.detach()) - float(loss2)) <= 1e-5 * max(1.0, abs(float(loss2)))
+    for a, b in ((m1.p2.grad, m2.p2.grad), (m1.p3.grad, m2.p3.grad)):
+        assert (a - b).abs().max() <= 5e-4 * b.abs().max()
+
+
 def test_async_backward_matches_the_synchronous_one(rnde):
     """rnde_node_backward_async (fused step with sync=False): same gradients as the synchronising call, valid in stream order."""
     rn = rnde

@@ -112,13 +112,8 @@ def run(reg, train, test, epochs, device, seed, max_attempts, steer, lam_scale=1
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             try:
-                if reg in ("vanilla", "error_est"):       # fused C-ABI step (same loss surface: agg = mean)
-                    loss, ce, rg, nfe_b = rn.fused_loss_and_grad(model, xb, yb, lam=lam, regularize=regularize, tspan=tspan, sync=False)
-                else:                                     # stiffness callbacks / agg = maximum: the layer call under torch.autograd
-                    for p in model.trainable():
-                        p.grad = None
-                    loss, ce, rg, nfe_b = rn.loss_function(xb, yb, model, lam=lam, regularize=True, agg=agg, func=func, tspan=tspan)
-                    loss.backward()
+                # the fused C-ABI step for every regulariser (round 5: `func` and `agg` are arguments of it; `maximum` runs as three library calls)
+                loss, ce, rg, nfe_b = rn.fused_loss_and_grad(model, xb, yb, lam=lam, regularize=regularize, tspan=tspan, sync=False, func=func, agg=agg)
                 opt.step()
             except Exception as e:
                 failed = f"epoch {epoch}: {e}"

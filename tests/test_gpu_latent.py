@@ -99,8 +99,11 @@ def test_latent_handle_refuses_out_of_order_calls_and_bad_shapes():
     L.rnde_latent_destroy(h)
 
 
-def test_fused_latent_training_step_matches_the_autograd_form():
-    """`fused_latent_loss_and_grad` (every piece of loss_function, latent_ode.jl:206-236, and of its reverse through the C ABI) against
+@pytest.mark.parametrize("func,agg,lam_r", [("error_est", "mean", 50.0), ("stiff_est", "max", 10.0), ("error_stiff_est", "mean", 10.0)])
+def test_fused_latent_training_step_matches_the_autograd_form(func, agg, lam_r):
+    """(Parametrised over the three `save_func`s / aggregators of experiments/latent_ode.jl:153-190: EEst*dt with mean, the stiffness estimate with
+    `maximum`, their blend with mean.)
+    `fused_latent_loss_and_grad` (every piece of loss_function, latent_ode.jl:206-236, and of its reverse through the C ABI) against
     `latent_loss_function` + torch.autograd on the same model, data and reparameterisation sample -- the layer call in the middle is the
     same device solve on both sides, so this checks the plumbing between the five library calls: loss terms 1e-5, gradients of the four
     parameter groups 2e-4 of their largest entry (tol 1e-3 on the solve: its step sequence is not rounding noise)."""
@@ -121,14 +124,14 @@ def test_fused_latent_training_step_matches_the_autograd_form():
     real_randn = torch.randn
     try:
         torch.randn = lambda *a, **k: eps.clone()
-        total_a, nll_a, kl_a, reg_a, nfe_a = rn.latent_loss_function(data, mask, t_row, model, lam_r=50.0, lam_k=0.3)
+        total_a, nll_a, kl_a, reg_a, nfe_a = rn.latent_loss_function(data, mask, t_row, model, lam_r=lam_r, lam_k=0.3, func=func, agg=torch.max if agg == "max" else torch.mean)
     finally:
         torch.randn = real_randn
     total_a.backward()
     ga = [p.grad.detach().clone() for p in model.trainable()]
     for p in model.trainable():
         p.grad = None
-    total_f, nll_f, kl_f, reg_f, nfe_f = rn.fused_latent_loss_and_grad(model, data, mask, t_row, lam_r=50.0, lam_k=0.3, eps=eps)
+    total_f, nll_f, kl_f, reg_f, nfe_f = rn.fused_latent_loss_and_grad(model, data, mask, t_row, lam_r=lam_r, lam_k=0.3, eps=eps, func=func, agg=agg)
     torch.cuda.synchronize()
     assert nfe_f == nfe_a
     assert abs(float(nll_f) - float(nll_a)) <= 1e-5 * abs(float(nll_a)) and abs(float(kl_f) - float(kl_a)) <= 1e-5 * abs(float(kl_a)) + 1e-7

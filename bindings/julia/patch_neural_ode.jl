@@ -19,16 +19,23 @@ using RegNeuralDE: TrackedNeuralODE, TDChain, _convert_tspan
 const RNDE_ODE_HANDLES = IdDict{Any,Dict{Tuple{Int,Int},RNDE.Handle}}()
 const TSIT5_STABILITY_SIZE = 3.5068      # OrdinaryDiffEq.alg_stability_size(Tsit5()), the constant mnist_node.jl:73,:86 divides by
 
-# Dense sizes / activations of the dynamics (TDChain or Chain of Dense layers; a leading `x -> tanh.(x)` is latent_ode.jl:114's pre-activation)
+# Dense sizes / activations of the dynamics (TDChain or Chain of Dense layers; a leading `x -> tanh.(x)` is latent_ode.jl:114's pre-activation).
+# Anything the library cannot represent is REFUSED here -- a layer that is silently skipped would integrate another vector field:
+# every layer must be a Flux.Dense with tanh or identity, except ONE leading element-wise function that is tanh (checked on a probe vector).
+_act_code(σ) = σ === tanh ? 1 : (σ === identity ? 0 : error("RNDE: Dense activation ", σ, " is not served (tanh / identity)"))
+_is_tanh_layer(l) = !(l isa Flux.Dense) && (v = Float32[-0.7, 0.1, 0.9]; try l(v) ≈ tanh.(v) catch; false end)
 function _dense_layout(model)
-    layers = model isa TDChain ? model.layers : model.layers
-    pre = !(first(layers) isa Flux.Dense)
-    ds = [l for l in layers if l isa Flux.Dense]
+    layers = collect(model.layers)
     td = model isa TDChain
+    pre = !(first(layers) isa Flux.Dense)
+    pre && (!td && _is_tanh_layer(first(layers)) ||
+            error("RNDE: the dynamics may start with ONE element-wise tanh (experiments/latent_ode.jl:114), nothing else in front of the Dense layers; got ", first(layers)))
+    ds = layers[(pre ? 2 : 1):end]
+    all(l -> l isa Flux.Dense, ds) || error("RNDE: the dynamics must be a chain of Flux.Dense layers; got ", [typeof(l) for l in ds if !(l isa Flux.Dense)])
     dims = Int[size(ds[1].W, 2) - (td ? 1 : 0)]
     acts = Int[]
     for l in ds
-        push!(dims, size(l.W, 1)); push!(acts, l.σ === tanh ? 1 : 0)
+        push!(dims, size(l.W, 1)); push!(acts, _act_code(l.σ))
     end
     return dims, acts, td, pre
 end

@@ -11,11 +11,15 @@ const SOSRI2_STABILITY_SIZE = 10.6       # StochasticDiffEq.alg_stability_size(S
 const _SDE_SOLVERS = Dict(:SOSRI => 0, :SRIW1 => 1, :SOSRI2 => 2)      # rnde_sde_solver (include/rnde.h)
 const RNDE_SDE_CALLS = Ref(0)      # one Philox stream per call: seed = a counter (pass `seed = ...` for a reproducible run)
 
+# drift / diffusion as the library holds them: chains of Flux.Dense (tanh / identity), nothing else.  A layer that cannot be represented is REFUSED,
+# never skipped (experiments/sde_toy_problem.jl's drift starts with `x -> x .^ 3`: that script is not served by this patch and now says so).
 function _chain_layout(model)
-    ds = model isa Flux.Dense ? [model] : [l for l in model.layers if l isa Flux.Dense]
-    dims = Int[size(ds[1].W, 2)]; acts = Int[]
-    for l in ds
-        push!(dims, size(l.W, 1)); push!(acts, l.σ === tanh ? 1 : 0)
+    ls = model isa Flux.Dense ? [model] : collect(model.layers)
+    all(l -> l isa Flux.Dense, ls) || error("RNDE: drift and diffusion of the SDE layer must be chains of Flux.Dense layers; got ", [typeof(l) for l in ls if !(l isa Flux.Dense)])
+    dims = Int[size(ls[1].W, 2)]; acts = Int[]
+    for l in ls
+        push!(dims, size(l.W, 1))
+        push!(acts, l.σ === tanh ? 1 : (l.σ === identity ? 0 : error("RNDE: Dense activation ", l.σ, " is not served (tanh / identity)")))
     end
     return dims, acts
 end

@@ -151,6 +151,8 @@ def test_julia_patches_dispatch_on_the_callers_func():
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bindings", "julia")
     ode, sde, mod = (open(os.path.join(d, f)).read() for f in ("patch_neural_ode.jl", "patch_neural_sde.jl", "RNDE.jl"))
     assert "kind::Symbol" not in ode and "kind =" not in ode
+    # a layer the library cannot represent is refused, never skipped (experiments/sde_toy_problem.jl's drift starts with `x -> x .^ 3`)
+    assert "all(l -> l isa Flux.Dense, ds) || error(" in ode and "all(l -> l isa Flux.Dense, ls) || error(" in sde and "_is_tanh_layer(first(layers))" in ode
     assert len(re.findall(r"h = rnde_handle\(n, size\(x, 2\), _reg_code\(n, func\)\)", ode)) == 4
     assert len(re.findall(r"h = rnde_handle\(n, size\(x, 2\), func\)", sde)) == 4
     assert "get!(tab, (B, code))" in ode and "get!(tab, (B, reg))" in sde

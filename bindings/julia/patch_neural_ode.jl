@@ -57,7 +57,7 @@ function rnde_handle(n::TrackedNeuralODE, B::Int, code::Int)
     end
 end
 
-_saveat_vec(n, saveat) = Float32.(collect(isnothing(saveat) ? n.kwargs[:saveat] : saveat))
+_saveat_vec(n, saveat) = Float32.(collect(Tracker.data(isnothing(saveat) ? n.kwargs[:saveat] : saveat)))      # (a tracked / device vector of save times is read back: they are host data for the library)
 # which times a multi-output call saves at: the given / stored saveat -- or, for a layer built with save_everystep = true and no saveat
 # (neural_ode.jl:10-11), the ends of the accepted steps, which an untracked solve has to find first (RNDE.solve_forward_everystep); the tracked
 # call then saves at exactly those (the value at a step's end is u_new itself)

@@ -48,7 +48,7 @@ function rnde_handle(n::TrackedNeuralDSDE, B::Int, func)
 end
 
 _sde_saved(tspan, p, saveval) = (sv = SavedValues(eltype(tspan), eltype(p)); append!(sv.saveval, saveval); sv)
-_sde_saveat(n) = Float32.(collect(n.kwargs[:saveat]))
+_sde_saveat(n) = Float32.(collect(Tracker.data(n.kwargs[:saveat])))
 _next_seed(seed) = isnothing(seed) ? (RNDE_SDE_CALLS[] += 1) : seed
 
 # {false,false} (reference :63-82)

@@ -30,7 +30,8 @@ def _worker(rank, world, store_path, q):
     opt = rn.FluxOptimiser([p1, p2, p3])
     avg = torch.cat([p2.grad, p3.grad]).clone()
     opt.step()
-    q.put((rank, local, avg, torch.cat([p2.detach(), p3.detach()])))
+    # (numpy, pickled by value: a tensor would travel as a file descriptor of this process, which may be gone by the time the parent reads the queue)
+    q.put((rank, local.numpy(), avg.numpy(), torch.cat([p2.detach(), p3.detach()]).numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -56,6 +57,6 @@ def test_gradient_allreduce_and_update_world2():
                 p.kill()
         if os.path.exists(store_path):
             os.unlink(store_path)
-    (_, l0, a0, w0), (_, l1, a1, w1) = res
+    (_, l0, a0, w0), (_, l1, a1, w1) = [(r, *(torch.from_numpy(a) for a in rest)) for r, *rest in res]
     assert torch.allclose(a0, (l0 + l1) / 2, atol=1e-6) and torch.equal(a0, a1)   # mean of the rank gradients
     assert torch.equal(w0, w1)                                                     # replicas stay identical

@@ -13,7 +13,23 @@
  * (test/test_node.jl has no @test).  This file restates the *published*
  * algorithm (Tsitouras 2011 tableau; Hairer initial-step rule; PI controller)
  * as recalled in SURVEY.md Appendix A/B, and is pinned only by its own
- * self-tests (order conditions, convergence order, fp64 finite differences).
+ * self-tests (order conditions, convergence order, fp64 finite differences)
+ * and by what third-party code in the build image can pin (tests/test_oracle.py):
+ *   B.1 initial step     == scipy.integrate._ivp.common.select_initial_step on the
+ *                           same f / tolerances / RMS norm (test_initdt_matches_hairer_scipy:
+ *                           1e-12; the deviation list is that test's docstring -- it is empty
+ *                           up to how the order argument is counted);
+ *   B.2/B.3 step + EEst  == scipy rk_step / RK45.E / DOP853 E5 for the tableau-as-data
+ *                           pairs (the Tsit5 table itself: order conditions only);
+ *   B.4 PI controller    STRUCTURE == Hairer's published dopri5.f recurrence, and its
+ *                           beta2 -> 0 limit == scipy's I controller
+ *                           (test_pi_controller_is_hairers_dopri5_form); the EXPONENTS
+ *                           beta1 = 7/(10 order), beta2 = 2/(5 order), gamma = 0.9,
+ *                           qmin = 0.2, qmax = 10, qoldinit = 1e-4 are OrdinaryDiffEq
+ *                           defaults as recalled: UNVERIFIABLE OFFLINE;
+ *   B.5 callback at init, B.6 save_start, tracked-time end-of-interval handling:
+ *                           UNVERIFIABLE OFFLINE (config flags below; tools/julia_golden.jl
+ *                           dumps what a Julia host does).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library.  The product path (librnde.so) never links or calls it.
@@ -57,9 +73,9 @@ typedef struct {
     real reltol, abstol;
     int reg_kind;      /* 0 none (func ignored, neural_ode.jl:48-77); 1 EEst*dt (neural_ode.jl:116);
                           2 stiffness estimate (mnist_node.jl:74-79); 3 err + 0.1*stiff (mnist_node.jl:88-97) */
-    int cb_save_start; /* 1: SavingCallback fires once at init with EEst=1, dt=0 -> pushes 0 */
-    int track_ctrl;    /* 1: differentiate dt_next = dt/q through the controller on accepted steps */
-    int track_initdt;  /* 1: differentiate the Hairer initial-step computation */
+    int cb_save_start; /* 1: SavingCallback fires once at init with EEst=1, dt=0 -> pushes 0 [RECALL: unverifiable offline] */
+    int track_ctrl;    /* 1: differentiate dt_next = dt/q through the controller on accepted steps [RECALL (Tracker overloads of DiffEqBase): unverifiable offline] */
+    int track_initdt;  /* 1: differentiate the Hairer initial-step computation [values: == scipy's select_initial_step; that Tracker differentiates it: RECALL, unverifiable offline] */
     int max_attempts;
     int solver;        /* 0 Tsit5 (every reference call site), 1 DP5: Dormand-Prince 5(4), the second 7-stage FSAL pair of the
                           tableau-as-data path (validated against scipy's RK45) */

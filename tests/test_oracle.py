@@ -471,3 +471,94 @@ def test_dop853_table_matches_scipy_step_for_step_and_differentiates():
     assert o.forward(x, p, saveat=np.array([0.5, 1.0]))["rc"] == 5          # no dense output in this table: refused, not approximated
     ep, ex, et, _ = _fd_check(arch_test_node(), 3, 1e-4, 3.0, 0, solver="DOP853")
     assert ep < 1e-5 and ex < 1e-5 and et < 1e-5
+
+
+# ---------------------------------------------------------------- 9. what third-party code in the image CAN pin of the [RECALL] surface
+def test_initdt_matches_hairer_scipy():
+    """SURVEY B.1 (OrdinaryDiffEq `src/initdt.jl`, out-of-place form, the `solve` -> `init` of src/models/neural_ode.jl:131) is Hairer's rule
+    (Solving ODEs I, II.4).  scipy.integrate._ivp.common.select_initial_step implements the same published algorithm; here both run on the
+    same f, same tolerances, same RMS norm.  The [RECALL] deviation list of B.1, i.e. every constant that differs between the two and why:
+      * scipy's `order` argument is the ERROR ESTIMATOR's order (4 for a 5(4) pair): h1 = (0.01 / max(d1, d2))^(1 / (order + 1)); the
+        restatement writes 10^(-(2 + log10(max(d1, d2))) / alg_order) with alg_order = 5 -- the same number (checked below to 1e-12);
+      * scipy bounds by `max_step`; the restatement by dtmax = t1 - t0 (= scipy's interval_length when max_step = inf): same here;
+      * scipy multiplies h0 by `direction`; the reference integrates forward only (tspan = [0, 1], mnist_node.jl:118): direction = +1;
+      * the 1e-5 / 1e-6 / 1e-15 / 1e-3 / 100 thresholds are equal in both.
+    Nothing else differs: the two agree to rounding on every case below, including the small-norm and the clamped branches."""
+    from scipy.integrate._ivp.common import select_initial_step
+    rng = np.random.default_rng(21)
+    cases = []
+    for arch, B, scale, x_scale, tol, t1 in ((arch_test_node(), 5, 3.0, 1.0, 1e-6, 1.0), (arch_mnist(36, 10), 6, 3.0, 1.0, 1.4e-8, 1.0),
+                                             (arch_latent(), 4, 2.0, 1.0, 1e-3, 1.0), (arch_test_node(), 3, 3.0, 1.0, 1e-6, 1e-4),    # 100 dt0 / dtmax clamps
+                                             (arch_test_node(), 3, 3.0, 1e-13, 1e-6, 1.0)):                                             # d0 < 1e-5: dt0 = 1e-6
+        D = arch.dims[0]
+        p = glorot_params(arch, rng, np.float64, scale)
+        x = rng.uniform(0, 1, (B, D)) * x_scale
+        cases.append((arch, p, x, tol, t1))
+    branches = set()
+    for arch, p, x, tol, t1 in cases:
+        o = Oracle(arch, np.float64, reltol=tol, abstol=tol)
+        B, D = x.shape
+
+        def fun(t, y):
+            return o.f_eval(p, y.reshape(B, D), t).reshape(-1)
+        f0 = fun(0.0, x.reshape(-1))
+        ref = select_initial_step(fun, 0.0, x.reshape(-1), t1, np.inf, f0, 1.0, 4, tol, tol)
+        got, f0o = o.initdt(p, x, 0.0, t1)
+        assert np.array_equal(f0o.reshape(-1), f0)
+        assert abs(got - ref) <= 1e-12 * ref, (got, ref)
+        branches.add("dtmax" if got == t1 else "other")
+        # and the float build the device follows takes the same branch to fp32 rounding
+        if tol >= 1e-6 and np.abs(x).max() > 1e-6:
+            got32, _ = Oracle(arch, np.float32, reltol=tol, abstol=tol).initdt(p.astype(np.float32), x.astype(np.float32), 0.0, t1)
+            assert abs(got32 - ref) <= 2e-4 * ref, (got32, ref)
+    assert branches == {"dtmax", "other"}
+
+
+def test_pi_controller_is_hairers_dopri5_form():
+    """SURVEY B.4 (OrdinaryDiffEq `integrator_utils.jl`: stepsize_controller! / step_accept_controller! / step_reject_controller!) is the PI
+    controller of Hairer's published dopri5.f: FAC11 = ERR^EXPO1; FAC = FAC11 / FACOLD^BETA; FAC = max(FACC2, min(FACC1, FAC / SAFE));
+    HNEW = H / FAC; accepted -> FACOLD = max(ERR, 1e-4); rejected -> H = H / min(FACC1, FAC11 / SAFE), with FACC1 = 1 / 0.2, FACC2 = 1 / 10,
+    SAFE = 0.9.  No implementation of it exists in the image (scipy's RK45 / DOP853 use the plain I controller), so the STRUCTURE is pinned
+    against this independent restatement of the published recurrence, run on the oracle's own EEst sequence; the exponents
+    (EXPO1 = beta1 = 7 / (10 order), BETA = beta2 = 2 / (5 order) -- OrdinaryDiffEq's defaults for Tsit5, where dopri5.f has 0.2 - 0.75 * 0.04
+    and 0.04) stay [RECALL]: unverifiable offline.  With beta2 = 0 and beta1 = 1 / 5 the recurrence IS scipy's I controller
+    (factor = min(10, 0.9 err^-0.2), rejected: max(0.2, 0.9 err^-0.2)); that limit is checked too."""
+    arch = arch_test_node()
+    seen_reject = False
+    for tol, seed, scale, t1 in ((1e-3, 3, 6.0, 1.0), (1e-6, 3, 6.0, 1.0), (1e-9, 3, 6.0, 1.0), (1e-2, 9, 15.0, 3.0)):      # (the last: the rejected-step case of the FD test)
+        rng = np.random.default_rng(seed)
+        p = glorot_params(arch, rng, np.float64); p = (p + 0.1 * rng.standard_normal(p.shape)) * scale
+        x = rng.uniform(0, 1, (3, 2))
+        o = Oracle(arch, np.float64, reltol=tol, abstol=tol, reg_kind=1, max_attempts=400)
+        r = o.forward(x, p, 0.0, t1)
+        assert r["rc"] == 0
+        ext = o.steps_ext()            # t, dt, dtp_in, EEst, accepted, q
+        dt0, _ = o.initdt(p, x, 0.0, t1)
+        beta1, beta2, safe, facc1, facc2 = 7.0 / 50.0, 2.0 / 25.0, 0.9, 1.0 / 0.2, 1.0 / 10.0
+        h, facold, t = dt0, 1e-4, 0.0
+        for n in range(len(ext)):
+            tn, dtn, dtp_in, err, acc, q = ext[n]
+            assert abs(dtp_in - h) <= 1e-13 * h and abs(tn - t) <= 1e-13
+            hh = min(h, t1 - t)
+            assert abs(dtn - hh) <= 1e-13 * hh
+            fac11 = err ** beta1
+            fac = max(facc2, min(facc1, fac11 / facold ** beta2 / safe))
+            assert abs(q - fac) <= 1e-12 * fac
+            assert bool(acc) == (err <= 1.0)
+            if err <= 1.0:
+                facold = max(err, 1e-4)
+                t = t + hh
+                h = min(hh / fac, t1)
+            else:
+                seen_reject = True
+                h = hh / min(facc1, fac11 / safe)
+        assert abs(t - t1) <= 1e-12
+    assert seen_reject
+    # the beta2 -> 0 limit is scipy's controller: same factor from the same error
+    from scipy.integrate._ivp.rk import SAFETY, MAX_FACTOR, MIN_FACTOR
+    for err in (1e-3, 0.3, 0.99, 1.7, 40.0):
+        fac11 = err ** 0.2
+        hairer_acc = 1.0 / max(facc2, min(facc1, fac11 / safe))
+        hairer_rej = 1.0 / min(facc1, fac11 / safe)
+        assert abs(hairer_acc - max(MIN_FACTOR, min(MAX_FACTOR, SAFETY * err ** -0.2))) < 1e-12
+        assert abs(hairer_rej - max(MIN_FACTOR, SAFETY * err ** -0.2)) < 1e-12

@@ -121,12 +121,12 @@ function solver_name(args)
     return nameof(typeof(alg)), false
 end
 
-# what the reference's run would record with this (func, solver) pair: a stiffness term under a non-composite solver is identically zero
+# the callback code a (func, solver) pair runs with: `integrator.eigen_est` is filled by the composite solvers only; under a plain one it keeps its initial
+# value (1 [RECALL], not 0), so the reference would record a constant there -- every callback that reads it is refused, the blend included
 function effective_reg(code::Int, composite::Bool)
     composite && return code
-    code == REG_ERR_STIFF && return REG_ERR
-    (code == REG_STIFF || code == REG_STIFF_DT) && error("RNDE: `func` reads integrator.eigen_est, which only the composite solvers (AutoTsit5 / AutoSOSRI2) fill; ",
-                               "with a plain solver the reference records zeros -- build the layer with the composite solver")
+    (code == REG_STIFF || code == REG_STIFF_DT || code == REG_ERR_STIFF) && error("RNDE: `func` reads integrator.eigen_est, which only the composite solvers (AutoTsit5 / AutoSOSRI2) fill; ",
+                               "with a plain solver the reference records its initial value, a constant -- build the layer with the composite solver")
     return code
 end
 

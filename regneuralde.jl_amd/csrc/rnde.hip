@@ -266,16 +266,26 @@ static rnde_status ensure_mw_slab(rnde_node* h, long long evals, int Bpad, hipSt
     (void)Bpad;
     if (h->mw_slab_evals >= evals) return RNDE_OK;
     long long want = std::max(evals, 2 * h->mw_slab_evals);
-    {   // 288 GB of HBM: when a quarter of what is free holds the slab of a max_attempts solve, take that at once -- growing it later costs a stream
+    {   // 288 GB of HBM: when the slab of a max_attempts solve is small next to what is free, take that at once -- growing it later costs a stream
         // synchronisation, a multi-GB hipMalloc, a copy and a hipFree (~40 ms), and while a model trains its step count creeps across the doubling
-        // thresholds in the middle of a run (seen in bench.py's latent_e2e record: one 45 ms step among 3.5 ms ones)
+        // thresholds in the middle of a run (seen in bench.py's latent_e2e record: one 45 ms step among 3.5 ms ones).  Bounded: the memory is invisible to
+        // the caller's own allocator (torch's caching allocator), several handles per layer and several ranks may share one device -- at most
+        // RNDE_EAGER_SLAB_MB (default 8192: the config-4 slab at B = 512, max_attempts 256 is 6.8 GB) and at most an eighth of what is free; beyond that the slab grows by doubling as before.
         const long long full = 2 + (long long)(h->rk_S - 1) * h->cfg.max_attempts;
+        long long cap_mb = 8192;
+        if (const char* e = getenv("RNDE_EAGER_SLAB_MB")) cap_mb = atoll(e);
         size_t fr = 0, tot = 0;
-        if (full > want && hipMemGetInfo(&fr, &tot) == hipSuccess && (size_t)full * per_eval * 4 <= fr / 4) want = full;
+        const size_t full_bytes = (size_t)full * per_eval * 4;
+        if (full > want && cap_mb > 0 && full_bytes <= (size_t)cap_mb << 20 && hipMemGetInfo(&fr, &tot) == hipSuccess && full_bytes <= fr / 8) want = full;
     }
     float* nb = nullptr;
     HIPCHK(h, hipStreamSynchronize(s));
-    HIPCHK(h, hipMalloc((void**)&nb, (size_t)want * per_eval * 4));
+    if (hipMalloc((void**)&nb, (size_t)want * per_eval * 4) != hipSuccess) {      // the eager size did not fit after all (fragmentation, a neighbour): what the call needs, no more
+        (void)hipGetLastError();
+        nb = nullptr;
+        want = evals;
+        HIPCHK(h, hipMalloc((void**)&nb, (size_t)want * per_eval * 4));
+    }
     if (h->mw_slab) {
         HIPCHK(h, hipMemcpy(nb, h->mw_slab, (size_t)h->mw_slab_evals * per_eval * 4, hipMemcpyDeviceToDevice));
         hipFree(h->mw_slab);

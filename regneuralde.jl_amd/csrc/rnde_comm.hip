@@ -19,8 +19,10 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 
 namespace {
 
@@ -350,8 +352,34 @@ extern "C" rnde_status rnde_comm_create(const uint8_t id[RNDE_COMM_ID_BYTES], in
     c->rank = rank; c->world = world; c->device = device;
     nccl_unique_id uid;
     std::memcpy(&uid, id, sizeof(uid));
-    const int r = a.CommInitRank(&c->comm, world, uid, rank);
-    if (r != kNcclSuccess) { g_comm_err = std::string("ncclCommInitRank: ") + a.GetErrorString(r); delete c; return RNDE_ERR_HIP; }
+    // ncclCommInitRank blocks until every rank has arrived.  A rank that never does (a crashed peer, an unreachable fabric, a wrong id) must not
+    // hang the caller for good: at world > 1 the call runs on a helper thread and the caller waits a BOUNDED time for it (RNDE_COMM_INIT_TIMEOUT_S,
+    // default 180 s; 0 = wait for ever).  On a time-out the helper is left behind (it still owns its own copy of everything it touches) and the call
+    // fails loudly with the limit in the message.
+    int r = kNcclSuccess;
+    double limit_s = 180.0;
+    if (const char* e = getenv("RNDE_COMM_INIT_TIMEOUT_S")) limit_s = atof(e);
+    if (world == 1 || limit_s <= 0.0) r = a.CommInitRank(&c->comm, world, uid, rank);
+    else {
+        struct InitJob { std::mutex mu; std::condition_variable cv; bool done = false; int rc = 0; nccl_comm_t comm = nullptr; };
+        auto job = std::make_shared<InitJob>();
+        RcclApi* ap = &a;
+        std::thread([job, ap, world, uid, rank, device] {
+            nccl_comm_t cm = nullptr;
+            int rc = hipSetDevice(device) == hipSuccess ? ap->CommInitRank(&cm, world, uid, rank) : -1;
+            std::lock_guard<std::mutex> lk(job->mu);
+            job->rc = rc; job->comm = cm; job->done = true;
+            job->cv.notify_all();
+        }).detach();
+        std::unique_lock<std::mutex> lk(job->mu);
+        if (!job->cv.wait_for(lk, std::chrono::duration<double>(limit_s), [&] { return job->done; })) {
+            char t[160];
+            snprintf(t, sizeof t, "ncclCommInitRank (rank %d of %d) did not return within %.3g s (RNDE_COMM_INIT_TIMEOUT_S): a rank is absent or the fabric is unreachable", rank, world, limit_s);
+            g_comm_err = t; delete c; return RNDE_ERR_HIP;
+        }
+        r = job->rc; c->comm = job->comm;
+    }
+    if (r != kNcclSuccess) { g_comm_err = std::string("ncclCommInitRank: ") + (r == -1 ? "hipSetDevice failed on the helper thread" : a.GetErrorString(r)); delete c; return RNDE_ERR_HIP; }
     c->path = "RCCL (ncclAllReduce)";
     const char* one = getenv("RNDE_ONESHOT");
     if (one && one[0] == '1' && world > 1) {

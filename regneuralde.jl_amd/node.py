@@ -57,14 +57,15 @@ def reg_code(func, stability_size):
 
 
 def effective_reg(code, composite):
-    """What the reference's run records with this callback under this solver: integrator.eigen_est is filled by the composite solvers only
-    (AutoTsit5(Tsit5()), AutoSOSRI2(SOSRI2()): mnist_node.jl:81,:99, mnist_nsde.jl:60), a stiffness term under a plain solver is zero."""
+    """The callback code a (func, solver) pair runs with, or an error: integrator.eigen_est is filled by the composite solvers only
+    (AutoTsit5(Tsit5()), AutoSOSRI2(SOSRI2()): mnist_node.jl:81,:99, mnist_nsde.jl:60).  Under a plain solver it keeps its INITIAL value -- 1, not 0
+    [RECALL] -- so the reference would record a constant there (|1| / stability_size, EEst*dt + 0.1 / stability_size), which no experiment does and the
+    kernels do not reproduce: every callback that reads eigen_est is refused under a plain solver, the blend included (round 5 mapped the blend to
+    EEst*dt, i.e. assumed eigen_est = 0: a constant offset of the saved values)."""
     if composite or code in (0, 1):
         return code
-    if code == 3:
-        return 1
     raise ValueError("func reads integrator.eigen_est, which only the composite solvers (AutoTsit5 / AutoSOSRI2) fill; with a plain solver "
-                     "the reference records zeros -- build the layer with the composite solver")
+                     "the reference records its initial value, a constant -- build the layer with the composite solver")
 
 
 class SavedValues:
@@ -288,10 +289,11 @@ class TrackedNeuralODE:
         if not self.regularize:
             return None
         if callable(func):
-            func = _FUNC_NAMES[effective_reg(reg_code(func, TSIT5_STABILITY_SIZE), self.solver == "AutoTsit5")]
+            func = _FUNC_NAMES[reg_code(func, TSIT5_STABILITY_SIZE)]
         if func not in _FUNCS:
             raise ValueError("func must be a callback (u, t, integrator) -> value or one of None/'error_est', 'stiff_est', "
                              "'error_stiff_est' (the three callbacks of experiments/mnist_node.jl:62-103), 'stiff_est_dt' (test/test_node.jl:75)")
+        effective_reg(_FUNCS[func], self.solver == "AutoTsit5")      # names and closures alike: a callback that reads eigen_est needs the composite solver
         return func
 
     # -- call operator ------------------------------------------------------------------------

@@ -175,8 +175,9 @@ class TrackedNeuralDSDE:
                              "(|eigen_est| / 10.6, experiments/mnist_nsde.jl:51-61)")
         if code in (3, 4):
             raise ValueError("the SDE layer records EEst*dt or the stiffness estimate (mnist_nsde.jl:45-61), not their blend and not |eigen_est*dt|")
-        if code == 2 and self.solver not in ("SOSRI2", "AutoSOSRI2"):
-            raise ValueError("the stiffness estimate of an SRI step is defined for SOSRI2 / AutoSOSRI2 only (mnist_nsde.jl:60)")
+        if code == 2 and self.solver != "AutoSOSRI2":      # names and closures alike (effective_reg checked the closure above)
+            raise ValueError("the stiffness estimate of an SRI step is filled by the composite AutoSOSRI2(SOSRI2()) only (mnist_nsde.jl:60); a plain "
+                             "solver -- SOSRI2 included -- leaves integrator.eigen_est at its initial value")
         return code
 
     def __call__(self, x, p=None, func=None, noise=None):

@@ -209,7 +209,7 @@ class FluxAdaMax:
 
 
 def build_latent_ode(in_dim=37, h_dim=40, rec_dim=50, latent=20, hidden=50, depth=8, saveat=None, regularize=True,
-                     generator=None, device="cuda", **solver_kwargs):
+                     generator=None, device="cuda", solver="Tsit5", **solver_kwargs):
     """The model of latent_ode.jl:111-147 at the reference's sizes: LatentGRU(37, 40, 50), rec_to_gen
     Dense(100, 50, tanh) -> Dense(50, 40), gen_dynamics (tanh + 8 Dense 20 <-> 50), gen_to_data Dense(20, 37)."""
     from .layers import LatentGenDynamics
@@ -218,7 +218,7 @@ def build_latent_ode(in_dim=37, h_dim=40, rec_dim=50, latent=20, hidden=50, dept
     dyn = LatentGenDynamics(latent, hidden, depth, generator)
     kw = dict(reltol=1.4e-8, abstol=1.4e-8)
     kw.update(solver_kwargs)
-    node = TrackedNeuralODE(dyn, [0.0, 1.0], False, regularize, "Tsit5", saveat=saveat, **kw)
+    node = TrackedNeuralODE(dyn, [0.0, 1.0], False, regularize, solver, saveat=saveat, **kw)      # solver: "AutoTsit5" for the stiffness callbacks (latent_ode.jl:127-136)
     dec = Dense(latent, in_dim, "identity", generator)
     return LatentTimeSeriesModel(rnn, enc, node, dec, device=device)
 
@@ -266,17 +266,19 @@ def fused_latent_loss_and_grad(model, data, mask, t_row, lam_r=1.0e2, lam_k=1.0,
     lat = 20                                     # latent state rows (latent_ode.jl:112-124); the kernels are built for the reference's sizes
     # rnde_latent_* is compiled for the experiment's own sizes (latent_ode.jl:39-124: LatentGRU(37, 40, 50), rec_to_gen 100-50-40, gen_to_data 20-37):
     # a model built with other sizes must not reach kernels that would read its parameter vectors out of bounds
-    if getattr(model, "_latent_sizes_ok", None) is None:
+    # (checked on EVERY call: the widths belong to the call's arrays, the parameter vectors can be replaced between calls; only the library's three counts are cached)
+    want_n = getattr(model, "_latent_want", None)
+    if want_n is None:
         n1, n2, n4 = C.c_int32(0), C.c_int32(0), C.c_int32(0)
         L.rnde_latent_param_counts(C.byref(n1), C.byref(n2), C.byref(n4))
-        p1_, p2_, p3_, p4_ = model.trainable()
-        have = (p1_.numel(), p2_.numel(), p4_.numel(), data.shape[2], mask.shape[2], t_row.shape[2], node.model.dims()[0])
-        want = (n1.value, n2.value, n4.value, 37, 37, 1, lat)
-        if have != want:
-            raise ValueError("fused_latent_loss_and_grad runs the kernels built for the reference's latent-ODE sizes (experiments/latent_ode.jl:39-124): "
-                             f"(len p1, len p2, len p4, data width, mask width, time width, latent rows) must be {want}, this model has {have}; "
-                             "use latent_loss_function (torch autograd around the layer call) for other sizes")
-        model._latent_sizes_ok = True
+        want_n = model._latent_want = (n1.value, n2.value, n4.value)
+    p1_, p2_, p3_, p4_ = model.trainable()
+    have = (p1_.numel(), p2_.numel(), p4_.numel(), data.shape[2], mask.shape[2], t_row.shape[2], node.model.dims()[0])
+    want = want_n + (37, 37, 1, lat)
+    if have != want:
+        raise ValueError("fused_latent_loss_and_grad runs the kernels built for the reference's latent-ODE sizes (experiments/latent_ode.jl:39-124): "
+                         f"(len p1, len p2, len p4, data width, mask width, time width, latent rows) must be {want}, this model has {have}; "
+                         "use latent_loss_function (torch autograd around the layer call) for other sizes")
     hl = getattr(model, "_latent_handle", None)
     if hl is None or hl.max_batch < B or hl.max_T < T:
         hl = model._latent_handle = _LatentHandle(max(B, getattr(hl, "max_batch", 0) if hl else 0), max(T, getattr(hl, "max_T", 0) if hl else 0), dev.index or 0)

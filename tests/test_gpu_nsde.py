@@ -679,6 +679,8 @@ def test_stiffness_estimate_layer_contract():
         mk("SOSRI2")(x, p, func=save_func)
     with pytest.raises(ValueError, match="SOSRI2"):
         mk("SOSRI")(x, p, func="stiff_est")
+    with pytest.raises(ValueError, match="composite"):      # the NAME takes the same check as the closure: plain SOSRI2 leaves eigen_est at its initial value
+        mk("SOSRI2")(x, p, func="stiff_est")
     with pytest.raises(ValueError, match="none of the callbacks"):
         nsde(x, p, func=lambda u, t, integ: integ.dt)
     drift, diff, _, _, _ = _setup("nsde", 16, 1, 1)

@@ -130,8 +130,8 @@ def test_callers_func_is_recognised_not_replaced(rnde):
         with pytest.raises(ValueError, match="none of the callbacks"):
             N.reg_code(bad, N.TSIT5_STABILITY_SIZE)
     # what the reference's run records under a plain solver: eigen_est stays 0 there
-    assert N.effective_reg(3, composite=False) == 1 and N.effective_reg(3, composite=True) == 3 and N.effective_reg(1, False) == 1
-    for code in (2, 4):
+    assert N.effective_reg(3, composite=True) == 3 and N.effective_reg(1, False) == 1 and N.effective_reg(0, False) == 0
+    for code in (2, 3, 4):      # (3, the blend: eigen_est's initial value under a plain solver is 1, not 0 -- it is refused like the others, not mapped to EEst*dt)
         with pytest.raises(ValueError, match="composite"):
             N.effective_reg(code, composite=False)
     assert N.effective_reg(4, composite=True) == 4

@@ -585,6 +585,15 @@ def main():
         if args.global_batch % world:
             raise SystemExit(f"--global-batch {args.global_batch} is not a multiple of the {world} ranks")
         B = args.global_batch // world
+    rig_note = None
+    if args.share_gpu:
+        rig_note = "share-gpu: ALL ranks on one device over gloo + peer windows -- exercises the N > 1 code path, NOT a throughput figure"
+        if world * 7 * ((B + 15) // 16) > 256 and "RNDE_PERSIST" not in os.environ:
+            # the one-launch solve / attempt kernels need all 7 x ceil(B / 16) workgroups of a rank resident at once; `world` ranks of them do not fit the 256 CUs of
+            # the ONE device they share here, and a rank whose workgroups wait for CUs another rank's spinning kernel holds gives up (bounded) -- with the
+            # asynchronous reverse pass that is an error one step later.  On the rig (never on a rank that owns its GPU) those ranks run launch by launch.
+            os.environ["RNDE_PERSIST"] = "0"
+            rig_note += f"; persistent kernels OFF on this rig ({world} ranks x {7 * ((B + 15) // 16)} workgroups > 256 CUs of the one shared device: 7 launches per attempted step)"
     model = build_model(rn, device, B)
     model.node.col_tile = args.col_tile
     opt = rn.FluxOptimiser(model.trainable())
@@ -788,7 +797,7 @@ def main():
                "controller": "coupled (one controller for all ranks, SURVEY 8e mode 2)" if args.coupled else "independent per rank (SURVEY 8e mode 1)",
                "collective": (None if not use_dist else "rnde_comm_allreduce (librnde.so; path: see dist.collective_path): ONE sum-all-reduce of the flat gradient buffer [p2-bar | p3-bar] "
                               "behind the reverse pass, on the compute stream; 1/world folded into the optimiser launch"),
-               "rig": "share-gpu: ALL ranks on one device over gloo + peer windows -- exercises the N > 1 code path, NOT a throughput figure" if args.share_gpu else None,
+               "rig": rig_note,
                "config": {"workload": f"MNIST NODE regularized (error_est), Tsit5 reltol=abstol=1.4e-8, batch {B} per GPU, "
                                       "1xMI355X per rank; step = loss fwd + reverse pass through the solver + "
                                       "InvDecay/Momentum update; the weights train during the timed steps (mean_nfe drifts with "

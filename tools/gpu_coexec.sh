@@ -12,7 +12,7 @@ OUT=$O/${R}_coexec_micro.csv
   echo "# part 1: times (tools/micro/coexec 256)"; cat $O/coexec_times.csv;
   echo "# part 2: rocprofv3 --kernel-trace --pmc <pair> -- tools/micro/coexec 256 '' 8 64 ; per-dispatch means (nm 4096 MFMAs, nv 32768 FMAs, K 64)";
   echo "kernel,counter,mean_per_dispatch,dispatches"; } > $OUT
-for c in "SQ_VALU_MFMA_COEXEC_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES" "SQ_ACTIVE_INST_VALU SQ_WAIT_ANY"; do
+for c in "SQ_VALU_MFMA_COEXEC_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU"; do
   d=$O/coexec_$(echo $c | tr ' ' '+')
   rm -rf $d
   timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d -- tools/micro/coexec 256 "" 8 64 > $d.log 2>&1
@@ -22,7 +22,7 @@ import csv, glob, sys, collections
 d = sys.argv[1]
 f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
 if not f: sys.exit()
-names = {0: "MFMA_ONLY", 1: "VALU_ONLY", 2: "SPLIT", 3: "LOCKSTEP", 4: "STAGGER", 5: "ONEWAVE_MIX"}
+names = {0: "MFMA_ONLY", 1: "VALU_ONLY", 2: "SPLIT", 3: "LOCKSTEP", 4: "STAGGER", 5: "ONEWAVE_MIX", 6: "SPLIT_PRIO_V", 7: "SPLIT_PRIO_M", 8: "SPLIT_NOP", 9: "TWOWAVE_MIX", 10: "ONEWAVE_SEQ"}
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f[0])):
     k = r["Kernel_Name"]

@@ -8,7 +8,11 @@
 //   SPLIT        waves 0-3 the MFMAs, waves 4-7 the FMAs, at the same time (roles split between SIMD partners)
 //   LOCKSTEP     all 8 waves run the same program: [N/K MFMAs, M/K FMAs] x K (both partners hit matrix and vector bursts together: the attempt kernels' shape)
 //   STAGGER      same work per wave as LOCKSTEP, waves 4-7 start with the vector burst: [FMAs, MFMAs] x K
-//   ONEWAVE_MIX  waves 0-3 alone, one MFMA followed by its share of independent FMAs (does a wave's own VALU run in its MFMA's shadow?)
+//   ONEWAVE_MIX  waves 0-3 alone, one MFMA followed by its share (8) of independent FMAs (does a wave's own VALU run in its MFMA's shadow?)
+//   ONEWAVE_SEQ  waves 0-3 alone, the same instructions as two bursts (all MFMAs, then all FMAs): the no-overlap reference of ONEWAVE_MIX
+//   TWOWAVE_MIX  all 8 waves run ONEWAVE_MIX's stream on half the work each (a SIMD carries the same totals as SPLIT)
+//   SPLIT_PRIO_V / _M   SPLIT with s_setprio 3 on the vector / the matrix waves (does the arbiter let the other pipe's wave in?)
+//   SPLIT_NOP    SPLIT, the matrix wave issues `s_nop 7` x 3 behind every MFMA (its next MFMA does not sit at the issue stage while the pipe is busy)
 // Output: shader cycles and wall time per variant; the COEXEC counter comes from the --pmc pass (tools/gpu_coexec.sh).
 //   time(SPLIT) ~ max(MFMA_ONLY, VALU_ONLY): the pipes co-execute across waves;  ~ sum: they do not.
 #include <hip/hip_runtime.h>
@@ -17,7 +21,7 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum { MFMA_ONLY = 0, VALU_ONLY = 1, SPLIT = 2, LOCKSTEP = 3, STAGGER = 4, ONEWAVE_MIX = 5 };
+enum { MFMA_ONLY = 0, VALU_ONLY = 1, SPLIT = 2, LOCKSTEP = 3, STAGGER = 4, ONEWAVE_MIX = 5, SPLIT_PRIO_V = 6, SPLIT_PRIO_M = 7, SPLIT_NOP = 8, TWOWAVE_MIX = 9, ONEWAVE_SEQ = 10 };
 
 // nm MFMAs on four independent accumulators (no back-to-back dependency stall: 16x16x4 f32 is 8 passes = 32 cycles, the same accumulator comes round every 4).
 // Inline asm, 16 per loop trip: exactly these instructions, whatever the optimiser would make of the C form.
@@ -62,23 +66,31 @@ __global__ __launch_bounds__(512) void coexec_kernel(float* out, unsigned long l
     } else if (MODE == STAGGER) {
         if (w < 4) for (int k = 0; k < K; ++k) { mfma_burst(acc, a, b, nm / (2 * K)); __builtin_amdgcn_sched_barrier(0); valu_burst(x, m, c, nv / (2 * K)); __builtin_amdgcn_sched_barrier(0); }
         else for (int k = 0; k < K; ++k) { valu_burst(x, m, c, nv / (2 * K)); __builtin_amdgcn_sched_barrier(0); mfma_burst(acc, a, b, nm / (2 * K)); __builtin_amdgcn_sched_barrier(0); }
-    } else {      // ONEWAVE_MIX: per MFMA its share of the FMAs, same wave
-        if (w < 4) {
-            const int per = nv / nm;      // FMAs per MFMA: 8 or 4
-            for (int i = 0; i < nm; i += 4) {
+    } else if (MODE == ONEWAVE_MIX || MODE == TWOWAVE_MIX) {      // per MFMA eight independent FMAs, same wave
+        const int n = MODE == TWOWAVE_MIX ? nm / 2 : nm;
+        if (MODE == TWOWAVE_MIX || w < 4) {
+            for (int i = 0; i < n; i += 4) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[j]) : "v"(a), "v"(b));
-                    if (per >= 8) {
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[r]) : "v"(m), "v"(c));
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[r]) : "v"(m), "v"(c));
-                    }
+                    for (int r = 0; r < 8; ++r) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[r]) : "v"(m), "v"(c));
                 }
             }
         }
+    } else if (MODE == ONEWAVE_SEQ) {
+        if (w < 4) { mfma_burst(acc, a, b, nm); valu_burst(x, m, c, nv); }
+    } else if (MODE == SPLIT_PRIO_V) {
+        if (w < 4) mfma_burst(acc, a, b, nm); else { __builtin_amdgcn_s_setprio(3); valu_burst(x, m, c, nv); __builtin_amdgcn_s_setprio(0); }
+    } else if (MODE == SPLIT_PRIO_M) {
+        if (w < 4) { __builtin_amdgcn_s_setprio(3); mfma_burst(acc, a, b, nm); __builtin_amdgcn_s_setprio(0); } else valu_burst(x, m, c, nv);
+    } else if (MODE == SPLIT_NOP) {
+        if (w < 4) {
+            for (int i = 0; i < nm; i += 4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(acc[j]) : "v"(a), "v"(b));
+            }
+        } else valu_burst(x, m, c, nv);
     }
     __syncthreads();
     const unsigned long long c1 = clock64(), w1 = wall_clock64();
@@ -136,7 +148,14 @@ int main(int argc, char** argv) {
             run<LOCKSTEP>("LOCKSTEP", out, st, grid, nm, nv, K, csv);
             run<STAGGER>("STAGGER", out, st, grid, nm, nv, K, csv);
         }
-        run<ONEWAVE_MIX>("ONEWAVE_MIX", out, st, grid, nm, nv, 1, csv);
+        if (ratio == 8) {      // (these streams are written for 8 FMAs per MFMA)
+            run<ONEWAVE_SEQ>("ONEWAVE_SEQ", out, st, grid, nm, nv, 1, csv);
+            run<ONEWAVE_MIX>("ONEWAVE_MIX", out, st, grid, nm, nv, 1, csv);
+            run<TWOWAVE_MIX>("TWOWAVE_MIX", out, st, grid, nm, nv, 1, csv);
+        }
+        run<SPLIT_PRIO_V>("SPLIT_PRIO_V", out, st, grid, nm, nv, 1, csv);
+        run<SPLIT_PRIO_M>("SPLIT_PRIO_M", out, st, grid, nm, nv, 1, csv);
+        run<SPLIT_NOP>("SPLIT_NOP", out, st, grid, nm, nv, 1, csv);
     }
     if (csv) fclose(csv);
     return 0;

@@ -602,6 +602,20 @@ def main():
     y = torch.eye(NCLS)[torch.randint(0, NCLS, (B,), generator=g)].to(device)
     fg = rn.FlatGrads(model.trainable()) if use_dist else None
     reducer = rn.GradientAllReducer(model.trainable(), flat=fg, collective="peers" if args.share_gpu else None) if use_dist else None   # the library's communicator (rnde_comm_*: RCCL unless RNDE_COLLECTIVE / RNDE_ONESHOT say otherwise)
+    if args.share_gpu and reducer is not None and world > 4:
+        # RIG ONLY: more than four ranks' queues on one device -- a rank's spinning one-shot kernel can wait 20 s for a peer whose own all-reduce sits behind
+        # compute kernels the device does not get to (seen at world 8: the first all-reduce gave up).  On the rig every rank drains its stream and meets
+        # the others on the host before the collective is enqueued, so the eight all-reduce kernels are the only work in flight (what tools/oneshot_worker.py
+        # does between its all-reduces); the step runs as separate library calls (RNDE_ONE_CALL=0).  Ranks that own their GPU never take this path.
+        os.environ["RNDE_ONE_CALL"] = "0"
+        inner_allreduce = reducer.allreduce_range_
+
+        def rig_allreduce(lo, hi, mean=False):
+            torch.cuda.synchronize()
+            dist.barrier()
+            return inner_allreduce(lo, hi, mean)
+        reducer.allreduce_range_ = rig_allreduce
+        rig_note += "; host barrier in front of every gradient all-reduce (world > 4 on one device)"
     if args.coupled:
         if reducer is None or reducer.comm is None:
             raise SystemExit("--coupled needs the library communicator: run with --gpus N > 1 (or --force-dist)")

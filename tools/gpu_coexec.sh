@@ -22,7 +22,7 @@ import csv, glob, sys, collections
 d = sys.argv[1]
 f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
 if not f: sys.exit()
-names = {0: "MFMA_ONLY", 1: "VALU_ONLY", 2: "SPLIT", 3: "LOCKSTEP", 4: "STAGGER", 5: "ONEWAVE_MIX", 6: "SPLIT_PRIO_V", 7: "SPLIT_PRIO_M", 8: "SPLIT_NOP", 9: "TWOWAVE_MIX", 10: "ONEWAVE_SEQ"}
+names = {0: "MFMA_ONLY", 1: "VALU_ONLY", 2: "SPLIT", 3: "LOCKSTEP", 4: "STAGGER", 5: "ONEWAVE_MIX", 6: "SPLIT_PRIO_V", 7: "SPLIT_PRIO_M", 8: "SPLIT_NOP", 9: "TWOWAVE_MIX", 10: "ONEWAVE_SEQ", 11: "BF16_MFMA_ONLY", 12: "BF16_SPLIT", 13: "BF16_LOCKSTEP"}
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f[0])):
     k = r["Kernel_Name"]

@@ -12,6 +12,8 @@
 //   ONEWAVE_SEQ  waves 0-3 alone, the same instructions as two bursts (all MFMAs, then all FMAs): the no-overlap reference of ONEWAVE_MIX
 //   TWOWAVE_MIX  all 8 waves run ONEWAVE_MIX's stream on half the work each (a SIMD carries the same totals as SPLIT)
 //   SPLIT_PRIO_V / _M   SPLIT with s_setprio 3 on the vector / the matrix waves (does the arbiter let the other pipe's wave in?)
+//   BF16_*       the control: MFMA_ONLY / SPLIT / LOCKSTEP with v_mfma_f32_16x16x16_bf16 (the matrix core proper) in place of the fp32 MFMA -- if THESE overlap
+//                with fp32 FMAs (and the counter moves) the fp32 result above is a property of the fp32 matrix path, not of the arbiter or of the counter
 //   SPLIT_NOP    SPLIT, the matrix wave issues `s_nop 7` x 3 behind every MFMA (its next MFMA does not sit at the issue stage while the pipe is busy)
 // Output: shader cycles and wall time per variant; the COEXEC counter comes from the --pmc pass (tools/gpu_coexec.sh).
 //   time(SPLIT) ~ max(MFMA_ONLY, VALU_ONLY): the pipes co-execute across waves;  ~ sum: they do not.
@@ -21,7 +23,7 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum { MFMA_ONLY = 0, VALU_ONLY = 1, SPLIT = 2, LOCKSTEP = 3, STAGGER = 4, ONEWAVE_MIX = 5, SPLIT_PRIO_V = 6, SPLIT_PRIO_M = 7, SPLIT_NOP = 8, TWOWAVE_MIX = 9, ONEWAVE_SEQ = 10 };
+enum { MFMA_ONLY = 0, VALU_ONLY = 1, SPLIT = 2, LOCKSTEP = 3, STAGGER = 4, ONEWAVE_MIX = 5, SPLIT_PRIO_V = 6, SPLIT_PRIO_M = 7, SPLIT_NOP = 8, TWOWAVE_MIX = 9, ONEWAVE_SEQ = 10, BF16_MFMA_ONLY = 11, BF16_SPLIT = 12, BF16_LOCKSTEP = 13 };
 
 // nm MFMAs on four independent accumulators (no back-to-back dependency stall: 16x16x4 f32 is 8 passes = 32 cycles, the same accumulator comes round every 4).
 // Inline asm, 16 per loop trip: exactly these instructions, whatever the optimiser would make of the C form.
@@ -31,6 +33,16 @@ __device__ __forceinline__ void mfma_burst(f32x4 (&acc)[4], float a, float b, in
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[j]) : "v"(a), "v"(b));
+        }
+    }
+}
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mfma_burst_bf16(f32x4 (&acc)[4], bf16x4 a, bf16x4 b, int nm) {
+    for (int i = 0; i < nm; i += 16) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("v_mfma_f32_16x16x16_bf16 %0, %1, %2, %0" : "+v"(acc[j]) : "v"(a), "v"(b));
         }
     }
 }
@@ -78,6 +90,11 @@ __global__ __launch_bounds__(512) void coexec_kernel(float* out, unsigned long l
                 }
             }
         }
+    } else if (MODE == BF16_MFMA_ONLY || MODE == BF16_SPLIT || MODE == BF16_LOCKSTEP) {
+        const bf16x4 ab = {(short)0x3f80, (short)0x3f00, (short)(0x3e80 + lane), (short)0x3f80}, bb = {(short)0x3f00, (short)0x3f80, (short)0x3e00, (short)(0x3f00 + lane)};
+        if (MODE == BF16_MFMA_ONLY) { if (w < 4) mfma_burst_bf16(acc, ab, bb, nm); }
+        else if (MODE == BF16_SPLIT) { if (w < 4) mfma_burst_bf16(acc, ab, bb, nm); else valu_burst(x, m, c, nv); }
+        else for (int k = 0; k < K; ++k) { mfma_burst_bf16(acc, ab, bb, nm / (2 * K)); __builtin_amdgcn_sched_barrier(0); valu_burst(x, m, c, nv / (2 * K)); __builtin_amdgcn_sched_barrier(0); }
     } else if (MODE == ONEWAVE_SEQ) {
         if (w < 4) { mfma_burst(acc, a, b, nm); valu_burst(x, m, c, nv); }
     } else if (MODE == SPLIT_PRIO_V) {
@@ -153,6 +170,9 @@ int main(int argc, char** argv) {
             run<ONEWAVE_MIX>("ONEWAVE_MIX", out, st, grid, nm, nv, 1, csv);
             run<TWOWAVE_MIX>("TWOWAVE_MIX", out, st, grid, nm, nv, 1, csv);
         }
+        run<BF16_MFMA_ONLY>("BF16_MFMA_ONLY", out, st, grid, nm, nv, 1, csv);
+        run<BF16_SPLIT>("BF16_SPLIT", out, st, grid, nm, nv, 1, csv);
+        run<BF16_LOCKSTEP>("BF16_LOCKSTEP", out, st, grid, nm, nv, only_K ? only_K : 64, csv);
         run<SPLIT_PRIO_V>("SPLIT_PRIO_V", out, st, grid, nm, nv, 1, csv);
         run<SPLIT_PRIO_M>("SPLIT_PRIO_M", out, st, grid, nm, nv, 1, csv);
         run<SPLIT_NOP>("SPLIT_NOP", out, st, grid, nm, nv, 1, csv);

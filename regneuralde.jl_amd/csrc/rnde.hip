@@ -399,6 +399,12 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
         const size_t xb = (size_t)(c->max_attempts + 1) * 3 * 256 * 8;
         if (hipMalloc((void**)&h->sxch, xb) != hipSuccess) { g_create_err = "device allocation failed"; rnde_node_destroy(h); return RNDE_ERR_HIP; }
         hipMemset(h->sxch, 0, xb);
+        // the one-launch solve's Dense layers on the matrix cores (rnde_x3.h): split weight images for the headline geometry (49 row tiles, 7 x 7 (hidden tile, row block) pairs)
+        if (const char* e7 = getenv("RNDE_X3")) h->x3 = atoi(e7) != 0;
+        if (h->sMT == 49 && h->sHT == 7 && h->sR == 7 && h->sWT == 7) {
+            const size_t img = (size_t)49 * 4 * 3 * 64 * 16;
+            if (hipMalloc(&h->x3B, img) != hipSuccess || hipMalloc(&h->x3D, img) != hipSuccess) { g_create_err = "device allocation failed"; rnde_node_destroy(h); return RNDE_ERR_HIP; }
+        } else h->x3 = 0;
     }
     h->predicted = 12;
     *out = h;
@@ -434,6 +440,8 @@ extern "C" void rnde_node_destroy(rnde_node* h) {
     if (h->mw_slab) hipFree(h->mw_slab);
     if (h->tslab) hipFree(h->tslab);
     if (h->sxch) hipFree(h->sxch);
+    if (h->x3B) hipFree(h->x3B);
+    if (h->x3D) hipFree(h->x3D);
     if (h->pabort) hipFree(h->pabort);
     if (h->pxcc) hipFree(h->pxcc);
     if (h->h_pchk) hipHostFree(h->h_pchk);
@@ -787,7 +795,9 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
         PersistSync Y{h->tslab, h->pabort, h->pxcc, h->persist_spins};
         HIPCHK(h, slab_prepare(h, SQ.Bpad16, s));
         if (++h->s_epoch >= 500000u) { h->s_epoch = 1; HIPCHK(h, hipMemsetAsync(h->sxch, 0, (size_t)(cap + 1) * 3 * 256 * 8, s)); }
-        SolveSync Z{h->sxch, h->s_epoch, cap};
+        const int x3 = (h->x3 && h->x3B && h->x3D) ? 1 : 0;
+        if (x3) HIPCHK(h, rnde_launch_x3_pack(p_dev, h->x3B, h->x3D, h->D, h->H, h->sMT, h->sWT, h->sR, h->sHT, s));      // (0.6 MB each, ~3 us: in front of every solve -- p changes between training steps)
+        SolveSync Z{h->sxch, h->s_epoch, cap, h->x3B, h->x3D};
 #ifdef RNDE_DIAG
         StageParams SD = SQ;
         if (getenv("RNDE_DIAG_SOLVE")) {      // cycle stamps of workgroup 0, every attempt (tools/diag_solve.py)
@@ -796,9 +806,9 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
             hipMemsetAsync(h->diag_buf, 0, 16384, s);
             SD.F.dbg_out = h->diag_buf;
         }
-        HIPCHK(h, rnde_launch_stage_solve(&SD, &Y, &Z, h->act2, s));
+        HIPCHK(h, rnde_launch_stage_solve(&SD, &Y, &Z, h->act2, x3, s));
 #else
-        HIPCHK(h, rnde_launch_stage_solve(&SQ, &Y, &Z, h->act2, s));
+        HIPCHK(h, rnde_launch_stage_solve(&SQ, &Y, &Z, h->act2, x3, s));
 #endif
         if (h->timing) { HIPCHK(h, hipEventRecord(h->tev[1], s)); h->tev_fwd = true; }
         hipLaunchKernelGGL(rnde_stage_finish_kernel, dim3(256), dim3(256), 0, s, SQ, -1, u_out_dev); HIPCHK(h, hipGetLastError());

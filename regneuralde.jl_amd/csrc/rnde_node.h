@@ -41,7 +41,8 @@ static hipError_t rnde_malloc(void** p, size_t bytes) {
 #define hipMalloc(p, n) rnde_malloc((void**)(p), (n))
 
 // rnde_stage_solve.hip (its own translation unit, parameter blocks by address: the same struct definitions on both sides)
-extern "C" hipError_t rnde_launch_stage_solve(const void* stage_params, const void* persist_sync, const void* solve_sync, int act2, hipStream_t s);
+extern "C" hipError_t rnde_launch_stage_solve(const void* stage_params, const void* persist_sync, const void* solve_sync, int act2, int x3, hipStream_t s);
+extern "C" hipError_t rnde_launch_x3_pack(const float* p, void* x3B, void* x3D, int D, int H, int MT, int WT, int R, int HT, hipStream_t s);
 using namespace rnde;
 
 struct rnde_node {
@@ -83,6 +84,8 @@ struct rnde_node {
     int persist = 0, persist_spins = kPersistMaxSpins; int tslab_Bpad = -1; size_t tslab_bytes = 0; float* tslab = nullptr; unsigned *pabort = nullptr, *pxcc = nullptr; unsigned* h_pchk = nullptr;
     // the whole forward solve as one launch (rnde_stage_solve.h): 1 = use it where it applies, 0 = off (RNDE_STAGE_SOLVE=0 at creation); meeting granules, epoch of their tags
     int stage_solve = 1; unsigned long long* sxch = nullptr; unsigned s_epoch = 0; int one_launch_solves = 0;
+    // the one-launch solve's Dense layers on the matrix cores (rnde_x3.h): 1 = on (RNDE_X3 at creation / rnde_node_set_matrix_mode), split weight images, "packed for the current p"
+    int x3 = 0; void *x3B = nullptr, *x3D = nullptr; bool x3_packed = false;
     hipStream_t wstream = nullptr;        // (experimental overlap path of the weight-gradient GEMMs)
     std::vector<hipEvent_t> wevents;
     // device

@@ -20,6 +20,7 @@
 #pragma once
 #include "rnde_stage_persist.h"
 #include "rnde_solve_sync.h"
+#include "rnde_x3.h"
 
 namespace rnde {
 
@@ -93,15 +94,21 @@ __device__ __forceinline__ StepState solve_state_get(const int* ss) {
     return S;
 }
 
-template <int ACT2>
+// X3 = 1: the two Dense-layer products of every stage on the matrix cores (rnde_x3.h: exact three-way bf16 split of both operands, six
+// v_mfma_f32_16x16x32_bf16 per 32 k-values) instead of the fp32-input MFMA, which this part executes on its vector ALUs.  Everything else -- hand-off,
+// meeting, controller, tape layout, the state in registers -- is the same code.  The products are rounded differently (more accurately: rnde_x3.h), so
+// an X3 solve is NOT bit-identical to the fp32-MFMA kernels; its parity is stated against the fp64 restatement (tests/test_gpu_x3.py).
+template <int ACT2, int X3>
 __global__ __launch_bounds__(64 * 7) void rnde_stage_solve_kernel(const StageParams Q, const PersistSync Y, const SolveSync Z) {
     const StepParams& P = Q.F;
     constexpr int gWT = 7, gHT = 7, gK2b = 7, gR = 7, gD = 784, gH = 100;
     constexpr int KH = 16 * gK2b + 4, KG = 16 * gWT + 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* HL = smem;
-    float* GL = HL + kSCB * KH;
-    float* RED = GL + kSCB * KG;         // [32]; RED[24] = "a wave of this workgroup gave up"
+    float* GL = HL + (X3 ? kX3ImageFloats : kSCB * KH);
+    float* RED = GL + (X3 ? kX3ImageFloats : kSCB * KG);         // [32]; RED[24] = "a wave of this workgroup gave up"
+    unsigned short* HX = (unsigned short*)HL;      // X3: the operand images [plane][column][kX3K] of bf16 in place of the fp32 images
+    unsigned short* GX = (unsigned short*)GL;
     double* SUMS = (double*)(RED + 32);  // [4]: the three cross-workgroup sums of the meeting, [3] != 0: the meeting failed
     float* QP = (float*)(SUMS + 4);      // [2] (by attempt parity: a fast wave writes the next one while a slow wave still reads this one): powf(qold, beta2) of the state the running attempt started from (evaluated off the critical path)
     int* SS = (int*)(QP + 2);            // [12] the controller state before the next attempt, as wave 0 derived it behind the meeting (see solve_state_put / _get)
@@ -132,8 +139,19 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_solve_kernel(const StagePar
         const int hr = 16 * w + 4 * (lane >> 4) + i;
         if (hr < gH) { w1t_own[i] = Q.p[(size_t)gH * gD + hr]; b1_own[i] = Q.p[(size_t)gH * (gD + 1) + hr]; }
     }
-    f32x4 wB[7], wD[7];
-    {
+    f32x4 wB[X3 ? 1 : 7], wD[X3 ? 1 : 7];
+    x3u4 xB[X3 ? 4 : 1][3], xD[X3 ? 4 : 1][3];
+    if constexpr (X3) {
+        const x3u4* pB = (const x3u4*)Z.x3B + ((size_t)T * 4 * 3) * 64 + lane;
+        const x3u4* pD = (const x3u4*)Z.x3D + ((size_t)(w * gR + rb) * 4 * 3) * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) { xD[s][pl] = pD[(size_t)(s * 3 + pl) * 64]; xB[s][pl] = pB[(size_t)(s * 3 + pl) * 64]; }
+        }
+        // the operand images start as zeros: k-values nobody writes (102 .. 127 of the hidden layer's, 112 .. 127 of the row block's) multiply zero weights
+        for (int i = tid; i < 2 * kX3ImageFloats; i += 64 * 7) HL[i] = 0.f;
+    } else {
         const f32x4* pB = Q.pwB + ((size_t)T * gK2b) * 64 + lane;
         const f32x4* pD = Q.pwD + ((size_t)w * 49 + rb * gWT) * 64 + lane;
 #pragma unroll
@@ -163,6 +181,13 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_solve_kernel(const StagePar
 
     // phase D: this row block's layer-1 partial of the stage input v -> slab, exchange number `ex`
     auto phase_d = [&](const f32x4& v, unsigned ex) {
+        if constexpr (X3) {
+            x3_store4(GX, col, 16 * w + 4 * (lane >> 4), v);
+            __syncthreads();
+            const size_t tile0x = (((size_t)slab_buf(ex) * Q.C + ct) * gR + rb) * gHT;
+            slab_put(Y.tslab, tile0x + w, lane, x3_tile<4>(xD, GX, lane));
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) GL[own_gl0 + 4 * i] = v[i];
         __syncthreads();
@@ -250,14 +275,23 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_solve_kernel(const StagePar
                 for (int i = 0; i < 4; ++i) hv[i] = own_kind[i] == 0 ? hv[i] : fmaf(own_c1[i], ts, own_c0[i]);
             }
             if (own_hstore) *(f32x4*)(hdst + own_hd0) = hv;
+            if constexpr (X3) x3_store4(HX, col, 16 * w + 4 * (lane >> 4), hv);
+            else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) HL[own_hl0 + 4 * i] = hv[i];
+                for (int i = 0; i < 4; ++i) HL[own_hl0 + 4 * i] = hv[i];
+            }
             if (dead && lane == 0) RED[24] = 1.f;
             __syncthreads();
             if (RED[24] != 0.f) { alive = false; return; }
             // ---- phase B ----
             f32x4 kv;
-            {
+            if constexpr (X3) {
+                kv = x3_tile<4>(xB, HX, lane);
+                if (ACT2) {
+                    const f32x2 a01 = tanh_fast2((f32x2){kv[0], kv[1]}), a23 = tanh_fast2((f32x2){kv[2], kv[3]});
+                    kv = (f32x4){a01.x, a01.y, a23.x, a23.y};
+                }
+            } else {
                 f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
                 const float* hb = HL + col * KH + 4 * (lane >> 4);
                 f32x4 bf[7];

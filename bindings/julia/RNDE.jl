@@ -535,4 +535,12 @@ function set_coupling!(h::Handle, comm::Ptr{Cvoid}, global_batch::Integer)
     return h
 end
 
+# Which unit forms the Dense-layer products of the one-launch forward solve (include/rnde.h: rnde_node_set_matrix_mode):
+# 0 = fp32-input MFMA (vector ALUs on gfx950), 1 = exact three-way bf16 split on the matrix cores (the default where the kernels serve the shape).
+function set_matrix_mode!(h::Handle, mode::Integer)
+    st = ccall((:rnde_node_set_matrix_mode, LIB), Cint, (Ptr{Cvoid}, Cint), h.ptr, Cint(mode))
+    check(h, st)
+end
+matrix_mode(h::Handle) = Int(ccall((:rnde_node_matrix_mode, LIB), Cint, (Ptr{Cvoid},), h.ptr))
+
 end # module

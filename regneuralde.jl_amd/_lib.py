@@ -88,6 +88,10 @@ def lib():
     L.rnde_node_launches_per_attempt.argtypes = [vp]
     L.rnde_node_one_launch_solves.restype = C.c_int32
     L.rnde_node_one_launch_solves.argtypes = [vp]
+    L.rnde_node_set_matrix_mode.restype = C.c_int32
+    L.rnde_node_set_matrix_mode.argtypes = [vp, i32]
+    L.rnde_node_matrix_mode.restype = C.c_int32
+    L.rnde_node_matrix_mode.argtypes = [vp]
     L.rnde_classifier_head.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]
     L.rnde_node_classifier_grad.argtypes = [vp, vp, vp, vp, vp, i32, i32, f, f, f, vp, vp, vp, vp, fp, C.POINTER(C.c_int64), vp, vp]
     L.rnde_momentum_step.argtypes = [vp, vp, vp, C.c_int64, C.c_int64, f, f, f, vp]
@@ -163,7 +167,7 @@ EXPORTS = ["rnde_version", "rnde_last_error", "rnde_param_count", "rnde_node_cre
            "rnde_node_forward", "rnde_node_forward_saveat", "rnde_node_forward_everystep", "rnde_node_forward_replay", "rnde_node_backward", "rnde_node_backward_async", "rnde_node_release_tape", "rnde_node_forward_host",
            "rnde_node_backward_host", "rnde_node_steps", "rnde_debug_feval", "rnde_debug_attempt",
            "rnde_bench_attempt", "rnde_bench_attempt_taped", "rnde_bench_attempt_cold_tape", "rnde_node_set_timing", "rnde_node_timing", "rnde_node_last_attempts", "rnde_node_fallback_count",
-           "rnde_node_launches_per_attempt", "rnde_node_one_launch_solves", "rnde_classifier_head", "rnde_node_classifier_grad", "rnde_momentum_step", "rnde_momentum_step_scaled", "rnde_adam_step",
+           "rnde_node_launches_per_attempt", "rnde_node_one_launch_solves", "rnde_node_set_matrix_mode", "rnde_node_matrix_mode", "rnde_classifier_head", "rnde_node_classifier_grad", "rnde_momentum_step", "rnde_momentum_step_scaled", "rnde_adam_step",
            "rnde_comm_unique_id", "rnde_comm_create", "rnde_comm_destroy", "rnde_comm_world", "rnde_comm_last_error", "rnde_comm_library", "rnde_comm_allreduce", "rnde_comm_create_local_group", "rnde_comm_health", "rnde_comm_window_create", "rnde_comm_window_destroy", "rnde_comm_create_peers", "rnde_comm_path", "rnde_node_set_coupling", "rnde_tapes_create", "rnde_tapes_destroy", "rnde_tapes_last_error", "rnde_tapes_in_use", "rnde_tapes_node", "rnde_tapes_forward", "rnde_tapes_backward", "rnde_tapes_release",
            "rnde_nsde_param_count", "rnde_nsde_create", "rnde_nsde_destroy", "rnde_nsde_last_error", "rnde_nsde_forward",
            "rnde_nsde_forward_saveat", "rnde_nsde_forward_everystep", "rnde_nsde_forward_replay", "rnde_nsde_backward", "rnde_nsde_backward_async", "rnde_nsde_classifier_head", "rnde_nsde_classifier_grad", "rnde_nsde_steps", "rnde_nsde_debug_attempt", "rnde_nsde_timing", "rnde_normal_fill", "rnde_latent_create", "rnde_latent_destroy", "rnde_latent_last_error", "rnde_latent_param_counts", "rnde_latent_encode",

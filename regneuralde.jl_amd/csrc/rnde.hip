@@ -400,6 +400,7 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
         if (hipMalloc((void**)&h->sxch, xb) != hipSuccess) { g_create_err = "device allocation failed"; rnde_node_destroy(h); return RNDE_ERR_HIP; }
         hipMemset(h->sxch, 0, xb);
         // the one-launch solve's Dense layers on the matrix cores (rnde_x3.h): split weight images for the headline geometry (49 row tiles, 7 x 7 (hidden tile, row block) pairs)
+        h->x3 = 1;      // default where the geometry fits (include/rnde.h: rnde_node_set_matrix_mode)
         if (const char* e7 = getenv("RNDE_X3")) h->x3 = atoi(e7) != 0;
         if (h->sMT == 49 && h->sHT == 7 && h->sR == 7 && h->sWT == 7) {
             const size_t img = (size_t)49 * 4 * 3 * 64 * 16;
@@ -1060,6 +1061,13 @@ extern "C" int32_t rnde_node_last_attempts(const rnde_node* h) { return h ? h->n
 extern "C" int32_t rnde_node_fallback_count(const rnde_node* h) { return h ? h->persist_fallbacks : 0; }
 
 extern "C" int32_t rnde_node_one_launch_solves(const rnde_node* h) { return h ? h->one_launch_solves : 0; }
+extern "C" rnde_status rnde_node_set_matrix_mode(rnde_node* h, int32_t mode) {
+    if (!h) return RNDE_ERR_BAD_ARG;
+    if (mode != RNDE_MATRIX_F32 && mode != RNDE_MATRIX_BF16X3) { h->err = "matrix mode: 0 (fp32-input MFMA) or 1 (bf16x3 on the matrix cores)"; return RNDE_ERR_BAD_ARG; }
+    h->x3 = (mode == RNDE_MATRIX_BF16X3 && h->x3B && h->x3D) ? 1 : 0;
+    return RNDE_OK;
+}
+extern "C" int32_t rnde_node_matrix_mode(const rnde_node* h) { return (h && h->x3 && h->x3B && h->x3D) ? RNDE_MATRIX_BF16X3 : RNDE_MATRIX_F32; }
 extern "C" int32_t rnde_node_launches_per_attempt(const rnde_node* h) {
     if (!h) return 0;
     return (h->engine == 2 && h->persist != 1) ? 7 : 1;

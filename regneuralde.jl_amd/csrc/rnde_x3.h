@@ -61,22 +61,31 @@ __device__ __forceinline__ x3u4 x3_frag(const unsigned short* img, int pl, int s
 __device__ __forceinline__ x3f4 x3_mfma(const x3u4& a, const x3u4& b, const x3f4& c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(x3bf8, a), __builtin_bit_cast(x3bf8, b), c, 0, 0, 0);
 }
-// one 16 x 16 output tile over NS k-steps of 32: A planes wa[s][plane] (registers), B planes from the LDS image.  Six terms per step; the three
-// accumulators collect terms of one magnitude class each (2^-16: lh, hl, mm | 2^-8: mh, hm | 1: hh) and are added smallest first.
+// one 16 x 16 output tile over NS k-steps of 32: A planes wa[s][plane] (registers), B planes from the LDS image.  Six terms per step; four
+// accumulators, one or two magnitude classes each (2^-16: lh + hl | mm; 2^-8: mh + hm; 1: hh), added smallest first at the end.
+// The B fragments of step s + 1 are requested BEFORE the six matrix instructions of step s are issued (sched_barrier pins that order): with the reads
+// of a step directly in front of its instructions a phase was 12 exposed LDS round trips long (~1.5 k cycles for 0.4 k of matrix work; the first
+// build of this kernel, profiles/r06_x3_stamps.txt).  Two instructions on one accumulator are at least two apart (the dependent-result latency of a
+// 16-cycle instruction is more than one issue slot).
 template <int NS>
 __device__ __forceinline__ x3f4 x3_tile(const x3u4 (&wa)[NS][3], const unsigned short* img, int lane) {
-    x3f4 aS = {0.f, 0.f, 0.f, 0.f}, aM = {0.f, 0.f, 0.f, 0.f}, aH = {0.f, 0.f, 0.f, 0.f};
+    x3f4 aL = {0.f, 0.f, 0.f, 0.f}, aN = {0.f, 0.f, 0.f, 0.f}, aM = {0.f, 0.f, 0.f, 0.f}, aH = {0.f, 0.f, 0.f, 0.f};
+    x3u4 bh = x3_frag(img, 0, 0, lane), bm = x3_frag(img, 1, 0, lane), bl = x3_frag(img, 2, 0, lane);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        const x3u4 bh = x3_frag(img, 0, s, lane), bm = x3_frag(img, 1, s, lane), bl = x3_frag(img, 2, s, lane);
-        aS = x3_mfma(wa[s][2], bh, aS);
-        aM = x3_mfma(wa[s][1], bh, aM);
-        aH = x3_mfma(wa[s][0], bh, aH);
-        aS = x3_mfma(wa[s][0], bl, aS);
-        aM = x3_mfma(wa[s][0], bm, aM);
-        aS = x3_mfma(wa[s][1], bm, aS);
+        x3u4 nh = bh, nm = bm, nl = bl;
+        if (s + 1 < NS) { nh = x3_frag(img, 0, s + 1, lane); nm = x3_frag(img, 1, s + 1, lane); nl = x3_frag(img, 2, s + 1, lane); }
+        __builtin_amdgcn_sched_barrier(0);
+        aL = x3_mfma(wa[s][2], bh, aL);      // lo * hi
+        aM = x3_mfma(wa[s][1], bh, aM);      // mid * hi
+        aH = x3_mfma(wa[s][0], bh, aH);      // hi * hi
+        aN = x3_mfma(wa[s][1], bm, aN);      // mid * mid
+        aL = x3_mfma(wa[s][0], bl, aL);      // hi * lo
+        aM = x3_mfma(wa[s][0], bm, aM);      // hi * mid
+        __builtin_amdgcn_sched_barrier(0);
+        bh = nh; bm = nm; bl = nl;
     }
-    return (aS + aM) + aH;
+    return ((aL + aN) + aM) + aH;
 }
 
 // ---- packed A operands (weights), split once per forward: image [tile][k-step s < 4][plane < 3][64 lanes] of 16-byte fragments, lane l holding

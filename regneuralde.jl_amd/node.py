@@ -191,7 +191,7 @@ class TrackedNeuralODE:
     """Mirror of reference src/models/neural_ode.jl:1-33 (struct + constructor) and :48-180 (call methods)."""
 
     def __init__(self, model, tspan, time_dep, regularize, solver="Tsit5", *, max_batch=512, max_attempts=128,
-                 cb_save_start=True, track_ctrl=True, track_initdt=True, col_tile=0, **kwargs):
+                 cb_save_start=True, track_ctrl=True, track_initdt=True, col_tile=0, matrix_mode=None, **kwargs):
         if solver not in ("Tsit5", "AutoTsit5", "DP5", "DOP853"):
             raise ValueError("solver: the reference's call sites use Tsit5() / AutoTsit5(Tsit5()) only; DP5 (a second 7-stage pair) and DOP853 "
                              "(a 13-stage table) run on the tableau-as-data kernels (Dense chains of width <= 64)")
@@ -208,6 +208,9 @@ class TrackedNeuralODE:
             raise ValueError("time_dep must match the model (TDChain => True)")
         self.max_batch, self.max_attempts = int(max_batch), int(max_attempts)
         self.cb_save_start, self.track_ctrl, self.track_initdt, self.col_tile = cb_save_start, track_ctrl, track_initdt, col_tile
+        # which unit forms the Dense-layer products of the one-launch solve (include/rnde.h: rnde_node_set_matrix_mode): None = the library's default
+        # (bf16x3 on the matrix cores where the kernels serve the shape, RNDE_X3 overrides), 0 = fp32-input MFMA, 1 = bf16x3
+        self.matrix_mode = matrix_mode
         self.P = self.p.numel()
         self._handles = {}
         self._coupling = None
@@ -249,6 +252,8 @@ class TrackedNeuralODE:
             raise RuntimeError(f"{len(hs)} taped forwards of this layer are pending without a backward pass; each owns a tape of "
                                "max_attempts records.  Run them under torch.no_grad() (NFE probes), call backward, or drop the graphs")
         h = _Handle(self._config(x.device.index or 0, self._func))
+        if self.matrix_mode is not None:
+            _lib.check(h.ptr, _lib.lib().rnde_node_set_matrix_mode(h.ptr, int(self.matrix_mode)))
         if self._coupling is not None:
             _lib.check(h.ptr, _lib.lib().rnde_node_set_coupling(h.ptr, self._coupling[0], self._coupling[1]))
         hs.append(h)

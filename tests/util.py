@@ -35,10 +35,13 @@ def make_cfg(dims, acts, max_batch, reltol=1.4e-8, abstol=1.4e-8, regularize=1, 
 class Node:
     """Thin RAII wrapper over the C ABI handle (device pointers in, device pointers out)."""
 
-    def __init__(self, cfg):
+    def __init__(self, cfg, matrix_mode=None):
+        """matrix_mode: None = the library's default (include/rnde.h: rnde_node_set_matrix_mode), 0 = fp32-input MFMA, 1 = bf16x3 on the matrix cores"""
         self.L = _lib.lib()
         self.h = C.c_void_p()
         _lib.check(None, self.L.rnde_node_create(C.byref(cfg), C.byref(self.h)))
+        if matrix_mode is not None:
+            _lib.check(self.h, self.L.rnde_node_set_matrix_mode(self.h, int(matrix_mode)))
         self.cfg = cfg
         self.D = cfg.dims[0]
         self.stream = None            # HIP stream of forward / backward (None: the default stream); see own_stream()

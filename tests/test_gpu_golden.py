@@ -139,7 +139,8 @@ def test_nsde_stiffness_regulariser_reproduces_golden(name, replay, mw, monkeypa
     node.close()
 
 
-def test_device_natural_run_at_reference_tolerance_matches_devorder_golden():
+def test_device_natural_run_at_reference_tolerance_matches_devorder_golden(monkeypatch):
+    monkeypatch.setenv("RNDE_X3", "0")      # the fixture is the oracle in the fp32-input-MFMA order: what matrix mode 0 computes
     """NFE at reltol = abstol = 1.4e-8 (experiments/mnist_node.jl:121-124) against a COMMITTED fixture: the oracle run in the device's
     summation order (tests/golden/make_golden.py main3).  Same number of attempts (+-1), same accept pattern, steps within 20 %,
     u_end to 3e-6 of the fp64 fixture; the sequential-k oracle's count (41) is stored beside it to show what the order does."""

@@ -164,7 +164,9 @@ def test_vanilla_b64_matches_oracle():
     print(f"vanilla B=64: attempts device {got['nattempts']}, fp32 oracle {r32['nattempts']}, fp64 oracle {r64['nattempts']}; "
           f"u_end vs fp64: device {_rel(got['u'], r64['u']):.2e}, fp32 oracle {_rel(r32['u'], r64['u']):.2e}")
     assert _rel(got["u"], r64["u"]) <= 5e-6
-    assert 0.6 * r32["nattempts"] <= got["nattempts"] <= 1.15 * r32["nattempts"]
+    # (the default matrix mode -- bf16x3 on the matrix cores -- rounds the Dense layers more accurately than the sequential fp32 oracle and takes ~0.6 of its attempts;
+    #  the fp32-input-MFMA kernels ~0.73, the fp64 oracle 0.25)
+    assert r64["nattempts"] <= got["nattempts"] <= 1.15 * r32["nattempts"]
     se = o32.steps_ext()
     rep = node.forward_replay(x, p, se[:, 2], se[:, 4])
     assert rep["nfe"] == r32["nfe"] and np.array_equal(rep["steps"][:, 1], se[:, 1])
@@ -172,7 +174,8 @@ def test_vanilla_b64_matches_oracle():
     node.close()
 
 
-def test_attempt_count_distribution_at_reference_tolerance():
+def test_attempt_count_distribution_at_reference_tolerance(monkeypatch):
+    monkeypatch.setenv("RNDE_X3", "0")      # device = device-order oracle, attempt for attempt: matrix mode 0 (fp32-input MFMA); mode 1 takes fewer, tests/test_gpu_x3.py
     """NFE 'parity' at 1.4e-8 is a distribution (DESIGN.md 3.1): 16 seeds, B = 64, device vs fp32 oracle (vs fp64 for scale).
     Measured: device 30.0 +- 0.0, fp32 oracle 40.8 +- 0.6, fp64 oracle ~10: the count is set by the rounding error of the fp32
     GEMMs (the device's error floor is 0.46 of the oracle's, test above, and dt ~ EEst^-0.14/0.2...), not by the ODE; both
@@ -217,7 +220,8 @@ def test_f_evaluation_equals_the_device_order_oracle_almost_bit_for_bit():
     node.close()
 
 
-def test_natural_run_attempts_equal_the_device_order_oracle():
+def test_natural_run_attempts_equal_the_device_order_oracle(monkeypatch):
+    monkeypatch.setenv("RNDE_X3", "0")      # (matrix mode 0: the oracle's device-order mode mirrors the fp32-input MFMA)
     """NFE parity at the reference tolerance as an EQUALITY (north star: 'trajectories and NFE counts within a stated fp32
     tolerance on identical inputs'): natural runs, device vs the oracle in the device's order, B = 64 over 16 seeds and B = 512
     over 2 -- the same number of attempts (+-1 allowed, 0 observed), the same accept/reject pattern, step sizes within 15 %

@@ -404,7 +404,7 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
         if (const char* e7 = getenv("RNDE_X3")) h->x3 = atoi(e7) != 0;
         if (h->sMT == 49 && h->sHT == 7 && h->sR == 7 && h->sWT == 7) {
             const size_t img = (size_t)49 * 4 * 3 * 64 * 16;
-            if (hipMalloc(&h->x3B, img) != hipSuccess || hipMalloc(&h->x3D, img) != hipSuccess) { g_create_err = "device allocation failed"; rnde_node_destroy(h); return RNDE_ERR_HIP; }
+            if (hipMalloc(&h->x3B, img) != hipSuccess || hipMalloc(&h->x3D, img) != hipSuccess || hipMalloc(&h->x3Bt, img) != hipSuccess || hipMalloc(&h->x3Dt, img) != hipSuccess) { g_create_err = "device allocation failed"; rnde_node_destroy(h); return RNDE_ERR_HIP; }
         } else h->x3 = 0;
     }
     h->predicted = 12;
@@ -443,6 +443,8 @@ extern "C" void rnde_node_destroy(rnde_node* h) {
     if (h->sxch) hipFree(h->sxch);
     if (h->x3B) hipFree(h->x3B);
     if (h->x3D) hipFree(h->x3D);
+    if (h->x3Bt) hipFree(h->x3Bt);
+    if (h->x3Dt) hipFree(h->x3Dt);
     if (h->pabort) hipFree(h->pabort);
     if (h->pxcc) hipFree(h->pxcc);
     if (h->h_pchk) hipHostFree(h->h_pchk);
@@ -687,7 +689,7 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
         return RNDE_ERR_BAD_ARG;
     }
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    h->have_tape = false; h->rev_packed = false;
+    h->have_tape = false; h->rev_packed = false; h->x3_packed = false;
     const float* x_caller = nullptr;
     if (keep_tape) {
         rnde_status st = ensure_arena(h, h->cfg.max_attempts);
@@ -797,7 +799,10 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
         HIPCHK(h, slab_prepare(h, SQ.Bpad16, s));
         if (++h->s_epoch >= 500000u) { h->s_epoch = 1; HIPCHK(h, hipMemsetAsync(h->sxch, 0, (size_t)(cap + 1) * 3 * 256 * 8, s)); }
         const int x3 = (h->x3 && h->x3B && h->x3D) ? 1 : 0;
-        if (x3) HIPCHK(h, rnde_launch_x3_pack(p_dev, h->x3B, h->x3D, h->D, h->H, h->sMT, h->sWT, h->sR, h->sHT, s));      // (0.6 MB each, ~3 us: in front of every solve -- p changes between training steps)
+        if (x3) {      // (0.6 MB each, ~3 us: in front of every solve -- p changes between training steps; a taped solve splits the reverse pass's transposed pair in the same launch)
+            HIPCHK(h, rnde_launch_x3_pack(p_dev, h->x3B, h->x3D, keep_tape ? h->x3Bt : nullptr, keep_tape ? h->x3Dt : nullptr, h->D, h->H, h->sMT, h->sWT, h->sR, h->sHT, s));
+            h->x3_packed = keep_tape;
+        }
         SolveSync Z{h->sxch, h->s_epoch, cap, h->x3B, h->x3D};
 #ifdef RNDE_DIAG
         StageParams SD = SQ;

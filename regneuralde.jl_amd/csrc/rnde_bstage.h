@@ -27,6 +27,7 @@ struct BStageParams {
     float* EXK; float* EXG;   // stiffness-estimate extras: direct cotangent of k6, of g6 (regularize >= 2)
     const float* sv_t; const float* sv_ubar; int nsave; float* SVW;   // saveat: times, D x T x B cotangent, W_i = sum_p b_i(theta_p) ubar_p (7 arrays)
     int MT, WT, R, C, HT, KHb;
+    const void* x3Bt; const void* x3Dt;   // rnde_x3.h: the two images above split into three bf16 planes (X3 form of rnde_bstage_attempt_kernel), or null
 };
 
 enum { BM_START = 0, BM_STAGE = 1 };

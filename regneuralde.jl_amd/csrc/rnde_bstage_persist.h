@@ -14,6 +14,7 @@
 #endif
 #include "rnde_bstage.h"
 #include "rnde_stage_persist.h"
+#include "rnde_x3.h"
 
 namespace rnde {
 
@@ -24,7 +25,10 @@ namespace rnde {
 #endif
 
 // FIX = 1: the headline geometry (D = 784, H = 100, 7 waves, 7 row blocks) as compile-time constants, see rnde_stage_attempt_kernel
-template <int ACT2, int FIX>
+// X3 = 1 (with FIX; no saveat, no stiffness-estimate cotangents -- the host launches it for the error-estimate / plain callbacks only): the two
+// transposed products of every stage on the matrix cores (rnde_x3.h: exact three-way bf16 split, six v_mfma_f32_16x16x32_bf16 per 32 k-values), as the
+// forward solve of matrix mode 1 forms its own.  Not bit-identical to the fp32-input-MFMA form; parity vs the fp64 restatement: tests/test_gpu_x3.py.
+template <int ACT2, int FIX, int X3 = 0>
 __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const BStageParams Q, const int n, const StepMeta m, const float eig_c1,
                                                                           const float eig_c2, const int sv_lo, const int sv_hi, const PersistSync Y, const double qo_host,
                                                                           const float svb_n /* = svb_att[n], known to the host: saves a dependent load in the scalar chain */) {
@@ -35,9 +39,12 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
     const int gD = FIX ? 784 : P.D, gH = FIX ? 100 : P.H;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int KZ = 16 * gKHb + 4, KG = 16 * gWT + 4;
+    static_assert(!X3 || FIX, "the X3 form exists for the headline geometry only");
     float* ZL = smem;
-    float* GL = ZL + kSCB * KZ;
-    float* RED = GL + kSCB * KG;         // [32]; RED[24..31]: per-wave "gave up" flags of the hand-off
+    float* GL = ZL + (X3 ? kX3ImageFloats : kSCB * KZ);
+    float* RED = GL + (X3 ? kX3ImageFloats : kSCB * KG);         // [32]; RED[24..31]: per-wave "gave up" flags of the hand-off
+    unsigned short* ZX = (unsigned short*)ZL;      // X3: operand images [plane][column][kX3K] of bf16
+    unsigned short* GX = (unsigned short*)GL;
 #if RNDE_BSTAGE_HDMA
     // FIX: the six stages' tape operands (a lane's 16 bytes of h_{j+1} and of k_j) are brought into LDS by START with `global_load_lds`, 1 KiB per
     // wave, stage and array -- a wave's vector-memory operations return in order, so a stage that requests its own (cold) operands in front of
@@ -83,7 +90,22 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
     unsigned long long aD = (unsigned long long)(Q.pwDt + ((size_t)w * gMT + rb * gWT) * 64 + lane);
     unsigned long long aB4 = aB + 4 * 1024, aD4 = aD + 4 * 1024;       // (the offset field of a load reaches 4095 bytes)
     asm volatile("" : "+v"(aB), "+v"(aD), "+v"(aB4), "+v"(aD4));
-    f32x4 wB[kSMaxHT], wD[kSMaxW];
+    f32x4 wB[X3 ? 1 : kSMaxHT], wD[X3 ? 1 : kSMaxW];
+    x3u4 xB[X3 ? 4 : 1][3], xD[X3 ? 4 : 1][3];
+    if constexpr (X3) {
+        typedef const __attribute__((address_space(1))) x3u4* gx4;
+        unsigned long long bD = (unsigned long long)((const x3u4*)Q.x3Dt + ((size_t)(w * gR + rb) * 4 * 3) * 64 + lane);
+        unsigned long long bB = (unsigned long long)((const x3u4*)Q.x3Bt + ((size_t)T * 4 * 3) * 64 + lane);
+        unsigned long long bD1 = bD + 4 * 1024, bD2 = bD + 8 * 1024, bB1 = bB + 4 * 1024, bB2 = bB + 8 * 1024;      // (the offset field of a load reaches 4095 bytes)
+        asm volatile("" : "+v"(bD), "+v"(bB), "+v"(bD1), "+v"(bD2), "+v"(bB1), "+v"(bB2));
+#pragma unroll
+        for (int f = 0; f < 12; ++f) xD[f / 3][f % 3] = f < 4 ? ((gx4)bD)[(size_t)f * 64] : (f < 8 ? ((gx4)bD1)[(size_t)(f - 4) * 64] : ((gx4)bD2)[(size_t)(f - 8) * 64]);
+#pragma unroll
+        for (int f = 0; f < 12; ++f) xB[f / 3][f % 3] = f < 4 ? ((gx4)bB)[(size_t)f * 64] : (f < 8 ? ((gx4)bB1)[(size_t)(f - 4) * 64] : ((gx4)bB2)[(size_t)(f - 8) * 64]);
+        // k-values 112 .. 135 of every (plane, column) row are written by nobody (they multiply zero weights, but must not hold NaN patterns another kernel
+        // left in LDS): zeroed here.  ONLY those -- rows 0 .. 111 are written by the waves' own x3_store4 with no barrier between this loop and START's.
+        for (int i = tid; i < 2 * 3 * 16 * 12; i += 64 * 7) ((unsigned*)ZL)[(i / 12) * (kX3K / 2) + 56 + i % 12] = 0u;
+    } else {
     // (wD first: the prologue's own phase D needs it; wB is not multiplied before phase B of the first stage and streams in behind)
 #pragma unroll
     for (int kb = 0; kb < kSMaxW; ++kb)
@@ -96,6 +118,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
                 wB[kb] = (f32x4){*(gw1)(aB4 + 2 * 1024), 0.f, 0.f, 0.f};       // every load issued before it
             } else wB[kb] = kb < 4 ? ((gw4)aB)[(size_t)kb * 64] : ((gw4)aB4)[(size_t)(kb - 4) * 64];
         }
+    }
     BSTAMP(43);
     float* R = P.arena + (long long)m.rec * P.rec_stride;
     BSTAMP(44);
@@ -104,8 +127,8 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
     const float dt = m.dt;
     const float* upsrc = P.x; const float* k1p = P.f0; bool upok = colok, upvec = P.xvec != 0;
     if (m.src >= 0) { const float* Rl = P.arena + (long long)m.src * P.rec_stride; upsrc = Rl + L.unew(); k1p = Rl + L.k(7); upok = true; upvec = vec; }
-    const bool has_eig = (eig_c1 != 0.f || eig_c2 != 0.f);
-    const bool has_sv = sv_hi > sv_lo;
+    const bool has_eig = X3 ? false : (eig_c1 != 0.f || eig_c2 != 0.f);      // (X3: the host launches this form only without these two)
+    const bool has_sv = X3 ? false : sv_hi > sv_lo;
 
     // per-stage partials {S, tau, exdt}: index 0 = START, 1..6 = stage j = 6..1 (reduced at the end in launch order)
     float pS[7], pT[7], pX[7];
@@ -128,6 +151,13 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
     const size_t own_zd0 = (size_t)gcol * gH + own_h0;                // tape offset of (column, own_h0) in the H x B arrays
     if (tid == 0) RED[24] = 0.f;                                       // "a wave of this workgroup gave up"
     auto phase_d = [&](const f32x4& v, unsigned ex) {
+        if constexpr (X3) {
+            x3_store4(GX, col, 16 * w + 4 * (lane >> 4), v);
+            __syncthreads();
+            const size_t tile0x = (((size_t)slab_buf(ex) * Q.C + ct) * gR + rb) * gHT;
+            slab_put(Y.tslab, tile0x + w, lane, x3_tile<4>(xD, GX, lane));
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) GL[own_gl0 + 4 * i] = tile_ok ? v[i] : 0.f;
         __syncthreads();
@@ -355,8 +385,11 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
 #pragma unroll
                 for (int i = 0; i < 4; ++i) tau += unit ? w1t_own[i] * zv[i] : ((i == 0 && trow) ? zs[0] : 0.f);
             }
+            if constexpr (X3) x3_store4(ZX, col, 16 * w + 4 * (lane >> 4), zv);
+            else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ZL[own_zl0 + 4 * i] = zv[i];
+                for (int i = 0; i < 4; ++i) ZL[own_zl0 + 4 * i] = zv[i];
+            }
         } else if (w < gHT) {      // this wave's own hidden tile (addressing precomputed)
             if (!dead) slab_clear(Y.tslab, tprev0 + w, lane);
 #pragma unroll
@@ -404,7 +437,8 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
         BSTAMP(4 + 5 * (6 - j));
         // ---- phase B ----
         f32x4 gb = {0.f, 0.f, 0.f, 0.f};
-        if (tile_ok) {
+        if constexpr (X3) gb = x3_tile<4>(xB, ZX, lane);
+        else if (tile_ok) {
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             const float* zb = ZL + col * KZ + 4 * (lane >> 4);
             f32x4 bf[kSMaxHT];

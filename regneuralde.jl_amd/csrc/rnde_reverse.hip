@@ -248,7 +248,7 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
         }
         h->rev_packed = false;
         BStageParams BQ{};
-        BQ.B = Q; BQ.p = h->pcopy; BQ.pwBt = h->spwBt; BQ.pwDt = h->spwDt; BQ.slab = h->slab2;
+        BQ.B = Q; BQ.p = h->pcopy; BQ.pwBt = h->spwBt; BQ.pwDt = h->spwDt; BQ.slab = h->slab2; BQ.x3Bt = h->x3Bt; BQ.x3Dt = h->x3Dt;
         BQ.UTB = b.UTB; BQ.UNB = b.UNB; BQ.UPB0 = b.UPB0; BQ.GB = b.GB;
         BQ.EXK = b.GB + 6 * A; BQ.EXG = b.GB + 7 * A; BQ.SVW = b.GB + 8 * A;
         BQ.sv_t = h->saveat.empty() ? nullptr : h->sv_t_dev; BQ.sv_ubar = u_bar_dev; BQ.nsave = (int)h->saveat.size();
@@ -304,7 +304,20 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
                         HIPCHK(h, hipFuncSetAttribute((const void*)rnde_bstage_attempt_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                         attr.done();
                     }
-                    if (h->act2) hipLaunchKernelGGL((rnde_bstage_attempt_kernel<1, 1>), pgrid, blk, flds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
+                    // matrix mode 1 (rnde_x3.h): the forward ran the x3 solve and split the transposed weights too; the x3 form serves the callbacks without
+                    // eigen_est cotangents and solves without saveat (the headline; everything else keeps the fp32-input-MFMA form)
+                    const bool x3 = h->x3_packed && h->x3Bt && h->x3Dt && h->saveat.empty() && h->cfg.regularize <= RNDE_REG_ERR && !getenv("RNDE_X3_REV_OFF");
+                    if (x3) {
+                        const size_t xlds = sizeof(float) * ((size_t)2 * kX3ImageFloats + 64) + (size_t)(RNDE_BSTAGE_HDMA ? 1 : 0) * 6 * 7 * 2 * 1024;
+                        static DeviceOnce attr3;
+                        if (attr3.need()) {
+                            HIPCHK(h, hipFuncSetAttribute((const void*)rnde_bstage_attempt_kernel<1, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                            HIPCHK(h, hipFuncSetAttribute((const void*)rnde_bstage_attempt_kernel<0, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                            attr3.done();
+                        }
+                        if (h->act2) hipLaunchKernelGGL((rnde_bstage_attempt_kernel<1, 1, 1>), pgrid, blk, xlds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
+                        else hipLaunchKernelGGL((rnde_bstage_attempt_kernel<0, 1, 1>), pgrid, blk, xlds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
+                    } else if (h->act2) hipLaunchKernelGGL((rnde_bstage_attempt_kernel<1, 1>), pgrid, blk, flds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
                     else hipLaunchKernelGGL((rnde_bstage_attempt_kernel<0, 1>), pgrid, blk, flds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
                 } else if (h->act2) hipLaunchKernelGGL((rnde_bstage_attempt_kernel<1, 0>), pgrid, blk, h->stage_lds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
                 else hipLaunchKernelGGL((rnde_bstage_attempt_kernel<0, 0>), pgrid, blk, h->stage_lds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);

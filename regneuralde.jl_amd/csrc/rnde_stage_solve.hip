@@ -26,9 +26,11 @@ extern "C" hipError_t rnde_launch_stage_solve(const void* stage_params, const vo
     }
     return hipGetLastError();
 }
-// the weights split into three bf16 planes (rnde_x3.h): one launch in front of a forward solve whose kernels run with x3
-extern "C" hipError_t rnde_launch_x3_pack(const float* p, void* x3B, void* x3D, int D, int H, int MT, int WT, int R, int HT, hipStream_t s) {
-    const long long total = (long long)(MT + HT * R) * 4 * 64;
-    hipLaunchKernelGGL(rnde_x3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, (x3u4*)x3B, (x3u4*)x3D, D, H, MT, WT, R, HT);
+// the weights split into three bf16 planes (rnde_x3.h): one launch in front of a forward solve whose kernels run with x3; x3Bt / x3Dt (may be null):
+// the transposed images of the reverse attempt kernel
+extern "C" hipError_t rnde_launch_x3_pack(const float* p, void* x3B, void* x3D, void* x3Bt, void* x3Dt, int D, int H, int MT, int WT, int R, int HT, hipStream_t s) {
+    const long long total = (long long)(MT + HT * R) * 4 * 64 * ((x3Bt && x3Dt) ? 2 : 1);
+    X3PackDst dst{{(x3u4*)x3B, (x3u4*)x3D, (x3Bt && x3Dt) ? (x3u4*)x3Bt : nullptr, (x3Bt && x3Dt) ? (x3u4*)x3Dt : nullptr}};
+    hipLaunchKernelGGL(rnde_x3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, dst, D, H, MT, WT, R, HT);
     return hipGetLastError();
 }

@@ -89,20 +89,26 @@ __device__ __forceinline__ x3f4 x3_tile(const x3u4 (&wa)[NS][3], const unsigned 
 }
 
 // ---- packed A operands (weights), split once per forward: image [tile][k-step s < 4][plane < 3][64 lanes] of 16-byte fragments, lane l holding
-// A[16 tile + (l & 15)][k = 32 s + 8 (l >> 4) + j], j < 8.
-//   which 0 (layer 2, phase B): tile = row tile T < 49 of the D = 784 outputs; k < H: W2[row][k]; k == H: the time column; k == H + 1: b2[row]; else 0
-//   which 1 (layer 1, phase D): tile = hidden tile w * R + row block rb (w < 7, rb < 7); row m = 16 w + (l & 15) < H; k = row inside the block:
-//                               state row 16 * WT * rb + k, k < 16 * WT (= 112); else 0
-// Parameter layout as stage_pack_elem (rnde_stage.h): Flux.destructure order, W stored out x in column-major.
-static __global__ void rnde_x3_pack_kernel(const float* __restrict__ p, x3u4* __restrict__ dstB, x3u4* __restrict__ dstD, int D, int H, int MT, int WT, int R, int HT) {
+// A[16 tile + (l & 15)][k = 32 s + 8 (l >> 4) + j], j < 8.  Four images, the x3 counterparts of stage_pack_elem's (rnde_stage.h):
+//   0 forward  layer 2 (phase B): tile = row tile T < MT of the D outputs; k < H: W2[row][k]; k == H: the time column; k == H + 1: b2[row]; else 0
+//   1 forward  layer 1 (phase D): tile = hidden tile w * R + row block rb; row m = 16 w + (l & 15) < H; k = row inside the block: state row
+//                                 16 WT rb + k, k < 16 WT (= 112); else 0
+//   2 reverse  W1x^T   (phase B): tile = row tile T; m = state row; k < H: W1[k][m]; else 0
+//   3 reverse  W2xt^T  (phase D): tile = hidden tile w * R + row block rb; m = 16 w + (l & 15) <= H (m == H: the time column); k as in image 1: W2[state row][m]
+// Parameter layout as stage_pack_elem: Flux.destructure order, W stored out x in column-major.  dst[0..1] forward, dst[2..3] reverse (nullptr: skipped).
+struct X3PackDst { x3u4* d[4]; };
+static __global__ void rnde_x3_pack_kernel(const float* __restrict__ p, const X3PackDst dst, int D, int H, int MT, int WT, int R, int HT) {
     const float* W1 = p;
     const float* b1 = W1 + (size_t)H * (D + 1);
     const float* W2 = b1 + H;
     const float* b2 = W2 + (size_t)D * (H + 1);
-    const long long nB = (long long)MT * 4 * 64, nD = (long long)HT * R * 4 * 64;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nB + nD; i += (long long)gridDim.x * blockDim.x) {
-        const bool isD = i >= nB;
-        const long long q = isD ? i - nB : i;
+    const long long nB = (long long)MT * 4 * 64, nD = (long long)HT * R * 4 * 64, per = nB + nD;
+    const int nimg = dst.d[2] ? 2 : 1;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nimg * per; i += (long long)gridDim.x * blockDim.x) {
+        const int rev = (int)(i / per);
+        const long long ii = i - rev * per;
+        const bool isD = ii >= nB;
+        const long long q = isD ? ii - nB : ii;
         const int l = (int)(q & 63), s = (int)((q >> 6) & 3), tile = (int)(q >> 8);
         float wv[8];
 #pragma unroll
@@ -111,21 +117,27 @@ static __global__ void rnde_x3_pack_kernel(const float* __restrict__ p, x3u4* __
             float w = 0.f;
             if (!isD) {
                 const int m = 16 * tile + (l & 15);
-                if (m < D) w = k <= H ? W2[(size_t)k * D + m] : (k == H + 1 ? b2[m] : 0.f);
+                if (m < D) {
+                    if (!rev) w = k <= H ? W2[(size_t)k * D + m] : (k == H + 1 ? b2[m] : 0.f);
+                    else if (k < H) w = W1[(size_t)m * H + k];
+                }
             } else {
                 const int wt = tile / R, rb = tile % R;
                 const int m = 16 * wt + (l & 15), row = 16 * WT * rb + k;
-                if (m < H && k < 16 * WT && row < D) w = W1[(size_t)row * H + m];
+                if (k < 16 * WT && row < D) {
+                    if (!rev) { if (m < H) w = W1[(size_t)row * H + m]; }
+                    else if (m <= H) w = W2[(size_t)m * D + row];
+                }
             }
             wv[j] = w;
         }
         unsigned hi[4], mid[4], lo[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) x3_split2(wv[2 * j], wv[2 * j + 1], hi[j], mid[j], lo[j]);
-        x3u4* dst = (isD ? dstD : dstB) + ((size_t)(tile * 4 + s) * 3) * 64 + l;
-        dst[0] = (x3u4){hi[0], hi[1], hi[2], hi[3]};
-        dst[64] = (x3u4){mid[0], mid[1], mid[2], mid[3]};
-        dst[128] = (x3u4){lo[0], lo[1], lo[2], lo[3]};
+        x3u4* o = dst.d[2 * rev + (isD ? 1 : 0)] + ((size_t)(tile * 4 + s) * 3) * 64 + l;
+        o[0] = (x3u4){hi[0], hi[1], hi[2], hi[3]};
+        o[64] = (x3u4){mid[0], mid[1], mid[2], mid[3]};
+        o[128] = (x3u4){lo[0], lo[1], lo[2], lo[3]};
     }
 }
 

@@ -1,6 +1,7 @@
 // rnde_reverse.hip -- C ABI (include/rnde.h), the reverse side: discretise-then-optimise reverse passes of the three ODE engines, the weight-gradient
 // GEMMs, the classifier head and its fused training step, the optimiser steps.  The handle and what rnde.hip offers this file: rnde_node.h.
 #include "rnde_node.h"
+#include "rnde_wgradx.h"
 
 static rnde_status chain_bwd_run(rnde_node* h, const float* u_bar_dev, const float* saveval_bar_host, float* x_bar_dev,
                                  float* p_bar_dev, float* tspan_bar_host, hipStream_t s, bool sync = true, float* tspan_bar_dev = nullptr);
@@ -101,6 +102,21 @@ static rnde_status launch_wgrad_part(rnde_node* h, const EvalDesc* ev, int n_eva
         const int steps_per_chunk = (total_steps + sc - 1) / sc;
         sc = (total_steps + steps_per_chunk - 1) / steps_per_chunk;
         if ((size_t)(*chunk_cursor + sc) * (size_t)len > h->bw.slab_floats) { h->err = "weight-gradient slab overflow"; return RNDE_ERR_BAD_ARG; }
+        // matrix mode 1 in effect for this step (the forward ran the x3 solve): the GEMMs on the matrix cores too (rnde_wgradx.h; RNDE_X3_WGRAD_OFF=1: A/B)
+        static const bool x3_off = getenv("RNDE_X3_WGRAD_OFF") != nullptr;
+        if (h->x3_packed && !x3_off) {
+            static DeviceOnce attrx;
+            if (attrx.need()) {
+                HIPCHK(h, hipFuncSetAttribute((const void*)rnde_wgrad3x_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWxLdsBytes));
+                HIPCHK(h, hipFuncSetAttribute((const void*)rnde_wgrad3x_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWxLdsBytes));
+                attrx.done();
+            }
+            if (tall) hipLaunchKernelGGL((rnde_wgrad3x_kernel<true>), dim3(2, sc), dim3(448), kWxLdsBytes, s, ev, n_evals, steps_per_chunk, M, Nx, Bpad, dst);
+            else hipLaunchKernelGGL((rnde_wgrad3x_kernel<false>), dim3(2, sc), dim3(448), kWxLdsBytes, s, ev, n_evals, steps_per_chunk, M, Nx, Bpad, dst);
+            HIPCHK(h, hipGetLastError());
+            *chunk_cursor += sc;
+            return RNDE_OK;
+        }
         const size_t lds = (size_t)2 * 32 * (464 + 144) * sizeof(float);   // two buffers
         static DeviceOnce attr;
         if (attr.need()) {

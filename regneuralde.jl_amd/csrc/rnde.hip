@@ -510,10 +510,20 @@ hipError_t stage_pack(rnde_node* h, const float* p, f32x4* dst, int which, int M
     hipLaunchKernelGGL(rnde_stage_pack_kernel, dim3(grid), dim3(256), 0, st, p, dst, which, h->D, h->H, MTrows, Kb);
     return hipGetLastError();
 }
+// matrix mode 1 (rnde_x3.h): the weights split into three bf16 planes for the x3 kernels, in front of every forward (p changes between training steps);
+// with_rev: the transposed pair of the reverse attempt kernel in the same launch.  Sets "this forward's stage kernels run with x3".
+static rnde_status x3_pack(rnde_node* h, const float* p_dev, bool with_rev, hipStream_t s) {
+    h->x3_fwd = false;
+    if (!(h->x3 && h->x3B && h->x3D && h->persist == 1 && !h->stage_generic)) return RNDE_OK;
+    HIPCHK(h, rnde_launch_x3_pack(p_dev, h->x3B, h->x3D, with_rev ? h->x3Bt : nullptr, with_rev ? h->x3Dt : nullptr, h->D, h->H, h->sMT, h->sWT, h->sR, h->sHT, s));
+    h->x3_fwd = true;
+    h->x3_packed = with_rev;
+    return RNDE_OK;
+}
 static rnde_status stage_pack_weights(rnde_node* h, const float* p_dev, hipStream_t s) {
     HIPCHK(h, stage_pack(h, p_dev, h->spwB, 0, h->sMT, h->sK2b, s));
     HIPCHK(h, stage_pack(h, p_dev, h->spwD, 1, h->sHT, h->sMT, s));
-    return RNDE_OK;
+    return x3_pack(h, p_dev, false, s);
 }
 rnde_status stage_pack_all(rnde_node* h, const float* p_dev, hipStream_t s, const float* x_src, long long x_floats) {
     PackJobs J{};
@@ -535,7 +545,7 @@ rnde_status stage_pack_all(rnde_node* h, const float* p_dev, hipStream_t s, cons
     hipLaunchKernelGGL(rnde_pack_all_kernel, dim3(grid, n), dim3(256), 0, s, p_dev, J, h->D, h->H);
     HIPCHK(h, hipGetLastError());
     h->rev_packed = true;
-    return RNDE_OK;
+    return x3_pack(h, p_dev, true, s);
 }
 // The hand-off slabs must read "empty" wherever the persistent kernels have not written in the current tile indexing: at
 // creation, and whenever the padded batch width (= number of column tiles) differs from the last persistent launch's.
@@ -552,18 +562,23 @@ static hipError_t stage_attempt(rnde_node* h, const StageParams& Q, int n, hipSt
         const bool fix = Q.WT == 7 && Q.HT == 7 && Q.K2b == 7 && Q.MT == 49 && Q.R == 7 && h->D == 784 && h->H == 100 && !h->stage_generic;
         // batches that fill the chip more than once: two column tiles per workgroup (rnde_stage_persist2.h; bit-identical results).
         // RNDE_PERSIST2=0 keeps one tile per workgroup (A/B and the bit-identity test), =1 takes two whenever the tile count is even.
-        if (fix && Q.C % 2 == 0 && h->persist2 != 0 && (Q.C >= kPersist2MinTiles || h->persist2 >= 1)) {
+        static const bool x3_over_mt = !(getenv("RNDE_X3_MT") && atoi(getenv("RNDE_X3_MT")) == 0);      // (A/B: 0 = keep the fp32 two-tile kernel for large batches even in matrix mode 1)
+        if (fix && Q.C % 2 == 0 && h->persist2 != 0 && (Q.C >= kPersist2MinTiles || h->persist2 >= 1) && !(h->x3_fwd && x3_over_mt)) {
             const dim3 grid2(8 * Q.R * ((Q.C / 2 + 7) / 8));
             const size_t lds2 = sizeof(float) * (2 * 2 * 16 * (16 * 7 + 4) + 32 * 3);
             if (h->act2) hipLaunchKernelGGL((rnde_stage_attempt_mt_kernel<1, 2>), grid2, dim3(64 * 7), lds2, s, Q, n, Y);
             else hipLaunchKernelGGL((rnde_stage_attempt_mt_kernel<0, 2>), grid2, dim3(64 * 7), lds2, s, Q, n, Y);
             return hipGetLastError();
         }
-        if (fix) {
-            if (h->act2) hipLaunchKernelGGL((rnde_stage_attempt_kernel<1, 1>), grid, dim3(64 * Q.WT), h->stage_lds, s, Q, n, Y);
-            else hipLaunchKernelGGL((rnde_stage_attempt_kernel<0, 1>), grid, dim3(64 * Q.WT), h->stage_lds, s, Q, n, Y);
-        } else if (h->act2) hipLaunchKernelGGL((rnde_stage_attempt_kernel<1, 0>), grid, dim3(64 * Q.WT), h->stage_lds, s, Q, n, Y);
-        else hipLaunchKernelGGL((rnde_stage_attempt_kernel<0, 0>), grid, dim3(64 * Q.WT), h->stage_lds, s, Q, n, Y);
+        if (fix && h->x3_fwd) {      // matrix mode 1: the same instruction sequence as the x3 one-launch solve (bit-identical to it)
+            const size_t xlds = sizeof(float) * ((size_t)2 * kX3ImageFloats + 64);
+            if (h->act2) hipLaunchKernelGGL((rnde_stage_attempt_kernel<1, 1, 1>), grid, dim3(64 * 7), xlds, s, Q, n, Y, (const void*)h->x3B, (const void*)h->x3D);
+            else hipLaunchKernelGGL((rnde_stage_attempt_kernel<0, 1, 1>), grid, dim3(64 * 7), xlds, s, Q, n, Y, (const void*)h->x3B, (const void*)h->x3D);
+        } else if (fix) {
+            if (h->act2) hipLaunchKernelGGL((rnde_stage_attempt_kernel<1, 1>), grid, dim3(64 * Q.WT), h->stage_lds, s, Q, n, Y, (const void*)nullptr, (const void*)nullptr);
+            else hipLaunchKernelGGL((rnde_stage_attempt_kernel<0, 1>), grid, dim3(64 * Q.WT), h->stage_lds, s, Q, n, Y, (const void*)nullptr, (const void*)nullptr);
+        } else if (h->act2) hipLaunchKernelGGL((rnde_stage_attempt_kernel<1, 0>), grid, dim3(64 * Q.WT), h->stage_lds, s, Q, n, Y, (const void*)nullptr, (const void*)nullptr);
+        else hipLaunchKernelGGL((rnde_stage_attempt_kernel<0, 0>), grid, dim3(64 * Q.WT), h->stage_lds, s, Q, n, Y, (const void*)nullptr, (const void*)nullptr);
         return hipGetLastError();
     }
     hipError_t e = launch_stage<SM_START>(h, Q, n, 0, s);
@@ -689,7 +704,7 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
         return RNDE_ERR_BAD_ARG;
     }
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    h->have_tape = false; h->rev_packed = false; h->x3_packed = false;
+    h->have_tape = false; h->rev_packed = false; h->x3_packed = false; h->x3_fwd = false;
     const float* x_caller = nullptr;
     if (keep_tape) {
         rnde_status st = ensure_arena(h, h->cfg.max_attempts);
@@ -798,11 +813,7 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
         PersistSync Y{h->tslab, h->pabort, h->pxcc, h->persist_spins};
         HIPCHK(h, slab_prepare(h, SQ.Bpad16, s));
         if (++h->s_epoch >= 500000u) { h->s_epoch = 1; HIPCHK(h, hipMemsetAsync(h->sxch, 0, (size_t)(cap + 1) * 3 * 256 * 8, s)); }
-        const int x3 = (h->x3 && h->x3B && h->x3D) ? 1 : 0;
-        if (x3) {      // (0.6 MB each, ~3 us: in front of every solve -- p changes between training steps; a taped solve splits the reverse pass's transposed pair in the same launch)
-            HIPCHK(h, rnde_launch_x3_pack(p_dev, h->x3B, h->x3D, keep_tape ? h->x3Bt : nullptr, keep_tape ? h->x3Dt : nullptr, h->D, h->H, h->sMT, h->sWT, h->sR, h->sHT, s));
-            h->x3_packed = keep_tape;
-        }
+        const int x3 = h->x3_fwd ? 1 : 0;      // (the weights were split by this forward's pack launch: x3_pack)
         SolveSync Z{h->sxch, h->s_epoch, cap, h->x3B, h->x3D};
 #ifdef RNDE_DIAG
         StageParams SD = SQ;

@@ -85,7 +85,7 @@ struct rnde_node {
     // the whole forward solve as one launch (rnde_stage_solve.h): 1 = use it where it applies, 0 = off (RNDE_STAGE_SOLVE=0 at creation); meeting granules, epoch of their tags
     int stage_solve = 1; unsigned long long* sxch = nullptr; unsigned s_epoch = 0; int one_launch_solves = 0;
     // the one-launch solve's Dense layers on the matrix cores (rnde_x3.h): 1 = on (RNDE_X3 at creation / rnde_node_set_matrix_mode), split weight images, "packed for the current p"
-    int x3 = 0; void *x3B = nullptr, *x3D = nullptr, *x3Bt = nullptr, *x3Dt = nullptr; bool x3_packed = false;      // x3_packed: the last forward ran the x3 solve, the four images hold ITS parameters (the reverse pass may use the transposed pair)
+    int x3 = 0; void *x3B = nullptr, *x3D = nullptr, *x3Bt = nullptr, *x3Dt = nullptr; bool x3_packed = false, x3_fwd = false;      // x3_fwd: this forward's stage kernels run with x3 (weights split by its pack launch); x3_packed: the last forward ran the x3 solve, the four images hold ITS parameters (the reverse pass may use the transposed pair)
     hipStream_t wstream = nullptr;        // (experimental overlap path of the weight-gradient GEMMs)
     std::vector<hipEvent_t> wevents;
     // device

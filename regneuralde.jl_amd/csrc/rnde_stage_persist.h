@@ -18,6 +18,7 @@
 // kernel raises `abort_flag`, all workgroups leave, and the host falls back to the multi-launch kernels for good.
 #pragma once
 #include "rnde_stage.h"
+#include "rnde_x3.h"
 
 #include <type_traits>
 
@@ -125,16 +126,21 @@ __device__ __forceinline__ bool slab_poll_sum(const PersistSync& Y, int buf, int
 
 // FIX = 1: the geometry of the headline configuration (D = 784 = 49 row tiles, H = 100 -> 7 hidden tiles, 7 waves, 7 row blocks) as
 // compile-time constants: the stages are instruction bound and full of wave-uniform conditions on these numbers.  FIX = 0: any geometry.
-template <int ACT2, int FIX>
-__global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const StageParams Q, const int n, const PersistSync Y) {
+// X3 = 1 (with FIX): the Dense-layer products on the matrix cores (rnde_x3.h), the same instruction sequence as rnde_stage_solve_kernel<.., 1> -- the two
+// are bit-identical to each other, as their fp32-input-MFMA forms are (tests/test_gpu_x3.py).  x3B / x3D: the split weights (rnde_launch_x3_pack).
+template <int ACT2, int FIX, int X3 = 0>
+__global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const StageParams Q, const int n, const PersistSync Y, const void* x3B = nullptr, const void* x3D = nullptr) {
+    static_assert(!X3 || FIX, "the X3 form exists for the headline geometry only");
     const StepParams& P = Q.F;
     const int gWT = FIX ? 7 : Q.WT, gHT = FIX ? 7 : Q.HT, gK2b = FIX ? 7 : Q.K2b, gMT = FIX ? 49 : Q.MT, gR = FIX ? 7 : Q.R;
     const int gD = FIX ? 784 : P.D, gH = FIX ? 100 : P.H;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int KH = 16 * gK2b + 4, KG = 16 * gWT + 4;
     float* HL = smem;
-    float* GL = HL + kSCB * KH;
-    float* RED = GL + kSCB * KG;         // [32]; RED[24..31] = per-wave "gave up" flags of the hand-off
+    float* GL = HL + (X3 ? kX3ImageFloats : kSCB * KH);
+    float* RED = GL + (X3 ? kX3ImageFloats : kSCB * KG);         // [32]; RED[24..31] = per-wave "gave up" flags of the hand-off
+    unsigned short* HX = (unsigned short*)HL;      // X3: operand images [plane][column][kX3K] of bf16
+    unsigned short* GX = (unsigned short*)GL;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (FIX) __builtin_assume(w >= 0 && w < 7);
@@ -190,7 +196,21 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
     unsigned long long aD = (unsigned long long)(Q.pwD + ((size_t)w * gMT + rb * gWT) * 64 + lane);
     unsigned long long aB4 = aB + 4 * 1024, aD4 = aD + 4 * 1024;       // (the offset field of a load reaches 4095 bytes: k-blocks 4.. need their own base)
     asm volatile("" : "+v"(aB), "+v"(aD), "+v"(aB4), "+v"(aD4));
-    f32x4 wB[kSMaxHT], wD[kSMaxW];
+    f32x4 wB[X3 ? 1 : kSMaxHT], wD[X3 ? 1 : kSMaxW];
+    x3u4 xB[X3 ? 4 : 1][3], xD[X3 ? 4 : 1][3];
+    if constexpr (X3) {
+        typedef const __attribute__((address_space(1))) x3u4* gx4;
+        unsigned long long bD = (unsigned long long)((const x3u4*)x3D + ((size_t)(w * gR + rb) * 4 * 3) * 64 + lane);
+        unsigned long long bB = (unsigned long long)((const x3u4*)x3B + ((size_t)T * 4 * 3) * 64 + lane);
+        unsigned long long bD1 = bD + 4 * 1024, bD2 = bD + 8 * 1024, bB1 = bB + 4 * 1024, bB2 = bB + 8 * 1024;
+        asm volatile("" : "+v"(bD), "+v"(bB), "+v"(bD1), "+v"(bD2), "+v"(bB1), "+v"(bB2));
+#pragma unroll
+        for (int f = 0; f < 12; ++f) xD[f / 3][f % 3] = f < 4 ? ((gx4)bD)[(size_t)f * 64] : (f < 8 ? ((gx4)bD1)[(size_t)(f - 4) * 64] : ((gx4)bD2)[(size_t)(f - 8) * 64]);
+#pragma unroll
+        for (int f = 0; f < 12; ++f) xB[f / 3][f % 3] = f < 4 ? ((gx4)bB)[(size_t)f * 64] : (f < 8 ? ((gx4)bB1)[(size_t)(f - 4) * 64] : ((gx4)bB2)[(size_t)(f - 8) * 64]);
+        // k-values 112 .. 135 of every (plane, column) row are written by nobody: zeroed (ONLY those: no barrier between this loop and START's x3_store4)
+        for (int i = tid; i < 2 * 3 * 16 * 12; i += 64 * 7) ((unsigned*)HL)[(i / 12) * (kX3K / 2) + 56 + i % 12] = 0u;
+    } else {
     // (wD first: the prologue's own phase D needs it; wB is not multiplied before phase B of the first stage and streams in behind)
 #pragma unroll
     for (int kb = 0; kb < kSMaxW; ++kb)
@@ -204,6 +224,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
                 wB[kb] = (f32x4){lo.x, lo.y, 0.f, 0.f};
             } else wB[kb] = kb < 4 ? ((gw4)aB)[(size_t)kb * 64] : ((gw4)aB4)[(size_t)(kb - 4) * 64];
         }
+    }
     const float* W1t = Q.p + (size_t)gH * gD;
     const float* b1 = Q.p + (size_t)gH * (gD + 1);
 
@@ -267,6 +288,13 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
     if (tid == 0) RED[24] = 0.f;                  // "a wave of this workgroup gave up" (written by any such wave; read after the phase-A barrier)
     // phase D: this row block's layer-1 partial of the stage input v -> slab[par], then publish exchange number `ex`
     auto phase_d = [&](const f32x4& v, unsigned ex) {
+        if constexpr (X3) {
+            x3_store4(GX, col, 16 * w + 4 * (lane >> 4), v);
+            __syncthreads();
+            const size_t tile0x = (((size_t)slab_buf(ex) * Q.C + ct) * gR + rb) * gHT;
+            slab_put(Y.tslab, tile0x + w, lane, x3_tile<4>(xD, GX, lane));
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) GL[own_gl[i]] = (FIX || (tile_ok && r0 + i < gD)) ? v[i] : 0.f;
         __syncthreads();
@@ -349,8 +377,11 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
                 for (int i = 0; i < 4; ++i) hv[i] = own_kind[i] == 0 ? hv[i] : fmaf(own_c1[i], ts, own_c0[i]);
             }
             if (own_hstore) *(f32x4*)(hdst + own_hd[0]) = hv;
+            if constexpr (X3) x3_store4(HX, col, 16 * w + 4 * (lane >> 4), hv);
+            else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) HL[own_hl[0] + 4 * i] = hv[i];      // kperm: the four rows of a lane sit 4 floats apart
+                for (int i = 0; i < 4; ++i) HL[own_hl[0] + 4 * i] = hv[i];      // kperm: the four rows of a lane sit 4 floats apart
+            }
         } else if (w < gHT) {      // this wave's own hidden tile: addressing precomputed (own_*)
             if (!dead) slab_clear(Y.tslab, tprev0 + w, lane);
             float pre[4];
@@ -405,7 +436,13 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
         PSTAMP(5 + 5 * (s - 1));
         // ---- phase B ----
         f32x4 kv = {0.f, 0.f, 0.f, 0.f};
-        if (tile_ok) {
+        if constexpr (X3) {
+            kv = x3_tile<4>(xB, HX, lane);
+            if (ACT2) {
+                const f32x2 a01 = tanh_fast2((f32x2){kv[0], kv[1]}), a23 = tanh_fast2((f32x2){kv[2], kv[3]});
+                kv = (f32x4){a01.x, a01.y, a23.x, a23.y};
+            }
+        } else if (tile_ok) {
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             const float* hb = HL + col * KH + 4 * (lane >> 4);
             f32x4 bf[kSMaxHT];

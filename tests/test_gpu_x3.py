@@ -135,3 +135,41 @@ def test_x3_regulariser_noise_gradient_is_no_larger_than_the_fp32_kernels():
         node.close()
     print(f"|g_reg| / |g_signal|: fp32-MFMA {d[0][0]:.3e} / {d[0][1]:.3e} ({d[0][2]} attempts) | bf16x3 {d[1][0]:.3e} / {d[1][1]:.3e} ({d[1][2]} attempts)")
     assert d[1][0] <= 1.5 * d[0][0] and d[1][0] <= 0.05 * d[1][1] and d[0][0] <= 0.05 * d[0][1]
+
+
+@pytest.mark.parametrize("B,tol,scale,reg", [(512, TOL, 1.0, 1), (64, TOL, 1.0, 1), (200, 1e-3, 3.0, 1), (37, 1e-4, 2.0, 0), (1024, TOL, 1.0, 1)])
+def test_x3_one_launch_solve_is_bit_identical_to_the_x3_attempt_kernel(B, tol, scale, reg, monkeypatch):
+    """The two x3 kernels issue the same matrix instructions in the same order on the same operands: the one-launch solve (B <= 512) and one launch per
+    attempted step (RNDE_STAGE_SOLVE=0; also what saveat, the coupled controller, B > 512 and the fallback run) agree bit for bit -- steps, u_end, saved
+    values, and the gradients of the reverse pass that follows (the mirror of tests/test_gpu_solve.py for matrix mode 1)."""
+    from tests.util import Node
+    arch, p, x, ubar = _problem(B, 41, scale)
+    out = []
+    for solve in ("1", "0"):
+        monkeypatch.setenv("RNDE_STAGE_SOLVE", solve)
+        node = Node(_cfg(B, tol, regularize=reg), matrix_mode=1)
+        got = node.forward(x, p, keep_tape=True)
+        assert node.L.rnde_node_one_launch_solves(node.h) == (1 if solve == "1" and B <= 512 else 0)
+        n = len(got["saveval"])
+        g = node.backward(ubar, np.full(n, 100.0 / max(n, 1), np.float32) if n else None)
+        out.append((got, g))
+        node.close()
+    (a, ga), (b, gb) = out
+    assert a["nattempts"] == b["nattempts"] and np.array_equal(a["steps"], b["steps"])
+    assert np.array_equal(a["u"], b["u"]) and np.array_equal(a["saveval"], b["saveval"])
+    assert all(np.array_equal(u, v) for u, v in zip(ga, gb))
+
+
+def test_x3_attempt_kernel_serves_saveat_against_the_fp64_restatement():
+    """saveat runs launch-per-attempt: in matrix mode 1 on the x3 attempt kernel.  Dense-output states vs the fp64 oracle along the device's steps."""
+    from tests.util import Node, Oracle
+    arch, p, x, _ = _problem(96, 51, 2.0)
+    sa = np.linspace(0.0, 1.0, 6).astype(np.float32)
+    node = Node(_cfg(96, 1e-4, regularize=1), matrix_mode=1)
+    got = node.forward_saveat(x, p, sa, keep_tape=False)
+    st = got["steps"]
+    o64 = Oracle(arch, np.float64, 1e-4, 1e-4, reg_kind=1, max_attempts=200)
+    o64.set_replay(st[:, 1].astype(np.float64), st[:, 3].astype(np.int32))
+    r64 = o64.forward(x.astype(np.float64), p.astype(np.float64), saveat=sa.astype(np.float64))
+    assert got["u"].shape == r64["u"].shape and _rel(got["u"], r64["u"]) <= 5e-6
+    node.close()

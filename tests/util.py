@@ -137,7 +137,11 @@ class Node:
         st = self.L.rnde_node_forward_saveat(self.h, xd.data_ptr(), pd.data_ptr(), B, t0, t1, sa, T, u.data_ptr(), C.byref(nfe), sv,
                                              C.byref(nsv), int(keep_tape), None)
         _lib.check(self.h, st)
-        return dict(u=u.cpu().numpy(), nfe=nfe.value, saveval=np.array(sv[:nsv.value], dtype=np.float32))
+        steps = (C.c_float * (4 * self.cfg.max_attempts))()
+        natt = C.c_int32(0)
+        self.L.rnde_node_steps(self.h, steps, self.cfg.max_attempts, C.byref(natt))
+        return dict(u=u.cpu().numpy(), nfe=nfe.value, saveval=np.array(sv[:nsv.value], dtype=np.float32),
+                    steps=np.array(steps[:4 * natt.value], dtype=np.float32).reshape(-1, 4), nattempts=natt.value)
 
     def backward(self, ubar, svbar=None):
         B = ubar.shape[0]

@@ -399,10 +399,13 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
         const size_t xb = (size_t)(c->max_attempts + 1) * 3 * 256 * 8;
         if (hipMalloc((void**)&h->sxch, xb) != hipSuccess) { g_create_err = "device allocation failed"; rnde_node_destroy(h); return RNDE_ERR_HIP; }
         hipMemset(h->sxch, 0, xb);
-        // the one-launch solve's Dense layers on the matrix cores (rnde_x3.h): split weight images for the headline geometry (49 row tiles, 7 x 7 (hidden tile, row block) pairs)
+    }
+    // the stage kernels' Dense layers on the matrix cores (rnde_x3.h): split weight images for the headline geometry (49 row tiles, 7 x 7 (hidden tile, row
+    // block) pairs) whenever the one-launch-per-attempt kernels are in use (persist == 1) -- with or without the one-launch solve
+    if (h->persist == 1) {
         h->x3 = 1;      // default where the geometry fits (include/rnde.h: rnde_node_set_matrix_mode)
         if (const char* e7 = getenv("RNDE_X3")) h->x3 = atoi(e7) != 0;
-        if (h->sMT == 49 && h->sHT == 7 && h->sR == 7 && h->sWT == 7) {
+        if (h->sMT == 49 && h->sHT == 7 && h->sR == 7 && h->sWT == 7 && h->D == 784 && h->H == 100 && !h->stage_generic) {
             const size_t img = (size_t)49 * 4 * 3 * 64 * 16;
             if (hipMalloc(&h->x3B, img) != hipSuccess || hipMalloc(&h->x3D, img) != hipSuccess || hipMalloc(&h->x3Bt, img) != hipSuccess || hipMalloc(&h->x3Dt, img) != hipSuccess) { g_create_err = "device allocation failed"; rnde_node_destroy(h); return RNDE_ERR_HIP; }
         } else h->x3 = 0;
@@ -563,11 +566,17 @@ static hipError_t stage_attempt(rnde_node* h, const StageParams& Q, int n, hipSt
         // batches that fill the chip more than once: two column tiles per workgroup (rnde_stage_persist2.h; bit-identical results).
         // RNDE_PERSIST2=0 keeps one tile per workgroup (A/B and the bit-identity test), =1 takes two whenever the tile count is even.
         static const bool x3_over_mt = !(getenv("RNDE_X3_MT") && atoi(getenv("RNDE_X3_MT")) == 0);      // (A/B: 0 = keep the fp32 two-tile kernel for large batches even in matrix mode 1)
-        if (fix && Q.C % 2 == 0 && h->persist2 != 0 && (Q.C >= kPersist2MinTiles || h->persist2 >= 1) && !(h->x3_fwd && x3_over_mt)) {
+        if (fix && Q.C % 2 == 0 && h->persist2 != 0 && (Q.C >= kPersist2MinTiles || h->persist2 >= 1)) {
             const dim3 grid2(8 * Q.R * ((Q.C / 2 + 7) / 8));
+            if (h->x3_fwd && x3_over_mt) {      // matrix mode 1: the two-tile kernel in its x3 form (RNDE_X3_MT=0: the fp32 form, A/B)
+                const size_t xlds2 = sizeof(float) * ((size_t)2 * 2 * kX3ImageFloats + 32 * 3);
+                if (h->act2) hipLaunchKernelGGL((rnde_stage_attempt_mt_kernel<1, 2, 1>), grid2, dim3(64 * 7), xlds2, s, Q, n, Y, (const void*)h->x3B, (const void*)h->x3D);
+                else hipLaunchKernelGGL((rnde_stage_attempt_mt_kernel<0, 2, 1>), grid2, dim3(64 * 7), xlds2, s, Q, n, Y, (const void*)h->x3B, (const void*)h->x3D);
+                return hipGetLastError();
+            }
             const size_t lds2 = sizeof(float) * (2 * 2 * 16 * (16 * 7 + 4) + 32 * 3);
-            if (h->act2) hipLaunchKernelGGL((rnde_stage_attempt_mt_kernel<1, 2>), grid2, dim3(64 * 7), lds2, s, Q, n, Y);
-            else hipLaunchKernelGGL((rnde_stage_attempt_mt_kernel<0, 2>), grid2, dim3(64 * 7), lds2, s, Q, n, Y);
+            if (h->act2) hipLaunchKernelGGL((rnde_stage_attempt_mt_kernel<1, 2>), grid2, dim3(64 * 7), lds2, s, Q, n, Y, (const void*)nullptr, (const void*)nullptr);
+            else hipLaunchKernelGGL((rnde_stage_attempt_mt_kernel<0, 2>), grid2, dim3(64 * 7), lds2, s, Q, n, Y, (const void*)nullptr, (const void*)nullptr);
             return hipGetLastError();
         }
         if (fix && h->x3_fwd) {      // matrix mode 1: the same instruction sequence as the x3 one-launch solve (bit-identical to it)

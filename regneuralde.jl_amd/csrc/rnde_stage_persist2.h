@@ -26,15 +26,21 @@ constexpr int kPersist2MinTiles = 64;      // B >= 1024: below that one tile per
 // attempt at B = 4096, profiles/r03_attempt_ablation.csv) disappears behind useful work.  (Two other schedules were measured in round 3 and are kept
 // under tools/experiments/stage_layouts/: lock step, 180 us against 178, and skewed -- one tile's MFMA step beside the other's element-wise step --,
 // 187 us: with fp32 operands the matrix pipe and the vector ALU of a SIMD do not run in the same cycle)
-template <int ACT2, int NCT>
-__global__ __launch_bounds__(64 * 7) void rnde_stage_attempt_mt_kernel(const StageParams Q, const int n, const PersistSync Y) {
+// X3 = 1: the Dense-layer products on the matrix cores (rnde_x3.h) -- the same instruction sequence per tile as rnde_stage_attempt_kernel<.., 1, 1> and the x3
+// one-launch solve, hence bit-identical to them.  Here the split pays twice: the matrix instructions of one tile no longer occupy the vector ALUs the
+// other tile's tanh / combinations need.
+template <int ACT2, int NCT, int X3 = 0>
+__global__ __launch_bounds__(64 * 7) void rnde_stage_attempt_mt_kernel(const StageParams Q, const int n, const PersistSync Y, const void* x3B = nullptr, const void* x3D = nullptr) {
     const StepParams& P = Q.F;
     constexpr int gWT = 7, gHT = 7, gK2b = 7, gMT = 49, gR = 7, gD = 784, gH = 100;
     constexpr int KH = 16 * gK2b + 4, KG = 16 * gWT + 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* HL = smem;                            // [NCT][16][KH]
-    float* GL = HL + NCT * kSCB * KH;            // [NCT][16][KG]
-    float* RED = GL + NCT * kSCB * KG;           // [NCT][32]; RED[24] = "a wave gave up"
+    float* HL = smem;                            // [NCT][16][KH]   (X3: [NCT] operand images of bf16 planes, rnde_x3.h)
+    float* GL = HL + NCT * (X3 ? kX3ImageFloats : kSCB * KH);            // [NCT][16][KG]
+    float* RED = GL + NCT * (X3 ? kX3ImageFloats : kSCB * KG);           // [NCT][32]; RED[24] = "a wave gave up"
+    unsigned short* HX = (unsigned short*)HL;
+    unsigned short* GX = (unsigned short*)GL;
+    constexpr int kImgShorts = 2 * kX3ImageFloats;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     __builtin_assume(w >= 0 && w < 7);
@@ -91,7 +97,21 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_attempt_mt_kernel(const Sta
     unsigned long long aD = (unsigned long long)(Q.pwD + ((size_t)w * gMT + rb * gWT) * 64 + lane);
     unsigned long long aB4 = aB + 4 * 1024, aD4 = aD + 4 * 1024;
     asm volatile("" : "+v"(aB), "+v"(aD), "+v"(aB4), "+v"(aD4));
-    f32x4 wB[7], wD[7];
+    f32x4 wB[X3 ? 1 : 7], wD[X3 ? 1 : 7];
+    x3u4 xB[X3 ? 4 : 1][3], xD[X3 ? 4 : 1][3];
+    if constexpr (X3) {
+        typedef const __attribute__((address_space(1))) x3u4* gx4;
+        unsigned long long bD = (unsigned long long)((const x3u4*)x3D + ((size_t)(w * gR + rb) * 4 * 3) * 64 + lane);
+        unsigned long long bB = (unsigned long long)((const x3u4*)x3B + ((size_t)T * 4 * 3) * 64 + lane);
+        unsigned long long bD1 = bD + 4 * 1024, bD2 = bD + 8 * 1024, bB1 = bB + 4 * 1024, bB2 = bB + 8 * 1024;
+        asm volatile("" : "+v"(bD), "+v"(bB), "+v"(bD1), "+v"(bD2), "+v"(bB1), "+v"(bB2));
+#pragma unroll
+        for (int f = 0; f < 12; ++f) xD[f / 3][f % 3] = f < 4 ? ((gx4)bD)[(size_t)f * 64] : (f < 8 ? ((gx4)bD1)[(size_t)(f - 4) * 64] : ((gx4)bD2)[(size_t)(f - 8) * 64]);
+#pragma unroll
+        for (int f = 0; f < 12; ++f) xB[f / 3][f % 3] = f < 4 ? ((gx4)bB)[(size_t)f * 64] : (f < 8 ? ((gx4)bB1)[(size_t)(f - 4) * 64] : ((gx4)bB2)[(size_t)(f - 8) * 64]);
+        // k-values 112 .. 135 of every (image, plane, column) row are written by nobody: zeroed (only those: no barrier before START's x3_store4)
+        for (int i = tid; i < 2 * NCT * 3 * 16 * 12; i += 64 * 7) ((unsigned*)HL)[(i / 12) * (kX3K / 2) + 56 + i % 12] = 0u;
+    } else {
 #pragma unroll
     for (int kb = 0; kb < 7; ++kb) wD[kb] = kb < 4 ? ((gw4)aD)[(size_t)kb * 64] : ((gw4)aD4)[(size_t)(kb - 4) * 64];
 #pragma unroll
@@ -101,6 +121,7 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_attempt_mt_kernel(const Sta
             const f32x2 lo = *(gw2)(aB4 + 2 * 1024);
             wB[kb] = (f32x4){lo.x, lo.y, 0.f, 0.f};
         } else wB[kb] = kb < 4 ? ((gw4)aB)[(size_t)kb * 64] : ((gw4)aB4)[(size_t)(kb - 4) * 64];
+    }
     }
 
     // ---- controller (identical to SM_START) ----
@@ -163,6 +184,17 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_attempt_mt_kernel(const Sta
     // phase D for all tiles: this row block's layer-1 partials of the stage inputs v[tt] -> slab, exchange number `ex`
     auto phase_d = [&](const f32x4 (&v)[NCT], unsigned ex, auto t0c, auto t1c) {
         constexpr int T0 = decltype(t0c)::value, T1 = decltype(t1c)::value;
+        if constexpr (X3) {
+#pragma unroll
+            for (int tt = T0; tt < T1; ++tt) x3_store4(GX + tt * kImgShorts, col, hr0, v[tt]);
+            __syncthreads();
+#pragma unroll
+            for (int tt = T0; tt < T1; ++tt) {
+                const size_t tile0x = (((size_t)slab_buf(ex) * Q.C + ct[tt]) * gR + rb) * gHT;
+                slab_put(Y.tslab, tile0x + w, lane, x3_tile<4>(xD, GX + tt * kImgShorts, lane));
+            }
+            return;
+        }
 #pragma unroll
         for (int tt = T0; tt < T1; ++tt) {
             float* gl = GL + tt * kSCB * KG + own_gl0;
@@ -238,16 +270,28 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_attempt_mt_kernel(const Sta
                 for (int i = 0; i < 4; ++i) hv[i] = own_kind[i] == 0 ? hv[i] : fmaf(own_c1[i], ts, own_c0[i]);
             }
             if (own_hstore) *(f32x4*)(hdst + (size_t)gcol[tt] * gH + hr0) = hv;
-            float* hl = HL + tt * kSCB * KH + own_hl0;
+            if constexpr (X3) x3_store4(HX + tt * kImgShorts, col, hr0, hv);
+            else {
+                float* hl = HL + tt * kSCB * KH + own_hl0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) hl[4 * i] = hv[i];
+                for (int i = 0; i < 4; ++i) hl[4 * i] = hv[i];
+            }
         }
         if (dead && lane == 0) RED[24] = 1.f;
         __syncthreads();
         if (RED[24] != 0.f) { alive = false; return; }
         // ---- phase B ----
         f32x4 kv[NCT];
-        {
+        if constexpr (X3) {
+#pragma unroll
+            for (int tt = T0; tt < T1; ++tt) {
+                kv[tt] = x3_tile<4>(xB, HX + tt * kImgShorts, lane);
+                if (ACT2) {
+                    const f32x2 a01 = tanh_fast2((f32x2){kv[tt][0], kv[tt][1]}), a23 = tanh_fast2((f32x2){kv[tt][2], kv[tt][3]});
+                    kv[tt] = (f32x4){a01.x, a01.y, a23.x, a23.y};
+                }
+            }
+        } else {
             f32x4 acc0[NCT], acc1[NCT];
 #pragma unroll
             for (int tt = T0; tt < T1; ++tt) { acc0[tt] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[tt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }

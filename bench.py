@@ -30,10 +30,14 @@ D, H, NCLS = 784, 100, 10
 P_DYN = (D + 1) * H + H + (H + 1) * D + D          # 158,568
 ALG_BYTES = lambda B: 34 * 4 * D * B + 6 * 4 * P_DYN   # 34 A + 24 P per attempted step
 ALG_FLOPS = lambda B: 6 * 2 * B * ((D + 1) * H + (H + 1) * D)
+# matrix mode 1 (csrc/rnde_x3.h): flops the matrix cores actually execute per attempted step -- per 16-column tile and stage 49 row tiles x (4 + 4) k-steps of 32 x 6 terms,
+# each a 16 x 16 x 32 instruction (16,384 flop), six stages (the padding of 102 / 112 k-values to 128 and the sixfold split included: it is what the unit does)
+X3_MATRIX_FLOPS = lambda B: 6 * ((B + 15) // 16) * 49 * 8 * 6 * 16384
 HBM_PEAK_GBS = 8000.0                              # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3
-PROFILE_ROUND = "r05"        # profiles/<round>_pmc_hbm_traffic*.csv: the committed --pmc passes `traffic` is read from
-ABLATION_ROUND = "r04"       # profiles/<round>_attempt_ablation.csv: the forward attempt kernel's stages are unchanged since (round 5 moved the controller, not the stages)
+PROFILE_ROUND = "r06"        # profiles/<round>_pmc_hbm_traffic*.csv: the committed --pmc passes `traffic` is read from
+ABLATION_ROUND = "r04"       # profiles/<round>_attempt_ablation.csv: ablation of the fp32-input-MFMA attempt kernel (matrix mode 0); the default mode since round 6 runs the matrix cores
+MATRIX_BF16_PEAK_TF = 2500.0 # MI355X_MICROARCH.md: dense bf16 MFMA
 
 
 def quiet_gc():
@@ -756,14 +760,23 @@ def main():
                 "alg_bytes_per_attempt": ALG_BYTES(B), "alg_bytes_per_launch": ALG_BYTES(B) * (sum(atts) / len(atts)) if one_launch else ALG_BYTES(B) / nl,
                 "mfma_f32_tflops": ALG_FLOPS(B) / t_att / 1e12,
                 "mfma_frac": ALG_FLOPS(B) / t_att / 1e12 / MFMA_F32_PEAK_TF,
-                # which roof actually binds: the counters show 0.39 x the algorithmic bytes reaching HBM (the state lives in registers / L2), i.e. ~1 TB/s of
-                # real traffic -- the kernel is NOT memory bound.  It is bound by instruction issue on the vector / matrix ALUs (fp32 MFMA and VALU share the
-                # SIMD's issue slots on this part: SQ_VALU_MFMA_COEXEC_CYCLES = 0, profiles/r05_pmc_sq_attempt.csv).  `frac` above stays the north star's unit
-                # (algorithmic bytes against the HBM roof); the binding fraction is the fp32 matrix one.
-                "binding": {"bound": "mfma (issue: fp32 matrix + vector instructions share the SIMDs)", "achieved": ALG_FLOPS(B) / t_att / 1e12, "peak": MFMA_F32_PEAK_TF,
-                            "unit": "TFLOP/s", "frac": ALG_FLOPS(B) / t_att / 1e12 / MFMA_F32_PEAK_TF,
-                            "evidence": "profiles/r05_pmc_hbm_traffic.csv (HBM bytes per attempt 0.39 x algorithmic), profiles/r05_pmc_sq_attempt.csv (matrix pipe busy 32 %, "
-                                        "co-execution 0), profiles/r04_attempt_ablation.csv (MFMAs alone: 13.8 us of the 23.3)"}}
+                # Which roof actually binds.  HBM does not (0.39 x the algorithmic bytes reach it: the state lives in registers / L2).  Round 6 settled the unit question
+                # (profiles/r06_coexec_micro.csv): on gfx950 the fp32-input MFMA executes on the VECTOR ALUs (64 FLOP/clk/SIMD, no overlap with the vector instructions
+                # of any wave on its SIMD: two waves take the SUM of their times; the same pair with a bf16 MFMA takes the MAXIMUM and SQ_VALU_MFMA_COEXEC_CYCLES counts
+                # it) -- so matrix mode 0 was bound by that shared unit.  Matrix mode 1 (default: csrc/rnde_x3.h) forms every fp32 product from six bf16 matrix-core
+                # products: `binding` is then the stage's own critical path -- vector issue (two tanh per stage, the splitting) + the hand-off latency + the matrix
+                # pipe, which the lock-step of a workgroup's waves keeps from overlapping fully.  `frac` above stays the north star's unit.
+                "matrix_mode": int(L.rnde_node_matrix_mode(h.ptr)),
+                "binding": ({"bound": "stage critical path: vector issue + hand-off latency + matrix-core pipe (bf16x3, six v_mfma_f32_16x16x32_bf16 per 32 k-values)",
+                             "achieved": X3_MATRIX_FLOPS(B) / t_att / 1e12, "peak": MATRIX_BF16_PEAK_TF, "unit": "TFLOP/s (bf16 matrix-core flops actually issued)",
+                             "frac": X3_MATRIX_FLOPS(B) / t_att / 1e12 / MATRIX_BF16_PEAK_TF,
+                             "fp32_equivalent_tflops": ALG_FLOPS(B) / t_att / 1e12,
+                             "evidence": "profiles/r06_coexec_micro.csv (fp32 MFMA = vector-ALU instruction; bf16 MFMA co-executes), profiles/r06_attempt_stamps.txt (cycle stamps "
+                                         "of both matrix modes), profiles/r06_pmc_sq_attempt.csv"}
+                            if int(L.rnde_node_matrix_mode(h.ptr)) == 1 else
+                            {"bound": "fp32 vector ALUs (the fp32-input MFMA and the vector instructions share them: profiles/r06_coexec_micro.csv)", "achieved": ALG_FLOPS(B) / t_att / 1e12,
+                             "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": ALG_FLOPS(B) / t_att / 1e12 / MFMA_F32_PEAK_TF,
+                             "evidence": "profiles/r05_pmc_sq_attempt.csv (fp32 MFMA busy 32 %), profiles/r04_attempt_ablation.csv (MFMAs alone: 13.8 us of the 23.3)"})}
         # HBM traffic per launch of that kernel: PMC counters cannot be collected from inside the bench; the committed separate
         # passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same command, corrected as MI355X_MICROARCH.md prescribes) are
         # reported when present, with their source.  `traffic` is per LAUNCH like `achieved`; the one-launch solve's launch holds
@@ -789,7 +802,7 @@ def main():
                 if row["variant"] == "mfmaonly" and int(row["B"]) == B:
                     roof["ceiling_us"] = float(row["us_taped"])
                     roof["ceiling_frac"] = ALG_BYTES(B) / (roof["ceiling_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
-                    roof["ceiling_source"] = "profiles/" + ABLATION_ROUND + "_attempt_ablation.csv: the kernel's MFMAs alone (operands in registers, no polls / tanh / LDS / tape), same launch geometry, back to back"
+                    roof["ceiling_source"] = "profiles/" + ABLATION_ROUND + "_attempt_ablation.csv: the fp32-input-MFMA attempt kernel's MFMAs alone (matrix mode 0: operands in registers, no polls / tanh / LDS / tape), same launch geometry, back to back -- NOT a bound of matrix mode 1, whose products run on the matrix cores"
         except Exception:
             pass
         out = {"metric": "training-step samples/sec + mean NFE, MNIST Neural ODE bs=512",

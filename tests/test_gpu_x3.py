@@ -173,3 +173,53 @@ def test_x3_attempt_kernel_serves_saveat_against_the_fp64_restatement():
     r64 = o64.forward(x.astype(np.float64), p.astype(np.float64), saveat=sa.astype(np.float64))
     assert got["u"].shape == r64["u"].shape and _rel(got["u"], r64["u"]) <= 5e-6
     node.close()
+
+
+# ---------------------------------------------------------------- the oracle's MIRROR of matrix mode 1 (Oracle(sum_order=7), oracle/rnde_oracle.c f_col_stage_x3)
+def test_x3_attempt_equals_the_oracles_mirror_almost_bit_for_bit():
+    """One attempted step (six f evaluations) from the same (uprev, k1, t, dt): the device in matrix mode 1 against the oracle restating it -- operands split
+    into three bf16 numbers, six cross products per fp32 product, every v_mfma_f32_16x16x32_bf16 as four exact 8-term sums added with a rounding each (the model
+    tools/micro/mfma_bf16_numerics.hip fits to raw matrix-core output), four accumulators added smallest first, the device's tanh.  >= 85 % of the k entries
+    bit-equal (the fp32-MFMA order: far fewer), every entry within 2e-7, EEst within 5 %."""
+    from tests.util import Node, Oracle
+    arch, p, x, _ = _problem(64, 3)
+    rng = np.random.default_rng(8)
+    k1 = np.tanh(rng.standard_normal((64, 784))).astype(np.float32)
+    node = Node(_cfg(64, regularize=1), matrix_mode=1)
+    kd, ud, ed = node.attempt(x, k1, p, 0.2, 0.03)
+    res = {}
+    for so in (3, 7):
+        ko, uo, eo, _ = Oracle(arch, np.float32, TOL, TOL, reg_kind=1, sum_order=so).attempt(p, x, k1, 0.2, 0.03)
+        res[so] = (float(np.mean(kd == ko)), float(np.abs(kd - ko).max()), float(np.mean(ud == uo)), eo)
+    print(f"attempt, k entries bit-equal to the device (matrix mode 1): oracle in the fp32-MFMA order {res[3][0]:.3f} (max diff {res[3][1]:.2e}), oracle mirror of mode 1 "
+          f"{res[7][0]:.3f} (max diff {res[7][1]:.2e}); u_new bit-equal {res[7][2]:.3f}; EEst device {ed:.4f} mirror {res[7][3]:.4f} fp32-order {res[3][3]:.4f}")
+    assert res[7][0] >= 0.85 and res[7][1] <= 2e-7 and res[7][0] > res[3][0] + 0.3
+    assert abs(ed / res[7][3] - 1) <= 0.05
+    node.close()
+
+
+def test_x3_natural_run_attempts_equal_the_oracles_mirror():
+    """NFE parity of the DEFAULT matrix mode at the reference tolerance as an equality: natural runs, device (mode 1) vs Oracle(sum_order=7), B = 64 over 16
+    seeds and B = 512 over 2 -- the same number of attempts (+-1 allowed), the same accept / reject pattern, step sizes and per-attempt EEst close, u_end to 3e-6
+    (the statement tests/test_gpu_replay.py::test_natural_run_attempts_equal_the_device_order_oracle makes for mode 0)."""
+    from tests.util import Node, Oracle
+    for B, seeds, dt_tol, ee_tol in ((64, range(100, 116), 0.15, 0.15), (512, (11, 12), 0.02, 0.04)):
+        node = Node(_cfg(B, regularize=1), matrix_mode=1)
+        worst_dt = worst_ee = 0.0
+        diff = []
+        for seed in seeds:
+            arch, p, x, _ = _problem(B, seed)
+            o7 = Oracle(arch, np.float32, TOL, TOL, reg_kind=1, max_attempts=200, sum_order=7)
+            r7 = o7.forward(x, p)
+            se = o7.steps_ext()
+            g = node.forward(x, p)
+            diff.append(g["nattempts"] - r7["nattempts"])
+            assert abs(diff[-1]) <= 1, (B, seed, g["nattempts"], r7["nattempts"])
+            n = min(g["nattempts"], r7["nattempts"])
+            assert np.array_equal(g["steps"][:n, 3].astype(np.int32), se[:n, 4].astype(np.int32))
+            worst_dt = max(worst_dt, float(np.abs(g["steps"][:n, 1] / se[:n, 1] - 1).max()))
+            worst_ee = max(worst_ee, float(np.abs(g["steps"][:n, 2] / se[:n, 3] - 1).max()))
+            assert _rel(g["u"], r7["u"]) <= 3e-6
+        print(f"B = {B}: device (matrix mode 1) - oracle mirror attempts over {len(diff)} seeds: {diff}; worst |dt ratio - 1| {worst_dt:.2e}, worst |EEst ratio - 1| {worst_ee:.2e}")
+        assert worst_dt <= dt_tol and worst_ee <= ee_tol
+        node.close()

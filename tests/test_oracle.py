@@ -562,3 +562,34 @@ def test_pi_controller_is_hairers_dopri5_form():
         hairer_rej = 1.0 / min(facc1, fac11 / safe)
         assert abs(hairer_acc - max(MIN_FACTOR, min(MAX_FACTOR, SAFETY * err ** -0.2))) < 1e-12
         assert abs(hairer_rej - max(MIN_FACTOR, SAFETY * err ** -0.2)) < 1e-12
+
+
+def test_oracle_mirror_of_matrix_mode_1_is_the_same_function_closer_to_fp64():
+    """Oracle(sum_order=7) restates the device's matrix mode 1 (csrc/rnde_x3.h): fp32 operands split EXACTLY into three bf16 numbers, the six leading cross products,
+    each 32-term matrix instruction as four exact 8-term sums added with a rounding each.  (a) the split is exact; (b) the mode is the same function as the others to
+    fp32 rounding; (c) it is CLOSER to the fp64 evaluation than the fp32-MFMA order (sum_order 3), which is closer than the sequential order (0): fewer roundings
+    per dot product; (d) hence fewer attempted steps at the reference tolerance, the ordering fp64 < mode 1 < fp32-MFMA order < sequential."""
+    import ctypes as C
+    arch = arch_mnist(784, 100)
+    rng = np.random.default_rng(2)
+    p = glorot_params(arch, rng, np.float32, 1.0)
+    x = rng.uniform(0, 1, (24, 784)).astype(np.float32)
+    # (a) x == hi + mid + lo exactly, each part a bf16 number (its low 16 bits are zero)
+    def bf16(v):
+        u = v.astype(np.float32).view(np.uint32).astype(np.uint64)
+        u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+        return u.astype(np.uint32).view(np.float32)
+    v = np.concatenate([p[:5000], x.reshape(-1)[:5000], (rng.standard_normal(5000) * 1e-6).astype(np.float32)])
+    hi = bf16(v); r1 = (v - hi).astype(np.float32); mid = bf16(r1); lo = (r1 - mid).astype(np.float32)
+    assert np.array_equal(hi.astype(np.float64) + mid.astype(np.float64) + lo.astype(np.float64), v.astype(np.float64))
+    assert np.array_equal(lo, bf16(lo))
+    # (b), (c)
+    f64 = Oracle(arch, np.float64).f_eval(p.astype(np.float64), x.astype(np.float64), 0.3)
+    err = {so: float(np.abs(Oracle(arch, np.float32, sum_order=so).f_eval(p, x, 0.3) - f64).max() / np.abs(f64).max()) for so in (0, 3, 7)}
+    print("f evaluation vs fp64:", err)
+    assert err[7] <= 3e-7 and err[7] < err[3] < err[0]
+    # (d)
+    att = {so: Oracle(arch, np.float32, 1.4e-8, 1.4e-8, reg_kind=1, max_attempts=200, sum_order=so).forward(x, p)["nattempts"] for so in (0, 3, 7)}
+    a64 = Oracle(arch, np.float64, 1.4e-8, 1.4e-8, reg_kind=1, max_attempts=200).forward(x.astype(np.float64), p.astype(np.float64))["nattempts"]
+    print("attempts at tol 1.4e-8:", att, "fp64", a64)
+    assert a64 < att[7] < att[3] < att[0]

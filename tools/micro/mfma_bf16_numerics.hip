@@ -64,40 +64,56 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(k, dim3(64), dim3(64), 0, 0, dA, dB, dC, dD, ncase);
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(D.data(), dD, D.size() * 4, hipMemcpyDeviceToHost));
-    const char* names[] = {"EXACT1", "EXACT1_TZ", "CHAIN", "HALVES", "QUADS", "ALIGN_T"};
-    long match[6] = {0, 0, 0, 0, 0, 0}, total = 0;
+    // candidate models: a list of k-groups; each group's products are summed exactly, the group sums are added to the running value in list order with one fp32
+    // rounding each (mode 0: to nearest even, mode 1: toward zero); "tree" variants add the group sums to each other first (exactly or rounded), then to C
+    struct Model { const char* name; int ngroups; int gsize; int layout; int rz; int tree; };
+    // layout 0: group q = k in [gsize q, gsize (q + 1)); layout 1 (two passes of a K = 16 instruction): pass h = 0, 1, lane group g = 0..3: k = 8 g + 4 h + j, j < 4, groups in (h, g) order;
+    // layout 2: the same groups in (g, h) order
+    const Model models[] = {
+        {"EXACT1 (32 exact, one rounding)", 1, 32, 0, 0, 0}, {"EXACT1 toward zero", 1, 32, 0, 1, 0}, {"CHAIN (32 fma)", 32, 1, 0, 0, 0}, {"HALVES (2 x 16 exact)", 2, 16, 0, 0, 0},
+        {"QUADS (4 x 8 exact, sequential)", 4, 8, 0, 0, 0}, {"QUADS toward zero", 4, 8, 0, 1, 0}, {"OCTS (8 x 4 exact, sequential)", 8, 4, 0, 0, 0},
+        {"P2G4 (2 passes x 4 lane groups of 4)", 8, 4, 1, 0, 0}, {"G4P2 (4 lane groups x 2 passes of 4)", 8, 4, 2, 0, 0},
+        {"P2x16 (2 passes, 16 exact each)", 2, 16, 1, 0, 0}, {"QUADS tree: exact quads, (q0+q1)+(q2+q3) rounded, + C", 4, 8, 0, 0, 1}, {"QUADS: quads summed exactly to fp32 first, then + C", 4, 8, 0, 0, 2},
+    };
+    const int nmodels = (int)(sizeof(models) / sizeof(models[0]));
+    std::vector<long> match(nmodels, 0);
+    long total = 0;
     double worst_exact = 0;
+    auto rnd = [&](long double v, int rz) { return rz ? rz32(v) : (float)v; };
     for (int n = 0; n < ncase; ++n)
         for (int r = 0; r < 16; ++r)
             for (int c = 0; c < 16; ++c) {
                 const float c0 = C[(size_t)n * 256 + r * 16 + c], d = D[(size_t)n * 256 + r * 16 + c];
                 long double p[32], sum = 0;
                 for (int kk = 0; kk < 32; ++kk) { p[kk] = (long double)bf2f(A[((size_t)n * 16 + r) * 32 + kk]) * (long double)bf2f(B[((size_t)n * 32 + kk) * 16 + c]); sum += p[kk]; }
-                float m[6];
-                m[0] = (float)((long double)c0 + sum);
-                m[1] = rz32((long double)c0 + sum);
-                { float t = c0; for (int kk = 0; kk < 32; ++kk) t = fmaf(bf2f(A[((size_t)n * 16 + r) * 32 + kk]), bf2f(B[((size_t)n * 32 + kk) * 16 + c]), t); m[2] = t; }
-                { long double h0 = 0, h1 = 0; for (int kk = 0; kk < 16; ++kk) { h0 += p[kk]; h1 += p[16 + kk]; } float t = (float)((long double)c0 + h0); m[3] = (float)((long double)t + h1); }
-                { float t = c0; for (int q = 0; q < 4; ++q) { long double s = 0; for (int j = 0; j < 8; ++j) s += p[8 * q + j]; t = (float)((long double)t + s); } m[4] = t; }
-                {   // aligned truncation: every addend (C included) cut below 2^(emax - 27) before the exact sum
-                    int emax = -1000, e;
-                    if (c0 != 0.f) { frexpf(c0, &e); emax = e; }
-                    for (int kk = 0; kk < 32; ++kk) if (p[kk] != 0) { frexpl(p[kk], &e); if (e > emax) emax = e; }
-                    const long double q = ldexpl(1.0L, emax - 27);
-                    long double s = truncl((long double)c0 / q) * q;
-                    for (int kk = 0; kk < 32; ++kk) s += truncl(p[kk] / q) * q;
-                    m[5] = (float)s;
+                for (int mi = 0; mi < nmodels; ++mi) {
+                    const Model& M = models[mi];
+                    long double gs[32];
+                    for (int q = 0; q < M.ngroups; ++q) {
+                        gs[q] = 0;
+                        for (int j = 0; j < M.gsize; ++j) {
+                            int k;
+                            if (M.layout == 0) k = M.gsize * q + j;
+                            else if (M.gsize == 4) { const int h = M.layout == 1 ? q / 4 : q % 2, g = M.layout == 1 ? q % 4 : q / 2; k = 8 * g + 4 * h + j; }
+                            else { const int h = q; k = 8 * (j / 4) + 4 * h + (j % 4); }      // 16 per pass: lane groups g = j / 4
+                            gs[q] += p[k];
+                        }
+                    }
+                    float t;
+                    if (M.tree == 0) { t = c0; for (int q = 0; q < M.ngroups; ++q) t = rnd((long double)t + gs[q], M.rz); }
+                    else if (M.tree == 1) { const float a = (float)(gs[0] + gs[1]), b = (float)(gs[2] + gs[3]); t = (float)((long double)c0 + (long double)(float)((long double)a + (long double)b)); }
+                    else { const float a = (float)(gs[0] + gs[1] + gs[2] + gs[3]); t = (float)((long double)c0 + (long double)a); }
+                    match[mi] += memcmp(&t, &d, 4) == 0;
                 }
-                for (int i = 0; i < 6; ++i) match[i] += memcmp(&m[i], &d, 4) == 0;
                 const double ex = (double)((long double)c0 + sum);
                 if (ex != 0) worst_exact = fmax(worst_exact, fabs((double)d - ex) / fmax(fabs(ex), 1e-30));
                 ++total;
             }
     FILE* csv = argc > 1 ? fopen(argv[1], "w") : nullptr;
     if (csv) fprintf(csv, "model,bit_equal,total,fraction\n");
-    for (int i = 0; i < 6; ++i) {
-        printf("%-10s %7ld / %ld bit-equal (%.2f %%)\n", names[i], match[i], total, 100.0 * match[i] / total);
-        if (csv) fprintf(csv, "%s,%ld,%ld,%.5f\n", names[i], match[i], total, (double)match[i] / total);
+    for (int i = 0; i < nmodels; ++i) {
+        printf("%-60s %7ld / %ld bit-equal (%.2f %%)\n", models[i].name, match[i], total, 100.0 * match[i] / total);
+        if (csv) fprintf(csv, "\"%s\",%ld,%ld,%.5f\n", models[i].name, match[i], total, (double)match[i] / total);
     }
     printf("largest |device - exact| / |exact| = %.3e (2^-24 = 5.96e-8)\n", worst_exact);
     if (csv) fclose(csv);

@@ -142,6 +142,20 @@ def main3():
               "bytes", os.path.getsize(os.path.join(HERE, name + ".npz")))
 
 
+def main5():
+    """Round 6: the same natural run as the device's DEFAULT matrix mode computes it -- Oracle(sum_order=7), the mirror of csrc/rnde_x3.h (operands split exactly into
+    three bf16 numbers, six cross products, each matrix instruction as four exact 8-term sums).  Stored beside the fp32-MFMA-order and sequential counts."""
+    for name in DEVORDER_CASES:
+        arch, p, x, tol = devorder_inputs(name)
+        r = Oracle(arch, np.float32, reltol=tol, abstol=tol, reg_kind=1, max_attempts=96, sum_order=7).forward(x, p)
+        o3 = Oracle(arch, np.float32, reltol=tol, abstol=tol, reg_kind=1, max_attempts=96, sum_order=3).forward(x, p)
+        o64 = Oracle(arch, np.float64, reltol=tol, abstol=tol, reg_kind=1, max_attempts=96).forward(x, p)
+        assert r["rc"] == 0
+        out = name.replace("devorder", "x3")
+        np.savez_compressed(os.path.join(HERE, out + ".npz"), u_x3=r["u"], nfe_x3=r["nfe"], steps_x3=r["steps"], saveval_x3=r["saveval"], nfe_devorder=o3["nfe"], u_f64=o64["u"])
+        print(out, "attempts: matrix mode 1", r["nattempts"], "fp32-MFMA order", o3["nattempts"], "fp64", o64["nattempts"], "bytes", os.path.getsize(os.path.join(HERE, out + ".npz")))
+
+
 def main2():
     from oracle.oracle_sde import SdeOracle
     for name in NSDE_CASES:
@@ -204,6 +218,9 @@ def main4():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "stiff":          # only the round-5 fixtures
         main4()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "x3":            # only the round-6 fixture
+        main5()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "devorder":      # only the round-3 fixture (the older ones stay byte-identical in git)
         main3()

@@ -205,3 +205,24 @@ def test_device_vs_julia_if_present():
             assert np.abs(got["u"].reshape(-1) - ref["u"]).max() <= 1e-5 * max(1.0, np.abs(ref["u"]).max()), name
             checked += 1
     assert checked > 0, "tests/golden/julia/ holds no case this test knows"
+
+
+def test_device_default_matrix_mode_matches_the_x3_golden():
+    """The committed fixture of the oracle's mirror of matrix mode 1 (tests/golden/mnist_B16_reftol_x3.npz, make_golden.py main5): the device in its DEFAULT mode takes
+    the same number of attempts (+-1), the same accept pattern, steps within 20 %, u_end to 3e-6 of the fp64 fixture -- and fewer attempts than the fp32-MFMA order."""
+    from tests.golden.make_golden import DEVORDER_CASES, devorder_inputs
+    from tests.test_gpu_forward import _cfg
+    from tests.util import Node
+    for name in DEVORDER_CASES:
+        arch, p, x, tol = devorder_inputs(name)
+        g = np.load(os.path.join(GOLD, name.replace("devorder", "x3") + ".npz"))
+        node = Node(_cfg(arch, x.shape[0], reltol=tol, abstol=tol, max_attempts=96), matrix_mode=1)
+        got = node.forward(x.astype(np.float32), p.astype(np.float32))
+        ng = len(g["steps_x3"])
+        assert abs(got["nattempts"] - ng) <= 1 and got["nfe"] == 3 + 6 * got["nattempts"] and got["nfe"] < int(g["nfe_devorder"])
+        n = min(ng, got["nattempts"])
+        assert np.array_equal(got["steps"][:n, 3], g["steps_x3"][:n, 3])
+        np.testing.assert_allclose(got["steps"][:n, 1], g["steps_x3"][:n, 1], rtol=0.2)
+        assert np.abs(got["u"] - g["u_f64"]).max() <= 3e-6 * max(1.0, np.abs(g["u_f64"]).max())
+        assert abs(got["saveval"].sum() / g["saveval_x3"].sum() - 1) <= 0.05
+        node.close()

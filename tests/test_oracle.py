@@ -593,3 +593,16 @@ def test_oracle_mirror_of_matrix_mode_1_is_the_same_function_closer_to_fp64():
     a64 = Oracle(arch, np.float64, 1.4e-8, 1.4e-8, reg_kind=1, max_attempts=200).forward(x.astype(np.float64), p.astype(np.float64))["nattempts"]
     print("attempts at tol 1.4e-8:", att, "fp64", a64)
     assert a64 < att[7] < att[3] < att[0]
+
+
+def test_oracle_reproduces_matrix_mode_1_golden():
+    """tests/golden/mnist_B16_reftol_x3.npz: the natural run at the reference tolerance as the device's default matrix mode computes it (Oracle(sum_order=7))."""
+    from tests.golden.make_golden import DEVORDER_CASES, devorder_inputs
+    for name in DEVORDER_CASES:
+        arch, p, x, tol = devorder_inputs(name)
+        g = np.load(os.path.join(GOLD, name.replace("devorder", "x3") + ".npz"))
+        r = Oracle(arch, np.float32, reltol=tol, abstol=tol, reg_kind=1, max_attempts=96, sum_order=7).forward(x, p)
+        assert r["nfe"] == int(g["nfe_x3"]) < int(g["nfe_devorder"])
+        assert np.array_equal(r["steps"][:, 3], g["steps_x3"][:, 3])
+        np.testing.assert_allclose(r["steps"][:, :3], g["steps_x3"][:, :3], rtol=2e-3)
+        assert np.abs(r["u"] - g["u_x3"]).max() <= 1e-6

@@ -10,8 +10,8 @@
 // xl = x - xh - xm (rounding to nearest at each level leaves a remainder of at most 16, then 8 significant bits: representable).  A product of two
 // such sums has nine exact bf16 x bf16 terms; the six of weight >= 2^-16 relative to the leading one (hh, hm, mh, mm, hl, lh) carry the fp32 product
 // to 2^-24: the same accuracy class as an fp32 multiply.  Each term is one v_mfma_f32_16x16x32_bf16 (K = 32 per instruction, products exact in
-// fp32, accumulation in fp32).  Accumulated smallest terms first, a K = 784 dot product of Glorot weights against [0, 1) data comes out 1.9e-7 from
-// fp64 where the fp32 MFMA's k-ordered FMA chain is 1.0e-6 (numpy model of this scheme, /tools/x3_model.py): the emulation is MORE accurate than
+// fp32, accumulation in fp32).  Accumulated smallest terms first, a K = 784 dot product of Glorot weights against [0, 1) data comes out 3.3e-7 from
+// fp64 where the fp32 MFMA's k-ordered FMA chain is 1.1e-6 (largest error over the largest result; rms 1.5e-7 against 5.2e-7; numpy model of this scheme, tools/x3_model.py): the emulation is MORE accurate than
 // the instruction it replaces, because 25 block accumulations replace 784 roundings.
 // Cost per 32 k-values of a 16 x 16 tile: 6 matrix-core instructions of 16 cycles = 96 cycles, against 8 fp32 MFMAs of 32 cycles = 256 on the
 // vector ALUs -- and the element-wise work (tanh, stage combinations, the splitting itself) now runs BESIDE them.

@@ -3,6 +3,8 @@
 Only truncation-dominated regimes are compared element-wise (identical accept/reject sequences, see
 test_gpu_forward.py); tolerance: 2e-3 of the largest gradient entry (fp32 accumulation over
 ~10^2 evaluations x batch in a different association order), fp64 oracle as arbiter."""
+import os
+
 import numpy as np
 import pytest
 
@@ -178,6 +180,30 @@ def test_stiffness_regulariser_matches_oracle(kind, B, tol, scale, seed, reg, ag
     print(f"reg {reg}/{agg} {kind}: x-bar {rel_err(xb, xb64):.2e} (oracle f32 {cx:.2e})  p-bar {rel_err(pb, pb64):.2e} (oracle f32 {cp:.2e})")
     assert rel_err(xb, xb64) <= 3e-3 + 3 * cx
     assert rel_err(pb, pb64) <= 3e-3 + 3 * cp
+
+
+def test_stiffness_gradient_at_trained_like_weights_is_bounded():
+    """Round-5 review, item 7 (reference experiments/mnist_node.jl:70-81: `stiff_est`, lambda 0.1, `maximum`).  The Glorot-init test above says little about
+    where the regulariser acts: after 24 optimiser steps of the reference loop on the synthetic set the dynamics have stiffened (max |eigen_est| / 3.5068 = 1.6,
+    38 attempts) and the term's gradient is the large, noisy object DESIGN.md 7 describes.  There: d(lambda * max_n |eigen_est_n| / 3.5068) / dp of the device
+    against the fp64 oracle replaying the device's own step sequence, per parameter block, largest deviation over the block's largest fp64 entry.
+    STATED BOUND: every block <= 8e-2 (measured 2.5e-2 .. 3.6e-2, profiles/r06_stiff_grad_trained.json) AND no worse than 1.5 x the deviation of the oracle's
+    own fp32 build (measured 9.8e-2 .. 2.4e-1: the device is 3 - 6 x closer), cosine with the fp64 gradient >= 0.999 (0.99975)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sp = importlib.util.spec_from_file_location("stiff_grad_trained", os.path.join(root, "tools", "stiff_grad_trained.py"))
+    sg = importlib.util.module_from_spec(sp)
+    sp.loader.exec_module(sg)
+    p2, x = sg.weights_after(24)
+    r = sg.reg_gradient_check(p2, x, 600)
+    dev, o32 = r["device_vs_fp64"], r["oracle_f32_vs_fp64"]
+    print(f"attempts {r['attempts']}, max saved value {r['saveval_max_fp64']:.3f}; device vs fp64 " + "  ".join(f"{k} {v['rel_max']:.2e}" for k, v in dev.items())
+          + " | fp32 oracle vs fp64 " + "  ".join(f"{k} {v['rel_max']:.2e}" for k, v in o32.items()) + f" | cos {dev['all']['cos']:.6f}")
+    assert r["saveval_max_fp64"] > r["init_value"] * 2      # the dynamics have stiffened: `maximum` selects a step, not the initial constant
+    for name in ("W1", "b1", "W2", "b2"):
+        assert dev[name]["rel_max"] <= 8e-2, (name, dev[name])
+        assert dev[name]["rel_max"] <= 1.5 * o32[name]["rel_max"] + 1e-3, (name, dev[name], o32[name])
+    assert dev["all"]["cos"] >= 0.999
 
 
 def test_retired_column_owner_tiles_are_refused():

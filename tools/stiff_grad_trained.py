@@ -86,6 +86,28 @@ def reg_gradient_check(p2, x, max_attempts):
     return res
 
 
+def weights_after(steps, batches=24, max_attempts=600):
+    """The dynamics' parameters after `steps` optimiser steps of the stiff_est loop (lambda 0.1, `maximum`; the first steps of main()'s run), and the batch the next
+    step would see -- the state tests/test_gpu_backward.py::test_stiffness_gradient_at_trained_like_weights_is_bounded measures the gradient at."""
+    import regneuralde_jl_amd as rn
+    from tools.train_synth import batches_of, synthetic_set
+    dev = torch.device("cuda", 0)
+    tr, _, _ = synthetic_set(batches * BATCH, BATCH, 1999)
+    train = batches_of(*tr, dev)
+    g = torch.Generator().manual_seed(1999)
+    lam0, _, func, agg, solver = rn.REGULARISERS["stiff_est"]
+    node = rn.TrackedNeuralODE(rn.MLPDynamics(D, H, generator=g), [0.0, 1.0], True, True, solver, save_everystep=False, reltol=TOL, abstol=TOL, save_start=False,
+                               max_batch=BATCH, max_attempts=max_attempts)
+    model = rn.ClassifierNODE(node, rn.Dense(D, NCLS, "identity", generator=g), device=dev)
+    opt = rn.FluxOptimiser(model.trainable())
+    for step in range(steps):
+        xb, yb = train[step % len(train)]
+        rn.fused_loss_and_grad(model, xb, yb, lam=lam0, regularize=True, sync=True, func=func, agg=agg)
+        opt.step()
+    xb, _ = train[steps % len(train)]
+    return model.p2.detach().cpu().numpy().copy(), xb.reshape(BATCH, -1).cpu().numpy()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--marks", default="24,72", help="optimiser steps after which (a) is measured")

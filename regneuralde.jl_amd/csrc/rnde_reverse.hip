@@ -104,6 +104,28 @@ static rnde_status launch_wgrad_part(rnde_node* h, const EvalDesc* ev, int n_eva
         if ((size_t)(*chunk_cursor + sc) * (size_t)len > h->bw.slab_floats) { h->err = "weight-gradient slab overflow"; return RNDE_ERR_BAD_ARG; }
         // matrix mode 1 in effect for this step (the forward ran the x3 solve): the GEMMs on the matrix cores too (rnde_wgradx.h; RNDE_X3_WGRAD_OFF=1: A/B)
         static const bool x3_off = getenv("RNDE_X3_WGRAD_OFF") != nullptr;
+        static const bool x3_half = getenv("RNDE_X3_WGRAD_HALF") != nullptr;      // (A/B: the single-buffered half form)
+        const int TT4 = ((tall ? M : Nx + 2) + 15) / 16;
+        if (h->x3_packed && !x3_off && !x3_half && TT4 >= 28 && TT4 <= 52) {
+            // quarter form (rnde_wgrad4x_kernel): four workgroups per chunk, two LDS images; the launches underneath the sweep stay at 32 workgroups (8 chunks)
+            static const int target4 = getenv("RNDE_WGRAD4_CHUNKS") ? atoi(getenv("RNDE_WGRAD4_CHUNKS")) : 64;
+            int sc4 = std::max(1, std::min({max_chunks > 0 ? max_chunks / 2 : target4, total_steps, 256}));
+            const int spc4 = (total_steps + sc4 - 1) / sc4;
+            sc4 = (total_steps + spc4 - 1) / spc4;
+            if ((size_t)(*chunk_cursor + sc4) * (size_t)len > h->bw.slab_floats) { h->err = "weight-gradient slab overflow"; return RNDE_ERR_BAD_ARG; }
+            static DeviceOnce attr4;
+            if (attr4.need()) {
+                HIPCHK(h, hipFuncSetAttribute((const void*)rnde_wgrad4x_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWx4LdsBytes));
+                HIPCHK(h, hipFuncSetAttribute((const void*)rnde_wgrad4x_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWx4LdsBytes));
+                attr4.done();
+            }
+            const dim3 g4(32 * ((sc4 + 7) / 8));
+            if (tall) hipLaunchKernelGGL((rnde_wgrad4x_kernel<true>), g4, dim3(448), kWx4LdsBytes, s, ev, n_evals, spc4, sc4, M, Nx, Bpad, dst);
+            else hipLaunchKernelGGL((rnde_wgrad4x_kernel<false>), g4, dim3(448), kWx4LdsBytes, s, ev, n_evals, spc4, sc4, M, Nx, Bpad, dst);
+            HIPCHK(h, hipGetLastError());
+            *chunk_cursor += sc4;
+            return RNDE_OK;
+        }
         if (h->x3_packed && !x3_off) {
             static DeviceOnce attrx;
             if (attrx.need()) {

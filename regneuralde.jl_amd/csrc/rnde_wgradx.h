@@ -161,4 +161,184 @@ __global__ __launch_bounds__(448) void rnde_wgrad3x_kernel(const EvalDesc* __res
     }
 }
 
+// ---- the QUARTER form (round 6, second build): the half form above is single-buffered -- 120 KB of image per workgroup -- so the splitting of step s + 1 (vector
+// instructions, LDS writes) and the matrix instructions of step s take turns between two barriers: 12.5 k cycles per step where the matrix instructions need
+// 5.4 k (rocprof: 30-33 % matrix-pipe busy).  Here a workgroup owns a QUARTER of the wide side (<= 13 tiles of 16 rows) against the whole narrow side: the
+// image is 76.8 KB, TWO of them fit, step s + 1 is split and written while step s is multiplied (one barrier per step), the vector work of a wave sits between
+// its own matrix instructions and beside those of its SIMD partner.  Wave w owns wide tiles w and w + 7 (one pass over the narrow side, both tiles' A fragments
+// in registers); the narrow operand is split by four workgroups instead of two (+22 % vector work and L2 reads), the four parts of a chunk sit on ONE XCD
+// (linear workgroup id -> (xcd, chunk, part) below) so that its L2 serves three of those four reads.  Same six terms in the same order per 32 columns, same
+// per-chunk slabs and fixed-order reduction as the half form.
+#ifndef RNDE_WX4_SB
+#define RNDE_WX4_SB 1
+#endif
+#ifndef RNDE_WX4_ABL      // timing ablations (wrong results): 1 no splitting, 2 no splitting and no loads, 3 B fragments read once per step, 4 matrix instructions only
+#define RNDE_WX4_ABL 0
+#endif
+constexpr int kWx4TallRows = 208;
+constexpr int kWx4PlaneT = kWx4TallRows * kWxRowShorts, kWx4PlaneS = kWxNarrowRows * kWxRowShorts;
+constexpr int kWx4ImageShorts = 3 * (kWx4PlaneT + kWx4PlaneS);      // 38,400 bf16
+constexpr size_t kWx4LdsBytes = (size_t)2 * kWx4ImageShorts * 2;    // 153,600 bytes: two images
+
+template <bool TALL_IS_Z>
+__global__ __launch_bounds__(448) void rnde_wgrad4x_kernel(const EvalDesc* __restrict__ evals, int n_evals, int per_chunk, int n_chunks, int M, int Nx, int Bpad,
+                                                           float* __restrict__ slab) {
+    constexpr int KC = 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned short wxs[];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mrow = lane & 15, kk = lane >> 4;
+    // linear id -> XCD (round-robin dispatch: id % 8), then chunk-major inside the XCD: the four parts of a chunk are neighbours on one XCD
+    const int lin = blockIdx.x, xcd = lin & 7, within = lin >> 3;
+    const int chunk = (within >> 2) * 8 + xcd, part = within & 3;
+    if (chunk >= n_chunks) return;
+    const int TR = TALL_IS_Z ? M : Nx + 2, SR = TALL_IS_Z ? Nx + 2 : M;          // rows of the wide / narrow operand, synthetic {t, 1} rows included
+    const int TRp = TALL_IS_Z ? M : Nx, SRp = TALL_IS_Z ? Nx : M;                 // rows that exist in memory
+    const int TT = (TR + 15) >> 4, base = TT >> 2, rem = TT & 3;
+    const int ntile = base + (part < rem ? 1 : 0), tile_lo = part * base + (part < rem ? part : rem);      // <= 13 (host: TT <= 52)
+    const int row_lo = 16 * tile_lo, nrow = 16 * ntile;                                                      // <= 208
+    const int steps_per_eval = (Bpad + KC - 1) / KC;
+    const int s_lo = chunk * per_chunk, s_hi = min(n_evals * steps_per_eval, s_lo + per_chunk);
+    const int total_steps = max(0, s_hi - s_lo);
+    x3f4 acc[2][7];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int n = 0; n < 7; ++n) acc[i][n] = (x3f4){0.f, 0.f, 0.f, 0.f};
+    const bool has2 = w + 7 < ntile;                       // tile w always exists (host: every part >= 7 tiles)
+    const int tile1 = has2 ? w + 7 : w;                    // (a wave without a second tile multiplies its first one again and drops the result: no branch per matrix instruction)
+
+    // ---- units: FOUR consecutive rows x EIGHT consecutive columns of one operand per thread, i.e. eight 16-byte loads (one per column: the operands are
+    // rows-contiguous) where the half form issues 24 four-byte ones -- a wave's load instruction costs the texture path the same 16 cycles whatever its width.
+    // Waves 0..3 split the wide operand (unit = tid mod nrow: quad tid >> 2 of the part's rows, column octet tid & 3), waves 4..6 the narrow one (unit =
+    // (tid - 256) mod 112); which operand is WAVE-uniform (one buffer descriptor per wave, scalar selects), threads past the last unit repeat an earlier one
+    // (same source, destination and values): the loop body has no branch of either kind.  Lane -> (quad, octet) makes the 16 lanes of a b128 LDS write cover
+    // the 64 banks exactly once (row stride 80 bytes: bank 20 r; 4 rows of a quad apart 16 banks, octets 4 banks).  Rows past the operand's end are the
+    // synthetic {t, 1, 0, 0} quad or zeros: their loads are out of the descriptor's range (they return 0) and the values come from two per-thread constants.
+    constexpr unsigned kNoSrc = 0x7FFFFF00u;
+    const bool wide_wave = w < 4;
+    const int Rp = wide_wave ? TRp : SRp;                                        // rows of this wave's operand in memory = its column stride
+    const int nunit = wide_wave ? nrow : kWxNarrowRows;                          // 4 octets x (rows / 4) quads
+    const int uid = (wide_wave ? tid : tid - 256) % nunit;
+    const int uq = uid >> 2, uo = uid & 3;
+    const int u_gr = (wide_wave ? row_lo : 0) + 4 * uq;
+    const bool u_mem = u_gr < Rp;
+    const bool u_syn = u_gr == Rp && (wide_wave ? !TALL_IS_Z : TALL_IS_Z);     // the quad {t, 1, 0, 0}
+    const unsigned u_voff = u_mem ? 4u * (unsigned)(u_gr + 8 * uo * Rp) : kNoSrc;
+    const int u_dst = (wide_wave ? 0 : 3 * kWx4PlaneT) + 4 * uq * kWxRowShorts + 8 * uo;
+    const int u_ps = wide_wave ? kWx4PlaneT : kWx4PlaneS;
+    // (evaluation, 32-column step in it) of the next step to fetch; past the chunk's last step the last one is fetched again (harmless, never written to LDS)
+    int e_nx = s_lo / steps_per_eval, cs_nx = s_lo - e_nx * steps_per_eval, left = total_steps;
+    // two register sets: the set a step's splitting reads was requested a step and a half earlier (the operands are read once, cold from HBM: with ONE set,
+    // requested behind the splitting and consumed at the head of the next step, every step waited for memory)
+    x3f4 stg[2][8];
+    float stg_t[2] = {0.f, 0.f}; int stg_ncols[2] = {0, 0};
+    auto fetch = [&](auto set_c) {
+        constexpr int SET = decltype(set_c)::value;
+        const int e = e_nx, c0 = cs_nx * KC;
+        {   // (selects, not branches: the loop body stays one basic block)
+            const bool adv = --left > 0, wrap = cs_nx + 1 == steps_per_eval;
+            e_nx = (adv && wrap) ? e_nx + 1 : e_nx;
+            cs_nx = adv ? (wrap ? 0 : cs_nx + 1) : cs_nx;
+        }
+        stg_t[SET] = evals[e].t;
+        stg_ncols[SET] = min(KC, Bpad - c0);
+        const float* src = wide_wave == TALL_IS_Z ? evals[e].Z : evals[e].X;      // wide is Z for layer 2 (TALL_IS_Z), narrow is Z for layer 1
+        // descriptor over the WHOLE array (rows x Bpad floats): a column past Bpad is out of range and loads 0
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 4 * Rp * Bpad, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            stg[SET][j] = __builtin_bit_cast(x3f4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)u_voff, 4 * (c0 + j) * Rp, 0));      // (column through the scalar offset: no vector address arithmetic)
+    };
+    auto spill_row = [&](unsigned short* img, int i, auto set_c) {      // row i < 4 of the thread's quad: eight values -> three 16-byte plane entries
+        constexpr int SET = decltype(set_c)::value;
+        const int o8 = 8 * uo;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float sv = i == 0 ? stg_t[SET] : (i == 1 ? 1.f : 0.f);
+            v[j] = u_mem ? stg[SET][j][i] : ((i < 2 && u_syn && o8 + j < stg_ncols[SET]) ? sv : 0.f);
+        }
+        unsigned hi[4], mid[4], lo[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x3_split2(v[2 * j], v[2 * j + 1], hi[j], mid[j], lo[j]);
+        unsigned short* d = img + u_dst + i * kWxRowShorts;
+        *(x3u4*)d = (x3u4){hi[0], hi[1], hi[2], hi[3]};
+        *(x3u4*)(d + u_ps) = (x3u4){mid[0], mid[1], mid[2], mid[3]};
+        *(x3u4*)(d + 2 * u_ps) = (x3u4){lo[0], lo[1], lo[2], lo[3]};
+    };
+    unsigned short* const img0 = wxs;
+    unsigned short* const img1 = wxs + kWx4ImageShorts;
+    if (total_steps == 0) return;      // (workgroup-uniform; the slab of such a chunk is never read: the host counts chunks from the steps)
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, 1> S1;
+    fetch(S0{});                                          // step 0
+#pragma unroll
+    for (int i = 0; i < 4; ++i) spill_row(img0, i, S0{});
+    fetch(S0{});                                          // step 1 -> set 0 (split during step 0)
+    fetch(S1{});                                          // step 2 -> set 1 (split during step 1)
+    __syncthreads();
+    // one step: the matrix instructions of image `cur`; MORE: the next step's image is written from register set SET -- one row of the thread's quad in each
+    // of the blocks n = 0..3, in ONE basic block with that block's twelve matrix instructions -- and the set is refilled behind them with the step after next
+    auto one_step = [&](const unsigned short* cur, unsigned short* nxt, auto more_c, auto set_c) {
+        constexpr bool MORE = decltype(more_c)::value;
+        const unsigned short* SPc = cur + 3 * kWx4PlaneT;
+        auto fragT = [&](int tile, int pl) { return *(const x3u4*)(cur + pl * kWx4PlaneT + (16 * tile + mrow) * kWxRowShorts + 8 * kk); };
+        auto fragS = [&](int tile, int pl) { return *(const x3u4*)(SPc + pl * kWx4PlaneS + (16 * tile + mrow) * kWxRowShorts + 8 * kk); };
+        x3u4 a[2][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) { a[0][pl] = fragT(w, pl); a[1][pl] = fragT(tile1, pl); }
+        x3u4 bh = fragS(0, 0), bm = fragS(0, 1), bl = fragS(0, 2);
+#pragma unroll
+        for (int n = 0; n < 7; ++n) {
+            x3u4 nh = bh, nm = bm, nl = bl;
+#if RNDE_WX4_ABL != 3 && RNDE_WX4_ABL != 4
+            if (n < 6) { nh = fragS(n + 1, 0); nm = fragS(n + 1, 1); nl = fragS(n + 1, 2); }
+#endif
+#if RNDE_WX4_ABL != 1 && RNDE_WX4_ABL != 2 && RNDE_WX4_ABL != 4
+            if (MORE && n < 4) spill_row(nxt, n, set_c);
+#endif
+#if RNDE_WX4_ABL != 2 && RNDE_WX4_ABL != 4
+            if (MORE && n == 4) fetch(set_c);
+#endif
+#define WX4_TERM(PA, BV) { acc[0][n] = x3_mfma(a[0][PA], BV, acc[0][n]); acc[1][n] = x3_mfma(a[1][PA], BV, acc[1][n]); }
+            WX4_TERM(2, bh) WX4_TERM(0, bl) WX4_TERM(1, bm) WX4_TERM(1, bh) WX4_TERM(0, bm) WX4_TERM(0, bh)
+#undef WX4_TERM
+            bh = nh; bm = nm; bl = nl;
+            // (block boundary for the scheduler: a row's ~70 vector instructions stay with THESE twelve matrix instructions -- left alone the compiler front-loads
+            //  the splitting of all four rows and issues the last ~40 matrix instructions back to back, and the two waves of a SIMD, released by the same barrier,
+            //  do so in step: vector phase against vector phase, matrix phase against matrix phase)
+#if RNDE_WX4_SB
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+    };
+    int step = 0;
+    for (; step + 2 < total_steps; step += 2) {
+        one_step(img0, img1, std::true_type{}, S0{});
+        __syncthreads();      // this step's image has been read by every wave, the next one is complete
+        one_step(img1, img0, std::true_type{}, S1{});
+        __syncthreads();
+    }
+    if (total_steps - step == 2) {
+        one_step(img0, img1, std::true_type{}, S0{});
+        __syncthreads();
+        one_step(img1, nullptr, std::false_type{}, S1{});
+    } else one_step(img0, nullptr, std::false_type{}, S0{});
+    float* out = slab + (size_t)chunk * M * (Nx + 2);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (w + 7 * i < ntile) {
+#pragma unroll
+            for (int n = 0; n < 7; ++n) {
+                const int sr = 16 * n + mrow;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int tr = row_lo + 16 * (w + 7 * i) + 4 * kk + q;
+                    if (tr < TR && sr < SR) out[TALL_IS_Z ? (size_t)sr * M + tr : (size_t)tr * M + sr] = acc[i][n][q];
+                }
+            }
+        }
+    }
+}
+
 }  // namespace rnde

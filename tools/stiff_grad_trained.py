@@ -86,9 +86,9 @@ def reg_gradient_check(p2, x, max_attempts):
     return res
 
 
-def weights_after(steps, batches=24, max_attempts=600):
-    """The dynamics' parameters after `steps` optimiser steps of the stiff_est loop (lambda 0.1, `maximum`; the first steps of main()'s run), and the batch the next
-    step would see -- the state tests/test_gpu_backward.py::test_stiffness_gradient_at_trained_like_weights_is_bounded measures the gradient at."""
+def weights_after(marks, batches=24, max_attempts=600):
+    """The dynamics' parameters after each of `marks` optimiser steps of the stiff_est loop (lambda 0.1, `maximum`; the first steps of main()'s run) with the batch the
+    next step would see: [(steps, p2, x)] -- the states tests/test_gpu_backward.py::test_stiffness_gradient_at_trained_like_weights_is_bounded measures the gradient at."""
     import regneuralde_jl_amd as rn
     from tools.train_synth import batches_of, synthetic_set
     dev = torch.device("cuda", 0)
@@ -100,12 +100,16 @@ def weights_after(steps, batches=24, max_attempts=600):
                                max_batch=BATCH, max_attempts=max_attempts)
     model = rn.ClassifierNODE(node, rn.Dense(D, NCLS, "identity", generator=g), device=dev)
     opt = rn.FluxOptimiser(model.trainable())
-    for step in range(steps):
+    out = []
+    for step in range(max(marks) + 1):
         xb, yb = train[step % len(train)]
+        if step in marks:
+            out.append((step, model.p2.detach().cpu().numpy().copy(), xb.reshape(BATCH, -1).cpu().numpy()))
+        if step == max(marks):
+            break
         rn.fused_loss_and_grad(model, xb, yb, lam=lam0, regularize=True, sync=True, func=func, agg=agg)
         opt.step()
-    xb, _ = train[steps % len(train)]
-    return model.p2.detach().cpu().numpy().copy(), xb.reshape(BATCH, -1).cpu().numpy()
+    return out
 
 
 def main():

@@ -210,6 +210,12 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
 #pragma unroll
             for (int s = 2; s <= 7; ++s) kq[s - 1] = ld4(R + L.k(s) + co, r0, gD, true, vec);
         }
+        // X3 form: the running cotangents (written by the previous launch: L2 / Infinity Cache) are requested WITH the record, not behind its arrival --
+        // two small loads in front of the scalar chain (round 5 moved them together with the twelve cold DMA requests and lost: those stay where they were)
+        f32x4 uin_e = {0.f, 0.f, 0.f, 0.f}, k1in_e = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (X3) {
+            if (tile_ok && (m.flags & F_ACCEPT) && !first) { uin_e = ld4(Bq.U + co, r0, gD, true, vec); k1in_e = ld4(Bq.K1 + co, r0, gD, true, vec); }
+        }
         __builtin_amdgcn_sched_barrier(0);   // keep these requests in front of the scalar chain (the scheduler sinks them to their uses otherwise)
         BSTAMP(40);
         double tb = 0, dtpb = 0, qoldb = 0, t1b = 0, t0b = 0;
@@ -258,7 +264,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
             f32x4 uin = {0.f, 0.f, 0.f, 0.f}, k1in = {0.f, 0.f, 0.f, 0.f};
             const bool sv_mode = Q.nsave > 0;
             if (accepted) {
-                if (!first) { uin = ld4(Bq.U + co, r0, gD, true, vec); k1in = ld4(Bq.K1 + co, r0, gD, true, vec); }
+                if (!first) { if constexpr (X3) { uin = uin_e; k1in = k1in_e; } else { uin = ld4(Bq.U + co, r0, gD, true, vec); k1in = ld4(Bq.K1 + co, r0, gD, true, vec); } }
                 else if (!sv_mode) uin = ld4(Bq.ubar + co, r0, gD, colok, false);
             }
 #if RNDE_BSTAGE_HDMA
@@ -277,10 +283,19 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
                 const float au = fabsf(upv[i]), an = fabsf(unv[i]);
                 const bool use_new = !(au > an);
                 const float sk = P.abstol + (use_new ? an : au) * P.reltol;
-                const float r = ut / sk;
-                const float rb_ = colok ? coef * r : 0.f;
-                const float skb = -rb_ * r / sk;
-                utb[i] = rb_ / sk;
+                float r, rb_, skb;
+                if constexpr (X3) {      // one IEEE division per element instead of three (the other two become products with 1 / sk: each within an ulp of the quotient)
+                    const float isk = 1.f / sk;
+                    r = ut * isk;
+                    rb_ = colok ? coef * r : 0.f;
+                    skb = -rb_ * r * isk;
+                    utb[i] = rb_ * isk;
+                } else {
+                    r = ut / sk;
+                    rb_ = colok ? coef * r : 0.f;
+                    skb = -rb_ * r / sk;
+                    utb[i] = rb_ / sk;
+                }
                 unb[i] = uin[i] + (use_new ? skb * P.reltol * sgnf(unv[i]) : 0.f);
                 upb0[i] = use_new ? 0.f : skb * P.reltol * sgnf(upv[i]);
             }

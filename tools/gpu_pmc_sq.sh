@@ -20,7 +20,7 @@ if not f: sys.exit()
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f[0])):
     k = r["Kernel_Name"].split("(")[0].split("::")[-1][:48]
-    if "stage_attempt" in k or "stage_solve" in k or "wgrad3" in k:
+    if "stage_attempt" in k or "stage_solve" in k or ("wgrad" in k and "reduce" not in k and "head" not in k):
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in sorted(agg.items()):
     for c, x in v.items():

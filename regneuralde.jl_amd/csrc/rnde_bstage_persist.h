@@ -23,6 +23,9 @@ namespace rnde {
 #else
 #define BSTAMP(i) do { } while (0)
 #endif
+#ifndef RNDE_BX3_LATE_WB      // 0: both weight-fragment sets requested first (round 6, first build); 1: xB at the end of START's queue (25.6 us per reversed attempt against 26.5);
+#define RNDE_BX3_LATE_WB 1     // 2: xD behind the record's requests as well (26.8: START's own phase D then waits for it)
+#endif
 
 // FIX = 1: the headline geometry (D = 784, H = 100, 7 waves, 7 row blocks) as compile-time constants, see rnde_stage_attempt_kernel
 // X3 = 1 (with FIX; no saveat, no stiffness-estimate cotangents -- the host launches it for the error-estimate / plain callbacks only): the two
@@ -92,16 +95,27 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
     asm volatile("" : "+v"(aB), "+v"(aD), "+v"(aB4), "+v"(aD4));
     f32x4 wB[X3 ? 1 : kSMaxHT], wD[X3 ? 1 : kSMaxW];
     x3u4 xB[X3 ? 4 : 1][3], xD[X3 ? 4 : 1][3];
+    unsigned long long xb_addr[3] = {0ull, 0ull, 0ull}, xd_addr[3] = {0ull, 0ull, 0ull};
     if constexpr (X3) {
         typedef const __attribute__((address_space(1))) x3u4* gx4;
         unsigned long long bD = (unsigned long long)((const x3u4*)Q.x3Dt + ((size_t)(w * gR + rb) * 4 * 3) * 64 + lane);
         unsigned long long bB = (unsigned long long)((const x3u4*)Q.x3Bt + ((size_t)T * 4 * 3) * 64 + lane);
         unsigned long long bD1 = bD + 4 * 1024, bD2 = bD + 8 * 1024, bB1 = bB + 4 * 1024, bB2 = bB + 8 * 1024;      // (the offset field of a load reaches 4095 bytes)
         asm volatile("" : "+v"(bD), "+v"(bB), "+v"(bD1), "+v"(bD2), "+v"(bB1), "+v"(bB2));
+#if RNDE_BX3_LATE_WB < 2
 #pragma unroll
         for (int f = 0; f < 12; ++f) xD[f / 3][f % 3] = f < 4 ? ((gx4)bD)[(size_t)f * 64] : (f < 8 ? ((gx4)bD1)[(size_t)(f - 4) * 64] : ((gx4)bD2)[(size_t)(f - 8) * 64]);
+#else
+        xd_addr[0] = bD; xd_addr[1] = bD1; xd_addr[2] = bD2;      // (xD -- first multiplied in START's own phase D -- behind the record's requests, see there)
+#endif
+#if !RNDE_BX3_LATE_WB
 #pragma unroll
         for (int f = 0; f < 12; ++f) xB[f / 3][f % 3] = f < 4 ? ((gx4)bB)[(size_t)f * 64] : (f < 8 ? ((gx4)bB1)[(size_t)(f - 4) * 64] : ((gx4)bB2)[(size_t)(f - 8) * 64]);
+#else
+        // (xB -- the fragments of phase B, first multiplied in stage 6 -- are requested at the END of START's queue, behind the record and the stages' operands:
+        //  84 KB per workgroup less in front of the arrays START itself waits for)
+        xb_addr[0] = bB; xb_addr[1] = bB1; xb_addr[2] = bB2;
+#endif
         // k-values 112 .. 135 of every (plane, column) row are written by nobody (they multiply zero weights, but must not hold NaN patterns another kernel
         // left in LDS): zeroed here.  ONLY those -- rows 0 .. 111 are written by the waves' own x3_store4 with no barrier between this loop and START's.
         for (int i = tid; i < 2 * 3 * 16 * 12; i += 64 * 7) ((unsigned*)ZL)[(i / 12) * (kX3K / 2) + 56 + i % 12] = 0u;
@@ -216,6 +230,14 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
         if constexpr (X3) {
             if (tile_ok && (m.flags & F_ACCEPT) && !first) { uin_e = ld4(Bq.U + co, r0, gD, true, vec); k1in_e = ld4(Bq.K1 + co, r0, gD, true, vec); }
         }
+#if RNDE_BX3_LATE_WB >= 2
+        if constexpr (X3) {
+            typedef const __attribute__((address_space(1))) x3u4* gx4;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int f = 0; f < 12; ++f) xD[f / 3][f % 3] = ((gx4)xd_addr[f >> 2])[(size_t)(f & 3) * 64];
+        }
+#endif
         __builtin_amdgcn_sched_barrier(0);   // keep these requests in front of the scalar chain (the scheduler sinks them to their uses otherwise)
         BSTAMP(40);
         double tb = 0, dtpb = 0, qoldb = 0, t1b = 0, t0b = 0;
@@ -272,9 +294,24 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
 #pragma unroll
                 for (int j = 6; j >= 1; --j) {
                     float* slot = HP + (size_t)(((6 - j) * 7 + w) * 2) * 256;
+                    // (measured and dropped in round 6: each stage's h requested one stage ahead, behind the previous stage's poll, instead of all six here --
+                    //  27.25 against 26.5 us per reversed attempt: a cold request in the wave's in-order queue costs the NEXT poll more than START saves)
                     if (own_h0 + 3 < gH) dma_unit((const f32x4*)(R + L.h(j + 1) + own_zd0), slot);
-                    dma_unit((const f32x4*)((j >= 2 ? R + L.k(j) : k1p) + co + r0), slot + 256);
+                    // k_j: the lane's 16 bytes are in kq[j - 1] already (START read k1..k7 for the error estimate's cotangent): the X3 form parks them in the
+                    // slot with an LDS store instead of requesting them a second time -- 42 KB less per workgroup through the CU's 64 B/clk vector-memory
+                    // path, which is what START waits on (the fp32 form keeps the request: its results stay bit for bit what the tests pin)
+                    if constexpr (X3) *(f32x4*)(slot + 256 + 4 * lane) = kq[j - 1];
+                    else dma_unit((const f32x4*)((j >= 2 ? R + L.k(j) : k1p) + co + r0), slot + 256);
                 }
+            }
+#endif
+#if RNDE_BX3_LATE_WB
+            if constexpr (X3) {
+                typedef const __attribute__((address_space(1))) x3u4* gx4;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int f = 0; f < 12; ++f) xB[f / 3][f % 3] = ((gx4)xb_addr[f >> 2])[(size_t)(f & 3) * 64];
+                __builtin_amdgcn_sched_barrier(0);
             }
 #endif
 #pragma unroll
@@ -342,9 +379,11 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
             st4(R + L.k(7) + co, r0, gD, true, vec, v);
         }
         if (!colok) { tau = 0.f; exdt = 0.f; }
-        pS[0] = S; pT[0] = tau; pX[0] = exdt;
         BSTAMP(1);
         phase_d(v, 1u);
+        // the wave sums of this part's partials are formed HERE, behind the put and in front of a poll that has to wait anyway, not in END (where fifteen
+        // dependent cross-lane reductions sat at the very end of every reversed attempt); the same function on the same values: the same bits
+        pS[0] = wave_sum_f(S); pT[0] = wave_sum_f(tau); pX[0] = wave_sum_f(exdt);
         BSTAMP(2);
     }
 
@@ -515,9 +554,9 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
             }
         }
         if (!colok) tau = 0.f;
-        pS[7 - j] = S; pT[7 - j] = tau;
         BSTAMP(6 + 5 * (6 - j));
         if constexpr (j > 1) phase_d(v, ex + 1u);
+        pS[7 - j] = wave_sum_f(S); pT[7 - j] = wave_sum_f(tau);      // (behind the put, see START)
         BSTAMP(7 + 5 * (6 - j));
     };
     stage(std::integral_constant<int, 6>{});
@@ -534,7 +573,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
     //  phase A barrier since -- a wave that is done with stage 1 forms its wave sums while the slower ones finish)
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
-        const float a = wave_sum_f(pS[i]), b = wave_sum_f(pT[i]), c = i == 0 ? wave_sum_f(pX[0]) : 0.f;      // (only START has an exdt term)
+        const float a = pS[i], b = pT[i], c = i == 0 ? pX[0] : 0.f;      // wave sums, formed behind each part's put (only START has an exdt term)
         if (lane == 0) { GL[(i * 3 + 0) * 8 + w] = a; GL[(i * 3 + 1) * 8 + w] = b; GL[(i * 3 + 2) * 8 + w] = c; }
     }
     __syncthreads();

@@ -198,6 +198,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
     asm volatile("" : "+v"(aB), "+v"(aD), "+v"(aB4), "+v"(aD4));
     f32x4 wB[X3 ? 1 : kSMaxHT], wD[X3 ? 1 : kSMaxW];
     x3u4 xB[X3 ? 4 : 1][3], xD[X3 ? 4 : 1][3];
+    unsigned long long xb_addr[3] = {0ull, 0ull, 0ull};
     if constexpr (X3) {
         typedef const __attribute__((address_space(1))) x3u4* gx4;
         unsigned long long bD = (unsigned long long)((const x3u4*)x3D + ((size_t)(w * gR + rb) * 4 * 3) * 64 + lane);
@@ -206,8 +207,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
         asm volatile("" : "+v"(bD), "+v"(bB), "+v"(bD1), "+v"(bD2), "+v"(bB1), "+v"(bB2));
 #pragma unroll
         for (int f = 0; f < 12; ++f) xD[f / 3][f % 3] = f < 4 ? ((gx4)bD)[(size_t)f * 64] : (f < 8 ? ((gx4)bD1)[(size_t)(f - 4) * 64] : ((gx4)bD2)[(size_t)(f - 8) * 64]);
-#pragma unroll
-        for (int f = 0; f < 12; ++f) xB[f / 3][f % 3] = f < 4 ? ((gx4)bB)[(size_t)f * 64] : (f < 8 ? ((gx4)bB1)[(size_t)(f - 4) * 64] : ((gx4)bB2)[(size_t)(f - 8) * 64]);
+        xb_addr[0] = bB; xb_addr[1] = bB1; xb_addr[2] = bB2;      // (xB: first multiplied in stage 1's phase B -- requested behind the controller and the state the step starts from, see there)
         // k-values 112 .. 135 of every (plane, column) row are written by nobody: zeroed (ONLY those: no barrier between this loop and START's x3_store4)
         for (int i = tid; i < 2 * 3 * 16 * 12; i += 64 * 7) ((unsigned*)HL)[(i / 12) * (kX3K / 2) + 56 + i % 12] = 0u;
     } else {
@@ -265,6 +265,15 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
     for (int j = 0; j < 7; ++j) c_k[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (spec && live == n - 1) { c_up = sp_up; c_k[0] = sp_k; }      // (the step starts from what attempt n - 1 wrote: already here)
     else if (tile_ok) { c_up = ld4(upsrc + co, r0, gD, upok, upvec); c_k[0] = ld4(k1p + co, r0, gD, true, vec); }
+    if constexpr (X3) {
+        // the weight fragments of phase B at the END of the prologue's request queue (a wave's loads return in order; round 6, rnde_bstage_persist.h: the same move
+        // took 0.9 us off a reversed attempt): START's own phase D waits for xD, the controller's inputs and the state only
+        typedef const __attribute__((address_space(1))) x3u4* gx4;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < 12; ++f) xB[f / 3][f % 3] = ((gx4)xb_addr[f >> 2])[(size_t)(f & 3) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+    }
 
     // Loop-invariant addressing of this lane's four rows of its own hidden tile (phase A) and row tile (phase D): the stages are
     // instruction bound between the hand-offs (7 waves share 4 SIMDs), so nothing that does not change is recomputed per stage.

@@ -23,9 +23,9 @@ namespace rnde {
 #else
 #define BSTAMP(i) do { } while (0)
 #endif
-#ifndef RNDE_BX3_LATE_WB      // 0: both weight-fragment sets requested first (round 6, first build); 1: xB at the end of START's queue (25.6 us per reversed attempt against 26.5);
-#define RNDE_BX3_LATE_WB 1     // 2: xD behind the record's requests as well (26.8: START's own phase D then waits for it)
-#endif
+#ifndef RNDE_BX3_LATE_WB      // where the X3 form requests its weight fragments (us per reversed attempt, B = 512, same box): 0 = both sets first (26.5); 1 = xB behind the
+#define RNDE_BX3_LATE_WB 1     // record's and the stages' requests, at the end of START's queue (25.6, shipped); 2 = xD behind the record's as well (26.8: START's own
+#endif                         // phase D then waits for it); 3 = xB behind START's put (26.1 against 24.9 for 1 on the later build: the first poll queues behind it)
 
 // FIX = 1: the headline geometry (D = 784, H = 100, 7 waves, 7 row blocks) as compile-time constants, see rnde_stage_attempt_kernel
 // X3 = 1 (with FIX; no saveat, no stiffness-estimate cotangents -- the host launches it for the error-estimate / plain callbacks only): the two
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
                 }
             }
 #endif
-#if RNDE_BX3_LATE_WB
+#if RNDE_BX3_LATE_WB == 1
             if constexpr (X3) {
                 typedef const __attribute__((address_space(1))) x3u4* gx4;
                 __builtin_amdgcn_sched_barrier(0);
@@ -383,6 +383,15 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
         phase_d(v, 1u);
         // the wave sums of this part's partials are formed HERE, behind the put and in front of a poll that has to wait anyway, not in END (where fifteen
         // dependent cross-lane reductions sat at the very end of every reversed attempt); the same function on the same values: the same bits
+#if RNDE_BX3_LATE_WB == 3
+        if constexpr (X3) {      // xB behind START's put: between the put and a poll that has to wait for six other row blocks anyway
+            typedef const __attribute__((address_space(1))) x3u4* gx4;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int f = 0; f < 12; ++f) xB[f / 3][f % 3] = ((gx4)xb_addr[f >> 2])[(size_t)(f & 3) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
         pS[0] = wave_sum_f(S); pT[0] = wave_sum_f(tau); pX[0] = wave_sum_f(exdt);
         BSTAMP(2);
     }

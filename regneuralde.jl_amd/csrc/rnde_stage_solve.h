@@ -232,12 +232,12 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_solve_kernel(const StagePar
     __syncthreads();
     S = solve_state_get(SS);
     f32x4 c_un = {0.f, 0.f, 0.f, 0.f};
-#if RNDE_SOLVE_DEFER_TAPE
     // the tape stores of a stage (k_{s+1}, g_{s+2} / u_new) are issued BEHIND the next stage's poll: a wave's polling load cannot complete before every
     // older store of the wave is acknowledged (vmcnt counts both), so a store in front of a poll puts its acknowledgement on the hand-off's critical path;
-    // behind the poll it has a whole stage to come back.  The values are in registers anyway (c_k[s]; the stage input is carried in `pend`).
+    // behind the poll it has a whole stage to come back.  The values are in registers anyway (c_k[s]; the stage input is carried in `pend`).  Matrix mode 1
+    // only: there it takes 0.3 us off an attempt in-step; the fp32-input-MFMA form's stages got 3 % LONGER with it (41.8 k against 40.5 k cycles, stamps).
+    constexpr bool DEFER = RNDE_SOLVE_DEFER_TAPE && X3;
     f32x4 pend = {0.f, 0.f, 0.f, 0.f};
-#endif
     for (int n = 0;; ++n) {
         ZSTAMP(0);
         // the controller of the NEXT attempt divides by qold^beta2, and qold is known now: wave 3 -- alone on its SIMD -- evaluates the power while
@@ -255,11 +255,8 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_solve_kernel(const StagePar
             // the clears of the previous attempt's last stage are acknowledged before this attempt's first put -- they were issued before the meeting, so
             // nothing waits here; BEHIND the tape store below the same wait would sit on that store's acknowledgement (vmcnt counts stores too)
             slab_clears_done();
-#if RNDE_SOLVE_DEFER_TAPE
-            pend = v;
-#else
-            if (P.tape) st4(R + L.g(2) + co, r0, gD, true, vec, v);
-#endif
+            if constexpr (DEFER) pend = v;
+            else if (P.tape) st4(R + L.g(2) + co, r0, gD, true, vec, v);
             phase_d(v, 1u);
         }
         ZSTAMP(2);
@@ -278,11 +275,11 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_solve_kernel(const StagePar
             const bool dead = !slab_poll_sum(Y, buf, Q.C, gR, gHT, ct, w, lane, zs);
             const size_t tprev0 = (((size_t)slab_buf((unsigned)(s + 2)) * Q.C + ct) * gR + rb) * gHT;
             if (!dead) slab_clear(Y.tslab, tprev0 + w, lane);
-#if RNDE_SOLVE_DEFER_TAPE
-            if constexpr (s >= 2) st4(R + L.k(s) + co, r0, gD, true, vec, c_k[s - 1]);
-            if constexpr (s == 6) st4(R + L.unew() + co, r0, gD, true, vec, pend);
-            else if (P.tape) st4(R + L.g(s + 1) + co, r0, gD, true, vec, pend);
-#endif
+            if constexpr (DEFER) {
+                if constexpr (s >= 2) st4(R + L.k(s) + co, r0, gD, true, vec, c_k[s - 1]);
+                if constexpr (s == 6) st4(R + L.unew() + co, r0, gD, true, vec, pend);
+                else if (P.tape) st4(R + L.g(s + 1) + co, r0, gD, true, vec, pend);
+            }
             float pre[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) pre[i] = fmaf(w1t_own[i], ts, zs[i]) + b1_own[i];
@@ -331,21 +328,17 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_solve_kernel(const StagePar
             // ---- phase C ----
             if constexpr (s < 6) {
                 slab_clears_done();      // (issued two phases ago: nothing to wait for in practice) before this stage's put, see slab_put
-#if !RNDE_SOLVE_DEFER_TAPE
-                st4(kdst + co, r0, gD, true, vec, kv);
-#endif
+                if constexpr (!DEFER) st4(kdst + co, r0, gD, true, vec, kv);
                 f32x4 acc = tsA(s + 1, 0) * c_k[0];
 #pragma unroll
                 for (int j = 1; j < 6; ++j) if (j < s) acc = fma4(tsA(s + 1, j), c_k[j], acc);
                 acc = fma4(tsA(s + 1, s), kv, acc);
                 const f32x4 v = fma4(dt, acc, c_up);
-#if RNDE_SOLVE_DEFER_TAPE
-                pend = v;
-                if (s == 5) c_un = v;
-#else
-                if (s == 5) { st4(R + L.unew() + co, r0, gD, true, vec, v); c_un = v; }
-                else if (P.tape) st4(R + L.g(s + 2) + co, r0, gD, true, vec, v);
-#endif
+                if constexpr (DEFER) { pend = v; if (s == 5) c_un = v; }
+                else {
+                    if (s == 5) { st4(R + L.unew() + co, r0, gD, true, vec, v); c_un = v; }
+                    else if (P.tape) st4(R + L.g(s + 2) + co, r0, gD, true, vec, v);
+                }
                 c_k[s] = kv;
                 phase_d(v, (unsigned)(s + 1));
             } else {

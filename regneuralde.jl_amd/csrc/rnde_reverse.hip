@@ -103,8 +103,8 @@ static rnde_status launch_wgrad_part(rnde_node* h, const EvalDesc* ev, int n_eva
         sc = (total_steps + steps_per_chunk - 1) / steps_per_chunk;
         if ((size_t)(*chunk_cursor + sc) * (size_t)len > h->bw.slab_floats) { h->err = "weight-gradient slab overflow"; return RNDE_ERR_BAD_ARG; }
         // matrix mode 1 in effect for this step (the forward ran the x3 solve): the GEMMs on the matrix cores too (rnde_wgradx.h; RNDE_X3_WGRAD_OFF=1: A/B)
-        static const bool x3_off = getenv("RNDE_X3_WGRAD_OFF") != nullptr;
-        static const bool x3_half = getenv("RNDE_X3_WGRAD_HALF") != nullptr;      // (A/B: the single-buffered half form)
+        const bool x3_off = getenv("RNDE_X3_WGRAD_OFF") != nullptr;            // (read per call: A/B runs and tests switch inside one process)
+        const bool x3_half = getenv("RNDE_X3_WGRAD_HALF") != nullptr;         // (A/B: the single-buffered half form)
         const int TT4 = ((tall ? M : Nx + 2) + 15) / 16;
         if (h->x3_packed && !x3_off && !x3_half && TT4 >= 28 && TT4 <= 52) {
             // quarter form (rnde_wgrad4x_kernel): four workgroups per chunk, two LDS images; the launches underneath the sweep stay at 32 workgroups (8 chunks)

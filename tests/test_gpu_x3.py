@@ -137,6 +137,41 @@ def test_x3_regulariser_noise_gradient_is_no_larger_than_the_fp32_kernels():
     assert d[1][0] <= 1.5 * d[0][0] and d[1][0] <= 0.05 * d[1][1] and d[0][0] <= 0.05 * d[0][1]
 
 
+@pytest.mark.parametrize("B,side", [(512, 30), (512, 0), (100, 100), (37, 0), (1500, 30)])
+def test_x3_weight_gradient_forms_agree(B, side, monkeypatch):
+    """The parameter gradient of matrix mode 1 through its two weight-gradient kernels -- the quarter form with two LDS images (rnde_wgrad4x_kernel, the default:
+    16-byte operand loads, wave-uniform operand per wave, repeated units in the idle lanes, two register sets) and the single-buffered half form
+    (rnde_wgrad3x_kernel, RNDE_X3_WGRAD_HALF=1) -- and through the fp32-input-MFMA kernel (RNDE_X3_WGRAD_OFF=1): the same evaluations off the same tape (the
+    forward solve and the reverse sweep do not depend on the switch: x-bar bit-equal), the six-term products in the same order per 32 columns, chunked
+    differently: 5e-6 of the largest entry between the two x3 forms and 3e-5 against the fp32 kernel for the signal's gradient; with the error-estimate regulariser's
+    cotangent on top (saved values that are rounding noise at this tolerance, divided by it: cancelling sums 1e4 x the result) 3e-3.  Batches that are no multiple of 32 (half-empty last step
+    of every evaluation), with and without the launches underneath the sweep, and a batch above 1024 (two-tile forward kernel, launch-per-attempt reverse)."""
+    from tests.util import Node, rel_err
+    arch, p, x, ubar = _problem(B, 41)
+    out = {}
+    for name, env in (("quarter", {}), ("half", {"RNDE_X3_WGRAD_HALF": "1"}), ("fp32", {"RNDE_X3_WGRAD_OFF": "1"})):
+        for k in ("RNDE_X3_WGRAD_HALF", "RNDE_X3_WGRAD_OFF"):
+            monkeypatch.delenv(k, raising=False)
+        monkeypatch.setenv("RNDE_WGRAD_SIDE", str(side))
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        node = Node(_cfg(B, regularize=1), matrix_mode=1)
+        got = node.forward(x, p, keep_tape=True)
+        n = len(got["saveval"])
+        sig = node.backward(ubar, np.zeros(n, np.float32))                       # the signal's gradient alone
+        node.forward(x, p, keep_tape=True)
+        reg = node.backward(ubar, np.full(n, 10.0 / n, np.float32))             # + the error-estimate regulariser's (rounding noise amplified ~1e4 x, see above)
+        out[name] = (sig, reg)
+        node.close()
+    for name in ("half", "fp32"):
+        assert np.array_equal(out["quarter"][0][0], out[name][0][0]) and np.array_equal(out["quarter"][1][0], out[name][1][0]), name
+    e = {(a, k): rel_err(out["quarter"][k][1], out[a][k][1]) for a in ("half", "fp32") for k in (0, 1)}
+    print(f"B = {B}, side {side}: p-bar quarter vs half {e['half', 0]:.2e} (with the regulariser's cotangent {e['half', 1]:.2e}), quarter vs fp32 kernel {e['fp32', 0]:.2e} ({e['fp32', 1]:.2e})")
+    assert np.abs(out["quarter"][0][1]).max() > 0
+    assert e["half", 0] <= 5e-6 and e["fp32", 0] <= 3e-5
+    assert e["half", 1] <= 3e-3 and e["fp32", 1] <= 3e-3      # (sums of cancelling terms 1e4 x the result: the summation order shows at 1e-4 .. 1e-3 of it)
+
+
 @pytest.mark.parametrize("B,tol,scale,reg", [(512, TOL, 1.0, 1), (64, TOL, 1.0, 1), (200, 1e-3, 3.0, 1), (37, 1e-4, 2.0, 0), (1024, TOL, 1.0, 1)])
 def test_x3_one_launch_solve_is_bit_identical_to_the_x3_attempt_kernel(B, tol, scale, reg, monkeypatch):
     """The two x3 kernels issue the same matrix instructions in the same order on the same operands: the one-launch solve (B <= 512) and one launch per

@@ -21,6 +21,9 @@
 #ifndef RNDE_SOLVE_DEFER_TAPE
 #define RNDE_SOLVE_DEFER_TAPE 1
 #endif
+#ifndef RNDE_SOLVE_LOCAL_LAYOUT
+#define RNDE_SOLVE_LOCAL_LAYOUT 1
+#endif
 #include "rnde_stage_persist.h"
 #include "rnde_solve_sync.h"
 #include "rnde_x3.h"
@@ -127,7 +130,11 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_solve_kernel(const StagePar
     const bool writer = (wg == 0 && tid == 0);
     const int T = rb * gWT + w;
     const int r0 = 16 * T + 4 * (lane >> 4);
+#if RNDE_SOLVE_LOCAL_LAYOUT
+    const RecLayout LL{(long long)gD * P.Bpad, (long long)gH * P.Bpad};
+#else
     const RecLayout L{(long long)gD * P.Bpad, (long long)gH * P.Bpad};
+#endif
     if (tid == 0) Y.xcc[wg] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15;   // HW_REG_XCC_ID
     const size_t co = (size_t)gcol * gD;
 
@@ -248,6 +255,13 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_solve_kernel(const StagePar
         const float t = S.t, dt = (P.t1 - S.t < S.dtp) ? (P.t1 - S.t) : S.dtp;
         const int rec = P.tape ? n : (S.live == 0 ? 1 : 0);
         float* R = P.arena + (long long)rec * P.rec_stride;
+#if RNDE_SOLVE_LOCAL_LAYOUT
+        // the record's array offsets are formed from (A, HB) where they are used, every attempt: left to itself the compiler keeps the ~19 loop-invariant 64-bit
+        // offsets in scalar registers across the attempt loop and spills them (75-81 SGPR spills, 143 v_readlane per attempt); the empty asm hides the invariance
+        long long A_n = LL.A, HB_n = LL.HB;
+        asm volatile("" : "+s"(A_n), "+s"(HB_n));
+        const RecLayout L{A_n, HB_n};
+#endif
 
         // ---- the attempt kernel's START: g2, exchange 1 ----
         {

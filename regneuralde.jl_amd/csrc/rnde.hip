@@ -181,7 +181,7 @@ static rnde_status chain_create(const rnde_node_config* c, rnde_node** out) {
     }
     ok &= dm((void**)&h->ctl, 2 * sizeof(StepState)) && dm((void**)&h->ctl_final, sizeof(StepState));
     ok &= dm((void**)&h->meta, (size_t)(c->max_attempts + 1) * sizeof(StepMeta)) && dm((void**)&h->initrec, sizeof(InitRec));
-    ok &= dm((void**)&h->errpart, (size_t)(6 * h->nwg_max + 256) * 4) && dm((void**)&h->initpart, (size_t)(3 * h->nwg_max + 256) * 4);   // (+256: sum_partials reads whole 256-entry blocks)
+    ok &= dm((void**)&h->errpart, (size_t)(6 * h->nwg_max + 256 + 16) * 4) && dm((void**)&h->initpart, (size_t)(3 * h->nwg_max + 256) * 4);   // (+256: sum_partials reads whole 256-entry blocks; +16: the [2][4] doubles of rnde_epart_reduce_kernel)
     h->arena_recs = 2;
     ok &= dm((void**)&h->arena, (size_t)h->arena_recs * h->rec_stride * 4);
     ok &= hipHostMalloc((void**)&h->h_ctl, sizeof(StepState)) == hipSuccess;
@@ -377,7 +377,7 @@ extern "C" rnde_status rnde_node_create(const rnde_node_config* c, rnde_node** o
         h->h_pchk = (unsigned*)(h->h_mbox + 1016); h->h_meta = (StepMeta*)(h->h_mbox + h->mbox_meta_off);
     }
     ok &= dm((void**)&h->ctl, 2 * sizeof(StepState));
-    ok &= dm((void**)&h->errpart, (size_t)(6 * h->nwg_max + 256) * 4) && dm((void**)&h->initpart, (size_t)(3 * h->nwg_max + 256) * 4);   // (+256: sum_partials reads whole 256-entry blocks)
+    ok &= dm((void**)&h->errpart, (size_t)(6 * h->nwg_max + 256 + 16) * 4) && dm((void**)&h->initpart, (size_t)(3 * h->nwg_max + 256) * 4);   // (+256: sum_partials reads whole 256-entry blocks; +16: the [2][4] doubles of rnde_epart_reduce_kernel)
     // scratch records: 2 (no-tape ring); grown to max_attempts on the first taped forward
     h->arena_recs = 2;
     ok &= dm((void**)&h->arena, (size_t)h->arena_recs * h->rec_stride * 4);
@@ -557,6 +557,16 @@ hipError_t slab_prepare(rnde_node* h, int Bpad, hipStream_t s) {
     h->tslab_Bpad = Bpad;
     return hipMemsetAsync(h->tslab, 0xFF, h->tslab_bytes, s);
 }
+// the two-tile attempt kernel serves this geometry (rnde_stage_persist2.h): the headline network, an even number of column tiles, enough of them
+static bool stage_two_tile(const rnde_node* h, const StageParams& Q) {
+    const bool fix = Q.WT == 7 && Q.HT == 7 && Q.K2b == 7 && Q.MT == 49 && Q.R == 7 && h->D == 784 && h->H == 100 && !h->stage_generic;
+    return h->persist == 1 && fix && Q.C % 2 == 0 && h->persist2 != 0 && (Q.C >= kPersist2MinTiles || h->persist2 >= 1);
+}
+// large batches: the error partials of an attempt summed once behind its launch (rnde_epart_reduce_kernel) instead of in every workgroup's prologue of the next --
+// from ~900 partials on (B >= 2048), where the two-tile kernel runs; RNDE_NO_EPART_REDUCE=1: A/B
+static bool stage_epart_reduce(const rnde_node* h, const StageParams& Q) {
+    return stage_two_tile(h, Q) && Q.F.nwg >= 896 && !getenv("RNDE_NO_EPART_REDUCE");
+}
 static hipError_t stage_attempt(rnde_node* h, const StageParams& Q, int n, hipStream_t s) {
     if (h->persist == 1) {   // one launch per attempt, slab hand-offs inside the kernel (rnde_stage_persist.h)
         PersistSync Y{h->tslab, h->pabort, h->pxcc, h->persist_spins};
@@ -566,7 +576,7 @@ static hipError_t stage_attempt(rnde_node* h, const StageParams& Q, int n, hipSt
         // batches that fill the chip more than once: two column tiles per workgroup (rnde_stage_persist2.h; bit-identical results).
         // RNDE_PERSIST2=0 keeps one tile per workgroup (A/B and the bit-identity test), =1 takes two whenever the tile count is even.
         static const bool x3_over_mt = !(getenv("RNDE_X3_MT") && atoi(getenv("RNDE_X3_MT")) == 0);      // (A/B: 0 = keep the fp32 two-tile kernel for large batches even in matrix mode 1)
-        if (fix && Q.C % 2 == 0 && h->persist2 != 0 && (Q.C >= kPersist2MinTiles || h->persist2 >= 1)) {
+        if (stage_two_tile(h, Q)) {
             const dim3 grid2(8 * Q.R * ((Q.C / 2 + 7) / 8));
             if (h->x3_fwd && x3_over_mt) {      // matrix mode 1: the two-tile kernel in its x3 form (RNDE_X3_MT=0: the fp32 form, A/B)
                 const size_t xlds2 = sizeof(float) * ((size_t)2 * 2 * kX3ImageFloats + 32 * 3);
@@ -762,6 +772,7 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
     } else if (h->engine == 2) {
         if (!keep_tape) { st = stage_pack_weights(h, p_dev, s); if (st != RNDE_OK) return st; }
         SQ = make_stage_params(h, P, keep_tape ? h->pcopy : p_dev);
+        if (stage_epart_reduce(h, SQ)) SQ.F.esum = (const double*)(h->errpart + 6 * (size_t)h->nwg_max + 256);      // (inside errpart's allocation, 8-byte aligned)
         HIPCHK(h, launch_stage<SM_I1>(h, SQ, 0, 0, s));
         HIPCHK(h, launch_stage<SM_I2>(h, SQ, 0, 0, s));
         if ((st = couple_sum(h, P.initpart, 2LL * P.nwg, s)) != RNDE_OK) return st;            // norms of u0 and f0
@@ -915,6 +926,7 @@ static rnde_status forward_core(rnde_node* h, const float* x_dev, const float* p
                 HIPCHK(h, stage_attempt(h, SQ, launched, s));
             }
             if ((st = couple_sum(h, P.errpart + (size_t)(launched & 1) * 3 * P.nwg, 3LL * P.nwg, s)) != RNDE_OK) return st;
+            if (h->engine == 2 && SQ.F.esum) { hipLaunchKernelGGL(rnde_epart_reduce_kernel, dim3(1), dim3(64), 0, s, SQ.F, launched, (double*)SQ.F.esum); HIPCHK(h, hipGetLastError()); }
             ++launched;
         }
         if (h->timing && !h->tev_fwd) { HIPCHK(h, hipEventRecord(h->tev[1], s)); h->tev_fwd = true; }   // (first chunk: normally the whole solve)

@@ -191,6 +191,9 @@ struct StepParams {
     // step-size controller exponents and the order in the initial-step rule: 7 / (10 order), 2 / (5 order), order -- kBeta1, kBeta2, 5 for
     // the order-5 pairs (every reference call site); another order only with a pair that comes as a table (RkTab.order, rnde_chainmw.h)
     float beta1, beta2, rk_order;
+    // large batches (round 6, stage engine's two-tile attempt kernel): the three cross-workgroup sums over errpart[parity], formed ONCE behind the launch that wrote
+    // them (rnde_epart_reduce_kernel: sum_partials, the same additions in the same order) -- [2][4] doubles, or NULL: every workgroup's prologue sums for itself
+    const double* esum;
 };
 
 // record layout inside the arena (floats): k2..k7 | g2..g6 | unew | h2..h7 | z1bar2..z1bar7

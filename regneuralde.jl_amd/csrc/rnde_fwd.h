@@ -45,6 +45,18 @@ __device__ __forceinline__ void finalize_state(const StepParams& P, StepState& S
     else if (!(dt > kDtMin)) { S.done = 1; S.status = 3; }
 }
 
+// Large batches: at B = 4096 every one of the 896 workgroups of an attempt launch summed all 1,792 x {1, 3} error partials of the previous attempt in its
+// prologue -- seven dependent blocks of cold loads in front of the controller (7 us of a 157 us attempt, round 5's scratch build).  One wave forms the sums
+// once, behind the launch that wrote the partials, with sum_partials itself (bit-identical); the prologue reads three doubles (advance_state_t's `sums`).
+static __global__ __launch_bounds__(64) void rnde_epart_reduce_kernel(const StepParams P, int m, double* __restrict__ out) {
+    const int lane = threadIdx.x;
+    const float* ep = P.errpart + (size_t)(m & 1) * 3 * P.nwg;
+    const double s0 = sum_partials(ep, P.nwg, lane);
+    double s1 = 0, s2 = 0;
+    if (P.reg_kind >= 2) { s1 = sum_partials(ep + P.nwg, P.nwg, lane); s2 = sum_partials(ep + 2 * P.nwg, P.nwg, lane); }
+    if (lane == 0) { double* o = out + 4 * (m & 1); o[0] = s0; o[1] = s1; o[2] = s2; o[3] = 0; }
+}
+
 // pre: the error partials of attempt n - 1 (first 256-entry block, this lane's four), requested by the caller ahead of this call --
 // the controller state and the partials are two cold loads that do not depend on each other
 // prev: the controller state of attempt n - 1 (P.ctl[(n - 1) & 1]), likewise loaded by the caller ahead of the call (both used when PRE and n > 0)

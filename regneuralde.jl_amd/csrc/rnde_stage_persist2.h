@@ -73,7 +73,7 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_attempt_mt_kernel(const Sta
     if (n > 0) {
         const f32x4* cp = (const f32x4*)&P.ctl[(n - 1) & 1];
         prev_raw[0] = cp[0]; prev_raw[1] = cp[1]; prev_raw[2] = cp[2];
-        partials_request(P.errpart + (size_t)((n - 1) & 1) * 3 * P.nwg, lane, pre_part);
+        if (!P.esum) partials_request(P.errpart + (size_t)((n - 1) & 1) * 3 * P.nwg, lane, pre_part);      // (esum: the sums were formed behind the previous launch, rnde_epart_reduce_kernel)
     }
     const bool spec = P.tape && n > 0 && !P.forced;
     f32x4 sp_up[NCT], sp_k[NCT];
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_attempt_mt_kernel(const Sta
     StepState prev_state;
     __builtin_memcpy(&prev_state, prev_raw, sizeof(StepState));
     prev_state.live = __builtin_amdgcn_readfirstlane(prev_state.live); prev_state.done = __builtin_amdgcn_readfirstlane(prev_state.done);
-    const StepState S = advance_state_t<true>(P, n, lane, writer, &P.ctl[n & 1], pre_part, prev_state);
+    const StepState S = advance_state_t<true>(P, n, lane, writer, &P.ctl[n & 1], pre_part, prev_state, (P.esum && n > 0) ? P.esum + 4 * ((n - 1) & 1) : nullptr);
     if (P.nsave > 0) {
         const int lo = (n == 0) ? 0 : P.ctl[(n - 1) & 1].next_save, hi = S.next_save;
         if (hi > lo) {

@@ -28,7 +28,7 @@ namespace rnde {
 #endif                         // phase D then waits for it); 3 = xB behind START's put (26.1 against 24.9 for 1 on the later build: the first poll queues behind it)
 
 // FIX = 1: the headline geometry (D = 784, H = 100, 7 waves, 7 row blocks) as compile-time constants, see rnde_stage_attempt_kernel
-// X3 = 1 (with FIX; no saveat, no stiffness-estimate cotangents -- the host launches it for the error-estimate / plain callbacks only): the two
+// X3 = 1 (with FIX; no saveat -- the host launches it for solves without save times, every callback): the two
 // transposed products of every stage on the matrix cores (rnde_x3.h: exact three-way bf16 split, six v_mfma_f32_16x16x32_bf16 per 32 k-values), as the
 // forward solve of matrix mode 1 forms its own.  Not bit-identical to the fp32-input-MFMA form; parity vs the fp64 restatement: tests/test_gpu_x3.py.
 template <int ACT2, int FIX, int X3 = 0>
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
     const float dt = m.dt;
     const float* upsrc = P.x; const float* k1p = P.f0; bool upok = colok, upvec = P.xvec != 0;
     if (m.src >= 0) { const float* Rl = P.arena + (long long)m.src * P.rec_stride; upsrc = Rl + L.unew(); k1p = Rl + L.k(7); upok = true; upvec = vec; }
-    const bool has_eig = X3 ? false : (eig_c1 != 0.f || eig_c2 != 0.f);      // (X3: the host launches this form only without these two)
+    const bool has_eig = eig_c1 != 0.f || eig_c2 != 0.f;
     const bool has_sv = X3 ? false : sv_hi > sv_lo;
 
     // per-stage partials {S, tau, exdt}: index 0 = START, 1..6 = stage j = 6..1 (reduced at the end in launch order)

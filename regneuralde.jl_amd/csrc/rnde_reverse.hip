@@ -342,9 +342,9 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
                         HIPCHK(h, hipFuncSetAttribute((const void*)rnde_bstage_attempt_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                         attr.done();
                     }
-                    // matrix mode 1 (rnde_x3.h): the forward ran the x3 solve and split the transposed weights too; the x3 form serves the callbacks without
-                    // eigen_est cotangents and solves without saveat (the headline; everything else keeps the fp32-input-MFMA form)
-                    const bool x3 = h->x3_packed && h->x3Bt && h->x3Dt && h->saveat.empty() && h->cfg.regularize <= RNDE_REG_ERR && !getenv("RNDE_X3_REV_OFF");
+                    // matrix mode 1 (rnde_x3.h): the forward ran the x3 solve and split the transposed weights too; the x3 form serves every callback of the
+                    // experiments (the eigen_est cotangents fit since the partial sums became scalars: 198 VGPRs) on solves without saveat; saveat keeps the fp32 form
+                    const bool x3 = h->x3_packed && h->x3Bt && h->x3Dt && h->saveat.empty() && !getenv("RNDE_X3_REV_OFF");
                     if (x3) {
                         const size_t xlds = sizeof(float) * ((size_t)2 * kX3ImageFloats + 64) + (size_t)(RNDE_BSTAGE_HDMA ? 1 : 0) * 6 * 7 * 2 * 1024;
                         static DeviceOnce attr3;

@@ -343,18 +343,25 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
                         attr.done();
                     }
                     // matrix mode 1 (rnde_x3.h): the forward ran the x3 solve and split the transposed weights too; the x3 form serves every callback of the
-                    // experiments (the eigen_est cotangents fit since the partial sums became scalars: 198 VGPRs) on solves without saveat; saveat keeps the fp32 form
-                    const bool x3 = h->x3_packed && h->x3Bt && h->x3Dt && h->saveat.empty() && !getenv("RNDE_X3_REV_OFF");
+                    // experiments (the eigen_est cotangents fit since the partial sums became scalars: 198 VGPRs), and saveat in an instantiation of its own (256)
+                    const bool x3 = h->x3_packed && h->x3Bt && h->x3Dt && !getenv("RNDE_X3_REV_OFF");
                     if (x3) {
                         const size_t xlds = sizeof(float) * ((size_t)2 * kX3ImageFloats + 64) + (size_t)(RNDE_BSTAGE_HDMA ? 1 : 0) * 6 * 7 * 2 * 1024;
                         static DeviceOnce attr3;
                         if (attr3.need()) {
-                            HIPCHK(h, hipFuncSetAttribute((const void*)rnde_bstage_attempt_kernel<1, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                            HIPCHK(h, hipFuncSetAttribute((const void*)rnde_bstage_attempt_kernel<0, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                            HIPCHK(h, hipFuncSetAttribute((const void*)rnde_bstage_attempt_kernel<1, 1, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                            HIPCHK(h, hipFuncSetAttribute((const void*)rnde_bstage_attempt_kernel<0, 1, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                            HIPCHK(h, hipFuncSetAttribute((const void*)rnde_bstage_attempt_kernel<1, 1, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                            HIPCHK(h, hipFuncSetAttribute((const void*)rnde_bstage_attempt_kernel<0, 1, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                             attr3.done();
                         }
-                        if (h->act2) hipLaunchKernelGGL((rnde_bstage_attempt_kernel<1, 1, 1>), pgrid, blk, xlds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
-                        else hipLaunchKernelGGL((rnde_bstage_attempt_kernel<0, 1, 1>), pgrid, blk, xlds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
+                        if (h->saveat.empty()) {
+                            if (h->act2) hipLaunchKernelGGL((rnde_bstage_attempt_kernel<1, 1, 1, 0>), pgrid, blk, xlds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
+                            else hipLaunchKernelGGL((rnde_bstage_attempt_kernel<0, 1, 1, 0>), pgrid, blk, xlds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
+                        } else {      // (saveat: the same form with the dense-output cotangents, at the 256-register limit)
+                            if (h->act2) hipLaunchKernelGGL((rnde_bstage_attempt_kernel<1, 1, 1, 1>), pgrid, blk, xlds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
+                            else hipLaunchKernelGGL((rnde_bstage_attempt_kernel<0, 1, 1, 1>), pgrid, blk, xlds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
+                        }
                     } else if (h->act2) hipLaunchKernelGGL((rnde_bstage_attempt_kernel<1, 1>), pgrid, blk, flds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
                     else hipLaunchKernelGGL((rnde_bstage_attempt_kernel<0, 1>), pgrid, blk, flds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
                 } else if (h->act2) hipLaunchKernelGGL((rnde_bstage_attempt_kernel<1, 0>), pgrid, blk, h->stage_lds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);

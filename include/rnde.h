@@ -202,12 +202,12 @@ int32_t     rnde_node_launches_per_attempt(const rnde_node* h);
  * rnde_stage_solve_kernel for the MNIST form at <= 512 columns, MW_SOLVE for the Dense-chain and SDE engines) -- the launch that replaces
  * the body of `solve(prob, Tsit5(); ...)`, reference src/models/neural_ode.jl:131-137.  bench.py's roofline bookkeeping and the tests. */
 int32_t     rnde_node_one_launch_solves(const rnde_node* h);
-/* Which arithmetic unit forms the Dense-layer products of the one-launch forward solve (the f(u, p, t) evaluations inside
- * `solve(prob, Tsit5(); ...)`, reference src/models/neural_ode.jl:131-137 with the dynamics of experiments/mnist_node.jl:41-54):
+/* Which arithmetic unit forms the Dense-layer products of the stage engine -- the f(u, p, t) evaluations inside `solve(prob, Tsit5(); ...)`, reference
+ * src/models/neural_ode.jl:131-137 with the dynamics of experiments/mnist_node.jl:41-54, their transposes in the reverse pass and the parameter-gradient GEMMs:
  *   RNDE_MATRIX_F32   (0) the fp32-input MFMA v_mfma_f32_16x16x4_f32 -- on gfx950 an instruction of the VECTOR ALUs (64 FLOP/clk/SIMD, no overlap with
  *                         other vector work: tools/micro/coexec.hip); bit-identical to the launch-per-attempt kernels and mirrored by the oracle's
  *                         device-order mode;
- *   RNDE_MATRIX_BF16X3 (1, default where it applies: the MNIST form at <= 512 columns) both operands split EXACTLY into three bf16 numbers, the six
+ *   RNDE_MATRIX_BF16X3 (1, default where it applies: the MNIST form D = 784, H = 100 on the persistent kernels, any batch) both operands split EXACTLY into three bf16 numbers, the six
  *                         leading cross products on the matrix cores (v_mfma_f32_16x16x32_bf16), fp32 accumulation: csrc/rnde_x3.h.  Closer to the fp64
  *                         restatement than mode 0 (fewer roundings per dot product), hence FEWER attempted steps at the reference tolerance, where
  *                         the step size is set by rounding noise; not bit-identical to mode 0.

@@ -31,8 +31,9 @@ namespace rnde {
 // X3 = 1 (with FIX; every callback, with saveat (SV = 1) or without): the two
 // transposed products of every stage on the matrix cores (rnde_x3.h: exact three-way bf16 split, six v_mfma_f32_16x16x32_bf16 per 32 k-values), as the
 // forward solve of matrix mode 1 forms its own.  Not bit-identical to the fp32-input-MFMA form; parity vs the fp64 restatement: tests/test_gpu_x3.py.
-// SV = 0: an instantiation without the saveat cotangents (the X3 form of the headline: 198 VGPRs; with them it sits at the 256-register limit)
-template <int ACT2, int FIX, int X3 = 0, int SV = 1>
+// SV: which optional cotangents the instantiation carries -- bit 0 the saveat ones, bit 1 the eigen_est ones.  The fp32 forms carry both (3) behind run-time tests, as since
+// round 2; the X3 form is instantiated per combination: 0 is the headline (198 VGPRs, no tests in the stages), with saveat it sits at the 256-register limit
+template <int ACT2, int FIX, int X3 = 0, int SV = 3>
 __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const BStageParams Q, const int n, const StepMeta m, const float eig_c1,
                                                                           const float eig_c2, const int sv_lo, const int sv_hi, const PersistSync Y, const double qo_host,
                                                                           const float svb_n /* = svb_att[n], known to the host: saves a dependent load in the scalar chain */) {
@@ -142,8 +143,8 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
     const float dt = m.dt;
     const float* upsrc = P.x; const float* k1p = P.f0; bool upok = colok, upvec = P.xvec != 0;
     if (m.src >= 0) { const float* Rl = P.arena + (long long)m.src * P.rec_stride; upsrc = Rl + L.unew(); k1p = Rl + L.k(7); upok = true; upvec = vec; }
-    const bool has_eig = eig_c1 != 0.f || eig_c2 != 0.f;
-    const bool has_sv = SV ? sv_hi > sv_lo : false;
+    const bool has_eig = (SV & 2) ? (eig_c1 != 0.f || eig_c2 != 0.f) : false;
+    const bool has_sv = (SV & 1) ? sv_hi > sv_lo : false;
 
     // per-stage partials {S, tau, exdt}: index 0 = START, 1..6 = stage j = 6..1 (reduced at the end in launch order)
     float pS[7], pT[7], pX[7];

@@ -349,19 +349,17 @@ static rnde_status bwd_run(rnde_node* h, const float* u_bar_dev, const float* sa
                         const size_t xlds = sizeof(float) * ((size_t)2 * kX3ImageFloats + 64) + (size_t)(RNDE_BSTAGE_HDMA ? 1 : 0) * 6 * 7 * 2 * 1024;
                         static DeviceOnce attr3;
                         if (attr3.need()) {
-                            HIPCHK(h, hipFuncSetAttribute((const void*)rnde_bstage_attempt_kernel<1, 1, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                            HIPCHK(h, hipFuncSetAttribute((const void*)rnde_bstage_attempt_kernel<0, 1, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                            HIPCHK(h, hipFuncSetAttribute((const void*)rnde_bstage_attempt_kernel<1, 1, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                            HIPCHK(h, hipFuncSetAttribute((const void*)rnde_bstage_attempt_kernel<0, 1, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define RNDE_X3_ATTR(A, E) HIPCHK(h, hipFuncSetAttribute((const void*)rnde_bstage_attempt_kernel<A, 1, 1, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                            RNDE_X3_ATTR(1, 0) RNDE_X3_ATTR(1, 1) RNDE_X3_ATTR(1, 2) RNDE_X3_ATTR(1, 3) RNDE_X3_ATTR(0, 0) RNDE_X3_ATTR(0, 1) RNDE_X3_ATTR(0, 2) RNDE_X3_ATTR(0, 3)
+#undef RNDE_X3_ATTR
                             attr3.done();
                         }
-                        if (h->saveat.empty()) {
-                            if (h->act2) hipLaunchKernelGGL((rnde_bstage_attempt_kernel<1, 1, 1, 0>), pgrid, blk, xlds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
-                            else hipLaunchKernelGGL((rnde_bstage_attempt_kernel<0, 1, 1, 0>), pgrid, blk, xlds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
-                        } else {      // (saveat: the same form with the dense-output cotangents, at the 256-register limit)
-                            if (h->act2) hipLaunchKernelGGL((rnde_bstage_attempt_kernel<1, 1, 1, 1>), pgrid, blk, xlds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
-                            else hipLaunchKernelGGL((rnde_bstage_attempt_kernel<0, 1, 1, 1>), pgrid, blk, xlds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
-                        }
+                        // the instantiation by what this reverse pass needs: saveat cotangents (bit 0), eigen_est cotangents (bit 1: the three stiffness callbacks)
+                        const int ex = (h->saveat.empty() ? 0 : 1) | (h->cfg.regularize >= RNDE_REG_STIFF ? 2 : 0);
+#define RNDE_X3_LAUNCH(A, E) hipLaunchKernelGGL((rnde_bstage_attempt_kernel<A, 1, 1, E>), pgrid, blk, xlds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n])
+                        if (h->act2) { if (ex == 0) RNDE_X3_LAUNCH(1, 0); else if (ex == 1) RNDE_X3_LAUNCH(1, 1); else if (ex == 2) RNDE_X3_LAUNCH(1, 2); else RNDE_X3_LAUNCH(1, 3); }
+                        else { if (ex == 0) RNDE_X3_LAUNCH(0, 0); else if (ex == 1) RNDE_X3_LAUNCH(0, 1); else if (ex == 2) RNDE_X3_LAUNCH(0, 2); else RNDE_X3_LAUNCH(0, 3); }
+#undef RNDE_X3_LAUNCH
                     } else if (h->act2) hipLaunchKernelGGL((rnde_bstage_attempt_kernel<1, 1>), pgrid, blk, flds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
                     else hipLaunchKernelGGL((rnde_bstage_attempt_kernel<0, 1>), pgrid, blk, flds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);
                 } else if (h->act2) hipLaunchKernelGGL((rnde_bstage_attempt_kernel<1, 0>), pgrid, blk, h->stage_lds, s, BQ, n, h->h_meta[n], c1, c2, sv_lo[n], sv_hi[n], Y, qo, b.h_svb[n]);

@@ -498,11 +498,15 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_bstage_attempt_kernel(const 
         }
         if (dead && lane == 0) RED[24] = 1.f;
         __syncthreads();
-        if (RED[24] != 0.f) { alive = false; return; }      // a wave that gave up takes the whole workgroup with it
+        if constexpr (!X3) { if (RED[24] != 0.f) { alive = false; return; } }      // a wave that gave up takes the whole workgroup with it
         BSTAMP(4 + 5 * (6 - j));
         // ---- phase B ----
         f32x4 gb = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (X3) gb = x3_tile<4>(xB, ZX, lane);
+        if constexpr (X3) {
+            const float gave_up = RED[24];      // (requested in front of the fragments -- x3_tile's first scheduling barrier keeps it there -- and looked at behind the products)
+            gb = x3_tile<4>(xB, ZX, lane);
+            if (gave_up != 0.f) { alive = false; return; }      // (X3: the flag is read with the fragments, not in front of them -- an LDS round trip per stage less on the chain; a workgroup that gives up has multiplied for nothing)
+        }
         else if (tile_ok) {
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             const float* zb = ZL + col * KZ + 4 * (lane >> 4);

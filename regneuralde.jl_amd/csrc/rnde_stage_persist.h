@@ -441,12 +441,14 @@ __global__ __launch_bounds__(64 * kSMaxW) void rnde_stage_attempt_kernel(const S
         WSTAMP(s, 1);
         __syncthreads();
         WSTAMP(s, 2);
-        if (RED[24] != 0.f) { alive = false; return; }      // a wave that gave up takes the whole workgroup with it (uniform after the barrier)
+        if constexpr (!X3) { if (RED[24] != 0.f) { alive = false; return; } }      // a wave that gave up takes the whole workgroup with it (uniform after the barrier)
         PSTAMP(5 + 5 * (s - 1));
         // ---- phase B ----
         f32x4 kv = {0.f, 0.f, 0.f, 0.f};
         if constexpr (X3) {
+            const float gave_up = RED[24];      // (requested in front of the fragments -- x3_tile's first scheduling barrier keeps it there -- and looked at behind the products)
             kv = x3_tile<4>(xB, HX, lane);
+            if (gave_up != 0.f) { alive = false; return; }      // (X3: the flag is read with the fragments, not in front of them -- an LDS round trip per stage less on the chain; a workgroup that gives up has multiplied for nothing)
             if (ACT2) {
                 const f32x2 a01 = tanh_fast2((f32x2){kv[0], kv[1]}), a23 = tanh_fast2((f32x2){kv[2], kv[3]});
                 kv = (f32x4){a01.x, a01.y, a23.x, a23.y};

@@ -288,13 +288,15 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_attempt_mt_kernel(const Sta
         }
         if (dead && lane == 0) RED[24] = 1.f;
         __syncthreads();
-        if (RED[24] != 0.f) { alive = false; return; }
+        if constexpr (!X3) { if (RED[24] != 0.f) { alive = false; return; } }
         // ---- phase B ----
         f32x4 kv[NCT];
         if constexpr (X3) {
 #pragma unroll
             for (int tt = T0; tt < T1; ++tt) {
+                const float gave_up = RED[24];      // (requested in front of the fragments -- x3_tile's first scheduling barrier keeps it there -- and looked at behind the products)
                 kv[tt] = x3_tile<4>(xB, HX + tt * kImgShorts, lane);
+                if (gave_up != 0.f) { alive = false; return; }      // (X3: the flag is read with the fragments, not in front of them -- an LDS round trip per stage less on the chain; a workgroup that gives up has multiplied for nothing)
                 if (ACT2) {
                     const f32x2 a01 = tanh_fast2((f32x2){kv[tt][0], kv[tt][1]}), a23 = tanh_fast2((f32x2){kv[tt][2], kv[tt][3]});
                     kv[tt] = (f32x4){a01.x, a01.y, a23.x, a23.y};

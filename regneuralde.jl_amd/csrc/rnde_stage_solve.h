@@ -311,11 +311,13 @@ __global__ __launch_bounds__(64 * 7) void rnde_stage_solve_kernel(const StagePar
             }
             if (dead && lane == 0) RED[24] = 1.f;
             __syncthreads();
-            if (RED[24] != 0.f) { alive = false; return; }
+            if constexpr (!X3) { if (RED[24] != 0.f) { alive = false; return; } }
             // ---- phase B ----
             f32x4 kv;
             if constexpr (X3) {
+                const float gave_up = RED[24];      // (requested in front of the fragments -- x3_tile's first scheduling barrier keeps it there -- and looked at behind the products)
                 kv = x3_tile<4>(xB, HX, lane);
+                if (gave_up != 0.f) { alive = false; return; }      // (X3: the flag is read with the fragments, not in front of them -- an LDS round trip per stage less on the chain; a workgroup that gives up has multiplied for nothing)
                 if (ACT2) {
                     const f32x2 a01 = tanh_fast2((f32x2){kv[0], kv[1]}), a23 = tanh_fast2((f32x2){kv[2], kv[3]});
                     kv = (f32x4){a01.x, a01.y, a23.x, a23.y};

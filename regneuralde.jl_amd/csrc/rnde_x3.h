@@ -35,14 +35,42 @@ __device__ __forceinline__ unsigned x3_cvt2(float a, float b) {
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-// (x0, x1) -> the three packed planes; x == hi + mid + lo exactly, component by component
+// (x0, x1) -> the three packed planes; x == hi + mid + lo exactly, component by component.
+// The remainder x - float(hi) is representable, so ANY correctly rounded way of forming it gives the same bits.  RNDE_X3_DOT2 = 1 forms it with
+// v_dot2_f32_bf16: D = A.lo * B.lo + A.hi * B.hi + C with B = {-1, 0} / {0, -1} and C = x -- two instructions per pair and level where rebuilding float(hi) from the
+// packed pair (shift / mask) and subtracting takes four.  tools/micro/dot2_exact.hip: 4.29e9 random pairs (every exponent, subnormals, ties of the bf16 rounding), the
+// three planes bit-equal in all but the 5e-4 of them whose hi overflows to Inf (|x| > 3.39e38, where the subtraction form is garbage too).  Two traps met on the way,
+// both in that probe's history: (1) as inline assembly the pair v_cvt_pk_bf16_f32 -> v_dot2 read a STALE register (the compiler does not know an asm's hazards): both are
+// compiler builtins here; (2) with B as a compile-time constant the compiler emits `v_dot2c_f32_bf16 v, -1.0, v`, an inline constant this hardware reads as an f16
+// pattern: the two constants are kept in registers the optimiser cannot see through (one empty asm each, not volatile: it may be hoisted and merged).
+// MEASURED AND NOT ADOPTED (round 6): exact, but no faster -- forward attempt 20.65 against 20.72-20.82 us, reversed attempt 24.79 against 24.85, and the weight-gradient
+// kernels, whose bound IS the splitting's issue time, slower (rev_rest 0.330 against 0.317 ms): a v_dot2c costs more issue time than the two instructions it replaces.
+#ifndef RNDE_X3_DOT2
+#define RNDE_X3_DOT2 0
+#endif
+typedef __bf16 x3bf2 __attribute__((ext_vector_type(2)));
+typedef float x3f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void x3_split2(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
 #pragma clang fp contract(off)
+#if RNDE_X3_DOT2
+    unsigned kl = 0x0000BF80u, kh = 0xBF800000u;      // {-1, 0}, {0, -1} as packed bf16 pairs
+    asm("" : "+s"(kl));
+    asm("" : "+s"(kh));
+    const x3bf2 bl = __builtin_bit_cast(x3bf2, kl), bh = __builtin_bit_cast(x3bf2, kh);
+    const x3bf2 h = __builtin_convertvector((x3f2){x0, x1}, x3bf2);
+    const float r0 = __builtin_amdgcn_fdot2_f32_bf16(h, bl, x0, false), r1 = __builtin_amdgcn_fdot2_f32_bf16(h, bh, x1, false);
+    const x3bf2 m = __builtin_convertvector((x3f2){r0, r1}, x3bf2);
+    const float s0 = __builtin_amdgcn_fdot2_f32_bf16(m, bl, r0, false), s1 = __builtin_amdgcn_fdot2_f32_bf16(m, bh, r1, false);
+    hi = __builtin_bit_cast(unsigned, h);
+    mid = __builtin_bit_cast(unsigned, m);
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector((x3f2){s0, s1}, x3bf2));
+#else
     hi = x3_cvt2(x0, x1);
     const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xFFFF0000u);
     mid = x3_cvt2(r0, r1);
     const float s0 = r0 - __uint_as_float(mid << 16), s1 = r1 - __uint_as_float(mid & 0xFFFF0000u);
     lo = x3_cvt2(s0, s1);
+#endif
 }
 // four consecutive k-values of one column (k0 .. k0 + 3, k0 a multiple of 4) into the three planes of an LDS operand image [plane][column][kX3K]
 __device__ __forceinline__ void x3_store4(unsigned short* img, int col, int k0, const x3f4& v) {

@@ -223,6 +223,7 @@ __global__ __launch_bounds__(448) void rnde_wgrad4x_kernel(const EvalDesc* __res
     const int u_gr = (wide_wave ? row_lo : 0) + 4 * uq;
     const bool u_mem = u_gr < Rp;
     const bool u_syn = u_gr == Rp && (wide_wave ? !TALL_IS_Z : TALL_IS_Z);     // the quad {t, 1, 0, 0}
+    const float syn_f = u_syn ? 1.f : 0.f;
     const unsigned u_voff = u_mem ? 4u * (unsigned)(u_gr + 8 * uo * Rp) : kNoSrc;
     const int u_dst = (wide_wave ? 0 : 3 * kWx4PlaneT) + 4 * uq * kWxRowShorts + 8 * uo;
     const int u_ps = wide_wave ? kWx4PlaneT : kWx4PlaneS;
@@ -251,13 +252,12 @@ __global__ __launch_bounds__(448) void rnde_wgrad4x_kernel(const EvalDesc* __res
     };
     auto spill_row = [&](unsigned short* img, int i, auto set_c) {      // row i < 4 of the thread's quad: eight values -> three 16-byte plane entries
         constexpr int SET = decltype(set_c)::value;
-        const int o8 = 8 * uo;
+        // rows that are not in memory were loaded out of range (= 0): the synthetic quad's {t, 1} come in by ONE addition per value of its two rows (0 for everybody
+        // else: x + 0 is x), not by a select per value of all four -- 17 vector instructions per step instead of 48.  No test on the column: past the batch's padded
+        // width the OTHER operand (always rows in memory) is out of range and 0, so what stands in a synthetic row there multiplies nothing.
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float sv = i == 0 ? stg_t[SET] : (i == 1 ? 1.f : 0.f);
-            v[j] = u_mem ? stg[SET][j][i] : ((i < 2 && u_syn && o8 + j < stg_ncols[SET]) ? sv : 0.f);
-        }
+        for (int j = 0; j < 8; ++j) v[j] = i < 2 ? stg[SET][j][i] + (i == 0 ? syn_f * stg_t[SET] : syn_f) : stg[SET][j][i];
         unsigned hi[4], mid[4], lo[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) x3_split2(v[2 * j], v[2 * j + 1], hi[j], mid[j], lo[j]);

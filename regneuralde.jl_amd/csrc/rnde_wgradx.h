@@ -172,7 +172,7 @@ __global__ __launch_bounds__(448) void rnde_wgrad3x_kernel(const EvalDesc* __res
 #ifndef RNDE_WX4_SB
 #define RNDE_WX4_SB 1
 #endif
-#ifndef RNDE_WX4_ABL      // timing ablations (wrong results): 1 no splitting, 2 no splitting and no loads, 3 B fragments read once per step, 4 matrix instructions only
+#ifndef RNDE_WX4_ABL      // timing ablations (wrong results): 1 no splitting, 2 no splitting and no loads, 3 B fragments read once per step, 4 matrix instructions only, 5 split without its LDS writes, 6 LDS writes without the split
 #define RNDE_WX4_ABL 0
 #endif
 constexpr int kWx4TallRows = 208;
@@ -250,6 +250,7 @@ __global__ __launch_bounds__(448) void rnde_wgrad4x_kernel(const EvalDesc* __res
         for (int j = 0; j < 8; ++j)
             stg[SET][j] = __builtin_bit_cast(x3f4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)u_voff, 4 * (c0 + j) * Rp, 0));      // (column through the scalar offset: no vector address arithmetic)
     };
+    unsigned abl_sink = 0u;
     auto spill_row = [&](unsigned short* img, int i, auto set_c) {      // row i < 4 of the thread's quad: eight values -> three 16-byte plane entries
         constexpr int SET = decltype(set_c)::value;
         // rows that are not in memory were loaded out of range (= 0): the synthetic quad's {t, 1} come in by ONE addition per value of its two rows (0 for everybody
@@ -259,12 +260,22 @@ __global__ __launch_bounds__(448) void rnde_wgrad4x_kernel(const EvalDesc* __res
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = i < 2 ? stg[SET][j][i] + (i == 0 ? syn_f * stg_t[SET] : syn_f) : stg[SET][j][i];
         unsigned hi[4], mid[4], lo[4];
+#if RNDE_WX4_ABL == 6      // (timing ablation: the LDS writes without the split)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { hi[j] = __float_as_uint(v[2 * j]); mid[j] = __float_as_uint(v[2 * j + 1]); lo[j] = hi[j]; }
+#else
 #pragma unroll
         for (int j = 0; j < 4; ++j) x3_split2(v[2 * j], v[2 * j + 1], hi[j], mid[j], lo[j]);
+#endif
         unsigned short* d = img + u_dst + i * kWxRowShorts;
+#if RNDE_WX4_ABL == 5      // (timing ablation: the split without its LDS writes -- the planes are folded into a register the epilogue stores)
+        abl_sink ^= hi[0] ^ hi[1] ^ hi[2] ^ hi[3] ^ mid[0] ^ mid[1] ^ mid[2] ^ mid[3] ^ lo[0] ^ lo[1] ^ lo[2] ^ lo[3];
+        (void)d;
+#else
         *(x3u4*)d = (x3u4){hi[0], hi[1], hi[2], hi[3]};
         *(x3u4*)(d + u_ps) = (x3u4){mid[0], mid[1], mid[2], mid[3]};
         *(x3u4*)(d + 2 * u_ps) = (x3u4){lo[0], lo[1], lo[2], lo[3]};
+#endif
     };
     unsigned short* const img0 = wxs;
     unsigned short* const img1 = wxs + kWx4ImageShorts;
@@ -324,6 +335,9 @@ __global__ __launch_bounds__(448) void rnde_wgrad4x_kernel(const EvalDesc* __res
         __syncthreads();
         one_step(img1, nullptr, std::false_type{}, S1{});
     } else one_step(img0, nullptr, std::false_type{}, S0{});
+#if RNDE_WX4_ABL == 5
+    if (abl_sink == 0x12345678u) slab[0] = 1.f;
+#endif
     float* out = slab + (size_t)chunk * M * (Nx + 2);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
